@@ -1,0 +1,223 @@
+/* navsim.h -- C ABI of the MI355X-native batched NavGym step().
+ *
+ * This is the drop-in boundary for the hot path of leekwoon/nav-gym
+ * (NavGymEnv.step, nav_gym/src/nav_gym_env/env.py:591-728).  The reference has no
+ * FFI of its own: its hot arithmetic lives behind four pip packages
+ * (range_libc, CMap2D, pose2d, pyastar2d; env.py:12-15).  Every entry point below
+ * names the reference call site it replaces.  All pointers are DEVICE pointers
+ * owned by the caller (torch tensors in the Python host); the library never
+ * allocates or frees caller-visible memory, never synchronises the device, and
+ * never throws: every function returns 0 on success or a negative NAVSIM_E_* code.
+ * `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *
+ * The CPU oracle (oracle/navsim_ref.h) exports the same functions with a `_cpu`
+ * suffix, host pointers and no stream argument.  The oracle is test
+ * infrastructure; nothing in this library calls it.
+ *
+ * Conventions:
+ *   occupancy[y][x] row-major, x = column = "i", y = row = "j"; cell (i,j) covers
+ *   world [ox + i*res, ox + (i+1)*res) x [oy + j*res, ...).  Angles are CCW from +x.
+ */
+#ifndef NAVSIM_H
+#define NAVSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NAVSIM_ABI_VERSION 1
+
+/* error codes */
+#define NAVSIM_OK            0
+#define NAVSIM_E_ARG        -1   /* null pointer / bad size */
+#define NAVSIM_E_LAUNCH     -2   /* hipGetLastError() after a launch was not hipSuccess */
+#define NAVSIM_E_UNSUPPORTED -3  /* configuration outside compiled limits */
+#define NAVSIM_E_NODEVICE   -4   /* no HIP device visible */
+
+/* pedestrian update model (navsim_config.ped_model) */
+#define NAVSIM_PED_NONE      0   /* n_peds ignored, no pedestrians */
+#define NAVSIM_PED_EXTERNAL  1   /* (v, omega) per pedestrian supplied by the caller: the slot the
+                                    reference fills with HumanPolicy (env.py:650-662) */
+#define NAVSIM_PED_SFM       2   /* build-defined social-force model */
+
+/* compiled limits */
+#define NAVSIM_MAX_PEDS      64
+#define NAVSIM_MAX_WAYPOINTS 8
+#define NAVSIM_OBS_TAIL      7   /* prev_pose(2) pose(2) vel(2) yaw(1): env.py:455 */
+
+/* ------------------------------------------------------------------------------------------
+ * Simulator configuration: the registered kwargs of NavGym-v0 (__init__.py:6-38) plus the
+ * batch geometry.  Plain data, passed by pointer, copied by the callee.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct navsim_config {
+    int32_t n_envs;          /* E: independent arenas in this shard */
+    int32_t n_beams;         /* B: KetiRobot.n_angles (keti_robot.py:48); 512 native, 1081 bench */
+    int32_t map_h;           /* H cells (rows, y) */
+    int32_t map_w;           /* W cells (cols, x) */
+    int32_t max_peds;        /* N: stride of the per-pedestrian arrays, <= NAVSIM_MAX_PEDS */
+    int32_t n_scan_stack;    /* S: num_scan_stack (__init__.py:11) */
+    int32_t ped_model;       /* NAVSIM_PED_* */
+    int32_t lidar_legs;      /* robot scan renders legs of has_legs pedestrians (env.py:695-698) */
+    int32_t auto_reset;      /* 1: a done env is re-seeded from the spawn table inside step() */
+    int32_t n_spawn;         /* K: spawn table entries per env (auto_reset) */
+    int32_t add_scan_noise;  /* 1: Gaussian noise on beams != range_max (env.py:437-440) */
+    int32_t env_index_base;  /* global index of local env 0 (multi-GPU sharding; seeds RNG) */
+
+    double resolution;       /* metres per cell (map_generator.py:116) */
+    double origin_x, origin_y;
+    double time_step;        /* __init__.py:8 */
+    double angle_min;        /* first beam angle in the robot frame (keti_robot.py:45) */
+    double angle_last;       /* last beam angle = angle_max - angle_increment (env.py:388-390) */
+    double range_max;        /* keti_robot.py:47 */
+    double axle_offset;      /* 0.14474 for KetiRobot (keti_robot.py:72-90); 0 = plain unicycle */
+    double min_turning_radius;   /* env.py:595-600 */
+    double distance_threshold;   /* __init__.py:10 */
+    double reward_scale;
+    double reward_success_factor;
+    double reward_crash_factor;
+    double reward_progress_factor;
+    double reward_forward_factor;
+    double reward_rotation_factor;
+    double reward_discomfort_factor;
+
+    /* social-force parameters (NAVSIM_PED_SFM only) */
+    double sfm_tau;          /* relaxation time, s */
+    double sfm_k_desired;
+    double sfm_k_social;
+    double sfm_k_obstacle;
+    double sfm_lambda;       /* lambdaImportance */
+    double sfm_gamma;
+    double sfm_n;
+    double sfm_n_prime;
+    double sfm_sigma_obstacle;
+    double sfm_agent_radius;
+
+    uint64_t seed;           /* counter-based RNG key (scan noise, spawn choice) */
+} navsim_config;
+
+/* ------------------------------------------------------------------------------------------
+ * Per-shard simulator state: structure of device arrays, env-major.  E = n_envs, N = max_peds,
+ * B = n_beams, S = n_scan_stack, K = n_spawn, P = NAVSIM_MAX_WAYPOINTS.
+ * Poses are float64 like the reference's Python floats; scans are float32 like env.py:387.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct navsim_state {
+    /* world */
+    const float*  field;            /* [E,H,W] distance field in cells, from navsim_build_dt */
+    const float*  scan_threshold;   /* [B] env.py:162-170 */
+    const float*  scan_discomfort;  /* [B] env.py:172-180 */
+    const float*  scan_noise_std;   /* [E] env_param['scan_noise_std'] (env.py:439) */
+
+    /* robot */
+    double*  robot_pose;            /* [E,3] px, py, theta in [0, 2pi) */
+    double*  robot_goal;            /* [E,2] gx, gy */
+    double*  prev_action;           /* [E,2] env.py:725 */
+    double*  prev_pose;             /* [E,3] x, y, wrapped yaw of prev_obs (env.py:710-717) */
+    int32_t* n_hist;                /* [E] len(prev_obs_queue), 0..S-1 (env.py:257-279) */
+    int64_t* episode;               /* [E] episodes finished so far (spawn / RNG counter) */
+    int64_t* steps;                 /* [E] steps_since_reset */
+
+    /* pedestrians (ignored when ped_model == NAVSIM_PED_NONE) */
+    const int32_t* n_peds;          /* [E] live pedestrians, <= N */
+    double*  ped_pose;              /* [E,N,3] */
+    double*  ped_vel;               /* [E,N,2] world vx, vy (human.py:35-36) */
+    double*  ped_prev_yaw;          /* [E,N] wrapped yaw of the pedestrian's previous obs (env.py:245-247) */
+    double*  ped_dist;              /* [E,N,3] leg odometry (env.py:255) */
+    const double*  ped_v_pref;      /* [E,N] */
+    const uint8_t* ped_has_legs;    /* [E,N] */
+    double*  ped_waypoints;         /* [E,N,P,2] remaining waypoints, [0] is the current local goal */
+    int32_t* ped_n_waypoints;       /* [E,N] >= 1 */
+    const double*  ped_cmd;         /* [E,N,2] (v, omega) for NAVSIM_PED_EXTERNAL, else NULL */
+
+    /* auto-reset tables */
+    const double* spawn_pose;       /* [E,K,3] */
+    const double* spawn_goal;       /* [E,K,2] */
+} navsim_state;
+
+/* What step() returns (env.py:728) with a leading env axis. */
+typedef struct navsim_step_io {
+    const double* action;           /* [E,2] (linvel, rotvel) -- not clipped (env.py:611-613) */
+    const float*  obs_prev;         /* [E,S*B+7] observation returned by the previous step/reset */
+    float*   obs;                   /* [E,S*B+7] scan stack, prev_pose, pose, vel, yaw (env.py:455) */
+    float*   achieved_goal;         /* [E,2] */
+    float*   desired_goal;          /* [E,2] */
+    double*  reward;                /* [E] */
+    uint8_t* done;                  /* [E] */
+    float*   is_success;            /* [E] info['is_success'] (env.py:475) */
+    float*   is_crash;              /* [E] info['is_crash']   (env.py:476) */
+    double*  distance;              /* [E] info['distance']   (env.py:474) */
+} navsim_step_io;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int         navsim_abi_version(void);
+const char* navsim_error_string(int code);
+/* Fills a config with the registered NavGym-v0 defaults (__init__.py:6-38, keti_robot.py:44-48). */
+int         navsim_default_config(navsim_config* cfg);
+
+/* ---- a3: range_libc.PyOMap + PyRayMarching.__init__ (env.py:337-340) -------------------- */
+/* Exact Euclidean distance transform of `occ` (nonzero = occupied), float32 cells.
+ * workspace: navsim_build_dt_workspace_bytes() bytes of device scratch. */
+size_t navsim_build_dt_workspace_bytes(int32_t n_maps, int32_t map_h, int32_t map_w);
+int    navsim_build_dt(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t map_w,
+                       float* field, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- a4: PyRayMarching.calc_range_many (env.py:425) ------------------------------------- */
+/* queries [E, n_per_env, 3] float32 (x, y, theta) in cell units, out [E, n_per_env] in cells. */
+int navsim_cast_static(const float* field, int32_t n_envs, int32_t map_h, int32_t map_w,
+                       const float* queries, int32_t n_per_env, float max_range,
+                       float* out, void* stream);
+
+/* ---- a5: CMap2D.flatten_contours + render_contours_in_lidar (env.py:430-431) ------------ */
+/* ranges [E,B] in/out (metres); angles [E,B] float64; verts [E,V,3] float32 (contour id, x, y),
+ * n_verts [E] live vertices per env (<= V); origin [E,2] float32. */
+int navsim_render_polys(float* ranges, const double* angles, int32_t n_envs, int32_t n_beams,
+                        const float* verts, const int32_t* n_verts, int32_t max_verts,
+                        const float* origin, void* stream);
+
+/* ---- a6: CSimAgent + CMap2D.render_agents_in_lidar (env.py:402, 432) -------------------- */
+/* agents [E,A,8] float32: pos(3) dist(3) vel(2); n_agents [E] (<= A). */
+int navsim_render_legs(float* ranges, const double* angles, int32_t n_envs, int32_t n_beams,
+                       const float* agents, const int32_t* n_agents, int32_t max_agents,
+                       const float* origin, void* stream);
+
+/* ---- a8 / a9: Human.set_vel (human.py:32-41), KetiRobot.set_vel (keti_robot.py:64-93) --- */
+/* pose [n,3] in/out, cmd [n,2] (v, omega), vel_out [n,2] world (vx, vy) or NULL.
+ * axle_offset = 0 gives Human.set_vel, 0.14474 gives KetiRobot.set_vel. */
+int navsim_integrate(double* pose, const double* cmd, double* vel_out, int32_t n,
+                     double time_step, double axle_offset, void* stream);
+
+/* ---- a12 / a13: compute_rewards, compute_terminals, compute_info (env.py:464-589) ------- */
+/* HER batch API.  obs [n, S*B+7] float32 or float64 (obs_is_f64), goals [n,2] same dtype.
+ * Any output pointer may be NULL. */
+int navsim_reward_done(const navsim_config* cfg, const void* obs, const void* goals,
+                       int32_t obs_is_f64, int32_t n,
+                       const float* scan_threshold, const float* scan_discomfort,
+                       double* reward, uint8_t* done, float* is_success, float* is_crash,
+                       double* distance, void* stream);
+
+/* ---- a14: _make_scan_threshold / _make_scan_discomfort_threshold (env.py:162-180) ------- */
+/* footprint [n_vert,2] float32 (un-closed polygon in the robot frame), out [B]. */
+int navsim_scan_threshold(const navsim_config* cfg, const float* footprint, int32_t n_vert,
+                          float* out, void* stream);
+
+/* ---- a1: NavGymEnv.step (env.py:591-728), fused ----------------------------------------- */
+/* One launch: pedestrian update, robot integration, scan, reward/done/info, crash revert (or
+ * respawn) with re-scan, observation packing.  State is updated in place. */
+int navsim_step(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
+                void* stream);
+
+/* First observation after reset() (env.py:822-831): scan at the current robot pose, stack filled
+ * with copies, prev_pose = pose, vel = 0; sets prev_pose/prev_action/n_hist.  `mask` [E] uint8 or
+ * NULL selects which envs are (re)initialised; others keep obs_prev -> obs copied through. */
+int navsim_reset_obs(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
+                     const uint8_t* mask, void* stream);
+
+/* Name and average launch statistics hooks used by bench.py (HIP events on `stream`). */
+const char* navsim_step_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAVSIM_H */

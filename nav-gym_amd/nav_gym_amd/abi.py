@@ -1,0 +1,184 @@
+"""ctypes mirror of include/navsim.h (the C ABI of the batched NavGym step).
+
+Pure declarations: importing this module touches neither the GPU nor the shared library.
+Field order and types must match include/navsim.h exactly; tests/test_abi.py compares
+``ctypes.sizeof`` with the ``sizeof`` the compiled library reports.
+"""
+import ctypes as C
+
+ABI_VERSION = 1
+
+OK = 0
+E_ARG = -1
+E_LAUNCH = -2
+E_UNSUPPORTED = -3
+E_NODEVICE = -4
+
+PED_NONE = 0
+PED_EXTERNAL = 1
+PED_SFM = 2
+
+MAX_PEDS = 64
+MAX_WAYPOINTS = 8
+OBS_TAIL = 7
+
+
+class NavsimConfig(C.Structure):
+    _fields_ = [
+        ("n_envs", C.c_int32),
+        ("n_beams", C.c_int32),
+        ("map_h", C.c_int32),
+        ("map_w", C.c_int32),
+        ("max_peds", C.c_int32),
+        ("n_scan_stack", C.c_int32),
+        ("ped_model", C.c_int32),
+        ("lidar_legs", C.c_int32),
+        ("auto_reset", C.c_int32),
+        ("n_spawn", C.c_int32),
+        ("add_scan_noise", C.c_int32),
+        ("env_index_base", C.c_int32),
+        ("resolution", C.c_double),
+        ("origin_x", C.c_double),
+        ("origin_y", C.c_double),
+        ("time_step", C.c_double),
+        ("angle_min", C.c_double),
+        ("angle_last", C.c_double),
+        ("range_max", C.c_double),
+        ("axle_offset", C.c_double),
+        ("min_turning_radius", C.c_double),
+        ("distance_threshold", C.c_double),
+        ("reward_scale", C.c_double),
+        ("reward_success_factor", C.c_double),
+        ("reward_crash_factor", C.c_double),
+        ("reward_progress_factor", C.c_double),
+        ("reward_forward_factor", C.c_double),
+        ("reward_rotation_factor", C.c_double),
+        ("reward_discomfort_factor", C.c_double),
+        ("sfm_tau", C.c_double),
+        ("sfm_k_desired", C.c_double),
+        ("sfm_k_social", C.c_double),
+        ("sfm_k_obstacle", C.c_double),
+        ("sfm_lambda", C.c_double),
+        ("sfm_gamma", C.c_double),
+        ("sfm_n", C.c_double),
+        ("sfm_n_prime", C.c_double),
+        ("sfm_sigma_obstacle", C.c_double),
+        ("sfm_agent_radius", C.c_double),
+        ("seed", C.c_uint64),
+    ]
+
+    def copy(self):
+        other = NavsimConfig()
+        C.memmove(C.byref(other), C.byref(self), C.sizeof(self))
+        return other
+
+
+_P = C.c_void_p
+
+
+class NavsimState(C.Structure):
+    _fields_ = [(name, _P) for name in (
+        "field", "scan_threshold", "scan_discomfort", "scan_noise_std",
+        "robot_pose", "robot_goal", "prev_action", "prev_pose", "n_hist", "episode", "steps",
+        "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist", "ped_v_pref", "ped_has_legs",
+        "ped_waypoints", "ped_n_waypoints", "ped_cmd",
+        "spawn_pose", "spawn_goal",
+    )]
+
+
+class NavsimStepIO(C.Structure):
+    _fields_ = [(name, _P) for name in (
+        "action", "obs_prev", "obs", "achieved_goal", "desired_goal",
+        "reward", "done", "is_success", "is_crash", "distance",
+    )]
+
+
+# dtype / trailing shape of every state array, in units of (E, N, B, S, K, P, H, W)
+STATE_LAYOUT = {
+    "field": ("float32", ("E", "H", "W")),
+    "scan_threshold": ("float32", ("B",)),
+    "scan_discomfort": ("float32", ("B",)),
+    "scan_noise_std": ("float32", ("E",)),
+    "robot_pose": ("float64", ("E", 3)),
+    "robot_goal": ("float64", ("E", 2)),
+    "prev_action": ("float64", ("E", 2)),
+    "prev_pose": ("float64", ("E", 3)),
+    "n_hist": ("int32", ("E",)),
+    "episode": ("int64", ("E",)),
+    "steps": ("int64", ("E",)),
+    "n_peds": ("int32", ("E",)),
+    "ped_pose": ("float64", ("E", "N", 3)),
+    "ped_vel": ("float64", ("E", "N", 2)),
+    "ped_prev_yaw": ("float64", ("E", "N")),
+    "ped_dist": ("float64", ("E", "N", 3)),
+    "ped_v_pref": ("float64", ("E", "N")),
+    "ped_has_legs": ("uint8", ("E", "N")),
+    "ped_waypoints": ("float64", ("E", "N", "P", 2)),
+    "ped_n_waypoints": ("int32", ("E", "N")),
+    "ped_cmd": ("float64", ("E", "N", 2)),
+    "spawn_pose": ("float64", ("E", "K", 3)),
+    "spawn_goal": ("float64", ("E", "K", 2)),
+}
+
+IO_LAYOUT = {
+    "action": ("float64", ("E", 2)),
+    "obs_prev": ("float32", ("E", "D")),
+    "obs": ("float32", ("E", "D")),
+    "achieved_goal": ("float32", ("E", 2)),
+    "desired_goal": ("float32", ("E", 2)),
+    "reward": ("float64", ("E",)),
+    "done": ("uint8", ("E",)),
+    "is_success": ("float32", ("E",)),
+    "is_crash": ("float32", ("E",)),
+    "distance": ("float64", ("E",)),
+}
+
+
+def resolve_shape(shape, cfg):
+    """Turns a symbolic shape of STATE_LAYOUT / IO_LAYOUT into integers for `cfg`."""
+    sym = {
+        "E": cfg.n_envs, "N": cfg.max_peds, "B": cfg.n_beams, "S": cfg.n_scan_stack,
+        "K": max(cfg.n_spawn, 1), "P": MAX_WAYPOINTS, "H": cfg.map_h, "W": cfg.map_w,
+        "D": cfg.n_scan_stack * cfg.n_beams + OBS_TAIL,
+    }
+    return tuple(sym[s] if isinstance(s, str) else s for s in shape)
+
+
+def declare(lib, suffix=""):
+    """Attaches argtypes/restypes for every entry point of include/navsim.h to `lib`.
+
+    suffix="" is the HIP library (trailing stream argument); suffix="_cpu" is the oracle.
+    """
+    stream = [] if suffix else [_P]
+    i32, f32, f64 = C.c_int32, C.c_float, C.c_double
+    cfgp, stp, iop = C.POINTER(NavsimConfig), C.POINTER(NavsimState), C.POINTER(NavsimStepIO)
+
+    def sig(name, args, res=C.c_int):
+        fn = getattr(lib, name + suffix)
+        fn.argtypes = args
+        fn.restype = res
+        return fn
+
+    sig("navsim_default_config", [cfgp])
+    if suffix:
+        sig("navsim_build_dt", [_P, i32, i32, i32, _P])
+    else:
+        sig("navsim_build_dt", [_P, i32, i32, i32, _P, _P, C.c_size_t, _P])
+    sig("navsim_cast_static", [_P, i32, i32, i32, _P, i32, f32, _P] + stream)
+    sig("navsim_render_polys", [_P, _P, i32, i32, _P, _P, i32, _P] + stream)
+    sig("navsim_render_legs", [_P, _P, i32, i32, _P, _P, i32, _P] + stream)
+    sig("navsim_integrate", [_P, _P, _P, i32, f64, f64] + stream)
+    sig("navsim_reward_done", [cfgp, _P, _P, i32, i32, _P, _P, _P, _P, _P, _P, _P] + stream)
+    sig("navsim_scan_threshold", [cfgp, _P, i32, _P] + stream)
+    sig("navsim_step", [cfgp, stp, iop] + stream)
+    sig("navsim_reset_obs", [cfgp, stp, iop, _P] + stream)
+    return lib
+
+
+# every symbol include/navsim.h declares (tests check the .so exports all of them)
+EXPORTS = (
+    "navsim_abi_version", "navsim_error_string", "navsim_default_config",
+    "navsim_build_dt_workspace_bytes", "navsim_build_dt", "navsim_cast_static",
+    "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
+    "navsim_scan_threshold", "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
+)

@@ -1,0 +1,933 @@
+/* navsim_ref.c -- TEST INFRASTRUCTURE: CPU oracle for the NavGym step() hot path.
+ * See navsim_ref.h for the parity status of every row.  Compile with -ffp-contract=off
+ * (oracle/Makefile): the HIP kernels must reproduce these float32/float64 operation sequences
+ * bit for bit, so no fused multiply-add may be introduced behind our back.
+ *
+ * Each function cites the reference file:line it restates (paths relative to
+ * /root/reference/nav_gym/src/nav_gym_env/ unless stated).
+ */
+#include "navsim_ref.h"
+#include "navmath_ref.h"
+
+#include <float.h>
+#include <stdlib.h>
+#include <string.h>
+
+
+static __thread int64_t g_probe_count = 0;
+
+int64_t navsim_probe_count_cpu(int32_t reset) {
+    int64_t v = g_probe_count;
+    if (reset) g_probe_count = 0;
+    return v;
+}
+
+/* =========================================================================================
+ * config defaults: __init__.py:6-38, keti_robot.py:44-48
+ * ======================================================================================= */
+int navsim_default_config_cpu(navsim_config* c) {
+    if (!c) return NAVSIM_E_ARG;
+    memset(c, 0, sizeof(*c));
+    c->n_envs = 1;
+    c->n_beams = 512;                       /* keti_robot.py:48 */
+    c->map_h = 400; c->map_w = 400;         /* map_generator.py:133 */
+    c->max_peds = 16;
+    c->n_scan_stack = 1;                    /* __init__.py:11 */
+    c->ped_model = NAVSIM_PED_NONE;
+    c->lidar_legs = 1;                      /* env.py:697 */
+    c->resolution = 0.05;                   /* map_generator.py:139 */
+    c->time_step = 0.2;                     /* __init__.py:8 */
+    c->angle_min = -3.141592;               /* keti_robot.py:45 */
+    c->angle_last = 3.141592 - 0.0122718463;/* keti_robot.py:44,46; env.py:389 */
+    c->range_max = 25.0;                    /* keti_robot.py:47 */
+    c->axle_offset = 0.14474;               /* keti_robot.py:73 */
+    c->min_turning_radius = 0.0;            /* __init__.py:9 */
+    c->distance_threshold = 0.5;            /* __init__.py:10 */
+    c->reward_scale = 15.0;                 /* __init__.py:19-25 */
+    c->reward_success_factor = 1.0;
+    c->reward_crash_factor = 1.0;
+    c->reward_progress_factor = 0.001;
+    c->reward_forward_factor = 0.0;
+    c->reward_rotation_factor = 0.005;
+    c->reward_discomfort_factor = 0.01;
+    c->sfm_tau = 0.5;                       /* build-defined: DESIGN.md section 5 */
+    c->sfm_k_desired = 1.0;
+    c->sfm_k_social = 2.1;
+    c->sfm_k_obstacle = 10.0;
+    c->sfm_lambda = 2.0;
+    c->sfm_gamma = 0.35;
+    c->sfm_n = 2.0;
+    c->sfm_n_prime = 3.0;
+    c->sfm_sigma_obstacle = 0.8;
+    c->sfm_agent_radius = 0.35;
+    c->seed = 1234;
+    return NAVSIM_OK;
+}
+
+/* =========================================================================================
+ * a3  range_libc.PyOMap + PyRayMarching.__init__  (called at env.py:337-340)
+ *
+ * [UPSTREAM-RECALL, unpinned] PyOMap(bool[H,W]) stores grid[x][y] = arr[y][x]; the
+ * DistanceTransform of RangeLib.h sets f = 0 on occupied cells, +inf elsewhere, runs the
+ * Felzenszwalb-Huttenlocher exact squared Euclidean transform and takes sqrt.  The exact
+ * transform has one answer, so we state the result, not the float parabola arithmetic:
+ *     field[y][x] = sqrtf((float)d2),  d2 = min over occupied (x',y') of (x-x')^2 + (y-y')^2
+ * computed here with Meijster's integer two-pass algorithm.  A column without obstacles uses
+ * g = 2^15, so an empty map yields d = 32768 everywhere (any value >= max_range behaves alike).
+ * ======================================================================================= */
+#define DT_INF 32768LL
+
+static inline int64_t mj_f(int64_t x, int64_t i, const int64_t* g) {
+    return (x - i) * (x - i) + g[i] * g[i];
+}
+static inline int64_t mj_sep(int64_t i, int64_t u, const int64_t* g) {
+    return (u * u - i * i + g[u] * g[u] - g[i] * g[i]) / (2 * (u - i));
+}
+
+int navsim_build_dt_cpu(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, float* field) {
+    if (!occ || !field || n_maps < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
+    int64_t* g = (int64_t*)malloc(sizeof(int64_t) * (size_t)H * W);
+    int64_t* s = (int64_t*)malloc(sizeof(int64_t) * (size_t)W);
+    int64_t* t = (int64_t*)malloc(sizeof(int64_t) * (size_t)W);
+    int64_t* row = (int64_t*)malloc(sizeof(int64_t) * (size_t)W);
+    if (!g || !s || !t || !row) { free(g); free(s); free(t); free(row); return NAVSIM_E_ARG; }
+    for (int32_t m = 0; m < n_maps; ++m) {
+        const uint8_t* o = occ + (size_t)m * H * W;
+        float* f = field + (size_t)m * H * W;
+        /* phase 1: per column, distance to the nearest occupied cell in that column */
+        for (int x = 0; x < W; ++x) {
+            g[x] = o[x] ? 0 : DT_INF;
+            for (int y = 1; y < H; ++y)
+                g[(size_t)y * W + x] = o[(size_t)y * W + x] ? 0 :
+                    (g[(size_t)(y - 1) * W + x] >= DT_INF ? DT_INF : g[(size_t)(y - 1) * W + x] + 1);
+            for (int y = H - 2; y >= 0; --y) {
+                int64_t below = g[(size_t)(y + 1) * W + x];
+                if (below < DT_INF && below + 1 < g[(size_t)y * W + x]) g[(size_t)y * W + x] = below + 1;
+            }
+        }
+        /* phase 2: per row, lower envelope of the parabolas (x-i)^2 + g(i)^2 */
+        for (int y = 0; y < H; ++y) {
+            for (int x = 0; x < W; ++x) row[x] = g[(size_t)y * W + x];
+            int64_t q = 0; s[0] = 0; t[0] = 0;
+            for (int64_t u = 1; u < W; ++u) {
+                while (q >= 0 && mj_f(t[q], s[q], row) > mj_f(t[q], u, row)) --q;
+                if (q < 0) { q = 0; s[0] = u; }
+                else {
+                    int64_t w = 1 + mj_sep(s[q], u, row);
+                    if (w < W) { ++q; s[q] = u; t[q] = w; }
+                }
+            }
+            for (int64_t u = W - 1; u >= 0; --u) {
+                int64_t d2 = mj_f(u, s[q], row);
+                f[(size_t)y * W + u] = sqrtf((float)d2);
+                if (u == t[q]) --q;
+            }
+        }
+    }
+    free(g); free(s); free(t); free(row);
+    return NAVSIM_OK;
+}
+
+/* =========================================================================================
+ * a4  range_libc.PyRayMarching.calc_range_many  (env.py:425)
+ *
+ * [UPSTREAM-RECALL, unpinned] RangeLib.h RayMarching::calc_range, float32 throughout:
+ *     dx = cosf(theta); dy = sinf(theta); t = 0
+ *     while t < max_range:
+ *         px = (int)(x + dx*t); py = (int)(y + dy*t)            (C truncation toward zero)
+ *         if px or py outside the grid: return max_range
+ *         d = distance_field[px][py]
+ *         if d <= 0: return sqrtf((px-x)^2 + (py-y)^2)
+ *         t += max(d * 0.999, 1.0)                                (0.999 is a double literal)
+ *     return max_range
+ * Assumptions stated: no ROS world<->grid conversion (numpy-constructed map), grid[x][y] is
+ * occupancy[y][x]; cosf/sinf are replaced by the specified nvr_cos/nvr_sin evaluated in double on
+ * the float32 heading and rounded once to float32.
+ * ======================================================================================= */
+static float trace_ray(const float* f, int H, int W, float x0, float y0, float dx, float dy,
+                       float max_range) {
+    float t = 0.0f;
+    while (t < max_range) {
+        float fx = x0 + dx * t;
+        float fy = y0 + dy * t;
+        int px = (int)fx;
+        int py = (int)fy;
+        if (px >= W || px < 0 || py < 0 || py >= H) return max_range;
+        float d = f[(size_t)py * W + px];
+        ++g_probe_count;
+        if (d <= 0.0f) {
+            float xd = (float)px - x0;
+            float yd = (float)py - y0;
+            return sqrtf(xd * xd + yd * yd);
+        }
+        float step = (float)((double)d * 0.999);
+        t += (step > 1.0f) ? step : 1.0f;
+    }
+    return max_range;
+}
+
+static inline void beam_dir(float heading, float* dx, float* dy) {
+    double s, c;
+    nvr_sincos((double)heading, &s, &c);
+    *dx = (float)c;
+    *dy = (float)s;
+}
+
+int navsim_cast_static_cpu(const float* field, int32_t E, int32_t H, int32_t W,
+                           const float* q, int32_t n, float max_range, float* out) {
+    if (!field || !q || !out || E < 0 || n < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
+    for (int e = 0; e < E; ++e) {
+        const float* f = field + (size_t)e * H * W;
+        for (int k = 0; k < n; ++k) {
+            const float* qq = q + ((size_t)e * n + k) * 3;
+            float dx, dy;
+            beam_dir(qq[2], &dx, &dy);
+            out[(size_t)e * n + k] = trace_ray(f, H, W, qq[0], qq[1], dx, dy, max_range);
+        }
+    }
+    return NAVSIM_OK;
+}
+
+/* cross-check only: same sampling rule with unit steps everywhere (no distance field) */
+int navsim_cast_unit_steps_cpu(const uint8_t* occ, int32_t H, int32_t W, const float* q, int32_t n,
+                               float max_range, float* out) {
+    if (!occ || !q || !out) return NAVSIM_E_ARG;
+    for (int k = 0; k < n; ++k) {
+        float x0 = q[3 * k], y0 = q[3 * k + 1], dx, dy;
+        beam_dir(q[3 * k + 2], &dx, &dy);
+        float t = 0.0f, r = max_range;
+        while (t < max_range) {
+            int px = (int)(x0 + dx * t), py = (int)(y0 + dy * t);
+            if (px >= W || px < 0 || py < 0 || py >= H) break;
+            if (occ[(size_t)py * W + px]) {
+                float xd = (float)px - x0, yd = (float)py - y0;
+                r = sqrtf(xd * xd + yd * yd);
+                break;
+            }
+            t += 1.0f;
+        }
+        out[k] = r;
+    }
+    return NAVSIM_OK;
+}
+
+/* =========================================================================================
+ * a5  CMap2D.flatten_contours + render_contours_in_lidar  (env.py:430-431)
+ *
+ * [UPSTREAM-RECALL, unpinned] for every beam and every polygon edge: ray/segment intersection
+ * distance from the lidar origin along the beam; ranges[k] = min(ranges[k], dist).  Polygons are
+ * closed automatically (edge from the last vertex of a contour id back to its first): env.py:168
+ * passes an un-closed 4-vertex footprint and needs all four sides.  Stated arithmetic (float32):
+ *     e = q - p;  w = p - o;  denom = c*e.y - s*e.x;  if denom == 0: skip (parallel)
+ *     t = (w.x*e.y - w.y*e.x)/denom;  u = (w.x*s - w.y*c)/denom;  hit iff t >= 0 and 0 <= u <= 1
+ * with (c, s) the beam direction of the float32-rounded angle (same direction as the map ray).
+ * ======================================================================================= */
+static inline void seg_merge(float* r, float ox, float oy, float c, float s,
+                             float px, float py, float qx, float qy) {
+    float ex = qx - px, ey = qy - py;
+    float wx = px - ox, wy = py - oy;
+    float denom = c * ey - s * ex;
+    if (denom == 0.0f) return;
+    float t = (wx * ey - wy * ex) / denom;
+    float u = (wx * s - wy * c) / denom;
+    if (t >= 0.0f && u >= 0.0f && u <= 1.0f && t < *r) *r = t;
+}
+
+static void render_polys_env(float* ranges, const double* angles, int B, const float* verts, int nv,
+                             float ox, float oy) {
+    for (int k = 0; k < B; ++k) {
+        float c, s;
+        beam_dir((float)angles[k], &c, &s);
+        float r = ranges[k];
+        int start = 0;
+        while (start < nv) {
+            int end = start;
+            while (end + 1 < nv && verts[3 * (end + 1)] == verts[3 * start]) ++end;
+            for (int v = start; v <= end; ++v) {
+                int w = (v == end) ? start : v + 1;
+                seg_merge(&r, ox, oy, c, s, verts[3 * v + 1], verts[3 * v + 2],
+                          verts[3 * w + 1], verts[3 * w + 2]);
+            }
+            start = end + 1;
+        }
+        ranges[k] = r;
+    }
+}
+
+int navsim_render_polys_cpu(float* ranges, const double* angles, int32_t E, int32_t B,
+                            const float* verts, const int32_t* n_verts, int32_t V, const float* origin) {
+    if (!ranges || !angles || !verts || !n_verts || !origin) return NAVSIM_E_ARG;
+    for (int e = 0; e < E; ++e)
+        render_polys_env(ranges + (size_t)e * B, angles + (size_t)e * B, B,
+                         verts + (size_t)e * V * 3, n_verts[e], origin[2 * e], origin[2 * e + 1]);
+    return NAVSIM_OK;
+}
+
+/* =========================================================================================
+ * a6  CSimAgent + CMap2D.render_agents_in_lidar  (env.py:402, 432)
+ *
+ * [UPSTREAM-RECALL, unpinned] two leg discs per agent, radius 0.03 m; body-frame offsets
+ *     front = 0.3*cos(2*dist_x/0.3 + dist_theta),  side = 0.1*cos(2*dist_y/0.1 + dist_theta)
+ *     right leg (front, side + 0.1),  left leg (-front, -side - 0.1)
+ * rotated by the agent heading and translated to the agent position (converter map has
+ * resolution 1, origin 0: env.py:102-103, so ij == xy).  Stated arithmetic: offsets and the
+ * frame change in double on the float32 inputs, centres rounded to float32; ray/circle in float32:
+ *     w = centre - o;  b = w.c + w.s (projection);  x = w.x*s - w.y*c;  disc = r^2 - x^2
+ *     miss if disc < 0;  t = b - sqrtf(disc);  miss if t < 0;  ranges = min(ranges, t)
+ * ======================================================================================= */
+#define LEG_RADIUS 0.03f
+
+static void leg_centres(const float* a, float* out4) {
+    double px = (double)a[0], py = (double)a[1], th = (double)a[2];
+    double dxx = (double)a[3], dyy = (double)a[4], dth = (double)a[5];
+    double front = 0.3 * nvr_cos(dxx * 2.0 / 0.3 + dth);
+    double side = 0.1 * nvr_cos(dyy * 2.0 / 0.1 + dth);
+    double s, c;
+    nvr_sincos(th, &s, &c);
+    double rx = front, ry = side + 0.1;
+    double lx = -front, ly = -side - 0.1;
+    out4[0] = (float)((c * rx - s * ry) + px);
+    out4[1] = (float)((s * rx + c * ry) + py);
+    out4[2] = (float)((c * lx - s * ly) + px);
+    out4[3] = (float)((s * lx + c * ly) + py);
+}
+
+int navsim_leg_centres_cpu(const float* agent8, float* out4) {
+    if (!agent8 || !out4) return NAVSIM_E_ARG;
+    leg_centres(agent8, out4);
+    return NAVSIM_OK;
+}
+
+static inline void circle_merge(float* r, float ox, float oy, float c, float s, float cx, float cy,
+                                float rad) {
+    float wx = cx - ox, wy = cy - oy;
+    float b = wx * c + wy * s;
+    float x = wx * s - wy * c;
+    float disc = rad * rad - x * x;
+    if (disc < 0.0f) return;
+    float t = b - sqrtf(disc);
+    if (t >= 0.0f && t < *r) *r = t;
+}
+
+int navsim_render_legs_cpu(float* ranges, const double* angles, int32_t E, int32_t B,
+                           const float* agents, const int32_t* n_agents, int32_t A, const float* origin) {
+    if (!ranges || !angles || !agents || !n_agents || !origin) return NAVSIM_E_ARG;
+    for (int e = 0; e < E; ++e) {
+        float ox = origin[2 * e], oy = origin[2 * e + 1];
+        for (int i = 0; i < n_agents[e]; ++i) {
+            float cc[4];
+            leg_centres(agents + ((size_t)e * A + i) * 8, cc);
+            for (int k = 0; k < B; ++k) {
+                float c, s;
+                beam_dir((float)angles[(size_t)e * B + k], &c, &s);
+                float r = ranges[(size_t)e * B + k];
+                circle_merge(&r, ox, oy, c, s, cc[0], cc[1], LEG_RADIUS);
+                circle_merge(&r, ox, oy, c, s, cc[2], cc[3], LEG_RADIUS);
+                ranges[(size_t)e * B + k] = r;
+            }
+        }
+    }
+    return NAVSIM_OK;
+}
+
+/* =========================================================================================
+ * a8 / a9  Human.set_vel (human.py:32-41), KetiRobot.set_vel (keti_robot.py:64-93)
+ * Heading-first unicycle; the Keti variant moves the point 0.14474 m ahead of the pose
+ * (keti_robot.py:71-90; the 4x4 products there reduce to px + tx exactly).
+ * ======================================================================================= */
+static void set_vel(double* p, double v, double w, double dt, double off, double* vel) {
+    double s0, c0, s1, c1;
+    nvr_sincos(p[2], &s0, &c0);
+    if (vel) { vel[0] = v * c0; vel[1] = v * s0; }     /* human.py:35-36: OLD heading */
+    double rx = p[0] + off * c0;
+    double ry = p[1] + off * s0;
+    double th = p[2] + w * dt;
+    nvr_sincos(th, &s1, &c1);
+    rx = rx + c1 * v * dt;
+    ry = ry + s1 * v * dt;
+    p[0] = rx + (-off) * c1;
+    p[1] = ry + (-off) * s1;
+    p[2] = nvr_mod_2pi(p[2] + w * dt);
+}
+
+int navsim_integrate_cpu(double* pose, const double* cmd, double* vel_out, int32_t n, double dt,
+                         double off) {
+    if (!pose || !cmd) return NAVSIM_E_ARG;
+    for (int i = 0; i < n; ++i)
+        set_vel(pose + 3 * i, cmd[2 * i], cmd[2 * i + 1], dt, off, vel_out ? vel_out + 2 * i : NULL);
+    return NAVSIM_OK;
+}
+
+/* =========================================================================================
+ * a15  batch_xy_to_ij (env.py:1228-1253): (xy - origin)/resolution stored to float32, clipped
+ * (i against height, j against width -- env.py:1244-1247), truncated.  This is the float64-input
+ * form (callers env.py:348-349); the float32-input form used by the scan is xy_to_ij_f32 below.
+ * ======================================================================================= */
+static inline void xy_to_ij(double x, double y, const navsim_config* c, int* i, int* j) {
+    float fi = (float)((x - c->origin_x) / c->resolution);
+    float fj = (float)((y - c->origin_y) / c->resolution);
+    if (fi >= (float)c->map_h) fi = (float)(c->map_h - 1);
+    if (fj >= (float)c->map_w) fj = (float)(c->map_w - 1);
+    if (fi < 0.0f) fi = 0.0f;
+    if (fj < 0.0f) fj = 0.0f;
+    *i = (int)fi;
+    *j = (int)fj;
+}
+
+/* The scan origin (env.py:419) feeds FLOAT32 coordinates (lidar_pos, env.py:386) into the same
+ * function.  Under NumPy >= 2 (NEP 50; the only NumPy the reference can be executed with here, and
+ * what the golden traces record) the Python-scalar origin and resolution are "weak", so the
+ * subtraction and the division happen in float32.  NumPy 1.x promoted the scalars to float64; the
+ * two differ by one cell on grid-aligned poses (e.g. x = 1.05 -> 20 vs 21).  The oracle follows the
+ * executable evidence; DESIGN.md section 3 records the alternative. */
+static inline void xy_to_ij_f32(float x, float y, const navsim_config* c, int* i, int* j) {
+    float fi = (x - (float)c->origin_x) / (float)c->resolution;
+    float fj = (y - (float)c->origin_y) / (float)c->resolution;
+    if (fi >= (float)c->map_h) fi = (float)(c->map_h - 1);
+    if (fj >= (float)c->map_w) fj = (float)(c->map_w - 1);
+    if (fi < 0.0f) fi = 0.0f;
+    if (fj < 0.0f) fj = 0.0f;
+    *i = (int)fi;
+    *j = (int)fj;
+}
+
+int navsim_xy_to_ij_cpu(const double* xy, int32_t n, double ox, double oy, double res,
+                        int32_t height, int32_t width, int64_t* out) {
+    if (!xy || !out) return NAVSIM_E_ARG;
+    navsim_config c;
+    memset(&c, 0, sizeof(c));
+    c.origin_x = ox; c.origin_y = oy; c.resolution = res; c.map_h = height; c.map_w = width;
+    for (int k = 0; k < n; ++k) {
+        int i, j;
+        xy_to_ij(xy[2 * k], xy[2 * k + 1], &c, &i, &j);
+        out[2 * k] = i; out[2 * k + 1] = j;
+    }
+    return NAVSIM_OK;
+}
+
+int navsim_xy_to_ij_f32_cpu(const float* xy, int32_t n, double ox, double oy, double res,
+                            int32_t height, int32_t width, int64_t* out) {
+    if (!xy || !out) return NAVSIM_E_ARG;
+    navsim_config c;
+    memset(&c, 0, sizeof(c));
+    c.origin_x = ox; c.origin_y = oy; c.resolution = res; c.map_h = height; c.map_w = width;
+    for (int k = 0; k < n; ++k) {
+        int i, j;
+        xy_to_ij_f32(xy[2 * k], xy[2 * k + 1], &c, &i, &j);
+        out[2 * k] = i; out[2 * k + 1] = j;
+    }
+    return NAVSIM_OK;
+}
+
+/* =========================================================================================
+ * a7  _update_dist_travelled (env.py:237-255) + pose2d.inverse_pose2d / apply_tf_to_vel
+ * vrot = (theta - prev_yaw)/dt with prev_yaw the WRAPPED yaw of the previous obs and theta in
+ * [0, 2pi) (the 2*pi jumps are reference behaviour); world (vx, vy) rotated
+ * by -theta ([UPSTREAM-RECALL] pose2d.rotate: x' = cos*x - sin*y, y' = sin*x + cos*y with the
+ * angle -theta); dist += vel_body * dt.
+ * ======================================================================================= */
+static void leg_odometry(const double* pose, const double* vel, double prev_yaw, double dt, double* dist) {
+    double vrot = (pose[2] - prev_yaw) / dt;
+    double s, c;
+    nvr_sincos(-pose[2], &s, &c);
+    double bx = c * vel[0] - s * vel[1];
+    double by = s * vel[0] + c * vel[1];
+    dist[0] += bx * dt;
+    dist[1] += by * dt;
+    dist[2] += vrot * dt;
+}
+
+int navsim_leg_odometry_cpu(const double* pose, const double* vel, const double* prev_yaw, double dt,
+                            int32_t n, double* dist) {
+    if (!pose || !vel || !prev_yaw || !dist) return NAVSIM_E_ARG;
+    for (int i = 0; i < n; ++i) leg_odometry(pose + 3 * i, vel + 2 * i, prev_yaw[i], dt, dist + 3 * i);
+    return NAVSIM_OK;
+}
+
+/* =========================================================================================
+ * a2  _compute_scan (env.py:385-441) for the robot: static map + pedestrians.
+ * ======================================================================================= */
+static const double HUMAN_FOOTPRINT[4][2] = {   /* human.py:5-10 */
+    {0.22, 0.19}, {-0.22, 0.19}, {-0.22, -0.19}, {0.22, -0.19}};
+
+typedef struct { float px, py, qx, qy; } seg_t;
+typedef struct { float cx, cy; } disc_t;
+
+/* builds the dynamic-obstacle primitives seen by the robot (env.py:392-414) */
+static void gather_prims(const navsim_config* c, const navsim_state* st, int e, int n,
+                         seg_t* segs, int* nseg, disc_t* discs, int* ndisc) {
+    const int N = c->max_peds;
+    *nseg = 0; *ndisc = 0;
+    for (int i = 0; i < n; ++i) {
+        const double* pp = st->ped_pose + ((size_t)e * N + i) * 3;
+        if (st->ped_has_legs[(size_t)e * N + i] && c->lidar_legs) {
+            float a[8];
+            const double* dd = st->ped_dist + ((size_t)e * N + i) * 3;
+            a[0] = (float)pp[0]; a[1] = (float)pp[1]; a[2] = (float)pp[2];     /* env.py:399 */
+            a[3] = (float)dd[0]; a[4] = (float)dd[1]; a[5] = (float)dd[2];     /* env.py:400 */
+            a[6] = 0.0f; a[7] = 0.0f;
+            float cc[4];
+            leg_centres(a, cc);
+            discs[*ndisc].cx = cc[0]; discs[*ndisc].cy = cc[1]; ++*ndisc;
+            discs[*ndisc].cx = cc[2]; discs[*ndisc].cy = cc[3]; ++*ndisc;
+        } else {
+            /* env.py:408-414: footprint + closing vertex through T(px,py)*R(theta), then float32 */
+            double s, cs;
+            nvr_sincos(pp[2], &s, &cs);
+            float vx[4], vy[4];
+            for (int v = 0; v < 4; ++v) {
+                double x = HUMAN_FOOTPRINT[v][0], y = HUMAN_FOOTPRINT[v][1];
+                vx[v] = (float)((cs * x - s * y) + pp[0]);
+                vy[v] = (float)((s * x + cs * y) + pp[1]);
+            }
+            for (int v = 0; v < 4; ++v) {
+                int w = (v + 1) & 3;
+                segs[*nseg].px = vx[v]; segs[*nseg].py = vy[v];
+                segs[*nseg].qx = vx[w]; segs[*nseg].qy = vy[w];
+                ++*nseg;
+            }
+        }
+    }
+}
+
+static inline double linspace_k(const navsim_config* c, int k) {
+    /* np.linspace(angle_min, angle_max - angle_increment, n): arange*step + start, last = stop */
+    int B = c->n_beams;
+    if (B == 1) return c->angle_min;
+    if (k == B - 1) return c->angle_last;
+    double step = (c->angle_last - c->angle_min) / (double)(B - 1);
+    return (double)k * step + c->angle_min;
+}
+
+static void robot_scan(const navsim_config* c, const navsim_state* st, int e, int n_peds,
+                       const double* pose, float* ranges) {
+    const int B = c->n_beams, H = c->map_h, W = c->map_w;
+    const float* f = st->field + (size_t)e * H * W;
+    float lx = (float)pose[0], ly = (float)pose[1], lth = (float)pose[2];     /* env.py:386 */
+    int i0, j0;
+    xy_to_ij_f32(lx, ly, c, &i0, &j0);                                         /* env.py:419 */
+    seg_t segs[4 * NAVSIM_MAX_PEDS];
+    disc_t discs[2 * NAVSIM_MAX_PEDS];
+    int nseg = 0, ndisc = 0;
+    if (n_peds > 0) gather_prims(c, st, e, n_peds, segs, &nseg, discs, &ndisc);
+    float max_range = (float)((int64_t)H * W);                                 /* env.py:337 */
+    float res = (float)c->resolution;
+    float rmax = (float)c->range_max;
+    for (int k = 0; k < B; ++k) {
+        double ang = linspace_k(c, k) + (double)lth;                           /* env.py:388-390 */
+        float heading = (float)ang;                                            /* env.py:424 */
+        float dx, dy;
+        beam_dir(heading, &dx, &dy);
+        float r = trace_ray(f, H, W, (float)i0, (float)j0, dx, dy, max_range); /* env.py:425 */
+        r = r * res;                                                           /* env.py:426 */
+        for (int q = 0; q < nseg; ++q)
+            seg_merge(&r, lx, ly, dx, dy, segs[q].px, segs[q].py, segs[q].qx, segs[q].qy);
+        for (int q = 0; q < ndisc; ++q)
+            circle_merge(&r, lx, ly, dx, dy, discs[q].cx, discs[q].cy, LEG_RADIUS);
+        if (r < 0.0f) r = 0.0f;                                                /* env.py:435 */
+        if (r > rmax) r = rmax;
+        ranges[k] = r;
+    }
+}
+
+/* a14  _make_scan_threshold (env.py:162-180): contour-only scan of a footprint at pose 0 */
+int navsim_scan_threshold_cpu(const navsim_config* c, const float* fp, int32_t nv, float* out) {
+    if (!c || !fp || !out || nv < 2 || nv > 16) return NAVSIM_E_ARG;
+    float rmax = (float)c->range_max;
+    for (int k = 0; k < c->n_beams; ++k) {
+        double ang = linspace_k(c, k) + (double)0.0f;
+        float dx, dy;
+        beam_dir((float)ang, &dx, &dy);
+        float r = rmax;
+        for (int v = 0; v < nv; ++v) {
+            int w = (v + 1 == nv) ? 0 : v + 1;
+            seg_merge(&r, 0.0f, 0.0f, dx, dy, fp[2 * v], fp[2 * v + 1], fp[2 * w], fp[2 * w + 1]);
+        }
+        if (r < 0.0f) r = 0.0f;
+        if (r > rmax) r = rmax;
+        out[k] = r;
+    }
+    return NAVSIM_OK;
+}
+
+/* =========================================================================================
+ * a12 / a13  compute_rewards (env.py:521-589), compute_terminals (491-512), compute_info (464-482)
+ * on one row: scan = latest scan of the stack, tail = prev_pose, pose, vel, yaw.
+ * ======================================================================================= */
+typedef struct { double reward; int done; float success, crash; double distance; } rd_t;
+
+static rd_t reward_done_row(const navsim_config* c, const double* scan_d, const float* scan_f,
+                            const double* prev_pose, const double* pose, const double* vel,
+                            const double* goal, const float* thr, const float* dthr) {
+    rd_t o;
+    const int B = c->n_beams;
+    double dx = goal[0] - pose[0], dy = goal[1] - pose[1];
+    double distance = sqrt(dx * dx + dy * dy);                                 /* env.py:539 */
+    double px = goal[0] - prev_pose[0], py = goal[1] - prev_pose[1];
+    double prev_distance = sqrt(px * px + py * py);                            /* env.py:540 */
+    int success = distance < c->distance_threshold;                            /* env.py:542 */
+    int crash = 0, discomfort = 0;
+    double ratio_min = 0.0;
+    for (int k = 0; k < B; ++k) {
+        double s = scan_d ? scan_d[k] : (double)scan_f[k];
+        if (s - (double)thr[k] < 0.0) crash = 1;                               /* env.py:543-544 */
+        if (s - (double)dthr[k] < 0.0) discomfort = 1;                         /* env.py:545-546 */
+        float den = (dthr[k] - thr[k]) + 1e-6f;                                /* env.py:566 (float32) */
+        double ratio = (s - (double)thr[k]) / (double)den;                     /* env.py:564-567 */
+        if (k == 0 || ratio < ratio_min) ratio_min = ratio;
+    }
+    if (crash) discomfort = 0;                                                 /* env.py:547 */
+    double r_success = success ? 1.0 * c->reward_success_factor * c->reward_scale : 0.0;
+    double r_crash = crash ? -1.0 * c->reward_crash_factor * c->reward_scale : 0.0;
+    double r_progress = (prev_distance - distance) * c->reward_progress_factor * c->reward_scale;
+    double r_forward = vel[0] * c->reward_forward_factor * c->reward_scale;
+    double r_rotation = -1.0 * (vel[1] * vel[1]) * c->reward_rotation_factor * c->reward_scale;
+    double r_discomfort = discomfort
+        ? -(1.0 - ratio_min) * c->reward_discomfort_factor * c->reward_scale : 0.0;
+    o.reward = r_success + r_crash + r_progress + r_forward + r_rotation + r_discomfort;
+    o.done = success || crash;                                                 /* env.py:511 */
+    o.success = (float)success;
+    o.crash = (float)crash;
+    o.distance = distance;
+    return o;
+}
+
+int navsim_reward_done_cpu(const navsim_config* c, const void* obs, const void* goals, int32_t is64,
+                           int32_t n, const float* thr, const float* dthr, double* reward,
+                           uint8_t* done, float* is_success, float* is_crash, double* distance) {
+    if (!c || !obs || !goals || !thr || !dthr) return NAVSIM_E_ARG;
+    const int B = c->n_beams, S = c->n_scan_stack, D = S * B + 7;
+    double* tmp = (double*)malloc(sizeof(double) * (size_t)B);
+    for (int r = 0; r < n; ++r) {
+        double tail[7], goal[2];
+        if (is64) {
+            const double* o = (const double*)obs + (size_t)r * D;
+            memcpy(tmp, o + (size_t)(S - 1) * B, sizeof(double) * B);
+            memcpy(tail, o + (size_t)S * B, sizeof(tail));
+            goal[0] = ((const double*)goals)[2 * r]; goal[1] = ((const double*)goals)[2 * r + 1];
+        } else {
+            const float* o = (const float*)obs + (size_t)r * D;
+            for (int k = 0; k < B; ++k) tmp[k] = (double)o[(size_t)(S - 1) * B + k];
+            for (int k = 0; k < 7; ++k) tail[k] = (double)o[(size_t)S * B + k];
+            goal[0] = (double)((const float*)goals)[2 * r]; goal[1] = (double)((const float*)goals)[2 * r + 1];
+        }
+        rd_t o = reward_done_row(c, tmp, NULL, tail, tail + 2, tail + 4, goal, thr, dthr);
+        if (reward) reward[r] = o.reward;
+        if (done) done[r] = (uint8_t)o.done;
+        if (is_success) is_success[r] = o.success;
+        if (is_crash) is_crash[r] = o.crash;
+        if (distance) distance[r] = o.distance;
+    }
+    free(tmp);
+    return NAVSIM_OK;
+}
+
+/* =========================================================================================
+ * BUILD-DEFINED social-force pedestrian update (NAVSIM_PED_SFM).
+ * Not in the reference (its pedestrians are driven by HumanPolicy, env.py:650-662, whose weights
+ * are missing).  Follows the public pedsim model named by BASELINE.json's north_star; force names
+ * as in third_party/pedsim_msgs/msg/AgentForce.msg:3-6.
+ * ======================================================================================= */
+static void sfm_update(const navsim_config* c, const navsim_state* st, int e, int n,
+                       const double* robot_pose, const double* robot_prev_action) {
+    const int N = c->max_peds, H = c->map_h, W = c->map_w, P = NAVSIM_MAX_WAYPOINTS;
+    const float* f = st->field + (size_t)e * H * W;
+    double ax[NAVSIM_MAX_PEDS + 1], ay[NAVSIM_MAX_PEDS + 1];      /* agent positions (peds + robot) */
+    double avx[NAVSIM_MAX_PEDS + 1], avy[NAVSIM_MAX_PEDS + 1];
+    for (int i = 0; i < n; ++i) {
+        const double* pp = st->ped_pose + ((size_t)e * N + i) * 3;
+        const double* vv = st->ped_vel + ((size_t)e * N + i) * 2;
+        ax[i] = pp[0]; ay[i] = pp[1]; avx[i] = vv[0]; avy[i] = vv[1];
+    }
+    {
+        double s, cs;
+        nvr_sincos(robot_pose[2], &s, &cs);
+        ax[n] = robot_pose[0]; ay[n] = robot_pose[1];
+        avx[n] = robot_prev_action[0] * cs; avy[n] = robot_prev_action[0] * s;
+    }
+    double nvx[NAVSIM_MAX_PEDS], nvy[NAVSIM_MAX_PEDS];
+    for (int i = 0; i < n; ++i) {
+        const double* wp = st->ped_waypoints + (((size_t)e * N + i) * P) * 2;
+        double vpref = st->ped_v_pref[(size_t)e * N + i];
+        /* desired force */
+        double ex = wp[0] - ax[i], ey = wp[1] - ay[i];
+        double L = sqrt(ex * ex + ey * ey);
+        if (L > 1e-9) { ex = ex / L; ey = ey / L; } else { ex = 0.0; ey = 0.0; }
+        double fdx = (vpref * ex - avx[i]) / c->sfm_tau;
+        double fdy = (vpref * ey - avy[i]) / c->sfm_tau;
+        /* social force */
+        double fsx = 0.0, fsy = 0.0;
+        for (int j = 0; j <= n; ++j) {
+            if (j == i) continue;
+            double dxx = ax[j] - ax[i], dyy = ay[j] - ay[i];
+            double dist = sqrt(dxx * dxx + dyy * dyy);
+            if (dist < 1e-9) continue;
+            double ddx = dxx / dist, ddy = dyy / dist;
+            double ivx = c->sfm_lambda * (avx[i] - avx[j]) + ddx;
+            double ivy = c->sfm_lambda * (avy[i] - avy[j]) + ddy;
+            double il = sqrt(ivx * ivx + ivy * ivy);
+            if (il < 1e-9) continue;
+            double idx = ivx / il, idy = ivy / il;
+            double theta = nvr_atan2(idx * ddy - idy * ddx, idx * ddx + idy * ddy);
+            double Bq = c->sfm_gamma * il;
+            double a1 = c->sfm_n_prime * Bq * theta;
+            double a2 = c->sfm_n * Bq * theta;
+            double fv = -nvr_exp_neg(-dist / Bq - a1 * a1);
+            double sgn = (theta > 0.0) ? 1.0 : ((theta < 0.0) ? -1.0 : 0.0);
+            double fa = -sgn * nvr_exp_neg(-dist / Bq - a2 * a2);
+            fsx += fv * idx + fa * (-idy);
+            fsy += fv * idy + fa * idx;
+        }
+        /* obstacle force from the distance field (central differences) */
+        double fox = 0.0, foy = 0.0;
+        {
+            int ci, cj;
+            xy_to_ij(ax[i], ay[i], c, &ci, &cj);
+            if (ci > W - 1) ci = W - 1;
+            if (cj > H - 1) cj = H - 1;
+            int il_ = ci > 0 ? ci - 1 : 0, ir = ci < W - 1 ? ci + 1 : W - 1;
+            int jl = cj > 0 ? cj - 1 : 0, jr = cj < H - 1 ? cj + 1 : H - 1;
+            double d = (double)f[(size_t)cj * W + ci] * c->resolution;
+            double gx = (double)f[(size_t)cj * W + ir] - (double)f[(size_t)cj * W + il_];
+            double gy = (double)f[(size_t)jr * W + ci] - (double)f[(size_t)jl * W + ci];
+            double gl = sqrt(gx * gx + gy * gy);
+            if (gl > 0.0) {
+                double mag = nvr_exp_neg(-(d - c->sfm_agent_radius) / c->sfm_sigma_obstacle);
+                fox = mag * (gx / gl);
+                foy = mag * (gy / gl);
+            }
+        }
+        double accx = c->sfm_k_desired * fdx + c->sfm_k_social * fsx + c->sfm_k_obstacle * fox;
+        double accy = c->sfm_k_desired * fdy + c->sfm_k_social * fsy + c->sfm_k_obstacle * foy;
+        double vx = avx[i] + accx * c->time_step;
+        double vy = avy[i] + accy * c->time_step;
+        double sp = sqrt(vx * vx + vy * vy);
+        if (sp > vpref) {
+            double k = (sp > 0.0) ? vpref / sp : 0.0;
+            vx = vx * k; vy = vy * k;
+        }
+        nvx[i] = vx; nvy[i] = vy;
+    }
+    for (int i = 0; i < n; ++i) {
+        double* pp = st->ped_pose + ((size_t)e * N + i) * 3;
+        double* vv = st->ped_vel + ((size_t)e * N + i) * 2;
+        pp[0] = pp[0] + nvx[i] * c->time_step;
+        pp[1] = pp[1] + nvy[i] * c->time_step;
+        double sp = sqrt(nvx[i] * nvx[i] + nvy[i] * nvy[i]);
+        if (sp > 1e-6) pp[2] = nvr_mod_2pi(nvr_atan2(nvy[i], nvx[i]));
+        vv[0] = nvx[i]; vv[1] = nvy[i];
+    }
+}
+
+/* =========================================================================================
+ * observation packing: _convert_obs (env.py:443-462) + _stack_scan (env.py:257-279), float32 out
+ * ======================================================================================= */
+static void pack_obs(const navsim_config* c, const float* scan, const float* obs_prev, int n_hist,
+                     const double* prev_xy, const double* pose, const double* vel, const double* goal,
+                     float* obs, float* ag, float* dg) {
+    const int B = c->n_beams, S = c->n_scan_stack;
+    for (int j = 0; j < S - 1; ++j) {
+        int age = S - 1 - j;                 /* this slot holds scan_{t-age} when available */
+        const float* src = (age <= n_hist && obs_prev) ? obs_prev + (size_t)(j + 1) * B : scan;
+        memcpy(obs + (size_t)j * B, src, sizeof(float) * B);
+    }
+    memcpy(obs + (size_t)(S - 1) * B, scan, sizeof(float) * B);
+    float* tail = obs + (size_t)S * B;
+    tail[0] = (float)prev_xy[0]; tail[1] = (float)prev_xy[1];
+    tail[2] = (float)pose[0];    tail[3] = (float)pose[1];
+    tail[4] = (float)vel[0];     tail[5] = (float)vel[1];
+    tail[6] = (float)nvr_wrap_pi(pose[2]);                                     /* env.py:454 */
+    if (ag) { ag[0] = (float)pose[0]; ag[1] = (float)pose[1]; }
+    if (dg) { dg[0] = (float)goal[0]; dg[1] = (float)goal[1]; }
+}
+
+/* =========================================================================================
+ * a1  NavGymEnv.step (env.py:591-728) for one env
+ * ======================================================================================= */
+static void step_env(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int e,
+                     float* scan) {
+    const int B = c->n_beams, S = c->n_scan_stack, N = c->max_peds, D = S * B + 7;
+    const int P = NAVSIM_MAX_WAYPOINTS;
+    const double dt = c->time_step;
+    const uint64_t genv = (uint64_t)(c->env_index_base + e);
+    double a0 = io->action[2 * e], a1 = io->action[2 * e + 1];
+    st->steps[e] += 1;                                                         /* env.py:592 */
+    if (c->min_turning_radius > 0.0) {                                         /* env.py:595-600 */
+        double lim = fabs(a1) * c->min_turning_radius;
+        if (a0 >= 0.0) a0 = (a0 > lim) ? a0 : lim;
+        else           a0 = (a0 < -lim) ? a0 : -lim;
+    }
+    double* rp = st->robot_pose + 3 * (size_t)e;
+    double* goal = st->robot_goal + 2 * (size_t)e;
+    double* pa = st->prev_action + 2 * (size_t)e;
+    double* pv = st->prev_pose + 3 * (size_t)e;
+    int n = (c->ped_model == NAVSIM_PED_NONE) ? 0 : st->n_peds[e];
+    if (n > N) n = N;
+
+    /* ---- pedestrians: waypoint pop (env.py:633-642), control + integration (env.py:650-662) */
+    for (int i = 0; i < n; ++i) {
+        double* pp = st->ped_pose + ((size_t)e * N + i) * 3;
+        double* wp = st->ped_waypoints + (((size_t)e * N + i) * P) * 2;
+        int* nw = st->ped_n_waypoints + (size_t)e * N + i;
+        while (*nw > 1) {
+            double ddx = pp[0] - wp[0], ddy = pp[1] - wp[1];
+            if (sqrt(ddx * ddx + ddy * ddy) < 1.0) {
+                for (int k = 0; k + 1 < *nw; ++k) { wp[2 * k] = wp[2 * k + 2]; wp[2 * k + 1] = wp[2 * k + 3]; }
+                *nw -= 1;
+            } else break;
+        }
+    }
+    if (n > 0 && c->ped_model == NAVSIM_PED_EXTERNAL) {
+        for (int i = 0; i < n; ++i) {
+            const double* cmd = st->ped_cmd + ((size_t)e * N + i) * 2;
+            set_vel(st->ped_pose + ((size_t)e * N + i) * 3, cmd[0], cmd[1], dt, 0.0,
+                    st->ped_vel + ((size_t)e * N + i) * 2);                     /* env.py:662 */
+        }
+    } else if (n > 0 && c->ped_model == NAVSIM_PED_SFM) {
+        sfm_update(c, st, e, n, rp, pa);
+    }
+
+    /* ---- robot (env.py:664) */
+    set_vel(rp, a0, a1, dt, c->axle_offset, NULL);
+
+    /* ---- pedestrians at their final waypoint take a new goal (env.py:667-680).  The reference
+     * re-plans with A* (pyastar2d, out of scope: SURVEY.md 8f #1); the build draws a goal >= 10 m
+     * away from the env's spawn table and heads straight for it. */
+    for (int i = 0; i < n; ++i) {
+        double* pp = st->ped_pose + ((size_t)e * N + i) * 3;
+        double* wp = st->ped_waypoints + (((size_t)e * N + i) * P) * 2;
+        int* nw = st->ped_n_waypoints + (size_t)e * N + i;
+        double ddx = pp[0] - wp[2 * (*nw - 1)], ddy = pp[1] - wp[2 * (*nw - 1) + 1];
+        if (sqrt(ddx * ddx + ddy * ddy) < 0.5 && c->n_spawn > 0 && st->spawn_pose) {
+            uint64_t h = nvr_hash4(c->seed, genv, (uint64_t)i + 1000, (uint64_t)st->steps[e]);
+            for (int tries = 0; tries < c->n_spawn; ++tries) {
+                int idx = (int)((h + (uint64_t)tries) % (uint64_t)c->n_spawn);
+                const double* cand = st->spawn_pose + ((size_t)e * c->n_spawn + idx) * 3;
+                double gx = cand[0] - pp[0], gy = cand[1] - pp[1];
+                if (sqrt(gx * gx + gy * gy) > 10.0) {
+                    wp[0] = cand[0]; wp[1] = cand[1]; *nw = 1;
+                    break;
+                }
+            }
+        }
+    }
+
+    /* ---- leg odometry (env.py:683), then the pedestrian's obs yaw is refreshed (env.py:685-693;
+     * the per-pedestrian 512-beam scans only feed HumanPolicy and are not produced: DESIGN.md) */
+    for (int i = 0; i < n; ++i) {
+        size_t q = (size_t)e * N + i;
+        leg_odometry(st->ped_pose + q * 3, st->ped_vel + q * 2, st->ped_prev_yaw[q], dt, st->ped_dist + q * 3);
+        st->ped_prev_yaw[q] = nvr_wrap_pi(st->ped_pose[q * 3 + 2]);
+    }
+
+    /* ---- robot scan A, reward / done / info on it (env.py:695-703) */
+    robot_scan(c, st, e, n, rp, scan);
+    rd_t o = reward_done_row(c, NULL, scan, pv, rp, pa, goal, st->scan_threshold, st->scan_discomfort);
+    io->reward[e] = o.reward;
+    io->done[e] = (uint8_t)o.done;
+    io->is_success[e] = o.success;
+    io->is_crash[e] = o.crash;
+    io->distance[e] = o.distance;
+
+    const float* obs_prev = io->obs_prev ? io->obs_prev + (size_t)e * D : NULL;
+    float* obs = io->obs + (size_t)e * D;
+    float* ag = io->achieved_goal ? io->achieved_goal + 2 * (size_t)e : NULL;
+    float* dg = io->desired_goal ? io->desired_goal + 2 * (size_t)e : NULL;
+    int n_hist = st->n_hist[e];
+
+    if (o.done && c->auto_reset && c->n_spawn > 0) {
+        /* BUILD-DEFINED vector-env reset: respawn from the table, first obs as in reset()
+         * (env.py:736-738, 822-831): prev_action = 0, prev_pose = pose, stack filled */
+        uint64_t h = nvr_hash4(c->seed, genv, (uint64_t)st->episode[e], 0x5eedULL);
+        int idx = (int)(h % (uint64_t)c->n_spawn);
+        const double* sp = st->spawn_pose + ((size_t)e * c->n_spawn + idx) * 3;
+        const double* sg = st->spawn_goal + ((size_t)e * c->n_spawn + idx) * 2;
+        rp[0] = sp[0]; rp[1] = sp[1]; rp[2] = sp[2];
+        goal[0] = sg[0]; goal[1] = sg[1];
+        st->episode[e] += 1;
+        st->steps[e] = 0;
+        double zero[2] = {0.0, 0.0};
+        robot_scan(c, st, e, n, rp, scan);
+        pack_obs(c, scan, NULL, 0, rp, rp, zero, goal, obs, ag, dg);
+        pa[0] = 0.0; pa[1] = 0.0;
+        st->n_hist[e] = (S - 1 < 1) ? S - 1 : 1;
+    } else {
+        double vel[2] = {pa[0], pa[1]};                                        /* env.py:453 */
+        if (o.crash != 0.0f) {                                                 /* env.py:707-723 */
+            rp[0] = pv[0]; rp[1] = pv[1]; rp[2] = pv[2];
+            robot_scan(c, st, e, n, rp, scan);
+        }
+        pack_obs(c, scan, obs_prev, n_hist, pv, rp, vel, goal, obs, ag, dg);
+        pa[0] = a0; pa[1] = a1;                                                /* env.py:725 */
+        st->n_hist[e] = (n_hist + 1 < S - 1) ? n_hist + 1 : S - 1;             /* env.py:727 */
+    }
+    pv[0] = rp[0]; pv[1] = rp[1]; pv[2] = nvr_wrap_pi(rp[2]);                  /* env.py:726 */
+}
+
+int navsim_step_range_cpu(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
+                          int32_t e0, int32_t e1) {
+    if (!c || !st || !io || !io->action || !io->obs || !io->reward || !io->done || !io->is_success ||
+        !io->is_crash || !io->distance) return NAVSIM_E_ARG;
+    if (c->max_peds > NAVSIM_MAX_PEDS || c->n_scan_stack < 1) return NAVSIM_E_UNSUPPORTED;
+    float* scan = (float*)malloc(sizeof(float) * (size_t)c->n_beams);
+    for (int e = e0; e < e1; ++e) step_env(c, st, io, e, scan);
+    free(scan);
+    return NAVSIM_OK;
+}
+
+int navsim_step_cpu(const navsim_config* c, const navsim_state* st, const navsim_step_io* io) {
+    if (!c) return NAVSIM_E_ARG;
+    return navsim_step_range_cpu(c, st, io, 0, c->n_envs);
+}
+
+/* first observation after reset() (env.py:808-831) */
+int navsim_reset_obs_cpu(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
+                         const uint8_t* mask) {
+    if (!c || !st || !io || !io->obs) return NAVSIM_E_ARG;
+    const int B = c->n_beams, S = c->n_scan_stack, N = c->max_peds, D = S * B + 7;
+    float* scan = (float*)malloc(sizeof(float) * (size_t)B);
+    for (int e = 0; e < c->n_envs; ++e) {
+        float* obs = io->obs + (size_t)e * D;
+        if (mask && !mask[e]) {
+            if (io->obs_prev) memcpy(obs, io->obs_prev + (size_t)e * D, sizeof(float) * D);
+            continue;
+        }
+        double* rp = st->robot_pose + 3 * (size_t)e;
+        double* goal = st->robot_goal + 2 * (size_t)e;
+        int n = (c->ped_model == NAVSIM_PED_NONE) ? 0 : st->n_peds[e];
+        if (n > N) n = N;
+        for (int i = 0; i < n; ++i) {
+            size_t q = (size_t)e * N + i;
+            st->ped_dist[q * 3] = 0.0; st->ped_dist[q * 3 + 1] = 0.0; st->ped_dist[q * 3 + 2] = 0.0; /* env.py:809 */
+            st->ped_prev_yaw[q] = nvr_wrap_pi(st->ped_pose[q * 3 + 2]);                              /* env.py:812-820 */
+        }
+        double zero[2] = {0.0, 0.0};
+        robot_scan(c, st, e, n, rp, scan);
+        pack_obs(c, scan, NULL, 0, rp, rp, zero, goal, obs,
+                 io->achieved_goal ? io->achieved_goal + 2 * (size_t)e : NULL,
+                 io->desired_goal ? io->desired_goal + 2 * (size_t)e : NULL);
+        st->prev_action[2 * e] = 0.0; st->prev_action[2 * e + 1] = 0.0;        /* env.py:736 */
+        st->prev_pose[3 * e] = rp[0]; st->prev_pose[3 * e + 1] = rp[1];
+        st->prev_pose[3 * e + 2] = nvr_wrap_pi(rp[2]);
+        st->n_hist[e] = (S - 1 < 1) ? S - 1 : 1;                               /* env.py:830 */
+        st->steps[e] = 0;                                                      /* env.py:735 */
+    }
+    free(scan);
+    return NAVSIM_OK;
+}
+
+int navsim_math_cpu(int32_t fn, const double* x, const double* x2, double* out, int32_t n) {
+    if (!x || !out) return NAVSIM_E_ARG;
+    for (int i = 0; i < n; ++i) {
+        switch (fn) {
+            case 0: out[i] = nvr_sin(x[i]); break;
+            case 1: out[i] = nvr_cos(x[i]); break;
+            case 2: out[i] = nvr_atan2(x[i], x2 ? x2[i] : 1.0); break;
+            case 3: out[i] = nvr_exp_neg(x[i]); break;
+            case 4: out[i] = nvr_wrap_pi(x[i]); break;
+            case 5: out[i] = nvr_mod_2pi(x[i]); break;
+            default: return NAVSIM_E_ARG;
+        }
+    }
+    return NAVSIM_OK;
+}

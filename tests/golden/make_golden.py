@@ -1,0 +1,486 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz from the importable parts of the reference (run in the build
+container only: /root/reference does not exist on the GPU box and is never read by tests).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What is captured:
+  golden_units.npz  -- inputs/outputs of the reference's own pure-NumPy functions, imported
+                       unmodified: Human.set_vel, KetiRobot.set_vel, batch_xy_to_ij,
+                       compute_rewards / compute_terminals / compute_info, _stack_scan,
+                       path_to_waypoints, angle_correction, transform_xys, registered kwargs.
+  golden_trace_*.npz -- input/output traces of the reference's own NavGymEnv.reset()/step()
+                       orchestration (env.py:591-831), executed unmodified.  The six pip packages it
+                       imports are absent here, so import-only stand-ins are injected into
+                       sys.modules: `range_libc`, `CMap2D` route the three L1 calls
+                       (calc_range_many, render_contours_in_lidar, render_agents_in_lidar) to the
+                       CPU oracle's primitives; `pose2d` is a NumPy restatement; `pyastar2d` is a
+                       BFS; `cv2` is a NumPy/SciPy subset; `gym` is a 20-line stub; torch.load of
+                       the missing human_policy.pth returns seeded random weights.
+                       => the traces pin ORCHESTRATION (order of operations, obs packing, leg
+                       odometry, reward/done/info, crash revert, scan stacking), NOT the L1
+                       arithmetic, which stays "parity unpinned" (oracle/navsim_ref.h).
+Only data (inputs and expected outputs) is written; no reference source text is stored.
+"""
+import os
+import sys
+import types
+from collections import deque
+
+sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+
+import numpy as np  # noqa: E402
+import scipy.ndimage as ndi  # noqa: E402
+import torch  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF_SRC = "/root/reference/nav_gym/src"
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ref as oracle  # noqa: E402
+
+
+# --------------------------------------------------------------------------------------------
+# import-only stand-ins for the missing pip packages
+# --------------------------------------------------------------------------------------------
+def install_shims():
+    # ---- gym ------------------------------------------------------------------------------
+    gym = types.ModuleType("gym")
+
+    class Env(object):
+        pass
+
+    class EzPickle(object):
+        def __init__(self, *a, **k):
+            pass
+
+    class Box(object):
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+
+    class Dict(object):
+        def __init__(self, spaces):
+            self.spaces = spaces
+    gym.Env = Env
+    gym.utils = types.ModuleType("gym.utils")
+    gym.utils.EzPickle = EzPickle
+    gym.spaces = types.ModuleType("gym.spaces")
+    gym.spaces.Box = Box
+    gym.spaces.Dict = Dict
+    gym.envs = types.ModuleType("gym.envs")
+    gym.envs.registration = types.ModuleType("gym.envs.registration")
+    gym.registry = {}
+
+    def register(id, kwargs=None, entry_point=None, **_):
+        gym.registry[id] = dict(kwargs=kwargs, entry_point=entry_point)
+    gym.envs.registration.register = register
+    for name in ("gym", "gym.utils", "gym.spaces", "gym.envs", "gym.envs.registration"):
+        sys.modules[name] = {"gym": gym, "gym.utils": gym.utils, "gym.spaces": gym.spaces,
+                             "gym.envs": gym.envs, "gym.envs.registration": gym.envs.registration}[name]
+
+    # ---- cv2 (reset path only) ---------------------------------------------------------------
+    cv2 = types.ModuleType("cv2")
+    cv2.__version__ = "4.6.0"
+    cv2.INTER_NEAREST = 0
+    cv2.THRESH_BINARY = 0
+    cv2.RETR_TREE = 3
+    cv2.CHAIN_APPROX_SIMPLE = 2
+
+    def resize(img, dsize, interpolation=0):
+        w, h = dsize
+        ys = np.minimum((np.arange(h) * (img.shape[0] / float(h))).astype(int), img.shape[0] - 1)
+        xs = np.minimum((np.arange(w) * (img.shape[1] / float(w))).astype(int), img.shape[1] - 1)
+        return img[np.ix_(ys, xs)]
+
+    def filter2D(img, ddepth, kernel):
+        out = ndi.correlate(img.astype(np.float64), kernel.astype(np.float64), mode="mirror")
+        return np.clip(out, 0, 255).astype(img.dtype)
+
+    def threshold(img, thresh, maxval, typ):
+        return thresh, (img > thresh).astype(img.dtype) * maxval
+
+    def dilate(img, kernel, iterations=1):
+        return ndi.grey_dilation(img, footprint=kernel.astype(bool))
+
+    def findContours(img, mode, method):
+        return [], None          # static contours are only used by thresholds, which overwrite them
+    cv2.resize, cv2.filter2D, cv2.threshold, cv2.dilate, cv2.findContours = \
+        resize, filter2D, threshold, dilate, findContours
+    sys.modules["cv2"] = cv2
+
+    # ---- range_libc -> oracle a3/a4 ------------------------------------------------------------
+    rl = types.ModuleType("range_libc")
+
+    class PyOMap(object):
+        def __init__(self, arr):
+            self.occ = np.ascontiguousarray(arr).astype(np.uint8)
+
+    class PyRayMarching(object):
+        def __init__(self, omap, max_range):
+            self.field = oracle.build_dt(omap.occ)
+            self.max_range = float(max_range)
+
+        def calc_range_many(self, ins, outs):
+            assert ins.dtype == np.float32 and outs.dtype == np.float32
+            outs[:] = oracle.cast_static(self.field, ins[None], self.max_range)[0]
+    rl.PyOMap, rl.PyRayMarching = PyOMap, PyRayMarching
+    sys.modules["range_libc"] = rl
+
+    # ---- CMap2D -> oracle a5/a6 ------------------------------------------------------------------
+    cm = types.ModuleType("CMap2D")
+
+    def flatten_contours(contours):
+        n = int(np.sum([len(c) for c in contours]))
+        flat = np.zeros((n, 3), dtype=np.float32)
+        v = 0
+        for idx, contour in enumerate(contours):
+            for vertex in contour:
+                flat[v, :] = np.array([idx, vertex[0], vertex[1]])
+                v += 1
+        return flat
+
+    def render_contours_in_lidar(ranges, angles, flat_contours, lidar_ij):
+        ranges[:] = oracle.render_polys(ranges[None], np.asarray(angles, np.float64)[None],
+                                        flat_contours[None], [len(flat_contours)],
+                                        np.asarray(lidar_ij, np.float32)[None])[0]
+
+    class CSimAgent(object):
+        def __init__(self, pos, dist, vel):
+            self.pos, self.dist, self.vel = pos, dist, vel
+
+    class CMap2D_(object):
+        def set_resolution(self, r):
+            self.res = r
+
+        def render_agents_in_lidar(self, ranges, angles, agents, lidar_ij):
+            if not agents:
+                return
+            a = np.zeros((1, len(agents), 8), np.float32)
+            for i, ag in enumerate(agents):
+                a[0, i, 0:3] = ag.pos
+                a[0, i, 3:6] = ag.dist
+                a[0, i, 6:8] = ag.vel
+            ranges[:] = oracle.render_legs(ranges[None], np.asarray(angles, np.float64)[None], a,
+                                           [len(agents)], np.asarray(lidar_ij, np.float32)[None])[0]
+    cm.flatten_contours, cm.render_contours_in_lidar = flatten_contours, render_contours_in_lidar
+    cm.CMap2D, cm.CSimAgent = CMap2D_, CSimAgent
+    sys.modules["CMap2D"] = cm
+
+    # ---- pose2d (NumPy restatement of the published helpers) ------------------------------------
+    p2 = types.ModuleType("pose2d")
+
+    def rotate(x, th):
+        rotmat = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        return np.matmul(rotmat, np.asarray(x).T).T
+
+    def inverse_pose2d(p):
+        inv_th = -p[2]
+        inv_xy = rotate(np.array([-p[:2]]), inv_th)[0]
+        return np.array([inv_xy[0], inv_xy[1], inv_th])
+
+    def apply_tf_to_vel(vel, pose2d):
+        xy = rotate(vel[:2], pose2d[2])
+        return np.array([xy[0], xy[1], vel[2]])
+    p2.inverse_pose2d, p2.apply_tf_to_vel = inverse_pose2d, apply_tf_to_vel
+    sys.modules["pose2d"] = p2
+
+    # ---- pyastar2d: 4-connected BFS ----------------------------------------------------------------
+    pa = types.ModuleType("pyastar2d")
+
+    def astar_path(grid, start, goal, allow_diagonal=False):
+        free = np.isfinite(grid)
+        s, g = (int(start[0]), int(start[1])), (int(goal[0]), int(goal[1]))
+        if not (free[s] and free[g]):
+            return None
+        prev = -np.ones(grid.shape + (2,), dtype=np.int32)
+        seen = np.zeros(grid.shape, bool)
+        seen[s] = True
+        dq = deque([s])
+        while dq:
+            c = dq.popleft()
+            if c == g:
+                break
+            for d in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                nb = (c[0] + d[0], c[1] + d[1])
+                if 0 <= nb[0] < grid.shape[0] and 0 <= nb[1] < grid.shape[1] and free[nb] and not seen[nb]:
+                    seen[nb] = True
+                    prev[nb] = c
+                    dq.append(nb)
+        if not seen[g]:
+            return None
+        path = [g]
+        while path[-1] != s:
+            path.append(tuple(prev[path[-1]]))
+        return np.array(path[::-1])
+    pa.astar_path = astar_path
+    sys.modules["pyastar2d"] = pa
+
+
+def import_reference():
+    install_shims()
+    sys.path.insert(0, REF_SRC)
+    import nav_gym_env  # noqa: F401  (registers NavGym-v0 into the gym stub)
+    from nav_gym_env import env as ref_env
+    from nav_gym_env import human, keti_robot, utils as ref_utils, human_policy
+    return ref_env, human, keti_robot, ref_utils, human_policy
+
+
+# --------------------------------------------------------------------------------------------
+# unit goldens
+# --------------------------------------------------------------------------------------------
+def make_units(ref_env, human, keti_robot, ref_utils):
+    rng = np.random.default_rng(20261002)
+    out = {}
+    # (1) set_vel: 1000 random (px, py, theta, v, w, dt)
+    n = 1000
+    inp = np.stack([rng.uniform(0, 50, n), rng.uniform(0, 50, n), rng.uniform(0, 2 * np.pi, n),
+                    rng.uniform(-0.2, 1.0, n), rng.uniform(-1.5, 1.5, n),
+                    rng.choice([0.1, 0.2, 0.25], n)], axis=1)
+    inp[:50, 2] = rng.uniform(-np.pi, np.pi, 50)         # wrapped yaws after a crash revert
+    h_out = np.zeros((n, 5)); k_out = np.zeros((n, 5))
+    for i in range(n):
+        px, py, th, v, w, dt = inp[i]
+        h = human.Human(px, py, th, 0., 0., dt); h.set_vel(v, w)
+        h_out[i] = [h.px, h.py, h.theta, h.vx, h.vy]
+        k = keti_robot.KetiRobot(px, py, th, 0., 0., dt); k.set_vel(v, w)
+        k_out[i] = [k.px, k.py, k.theta, k.vx, k.vy]
+    out.update(set_vel_in=inp, human_set_vel_out=h_out, keti_set_vel_out=k_out)
+    # robot constants
+    K = keti_robot.KetiRobot
+    out.update(keti_footprint=np.array(K.footprint), keti_threshold_footprint=np.array(K.threshold_footprint),
+               keti_discomfort_footprint=np.array(K.discomfort_threshold_footprint),
+               keti_lidar=np.array([K.angle_min, K.angle_max, K.angle_increment, K.range_max, K.n_angles]),
+               human_footprint=np.array(human.Human.footprint),
+               human_lidar=np.array([human.Human.angle_min, human.Human.angle_max,
+                                     human.Human.angle_increment, human.Human.range_max, human.Human.n_angles]))
+    # (2) xy -> ij: float32-representable values carried in float64
+    for size in (100, 400, 500, 1000):
+        xy = rng.uniform(-1.0, size * 0.05 + 1.0, (1000, 2)).astype(np.float32).astype(np.float64)
+        mi = dict(resolution=0.05, origin=(0, 0), height=size, width=size)
+        out["xy_%d" % size] = xy
+        out["ij_%d" % size] = ref_env.batch_xy_to_ij(xy, mi)
+        # float32 inputs, as the scan origin passes them (env.py:419); grid-aligned values included
+        xyf = xy.astype(np.float32)
+        xyf[:200] = (rng.integers(0, size, (200, 2)) * 0.05 + rng.choice([0.0, 0.025, 0.05], (200, 2))).astype(np.float32)
+        out["xyf32_%d" % size] = xyf
+        out["ijf32_%d" % size] = ref_env.batch_xy_to_ij(xyf, mi)
+    out["ij_to_xy_in"] = rng.integers(0, 400, (64, 2))
+    out["ij_to_xy_out"] = ref_env.batch_ij_to_xy(out["ij_to_xy_in"], dict(resolution=0.05, origin=(0, 0)))
+    # (3) reward / terminals / info on random obs batches with synthetic thresholds
+    for S, B in ((1, 128), (3, 64)):
+        env = object.__new__(ref_env.NavGymEnv)
+        kw = sys.modules["gym"].registry["NavGym-v0"]["kwargs"]
+        for k, v in kw.items():
+            setattr(env, k, v)
+        env.num_scan_stack = S
+        env.robot = types.SimpleNamespace(n_angles=B)
+        thr = rng.uniform(0.5, 0.9, B).astype(np.float32)
+        dthr = (thr + rng.uniform(0.3, 0.6, B)).astype(np.float32)
+        env.scan_threshold, env.scan_discomfort_threshold = thr, dthr
+        nb = 96
+        scans = rng.uniform(0.3, 6.0, (nb, S * B)).astype(np.float32)
+        scans[: nb // 2] += 1.0                              # half the rows comfortably clear
+        scans[: nb // 4] += 2.0
+        tail = np.concatenate([rng.uniform(0, 20, (nb, 4)), rng.uniform(-0.7, 0.7, (nb, 2)),
+                               rng.uniform(-np.pi, np.pi, (nb, 1))], axis=1)
+        obs = np.concatenate([scans.astype(np.float64), tail], axis=1)
+        goals = tail[:, 2:4] + rng.uniform(-3, 3, (nb, 2))
+        goals[:16] = tail[:16, 2:4] + rng.uniform(-0.3, 0.3, (16, 2))   # successes
+        # obs = concat(scans (float32 values) as float64, tail): stored split to keep the file small
+        actions = rng.uniform(-1, 1, (nb, 2))
+        od = dict(observation=obs, desired_goal=goals)
+        tag = "rd_S%d_B%d_" % (S, B)
+        out[tag + "scans"] = scans; out[tag + "tail"] = tail; out[tag + "goals"] = goals; out[tag + "thr"] = thr; out[tag + "dthr"] = dthr
+        out[tag + "reward"] = env.compute_rewards(actions, od)
+        out[tag + "done"] = env.compute_terminals(od)
+        infos = [env.compute_info(dict(observation=obs[i], desired_goal=goals[i])) for i in range(nb)]
+        out[tag + "is_success"] = np.array([i["is_success"] for i in infos], np.float32)
+        out[tag + "is_crash"] = np.array([i["is_crash"] for i in infos], np.float32)
+        out[tag + "distance"] = np.array([i["distance"] for i in infos], np.float64)
+        # _stack_scan with queues of every fill level
+        if S == 3:
+            stack_in, stack_q, stack_out = [], [], []
+            for fill in range(S):
+                q = deque(maxlen=S - 1)
+                prevs = []
+                for _ in range(fill):
+                    po = rng.uniform(0, 6, S * B + 7)
+                    q.append(dict(observation=po)); prevs.append(po)
+                cur = rng.uniform(0, 6, B + 7)
+                res = env._stack_scan(dict(observation=cur), q, S, B)
+                stack_in.append(cur)
+                stack_q.append(np.stack(prevs + [np.zeros(S * B + 7)] * (S - 1 - fill)))
+                stack_out.append(res["observation"])
+            out["stack_cur"] = np.stack(stack_in); out["stack_queue"] = np.stack(stack_q)
+            out["stack_out"] = np.stack(stack_out)
+    # (4) path_to_waypoints on synthetic paths
+    wp_paths, wp_out, wp_int = [], [], []
+    for t in range(20):
+        m = int(rng.integers(5, 120))
+        steps = rng.choice([[0.25, 0], [0, 0.25], [-0.25, 0], [0, -0.25]], m, p=[0.4, 0.3, 0.15, 0.15])
+        path = np.cumsum(np.vstack([[rng.uniform(0, 20, 2)], steps]), axis=0)
+        interval = [2, 5][t % 2]
+        w = ref_env.path_to_waypoints(path, interval=interval)
+        pad = np.full((128, 2), np.nan); pad[: len(path)] = path
+        wpad = np.full((64, 2), np.nan); wpad[: len(w)] = w
+        wp_paths.append(pad); wp_out.append(wpad); wp_int.append(interval)
+    out.update(wp_paths=np.stack(wp_paths), wp_out=np.stack(wp_out), wp_interval=np.array(wp_int))
+    # (5) utils
+    ang = rng.uniform(-20, 20, 256)
+    out.update(angle_in=ang, angle_out=ref_utils.angle_correction(ang))
+    xys = rng.uniform(-1, 1, (16, 2))
+    T = ref_utils.translation_matrix_from_xyz(3.25, -1.5, 0)
+    R = ref_utils.quaternion_matrix_from_yaw(0.7)
+    out.update(tf_xys_in=xys, tf_xys_out=ref_utils.transform_xys(T, R, xys))
+    # (6) registered kwargs
+    kw = sys.modules["gym"].registry["NavGym-v0"]["kwargs"]
+    flat = {k: v for k, v in kw.items() if k != "env_param_range"}
+    out["kwargs_keys"] = np.array(sorted(flat.keys()))
+    out["kwargs_vals"] = np.array([str(flat[k]) for k in sorted(flat.keys())])
+    epr = kw["env_param_range"]
+    out["env_param_keys"] = np.array(sorted(epr.keys()))
+    out["env_param_vals"] = np.array([str(epr[k]) for k in sorted(epr.keys())])
+    out["entry_point"] = np.array(sys.modules["gym"].registry["NavGym-v0"]["entry_point"])
+    np.savez_compressed(os.path.join(HERE, "golden_units.npz"), **out)
+    print("golden_units.npz:", len(out), "arrays")
+
+
+# --------------------------------------------------------------------------------------------
+# step() traces
+# --------------------------------------------------------------------------------------------
+def make_env(ref_env, human_policy, S, seed):
+    kw = dict(sys.modules["gym"].registry["NavGym-v0"]["kwargs"])
+    kw["num_scan_stack"] = S
+    kw["indoor_ratio"] = 0.0                      # outdoor 400x400 maps keep the fixture small
+    epr = dict(kw["env_param_range"])
+    epr["scan_noise_std"] = ([0., 0.], "float")   # parity is defined without noise
+    epr["num_humans"] = ([5, 7], "int")
+    kw["env_param_range"] = epr
+    torch.manual_seed(seed)
+    weights = human_policy.HumanPolicy(frames=3, action_space=2).state_dict()
+    real_load = torch.load
+    torch.load = lambda *a, **k: weights          # human_policy.pth is a missing blob
+    np.random.seed(seed)
+    try:
+        env = ref_env.NavGymEnv(**kw)
+        env.reset()
+    finally:
+        torch.load = real_load
+    return env
+
+
+def rebuild_first_obs(env):
+    """The tail of the reference's reset() (env.py:808-831) after poses were edited."""
+    env.prev_action = np.array([0., 0.])
+    env.prev_obs = None
+    env.prev_obs_queue = deque(maxlen=env.num_scan_stack - 1)
+    env.distances_travelled_in_base_frame = np.zeros((len(env.humans), 3))
+    env.prev_humans_obs_queue = [deque(maxlen=2) for _ in env.humans]
+    for i, h in enumerate(env.humans):
+        others = [env.robot] + [x for x in env.humans if x != h]
+        ho = env._convert_obs(h, others, env.prev_obs, env.prev_action, add_scan_noise=False, lidar_legs=False)
+        ho = env._stack_scan(ho, env.prev_humans_obs_queue[i], 3, h.n_angles)
+        env.prev_humans_obs_queue[i].append(ho)
+    obs = env._convert_obs(env.robot, env.humans, env.prev_obs, env.prev_action, add_scan_noise=True, lidar_legs=True)
+    obs = env._stack_scan(obs, env.prev_obs_queue, env.num_scan_stack, env.robot.n_angles)
+    env.prev_obs = obs
+    env.prev_obs_queue.append(obs)
+    return obs
+
+
+def snapshot(env):
+    hs = env.humans
+    return dict(
+        robot_pose=np.array([env.robot.px, env.robot.py, env.robot.theta]),
+        ped_pose=np.array([[h.px, h.py, h.theta] for h in hs]).reshape(-1, 3),
+        ped_vel=np.array([[h.vx, h.vy] for h in hs]).reshape(-1, 2),
+        ped_dist=np.array(env.distances_travelled_in_base_frame).reshape(-1, 3),
+    )
+
+
+def run_trace(name, ref_env, human, human_policy, S, seed, scenario, n_steps):
+    env = make_env(ref_env, human_policy, S, seed)
+    rng = np.random.default_rng(seed)
+    B = env.robot.n_angles
+    occ = (env.map_info["data"] >= 0.1)
+    if scenario == "crash":
+        # face the west border wall (5 cells = 0.25 m thick) from 0.5 m outside the crash zone
+        field = oracle.build_dt(occ)[0]
+        rows = np.where((field[:, 27] == 23.0) & (field[:, 45] >= 30.0))[0]     # nothing but the wall nearby
+        env.robot.px, env.robot.py, env.robot.theta = 0.25 + 0.6 + 0.5, (rows[len(rows) // 2] + 0.5) * 0.05, np.pi
+    if scenario == "success":
+        env.robot.gx = env.robot.px + 0.9 * np.cos(env.robot.theta)
+        env.robot.gy = env.robot.py + 0.9 * np.sin(env.robot.theta)
+    if scenario in ("peds", "crash"):
+        # one legged and one legless pedestrian in view of the robot
+        layout = ((2.0, 0.4, True), (3.0, -0.5, False), (1.6, 2.4, True)) if scenario == "peds" else \
+                 ((2.0, 2.5, True), (3.0, -2.4, False), (1.6, 3.0, True))
+        for k, (dist, bearing, legs) in enumerate(layout):
+            h = env.humans[k]
+            h.px = env.robot.px + dist * np.cos(env.robot.theta + bearing)
+            h.py = env.robot.py + dist * np.sin(env.robot.theta + bearing)
+            h.has_legs = legs
+    first = rebuild_first_obs(env)
+    rec = dict(
+        occ_packed=np.packbits(occ), occ_shape=np.array(occ.shape),
+        S=np.array(S), B=np.array(B),
+        scan_threshold=env.scan_threshold.copy(), scan_discomfort=env.scan_discomfort_threshold.copy(),
+        robot_goal=np.array([env.robot.gx, env.robot.gy]),
+        ped_v_pref=np.array([h.v_pref for h in env.humans]),
+        ped_has_legs=np.array([h.has_legs for h in env.humans], np.uint8),
+        first_obs=first["observation"].copy(),
+        time_step=np.array(env.time_step),
+    )
+    for k, v in snapshot(env).items():
+        rec["init_" + k] = v
+    # record the (v, w) the reference hands to Human.set_vel (env.py:662)
+    cmds = []
+    orig = human.Human.set_vel
+
+    def spy(self, v, w):
+        cmds.append((float(v), float(w)))
+        return orig(self, v, w)
+    human.Human.set_vel = spy
+    T = n_steps
+    N = len(env.humans)
+    acts = np.zeros((T, 2)); obs = np.zeros((T, S * B + 7)); rew = np.zeros(T); done = np.zeros(T, np.uint8)
+    succ = np.zeros(T, np.float32); crash = np.zeros(T, np.float32); dist = np.zeros(T)
+    ped_cmd = np.zeros((T, N, 2)); snaps = {k: [] for k in ("robot_pose", "ped_pose", "ped_vel", "ped_dist")}
+    try:
+        for t in range(T):
+            if scenario == "random":
+                a = np.array([rng.uniform(0, 0.5), rng.uniform(-0.64, 0.64)])
+            elif scenario == "crash":
+                a = np.array([0.5, 0.0]) if t < 8 else np.array([rng.uniform(0, 0.5), rng.uniform(-0.64, 0.64)])
+            else:
+                a = np.array([0.5, rng.uniform(-0.1, 0.1)])
+            del cmds[:]
+            o, r, d, info = env.step(a.copy())
+            acts[t] = a; obs[t] = o["observation"]; rew[t] = r; done[t] = d
+            succ[t] = info["is_success"]; crash[t] = info["is_crash"]; dist[t] = info["distance"]
+            ped_cmd[t] = np.array(cmds).reshape(N, 2)
+            for k, v in snapshot(env).items():
+                snaps[k].append(v)
+    finally:
+        human.Human.set_vel = orig
+    rec.update(actions=acts, obs_scan=obs[:, : S * B].astype(np.float32), obs_tail=obs[:, S * B:],
+               reward=rew, done=done, is_success=succ, is_crash=crash, distance=dist, ped_cmd=ped_cmd)
+    assert np.array_equal(rec["obs_scan"].astype(np.float64), obs[:, : S * B])   # scans are float32 values
+    for k, v in snaps.items():
+        rec["traj_" + k] = np.stack(v)
+    np.savez_compressed(os.path.join(HERE, "golden_trace_%s.npz" % name), **rec)
+    print("golden_trace_%s.npz: T=%d N=%d crashes=%d successes=%d" % (name, T, N, int(crash.sum()), int(succ.sum())))
+
+
+def main():
+    ref_env, human, keti_robot, ref_utils, human_policy = import_reference()
+    make_units(ref_env, human, keti_robot, ref_utils)
+    run_trace("random_S1", ref_env, human, human_policy, S=1, seed=11, scenario="random", n_steps=40)
+    run_trace("peds_S1", ref_env, human, human_policy, S=1, seed=12, scenario="peds", n_steps=30)
+    run_trace("crash_S3", ref_env, human, human_policy, S=3, seed=13, scenario="crash", n_steps=24)
+    run_trace("success_S2", ref_env, human, human_policy, S=2, seed=14, scenario="success", n_steps=12)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+"""CPU: the oracle against golden vectors captured from the reference (tests/golden/make_golden.py).
+
+Pinned rows of SURVEY.md section 8a: a7 (leg odometry), a8/a9 (set_vel), a11 (obs packing /
+stacking), a12/a13 (reward, terminals, info), a15 (xy->ij), and the orchestration of a1 through
+full reset()/step() traces of the reference's own code."""
+import os
+
+import numpy as np
+import pytest
+
+import ref
+from helpers import load_trace, trace_setup
+
+
+@pytest.fixture(scope="module")
+def units(golden_dir):
+    d = np.load(os.path.join(golden_dir, "golden_units.npz"))
+    return {k: d[k] for k in d.files}
+
+
+def test_human_set_vel(units):
+    inp = units["set_vel_in"]
+    for dt in np.unique(inp[:, 5]):
+        m = inp[:, 5] == dt
+        pose, vel = ref.integrate(inp[m, 0:3], inp[m, 3:5], float(dt), 0.0)
+        exp = units["human_set_vel_out"][m]
+        np.testing.assert_allclose(pose, exp[:, 0:3], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(vel, exp[:, 3:5], rtol=0, atol=1e-12)
+
+
+def test_keti_set_vel(units):
+    inp = units["set_vel_in"]
+    for dt in np.unique(inp[:, 5]):
+        m = inp[:, 5] == dt
+        pose, vel = ref.integrate(inp[m, 0:3], inp[m, 3:5], float(dt), 0.14474)
+        exp = units["keti_set_vel_out"][m]
+        np.testing.assert_allclose(pose, exp[:, 0:3], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(vel, exp[:, 3:5], rtol=0, atol=1e-12)
+
+
+def test_set_vel_survey_goldens():
+    # SURVEY.md 8a rows a8 / a9 [PROBE]
+    p, _ = ref.integrate([[1.0, 2.0, 0.3]], [[0.5, 0.64]], 0.2, 0.0)
+    assert p[0].tolist() == [1.0909797672793022, 2.0415052038400487, 0.428]
+    p, _ = ref.integrate([[1.0, 2.0, 0.3]], [[0.5, 0.64]], 0.2, 0.14474)
+    assert p[0].tolist() == [1.0975710555552805, 2.0242041665141244, 0.428]
+
+
+@pytest.mark.parametrize("size", [100, 400, 500, 1000])
+def test_xy_to_ij(units, size):
+    got = ref.xy_to_ij(units["xy_%d" % size], (0.0, 0.0), 0.05, size, size)
+    assert np.array_equal(got, units["ij_%d" % size])
+
+
+@pytest.mark.parametrize("size", [100, 400, 500, 1000])
+def test_xy_to_ij_float32_inputs(units, size):
+    """env.py:419 passes float32 coordinates: NumPy >= 2 then divides in float32."""
+    got = ref.xy_to_ij_f32(units["xyf32_%d" % size], (0.0, 0.0), 0.05, size, size)
+    assert np.array_equal(got, units["ijf32_%d" % size])
+
+
+def test_xy_to_ij_survey_golden():
+    assert ref.xy_to_ij([[3.14, 7.77]], (0, 0), 0.05, 500, 500).tolist() == [[62, 155]]
+
+
+@pytest.mark.parametrize("S,B", [(1, 128), (3, 64)])
+def test_reward_terminals_info(units, S, B):
+    tag = "rd_S%d_B%d_" % (S, B)
+    obs = np.concatenate([units[tag + "scans"].astype(np.float64), units[tag + "tail"]], axis=1)
+    cfg = ref.default_config(n_beams=B, n_scan_stack=S)
+    out = ref.reward_done(cfg, obs, units[tag + "goals"], units[tag + "thr"], units[tag + "dthr"])
+    np.testing.assert_allclose(out["reward"], units[tag + "reward"], rtol=0, atol=1e-9)
+    assert np.array_equal(out["done"].astype(bool), units[tag + "done"].astype(bool))
+    assert np.array_equal(out["is_success"], units[tag + "is_success"])
+    assert np.array_equal(out["is_crash"], units[tag + "is_crash"])
+    np.testing.assert_allclose(out["distance"], units[tag + "distance"], rtol=0, atol=1e-12)
+    # the batch must exercise every branch
+    assert out["is_crash"].any() and out["is_success"].any() and (out["is_crash"] == 0).any()
+
+
+def test_angle_correction(units):
+    got = ref.math_fn(4, units["angle_in"])
+    np.testing.assert_allclose(got, units["angle_out"], rtol=0, atol=1e-12)
+
+
+def test_constants(units):
+    cfg = ref.default_config()
+    amin, amax, ainc, rmax, n = units["keti_lidar"]
+    assert cfg.angle_min == amin and cfg.angle_last == amax - ainc
+    assert cfg.range_max == rmax and cfg.n_beams == int(n)
+    kw = dict(zip(units["kwargs_keys"].tolist(), units["kwargs_vals"].tolist()))
+    assert float(kw["time_step"]) == cfg.time_step
+    assert float(kw["distance_threshold"]) == cfg.distance_threshold
+    assert int(kw["num_scan_stack"]) == cfg.n_scan_stack
+    for k in ("scale", "success_factor", "crash_factor", "progress_factor", "forward_factor",
+              "rotation_factor", "discomfort_factor"):
+        assert float(kw["reward_" + k]) == getattr(cfg, "reward_" + k)
+    assert float(kw["min_turning_radius"]) == cfg.min_turning_radius
+
+
+def test_scan_thresholds_match_reference_built(units):
+    """Thresholds the reference code derived (through the oracle's polygon renderer) at init."""
+    tr = load_trace("random_S1")
+    cfg = ref.default_config()
+    thr = ref.scan_threshold(cfg, units["keti_threshold_footprint"])
+    dthr = ref.scan_threshold(cfg, units["keti_discomfort_footprint"])
+    assert np.array_equal(thr, tr["scan_threshold"])
+    assert np.array_equal(dthr, tr["scan_discomfort"])
+    # closed form (keti_robot.py:18-23): front 0.6, sides 0.6, rear 0.7
+    assert abs(thr[256] - 0.6) < 1e-6 and abs(thr[128] - 0.6) < 1e-6 and abs(thr[384] - 0.6) < 1e-6
+    assert abs(thr[0] - 0.7) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["random_S1", "peds_S1", "crash_S3", "success_S2"])
+def test_step_trace(name):
+    """The oracle's step() reproduces the reference's own step() on the recorded traces."""
+    tr = load_trace(name)
+    cfg, arrays, _ = trace_setup(tr, ref.default_config, ref.build_dt)
+    sim = ref.RefSim(cfg, arrays)
+    S, B = int(tr["S"]), int(tr["B"])
+    first = sim.reset_obs()
+    assert np.array_equal(first[0, : S * B], tr["first_obs"][: S * B].astype(np.float32))
+    np.testing.assert_allclose(first[0, S * B:], tr["first_obs"][S * B:], rtol=0, atol=2e-6)
+    T = tr["actions"].shape[0]
+    for t in range(T):
+        sim.set_ped_cmd(tr["ped_cmd"][t][None])
+        obs, out = sim.step(tr["actions"][t][None])
+        # flags bit-exact, reward/pose tight
+        assert out["done"][0] == tr["done"][t], t
+        assert out["is_crash"][0] == tr["is_crash"][t], t
+        assert out["is_success"][0] == tr["is_success"][t], t
+        assert abs(out["reward"][0] - tr["reward"][t]) < 1e-9, t
+        assert abs(out["distance"][0] - tr["distance"][t]) < 1e-12, t
+        assert np.array_equal(obs[0, : S * B], tr["obs_scan"][t]), t
+        np.testing.assert_allclose(obs[0, S * B:], tr["obs_tail"][t], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(sim.a["robot_pose"][0], tr["traj_robot_pose"][t], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(sim.a["ped_pose"][0], tr["traj_ped_pose"][t], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(sim.a["ped_vel"][0], tr["traj_ped_vel"][t], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(sim.a["ped_dist"][0], tr["traj_ped_dist"][t], rtol=0, atol=1e-10)
+    if name.startswith("crash"):
+        assert tr["is_crash"].sum() > 0 and (tr["is_crash"] == 0).sum() > 0
+    if name.startswith("success"):
+        assert tr["is_success"].sum() > 0
