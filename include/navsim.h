@@ -214,8 +214,16 @@ int navsim_step(const navsim_config* cfg, const navsim_state* st, const navsim_s
 int navsim_reset_obs(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                      const uint8_t* mask, void* stream);
 
-/* Name and average launch statistics hooks used by bench.py (HIP events on `stream`). */
+/* Name of the fused step kernel as rocprofv3 reports it (bench.py / profiles). */
 const char* navsim_step_kernel_name(void);
+
+/* ---- test hooks (used by tests/ only) ---------------------------------------------------- */
+size_t navsim_sizeof_config(void);
+size_t navsim_sizeof_state(void);
+size_t navsim_sizeof_step_io(void);
+/* deterministic device math of DESIGN.md section 4: fn 0 sin, 1 cos, 2 atan2(x, x2), 3 exp(x<=0),
+ * 4 angle_correction (utils.py:5-9), 5 python-float % 2pi.  x, x2, out are device float64 [n]. */
+int navsim_debug_math(int32_t fn, const double* x, const double* x2, double* out, int32_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,842 @@
+// navsim_kernels.hip -- hand-written gfx950 kernels + the C ABI of include/navsim.h.
+//
+// Hot path: NavGymEnv.step (nav_gym/src/nav_gym_env/env.py:591-728 of leekwoon/nav-gym), batched
+// over E independent arenas.  One workgroup owns one arena for the whole step: pedestrian update,
+// robot integration, lidar ray-march over the arena's distance field, reward / done / info,
+// crash revert (or respawn) with re-scan and observation packing all happen in ONE launch, so the
+// only HBM traffic is the distance-field sectors the rays touch, the arena's small state and the
+// observation row written once.  No MFMA: there is no dense contraction on this path.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see nav-gym_amd/csrc/build.sh).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/navsim.h"
+#include "navmath.hpp"
+#include "navsim_device.hpp"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kStepBlock = 256;       // threads per arena workgroup (4 waves)
+constexpr int kMaxWaves = 16;
+
+// ============================================================================================
+// a3: exact Euclidean distance transform (replaces range_libc.PyOMap + PyRayMarching.__init__,
+// env.py:337-340).  Pass 1: per column, distance to the nearest occupied cell of that column
+// (uint16, 0xFFFF = none).  Pass 2: per row, d2(x) = min_i (x-i)^2 + g(i)^2 by an outward search
+// that stops as soon as (x-i)^2 alone exceeds the best value: exact, integer, and the search
+// radius is the answer itself, so cells near obstacles (most of them) cost a handful of reads.
+// ============================================================================================
+constexpr int kDtInf = 32768;
+
+__global__ __launch_bounds__(256) void dt_columns_kernel(const uint8_t* __restrict__ occ,
+                                                         uint16_t* __restrict__ g, int H, int W) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t m = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t* o = occ + m * (size_t)H * W;
+    uint16_t* gg = g + m * (size_t)H * W;
+    int d = kDtInf;
+    for (int y = 0; y < H; ++y) {
+        d = o[(size_t)y * W + x] ? 0 : (d >= kDtInf ? kDtInf : d + 1);
+        gg[(size_t)y * W + x] = (uint16_t)(d >= kDtInf ? 0xFFFF : d);
+    }
+    d = kDtInf;
+    for (int y = H - 1; y >= 0; --y) {
+        int cur = gg[(size_t)y * W + x];
+        cur = (cur == 0xFFFF) ? kDtInf : cur;
+        d = (cur == 0) ? 0 : (d >= kDtInf ? kDtInf : d + 1);
+        if (d < cur) gg[(size_t)y * W + x] = (uint16_t)d;
+        else d = cur;
+    }
+}
+
+__global__ __launch_bounds__(256) void dt_rows_kernel(const uint16_t* __restrict__ g,
+                                                      float* __restrict__ field, int H, int W) {
+    extern __shared__ int32_t row[];                 // W entries of g(i)^2-ready distances
+    size_t m = blockIdx.y;
+    int y = blockIdx.x;
+    const uint16_t* gr = g + (m * (size_t)H + y) * W;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        int v = gr[x];
+        row[x] = (v == 0xFFFF) ? kDtInf : v;
+    }
+    __syncthreads();
+    float* out = field + (m * (size_t)H + y) * W;
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
+        int g0 = row[x];
+        int best = g0 * g0;
+        for (int dx = 1; dx < W; ++dx) {
+            int dx2 = dx * dx;
+            if (dx2 >= best) break;
+            int xl = x - dx, xr = x + dx;
+            if (xl >= 0) { int v = row[xl]; int c = dx2 + v * v; best = c < best ? c : best; }
+            if (xr < W)  { int v = row[xr]; int c = dx2 + v * v; best = c < best ? c : best; }
+        }
+        out[x] = sqrtf((float)best);
+    }
+}
+
+// ============================================================================================
+// a4: PyRayMarching.calc_range_many (env.py:425): one thread per query
+// ============================================================================================
+__global__ __launch_bounds__(256) void cast_static_kernel(const float* __restrict__ field, int H, int W,
+                                                          const float* __restrict__ q, int n_per_env,
+                                                          long long n_total, float max_range,
+                                                          float* __restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_total) return;
+    long long e = i / n_per_env;
+    const float* f = field + (size_t)e * H * W;
+    float dx, dy;
+    nv::beam_dir(q[3 * i + 2], dx, dy);
+    out[i] = nv::trace_ray(f, H, W, q[3 * i], q[3 * i + 1], dx, dy, max_range);
+}
+
+// ============================================================================================
+// a5: CMap2D.render_contours_in_lidar (env.py:431): one thread per (env, beam)
+// ============================================================================================
+__global__ __launch_bounds__(256) void render_polys_kernel(float* __restrict__ ranges,
+                                                           const double* __restrict__ angles, int B,
+                                                           const float* __restrict__ verts,
+                                                           const int32_t* __restrict__ n_verts, int V,
+                                                           const float* __restrict__ origin) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    int e = blockIdx.y;
+    if (k >= B) return;
+    const float* vv = verts + (size_t)e * V * 3;
+    int nv_ = n_verts[e];
+    float ox = origin[2 * e], oy = origin[2 * e + 1];
+    float c, s;
+    nv::beam_dir((float)angles[(size_t)e * B + k], c, s);
+    float r = ranges[(size_t)e * B + k];
+    int start = 0;
+    while (start < nv_) {
+        int end = start;
+        while (end + 1 < nv_ && vv[3 * (end + 1)] == vv[3 * start]) ++end;
+        for (int v = start; v <= end; ++v) {
+            int w = (v == end) ? start : v + 1;      // polygons are closed automatically
+            nv::seg_merge(r, ox, oy, c, s, vv[3 * v + 1], vv[3 * v + 2], vv[3 * w + 1], vv[3 * w + 2]);
+        }
+        start = end + 1;
+    }
+    ranges[(size_t)e * B + k] = r;
+}
+
+// ============================================================================================
+// a6: CMap2D.render_agents_in_lidar (env.py:432): one thread per (env, beam)
+// ============================================================================================
+__global__ __launch_bounds__(256) void render_legs_kernel(float* __restrict__ ranges,
+                                                          const double* __restrict__ angles, int B,
+                                                          const float* __restrict__ agents,
+                                                          const int32_t* __restrict__ n_agents, int A,
+                                                          const float* __restrict__ origin) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    int e = blockIdx.y;
+    if (k >= B) return;
+    float ox = origin[2 * e], oy = origin[2 * e + 1];
+    float c, s;
+    nv::beam_dir((float)angles[(size_t)e * B + k], c, s);
+    float r = ranges[(size_t)e * B + k];
+    int na = n_agents[e];
+    for (int i = 0; i < na; ++i) {
+        const float* a = agents + ((size_t)e * A + i) * 8;
+        float cc[4];
+        nv::leg_centres(a[0], a[1], a[2], a[3], a[4], a[5], cc);
+        nv::circle_merge(r, ox, oy, c, s, cc[0], cc[1], nv::kLegRadius);
+        nv::circle_merge(r, ox, oy, c, s, cc[2], cc[3], nv::kLegRadius);
+    }
+    ranges[(size_t)e * B + k] = r;
+}
+
+// ============================================================================================
+// a8 / a9: set_vel
+// ============================================================================================
+__global__ __launch_bounds__(256) void integrate_kernel(double* __restrict__ pose,
+                                                        const double* __restrict__ cmd,
+                                                        double* __restrict__ vel_out, int n, double dt,
+                                                        double off) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double p[3] = {pose[3 * i], pose[3 * i + 1], pose[3 * i + 2]};
+    double v[2];
+    nv::set_vel(p, cmd[2 * i], cmd[2 * i + 1], dt, off, v);
+    pose[3 * i] = p[0]; pose[3 * i + 1] = p[1]; pose[3 * i + 2] = p[2];
+    if (vel_out) { vel_out[2 * i] = v[0]; vel_out[2 * i + 1] = v[1]; }
+}
+
+// ============================================================================================
+// block-level helpers
+// ============================================================================================
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double o = __shfl_xor(v, off, 64);
+        v = (o < v) ? o : v;
+    }
+    return v;
+}
+
+// ============================================================================================
+// a12 / a13: compute_rewards / compute_terminals / compute_info on arbitrary obs rows (HER API)
+// one workgroup per row
+// ============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void reward_done_kernel(navsim_config c, const T* __restrict__ obs,
+                                                          const T* __restrict__ goals,
+                                                          const float* __restrict__ thr,
+                                                          const float* __restrict__ dthr,
+                                                          double* reward, uint8_t* done, float* is_success,
+                                                          float* is_crash, double* distance) {
+    __shared__ double s_ratio[kMaxWaves];
+    const int B = c.n_beams, S = c.n_scan_stack, D = S * B + 7;
+    const int row = blockIdx.x;
+    const T* o = obs + (size_t)row * D;
+    const T* scan = o + (size_t)(S - 1) * B;
+    int crash = 0, disc = 0;
+    double rmin = 1.0e300;
+    for (int k = threadIdx.x; k < B; k += blockDim.x) {
+        double s = (double)scan[k];
+        if (s - (double)thr[k] < 0.0) crash = 1;
+        if (s - (double)dthr[k] < 0.0) disc = 1;
+        double ratio = nv::discomfort_ratio(s, thr[k], dthr[k]);
+        rmin = ratio < rmin ? ratio : rmin;
+    }
+    crash = __syncthreads_or(crash);
+    disc = __syncthreads_or(disc);
+    rmin = wave_min_f64(rmin);
+    if ((threadIdx.x & 63) == 0) s_ratio[threadIdx.x >> 6] = rmin;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int nw = (blockDim.x + 63) >> 6;
+        for (int w = 1; w < nw; ++w) rmin = s_ratio[w] < rmin ? s_ratio[w] : rmin;
+        const T* tail = o + (size_t)S * B;
+        double prev_xy[2] = {(double)tail[0], (double)tail[1]};
+        double pose[2] = {(double)tail[2], (double)tail[3]};
+        double vel[2] = {(double)tail[4], (double)tail[5]};
+        double goal[2] = {(double)goals[2 * row], (double)goals[2 * row + 1]};
+        nv::RewardOut r = nv::reward_scalar(c, prev_xy, pose, vel, goal, crash != 0, disc != 0, rmin);
+        if (reward) reward[row] = r.reward;
+        if (done) done[row] = (uint8_t)r.done;
+        if (is_success) is_success[row] = r.success;
+        if (is_crash) is_crash[row] = r.crash;
+        if (distance) distance[row] = r.distance;
+    }
+}
+
+// ============================================================================================
+// a14: _make_scan_threshold (env.py:162-180)
+// ============================================================================================
+__global__ __launch_bounds__(256) void scan_threshold_kernel(navsim_config c, const float* __restrict__ fp,
+                                                             int nvert, float* __restrict__ out) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= c.n_beams) return;
+    double step = nv::linspace_step(c);
+    double ang = nv::linspace_k(c, k, step) + (double)0.0f;
+    float dx, dy;
+    nv::beam_dir((float)ang, dx, dy);
+    float rmax = (float)c.range_max;
+    float r = rmax;
+    for (int v = 0; v < nvert; ++v) {
+        int w = (v + 1 == nvert) ? 0 : v + 1;
+        nv::seg_merge(r, 0.0f, 0.0f, dx, dy, fp[2 * v], fp[2 * v + 1], fp[2 * w], fp[2 * w + 1]);
+    }
+    r = r < 0.0f ? 0.0f : r;
+    r = r > rmax ? rmax : r;
+    out[k] = r;
+}
+
+// ============================================================================================
+// a1: the fused step.  One workgroup = one arena.
+// ============================================================================================
+struct StepShared {
+    double rp[3];                 // robot pose being scanned
+    double old_rp[3];             // robot pose at the start of the step (social force input)
+    double act[2];                // action after the turning-radius clamp
+    float lx, ly, lth;            // float32 lidar pose (env.py:386)
+    int i0, j0;                   // integer ray origin (env.py:419)
+    int nseg, ndisc;
+    int rescan;
+    int respawn;
+    float seg[4 * NAVSIM_MAX_PEDS][4];
+    float disc[2 * NAVSIM_MAX_PEDS][2];
+    double ax[NAVSIM_MAX_PEDS + 1], ay[NAVSIM_MAX_PEDS + 1];
+    double avx[NAVSIM_MAX_PEDS + 1], avy[NAVSIM_MAX_PEDS + 1];
+    double wave_ratio[kMaxWaves];
+};
+
+// robot scan (env.py:385-441 with other_agents = all pedestrians).  Writes the latest-scan slot
+// of the observation row and every "not yet filled" stack slot (env.py:262-265).
+template <int BLOCK>
+__device__ __forceinline__ void scan_beams(const navsim_config& c, const StepShared& sh,
+                                           const float* __restrict__ field,
+                                           const float* __restrict__ thr, const float* __restrict__ dthr,
+                                           float* __restrict__ obs_row, int n_hist, float noise_std,
+                                           uint64_t noise_key, uint64_t genv,
+                                           int& crash, int& discomfort) {
+    const int B = c.n_beams, S = c.n_scan_stack, H = c.map_h, W = c.map_w;
+    const float max_range = (float)((long long)H * W);       // env.py:337
+    const float res = (float)c.resolution;
+    const float rmax = (float)c.range_max;
+    const double step = nv::linspace_step(c);
+    const float x0 = (float)sh.i0, y0 = (float)sh.j0;
+    const float lx = sh.lx, ly = sh.ly;
+    const double lth = (double)sh.lth;
+    const int nseg = sh.nseg, ndisc = sh.ndisc;
+    int cr = 0, dc = 0;
+    for (int k = threadIdx.x; k < B; k += BLOCK) {
+        double ang = nv::linspace_k(c, k, step) + lth;        // env.py:388-390
+        float heading = (float)ang;                           // env.py:424
+        float dx, dy;
+        nv::beam_dir(heading, dx, dy);
+        float r = nv::trace_ray(field, H, W, x0, y0, dx, dy, max_range);   // env.py:425
+        r = r * res;                                          // env.py:426
+        for (int q = 0; q < nseg; ++q)
+            nv::seg_merge(r, lx, ly, dx, dy, sh.seg[q][0], sh.seg[q][1], sh.seg[q][2], sh.seg[q][3]);
+        for (int q = 0; q < ndisc; ++q)
+            nv::circle_merge(r, lx, ly, dx, dy, sh.disc[q][0], sh.disc[q][1], nv::kLegRadius);
+        r = r < 0.0f ? 0.0f : r;                              // env.py:435
+        r = r > rmax ? rmax : r;
+        if (noise_std > 0.0f && r != rmax)                    // env.py:437-440
+            r = r + noise_std * nv::gauss_noise(c.seed ^ noise_key, genv, noise_key, (uint32_t)k);
+        cr |= (r < thr[k]);
+        dc |= (r < dthr[k]);
+        obs_row[(size_t)(S - 1) * B + k] = r;
+        for (int j = 0; j < S - 1; ++j)
+            if (S - 1 - j > n_hist) obs_row[(size_t)j * B + k] = r;
+    }
+    crash = cr;
+    discomfort = dc;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void navsim_step_kernel(navsim_config c, navsim_state st,
+                                                            navsim_step_io io, int reset_only,
+                                                            const uint8_t* __restrict__ reset_mask) {
+    __shared__ StepShared sh;
+    const int e = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int B = c.n_beams, S = c.n_scan_stack, N = c.max_peds, D = S * B + 7;
+    const int P = NAVSIM_MAX_WAYPOINTS;
+    const double dt = c.time_step;
+    const uint64_t genv = (uint64_t)(c.env_index_base + e);
+    const float* field = st.field + (size_t)e * c.map_h * c.map_w;
+    float* obs_row = io.obs + (size_t)e * D;
+    const float* obs_prev = io.obs_prev ? io.obs_prev + (size_t)e * D : nullptr;
+    double* rp_g = st.robot_pose + 3 * (size_t)e;
+    double* goal_g = st.robot_goal + 2 * (size_t)e;
+    double* pa_g = st.prev_action + 2 * (size_t)e;
+    double* pv_g = st.prev_pose + 3 * (size_t)e;
+
+    if (reset_only && reset_mask && !reset_mask[e]) {          // untouched env: carry the row over
+        if (obs_prev)
+            for (int k = tid; k < D; k += BLOCK) obs_row[k] = obs_prev[k];
+        return;
+    }
+
+    int n = (c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
+    n = n > N ? N : n;
+    const float noise_std = (c.add_scan_noise && st.scan_noise_std) ? st.scan_noise_std[e] : 0.0f;
+
+    // ---------------------------------------------------------------- phase 0: scalars
+    if (tid == 0) {
+        sh.old_rp[0] = rp_g[0]; sh.old_rp[1] = rp_g[1]; sh.old_rp[2] = rp_g[2];
+        sh.nseg = 0; sh.ndisc = 0; sh.rescan = 0; sh.respawn = 0;
+        if (!reset_only) {
+            double a0 = io.action[2 * e], a1 = io.action[2 * e + 1];
+            st.steps[e] += 1;                                  // env.py:592
+            if (c.min_turning_radius > 0.0) {                  // env.py:595-600
+                double lim = fabs(a1) * c.min_turning_radius;
+                if (a0 >= 0.0) a0 = (a0 > lim) ? a0 : lim;
+                else           a0 = (a0 < -lim) ? a0 : -lim;
+            }
+            sh.act[0] = a0; sh.act[1] = a1;
+        }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- phase 1: pedestrians
+    double pp[3] = {0.0, 0.0, 0.0};
+    double pvel[2] = {0.0, 0.0};
+    const size_t pq = (size_t)e * N + (tid < n ? tid : 0);
+    const bool is_ped = tid < n;
+    if (is_ped) {
+        pp[0] = st.ped_pose[pq * 3]; pp[1] = st.ped_pose[pq * 3 + 1]; pp[2] = st.ped_pose[pq * 3 + 2];
+        pvel[0] = st.ped_vel[pq * 2]; pvel[1] = st.ped_vel[pq * 2 + 1];
+    }
+    if (!reset_only) {
+        double* wp = st.ped_waypoints ? st.ped_waypoints + (pq * P) * 2 : nullptr;
+        int nw = 1;
+        if (is_ped) {
+            nw = st.ped_n_waypoints[pq];
+            while (nw > 1) {                                   // env.py:633-642
+                double ddx = pp[0] - wp[0], ddy = pp[1] - wp[1];
+                if (sqrt(ddx * ddx + ddy * ddy) < 1.0) {
+                    for (int k = 0; k + 1 < nw; ++k) { wp[2 * k] = wp[2 * k + 2]; wp[2 * k + 1] = wp[2 * k + 3]; }
+                    nw -= 1;
+                } else break;
+            }
+        }
+        if (c.ped_model == NAVSIM_PED_SFM) {
+            // stage every agent's position / velocity at time t (pedestrians, then the robot)
+            if (is_ped) { sh.ax[tid] = pp[0]; sh.ay[tid] = pp[1]; sh.avx[tid] = pvel[0]; sh.avy[tid] = pvel[1]; }
+            if (tid == 0) {
+                double s, cs;
+                nv::sincos(sh.old_rp[2], s, cs);
+                sh.ax[n] = sh.old_rp[0]; sh.ay[n] = sh.old_rp[1];
+                sh.avx[n] = pa_g[0] * cs; sh.avy[n] = pa_g[0] * s;
+            }
+            __syncthreads();
+            if (is_ped) {
+                const int i = tid;
+                double vpref = st.ped_v_pref[pq];
+                double ex = wp[0] - sh.ax[i], ey = wp[1] - sh.ay[i];
+                double L = sqrt(ex * ex + ey * ey);
+                if (L > 1e-9) { ex = ex / L; ey = ey / L; } else { ex = 0.0; ey = 0.0; }
+                double fdx = (vpref * ex - sh.avx[i]) / c.sfm_tau;
+                double fdy = (vpref * ey - sh.avy[i]) / c.sfm_tau;
+                double fsx = 0.0, fsy = 0.0;
+                for (int j = 0; j <= n; ++j) {
+                    if (j == i) continue;
+                    double dxx = sh.ax[j] - sh.ax[i], dyy = sh.ay[j] - sh.ay[i];
+                    double dist = sqrt(dxx * dxx + dyy * dyy);
+                    if (dist < 1e-9) continue;
+                    double ddx = dxx / dist, ddy = dyy / dist;
+                    double ivx = c.sfm_lambda * (sh.avx[i] - sh.avx[j]) + ddx;
+                    double ivy = c.sfm_lambda * (sh.avy[i] - sh.avy[j]) + ddy;
+                    double il = sqrt(ivx * ivx + ivy * ivy);
+                    if (il < 1e-9) continue;
+                    double idx = ivx / il, idy = ivy / il;
+                    double theta = nv::atan2_(idx * ddy - idy * ddx, idx * ddx + idy * ddy);
+                    double Bq = c.sfm_gamma * il;
+                    double a1 = c.sfm_n_prime * Bq * theta;
+                    double a2 = c.sfm_n * Bq * theta;
+                    double fv = -nv::exp_neg(-dist / Bq - a1 * a1);
+                    double sgn = (theta > 0.0) ? 1.0 : ((theta < 0.0) ? -1.0 : 0.0);
+                    double fa = -sgn * nv::exp_neg(-dist / Bq - a2 * a2);
+                    fsx += fv * idx + fa * (-idy);
+                    fsy += fv * idy + fa * idx;
+                }
+                double fox = 0.0, foy = 0.0;
+                {
+                    const int H = c.map_h, W = c.map_w;
+                    int ci, cj;
+                    nv::xy_to_ij(sh.ax[i], sh.ay[i], c, ci, cj);
+                    ci = ci > W - 1 ? W - 1 : ci;
+                    cj = cj > H - 1 ? H - 1 : cj;
+                    int il_ = ci > 0 ? ci - 1 : 0, ir = ci < W - 1 ? ci + 1 : W - 1;
+                    int jl = cj > 0 ? cj - 1 : 0, jr = cj < H - 1 ? cj + 1 : H - 1;
+                    double d = (double)field[(size_t)cj * W + ci] * c.resolution;
+                    double gx = (double)field[(size_t)cj * W + ir] - (double)field[(size_t)cj * W + il_];
+                    double gy = (double)field[(size_t)jr * W + ci] - (double)field[(size_t)jl * W + ci];
+                    double gl = sqrt(gx * gx + gy * gy);
+                    if (gl > 0.0) {
+                        double mag = nv::exp_neg(-(d - c.sfm_agent_radius) / c.sfm_sigma_obstacle);
+                        fox = mag * (gx / gl);
+                        foy = mag * (gy / gl);
+                    }
+                }
+                double accx = c.sfm_k_desired * fdx + c.sfm_k_social * fsx + c.sfm_k_obstacle * fox;
+                double accy = c.sfm_k_desired * fdy + c.sfm_k_social * fsy + c.sfm_k_obstacle * foy;
+                double vx = sh.avx[i] + accx * dt;
+                double vy = sh.avy[i] + accy * dt;
+                double sp = sqrt(vx * vx + vy * vy);
+                if (sp > vpref) {
+                    double k = (sp > 0.0) ? vpref / sp : 0.0;
+                    vx = vx * k; vy = vy * k;
+                }
+                pp[0] = pp[0] + vx * dt;
+                pp[1] = pp[1] + vy * dt;
+                double sp2 = sqrt(vx * vx + vy * vy);
+                if (sp2 > 1e-6) pp[2] = nv::mod_2pi(nv::atan2_(vy, vx));
+                pvel[0] = vx; pvel[1] = vy;
+            }
+        } else if (c.ped_model == NAVSIM_PED_EXTERNAL && is_ped) {
+            const double* cmd = st.ped_cmd + pq * 2;
+            nv::set_vel(pp, cmd[0], cmd[1], dt, 0.0, pvel);     // env.py:662
+        }
+        // ---- robot (env.py:664)
+        if (tid == 0) {
+            double p[3] = {sh.old_rp[0], sh.old_rp[1], sh.old_rp[2]};
+            nv::set_vel(p, sh.act[0], sh.act[1], dt, c.axle_offset, nullptr);
+            sh.rp[0] = p[0]; sh.rp[1] = p[1]; sh.rp[2] = p[2];
+        }
+        if (is_ped) {
+            // ---- new goal at the final waypoint (env.py:667-680; A* replaced by a table draw)
+            double ddx = pp[0] - wp[2 * (nw - 1)], ddy = pp[1] - wp[2 * (nw - 1) + 1];
+            if (sqrt(ddx * ddx + ddy * ddy) < 0.5 && c.n_spawn > 0 && st.spawn_pose) {
+                uint64_t h = nv::hash4(c.seed, genv, (uint64_t)tid + 1000, (uint64_t)st.steps[e]);
+                for (int tries = 0; tries < c.n_spawn; ++tries) {
+                    int idx = (int)((h + (uint64_t)tries) % (uint64_t)c.n_spawn);
+                    const double* cand = st.spawn_pose + ((size_t)e * c.n_spawn + idx) * 3;
+                    double gx = cand[0] - pp[0], gy = cand[1] - pp[1];
+                    if (sqrt(gx * gx + gy * gy) > 10.0) {
+                        wp[0] = cand[0]; wp[1] = cand[1]; nw = 1;
+                        break;
+                    }
+                }
+            }
+            st.ped_n_waypoints[pq] = nw;
+            // ---- leg odometry, then the pedestrian's obs yaw (env.py:683-693)
+            double dist[3] = {st.ped_dist[pq * 3], st.ped_dist[pq * 3 + 1], st.ped_dist[pq * 3 + 2]};
+            nv::leg_odometry(pp, pvel, st.ped_prev_yaw[pq], dt, dist);
+            st.ped_dist[pq * 3] = dist[0]; st.ped_dist[pq * 3 + 1] = dist[1]; st.ped_dist[pq * 3 + 2] = dist[2];
+            st.ped_prev_yaw[pq] = nv::wrap_pi(pp[2]);
+            st.ped_pose[pq * 3] = pp[0]; st.ped_pose[pq * 3 + 1] = pp[1]; st.ped_pose[pq * 3 + 2] = pp[2];
+            st.ped_vel[pq * 2] = pvel[0]; st.ped_vel[pq * 2 + 1] = pvel[1];
+        }
+    } else {
+        if (tid == 0) { sh.rp[0] = sh.old_rp[0]; sh.rp[1] = sh.old_rp[1]; sh.rp[2] = sh.old_rp[2]; }
+        if (is_ped) {                                           // env.py:809, 812-820
+            st.ped_dist[pq * 3] = 0.0; st.ped_dist[pq * 3 + 1] = 0.0; st.ped_dist[pq * 3 + 2] = 0.0;
+            st.ped_prev_yaw[pq] = nv::wrap_pi(pp[2]);
+        }
+    }
+
+    // ---------------------------------------------------------------- phase 2: what the lidar sees
+    if (is_ped) {                                               // env.py:392-414
+        float dist3[3];
+        if (reset_only) { dist3[0] = dist3[1] = dist3[2] = 0.0f; }
+        else { dist3[0] = (float)st.ped_dist[pq * 3]; dist3[1] = (float)st.ped_dist[pq * 3 + 1];
+               dist3[2] = (float)st.ped_dist[pq * 3 + 2]; }
+        if (st.ped_has_legs[pq] && c.lidar_legs) {
+            float cc[4];
+            nv::leg_centres((float)pp[0], (float)pp[1], (float)pp[2], dist3[0], dist3[1], dist3[2], cc);
+            int q = atomicAdd(&sh.ndisc, 2);
+            sh.disc[q][0] = cc[0]; sh.disc[q][1] = cc[1];
+            sh.disc[q + 1][0] = cc[2]; sh.disc[q + 1][1] = cc[3];
+        } else {
+            const double fpx[4] = {0.22, -0.22, -0.22, 0.22};   // human.py:5-10
+            const double fpy[4] = {0.19, 0.19, -0.19, -0.19};
+            double s, cs;
+            nv::sincos(pp[2], s, cs);
+            float vx[4], vy[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                vx[v] = (float)((cs * fpx[v] - s * fpy[v]) + pp[0]);
+                vy[v] = (float)((s * fpx[v] + cs * fpy[v]) + pp[1]);
+            }
+            int q = atomicAdd(&sh.nseg, 4);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                int w = (v + 1) & 3;
+                sh.seg[q + v][0] = vx[v]; sh.seg[q + v][1] = vy[v];
+                sh.seg[q + v][2] = vx[w]; sh.seg[q + v][3] = vy[w];
+            }
+        }
+    }
+    if (tid == 0) {
+        sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];   // env.py:386
+        nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);                              // env.py:419
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- phase 3: scan A
+    int n_hist = reset_only ? 0 : st.n_hist[e];
+    int crash = 0, discomfort = 0;
+    const uint64_t step_key = (uint64_t)st.episode[e] * 0x100000000ULL + (uint64_t)(reset_only ? 0 : st.steps[e]) * 2;
+    scan_beams<BLOCK>(c, sh, field, st.scan_threshold, st.scan_discomfort, obs_row, n_hist, noise_std,
+                      step_key, genv, crash, discomfort);
+
+    if (!reset_only) {
+        crash = __syncthreads_or(crash);
+        discomfort = __syncthreads_or(discomfort);
+        double rmin = 1.0e300;
+        if (discomfort && !crash) {                             // env.py:563-569
+            for (int k = tid; k < B; k += BLOCK)
+            {
+                double ratio = nv::discomfort_ratio((double)obs_row[(size_t)(S - 1) * B + k],
+                                                    st.scan_threshold[k], st.scan_discomfort[k]);
+                rmin = ratio < rmin ? ratio : rmin;
+            }
+            rmin = wave_min_f64(rmin);
+            if ((tid & 63) == 0) sh.wave_ratio[tid >> 6] = rmin;
+            __syncthreads();
+        }
+        // ------------------------------------------------------------ phase 4: reward / done / info
+        if (tid == 0) {
+            if (discomfort && !crash)
+                for (int w = 1; w < BLOCK / 64; ++w) rmin = sh.wave_ratio[w] < rmin ? sh.wave_ratio[w] : rmin;
+            double prev_xy[2] = {pv_g[0], pv_g[1]};
+            double pose[2] = {sh.rp[0], sh.rp[1]};
+            double vel[2] = {pa_g[0], pa_g[1]};                 // env.py:453: the PREVIOUS action
+            double goal[2] = {goal_g[0], goal_g[1]};
+            nv::RewardOut o = nv::reward_scalar(c, prev_xy, pose, vel, goal, crash != 0, discomfort != 0, rmin);
+            io.reward[e] = o.reward;
+            io.done[e] = (uint8_t)o.done;
+            io.is_success[e] = o.success;
+            io.is_crash[e] = o.crash;
+            io.distance[e] = o.distance;
+            if (o.done && c.auto_reset && c.n_spawn > 0) {      // build-defined respawn
+                uint64_t h = nv::hash4(c.seed, genv, (uint64_t)st.episode[e], 0x5eedULL);
+                int idx = (int)(h % (uint64_t)c.n_spawn);
+                const double* sp = st.spawn_pose + ((size_t)e * c.n_spawn + idx) * 3;
+                const double* sg = st.spawn_goal + ((size_t)e * c.n_spawn + idx) * 2;
+                sh.rp[0] = sp[0]; sh.rp[1] = sp[1]; sh.rp[2] = sp[2];
+                goal_g[0] = sg[0]; goal_g[1] = sg[1];
+                st.episode[e] += 1;
+                st.steps[e] = 0;
+                sh.respawn = 1; sh.rescan = 1;
+            } else if (o.crash != 0.0f) {                       // env.py:707-717
+                sh.rp[0] = pv_g[0]; sh.rp[1] = pv_g[1]; sh.rp[2] = pv_g[2];
+                sh.rescan = 1;
+            }
+            if (sh.rescan) {
+                sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];
+                nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);
+            }
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ phase 5: scan B (env.py:718-723)
+        if (sh.rescan) {
+            if (sh.respawn) n_hist = 0;
+            int c2, d2;
+            scan_beams<BLOCK>(c, sh, field, st.scan_threshold, st.scan_discomfort, obs_row, n_hist,
+                              noise_std, step_key + 1, genv, c2, d2);
+        }
+    }
+
+    // ---------------------------------------------------------------- phase 6: pack the observation
+    const bool fresh = reset_only || sh.respawn;                // first obs of an episode
+    if (!fresh && obs_prev) {                                   // env.py:267-274: shift the stack
+        for (int j = 0; j < S - 1; ++j)
+            if (S - 1 - j <= n_hist)
+                for (int k = tid; k < B; k += BLOCK) obs_row[(size_t)j * B + k] = obs_prev[(size_t)(j + 1) * B + k];
+    }
+    if (tid == 0) {
+        float* tail = obs_row + (size_t)S * B;
+        double yaw = nv::wrap_pi(sh.rp[2]);                     // env.py:454
+        double pxy0 = fresh ? sh.rp[0] : pv_g[0];               // env.py:449-452
+        double pxy1 = fresh ? sh.rp[1] : pv_g[1];
+        double v0 = fresh ? 0.0 : pa_g[0], v1 = fresh ? 0.0 : pa_g[1];
+        tail[0] = (float)pxy0; tail[1] = (float)pxy1;
+        tail[2] = (float)sh.rp[0]; tail[3] = (float)sh.rp[1];
+        tail[4] = (float)v0; tail[5] = (float)v1;
+        tail[6] = (float)yaw;
+        if (io.achieved_goal) { io.achieved_goal[2 * e] = (float)sh.rp[0]; io.achieved_goal[2 * e + 1] = (float)sh.rp[1]; }
+        if (io.desired_goal) { io.desired_goal[2 * e] = (float)goal_g[0]; io.desired_goal[2 * e + 1] = (float)goal_g[1]; }
+        // state for the next step (env.py:725-727)
+        rp_g[0] = sh.rp[0]; rp_g[1] = sh.rp[1]; rp_g[2] = sh.rp[2];
+        if (fresh) { pa_g[0] = 0.0; pa_g[1] = 0.0; st.n_hist[e] = (S - 1 < 1) ? S - 1 : 1; }
+        else       { pa_g[0] = sh.act[0]; pa_g[1] = sh.act[1]; st.n_hist[e] = (n_hist + 1 < S - 1) ? n_hist + 1 : S - 1; }
+        if (reset_only) st.steps[e] = 0;
+        pv_g[0] = sh.rp[0]; pv_g[1] = sh.rp[1]; pv_g[2] = yaw;
+    }
+}
+
+// test hook: the deterministic math on device
+__global__ void math_kernel(int fn, const double* x, const double* x2, double* out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s, c;
+    switch (fn) {
+        case 0: nv::sincos(x[i], s, c); out[i] = s; break;
+        case 1: nv::sincos(x[i], s, c); out[i] = c; break;
+        case 2: out[i] = nv::atan2_(x[i], x2 ? x2[i] : 1.0); break;
+        case 3: out[i] = nv::exp_neg(x[i]); break;
+        case 4: out[i] = nv::wrap_pi(x[i]); break;
+        case 5: out[i] = nv::mod_2pi(x[i]); break;
+        default: out[i] = 0.0;
+    }
+}
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? NAVSIM_OK : NAVSIM_E_LAUNCH; }
+
+}  // namespace
+
+// ============================================================================================
+// C ABI
+// ============================================================================================
+extern "C" {
+
+int navsim_abi_version(void) { return NAVSIM_ABI_VERSION; }
+
+const char* navsim_error_string(int code) {
+    switch (code) {
+        case NAVSIM_OK: return "ok";
+        case NAVSIM_E_ARG: return "invalid argument";
+        case NAVSIM_E_LAUNCH: return "kernel launch failed";
+        case NAVSIM_E_UNSUPPORTED: return "configuration outside compiled limits";
+        case NAVSIM_E_NODEVICE: return "no HIP device";
+        default: return "unknown error";
+    }
+}
+
+int navsim_default_config(navsim_config* c) {
+    if (!c) return NAVSIM_E_ARG;
+    memset(c, 0, sizeof(*c));
+    c->n_envs = 1;
+    c->n_beams = 512;                          // keti_robot.py:48
+    c->map_h = 400; c->map_w = 400;            // map_generator.py:133
+    c->max_peds = 16;
+    c->n_scan_stack = 1;                       // __init__.py:11
+    c->ped_model = NAVSIM_PED_NONE;
+    c->lidar_legs = 1;                         // env.py:697
+    c->resolution = 0.05;                      // map_generator.py:139
+    c->time_step = 0.2;                        // __init__.py:8
+    c->angle_min = -3.141592;                  // keti_robot.py:45
+    c->angle_last = 3.141592 - 0.0122718463;   // keti_robot.py:44,46 / env.py:389
+    c->range_max = 25.0;                       // keti_robot.py:47
+    c->axle_offset = 0.14474;                  // keti_robot.py:73
+    c->min_turning_radius = 0.0;               // __init__.py:9
+    c->distance_threshold = 0.5;               // __init__.py:10
+    c->reward_scale = 15.0;                    // __init__.py:19-25
+    c->reward_success_factor = 1.0;
+    c->reward_crash_factor = 1.0;
+    c->reward_progress_factor = 0.001;
+    c->reward_forward_factor = 0.0;
+    c->reward_rotation_factor = 0.005;
+    c->reward_discomfort_factor = 0.01;
+    c->sfm_tau = 0.5;
+    c->sfm_k_desired = 1.0;
+    c->sfm_k_social = 2.1;
+    c->sfm_k_obstacle = 10.0;
+    c->sfm_lambda = 2.0;
+    c->sfm_gamma = 0.35;
+    c->sfm_n = 2.0;
+    c->sfm_n_prime = 3.0;
+    c->sfm_sigma_obstacle = 0.8;
+    c->sfm_agent_radius = 0.35;
+    c->seed = 1234;
+    return NAVSIM_OK;
+}
+
+size_t navsim_sizeof_config(void) { return sizeof(navsim_config); }
+size_t navsim_sizeof_state(void) { return sizeof(navsim_state); }
+size_t navsim_sizeof_step_io(void) { return sizeof(navsim_step_io); }
+
+size_t navsim_build_dt_workspace_bytes(int32_t n_maps, int32_t H, int32_t W) {
+    if (n_maps <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)n_maps * H * W * sizeof(uint16_t);
+}
+
+int navsim_build_dt(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, float* field,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!occ || !field || !workspace || n_maps < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
+    if (H >= kDtInf || W >= kDtInf || (size_t)W * 4 > 64 * 1024) return NAVSIM_E_UNSUPPORTED;
+    size_t per_map = (size_t)H * W * sizeof(uint16_t);
+    size_t chunk = workspace_bytes / per_map;                 // maps per pass through the scratch
+    if (chunk == 0) return NAVSIM_E_ARG;
+    if (chunk > 65535) chunk = 65535;
+    hipStream_t s = (hipStream_t)stream;
+    for (int32_t m0 = 0; m0 < n_maps; m0 += (int32_t)chunk) {
+        int32_t m = (n_maps - m0 < (int32_t)chunk) ? n_maps - m0 : (int32_t)chunk;
+        dt_columns_kernel<<<dim3((W + 255) / 256, m), 256, 0, s>>>(occ + (size_t)m0 * H * W,
+                                                                   (uint16_t*)workspace, H, W);
+        dt_rows_kernel<<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace,
+                                                               field + (size_t)m0 * H * W, H, W);
+    }
+    return launch_status();
+}
+
+int navsim_cast_static(const float* field, int32_t E, int32_t H, int32_t W, const float* q,
+                       int32_t n_per_env, float max_range, float* out, void* stream) {
+    if (!field || E < 0 || n_per_env < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
+    long long total = (long long)E * n_per_env;
+    if (total == 0) return NAVSIM_OK;
+    if (!q || !out) return NAVSIM_E_ARG;
+    cast_static_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        field, H, W, q, n_per_env, total, max_range, out);
+    return launch_status();
+}
+
+int navsim_render_polys(float* ranges, const double* angles, int32_t E, int32_t B, const float* verts,
+                        const int32_t* n_verts, int32_t V, const float* origin, void* stream) {
+    if (!ranges || !angles || !verts || !n_verts || !origin || E < 0 || B < 0 || V < 0) return NAVSIM_E_ARG;
+    if (E == 0 || B == 0) return NAVSIM_OK;
+    render_polys_kernel<<<dim3((B + 255) / 256, E), 256, 0, (hipStream_t)stream>>>(ranges, angles, B, verts,
+                                                                                  n_verts, V, origin);
+    return launch_status();
+}
+
+int navsim_render_legs(float* ranges, const double* angles, int32_t E, int32_t B, const float* agents,
+                       const int32_t* n_agents, int32_t A, const float* origin, void* stream) {
+    if (!ranges || !angles || !agents || !n_agents || !origin || E < 0 || B < 0 || A < 0) return NAVSIM_E_ARG;
+    if (E == 0 || B == 0) return NAVSIM_OK;
+    render_legs_kernel<<<dim3((B + 255) / 256, E), 256, 0, (hipStream_t)stream>>>(ranges, angles, B, agents,
+                                                                                 n_agents, A, origin);
+    return launch_status();
+}
+
+int navsim_integrate(double* pose, const double* cmd, double* vel_out, int32_t n, double dt, double off,
+                     void* stream) {
+    if (!pose || !cmd || n < 0) return NAVSIM_E_ARG;
+    if (n == 0) return NAVSIM_OK;
+    integrate_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(pose, cmd, vel_out, n, dt, off);
+    return launch_status();
+}
+
+int navsim_reward_done(const navsim_config* c, const void* obs, const void* goals, int32_t is64, int32_t n,
+                       const float* thr, const float* dthr, double* reward, uint8_t* done,
+                       float* is_success, float* is_crash, double* distance, void* stream) {
+    if (!c || !obs || !goals || !thr || !dthr || n < 0) return NAVSIM_E_ARG;
+    if (n == 0) return NAVSIM_OK;
+    if (is64)
+        reward_done_kernel<double><<<n, 256, 0, (hipStream_t)stream>>>(
+            *c, (const double*)obs, (const double*)goals, thr, dthr, reward, done, is_success, is_crash, distance);
+    else
+        reward_done_kernel<float><<<n, 256, 0, (hipStream_t)stream>>>(
+            *c, (const float*)obs, (const float*)goals, thr, dthr, reward, done, is_success, is_crash, distance);
+    return launch_status();
+}
+
+int navsim_scan_threshold(const navsim_config* c, const float* fp, int32_t nvert, float* out, void* stream) {
+    if (!c || !fp || !out || nvert < 2 || nvert > 16) return NAVSIM_E_ARG;
+    scan_threshold_kernel<<<(c->n_beams + 255) / 256, 256, 0, (hipStream_t)stream>>>(*c, fp, nvert, out);
+    return launch_status();
+}
+
+static int check_step_args(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
+                           int reset_only) {
+    if (!c || !st || !io) return NAVSIM_E_ARG;
+    if (c->n_envs < 0 || c->n_beams < 1 || c->n_scan_stack < 1 || c->map_h < 1 || c->map_w < 1) return NAVSIM_E_ARG;
+    if (c->max_peds > NAVSIM_MAX_PEDS || c->max_peds > kStepBlock) return NAVSIM_E_UNSUPPORTED;
+    if (!st->field || !st->scan_threshold || !st->scan_discomfort || !st->robot_pose || !st->robot_goal ||
+        !st->prev_action || !st->prev_pose || !st->n_hist || !st->episode || !st->steps || !io->obs)
+        return NAVSIM_E_ARG;
+    if (!reset_only && (!io->action || !io->reward || !io->done || !io->is_success || !io->is_crash ||
+                        !io->distance))
+        return NAVSIM_E_ARG;
+    if (!reset_only && c->n_scan_stack > 1 && !io->obs_prev) return NAVSIM_E_ARG;
+    if (c->ped_model != NAVSIM_PED_NONE) {
+        if (!st->n_peds || !st->ped_pose || !st->ped_vel || !st->ped_prev_yaw || !st->ped_dist ||
+            !st->ped_has_legs || !st->ped_waypoints || !st->ped_n_waypoints)
+            return NAVSIM_E_ARG;
+        if (c->ped_model == NAVSIM_PED_EXTERNAL && !st->ped_cmd && !reset_only) return NAVSIM_E_ARG;
+        if (c->ped_model == NAVSIM_PED_SFM && !st->ped_v_pref) return NAVSIM_E_ARG;
+    }
+    if (c->auto_reset && c->n_spawn > 0 && (!st->spawn_pose || !st->spawn_goal)) return NAVSIM_E_ARG;
+    return NAVSIM_OK;
+}
+
+int navsim_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, void* stream) {
+    int rc = check_step_args(c, st, io, 0);
+    if (rc != NAVSIM_OK) return rc;
+    if (c->n_envs == 0) return NAVSIM_OK;
+    navsim_step_kernel<kStepBlock><<<c->n_envs, kStepBlock, 0, (hipStream_t)stream>>>(*c, *st, *io, 0, nullptr);
+    return launch_status();
+}
+
+int navsim_reset_obs(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
+                     const uint8_t* mask, void* stream) {
+    int rc = check_step_args(c, st, io, 1);
+    if (rc != NAVSIM_OK) return rc;
+    if (c->n_envs == 0) return NAVSIM_OK;
+    navsim_step_kernel<kStepBlock><<<c->n_envs, kStepBlock, 0, (hipStream_t)stream>>>(*c, *st, *io, 1, mask);
+    return launch_status();
+}
+
+const char* navsim_step_kernel_name(void) { return "navsim_step_kernel"; }
+
+// test hook (declared in include/navsim.h under "test hooks")
+int navsim_debug_math(int32_t fn, const double* x, const double* x2, double* out, int32_t n, void* stream) {
+    if (!x || !out || n < 0) return NAVSIM_E_ARG;
+    if (n == 0) return NAVSIM_OK;
+    math_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(fn, x, x2, out, n);
+    return launch_status();
+}
+
+}  // extern "C"

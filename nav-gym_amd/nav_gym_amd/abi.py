@@ -181,4 +181,5 @@ EXPORTS = (
     "navsim_build_dt_workspace_bytes", "navsim_build_dt", "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
     "navsim_scan_threshold", "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
+    "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math",
 )

@@ -1,0 +1,201 @@
+"""Device-resident state of E arenas and the calls into the C ABI (include/navsim.h).
+
+torch is plumbing here: it owns the HBM buffers and the HIP stream; every computation of the hot
+path happens in libnavsim_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .lib import check, load, require_gpu
+
+_TORCH_DTYPE = None
+
+
+def _dtype(name):
+    global _TORCH_DTYPE
+    import torch
+    if _TORCH_DTYPE is None:
+        _TORCH_DTYPE = {"float32": torch.float32, "float64": torch.float64, "int32": torch.int32,
+                        "int64": torch.int64, "uint8": torch.uint8}
+    return _TORCH_DTYPE[name]
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---- thin functional wrappers over the mirror primitives (used by tests and by NavSim) ----------
+def build_dt(occ):
+    """occ: uint8 CUDA tensor [E,H,W] (nonzero = occupied) -> float32 distance field [E,H,W]."""
+    torch = require_gpu()
+    L = load()
+    occ = occ.contiguous()
+    E, H, W = occ.shape
+    field = torch.empty((E, H, W), dtype=torch.float32, device=occ.device)
+    per_map = L.navsim_build_dt_workspace_bytes(1, H, W)
+    chunk = max(1, min(E, (512 << 20) // max(per_map, 1)))       # <= 512 MiB of scratch
+    ws = torch.empty(per_map * chunk, dtype=torch.uint8, device=occ.device)
+    check(L.navsim_build_dt(_ptr(occ), E, H, W, _ptr(field), _ptr(ws), ws.numel(), _stream()), "navsim_build_dt")
+    return field
+
+
+def cast_static(field, queries, max_range):
+    torch = require_gpu()
+    E, H, W = field.shape
+    q = queries.contiguous()
+    out = torch.empty(q.shape[:2], dtype=torch.float32, device=field.device)
+    check(load().navsim_cast_static(_ptr(field), E, H, W, _ptr(q), q.shape[1], float(max_range), _ptr(out),
+                                    _stream()), "navsim_cast_static")
+    return out
+
+
+def render_polys(ranges, angles, verts, n_verts, origin):
+    require_gpu()
+    E, B = ranges.shape
+    check(load().navsim_render_polys(_ptr(ranges), _ptr(angles), E, B, _ptr(verts), _ptr(n_verts),
+                                     verts.shape[1], _ptr(origin), _stream()), "navsim_render_polys")
+    return ranges
+
+
+def render_legs(ranges, angles, agents, n_agents, origin):
+    require_gpu()
+    E, B = ranges.shape
+    check(load().navsim_render_legs(_ptr(ranges), _ptr(angles), E, B, _ptr(agents), _ptr(n_agents),
+                                    agents.shape[1], _ptr(origin), _stream()), "navsim_render_legs")
+    return ranges
+
+
+def integrate(pose, cmd, time_step, axle_offset, vel_out=None):
+    require_gpu()
+    check(load().navsim_integrate(_ptr(pose), _ptr(cmd), _ptr(vel_out), pose.shape[0], float(time_step),
+                                  float(axle_offset), _stream()), "navsim_integrate")
+    return pose
+
+
+def scan_threshold(cfg, footprint):
+    torch = require_gpu()
+    fp = footprint.contiguous()
+    out = torch.empty(cfg.n_beams, dtype=torch.float32, device=fp.device)
+    check(load().navsim_scan_threshold(C.byref(cfg), _ptr(fp), fp.shape[0], _ptr(out), _stream()),
+          "navsim_scan_threshold")
+    return out
+
+
+def reward_done(cfg, obs, goals, thr, dthr):
+    torch = require_gpu()
+    obs = obs.contiguous()
+    is64 = obs.dtype == torch.float64
+    goals = goals.to(obs.dtype).contiguous()
+    n = obs.shape[0]
+    dev = obs.device
+    out = dict(reward=torch.empty(n, dtype=torch.float64, device=dev),
+               done=torch.empty(n, dtype=torch.uint8, device=dev),
+               is_success=torch.empty(n, dtype=torch.float32, device=dev),
+               is_crash=torch.empty(n, dtype=torch.float32, device=dev),
+               distance=torch.empty(n, dtype=torch.float64, device=dev))
+    check(load().navsim_reward_done(C.byref(cfg), _ptr(obs), _ptr(goals), int(is64), n, _ptr(thr), _ptr(dthr),
+                                    _ptr(out["reward"]), _ptr(out["done"]), _ptr(out["is_success"]),
+                                    _ptr(out["is_crash"]), _ptr(out["distance"]), _stream()), "navsim_reward_done")
+    return out
+
+
+def debug_math(fn, x, x2=None):
+    torch = require_gpu()
+    out = torch.empty_like(x)
+    check(load().navsim_debug_math(fn, _ptr(x), _ptr(x2), _ptr(out), x.numel(), _stream()), "navsim_debug_math")
+    return out
+
+
+class NavSim(object):
+    """E arenas resident on one GPU.  `arrays` maps navsim_state field names to numpy arrays or
+    torch tensors (host or device); missing optional fields stay NULL."""
+
+    def __init__(self, cfg, arrays, device="cuda:0"):
+        torch = require_gpu()
+        self.lib = load()
+        self.cfg = cfg.copy()
+        self.device = torch.device(device)
+        self.t = {}
+        self.st = abi.NavsimState()
+        for name, (dtype, shape) in abi.STATE_LAYOUT.items():
+            a = arrays.get(name)
+            if a is None:
+                setattr(self.st, name, None)
+                continue
+            if isinstance(a, np.ndarray):
+                a = torch.from_numpy(np.ascontiguousarray(a))
+            t = a.to(device=self.device, dtype=_dtype(dtype)).contiguous()
+            if t.data_ptr() == a.data_ptr():
+                t = t.clone()
+            want = abi.resolve_shape(shape, self.cfg)
+            if tuple(t.shape) != want:
+                raise ValueError("%s: shape %s, expected %s" % (name, tuple(t.shape), want))
+            self.t[name] = t
+            setattr(self.st, name, t.data_ptr())
+        E = self.cfg.n_envs
+        D = self.cfg.n_scan_stack * self.cfg.n_beams + abi.OBS_TAIL
+        self.obs_buf = [torch.zeros((E, D), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.cur = 0
+        self.out = {k: torch.zeros(abi.resolve_shape(s, self.cfg), dtype=_dtype(d), device=self.device)
+                    for k, (d, s) in abi.IO_LAYOUT.items() if k not in ("obs", "obs_prev", "action")}
+        self.action = torch.zeros((E, 2), dtype=torch.float64, device=self.device)
+        self.io = abi.NavsimStepIO()
+        self.io.action = self.action.data_ptr()
+        for k, v in self.out.items():
+            setattr(self.io, k, v.data_ptr())
+
+    @property
+    def obs(self):
+        return self.obs_buf[self.cur]
+
+    def _flip(self):
+        self.io.obs_prev = self.obs_buf[self.cur].data_ptr()
+        self.io.obs = self.obs_buf[1 - self.cur].data_ptr()
+
+    def reset_obs(self, mask=None):
+        """First observation of an episode (reference reset(), env.py:808-831) for masked envs."""
+        self._flip()
+        m = None
+        if mask is not None:
+            import torch
+            m = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
+        check(self.lib.navsim_reset_obs(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), _ptr(m), _stream()),
+              "navsim_reset_obs")
+        self.cur = 1 - self.cur
+        return self.obs
+
+    def step(self, action=None):
+        """One fused launch: NavGymEnv.step for all E arenas.  `action` [E,2] (v, omega)."""
+        if action is not None:
+            self.action.copy_(self._as(action, self.action))
+        self._flip()
+        check(self.lib.navsim_step(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), _stream()), "navsim_step")
+        self.cur = 1 - self.cur
+        return self.obs, self.out
+
+    def launch_step(self):
+        """step() without the action copy: inputs already resident (bench inner loop)."""
+        self._flip()
+        rc = self.lib.navsim_step(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), _stream())
+        if rc:
+            check(rc, "navsim_step")
+        self.cur = 1 - self.cur
+
+    def set_ped_cmd(self, cmd):
+        self.t["ped_cmd"].copy_(self._as(cmd, self.t["ped_cmd"]))
+
+    def _as(self, a, like):
+        import torch
+        if not isinstance(a, torch.Tensor):          # numpy >= 2 arrays also carry a `.device`
+            a = torch.as_tensor(np.asarray(a))
+        return a.to(device=self.device, dtype=like.dtype).reshape(like.shape)
+
+    def numpy_state(self, *names):
+        return {n: self.t[n].detach().cpu().numpy() for n in (names or self.t.keys())}

@@ -1,0 +1,202 @@
+"""Reset-path world generation (host + torch plumbing; NOT the hot path).
+
+Restates what NavGymEnv.reset() needs before the first step (env.py:730-831) for E arenas at once:
+occupancy maps, the distance field (navsim_build_dt on the GPU), start / goal tables and
+pedestrians.  A* path planning (pyastar2d, env.py:342-383) is out of scope for this round
+(SURVEY.md 8f #1): goals are accepted on straight-line distance only.
+
+Everything is keyed by the GLOBAL env index (seed + env_index_base + e), so a sharded run over
+G GPUs builds bit-identical arenas to a single-GPU run.
+"""
+import numpy as np
+
+from . import abi
+
+
+def outdoor_map(rng, size, n_obstacles=10, width_range=(0.3, 1.0)):
+    """create_outdoor_map (map_generator.py:126-143) scaled to size x size cells: 5-cell border
+    wall and `n_obstacles` squares of half-width int(10*U[width_range]) cells; uint8 {0,1}."""
+    m = np.ones((size, size), np.uint8)
+    m[5:size - 5, 5:size - 5] = 0
+    hw = int(10 * rng.uniform(*width_range))
+    for _ in range(n_obstacles):
+        cx = rng.integers(hw + 2, size - hw - 1)
+        cy = rng.integers(hw + 2, size - hw - 1)
+        m[cx - hw:cx + hw + 1, cy - hw:cy + hw + 1] = 1
+    return np.flipud(m)
+
+
+def indoor_map(rng, size, corridor_width=3, iterations=100):
+    """create_indoor_map (map_generator.py:97-123): a random tree of corridors carved on a
+    100x100 grid (L1-nearest node, L-shaped paths), nearest-neighbour upscaled to `size`."""
+    g = np.ones((100, 100), np.uint8)
+    tree = [(50, 50)]
+    g[50, 50] = 0
+    r = int(corridor_width)
+    for _ in range(int(iterations)):
+        p = (int(rng.integers(r + 2, 100 - r - 1)), int(rng.integers(r + 2, 100 - r - 1)))
+        d = [abs(p[0] - q[0]) + abs(p[1] - q[1]) for q in tree]
+        q = tree[int(np.argmin(d))]
+        tree.append(p)
+        x1, x2 = sorted((p[0], q[0]))
+        y1, y2 = sorted((p[1], q[1]))
+        if rng.random() >= 0.5:
+            g[x1 - r:x1 + r + 1, y1 - r:y2 + r + 1] = 0
+            corner_y = y1 if ((p[0] > q[0]) != (p[1] < q[1])) else y2
+            g[x1 - r:x2 + r + 1, corner_y - r:corner_y + r + 1] = 0
+        else:
+            g[x2 - r:x2 + r + 1, y1 - r:y2 + r + 1] = 0
+            corner_y = y2 if ((p[0] > q[0]) != (p[1] < q[1])) else y1
+            g[x1 - r:x2 + r + 1, corner_y - r:corner_y + r + 1] = 0
+    idx = np.minimum((np.arange(size) * (100.0 / size)).astype(int), 99)
+    return np.flipud(g[np.ix_(idx, idx)])
+
+
+def make_maps(n_envs, size, seed, env_index_base=0, indoor_ratio=0.0):
+    """uint8 [E, size, size], nonzero = occupied (map_info['data'] >= 0.1, env.py:339)."""
+    occ = np.empty((n_envs, size, size), np.uint8)
+    for e in range(n_envs):
+        rng = np.random.default_rng(seed + env_index_base + e)
+        if rng.random() < indoor_ratio:
+            occ[e] = indoor_map(rng, size, rng.integers(3, 5), rng.integers(80, 151))
+        else:
+            occ[e] = outdoor_map(rng, size)
+    return occ
+
+
+# ---- counter-based uniforms in torch (shard-invariant) -------------------------------------------
+def _s64(c):
+    return c - (1 << 64) if c >= (1 << 63) else c
+
+
+def _mix64(z):
+    """splitmix64 finaliser on int64 tensors (wrapping multiply, logical shifts via masks)."""
+    m34, m37, m33 = (1 << 34) - 1, (1 << 37) - 1, (1 << 33) - 1
+    z = z + _s64(0x9E3779B97F4A7C15)
+    z = (z ^ ((z >> 30) & m34)) * _s64(0xBF58476D1CE4E5B9)
+    z = (z ^ ((z >> 27) & m37)) * _s64(0x94D049BB133111EB)
+    return z ^ ((z >> 31) & m33)
+
+
+def _uniform(seed, genv, stream, shape_tail, device):
+    """float64 uniforms in [0,1) of shape [E, *shape_tail], keyed by (seed, global env, stream, index)."""
+    import torch
+    n = int(np.prod(shape_tail)) if len(shape_tail) else 1
+    idx = torch.arange(n, dtype=torch.int64, device=device)[None, :]
+    key = _mix64(genv.to(torch.int64)[:, None] * 1000003 + seed * 7919 + stream)
+    h = _mix64(key ^ _mix64(idx))
+    u = ((h >> 11) & ((1 << 53) - 1)).to(torch.float64) / float(1 << 53)
+    return u.reshape((genv.shape[0],) + tuple(shape_tail))
+
+
+def sample_free_cells(field, clearance_cells, k, seed, genv, stream, chunk=128):
+    """k cells per env with field >= clearance, uniformly (hash scores + top-k).  -> int64 [E,k] (j*W+i)."""
+    import torch
+    E, H, W = field.shape
+    out = torch.empty((E, k), dtype=torch.int64, device=field.device)
+    for e0 in range(0, E, chunk):
+        f = field[e0:e0 + chunk].reshape(-1, H * W)
+        u = _uniform(seed, genv[e0:e0 + chunk], stream, (H * W,), field.device).to(torch.float32)
+        u = torch.where(f >= clearance_cells, u, torch.full_like(u, -1.0))
+        out[e0:e0 + chunk] = torch.topk(u, k, dim=1).indices
+    return out
+
+
+def cells_to_xy(cells, W, resolution, origin):
+    """ij_to_xy (env.py:1214-1220): cell centres."""
+    import torch
+    i = (cells % W).to(torch.float64)
+    j = (cells // W).to(torch.float64)
+    return torch.stack([(i + 0.5) * resolution + origin[0], (j + 0.5) * resolution + origin[1]], dim=-1)
+
+
+def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=20.0,
+               robot_clearance=1.2, ped_clearance=0.5, noise_std_range=(0.0, 0.0),
+               has_legs_ratio=0.5, v_pref_range=(0.0, 0.6), device="cuda:0", field=None):
+    """Builds every navsim_state array for cfg.n_envs arenas on `device`.
+
+    occ: uint8 numpy/torch [E,H,W].  Returns dict name -> torch tensor (see abi.STATE_LAYOUT)."""
+    import torch
+    from . import sim
+    seed = int(cfg.seed if seed is None else seed)
+    dev = torch.device(device)
+    E, N, K = cfg.n_envs, cfg.max_peds, max(cfg.n_spawn, 1)
+    res, org = cfg.resolution, (cfg.origin_x, cfg.origin_y)
+    occ_t = torch.as_tensor(occ).to(dev)
+    if field is None:
+        field = sim.build_dt(occ_t)
+    H, W = field.shape[1:]
+    genv = torch.arange(E, device=dev, dtype=torch.int64) + int(cfg.env_index_base)
+    a = {"field": field}
+    # ---- robot start / goal tables (env.py:748-783 without A*) -------------------------------------
+    KK = max(2 * K, 8)
+    cells = sample_free_cells(field, robot_clearance / res, KK, seed, genv, 11)
+    xy = cells_to_xy(cells, W, res, org)                                   # [E,KK,2]
+    theta = _uniform(seed, genv, 12, (KK,), dev) * (2 * np.pi)
+    d = torch.cdist(xy, xy)                                                # [E,KK,KK]
+    ok = (d > min_goal_dist) & (d < max_goal_dist)
+    # first acceptable partner in cyclic order, else the farthest candidate
+    order = (torch.arange(KK, device=dev)[None, :] + torch.arange(KK, device=dev)[:, None] + 1) % KK   # [KK,KK]
+    ok_c = torch.gather(ok, 2, order[None].expand(E, KK, KK))
+    first = torch.argmax(ok_c.to(torch.int8), dim=2)
+    partner = torch.gather(order[None].expand(E, KK, KK), 2, first[..., None])[..., 0]
+    far = torch.argmax(d, dim=2)
+    partner = torch.where(ok_c.any(dim=2), partner, far)
+    goal = torch.gather(xy, 1, partner[..., None].expand(E, KK, 2))
+    a["spawn_pose"] = torch.cat([xy[:, :K], theta[:, :K, None]], dim=2).contiguous()
+    a["spawn_goal"] = goal[:, :K].contiguous()
+    a["robot_pose"] = a["spawn_pose"][:, 0].clone()
+    a["robot_goal"] = a["spawn_goal"][:, 0].clone()
+    a["prev_action"] = torch.zeros((E, 2), dtype=torch.float64, device=dev)
+    a["prev_pose"] = torch.zeros((E, 3), dtype=torch.float64, device=dev)
+    a["n_hist"] = torch.zeros(E, dtype=torch.int32, device=dev)
+    a["episode"] = torch.zeros(E, dtype=torch.int64, device=dev)
+    a["steps"] = torch.zeros(E, dtype=torch.int64, device=dev)
+    lo, hi = noise_std_range
+    a["scan_noise_std"] = (lo + (hi - lo) * _uniform(seed, genv, 13, (), dev)).to(torch.float32).reshape(E)
+    # ---- pedestrians (env.py:786-806 without A*) -----------------------------------------------------
+    if cfg.ped_model != abi.PED_NONE:
+        n_peds_t = torch.as_tensor(n_peds, device=dev).to(torch.int32).expand(E).contiguous() \
+            if not hasattr(n_peds, "shape") or len(getattr(n_peds, "shape", ())) == 0 \
+            else torch.as_tensor(n_peds).to(device=dev, dtype=torch.int32)
+        M = 4 * N
+        pc = sample_free_cells(field, ped_clearance / res, M, seed, genv, 21)
+        pxy = cells_to_xy(pc, W, res, org)                                  # [E,M,2]
+        far_enough = (pxy - a["robot_pose"][:, None, :2]).norm(dim=2) >= 4.0   # env.py:372
+        rank = torch.argsort((~far_enough).to(torch.int8), dim=1, stable=True)  # acceptable starts first
+        start = torch.gather(pxy, 1, rank[:, :N, None].expand(E, N, 2))
+        gd = torch.cdist(start, pxy)                                        # [E,N,M]
+        gok = gd > 10.0                                                     # env.py:788-791
+        gfirst = torch.argmax(gok.to(torch.int8), dim=2)
+        gidx = torch.where(gok.any(dim=2), gfirst, torch.argmax(gd, dim=2))
+        pgoal = torch.gather(pxy, 1, gidx[..., None].expand(E, N, 2))
+        pth = _uniform(seed, genv, 22, (N,), dev) * (2 * np.pi)
+        a["n_peds"] = n_peds_t
+        a["ped_pose"] = torch.cat([start, pth[..., None]], dim=2).contiguous()
+        a["ped_vel"] = torch.zeros((E, N, 2), dtype=torch.float64, device=dev)
+        a["ped_prev_yaw"] = torch.zeros((E, N), dtype=torch.float64, device=dev)
+        a["ped_dist"] = torch.zeros((E, N, 3), dtype=torch.float64, device=dev)
+        a["ped_v_pref"] = v_pref_range[0] + (v_pref_range[1] - v_pref_range[0]) * _uniform(seed, genv, 23, (N,), dev)
+        a["ped_has_legs"] = (_uniform(seed, genv, 24, (N,), dev) < has_legs_ratio).to(torch.uint8)
+        wp = torch.zeros((E, N, abi.MAX_WAYPOINTS, 2), dtype=torch.float64, device=dev)
+        wp[:, :, 0] = pgoal
+        a["ped_waypoints"] = wp
+        a["ped_n_waypoints"] = torch.ones((E, N), dtype=torch.int32, device=dev)
+        a["ped_cmd"] = torch.zeros((E, N, 2), dtype=torch.float64, device=dev)
+    return a
+
+
+def lidar_1081(cfg):
+    """270 deg / 0.25 deg planar lidar of the BASELINE configs: beams at -135 .. +135 deg inclusive."""
+    cfg.n_beams = 1081
+    cfg.angle_min = -0.75 * np.pi
+    cfg.angle_last = 0.75 * np.pi
+    return cfg
+
+
+def lidar_full_circle(cfg, n_beams):
+    """n beams over 2*pi, np.linspace(-pi, pi - 2*pi/n, n) (BASELINE config 1 uses 64)."""
+    cfg.n_beams = n_beams
+    cfg.angle_min = -np.pi
+    cfg.angle_last = np.pi - 2 * np.pi / n_beams
+    return cfg
