@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the fused MI355X NavGym step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1: BASELINE.json configs[1] -- 4096 arenas, 1081-beam lidar, 500x500 static occupancy map,
+diff-drive (KetiRobot kinematics), no pedestrians, auto-respawn of finished arenas in place.
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns its own 4096 arenas
+(weak scaling, arenas keyed by global env index); the step has no exchange, so there is no
+data-path collective (`--gather all` adds the optional RCCL all_gather of observations).
+
+One "step" = one launch of navsim_step over all local arenas, inputs resident in HBM.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "nav-gym_amd"))
+
+WORKLOADS = {
+    # name: (envs per GPU, beams, map size, pedestrians, ped model)
+    "c1": dict(envs=1, beams=64, size=100, peds=0),
+    "c2": dict(envs=4096, beams=1081, size=500, peds=0),
+    "c3": dict(envs=4096, beams=1081, size=500, peds=20),
+    "c4": dict(envs=2048, beams=1081, size=1000, peds=0),      # 16384 arenas over 8 GPUs
+}
+
+
+def algorithmic_bytes_per_env_step(H, W, B, S, n_peds, s_map):
+    """map streamed once + ranges written + packed obs written + scalar state."""
+    return H * W * s_map + 4 * B + 4 * (S * B + 7 + 2 + 2) + 96 + 96 * n_peds
+
+
+def build_sim(wl, rank, world_size, seed=1234, device="cuda:0"):
+    import numpy as np
+    import torch
+    from nav_gym_amd import abi, lib, robots, sim, world
+    E = wl["envs"]
+    cfg = lib.default_config(n_envs=E, map_h=wl["size"], map_w=wl["size"], max_peds=max(wl["peds"], 1),
+                             ped_model=abi.PED_SFM if wl["peds"] else abi.PED_NONE,
+                             n_spawn=16, auto_reset=1, seed=seed, env_index_base=rank * E)
+    if wl["beams"] == 1081:
+        world.lidar_1081(cfg)
+    else:
+        world.lidar_full_circle(cfg, wl["beams"])
+    occ = world.make_maps(E, wl["size"], seed, env_index_base=rank * E)
+    goal = (10.0, 20.0) if wl["size"] >= 400 else (2.0, 4.0)
+    arrays = world.make_world(cfg, occ, n_peds=wl["peds"], device=device, min_goal_dist=goal[0], max_goal_dist=goal[1],
+                              robot_clearance=1.2 if wl["size"] >= 400 else 0.9)
+    dev = torch.device(device)
+    for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
+        arrays[key] = sim.scan_threshold(cfg, torch.from_numpy(robots.footprint_array("keti", name)).to(dev))
+    s = sim.NavSim(cfg, arrays, device=device)
+    s.reset_obs()
+    return cfg, s, arrays, occ
+
+
+def cpu_baseline(wl, seconds=15.0):
+    """The CPU oracle (oracle/, kind "port": a restatement, not the reference binary -- the
+    reference's own step() cannot execute) on a bounded sample of the same
+    workload, all host cores, arenas split statically over threads."""
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from nav_gym_amd import abi, lib, robots, world
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref
+    cores = os.cpu_count() or 1
+    E = min(wl["envs"], 8 * cores)
+    cfg = lib.default_config(n_envs=E, map_h=wl["size"], map_w=wl["size"], max_peds=max(wl["peds"], 1),
+                             ped_model=abi.PED_SFM if wl["peds"] else abi.PED_NONE, n_spawn=16, auto_reset=1, seed=1234)
+    if wl["beams"] == 1081:
+        world.lidar_1081(cfg)
+    else:
+        world.lidar_full_circle(cfg, wl["beams"])
+    occ = world.make_maps(E, wl["size"], 1234)
+    field = torch.from_numpy(ref.build_dt(occ))
+    goal = (10.0, 20.0) if wl["size"] >= 400 else (2.0, 4.0)
+    arrays = world.make_world(cfg, occ, n_peds=wl["peds"], device="cpu", field=field, min_goal_dist=goal[0],
+                              max_goal_dist=goal[1], robot_clearance=1.2 if wl["size"] >= 400 else 0.9)
+    host = {k: v.numpy() for k, v in arrays.items()}
+    host["scan_threshold"] = ref.scan_threshold(cfg, robots.footprint_array("keti", "threshold_footprint"))
+    host["scan_discomfort"] = ref.scan_threshold(cfg, robots.footprint_array("keti", "discomfort_threshold_footprint"))
+    r = ref.RefSim(cfg, host)
+    r.reset_obs()
+    rng = np.random.default_rng(0)
+    pool = ThreadPoolExecutor(cores)
+    nthr = min(cores, E)
+
+    def one():
+        act = np.stack([rng.uniform(0, 0.5, E), rng.uniform(-0.64, 0.64, E)], axis=1)
+        r.step_threads(act, pool, nthr)
+    one()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds and n < 2000:
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    pool.shutdown()
+    return dict(value=E * n / dt, unit="env-steps/s", cores=nthr, kind="port",
+                sample="%d arenas x %d steps of the same workload (oracle/navsim_ref.c, %d threads, %.1f s)"
+                       % (E, n, nthr, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs", type=int, default=0, help="override arenas per GPU")
+    ap.add_argument("--gather", default="none", choices=["none", "all"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
+    device = "cuda:%d" % local_rank
+    torch.cuda.set_device(local_rank)
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.envs:
+        wl["envs"] = args.envs
+    cfg, sim, arrays, _ = build_sim(wl, rank, world_size, device=device)
+    E, K, Wm = cfg.n_envs, args.steps, args.warmup
+
+    # pre-generated in-range actions, resident in HBM; step t reads slice t (no copies in the loop)
+    g = torch.Generator(device=device)
+    g.manual_seed(1000 + rank)
+    acts = torch.rand((K + Wm, E, 2), generator=g, device=device, dtype=torch.float64)
+    acts[..., 0] *= 0.5
+    acts[..., 1] = acts[..., 1] * 1.28 - 0.64
+    gather_buf = None
+    if args.gather == "all" and dist is not None:
+        gather_buf = torch.empty((world_size * E, sim.obs.shape[1]), dtype=torch.float32, device=device)
+
+    def run(t):
+        sim.io.action = acts[t].data_ptr()
+        sim.launch_step()
+        if gather_buf is not None:
+            dist.all_gather_into_tensor(gather_buf, sim.obs)
+
+    for t in range(Wm):
+        run(t)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    t0 = time.perf_counter()
+    for t in range(K):
+        ev[t][0].record()
+        run(Wm + t)
+        ev[t][1].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / K          # HIP events on the launch stream
+
+    if rank == 0:
+        n_done = int(sim.t["episode"].sum().item())
+        A = algorithmic_bytes_per_env_step(cfg.map_h, cfg.map_w, cfg.n_beams, cfg.n_scan_stack, wl["peds"], 4)
+        achieved = A * E / (kernel_ms * 1e-3) / 1e9                # GB/s
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env steps/sec (whole node), 4096 envs x 1081-beam lidar",
+            "value": world_size * E * K / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world_size,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %d arenas/GPU x %d-beam lidar, %dx%d per-arena occupancy maps (float32 distance "
+                            "field), %d pedestrians/arena, KetiRobot diff-drive, auto-respawn in place"
+                            % (args.workload, E, cfg.n_beams, cfg.map_h, cfg.map_w, wl["peds"]),
+                "envs_per_gpu": E, "n_beams": cfg.n_beams, "map": [cfg.map_h, cfg.map_w],
+                "pedestrians": wl["peds"], "obs_gather": args.gather, "episodes_finished_rank0": n_done,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                "traffic": traffic, "kernel": "navsim_step_kernel", "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_env_step": A, "s_map": 4,
+            },
+        }
+        if not args.no_cpu_baseline and world_size == 1:
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 csv output (kernel trace/stats + PMC passes) into a small text summary."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, "**", pattern), recursive=True))
+
+
+print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+for f in find("*kernel_stats.csv"):
+    for i, row in enumerate(csv.DictReader(open(f))):
+        if i < 12:
+            print({k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+step_ns = []
+for f in find("*kernel_trace.csv"):
+    for row in csv.DictReader(open(f)):
+        if "navsim_step_kernel" in row.get("Kernel_Name", ""):
+            step_ns.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            last = row
+if step_ns:
+    # reset_obs uses the same kernel once; steady-state = all but the first launches
+    s = step_ns[1:] if len(step_ns) > 1 else step_ns
+    print("navsim_step_kernel launches=%d avg_us=%.2f min_us=%.2f max_us=%.2f" % (len(s), sum(s) / len(s) / 1e3, min(s) / 1e3, max(s) / 1e3))
+    print("last dispatch:", {k: last[k] for k in last if k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")})
+print("== PMC (per navsim_step_kernel dispatch, mean over steady-state dispatches) ==")
+res = {}
+for f in find("*counter_collection.csv"):
+    acc = defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        if "navsim_step_kernel" in row.get("Kernel_Name", ""):
+            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, v in acc.items():
+        v = v[1:] if len(v) > 1 else v
+        res[k] = sum(v) / len(v)
+for k in sorted(res):
+    print("%-22s %.6g" % (k, res[k]))
+if "FETCH_SIZE" in res or "WRITE_SIZE" in res:
+    f = res.get("FETCH_SIZE", 0.0) * 1024.0
+    w = res.get("WRITE_SIZE", 0.0) * 1024.0
+    print("FETCH bytes/launch as reported %.4g  (x2 if wide streaming: %.4g)   WRITE bytes/launch %.4g" % (f, 2 * f, w))
+    json.dump({"fetch_bytes_reported": f, "write_bytes": w, "counters": res}, open(os.path.join(out, "pmc.json"), "w"), indent=1)
+if "TCC_HIT_sum" in res:
+    print("L2 hit rate %.3f" % (res["TCC_HIT_sum"] / (res["TCC_HIT_sum"] + res["TCC_MISS_sum"])))
