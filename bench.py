@@ -42,7 +42,8 @@ def build_sim(wl, rank, world_size, seed=1234, device="cuda:0"):
     E = wl["envs"]
     cfg = lib.default_config(n_envs=E, map_h=wl["size"], map_w=wl["size"], max_peds=max(wl["peds"], 1),
                              ped_model=abi.PED_SFM if wl["peds"] else abi.PED_NONE,
-                             n_spawn=16, auto_reset=1, seed=seed, env_index_base=rank * E)
+                             n_spawn=16, auto_reset=1, seed=seed, env_index_base=rank * E,
+                             field_format=abi.FIELD_F32 if wl.get("field") == "f32" else abi.FIELD_U16T)
     if wl["beams"] == 1081:
         world.lidar_1081(cfg)
     else:
@@ -115,6 +116,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=0, help="override arenas per GPU")
     ap.add_argument("--gather", default="none", choices=["none", "all"])
+    ap.add_argument("--field", default="u16t", choices=["u16t", "f32"], help="distance-field storage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -137,6 +139,7 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.envs:
         wl["envs"] = args.envs
+    wl["field"] = args.field
     cfg, sim, arrays, _ = build_sim(wl, rank, world_size, device=device)
     E, K, Wm = cfg.n_envs, args.steps, args.warmup
 
@@ -181,7 +184,10 @@ def main():
 
     if rank == 0:
         n_done = int(sim.t["episode"].sum().item())
-        A = algorithmic_bytes_per_env_step(cfg.map_h, cfg.map_w, cfg.n_beams, cfg.n_scan_stack, wl["peds"], 4)
+        # s_map = 1: the arena's occupancy grid as the reference stores it (int8 map_info['data'],
+        # map_generator.py:136) read once per env-step -- BASELINE.md section 3's definition.  The
+        # on-device distance-field encoding is an implementation choice, not algorithmic bytes.
+        A = algorithmic_bytes_per_env_step(cfg.map_h, cfg.map_w, cfg.n_beams, cfg.n_scan_stack, wl["peds"], 1)
         achieved = A * E / (kernel_ms * 1e-3) / 1e9                # GB/s
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
@@ -204,16 +210,16 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s: %d arenas/GPU x %d-beam lidar, %dx%d per-arena occupancy maps (float32 distance "
+                "workload": "%s: %d arenas/GPU x %d-beam lidar, %dx%d per-arena occupancy maps (%s distance "
                             "field), %d pedestrians/arena, KetiRobot diff-drive, auto-respawn in place"
-                            % (args.workload, E, cfg.n_beams, cfg.map_h, cfg.map_w, wl["peds"]),
+                            % (args.workload, E, cfg.n_beams, cfg.map_h, cfg.map_w, args.field, wl["peds"]),
                 "envs_per_gpu": E, "n_beams": cfg.n_beams, "map": [cfg.map_h, cfg.map_w],
                 "pedestrians": wl["peds"], "obs_gather": args.gather, "episodes_finished_rank0": n_done,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": traffic, "kernel": "navsim_step_kernel", "kernel_ms": kernel_ms,
-                "algorithmic_bytes_per_env_step": A, "s_map": 4,
+                "algorithmic_bytes_per_env_step": A, "s_map": 1,
             },
         }
         if not args.no_cpu_baseline and world_size == 1:

@@ -43,6 +43,13 @@ extern "C" {
                                     reference fills with HumanPolicy (env.py:650-662) */
 #define NAVSIM_PED_SFM       2   /* build-defined social-force model */
 
+/* distance-field storage (navsim_config.field_format, navsim_build_field) */
+#define NAVSIM_FIELD_F32     0   /* float32 [E,H,W] row-major, distance in cells (what range_libc holds) */
+#define NAVSIM_FIELD_U16T    1   /* uint16 squared distance in 8x8-cell tiles (128-B lines), 0xFFFF =
+                                    "d2 >= 65535, read the float32 overflow plane"; d = sqrtf(d2) is
+                                    bit-identical to the float32 field */
+#define NAVSIM_FIELD_TILE    8
+
 /* compiled limits */
 #define NAVSIM_MAX_PEDS      64
 #define NAVSIM_MAX_WAYPOINTS 8
@@ -65,6 +72,8 @@ typedef struct navsim_config {
     int32_t n_spawn;         /* K: spawn table entries per env (auto_reset) */
     int32_t add_scan_noise;  /* 1: Gaussian noise on beams != range_max (env.py:437-440) */
     int32_t env_index_base;  /* global index of local env 0 (multi-GPU sharding; seeds RNG) */
+    int32_t field_format;    /* NAVSIM_FIELD_* of navsim_state.field */
+    int32_t reserved0;
 
     double resolution;       /* metres per cell (map_generator.py:116) */
     double origin_x, origin_y;
@@ -105,7 +114,13 @@ typedef struct navsim_config {
  * ---------------------------------------------------------------------------------------- */
 typedef struct navsim_state {
     /* world */
-    const float*  field;            /* [E,H,W] distance field in cells, from navsim_build_dt */
+    const void*   field;            /* distance field of every arena in cfg.field_format
+                                       (navsim_build_dt / navsim_build_field) */
+    const float*  field_overflow;   /* [E,H,W] float32 distances, read only where the packed field
+                                       holds 0xFFFF; may be NULL when navsim_build_field reported
+                                       no saturated cell (NAVSIM_FIELD_U16T only) */
+    const double* beam_table;       /* [B,2] cos, sin of the robot-frame beam angles (navsim_beam_table);
+                                       optional accelerator, NULL = evaluate every beam direction in full */
     const float*  scan_threshold;   /* [B] env.py:162-170 */
     const float*  scan_discomfort;  /* [B] env.py:172-180 */
     const float*  scan_noise_std;   /* [E] env_param['scan_noise_std'] (env.py:439) */
@@ -163,6 +178,16 @@ size_t navsim_build_dt_workspace_bytes(int32_t n_maps, int32_t map_h, int32_t ma
 int    navsim_build_dt(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t map_w,
                        float* field, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Same transform, written in `format` (the layout the fused step streams).  `field` needs
+ * navsim_field_bytes() bytes.  `overflow` (float32 [n,H,W], may be NULL) receives the exact float
+ * distance of every cell; `n_saturated` (device int32, may be NULL) is incremented once per cell whose
+ * squared distance does not fit the packed format -- when it stays 0 the overflow plane is never read
+ * and may be dropped. */
+size_t navsim_field_bytes(int32_t n_maps, int32_t map_h, int32_t map_w, int32_t format);
+int    navsim_build_field(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t map_w, int32_t format,
+                          void* field, float* overflow, int32_t* n_saturated,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- a4: PyRayMarching.calc_range_many (env.py:425) ------------------------------------- */
 /* queries [E, n_per_env, 3] float32 (x, y, theta) in cell units, out [E, n_per_env] in cells. */
 int navsim_cast_static(const float* field, int32_t n_envs, int32_t map_h, int32_t map_w,
@@ -202,6 +227,11 @@ int navsim_reward_done(const navsim_config* cfg, const void* obs, const void* go
 int navsim_scan_threshold(const navsim_config* cfg, const float* footprint, int32_t n_vert,
                           float* out, void* stream);
 
+/* cos / sin (float64, DESIGN.md section 4 functions) of np.linspace(angle_min, angle_last, B): lets the
+ * step derive each beam direction by one angle addition and prove, per beam, that the float32
+ * rounding equals the full evaluation's (falling back to it otherwise) -- results are unchanged. */
+int navsim_beam_table(const navsim_config* cfg, double* table, void* stream);
+
 /* ---- a1: NavGymEnv.step (env.py:591-728), fused ----------------------------------------- */
 /* One launch: pedestrian update, robot integration, scan, reward/done/info, crash revert (or
  * respawn) with re-scan, observation packing.  State is updated in place. */
@@ -222,7 +252,8 @@ size_t navsim_sizeof_config(void);
 size_t navsim_sizeof_state(void);
 size_t navsim_sizeof_step_io(void);
 /* deterministic device math of DESIGN.md section 4: fn 0 sin, 1 cos, 2 atan2(x, x2), 3 exp(x<=0),
- * 4 angle_correction (utils.py:5-9), 5 python-float % 2pi.  x, x2, out are device float64 [n]. */
+ * 4 angle_correction (utils.py:5-9), 5 python-float % 2pi, 6 the packed field's sqrtf on integers.
+ * x, x2, out are device float64 [n]. */
 int navsim_debug_math(int32_t fn, const double* x, const double* x2, double* out, int32_t n, void* stream);
 
 #ifdef __cplusplus

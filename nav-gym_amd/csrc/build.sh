@@ -4,9 +4,9 @@
 # no v_mul/v_add pair of the specified float32/float64 sequences may be fused.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-OUT="${HERE}/../nav_gym_amd/libnavsim_hip.so"
+OUT="${NAVSIM_OUT:-${HERE}/../nav_gym_amd/libnavsim_hip.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off \
-    -Wall -Wno-unused-function ${NAVSIM_EXTRA_FLAGS:-} \
+    -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical -Wno-pass-failed ${NAVSIM_EXTRA_FLAGS:-} \
     -o "${OUT}" "${HERE}/navsim_kernels.hip"
 echo "built ${OUT}"

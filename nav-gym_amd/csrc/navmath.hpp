@@ -155,6 +155,21 @@ __device__ __forceinline__ double wrap_pi(double a) {
     return atan2_(s, c);
 }
 
+// Correctly rounded sqrtf for 1 <= x <= 2^24 (integers from the packed distance field): the raw
+// v_sqrt_f32 is within 1 ulp, and the two exact FMA residuals pick the neighbour whose square
+// brackets x (the same correction hipcc emits for sqrtf, minus the denormal scaling and the class
+// test, which cannot trigger in this range).  tests/test_gpu_parity.py checks all 65,535 inputs.
+__device__ __forceinline__ float sqrt_small_int(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    float sm = __uint_as_float(__float_as_uint(s) - 1u);
+    float sp = __uint_as_float(__float_as_uint(s) + 1u);
+    float em = __builtin_fmaf(-sm, s, x);
+    float ep = __builtin_fmaf(-sp, s, x);
+    s = (em <= 0.0f) ? sm : s;
+    s = (ep > 0.0f) ? sp : s;
+    return s;
+}
+
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ULL;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;

@@ -35,6 +35,34 @@ __device__ __forceinline__ void beam_dir(float heading, float& dx, float& dy) {
     dy = (float)s;
 }
 
+// Same direction from the beam table: cos/sin(lin_k + th + delta) by one angle addition, accepted
+// only when the float32 rounding is PROVABLY the one beam_dir() produces.  Error budget of the
+// candidate against the true cos/sin of the float32 heading: table entries and cos/sin(th) are within
+// 1 ulp (1.1e-16), the two products and their sum add <= 8e-16 absolute, the second-order series in
+// delta is exact to 1e-19; beam_dir() itself is within 1.1e-16.  So both round alike whenever the
+// candidate sits more than 3e-15 inside its float32 rounding interval; otherwise the caller falls
+// back to beam_dir() -- a few beams in 1e7.
+__device__ __forceinline__ bool round_if_safe(double v, float& out) {
+    float f = (float)v;
+    uint32_t bits = __float_as_uint(f);
+    uint32_t eb = bits & 0x7F800000u;
+    if (eb < (40u << 23) || (bits & 0x007FFFFFu) == 0u) return false;   // tiny or a power of two
+    double half_ulp = (double)__uint_as_float(eb - (24u << 23));
+    double r = v - (double)f;
+    if (half_ulp - __builtin_fabs(r) < 3.0e-15) return false;
+    out = f;
+    return true;
+}
+__device__ __forceinline__ bool beam_dir_from_table(double ct, double st, double cT, double sT, double delta,
+                                                    float& dx, float& dy) {
+    double C = ct * cT - st * sT;
+    double S = st * cT + ct * sT;
+    double h = 0.5 * delta * delta;
+    double c = (C - C * h) - S * delta;
+    double s = (S - S * h) + C * delta;
+    return round_if_safe(c, dx) & round_if_safe(s, dy);
+}
+
 // range_libc RayMarching::calc_range (PyRayMarching.calc_range_many, env.py:425): sphere tracing
 // through the distance field, float32, C truncation of the sample position.
 __device__ __forceinline__ float trace_ray(const float* __restrict__ f, int H, int W, float x0, float y0,

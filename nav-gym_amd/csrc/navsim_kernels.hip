@@ -10,6 +10,8 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see nav-gym_amd/csrc/build.sh).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/navsim.h"
@@ -20,8 +22,17 @@
 
 namespace {
 
-constexpr int kStepBlock = 256;       // threads per arena workgroup (4 waves)
 constexpr int kMaxWaves = 16;
+
+// Diagnostic build only (-DNAVSIM_STAMPS, profiles/stamp_phases.py): s_memtime at the phase
+// boundaries of each arena's workgroup, written to a buffer nothing else reads.  The shipped library
+// is built without it (no stamp executes in the measured kernel).
+#ifdef NAVSIM_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+#define NAVSIM_STAMP(i) do { if (threadIdx.x == 0 && g_stamps) g_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NAVSIM_STAMP(i) do { } while (0)
+#endif
 
 // ============================================================================================
 // a3: exact Euclidean distance transform (replaces range_libc.PyOMap + PyRayMarching.__init__,
@@ -54,8 +65,58 @@ __global__ __launch_bounds__(256) void dt_columns_kernel(const uint8_t* __restri
     }
 }
 
+// distance-field accessors -------------------------------------------------------------------
+// FieldF32: float32 row-major (what range_libc keeps).  FieldU16T: uint16 squared distances in
+// 8x8-cell tiles, one tile = one 128-B line = one HBM fill (profiles/gather_granularity.py): a
+// fan of adjacent beams touches ~2.2x fewer lines than with float32 rows, and sqrtf(d2) is the
+// very float the float32 field holds.
+struct FieldF32 {
+    const float* p; int W;
+    __device__ __forceinline__ FieldF32(const void* base, const float*, int e, int H, int W_)
+        : p((const float*)base + (size_t)e * H * W_), W(W_) {}
+    typedef float raw_t;
+    // byte offsets stay below 4 GiB per arena, so a 32-bit lane offset on a uniform base suffices
+    __device__ __forceinline__ raw_t load(int px, int py) const {
+        unsigned off = ((unsigned)py * (unsigned)W + (unsigned)px) * 4u;
+        return *(const float*)((const char*)p + off);
+    }
+    __device__ __forceinline__ bool occupied(raw_t v) const { return v <= 0.0f; }
+    __device__ __forceinline__ float decode(raw_t v, int, int) const { return v; }
+    __device__ __forceinline__ float at(int px, int py) const { return load(px, py); }
+};
+struct FieldU16T {
+    const uint16_t* p; const float* ovf; int W, tpr;
+    __device__ __forceinline__ FieldU16T(const void* base, const float* overflow, int e, int H, int W_)
+        : W(W_), tpr((W_ + 7) >> 3) {
+        size_t per_map = (size_t)((H + 7) >> 3) * tpr * 64;
+        p = (const uint16_t*)base + (size_t)e * per_map;
+        ovf = overflow ? overflow + (size_t)e * H * W_ : nullptr;
+    }
+    __device__ __forceinline__ static size_t index(int px, int py, int tpr) {
+        return ((size_t)((py >> 3) * tpr + (px >> 3)) << 6) + ((py & 7) << 3) + (px & 7);
+    }
+    typedef unsigned raw_t;
+    // load and decode are split so that a thread can issue the loads of all its rays back to back
+    // before the (rare, divergent) overflow read of any of them
+    __device__ __forceinline__ raw_t load(int px, int py) const {
+        unsigned upx = (unsigned)px, upy = (unsigned)py;
+        unsigned off = ((((upy >> 3) * (unsigned)tpr + (upx >> 3)) << 6) | ((upy & 7u) << 3) | (upx & 7u)) * 2u;
+        return *(const uint16_t*)((const char*)p + off);
+    }
+    __device__ __forceinline__ bool occupied(raw_t v) const { return v == 0u; }
+    __device__ __forceinline__ float decode(raw_t v, int px, int py) const {
+        if (v == 0xFFFFu) return ovf[(size_t)py * W + px];      // d2 >= 65535: exact float plane
+        return nv::sqrt_small_int((float)v);
+    }
+    __device__ __forceinline__ float at(int px, int py) const { return decode(load(px, py), px, py); }
+};
+
+// FORMAT 0: float32 row-major to `field`; 1: uint16 tiles to `field` (+ float32 to `overflow` if
+// given, + saturation count)
+template <int FORMAT>
 __global__ __launch_bounds__(256) void dt_rows_kernel(const uint16_t* __restrict__ g,
-                                                      float* __restrict__ field, int H, int W) {
+                                                      void* __restrict__ field_v, float* __restrict__ overflow,
+                                                      int32_t* __restrict__ n_saturated, int H, int W) {
     extern __shared__ int32_t row[];                 // W entries of g(i)^2-ready distances
     size_t m = blockIdx.y;
     int y = blockIdx.x;
@@ -65,7 +126,9 @@ __global__ __launch_bounds__(256) void dt_rows_kernel(const uint16_t* __restrict
         row[x] = (v == 0xFFFF) ? kDtInf : v;
     }
     __syncthreads();
-    float* out = field + (m * (size_t)H + y) * W;
+    const int tpr = (W + 7) >> 3;
+    const size_t per_map_t = (size_t)((H + 7) >> 3) * tpr * 64;
+    int sat = 0;
     for (int x = threadIdx.x; x < W; x += blockDim.x) {
         int g0 = row[x];
         int best = g0 * g0;
@@ -76,8 +139,16 @@ __global__ __launch_bounds__(256) void dt_rows_kernel(const uint16_t* __restrict
             if (xl >= 0) { int v = row[xl]; int c = dx2 + v * v; best = c < best ? c : best; }
             if (xr < W)  { int v = row[xr]; int c = dx2 + v * v; best = c < best ? c : best; }
         }
-        out[x] = sqrtf((float)best);
+        if (FORMAT == 0) {
+            ((float*)field_v)[(m * (size_t)H + y) * W + x] = sqrtf((float)best);
+        } else {
+            uint16_t* out = (uint16_t*)field_v + m * per_map_t;
+            out[FieldU16T::index(x, y, tpr)] = (uint16_t)(best >= 65535 ? 0xFFFF : best);
+            if (overflow) overflow[(m * (size_t)H + y) * W + x] = sqrtf((float)best);
+            sat += best >= 65535;
+        }
     }
+    if (FORMAT != 0 && n_saturated && sat) atomicAdd(n_saturated, sat);
 }
 
 // ============================================================================================
@@ -257,6 +328,7 @@ struct StepShared {
     double old_rp[3];             // robot pose at the start of the step (social force input)
     double act[2];                // action after the turning-radius clamp
     float lx, ly, lth;            // float32 lidar pose (env.py:386)
+    double cT, sT;                // cos / sin of (double)lth for the beam-table fast path
     int i0, j0;                   // integer ray origin (env.py:419)
     int nseg, ndisc;
     int rescan;
@@ -270,9 +342,15 @@ struct StepShared {
 
 // robot scan (env.py:385-441 with other_agents = all pedestrians).  Writes the latest-scan slot
 // of the observation row and every "not yet filled" stack slot (env.py:262-265).
-template <int BLOCK>
+//
+// The march is latency-bound (each probe of the distance field is a dependent HBM/L2 access), so
+// every thread advances R independent rays in lock-step: the R loads of one round are issued back
+// to back before any of them is consumed, which multiplies the lines in flight per CU by R.
+// Beam k of round-slot q is base + q*BLOCK + tid, so lanes of a wave hold adjacent beams (their
+// probes fall on neighbouring cells and their range stores coalesce).
+template <int BLOCK, int R, typename Field>
 __device__ __forceinline__ void scan_beams(const navsim_config& c, const StepShared& sh,
-                                           const float* __restrict__ field,
+                                           const Field& field, const double* __restrict__ tab,
                                            const float* __restrict__ thr, const float* __restrict__ dthr,
                                            float* __restrict__ obs_row, int n_hist, float noise_std,
                                            uint64_t noise_key, uint64_t genv,
@@ -287,33 +365,106 @@ __device__ __forceinline__ void scan_beams(const navsim_config& c, const StepSha
     const double lth = (double)sh.lth;
     const int nseg = sh.nseg, ndisc = sh.ndisc;
     int cr = 0, dc = 0;
-    for (int k = threadIdx.x; k < B; k += BLOCK) {
-        double ang = nv::linspace_k(c, k, step) + lth;        // env.py:388-390
-        float heading = (float)ang;                           // env.py:424
-        float dx, dy;
-        nv::beam_dir(heading, dx, dy);
-        float r = nv::trace_ray(field, H, W, x0, y0, dx, dy, max_range);   // env.py:425
-        r = r * res;                                          // env.py:426
-        for (int q = 0; q < nseg; ++q)
-            nv::seg_merge(r, lx, ly, dx, dy, sh.seg[q][0], sh.seg[q][1], sh.seg[q][2], sh.seg[q][3]);
-        for (int q = 0; q < ndisc; ++q)
-            nv::circle_merge(r, lx, ly, dx, dy, sh.disc[q][0], sh.disc[q][1], nv::kLegRadius);
-        r = r < 0.0f ? 0.0f : r;                              // env.py:435
-        r = r > rmax ? rmax : r;
-        if (noise_std > 0.0f && r != rmax)                    // env.py:437-440
-            r = r + noise_std * nv::gauss_noise(c.seed ^ noise_key, genv, noise_key, (uint32_t)k);
-        cr |= (r < thr[k]);
-        dc |= (r < dthr[k]);
-        obs_row[(size_t)(S - 1) * B + k] = r;
-        for (int j = 0; j < S - 1; ++j)
-            if (S - 1 - j > n_hist) obs_row[(size_t)j * B + k] = r;
+    for (int base = 0; base < B; base += BLOCK * R) {
+        float dx[R], dy[R], t[R], r[R];
+        unsigned active = 0;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            int k = base + q * BLOCK + (int)threadIdx.x;
+            bool valid = k < B;
+            const int kk = valid ? k : 0;
+            const double lin = nv::linspace_k(c, kk, step);
+            double ang = lin + lth;                                     // env.py:388-390
+            float heading = (float)ang;                                 // env.py:424
+            bool fast = false;
+            if (tab) {
+                // heading = lin + lth + delta EXACTLY: (heading - ang) is exact (Sterbenz), and the
+                // rounding error of the float64 sum is recovered by TwoSum
+                double bb = ang - lin;
+                double eps = (lin - (ang - bb)) + (lth - bb);
+                double delta = ((double)heading - ang) + eps;
+                double2 cs = ((const double2*)tab)[kk];
+                fast = nv::beam_dir_from_table(cs.x, cs.y, sh.cT, sh.sT, delta, dx[q], dy[q]);
+            }
+            if (!fast) nv::beam_dir(heading, dx[q], dy[q]);
+            t[q] = 0.0f;
+            r[q] = max_range;
+            active |= valid ? (1u << q) : 0u;
+        }
+        // range_libc RayMarching::calc_range (env.py:425), R rays per thread in lock-step.  The hit
+        // distance is evaluated once after the march (hx, hy), not speculatively in every round.
+        int hx[R], hy[R];
+        unsigned hit = 0;
+        const unsigned uW = (unsigned)W, uH = (unsigned)H;
+        while (active) {
+            int px[R], py[R];
+            typename Field::raw_t raw[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                float fx = x0 + dx[q] * t[q];
+                float fy = y0 + dy[q] * t[q];
+                px[q] = (int)fx;
+                py[q] = (int)fy;
+                // px >= W || px < 0 || py < 0 || py >= H, as two unsigned compares
+                bool inb = ((unsigned)px[q] < uW) & ((unsigned)py[q] < uH);
+                bool a = (active >> q) & 1u;
+                if (a && !inb) active &= ~(1u << q);                    // left the map: max_range
+                bool live = a && inb;
+                px[q] = live ? px[q] : 0;
+                py[q] = live ? py[q] : 0;
+                raw[q] = field.load(px[q], py[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                if ((active >> q) & 1u) {
+                    if (field.occupied(raw[q])) {
+                        hx[q] = px[q]; hy[q] = py[q];
+                        hit |= 1u << q;
+                        active &= ~(1u << q);
+                    } else {
+                        const float dq = field.decode(raw[q], px[q], py[q]);
+                        float stp = (float)((double)dq * 0.999);
+                        t[q] += (stp > 1.0f) ? stp : 1.0f;
+                        if (!(t[q] < max_range)) active &= ~(1u << q);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            if ((hit >> q) & 1u) {
+                float xd = (float)hx[q] - x0;
+                float yd = (float)hy[q] - y0;
+                r[q] = sqrtf(xd * xd + yd * yd);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            int k = base + q * BLOCK + (int)threadIdx.x;
+            if (k < B) {
+                float rr = r[q] * res;                                  // env.py:426
+                for (int p = 0; p < nseg; ++p)
+                    nv::seg_merge(rr, lx, ly, dx[q], dy[q], sh.seg[p][0], sh.seg[p][1], sh.seg[p][2], sh.seg[p][3]);
+                for (int p = 0; p < ndisc; ++p)
+                    nv::circle_merge(rr, lx, ly, dx[q], dy[q], sh.disc[p][0], sh.disc[p][1], nv::kLegRadius);
+                rr = rr < 0.0f ? 0.0f : rr;                             // env.py:435
+                rr = rr > rmax ? rmax : rr;
+                if (noise_std > 0.0f && rr != rmax)                     // env.py:437-440
+                    rr = rr + noise_std * nv::gauss_noise(c.seed ^ noise_key, genv, noise_key, (uint32_t)k);
+                cr |= (rr < thr[k]);
+                dc |= (rr < dthr[k]);
+                obs_row[(size_t)(S - 1) * B + k] = rr;
+                for (int j = 0; j < S - 1; ++j)
+                    if (S - 1 - j > n_hist) obs_row[(size_t)j * B + k] = rr;
+            }
+        }
     }
     crash = cr;
     discomfort = dc;
 }
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void navsim_step_kernel(navsim_config c, navsim_state st,
+template <int BLOCK, int R, bool PEDS, typename Field>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void navsim_step_kernel(navsim_config c, navsim_state st,
                                                             navsim_step_io io, int reset_only,
                                                             const uint8_t* __restrict__ reset_mask) {
     __shared__ StepShared sh;
@@ -323,7 +474,7 @@ __global__ __launch_bounds__(BLOCK) void navsim_step_kernel(navsim_config c, nav
     const int P = NAVSIM_MAX_WAYPOINTS;
     const double dt = c.time_step;
     const uint64_t genv = (uint64_t)(c.env_index_base + e);
-    const float* field = st.field + (size_t)e * c.map_h * c.map_w;
+    const Field field(st.field, st.field_overflow, e, c.map_h, c.map_w);
     float* obs_row = io.obs + (size_t)e * D;
     const float* obs_prev = io.obs_prev ? io.obs_prev + (size_t)e * D : nullptr;
     double* rp_g = st.robot_pose + 3 * (size_t)e;
@@ -337,10 +488,11 @@ __global__ __launch_bounds__(BLOCK) void navsim_step_kernel(navsim_config c, nav
         return;
     }
 
-    int n = (c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
+    int n = (!PEDS || c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
     n = n > N ? N : n;
     const float noise_std = (c.add_scan_noise && st.scan_noise_std) ? st.scan_noise_std[e] : 0.0f;
 
+    NAVSIM_STAMP(0);
     // ---------------------------------------------------------------- phase 0: scalars
     if (tid == 0) {
         sh.old_rp[0] = rp_g[0]; sh.old_rp[1] = rp_g[1]; sh.old_rp[2] = rp_g[2];
@@ -358,16 +510,23 @@ __global__ __launch_bounds__(BLOCK) void navsim_step_kernel(navsim_config c, nav
     }
     __syncthreads();
 
+    NAVSIM_STAMP(1);
     // ---------------------------------------------------------------- phase 1: pedestrians
     double pp[3] = {0.0, 0.0, 0.0};
     double pvel[2] = {0.0, 0.0};
     const size_t pq = (size_t)e * N + (tid < n ? tid : 0);
-    const bool is_ped = tid < n;
+    const bool is_ped = PEDS && tid < n;
     if (is_ped) {
         pp[0] = st.ped_pose[pq * 3]; pp[1] = st.ped_pose[pq * 3 + 1]; pp[2] = st.ped_pose[pq * 3 + 2];
         pvel[0] = st.ped_vel[pq * 2]; pvel[1] = st.ped_vel[pq * 2 + 1];
     }
-    if (!reset_only) {
+    if (!reset_only && !PEDS) {
+        if (tid == 0) {                                         // env.py:664
+            double p[3] = {sh.old_rp[0], sh.old_rp[1], sh.old_rp[2]};
+            nv::set_vel(p, sh.act[0], sh.act[1], dt, c.axle_offset, nullptr);
+            sh.rp[0] = p[0]; sh.rp[1] = p[1]; sh.rp[2] = p[2];
+        }
+    } else if (!reset_only) {
         double* wp = st.ped_waypoints ? st.ped_waypoints + (pq * P) * 2 : nullptr;
         int nw = 1;
         if (is_ped) {
@@ -429,9 +588,9 @@ __global__ __launch_bounds__(BLOCK) void navsim_step_kernel(navsim_config c, nav
                     cj = cj > H - 1 ? H - 1 : cj;
                     int il_ = ci > 0 ? ci - 1 : 0, ir = ci < W - 1 ? ci + 1 : W - 1;
                     int jl = cj > 0 ? cj - 1 : 0, jr = cj < H - 1 ? cj + 1 : H - 1;
-                    double d = (double)field[(size_t)cj * W + ci] * c.resolution;
-                    double gx = (double)field[(size_t)cj * W + ir] - (double)field[(size_t)cj * W + il_];
-                    double gy = (double)field[(size_t)jr * W + ci] - (double)field[(size_t)jl * W + ci];
+                    double d = (double)field.at(ci, cj) * c.resolution;
+                    double gx = (double)field.at(ir, cj) - (double)field.at(il_, cj);
+                    double gy = (double)field.at(ci, jr) - (double)field.at(ci, jl);
                     double gl = sqrt(gx * gx + gy * gy);
                     if (gl > 0.0) {
                         double mag = nv::exp_neg(-(d - c.sfm_agent_radius) / c.sfm_sigma_obstacle);
@@ -531,16 +690,19 @@ __global__ __launch_bounds__(BLOCK) void navsim_step_kernel(navsim_config c, nav
     if (tid == 0) {
         sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];   // env.py:386
         nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);                              // env.py:419
+        nv::sincos((double)sh.lth, sh.sT, sh.cT);
     }
     __syncthreads();
 
+    NAVSIM_STAMP(2);
     // ---------------------------------------------------------------- phase 3: scan A
     int n_hist = reset_only ? 0 : st.n_hist[e];
     int crash = 0, discomfort = 0;
     const uint64_t step_key = (uint64_t)st.episode[e] * 0x100000000ULL + (uint64_t)(reset_only ? 0 : st.steps[e]) * 2;
-    scan_beams<BLOCK>(c, sh, field, st.scan_threshold, st.scan_discomfort, obs_row, n_hist, noise_std,
+    scan_beams<BLOCK, R, Field>(c, sh, field, st.beam_table, st.scan_threshold, st.scan_discomfort, obs_row, n_hist, noise_std,
                       step_key, genv, crash, discomfort);
 
+    NAVSIM_STAMP(3);
     if (!reset_only) {
         crash = __syncthreads_or(crash);
         discomfort = __syncthreads_or(discomfort);
@@ -556,10 +718,11 @@ __global__ __launch_bounds__(BLOCK) void navsim_step_kernel(navsim_config c, nav
             if ((tid & 63) == 0) sh.wave_ratio[tid >> 6] = rmin;
             __syncthreads();
         }
+        NAVSIM_STAMP(4);
         // ------------------------------------------------------------ phase 4: reward / done / info
         if (tid == 0) {
             if (discomfort && !crash)
-                for (int w = 1; w < BLOCK / 64; ++w) rmin = sh.wave_ratio[w] < rmin ? sh.wave_ratio[w] : rmin;
+                for (int w = 1; w < (BLOCK + 63) / 64; ++w) rmin = sh.wave_ratio[w] < rmin ? sh.wave_ratio[w] : rmin;
             double prev_xy[2] = {pv_g[0], pv_g[1]};
             double pose[2] = {sh.rp[0], sh.rp[1]};
             double vel[2] = {pa_g[0], pa_g[1]};                 // env.py:453: the PREVIOUS action
@@ -587,6 +750,7 @@ __global__ __launch_bounds__(BLOCK) void navsim_step_kernel(navsim_config c, nav
             if (sh.rescan) {
                 sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];
                 nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);
+                nv::sincos((double)sh.lth, sh.sT, sh.cT);
             }
         }
         __syncthreads();
@@ -594,11 +758,12 @@ __global__ __launch_bounds__(BLOCK) void navsim_step_kernel(navsim_config c, nav
         if (sh.rescan) {
             if (sh.respawn) n_hist = 0;
             int c2, d2;
-            scan_beams<BLOCK>(c, sh, field, st.scan_threshold, st.scan_discomfort, obs_row, n_hist,
+            scan_beams<BLOCK, R, Field>(c, sh, field, st.beam_table, st.scan_threshold, st.scan_discomfort, obs_row, n_hist,
                               noise_std, step_key + 1, genv, c2, d2);
         }
     }
 
+    NAVSIM_STAMP(5);
     // ---------------------------------------------------------------- phase 6: pack the observation
     const bool fresh = reset_only || sh.respawn;                // first obs of an episode
     if (!fresh && obs_prev) {                                   // env.py:267-274: shift the stack
@@ -625,6 +790,16 @@ __global__ __launch_bounds__(BLOCK) void navsim_step_kernel(navsim_config c, nav
         if (reset_only) st.steps[e] = 0;
         pv_g[0] = sh.rp[0]; pv_g[1] = sh.rp[1]; pv_g[2] = yaw;
     }
+    NAVSIM_STAMP(6);
+}
+
+__global__ __launch_bounds__(256) void beam_table_kernel(navsim_config c, double* __restrict__ tab) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= c.n_beams) return;
+    double s, cs;
+    nv::sincos(nv::linspace_k(c, k, nv::linspace_step(c)), s, cs);
+    tab[2 * k] = cs;
+    tab[2 * k + 1] = s;
 }
 
 // test hook: the deterministic math on device
@@ -639,11 +814,71 @@ __global__ void math_kernel(int fn, const double* x, const double* x2, double* o
         case 3: out[i] = nv::exp_neg(x[i]); break;
         case 4: out[i] = nv::wrap_pi(x[i]); break;
         case 5: out[i] = nv::mod_2pi(x[i]); break;
+        case 6: out[i] = (double)nv::sqrt_small_int((float)x[i]); break;
         default: out[i] = 0.0;
     }
 }
 
+// microbenchmark (profiles/gather_granularity.py): random 4-byte gathers over a large buffer.
+// mode 0: one load per thread; 1: + the neighbour in the same 64-B sector; 2: + the word 64 B away
+// in the same 128-B line; 3: + a second independent random word.
+__global__ __launch_bounds__(256) void gather_probe_kernel(const float* __restrict__ x, uint64_t n_words,
+                                                           int mode, int iters, uint64_t seed,
+                                                           float* __restrict__ out) {
+    uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float acc = 0.0f;
+    for (int it = 0; it < iters; ++it) {
+        uint64_t h = nv::mix64(seed + gid * 0x9E3779B97F4A7C15ULL + (uint64_t)it);
+        uint64_t i = h % n_words;
+        acc += x[i];
+        if (mode == 1) acc += x[i ^ 1];
+        if (mode == 2) acc += x[i ^ 16];
+        if (mode == 3) acc += x[nv::mix64(h) % n_words];
+    }
+    out[gid] = acc;
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? NAVSIM_OK : NAVSIM_E_LAUNCH; }
+
+// Launch geometry: BLOCK threads per arena, R rays per thread.  The default covers all beams in
+// one round with the fewest idle lanes; NAVSIM_STEP_VARIANT="<block>x<rays>" overrides (tuning).
+template <int BLOCK, int R>
+void launch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
+                        int reset_only, const uint8_t* mask, hipStream_t s) {
+    const bool peds = c->ped_model != NAVSIM_PED_NONE;
+    if (c->field_format == NAVSIM_FIELD_U16T) {
+        if (peds) navsim_step_kernel<BLOCK, R, true, FieldU16T><<<c->n_envs, BLOCK, 0, s>>>(*c, *st, *io, reset_only, mask);
+        else      navsim_step_kernel<BLOCK, R, false, FieldU16T><<<c->n_envs, BLOCK, 0, s>>>(*c, *st, *io, reset_only, mask);
+    } else {
+        if (peds) navsim_step_kernel<BLOCK, R, true, FieldF32><<<c->n_envs, BLOCK, 0, s>>>(*c, *st, *io, reset_only, mask);
+        else      navsim_step_kernel<BLOCK, R, false, FieldF32><<<c->n_envs, BLOCK, 0, s>>>(*c, *st, *io, reset_only, mask);
+    }
+}
+
+int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
+                         int reset_only, const uint8_t* mask, hipStream_t s) {
+    int block = 0, rays = 0;
+    const char* v = getenv("NAVSIM_STEP_VARIANT");
+    if (v && sscanf(v, "%dx%d", &block, &rays) != 2) { block = 0; rays = 0; }
+    if (!block) {
+        const int B = c->n_beams;
+        if (B <= 64) { block = 64; rays = 1; }
+        else if (B <= 256) { block = 256; rays = 1; }
+        else { block = 256; rays = 1; }               // profiles/tune_variants.py
+    }
+#define NAVSIM_VARIANT(BK, RR) if (block == BK && rays == RR) { launch_step<BK, RR>(c, st, io, reset_only, mask, s); return launch_status(); }
+    NAVSIM_VARIANT(64, 1)
+    NAVSIM_VARIANT(256, 1)
+    NAVSIM_VARIANT(256, 2)
+    NAVSIM_VARIANT(256, 3)
+    NAVSIM_VARIANT(256, 5)
+    NAVSIM_VARIANT(256, 8)
+    NAVSIM_VARIANT(384, 3)
+    NAVSIM_VARIANT(512, 3)
+#undef NAVSIM_VARIANT
+    return NAVSIM_E_UNSUPPORTED;
+}
+
 
 }  // namespace
 
@@ -713,23 +948,45 @@ size_t navsim_build_dt_workspace_bytes(int32_t n_maps, int32_t H, int32_t W) {
     return (size_t)n_maps * H * W * sizeof(uint16_t);
 }
 
-int navsim_build_dt(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, float* field,
-                    void* workspace, size_t workspace_bytes, void* stream) {
+size_t navsim_field_bytes(int32_t n_maps, int32_t H, int32_t W, int32_t format) {
+    if (n_maps <= 0 || H <= 0 || W <= 0) return 0;
+    if (format == NAVSIM_FIELD_F32) return (size_t)n_maps * H * W * sizeof(float);
+    if (format == NAVSIM_FIELD_U16T) return (size_t)n_maps * ((H + 7) / 8) * ((W + 7) / 8) * 64 * sizeof(uint16_t);
+    return 0;
+}
+
+int navsim_build_field(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, int32_t format, void* field,
+                       float* overflow, int32_t* n_saturated, void* workspace, size_t workspace_bytes,
+                       void* stream) {
     if (!occ || !field || !workspace || n_maps < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
+    if (format != NAVSIM_FIELD_F32 && format != NAVSIM_FIELD_U16T) return NAVSIM_E_UNSUPPORTED;
     if (H >= kDtInf || W >= kDtInf || (size_t)W * 4 > 64 * 1024) return NAVSIM_E_UNSUPPORTED;
     size_t per_map = (size_t)H * W * sizeof(uint16_t);
-    size_t chunk = workspace_bytes / per_map;                 // maps per pass through the scratch
+    size_t chunk = workspace_bytes / per_map;
     if (chunk == 0) return NAVSIM_E_ARG;
     if (chunk > 65535) chunk = 65535;
     hipStream_t s = (hipStream_t)stream;
+    const size_t field_per_map = navsim_field_bytes(1, H, W, format);
+    if (format == NAVSIM_FIELD_U16T)       // padding cells of edge tiles are never read; keep them defined
+        (void)hipMemsetAsync(field, 0xFF, field_per_map * (size_t)n_maps, s);
     for (int32_t m0 = 0; m0 < n_maps; m0 += (int32_t)chunk) {
         int32_t m = (n_maps - m0 < (int32_t)chunk) ? n_maps - m0 : (int32_t)chunk;
         dt_columns_kernel<<<dim3((W + 255) / 256, m), 256, 0, s>>>(occ + (size_t)m0 * H * W,
                                                                    (uint16_t*)workspace, H, W);
-        dt_rows_kernel<<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace,
-                                                               field + (size_t)m0 * H * W, H, W);
+        void* f = (char*)field + field_per_map * (size_t)m0;
+        float* o = overflow ? overflow + (size_t)m0 * H * W : nullptr;
+        if (format == NAVSIM_FIELD_F32)
+            dt_rows_kernel<0><<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace, f, nullptr, nullptr, H, W);
+        else
+            dt_rows_kernel<1><<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace, f, o, n_saturated, H, W);
     }
     return launch_status();
+}
+
+int navsim_build_dt(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, float* field,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    return navsim_build_field(occ, n_maps, H, W, NAVSIM_FIELD_F32, field, nullptr, nullptr, workspace,
+                              workspace_bytes, stream);
 }
 
 int navsim_cast_static(const float* field, int32_t E, int32_t H, int32_t W, const float* q,
@@ -789,11 +1046,18 @@ int navsim_scan_threshold(const navsim_config* c, const float* fp, int32_t nvert
     return launch_status();
 }
 
+int navsim_beam_table(const navsim_config* c, double* table, void* stream) {
+    if (!c || !table || c->n_beams < 1) return NAVSIM_E_ARG;
+    beam_table_kernel<<<(c->n_beams + 255) / 256, 256, 0, (hipStream_t)stream>>>(*c, table);
+    return launch_status();
+}
+
 static int check_step_args(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
                            int reset_only) {
     if (!c || !st || !io) return NAVSIM_E_ARG;
     if (c->n_envs < 0 || c->n_beams < 1 || c->n_scan_stack < 1 || c->map_h < 1 || c->map_w < 1) return NAVSIM_E_ARG;
-    if (c->max_peds > NAVSIM_MAX_PEDS || c->max_peds > kStepBlock) return NAVSIM_E_UNSUPPORTED;
+    if (c->max_peds > NAVSIM_MAX_PEDS) return NAVSIM_E_UNSUPPORTED;
+    if (c->field_format != NAVSIM_FIELD_F32 && c->field_format != NAVSIM_FIELD_U16T) return NAVSIM_E_UNSUPPORTED;
     if (!st->field || !st->scan_threshold || !st->scan_discomfort || !st->robot_pose || !st->robot_goal ||
         !st->prev_action || !st->prev_pose || !st->n_hist || !st->episode || !st->steps || !io->obs)
         return NAVSIM_E_ARG;
@@ -816,8 +1080,7 @@ int navsim_step(const navsim_config* c, const navsim_state* st, const navsim_ste
     int rc = check_step_args(c, st, io, 0);
     if (rc != NAVSIM_OK) return rc;
     if (c->n_envs == 0) return NAVSIM_OK;
-    navsim_step_kernel<kStepBlock><<<c->n_envs, kStepBlock, 0, (hipStream_t)stream>>>(*c, *st, *io, 0, nullptr);
-    return launch_status();
+    return dispatch_step(c, st, io, 0, nullptr, (hipStream_t)stream);
 }
 
 int navsim_reset_obs(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
@@ -825,8 +1088,7 @@ int navsim_reset_obs(const navsim_config* c, const navsim_state* st, const navsi
     int rc = check_step_args(c, st, io, 1);
     if (rc != NAVSIM_OK) return rc;
     if (c->n_envs == 0) return NAVSIM_OK;
-    navsim_step_kernel<kStepBlock><<<c->n_envs, kStepBlock, 0, (hipStream_t)stream>>>(*c, *st, *io, 1, mask);
-    return launch_status();
+    return dispatch_step(c, st, io, 1, mask, (hipStream_t)stream);
 }
 
 const char* navsim_step_kernel_name(void) { return "navsim_step_kernel"; }
@@ -837,6 +1099,24 @@ int navsim_debug_math(int32_t fn, const double* x, const double* x2, double* out
     if (n == 0) return NAVSIM_OK;
     math_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(fn, x, x2, out, n);
     return launch_status();
+}
+
+// microbenchmark hook, see gather_probe_kernel
+int navsim_debug_gather(const float* x, uint64_t n_words, int32_t mode, int32_t iters, int32_t n_threads,
+                        float* out, void* stream) {
+    if (!x || !out || n_threads <= 0) return NAVSIM_E_ARG;
+    gather_probe_kernel<<<(n_threads + 255) / 256, 256, 0, (hipStream_t)stream>>>(x, n_words, mode, iters, 12345, out);
+    return launch_status();
+}
+
+// diagnostic build only: where the per-arena stamps go (NULL disables)
+int navsim_debug_set_stamps(unsigned long long* buf) {
+#ifdef NAVSIM_STAMPS
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)) == hipSuccess ? NAVSIM_OK : NAVSIM_E_LAUNCH;
+#else
+    (void)buf;
+    return NAVSIM_E_UNSUPPORTED;
+#endif
 }
 
 }  // extern "C"

@@ -22,6 +22,10 @@ MAX_PEDS = 64
 MAX_WAYPOINTS = 8
 OBS_TAIL = 7
 
+FIELD_F32 = 0
+FIELD_U16T = 1
+FIELD_TILE = 8
+
 
 class NavsimConfig(C.Structure):
     _fields_ = [
@@ -37,6 +41,8 @@ class NavsimConfig(C.Structure):
         ("n_spawn", C.c_int32),
         ("add_scan_noise", C.c_int32),
         ("env_index_base", C.c_int32),
+        ("field_format", C.c_int32),
+        ("reserved0", C.c_int32),
         ("resolution", C.c_double),
         ("origin_x", C.c_double),
         ("origin_y", C.c_double),
@@ -78,7 +84,7 @@ _P = C.c_void_p
 
 class NavsimState(C.Structure):
     _fields_ = [(name, _P) for name in (
-        "field", "scan_threshold", "scan_discomfort", "scan_noise_std",
+        "field", "field_overflow", "beam_table", "scan_threshold", "scan_discomfort", "scan_noise_std",
         "robot_pose", "robot_goal", "prev_action", "prev_pose", "n_hist", "episode", "steps",
         "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist", "ped_v_pref", "ped_has_legs",
         "ped_waypoints", "ped_n_waypoints", "ped_cmd",
@@ -95,7 +101,9 @@ class NavsimStepIO(C.Structure):
 
 # dtype / trailing shape of every state array, in units of (E, N, B, S, K, P, H, W)
 STATE_LAYOUT = {
-    "field": ("float32", ("E", "H", "W")),
+    "field": ("float32", ("E", "H", "W")),          # FIELD_F32; a uint8 blob for packed formats
+    "field_overflow": ("float32", ("E", "H", "W")),
+    "beam_table": ("float64", ("B", 2)),
     "scan_threshold": ("float32", ("B",)),
     "scan_discomfort": ("float32", ("B",)),
     "scan_noise_std": ("float32", ("E",)),
@@ -164,12 +172,17 @@ def declare(lib, suffix=""):
         sig("navsim_build_dt", [_P, i32, i32, i32, _P])
     else:
         sig("navsim_build_dt", [_P, i32, i32, i32, _P, _P, C.c_size_t, _P])
+    if not suffix:
+        sig("navsim_field_bytes", [i32, i32, i32, i32], C.c_size_t)
+        sig("navsim_build_field", [_P, i32, i32, i32, i32, _P, _P, _P, _P, C.c_size_t, _P])
     sig("navsim_cast_static", [_P, i32, i32, i32, _P, i32, f32, _P] + stream)
     sig("navsim_render_polys", [_P, _P, i32, i32, _P, _P, i32, _P] + stream)
     sig("navsim_render_legs", [_P, _P, i32, i32, _P, _P, i32, _P] + stream)
     sig("navsim_integrate", [_P, _P, _P, i32, f64, f64] + stream)
     sig("navsim_reward_done", [cfgp, _P, _P, i32, i32, _P, _P, _P, _P, _P, _P, _P] + stream)
     sig("navsim_scan_threshold", [cfgp, _P, i32, _P] + stream)
+    if not suffix:
+        sig("navsim_beam_table", [cfgp, _P, _P])
     sig("navsim_step", [cfgp, stp, iop] + stream)
     sig("navsim_reset_obs", [cfgp, stp, iop, _P] + stream)
     return lib
@@ -178,8 +191,9 @@ def declare(lib, suffix=""):
 # every symbol include/navsim.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "navsim_abi_version", "navsim_error_string", "navsim_default_config",
-    "navsim_build_dt_workspace_bytes", "navsim_build_dt", "navsim_cast_static",
+    "navsim_build_dt_workspace_bytes", "navsim_build_dt", "navsim_field_bytes", "navsim_build_field",
+    "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
-    "navsim_scan_threshold", "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
+    "navsim_scan_threshold", "navsim_beam_table", "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math",
 )

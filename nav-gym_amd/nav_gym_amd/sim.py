@@ -46,6 +46,31 @@ def build_dt(occ):
     return field
 
 
+def build_field(occ, fmt=abi.FIELD_U16T, keep_overflow=None):
+    """occ: uint8 CUDA tensor [E,H,W] -> (field, overflow, n_saturated).
+
+    fmt FIELD_F32: field is the float32 [E,H,W] distance field, overflow None.
+    fmt FIELD_U16T: field is the packed uint16 tile blob the fused step streams; the float32 plane is
+    computed alongside (the reset path samples spawn cells from it) and returned as `overflow`;
+    it is only REQUIRED by the step when n_saturated > 0."""
+    torch = require_gpu()
+    L = load()
+    occ = occ.contiguous()
+    E, H, W = occ.shape
+    if fmt == abi.FIELD_F32:
+        return build_dt(occ), None, 0
+    nbytes = L.navsim_field_bytes(E, H, W, fmt)
+    field = torch.empty(nbytes // 2, dtype=torch.int16, device=occ.device)
+    overflow = torch.empty((E, H, W), dtype=torch.float32, device=occ.device)
+    nsat = torch.zeros(1, dtype=torch.int32, device=occ.device)
+    per_map = L.navsim_build_dt_workspace_bytes(1, H, W)
+    chunk = max(1, min(E, (512 << 20) // max(per_map, 1)))
+    ws = torch.empty(per_map * chunk, dtype=torch.uint8, device=occ.device)
+    check(L.navsim_build_field(_ptr(occ), E, H, W, fmt, _ptr(field), _ptr(overflow), _ptr(nsat), _ptr(ws),
+                               ws.numel(), _stream()), "navsim_build_field")
+    return field, overflow, int(nsat.item())          # reset path: a sync is fine here
+
+
 def cast_static(field, queries, max_range):
     torch = require_gpu()
     E, H, W = field.shape
@@ -129,6 +154,15 @@ class NavSim(object):
             if a is None:
                 setattr(self.st, name, None)
                 continue
+            if name == "field" and self.cfg.field_format != abi.FIELD_F32:
+                t = a.to(self.device).contiguous()              # packed blob, kept as is
+                want = self.lib.navsim_field_bytes(self.cfg.n_envs, self.cfg.map_h, self.cfg.map_w,
+                                                   self.cfg.field_format)
+                if t.numel() * t.element_size() != want:
+                    raise ValueError("field blob has %d bytes, expected %d" % (t.numel() * t.element_size(), want))
+                self.t[name] = t
+                setattr(self.st, name, t.data_ptr())
+                continue
             if isinstance(a, np.ndarray):
                 a = torch.from_numpy(np.ascontiguousarray(a))
             t = a.to(device=self.device, dtype=_dtype(dtype)).contiguous()
@@ -139,6 +173,11 @@ class NavSim(object):
                 raise ValueError("%s: shape %s, expected %s" % (name, tuple(t.shape), want))
             self.t[name] = t
             setattr(self.st, name, t.data_ptr())
+        if "beam_table" not in self.t:                          # accelerator table, built on device
+            tab = torch.empty((self.cfg.n_beams, 2), dtype=torch.float64, device=self.device)
+            check(self.lib.navsim_beam_table(C.byref(self.cfg), _ptr(tab), _stream()), "navsim_beam_table")
+            self.t["beam_table"] = tab
+            self.st.beam_table = tab.data_ptr()
         E = self.cfg.n_envs
         D = self.cfg.n_scan_stack * self.cfg.n_beams + abi.OBS_TAIL
         self.obs_buf = [torch.zeros((E, D), dtype=torch.float32, device=self.device) for _ in range(2)]

@@ -122,12 +122,25 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
     dev = torch.device(device)
     E, N, K = cfg.n_envs, cfg.max_peds, max(cfg.n_spawn, 1)
     res, org = cfg.resolution, (cfg.origin_x, cfg.origin_y)
-    occ_t = torch.as_tensor(occ).to(dev)
+    a = {}
     if field is None:
-        field = sim.build_dt(occ_t)
+        occ_t = torch.as_tensor(occ).to(dev)
+        packed, f32, nsat = sim.build_field(occ_t, cfg.field_format)
+        if cfg.field_format == abi.FIELD_F32:
+            field = packed
+            a["field"] = field
+        else:
+            field = f32                                   # float32 plane: spawn sampling below
+            a["field"] = packed
+            if nsat > 0:
+                a["field_overflow"] = f32                 # some cell is >= 256 cells from any obstacle
+        del occ_t
+    else:
+        if cfg.field_format != abi.FIELD_F32:
+            raise ValueError("a pre-built field must be float32 (cfg.field_format = FIELD_F32)")
+        a["field"] = field
     H, W = field.shape[1:]
     genv = torch.arange(E, device=dev, dtype=torch.int64) + int(cfg.env_index_base)
-    a = {"field": field}
     # ---- robot start / goal tables (env.py:748-783 without A*) -------------------------------------
     KK = max(2 * K, 8)
     cells = sample_free_cells(field, robot_clearance / res, KK, seed, genv, 11)

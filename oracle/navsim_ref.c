@@ -502,7 +502,7 @@ static inline double linspace_k(const navsim_config* c, int k) {
 static void robot_scan(const navsim_config* c, const navsim_state* st, int e, int n_peds,
                        const double* pose, float* ranges) {
     const int B = c->n_beams, H = c->map_h, W = c->map_w;
-    const float* f = st->field + (size_t)e * H * W;
+    const float* f = (const float*)st->field + (size_t)e * H * W;
     float lx = (float)pose[0], ly = (float)pose[1], lth = (float)pose[2];     /* env.py:386 */
     int i0, j0;
     xy_to_ij_f32(lx, ly, c, &i0, &j0);                                         /* env.py:419 */
@@ -631,7 +631,7 @@ int navsim_reward_done_cpu(const navsim_config* c, const void* obs, const void* 
 static void sfm_update(const navsim_config* c, const navsim_state* st, int e, int n,
                        const double* robot_pose, const double* robot_prev_action) {
     const int N = c->max_peds, H = c->map_h, W = c->map_w, P = NAVSIM_MAX_WAYPOINTS;
-    const float* f = st->field + (size_t)e * H * W;
+    const float* f = (const float*)st->field + (size_t)e * H * W;
     double ax[NAVSIM_MAX_PEDS + 1], ay[NAVSIM_MAX_PEDS + 1];      /* agent positions (peds + robot) */
     double avx[NAVSIM_MAX_PEDS + 1], avy[NAVSIM_MAX_PEDS + 1];
     for (int i = 0; i < n; ++i) {
@@ -869,6 +869,7 @@ int navsim_step_range_cpu(const navsim_config* c, const navsim_state* st, const 
     if (!c || !st || !io || !io->action || !io->obs || !io->reward || !io->done || !io->is_success ||
         !io->is_crash || !io->distance) return NAVSIM_E_ARG;
     if (c->max_peds > NAVSIM_MAX_PEDS || c->n_scan_stack < 1) return NAVSIM_E_UNSUPPORTED;
+    if (c->field_format != NAVSIM_FIELD_F32) return NAVSIM_E_UNSUPPORTED;   /* oracle reads float32 only */
     float* scan = (float*)malloc(sizeof(float) * (size_t)c->n_beams);
     for (int e = e0; e < e1; ++e) step_env(c, st, io, e, scan);
     free(scan);
@@ -884,6 +885,7 @@ int navsim_step_cpu(const navsim_config* c, const navsim_state* st, const navsim
 int navsim_reset_obs_cpu(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
                          const uint8_t* mask) {
     if (!c || !st || !io || !io->obs) return NAVSIM_E_ARG;
+    if (c->field_format != NAVSIM_FIELD_F32) return NAVSIM_E_UNSUPPORTED;
     const int B = c->n_beams, S = c->n_scan_stack, N = c->max_peds, D = S * B + 7;
     float* scan = (float*)malloc(sizeof(float) * (size_t)B);
     for (int e = 0; e < c->n_envs; ++e) {

@@ -208,6 +208,7 @@ class RefSim(object):
     def __init__(self, cfg, arrays):
         """arrays: dict name -> numpy array for every non-NULL field of navsim_state."""
         self.cfg = cfg.copy() if hasattr(cfg, "copy") else cfg
+        self.cfg.field_format = abi.FIELD_F32     # the oracle always reads the float32 field
         self.a = {}
         self.st = abi.NavsimState()
         for name, (dtype, shape) in abi.STATE_LAYOUT.items():

@@ -53,6 +53,14 @@ def test_device_math_bit_exact(gpu):
     _eq(gpu.sim.debug_math(3, _t(gpu, e)).cpu().numpy(), ref.math_fn(3, e), "exp")
 
 
+def test_packed_field_sqrt_is_correctly_rounded(gpu):
+    """The packed field decodes d = sqrtf(d2) with a hand-rolled correction of v_sqrt_f32: check it
+    against IEEE sqrt for EVERY encodable value and a sample of larger integers."""
+    v = np.concatenate([np.arange(1, 65536), np.random.default_rng(0).integers(65536, 1 << 24, 200000)]).astype(np.float64)
+    got = gpu.sim.debug_math(6, _t(gpu, v)).cpu().numpy()
+    _eq(got.astype(np.float32), np.sqrt(v.astype(np.float32)), "sqrt_small_int")
+
+
 @pytest.mark.parametrize("size,n", [(100, 3), (400, 2), (500, 2), (1000, 1)])
 def test_build_dt(gpu, size, n):
     occ = gpu.world.make_maps(n, size, 77 + size, indoor_ratio=0.5 if size == 1000 else 0.0)
@@ -197,13 +205,13 @@ def test_step_golden_traces(gpu, name):
 def _rollout_pair(gpu, cfg, occ, n_peds, steps, seed, noise=False):
     """Runs the same world through the HIP step and the oracle; yields per-step comparisons."""
     torch = gpu.torch
-    field = gpu.sim.build_dt(_t(gpu, occ))
-    arrays = gpu.world.make_world(cfg, occ, n_peds=n_peds, device=gpu.dev, field=field)
+    arrays = gpu.world.make_world(cfg, occ, n_peds=n_peds, device=gpu.dev)
     key = "keti"
     from nav_gym_amd import robots
     arrays["scan_threshold"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array(key, "threshold_footprint")))
     arrays["scan_discomfort"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array(key, "discomfort_threshold_footprint")))
-    host = {k: v.cpu().numpy() for k, v in arrays.items()}
+    host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow")}
+    host["field"] = ref.build_dt(occ)                 # the oracle always reads its own float32 field
     g = gpu.sim.NavSim(cfg, arrays)
     r = ref.RefSim(cfg, host)
     _eq(g.reset_obs().cpu().numpy(), r.reset_obs(), "reset obs")
@@ -221,13 +229,15 @@ def _rollout_pair(gpu, cfg, occ, n_peds, steps, seed, noise=False):
         yield t, go.cpu().numpy(), {k: v.cpu().numpy() for k, v in gout.items()}, ro, rout, g, r
 
 
+@pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T])
 @pytest.mark.parametrize("ped_model,S,auto_reset", [(abi.PED_NONE, 1, 1), (abi.PED_SFM, 2, 1), (abi.PED_EXTERNAL, 3, 0)])
-def test_step_rollout_vs_oracle(gpu, ped_model, S, auto_reset):
+def test_step_rollout_vs_oracle(gpu, ped_model, S, auto_reset, fmt):
     """48 arenas x 60 steps on 240x240 maps, 1081 beams: every output and every state array of the
-    fused kernel equals the oracle's, bit for bit, including crash reverts and respawns."""
+    fused kernel equals the oracle's, bit for bit, including crash reverts and respawns -- for the
+    float32 field and for the packed uint16 tile field the bench streams."""
     E, size, N = 48, 240, 8
     cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, n_scan_stack=S, ped_model=ped_model,
-                                 auto_reset=auto_reset, n_spawn=8, seed=4242)
+                                 auto_reset=auto_reset, n_spawn=8, seed=4242, field_format=fmt)
     gpu.world.lidar_1081(cfg)
     occ = gpu.world.make_maps(E, size, 4242)
     crashes = resets = 0
@@ -239,10 +249,45 @@ def test_step_rollout_vs_oracle(gpu, ped_model, S, auto_reset):
         if t % 10 == 9:
             gs = g.numpy_state()
             for k, v in r.a.items():
-                if k in gs and k not in ("field",):
+                if k in gs and k not in ("field", "field_overflow"):
                     _eq(gs[k], v, "state %s at step %d" % (k, t))
     assert crashes > 0, "rollout never exercised the crash-revert branch"
     assert resets > 0
+
+
+def test_packed_field_decodes_to_float_field(gpu):
+    """uint16 tiles: sqrtf(d2) must be the float32 field bit for bit; odd sizes exercise edge tiles."""
+    for size, n in ((100, 2), (253, 2), (500, 1)):
+        occ = gpu.world.make_maps(n, size, 31 + size)
+        packed, f32, nsat = gpu.sim.build_field(_t(gpu, occ), abi.FIELD_U16T)
+        _eq(f32.cpu().numpy(), ref.build_dt(occ), "overflow plane %d" % size)
+        assert nsat == 0
+        tpr = (size + 7) // 8
+        raw = packed.cpu().numpy().view(np.uint16).reshape(n, tpr, tpr, 8, 8)
+        full = raw.transpose(0, 1, 3, 2, 4).reshape(n, tpr * 8, tpr * 8)[:, :size, :size]
+        _eq(np.sqrt(full.astype(np.float32)), ref.build_dt(occ), "decoded tiles %d" % size)
+
+
+def test_packed_field_overflow_path(gpu):
+    """An arena with > 256 cells of free space around the robot: the packed field saturates and the
+    step must read the exact float32 overflow plane (results still bit-identical to the oracle)."""
+    E, size = 4, 720
+    occ = np.zeros((E, size, size), np.uint8)
+    occ[:, :5] = 1; occ[:, -5:] = 1; occ[:, :, :5] = 1; occ[:, :, -5:] = 1
+    occ[:, 350:370, 100:120] = 1
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, n_spawn=4, auto_reset=1, seed=5,
+                                 field_format=abi.FIELD_U16T)
+    gpu.world.lidar_1081(cfg)
+    packed, f32, nsat = gpu.sim.build_field(_t(gpu, occ), abi.FIELD_U16T)
+    assert nsat > 0
+    seen = 0
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=0, steps=25, seed=3):
+        assert "field_overflow" in g.t
+        _eq(go, ro, "obs at step %d" % t)
+        for k in rout:
+            _eq(gout[k], rout[k], "%s at step %d" % (k, t))
+        seen += 1
+    assert seen == 25
 
 
 def test_config1_single_env_64_beams(gpu):
