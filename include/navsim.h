@@ -73,7 +73,7 @@ typedef struct navsim_config {
     int32_t add_scan_noise;  /* 1: Gaussian noise on beams != range_max (env.py:437-440) */
     int32_t env_index_base;  /* global index of local env 0 (multi-GPU sharding; seeds RNG) */
     int32_t field_format;    /* NAVSIM_FIELD_* of navsim_state.field */
-    int32_t reserved0;
+    int32_t shared_field;    /* 1: every arena reads arena 0's field (one map for the whole batch) */
 
     double resolution;       /* metres per cell (map_generator.py:116) */
     double origin_x, origin_y;
@@ -149,6 +149,11 @@ typedef struct navsim_state {
     /* auto-reset tables */
     const double* spawn_pose;       /* [E,K,3] */
     const double* spawn_goal;       /* [E,K,2] */
+
+    /* scratch of navsim_step_workspace_bytes(cfg) bytes.  Non-NULL selects the pooled schedule
+     * (per-arena prologue -> one flat pool of 64-beam march tasks -> per-arena epilogue, DESIGN.md
+     * section 6); NULL runs the whole step as one launch.  Results are identical. */
+    void* workspace;
 } navsim_state;
 
 /* What step() returns (env.py:728) with a leading env axis. */
@@ -237,6 +242,8 @@ int navsim_beam_table(const navsim_config* cfg, double* table, void* stream);
  * respawn) with re-scan, observation packing.  State is updated in place. */
 int navsim_step(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                 void* stream);
+
+size_t navsim_step_workspace_bytes(const navsim_config* cfg);
 
 /* First observation after reset() (env.py:822-831): scan at the current robot pose, stack filled
  * with copies, prev_pose = pose, vel = 0; sets prev_pose/prev_action/n_hist.  `mask` [E] uint8 or

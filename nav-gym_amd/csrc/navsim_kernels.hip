@@ -333,12 +333,21 @@ struct StepShared {
     int nseg, ndisc;
     int rescan;
     int respawn;
+    float t1;                     // march parameter after the shared first probe (origin cell)
+    float r_all;                  // >= 0: every beam has this raw range (origin occupied / no march)
+    unsigned long long step_key;  // scan-noise counter of this step
+    double wave_ratio[kMaxWaves];
+};
+constexpr size_t kPoolEnvBytes = 512;     // StepShared slot per arena in the step workspace
+static_assert(sizeof(StepShared) <= kPoolEnvBytes, "StepShared must fit its workspace slot");
+// only instantiated by the pedestrian variants of the kernel (LDS budget: 8 arenas per CU without)
+struct PedShared {
     float seg[4 * NAVSIM_MAX_PEDS][4];
     float disc[2 * NAVSIM_MAX_PEDS][2];
     double ax[NAVSIM_MAX_PEDS + 1], ay[NAVSIM_MAX_PEDS + 1];
     double avx[NAVSIM_MAX_PEDS + 1], avy[NAVSIM_MAX_PEDS + 1];
-    double wave_ratio[kMaxWaves];
 };
+struct Prims { const float (*seg)[4]; const float (*disc)[2]; };
 
 // robot scan (env.py:385-441 with other_agents = all pedestrians).  Writes the latest-scan slot
 // of the observation row and every "not yet filled" stack slot (env.py:262-265).
@@ -351,6 +360,7 @@ struct StepShared {
 template <int BLOCK, int R, typename Field>
 __device__ __forceinline__ void scan_beams(const navsim_config& c, const StepShared& sh,
                                            const Field& field, const double* __restrict__ tab,
+                                           const Prims pr,
                                            const float* __restrict__ thr, const float* __restrict__ dthr,
                                            float* __restrict__ obs_row, int n_hist, float noise_std,
                                            uint64_t noise_key, uint64_t genv,
@@ -387,9 +397,9 @@ __device__ __forceinline__ void scan_beams(const navsim_config& c, const StepSha
                 fast = nv::beam_dir_from_table(cs.x, cs.y, sh.cT, sh.sT, delta, dx[q], dy[q]);
             }
             if (!fast) nv::beam_dir(heading, dx[q], dy[q]);
-            t[q] = 0.0f;
-            r[q] = max_range;
-            active |= valid ? (1u << q) : 0u;
+            t[q] = sh.t1;                              // the t = 0 probe (origin cell) was taken once
+            r[q] = (sh.r_all >= 0.0f) ? sh.r_all : max_range;
+            active |= (valid && sh.r_all < 0.0f) ? (1u << q) : 0u;
         }
         // range_libc RayMarching::calc_range (env.py:425), R rays per thread in lock-step.  The hit
         // distance is evaluated once after the march (hx, hy), not speculatively in every round.
@@ -444,9 +454,9 @@ __device__ __forceinline__ void scan_beams(const navsim_config& c, const StepSha
             if (k < B) {
                 float rr = r[q] * res;                                  // env.py:426
                 for (int p = 0; p < nseg; ++p)
-                    nv::seg_merge(rr, lx, ly, dx[q], dy[q], sh.seg[p][0], sh.seg[p][1], sh.seg[p][2], sh.seg[p][3]);
+                    nv::seg_merge(rr, lx, ly, dx[q], dy[q], pr.seg[p][0], pr.seg[p][1], pr.seg[p][2], pr.seg[p][3]);
                 for (int p = 0; p < ndisc; ++p)
-                    nv::circle_merge(rr, lx, ly, dx[q], dy[q], sh.disc[p][0], sh.disc[p][1], nv::kLegRadius);
+                    nv::circle_merge(rr, lx, ly, dx[q], dy[q], pr.disc[p][0], pr.disc[p][1], nv::kLegRadius);
                 rr = rr < 0.0f ? 0.0f : rr;                             // env.py:435
                 rr = rr > rmax ? rmax : rr;
                 if (noise_std > 0.0f && rr != rmax)                     // env.py:437-440
@@ -463,18 +473,257 @@ __device__ __forceinline__ void scan_beams(const navsim_config& c, const StepSha
     discomfort = dc;
 }
 
-template <int BLOCK, int R, bool PEDS, typename Field>
+// direction of beam k (env.py:388-390, 424): table fast path with proven rounding, else full sincos
+__device__ __forceinline__ void beam_dir_k(const navsim_config& c, const double* __restrict__ tab, int k,
+                                           double step, double lth, double cT, double sT,
+                                           float& dx, float& dy) {
+    const double lin = nv::linspace_k(c, k, step);
+    double ang = lin + lth;
+    float heading = (float)ang;
+    bool fast = false;
+    if (tab) {
+        // heading = lin + lth + delta EXACTLY: (heading - ang) is exact (Sterbenz), and the
+        // rounding error of the float64 sum is recovered by TwoSum
+        double bb = ang - lin;
+        double eps = (lin - (ang - bb)) + (lth - bb);
+        double delta = ((double)heading - ang) + eps;
+        double2 cs = ((const double2*)tab)[k];
+        fast = nv::beam_dir_from_table(cs.x, cs.y, cT, sT, delta, dx, dy);
+    }
+    if (!fast) nv::beam_dir(heading, dx, dy);
+}
+
+// the t = 0 sample of calc_range is the origin cell for every beam: take it once per scan
+template <typename Field>
+__device__ __forceinline__ void first_probe(const Field& field, int i0, int j0, float max_range,
+                                            float& t1, float& r_all) {
+    t1 = 0.0f; r_all = -1.0f;
+    typename Field::raw_t raw0 = field.load(i0, j0);               // origin is clipped into the map
+    if (field.occupied(raw0)) { r_all = 0.0f; return; }            // sqrtf(0): starts inside an obstacle
+    float d0 = field.decode(raw0, i0, j0);
+    float stp = (float)((double)d0 * 0.999);
+    t1 = (stp > 1.0f) ? stp : 1.0f;
+    if (!(t1 < max_range)) r_all = max_range;
+}
+
+// one ray of calc_range from t = t1 on (env.py:425); returns the raw range in cells
+template <typename Field>
+__device__ __forceinline__ float march_ray(const Field& field, float x0, float y0, float dx, float dy,
+                                           float t, float max_range, unsigned uW, unsigned uH) {
+    for (;;) {
+        float fx = x0 + dx * t;
+        float fy = y0 + dy * t;
+        int px = (int)fx, py = (int)fy;
+        if (!(((unsigned)px < uW) & ((unsigned)py < uH))) return max_range;     // left the map
+        typename Field::raw_t raw = field.load(px, py);
+        if (field.occupied(raw)) {
+            float xd = (float)px - x0;
+            float yd = (float)py - y0;
+            return sqrtf(xd * xd + yd * yd);
+        }
+        float dq = field.decode(raw, px, py);
+        float stp = (float)((double)dq * 0.999);
+        t += (stp > 1.0f) ? stp : 1.0f;
+        if (!(t < max_range)) return max_range;
+    }
+}
+
+// raw ranges (cells) -> metres, pedestrians, clip, noise, crash / discomfort flags, observation row
+// (env.py:426-440 + the stack fill of env.py:262-265).  `dir` may be NULL: directions are then
+// recomputed (same function, same values) for the beams that need them.
+template <int BLOCK>
+__device__ __forceinline__ void finish_beams(const navsim_config& c, const StepShared& sh, const Prims pr,
+                                             const double* __restrict__ tab, const float2* __restrict__ dir,
+                                             const float* __restrict__ rng,
+                                             const float* __restrict__ thr, const float* __restrict__ dthr,
+                                             float* __restrict__ obs_row, int n_hist, float noise_std,
+                                             uint64_t noise_key, uint64_t genv, int& crash, int& discomfort) {
+    const int B = c.n_beams, S = c.n_scan_stack;
+    const float res = (float)c.resolution;
+    const float rmax = (float)c.range_max;
+    const double step = nv::linspace_step(c);
+    const float lx = sh.lx, ly = sh.ly;
+    const int nseg = sh.nseg, ndisc = sh.ndisc;
+    const float r_all = sh.r_all;
+    int cr = 0, dc = 0;
+    for (int k = (int)threadIdx.x; k < B; k += BLOCK) {
+        float rr = ((r_all >= 0.0f) ? r_all : rng[k]) * res;       // env.py:426
+        if (nseg | ndisc) {
+            float dx, dy;
+            if (dir) { float2 d = dir[k]; dx = d.x; dy = d.y; }
+            else beam_dir_k(c, tab, k, step, (double)sh.lth, sh.cT, sh.sT, dx, dy);
+            for (int p = 0; p < nseg; ++p)
+                nv::seg_merge(rr, lx, ly, dx, dy, pr.seg[p][0], pr.seg[p][1], pr.seg[p][2], pr.seg[p][3]);
+            for (int p = 0; p < ndisc; ++p)
+                nv::circle_merge(rr, lx, ly, dx, dy, pr.disc[p][0], pr.disc[p][1], nv::kLegRadius);
+        }
+        rr = rr < 0.0f ? 0.0f : rr;                                 // env.py:435
+        rr = rr > rmax ? rmax : rr;
+        if (noise_std > 0.0f && rr != rmax)                         // env.py:437-440
+            rr = rr + noise_std * nv::gauss_noise(c.seed ^ noise_key, genv, noise_key, (uint32_t)k);
+        cr |= (rr < thr[k]);
+        dc |= (rr < dthr[k]);
+        obs_row[(size_t)(S - 1) * B + k] = rr;
+        for (int j = 0; j < S - 1; ++j)
+            if (S - 1 - j > n_hist) obs_row[(size_t)j * B + k] = rr;
+    }
+    crash = cr;
+    discomfort = dc;
+}
+
+// Wave-dynamic robot scan (R == 0 variants; the default).  Same results as scan_beams, different
+// schedule, built on what the profiles showed (profiles/README.md):
+//   * lanes of a wave finish their rays after very different numbers of probes (mean 7.9, wave
+//     maximum 13.5), so with one fixed ray per lane 45 % of the issue slots idle.  Here every wave
+//     owns a contiguous fan of beams and a lane that finishes a ray immediately takes the next
+//     unassigned beam of its wave (ballot + popcount, no atomics) -- "persistent lanes";
+//   * beam directions are produced once per scan by a coalesced pass into LDS, so a refill is one
+//     ds_read_b64; ranges go back to LDS and a second coalesced pass merges pedestrians, clips,
+//     adds noise, raises the crash / discomfort flags and stores the observation row;
+//   * the first probe (the robot's own cell) is identical for every beam and is taken once.
+template <int BLOCK, typename Field>
+__device__ __forceinline__ void scan_beams_dyn(const navsim_config& c, StepShared& sh,
+                                               const Field& field, const double* __restrict__ tab,
+                                               const Prims pr, float2* __restrict__ dir, float* __restrict__ rng,
+                                               const float* __restrict__ thr, const float* __restrict__ dthr,
+                                               float* __restrict__ obs_row, int n_hist, float noise_std,
+                                               uint64_t noise_key, uint64_t genv,
+                                               int& crash, int& discomfort) {
+    const int B = c.n_beams, H = c.map_h, W = c.map_w;
+    const float max_range = (float)((long long)H * W);       // env.py:337
+    const double step = nv::linspace_step(c);
+    const float x0 = (float)sh.i0, y0 = (float)sh.j0;
+    const int tid = (int)threadIdx.x;
+
+    // ---- pass 1: beam directions -> LDS
+    for (int k = tid; k < B; k += BLOCK) {
+        float dx, dy;
+        beam_dir_k(c, tab, k, step, (double)sh.lth, sh.cT, sh.sT, dx, dy);
+        dir[k] = make_float2(dx, dy);
+    }
+    const float t1 = sh.t1, r_all = sh.r_all;                // first probe, taken by thread 0 earlier
+    __syncthreads();
+
+    // ---- pass 2: march (env.py:425), persistent lanes
+    if (r_all < 0.0f) {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int per = (B + (BLOCK / 64) - 1) / (BLOCK / 64);
+        int next = wave * per;
+        const int end = (next + per < B) ? next + per : B;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const unsigned uW = (unsigned)W, uH = (unsigned)H;
+        bool active = false;
+        int k = 0;
+        float t = 0.0f, dx = 0.0f, dy = 0.0f;
+        for (;;) {
+            unsigned long long idle = __ballot(!active);
+            if (next < end && idle) {
+                int my = next + __popcll(idle & lt);
+                if (!active && my < end) {
+                    k = my;
+                    float2 d = dir[k];
+                    dx = d.x; dy = d.y;
+                    t = t1;
+                    active = true;
+                }
+                next += __popcll(idle);
+            }
+            if (!__any(active)) break;
+            if (active) {
+                float fx = x0 + dx * t;
+                float fy = y0 + dy * t;
+                int px = (int)fx, py = (int)fy;
+                if (!(((unsigned)px < uW) & ((unsigned)py < uH))) {
+                    rng[k] = max_range;                             // left the map
+                    active = false;
+                } else {
+                    typename Field::raw_t raw = field.load(px, py);
+                    if (field.occupied(raw)) {
+                        float xd = (float)px - x0;
+                        float yd = (float)py - y0;
+                        rng[k] = sqrtf(xd * xd + yd * yd);
+                        active = false;
+                    } else {
+                        float dq = field.decode(raw, px, py);
+                        float stp = (float)((double)dq * 0.999);
+                        t += (stp > 1.0f) ? stp : 1.0f;
+                        if (!(t < max_range)) { rng[k] = max_range; active = false; }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 3
+    finish_beams<BLOCK>(c, sh, pr, tab, dir, rng, thr, dthr, obs_row, n_hist, noise_std, noise_key, genv,
+                        crash, discomfort);
+}
+
+// ============================================================================================
+// Pool scan: the march of ALL arenas as one flat pool of 64-beam wave tasks.  No workgroup barrier,
+// no idle waves waiting for an arena's slowest fan: a CU always holds 32 marching waves, whatever
+// the number of arenas.  Reads each arena's scan request (StepShared slot in the workspace), writes
+// raw ranges in cells.  `only_flagged`: the re-scan after a crash revert / respawn (env.py:718-723).
+// ============================================================================================
+template <typename Field>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void pool_scan_kernel(navsim_config c, navsim_state st, char* __restrict__ ws_env, float* __restrict__ ranges,
+                      int only_flagged, unsigned n_blocks_logical) {
+    // XCD-aware block order: consecutive logical blocks (the fans of one arena) share an XCD's L2
+    const unsigned nb = gridDim.x;
+    unsigned bid = blockIdx.x;
+    if ((nb & 7u) == 0u) bid = (bid & 7u) * (nb >> 3) + (bid >> 3);
+    if (bid >= n_blocks_logical) return;
+    const int B = c.n_beams;
+    const int G = (B + 63) >> 6;
+    const unsigned task = bid * 4u + (threadIdx.x >> 6);
+    const int e = (int)(task / (unsigned)G);
+    if (e >= c.n_envs) return;
+    const int g = (int)(task - (unsigned)e * (unsigned)G);
+    const StepShared* __restrict__ s = (const StepShared*)(ws_env + (size_t)e * kPoolEnvBytes);
+    if (only_flagged && !s->rescan) return;
+    const float r_all = s->r_all;
+    if (r_all >= 0.0f) return;                                   // finish_beams supplies the range
+    const int k = g * 64 + (int)(threadIdx.x & 63);
+    if (k >= B) return;
+    const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, c.map_h, c.map_w);
+    float dx, dy;
+    beam_dir_k(c, st.beam_table, k, nv::linspace_step(c), (double)s->lth, s->cT, s->sT, dx, dy);
+    const float max_range = (float)((long long)c.map_h * c.map_w);
+    ranges[(size_t)e * B + k] = march_ray(field, (float)s->i0, (float)s->j0, dx, dy, s->t1, max_range,
+                                          (unsigned)c.map_w, (unsigned)c.map_h);
+}
+
+// MODE 0: the whole step in one launch.  MODE 1 / 2 / 3: the same code cut at the scan, for the
+// pooled schedule (navsim_step with a workspace): 1 = everything before the scan, then the arena's
+// StepShared (+ pedestrian primitives) is parked in the workspace; pool_scan_kernel marches;
+// 2 = flags, reward / done / info, relocation decision and -- unless the arena must be re-scanned --
+// the observation row and state; 3 = the same tail for re-scanned arenas.
+enum { kModeFused = 0, kModePre = 1, kModePost = 2, kModeFinal = 3 };
+
+template <int BLOCK, int R, bool PEDS, typename Field, int MODE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void navsim_step_kernel(navsim_config c, navsim_state st,
                                                             navsim_step_io io, int reset_only,
-                                                            const uint8_t* __restrict__ reset_mask) {
+                                                            const uint8_t* __restrict__ reset_mask,
+                                                            char* __restrict__ ws_env, char* __restrict__ ws_prims,
+                                                            float* __restrict__ ws_ranges) {
     __shared__ StepShared sh;
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];   // R == 0: float2 dir[B], float rng[B]
+    PedShared* psp = nullptr;
+    if constexpr (PEDS) {
+        __shared__ PedShared ps_storage;
+        psp = &ps_storage;
+    }
+    PedShared& ps = *psp;
+    const Prims prims = {PEDS ? ps.seg : nullptr, PEDS ? ps.disc : nullptr};
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
     const int B = c.n_beams, S = c.n_scan_stack, N = c.max_peds, D = S * B + 7;
     const int P = NAVSIM_MAX_WAYPOINTS;
     const double dt = c.time_step;
     const uint64_t genv = (uint64_t)(c.env_index_base + e);
-    const Field field(st.field, st.field_overflow, e, c.map_h, c.map_w);
+    const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, c.map_h, c.map_w);
     float* obs_row = io.obs + (size_t)e * D;
     const float* obs_prev = io.obs_prev ? io.obs_prev + (size_t)e * D : nullptr;
     double* rp_g = st.robot_pose + 3 * (size_t)e;
@@ -483,9 +732,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     double* pv_g = st.prev_pose + 3 * (size_t)e;
 
     if (reset_only && reset_mask && !reset_mask[e]) {          // untouched env: carry the row over
-        if (obs_prev)
+        if ((MODE == kModeFused || MODE == kModePre) && obs_prev)
             for (int k = tid; k < D; k += BLOCK) obs_row[k] = obs_prev[k];
         return;
+    }
+    StepShared* slot = (MODE == kModeFused) ? nullptr : (StepShared*)(ws_env + (size_t)e * kPoolEnvBytes);
+    constexpr int kPrimWords = (int)((sizeof(float) * 4 * 4 * NAVSIM_MAX_PEDS + sizeof(float) * 2 * 2 * NAVSIM_MAX_PEDS) / 4);
+    if constexpr (MODE == kModePost || MODE == kModeFinal) {
+        if (MODE == kModeFinal && !slot->rescan) return;        // nothing was re-scanned for this arena
+        for (int i = tid; i < (int)(sizeof(StepShared) / 4); i += BLOCK) ((int*)&sh)[i] = ((const int*)slot)[i];
+        if constexpr (PEDS) {
+            const int* src = (const int*)(ws_prims + (size_t)e * kPrimWords * 4);
+            for (int i = tid; i < kPrimWords; i += BLOCK) ((int*)&ps)[i] = src[i];     // seg, then disc
+        }
+        __syncthreads();
     }
 
     int n = (!PEDS || c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
@@ -493,6 +753,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const float noise_std = (c.add_scan_noise && st.scan_noise_std) ? st.scan_noise_std[e] : 0.0f;
 
     NAVSIM_STAMP(0);
+    if constexpr (MODE == kModeFused || MODE == kModePre) {
     // ---------------------------------------------------------------- phase 0: scalars
     if (tid == 0) {
         sh.old_rp[0] = rp_g[0]; sh.old_rp[1] = rp_g[1]; sh.old_rp[2] = rp_g[2];
@@ -541,31 +802,31 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         }
         if (c.ped_model == NAVSIM_PED_SFM) {
             // stage every agent's position / velocity at time t (pedestrians, then the robot)
-            if (is_ped) { sh.ax[tid] = pp[0]; sh.ay[tid] = pp[1]; sh.avx[tid] = pvel[0]; sh.avy[tid] = pvel[1]; }
+            if (is_ped) { ps.ax[tid] = pp[0]; ps.ay[tid] = pp[1]; ps.avx[tid] = pvel[0]; ps.avy[tid] = pvel[1]; }
             if (tid == 0) {
                 double s, cs;
                 nv::sincos(sh.old_rp[2], s, cs);
-                sh.ax[n] = sh.old_rp[0]; sh.ay[n] = sh.old_rp[1];
-                sh.avx[n] = pa_g[0] * cs; sh.avy[n] = pa_g[0] * s;
+                ps.ax[n] = sh.old_rp[0]; ps.ay[n] = sh.old_rp[1];
+                ps.avx[n] = pa_g[0] * cs; ps.avy[n] = pa_g[0] * s;
             }
             __syncthreads();
             if (is_ped) {
                 const int i = tid;
                 double vpref = st.ped_v_pref[pq];
-                double ex = wp[0] - sh.ax[i], ey = wp[1] - sh.ay[i];
+                double ex = wp[0] - ps.ax[i], ey = wp[1] - ps.ay[i];
                 double L = sqrt(ex * ex + ey * ey);
                 if (L > 1e-9) { ex = ex / L; ey = ey / L; } else { ex = 0.0; ey = 0.0; }
-                double fdx = (vpref * ex - sh.avx[i]) / c.sfm_tau;
-                double fdy = (vpref * ey - sh.avy[i]) / c.sfm_tau;
+                double fdx = (vpref * ex - ps.avx[i]) / c.sfm_tau;
+                double fdy = (vpref * ey - ps.avy[i]) / c.sfm_tau;
                 double fsx = 0.0, fsy = 0.0;
                 for (int j = 0; j <= n; ++j) {
                     if (j == i) continue;
-                    double dxx = sh.ax[j] - sh.ax[i], dyy = sh.ay[j] - sh.ay[i];
+                    double dxx = ps.ax[j] - ps.ax[i], dyy = ps.ay[j] - ps.ay[i];
                     double dist = sqrt(dxx * dxx + dyy * dyy);
                     if (dist < 1e-9) continue;
                     double ddx = dxx / dist, ddy = dyy / dist;
-                    double ivx = c.sfm_lambda * (sh.avx[i] - sh.avx[j]) + ddx;
-                    double ivy = c.sfm_lambda * (sh.avy[i] - sh.avy[j]) + ddy;
+                    double ivx = c.sfm_lambda * (ps.avx[i] - ps.avx[j]) + ddx;
+                    double ivy = c.sfm_lambda * (ps.avy[i] - ps.avy[j]) + ddy;
                     double il = sqrt(ivx * ivx + ivy * ivy);
                     if (il < 1e-9) continue;
                     double idx = ivx / il, idy = ivy / il;
@@ -583,7 +844,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 {
                     const int H = c.map_h, W = c.map_w;
                     int ci, cj;
-                    nv::xy_to_ij(sh.ax[i], sh.ay[i], c, ci, cj);
+                    nv::xy_to_ij(ps.ax[i], ps.ay[i], c, ci, cj);
                     ci = ci > W - 1 ? W - 1 : ci;
                     cj = cj > H - 1 ? H - 1 : cj;
                     int il_ = ci > 0 ? ci - 1 : 0, ir = ci < W - 1 ? ci + 1 : W - 1;
@@ -600,8 +861,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 }
                 double accx = c.sfm_k_desired * fdx + c.sfm_k_social * fsx + c.sfm_k_obstacle * fox;
                 double accy = c.sfm_k_desired * fdy + c.sfm_k_social * fsy + c.sfm_k_obstacle * foy;
-                double vx = sh.avx[i] + accx * dt;
-                double vy = sh.avy[i] + accy * dt;
+                double vx = ps.avx[i] + accx * dt;
+                double vy = ps.avy[i] + accy * dt;
                 double sp = sqrt(vx * vx + vy * vy);
                 if (sp > vpref) {
                     double k = (sp > 0.0) ? vpref / sp : 0.0;
@@ -665,8 +926,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             float cc[4];
             nv::leg_centres((float)pp[0], (float)pp[1], (float)pp[2], dist3[0], dist3[1], dist3[2], cc);
             int q = atomicAdd(&sh.ndisc, 2);
-            sh.disc[q][0] = cc[0]; sh.disc[q][1] = cc[1];
-            sh.disc[q + 1][0] = cc[2]; sh.disc[q + 1][1] = cc[3];
+            ps.disc[q][0] = cc[0]; ps.disc[q][1] = cc[1];
+            ps.disc[q + 1][0] = cc[2]; ps.disc[q + 1][1] = cc[3];
         } else {
             const double fpx[4] = {0.22, -0.22, -0.22, 0.22};   // human.py:5-10
             const double fpy[4] = {0.19, 0.19, -0.19, -0.19};
@@ -682,8 +943,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 int w = (v + 1) & 3;
-                sh.seg[q + v][0] = vx[v]; sh.seg[q + v][1] = vy[v];
-                sh.seg[q + v][2] = vx[w]; sh.seg[q + v][3] = vy[w];
+                ps.seg[q + v][0] = vx[v]; ps.seg[q + v][1] = vy[v];
+                ps.seg[q + v][2] = vx[w]; ps.seg[q + v][3] = vy[w];
             }
         }
     }
@@ -691,19 +952,41 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];   // env.py:386
         nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);                              // env.py:419
         nv::sincos((double)sh.lth, sh.sT, sh.cT);
+        first_probe(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
+        sh.step_key = (unsigned long long)st.episode[e] * 0x100000000ULL +
+                      (unsigned long long)(reset_only ? 0 : st.steps[e]) * 2ULL;
     }
     __syncthreads();
+    if constexpr (MODE == kModePre) {                           // park the arena, the pool marches next
+        for (int i = tid; i < (int)(sizeof(StepShared) / 4); i += BLOCK) ((int*)slot)[i] = ((const int*)&sh)[i];
+        if constexpr (PEDS) {
+            int* dst = (int*)(ws_prims + (size_t)e * kPrimWords * 4);
+            for (int i = tid; i < kPrimWords; i += BLOCK) dst[i] = ((const int*)&ps)[i];
+        }
+        return;
+    }
+    }   // MODE fused / pre
 
     NAVSIM_STAMP(2);
     // ---------------------------------------------------------------- phase 3: scan A
     int n_hist = reset_only ? 0 : st.n_hist[e];
+    if (MODE == kModeFinal && sh.respawn) n_hist = 0;
     int crash = 0, discomfort = 0;
-    const uint64_t step_key = (uint64_t)st.episode[e] * 0x100000000ULL + (uint64_t)(reset_only ? 0 : st.steps[e]) * 2;
-    scan_beams<BLOCK, R, Field>(c, sh, field, st.beam_table, st.scan_threshold, st.scan_discomfort, obs_row, n_hist, noise_std,
-                      step_key, genv, crash, discomfort);
+    const uint64_t step_key = sh.step_key + (MODE == kModeFinal ? 1 : 0);
+    float2* dir_lds = (float2*)dyn_lds;
+    float* rng_lds = (float*)(dyn_lds + sizeof(float2) * (size_t)B);
+    if constexpr (MODE != kModeFused)
+        finish_beams<BLOCK>(c, sh, prims, st.beam_table, nullptr, ws_ranges + (size_t)e * B, st.scan_threshold,
+                            st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
+    else if constexpr (R == 0)
+        scan_beams_dyn<BLOCK, Field>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
+                                     st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
+    else
+        scan_beams<BLOCK, R, Field>(c, sh, field, st.beam_table, prims, st.scan_threshold, st.scan_discomfort,
+                                    obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
 
     NAVSIM_STAMP(3);
-    if (!reset_only) {
+    if (!reset_only && MODE != kModeFinal) {
         crash = __syncthreads_or(crash);
         discomfort = __syncthreads_or(discomfort);
         double rmin = 1.0e300;
@@ -751,15 +1034,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];
                 nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);
                 nv::sincos((double)sh.lth, sh.sT, sh.cT);
+                first_probe(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
             }
         }
         __syncthreads();
+        if constexpr (MODE == kModePost) {
+            if (sh.rescan) {                                    // hand the arena back to the pool
+                for (int i = tid; i < (int)(sizeof(StepShared) / 4); i += BLOCK) ((int*)slot)[i] = ((const int*)&sh)[i];
+                return;
+            }
+        }
         // ------------------------------------------------------------ phase 5: scan B (env.py:718-723)
-        if (sh.rescan) {
+        if (MODE == kModeFused && sh.rescan) {
             if (sh.respawn) n_hist = 0;
             int c2, d2;
-            scan_beams<BLOCK, R, Field>(c, sh, field, st.beam_table, st.scan_threshold, st.scan_discomfort, obs_row, n_hist,
-                              noise_std, step_key + 1, genv, c2, d2);
+            if constexpr (R == 0)
+                scan_beams_dyn<BLOCK, Field>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
+                                             st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
+            else
+                scan_beams<BLOCK, R, Field>(c, sh, field, st.beam_table, prims, st.scan_threshold, st.scan_discomfort,
+                                            obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
         }
     }
 
@@ -840,45 +1134,78 @@ __global__ __launch_bounds__(256) void gather_probe_kernel(const float* __restri
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? NAVSIM_OK : NAVSIM_E_LAUNCH; }
 
-// Launch geometry: BLOCK threads per arena, R rays per thread.  The default covers all beams in
-// one round with the fewest idle lanes; NAVSIM_STEP_VARIANT="<block>x<rays>" overrides (tuning).
-template <int BLOCK, int R>
+// Launch geometry: BLOCK threads per arena, R rays per thread (R = 0: wave-dynamic scan).
+// NAVSIM_STEP_VARIANT="<block>x<rays>" overrides the default of the one-launch schedule (tuning).
+template <int BLOCK, int R, int MODE>
 void launch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
-                        int reset_only, const uint8_t* mask, hipStream_t s) {
+                 int reset_only, const uint8_t* mask, char* ws_env, char* ws_prims, float* ws_ranges,
+                 hipStream_t s) {
     const bool peds = c->ped_model != NAVSIM_PED_NONE;
+    const size_t lds = (R == 0 && MODE == kModeFused) ? (size_t)c->n_beams * (sizeof(float2) + sizeof(float)) : 0;
     if (c->field_format == NAVSIM_FIELD_U16T) {
-        if (peds) navsim_step_kernel<BLOCK, R, true, FieldU16T><<<c->n_envs, BLOCK, 0, s>>>(*c, *st, *io, reset_only, mask);
-        else      navsim_step_kernel<BLOCK, R, false, FieldU16T><<<c->n_envs, BLOCK, 0, s>>>(*c, *st, *io, reset_only, mask);
+        if (peds) navsim_step_kernel<BLOCK, R, true, FieldU16T, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges);
+        else      navsim_step_kernel<BLOCK, R, false, FieldU16T, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges);
     } else {
-        if (peds) navsim_step_kernel<BLOCK, R, true, FieldF32><<<c->n_envs, BLOCK, 0, s>>>(*c, *st, *io, reset_only, mask);
-        else      navsim_step_kernel<BLOCK, R, false, FieldF32><<<c->n_envs, BLOCK, 0, s>>>(*c, *st, *io, reset_only, mask);
+        if (peds) navsim_step_kernel<BLOCK, R, true, FieldF32, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges);
+        else      navsim_step_kernel<BLOCK, R, false, FieldF32, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges);
     }
 }
 
+constexpr size_t kPrimBytes = sizeof(float) * 4 * 4 * NAVSIM_MAX_PEDS + sizeof(float) * 2 * 2 * NAVSIM_MAX_PEDS;
+
+size_t workspace_bytes(const navsim_config* c) {
+    size_t E = (size_t)c->n_envs;
+    size_t b = E * kPoolEnvBytes + E * (size_t)c->n_beams * sizeof(float);
+    if (c->ped_model != NAVSIM_PED_NONE) b += E * kPrimBytes;
+    return b;
+}
+
+// pooled schedule: prologue per arena, one flat pool of march tasks, epilogue per arena, and the
+// same pair again for the (few) arenas that were reverted / respawned
+int run_pooled(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
+               const uint8_t* mask, hipStream_t s) {
+    const size_t E = (size_t)c->n_envs;
+    char* ws_env = (char*)st->workspace;
+    float* ws_ranges = (float*)(ws_env + E * kPoolEnvBytes);
+    char* ws_prims = (char*)(ws_ranges + E * (size_t)c->n_beams);
+    const unsigned G = (unsigned)((c->n_beams + 63) / 64);
+    const unsigned n_logical = (unsigned)((E * G + 3) / 4);
+    const unsigned grid = (n_logical + 7u) & ~7u;
+    launch_step<64, 1, kModePre>(c, st, io, reset_only, mask, ws_env, ws_prims, ws_ranges, s);
+    for (int pass = 0; pass < (reset_only ? 1 : 2); ++pass) {
+        if (c->field_format == NAVSIM_FIELD_U16T)
+            pool_scan_kernel<FieldU16T><<<grid, 256, 0, s>>>(*c, *st, ws_env, ws_ranges, pass, n_logical);
+        else
+            pool_scan_kernel<FieldF32><<<grid, 256, 0, s>>>(*c, *st, ws_env, ws_ranges, pass, n_logical);
+        if (pass == 0) launch_step<256, 1, kModePost>(c, st, io, reset_only, mask, ws_env, ws_prims, ws_ranges, s);
+        else           launch_step<256, 1, kModeFinal>(c, st, io, reset_only, mask, ws_env, ws_prims, ws_ranges, s);
+    }
+    return launch_status();
+}
+
 int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
-                         int reset_only, const uint8_t* mask, hipStream_t s) {
+                  int reset_only, const uint8_t* mask, hipStream_t s) {
+    const char* mode = getenv("NAVSIM_STEP_MODE");
+    if (st->workspace && mode && strcmp(mode, "pool") == 0)      // opt-in: measured slower than one launch
+        return run_pooled(c, st, io, reset_only, mask, s);
     int block = 0, rays = 0;
     const char* v = getenv("NAVSIM_STEP_VARIANT");
     if (v && sscanf(v, "%dx%d", &block, &rays) != 2) { block = 0; rays = 0; }
     if (!block) {
         const int B = c->n_beams;
         if (B <= 64) { block = 64; rays = 1; }
-        else if (B <= 256) { block = 256; rays = 1; }
         else { block = 256; rays = 1; }               // profiles/tune_variants.py
     }
-#define NAVSIM_VARIANT(BK, RR) if (block == BK && rays == RR) { launch_step<BK, RR>(c, st, io, reset_only, mask, s); return launch_status(); }
+#define NAVSIM_VARIANT(BK, RR) if (block == BK && rays == RR) { launch_step<BK, RR, kModeFused>(c, st, io, reset_only, mask, nullptr, nullptr, nullptr, s); return launch_status(); }
     NAVSIM_VARIANT(64, 1)
+    NAVSIM_VARIANT(256, 0)
     NAVSIM_VARIANT(256, 1)
     NAVSIM_VARIANT(256, 2)
-    NAVSIM_VARIANT(256, 3)
     NAVSIM_VARIANT(256, 5)
-    NAVSIM_VARIANT(256, 8)
-    NAVSIM_VARIANT(384, 3)
-    NAVSIM_VARIANT(512, 3)
+    NAVSIM_VARIANT(512, 0)
 #undef NAVSIM_VARIANT
     return NAVSIM_E_UNSUPPORTED;
 }
-
 
 }  // namespace
 
@@ -1075,6 +1402,8 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
     if (c->auto_reset && c->n_spawn > 0 && (!st->spawn_pose || !st->spawn_goal)) return NAVSIM_E_ARG;
     return NAVSIM_OK;
 }
+
+size_t navsim_step_workspace_bytes(const navsim_config* c) { return c ? workspace_bytes(c) : 0; }
 
 int navsim_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, void* stream) {
     int rc = check_step_args(c, st, io, 0);

@@ -42,7 +42,7 @@ class NavsimConfig(C.Structure):
         ("add_scan_noise", C.c_int32),
         ("env_index_base", C.c_int32),
         ("field_format", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("shared_field", C.c_int32),
         ("resolution", C.c_double),
         ("origin_x", C.c_double),
         ("origin_y", C.c_double),
@@ -88,7 +88,7 @@ class NavsimState(C.Structure):
         "robot_pose", "robot_goal", "prev_action", "prev_pose", "n_hist", "episode", "steps",
         "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist", "ped_v_pref", "ped_has_legs",
         "ped_waypoints", "ped_n_waypoints", "ped_cmd",
-        "spawn_pose", "spawn_goal",
+        "spawn_pose", "spawn_goal", "workspace",
     )]
 
 
@@ -183,6 +183,7 @@ def declare(lib, suffix=""):
     sig("navsim_scan_threshold", [cfgp, _P, i32, _P] + stream)
     if not suffix:
         sig("navsim_beam_table", [cfgp, _P, _P])
+        sig("navsim_step_workspace_bytes", [cfgp], C.c_size_t)
     sig("navsim_step", [cfgp, stp, iop] + stream)
     sig("navsim_reset_obs", [cfgp, stp, iop, _P] + stream)
     return lib
@@ -194,6 +195,6 @@ EXPORTS = (
     "navsim_build_dt_workspace_bytes", "navsim_build_dt", "navsim_field_bytes", "navsim_build_field",
     "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
-    "navsim_scan_threshold", "navsim_beam_table", "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
+    "navsim_scan_threshold", "navsim_beam_table", "navsim_step_workspace_bytes", "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math",
 )

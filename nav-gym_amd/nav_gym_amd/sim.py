@@ -178,6 +178,11 @@ class NavSim(object):
             check(self.lib.navsim_beam_table(C.byref(self.cfg), _ptr(tab), _stream()), "navsim_beam_table")
             self.t["beam_table"] = tab
             self.st.beam_table = tab.data_ptr()
+        import os
+        if os.environ.get("NAVSIM_STEP_MODE", "fused") == "pool":   # the pooled schedule needs scratch
+            nbytes = self.lib.navsim_step_workspace_bytes(C.byref(self.cfg))
+            self.t["workspace"] = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+            self.st.workspace = self.t["workspace"].data_ptr()
         E = self.cfg.n_envs
         D = self.cfg.n_scan_stack * self.cfg.n_beams + abi.OBS_TAIL
         self.obs_buf = [torch.zeros((E, D), dtype=torch.float32, device=self.device) for _ in range(2)]

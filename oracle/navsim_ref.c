@@ -502,7 +502,7 @@ static inline double linspace_k(const navsim_config* c, int k) {
 static void robot_scan(const navsim_config* c, const navsim_state* st, int e, int n_peds,
                        const double* pose, float* ranges) {
     const int B = c->n_beams, H = c->map_h, W = c->map_w;
-    const float* f = (const float*)st->field + (size_t)e * H * W;
+    const float* f = (const float*)st->field + (size_t)(c->shared_field ? 0 : e) * H * W;
     float lx = (float)pose[0], ly = (float)pose[1], lth = (float)pose[2];     /* env.py:386 */
     int i0, j0;
     xy_to_ij_f32(lx, ly, c, &i0, &j0);                                         /* env.py:419 */
@@ -631,7 +631,7 @@ int navsim_reward_done_cpu(const navsim_config* c, const void* obs, const void* 
 static void sfm_update(const navsim_config* c, const navsim_state* st, int e, int n,
                        const double* robot_pose, const double* robot_prev_action) {
     const int N = c->max_peds, H = c->map_h, W = c->map_w, P = NAVSIM_MAX_WAYPOINTS;
-    const float* f = (const float*)st->field + (size_t)e * H * W;
+    const float* f = (const float*)st->field + (size_t)(c->shared_field ? 0 : e) * H * W;
     double ax[NAVSIM_MAX_PEDS + 1], ay[NAVSIM_MAX_PEDS + 1];      /* agent positions (peds + robot) */
     double avx[NAVSIM_MAX_PEDS + 1], avy[NAVSIM_MAX_PEDS + 1];
     for (int i = 0; i < n; ++i) {

@@ -30,15 +30,18 @@ if step_ns:
     s = step_ns[1:] if len(step_ns) > 1 else step_ns
     print("navsim_step_kernel launches=%d avg_us=%.2f min_us=%.2f max_us=%.2f" % (len(s), sum(s) / len(s) / 1e3, min(s) / 1e3, max(s) / 1e3))
     print("last dispatch:", {k: last[k] for k in last if k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")})
-print("== PMC (per navsim_step_kernel dispatch, mean over steady-state dispatches) ==")
+KERNEL = os.environ.get("NAVSIM_PROFILE_KERNEL", "navsim_step_kernel")
+print("== PMC (per %s dispatch, mean over steady-state dispatches; pooled schedule: the two scan passes are averaged) ==" % KERNEL)
 res = {}
 for f in find("*counter_collection.csv"):
     acc = defaultdict(list)
     for row in csv.DictReader(open(f)):
-        if "navsim_step_kernel" in row.get("Kernel_Name", ""):
+        if KERNEL in row.get("Kernel_Name", ""):
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, v in acc.items():
         v = v[1:] if len(v) > 1 else v
+        if os.environ.get("NAVSIM_PROFILE_MAXHALF"):      # keep the larger half (main pass of the pool scan)
+            v = sorted(v)[len(v) // 2:]
         res[k] = sum(v) / len(v)
 for k in sorted(res):
     print("%-22s %.6g" % (k, res[k]))

@@ -19,6 +19,8 @@ K = 40
 wl = dict(bench.WORKLOADS[wl_name])
 wl["field"] = os.environ.get("NAVSIM_FIELD", "u16t")
 cfg, sim, arrays, _ = bench.build_sim(wl, 0, 1)
+if os.environ.get("NAVSIM_SHARED_FIELD"):            # diagnostic: all arenas march arena 0's field (L2-resident)
+    sim.cfg.shared_field = 1
 E = cfg.n_envs
 g = torch.Generator(device="cuda:0"); g.manual_seed(5)
 acts = torch.rand((K, E, 2), generator=g, device="cuda:0", dtype=torch.float64)
