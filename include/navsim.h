@@ -175,6 +175,8 @@ int         navsim_abi_version(void);
 const char* navsim_error_string(int code);
 /* Fills a config with the registered NavGym-v0 defaults (__init__.py:6-38, keti_robot.py:44-48). */
 int         navsim_default_config(navsim_config* cfg);
+/* hipGetErrorString of the launch failure behind the last NAVSIM_E_LAUNCH on the calling thread */
+const char* navsim_last_hip_error(void);
 
 /* ---- a3: range_libc.PyOMap + PyRayMarching.__init__ (env.py:337-340) -------------------- */
 /* Exact Euclidean distance transform of `occ` (nonzero = occupied), float32 cells.

@@ -1132,7 +1132,13 @@ __global__ __launch_bounds__(256) void gather_probe_kernel(const float* __restri
     out[gid] = acc;
 }
 
-inline int launch_status() { return hipGetLastError() == hipSuccess ? NAVSIM_OK : NAVSIM_E_LAUNCH; }
+thread_local hipError_t g_last_hip_error = hipSuccess;
+inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return NAVSIM_OK;
+    g_last_hip_error = e;
+    return NAVSIM_E_LAUNCH;
+}
 
 // Launch geometry: BLOCK threads per arena, R rays per thread (R = 0: wave-dynamic scan).
 // NAVSIM_STEP_VARIANT="<block>x<rays>" overrides the default of the one-launch schedule (tuning).
@@ -1285,6 +1291,7 @@ size_t navsim_field_bytes(int32_t n_maps, int32_t H, int32_t W, int32_t format) 
 int navsim_build_field(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, int32_t format, void* field,
                        float* overflow, int32_t* n_saturated, void* workspace, size_t workspace_bytes,
                        void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     if (!occ || !field || !workspace || n_maps < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
     if (format != NAVSIM_FIELD_F32 && format != NAVSIM_FIELD_U16T) return NAVSIM_E_UNSUPPORTED;
     if (H >= kDtInf || W >= kDtInf || (size_t)W * 4 > 64 * 1024) return NAVSIM_E_UNSUPPORTED;
@@ -1318,6 +1325,7 @@ int navsim_build_dt(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, fl
 
 int navsim_cast_static(const float* field, int32_t E, int32_t H, int32_t W, const float* q,
                        int32_t n_per_env, float max_range, float* out, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     if (!field || E < 0 || n_per_env < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
     long long total = (long long)E * n_per_env;
     if (total == 0) return NAVSIM_OK;
@@ -1329,6 +1337,7 @@ int navsim_cast_static(const float* field, int32_t E, int32_t H, int32_t W, cons
 
 int navsim_render_polys(float* ranges, const double* angles, int32_t E, int32_t B, const float* verts,
                         const int32_t* n_verts, int32_t V, const float* origin, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     if (!ranges || !angles || !verts || !n_verts || !origin || E < 0 || B < 0 || V < 0) return NAVSIM_E_ARG;
     if (E == 0 || B == 0) return NAVSIM_OK;
     render_polys_kernel<<<dim3((B + 255) / 256, E), 256, 0, (hipStream_t)stream>>>(ranges, angles, B, verts,
@@ -1338,6 +1347,7 @@ int navsim_render_polys(float* ranges, const double* angles, int32_t E, int32_t 
 
 int navsim_render_legs(float* ranges, const double* angles, int32_t E, int32_t B, const float* agents,
                        const int32_t* n_agents, int32_t A, const float* origin, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     if (!ranges || !angles || !agents || !n_agents || !origin || E < 0 || B < 0 || A < 0) return NAVSIM_E_ARG;
     if (E == 0 || B == 0) return NAVSIM_OK;
     render_legs_kernel<<<dim3((B + 255) / 256, E), 256, 0, (hipStream_t)stream>>>(ranges, angles, B, agents,
@@ -1347,6 +1357,7 @@ int navsim_render_legs(float* ranges, const double* angles, int32_t E, int32_t B
 
 int navsim_integrate(double* pose, const double* cmd, double* vel_out, int32_t n, double dt, double off,
                      void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     if (!pose || !cmd || n < 0) return NAVSIM_E_ARG;
     if (n == 0) return NAVSIM_OK;
     integrate_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(pose, cmd, vel_out, n, dt, off);
@@ -1356,6 +1367,7 @@ int navsim_integrate(double* pose, const double* cmd, double* vel_out, int32_t n
 int navsim_reward_done(const navsim_config* c, const void* obs, const void* goals, int32_t is64, int32_t n,
                        const float* thr, const float* dthr, double* reward, uint8_t* done,
                        float* is_success, float* is_crash, double* distance, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     if (!c || !obs || !goals || !thr || !dthr || n < 0) return NAVSIM_E_ARG;
     if (n == 0) return NAVSIM_OK;
     if (is64)
@@ -1368,12 +1380,14 @@ int navsim_reward_done(const navsim_config* c, const void* obs, const void* goal
 }
 
 int navsim_scan_threshold(const navsim_config* c, const float* fp, int32_t nvert, float* out, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     if (!c || !fp || !out || nvert < 2 || nvert > 16) return NAVSIM_E_ARG;
     scan_threshold_kernel<<<(c->n_beams + 255) / 256, 256, 0, (hipStream_t)stream>>>(*c, fp, nvert, out);
     return launch_status();
 }
 
 int navsim_beam_table(const navsim_config* c, double* table, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     if (!c || !table || c->n_beams < 1) return NAVSIM_E_ARG;
     beam_table_kernel<<<(c->n_beams + 255) / 256, 256, 0, (hipStream_t)stream>>>(*c, table);
     return launch_status();
@@ -1406,6 +1420,7 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
 size_t navsim_step_workspace_bytes(const navsim_config* c) { return c ? workspace_bytes(c) : 0; }
 
 int navsim_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     int rc = check_step_args(c, st, io, 0);
     if (rc != NAVSIM_OK) return rc;
     if (c->n_envs == 0) return NAVSIM_OK;
@@ -1414,6 +1429,7 @@ int navsim_step(const navsim_config* c, const navsim_state* st, const navsim_ste
 
 int navsim_reset_obs(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
                      const uint8_t* mask, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     int rc = check_step_args(c, st, io, 1);
     if (rc != NAVSIM_OK) return rc;
     if (c->n_envs == 0) return NAVSIM_OK;
@@ -1424,15 +1440,20 @@ const char* navsim_step_kernel_name(void) { return "navsim_step_kernel"; }
 
 // test hook (declared in include/navsim.h under "test hooks")
 int navsim_debug_math(int32_t fn, const double* x, const double* x2, double* out, int32_t n, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     if (!x || !out || n < 0) return NAVSIM_E_ARG;
     if (n == 0) return NAVSIM_OK;
     math_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(fn, x, x2, out, n);
     return launch_status();
 }
 
+// text of the HIP error behind the last NAVSIM_E_LAUNCH on this thread
+const char* navsim_last_hip_error(void) { return hipGetErrorString(g_last_hip_error); }
+
 // microbenchmark hook, see gather_probe_kernel
 int navsim_debug_gather(const float* x, uint64_t n_words, int32_t mode, int32_t iters, int32_t n_threads,
                         float* out, void* stream) {
+    (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     if (!x || !out || n_threads <= 0) return NAVSIM_E_ARG;
     gather_probe_kernel<<<(n_threads + 255) / 256, 256, 0, (hipStream_t)stream>>>(x, n_words, mode, iters, 12345, out);
     return launch_status();

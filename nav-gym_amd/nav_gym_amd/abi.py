@@ -191,7 +191,7 @@ def declare(lib, suffix=""):
 
 # every symbol include/navsim.h declares (tests check the .so exports all of them)
 EXPORTS = (
-    "navsim_abi_version", "navsim_error_string", "navsim_default_config",
+    "navsim_abi_version", "navsim_error_string", "navsim_last_hip_error", "navsim_default_config",
     "navsim_build_dt_workspace_bytes", "navsim_build_dt", "navsim_field_bytes", "navsim_build_field",
     "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",

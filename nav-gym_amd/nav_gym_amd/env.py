@@ -1,0 +1,282 @@
+"""NavGymEnv: the reference's gym.Env API (nav_gym_env/env.py:30-831) over E batched arenas.
+
+Same constructor keywords as the registered NavGym-v0 (nav_gym_env/__init__.py:6-38), same methods
+(reset, step, compute_reward(s), compute_terminals, compute_done, compute_info,
+_override_reward_factor), same observation dict keys and layout.  Build additions are keyword-only
+and default to the reference's behaviour for num_envs == 1:
+
+    num_envs        arenas stepped per call (leading axis of every returned array)
+    n_beams, lidar  lidar geometry (default: KetiRobot's 512 beams over 2*pi)
+    map_size        cells per side of every arena (default 400, the reference's outdoor size)
+    pedestrian_model 'sfm' (build-defined social force), 'external' (caller supplies (v, w) per
+                    pedestrian -- the slot the reference fills with HumanPolicy) or 'none'
+    device, seed, env_index_base (global index of arena 0: sharding), auto_reset, field_format
+
+num_envs == 1 returns NumPy float64 arrays with the reference's shapes; num_envs > 1 returns torch
+tensors on `device` (float32 observations).  Everything on the step() path runs in the HIP library;
+there is no CPU fallback.
+"""
+import numpy as np
+
+from . import abi, robots, world
+from .registry import spaces
+
+DEFAULT_KWARGS = {                       # nav_gym_env/__init__.py:6-38
+    'robot_type': 'keti',
+    'time_step': 0.2,
+    'min_turning_radius': 0,
+    'distance_threshold': 0.5,
+    'num_scan_stack': 1,
+    'linvel_range': [0, 0.5],
+    'rotvel_range': [-0.64, 0.64],
+    'human_v_pref_range': [0., 0.6],
+    'human_has_legs_ratio': 0.5,
+    'indoor_ratio': 0.5,
+    'min_goal_dist': 10,
+    'max_goal_dist': 20,
+    'reward_scale': 15.,
+    'reward_success_factor': 1,
+    'reward_crash_factor': 1,
+    'reward_progress_factor': 0.001,
+    'reward_forward_factor': 0.0,
+    'reward_rotation_factor': 0.005,
+    'reward_discomfort_factor': 0.01,
+    'env_param_range': dict(
+        num_humans=([5, 15], 'int'),
+        corridor_width=([3, 4], 'int'),
+        iterations=([80, 150], 'int'),
+        obstacle_number=([10, 10], 'int'),
+        obstacle_width=([0.3, 1.0], 'float'),
+        scan_noise_std=([0., 0.05], 'float'),
+    ),
+}
+
+
+class _AgentView(object):
+    """Read-only view of one agent of arena 0 with the attribute names RosEnv reads
+    (ros_env.py:83-176): px, py, theta, vx, vy, footprint, ..."""
+
+    def __init__(self, env, kind, index=0):
+        self._env, self._kind, self._i = env, kind, index
+        spec = robots.ROBOTS[env.robot_type] if kind == "robot" else robots.HUMAN
+        for k, v in spec.items():
+            setattr(self, k, v)
+
+    def _pose(self):
+        t = self._env.sim.t
+        p = t["robot_pose"][0] if self._kind == "robot" else t["ped_pose"][0, self._i]
+        return p.cpu().numpy()
+
+    px = property(lambda s: float(s._pose()[0]))
+    py = property(lambda s: float(s._pose()[1]))
+    theta = property(lambda s: float(s._pose()[2]))
+
+    @property
+    def vx(self):
+        return float(self._env.sim.t["ped_vel"][0, self._i, 0]) if self._kind != "robot" else 0.0
+
+    @property
+    def vy(self):
+        return float(self._env.sim.t["ped_vel"][0, self._i, 1]) if self._kind != "robot" else 0.0
+
+    @property
+    def gx(self):
+        return float(self._env.sim.t["robot_goal"][0, 0])
+
+    @property
+    def gy(self):
+        return float(self._env.sim.t["robot_goal"][0, 1])
+
+
+class NavGymEnv(object):
+    metadata = {"render.modes": []}
+
+    def __init__(self, robot_type, time_step, min_turning_radius, distance_threshold, num_scan_stack,
+                 linvel_range, rotvel_range, human_v_pref_range, human_has_legs_ratio, indoor_ratio,
+                 min_goal_dist, max_goal_dist, reward_scale, reward_success_factor, reward_crash_factor,
+                 reward_progress_factor, reward_forward_factor, reward_rotation_factor,
+                 reward_discomfort_factor, env_param_range, *,
+                 num_envs=1, n_beams=None, lidar=None, map_size=400, pedestrian_model="sfm",
+                 num_humans=None, device="cuda:0", seed=0, env_index_base=0, auto_reset=None,
+                 field_format=abi.FIELD_U16T, n_spawn=16):
+        from . import lib
+        if robot_type not in robots.ROBOTS:
+            raise NotImplementedError(robot_type)            # env.py:772-773
+        self.robot_type = robot_type
+        self.time_step = time_step
+        self.min_turning_radius = min_turning_radius
+        self.distance_threshold = distance_threshold
+        self.num_scan_stack = num_scan_stack
+        self.linvel_range = linvel_range
+        self.rotvel_range = rotvel_range
+        self.human_v_pref_range = human_v_pref_range
+        self.human_has_legs_ratio = human_has_legs_ratio
+        self.indoor_ratio = indoor_ratio
+        self.min_goal_dist = min_goal_dist
+        self.max_goal_dist = max_goal_dist
+        self.env_param_range = env_param_range
+        self.num_envs = int(num_envs)
+        self.map_size = int(map_size)
+        self.device = device
+        self.seed_value = int(seed)
+        self.pedestrian_model = pedestrian_model
+        self.auto_reset = (self.num_envs > 1) if auto_reset is None else bool(auto_reset)
+        self._num_humans_fixed = num_humans
+        self._episode_batch = 0
+        spec = robots.ROBOTS[robot_type]
+        nh_hi = int(env_param_range["num_humans"][0][1]) if num_humans is None else int(num_humans)
+        ped = {"none": abi.PED_NONE, "external": abi.PED_EXTERNAL, "sfm": abi.PED_SFM}[pedestrian_model]
+        if nh_hi == 0:
+            ped = abi.PED_NONE
+        cfg = lib.default_config(
+            n_envs=self.num_envs, map_h=self.map_size, map_w=self.map_size, max_peds=max(nh_hi, 1),
+            n_scan_stack=num_scan_stack, ped_model=ped, lidar_legs=1, auto_reset=int(self.auto_reset),
+            n_spawn=n_spawn, add_scan_noise=1, env_index_base=env_index_base, field_format=field_format,
+            time_step=time_step, axle_offset=spec["axle_offset"], min_turning_radius=float(min_turning_radius),
+            distance_threshold=distance_threshold, range_max=spec["range_max"], seed=self.seed_value)
+        if lidar is not None:                         # (angle_min, angle_last, n_beams)
+            cfg.angle_min, cfg.angle_last, cfg.n_beams = float(lidar[0]), float(lidar[1]), int(lidar[2])
+        elif n_beams is not None and int(n_beams) == 1081:
+            world.lidar_1081(cfg)
+        elif n_beams is not None:
+            world.lidar_full_circle(cfg, int(n_beams))
+        else:                                         # keti_robot.py:44-48, env.py:388-390
+            cfg.n_beams = spec["n_angles"]
+            cfg.angle_min = spec["angle_min"]
+            cfg.angle_last = spec["angle_max"] - spec["angle_increment"]
+        self.cfg = cfg
+        self._override_reward_factor(reward_scale, reward_success_factor, reward_crash_factor,
+                                     reward_progress_factor, reward_forward_factor, reward_rotation_factor,
+                                     reward_discomfort_factor)
+        self.sim = None
+        self.prev_obs = None
+        self.robot = _AgentView(self, "robot")
+        self.humans = []
+        self.map_info = None
+        self.scan_threshold = None
+        self.scan_discomfort_threshold = None
+        self.action_space = spaces.Box(low=np.array([linvel_range[0], rotvel_range[0]]),
+                                       high=np.array([linvel_range[1], rotvel_range[1]]), dtype=np.float32)
+        D = num_scan_stack * cfg.n_beams + 7
+        self.observation_space = spaces.Dict({
+            'observation': spaces.Box(-np.inf, np.inf, shape=(D,), dtype=np.float32),
+            'achieved_goal': spaces.Box(-np.inf, np.inf, shape=(2,), dtype=np.float32),
+            'desired_goal': spaces.Box(-np.inf, np.inf, shape=(2,), dtype=np.float32)})
+
+    # ---- env.py:144-160 -------------------------------------------------------------------------
+    def _override_reward_factor(self, reward_scale=15., reward_success_factor=1, reward_crash_factor=1,
+                                reward_progress_factor=0.001, reward_forward_factor=0.0,
+                                reward_rotation_factor=0.005, reward_discomfort_factor=0.01):
+        self.reward_scale = reward_scale
+        self.reward_success_factor = reward_success_factor
+        self.reward_crash_factor = reward_crash_factor
+        self.reward_progress_factor = reward_progress_factor
+        self.reward_forward_factor = reward_forward_factor
+        self.reward_rotation_factor = reward_rotation_factor
+        self.reward_discomfort_factor = reward_discomfort_factor
+        for k in ("scale", "success_factor", "crash_factor", "progress_factor", "forward_factor",
+                  "rotation_factor", "discomfort_factor"):
+            setattr(self.cfg, "reward_" + k, float(getattr(self, "reward_" + k)))
+        if getattr(self, "sim", None) is not None:
+            for k in ("scale", "success_factor", "crash_factor", "progress_factor", "forward_factor",
+                      "rotation_factor", "discomfort_factor"):
+                setattr(self.sim.cfg, "reward_" + k, float(getattr(self, "reward_" + k)))
+
+    # ---- reset (env.py:730-831), all arenas ---------------------------------------------------------
+    def reset(self):
+        from . import lib
+        lib.require_gpu()                                 # no CPU fallback: fail before any work
+        import torch
+        from . import sim as simmod
+        cfg = self.cfg
+        seed = self.seed_value + 7919 * self._episode_batch
+        self._episode_batch += 1
+        rng = np.random.default_rng(seed)
+        occ = world.make_maps(cfg.n_envs, self.map_size, seed, env_index_base=cfg.env_index_base,
+                              indoor_ratio=self.indoor_ratio)
+        lo, hi = self.env_param_range["num_humans"][0]
+        if self._num_humans_fixed is not None:
+            n_peds = int(self._num_humans_fixed)
+        else:
+            n_peds = torch.from_numpy(rng.integers(lo, hi + 1, cfg.n_envs).astype(np.int32))
+        nlo, nhi = self.env_param_range["scan_noise_std"][0]
+        room = self.map_size * cfg.resolution
+        arrays = world.make_world(
+            cfg, occ, seed=seed, n_peds=n_peds if cfg.ped_model != abi.PED_NONE else 0,
+            min_goal_dist=min(self.min_goal_dist, 0.4 * room), max_goal_dist=min(self.max_goal_dist, 0.8 * room),
+            noise_std_range=(nlo, nhi), has_legs_ratio=self.human_has_legs_ratio,
+            v_pref_range=tuple(self.human_v_pref_range), device=self.device)
+        dev = torch.device(self.device)
+        for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
+            arrays[key] = simmod.scan_threshold(cfg, torch.from_numpy(robots.footprint_array(self.robot_type, name)).to(dev))
+        self.sim = simmod.NavSim(cfg, arrays, device=self.device)
+        self.scan_threshold = arrays["scan_threshold"]
+        self.scan_discomfort_threshold = arrays["scan_discomfort"]
+        self.map_info = {"data": (occ[0].astype(np.int8) * 100), "origin": (cfg.origin_x, cfg.origin_y),
+                         "resolution": cfg.resolution, "width": self.map_size, "height": self.map_size}
+        n0 = int(self.sim.t["n_peds"][0]) if "n_peds" in self.sim.t else 0
+        self.humans = [_AgentView(self, "human", i) for i in range(n0)]
+        self.sim.reset_obs()
+        return self._obs_dict()
+
+    def _obs_dict(self):
+        o = self.sim.obs
+        pose = o[:, -5:-3]
+        goal = self.sim.t["robot_goal"].to(o.dtype)
+        d = {"observation": o, "achieved_goal": pose, "desired_goal": goal}
+        if self.num_envs == 1:
+            d = {k: v[0].double().cpu().numpy() for k, v in d.items()}
+        self.prev_obs = d
+        return d
+
+    # ---- step (env.py:591-728) -------------------------------------------------------------------------
+    def step(self, action, human_actions=None):
+        if self.sim is None:
+            raise RuntimeError("call reset() before step()")
+        if human_actions is not None:
+            self.sim.set_ped_cmd(human_actions)
+        a = np.asarray(action, dtype=np.float64).reshape(self.num_envs, 2) if not hasattr(action, "is_cuda") else action
+        _, out = self.sim.step(a)
+        obs = self._obs_dict()
+        if self.num_envs == 1:
+            info = {"is_success": np.float32(out["is_success"][0].item()),
+                    "is_crash": np.float32(out["is_crash"][0].item()),
+                    "distance": float(out["distance"][0].item())}
+            return obs, float(out["reward"][0].item()), bool(out["done"][0].item()), info
+        info = {"is_success": out["is_success"], "is_crash": out["is_crash"], "distance": out["distance"]}
+        return obs, out["reward"], out["done"].bool(), info
+
+    # ---- HER batch API (env.py:464-589) ---------------------------------------------------------------
+    def _rd(self, obs):
+        import torch
+        from . import sim as simmod
+        o = torch.as_tensor(np.asarray(obs["observation"])) if not hasattr(obs["observation"], "is_cuda") else obs["observation"]
+        g = torch.as_tensor(np.asarray(obs["desired_goal"])) if not hasattr(obs["desired_goal"], "is_cuda") else obs["desired_goal"]
+        o = o.to(self.device)
+        if o.dtype not in (torch.float32, torch.float64):
+            o = o.double()
+        return simmod.reward_done(self.sim.cfg, o.reshape(-1, o.shape[-1]), g.to(self.device).reshape(-1, 2),
+                                  self.scan_threshold, self.scan_discomfort_threshold)
+
+    def compute_rewards(self, actions, obs, make_render_reward_txt=False):
+        return self._rd(obs)["reward"].cpu().numpy()
+
+    def compute_terminals(self, obs):
+        return self._rd(obs)["done"].cpu().numpy().astype(bool)
+
+    def compute_reward(self, action, obs, make_render_reward_txt=False):
+        return self.compute_rewards(np.asarray(action)[None], {k: np.asarray(v)[None] for k, v in obs.items()})[0]
+
+    def compute_done(self, obs):
+        return self.compute_terminals({k: np.asarray(v)[None] for k, v in obs.items()})[0]
+
+    def compute_info(self, obs):
+        r = self._rd({k: np.asarray(v)[None] for k, v in obs.items()})
+        return {"is_success": np.float32(r["is_success"][0].item()), "is_crash": np.float32(r["is_crash"][0].item()),
+                "distance": float(r["distance"][0].item())}
+
+    def render(self, mode="human"):
+        raise NotImplementedError("render() (env.py:833-1212) is out of scope: SURVEY.md section 8f #3")
+
+    def close(self):
+        self.sim = None

@@ -37,12 +37,17 @@ def load():
             raise NavsimError(
                 "HIP extension %s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or nav-gym_amd/csrc/build.sh (there is no CPU fallback)" % LIB_PATH)
+        # torch first: it ships its own libamdhip64; loading ours afterwards binds the library to the
+        # SAME HIP runtime instance (one device context, shared streams).  The other order leaves two
+        # runtimes in the process and ours reports "no ROCm-capable device".
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         abi.declare(L, "")
         L.navsim_abi_version.restype = C.c_int
         L.navsim_error_string.restype = C.c_char_p
         L.navsim_error_string.argtypes = [C.c_int]
         L.navsim_step_kernel_name.restype = C.c_char_p
+        L.navsim_last_hip_error.restype = C.c_char_p
         L.navsim_build_dt_workspace_bytes.restype = C.c_size_t
         L.navsim_build_dt_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
         for n in ("navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io"):
@@ -59,6 +64,8 @@ def load():
 def check(rc, what):
     if rc != 0:
         msg = load().navsim_error_string(rc).decode()
+        if rc == abi.E_LAUNCH:
+            msg += " [HIP: %s]" % load().navsim_last_hip_error().decode()
         raise NavsimError("%s: %s (%d)" % (what, msg, rc))
 
 

@@ -90,14 +90,16 @@ def _uniform(seed, genv, stream, shape_tail, device):
 
 
 def sample_free_cells(field, clearance_cells, k, seed, genv, stream, chunk=128):
-    """k cells per env with field >= clearance, uniformly (hash scores + top-k).  -> int64 [E,k] (j*W+i)."""
+    """k cells per env with field >= clearance, uniformly (hash scores + top-k).  -> int64 [E,k] (j*W+i).
+    An arena too cramped for `clearance_cells` uses 60 % of its own largest clearance instead."""
     import torch
     E, H, W = field.shape
     out = torch.empty((E, k), dtype=torch.int64, device=field.device)
     for e0 in range(0, E, chunk):
         f = field[e0:e0 + chunk].reshape(-1, H * W)
         u = _uniform(seed, genv[e0:e0 + chunk], stream, (H * W,), field.device).to(torch.float32)
-        u = torch.where(f >= clearance_cells, u, torch.full_like(u, -1.0))
+        thr = torch.clamp(0.6 * f.max(dim=1, keepdim=True).values, max=float(clearance_cells))
+        u = torch.where(f >= thr, u, torch.full_like(u, -1.0))
         out[e0:e0 + chunk] = torch.topk(u, k, dim=1).indices
     return out
 

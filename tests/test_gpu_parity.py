@@ -320,3 +320,34 @@ def test_scan_noise_statistics(gpu):
     assert np.array_equal(noisy[clean == 25.0], clean[clean == 25.0])
     k = np.mean(d ** 4) / d.var() ** 2
     assert 2.8 < k < 3.2                              # Gaussian kurtosis
+
+
+def test_env_wrapper_gym_api(gpu):
+    """gym.make('NavGym-v0')-style usage: reference shapes / dtypes for one arena, batched tensors
+    for many, HER batch API consistent with step()."""
+    import nav_gym_env
+    env = nav_gym_env.make("NavGym-v0", map_size=400, num_humans=5, seed=3)
+    obs = env.reset()
+    assert obs["observation"].shape == (519,) and obs["observation"].dtype == np.float64
+    assert obs["achieved_goal"].shape == (2,) and obs["desired_goal"].shape == (2,)
+    assert len(env.humans) == 5 and env.map_info["data"].shape == (400, 400)
+    o2, r, d, info = env.step(env.action_space.sample())
+    assert isinstance(r, float) and isinstance(d, bool)
+    assert set(info) == {"is_success", "is_crash", "distance"} and info["is_success"].dtype == np.float32
+    if not info["is_crash"]:      # after a crash the returned obs is the reverted pose's (env.py:707-723)
+        assert abs(env.compute_reward(np.zeros(2), o2) - r) < 1e-4      # float32 obs row vs float64 state
+    assert env.compute_done(o2) == d
+    assert abs(env.compute_info(o2)["distance"] - info["distance"]) < 1e-4
+    assert abs(env.robot.px - o2["achieved_goal"][0]) < 1e-5
+    # batched
+    benv = nav_gym_env.make("NavGym-v0", num_envs=32, map_size=200, n_beams=1081, num_scan_stack=2, seed=4)
+    bo = benv.reset()
+    assert tuple(bo["observation"].shape) == (32, 2 * 1081 + 7) and bo["observation"].is_cuda
+    acts = np.tile([[0.4, 0.1]], (32, 1))
+    for _ in range(5):
+        bo, br, bd, binfo = benv.step(acts)
+    assert tuple(br.shape) == (32,) and bd.dtype == gpu.torch.bool
+    rr = benv.compute_rewards(acts, {k: v for k, v in bo.items()})
+    assert rr.shape == (32,)
+    done_again = benv.compute_terminals(bo)
+    assert done_again.shape == (32,)
