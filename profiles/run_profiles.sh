@@ -12,8 +12,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace --
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 "$R/bench.py" $ARGS --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 "$R/bench.py" $ARGS --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM --output-format csv -d "$OUT/pmc_sq" -o pmc -- python3 "$R/bench.py" $ARGS --no-cpu-baseline > "$OUT/pmc_sq.log" 2>&1
-if [ "${NAVSIM_PROFILE_DEEP:-0}" = "1" ]; then
+# read-request size split: calibrates FETCH_SIZE for THIS access pattern (guide: FETCH_SIZE tallies 128-B requests at 64 B)
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d "$OUT/pmc_ea" -o pmc -- python3 "$R/bench.py" $ARGS --no-cpu-baseline > "$OUT/pmc_ea.log" 2>&1
+if [ "${NAVSIM_PROFILE_DEEP:-0}" = "1" ]; then
 rocprofv3 --pmc TCC_REQ_sum TCC_READ_sum TCC_EA0_RDREQ_DRAM_sum TCC_TAG_STALL_sum --output-format csv -d "$OUT/pmc_tcc" -o pmc -- python3 "$R/bench.py" $ARGS --no-cpu-baseline > "$OUT/pmc_tcc.log" 2>&1
 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum --output-format csv -d "$OUT/pmc_tcp" -o pmc -- python3 "$R/bench.py" $ARGS --no-cpu-baseline > "$OUT/pmc_tcp.log" 2>&1
 rocprofv3 --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TA_TA_BUSY_sum TA_TOTAL_WAVEFRONTS_sum --output-format csv -d "$OUT/pmc_lat" -o pmc -- python3 "$R/bench.py" $ARGS --no-cpu-baseline > "$OUT/pmc_lat.log" 2>&1

@@ -50,5 +50,14 @@ if "FETCH_SIZE" in res or "WRITE_SIZE" in res:
     w = res.get("WRITE_SIZE", 0.0) * 1024.0
     print("FETCH bytes/launch as reported %.4g  (x2 if wide streaming: %.4g)   WRITE bytes/launch %.4g" % (f, 2 * f, w))
     json.dump({"fetch_bytes_reported": f, "write_bytes": w, "counters": res}, open(os.path.join(out, "pmc.json"), "w"), indent=1)
+if "TCC_EA0_RDREQ_128B_sum" in res:
+    rd = res.get("TCC_EA0_RDREQ_32B_sum", 0) * 32 + res.get("TCC_EA0_RDREQ_64B_sum", 0) * 64 + res["TCC_EA0_RDREQ_128B_sum"] * 128
+    w = res.get("WRITE_SIZE", 0.0) * 1024.0
+    print("HBM read bytes/launch from the request-size split %.4g (FETCH_SIZE x2 = %.4g) ; + writes = %.4g"
+          % (rd, 2 * res.get("FETCH_SIZE", 0) * 1024.0, rd + w))
+    json.dump({"hbm_bytes_per_launch": rd + w, "read_bytes": rd, "write_bytes": w,
+               "method": "TCC_EA0_RDREQ_{32,64,128}B x size + WRITE_SIZE x 1024 (separate --pmc passes); "
+                         "FETCH_SIZE x 2 agrees (gfx950 tallies 128-B reads at 64 B)",
+               "counters": res}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 if "TCC_HIT_sum" in res:
     print("L2 hit rate %.3f" % (res["TCC_HIT_sum"] / (res["TCC_HIT_sum"] + res["TCC_MISS_sum"])))
