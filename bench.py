@@ -43,7 +43,7 @@ def build_sim(wl, rank, world_size, seed=1234, device="cuda:0"):
     cfg = lib.default_config(n_envs=E, map_h=wl["size"], map_w=wl["size"], max_peds=max(wl["peds"], 1),
                              ped_model=abi.PED_SFM if wl["peds"] else abi.PED_NONE,
                              n_spawn=16, auto_reset=1, seed=seed, env_index_base=rank * E,
-                             field_format=abi.FIELD_F32 if wl.get("field") == "f32" else abi.FIELD_U16T)
+                             field_format={"f32": abi.FIELD_F32, "f32s": abi.FIELD_F32S}.get(wl.get("field"), abi.FIELD_U16T))
     if wl["beams"] == 1081:
         world.lidar_1081(cfg)
     else:
@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=0, help="override arenas per GPU")
     ap.add_argument("--gather", default="none", choices=["none", "all"])
-    ap.add_argument("--field", default="u16t", choices=["u16t", "f32"], help="distance-field storage")
+    ap.add_argument("--field", default="u16t", choices=["u16t", "f32", "f32s"], help="distance-field storage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -126,15 +126,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
+    # NAVSIM_BENCH_BACKEND=gloo + NAVSIM_BENCH_ONE_GPU=1: control-flow test of the N > 1 path with
+    # several ranks sharing one GPU (the driver's real runs use nccl = RCCL, one rank per GPU)
+    backend = os.environ.get("NAVSIM_BENCH_BACKEND", "nccl")
+    if os.environ.get("NAVSIM_BENCH_ONE_GPU"):
+        local_rank = 0
+    device = "cuda:%d" % local_rank
+    torch.cuda.set_device(local_rank)
     if world_size > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
-    device = "cuda:%d" % local_rank
-    torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = device if backend == "nccl" else "cpu"
 
     wl = dict(WORKLOADS[args.workload])
     if args.envs:
@@ -150,7 +158,7 @@ def main():
     acts[..., 0] *= 0.5
     acts[..., 1] = acts[..., 1] * 1.28 - 0.64
     gather_buf = None
-    if args.gather == "all" and dist is not None:
+    if args.gather == "all" and dist is not None and backend == "nccl":
         gather_buf = torch.empty((world_size * E, sim.obs.shape[1]), dtype=torch.float32, device=device)
 
     def run(t):
@@ -177,7 +185,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / K          # HIP events on the launch stream
@@ -191,7 +199,7 @@ def main():
         achieved = A * E / (kernel_ms * 1e-3) / 1e9                # GB/s
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if os.path.exists(tp):
+        if os.path.exists(tp) and E == WORKLOADS[args.workload]["envs"] and args.field == "u16t":   # same launch only
             try:
                 traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
             except Exception:

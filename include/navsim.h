@@ -48,6 +48,9 @@ extern "C" {
 #define NAVSIM_FIELD_U16T    1   /* uint16 squared distance in 8x8-cell tiles (128-B lines), 0xFFFF =
                                     "d2 >= 65535, read the float32 overflow plane"; d = sqrtf(d2) is
                                     bit-identical to the float32 field */
+#define NAVSIM_FIELD_F32S    2   /* float32 march step max(fl32(fl64(d)*0.999), 1) (0 = occupied) in tiles of
+                                    8x4 cells (128-B lines): no decode in the march loop, twice the bytes;
+                                    the float32 overflow plane (exact d) is REQUIRED by the social force */
 #define NAVSIM_FIELD_TILE    8
 
 /* compiled limits */

@@ -83,6 +83,11 @@ struct FieldF32 {
     __device__ __forceinline__ bool occupied(raw_t v) const { return v <= 0.0f; }
     __device__ __forceinline__ float decode(raw_t v, int, int) const { return v; }
     __device__ __forceinline__ float at(int px, int py) const { return load(px, py); }
+    // march step of a non-occupied sample: t += max(fl32(fl64(d) * 0.999), 1)
+    __device__ __forceinline__ float step_of(raw_t v, int, int) const {
+        float stp = (float)((double)v * 0.999);
+        return (stp > 1.0f) ? stp : 1.0f;
+    }
 };
 struct FieldU16T {
     const uint16_t* p; const float* ovf; int W, tpr;
@@ -109,6 +114,34 @@ struct FieldU16T {
         return nv::sqrt_small_int((float)v);
     }
     __device__ __forceinline__ float at(int px, int py) const { return decode(load(px, py), px, py); }
+    __device__ __forceinline__ float step_of(raw_t v, int px, int py) const {
+        float stp = (float)((double)decode(v, px, py) * 0.999);
+        return (stp > 1.0f) ? stp : 1.0f;
+    }
+};
+// float32 march steps in 8x4-cell tiles (one tile = one 128-B line): the loop adds the loaded value
+struct FieldF32S {
+    const float* p; const float* ovf; int W, tpr;
+    __device__ __forceinline__ FieldF32S(const void* base, const float* overflow, int e, int H, int W_)
+        : W(W_), tpr((W_ + 7) >> 3) {
+        size_t per_map = (size_t)((H + 3) >> 2) * tpr * 32;
+        p = (const float*)base + (size_t)e * per_map;
+        ovf = overflow ? overflow + (size_t)e * H * W_ : nullptr;
+    }
+    __device__ __forceinline__ static size_t index(int px, int py, int tpr) {
+        return ((size_t)((py >> 2) * tpr + (px >> 3)) << 5) + ((py & 3) << 3) + (px & 7);
+    }
+    typedef float raw_t;
+    __device__ __forceinline__ raw_t load(int px, int py) const {
+        unsigned upx = (unsigned)px, upy = (unsigned)py;
+        unsigned off = ((((upy >> 2) * (unsigned)tpr + (upx >> 3)) << 5) | ((upy & 3u) << 3) | (upx & 7u)) * 4u;
+        return *(const float*)((const char*)p + off);
+    }
+    __device__ __forceinline__ bool occupied(raw_t v) const { return v == 0.0f; }
+    __device__ __forceinline__ float step_of(raw_t v, int, int) const { return v; }
+    // exact distance (first probe, social force): from the float32 plane
+    __device__ __forceinline__ float decode(raw_t, int px, int py) const { return ovf[(size_t)py * W + px]; }
+    __device__ __forceinline__ float at(int px, int py) const { return ovf[(size_t)py * W + px]; }
 };
 
 // FORMAT 0: float32 row-major to `field`; 1: uint16 tiles to `field` (+ float32 to `overflow` if
@@ -141,11 +174,19 @@ __global__ __launch_bounds__(256) void dt_rows_kernel(const uint16_t* __restrict
         }
         if (FORMAT == 0) {
             ((float*)field_v)[(m * (size_t)H + y) * W + x] = sqrtf((float)best);
-        } else {
+        } else if (FORMAT == 1) {
             uint16_t* out = (uint16_t*)field_v + m * per_map_t;
             out[FieldU16T::index(x, y, tpr)] = (uint16_t)(best >= 65535 ? 0xFFFF : best);
             if (overflow) overflow[(m * (size_t)H + y) * W + x] = sqrtf((float)best);
             sat += best >= 65535;
+        } else {
+            const size_t per_map_s = (size_t)((H + 3) >> 2) * tpr * 32;
+            float d = sqrtf((float)best);
+            float stp = (float)((double)d * 0.999);
+            stp = (stp > 1.0f) ? stp : 1.0f;
+            ((float*)field_v)[m * per_map_s + FieldF32S::index(x, y, tpr)] = (best == 0) ? 0.0f : stp;
+            if (overflow) overflow[(m * (size_t)H + y) * W + x] = d;
+            sat += 1;                                  // "saturated": the overflow plane is always needed
         }
     }
     if (FORMAT != 0 && n_saturated && sat) atomicAdd(n_saturated, sat);
@@ -357,10 +398,10 @@ struct Prims { const float (*seg)[4]; const float (*disc)[2]; };
 // to back before any of them is consumed, which multiplies the lines in flight per CU by R.
 // Beam k of round-slot q is base + q*BLOCK + tid, so lanes of a wave hold adjacent beams (their
 // probes fall on neighbouring cells and their range stores coalesce).
-template <int BLOCK, int R, typename Field>
+template <int BLOCK, int R, typename Field, bool TO_LDS>
 __device__ __forceinline__ void scan_beams(const navsim_config& c, const StepShared& sh,
                                            const Field& field, const double* __restrict__ tab,
-                                           const Prims pr,
+                                           const Prims pr, float2* __restrict__ dir_lds, float* __restrict__ rng_lds,
                                            const float* __restrict__ thr, const float* __restrict__ dthr,
                                            float* __restrict__ obs_row, int n_hist, float noise_std,
                                            uint64_t noise_key, uint64_t genv,
@@ -432,9 +473,7 @@ __device__ __forceinline__ void scan_beams(const navsim_config& c, const StepSha
                         hit |= 1u << q;
                         active &= ~(1u << q);
                     } else {
-                        const float dq = field.decode(raw[q], px[q], py[q]);
-                        float stp = (float)((double)dq * 0.999);
-                        t[q] += (stp > 1.0f) ? stp : 1.0f;
+                        t[q] += field.step_of(raw[q], px[q], py[q]);
                         if (!(t[q] < max_range)) active &= ~(1u << q);
                     }
                 }
@@ -451,7 +490,9 @@ __device__ __forceinline__ void scan_beams(const navsim_config& c, const StepSha
 #pragma unroll
         for (int q = 0; q < R; ++q) {
             int k = base + q * BLOCK + (int)threadIdx.x;
-            if (k < B) {
+            if (TO_LDS) {                                               // pedestrian variants: merge later, culled
+                if (k < B) { rng_lds[k] = r[q]; dir_lds[k] = make_float2(dx[q], dy[q]); }
+            } else if (k < B) {
                 float rr = r[q] * res;                                  // env.py:426
                 for (int p = 0; p < nseg; ++p)
                     nv::seg_merge(rr, lx, ly, dx[q], dy[q], pr.seg[p][0], pr.seg[p][1], pr.seg[p][2], pr.seg[p][3]);
@@ -469,8 +510,38 @@ __device__ __forceinline__ void scan_beams(const navsim_config& c, const StepSha
             }
         }
     }
+    if (TO_LDS) {
+        __syncthreads();
+        finish_beams<BLOCK>(c, sh, pr, tab, dir_lds, rng_lds, rng_lds, thr, dthr, obs_row, n_hist, noise_std,
+                            noise_key, genv, cr, dc);
+    }
     crash = cr;
     discomfort = dc;
+}
+
+// one social-force term of the build-defined pedestrian model: force on agent
+// i from agent j; (0, 0) when the pair is skipped
+__device__ __forceinline__ void sfm_pair(const navsim_config& c, double xi, double yi, double vxi, double vyi,
+                                         double xj, double yj, double vxj, double vyj, double& fx, double& fy) {
+    fx = 0.0; fy = 0.0;
+    double dxx = xj - xi, dyy = yj - yi;
+    double dist = sqrt(dxx * dxx + dyy * dyy);
+    if (dist < 1e-9) return;
+    double ddx = dxx / dist, ddy = dyy / dist;
+    double ivx = c.sfm_lambda * (vxi - vxj) + ddx;
+    double ivy = c.sfm_lambda * (vyi - vyj) + ddy;
+    double il = sqrt(ivx * ivx + ivy * ivy);
+    if (il < 1e-9) return;
+    double idx = ivx / il, idy = ivy / il;
+    double theta = nv::atan2_(idx * ddy - idy * ddx, idx * ddx + idy * ddy);
+    double Bq = c.sfm_gamma * il;
+    double a1 = c.sfm_n_prime * Bq * theta;
+    double a2 = c.sfm_n * Bq * theta;
+    double fv = -nv::exp_neg(-dist / Bq - a1 * a1);
+    double sgn = (theta > 0.0) ? 1.0 : ((theta < 0.0) ? -1.0 : 0.0);
+    double fa = -sgn * nv::exp_neg(-dist / Bq - a2 * a2);
+    fx = fv * idx + fa * (-idy);
+    fy = fv * idy + fa * idx;
 }
 
 // direction of beam k (env.py:388-390, 424): table fast path with proven rounding, else full sincos
@@ -521,10 +592,66 @@ __device__ __forceinline__ float march_ray(const Field& field, float x0, float y
             float yd = (float)py - y0;
             return sqrtf(xd * xd + yd * yd);
         }
-        float dq = field.decode(raw, px, py);
-        float stp = (float)((double)dq * 0.999);
-        t += (stp > 1.0f) ? stp : 1.0f;
+        t += field.step_of(raw, px, py);
         if (!(t < max_range)) return max_range;
+    }
+}
+
+// Pedestrians into the scan (env.py:428-432), culled by bearing.  A rectangle side or a leg disc is
+// seen under a small angle, so instead of testing every beam against every primitive (B x P ray
+// tests: 3x the cost of the whole map march at 20 pedestrians) each wave takes one primitive, derives
+// the beam-index interval that can possibly hit it (bearing +- half-width, two beams of margin, all
+// three 2*pi aliases) and runs the SAME float32 seg_merge / circle_merge on those beams only;
+// results land with an LDS atomicMin on the (non-negative) float bits, so they do not depend on the
+// order of primitives.  rng[] holds metres, dir[] the beam directions.
+template <int BLOCK>
+__device__ __forceinline__ void merge_prims_culled(const navsim_config& c, const StepShared& sh, const Prims pr,
+                                                   const float2* __restrict__ dir, float* __restrict__ rng) {
+    const int B = c.n_beams;
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const float lx = sh.lx, ly = sh.ly;
+    const float stepf = (float)nv::linspace_step(c);
+    const float beta0 = (float)(c.angle_min + (double)sh.lth);      // bearing of beam 0
+    const float kTwoPiF = 6.2831853f;
+    const float Kf = (stepf > 0.0f) ? kTwoPiF / stepf : 0.0f;
+    const int nseg = sh.nseg, nprim = sh.nseg + sh.ndisc;
+    for (int p = wave; p < nprim; p += BLOCK / 64) {
+        const bool is_seg = p < nseg;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float ac = 0.0f, w = 0.0f;
+        bool full = (stepf <= 0.0f);
+        if (is_seg) {
+            a0 = pr.seg[p][0]; a1 = pr.seg[p][1]; a2 = pr.seg[p][2]; a3 = pr.seg[p][3];
+            float ux = a0 - lx, uy = a1 - ly, vx = a2 - lx, vy = a3 - ly;
+            float b1 = atan2f(uy, ux), b2 = atan2f(vy, vx);
+            float d = b2 - b1;
+            d -= kTwoPiF * floorf(d / kTwoPiF + 0.5f);              // (-pi, pi]
+            ac = b1 + 0.5f * d;
+            w = 0.5f * fabsf(d);
+            if (fabsf(d) > 3.0f || ux * ux + uy * uy < 1e-6f || vx * vx + vy * vy < 1e-6f) full = true;
+        } else {
+            a0 = pr.disc[p - nseg][0]; a1 = pr.disc[p - nseg][1];
+            float ux = a0 - lx, uy = a1 - ly;
+            float dist = sqrtf(ux * ux + uy * uy);
+            if (dist <= nv::kLegRadius * 1.05f) full = true;
+            else { ac = atan2f(uy, ux); w = asinf(fminf(1.0f, nv::kLegRadius / dist)); }
+        }
+        float rel = ac - beta0;
+        rel -= kTwoPiF * floorf(rel / kTwoPiF + 0.5f);              // [-pi, pi)
+        const float klo = (rel - w) / stepf - 2.0f, khi = (rel + w) / stepf + 2.0f;
+        for (int m = full ? 0 : -1; m <= (full ? 0 : 1); ++m) {
+            int k0 = full ? 0 : (int)floorf(klo + (float)m * Kf);
+            int k1 = full ? B - 1 : (int)ceilf(khi + (float)m * Kf);
+            k0 = k0 < 0 ? 0 : k0;
+            k1 = k1 > B - 1 ? B - 1 : k1;
+            for (int k = k0 + lane; k <= k1; k += 64) {
+                float2 d = dir[k];
+                float old = rng[k], rr = old;
+                if (is_seg) nv::seg_merge(rr, lx, ly, d.x, d.y, a0, a1, a2, a3);
+                else        nv::circle_merge(rr, lx, ly, d.x, d.y, a0, a1, nv::kLegRadius);
+                if (rr < old) atomicMin((int*)&rng[k], __float_as_int(rr));
+            }
+        }
     }
 }
 
@@ -534,7 +661,7 @@ __device__ __forceinline__ float march_ray(const Field& field, float x0, float y
 template <int BLOCK>
 __device__ __forceinline__ void finish_beams(const navsim_config& c, const StepShared& sh, const Prims pr,
                                              const double* __restrict__ tab, const float2* __restrict__ dir,
-                                             const float* __restrict__ rng,
+                                             const float* __restrict__ rng, float* __restrict__ rng_rw,
                                              const float* __restrict__ thr, const float* __restrict__ dthr,
                                              float* __restrict__ obs_row, int n_hist, float noise_std,
                                              uint64_t noise_key, uint64_t genv, int& crash, int& discomfort) {
@@ -546,9 +673,17 @@ __device__ __forceinline__ void finish_beams(const navsim_config& c, const StepS
     const int nseg = sh.nseg, ndisc = sh.ndisc;
     const float r_all = sh.r_all;
     int cr = 0, dc = 0;
+    const bool culled = dir && rng_rw && (nseg | ndisc);           // LDS-resident: bearing-culled merge
+    if (culled) {
+        for (int k = (int)threadIdx.x; k < B; k += BLOCK)
+            rng_rw[k] = ((r_all >= 0.0f) ? r_all : rng[k]) * res;   // env.py:426
+        __syncthreads();
+        merge_prims_culled<BLOCK>(c, sh, pr, dir, rng_rw);
+        __syncthreads();
+    }
     for (int k = (int)threadIdx.x; k < B; k += BLOCK) {
-        float rr = ((r_all >= 0.0f) ? r_all : rng[k]) * res;       // env.py:426
-        if (nseg | ndisc) {
+        float rr = culled ? rng[k] : ((r_all >= 0.0f) ? r_all : rng[k]) * res;
+        if (!culled && (nseg | ndisc)) {
             float dx, dy;
             if (dir) { float2 d = dir[k]; dx = d.x; dy = d.y; }
             else beam_dir_k(c, tab, k, step, (double)sh.lth, sh.cT, sh.sT, dx, dy);
@@ -560,6 +695,77 @@ __device__ __forceinline__ void finish_beams(const navsim_config& c, const StepS
         rr = rr < 0.0f ? 0.0f : rr;                                 // env.py:435
         rr = rr > rmax ? rmax : rr;
         if (noise_std > 0.0f && rr != rmax)                         // env.py:437-440
+            rr = rr + noise_std * nv::gauss_noise(c.seed ^ noise_key, genv, noise_key, (uint32_t)k);
+        cr |= (rr < thr[k]);
+        dc |= (rr < dthr[k]);
+        obs_row[(size_t)(S - 1) * B + k] = rr;
+        for (int j = 0; j < S - 1; ++j)
+            if (S - 1 - j > n_hist) obs_row[(size_t)j * B + k] = rr;
+    }
+    crash = cr;
+    discomfort = dc;
+}
+
+// Predicated one-ray-per-lane scan (R == 11 variant): the march loop has ONE wave-level branch
+// (any lane still marching?) instead of a divergent if-ladder per probe; finished or out-of-map
+// lanes keep executing with their updates masked off.  Same results as scan_beams.
+template <int BLOCK, typename Field>
+__device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const StepShared& sh,
+                                                const Field& field, const double* __restrict__ tab,
+                                                const Prims pr,
+                                                const float* __restrict__ thr, const float* __restrict__ dthr,
+                                                float* __restrict__ obs_row, int n_hist, float noise_std,
+                                                uint64_t noise_key, uint64_t genv,
+                                                int& crash, int& discomfort) {
+    const int B = c.n_beams, S = c.n_scan_stack, H = c.map_h, W = c.map_w;
+    const float max_range = (float)((long long)H * W);       // env.py:337
+    const float res = (float)c.resolution;
+    const float rmax = (float)c.range_max;
+    const double step = nv::linspace_step(c);
+    const float x0 = (float)sh.i0, y0 = (float)sh.j0;
+    const float lx = sh.lx, ly = sh.ly;
+    const int nseg = sh.nseg, ndisc = sh.ndisc;
+    const unsigned uW = (unsigned)W, uH = (unsigned)H;
+    const float t1 = sh.t1, r_all = sh.r_all;
+    int cr = 0, dc = 0;
+    for (int k = (int)threadIdx.x; k < B; k += BLOCK) {
+        float dx, dy;
+        beam_dir_k(c, tab, k, step, (double)sh.lth, sh.cT, sh.sT, dx, dy);
+        float t = t1;
+        bool active = r_all < 0.0f;
+        bool hit = false;
+        int hx = 0, hy = 0;
+        while (__any(active)) {
+            float fx = x0 + dx * t;
+            float fy = y0 + dy * t;
+            int px = (int)fx, py = (int)fy;
+            bool live = active & ((unsigned)px < uW) & ((unsigned)py < uH);
+            px = live ? px : 0;
+            py = live ? py : 0;
+            typename Field::raw_t raw = field.load(px, py);
+            bool occ = live & field.occupied(raw);
+            hx = occ ? px : hx;
+            hy = occ ? py : hy;
+            hit |= occ;
+            float tn = t + field.step_of(raw, px, py);
+            bool go = live & !occ;
+            t = go ? tn : t;
+            active = go & (tn < max_range);
+        }
+        float rr = (r_all >= 0.0f) ? r_all : max_range;
+        if (hit) {
+            float xd = (float)hx - x0;
+            float yd = (float)hy - y0;
+            rr = sqrtf(xd * xd + yd * yd);
+        }
+        rr = rr * res;                                          // env.py:426
+        for (int p = 0; p < nseg; ++p)
+            nv::seg_merge(rr, lx, ly, dx, dy, pr.seg[p][0], pr.seg[p][1], pr.seg[p][2], pr.seg[p][3]);
+        for (int p = 0; p < ndisc; ++p)
+            nv::circle_merge(rr, lx, ly, dx, dy, pr.disc[p][0], pr.disc[p][1], nv::kLegRadius);
+        rr = rr < 0.0f ? 0.0f : rr;                             // env.py:435
+        rr = rr > rmax ? rmax : rr;
+        if (noise_std > 0.0f && rr != rmax)                     // env.py:437-440
             rr = rr + noise_std * nv::gauss_noise(c.seed ^ noise_key, genv, noise_key, (uint32_t)k);
         cr |= (rr < thr[k]);
         dc |= (rr < dthr[k]);
@@ -644,9 +850,7 @@ __device__ __forceinline__ void scan_beams_dyn(const navsim_config& c, StepShare
                         rng[k] = sqrtf(xd * xd + yd * yd);
                         active = false;
                     } else {
-                        float dq = field.decode(raw, px, py);
-                        float stp = (float)((double)dq * 0.999);
-                        t += (stp > 1.0f) ? stp : 1.0f;
+                        t += field.step_of(raw, px, py);
                         if (!(t < max_range)) { rng[k] = max_range; active = false; }
                     }
                 }
@@ -656,7 +860,7 @@ __device__ __forceinline__ void scan_beams_dyn(const navsim_config& c, StepShare
     __syncthreads();
 
     // ---- pass 3
-    finish_beams<BLOCK>(c, sh, pr, tab, dir, rng, thr, dthr, obs_row, n_hist, noise_std, noise_key, genv,
+    finish_beams<BLOCK>(c, sh, pr, tab, dir, rng, rng, thr, dthr, obs_row, n_hist, noise_std, noise_key, genv,
                         crash, discomfort);
 }
 
@@ -707,7 +911,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                                             navsim_step_io io, int reset_only,
                                                             const uint8_t* __restrict__ reset_mask,
                                                             char* __restrict__ ws_env, char* __restrict__ ws_prims,
-                                                            float* __restrict__ ws_ranges) {
+                                                            float* __restrict__ ws_ranges, unsigned dyn_lds_bytes) {
     __shared__ StepShared sh;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];   // R == 0: float2 dir[B], float rng[B]
     PedShared* psp = nullptr;
@@ -810,6 +1014,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 ps.avx[n] = pa_g[0] * cs; ps.avy[n] = pa_g[0] * s;
             }
             __syncthreads();
+            // the n*(n+1) pair terms are independent: spread them over the whole workgroup (LDS scratch
+            // = the scan's dir/rng area, free until the march), then every pedestrian adds its row in
+            // partner order -- the same sums, in the same order, as a sequential loop
+            double2* pair = (double2*)dyn_lds;
+            const bool pair_par = dyn_lds_bytes >= (unsigned)(n * (n + 1)) * sizeof(double2) && n > 1;
+            if (pair_par) {
+                for (int t = tid; t < n * (n + 1); t += BLOCK) {
+                    int i = t / (n + 1), j = t - i * (n + 1);
+                    double fx = 0.0, fy = 0.0;
+                    if (j != i)
+                        sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
+                    pair[t] = make_double2(fx, fy);
+                }
+                __syncthreads();
+            }
             if (is_ped) {
                 const int i = tid;
                 double vpref = st.ped_v_pref[pq];
@@ -821,24 +1040,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 double fsx = 0.0, fsy = 0.0;
                 for (int j = 0; j <= n; ++j) {
                     if (j == i) continue;
-                    double dxx = ps.ax[j] - ps.ax[i], dyy = ps.ay[j] - ps.ay[i];
-                    double dist = sqrt(dxx * dxx + dyy * dyy);
-                    if (dist < 1e-9) continue;
-                    double ddx = dxx / dist, ddy = dyy / dist;
-                    double ivx = c.sfm_lambda * (ps.avx[i] - ps.avx[j]) + ddx;
-                    double ivy = c.sfm_lambda * (ps.avy[i] - ps.avy[j]) + ddy;
-                    double il = sqrt(ivx * ivx + ivy * ivy);
-                    if (il < 1e-9) continue;
-                    double idx = ivx / il, idy = ivy / il;
-                    double theta = nv::atan2_(idx * ddy - idy * ddx, idx * ddx + idy * ddy);
-                    double Bq = c.sfm_gamma * il;
-                    double a1 = c.sfm_n_prime * Bq * theta;
-                    double a2 = c.sfm_n * Bq * theta;
-                    double fv = -nv::exp_neg(-dist / Bq - a1 * a1);
-                    double sgn = (theta > 0.0) ? 1.0 : ((theta < 0.0) ? -1.0 : 0.0);
-                    double fa = -sgn * nv::exp_neg(-dist / Bq - a2 * a2);
-                    fsx += fv * idx + fa * (-idy);
-                    fsy += fv * idy + fa * idx;
+                    double fx, fy;
+                    if (pair_par) { double2 f = pair[i * (n + 1) + j]; fx = f.x; fy = f.y; }
+                    else sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
+                    fsx += fx;
+                    fsy += fy;
                 }
                 double fox = 0.0, foy = 0.0;
                 {
@@ -976,14 +1182,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     float2* dir_lds = (float2*)dyn_lds;
     float* rng_lds = (float*)(dyn_lds + sizeof(float2) * (size_t)B);
     if constexpr (MODE != kModeFused)
-        finish_beams<BLOCK>(c, sh, prims, st.beam_table, nullptr, ws_ranges + (size_t)e * B, st.scan_threshold,
+        finish_beams<BLOCK>(c, sh, prims, st.beam_table, nullptr, ws_ranges + (size_t)e * B, nullptr, st.scan_threshold,
                             st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
+    else if constexpr (R == 11)
+        scan_beams_pred<BLOCK, Field>(c, sh, field, st.beam_table, prims, st.scan_threshold, st.scan_discomfort,
+                                      obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
     else if constexpr (R == 0)
         scan_beams_dyn<BLOCK, Field>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
                                      st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
     else
-        scan_beams<BLOCK, R, Field>(c, sh, field, st.beam_table, prims, st.scan_threshold, st.scan_discomfort,
-                                    obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
+        scan_beams<BLOCK, R, Field, PEDS>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
+                                          st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
 
     NAVSIM_STAMP(3);
     if (!reset_only && MODE != kModeFinal) {
@@ -1048,12 +1257,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         if (MODE == kModeFused && sh.rescan) {
             if (sh.respawn) n_hist = 0;
             int c2, d2;
-            if constexpr (R == 0)
+            if constexpr (R == 11)
+                scan_beams_pred<BLOCK, Field>(c, sh, field, st.beam_table, prims, st.scan_threshold, st.scan_discomfort,
+                                              obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
+            else if constexpr (R == 0)
                 scan_beams_dyn<BLOCK, Field>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
                                              st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
             else
-                scan_beams<BLOCK, R, Field>(c, sh, field, st.beam_table, prims, st.scan_threshold, st.scan_discomfort,
-                                            obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
+                scan_beams<BLOCK, R, Field, PEDS>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
+                                                  st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
         }
     }
 
@@ -1147,13 +1359,19 @@ void launch_step(const navsim_config* c, const navsim_state* st, const navsim_st
                  int reset_only, const uint8_t* mask, char* ws_env, char* ws_prims, float* ws_ranges,
                  hipStream_t s) {
     const bool peds = c->ped_model != NAVSIM_PED_NONE;
-    const size_t lds = (R == 0 && MODE == kModeFused) ? (size_t)c->n_beams * (sizeof(float2) + sizeof(float)) : 0;
+    const bool peds_ = c->ped_model != NAVSIM_PED_NONE;
+    size_t lds = ((R == 0 || (peds_ && R != 11)) && MODE == kModeFused)
+                     ? (size_t)c->n_beams * (sizeof(float2) + sizeof(float)) : 0;      // dir + rng
+    if (const char* pad = getenv("NAVSIM_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments only
     if (c->field_format == NAVSIM_FIELD_U16T) {
-        if (peds) navsim_step_kernel<BLOCK, R, true, FieldU16T, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges);
-        else      navsim_step_kernel<BLOCK, R, false, FieldU16T, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges);
+        if (peds) navsim_step_kernel<BLOCK, R, true, FieldU16T, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds);
+        else      navsim_step_kernel<BLOCK, R, false, FieldU16T, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds);
+    } else if (c->field_format == NAVSIM_FIELD_F32S) {
+        if (peds) navsim_step_kernel<BLOCK, R, true, FieldF32S, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds);
+        else      navsim_step_kernel<BLOCK, R, false, FieldF32S, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds);
     } else {
-        if (peds) navsim_step_kernel<BLOCK, R, true, FieldF32, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges);
-        else      navsim_step_kernel<BLOCK, R, false, FieldF32, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges);
+        if (peds) navsim_step_kernel<BLOCK, R, true, FieldF32, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds);
+        else      navsim_step_kernel<BLOCK, R, false, FieldF32, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds);
     }
 }
 
@@ -1181,6 +1399,8 @@ int run_pooled(const navsim_config* c, const navsim_state* st, const navsim_step
     for (int pass = 0; pass < (reset_only ? 1 : 2); ++pass) {
         if (c->field_format == NAVSIM_FIELD_U16T)
             pool_scan_kernel<FieldU16T><<<grid, 256, 0, s>>>(*c, *st, ws_env, ws_ranges, pass, n_logical);
+        else if (c->field_format == NAVSIM_FIELD_F32S)
+            pool_scan_kernel<FieldF32S><<<grid, 256, 0, s>>>(*c, *st, ws_env, ws_ranges, pass, n_logical);
         else
             pool_scan_kernel<FieldF32><<<grid, 256, 0, s>>>(*c, *st, ws_env, ws_ranges, pass, n_logical);
         if (pass == 0) launch_step<256, 1, kModePost>(c, st, io, reset_only, mask, ws_env, ws_prims, ws_ranges, s);
@@ -1206,6 +1426,7 @@ int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_s
     NAVSIM_VARIANT(64, 1)
     NAVSIM_VARIANT(256, 0)
     NAVSIM_VARIANT(256, 1)
+    NAVSIM_VARIANT(256, 11)
     NAVSIM_VARIANT(256, 2)
     NAVSIM_VARIANT(256, 5)
     NAVSIM_VARIANT(512, 0)
@@ -1285,6 +1506,7 @@ size_t navsim_field_bytes(int32_t n_maps, int32_t H, int32_t W, int32_t format) 
     if (n_maps <= 0 || H <= 0 || W <= 0) return 0;
     if (format == NAVSIM_FIELD_F32) return (size_t)n_maps * H * W * sizeof(float);
     if (format == NAVSIM_FIELD_U16T) return (size_t)n_maps * ((H + 7) / 8) * ((W + 7) / 8) * 64 * sizeof(uint16_t);
+    if (format == NAVSIM_FIELD_F32S) return (size_t)n_maps * ((H + 3) / 4) * ((W + 7) / 8) * 32 * sizeof(float);
     return 0;
 }
 
@@ -1293,7 +1515,8 @@ int navsim_build_field(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W,
                        void* stream) {
     (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     if (!occ || !field || !workspace || n_maps < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
-    if (format != NAVSIM_FIELD_F32 && format != NAVSIM_FIELD_U16T) return NAVSIM_E_UNSUPPORTED;
+    if (format != NAVSIM_FIELD_F32 && format != NAVSIM_FIELD_U16T && format != NAVSIM_FIELD_F32S) return NAVSIM_E_UNSUPPORTED;
+    if (format == NAVSIM_FIELD_F32S && !overflow) return NAVSIM_E_ARG;
     if (H >= kDtInf || W >= kDtInf || (size_t)W * 4 > 64 * 1024) return NAVSIM_E_UNSUPPORTED;
     size_t per_map = (size_t)H * W * sizeof(uint16_t);
     size_t chunk = workspace_bytes / per_map;
@@ -1301,8 +1524,8 @@ int navsim_build_field(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W,
     if (chunk > 65535) chunk = 65535;
     hipStream_t s = (hipStream_t)stream;
     const size_t field_per_map = navsim_field_bytes(1, H, W, format);
-    if (format == NAVSIM_FIELD_U16T)       // padding cells of edge tiles are never read; keep them defined
-        (void)hipMemsetAsync(field, 0xFF, field_per_map * (size_t)n_maps, s);
+    if (format != NAVSIM_FIELD_F32)        // padding cells of edge tiles are never read; keep them defined
+        (void)hipMemsetAsync(field, format == NAVSIM_FIELD_U16T ? 0xFF : 0, field_per_map * (size_t)n_maps, s);
     for (int32_t m0 = 0; m0 < n_maps; m0 += (int32_t)chunk) {
         int32_t m = (n_maps - m0 < (int32_t)chunk) ? n_maps - m0 : (int32_t)chunk;
         dt_columns_kernel<<<dim3((W + 255) / 256, m), 256, 0, s>>>(occ + (size_t)m0 * H * W,
@@ -1311,8 +1534,10 @@ int navsim_build_field(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W,
         float* o = overflow ? overflow + (size_t)m0 * H * W : nullptr;
         if (format == NAVSIM_FIELD_F32)
             dt_rows_kernel<0><<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace, f, nullptr, nullptr, H, W);
-        else
+        else if (format == NAVSIM_FIELD_U16T)
             dt_rows_kernel<1><<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace, f, o, n_saturated, H, W);
+        else
+            dt_rows_kernel<2><<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace, f, o, n_saturated, H, W);
     }
     return launch_status();
 }
@@ -1398,7 +1623,9 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
     if (!c || !st || !io) return NAVSIM_E_ARG;
     if (c->n_envs < 0 || c->n_beams < 1 || c->n_scan_stack < 1 || c->map_h < 1 || c->map_w < 1) return NAVSIM_E_ARG;
     if (c->max_peds > NAVSIM_MAX_PEDS) return NAVSIM_E_UNSUPPORTED;
-    if (c->field_format != NAVSIM_FIELD_F32 && c->field_format != NAVSIM_FIELD_U16T) return NAVSIM_E_UNSUPPORTED;
+    if (c->field_format != NAVSIM_FIELD_F32 && c->field_format != NAVSIM_FIELD_U16T &&
+        c->field_format != NAVSIM_FIELD_F32S) return NAVSIM_E_UNSUPPORTED;
+    if (c->field_format == NAVSIM_FIELD_F32S && !st->field_overflow) return NAVSIM_E_ARG;
     if (!st->field || !st->scan_threshold || !st->scan_discomfort || !st->robot_pose || !st->robot_goal ||
         !st->prev_action || !st->prev_pose || !st->n_hist || !st->episode || !st->steps || !io->obs)
         return NAVSIM_E_ARG;

@@ -24,6 +24,7 @@ OBS_TAIL = 7
 
 FIELD_F32 = 0
 FIELD_U16T = 1
+FIELD_F32S = 2
 FIELD_TILE = 8
 
 

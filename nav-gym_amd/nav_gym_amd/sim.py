@@ -60,7 +60,7 @@ def build_field(occ, fmt=abi.FIELD_U16T, keep_overflow=None):
     if fmt == abi.FIELD_F32:
         return build_dt(occ), None, 0
     nbytes = L.navsim_field_bytes(E, H, W, fmt)
-    field = torch.empty(nbytes // 2, dtype=torch.int16, device=occ.device)
+    field = torch.empty(nbytes // 2, dtype=torch.int16, device=occ.device)     # opaque blob
     overflow = torch.empty((E, H, W), dtype=torch.float32, device=occ.device)
     nsat = torch.zeros(1, dtype=torch.int32, device=occ.device)
     per_map = L.navsim_build_dt_workspace_bytes(1, H, W)

@@ -134,8 +134,8 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
         else:
             field = f32                                   # float32 plane: spawn sampling below
             a["field"] = packed
-            if nsat > 0:
-                a["field_overflow"] = f32                 # some cell is >= 256 cells from any obstacle
+            if nsat > 0:                                  # U16T: some cell >= 256 cells from any obstacle;
+                a["field_overflow"] = f32                 # F32S: always (exact distances live here)
         del occ_t
     else:
         if cfg.field_format != abi.FIELD_F32:

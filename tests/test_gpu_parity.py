@@ -229,7 +229,7 @@ def _rollout_pair(gpu, cfg, occ, n_peds, steps, seed, noise=False):
         yield t, go.cpu().numpy(), {k: v.cpu().numpy() for k, v in gout.items()}, ro, rout, g, r
 
 
-@pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T])
+@pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T, abi.FIELD_F32S])
 @pytest.mark.parametrize("ped_model,S,auto_reset", [(abi.PED_NONE, 1, 1), (abi.PED_SFM, 2, 1), (abi.PED_EXTERNAL, 3, 0)])
 def test_step_rollout_vs_oracle(gpu, ped_model, S, auto_reset, fmt):
     """48 arenas x 60 steps on 240x240 maps, 1081 beams: every output and every state array of the
