@@ -351,3 +351,102 @@ def test_env_wrapper_gym_api(gpu):
     assert rr.shape == (32,)
     done_again = benv.compute_terminals(bo)
     assert done_again.shape == (32,)
+
+
+@pytest.fixture(scope="module")
+def full_c2(gpu):
+    """BASELINE config 2 at full size: 4096 arenas x 1081 beams x 500x500 maps (built once)."""
+    import bench
+    wl = dict(bench.WORKLOADS["c2"]); wl["field"] = "u16t"
+    cfg, sim, arrays, occ = bench.build_sim(wl, 0, 1)
+    return cfg, sim, arrays, occ
+
+
+def test_full_size_c2_properties_and_sampled_oracle(gpu, full_c2):
+    """Full-size run (the oracle cannot step 4096 arenas in seconds): size-independent properties on
+    every arena + bit-exact oracle comparison on a sample of arenas (arenas are independent, so a
+    sampled arena's rows must equal an oracle run of just that arena)."""
+    torch = gpu.torch
+    cfg, sim, arrays, occ = full_c2
+    E, B = cfg.n_envs, cfg.n_beams
+    sample = np.array([0, 1, 7, 63, 64, 511, 1000, 2047, 2048, 3000, 4094, 4095])
+    sub_cfg = cfg.copy(); sub_cfg.n_envs = 1
+    refs = []
+    for e in sample:                                  # one single-arena oracle per sampled arena
+        c1 = sub_cfg.copy(); c1.env_index_base = int(e)
+        host = {}
+        for k, t in sim.t.items():
+            if k in ("field", "field_overflow", "workspace", "beam_table"):
+                continue
+            a = t.detach().cpu().numpy()
+            host[k] = a if k in ("scan_threshold", "scan_discomfort") else a[e:e + 1]
+        host["field"] = ref.build_dt(occ[e:e + 1])
+        r = ref.RefSim(c1, host)
+        r.obs[r.cur][...] = sim.obs[e:e + 1].cpu().numpy()
+        refs.append(r)
+    rng = np.random.default_rng(11)
+    g = torch.Generator(device=gpu.dev); g.manual_seed(3)
+    total_done = 0
+    for t in range(12):
+        act = torch.rand((E, 2), generator=g, device=gpu.dev, dtype=torch.float64)
+        act[:, 0] *= 0.5; act[:, 1] = act[:, 1] * 1.28 - 0.64
+        if t % 4 == 1:
+            act[:, 0] = 0.5; act[:, 1] = 0.0
+        obs, out = sim.step(act)
+        o = obs.cpu().numpy(); scan = o[:, :B]
+        assert np.isfinite(o).all() and (scan >= 0).all() and (scan <= 25.0).all()
+        done = out["done"].cpu().numpy().astype(bool)
+        succ = out["is_success"].cpu().numpy() > 0; crash = out["is_crash"].cpu().numpy() > 0
+        assert np.array_equal(done, succ | crash)
+        assert np.array_equal(succ, out["distance"].cpu().numpy() < cfg.distance_threshold)
+        total_done += int(done.sum())
+        a_host = act.cpu().numpy()
+        for e, r in zip(sample, refs):
+            ro, rout = r.step(a_host[e:e + 1])
+            _eq(o[e:e + 1], ro, "arena %d obs at step %d" % (e, t))
+            for k in rout:
+                _eq(out[k][e:e + 1].cpu().numpy(), rout[k], "arena %d %s at step %d" % (e, k, t))
+    assert total_done > 0
+
+
+def test_full_size_c2_determinism_and_shard_invariance(gpu, full_c2):
+    """Two half-shards (env_index_base 0 and 2048) reproduce the full batch bit for bit, and a
+    repeated run reproduces itself: arenas never interact and all randomness is keyed by the
+    global arena index."""
+    torch = gpu.torch
+    cfg, sim, arrays, occ = full_c2
+    E = cfg.n_envs
+    state0 = {k: v.clone() for k, v in sim.t.items()}
+    obs0 = sim.obs.clone()
+    g = torch.Generator(device=gpu.dev); g.manual_seed(5)
+    acts = torch.rand((6, E, 2), generator=g, device=gpu.dev, dtype=torch.float64)
+    acts[..., 0] *= 0.5; acts[..., 1] = acts[..., 1] * 1.28 - 0.64
+
+    def run(lo, hi, base):
+        c = cfg.copy(); c.n_envs = hi - lo; c.env_index_base = base
+        arr = {}
+        for k, v in state0.items():
+            if k in ("workspace",):
+                continue
+            if k == "field":
+                per = v.numel() // E
+                arr[k] = v.reshape(E, per)[lo:hi].reshape(-1).clone()
+            elif k in ("scan_threshold", "scan_discomfort", "beam_table"):
+                arr[k] = v.clone()
+            else:
+                arr[k] = v[lo:hi].clone()
+        s = gpu.sim.NavSim(c, arr)
+        s.obs_buf[s.cur].copy_(obs0[lo:hi])
+        outs = []
+        for t in range(6):
+            o, out = s.step(acts[t, lo:hi])
+            outs.append((o.clone(), {k: v.clone() for k, v in out.items()}))
+        return outs
+    full = run(0, E, 0)
+    again = run(0, E, 0)
+    a, b = run(0, E // 2, 0), run(E // 2, E, E // 2)
+    for t in range(6):
+        assert torch.equal(full[t][0], again[t][0])
+        assert torch.equal(full[t][0], torch.cat([a[t][0], b[t][0]]))
+        for k in full[t][1]:
+            assert torch.equal(full[t][1][k], torch.cat([a[t][1][k], b[t][1][k]])), k
