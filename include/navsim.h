@@ -122,6 +122,9 @@ typedef struct navsim_state {
     const float*  field_overflow;   /* [E,H,W] float32 distances, read only where the packed field
                                        holds 0xFFFF; may be NULL when navsim_build_field reported
                                        no saturated cell (NAVSIM_FIELD_U16T only) */
+    const uint32_t* tile_table;     /* [E, ceil(H/8)*ceil(W/8)] analytic 8x8-tile records (navsim_build_tiles);
+                                       optional accelerator staged in LDS by the step, NULL = every probe reads
+                                       the field.  Results are unchanged. */
     const double* beam_table;       /* [B,2] cos, sin of the robot-frame beam angles (navsim_beam_table);
                                        optional accelerator, NULL = evaluate every beam direction in full */
     const float*  scan_threshold;   /* [B] env.py:162-170 */
@@ -197,6 +200,18 @@ size_t navsim_field_bytes(int32_t n_maps, int32_t map_h, int32_t map_w, int32_t 
 int    navsim_build_field(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t map_w, int32_t format,
                           void* field, float* overflow, int32_t* n_saturated,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* Analytic tile records.  In an 8x8-cell tile whose cells all have their nearest obstacle on ONE
+ * axis-aligned feature (a wall row, a wall column, a corner cell, or the tile is solid), the squared
+ * distance is (px-ox)^2 [or 0] + (py-oy)^2 [or 0] with one (ox, oy) for the whole tile.  The builder
+ * derives the feature from the exact transform and VERIFIES the formula on all 64 cells before
+ * marking the tile valid, so a valid record reproduces the field exactly; the step keeps the table
+ * of an arena in LDS (4 B per tile) and reads HBM only for probes in the remaining mixed tiles.
+ * Record: bit 31 valid, bit 30 dx == 0, bit 29 dy == 0, bits 27..14 oy, bits 13..0 ox. */
+size_t navsim_tile_table_bytes(int32_t n_maps, int32_t map_h, int32_t map_w);
+size_t navsim_build_tiles_workspace_bytes(int32_t n_maps, int32_t map_h, int32_t map_w);
+int    navsim_build_tiles(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t map_w,
+                          uint32_t* tiles, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- a4: PyRayMarching.calc_range_many (env.py:425) ------------------------------------- */
 /* queries [E, n_per_env, 3] float32 (x, y, theta) in cell units, out [E, n_per_env] in cells. */

@@ -160,6 +160,9 @@ __device__ __forceinline__ double wrap_pi(double a) {
 // brackets x (the same correction hipcc emits for sqrtf, minus the denormal scaling and the class
 // test, which cannot trigger in this range).  tests/test_gpu_parity.py checks all 65,535 inputs.
 __device__ __forceinline__ float sqrt_small_int(float x) {
+#ifdef NAVSIM_DIAG_RAW_SQRT          // diagnostic build only: how much of the step is the sqrt correction?
+    return __builtin_amdgcn_sqrtf(x);
+#endif
     float s = __builtin_amdgcn_sqrtf(x);
     float sm = __uint_as_float(__float_as_uint(s) - 1u);
     float sp = __uint_as_float(__float_as_uint(s) + 1u);

@@ -71,6 +71,21 @@ def build_field(occ, fmt=abi.FIELD_U16T, keep_overflow=None):
     return field, overflow, int(nsat.item())          # reset path: a sync is fine here
 
 
+def build_tiles(occ):
+    """occ: uint8 CUDA tensor [E,H,W] -> int32 [E,T] analytic tile records (navsim_build_tiles)."""
+    torch = require_gpu()
+    L = load()
+    occ = occ.contiguous()
+    E, H, W = occ.shape
+    per = L.navsim_tile_table_bytes(1, H, W) // 4
+    tiles = torch.zeros((E, per), dtype=torch.int32, device=occ.device)
+    per_ws = L.navsim_build_tiles_workspace_bytes(1, H, W)
+    chunk = max(1, min(E, (512 << 20) // max(per_ws, 1)))
+    ws = torch.empty(per_ws * chunk, dtype=torch.uint8, device=occ.device)
+    check(L.navsim_build_tiles(_ptr(occ), E, H, W, _ptr(tiles), _ptr(ws), ws.numel(), _stream()), "navsim_build_tiles")
+    return tiles
+
+
 def cast_static(field, queries, max_range):
     torch = require_gpu()
     E, H, W = field.shape

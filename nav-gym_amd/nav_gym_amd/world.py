@@ -127,6 +127,7 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
     a = {}
     if field is None:
         occ_t = torch.as_tensor(occ).to(dev)
+        H0, W0 = occ_t.shape[1:]
         packed, f32, nsat = sim.build_field(occ_t, cfg.field_format)
         if cfg.field_format == abi.FIELD_F32:
             field = packed
@@ -136,6 +137,12 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
             a["field"] = packed
             if nsat > 0:                                  # U16T: some cell >= 256 cells from any obstacle;
                 a["field_overflow"] = f32                 # F32S: always (exact distances live here)
+            # analytic tile records (LDS-resident accelerator): exact, but measured no faster than the
+            # plain march on c2 (profiles/README.md), so opt-in
+            import os
+            if (os.environ.get("NAVSIM_TILES") == "1" and cfg.field_format == abi.FIELD_U16T
+                    and sim.load().navsim_tile_table_bytes(1, H0, W0) <= 40960):
+                a["tile_table"] = sim.build_tiles(occ_t)
         del occ_t
     else:
         if cfg.field_format != abi.FIELD_F32:

@@ -450,3 +450,43 @@ def test_full_size_c2_determinism_and_shard_invariance(gpu, full_c2):
         assert torch.equal(full[t][0], torch.cat([a[t][0], b[t][0]]))
         for k in full[t][1]:
             assert torch.equal(full[t][1][k], torch.cat([a[t][1][k], b[t][1][k]])), k
+
+
+def test_step_with_tile_table_matches_oracle(gpu, monkeypatch):
+    """Opt-in LDS tile-table march (NAVSIM_TILES=1): same bits as the oracle."""
+    monkeypatch.setenv("NAVSIM_TILES", "1")
+    E, size = 24, 240
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, n_spawn=8, auto_reset=1, seed=77,
+                                 field_format=abi.FIELD_U16T)
+    gpu.world.lidar_1081(cfg)
+    occ = gpu.world.make_maps(E, size, 77)
+    n = 0
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=0, steps=40, seed=4):
+        assert "tile_table" in g.t
+        _eq(go, ro, "obs at step %d" % t)
+        for k in rout:
+            _eq(gout[k], rout[k], "%s at step %d" % (k, t))
+        n += 1
+    assert n == 40
+
+
+def test_tile_table_reproduces_field(gpu):
+    """Every VALID analytic tile record must give the exact squared distance of all its in-map
+    cells; mixed tiles are simply not marked.  Outdoor maps should be mostly valid."""
+    for size, n, indoor in ((100, 2, 0.0), (253, 2, 0.0), (500, 2, 0.0), (400, 2, 1.0)):
+        occ = gpu.world.make_maps(n, size, 5 + size, indoor_ratio=indoor)
+        tiles = gpu.sim.build_tiles(_t(gpu, occ)).cpu().numpy().view(np.uint32)
+        d2 = np.rint(ref.build_dt(occ).astype(np.float64) ** 2).astype(np.int64)
+        tpr = (size + 7) // 8
+        yy, xx = np.mgrid[0:size, 0:size]
+        frac = []
+        for m in range(n):
+            rec = tiles[m, : tpr * tpr].reshape(tpr, tpr)[yy // 8, xx // 8]
+            valid = (rec >> 31) & 1
+            ox = (rec & 0x3FFF).astype(np.int64); oy = ((rec >> 14) & 0x3FFF).astype(np.int64)
+            ddx = np.where((rec >> 30) & 1, 0, xx - ox); ddy = np.where((rec >> 29) & 1, 0, yy - oy)
+            got = ddx * ddx + ddy * ddy
+            assert np.array_equal(got[valid == 1], d2[m][valid == 1]), (size, m)
+            frac.append(valid.mean())
+        if indoor == 0.0 and size >= 253:
+            assert np.mean(frac) > 0.5, frac
