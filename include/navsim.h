@@ -108,6 +108,13 @@ typedef struct navsim_config {
     double sfm_agent_radius;
 
     uint64_t seed;           /* counter-based RNG key (scan noise, spawn choice) */
+
+    /* pedestrian lidar (human.py:12-16) and the robot as pedestrians see it (env.py:404-405):
+     * only used by navsim_ped_scans */
+    double ped_angle_min, ped_angle_last, ped_range_max;
+    int32_t ped_n_beams;
+    int32_t reserved1;
+    double robot_seen_footprint[8];   /* threshold_footprint, 4 x (x, y) in the robot frame */
 } navsim_config;
 
 /* ------------------------------------------------------------------------------------------
@@ -264,6 +271,13 @@ int navsim_step(const navsim_config* cfg, const navsim_state* st, const navsim_s
                 void* stream);
 
 size_t navsim_step_workspace_bytes(const navsim_config* cfg);
+
+/* ---- env.py:685-693: the scan of every pedestrian (input of the reference's HumanPolicy) --------- */
+/* out [E, N, ped_n_beams] float32 metres: static map from the pedestrian's integer cell, the robot as its
+ * threshold footprint and the other pedestrians as footprint rectangles (lidar_legs=False), clipped to
+ * ped_range_max, no noise.  Uses the CURRENT state (call it after navsim_step / navsim_reset_obs).
+ * Rows of pedestrians >= n_peds[e] are left untouched. */
+int navsim_ped_scans(const navsim_config* cfg, const navsim_state* st, float* out, void* stream);
 
 /* First observation after reset() (env.py:822-831): scan at the current robot pose, stack filled
  * with copies, prev_pose = pose, vel = 0; sets prev_pose/prev_action/n_hist.  `mask` [E] uint8 or

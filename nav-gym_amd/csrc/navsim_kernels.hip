@@ -764,16 +764,13 @@ __device__ __forceinline__ float march_ray(const Field& field, float x0, float y
 // results land with an LDS atomicMin on the (non-negative) float bits, so they do not depend on the
 // order of primitives.  rng[] holds metres, dir[] the beam directions.
 template <int BLOCK>
-__device__ __forceinline__ void merge_prims_culled(const navsim_config& c, const StepShared& sh, const Prims pr,
-                                                   const float2* __restrict__ dir, float* __restrict__ rng) {
-    const int B = c.n_beams;
+__device__ __forceinline__ void merge_prims_culled_core(int B, float lx, float ly, float stepf, float beta0,
+                                                        int nseg, int ndisc, const Prims pr,
+                                                        const float2* __restrict__ dir, float* __restrict__ rng) {
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const float lx = sh.lx, ly = sh.ly;
-    const float stepf = (float)nv::linspace_step(c);
-    const float beta0 = (float)(c.angle_min + (double)sh.lth);      // bearing of beam 0
     const float kTwoPiF = 6.2831853f;
     const float Kf = (stepf > 0.0f) ? kTwoPiF / stepf : 0.0f;
-    const int nseg = sh.nseg, nprim = sh.nseg + sh.ndisc;
+    const int nprim = nseg + ndisc;
     for (int p = wave; p < nprim; p += BLOCK / 64) {
         const bool is_seg = p < nseg;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -812,6 +809,13 @@ __device__ __forceinline__ void merge_prims_culled(const navsim_config& c, const
             }
         }
     }
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void merge_prims_culled(const navsim_config& c, const StepShared& sh, const Prims pr,
+                                                   const float2* __restrict__ dir, float* __restrict__ rng) {
+    merge_prims_culled_core<BLOCK>(c.n_beams, sh.lx, sh.ly, (float)nv::linspace_step(c),
+                                   (float)(c.angle_min + (double)sh.lth), sh.nseg, sh.ndisc, pr, dir, rng);
 }
 
 // raw ranges (cells) -> metres, pedestrians, clip, noise, crash / discomfort flags, observation row
@@ -1468,6 +1472,79 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     NAVSIM_STAMP(6);
 }
 
+// ============================================================================================
+// env.py:685-693: the 512-beam half-plane scan of every pedestrian (what the reference feeds to
+// HumanPolicy).  One workgroup per (pedestrian, arena): rectangles of the other agents in LDS,
+// march from the pedestrian's integer cell, bearing-culled polygon merge, clip to 6 m.
+// ============================================================================================
+template <typename Field>
+__global__ __launch_bounds__(256) void ped_scan_kernel(navsim_config c, navsim_state st, float* __restrict__ out) {
+    constexpr int BLOCK = 256;
+    __shared__ float seg[4 * (NAVSIM_MAX_PEDS + 1)][4];
+    __shared__ int nseg_s, i0_s, j0_s;
+    __shared__ float lx_s, ly_s, lth_s;
+    extern __shared__ __attribute__((aligned(16))) char dyn[];       // float2 dir[PB], float rng[PB]
+    const int e = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
+    const int N = c.max_peds, PB = c.ped_n_beams, H = c.map_h, W = c.map_w;
+    int n = st.n_peds[e];
+    n = n > N ? N : n;
+    if (i >= n) return;
+    float2* dir = (float2*)dyn;
+    float* rng = (float*)(dyn + sizeof(float2) * (size_t)PB);
+    if (tid == 0) {
+        nseg_s = 0;
+        const double* pp = st.ped_pose + ((size_t)e * N + i) * 3;
+        lx_s = (float)pp[0]; ly_s = (float)pp[1]; lth_s = (float)pp[2];              // env.py:386
+        nv::xy_to_ij_f32(lx_s, ly_s, c, i0_s, j0_s);                                 // env.py:419
+    }
+    __syncthreads();
+    if (tid <= n && tid != i) {                                                      // env.py:404-414
+        const int a = tid;
+        const double* pose = (a < n) ? st.ped_pose + ((size_t)e * N + a) * 3 : st.robot_pose + 3 * (size_t)e;
+        const double hfx[4] = {0.22, -0.22, -0.22, 0.22}, hfy[4] = {0.19, 0.19, -0.19, -0.19};   // human.py:5-10
+        double s, cs;
+        nv::sincos(pose[2], s, cs);
+        float vx[4], vy[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            double x = (a < n) ? hfx[v] : c.robot_seen_footprint[2 * v];
+            double y = (a < n) ? hfy[v] : c.robot_seen_footprint[2 * v + 1];
+            vx[v] = (float)((cs * x - s * y) + pose[0]);
+            vy[v] = (float)((s * x + cs * y) + pose[1]);
+        }
+        int q = atomicAdd(&nseg_s, 4);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            int w = (v + 1) & 3;
+            seg[q + v][0] = vx[v]; seg[q + v][1] = vy[v]; seg[q + v][2] = vx[w]; seg[q + v][3] = vy[w];
+        }
+    }
+    const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, H, W);
+    const float max_range = (float)((long long)H * W);
+    const float res = (float)c.resolution, rmax = (float)c.ped_range_max;
+    const double step = (PB > 1) ? (c.ped_angle_last - c.ped_angle_min) / (double)(PB - 1) : 0.0;
+    const float x0 = (float)i0_s, y0 = (float)j0_s;
+    const double lth = (double)lth_s;
+    for (int k = tid; k < PB; k += BLOCK) {
+        double lin = (PB == 1) ? c.ped_angle_min : ((k == PB - 1) ? c.ped_angle_last : (double)k * step + c.ped_angle_min);
+        float dx, dy;
+        nv::beam_dir((float)(lin + lth), dx, dy);
+        dir[k] = make_float2(dx, dy);
+        rng[k] = march_ray(field, x0, y0, dx, dy, 0.0f, max_range, (unsigned)W, (unsigned)H) * res;
+    }
+    __syncthreads();
+    const Prims pr = {seg, nullptr};
+    merge_prims_culled_core<BLOCK>(PB, lx_s, ly_s, (float)step, (float)(c.ped_angle_min + lth), nseg_s, 0, pr, dir, rng);
+    __syncthreads();
+    float* row = out + ((size_t)e * N + i) * PB;
+    for (int k = tid; k < PB; k += BLOCK) {
+        float r = rng[k];
+        r = r < 0.0f ? 0.0f : r;
+        r = r > rmax ? rmax : r;
+        row[k] = r;
+    }
+}
+
 __global__ __launch_bounds__(256) void beam_table_kernel(navsim_config c, double* __restrict__ tab) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= c.n_beams) return;
@@ -1672,6 +1749,14 @@ int navsim_default_config(navsim_config* c) {
     c->sfm_n_prime = 3.0;
     c->sfm_sigma_obstacle = 0.8;
     c->sfm_agent_radius = 0.35;
+    c->ped_angle_min = -1.57079632679;      // human.py:13 
+    c->ped_angle_last = 1.57079632679 - 0.00613592315;   // human.py:12,14; env.py:389 
+    c->ped_range_max = 6.0;                 // human.py:15 
+    c->ped_n_beams = 512;                   // human.py:16 
+    {   // keti_robot.py:18-23 threshold_footprint 
+        const double fp[8] = {0.6, 0.6, -0.7, 0.6, -0.7, -0.6, 0.6, -0.6};
+        for (int i = 0; i < 8; ++i) c->robot_seen_footprint[i] = fp[i];
+    }
     c->seed = 1234;
     return NAVSIM_OK;
 }
@@ -1859,6 +1944,23 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
     }
     if (c->auto_reset && c->n_spawn > 0 && (!st->spawn_pose || !st->spawn_goal)) return NAVSIM_E_ARG;
     return NAVSIM_OK;
+}
+
+int navsim_ped_scans(const navsim_config* c, const navsim_state* st, float* out, void* stream) {
+    (void)hipGetLastError();
+    if (!c || !st || !out || c->ped_model == NAVSIM_PED_NONE || !st->n_peds || !st->ped_pose || !st->robot_pose ||
+        !st->field || c->ped_n_beams < 1 || c->max_peds < 1) return NAVSIM_E_ARG;
+    if (c->max_peds > NAVSIM_MAX_PEDS || c->ped_n_beams > 4096) return NAVSIM_E_UNSUPPORTED;
+    if (c->field_format == NAVSIM_FIELD_F32S && !st->field_overflow) return NAVSIM_E_ARG;
+    if (c->n_envs == 0) return NAVSIM_OK;
+    dim3 grid(c->max_peds, c->n_envs);
+    size_t lds = (size_t)c->ped_n_beams * (sizeof(float2) + sizeof(float));
+    hipStream_t s = (hipStream_t)stream;
+    if (c->field_format == NAVSIM_FIELD_U16T)      ped_scan_kernel<FieldU16T><<<grid, 256, lds, s>>>(*c, *st, out);
+    else if (c->field_format == NAVSIM_FIELD_F32S) ped_scan_kernel<FieldF32S><<<grid, 256, lds, s>>>(*c, *st, out);
+    else if (c->field_format == NAVSIM_FIELD_F32)  ped_scan_kernel<FieldF32><<<grid, 256, lds, s>>>(*c, *st, out);
+    else return NAVSIM_E_UNSUPPORTED;
+    return launch_status();
 }
 
 size_t navsim_step_workspace_bytes(const navsim_config* c) { return c ? workspace_bytes(c) : 0; }

@@ -72,6 +72,12 @@ class NavsimConfig(C.Structure):
         ("sfm_sigma_obstacle", C.c_double),
         ("sfm_agent_radius", C.c_double),
         ("seed", C.c_uint64),
+        ("ped_angle_min", C.c_double),
+        ("ped_angle_last", C.c_double),
+        ("ped_range_max", C.c_double),
+        ("ped_n_beams", C.c_int32),
+        ("reserved1", C.c_int32),
+        ("robot_seen_footprint", C.c_double * 8),
     ]
 
     def copy(self):
@@ -190,6 +196,7 @@ def declare(lib, suffix=""):
     if not suffix:
         sig("navsim_beam_table", [cfgp, _P, _P])
         sig("navsim_step_workspace_bytes", [cfgp], C.c_size_t)
+    sig("navsim_ped_scans", [cfgp, stp, _P] + stream)
     sig("navsim_step", [cfgp, stp, iop] + stream)
     sig("navsim_reset_obs", [cfgp, stp, iop, _P] + stream)
     return lib
@@ -202,6 +209,6 @@ EXPORTS = (
     "navsim_tile_table_bytes", "navsim_build_tiles_workspace_bytes", "navsim_build_tiles",
     "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
-    "navsim_scan_threshold", "navsim_beam_table", "navsim_step_workspace_bytes", "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
+    "navsim_scan_threshold", "navsim_beam_table", "navsim_step_workspace_bytes", "navsim_ped_scans", "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math",
 )

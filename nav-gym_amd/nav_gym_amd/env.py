@@ -246,6 +246,12 @@ class NavGymEnv(object):
         info = {"is_success": out["is_success"], "is_crash": out["is_crash"], "distance": out["distance"]}
         return obs, out["reward"], out["done"].bool(), info
 
+    def human_scans(self):
+        """The pedestrians' own 512-beam half-plane scans (env.py:685-693), float32 [E, N, 512]: what
+        the reference stacks and feeds to HumanPolicy.  With pedestrian_model='external' a caller can run
+        that policy (or any other) on them and pass the resulting (v, w) to step(human_actions=...)."""
+        return self.sim.ped_scans()
+
     # ---- HER batch API (env.py:464-589) ---------------------------------------------------------------
     def _rd(self, obs):
         import torch

@@ -239,6 +239,14 @@ class NavSim(object):
         self.cur = 1 - self.cur
         return self.obs, self.out
 
+    def ped_scans(self):
+        """Scan of every pedestrian (env.py:685-693) from the current state -> float32 [E, N, 512]."""
+        import torch
+        out = torch.zeros((self.cfg.n_envs, self.cfg.max_peds, self.cfg.ped_n_beams), dtype=torch.float32,
+                          device=self.device)
+        check(self.lib.navsim_ped_scans(C.byref(self.cfg), C.byref(self.st), _ptr(out), _stream()), "navsim_ped_scans")
+        return out
+
     def launch_step(self):
         """step() without the action copy: inputs already resident (bench inner loop)."""
         self._flip()

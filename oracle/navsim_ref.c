@@ -60,6 +60,14 @@ int navsim_default_config_cpu(navsim_config* c) {
     c->sfm_n_prime = 3.0;
     c->sfm_sigma_obstacle = 0.8;
     c->sfm_agent_radius = 0.35;
+    c->ped_angle_min = -1.57079632679;      /* human.py:13 */
+    c->ped_angle_last = 1.57079632679 - 0.00613592315;   /* human.py:12,14; env.py:389 */
+    c->ped_range_max = 6.0;                 /* human.py:15 */
+    c->ped_n_beams = 512;                   /* human.py:16 */
+    {   /* keti_robot.py:18-23 threshold_footprint */
+        const double fp[8] = {0.6, 0.6, -0.7, 0.6, -0.7, -0.6, 0.6, -0.6};
+        for (int i = 0; i < 8; ++i) c->robot_seen_footprint[i] = fp[i];
+    }
     c->seed = 1234;
     return NAVSIM_OK;
 }
@@ -528,6 +536,58 @@ static void robot_scan(const navsim_config* c, const navsim_state* st, int e, in
         if (r > rmax) r = rmax;
         ranges[k] = r;
     }
+}
+
+/* env.py:685-693: pedestrian scans (human lidar, robot + other pedestrians as polygons, no legs) */
+int navsim_ped_scans_cpu(const navsim_config* c, const navsim_state* st, float* out) {
+    if (!c || !st || !out || c->ped_model == NAVSIM_PED_NONE) return NAVSIM_E_ARG;
+    if (c->field_format != NAVSIM_FIELD_F32) return NAVSIM_E_UNSUPPORTED;
+    const int N = c->max_peds, PB = c->ped_n_beams, H = c->map_h, W = c->map_w;
+    const float max_range = (float)((int64_t)H * W);
+    const float res = (float)c->resolution, rmax = (float)c->ped_range_max;
+    const double step = (PB > 1) ? (c->ped_angle_last - c->ped_angle_min) / (double)(PB - 1) : 0.0;
+    for (int e = 0; e < c->n_envs; ++e) {
+        const float* f = (const float*)st->field + (size_t)(c->shared_field ? 0 : e) * H * W;
+        int n = st->n_peds[e] > N ? N : st->n_peds[e];
+        /* rectangles of every agent: pedestrians 0..n-1, then the robot (env.py:404-414) */
+        float vx[NAVSIM_MAX_PEDS + 1][4], vy[NAVSIM_MAX_PEDS + 1][4];
+        for (int a = 0; a <= n; ++a) {
+            const double* pose = (a < n) ? st->ped_pose + ((size_t)e * N + a) * 3 : st->robot_pose + 3 * (size_t)e;
+            double s, cs;
+            nvr_sincos(pose[2], &s, &cs);
+            for (int v = 0; v < 4; ++v) {
+                double x = (a < n) ? HUMAN_FOOTPRINT[v][0] : c->robot_seen_footprint[2 * v];
+                double y = (a < n) ? HUMAN_FOOTPRINT[v][1] : c->robot_seen_footprint[2 * v + 1];
+                vx[a][v] = (float)((cs * x - s * y) + pose[0]);
+                vy[a][v] = (float)((s * x + cs * y) + pose[1]);
+            }
+        }
+        for (int i = 0; i < n; ++i) {
+            const double* pp = st->ped_pose + ((size_t)e * N + i) * 3;
+            float lx = (float)pp[0], ly = (float)pp[1], lth = (float)pp[2];
+            int i0, j0;
+            xy_to_ij_f32(lx, ly, c, &i0, &j0);
+            float* row = out + ((size_t)e * N + i) * PB;
+            for (int k = 0; k < PB; ++k) {
+                double lin = (PB == 1) ? c->ped_angle_min : ((k == PB - 1) ? c->ped_angle_last : (double)k * step + c->ped_angle_min);
+                float heading = (float)(lin + (double)lth);
+                float dx, dy;
+                beam_dir(heading, &dx, &dy);
+                float r = trace_ray(f, H, W, (float)i0, (float)j0, dx, dy, max_range) * res;
+                for (int a = 0; a <= n; ++a) {
+                    if (a == i) continue;
+                    for (int v = 0; v < 4; ++v) {
+                        int w = (v + 1) & 3;
+                        seg_merge(&r, lx, ly, dx, dy, vx[a][v], vy[a][v], vx[a][w], vy[a][w]);
+                    }
+                }
+                if (r < 0.0f) r = 0.0f;
+                if (r > rmax) r = rmax;
+                row[k] = r;
+            }
+        }
+    }
+    return NAVSIM_OK;
 }
 
 /* a14  _make_scan_threshold (env.py:162-180): contour-only scan of a footprint at pose 0 */

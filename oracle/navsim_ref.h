@@ -64,6 +64,8 @@ int navsim_reward_done_cpu(const navsim_config* cfg, const void* obs, const void
 int navsim_scan_threshold_cpu(const navsim_config* cfg, const float* footprint, int32_t n_vert,
                               float* out);
 
+int navsim_ped_scans_cpu(const navsim_config* cfg, const navsim_state* st, float* out);
+
 int navsim_step_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io);
 /* same, envs [e0, e1) only: lets the CPU baseline split envs over threads */
 int navsim_step_range_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,

@@ -242,6 +242,11 @@ class RefSim(object):
     def set_ped_cmd(self, cmd):
         self.a["ped_cmd"][...] = cmd
 
+    def ped_scans(self):
+        out = np.zeros((self.cfg.n_envs, self.cfg.max_peds, self.cfg.ped_n_beams), np.float32)
+        _chk(lib().navsim_ped_scans_cpu(C.byref(self.cfg), C.byref(self.st), _p(out)), "ped_scans")
+        return out
+
     def reset_obs(self, mask=None):
         io = self._io(None)
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)

@@ -399,7 +399,7 @@ def snapshot(env):
     )
 
 
-def run_trace(name, ref_env, human, human_policy, S, seed, scenario, n_steps):
+def run_trace(name, ref_env, human, human_policy, S, seed, scenario, n_steps, ped_scan_every=0):
     env = make_env(ref_env, human_policy, S, seed)
     rng = np.random.default_rng(seed)
     B = env.robot.n_angles
@@ -447,6 +447,10 @@ def run_trace(name, ref_env, human, human_policy, S, seed, scenario, n_steps):
     acts = np.zeros((T, 2)); obs = np.zeros((T, S * B + 7)); rew = np.zeros(T); done = np.zeros(T, np.uint8)
     succ = np.zeros(T, np.float32); crash = np.zeros(T, np.float32); dist = np.zeros(T)
     ped_cmd = np.zeros((T, N, 2)); snaps = {k: [] for k in ("robot_pose", "ped_pose", "ped_vel", "ped_dist")}
+    # pedestrian scans (env.py:685-693, the input of HumanPolicy): latest 512-beam scan of every
+    # pedestrian on a few steps (kept small; steps with a crash are skipped because those scans saw
+    # the robot at the pre-revert pose, which the returned state no longer holds)
+    ped_scan_steps, ped_scans = [], []
     try:
         for t in range(T):
             if scenario == "random":
@@ -460,6 +464,10 @@ def run_trace(name, ref_env, human, human_policy, S, seed, scenario, n_steps):
             acts[t] = a; obs[t] = o["observation"]; rew[t] = r; done[t] = d
             succ[t] = info["is_success"]; crash[t] = info["is_crash"]; dist[t] = info["distance"]
             ped_cmd[t] = np.array(cmds).reshape(N, 2)
+            if ped_scan_every and t % ped_scan_every == 0 and not info["is_crash"]:
+                ped_scan_steps.append(t)
+                ped_scans.append(np.stack([env.prev_humans_obs_queue[i][-1]["observation"][2 * 512:3 * 512]
+                                           for i in range(N)]).astype(np.float32))
             for k, v in snapshot(env).items():
                 snaps[k].append(v)
     finally:
@@ -469,6 +477,9 @@ def run_trace(name, ref_env, human, human_policy, S, seed, scenario, n_steps):
     assert np.array_equal(rec["obs_scan"].astype(np.float64), obs[:, : S * B])   # scans are float32 values
     for k, v in snaps.items():
         rec["traj_" + k] = np.stack(v)
+    if ped_scans:
+        rec["ped_scan_steps"] = np.array(ped_scan_steps)
+        rec["ped_scan"] = np.stack(ped_scans)
     np.savez_compressed(os.path.join(HERE, "golden_trace_%s.npz" % name), **rec)
     print("golden_trace_%s.npz: T=%d N=%d crashes=%d successes=%d" % (name, T, N, int(crash.sum()), int(succ.sum())))
 
@@ -476,8 +487,8 @@ def run_trace(name, ref_env, human, human_policy, S, seed, scenario, n_steps):
 def main():
     ref_env, human, keti_robot, ref_utils, human_policy = import_reference()
     make_units(ref_env, human, keti_robot, ref_utils)
-    run_trace("random_S1", ref_env, human, human_policy, S=1, seed=11, scenario="random", n_steps=40)
-    run_trace("peds_S1", ref_env, human, human_policy, S=1, seed=12, scenario="peds", n_steps=30)
+    run_trace("random_S1", ref_env, human, human_policy, S=1, seed=11, scenario="random", n_steps=40, ped_scan_every=5)
+    run_trace("peds_S1", ref_env, human, human_policy, S=1, seed=12, scenario="peds", n_steps=30, ped_scan_every=3)
     run_trace("crash_S3", ref_env, human, human_policy, S=3, seed=13, scenario="crash", n_steps=24)
     run_trace("success_S2", ref_env, human, human_policy, S=2, seed=14, scenario="success", n_steps=12)
 

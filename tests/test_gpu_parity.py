@@ -196,6 +196,9 @@ def test_step_golden_traces(gpu, name):
         assert abs(o["reward"][0] - tr["reward"][t]) < 1e-9, t
         _eq(obs[0, : S * B], tr["obs_scan"][t], "scan stack at step %d" % t)
         np.testing.assert_allclose(obs[0, S * B:], tr["obs_tail"][t], rtol=0, atol=2e-6)
+        if "ped_scan_steps" in tr and t in tr["ped_scan_steps"]:          # env.py:685-693 on the GPU
+            idx = int(np.where(tr["ped_scan_steps"] == t)[0][0])
+            _eq(sim.ped_scans().cpu().numpy()[0, : tr["ped_scan"].shape[1]], tr["ped_scan"][idx], "pedestrian scans")
         stt = sim.numpy_state("robot_pose", "ped_pose", "ped_dist")
         np.testing.assert_allclose(stt["robot_pose"][0], tr["traj_robot_pose"][t], rtol=0, atol=1e-12)
         np.testing.assert_allclose(stt["ped_pose"][0], tr["traj_ped_pose"][t], rtol=0, atol=1e-12)
@@ -288,6 +291,21 @@ def test_packed_field_overflow_path(gpu):
             _eq(gout[k], rout[k], "%s at step %d" % (k, t))
         seen += 1
     assert seen == 25
+
+
+@pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T])
+def test_ped_scans_vs_oracle(gpu, fmt):
+    """navsim_ped_scans (env.py:685-693) for 20 pedestrians per arena: bit-exact vs the oracle."""
+    E, size, N = 12, 240, 20
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_SFM, n_spawn=8,
+                                 auto_reset=1, seed=31, field_format=fmt)
+    gpu.world.lidar_1081(cfg)
+    occ = gpu.world.make_maps(E, size, 31)
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=17, steps=6, seed=8):
+        got = g.ped_scans().cpu().numpy()
+        exp = r.ped_scans()
+        _eq(got[:, :17], exp[:, :17], "pedestrian scans at step %d" % t)
+        assert (exp[:, :17] < 6.0).any()
 
 
 def test_config1_single_env_64_beams(gpu):

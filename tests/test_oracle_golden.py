@@ -137,6 +137,12 @@ def test_step_trace(name):
         np.testing.assert_allclose(sim.a["ped_pose"][0], tr["traj_ped_pose"][t], rtol=0, atol=1e-12)
         np.testing.assert_allclose(sim.a["ped_vel"][0], tr["traj_ped_vel"][t], rtol=0, atol=1e-12)
         np.testing.assert_allclose(sim.a["ped_dist"][0], tr["traj_ped_dist"][t], rtol=0, atol=1e-10)
+        if "ped_scan_steps" in tr and t in tr["ped_scan_steps"]:
+            # env.py:685-693: the pedestrians' own scans (robot + other pedestrians as polygons)
+            idx = int(np.where(tr["ped_scan_steps"] == t)[0][0])
+            got = sim.ped_scans()[0, : tr["ped_scan"].shape[1]]
+            assert np.array_equal(got, tr["ped_scan"][idx]), ("pedestrian scans", t)
+            assert (got < 6.0).any()
     if name.startswith("crash"):
         assert tr["is_crash"].sum() > 0 and (tr["is_crash"] == 0).sum() > 0
     if name.startswith("success"):
