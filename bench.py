@@ -27,6 +27,8 @@ WORKLOADS = {
     "c2": dict(envs=4096, beams=1081, size=500, peds=0),
     "c3": dict(envs=4096, beams=1081, size=500, peds=20),
     "c4": dict(envs=2048, beams=1081, size=1000, peds=0),      # 16384 arenas over 8 GPUs
+    # 4096 arenas over 8 GPUs, Husky, 20 pedestrians, a NEW random map at every episode end (navsim_regen)
+    "c5": dict(envs=512, beams=1081, size=500, peds=20, robot="husky", regen=True),
 }
 
 
@@ -53,8 +55,12 @@ def build_sim(wl, rank, world_size, seed=1234, device="cuda:0"):
     arrays = world.make_world(cfg, occ, n_peds=wl["peds"], device=device, min_goal_dist=goal[0], max_goal_dist=goal[1],
                               robot_clearance=1.2 if wl["size"] >= 400 else 0.9)
     dev = torch.device(device)
+    robot = wl.get("robot", "keti")
+    cfg.axle_offset = robots.ROBOTS[robot]["axle_offset"]
+    for i, v in enumerate(np.asarray(robots.ROBOTS[robot]["threshold_footprint"], dtype=np.float64).reshape(-1)):
+        cfg.robot_seen_footprint[i] = float(v)
     for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
-        arrays[key] = sim.scan_threshold(cfg, torch.from_numpy(robots.footprint_array("keti", name)).to(dev))
+        arrays[key] = sim.scan_threshold(cfg, torch.from_numpy(robots.footprint_array(robot, name)).to(dev))
     s = sim.NavSim(cfg, arrays, device=device)
     s.reset_obs()
     return cfg, s, arrays, occ
@@ -161,9 +167,16 @@ def main():
     if args.gather == "all" and dist is not None and backend == "nccl":
         gather_buf = torch.empty((world_size * E, sim.obs.shape[1]), dtype=torch.float32, device=device)
 
+    regen = bool(wl.get("regen"))
+    lin_hi, rot_hi = (1.0, 2.0) if wl.get("robot") == "husky" else (0.5, 0.64)
+    acts[..., 0] *= lin_hi / 0.5
+    acts[..., 1] *= rot_hi / 0.64
+
     def run(t):
         sim.io.action = acts[t].data_ptr()
         sim.launch_step()
+        if regen:                       # finished arenas restart on a freshly generated map, on the device
+            sim.regen()
         if gather_buf is not None:
             dist.all_gather_into_tensor(gather_buf, sim.obs)
 
@@ -219,8 +232,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%s: %d arenas/GPU x %d-beam lidar, %dx%d per-arena occupancy maps (%s distance "
-                            "field), %d pedestrians/arena, KetiRobot diff-drive, auto-respawn in place"
-                            % (args.workload, E, cfg.n_beams, cfg.map_h, cfg.map_w, args.field, wl["peds"]),
+                            "field), %d pedestrians/arena, %s kinematics, %s"
+                            % (args.workload, E, cfg.n_beams, cfg.map_h, cfg.map_w, args.field, wl["peds"],
+                               wl.get("robot", "keti"),
+                               "new random map per episode (navsim_regen)" if regen else "auto-respawn in place"),
                 "envs_per_gpu": E, "n_beams": cfg.n_beams, "map": [cfg.map_h, cfg.map_w],
                 "pedestrians": wl["peds"], "obs_gather": args.gather, "episodes_finished_rank0": n_done,
             },

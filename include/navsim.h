@@ -115,6 +115,19 @@ typedef struct navsim_config {
     int32_t ped_n_beams;
     int32_t reserved1;
     double robot_seen_footprint[8];   /* threshold_footprint, 4 x (x, y) in the robot frame */
+
+    /* device-side reset of finished arenas with a NEW map (navsim_regen):
+     * the per-episode ranges of the reference (__init__.py:14-15, 17-18, 26-37; env.py:748-806) */
+    int32_t regen_cap;                /* arenas regenerated per call at most (the rest keep their map) */
+    int32_t obstacle_number;          /* env_param_range['obstacle_number'] */
+    double obstacle_width_lo, obstacle_width_hi;   /* env_param_range['obstacle_width'] */
+    double spawn_clearance;           /* robot start / goal cells keep this distance to obstacles, m */
+    double ped_clearance;             /* same for pedestrians */
+    double min_goal_dist, max_goal_dist;           /* __init__.py:17-18 */
+    double ped_min_robot_dist;        /* env.py:372: 4 m */
+    double ped_min_goal_dist;         /* env.py:788-791: 10 m */
+    double v_pref_lo, v_pref_hi;      /* human_v_pref_range */
+    double has_legs_ratio;            /* human_has_legs_ratio */
 } navsim_config;
 
 /* ------------------------------------------------------------------------------------------
@@ -278,6 +291,19 @@ size_t navsim_step_workspace_bytes(const navsim_config* cfg);
  * ped_range_max, no noise.  Uses the CURRENT state (call it after navsim_step / navsim_reset_obs).
  * Rows of pedestrians >= n_peds[e] are left untouched. */
 int navsim_ped_scans(const navsim_config* cfg, const navsim_state* st, float* out, void* stream);
+
+/* ---- reset() of finished arenas on the device, with a new random map ------------ */
+/* For every arena with done[e] != 0 (at most cfg.regen_cap, lowest indices first): a fresh outdoor map
+ * (create_outdoor_map, map_generator.py:126-143, counter-based RNG keyed by seed / global arena /
+ * episode), its distance field, a new table of start / goal pairs (clearance and distance rules of
+ * env.py:748-783 without the A* path test), the robot placed on one of them, every pedestrian re-drawn
+ * (start >= 4 m from the robot, goal >= 10 m away, v_pref, has_legs: env.py:786-806) and the first
+ * observation of the new episode (env.py:808-831) written to io->obs.  Call it right after navsim_step on
+ * the same stream with the same io.  Mutates field, spawn tables and pedestrian parameters in place.
+ * Square maps, FIELD_F32 or FIELD_U16T without an overflow plane or tile table. */
+size_t navsim_regen_workspace_bytes(const navsim_config* cfg);
+int    navsim_regen(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
+                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* First observation after reset() (env.py:822-831): scan at the current robot pose, stack filled
  * with copies, prev_pose = pose, vel = 0; sets prev_pose/prev_action/n_hist.  `mask` [E] uint8 or

@@ -44,9 +44,11 @@ __device__ unsigned long long* g_stamps = nullptr;
 constexpr int kDtInf = 32768;
 
 __global__ __launch_bounds__(256) void dt_columns_kernel(const uint8_t* __restrict__ occ,
-                                                         uint16_t* __restrict__ g, int H, int W) {
+                                                         uint16_t* __restrict__ g, int H, int W,
+                                                         const int* __restrict__ n_live) {
     int x = blockIdx.x * blockDim.x + threadIdx.x;
     size_t m = blockIdx.y;
+    if (n_live && (int)m >= *n_live) return;          // navsim_regen: only the first *n_live maps are live
     if (x >= W) return;
     const uint8_t* o = occ + m * (size_t)H * W;
     uint16_t* gg = g + m * (size_t)H * W;
@@ -149,9 +151,11 @@ struct FieldF32S {
 template <int FORMAT>
 __global__ __launch_bounds__(256) void dt_rows_kernel(const uint16_t* __restrict__ g,
                                                       void* __restrict__ field_v, float* __restrict__ overflow,
-                                                      int32_t* __restrict__ n_saturated, int H, int W) {
+                                                      int32_t* __restrict__ n_saturated, int H, int W,
+                                                      const int* __restrict__ n_live) {
     extern __shared__ int32_t row[];                 // W entries of g(i)^2-ready distances
     size_t m = blockIdx.y;
+    if (n_live && (int)m >= *n_live) return;
     int y = blockIdx.x;
     const uint16_t* gr = g + (m * (size_t)H + y) * W;
     for (int x = threadIdx.x; x < W; x += blockDim.x) {
@@ -1473,6 +1477,157 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 }
 
 // ============================================================================================
+// navsim_regen: reset() of finished arenas on the device with a new random map.
+// Specification: oracle/navsim_ref.c navsim_regen_cpu (same hash-keyed uniforms, same tries).
+// ============================================================================================
+__device__ __forceinline__ double rg_u(uint64_t key, uint64_t i) {
+    return (double)(nv::mix64(key + i * 0x9E3779B97F4A7C15ULL) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ordered compaction of the arenas that finished in this step: list[0..count), mask[e]
+__global__ __launch_bounds__(1024) void regen_select_kernel(const uint8_t* __restrict__ done, int E, int cap,
+                                                            int* __restrict__ count, int* __restrict__ list,
+                                                            uint8_t* __restrict__ mask) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (E + 1023) / 1024;
+    const int lo = tid * per, hi = (lo + per < E) ? lo + per : E;
+    int n = 0;
+    for (int e = lo; e < hi; ++e) n += done[e] != 0;
+    part[tid] = n;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                 // inclusive scan
+        int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int pos = part[tid] - n;
+    for (int e = lo; e < hi; ++e) {
+        bool take = done[e] != 0 && pos < cap;
+        mask[e] = take ? 1 : 0;
+        if (take) list[pos] = e;
+        pos += done[e] != 0;
+    }
+    if (tid == 1023) *count = part[1023] < cap ? part[1023] : cap;
+}
+
+// create_outdoor_map (map_generator.py:126-143) at size x size, hash-keyed
+__global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim_state st,
+                                                         const int* __restrict__ count, const int* __restrict__ list,
+                                                         uint8_t* __restrict__ occ_all) {
+    const int b = blockIdx.x;
+    if (b >= *count) return;
+    const int e = list[b], size = c.map_w, tid = threadIdx.x;
+    uint8_t* occ = occ_all + (size_t)b * size * size;
+    const uint64_t key = nv::hash4(c.seed, (uint64_t)(c.env_index_base + e), (uint64_t)st.episode[e], 0x4D4150ULL);
+    double w = c.obstacle_width_lo + (c.obstacle_width_hi - c.obstacle_width_lo) * rg_u(key, 0);
+    const int hw = (int)(10.0 * w);
+    for (int idx = tid; idx < size * size; idx += 256) {
+        int r = idx / size, q = idx - r * size;
+        occ[(size_t)(size - 1 - r) * size + q] = !(r >= 5 && r < size - 5 && q >= 5 && q < size - 5);
+    }
+    __syncthreads();
+    int span = size - 2 * hw - 3;
+    span = span < 1 ? 1 : span;
+    const int side = 2 * hw + 1;
+    for (int o = 0; o < c.obstacle_number; ++o) {
+        int cx = hw + 2 + (int)(rg_u(key, 1 + 2 * (uint64_t)o) * span);
+        int cy = hw + 2 + (int)(rg_u(key, 2 + 2 * (uint64_t)o) * span);
+        for (int idx = tid; idx < side * side; idx += 256) {
+            int r = cx - hw + idx / side, q = cy - hw + idx % side;
+            if (r >= 0 && r < size && q >= 0 && q < size) occ[(size_t)(size - 1 - r) * size + q] = 1;
+        }
+    }
+}
+
+template <typename Field>
+__device__ __forceinline__ void rg_sample(const navsim_config& c, const Field& f, uint64_t key, uint64_t& n,
+                                          double clr, bool use_ref, double rx, double ry, double dmin, double dmax,
+                                          double& x, double& y) {
+    const int W = c.map_w, H = c.map_h;
+    int bi = 0, bj = 0;
+    float bd = -1.0f;
+    for (int t = 0; t < 64; ++t) {
+        int i = (int)(rg_u(key, n++) * W), j = (int)(rg_u(key, n++) * H);
+        float d = f.at(i, j);
+        double px = ((double)i + 0.5) * c.resolution + c.origin_x;
+        double py = ((double)j + 0.5) * c.resolution + c.origin_y;
+        bool ok = (double)d >= clr;
+        if (ok && use_ref) {
+            double ddx = px - rx, ddy = py - ry;
+            double dist = sqrt(ddx * ddx + ddy * ddy);
+            ok = dist > dmin && dist < dmax;
+        }
+        if (ok) { x = px; y = py; return; }
+        if (d > bd) { bd = d; bi = i; bj = j; }
+    }
+    x = ((double)bi + 0.5) * c.resolution + c.origin_x;
+    y = ((double)bj + 0.5) * c.resolution + c.origin_y;
+}
+
+// install the new field, draw the start / goal table, the robot and the pedestrians
+template <typename Field>
+__global__ __launch_bounds__(256) void regen_commit_kernel(navsim_config c, navsim_state st,
+                                                           const int* __restrict__ count, const int* __restrict__ list,
+                                                           const char* __restrict__ field_scratch, size_t field_bytes) {
+    __shared__ double robot_xy[2];
+    const int b = blockIdx.x;
+    if (b >= *count) return;
+    const int e = list[b], tid = threadIdx.x;
+    const int N = c.max_peds, K = c.n_spawn, P = NAVSIM_MAX_WAYPOINTS;
+    {   // field_bytes is a multiple of 16 for both formats at square sizes used here; copy in 4-byte words
+        const uint32_t* src = (const uint32_t*)(field_scratch + (size_t)b * field_bytes);
+        uint32_t* dst = (uint32_t*)((char*)st.field + (size_t)e * field_bytes);
+        for (size_t i = tid; i < field_bytes / 4; i += 256) dst[i] = src[i];
+    }
+    __threadfence_block();
+    __syncthreads();
+    const Field f(st.field, st.field_overflow, e, c.map_h, c.map_w);
+    const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
+    double* sp = (double*)st.spawn_pose + (size_t)e * K * 3;
+    double* sg = (double*)st.spawn_goal + (size_t)e * K * 2;
+    const double clr = c.spawn_clearance / c.resolution;
+    for (int k = tid; k < K; k += 256) {
+        uint64_t key = nv::hash4(c.seed, genv, ep, 0x53504157ULL + (uint64_t)k), n = 0;
+        double x, y, gx, gy;
+        rg_sample(c, f, key, n, clr, false, 0, 0, 0, 0, x, y);
+        double th = nv::kTwoPi * rg_u(key, n++);
+        rg_sample(c, f, key, n, clr, true, x, y, c.min_goal_dist, c.max_goal_dist, gx, gy);
+        sp[3 * k] = x; sp[3 * k + 1] = y; sp[3 * k + 2] = th;
+        sg[2 * k] = gx; sg[2 * k + 1] = gy;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        int idx = (int)(nv::hash4(c.seed, genv, ep, 0x5eedULL) % (uint64_t)K);
+        double* rp = st.robot_pose + 3 * (size_t)e;
+        rp[0] = sp[3 * idx]; rp[1] = sp[3 * idx + 1]; rp[2] = sp[3 * idx + 2];
+        st.robot_goal[2 * e] = sg[2 * idx]; st.robot_goal[2 * e + 1] = sg[2 * idx + 1];
+        robot_xy[0] = rp[0]; robot_xy[1] = rp[1];
+    }
+    __syncthreads();
+    int n = (c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
+    n = n > N ? N : n;
+    const double pclr = c.ped_clearance / c.resolution;
+    for (int i = tid; i < n; i += 256) {
+        size_t q = (size_t)e * N + i;
+        uint64_t key = nv::hash4(c.seed, genv, ep, 0x504544ULL + (uint64_t)i), m = 0;
+        double x, y, gx, gy;
+        rg_sample(c, f, key, m, pclr, true, robot_xy[0], robot_xy[1], c.ped_min_robot_dist, 1.0e300, x, y);
+        double th = nv::kTwoPi * rg_u(key, m++);
+        rg_sample(c, f, key, m, pclr, true, x, y, c.ped_min_goal_dist, 1.0e300, gx, gy);
+        st.ped_pose[q * 3] = x; st.ped_pose[q * 3 + 1] = y; st.ped_pose[q * 3 + 2] = th;
+        st.ped_vel[q * 2] = 0.0; st.ped_vel[q * 2 + 1] = 0.0;
+        ((double*)st.ped_v_pref)[q] = c.v_pref_lo + (c.v_pref_hi - c.v_pref_lo) * rg_u(key, m++);
+        ((uint8_t*)st.ped_has_legs)[q] = rg_u(key, m++) < c.has_legs_ratio;
+        double* wp = st.ped_waypoints + (q * P) * 2;
+        wp[0] = gx; wp[1] = gy;
+        st.ped_n_waypoints[q] = 1;
+    }
+}
+
+// ============================================================================================
 // env.py:685-693: the 512-beam half-plane scan of every pedestrian (what the reference feeds to
 // HumanPolicy).  One workgroup per (pedestrian, arena): rectangles of the other agents in LDS,
 // march from the pedestrian's integer cell, bearing-culled polygon merge, clip to 6 m.
@@ -1757,6 +1912,19 @@ int navsim_default_config(navsim_config* c) {
         const double fp[8] = {0.6, 0.6, -0.7, 0.6, -0.7, -0.6, 0.6, -0.6};
         for (int i = 0; i < 8; ++i) c->robot_seen_footprint[i] = fp[i];
     }
+    c->regen_cap = 64;
+    c->obstacle_number = 10;                // __init__.py:34
+    c->obstacle_width_lo = 0.3;             // __init__.py:35
+    c->obstacle_width_hi = 1.0;
+    c->spawn_clearance = 1.2;
+    c->ped_clearance = 0.5;
+    c->min_goal_dist = 10.0;                // __init__.py:17-18
+    c->max_goal_dist = 20.0;
+    c->ped_min_robot_dist = 4.0;            // env.py:372
+    c->ped_min_goal_dist = 10.0;            // env.py:788-791
+    c->v_pref_lo = 0.0;                     // __init__.py:14
+    c->v_pref_hi = 0.6;
+    c->has_legs_ratio = 0.5;                // __init__.py:15
     c->seed = 1234;
     return NAVSIM_OK;
 }
@@ -1797,15 +1965,15 @@ int navsim_build_field(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W,
     for (int32_t m0 = 0; m0 < n_maps; m0 += (int32_t)chunk) {
         int32_t m = (n_maps - m0 < (int32_t)chunk) ? n_maps - m0 : (int32_t)chunk;
         dt_columns_kernel<<<dim3((W + 255) / 256, m), 256, 0, s>>>(occ + (size_t)m0 * H * W,
-                                                                   (uint16_t*)workspace, H, W);
+                                                                   (uint16_t*)workspace, H, W, nullptr);
         void* f = (char*)field + field_per_map * (size_t)m0;
         float* o = overflow ? overflow + (size_t)m0 * H * W : nullptr;
         if (format == NAVSIM_FIELD_F32)
-            dt_rows_kernel<0><<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace, f, nullptr, nullptr, H, W);
+            dt_rows_kernel<0><<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace, f, nullptr, nullptr, H, W, nullptr);
         else if (format == NAVSIM_FIELD_U16T)
-            dt_rows_kernel<1><<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace, f, o, n_saturated, H, W);
+            dt_rows_kernel<1><<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace, f, o, n_saturated, H, W, nullptr);
         else
-            dt_rows_kernel<2><<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace, f, o, n_saturated, H, W);
+            dt_rows_kernel<2><<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace, f, o, n_saturated, H, W, nullptr);
     }
     return launch_status();
 }
@@ -1961,6 +2129,64 @@ int navsim_ped_scans(const navsim_config* c, const navsim_state* st, float* out,
     else if (c->field_format == NAVSIM_FIELD_F32)  ped_scan_kernel<FieldF32><<<grid, 256, lds, s>>>(*c, *st, out);
     else return NAVSIM_E_UNSUPPORTED;
     return launch_status();
+}
+
+size_t navsim_regen_workspace_bytes(const navsim_config* c) {
+    if (!c || c->regen_cap < 1) return 0;
+    const size_t M = (size_t)c->regen_cap, cells = (size_t)c->map_h * c->map_w;
+    size_t b = 16 + M * 4;                                  // count, list
+    b = (b + 255) & ~(size_t)255;
+    b += ((size_t)c->n_envs + 255) & ~(size_t)255;          // mask
+    b += M * cells;                                         // occupancy scratch
+    b += M * cells * sizeof(uint16_t);                      // column pass
+    b += M * navsim_field_bytes(1, c->map_h, c->map_w, c->field_format);
+    return b + 1024;
+}
+
+int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, void* workspace,
+                 size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
+    if (!c || !st || !io || !io->done || !io->obs || !workspace) return NAVSIM_E_ARG;
+    if (c->map_h != c->map_w || c->n_spawn < 1 || c->regen_cap < 1 || st->tile_table || st->field_overflow ||
+        (c->field_format != NAVSIM_FIELD_F32 && c->field_format != NAVSIM_FIELD_U16T) || c->shared_field)
+        return NAVSIM_E_UNSUPPORTED;
+    if (workspace_bytes < navsim_regen_workspace_bytes(c) || !st->spawn_pose || !st->spawn_goal) return NAVSIM_E_ARG;
+    int rc = check_step_args(c, st, io, 1);
+    if (rc != NAVSIM_OK) return rc;
+    if (c->n_envs == 0) return NAVSIM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int M = c->regen_cap, H = c->map_h, W = c->map_w;
+    const size_t cells = (size_t)H * W;
+    char* w = (char*)workspace;
+    int* count = (int*)w;
+    int* list = count + 4;
+    size_t off = (16 + (size_t)M * 4 + 255) & ~(size_t)255;
+    uint8_t* mask = (uint8_t*)(w + off);
+    off += ((size_t)c->n_envs + 255) & ~(size_t)255;
+    uint8_t* occ = (uint8_t*)(w + off);
+    off += (size_t)M * cells;
+    off = (off + 255) & ~(size_t)255;
+    uint16_t* cols = (uint16_t*)(w + off);
+    off += (size_t)M * cells * sizeof(uint16_t);
+    off = (off + 255) & ~(size_t)255;
+    char* fscratch = w + off;
+    const size_t fbytes = navsim_field_bytes(1, H, W, c->field_format);
+    regen_select_kernel<<<1, 1024, 0, s>>>(io->done, c->n_envs, M, count, list, mask);
+    regen_maps_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, occ);
+    if (c->field_format == NAVSIM_FIELD_U16T) (void)hipMemsetAsync(fscratch, 0xFF, fbytes * (size_t)M, s);
+    dt_columns_kernel<<<dim3((W + 255) / 256, M), 256, 0, s>>>(occ, cols, H, W, count);
+    if (c->field_format == NAVSIM_FIELD_F32) {
+        dt_rows_kernel<0><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, nullptr, nullptr, H, W, count);
+        regen_commit_kernel<FieldF32><<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes);
+    } else {
+        dt_rows_kernel<1><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, nullptr, nullptr, H, W, count);
+        regen_commit_kernel<FieldU16T><<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes);
+    }
+    if (launch_status() != NAVSIM_OK) return NAVSIM_E_LAUNCH;
+    // first observation of the new episodes; the other arenas keep the row the step just wrote
+    navsim_step_io io2 = *io;
+    io2.obs_prev = io->obs;
+    return dispatch_step(c, st, &io2, 1, mask, s);
 }
 
 size_t navsim_step_workspace_bytes(const navsim_config* c) { return c ? workspace_bytes(c) : 0; }

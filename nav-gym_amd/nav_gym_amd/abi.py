@@ -78,6 +78,19 @@ class NavsimConfig(C.Structure):
         ("ped_n_beams", C.c_int32),
         ("reserved1", C.c_int32),
         ("robot_seen_footprint", C.c_double * 8),
+        ("regen_cap", C.c_int32),
+        ("obstacle_number", C.c_int32),
+        ("obstacle_width_lo", C.c_double),
+        ("obstacle_width_hi", C.c_double),
+        ("spawn_clearance", C.c_double),
+        ("ped_clearance", C.c_double),
+        ("min_goal_dist", C.c_double),
+        ("max_goal_dist", C.c_double),
+        ("ped_min_robot_dist", C.c_double),
+        ("ped_min_goal_dist", C.c_double),
+        ("v_pref_lo", C.c_double),
+        ("v_pref_hi", C.c_double),
+        ("has_legs_ratio", C.c_double),
     ]
 
     def copy(self):
@@ -197,6 +210,11 @@ def declare(lib, suffix=""):
         sig("navsim_beam_table", [cfgp, _P, _P])
         sig("navsim_step_workspace_bytes", [cfgp], C.c_size_t)
     sig("navsim_ped_scans", [cfgp, stp, _P] + stream)
+    if suffix:
+        sig("navsim_regen", [cfgp, stp, iop])
+    else:
+        sig("navsim_regen_workspace_bytes", [cfgp], C.c_size_t)
+        sig("navsim_regen", [cfgp, stp, iop, _P, C.c_size_t, _P])
     sig("navsim_step", [cfgp, stp, iop] + stream)
     sig("navsim_reset_obs", [cfgp, stp, iop, _P] + stream)
     return lib
@@ -209,6 +227,7 @@ EXPORTS = (
     "navsim_tile_table_bytes", "navsim_build_tiles_workspace_bytes", "navsim_build_tiles",
     "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
-    "navsim_scan_threshold", "navsim_beam_table", "navsim_step_workspace_bytes", "navsim_ped_scans", "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
+    "navsim_scan_threshold", "navsim_beam_table", "navsim_step_workspace_bytes", "navsim_ped_scans", "navsim_regen_workspace_bytes", "navsim_regen",
+    "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math",
 )

@@ -8,6 +8,8 @@ and default to the reference's behaviour for num_envs == 1:
     num_envs        arenas stepped per call (leading axis of every returned array)
     n_beams, lidar  lidar geometry (default: KetiRobot's 512 beams over 2*pi)
     map_size        cells per side of every arena (default 400, the reference's outdoor size)
+    randomize_maps  True: an arena that finishes an episode restarts on a NEW random outdoor map,
+                    generated on the device inside step() (navsim_regen); False: it respawns in place
     pedestrian_model 'sfm' (build-defined social force), 'external' (caller supplies (v, w) per
                     pedestrian -- the slot the reference fills with HumanPolicy) or 'none'
     device, seed, env_index_base (global index of arena 0: sharding), auto_reset, field_format
@@ -98,7 +100,7 @@ class NavGymEnv(object):
                  reward_discomfort_factor, env_param_range, *,
                  num_envs=1, n_beams=None, lidar=None, map_size=400, pedestrian_model="sfm",
                  num_humans=None, device="cuda:0", seed=0, env_index_base=0, auto_reset=None,
-                 field_format=abi.FIELD_U16T, n_spawn=16):
+                 field_format=abi.FIELD_U16T, n_spawn=16, randomize_maps=False):
         from . import lib
         if robot_type not in robots.ROBOTS:
             raise NotImplementedError(robot_type)            # env.py:772-773
@@ -123,6 +125,7 @@ class NavGymEnv(object):
         self.auto_reset = (self.num_envs > 1) if auto_reset is None else bool(auto_reset)
         self._num_humans_fixed = num_humans
         self._episode_batch = 0
+        self.randomize_maps = bool(randomize_maps)
         spec = robots.ROBOTS[robot_type]
         nh_hi = int(env_param_range["num_humans"][0][1]) if num_humans is None else int(num_humans)
         ped = {"none": abi.PED_NONE, "external": abi.PED_EXTERNAL, "sfm": abi.PED_SFM}[pedestrian_model]
@@ -134,6 +137,15 @@ class NavGymEnv(object):
             n_spawn=n_spawn, add_scan_noise=1, env_index_base=env_index_base, field_format=field_format,
             time_step=time_step, axle_offset=spec["axle_offset"], min_turning_radius=float(min_turning_radius),
             distance_threshold=distance_threshold, range_max=spec["range_max"], seed=self.seed_value)
+        room = self.map_size * cfg.resolution                # per-episode ranges used by navsim_regen
+        cfg.min_goal_dist = float(min(min_goal_dist, 0.4 * room))
+        cfg.max_goal_dist = float(min(max_goal_dist, 0.8 * room))
+        cfg.v_pref_lo, cfg.v_pref_hi = float(human_v_pref_range[0]), float(human_v_pref_range[1])
+        cfg.has_legs_ratio = float(human_has_legs_ratio)
+        cfg.obstacle_number = int(env_param_range["obstacle_number"][0][0])
+        cfg.obstacle_width_lo, cfg.obstacle_width_hi = [float(x) for x in env_param_range["obstacle_width"][0]]
+        for i, v in enumerate(np.asarray(spec["threshold_footprint"], dtype=np.float64).reshape(-1)):
+            cfg.robot_seen_footprint[i] = float(v)
         if lidar is not None:                         # (angle_min, angle_last, n_beams)
             cfg.angle_min, cfg.angle_last, cfg.n_beams = float(lidar[0]), float(lidar[1]), int(lidar[2])
         elif n_beams is not None and int(n_beams) == 1081:
@@ -237,6 +249,8 @@ class NavGymEnv(object):
             self.sim.set_ped_cmd(human_actions)
         a = np.asarray(action, dtype=np.float64).reshape(self.num_envs, 2) if not hasattr(action, "is_cuda") else action
         _, out = self.sim.step(a)
+        if self.randomize_maps and self.auto_reset:
+            self.sim.regen()
         obs = self._obs_dict()
         if self.num_envs == 1:
             info = {"is_success": np.float32(out["is_success"][0].item()),

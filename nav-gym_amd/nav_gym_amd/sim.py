@@ -239,6 +239,20 @@ class NavSim(object):
         self.cur = 1 - self.cur
         return self.obs, self.out
 
+    def regen(self):
+        """navsim_regen right after step(): finished arenas get a new map, tables, pedestrians, first obs."""
+        import torch
+        if "regen_ws" not in self.t:
+            nbytes = self.lib.navsim_regen_workspace_bytes(C.byref(self.cfg))
+            self.t["regen_ws"] = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        io = abi.NavsimStepIO()
+        C.memmove(C.byref(io), C.byref(self.io), C.sizeof(io))
+        io.obs = self.obs_buf[self.cur].data_ptr()
+        ws = self.t["regen_ws"]
+        check(self.lib.navsim_regen(C.byref(self.cfg), C.byref(self.st), C.byref(io), _ptr(ws), ws.numel(), _stream()),
+              "navsim_regen")
+        return self.obs
+
     def ped_scans(self):
         """Scan of every pedestrian (env.py:685-693) from the current state -> float32 [E, N, 512]."""
         import torch

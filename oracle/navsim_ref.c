@@ -68,6 +68,19 @@ int navsim_default_config_cpu(navsim_config* c) {
         const double fp[8] = {0.6, 0.6, -0.7, 0.6, -0.7, -0.6, 0.6, -0.6};
         for (int i = 0; i < 8; ++i) c->robot_seen_footprint[i] = fp[i];
     }
+    c->regen_cap = 64;
+    c->obstacle_number = 10;                /* __init__.py:34 */
+    c->obstacle_width_lo = 0.3;             /* __init__.py:35 */
+    c->obstacle_width_hi = 1.0;
+    c->spawn_clearance = 1.2;
+    c->ped_clearance = 0.5;
+    c->min_goal_dist = 10.0;                /* __init__.py:17-18 */
+    c->max_goal_dist = 20.0;
+    c->ped_min_robot_dist = 4.0;            /* env.py:372 */
+    c->ped_min_goal_dist = 10.0;            /* env.py:788-791 */
+    c->v_pref_lo = 0.0;                     /* __init__.py:14 */
+    c->v_pref_hi = 0.6;
+    c->has_legs_ratio = 0.5;                /* __init__.py:15 */
     c->seed = 1234;
     return NAVSIM_OK;
 }
@@ -951,7 +964,8 @@ int navsim_reset_obs_cpu(const navsim_config* c, const navsim_state* st, const n
     for (int e = 0; e < c->n_envs; ++e) {
         float* obs = io->obs + (size_t)e * D;
         if (mask && !mask[e]) {
-            if (io->obs_prev) memcpy(obs, io->obs_prev + (size_t)e * D, sizeof(float) * D);
+            if (io->obs_prev && io->obs_prev != io->obs)
+                memcpy(obs, io->obs_prev + (size_t)e * D, sizeof(float) * D);
             continue;
         }
         double* rp = st->robot_pose + 3 * (size_t)e;
@@ -976,6 +990,128 @@ int navsim_reset_obs_cpu(const navsim_config* c, const navsim_state* st, const n
     }
     free(scan);
     return NAVSIM_OK;
+}
+
+/* =========================================================================================
+ * reset() of finished arenas with a new random map, restated for the device
+ * (navsim_regen).  BUILD-DEFINED where the reference relies on NumPy's global RNG and A*:
+ *   - uniforms: u(key, i) = (mix64(key + i * 0x9E3779B97F4A7C15) >> 11) * 2^-53, keys from
+ *     hash4(seed, global arena, episode, purpose);
+ *   - map: create_outdoor_map (map_generator.py:126-143) at map_w x map_w cells;
+ *   - start / goal pairs: 64 rejection tries each on clearance and (min, max) goal distance
+ *     (env.py:366-383) -- no A* path-length test;
+ *   - pedestrians: start >= ped_min_robot_dist from the robot (env.py:372), goal farther than
+ *     ped_min_goal_dist (env.py:788-791), v_pref and has_legs re-drawn (env.py:800-803).
+ * ======================================================================================= */
+static inline double rg_u(uint64_t key, uint64_t i) {
+    return (double)(nvr_mix64(key + i * 0x9E3779B97F4A7C15ULL) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+static void regen_map(const navsim_config* c, uint64_t genv, uint64_t ep, uint8_t* occ) {
+    const int size = c->map_w;
+    const uint64_t key = nvr_hash4(c->seed, genv, ep, 0x4D4150ULL);
+    uint64_t n = 0;
+    double w = c->obstacle_width_lo + (c->obstacle_width_hi - c->obstacle_width_lo) * rg_u(key, n++);
+    int hw = (int)(10.0 * w);                                              /* map_generator.py:134 */
+    for (int r = 0; r < size; ++r)
+        for (int q = 0; q < size; ++q)
+            occ[(size_t)(size - 1 - r) * size + q] = !(r >= 5 && r < size - 5 && q >= 5 && q < size - 5);
+    int span = size - 2 * hw - 3;                                          /* range(hw+2, size-hw-1) */
+    if (span < 1) span = 1;
+    for (int o = 0; o < c->obstacle_number; ++o) {
+        int cx = hw + 2 + (int)(rg_u(key, n++) * span);
+        int cy = hw + 2 + (int)(rg_u(key, n++) * span);
+        for (int r = cx - hw; r <= cx + hw; ++r)
+            for (int q = cy - hw; q <= cy + hw; ++q)
+                if (r >= 0 && r < size && q >= 0 && q < size) occ[(size_t)(size - 1 - r) * size + q] = 1;
+    }
+}
+
+static inline void rg_cell_xy(const navsim_config* c, int i, int j, double* x, double* y) {
+    *x = ((double)i + 0.5) * c->resolution + c->origin_x;                  /* env.py:1218-1219 */
+    *y = ((double)j + 0.5) * c->resolution + c->origin_y;
+}
+
+/* one rejection-sampled free cell: first try (of 64) with field >= clr whose distance to (rx, ry)
+ * lies in (dmin, dmax); fallback = the tried cell with the best clearance */
+static void rg_sample(const navsim_config* c, const float* f, uint64_t key, uint64_t* n, double clr,
+                      int use_ref, double rx, double ry, double dmin, double dmax, double* x, double* y) {
+    const int W = c->map_w, H = c->map_h;
+    int bi = 0, bj = 0; float bd = -1.0f;
+    for (int t = 0; t < 64; ++t) {
+        int i = (int)(rg_u(key, (*n)++) * W), j = (int)(rg_u(key, (*n)++) * H);
+        float d = f[(size_t)j * W + i];
+        double px, py;
+        rg_cell_xy(c, i, j, &px, &py);
+        int ok = (double)d >= clr;
+        if (ok && use_ref) {
+            double ddx = px - rx, ddy = py - ry;
+            double dist = sqrt(ddx * ddx + ddy * ddy);
+            ok = dist > dmin && dist < dmax;
+        }
+        if (ok) { *x = px; *y = py; return; }
+        if (d > bd) { bd = d; bi = i; bj = j; }
+    }
+    rg_cell_xy(c, bi, bj, x, y);
+}
+
+int navsim_regen_cpu(const navsim_config* c, const navsim_state* st, const navsim_step_io* io) {
+    if (!c || !st || !io || !io->done || !io->obs) return NAVSIM_E_ARG;
+    if (c->field_format != NAVSIM_FIELD_F32 || c->map_h != c->map_w || c->n_spawn < 1) return NAVSIM_E_UNSUPPORTED;
+    const int E = c->n_envs, N = c->max_peds, K = c->n_spawn, H = c->map_h, W = c->map_w;
+    const int P = NAVSIM_MAX_WAYPOINTS;
+    uint8_t* mask = (uint8_t*)calloc((size_t)E, 1);
+    uint8_t* occ = (uint8_t*)malloc((size_t)H * W);
+    int taken = 0;
+    for (int e = 0; e < E && taken < c->regen_cap; ++e) {
+        if (!io->done[e]) continue;
+        ++taken;
+        mask[e] = 1;
+        const uint64_t genv = (uint64_t)(c->env_index_base + e), ep = (uint64_t)st->episode[e];
+        float* f = (float*)st->field + (size_t)e * H * W;
+        regen_map(c, genv, ep, occ);
+        navsim_build_dt_cpu(occ, 1, H, W, f);
+        /* start / goal table */
+        double* sp = (double*)st->spawn_pose + (size_t)e * K * 3;
+        double* sg = (double*)st->spawn_goal + (size_t)e * K * 2;
+        const double clr = c->spawn_clearance / c->resolution;
+        for (int k = 0; k < K; ++k) {
+            uint64_t key = nvr_hash4(c->seed, genv, ep, 0x53504157ULL + (uint64_t)k), n = 0;
+            rg_sample(c, f, key, &n, clr, 0, 0, 0, 0, 0, &sp[3 * k], &sp[3 * k + 1]);
+            sp[3 * k + 2] = NVR_TWO_PI * rg_u(key, n++);
+            rg_sample(c, f, key, &n, clr, 1, sp[3 * k], sp[3 * k + 1], c->min_goal_dist, c->max_goal_dist,
+                      &sg[2 * k], &sg[2 * k + 1]);
+        }
+        int idx = (int)(nvr_hash4(c->seed, genv, ep, 0x5eedULL) % (uint64_t)K);
+        double* rp = st->robot_pose + 3 * (size_t)e;
+        rp[0] = sp[3 * idx]; rp[1] = sp[3 * idx + 1]; rp[2] = sp[3 * idx + 2];
+        st->robot_goal[2 * e] = sg[2 * idx]; st->robot_goal[2 * e + 1] = sg[2 * idx + 1];
+        /* pedestrians */
+        int n = (c->ped_model == NAVSIM_PED_NONE) ? 0 : st->n_peds[e];
+        if (n > N) n = N;
+        const double pclr = c->ped_clearance / c->resolution;
+        for (int i = 0; i < n; ++i) {
+            size_t q = (size_t)e * N + i;
+            uint64_t key = nvr_hash4(c->seed, genv, ep, 0x504544ULL + (uint64_t)i), m = 0;
+            double x, y, gx, gy;
+            rg_sample(c, f, key, &m, pclr, 1, rp[0], rp[1], c->ped_min_robot_dist, 1.0e300, &x, &y);
+            double th = NVR_TWO_PI * rg_u(key, m++);
+            rg_sample(c, f, key, &m, pclr, 1, x, y, c->ped_min_goal_dist, 1.0e300, &gx, &gy);
+            st->ped_pose[q * 3] = x; st->ped_pose[q * 3 + 1] = y; st->ped_pose[q * 3 + 2] = th;
+            st->ped_vel[q * 2] = 0.0; st->ped_vel[q * 2 + 1] = 0.0;
+            ((double*)st->ped_v_pref)[q] = c->v_pref_lo + (c->v_pref_hi - c->v_pref_lo) * rg_u(key, m++);
+            ((uint8_t*)st->ped_has_legs)[q] = rg_u(key, m++) < c->has_legs_ratio;
+            double* wp = st->ped_waypoints + (q * P) * 2;
+            wp[0] = gx; wp[1] = gy;
+            st->ped_n_waypoints[q] = 1;
+        }
+    }
+    /* first observation of the new episodes (env.py:808-831); other arenas keep the row the step wrote */
+    navsim_step_io io2 = *io;
+    io2.obs_prev = io->obs;
+    int rc = navsim_reset_obs_cpu(c, st, &io2, mask);
+    free(mask); free(occ);
+    return rc;
 }
 
 int navsim_math_cpu(int32_t fn, const double* x, const double* x2, double* out, int32_t n) {

@@ -66,6 +66,8 @@ int navsim_scan_threshold_cpu(const navsim_config* cfg, const float* footprint, 
 
 int navsim_ped_scans_cpu(const navsim_config* cfg, const navsim_state* st, float* out);
 
+int navsim_regen_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io);
+
 int navsim_step_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io);
 /* same, envs [e0, e1) only: lets the CPU baseline split envs over threads */
 int navsim_step_range_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,

@@ -242,6 +242,16 @@ class RefSim(object):
     def set_ped_cmd(self, cmd):
         self.a["ped_cmd"][...] = cmd
 
+    def regen(self):
+        """navsim_regen_cpu right after step(): new maps / tables / pedestrians / first obs for the
+        arenas that finished in that step."""
+        io = abi.NavsimStepIO()
+        io.obs = self.obs[self.cur].ctypes.data
+        for k, v in self.out.items():
+            setattr(io, k, v.ctypes.data)
+        _chk(lib().navsim_regen_cpu(C.byref(self.cfg), C.byref(self.st), C.byref(io)), "regen")
+        return self.obs[self.cur]
+
     def ped_scans(self):
         out = np.zeros((self.cfg.n_envs, self.cfg.max_peds, self.cfg.ped_n_beams), np.float32)
         _chk(lib().navsim_ped_scans_cpu(C.byref(self.cfg), C.byref(self.st), _p(out)), "ped_scans")

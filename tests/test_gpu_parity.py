@@ -308,6 +308,37 @@ def test_ped_scans_vs_oracle(gpu, fmt):
         assert (exp[:, :17] < 6.0).any()
 
 
+@pytest.mark.parametrize("fmt,ped_model", [(abi.FIELD_F32, abi.PED_NONE), (abi.FIELD_U16T, abi.PED_SFM)])
+def test_regen_vs_oracle(gpu, fmt, ped_model):
+    """navsim_regen: finished arenas get a new map, field, start/goal table, robot,
+    pedestrians and first observation on the device -- every array bit-identical to the oracle's."""
+    E, size, N = 40, 200, 6
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=ped_model, n_spawn=6,
+                                 auto_reset=1, seed=17, field_format=fmt, regen_cap=5, min_goal_dist=3.0,
+                                 max_goal_dist=8.0, spawn_clearance=0.9, ped_min_robot_dist=2.0, ped_min_goal_dist=4.0)
+    gpu.world.lidar_1081(cfg)
+    occ = gpu.world.make_maps(E, size, 17)
+    regenerated = capped = 0
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=5, steps=45, seed=6):
+        _eq(go, ro, "obs at step %d" % t)
+        n_done = int(rout["done"].sum())
+        go2 = g.regen().cpu().numpy()
+        ro2 = r.regen()
+        _eq(go2, ro2, "obs after regen at step %d" % t)
+        regenerated += min(n_done, 5); capped += n_done > 5
+        if n_done:
+            gs = g.numpy_state()
+            for k, v in r.a.items():
+                if k in gs and k not in ("field", "field_overflow"):
+                    _eq(gs[k], v, "state %s after regen at step %d" % (k, t))
+            if fmt == abi.FIELD_F32:
+                _eq(gs["field"], r.a["field"], "field after regen at step %d" % t)
+    assert regenerated > 5
+    # a regenerated arena has a valid closed map: 5-cell border, obstacles inside
+    f = r.a["field"]
+    assert (f[:, :5] == 0).all() and (f[:, :, -5:] == 0).all()
+
+
 def test_config1_single_env_64_beams(gpu):
     """BASELINE config 1: 1 env, 64-beam lidar, 100x100 static map, no pedestrians."""
     cfg = gpu.lib.default_config(n_envs=1, map_h=100, map_w=100, n_spawn=4, auto_reset=0, seed=7)
