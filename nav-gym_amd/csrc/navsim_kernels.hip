@@ -52,18 +52,37 @@ __global__ __launch_bounds__(256) void dt_columns_kernel(const uint8_t* __restri
     if (x >= W) return;
     const uint8_t* o = occ + m * (size_t)H * W;
     uint16_t* gg = g + m * (size_t)H * W;
+    // both passes walk the column in chunks of 16 rows: the 16 loads of a chunk are independent and
+    // issued together, only the running distance is carried (a plain row-by-row walk pays one memory
+    // latency per row, which dominates when few maps are live, as in navsim_regen)
+    constexpr int CH = 16;
     int d = kDtInf;
-    for (int y = 0; y < H; ++y) {
-        d = o[(size_t)y * W + x] ? 0 : (d >= kDtInf ? kDtInf : d + 1);
-        gg[(size_t)y * W + x] = (uint16_t)(d >= kDtInf ? 0xFFFF : d);
+    for (int y0 = 0; y0 < H; y0 += CH) {
+        uint8_t v[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) v[j] = (y0 + j < H) ? o[(size_t)(y0 + j) * W + x] : 0;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (y0 + j < H) {
+                d = v[j] ? 0 : (d >= kDtInf ? kDtInf : d + 1);
+                gg[(size_t)(y0 + j) * W + x] = (uint16_t)(d >= kDtInf ? 0xFFFF : d);
+            }
+        }
     }
     d = kDtInf;
-    for (int y = H - 1; y >= 0; --y) {
-        int cur = gg[(size_t)y * W + x];
-        cur = (cur == 0xFFFF) ? kDtInf : cur;
-        d = (cur == 0) ? 0 : (d >= kDtInf ? kDtInf : d + 1);
-        if (d < cur) gg[(size_t)y * W + x] = (uint16_t)d;
-        else d = cur;
+    for (int y1 = H - 1; y1 >= 0; y1 -= CH) {
+        uint16_t v[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) v[j] = (y1 - j >= 0) ? gg[(size_t)(y1 - j) * W + x] : 0;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (y1 - j >= 0) {
+                int cur = (v[j] == 0xFFFF) ? kDtInf : v[j];
+                d = (cur == 0) ? 0 : (d >= kDtInf ? kDtInf : d + 1);
+                if (d < cur) gg[(size_t)(y1 - j) * W + x] = (uint16_t)d;
+                else d = cur;
+            }
+        }
     }
 }
 
@@ -1523,9 +1542,24 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
     const uint64_t key = nv::hash4(c.seed, (uint64_t)(c.env_index_base + e), (uint64_t)st.episode[e], 0x4D4150ULL);
     double w = c.obstacle_width_lo + (c.obstacle_width_hi - c.obstacle_width_lo) * rg_u(key, 0);
     const int hw = (int)(10.0 * w);
-    for (int idx = tid; idx < size * size; idx += 256) {
-        int r = idx / size, q = idx - r * size;
-        occ[(size_t)(size - 1 - r) * size + q] = !(r >= 5 && r < size - 5 && q >= 5 && q < size - 5);
+    if ((size & 3) == 0) {                                       // 4 cells per store
+        const int wpr = size >> 2;
+        uint32_t* occ32 = (uint32_t*)occ;
+        for (int idx = tid; idx < size * wpr; idx += 256) {
+            int r = idx / wpr, q4 = (idx - r * wpr) * 4;
+            uint32_t wv = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int q = q4 + j;
+                wv |= (uint32_t)(!(r >= 5 && r < size - 5 && q >= 5 && q < size - 5)) << (8 * j);
+            }
+            occ32[(size_t)(size - 1 - r) * wpr + (q4 >> 2)] = wv;
+        }
+    } else {
+        for (int idx = tid; idx < size * size; idx += 256) {
+            int r = idx / size, q = idx - r * size;
+            occ[(size_t)(size - 1 - r) * size + q] = !(r >= 5 && r < size - 5 && q >= 5 && q < size - 5);
+        }
     }
     __syncthreads();
     int span = size - 2 * hw - 3;
@@ -1577,9 +1611,11 @@ __global__ __launch_bounds__(256) void regen_commit_kernel(navsim_config c, navs
     const int e = list[b], tid = threadIdx.x;
     const int N = c.max_peds, K = c.n_spawn, P = NAVSIM_MAX_WAYPOINTS;
     {   // field_bytes is a multiple of 16 for both formats at square sizes used here; copy in 4-byte words
-        const uint32_t* src = (const uint32_t*)(field_scratch + (size_t)b * field_bytes);
-        uint32_t* dst = (uint32_t*)((char*)st.field + (size_t)e * field_bytes);
-        for (size_t i = tid; i < field_bytes / 4; i += 256) dst[i] = src[i];
+        const uint4* src = (const uint4*)(field_scratch + (size_t)b * field_bytes);
+        uint4* dst = (uint4*)((char*)st.field + (size_t)e * field_bytes);
+        for (size_t i = tid; i < field_bytes / 16; i += 256) dst[i] = src[i];
+        for (size_t i = (field_bytes / 16) * 16 + tid; i < field_bytes; i += 256)          // tail bytes
+            ((char*)st.field)[(size_t)e * field_bytes + i] = field_scratch[(size_t)b * field_bytes + i];
     }
     __threadfence_block();
     __syncthreads();
