@@ -305,6 +305,20 @@ size_t navsim_regen_workspace_bytes(const navsim_config* cfg);
 int    navsim_regen(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- reset path: costmap (env.py:312-332), pyastar2d.astar_path (env.py:343-354),
+ *      path_to_waypoints (env.py:1261-1277) ---------------------------------------------------- */
+/* cost [n, H/5, W/5] uint8 (1 = blocked): 5x nearest subsampling + 9x9 dilation (reflect-101 border). */
+int navsim_costmap(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t map_w, uint8_t* cost, void* stream);
+/* n queries; query q plans on costmap map_index[q] (q when NULL).  Shortest 4-connected path between the
+ * cells of start[q] and goal[q] (build-defined tie-break), cut into waypoints every
+ * `interval` metres.  wp [n,max_wp,2], n_wp [n] (0 = no path), path_cells [n], path_len [n] (env.py:757-759);
+ * the last three may be NULL. */
+size_t navsim_plan_workspace_bytes(int32_t n_queries, int32_t cost_h, int32_t cost_w);
+int    navsim_plan(const uint8_t* cost, const int32_t* map_index, int32_t n_queries, int32_t cost_h, int32_t cost_w,
+                   double cost_resolution, double origin_x, double origin_y, const double* start, const double* goal,
+                   double interval, int32_t max_wp, double* wp, int32_t* n_wp, int32_t* path_cells, double* path_len,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* First observation after reset() (env.py:822-831): scan at the current robot pose, stack filled
  * with copies, prev_pose = pose, vel = 0; sets prev_pose/prev_action/n_hist.  `mask` [E] uint8 or
  * NULL selects which envs are (re)initialised; others keep obs_prev -> obs copied through. */

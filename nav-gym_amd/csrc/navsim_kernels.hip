@@ -1664,6 +1664,130 @@ __global__ __launch_bounds__(256) void regen_commit_kernel(navsim_config c, navs
 }
 
 // ============================================================================================
+// reset path: costmap (env.py:312-332), shortest path (pyastar2d at env.py:343-354), waypoints
+// (env.py:1261-1277).  Specification incl. the tie-break: oracle/navsim_ref.c.
+// ============================================================================================
+__device__ __forceinline__ int reflect101(int k, int n) {
+    if (n == 1) return 0;
+    while (k < 0 || k >= n) { if (k < 0) k = -k; if (k >= n) k = 2 * (n - 1) - k; }
+    return k;
+}
+
+__global__ __launch_bounds__(256) void costmap_kernel(const uint8_t* __restrict__ occ, int H, int W,
+                                                      uint8_t* __restrict__ cost) {
+    const int Hc = H / 5, Wc = W / 5;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t m = blockIdx.y;
+    if (idx >= Hc * Wc) return;
+    int J = idx / Wc, I = idx - J * Wc;
+    const uint8_t* o = occ + m * (size_t)H * W;
+    int any = 0;
+    for (int dj = -4; dj <= 4; ++dj)
+        for (int di = -4; di <= 4; ++di) {
+            int jj = reflect101(J + dj, Hc), ii = reflect101(I + di, Wc);
+            any |= o[(size_t)(jj * 5) * W + ii * 5];
+        }
+    cost[m * (size_t)Hc * Wc + idx] = any ? 1 : 0;
+}
+
+// one workgroup per query: level-synchronous breadth-first distances from the goal in LDS (int16),
+// stopped at the start's level; thread 0 then walks the path (+i, -i, +j, -j order) and cuts it
+// into waypoints exactly like path_to_waypoints.
+__global__ __launch_bounds__(256) void plan_kernel(const uint8_t* __restrict__ cost, const int32_t* __restrict__ map_index,
+                                                   int Hc, int Wc, double res_c, double ox, double oy,
+                                                   const double* __restrict__ start, const double* __restrict__ goal,
+                                                   double interval, int max_wp, double* __restrict__ wp,
+                                                   int32_t* __restrict__ n_wp, int32_t* __restrict__ path_cells,
+                                                   double* __restrict__ path_len, int32_t* __restrict__ path_ws) {
+    extern __shared__ int16_t dist[];                  // Hc * Wc, -1 = unreached
+    __shared__ int changed, reached;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const uint8_t* c = cost + (size_t)(map_index ? map_index[q] : q) * Hc * Wc;
+    navsim_config cc = {};
+    cc.origin_x = ox; cc.origin_y = oy; cc.resolution = res_c; cc.map_h = Hc; cc.map_w = Wc;
+    int si, sj, gi, gj;
+    nv::xy_to_ij(start[2 * q], start[2 * q + 1], cc, si, sj);
+    nv::xy_to_ij(goal[2 * q], goal[2 * q + 1], cc, gi, gj);
+    bool ok = si < Wc && sj < Hc && gi < Wc && gj < Hc;
+    if (ok) ok = !c[(size_t)sj * Wc + si] && !c[(size_t)gj * Wc + gi];
+    if (tid == 0) {
+        n_wp[q] = 0;
+        if (path_cells) path_cells[q] = 0;
+        if (path_len) path_len[q] = 0.0;
+    }
+    if (!ok) return;                                     // uniform: depends on q only
+    const int n_cells = Hc * Wc;
+    for (int k = tid; k < n_cells; k += 256) dist[k] = -1;
+    __syncthreads();
+    if (tid == 0) { dist[gj * Wc + gi] = 0; reached = (si == gi && sj == gj); }
+    __syncthreads();
+    for (int level = 1; level < 32767; ++level) {
+        if (reached) break;
+        if (tid == 0) changed = 0;
+        __syncthreads();
+        int mine = 0;
+        for (int k = tid; k < n_cells; k += 256) {
+            if (dist[k] != -1 || c[k]) continue;
+            int j = k / Wc, i = k - j * Wc;
+            bool nb = (i + 1 < Wc && dist[k + 1] == level - 1) || (i > 0 && dist[k - 1] == level - 1) ||
+                      (j + 1 < Hc && dist[k + Wc] == level - 1) || (j > 0 && dist[k - Wc] == level - 1);
+            if (nb) mine |= 1 | ((k == sj * Wc + si) ? 2 : 0);
+            if (nb) dist[k] = (int16_t)(-2 - level);       // tentative: invisible to this level's readers
+        }
+        __syncthreads();
+        for (int k = tid; k < n_cells; k += 256)
+            if (dist[k] < -1) dist[k] = (int16_t)(-2 - dist[k]);
+        if (mine & 1) changed = 1;
+        if (mine & 2) reached = 1;
+        __syncthreads();
+        if (!changed) break;
+    }
+    __syncthreads();
+    if (tid != 0 || dist[sj * Wc + si] < 0) return;
+    int32_t* path = path_ws + (size_t)q * n_cells;
+    int n = 0, ci = si, cj = sj;
+    for (;;) {
+        path[n++] = cj * Wc + ci;
+        int dcur = dist[cj * Wc + ci];
+        if (dcur == 0) break;
+        const int DI[4] = {1, -1, 0, 0}, DJ[4] = {0, 0, 1, -1};
+        for (int d = 0; d < 4; ++d) {
+            int ni = ci + DI[d], nj = cj + DJ[d];
+            if (ni < 0 || ni >= Wc || nj < 0 || nj >= Hc) continue;
+            if (dist[nj * Wc + ni] == dcur - 1) { ci = ni; cj = nj; break; }
+        }
+    }
+    auto px = [&](int k) { return ((double)(path[k] % Wc) + 0.5) * res_c + ox; };
+    auto py = [&](int k) { return ((double)(path[k] / Wc) + 0.5) * res_c + oy; };
+    double* w = wp + (size_t)q * max_wp * 2;
+    int first = 0, count = 0;
+    for (;;) {                                           // env.py:1261-1277
+        int found = -1;
+        for (int k = first; k < n; ++k) {
+            double dx = px(first) - px(k), dy = py(first) - py(k);
+            if (sqrt(dx * dx + dy * dy) > interval) { found = k; break; }
+        }
+        int pick = (found >= 0) ? found : n - 1;
+        if (count < max_wp) { w[2 * count] = px(pick); w[2 * count + 1] = py(pick); }
+        ++count;
+        if (found < 0) break;
+        first = found;
+    }
+    int nw = count < max_wp ? count : max_wp;
+    n_wp[q] = nw;
+    if (path_cells) path_cells[q] = n;
+    if (path_len) {
+        double sx = start[2 * q] - w[0], sy = start[2 * q + 1] - w[1];
+        double L = sqrt(sx * sx + sy * sy);
+        for (int k = 0; k + 1 < nw; ++k) {
+            double ax = w[2 * k + 2] - w[2 * k], ay = w[2 * k + 3] - w[2 * k + 1];
+            L += sqrt(ax * ax + ay * ay);
+        }
+        path_len[q] = L;
+    }
+}
+
+// ============================================================================================
 // env.py:685-693: the 512-beam half-plane scan of every pedestrian (what the reference feeds to
 // HumanPolicy).  One workgroup per (pedestrian, arena): rectangles of the other agents in LDS,
 // march from the pedestrian's integer cell, bearing-culled polygon merge, clip to 6 m.
@@ -2164,6 +2288,37 @@ int navsim_ped_scans(const navsim_config* c, const navsim_state* st, float* out,
     else if (c->field_format == NAVSIM_FIELD_F32S) ped_scan_kernel<FieldF32S><<<grid, 256, lds, s>>>(*c, *st, out);
     else if (c->field_format == NAVSIM_FIELD_F32)  ped_scan_kernel<FieldF32><<<grid, 256, lds, s>>>(*c, *st, out);
     else return NAVSIM_E_UNSUPPORTED;
+    return launch_status();
+}
+
+int navsim_costmap(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, uint8_t* cost, void* stream) {
+    (void)hipGetLastError();
+    if (!occ || !cost || n_maps < 0 || H < 5 || W < 5) return NAVSIM_E_ARG;
+    if (n_maps == 0) return NAVSIM_OK;
+    if (n_maps > 65535) return NAVSIM_E_UNSUPPORTED;
+    int cells = (H / 5) * (W / 5);
+    costmap_kernel<<<dim3((cells + 255) / 256, n_maps), 256, 0, (hipStream_t)stream>>>(occ, H, W, cost);
+    return launch_status();
+}
+
+size_t navsim_plan_workspace_bytes(int32_t n_queries, int32_t Hc, int32_t Wc) {
+    if (n_queries <= 0 || Hc <= 0 || Wc <= 0) return 0;
+    return (size_t)n_queries * Hc * Wc * sizeof(int32_t);
+}
+
+int navsim_plan(const uint8_t* cost, const int32_t* map_index, int32_t n, int32_t Hc, int32_t Wc, double res_c,
+                double ox, double oy, const double* start, const double* goal, double interval, int32_t max_wp,
+                double* wp, int32_t* n_wp, int32_t* path_cells, double* path_len, void* workspace,
+                size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
+    if (!cost || !start || !goal || !wp || !n_wp || !workspace || n < 0 || Hc <= 0 || Wc <= 0 || max_wp < 1)
+        return NAVSIM_E_ARG;
+    if (workspace_bytes < navsim_plan_workspace_bytes(n, Hc, Wc)) return NAVSIM_E_ARG;
+    if ((size_t)Hc * Wc * 2 > 150 * 1024 || Hc * Wc > 32000 * 4) return NAVSIM_E_UNSUPPORTED;   // LDS-resident BFS
+    if (n == 0) return NAVSIM_OK;
+    plan_kernel<<<n, 256, (size_t)Hc * Wc * sizeof(int16_t), (hipStream_t)stream>>>(
+        cost, map_index, Hc, Wc, res_c, ox, oy, start, goal, interval, max_wp, wp, n_wp, path_cells, path_len,
+        (int32_t*)workspace);
     return launch_status();
 }
 

@@ -213,6 +213,9 @@ def declare(lib, suffix=""):
     if suffix:
         sig("navsim_regen", [cfgp, stp, iop])
     else:
+        sig("navsim_costmap", [_P, i32, i32, i32, _P, _P])
+        sig("navsim_plan_workspace_bytes", [i32, i32, i32], C.c_size_t)
+        sig("navsim_plan", [_P, _P, i32, i32, i32, f64, f64, f64, _P, _P, f64, i32, _P, _P, _P, _P, _P, C.c_size_t, _P])
         sig("navsim_regen_workspace_bytes", [cfgp], C.c_size_t)
         sig("navsim_regen", [cfgp, stp, iop, _P, C.c_size_t, _P])
     sig("navsim_step", [cfgp, stp, iop] + stream)
@@ -228,6 +231,7 @@ EXPORTS = (
     "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
     "navsim_scan_threshold", "navsim_beam_table", "navsim_step_workspace_bytes", "navsim_ped_scans", "navsim_regen_workspace_bytes", "navsim_regen",
+    "navsim_costmap", "navsim_plan_workspace_bytes", "navsim_plan",
     "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math",
 )

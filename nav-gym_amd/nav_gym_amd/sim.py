@@ -146,6 +146,38 @@ def reward_done(cfg, obs, goals, thr, dthr):
     return out
 
 
+def costmap(occ):
+    """occ uint8 CUDA [n,H,W] -> uint8 [n,H/5,W/5] (env.py:312-332)."""
+    torch = require_gpu()
+    occ = occ.contiguous()
+    n, H, W = occ.shape
+    out = torch.zeros((n, H // 5, W // 5), dtype=torch.uint8, device=occ.device)
+    check(load().navsim_costmap(_ptr(occ), n, H, W, _ptr(out), _stream()), "navsim_costmap")
+    return out
+
+
+def plan(cost, start, goal, interval, max_wp=8, res_c=0.25, origin=(0.0, 0.0), map_index=None):
+    """Shortest 4-connected paths + waypoints for n queries (env.py:343-354, 1261-1277)."""
+    torch = require_gpu()
+    L = load()
+    cost = cost.contiguous()
+    _, Hc, Wc = cost.shape
+    start = start.to(torch.float64).contiguous().reshape(-1, 2)
+    n = start.shape[0]
+    goal = goal.to(torch.float64).contiguous().reshape(n, 2)
+    dev = cost.device
+    mi = None if map_index is None else map_index.to(device=dev, dtype=torch.int32).contiguous()
+    wp = torch.zeros((n, max_wp, 2), dtype=torch.float64, device=dev)
+    n_wp = torch.zeros(n, dtype=torch.int32, device=dev)
+    cells = torch.zeros(n, dtype=torch.int32, device=dev)
+    plen = torch.zeros(n, dtype=torch.float64, device=dev)
+    ws = torch.empty(max(L.navsim_plan_workspace_bytes(n, Hc, Wc), 16), dtype=torch.uint8, device=dev)
+    check(L.navsim_plan(_ptr(cost), _ptr(mi), n, Hc, Wc, float(res_c), float(origin[0]), float(origin[1]), _ptr(start),
+                        _ptr(goal), float(interval), max_wp, _ptr(wp), _ptr(n_wp), _ptr(cells), _ptr(plen), _ptr(ws),
+                        ws.numel(), _stream()), "navsim_plan")
+    return wp, n_wp, cells, plen
+
+
 def debug_math(fn, x, x2=None):
     torch = require_gpu()
     out = torch.empty_like(x)

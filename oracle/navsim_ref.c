@@ -1114,6 +1114,142 @@ int navsim_regen_cpu(const navsim_config* c, const navsim_state* st, const navsi
     return rc;
 }
 
+/* =========================================================================================
+ * a16 + reset path: costmap (env.py:312-332), shortest 4-connected path (pyastar2d.astar_path with
+ * allow_diagonal=False on uniform costs, called at env.py:343-354) and path_to_waypoints
+ * (env.py:1261-1277).
+ *   costmap: cv2.resize(INTER_NEAREST) by the integer factor 5 samples occ[5J][5I]; the 9x9 box
+ *   filter2D (default border BORDER_REFLECT_101) followed by "> 0 -> 100" is a 4-cell dilation.
+ *   path: [UPSTREAM-RECALL] pyastar2d returns a minimum-cost path including both end cells, or None
+ *   when the goal is unreachable; with uniform weights every shortest path has the same length, and
+ *   WHICH one A* returns depends on its heap order, which is not pinned -- BUILD-DEFINED tie-break:
+ *   breadth-first distances from the goal, then from the start always step to the first neighbour in
+ *   the order (+i, -i, +j, -j) that is one closer.
+ *   path_to_waypoints is pinned by golden vectors (tests/golden/golden_units.npz wp_*).
+ * ======================================================================================= */
+#define COST_FACTOR 5
+
+static inline int reflect101(int k, int n) {
+    if (n == 1) return 0;
+    while (k < 0 || k >= n) { if (k < 0) k = -k; if (k >= n) k = 2 * (n - 1) - k; }
+    return k;
+}
+
+int navsim_costmap_cpu(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, uint8_t* cost) {
+    if (!occ || !cost || H < COST_FACTOR || W < COST_FACTOR) return NAVSIM_E_ARG;
+    const int Hc = H / COST_FACTOR, Wc = W / COST_FACTOR;
+    for (int m = 0; m < n_maps; ++m) {
+        const uint8_t* o = occ + (size_t)m * H * W;
+        uint8_t* c = cost + (size_t)m * Hc * Wc;
+        for (int J = 0; J < Hc; ++J)
+            for (int I = 0; I < Wc; ++I) {
+                int any = 0;
+                for (int dj = -4; dj <= 4 && !any; ++dj)
+                    for (int di = -4; di <= 4; ++di) {
+                        int jj = reflect101(J + dj, Hc), ii = reflect101(I + di, Wc);
+                        if (o[(size_t)(jj * COST_FACTOR) * W + ii * COST_FACTOR]) { any = 1; break; }
+                    }
+                c[(size_t)J * Wc + I] = (uint8_t)any;
+            }
+    }
+    return NAVSIM_OK;
+}
+
+/* env.py:1261-1277 on a path of n points (x, y); returns the number of waypoints written (<= max_wp;
+ * the scan continues past max_wp so that the count is exact, later ones are dropped) */
+static int path_to_waypoints(const double* path, int n, double interval, double* wp, int max_wp) {
+    int first = 0, count = 0;
+    for (;;) {
+        int found = -1;
+        for (int k = first; k < n; ++k) {
+            double dx = path[2 * first] - path[2 * k], dy = path[2 * first + 1] - path[2 * k + 1];
+            if (sqrt(dx * dx + dy * dy) > interval) { found = k; break; }
+        }
+        int pick = (found >= 0) ? found : n - 1;
+        if (count < max_wp) { wp[2 * count] = path[2 * pick]; wp[2 * count + 1] = path[2 * pick + 1]; }
+        ++count;
+        if (found < 0) break;
+        first = found;
+    }
+    return count;
+}
+
+int navsim_path_to_waypoints_cpu(const double* path, int32_t n, double interval, double* wp, int32_t max_wp) {
+    if (!path || !wp || n < 1) return NAVSIM_E_ARG;
+    return path_to_waypoints(path, n, interval, wp, max_wp);
+}
+
+/* n queries: query m plans on costmap map_index[m] (or m when map_index is NULL); cost [*,Hc,Wc]
+ * (nonzero = blocked), start/goal [n,2] metres, cost resolution res_c.  Outputs: wp [n,max_wp,2], n_wp [n] (0 = no path), path_cells [n] (cells on the path),
+ * path_len [n] = |start - wp0| + sum |wp_k+1 - wp_k| (env.py:757-759). */
+int navsim_plan_cpu(const uint8_t* cost, const int32_t* map_index, int32_t n_maps, int32_t Hc, int32_t Wc,
+                    double res_c, double ox, double oy, const double* start, const double* goal, double interval,
+                    int32_t max_wp, double* wp, int32_t* n_wp, int32_t* path_cells, double* path_len) {
+    if (!cost || !start || !goal || !wp || !n_wp) return NAVSIM_E_ARG;
+    navsim_config cc;
+    memset(&cc, 0, sizeof(cc));
+    cc.origin_x = ox; cc.origin_y = oy; cc.resolution = res_c; cc.map_h = Hc; cc.map_w = Wc;
+    int32_t* dist = (int32_t*)malloc(sizeof(int32_t) * (size_t)Hc * Wc);
+    int32_t* queue = (int32_t*)malloc(sizeof(int32_t) * (size_t)Hc * Wc);
+    double* path = (double*)malloc(sizeof(double) * 2 * (size_t)Hc * Wc);
+    static const int DI[4] = {1, -1, 0, 0}, DJ[4] = {0, 0, 1, -1};
+    for (int m = 0; m < n_maps; ++m) {
+        const uint8_t* c = cost + (size_t)(map_index ? map_index[m] : m) * Hc * Wc;
+        int si, sj, gi, gj;
+        xy_to_ij(start[2 * m], start[2 * m + 1], &cc, &si, &sj);           /* env.py:348-349 */
+        xy_to_ij(goal[2 * m], goal[2 * m + 1], &cc, &gi, &gj);
+        n_wp[m] = 0;
+        if (path_cells) path_cells[m] = 0;
+        if (path_len) path_len[m] = 0.0;
+        if (si >= Wc || sj >= Hc || gi >= Wc || gj >= Hc) continue;
+        if (c[(size_t)sj * Wc + si] || c[(size_t)gj * Wc + gi]) continue;
+        for (size_t k = 0; k < (size_t)Hc * Wc; ++k) dist[k] = -1;
+        int head = 0, tail = 0;
+        dist[(size_t)gj * Wc + gi] = 0;
+        queue[tail++] = gj * Wc + gi;
+        while (head < tail) {
+            int cur = queue[head++], ci = cur % Wc, cj = cur / Wc;
+            for (int d = 0; d < 4; ++d) {
+                int ni = ci + DI[d], nj = cj + DJ[d];
+                if (ni < 0 || ni >= Wc || nj < 0 || nj >= Hc) continue;
+                size_t q = (size_t)nj * Wc + ni;
+                if (c[q] || dist[q] >= 0) continue;
+                dist[q] = dist[cur] + 1;
+                queue[tail++] = (int)q;
+            }
+        }
+        if (dist[(size_t)sj * Wc + si] < 0) continue;                       /* unreachable: None */
+        int n = 0, ci = si, cj = sj;
+        for (;;) {
+            path[2 * n] = ((double)ci + 0.5) * res_c + ox;                 /* env.py:1218-1219 */
+            path[2 * n + 1] = ((double)cj + 0.5) * res_c + oy;
+            ++n;
+            int dcur = dist[(size_t)cj * Wc + ci];
+            if (dcur == 0) break;
+            for (int d = 0; d < 4; ++d) {
+                int ni = ci + DI[d], nj = cj + DJ[d];
+                if (ni < 0 || ni >= Wc || nj < 0 || nj >= Hc) continue;
+                if (dist[(size_t)nj * Wc + ni] == dcur - 1) { ci = ni; cj = nj; break; }
+            }
+        }
+        double* w = wp + (size_t)m * max_wp * 2;
+        int cnt = path_to_waypoints(path, n, interval, w, max_wp);
+        n_wp[m] = cnt < max_wp ? cnt : max_wp;
+        if (path_cells) path_cells[m] = n;
+        if (path_len) {
+            double sx = start[2 * m] - w[0], sy = start[2 * m + 1] - w[1];
+            double L = sqrt(sx * sx + sy * sy);
+            for (int k = 0; k + 1 < n_wp[m]; ++k) {
+                double ax = w[2 * k + 2] - w[2 * k], ay = w[2 * k + 3] - w[2 * k + 1];
+                L += sqrt(ax * ax + ay * ay);
+            }
+            path_len[m] = L;
+        }
+    }
+    free(dist); free(queue); free(path);
+    return NAVSIM_OK;
+}
+
 int navsim_math_cpu(int32_t fn, const double* x, const double* x2, double* out, int32_t n) {
     if (!x || !out) return NAVSIM_E_ARG;
     for (int i = 0; i < n; ++i) {

@@ -68,6 +68,14 @@ int navsim_ped_scans_cpu(const navsim_config* cfg, const navsim_state* st, float
 
 int navsim_regen_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io);
 
+/* costmap (env.py:312-332), shortest 4-connected path (env.py:343-354) and path_to_waypoints
+ * (env.py:1261-1277); see navsim_ref.c for the stated tie-break */
+int navsim_costmap_cpu(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t map_w, uint8_t* cost);
+int navsim_path_to_waypoints_cpu(const double* path, int32_t n, double interval, double* wp, int32_t max_wp);
+int navsim_plan_cpu(const uint8_t* cost, const int32_t* map_index, int32_t n_queries, int32_t Hc, int32_t Wc,
+                    double res_c, double ox, double oy, const double* start, const double* goal, double interval,
+                    int32_t max_wp, double* wp, int32_t* n_wp, int32_t* path_cells, double* path_len);
+
 int navsim_step_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io);
 /* same, envs [e0, e1) only: lets the CPU baseline split envs over threads */
 int navsim_step_range_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,

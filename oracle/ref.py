@@ -190,6 +190,42 @@ def reward_done(cfg, obs, goals, thr, dthr):
     return dict(reward=reward, done=done, is_success=succ, is_crash=crash, distance=dist)
 
 
+def costmap(occ):
+    occ = np.ascontiguousarray(occ, dtype=np.uint8)
+    n, H, W = occ.shape
+    out = np.zeros((n, H // 5, W // 5), np.uint8)
+    L = lib()
+    L.navsim_costmap_cpu.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    _chk(L.navsim_costmap_cpu(_p(occ), n, H, W, _p(out)), "costmap")
+    return out
+
+
+def path_to_waypoints(path, interval, max_wp=64):
+    path = np.ascontiguousarray(path, dtype=np.float64).reshape(-1, 2)
+    wp = np.zeros((max_wp, 2), np.float64)
+    L = lib()
+    L.navsim_path_to_waypoints_cpu.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int32]
+    n = L.navsim_path_to_waypoints_cpu(_p(path), path.shape[0], float(interval), _p(wp), max_wp)
+    return wp[:min(n, max_wp)]
+
+
+def plan(cost, start, goal, interval, max_wp=8, res_c=0.25, origin=(0.0, 0.0), map_index=None):
+    cost = np.ascontiguousarray(cost, dtype=np.uint8)
+    _, Hc, Wc = cost.shape
+    start = np.ascontiguousarray(start, dtype=np.float64).reshape(-1, 2)
+    n = start.shape[0]
+    goal = np.ascontiguousarray(goal, dtype=np.float64).reshape(n, 2)
+    mi = None if map_index is None else np.ascontiguousarray(map_index, dtype=np.int32)
+    wp = np.zeros((n, max_wp, 2)); n_wp = np.zeros(n, np.int32); cells = np.zeros(n, np.int32); plen = np.zeros(n)
+    L = lib()
+    L.navsim_plan_cpu.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
+                                  C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]
+    _chk(L.navsim_plan_cpu(_p(cost), _p(mi), n, Hc, Wc, res_c, origin[0], origin[1], _p(start), _p(goal), float(interval),
+                           max_wp, _p(wp), _p(n_wp), _p(cells), _p(plen)), "plan")
+    return wp, n_wp, cells, plen
+
+
 def math_fn(fn, x, x2=None):
     x = np.ascontiguousarray(x, dtype=np.float64)
     x2a = None if x2 is None else np.ascontiguousarray(x2, dtype=np.float64)

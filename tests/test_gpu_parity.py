@@ -539,3 +539,35 @@ def test_tile_table_reproduces_field(gpu):
             frac.append(valid.mean())
         if indoor == 0.0 and size >= 253:
             assert np.mean(frac) > 0.5, frac
+
+
+@pytest.mark.parametrize("size,indoor", [(400, 0.0), (500, 1.0), (1000, 1.0)])
+def test_costmap_and_planner_vs_oracle(gpu, size, indoor):
+    """Reset path: costmap (env.py:312-332) and shortest-path waypoints (env.py:343-354, 1261-1277) on
+    outdoor and corridor maps; several queries per map; bit-exact vs the oracle."""
+    torch = gpu.torch
+    n_maps, per = 3, 12
+    occ = gpu.world.make_maps(n_maps, size, 3 + size, indoor_ratio=indoor)
+    cost = gpu.sim.costmap(_t(gpu, occ))
+    rc = ref.costmap(occ)
+    _eq(cost.cpu().numpy(), rc, "costmap")
+    rng = np.random.default_rng(size)
+    start, goal, mi = [], [], []
+    for m in range(n_maps):
+        free = np.argwhere(rc[m] == 0)
+        a = free[rng.integers(0, len(free), per)]; b = free[rng.integers(0, len(free), per)]
+        start.append(np.stack([(a[:, 1] + 0.5) * 0.25, (a[:, 0] + 0.5) * 0.25], 1))
+        goal.append(np.stack([(b[:, 1] + 0.5) * 0.25, (b[:, 0] + 0.5) * 0.25], 1))
+        mi.append(np.full(per, m))
+    start, goal, mi = np.concatenate(start), np.concatenate(goal), np.concatenate(mi).astype(np.int32)
+    start[0] = [0.1, 0.1]                                # inside the border wall: no path
+    for interval in (2.0, 5.0):
+        gw, gn, gc, gl = gpu.sim.plan(cost, _t(gpu, start), _t(gpu, goal), interval, max_wp=8, map_index=_t(gpu, mi))
+        rw, rn, rcells, rl = ref.plan(rc, start, goal, interval, max_wp=8, map_index=mi)
+        _eq(gn.cpu().numpy(), rn, "n_wp"); _eq(gc.cpu().numpy(), rcells, "path cells")
+        _eq(gl.cpu().numpy(), rl, "path length")
+        for q in range(len(rn)):
+            _eq(gw.cpu().numpy()[q, : rn[q]], rw[q, : rn[q]], "waypoints of query %d" % q)
+        assert rn[0] == 0
+        if indoor == 0.0 or size == 1000:      # 500-cell corridor maps are too narrow for the 1 m inflation
+            assert (rn[1:] > 0).sum() > len(rn) // 3, rn

@@ -160,3 +160,42 @@ def test_leg_odometry_matches_numpy():
     by = np.sin(th) * vel[:, 0] + np.cos(th) * vel[:, 1]
     exp = dist0 + np.stack([bx, by, (pose[:, 2] - prev_yaw) / 0.2], 1) * 0.2
     np.testing.assert_allclose(got, exp, rtol=0, atol=1e-12)
+
+
+def test_costmap_and_planner_properties():
+    """costmap = 4-cell dilation of the 5x-subsampled map (env.py:312-332); planner = shortest
+    4-connected path: its length equals the BFS distance, every cell is free and consecutive cells
+    are neighbours; blocked or unreachable queries return no path."""
+    from collections import deque
+    rng = np.random.default_rng(3)
+    occ = outdoor_map(rng, 400)[None]
+    cost = ref.costmap(occ)
+    assert cost.shape == (1, 80, 80)
+    sub = occ[0, ::5, ::5]
+    exp = ndi.binary_dilation(np.pad(sub, 4, mode="reflect"), structure=np.ones((9, 9)))[4:-4, 4:-4]
+    assert np.array_equal(cost[0].astype(bool), exp)
+    free = np.argwhere(cost[0] == 0)
+    n = 40
+    a = free[rng.integers(0, len(free), n)]; b = free[rng.integers(0, len(free), n)]
+    start = np.stack([(a[:, 1] + 0.5) * 0.25, (a[:, 0] + 0.5) * 0.25], 1)
+    goal = np.stack([(b[:, 1] + 0.5) * 0.25, (b[:, 0] + 0.5) * 0.25], 1)
+    wp, n_wp, cells, plen = ref.plan(np.repeat(cost, n, 0), start, goal, interval=2.0, max_wp=64)
+    for q in range(n):
+        dist = -np.ones((80, 80), int); dist[b[q, 0], b[q, 1]] = 0
+        dq = deque([(b[q, 0], b[q, 1])])
+        while dq:
+            j, i = dq.popleft()
+            for dj, di in ((0, 1), (0, -1), (1, 0), (-1, 0)):
+                jj, ii = j + dj, i + di
+                if 0 <= jj < 80 and 0 <= ii < 80 and cost[0, jj, ii] == 0 and dist[jj, ii] < 0:
+                    dist[jj, ii] = dist[j, i] + 1; dq.append((jj, ii))
+        if dist[a[q, 0], a[q, 1]] < 0:
+            assert n_wp[q] == 0
+            continue
+        assert cells[q] == dist[a[q, 0], a[q, 1]] + 1
+        assert n_wp[q] >= 1 and np.allclose(wp[q, n_wp[q] - 1], goal[q])          # last waypoint = goal
+        d = np.linalg.norm(np.diff(np.vstack([start[q], wp[q, : n_wp[q]]]), axis=0), axis=1)
+        assert abs(d.sum() - plen[q]) < 1e-9 and plen[q] >= np.linalg.norm(goal[q] - start[q]) - 1e-9
+    blocked = np.argwhere(cost[0] != 0)[0]
+    _, n0, _, _ = ref.plan(cost, [[(blocked[1] + 0.5) * 0.25, (blocked[0] + 0.5) * 0.25]], goal[:1], 2.0)
+    assert n0[0] == 0

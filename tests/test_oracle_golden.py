@@ -147,3 +147,15 @@ def test_step_trace(name):
         assert tr["is_crash"].sum() > 0 and (tr["is_crash"] == 0).sum() > 0
     if name.startswith("success"):
         assert tr["is_success"].sum() > 0
+
+
+def test_path_to_waypoints(units):
+    """env.py:1261-1277 against the reference's outputs on 20 synthetic paths."""
+    for k in range(units["wp_paths"].shape[0]):
+        p = units["wp_paths"][k]; p = p[np.isfinite(p[:, 0])]
+        exp = units["wp_out"][k]; exp = exp[np.isfinite(exp[:, 0])]
+        got = ref.path_to_waypoints(p, float(units["wp_interval"][k]))
+        assert got.shape == exp.shape and np.array_equal(got, exp), k
+    # SURVEY.md 8a row a16 [PROBE]: straight path at 0.25 m spacing, interval 2 -> first waypoint x = 2.25
+    straight = np.stack([np.arange(0, 10, 0.25), np.zeros(40)], 1)
+    assert ref.path_to_waypoints(straight, 2)[0, 0] == 2.25
