@@ -571,3 +571,51 @@ def test_costmap_and_planner_vs_oracle(gpu, size, indoor):
         assert rn[0] == 0
         if indoor == 0.0 or size == 1000:      # 500-cell corridor maps are too narrow for the 1 m inflation
             assert (rn[1:] > 0).sum() > len(rn) // 3, rn
+
+
+def test_edge_shapes(gpu):
+    """Ragged / extreme shapes: odd map size (edge tiles), beam count not a multiple of 64, deep scan
+    stack, the compiled maximum of 64 pedestrians with ragged n_peds (0, 1, 64), wide action range,
+    turning-radius clamp; plus empty batches through every entry point."""
+    torch = gpu.torch
+    E, size, N = 5, 253, 64
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, n_scan_stack=4,
+                                 ped_model=abi.PED_EXTERNAL, auto_reset=1, n_spawn=3, seed=91,
+                                 field_format=abi.FIELD_U16T, min_turning_radius=0.33712)
+    gpu.world.lidar_full_circle(cfg, 77)
+    occ = gpu.world.make_maps(E, size, 91)
+    n_peds = torch.tensor([0, 1, 64, 17, 64], dtype=torch.int32)
+    arrays = gpu.world.make_world(cfg, occ, n_peds=n_peds, device=gpu.dev, min_goal_dist=2, max_goal_dist=6,
+                                  robot_clearance=0.8)
+    from nav_gym_amd import robots
+    arrays["scan_threshold"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array("keti", "threshold_footprint")))
+    arrays["scan_discomfort"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array("keti", "discomfort_threshold_footprint")))
+    host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "tile_table")}
+    host["field"] = ref.build_dt(occ)
+    g = gpu.sim.NavSim(cfg, arrays); r = ref.RefSim(cfg, host)
+    _eq(g.reset_obs().cpu().numpy(), r.reset_obs(), "reset obs")
+    rng = np.random.default_rng(4)
+    for t in range(30):
+        act = np.stack([rng.uniform(-0.3, 0.9, E), rng.uniform(-1.5, 1.5, E)], axis=1)    # out of range: not clipped
+        cmd = np.stack([rng.uniform(0, 0.6, (E, N)), rng.uniform(-0.6, 0.6, (E, N))], axis=2)
+        g.set_ped_cmd(cmd); r.set_ped_cmd(cmd)
+        go, gout = g.step(torch.from_numpy(act).to(gpu.dev)); ro, rout = r.step(act)
+        _eq(go.cpu().numpy(), ro, "obs at step %d" % t)
+        for k in rout:
+            _eq(gout[k].cpu().numpy(), rout[k], "%s at step %d" % (k, t))
+    _eq(g.ped_scans().cpu().numpy()[2], r.ped_scans()[2], "64-pedestrian scans")
+    # empty batches
+    L = gpu.lib.load()
+    cfg0 = cfg.copy(); cfg0.n_envs = 0
+    st0 = abi.NavsimState(); io0 = abi.NavsimStepIO()
+    for name in ("field", "scan_threshold", "scan_discomfort", "robot_pose", "robot_goal", "prev_action", "prev_pose",
+                 "n_hist", "episode", "steps", "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist", "ped_has_legs",
+                 "ped_waypoints", "ped_n_waypoints", "ped_cmd", "spawn_pose", "spawn_goal"):
+        setattr(st0, name, g.t.get(name, g.t["robot_pose"]).data_ptr())
+    for name in ("action", "obs", "obs_prev", "reward", "done", "is_success", "is_crash", "distance"):
+        setattr(io0, name, g.obs.data_ptr())
+    assert L.navsim_step(C.byref(cfg0), C.byref(st0), C.byref(io0), None) == 0
+    assert L.navsim_reset_obs(C.byref(cfg0), C.byref(st0), C.byref(io0), None, None) == 0
+    z = torch.zeros(4, device=gpu.dev, dtype=torch.float64)
+    assert L.navsim_integrate(z.data_ptr(), z.data_ptr(), None, 0, 0.2, 0.0, None) == 0
+    assert L.navsim_cast_static(g.t["field"].data_ptr(), 0, size, size, None, 7, 1.0, None, None) == 0
