@@ -55,7 +55,7 @@ extern "C" {
 
 /* compiled limits */
 #define NAVSIM_MAX_PEDS      64
-#define NAVSIM_MAX_WAYPOINTS 8
+#define NAVSIM_MAX_WAYPOINTS 16
 #define NAVSIM_OBS_TAIL      7   /* prev_pose(2) pose(2) vel(2) yaw(1): env.py:455 */
 
 /* ------------------------------------------------------------------------------------------
@@ -113,7 +113,8 @@ typedef struct navsim_config {
      * only used by navsim_ped_scans */
     double ped_angle_min, ped_angle_last, ped_range_max;
     int32_t ped_n_beams;
-    int32_t reserved1;
+    int32_t regen_plan;               /* navsim_regen: 1 = sample on the costmap and keep only start/goal pairs
+                                         joined by a path (env.py:342-383), pedestrians get path waypoints */
     double robot_seen_footprint[8];   /* threshold_footprint, 4 x (x, y) in the robot frame */
 
     /* device-side reset of finished arenas with a NEW map (navsim_regen):

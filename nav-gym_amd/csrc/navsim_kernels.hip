@@ -1674,10 +1674,11 @@ __device__ __forceinline__ int reflect101(int k, int n) {
 }
 
 __global__ __launch_bounds__(256) void costmap_kernel(const uint8_t* __restrict__ occ, int H, int W,
-                                                      uint8_t* __restrict__ cost) {
+                                                      uint8_t* __restrict__ cost, const int* __restrict__ n_live) {
     const int Hc = H / 5, Wc = W / 5;
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     size_t m = blockIdx.y;
+    if (n_live && (int)m >= *n_live) return;
     if (idx >= Hc * Wc) return;
     int J = idx / Wc, I = idx - J * Wc;
     const uint8_t* o = occ + m * (size_t)H * W;
@@ -1693,29 +1694,29 @@ __global__ __launch_bounds__(256) void costmap_kernel(const uint8_t* __restrict_
 // one workgroup per query: level-synchronous breadth-first distances from the goal in LDS (int16),
 // stopped at the start's level; thread 0 then walks the path (+i, -i, +j, -j order) and cuts it
 // into waypoints exactly like path_to_waypoints.
-__global__ __launch_bounds__(256) void plan_kernel(const uint8_t* __restrict__ cost, const int32_t* __restrict__ map_index,
-                                                   int Hc, int Wc, double res_c, double ox, double oy,
-                                                   const double* __restrict__ start, const double* __restrict__ goal,
-                                                   double interval, int max_wp, double* __restrict__ wp,
-                                                   int32_t* __restrict__ n_wp, int32_t* __restrict__ path_cells,
-                                                   double* __restrict__ path_len, int32_t* __restrict__ path_ws) {
+// One query, executed by the whole 256-thread workgroup.  c = this query's costmap, w = its waypoint
+// row (max_wp x 2), path = its Hc*Wc int32 scratch; n_wp / path_cells / path_len point at its slots.
+__device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc, int Wc, double res_c, double ox,
+                                           double oy, double sx_, double sy_, double gx_, double gy_, double interval,
+                                           int max_wp, double* __restrict__ w, int32_t* __restrict__ n_wp,
+                                           int32_t* __restrict__ path_cells, double* __restrict__ path_len,
+                                           int32_t* __restrict__ path) {
     extern __shared__ int16_t dist[];                  // Hc * Wc, -1 = unreached
     __shared__ int changed, reached;
-    const int q = blockIdx.x, tid = threadIdx.x;
-    const uint8_t* c = cost + (size_t)(map_index ? map_index[q] : q) * Hc * Wc;
+    const int tid = threadIdx.x;
     navsim_config cc = {};
     cc.origin_x = ox; cc.origin_y = oy; cc.resolution = res_c; cc.map_h = Hc; cc.map_w = Wc;
     int si, sj, gi, gj;
-    nv::xy_to_ij(start[2 * q], start[2 * q + 1], cc, si, sj);
-    nv::xy_to_ij(goal[2 * q], goal[2 * q + 1], cc, gi, gj);
+    nv::xy_to_ij(sx_, sy_, cc, si, sj);
+    nv::xy_to_ij(gx_, gy_, cc, gi, gj);
     bool ok = si < Wc && sj < Hc && gi < Wc && gj < Hc;
     if (ok) ok = !c[(size_t)sj * Wc + si] && !c[(size_t)gj * Wc + gi];
     if (tid == 0) {
-        n_wp[q] = 0;
-        if (path_cells) path_cells[q] = 0;
-        if (path_len) path_len[q] = 0.0;
+        *n_wp = 0;
+        if (path_cells) *path_cells = 0;
+        if (path_len) *path_len = 0.0;
     }
-    if (!ok) return;                                     // uniform: depends on q only
+    if (!ok) return;                                     // uniform: depends on the query only
     const int n_cells = Hc * Wc;
     for (int k = tid; k < n_cells; k += 256) dist[k] = -1;
     __syncthreads();
@@ -1744,7 +1745,6 @@ __global__ __launch_bounds__(256) void plan_kernel(const uint8_t* __restrict__ c
     }
     __syncthreads();
     if (tid != 0 || dist[sj * Wc + si] < 0) return;
-    int32_t* path = path_ws + (size_t)q * n_cells;
     int n = 0, ci = si, cj = sj;
     for (;;) {
         path[n++] = cj * Wc + ci;
@@ -1759,7 +1759,6 @@ __global__ __launch_bounds__(256) void plan_kernel(const uint8_t* __restrict__ c
     }
     auto px = [&](int k) { return ((double)(path[k] % Wc) + 0.5) * res_c + ox; };
     auto py = [&](int k) { return ((double)(path[k] / Wc) + 0.5) * res_c + oy; };
-    double* w = wp + (size_t)q * max_wp * 2;
     int first = 0, count = 0;
     for (;;) {                                           // env.py:1261-1277
         int found = -1;
@@ -1774,17 +1773,191 @@ __global__ __launch_bounds__(256) void plan_kernel(const uint8_t* __restrict__ c
         first = found;
     }
     int nw = count < max_wp ? count : max_wp;
-    n_wp[q] = nw;
-    if (path_cells) path_cells[q] = n;
+    *n_wp = nw;
+    if (path_cells) *path_cells = n;
     if (path_len) {
-        double sx = start[2 * q] - w[0], sy = start[2 * q + 1] - w[1];
+        double sx = sx_ - w[0], sy = sy_ - w[1];
         double L = sqrt(sx * sx + sy * sy);
         for (int k = 0; k + 1 < nw; ++k) {
             double ax = w[2 * k + 2] - w[2 * k], ay = w[2 * k + 3] - w[2 * k + 1];
             L += sqrt(ax * ax + ay * ay);
         }
-        path_len[q] = L;
+        *path_len = L;
     }
+}
+
+__global__ __launch_bounds__(256) void plan_kernel(const uint8_t* __restrict__ cost, const int32_t* __restrict__ map_index,
+                                                   int Hc, int Wc, double res_c, double ox, double oy,
+                                                   const double* __restrict__ start, const double* __restrict__ goal,
+                                                   double interval, int max_wp, double* __restrict__ wp,
+                                                   int32_t* __restrict__ n_wp, int32_t* __restrict__ path_cells,
+                                                   double* __restrict__ path_len, int32_t* __restrict__ path_ws) {
+    const int q = blockIdx.x;
+    plan_query(cost + (size_t)(map_index ? map_index[q] : q) * Hc * Wc, Hc, Wc, res_c, ox, oy, start[2 * q],
+               start[2 * q + 1], goal[2 * q], goal[2 * q + 1], interval, max_wp, wp + (size_t)q * max_wp * 2, n_wp + q,
+               path_cells ? path_cells + q : nullptr, path_len ? path_len + q : nullptr,
+               path_ws + (size_t)q * Hc * Wc);
+}
+
+// --------------------------------------------------------------------------------------------
+// navsim_regen with cfg.regen_plan = 1 (oracle/navsim_ref.c regen_planned): candidates on the costmap,
+// a path must join start and goal.  Rounds of {sample, plan, accept} kernels; no host round trip.
+// --------------------------------------------------------------------------------------------
+struct RegenPlanWs {
+    uint8_t* cost;        // [M, Hc, Wc]
+    double* qstart;       // [M, Q, 2]
+    double* qgoal;        // [M, Q, 2]
+    double* qwp;          // [M, Q, P, 2]   robot stage only (pedestrian paths go straight into the state)
+    int32_t* qnwp;        // [M, Q]
+    double* qlen;         // [M, Q]
+    uint8_t* active;      // [M, Q]
+    uint8_t* res_robot;   // [M, K]
+    uint8_t* res_ped;     // [M, N]
+    int32_t* path_ws;     // [M, Q, Hc*Wc]
+    int Q;
+};
+
+__device__ __forceinline__ void rgp_cell(const navsim_config& c, const uint8_t* __restrict__ cost, int Hc, int Wc,
+                                         double res_c, uint64_t key, uint64_t& n, bool use_ref, double rx, double ry,
+                                         double dmin, double dmax, double& x, double& y) {
+    for (int t = 0; t < 16; ++t) {
+        int I = (int)(rg_u(key, n++) * Wc), J = (int)(rg_u(key, n++) * Hc);
+        x = ((double)I + 0.5) * res_c + c.origin_x;
+        y = ((double)J + 0.5) * res_c + c.origin_y;
+        if (cost[(size_t)J * Wc + I]) continue;
+        if (use_ref) {
+            double ddx = x - rx, ddy = y - ry;
+            double dist = sqrt(ddx * ddx + ddy * ddy);
+            if (!(dist > dmin && dist < dmax)) continue;
+        }
+        return;
+    }
+}
+
+// install the new field (same copy as regen_commit_kernel) and clear the per-slot flags
+__global__ __launch_bounds__(256) void regen_install_kernel(navsim_config c, navsim_state st,
+                                                            const int* __restrict__ count, const int* __restrict__ list,
+                                                            const char* __restrict__ field_scratch, size_t field_bytes,
+                                                            RegenPlanWs ws) {
+    const int b = blockIdx.x;
+    if (b >= *count) return;
+    const int e = list[b], tid = threadIdx.x;
+    const uint4* src = (const uint4*)(field_scratch + (size_t)b * field_bytes);
+    uint4* dst = (uint4*)((char*)st.field + (size_t)e * field_bytes);
+    for (size_t i = tid; i < field_bytes / 16; i += 256) dst[i] = src[i];
+    for (size_t i = (field_bytes / 16) * 16 + tid; i < field_bytes; i += 256)
+        ((char*)st.field)[(size_t)e * field_bytes + i] = field_scratch[(size_t)b * field_bytes + i];
+    for (int k = tid; k < c.n_spawn; k += 256) ws.res_robot[(size_t)b * c.n_spawn + k] = 0;
+    for (int i = tid; i < c.max_peds; i += 256) ws.res_ped[(size_t)b * c.max_peds + i] = 0;
+}
+
+// robot stage, one round: accept what the previous round planned, then draw a new candidate for every
+// slot that is still open (round == 4: accept only, pick the robot, initialise the pedestrians)
+__global__ __launch_bounds__(256) void regen_robot_round_kernel(navsim_config c, navsim_state st,
+                                                                const int* __restrict__ count,
+                                                                const int* __restrict__ list, RegenPlanWs ws, int round) {
+    const int b = blockIdx.x;
+    if (b >= *count) return;
+    const int e = list[b], tid = threadIdx.x;
+    const int N = c.max_peds, K = c.n_spawn, Q = ws.Q;
+    const int Hc = c.map_h / 5, Wc = c.map_w / 5;
+    const double res_c = c.resolution * 5.0;
+    const uint8_t* cost = ws.cost + (size_t)b * Hc * Wc;
+    const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
+    double* sp = (double*)st.spawn_pose + (size_t)e * K * 3;
+    double* sg = (double*)st.spawn_goal + (size_t)e * K * 2;
+    for (int k = tid; k < Q; k += 256) {
+        const size_t q = (size_t)b * Q + k;
+        if (k >= K) { ws.active[q] = 0; continue; }
+        uint8_t& res = ws.res_robot[(size_t)b * K + k];
+        if (round > 0 && !res) {
+            double ddx = sg[2 * k] - sp[3 * k], ddy = sg[2 * k + 1] - sp[3 * k + 1];
+            res = ws.qnwp[q] > 0 && ws.qlen[q] <= 2.0 * sqrt(ddx * ddx + ddy * ddy);      // env.py:761
+        }
+        ws.active[q] = 0;
+        if (res || round >= 4) continue;
+        uint64_t key = nv::hash4(c.seed, genv, ep, 0x52504C00ULL + (uint64_t)round * 256 + (uint64_t)k), n = 0;
+        double x, y, gx, gy;
+        rgp_cell(c, cost, Hc, Wc, res_c, key, n, false, 0, 0, 0, 0, x, y);
+        rgp_cell(c, cost, Hc, Wc, res_c, key, n, true, x, y, c.min_goal_dist, c.max_goal_dist, gx, gy);
+        sp[3 * k] = x; sp[3 * k + 1] = y; sp[3 * k + 2] = nv::kTwoPi * rg_u(key, n++);
+        sg[2 * k] = gx; sg[2 * k + 1] = gy;
+        ws.qstart[2 * q] = x; ws.qstart[2 * q + 1] = y;
+        ws.qgoal[2 * q] = gx; ws.qgoal[2 * q + 1] = gy;
+        ws.active[q] = 1;
+    }
+    if (round < 4) return;
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        int idx = (int)(nv::hash4(c.seed, genv, ep, 0x5eedULL) % (uint64_t)K);
+        const uint8_t* res = ws.res_robot + (size_t)b * K;
+        if (!res[idx])
+            for (int s_ = 1; s_ < K; ++s_) { int j = (idx + s_) % K; if (res[j]) { idx = j; break; } }
+        double* rp = st.robot_pose + 3 * (size_t)e;
+        rp[0] = sp[3 * idx]; rp[1] = sp[3 * idx + 1]; rp[2] = sp[3 * idx + 2];
+        st.robot_goal[2 * e] = sg[2 * idx]; st.robot_goal[2 * e + 1] = sg[2 * idx + 1];
+    }
+    int n = (c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
+    n = n > N ? N : n;
+    for (int i = tid; i < n; i += 256) {
+        size_t q = (size_t)e * N + i;
+        uint64_t k0 = nv::hash4(c.seed, genv, ep, 0x504544ULL + (uint64_t)i), m = 0;
+        st.ped_pose[q * 3 + 2] = nv::kTwoPi * rg_u(k0, m++);
+        ((double*)st.ped_v_pref)[q] = c.v_pref_lo + (c.v_pref_hi - c.v_pref_lo) * rg_u(k0, m++);
+        ((uint8_t*)st.ped_has_legs)[q] = rg_u(k0, m++) < c.has_legs_ratio;
+        st.ped_vel[q * 2] = 0.0; st.ped_vel[q * 2 + 1] = 0.0;
+    }
+}
+
+// pedestrian stage, one round (round == 4: accept only)
+__global__ __launch_bounds__(256) void regen_ped_round_kernel(navsim_config c, navsim_state st,
+                                                              const int* __restrict__ count,
+                                                              const int* __restrict__ list, RegenPlanWs ws, int round) {
+    const int b = blockIdx.x;
+    if (b >= *count) return;
+    const int e = list[b], tid = threadIdx.x;
+    const int N = c.max_peds, Q = ws.Q, P = NAVSIM_MAX_WAYPOINTS;
+    const int Hc = c.map_h / 5, Wc = c.map_w / 5;
+    const double res_c = c.resolution * 5.0;
+    const uint8_t* cost = ws.cost + (size_t)b * Hc * Wc;
+    const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
+    const double rx = st.robot_pose[3 * (size_t)e], ry = st.robot_pose[3 * (size_t)e + 1];
+    int n = (c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
+    n = n > N ? N : n;
+    for (int i = tid; i < Q; i += 256) {
+        const size_t q = (size_t)b * Q + i;
+        if (i >= n) { ws.active[q] = 0; continue; }
+        const size_t pq = (size_t)e * N + i;
+        uint8_t& res = ws.res_ped[(size_t)b * N + i];
+        if (round > 0 && !res && ws.qnwp[q] > 0) { st.ped_n_waypoints[pq] = ws.qnwp[q]; res = 1; }
+        ws.active[q] = 0;
+        if (res || round >= 4) continue;
+        uint64_t key = nv::hash4(c.seed, genv, ep, 0x50504C00ULL + (uint64_t)round * 256 + (uint64_t)i), nn = 0;
+        double x, y, gx, gy;
+        rgp_cell(c, cost, Hc, Wc, res_c, key, nn, true, rx, ry, c.ped_min_robot_dist, 1.0e300, x, y);
+        rgp_cell(c, cost, Hc, Wc, res_c, key, nn, true, x, y, c.ped_min_goal_dist, 1.0e300, gx, gy);
+        st.ped_pose[pq * 3] = x; st.ped_pose[pq * 3 + 1] = y;
+        double* w = st.ped_waypoints + (pq * P) * 2;
+        w[0] = gx; w[1] = gy;
+        st.ped_n_waypoints[pq] = 1;
+        ws.qstart[2 * q] = x; ws.qstart[2 * q + 1] = y;
+        ws.qgoal[2 * q] = gx; ws.qgoal[2 * q + 1] = gy;
+        ws.active[q] = 1;
+    }
+}
+
+// plan every active query of the round; ped_stage: waypoints go straight into st.ped_waypoints
+__global__ __launch_bounds__(256) void regen_plan_kernel(navsim_config c, navsim_state st, const int* __restrict__ count,
+                                                         const int* __restrict__ list, RegenPlanWs ws, int ped_stage) {
+    const int q = blockIdx.x, b = q / ws.Q, k = q - b * ws.Q;
+    if (b >= *count || !ws.active[q]) return;            // uniform per workgroup
+    const int Hc = c.map_h / 5, Wc = c.map_w / 5, P = NAVSIM_MAX_WAYPOINTS;
+    double* w = ped_stage ? st.ped_waypoints + (((size_t)list[b] * c.max_peds + k) * P) * 2
+                          : ws.qwp + (size_t)q * P * 2;
+    plan_query(ws.cost + (size_t)b * Hc * Wc, Hc, Wc, c.resolution * 5.0, c.origin_x, c.origin_y, ws.qstart[2 * q],
+               ws.qstart[2 * q + 1], ws.qgoal[2 * q], ws.qgoal[2 * q + 1], ped_stage ? 2.0 : 5.0, P, w, ws.qnwp + q,
+               nullptr, ped_stage ? nullptr : ws.qlen + q, ws.path_ws + (size_t)q * Hc * Wc);
 }
 
 // ============================================================================================
@@ -2297,7 +2470,7 @@ int navsim_costmap(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, uin
     if (n_maps == 0) return NAVSIM_OK;
     if (n_maps > 65535) return NAVSIM_E_UNSUPPORTED;
     int cells = (H / 5) * (W / 5);
-    costmap_kernel<<<dim3((cells + 255) / 256, n_maps), 256, 0, (hipStream_t)stream>>>(occ, H, W, cost);
+    costmap_kernel<<<dim3((cells + 255) / 256, n_maps), 256, 0, (hipStream_t)stream>>>(occ, H, W, cost, nullptr);
     return launch_status();
 }
 
@@ -2331,6 +2504,16 @@ size_t navsim_regen_workspace_bytes(const navsim_config* c) {
     b += M * cells;                                         // occupancy scratch
     b += M * cells * sizeof(uint16_t);                      // column pass
     b += M * navsim_field_bytes(1, c->map_h, c->map_w, c->field_format);
+    if (c->regen_plan) {
+        const size_t cc = (size_t)(c->map_h / 5) * (c->map_w / 5), P = NAVSIM_MAX_WAYPOINTS;
+        const size_t Q = (size_t)(c->n_spawn > c->max_peds ? c->n_spawn : c->max_peds);
+        b += M * cc + 256;                                            // costmaps
+        b += M * Q * (2 + 2 + 2 * P + 1) * sizeof(double) + 256;      // start, goal, waypoints, length
+        b += M * Q * sizeof(int32_t) + 256;                           // waypoint counts
+        b += M * (Q + (size_t)c->n_spawn + (size_t)c->max_peds) + 256;   // active, resolved flags
+        b += M * Q * cc * sizeof(int32_t) + 256;                      // path scratch
+        b += 8 * 256;                                                 // alignment of the ten sub-buffers
+    }
     return b + 1024;
 }
 
@@ -2342,6 +2525,9 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         (c->field_format != NAVSIM_FIELD_F32 && c->field_format != NAVSIM_FIELD_U16T) || c->shared_field)
         return NAVSIM_E_UNSUPPORTED;
     if (workspace_bytes < navsim_regen_workspace_bytes(c) || !st->spawn_pose || !st->spawn_goal) return NAVSIM_E_ARG;
+    if (c->regen_plan && (c->n_spawn > 256 || c->map_h < 5 ||
+                          (size_t)(c->map_h / 5) * (c->map_w / 5) * sizeof(int16_t) > 150 * 1024))
+        return NAVSIM_E_UNSUPPORTED;
     int rc = check_step_args(c, st, io, 1);
     if (rc != NAVSIM_OK) return rc;
     if (c->n_envs == 0) return NAVSIM_OK;
@@ -2366,11 +2552,43 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     regen_maps_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, occ);
     if (c->field_format == NAVSIM_FIELD_U16T) (void)hipMemsetAsync(fscratch, 0xFF, fbytes * (size_t)M, s);
     dt_columns_kernel<<<dim3((W + 255) / 256, M), 256, 0, s>>>(occ, cols, H, W, count);
-    if (c->field_format == NAVSIM_FIELD_F32) {
+    if (c->field_format == NAVSIM_FIELD_F32)
         dt_rows_kernel<0><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, nullptr, nullptr, H, W, count);
+    else
+        dt_rows_kernel<1><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, nullptr, nullptr, H, W, count);
+    if (c->regen_plan) {
+        const int Hc = H / 5, Wc = W / 5, P = NAVSIM_MAX_WAYPOINTS;
+        const size_t cc = (size_t)Hc * Wc;
+        const int Q = c->n_spawn > c->max_peds ? c->n_spawn : c->max_peds;
+        auto take = [&](size_t bytes) { off = (off + 255) & ~(size_t)255; char* p = w + off; off += bytes; return p; };
+        off += fbytes * (size_t)M;
+        RegenPlanWs ws;
+        ws.Q = Q;
+        ws.cost = (uint8_t*)take((size_t)M * cc);
+        ws.qstart = (double*)take((size_t)M * Q * 2 * sizeof(double));
+        ws.qgoal = (double*)take((size_t)M * Q * 2 * sizeof(double));
+        ws.qwp = (double*)take((size_t)M * Q * P * 2 * sizeof(double));
+        ws.qlen = (double*)take((size_t)M * Q * sizeof(double));
+        ws.qnwp = (int32_t*)take((size_t)M * Q * sizeof(int32_t));
+        ws.active = (uint8_t*)take((size_t)M * Q);
+        ws.res_robot = (uint8_t*)take((size_t)M * c->n_spawn);
+        ws.res_ped = (uint8_t*)take((size_t)M * (c->max_peds > 0 ? c->max_peds : 1));
+        ws.path_ws = (int32_t*)take((size_t)M * Q * cc * sizeof(int32_t));
+        const size_t lds = cc * sizeof(int16_t);
+        costmap_kernel<<<dim3(((int)cc + 255) / 256, M), 256, 0, s>>>(occ, H, W, ws.cost, count);
+        regen_install_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes, ws);
+        for (int round = 0; round <= 4; ++round) {
+            regen_robot_round_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, ws, round);
+            if (round < 4) regen_plan_kernel<<<M * Q, 256, lds, s>>>(*c, *st, count, list, ws, 0);
+        }
+        if (c->ped_model != NAVSIM_PED_NONE && c->max_peds > 0)
+            for (int round = 0; round <= 4; ++round) {
+                regen_ped_round_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, ws, round);
+                if (round < 4) regen_plan_kernel<<<M * Q, 256, lds, s>>>(*c, *st, count, list, ws, 1);
+            }
+    } else if (c->field_format == NAVSIM_FIELD_F32) {
         regen_commit_kernel<FieldF32><<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes);
     } else {
-        dt_rows_kernel<1><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, nullptr, nullptr, H, W, count);
         regen_commit_kernel<FieldU16T><<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes);
     }
     if (launch_status() != NAVSIM_OK) return NAVSIM_E_LAUNCH;

@@ -19,7 +19,7 @@ PED_EXTERNAL = 1
 PED_SFM = 2
 
 MAX_PEDS = 64
-MAX_WAYPOINTS = 8
+MAX_WAYPOINTS = 16
 OBS_TAIL = 7
 
 FIELD_F32 = 0
@@ -76,7 +76,7 @@ class NavsimConfig(C.Structure):
         ("ped_angle_last", C.c_double),
         ("ped_range_max", C.c_double),
         ("ped_n_beams", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("regen_plan", C.c_int32),
         ("robot_seen_footprint", C.c_double * 8),
         ("regen_cap", C.c_int32),
         ("obstacle_number", C.c_int32),

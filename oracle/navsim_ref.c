@@ -15,6 +15,10 @@
 
 
 static __thread int64_t g_probe_count = 0;
+int navsim_costmap_cpu(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, uint8_t* cost);
+int navsim_plan_cpu(const uint8_t* cost, const int32_t* map_index, int32_t n_maps, int32_t Hc, int32_t Wc,
+                    double res_c, double ox, double oy, const double* start, const double* goal, double interval,
+                    int32_t max_wp, double* wp, int32_t* n_wp, int32_t* path_cells, double* path_len);
 
 int64_t navsim_probe_count_cpu(int32_t reset) {
     int64_t v = g_probe_count;
@@ -1055,6 +1059,85 @@ static void rg_sample(const navsim_config* c, const float* f, uint64_t key, uint
     rg_cell_xy(c, bi, bj, x, y);
 }
 
+/* regen with path planning (cfg.regen_plan = 1): _sample_start_goal_path (env.py:342-383) on the
+ * costmap -- starts and goals are centres of free COSTMAP cells, a pair is kept only if a path joins
+ * it, and for the robot only if that path is not longer than 2x the straight line (env.py:756-762);
+ * pedestrians start >= 4 m from the robot and walk > 10 m (env.py:369-379, 788-791) along waypoints every
+ * 2 m (env.py:804).  Four rounds of candidates; a slot that never succeeds keeps its last candidate.
+ * Each candidate cell: up to 16 uniform tries, fallback = last try. */
+static void rgp_cell(const navsim_config* c, const uint8_t* cost, int Hc, int Wc, double res_c, uint64_t key,
+                     uint64_t* n, int use_ref, double rx, double ry, double dmin, double dmax, double* x, double* y) {
+    for (int t = 0; t < 16; ++t) {
+        int I = (int)(rg_u(key, (*n)++) * Wc), J = (int)(rg_u(key, (*n)++) * Hc);
+        *x = ((double)I + 0.5) * res_c + c->origin_x;
+        *y = ((double)J + 0.5) * res_c + c->origin_y;
+        if (cost[(size_t)J * Wc + I]) continue;
+        if (use_ref) {
+            double ddx = *x - rx, ddy = *y - ry;
+            double dist = sqrt(ddx * ddx + ddy * ddy);
+            if (!(dist > dmin && dist < dmax)) continue;
+        }
+        return;
+    }
+}
+
+static void regen_planned(const navsim_config* c, const navsim_state* st, int e, uint64_t genv, uint64_t ep,
+                          const uint8_t* occ) {
+    const int N = c->max_peds, K = c->n_spawn, H = c->map_h, W = c->map_w, P = NAVSIM_MAX_WAYPOINTS;
+    const int Hc = H / 5, Wc = W / 5;
+    const double res_c = c->resolution * 5.0;
+    uint8_t* cost = (uint8_t*)malloc((size_t)Hc * Wc);
+    navsim_costmap_cpu(occ, 1, H, W, cost);
+    double* sp = (double*)st->spawn_pose + (size_t)e * K * 3;
+    double* sg = (double*)st->spawn_goal + (size_t)e * K * 2;
+    double wp[2 * NAVSIM_MAX_WAYPOINTS];
+    int32_t nwp; double plen;
+    int resolved[256];
+    for (int k = 0; k < K; ++k) resolved[k] = 0;
+    for (int round = 0; round < 4; ++round)
+        for (int k = 0; k < K && k < 256; ++k) {
+            if (resolved[k]) continue;
+            uint64_t key = nvr_hash4(c->seed, genv, ep, 0x52504C00ULL + (uint64_t)round * 256 + (uint64_t)k), n = 0;
+            double s[2], g[2];
+            rgp_cell(c, cost, Hc, Wc, res_c, key, &n, 0, 0, 0, 0, 0, &s[0], &s[1]);
+            rgp_cell(c, cost, Hc, Wc, res_c, key, &n, 1, s[0], s[1], c->min_goal_dist, c->max_goal_dist, &g[0], &g[1]);
+            sp[3 * k] = s[0]; sp[3 * k + 1] = s[1]; sp[3 * k + 2] = NVR_TWO_PI * rg_u(key, n++);
+            sg[2 * k] = g[0]; sg[2 * k + 1] = g[1];
+            navsim_plan_cpu(cost, NULL, 1, Hc, Wc, res_c, c->origin_x, c->origin_y, s, g, 5.0, P, wp, &nwp, NULL, &plen);
+            double ddx = g[0] - s[0], ddy = g[1] - s[1];
+            resolved[k] = nwp > 0 && plen <= 2.0 * sqrt(ddx * ddx + ddy * ddy);          /* env.py:761 */
+        }
+    int idx = (int)(nvr_hash4(c->seed, genv, ep, 0x5eedULL) % (uint64_t)K);
+    if (!resolved[idx])
+        for (int s_ = 1; s_ < K; ++s_) { int j = (idx + s_) % K; if (resolved[j]) { idx = j; break; } }
+    double* rp = st->robot_pose + 3 * (size_t)e;
+    rp[0] = sp[3 * idx]; rp[1] = sp[3 * idx + 1]; rp[2] = sp[3 * idx + 2];
+    st->robot_goal[2 * e] = sg[2 * idx]; st->robot_goal[2 * e + 1] = sg[2 * idx + 1];
+    int n = (c->ped_model == NAVSIM_PED_NONE) ? 0 : st->n_peds[e];
+    if (n > N) n = N;
+    for (int i = 0; i < n; ++i) {
+        size_t q = (size_t)e * N + i;
+        uint64_t k0 = nvr_hash4(c->seed, genv, ep, 0x504544ULL + (uint64_t)i), m = 0;
+        st->ped_pose[q * 3 + 2] = NVR_TWO_PI * rg_u(k0, m++);
+        ((double*)st->ped_v_pref)[q] = c->v_pref_lo + (c->v_pref_hi - c->v_pref_lo) * rg_u(k0, m++);
+        ((uint8_t*)st->ped_has_legs)[q] = rg_u(k0, m++) < c->has_legs_ratio;
+        st->ped_vel[q * 2] = 0.0; st->ped_vel[q * 2 + 1] = 0.0;
+        double* w = st->ped_waypoints + (q * P) * 2;
+        int done = 0;
+        for (int round = 0; round < 4 && !done; ++round) {
+            uint64_t key = nvr_hash4(c->seed, genv, ep, 0x50504C00ULL + (uint64_t)round * 256 + (uint64_t)i), nn = 0;
+            double s[2], g[2];
+            rgp_cell(c, cost, Hc, Wc, res_c, key, &nn, 1, rp[0], rp[1], c->ped_min_robot_dist, 1.0e300, &s[0], &s[1]);
+            rgp_cell(c, cost, Hc, Wc, res_c, key, &nn, 1, s[0], s[1], c->ped_min_goal_dist, 1.0e300, &g[0], &g[1]);
+            st->ped_pose[q * 3] = s[0]; st->ped_pose[q * 3 + 1] = s[1];
+            navsim_plan_cpu(cost, NULL, 1, Hc, Wc, res_c, c->origin_x, c->origin_y, s, g, 2.0, P, w, &nwp, NULL, NULL);
+            if (nwp > 0) { st->ped_n_waypoints[q] = nwp; done = 1; }
+            else { w[0] = g[0]; w[1] = g[1]; st->ped_n_waypoints[q] = 1; }
+        }
+    }
+    free(cost);
+}
+
 int navsim_regen_cpu(const navsim_config* c, const navsim_state* st, const navsim_step_io* io) {
     if (!c || !st || !io || !io->done || !io->obs) return NAVSIM_E_ARG;
     if (c->field_format != NAVSIM_FIELD_F32 || c->map_h != c->map_w || c->n_spawn < 1) return NAVSIM_E_UNSUPPORTED;
@@ -1071,6 +1154,7 @@ int navsim_regen_cpu(const navsim_config* c, const navsim_state* st, const navsi
         float* f = (float*)st->field + (size_t)e * H * W;
         regen_map(c, genv, ep, occ);
         navsim_build_dt_cpu(occ, 1, H, W, f);
+        if (c->regen_plan) { regen_planned(c, st, e, genv, ep, occ); continue; }
         /* start / goal table */
         double* sp = (double*)st->spawn_pose + (size_t)e * K * 3;
         double* sg = (double*)st->spawn_goal + (size_t)e * K * 2;

@@ -32,7 +32,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = build()
+        so = os.environ.get("NAVSIM_REF_LIB") or build()     # e.g. the sanitizer build (oracle/Makefile)
         L = C.CDLL(so)
         abi.declare(L, "_cpu")
         L.navsim_cast_unit_steps_cpu.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,

@@ -59,3 +59,28 @@ def outdoor_map(rng, size, n_obstacles=10, width_range=(0.3, 1.0)):
         cy = rng.integers(hw + 2, size - hw - 1)
         m[cx - hw:cx + hw + 1, cy - hw:cy + hw + 1] = 1
     return np.flipud(m).copy()
+
+
+def finished_world(cfg, occ, field, n_peds, thresholds):
+    """Host arrays for a RefSim whose robots already stand on their goals (every arena finishes in
+    the first step), for exercising navsim_regen without a rollout.  thresholds = (thr, dthr)."""
+    E, N, K = cfg.n_envs, cfg.max_peds, max(cfg.n_spawn, 1)
+    res = cfg.resolution
+    pose = np.zeros((E, 3))
+    for e in range(E):
+        j, i = np.unravel_index(np.argmax(field[e]), field[e].shape)
+        pose[e, :2] = ((i + 0.5) * res + cfg.origin_x, (j + 0.5) * res + cfg.origin_y)
+    return dict(
+        field=field, scan_threshold=thresholds[0], scan_discomfort=thresholds[1],
+        scan_noise_std=np.zeros(E, np.float32),
+        robot_pose=pose, robot_goal=pose[:, :2].copy(),
+        prev_action=np.zeros((E, 2)), prev_pose=np.zeros((E, 3)),
+        n_hist=np.zeros(E, np.int32), episode=np.zeros(E, np.int64), steps=np.zeros(E, np.int64),
+        n_peds=np.full(E, n_peds, np.int32),
+        ped_pose=np.full((E, N, 3), 1.0e6), ped_vel=np.zeros((E, N, 2)),
+        ped_prev_yaw=np.zeros((E, N)), ped_dist=np.zeros((E, N, 3)),
+        ped_v_pref=np.ones((E, N)), ped_has_legs=np.ones((E, N), np.uint8),
+        ped_waypoints=np.full((E, N, abi.MAX_WAYPOINTS, 2), 1.0e6),
+        ped_n_waypoints=np.ones((E, N), np.int32), ped_cmd=np.zeros((E, N, 2)),
+        spawn_pose=np.tile(pose[:, None, :], (1, K, 1)), spawn_goal=np.tile(pose[:, None, :2], (1, K, 1)),
+    )

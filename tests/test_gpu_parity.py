@@ -308,14 +308,17 @@ def test_ped_scans_vs_oracle(gpu, fmt):
         assert (exp[:, :17] < 6.0).any()
 
 
-@pytest.mark.parametrize("fmt,ped_model", [(abi.FIELD_F32, abi.PED_NONE), (abi.FIELD_U16T, abi.PED_SFM)])
-def test_regen_vs_oracle(gpu, fmt, ped_model):
+@pytest.mark.parametrize("fmt,ped_model,plan", [(abi.FIELD_F32, abi.PED_NONE, 0), (abi.FIELD_U16T, abi.PED_SFM, 0),
+                                                (abi.FIELD_F32, abi.PED_SFM, 1), (abi.FIELD_U16T, abi.PED_NONE, 1)])
+def test_regen_vs_oracle(gpu, fmt, ped_model, plan):
     """navsim_regen: finished arenas get a new map, field, start/goal table, robot,
-    pedestrians and first observation on the device -- every array bit-identical to the oracle's."""
-    E, size, N = 40, 200, 6
+    pedestrians and first observation on the device -- every array bit-identical to the oracle's.
+    plan=1: candidates on the costmap, kept only when the planner joins them (env.py:342-383)."""
+    E, size, N = 40, 200 + 60 * plan, 6
     cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=ped_model, n_spawn=6,
                                  auto_reset=1, seed=17, field_format=fmt, regen_cap=5, min_goal_dist=3.0,
-                                 max_goal_dist=8.0, spawn_clearance=0.9, ped_min_robot_dist=2.0, ped_min_goal_dist=4.0)
+                                 max_goal_dist=8.0, spawn_clearance=0.9, ped_min_robot_dist=2.0, ped_min_goal_dist=4.0,
+                                 regen_plan=plan)
     gpu.world.lidar_1081(cfg)
     occ = gpu.world.make_maps(E, size, 17)
     regenerated = capped = 0
@@ -334,6 +337,8 @@ def test_regen_vs_oracle(gpu, fmt, ped_model):
             if fmt == abi.FIELD_F32:
                 _eq(gs["field"], r.a["field"], "field after regen at step %d" % t)
     assert regenerated > 5
+    if plan and ped_model != abi.PED_NONE:
+        assert (r.a["ped_n_waypoints"] > 1).any(), "no pedestrian ever received a planned path"
     # a regenerated arena has a valid closed map: 5-cell border, obstacles inside
     f = r.a["field"]
     assert (f[:, :5] == 0).all() and (f[:, :, -5:] == 0).all()

@@ -199,3 +199,46 @@ def test_costmap_and_planner_properties():
     blocked = np.argwhere(cost[0] != 0)[0]
     _, n0, _, _ = ref.plan(cost, [[(blocked[1] + 0.5) * 0.25, (blocked[0] + 0.5) * 0.25]], goal[:1], 2.0)
     assert n0[0] == 0
+
+
+def test_regen_with_planning_properties():
+    """cfg.regen_plan = 1 (env.py:342-383, 756-804): the new robot start and goal are centres of free
+    costmap cells joined by a path no longer than twice the straight line; pedestrians start at least
+    ped_min_robot_dist from the robot and their waypoints are exactly what the planner returns for
+    (start, last waypoint) at a 2 m interval."""
+    from nav_gym_amd import abi, robots
+    from helpers import finished_world
+    E, size, N = 8, 300, 6
+    cfg = ref.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_SFM, n_spawn=6,
+                             auto_reset=1, seed=5, regen_cap=8, min_goal_dist=3.0, max_goal_dist=8.0,
+                             ped_min_robot_dist=2.0, ped_min_goal_dist=4.0, regen_plan=1, obstacle_number=6)
+    rng = np.random.default_rng(0)
+    occ = np.stack([outdoor_map(rng, size) for _ in range(E)])
+    thr = ref.scan_threshold(cfg, robots.footprint_array("keti", "threshold_footprint"))
+    dthr = ref.scan_threshold(cfg, robots.footprint_array("keti", "discomfort_threshold_footprint"))
+    r = ref.RefSim(cfg, finished_world(cfg, occ, ref.build_dt(occ), 5, (thr, dthr)))
+    r.reset_obs()
+    _, out = r.step(np.zeros((E, 2)))
+    assert out["done"].all()
+    r.regen()
+    cost = ref.costmap((r.a["field"] == 0).astype(np.uint8))
+    cell = lambda xy: (int(xy[1] / 0.25), int(xy[0] / 0.25))
+    robots_ok = planned_peds = 0
+    for e in range(E):
+        s, g = r.a["robot_pose"][e, :2], r.a["robot_goal"][e]
+        wp, n_wp, _, plen = ref.plan(cost[e:e + 1], [s], [g], 5.0, max_wp=abi.MAX_WAYPOINTS)
+        if n_wp[0] > 0 and plen[0] <= 2.0 * np.linalg.norm(g - s):
+            robots_ok += 1
+            assert cost[e][cell(s)] == 0 and cost[e][cell(g)] == 0
+            assert 3.0 < np.linalg.norm(g - s) < 8.0
+        for i in range(5):
+            p, n = r.a["ped_pose"][e, i, :2], r.a["ped_n_waypoints"][e, i]
+            w = r.a["ped_waypoints"][e, i]
+            if n > 1 or cost[e][cell(w[0])] == 0:
+                wp, n_wp, _, _ = ref.plan(cost[e:e + 1], [p], [w[n - 1]], 2.0, max_wp=abi.MAX_WAYPOINTS)
+                if n_wp[0] == n and n < abi.MAX_WAYPOINTS:
+                    assert np.array_equal(wp[0, :n], w[:n])
+                    planned_peds += 1
+                    assert np.linalg.norm(p - s) >= 2.0 and np.linalg.norm(w[n - 1] - p) > 4.0
+        assert (r.a["ped_n_waypoints"][e, 5:] == 1).all()
+    assert robots_ok >= E - 1 and planned_peds >= 3 * E
