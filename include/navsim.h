@@ -301,7 +301,10 @@ int navsim_ped_scans(const navsim_config* cfg, const navsim_state* st, float* ou
  * (start >= 4 m from the robot, goal >= 10 m away, v_pref, has_legs: env.py:786-806) and the first
  * observation of the new episode (env.py:808-831) written to io->obs.  Call it right after navsim_step on
  * the same stream with the same io.  Mutates field, spawn tables and pedestrian parameters in place.
- * Square maps, FIELD_F32 or FIELD_U16T without an overflow plane or tile table. */
+ * Square maps, FIELD_F32 or FIELD_U16T without an overflow plane or tile table.
+ * cfg->regen_plan = 1: starts and goals are centres of free COSTMAP cells and a pair is kept only when the
+ * planner joins it (robot: path no longer than twice the straight line, env.py:756-762; pedestrians get the
+ * path's waypoints every 2 m, env.py:804); four rounds of candidates, the last one stays if none passes. */
 size_t navsim_regen_workspace_bytes(const navsim_config* cfg);
 int    navsim_regen(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                     void* workspace, size_t workspace_bytes, void* stream);
@@ -313,7 +316,8 @@ int navsim_costmap(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t ma
 /* n queries; query q plans on costmap map_index[q] (q when NULL).  Shortest 4-connected path between the
  * cells of start[q] and goal[q] (build-defined tie-break), cut into waypoints every
  * `interval` metres.  wp [n,max_wp,2], n_wp [n] (0 = no path), path_cells [n], path_len [n] (env.py:757-759);
- * the last three may be NULL. */
+ * the last three may be NULL.  The search runs in LDS (4 bytes per costmap cell: up to 200 x 200 cells,
+ * i.e. 1000 x 1000 maps); `workspace` is unused (navsim_plan_workspace_bytes returns 0) and may be NULL. */
 size_t navsim_plan_workspace_bytes(int32_t n_queries, int32_t cost_h, int32_t cost_w);
 int    navsim_plan(const uint8_t* cost, const int32_t* map_index, int32_t n_queries, int32_t cost_h, int32_t cost_w,
                    double cost_resolution, double origin_x, double origin_y, const double* start, const double* goal,

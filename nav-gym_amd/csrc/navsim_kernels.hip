@@ -1695,15 +1695,28 @@ __global__ __launch_bounds__(256) void costmap_kernel(const uint8_t* __restrict_
 // stopped at the start's level; thread 0 then walks the path (+i, -i, +j, -j order) and cuts it
 // into waypoints exactly like path_to_waypoints.
 // One query, executed by the whole 256-thread workgroup.  c = this query's costmap, w = its waypoint
-// row (max_wp x 2), path = its Hc*Wc int32 scratch; n_wp / path_cells / path_len point at its slots.
+// row (max_wp x 2); n_wp / path_cells / path_len point at its slots.
+//
+// LDS: dist[n_cells] int16 (-2 blocked, -1 free and unreached, else hops from the goal) followed by
+// queue[n_cells] uint16, the breadth-first queue (every cell enters once; a level is the slice [lo, hi)).
+// A level costs O(frontier), not O(grid): phase A marks the free unreached neighbours of the frontier
+// (racing stores all write the same value), phase B appends each marked cell exactly once -- by the
+// frontier cell that is its first neighbour in (+i, -i, +j, -j) order at the previous level -- so no 16-bit
+// atomics are needed.  Queue order is arbitrary; only `dist` feeds the path, so results are deterministic.
+// Thread 0 then walks the path and cuts the waypoints on the fly (nothing is stored per path cell).
+constexpr size_t kPlanLdsMax = 160 * 1024 - 256;       // LDS per CU minus the static variables
+inline size_t plan_lds(int Hc, int Wc) { return (size_t)((Hc * Wc + 1) & ~1) * 4; }
+inline bool plan_fits(int Hc, int Wc) { return (size_t)Hc * Wc <= 65535 && plan_lds(Hc, Wc) <= kPlanLdsMax; }
+
 __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc, int Wc, double res_c, double ox,
                                            double oy, double sx_, double sy_, double gx_, double gy_, double interval,
                                            int max_wp, double* __restrict__ w, int32_t* __restrict__ n_wp,
-                                           int32_t* __restrict__ path_cells, double* __restrict__ path_len,
-                                           int32_t* __restrict__ path) {
-    extern __shared__ int16_t dist[];                  // Hc * Wc, -1 = unreached
-    __shared__ int changed, reached;
+                                           int32_t* __restrict__ path_cells, double* __restrict__ path_len) {
+    extern __shared__ int16_t dist[];
+    __shared__ int tail_s, reached;
     const int tid = threadIdx.x;
+    const int n_cells = Hc * Wc;
+    uint16_t* queue = (uint16_t*)(dist + ((n_cells + 1) & ~1));
     navsim_config cc = {};
     cc.origin_x = ox; cc.origin_y = oy; cc.resolution = res_c; cc.map_h = Hc; cc.map_w = Wc;
     int si, sj, gi, gj;
@@ -1717,60 +1730,72 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
         if (path_len) *path_len = 0.0;
     }
     if (!ok) return;                                     // uniform: depends on the query only
-    const int n_cells = Hc * Wc;
-    for (int k = tid; k < n_cells; k += 256) dist[k] = -1;
+    const int s_cell = sj * Wc + si, g_cell = gj * Wc + gi;
+    for (int k = tid; k < n_cells; k += 256) dist[k] = c[k] ? (int16_t)-2 : (int16_t)-1;
     __syncthreads();
-    if (tid == 0) { dist[gj * Wc + gi] = 0; reached = (si == gi && sj == gj); }
+    if (tid == 0) { dist[g_cell] = 0; queue[0] = (uint16_t)g_cell; tail_s = 1; reached = (s_cell == g_cell); }
     __syncthreads();
+    int lo = 0, hi = 1;
     for (int level = 1; level < 32767; ++level) {
-        if (reached) break;
-        if (tid == 0) changed = 0;
-        __syncthreads();
-        int mine = 0;
-        for (int k = tid; k < n_cells; k += 256) {
-            if (dist[k] != -1 || c[k]) continue;
-            int j = k / Wc, i = k - j * Wc;
-            bool nb = (i + 1 < Wc && dist[k + 1] == level - 1) || (i > 0 && dist[k - 1] == level - 1) ||
-                      (j + 1 < Hc && dist[k + Wc] == level - 1) || (j > 0 && dist[k - Wc] == level - 1);
-            if (nb) mine |= 1 | ((k == sj * Wc + si) ? 2 : 0);
-            if (nb) dist[k] = (int16_t)(-2 - level);       // tentative: invisible to this level's readers
+        if (reached || lo == hi) break;
+        for (int f = lo + tid; f < hi; f += 256) {                       // phase A
+            int k = queue[f], j = k / Wc, i = k - j * Wc;
+            if (i + 1 < Wc && dist[k + 1] == -1) dist[k + 1] = (int16_t)level;
+            if (i > 0 && dist[k - 1] == -1) dist[k - 1] = (int16_t)level;
+            if (j + 1 < Hc && dist[k + Wc] == -1) dist[k + Wc] = (int16_t)level;
+            if (j > 0 && dist[k - Wc] == -1) dist[k - Wc] = (int16_t)level;
         }
         __syncthreads();
-        for (int k = tid; k < n_cells; k += 256)
-            if (dist[k] < -1) dist[k] = (int16_t)(-2 - dist[k]);
-        if (mine & 1) changed = 1;
-        if (mine & 2) reached = 1;
+        for (int f = lo + tid; f < hi; f += 256) {                       // phase B
+            int k = queue[f], j = k / Wc, i = k - j * Wc;
+            const int16_t prev = (int16_t)(level - 1);
+            // is k the first previous-level neighbour of m, looking from m in (+i, -i, +j, -j) order?
+            auto mine = [&](int m, int mi, int mj) {
+                if (dist[m] != (int16_t)level) return false;
+                int parent;
+                if (mi + 1 < Wc && dist[m + 1] == prev) parent = m + 1;
+                else if (mi > 0 && dist[m - 1] == prev) parent = m - 1;
+                else if (mj + 1 < Hc && dist[m + Wc] == prev) parent = m + Wc;
+                else parent = m - Wc;
+                return parent == k;
+            };
+            auto push = [&](int m) {
+                queue[atomicAdd(&tail_s, 1)] = (uint16_t)m;
+                if (m == s_cell) reached = 1;
+            };
+            if (i + 1 < Wc && mine(k + 1, i + 1, j)) push(k + 1);
+            if (i > 0 && mine(k - 1, i - 1, j)) push(k - 1);
+            if (j + 1 < Hc && mine(k + Wc, i, j + 1)) push(k + Wc);
+            if (j > 0 && mine(k - Wc, i, j - 1)) push(k - Wc);
+        }
         __syncthreads();
-        if (!changed) break;
+        lo = hi;
+        hi = tail_s;
     }
-    __syncthreads();
-    if (tid != 0 || dist[sj * Wc + si] < 0) return;
-    int n = 0, ci = si, cj = sj;
+    if (tid != 0 || dist[s_cell] < 0) return;
+    int n = 0, count = 0, ci = si, cj = sj;
+    const double fx0 = ((double)si + 0.5) * res_c + ox, fy0 = ((double)sj + 0.5) * res_c + oy;
+    double fx = fx0, fy = fy0;                           // env.py:1261-1277, cut while walking
     for (;;) {
-        path[n++] = cj * Wc + ci;
-        int dcur = dist[cj * Wc + ci];
-        if (dcur == 0) break;
-        const int DI[4] = {1, -1, 0, 0}, DJ[4] = {0, 0, 1, -1};
-        for (int d = 0; d < 4; ++d) {
-            int ni = ci + DI[d], nj = cj + DJ[d];
-            if (ni < 0 || ni >= Wc || nj < 0 || nj >= Hc) continue;
-            if (dist[nj * Wc + ni] == dcur - 1) { ci = ni; cj = nj; break; }
+        ++n;
+        const double cx = ((double)ci + 0.5) * res_c + ox, cy = ((double)cj + 0.5) * res_c + oy;
+        const double dx = fx - cx, dy = fy - cy;
+        const int k = cj * Wc + ci;
+        const int dcur = dist[k];
+        const bool far = sqrt(dx * dx + dy * dy) > interval;
+        if (far) {
+            if (count < max_wp) { w[2 * count] = cx; w[2 * count + 1] = cy; }
+            ++count; fx = cx; fy = cy;
         }
-    }
-    auto px = [&](int k) { return ((double)(path[k] % Wc) + 0.5) * res_c + ox; };
-    auto py = [&](int k) { return ((double)(path[k] / Wc) + 0.5) * res_c + oy; };
-    int first = 0, count = 0;
-    for (;;) {                                           // env.py:1261-1277
-        int found = -1;
-        for (int k = first; k < n; ++k) {
-            double dx = px(first) - px(k), dy = py(first) - py(k);
-            if (sqrt(dx * dx + dy * dy) > interval) { found = k; break; }
+        if (dcur == 0) {                                 // the goal cell closes the list
+            if (count < max_wp) { w[2 * count] = cx; w[2 * count + 1] = cy; }
+            ++count;
+            break;
         }
-        int pick = (found >= 0) ? found : n - 1;
-        if (count < max_wp) { w[2 * count] = px(pick); w[2 * count + 1] = py(pick); }
-        ++count;
-        if (found < 0) break;
-        first = found;
+        const int want = dcur - 1;                       // first neighbour one hop closer, (+i, -i, +j, -j)
+        const bool e0 = ci + 1 < Wc && dist[k + 1] == want, e1 = ci > 0 && dist[k - 1] == want;
+        const bool e2 = cj + 1 < Hc && dist[k + Wc] == want;
+        if (e0) ++ci; else if (e1) --ci; else if (e2) ++cj; else --cj;
     }
     int nw = count < max_wp ? count : max_wp;
     *n_wp = nw;
@@ -1791,12 +1816,11 @@ __global__ __launch_bounds__(256) void plan_kernel(const uint8_t* __restrict__ c
                                                    const double* __restrict__ start, const double* __restrict__ goal,
                                                    double interval, int max_wp, double* __restrict__ wp,
                                                    int32_t* __restrict__ n_wp, int32_t* __restrict__ path_cells,
-                                                   double* __restrict__ path_len, int32_t* __restrict__ path_ws) {
+                                                   double* __restrict__ path_len) {
     const int q = blockIdx.x;
     plan_query(cost + (size_t)(map_index ? map_index[q] : q) * Hc * Wc, Hc, Wc, res_c, ox, oy, start[2 * q],
                start[2 * q + 1], goal[2 * q], goal[2 * q + 1], interval, max_wp, wp + (size_t)q * max_wp * 2, n_wp + q,
-               path_cells ? path_cells + q : nullptr, path_len ? path_len + q : nullptr,
-               path_ws + (size_t)q * Hc * Wc);
+               path_cells ? path_cells + q : nullptr, path_len ? path_len + q : nullptr);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1813,7 +1837,6 @@ struct RegenPlanWs {
     uint8_t* active;      // [M, Q]
     uint8_t* res_robot;   // [M, K]
     uint8_t* res_ped;     // [M, N]
-    int32_t* path_ws;     // [M, Q, Hc*Wc]
     int Q;
 };
 
@@ -1957,7 +1980,7 @@ __global__ __launch_bounds__(256) void regen_plan_kernel(navsim_config c, navsim
                           : ws.qwp + (size_t)q * P * 2;
     plan_query(ws.cost + (size_t)b * Hc * Wc, Hc, Wc, c.resolution * 5.0, c.origin_x, c.origin_y, ws.qstart[2 * q],
                ws.qstart[2 * q + 1], ws.qgoal[2 * q], ws.qgoal[2 * q + 1], ped_stage ? 2.0 : 5.0, P, w, ws.qnwp + q,
-               nullptr, ped_stage ? nullptr : ws.qlen + q, ws.path_ws + (size_t)q * Hc * Wc);
+               nullptr, ped_stage ? nullptr : ws.qlen + q);
 }
 
 // ============================================================================================
@@ -2187,6 +2210,13 @@ int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_s
 // ============================================================================================
 // C ABI
 // ============================================================================================
+// kernels that want more than 64 KB of dynamic LDS must say so once
+static int allow_lds(const void* kernel, size_t lds) {
+    if (lds <= 64 * 1024) return NAVSIM_OK;
+    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess
+               ? NAVSIM_OK : NAVSIM_E_UNSUPPORTED;
+}
+
 extern "C" {
 
 int navsim_abi_version(void) { return NAVSIM_ABI_VERSION; }
@@ -2475,8 +2505,8 @@ int navsim_costmap(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, uin
 }
 
 size_t navsim_plan_workspace_bytes(int32_t n_queries, int32_t Hc, int32_t Wc) {
-    if (n_queries <= 0 || Hc <= 0 || Wc <= 0) return 0;
-    return (size_t)n_queries * Hc * Wc * sizeof(int32_t);
+    (void)n_queries; (void)Hc; (void)Wc;
+    return 0;                                              // the search lives in LDS; kept for ABI stability
 }
 
 int navsim_plan(const uint8_t* cost, const int32_t* map_index, int32_t n, int32_t Hc, int32_t Wc, double res_c,
@@ -2484,14 +2514,13 @@ int navsim_plan(const uint8_t* cost, const int32_t* map_index, int32_t n, int32_
                 double* wp, int32_t* n_wp, int32_t* path_cells, double* path_len, void* workspace,
                 size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
-    if (!cost || !start || !goal || !wp || !n_wp || !workspace || n < 0 || Hc <= 0 || Wc <= 0 || max_wp < 1)
-        return NAVSIM_E_ARG;
-    if (workspace_bytes < navsim_plan_workspace_bytes(n, Hc, Wc)) return NAVSIM_E_ARG;
-    if ((size_t)Hc * Wc * 2 > 150 * 1024 || Hc * Wc > 32000 * 4) return NAVSIM_E_UNSUPPORTED;   // LDS-resident BFS
+    (void)workspace; (void)workspace_bytes;
+    if (!cost || !start || !goal || !wp || !n_wp || n < 0 || Hc <= 0 || Wc <= 0 || max_wp < 1) return NAVSIM_E_ARG;
+    if (!plan_fits(Hc, Wc)) return NAVSIM_E_UNSUPPORTED;                // LDS-resident search
     if (n == 0) return NAVSIM_OK;
-    plan_kernel<<<n, 256, (size_t)Hc * Wc * sizeof(int16_t), (hipStream_t)stream>>>(
-        cost, map_index, Hc, Wc, res_c, ox, oy, start, goal, interval, max_wp, wp, n_wp, path_cells, path_len,
-        (int32_t*)workspace);
+    if (allow_lds((const void*)plan_kernel, plan_lds(Hc, Wc)) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
+    plan_kernel<<<n, 256, plan_lds(Hc, Wc), (hipStream_t)stream>>>(
+        cost, map_index, Hc, Wc, res_c, ox, oy, start, goal, interval, max_wp, wp, n_wp, path_cells, path_len);
     return launch_status();
 }
 
@@ -2511,7 +2540,6 @@ size_t navsim_regen_workspace_bytes(const navsim_config* c) {
         b += M * Q * (2 + 2 + 2 * P + 1) * sizeof(double) + 256;      // start, goal, waypoints, length
         b += M * Q * sizeof(int32_t) + 256;                           // waypoint counts
         b += M * (Q + (size_t)c->n_spawn + (size_t)c->max_peds) + 256;   // active, resolved flags
-        b += M * Q * cc * sizeof(int32_t) + 256;                      // path scratch
         b += 8 * 256;                                                 // alignment of the ten sub-buffers
     }
     return b + 1024;
@@ -2525,8 +2553,8 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         (c->field_format != NAVSIM_FIELD_F32 && c->field_format != NAVSIM_FIELD_U16T) || c->shared_field)
         return NAVSIM_E_UNSUPPORTED;
     if (workspace_bytes < navsim_regen_workspace_bytes(c) || !st->spawn_pose || !st->spawn_goal) return NAVSIM_E_ARG;
-    if (c->regen_plan && (c->n_spawn > 256 || c->map_h < 5 ||
-                          (size_t)(c->map_h / 5) * (c->map_w / 5) * sizeof(int16_t) > 150 * 1024))
+    if (c->regen_plan && (c->n_spawn > 256 || c->map_h < 5 || !plan_fits(c->map_h / 5, c->map_w / 5) ||
+                          allow_lds((const void*)regen_plan_kernel, plan_lds(c->map_h / 5, c->map_w / 5)) != NAVSIM_OK))
         return NAVSIM_E_UNSUPPORTED;
     int rc = check_step_args(c, st, io, 1);
     if (rc != NAVSIM_OK) return rc;
@@ -2573,8 +2601,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         ws.active = (uint8_t*)take((size_t)M * Q);
         ws.res_robot = (uint8_t*)take((size_t)M * c->n_spawn);
         ws.res_ped = (uint8_t*)take((size_t)M * (c->max_peds > 0 ? c->max_peds : 1));
-        ws.path_ws = (int32_t*)take((size_t)M * Q * cc * sizeof(int32_t));
-        const size_t lds = cc * sizeof(int16_t);
+        const size_t lds = plan_lds(Hc, Wc);
         costmap_kernel<<<dim3(((int)cc + 255) / 256, M), 256, 0, s>>>(occ, H, W, ws.cost, count);
         regen_install_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes, ws);
         for (int round = 0; round <= 4; ++round) {

@@ -10,6 +10,8 @@ and default to the reference's behaviour for num_envs == 1:
     map_size        cells per side of every arena (default 400, the reference's outdoor size)
     randomize_maps  True: an arena that finishes an episode restarts on a NEW random outdoor map,
                     generated on the device inside step() (navsim_regen); False: it respawns in place
+    plan_paths      with randomize_maps: new starts / goals are sampled on the costmap and kept only when
+                    the planner joins them, pedestrians get path waypoints (env.py:342-383, 756-804)
     pedestrian_model 'sfm' (build-defined social force), 'external' (caller supplies (v, w) per
                     pedestrian -- the slot the reference fills with HumanPolicy) or 'none'
     device, seed, env_index_base (global index of arena 0: sharding), auto_reset, field_format
@@ -100,7 +102,7 @@ class NavGymEnv(object):
                  reward_discomfort_factor, env_param_range, *,
                  num_envs=1, n_beams=None, lidar=None, map_size=400, pedestrian_model="sfm",
                  num_humans=None, device="cuda:0", seed=0, env_index_base=0, auto_reset=None,
-                 field_format=abi.FIELD_U16T, n_spawn=16, randomize_maps=False):
+                 field_format=abi.FIELD_U16T, n_spawn=16, randomize_maps=False, plan_paths=True):
         from . import lib
         if robot_type not in robots.ROBOTS:
             raise NotImplementedError(robot_type)            # env.py:772-773
@@ -126,6 +128,7 @@ class NavGymEnv(object):
         self._num_humans_fixed = num_humans
         self._episode_batch = 0
         self.randomize_maps = bool(randomize_maps)
+        self.plan_paths = bool(plan_paths)
         spec = robots.ROBOTS[robot_type]
         nh_hi = int(env_param_range["num_humans"][0][1]) if num_humans is None else int(num_humans)
         ped = {"none": abi.PED_NONE, "external": abi.PED_EXTERNAL, "sfm": abi.PED_SFM}[pedestrian_model]
@@ -137,6 +140,7 @@ class NavGymEnv(object):
             n_spawn=n_spawn, add_scan_noise=1, env_index_base=env_index_base, field_format=field_format,
             time_step=time_step, axle_offset=spec["axle_offset"], min_turning_radius=float(min_turning_radius),
             distance_threshold=distance_threshold, range_max=spec["range_max"], seed=self.seed_value)
+        cfg.regen_plan = int(self.randomize_maps and self.plan_paths)
         room = self.map_size * cfg.resolution                # per-episode ranges used by navsim_regen
         cfg.min_goal_dist = float(min(min_goal_dist, 0.4 * room))
         cfg.max_goal_dist = float(min(max_goal_dist, 0.8 * room))
