@@ -177,6 +177,11 @@ typedef struct navsim_state {
     const double* spawn_pose;       /* [E,K,3] */
     const double* spawn_goal;       /* [E,K,2] */
 
+    /* planning costmap of every arena, [E, H/5, W/5] uint8 (navsim_costmap), or NULL.  When present a
+     * pedestrian that reaches its final waypoint waits for navsim_replan (env.py:667-680) instead of
+     * drawing a straight-line goal from the spawn table, and navsim_regen refreshes it (regen_plan). */
+    uint8_t* costmap;
+
     /* scratch of navsim_step_workspace_bytes(cfg) bytes.  Non-NULL selects the pooled schedule
      * (per-arena prologue -> one flat pool of 64-beam march tasks -> per-arena epilogue, DESIGN.md
      * section 6); NULL runs the whole step as one launch.  Results are identical. */
@@ -323,6 +328,15 @@ int    navsim_plan(const uint8_t* cost, const int32_t* map_index, int32_t n_quer
                    double cost_resolution, double origin_x, double origin_y, const double* start, const double* goal,
                    double interval, int32_t max_wp, double* wp, int32_t* n_wp, int32_t* path_cells, double* path_len,
                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* env.py:667-680: every pedestrian within 0.5 m of its final waypoint gets a new goal -- a free costmap cell
+ * more than cfg->ped_min_goal_dist away (up to 4 rounds of 16 draws) -- and the waypoints of the shortest
+ * path to it every 2 m; it keeps its old waypoint when no round finds a path ("only if the human is not
+ * adjacent to a wall").  At most max_queries pedestrians per call, in (arena, pedestrian) order; the rest
+ * are served by a later call.  Needs st->costmap.  Call after navsim_step / navsim_regen on the same stream. */
+size_t navsim_replan_workspace_bytes(const navsim_config* cfg, int32_t max_queries);
+int    navsim_replan(const navsim_config* cfg, const navsim_state* st, int32_t max_queries, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* First observation after reset() (env.py:822-831): scan at the current robot pose, stack filled
  * with copies, prev_pose = pose, vel = 0; sets prev_pose/prev_action/n_hist.  `mask` [E] uint8 or

@@ -1287,9 +1287,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             sh.rp[0] = p[0]; sh.rp[1] = p[1]; sh.rp[2] = p[2];
         }
         if (is_ped) {
-            // ---- new goal at the final waypoint (env.py:667-680; A* replaced by a table draw)
+            // ---- new goal at the final waypoint (env.py:667-680): table draw, or wait for navsim_replan
             double ddx = pp[0] - wp[2 * (nw - 1)], ddy = pp[1] - wp[2 * (nw - 1) + 1];
-            if (sqrt(ddx * ddx + ddy * ddy) < 0.5 && c.n_spawn > 0 && st.spawn_pose) {
+            if (sqrt(ddx * ddx + ddy * ddy) < 0.5 && c.n_spawn > 0 && st.spawn_pose && !st.costmap) {
                 uint64_t h = nv::hash4(c.seed, genv, (uint64_t)tid + 1000, (uint64_t)st.steps[e]);
                 for (int tries = 0; tries < c.n_spawn; ++tries) {
                     int idx = (int)((h + (uint64_t)tries) % (uint64_t)c.n_spawn);
@@ -1674,7 +1674,8 @@ __device__ __forceinline__ int reflect101(int k, int n) {
 }
 
 __global__ __launch_bounds__(256) void costmap_kernel(const uint8_t* __restrict__ occ, int H, int W,
-                                                      uint8_t* __restrict__ cost, const int* __restrict__ n_live) {
+                                                      uint8_t* __restrict__ cost, const int* __restrict__ n_live,
+                                                      const int* __restrict__ out_index) {
     const int Hc = H / 5, Wc = W / 5;
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     size_t m = blockIdx.y;
@@ -1688,7 +1689,7 @@ __global__ __launch_bounds__(256) void costmap_kernel(const uint8_t* __restrict_
             int jj = reflect101(J + dj, Hc), ii = reflect101(I + di, Wc);
             any |= o[(size_t)(jj * 5) * W + ii * 5];
         }
-    cost[m * (size_t)Hc * Wc + idx] = any ? 1 : 0;
+    cost[(out_index ? (size_t)out_index[m] : m) * (size_t)Hc * Wc + idx] = any ? 1 : 0;
 }
 
 // one workgroup per query: level-synchronous breadth-first distances from the goal in LDS (int16),
@@ -1828,7 +1829,8 @@ __global__ __launch_bounds__(256) void plan_kernel(const uint8_t* __restrict__ c
 // a path must join start and goal.  Rounds of {sample, plan, accept} kernels; no host round trip.
 // --------------------------------------------------------------------------------------------
 struct RegenPlanWs {
-    uint8_t* cost;        // [M, Hc, Wc]
+    uint8_t* cost;        // [M, Hc, Wc] scratch, or the resident st.costmap (then indexed by arena)
+    int cost_by_arena;
     double* qstart;       // [M, Q, 2]
     double* qgoal;        // [M, Q, 2]
     double* qwp;          // [M, Q, P, 2]   robot stage only (pedestrian paths go straight into the state)
@@ -1885,7 +1887,7 @@ __global__ __launch_bounds__(256) void regen_robot_round_kernel(navsim_config c,
     const int N = c.max_peds, K = c.n_spawn, Q = ws.Q;
     const int Hc = c.map_h / 5, Wc = c.map_w / 5;
     const double res_c = c.resolution * 5.0;
-    const uint8_t* cost = ws.cost + (size_t)b * Hc * Wc;
+    const uint8_t* cost = ws.cost + (size_t)(ws.cost_by_arena ? e : b) * Hc * Wc;
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
     double* sp = (double*)st.spawn_pose + (size_t)e * K * 3;
     double* sg = (double*)st.spawn_goal + (size_t)e * K * 2;
@@ -1943,7 +1945,7 @@ __global__ __launch_bounds__(256) void regen_ped_round_kernel(navsim_config c, n
     const int N = c.max_peds, Q = ws.Q, P = NAVSIM_MAX_WAYPOINTS;
     const int Hc = c.map_h / 5, Wc = c.map_w / 5;
     const double res_c = c.resolution * 5.0;
-    const uint8_t* cost = ws.cost + (size_t)b * Hc * Wc;
+    const uint8_t* cost = ws.cost + (size_t)(ws.cost_by_arena ? e : b) * Hc * Wc;
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
     const double rx = st.robot_pose[3 * (size_t)e], ry = st.robot_pose[3 * (size_t)e + 1];
     int n = (c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
@@ -1978,9 +1980,80 @@ __global__ __launch_bounds__(256) void regen_plan_kernel(navsim_config c, navsim
     const int Hc = c.map_h / 5, Wc = c.map_w / 5, P = NAVSIM_MAX_WAYPOINTS;
     double* w = ped_stage ? st.ped_waypoints + (((size_t)list[b] * c.max_peds + k) * P) * 2
                           : ws.qwp + (size_t)q * P * 2;
-    plan_query(ws.cost + (size_t)b * Hc * Wc, Hc, Wc, c.resolution * 5.0, c.origin_x, c.origin_y, ws.qstart[2 * q],
+    plan_query(ws.cost + (size_t)(ws.cost_by_arena ? list[b] : b) * Hc * Wc, Hc, Wc, c.resolution * 5.0, c.origin_x, c.origin_y, ws.qstart[2 * q],
                ws.qstart[2 * q + 1], ws.qgoal[2 * q], ws.qgoal[2 * q + 1], ped_stage ? 2.0 : 5.0, P, w, ws.qnwp + q,
                nullptr, ped_stage ? nullptr : ws.qlen + q);
+}
+
+// --------------------------------------------------------------------------------------------
+// navsim_replan (env.py:667-680; oracle navsim_replan_cpu): ordered list of the pedestrians standing on
+// their final waypoint, then one workgroup per listed pedestrian: draw a goal, plan, up to 4 rounds.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void replan_select_kernel(navsim_config c, navsim_state st, int cap,
+                                                             int* __restrict__ count, int* __restrict__ list) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, N = c.max_peds, P = NAVSIM_MAX_WAYPOINTS;
+    const int total = c.n_envs * N;
+    const int per = (total + 1023) / 1024;
+    const int lo = tid * per, hi = (lo + per < total) ? lo + per : total;
+    auto due = [&](int q) {
+        int e = q / N, i = q - e * N;
+        if (i >= st.n_peds[e]) return false;
+        const double* pp = st.ped_pose + (size_t)q * 3;
+        const double* w = st.ped_waypoints + ((size_t)q * P) * 2;
+        int nw = st.ped_n_waypoints[q];
+        double ddx = pp[0] - w[2 * (nw - 1)], ddy = pp[1] - w[2 * (nw - 1) + 1];
+        return sqrt(ddx * ddx + ddy * ddy) < 0.5;
+    };
+    int n = 0;
+    for (int q = lo; q < hi; ++q) n += due(q);
+    part[tid] = n;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int pos = part[tid] - n;
+    if (n)
+        for (int q = lo; q < hi && pos < cap; ++q)
+            if (due(q)) list[pos++] = q;
+    if (tid == 1023) *count = part[1023] < cap ? part[1023] : cap;
+}
+
+__global__ __launch_bounds__(256) void replan_kernel(navsim_config c, navsim_state st, const int* __restrict__ count,
+                                                     const int* __restrict__ list) {
+    __shared__ double goal_s[2];
+    __shared__ int32_t nwp_s;
+    const int b = blockIdx.x;
+    if (b >= *count) return;
+    const int q = list[b], N = c.max_peds, P = NAVSIM_MAX_WAYPOINTS, tid = threadIdx.x;
+    const int e = q / N, i = q - e * N;
+    const int Hc = c.map_h / 5, Wc = c.map_w / 5;
+    const double res_c = c.resolution * 5.0;
+    const uint8_t* cost = st.costmap + (size_t)(c.shared_field ? 0 : e) * Hc * Wc;
+    const uint64_t genv = (uint64_t)(c.env_index_base + e);
+    const uint64_t when = (uint64_t)st.steps[e] + ((uint64_t)st.episode[e] << 40);
+    const double px = st.ped_pose[(size_t)q * 3], py = st.ped_pose[(size_t)q * 3 + 1];
+    double* w = st.ped_waypoints + ((size_t)q * P) * 2;
+    for (int round = 0; round < 4; ++round) {
+        if (tid == 0) {
+            uint64_t key = nv::hash4(c.seed, genv, when, 0x52504E00ULL + (uint64_t)round * 256 + (uint64_t)i), m = 0;
+            double gx, gy;
+            rgp_cell(c, cost, Hc, Wc, res_c, key, m, true, px, py, c.ped_min_goal_dist, 1.0e300, gx, gy);
+            goal_s[0] = gx; goal_s[1] = gy;
+        }
+        __syncthreads();
+        plan_query(cost, Hc, Wc, res_c, c.origin_x, c.origin_y, px, py, goal_s[0], goal_s[1], 2.0, P, w, &nwp_s,
+                   nullptr, nullptr);
+        __syncthreads();
+        if (nwp_s > 0) {
+            if (tid == 0) st.ped_n_waypoints[q] = nwp_s;
+            break;
+        }
+        __syncthreads();                                 // nwp_s is rewritten by the next round
+    }
 }
 
 // ============================================================================================
@@ -2500,7 +2573,7 @@ int navsim_costmap(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, uin
     if (n_maps == 0) return NAVSIM_OK;
     if (n_maps > 65535) return NAVSIM_E_UNSUPPORTED;
     int cells = (H / 5) * (W / 5);
-    costmap_kernel<<<dim3((cells + 255) / 256, n_maps), 256, 0, (hipStream_t)stream>>>(occ, H, W, cost, nullptr);
+    costmap_kernel<<<dim3((cells + 255) / 256, n_maps), 256, 0, (hipStream_t)stream>>>(occ, H, W, cost, nullptr, nullptr);
     return launch_status();
 }
 
@@ -2593,6 +2666,8 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         RegenPlanWs ws;
         ws.Q = Q;
         ws.cost = (uint8_t*)take((size_t)M * cc);
+        ws.cost_by_arena = st->costmap != nullptr;
+        if (st->costmap) ws.cost = st->costmap;
         ws.qstart = (double*)take((size_t)M * Q * 2 * sizeof(double));
         ws.qgoal = (double*)take((size_t)M * Q * 2 * sizeof(double));
         ws.qwp = (double*)take((size_t)M * Q * P * 2 * sizeof(double));
@@ -2602,7 +2677,8 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         ws.res_robot = (uint8_t*)take((size_t)M * c->n_spawn);
         ws.res_ped = (uint8_t*)take((size_t)M * (c->max_peds > 0 ? c->max_peds : 1));
         const size_t lds = plan_lds(Hc, Wc);
-        costmap_kernel<<<dim3(((int)cc + 255) / 256, M), 256, 0, s>>>(occ, H, W, ws.cost, count);
+        costmap_kernel<<<dim3(((int)cc + 255) / 256, M), 256, 0, s>>>(occ, H, W, ws.cost, count,
+                                                                      st->costmap ? list : nullptr);
         regen_install_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes, ws);
         for (int round = 0; round <= 4; ++round) {
             regen_robot_round_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, ws, round);
@@ -2613,16 +2689,44 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
                 regen_ped_round_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, ws, round);
                 if (round < 4) regen_plan_kernel<<<M * Q, 256, lds, s>>>(*c, *st, count, list, ws, 1);
             }
-    } else if (c->field_format == NAVSIM_FIELD_F32) {
-        regen_commit_kernel<FieldF32><<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes);
-    } else {
-        regen_commit_kernel<FieldU16T><<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes);
+    } else if (st->costmap) {
+        costmap_kernel<<<dim3(((H / 5) * (W / 5) + 255) / 256, M), 256, 0, s>>>(occ, H, W, st->costmap, count, list);
+    }
+    if (!c->regen_plan) {
+        if (c->field_format == NAVSIM_FIELD_F32)
+            regen_commit_kernel<FieldF32><<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes);
+        else
+            regen_commit_kernel<FieldU16T><<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes);
     }
     if (launch_status() != NAVSIM_OK) return NAVSIM_E_LAUNCH;
     // first observation of the new episodes; the other arenas keep the row the step just wrote
     navsim_step_io io2 = *io;
     io2.obs_prev = io->obs;
     return dispatch_step(c, st, &io2, 1, mask, s);
+}
+
+size_t navsim_replan_workspace_bytes(const navsim_config* c, int32_t max_queries) {
+    if (!c || max_queries < 0) return 0;
+    return 256 + (size_t)max_queries * sizeof(int32_t);
+}
+
+int navsim_replan(const navsim_config* c, const navsim_state* st, int32_t max_queries, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
+    if (!c || !st || !workspace || max_queries < 0 || !st->costmap || !st->ped_pose || !st->ped_waypoints ||
+        !st->ped_n_waypoints || !st->n_peds || !st->steps || !st->episode)
+        return NAVSIM_E_ARG;
+    if (workspace_bytes < navsim_replan_workspace_bytes(c, max_queries)) return NAVSIM_E_ARG;
+    if (c->ped_model == NAVSIM_PED_NONE || c->n_envs == 0 || max_queries == 0) return NAVSIM_OK;
+    const int Hc = c->map_h / 5, Wc = c->map_w / 5;
+    if (Hc < 1 || Wc < 1 || !plan_fits(Hc, Wc) || allow_lds((const void*)replan_kernel, plan_lds(Hc, Wc)) != NAVSIM_OK)
+        return NAVSIM_E_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    int* count = (int*)workspace;
+    int* list = (int*)((char*)workspace + 256);
+    replan_select_kernel<<<1, 1024, 0, s>>>(*c, *st, max_queries, count, list);
+    replan_kernel<<<max_queries, 256, plan_lds(Hc, Wc), s>>>(*c, *st, count, list);
+    return launch_status();
 }
 
 size_t navsim_step_workspace_bytes(const navsim_config* c) { return c ? workspace_bytes(c) : 0; }

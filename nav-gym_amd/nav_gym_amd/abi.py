@@ -108,7 +108,7 @@ class NavsimState(C.Structure):
         "robot_pose", "robot_goal", "prev_action", "prev_pose", "n_hist", "episode", "steps",
         "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist", "ped_v_pref", "ped_has_legs",
         "ped_waypoints", "ped_n_waypoints", "ped_cmd",
-        "spawn_pose", "spawn_goal", "workspace",
+        "spawn_pose", "spawn_goal", "costmap", "workspace",
     )]
 
 
@@ -147,6 +147,7 @@ STATE_LAYOUT = {
     "ped_cmd": ("float64", ("E", "N", 2)),
     "spawn_pose": ("float64", ("E", "K", 3)),
     "spawn_goal": ("float64", ("E", "K", 2)),
+    "costmap": ("uint8", ("E", "Hc", "Wc")),
 }
 
 IO_LAYOUT = {
@@ -168,7 +169,7 @@ def resolve_shape(shape, cfg):
     sym = {
         "E": cfg.n_envs, "N": cfg.max_peds, "B": cfg.n_beams, "S": cfg.n_scan_stack,
         "K": max(cfg.n_spawn, 1), "P": MAX_WAYPOINTS, "H": cfg.map_h, "W": cfg.map_w,
-        "D": cfg.n_scan_stack * cfg.n_beams + OBS_TAIL,
+        "D": cfg.n_scan_stack * cfg.n_beams + OBS_TAIL, "Hc": cfg.map_h // 5, "Wc": cfg.map_w // 5,
         "T": (((cfg.map_h + 7) // 8) * ((cfg.map_w + 7) // 8) + 3) // 4 * 4,
     }
     return tuple(sym[s] if isinstance(s, str) else s for s in shape)
@@ -212,7 +213,10 @@ def declare(lib, suffix=""):
     sig("navsim_ped_scans", [cfgp, stp, _P] + stream)
     if suffix:
         sig("navsim_regen", [cfgp, stp, iop])
+        sig("navsim_replan", [cfgp, stp, i32])
     else:
+        sig("navsim_replan_workspace_bytes", [cfgp, i32], C.c_size_t)
+        sig("navsim_replan", [cfgp, stp, i32, _P, C.c_size_t, _P])
         sig("navsim_costmap", [_P, i32, i32, i32, _P, _P])
         sig("navsim_plan_workspace_bytes", [i32, i32, i32], C.c_size_t)
         sig("navsim_plan", [_P, _P, i32, i32, i32, f64, f64, f64, _P, _P, f64, i32, _P, _P, _P, _P, _P, C.c_size_t, _P])
@@ -231,7 +235,7 @@ EXPORTS = (
     "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
     "navsim_scan_threshold", "navsim_beam_table", "navsim_step_workspace_bytes", "navsim_ped_scans", "navsim_regen_workspace_bytes", "navsim_regen",
-    "navsim_costmap", "navsim_plan_workspace_bytes", "navsim_plan",
+    "navsim_costmap", "navsim_plan_workspace_bytes", "navsim_plan", "navsim_replan_workspace_bytes", "navsim_replan",
     "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math",
 )

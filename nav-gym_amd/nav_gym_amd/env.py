@@ -10,8 +10,11 @@ and default to the reference's behaviour for num_envs == 1:
     map_size        cells per side of every arena (default 400, the reference's outdoor size)
     randomize_maps  True: an arena that finishes an episode restarts on a NEW random outdoor map,
                     generated on the device inside step() (navsim_regen); False: it respawns in place
-    plan_paths      with randomize_maps: new starts / goals are sampled on the costmap and kept only when
-                    the planner joins them, pedestrians get path waypoints (env.py:342-383, 756-804)
+    plan_paths      True (default): pedestrians follow the waypoints of planned shortest paths and re-plan
+                    at their goal (env.py:667-680, 788-804; navsim_replan after every step); with
+                    randomize_maps new starts / goals are sampled on the costmap and kept only when the
+                    planner joins them (env.py:342-383, 756-762).  False: straight-line goals.
+                    Maps above 1000 cells per side fall back to False (the search lives in LDS).
     pedestrian_model 'sfm' (build-defined social force), 'external' (caller supplies (v, w) per
                     pedestrian -- the slot the reference fills with HumanPolicy) or 'none'
     device, seed, env_index_base (global index of arena 0: sharding), auto_reset, field_format
@@ -128,7 +131,8 @@ class NavGymEnv(object):
         self._num_humans_fixed = num_humans
         self._episode_batch = 0
         self.randomize_maps = bool(randomize_maps)
-        self.plan_paths = bool(plan_paths)
+        self.replan_cap = 1024                              # pedestrians re-planned per step, at most
+        self.plan_paths = bool(plan_paths) and int(map_size) <= 1000
         spec = robots.ROBOTS[robot_type]
         nh_hi = int(env_param_range["num_humans"][0][1]) if num_humans is None else int(num_humans)
         ped = {"none": abi.PED_NONE, "external": abi.PED_EXTERNAL, "sfm": abi.PED_SFM}[pedestrian_model]
@@ -221,7 +225,8 @@ class NavGymEnv(object):
             cfg, occ, seed=seed, n_peds=n_peds if cfg.ped_model != abi.PED_NONE else 0,
             min_goal_dist=min(self.min_goal_dist, 0.4 * room), max_goal_dist=min(self.max_goal_dist, 0.8 * room),
             noise_std_range=(nlo, nhi), has_legs_ratio=self.human_has_legs_ratio,
-            v_pref_range=tuple(self.human_v_pref_range), device=self.device)
+            v_pref_range=tuple(self.human_v_pref_range), device=self.device,
+            plan_paths=self.plan_paths and cfg.ped_model != abi.PED_NONE)
         dev = torch.device(self.device)
         for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
             arrays[key] = simmod.scan_threshold(cfg, torch.from_numpy(robots.footprint_array(self.robot_type, name)).to(dev))
@@ -255,6 +260,8 @@ class NavGymEnv(object):
         _, out = self.sim.step(a)
         if self.randomize_maps and self.auto_reset:
             self.sim.regen()
+        if "costmap" in self.sim.t:
+            self.sim.replan(self.replan_cap)
         obs = self._obs_dict()
         if self.num_envs == 1:
             info = {"is_success": np.float32(out["is_success"][0].item()),

@@ -285,6 +285,18 @@ class NavSim(object):
               "navsim_regen")
         return self.obs
 
+    def replan(self, max_queries=1024):
+        """navsim_replan (env.py:667-680): pedestrians standing on their final waypoint get a new goal and
+        the waypoints of a planned path.  Needs the resident costmap (world.make_world(plan_paths=True))."""
+        import torch
+        key = "replan_ws_%d" % max_queries
+        if key not in self.t:
+            nbytes = self.lib.navsim_replan_workspace_bytes(C.byref(self.cfg), max_queries)
+            self.t[key] = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        ws = self.t[key]
+        check(self.lib.navsim_replan(C.byref(self.cfg), C.byref(self.st), max_queries, _ptr(ws), ws.numel(), _stream()),
+              "navsim_replan")
+
     def ped_scans(self):
         """Scan of every pedestrian (env.py:685-693) from the current state -> float32 [E, N, 512]."""
         import torch

@@ -52,7 +52,7 @@ def indoor_map(rng, size, corridor_width=3, iterations=100):
     return np.flipud(g[np.ix_(idx, idx)])
 
 
-def make_maps(n_envs, size, seed, env_index_base=0, indoor_ratio=0.0):
+def make_maps(n_envs, size, seed, env_index_base=0, indoor_ratio=0.0, n_obstacles=10):
     """uint8 [E, size, size], nonzero = occupied (map_info['data'] >= 0.1, env.py:339)."""
     occ = np.empty((n_envs, size, size), np.uint8)
     for e in range(n_envs):
@@ -60,7 +60,7 @@ def make_maps(n_envs, size, seed, env_index_base=0, indoor_ratio=0.0):
         if rng.random() < indoor_ratio:
             occ[e] = indoor_map(rng, size, rng.integers(3, 5), rng.integers(80, 151))
         else:
-            occ[e] = outdoor_map(rng, size)
+            occ[e] = outdoor_map(rng, size, n_obstacles)
     return occ
 
 
@@ -114,10 +114,13 @@ def cells_to_xy(cells, W, resolution, origin):
 
 def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=20.0,
                robot_clearance=1.2, ped_clearance=0.5, noise_std_range=(0.0, 0.0),
-               has_legs_ratio=0.5, v_pref_range=(0.0, 0.6), device="cuda:0", field=None):
+               has_legs_ratio=0.5, v_pref_range=(0.0, 0.6), device="cuda:0", field=None, plan_paths=False):
     """Builds every navsim_state array for cfg.n_envs arenas on `device`.
 
-    occ: uint8 numpy/torch [E,H,W].  Returns dict name -> torch tensor (see abi.STATE_LAYOUT)."""
+    occ: uint8 numpy/torch [E,H,W].  Returns dict name -> torch tensor (see abi.STATE_LAYOUT).
+    plan_paths: also keep the planning costmap of every arena resident (env.py:312-332) and give the
+    pedestrians the waypoints of a planned path to their first goal (env.py:788-804); pedestrians
+    then re-plan through NavSim.replan() (env.py:667-680)."""
     import torch
     from . import sim
     seed = int(cfg.seed if seed is None else seed)
@@ -143,6 +146,8 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
             if (os.environ.get("NAVSIM_TILES") == "1" and cfg.field_format == abi.FIELD_U16T
                     and sim.load().navsim_tile_table_bytes(1, H0, W0) <= 40960):
                 a["tile_table"] = sim.build_tiles(occ_t)
+        if plan_paths:
+            a["costmap"] = sim.costmap(occ_t)
         del occ_t
     else:
         if cfg.field_format != abi.FIELD_F32:
@@ -188,7 +193,7 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
         rank = torch.argsort((~far_enough).to(torch.int8), dim=1, stable=True)  # acceptable starts first
         start = torch.gather(pxy, 1, rank[:, :N, None].expand(E, N, 2))
         gd = torch.cdist(start, pxy)                                        # [E,N,M]
-        gok = gd > 10.0                                                     # env.py:788-791
+        gok = gd > float(cfg.ped_min_goal_dist)                             # env.py:788-791 (10 m)
         gfirst = torch.argmax(gok.to(torch.int8), dim=2)
         gidx = torch.where(gok.any(dim=2), gfirst, torch.argmax(gd, dim=2))
         pgoal = torch.gather(pxy, 1, gidx[..., None].expand(E, N, 2))
@@ -202,8 +207,16 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
         a["ped_has_legs"] = (_uniform(seed, genv, 24, (N,), dev) < has_legs_ratio).to(torch.uint8)
         wp = torch.zeros((E, N, abi.MAX_WAYPOINTS, 2), dtype=torch.float64, device=dev)
         wp[:, :, 0] = pgoal
-        a["ped_waypoints"] = wp
-        a["ped_n_waypoints"] = torch.ones((E, N), dtype=torch.int32, device=dev)
+        nwp = torch.ones((E, N), dtype=torch.int32, device=dev)
+        if "costmap" in a:                                                  # env.py:788-804
+            mi = torch.arange(E, device=dev, dtype=torch.int32).repeat_interleave(N)
+            pw, pn, _, _ = sim.plan(a["costmap"], start.reshape(-1, 2), pgoal.reshape(-1, 2), 2.0,
+                                    max_wp=abi.MAX_WAYPOINTS, res_c=res * 5, origin=org, map_index=mi)
+            found = (pn > 0).reshape(E, N)
+            wp = torch.where(found[..., None, None], pw.reshape(E, N, abi.MAX_WAYPOINTS, 2), wp)
+            nwp = torch.where(found, pn.reshape(E, N), nwp)
+        a["ped_waypoints"] = wp.contiguous()
+        a["ped_n_waypoints"] = nwp.contiguous()
         a["ped_cmd"] = torch.zeros((E, N, 2), dtype=torch.float64, device=dev)
     return a
 

@@ -867,15 +867,15 @@ static void step_env(const navsim_config* c, const navsim_state* st, const navsi
     /* ---- robot (env.py:664) */
     set_vel(rp, a0, a1, dt, c->axle_offset, NULL);
 
-    /* ---- pedestrians at their final waypoint take a new goal (env.py:667-680).  The reference
-     * re-plans with A* (pyastar2d, out of scope: SURVEY.md 8f #1); the build draws a goal >= 10 m
-     * away from the env's spawn table and heads straight for it. */
+    /* ---- pedestrians at their final waypoint take a new goal (env.py:667-680).  With a resident
+     * costmap the pedestrian waits for navsim_replan_cpu, which plans like the reference; without one
+     * it draws a goal >= 10 m away from the env's spawn table and heads straight for it. */
     for (int i = 0; i < n; ++i) {
         double* pp = st->ped_pose + ((size_t)e * N + i) * 3;
         double* wp = st->ped_waypoints + (((size_t)e * N + i) * P) * 2;
         int* nw = st->ped_n_waypoints + (size_t)e * N + i;
         double ddx = pp[0] - wp[2 * (*nw - 1)], ddy = pp[1] - wp[2 * (*nw - 1) + 1];
-        if (sqrt(ddx * ddx + ddy * ddy) < 0.5 && c->n_spawn > 0 && st->spawn_pose) {
+        if (sqrt(ddx * ddx + ddy * ddy) < 0.5 && c->n_spawn > 0 && st->spawn_pose && !st->costmap) {
             uint64_t h = nvr_hash4(c->seed, genv, (uint64_t)i + 1000, (uint64_t)st->steps[e]);
             for (int tries = 0; tries < c->n_spawn; ++tries) {
                 int idx = (int)((h + (uint64_t)tries) % (uint64_t)c->n_spawn);
@@ -1138,6 +1138,45 @@ static void regen_planned(const navsim_config* c, const navsim_state* st, int e,
     free(cost);
 }
 
+/* env.py:667-680 (see include/navsim.h navsim_replan) */
+int navsim_replan_cpu(const navsim_config* c, const navsim_state* st, int32_t max_queries) {
+    if (!c || !st || !st->costmap || !st->ped_pose || !st->ped_waypoints || !st->ped_n_waypoints || !st->n_peds ||
+        max_queries < 0)
+        return NAVSIM_E_ARG;
+    if (c->ped_model == NAVSIM_PED_NONE) return NAVSIM_OK;
+    const int N = c->max_peds, P = NAVSIM_MAX_WAYPOINTS, Hc = c->map_h / 5, Wc = c->map_w / 5;
+    const double res_c = c->resolution * 5.0;
+    int served = 0;
+    for (int e = 0; e < c->n_envs; ++e) {
+        int n = st->n_peds[e] > N ? N : st->n_peds[e];
+        const uint8_t* cost = st->costmap + (size_t)(c->shared_field ? 0 : e) * Hc * Wc;
+        const uint64_t genv = (uint64_t)(c->env_index_base + e);
+        const uint64_t when = (uint64_t)st->steps[e] + ((uint64_t)st->episode[e] << 40);
+        for (int i = 0; i < n; ++i) {
+            size_t q = (size_t)e * N + i;
+            double* pp = st->ped_pose + q * 3;
+            double* w = st->ped_waypoints + (q * P) * 2;
+            int nw = st->ped_n_waypoints[q];
+            double ddx = pp[0] - w[2 * (nw - 1)], ddy = pp[1] - w[2 * (nw - 1) + 1];
+            if (!(sqrt(ddx * ddx + ddy * ddy) < 0.5)) continue;
+            if (served++ >= max_queries) return NAVSIM_OK;
+            for (int round = 0; round < 4; ++round) {
+                uint64_t key = nvr_hash4(c->seed, genv, when, 0x52504E00ULL + (uint64_t)round * 256 + (uint64_t)i), m = 0;
+                double g[2], wp[2 * NAVSIM_MAX_WAYPOINTS];
+                int32_t nwp;
+                rgp_cell(c, cost, Hc, Wc, res_c, key, &m, 1, pp[0], pp[1], c->ped_min_goal_dist, 1.0e300, &g[0], &g[1]);
+                navsim_plan_cpu(cost, NULL, 1, Hc, Wc, res_c, c->origin_x, c->origin_y, pp, g, 2.0, P, wp, &nwp, NULL, NULL);
+                if (nwp > 0) {
+                    memcpy(w, wp, sizeof(double) * 2 * (size_t)nwp);
+                    st->ped_n_waypoints[q] = nwp;
+                    break;
+                }
+            }
+        }
+    }
+    return NAVSIM_OK;
+}
+
 int navsim_regen_cpu(const navsim_config* c, const navsim_state* st, const navsim_step_io* io) {
     if (!c || !st || !io || !io->done || !io->obs) return NAVSIM_E_ARG;
     if (c->field_format != NAVSIM_FIELD_F32 || c->map_h != c->map_w || c->n_spawn < 1) return NAVSIM_E_UNSUPPORTED;
@@ -1154,6 +1193,7 @@ int navsim_regen_cpu(const navsim_config* c, const navsim_state* st, const navsi
         float* f = (float*)st->field + (size_t)e * H * W;
         regen_map(c, genv, ep, occ);
         navsim_build_dt_cpu(occ, 1, H, W, f);
+        if (st->costmap) navsim_costmap_cpu(occ, 1, H, W, st->costmap + (size_t)e * (H / 5) * (W / 5));
         if (c->regen_plan) { regen_planned(c, st, e, genv, ep, occ); continue; }
         /* start / goal table */
         double* sp = (double*)st->spawn_pose + (size_t)e * K * 3;

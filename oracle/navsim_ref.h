@@ -67,6 +67,7 @@ int navsim_scan_threshold_cpu(const navsim_config* cfg, const float* footprint, 
 int navsim_ped_scans_cpu(const navsim_config* cfg, const navsim_state* st, float* out);
 
 int navsim_regen_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io);
+int navsim_replan_cpu(const navsim_config* cfg, const navsim_state* st, int32_t max_queries);
 
 /* costmap (env.py:312-332), shortest 4-connected path (env.py:343-354) and path_to_waypoints
  * (env.py:1261-1277); see navsim_ref.c for the stated tie-break */

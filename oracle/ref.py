@@ -288,6 +288,9 @@ class RefSim(object):
         _chk(lib().navsim_regen_cpu(C.byref(self.cfg), C.byref(self.st), C.byref(io)), "regen")
         return self.obs[self.cur]
 
+    def replan(self, max_queries=1024):
+        _chk(lib().navsim_replan_cpu(C.byref(self.cfg), C.byref(self.st), max_queries), "replan")
+
     def ped_scans(self):
         out = np.zeros((self.cfg.n_envs, self.cfg.max_peds, self.cfg.ped_n_beams), np.float32)
         _chk(lib().navsim_ped_scans_cpu(C.byref(self.cfg), C.byref(self.st), _p(out)), "ped_scans")

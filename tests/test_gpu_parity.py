@@ -205,10 +205,10 @@ def test_step_golden_traces(gpu, name):
         np.testing.assert_allclose(stt["ped_dist"][0], tr["traj_ped_dist"][t], rtol=0, atol=1e-10)
 
 
-def _rollout_pair(gpu, cfg, occ, n_peds, steps, seed, noise=False):
+def _rollout_pair(gpu, cfg, occ, n_peds, steps, seed, noise=False, **world_kw):
     """Runs the same world through the HIP step and the oracle; yields per-step comparisons."""
     torch = gpu.torch
-    arrays = gpu.world.make_world(cfg, occ, n_peds=n_peds, device=gpu.dev)
+    arrays = gpu.world.make_world(cfg, occ, n_peds=n_peds, device=gpu.dev, **world_kw)
     key = "keti"
     from nav_gym_amd import robots
     arrays["scan_threshold"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array(key, "threshold_footprint")))
@@ -322,7 +322,8 @@ def test_regen_vs_oracle(gpu, fmt, ped_model, plan):
     gpu.world.lidar_1081(cfg)
     occ = gpu.world.make_maps(E, size, 17)
     regenerated = capped = 0
-    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=5, steps=45, seed=6):
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=5, steps=45, seed=6,
+                                                     plan_paths=bool(plan) and ped_model != abi.PED_NONE):
         _eq(go, ro, "obs at step %d" % t)
         n_done = int(rout["done"].sum())
         go2 = g.regen().cpu().numpy()
@@ -342,6 +343,37 @@ def test_regen_vs_oracle(gpu, fmt, ped_model, plan):
     # a regenerated arena has a valid closed map: 5-cell border, obstacles inside
     f = r.a["field"]
     assert (f[:, :5] == 0).all() and (f[:, :, -5:] == 0).all()
+
+
+@pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T])
+def test_replan_vs_oracle(gpu, fmt):
+    """navsim_replan (env.py:667-680): pedestrians that reach their final waypoint get a new planned path;
+    waypoints, counts and everything downstream stay bit-identical to the oracle over a rollout, including
+    calls that hit the per-call query cap."""
+    E, size, N = 16, 300, 6
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_SFM, n_spawn=6,
+                                 auto_reset=1, seed=23, field_format=fmt, ped_min_goal_dist=3.0, obstacle_number=6)
+    gpu.world.lidar_full_circle(cfg, 180)
+    occ = gpu.world.make_maps(E, size, 23, n_obstacles=6)
+    replans = 0
+    prev_n = None
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=5, steps=120, seed=4, plan_paths=True,
+                                                     v_pref_range=(0.5, 0.6)):
+        _eq(go, ro, "obs at step %d" % t)
+        if prev_n is None:
+            assert (r.a["ped_n_waypoints"] > 1).any(), "no pedestrian started with a planned path"
+        cap = 2 if t % 2 else 64
+        g.replan(cap); r.replan(cap)
+        gs = g.numpy_state("ped_waypoints", "ped_n_waypoints", "costmap")
+        n_now = r.a["ped_n_waypoints"].copy()
+        _eq(gs["ped_n_waypoints"], n_now, "waypoint counts at step %d" % t)
+        live = np.arange(abi.MAX_WAYPOINTS)[None, None, :] < n_now[..., None]
+        _eq(gs["ped_waypoints"][live], r.a["ped_waypoints"][live], "waypoints at step %d" % t)
+        if prev_n is not None:
+            replans += int((n_now > prev_n).sum())
+        prev_n = n_now
+    _eq(gs["costmap"], r.a["costmap"], "costmap")
+    assert replans >= 5, replans
 
 
 def test_config1_single_env_64_beams(gpu):
@@ -405,6 +437,19 @@ def test_env_wrapper_gym_api(gpu):
     assert rr.shape == (32,)
     done_again = benv.compute_terminals(bo)
     assert done_again.shape == (32,)
+    # pedestrians follow planned paths (plan_paths defaults to True): resident costmap, multi-waypoint routes
+    assert "costmap" in env.sim.t and tuple(env.sim.t["costmap"].shape) == (1, 80, 80)
+    assert int(env.sim.t["ped_n_waypoints"][0, :5].max()) > 1
+    renv = nav_gym_env.make("NavGym-v0", num_envs=16, map_size=300, num_humans=4, seed=5, randomize_maps=True,
+                            min_goal_dist=3, max_goal_dist=8)
+    renv.reset()
+    assert renv.cfg.regen_plan == 1
+    straight = gpu.torch.tensor([[0.5, 0.0]] * 16, dtype=gpu.torch.float64, device=gpu.dev)
+    finished = 0
+    for _ in range(60):
+        _, _, bd, _ = renv.step(straight)
+        finished += int(bd.sum())
+    assert finished > 0 and int(renv.sim.t["episode"].sum()) == finished
 
 
 @pytest.fixture(scope="module")
