@@ -27,14 +27,19 @@ def outdoor_map(rng, size, n_obstacles=10, width_range=(0.3, 1.0)):
 
 
 def indoor_map(rng, size, corridor_width=3, iterations=100):
-    """create_indoor_map (map_generator.py:97-123): a random tree of corridors carved on a
-    100x100 grid (L1-nearest node, L-shaped paths), nearest-neighbour upscaled to `size`."""
-    g = np.ones((100, 100), np.uint8)
-    tree = [(50, 50)]
-    g[50, 50] = 0
+    """create_indoor_map (map_generator.py:97-123): a random tree of corridors carved on a coarse grid
+    (L1-nearest node, L-shaped paths), nearest-neighbour upscaled to `size`.  The reference carves a
+    100x100 grid for its 1000-cell maps (0.5 m per grid cell); other sizes keep that METRIC scale --
+    size/10 grid cells, iterations scaled with the area -- so corridors stay 3.5-4.5 m wide and survive
+    the planner's 1 m inflation."""
     r = int(corridor_width)
-    for _ in range(int(iterations)):
-        p = (int(rng.integers(r + 2, 100 - r - 1)), int(rng.integers(r + 2, 100 - r - 1)))
+    G = max(int(size) // 10, 2 * r + 8)
+    n_it = max(4, int(round(int(iterations) * (G / 100.0) ** 2)))
+    g = np.ones((G, G), np.uint8)
+    tree = [(G // 2, G // 2)]
+    g[G // 2, G // 2] = 0
+    for _ in range(n_it):
+        p = (int(rng.integers(r + 2, G - r - 1)), int(rng.integers(r + 2, G - r - 1)))
         d = [abs(p[0] - q[0]) + abs(p[1] - q[1]) for q in tree]
         q = tree[int(np.argmin(d))]
         tree.append(p)
@@ -48,7 +53,7 @@ def indoor_map(rng, size, corridor_width=3, iterations=100):
             g[x2 - r:x2 + r + 1, y1 - r:y2 + r + 1] = 0
             corner_y = y2 if ((p[0] > q[0]) != (p[1] < q[1])) else y1
             g[x1 - r:x2 + r + 1, corner_y - r:corner_y + r + 1] = 0
-    idx = np.minimum((np.arange(size) * (100.0 / size)).astype(int), 99)
+    idx = np.minimum((np.arange(size) * (float(G) / size)).astype(int), G - 1)
     return np.flipud(g[np.ix_(idx, idx)])
 
 
@@ -157,8 +162,14 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
     genv = torch.arange(E, device=dev, dtype=torch.int64) + int(cfg.env_index_base)
     # ---- robot start / goal tables (env.py:748-783 without A*) -------------------------------------
     KK = max(2 * K, 8)
-    cells = sample_free_cells(field, robot_clearance / res, KK, seed, genv, 11)
-    xy = cells_to_xy(cells, W, res, org)                                   # [E,KK,2]
+    if "costmap" in a:              # env.py:356-368: starts and goals are centres of free costmap cells
+        cfield = (1.0 - a["costmap"].to(torch.float32)) * 1000.0
+        Wc = cfield.shape[2]
+        cells = sample_free_cells(cfield, 0.5, KK, seed, genv, 11)
+        xy = cells_to_xy(cells, Wc, res * 5, org)
+    else:
+        cells = sample_free_cells(field, robot_clearance / res, KK, seed, genv, 11)
+        xy = cells_to_xy(cells, W, res, org)                               # [E,KK,2]
     theta = _uniform(seed, genv, 12, (KK,), dev) * (2 * np.pi)
     d = torch.cdist(xy, xy)                                                # [E,KK,KK]
     ok = (d > min_goal_dist) & (d < max_goal_dist)
@@ -170,6 +181,18 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
     far = torch.argmax(d, dim=2)
     partner = torch.where(ok_c.any(dim=2), partner, far)
     goal = torch.gather(xy, 1, partner[..., None].expand(E, KK, 2))
+    if "costmap" in a:              # env.py:756-762: keep pairs joined by a path <= 2x the straight line
+        mi = torch.arange(E, device=dev, dtype=torch.int32).repeat_interleave(K)
+        s_, g_ = xy[:, :K].reshape(-1, 2), goal[:, :K].reshape(-1, 2)
+        _, pn, _, plen = sim.plan(a["costmap"], s_, g_, 5.0, max_wp=abi.MAX_WAYPOINTS, res_c=res * 5, origin=org,
+                                  map_index=mi)
+        valid = ((pn > 0) & (plen <= 2.0 * (g_ - s_).norm(dim=1))).reshape(E, K)
+        # an invalid slot borrows the next valid one in cyclic order (none valid: left as drawn)
+        order_k = (torch.arange(K, device=dev)[None, :] + torch.arange(K, device=dev)[:, None]) % K      # [K,K]
+        v_c = torch.gather(valid[:, None, :].expand(E, K, K), 2, order_k[None].expand(E, K, K))
+        src = torch.gather(order_k[None].expand(E, K, K), 2, torch.argmax(v_c.to(torch.int8), dim=2)[..., None])[..., 0]
+        xy = torch.cat([torch.gather(xy[:, :K], 1, src[..., None].expand(E, K, 2)), xy[:, K:]], dim=1)
+        goal = torch.cat([torch.gather(goal[:, :K], 1, src[..., None].expand(E, K, 2)), goal[:, K:]], dim=1)
     a["spawn_pose"] = torch.cat([xy[:, :K], theta[:, :K, None]], dim=2).contiguous()
     a["spawn_goal"] = goal[:, :K].contiguous()
     a["robot_pose"] = a["spawn_pose"][:, 0].clone()
@@ -187,8 +210,12 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
             if not hasattr(n_peds, "shape") or len(getattr(n_peds, "shape", ())) == 0 \
             else torch.as_tensor(n_peds).to(device=dev, dtype=torch.int32)
         M = 4 * N
-        pc = sample_free_cells(field, ped_clearance / res, M, seed, genv, 21)
-        pxy = cells_to_xy(pc, W, res, org)                                  # [E,M,2]
+        if "costmap" in a:
+            pc = sample_free_cells(cfield, 0.5, M, seed, genv, 21)
+            pxy = cells_to_xy(pc, Wc, res * 5, org)
+        else:
+            pc = sample_free_cells(field, ped_clearance / res, M, seed, genv, 21)
+            pxy = cells_to_xy(pc, W, res, org)                              # [E,M,2]
         far_enough = (pxy - a["robot_pose"][:, None, :2]).norm(dim=2) >= 4.0   # env.py:372
         rank = torch.argsort((~far_enough).to(torch.int8), dim=1, stable=True)  # acceptable starts first
         start = torch.gather(pxy, 1, rank[:, :N, None].expand(E, N, 2))
