@@ -1700,10 +1700,9 @@ __global__ __launch_bounds__(256) void costmap_kernel(const uint8_t* __restrict_
 //
 // LDS: dist[n_cells] int16 (-2 blocked, -1 free and unreached, else hops from the goal) followed by
 // queue[n_cells] uint16, the breadth-first queue (every cell enters once; a level is the slice [lo, hi)).
-// A level costs O(frontier), not O(grid): phase A marks the free unreached neighbours of the frontier
-// (racing stores all write the same value), phase B appends each marked cell exactly once -- by the
-// frontier cell that is its first neighbour in (+i, -i, +j, -j) order at the previous level -- so no 16-bit
-// atomics are needed.  Queue order is arbitrary; only `dist` feeds the path, so results are deterministic.
+// A level costs O(frontier) and ONE barrier: each frontier lane claims its free unreached neighbours with
+// a 32-bit LDS atomic AND on the word holding the int16 (see `claim`), and the winner appends the cell.
+// Queue order is arbitrary; only `dist` feeds the path, so results are deterministic.
 // Thread 0 then walks the path and cuts the waypoints on the fly (nothing is stored per path cell).
 constexpr size_t kPlanLdsMax = 160 * 1024 - 256;       // LDS per CU minus the static variables
 inline size_t plan_lds(int Hc, int Wc) { return (size_t)((Hc * Wc + 1) & ~1) * 4; }
@@ -1714,7 +1713,7 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
                                            int max_wp, double* __restrict__ w, int32_t* __restrict__ n_wp,
                                            int32_t* __restrict__ path_cells, double* __restrict__ path_len) {
     extern __shared__ int16_t dist[];
-    __shared__ int tail_s, reached;
+    __shared__ int cnt[3], reached;
     const int tid = threadIdx.x;
     const int n_cells = Hc * Wc;
     uint16_t* queue = (uint16_t*)(dist + ((n_cells + 1) & ~1));
@@ -1732,58 +1731,99 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
     }
     if (!ok) return;                                     // uniform: depends on the query only
     const int s_cell = sj * Wc + si, g_cell = gj * Wc + gi;
-    for (int k = tid; k < n_cells; k += 256) dist[k] = c[k] ? (int16_t)-2 : (int16_t)-1;
+    if ((((uintptr_t)c) & 3) == 0) {                                       // four cells per load
+        const uint32_t* c4 = (const uint32_t*)c;
+        uint2* d4 = (uint2*)dist;
+        for (int k = tid; k < n_cells / 4; k += 256) {
+            const uint32_t v = c4[k];
+            uint2 o;
+            o.x = ((v & 0xFFu) ? 0xFFFEu : 0xFFFFu) | (((v >> 8) & 0xFFu) ? 0xFFFE0000u : 0xFFFF0000u);
+            o.y = (((v >> 16) & 0xFFu) ? 0xFFFEu : 0xFFFFu) | ((v >> 24) ? 0xFFFE0000u : 0xFFFF0000u);
+            d4[k] = o;
+        }
+        for (int k = (n_cells & ~3) + tid; k < n_cells; k += 256) dist[k] = c[k] ? (int16_t)-2 : (int16_t)-1;
+    } else {
+        for (int k = tid; k < n_cells; k += 256) dist[k] = c[k] ? (int16_t)-2 : (int16_t)-1;
+    }
+    if ((n_cells & 1) && tid == 0) dist[n_cells] = -2;                    // pad half of the last 32-bit word
     __syncthreads();
-    if (tid == 0) { dist[g_cell] = 0; queue[0] = (uint16_t)g_cell; tail_s = 1; reached = (s_cell == g_cell); }
+    if (tid == 0) {
+        dist[g_cell] = 0; queue[0] = (uint16_t)g_cell;
+        cnt[0] = 0; cnt[1] = 0; cnt[2] = 0;
+        reached = (s_cell == g_cell);
+    }
     __syncthreads();
+    uint32_t* words = (uint32_t*)dist;
+    const uint16_t* half = (const uint16_t*)dist;
     int lo = 0, hi = 1;
     for (int level = 1; level < 32767; ++level) {
         if (reached || lo == hi) break;
-        for (int f = lo + tid; f < hi; f += 256) {                       // phase A
-            int k = queue[f], j = k / Wc, i = k - j * Wc;
-            if (i + 1 < Wc && dist[k + 1] == -1) dist[k + 1] = (int16_t)level;
-            if (i > 0 && dist[k - 1] == -1) dist[k - 1] = (int16_t)level;
-            if (j + 1 < Hc && dist[k + Wc] == -1) dist[k + Wc] = (int16_t)level;
-            if (j > 0 && dist[k - Wc] == -1) dist[k - Wc] = (int16_t)level;
-        }
-        __syncthreads();
-        for (int f = lo + tid; f < hi; f += 256) {                       // phase B
-            int k = queue[f], j = k / Wc, i = k - j * Wc;
-            const int16_t prev = (int16_t)(level - 1);
-            // is k the first previous-level neighbour of m, looking from m in (+i, -i, +j, -j) order?
-            auto mine = [&](int m, int mi, int mj) {
-                if (dist[m] != (int16_t)level) return false;
-                int parent;
-                if (mi + 1 < Wc && dist[m + 1] == prev) parent = m + 1;
-                else if (mi > 0 && dist[m - 1] == prev) parent = m - 1;
-                else if (mj + 1 < Hc && dist[m + Wc] == prev) parent = m + Wc;
-                else parent = m - Wc;
-                return parent == k;
-            };
-            auto push = [&](int m) {
-                queue[atomicAdd(&tail_s, 1)] = (uint16_t)m;
-                if (m == s_cell) reached = 1;
-            };
-            if (i + 1 < Wc && mine(k + 1, i + 1, j)) push(k + 1);
-            if (i > 0 && mine(k - 1, i - 1, j)) push(k - 1);
-            if (j + 1 < Hc && mine(k + Wc, i, j + 1)) push(k + Wc);
-            if (j > 0 && mine(k - Wc, i, j - 1)) push(k - Wc);
+        const int slot = level % 3;
+        if (tid == 0) cnt[(level + 1) % 3] = 0;          // last read two barriers ago
+        // claim a neighbour for this level: one atomic AND turns an unreached half-word (0xFFFF) into
+        // `level` and leaves a half-word some other lane claimed in this level unchanged; the lane that
+        // saw 0xFFFF come back owns the cell.  Reached and blocked cells are filtered by the plain read.
+        // The four reads, then the four atomics, are issued together (independent LDS round trips).
+        for (int f = lo + tid; f < hi; f += 256) {
+            const int k = queue[f], j = k / Wc, i = k - j * Wc;
+            const int m[4] = {k + 1, k - 1, k + Wc, k - Wc};
+            const bool in[4] = {i + 1 < Wc, i > 0, j + 1 < Hc, j > 0};
+            bool want[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) want[d] = in[d] && half[in[d] ? m[d] : k] == 0xFFFFu;
+            uint32_t old[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {               // branch-free: a lane with nothing to claim ANDs all ones
+                const uint32_t sh = (uint32_t)(m[d] & 1) * 16u;
+                const uint32_t mask = want[d] ? (((uint32_t)level << sh) | (0xFFFFu << (16u - sh))) : 0xFFFFFFFFu;
+                old[d] = atomicAnd(&words[(want[d] ? m[d] : k) >> 1], mask);
+            }
+            // queue slots: one atomic per wavefront (ballot prefix), not one per lane or per cell
+            uint64_t won[4];
+            int total = 0;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                want[d] = want[d] && ((old[d] >> ((uint32_t)(m[d] & 1) * 16u)) & 0xFFFFu) == 0xFFFFu;
+                won[d] = __ballot(want[d]);
+                total += __popcll(won[d]);
+            }
+            if (total) {                                     // wave-uniform
+                const uint64_t below = (1ull << (tid & 63)) - 1ull;
+                int base = 0;
+                if ((__ballot(1) & below) == 0) base = atomicAdd(&cnt[slot], total);     // first active lane
+                base = hi + __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if (want[d]) {
+                        queue[base + __popcll(won[d] & below)] = (uint16_t)m[d];
+                        if (m[d] == s_cell) reached = 1;
+                    }
+                    base += __popcll(won[d]);
+                }
+            }
         }
         __syncthreads();
         lo = hi;
-        hi = tail_s;
+        hi += cnt[slot];
     }
+#ifdef NAVSIM_DIAG_NO_WALK
+    return;
+#endif
     if (tid != 0 || dist[s_cell] < 0) return;
     int n = 0, count = 0, ci = si, cj = sj;
     const double fx0 = ((double)si + 0.5) * res_c + ox, fy0 = ((double)sj + 0.5) * res_c + oy;
     double fx = fx0, fy = fy0;                           // env.py:1261-1277, cut while walking
+    const double i2_hi = interval * interval * (1.0 + 1.0e-12), i2_lo = interval * interval * (1.0 - 1.0e-12);
     for (;;) {
         ++n;
         const double cx = ((double)ci + 0.5) * res_c + ox, cy = ((double)cj + 0.5) * res_c + oy;
         const double dx = fx - cx, dy = fy - cy;
         const int k = cj * Wc + ci;
         const int dcur = dist[k];
-        const bool far = sqrt(dx * dx + dy * dy) > interval;
+        // sqrt(d2) > interval, decided on d2 unless it sits within 1e-12 of interval^2 (sqrt is monotone
+        // and correctly rounded, so the two tests agree outside that band)
+        const double d2 = dx * dx + dy * dy;
+        const bool far = (d2 > i2_hi) || (!(d2 < i2_lo) && sqrt(d2) > interval);
         if (far) {
             if (count < max_wp) { w[2 * count] = cx; w[2 * count + 1] = cy; }
             ++count; fx = cx; fy = cy;
@@ -1989,24 +2029,31 @@ __global__ __launch_bounds__(256) void regen_plan_kernel(navsim_config c, navsim
 // navsim_replan (env.py:667-680; oracle navsim_replan_cpu): ordered list of the pedestrians standing on
 // their final waypoint, then one workgroup per listed pedestrian: draw a goal, plan, up to 4 rounds.
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void replan_select_kernel(navsim_config c, navsim_state st, int cap,
-                                                             int* __restrict__ count, int* __restrict__ list) {
-    __shared__ int part[1024];
-    const int tid = threadIdx.x, N = c.max_peds, P = NAVSIM_MAX_WAYPOINTS;
-    const int total = c.n_envs * N;
-    const int per = (total + 1023) / 1024;
-    const int lo = tid * per, hi = (lo + per < total) ? lo + per : total;
-    auto due = [&](int q) {
-        int e = q / N, i = q - e * N;
-        if (i >= st.n_peds[e]) return false;
-        const double* pp = st.ped_pose + (size_t)q * 3;
-        const double* w = st.ped_waypoints + ((size_t)q * P) * 2;
+// one wavefront per arena: bit i of due[e] = pedestrian i stands within 0.5 m of its final waypoint
+__global__ __launch_bounds__(64) void replan_flag_kernel(navsim_config c, navsim_state st, uint64_t* __restrict__ due) {
+    const int e = blockIdx.x, i = threadIdx.x, N = c.max_peds, P = NAVSIM_MAX_WAYPOINTS;
+    bool flag = false;
+    if (i < N && i < st.n_peds[e]) {
+        const size_t q = (size_t)e * N + i;
+        const double* pp = st.ped_pose + q * 3;
+        const double* w = st.ped_waypoints + (q * P) * 2;
         int nw = st.ped_n_waypoints[q];
         double ddx = pp[0] - w[2 * (nw - 1)], ddy = pp[1] - w[2 * (nw - 1) + 1];
-        return sqrt(ddx * ddx + ddy * ddy) < 0.5;
-    };
+        flag = sqrt(ddx * ddx + ddy * ddy) < 0.5;
+    }
+    uint64_t m = __ballot(flag);
+    if (i == 0) due[e] = m;
+}
+
+// ordered compaction of the set bits, (arena, pedestrian) order, at most cap entries
+__global__ __launch_bounds__(1024) void replan_select_kernel(const uint64_t* __restrict__ due, int E, int N, int cap,
+                                                             int* __restrict__ count, int* __restrict__ list) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (E + 1023) / 1024;
+    const int lo = tid * per, hi = (lo + per < E) ? lo + per : E;
     int n = 0;
-    for (int q = lo; q < hi; ++q) n += due(q);
+    for (int e = lo; e < hi; ++e) n += __popcll(due[e]);
     part[tid] = n;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -2017,8 +2064,8 @@ __global__ __launch_bounds__(1024) void replan_select_kernel(navsim_config c, na
     }
     int pos = part[tid] - n;
     if (n)
-        for (int q = lo; q < hi && pos < cap; ++q)
-            if (due(q)) list[pos++] = q;
+        for (int e = lo; e < hi && pos < cap; ++e)
+            for (uint64_t m = due[e]; m && pos < cap; m &= m - 1) list[pos++] = e * N + (__ffsll((unsigned long long)m) - 1);
     if (tid == 1023) *count = part[1023] < cap ? part[1023] : cap;
 }
 
@@ -2707,7 +2754,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
 
 size_t navsim_replan_workspace_bytes(const navsim_config* c, int32_t max_queries) {
     if (!c || max_queries < 0) return 0;
-    return 256 + (size_t)max_queries * sizeof(int32_t);
+    return 256 + (((size_t)max_queries * sizeof(int32_t) + 255) & ~(size_t)255) + (size_t)c->n_envs * sizeof(uint64_t);
 }
 
 int navsim_replan(const navsim_config* c, const navsim_state* st, int32_t max_queries, void* workspace,
@@ -2724,7 +2771,9 @@ int navsim_replan(const navsim_config* c, const navsim_state* st, int32_t max_qu
     hipStream_t s = (hipStream_t)stream;
     int* count = (int*)workspace;
     int* list = (int*)((char*)workspace + 256);
-    replan_select_kernel<<<1, 1024, 0, s>>>(*c, *st, max_queries, count, list);
+    uint64_t* due = (uint64_t*)((char*)workspace + 256 + (((size_t)max_queries * sizeof(int32_t) + 255) & ~(size_t)255));
+    replan_flag_kernel<<<c->n_envs, 64, 0, s>>>(*c, *st, due);
+    replan_select_kernel<<<1, 1024, 0, s>>>(due, c->n_envs, c->max_peds, max_queries, count, list);
     replan_kernel<<<max_queries, 256, plan_lds(Hc, Wc), s>>>(*c, *st, count, list);
     return launch_status();
 }

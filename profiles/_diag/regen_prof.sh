@@ -1,7 +1,7 @@
 #!/bin/bash
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/regenprof -o rp -- python3 $R/profiles/regen_cost.py regen+plan > $R/gpurun_out/regenprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/regenprof -o rp -- python3 $R/profiles/regen_cost.py ${MODE:-regen+plan} > $R/gpurun_out/regenprof.log 2>&1
 cd $R
 python3 - <<PY
 import csv,glob
