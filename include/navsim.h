@@ -338,6 +338,38 @@ size_t navsim_replan_workspace_bytes(const navsim_config* cfg, int32_t max_queri
 int    navsim_replan(const navsim_config* cfg, const navsim_state* st, int32_t max_queries, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* ---- pedestrian control block (env.py:617-662) with the reference's HumanPolicy actor --------------
+ * Weights of human_policy.py:24-30 in torch's own layouts (state_dict order). */
+typedef struct navsim_policy_weights {
+    const float* cv1_w;   /* [32,3,5]    act_fea_cv1.weight (Conv1d 3->32, k5, s2, p1) */
+    const float* cv1_b;   /* [32] */
+    const float* cv2_w;   /* [32,32,3]   act_fea_cv2.weight (Conv1d 32->32, k3, s2, p1) */
+    const float* cv2_b;   /* [32] */
+    const float* fc1_w;   /* [256,4096]  act_fc1.weight */
+    const float* fc1_b;   /* [256] */
+    const float* fc2_w;   /* [128,260]   act_fc2.weight */
+    const float* fc2_b;   /* [128] */
+    const float* a1_w;    /* [128]       actor1.weight */
+    const float* a1_b;    /* [1] */
+    const float* a2_w;    /* [128]       actor2.weight */
+    const float* a2_b;    /* [1] */
+} navsim_policy_weights;
+
+/* For every live pedestrian: pop waypoints closer than 1 m (env.py:633-640), local goal in the body frame
+ * (env.py:644-645), network input = its latest scan clipped to [0, 6], / 6 - 0.5, the same in all three
+ * channels (env.py:629-630, 647), speed input = prev_actions; HumanPolicy actor forward
+ * (human_policy.py:43-52); prev_actions <- clip(mean, [0,-1], [1,1]) (env.py:655-658);
+ * ped_cmd <- prev_actions * v_pref (env.py:659-662), ready for navsim_step with NAVSIM_PED_EXTERNAL.
+ * ped_scans [E,N,512] float32 is the output of navsim_ped_scans on the current state (cfg.ped_n_beams must
+ * be 512); prev_actions [E,N,2] float32 in/out (zeros at reset, env.py:739); ped_cmd [E,N,2] float64 out.
+ * Arithmetic: every dot product is a float32 fused-multiply-add chain in index order
+ * starting from 0, bias added last -- what v_mfma_f32_32x32x2_f32 computes -- so device and oracle agree bit
+ * for bit; against torch's kernels the mean differs by ~1e-6. */
+size_t navsim_ped_policy_workspace_bytes(const navsim_config* cfg);
+int    navsim_ped_policy(const navsim_config* cfg, const navsim_state* st, const navsim_policy_weights* w,
+                         const float* ped_scans, float* prev_actions, double* ped_cmd, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* First observation after reset() (env.py:822-831): scan at the current robot pose, stack filled
  * with copies, prev_pose = pose, vel = 0; sets prev_pose/prev_action/n_hist.  `mask` [E] uint8 or
  * NULL selects which envs are (re)initialised; others keep obs_prev -> obs copied through. */

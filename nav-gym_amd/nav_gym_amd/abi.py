@@ -112,6 +112,21 @@ class NavsimState(C.Structure):
     )]
 
 
+POLICY_FIELDS = ("cv1_w", "cv1_b", "cv2_w", "cv2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "a1_w", "a1_b", "a2_w", "a2_b")
+POLICY_SHAPES = {"cv1_w": (32, 3, 5), "cv1_b": (32,), "cv2_w": (32, 32, 3), "cv2_b": (32,), "fc1_w": (256, 4096),
+                 "fc1_b": (256,), "fc2_w": (128, 260), "fc2_b": (128,), "a1_w": (128,), "a1_b": (1,), "a2_w": (128,),
+                 "a2_b": (1,)}
+# reference state_dict names (human_policy.py:24-30) -> fields of navsim_policy_weights
+POLICY_STATE_DICT = {"act_fea_cv1.weight": "cv1_w", "act_fea_cv1.bias": "cv1_b", "act_fea_cv2.weight": "cv2_w",
+                     "act_fea_cv2.bias": "cv2_b", "act_fc1.weight": "fc1_w", "act_fc1.bias": "fc1_b",
+                     "act_fc2.weight": "fc2_w", "act_fc2.bias": "fc2_b", "actor1.weight": "a1_w", "actor1.bias": "a1_b",
+                     "actor2.weight": "a2_w", "actor2.bias": "a2_b"}
+
+
+class NavsimPolicyWeights(C.Structure):
+    _fields_ = [(name, _P) for name in POLICY_FIELDS]
+
+
 class NavsimStepIO(C.Structure):
     _fields_ = [(name, _P) for name in (
         "action", "obs_prev", "obs", "achieved_goal", "desired_goal",
@@ -214,7 +229,10 @@ def declare(lib, suffix=""):
     if suffix:
         sig("navsim_regen", [cfgp, stp, iop])
         sig("navsim_replan", [cfgp, stp, i32])
+        sig("navsim_ped_policy", [cfgp, stp, C.POINTER(NavsimPolicyWeights), _P, _P, _P])
     else:
+        sig("navsim_ped_policy_workspace_bytes", [cfgp], C.c_size_t)
+        sig("navsim_ped_policy", [cfgp, stp, C.POINTER(NavsimPolicyWeights), _P, _P, _P, _P, C.c_size_t, _P])
         sig("navsim_replan_workspace_bytes", [cfgp, i32], C.c_size_t)
         sig("navsim_replan", [cfgp, stp, i32, _P, C.c_size_t, _P])
         sig("navsim_costmap", [_P, i32, i32, i32, _P, _P])
@@ -235,7 +253,7 @@ EXPORTS = (
     "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
     "navsim_scan_threshold", "navsim_beam_table", "navsim_step_workspace_bytes", "navsim_ped_scans", "navsim_regen_workspace_bytes", "navsim_regen",
-    "navsim_costmap", "navsim_plan_workspace_bytes", "navsim_plan", "navsim_replan_workspace_bytes", "navsim_replan",
+    "navsim_costmap", "navsim_plan_workspace_bytes", "navsim_plan", "navsim_replan_workspace_bytes", "navsim_replan", "navsim_ped_policy_workspace_bytes", "navsim_ped_policy",
     "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math",
 )

@@ -1138,6 +1138,122 @@ static void regen_planned(const navsim_config* c, const navsim_state* st, int e,
     free(cost);
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * Pedestrian control block with the HumanPolicy actor (env.py:617-662, human_policy.py:19-52).
+ * Specification shared with the HIP kernels: float32, every dot product is the fused-multiply-add
+ * chain acc = fmaf(w_k, x_k, acc) in the index order written below starting from acc = 0, the bias is
+ * added after the chain, ReLU is max(.,0); sigmoid / tanh are evaluated in float64 on the deterministic
+ * exp and rounded once.  fmaf() is exact (one rounding) with or without hardware FMA.
+ * ------------------------------------------------------------------------------------------- */
+static float policy_sigmoid(float x) {
+    double xd = (double)x;
+    if (xd >= 0.0) return (float)(1.0 / (1.0 + nvr_exp_neg(-xd)));
+    double e = nvr_exp_neg(xd);
+    return (float)(e / (1.0 + e));
+}
+static float policy_tanh(float x) {
+    double a = fabs((double)x);
+    double e = nvr_exp_neg(-2.0 * a);
+    double t = (1.0 - e) / (1.0 + e);
+    return (float)(x < 0.0f ? -t : t);
+}
+
+static void policy_actor(const navsim_policy_weights* w, const float x[512], const float goal[2], const float speed[2],
+                         float mean[2]) {
+    static __thread float o1[32][256], feat[4096], h1[260], h2[128];
+    /* conv1: 3 identical channels (env.py:647), k = 5, stride 2, zero padding 1 -> 255 outputs */
+    for (int o = 0; o < 32; ++o)
+        for (int t = 0; t < 255; ++t) {
+            float acc = 0.0f;
+            for (int ch = 0; ch < 3; ++ch)
+                for (int k = 0; k < 5; ++k) {
+                    int idx = 2 * t + k - 1;
+                    float xv = (idx >= 0 && idx < 512) ? x[idx] : 0.0f;
+                    acc = fmaf(w->cv1_w[(o * 3 + ch) * 5 + k], xv, acc);
+                }
+            acc = acc + w->cv1_b[o];
+            o1[o][t] = acc > 0.0f ? acc : 0.0f;
+        }
+    /* conv2: k = 3, stride 2, zero padding 1 -> 128 outputs; flatten channel-major */
+    for (int o = 0; o < 32; ++o)
+        for (int t = 0; t < 128; ++t) {
+            float acc = 0.0f;
+            for (int ch = 0; ch < 32; ++ch)
+                for (int k = 0; k < 3; ++k) {
+                    int idx = 2 * t + k - 1;
+                    float xv = (idx >= 0 && idx < 255) ? o1[ch][idx] : 0.0f;
+                    acc = fmaf(w->cv2_w[(o * 32 + ch) * 3 + k], xv, acc);
+                }
+            acc = acc + w->cv2_b[o];
+            feat[o * 128 + t] = acc > 0.0f ? acc : 0.0f;
+        }
+    for (int j = 0; j < 256; ++j) {
+        const float* wr = w->fc1_w + (size_t)j * 4096;
+        float acc = 0.0f;
+        for (int k = 0; k < 4096; ++k) acc = fmaf(feat[k], wr[k], acc);       /* MFMA order: A = features */
+        acc = acc + w->fc1_b[j];
+        h1[j] = acc > 0.0f ? acc : 0.0f;
+    }
+    h1[256] = goal[0]; h1[257] = goal[1]; h1[258] = speed[0]; h1[259] = speed[1];
+    for (int j = 0; j < 128; ++j) {
+        const float* wr = w->fc2_w + (size_t)j * 260;
+        float acc = 0.0f;
+        for (int k = 0; k < 260; ++k) acc = fmaf(wr[k], h1[k], acc);
+        acc = acc + w->fc2_b[j];
+        h2[j] = acc > 0.0f ? acc : 0.0f;
+    }
+    float a1 = 0.0f, a2 = 0.0f;
+    for (int k = 0; k < 128; ++k) { a1 = fmaf(w->a1_w[k], h2[k], a1); a2 = fmaf(w->a2_w[k], h2[k], a2); }
+    mean[0] = policy_sigmoid(a1 + w->a1_b[0]);
+    mean[1] = policy_tanh(a2 + w->a2_b[0]);
+}
+
+int navsim_ped_policy_cpu(const navsim_config* c, const navsim_state* st, const navsim_policy_weights* w,
+                          const float* ped_scans, float* prev_actions, double* ped_cmd) {
+    if (!c || !st || !w || !ped_scans || !prev_actions || !ped_cmd || !st->ped_pose || !st->ped_waypoints ||
+        !st->ped_n_waypoints || !st->ped_v_pref || !st->n_peds)
+        return NAVSIM_E_ARG;
+    if (c->ped_n_beams != 512) return NAVSIM_E_UNSUPPORTED;
+    const int N = c->max_peds, P = NAVSIM_MAX_WAYPOINTS;
+    for (int e = 0; e < c->n_envs; ++e) {
+        int n = st->n_peds[e] > N ? N : st->n_peds[e];
+        for (int i = 0; i < N; ++i) {
+            size_t q = (size_t)e * N + i;
+            if (i >= n) { ped_cmd[2 * q] = 0.0; ped_cmd[2 * q + 1] = 0.0; continue; }
+            const double* pp = st->ped_pose + q * 3;
+            double* wp = st->ped_waypoints + (q * P) * 2;
+            int nw = st->ped_n_waypoints[q];
+            while (nw > 1) {                                                  /* env.py:633-640 */
+                double ddx = pp[0] - wp[0], ddy = pp[1] - wp[1];
+                if (sqrt(ddx * ddx + ddy * ddy) < 1.0) {
+                    for (int k = 0; k + 1 < nw; ++k) { wp[2 * k] = wp[2 * k + 2]; wp[2 * k + 1] = wp[2 * k + 3]; }
+                    nw -= 1;
+                } else break;
+            }
+            st->ped_n_waypoints[q] = nw;
+            double s, cs;
+            nvr_sincos(pp[2], &s, &cs);                                       /* env.py:644-645 */
+            double gx = wp[0] - pp[0], gy = wp[1] - pp[1];
+            float goal[2] = {(float)(gx * cs + gy * s), (float)(-gx * s + gy * cs)};
+            float x[512];
+            const float* scan = ped_scans + q * 512;
+            for (int k = 0; k < 512; ++k) {                                   /* env.py:629-630 */
+                double v = (double)scan[k];
+                v = v < 0.0 ? 0.0 : (v > 6.0 ? 6.0 : v);
+                x[k] = (float)(v / 6.0 - 0.5);
+            }
+            float speed[2] = {prev_actions[2 * q], prev_actions[2 * q + 1]}, mean[2];
+            policy_actor(w, x, goal, speed, mean);
+            mean[0] = mean[0] < 0.0f ? 0.0f : (mean[0] > 1.0f ? 1.0f : mean[0]);     /* env.py:656-657 */
+            mean[1] = mean[1] < -1.0f ? -1.0f : (mean[1] > 1.0f ? 1.0f : mean[1]);
+            prev_actions[2 * q] = mean[0]; prev_actions[2 * q + 1] = mean[1];
+            ped_cmd[2 * q] = (double)mean[0] * st->ped_v_pref[q];              /* env.py:659-662 */
+            ped_cmd[2 * q + 1] = (double)mean[1] * st->ped_v_pref[q];
+        }
+    }
+    return NAVSIM_OK;
+}
+
 /* env.py:667-680 (see include/navsim.h navsim_replan) */
 int navsim_replan_cpu(const navsim_config* c, const navsim_state* st, int32_t max_queries) {
     if (!c || !st || !st->costmap || !st->ped_pose || !st->ped_waypoints || !st->ped_n_waypoints || !st->n_peds ||

@@ -67,6 +67,8 @@ int navsim_scan_threshold_cpu(const navsim_config* cfg, const float* footprint, 
 int navsim_ped_scans_cpu(const navsim_config* cfg, const navsim_state* st, float* out);
 
 int navsim_regen_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io);
+int navsim_ped_policy_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_policy_weights* w,
+                          const float* ped_scans, float* prev_actions, double* ped_cmd);
 int navsim_replan_cpu(const navsim_config* cfg, const navsim_state* st, int32_t max_queries);
 
 /* costmap (env.py:312-332), shortest 4-connected path (env.py:343-354) and path_to_waypoints

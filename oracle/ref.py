@@ -288,6 +288,20 @@ class RefSim(object):
         _chk(lib().navsim_regen_cpu(C.byref(self.cfg), C.byref(self.st), C.byref(io)), "regen")
         return self.obs[self.cur]
 
+    def ped_policy(self, weights, scans=None):
+        """navsim_ped_policy_cpu: HumanPolicy control block -> fills ped_cmd, returns (cmd, clip(mean)).
+        weights: dict of float32 arrays named like abi.POLICY_FIELDS."""
+        if not hasattr(self, "prev_actions"):
+            self.prev_actions = np.zeros((self.cfg.n_envs, self.cfg.max_peds, 2), np.float32)
+        scans = self.ped_scans() if scans is None else np.ascontiguousarray(scans, dtype=np.float32)
+        self._pw = {k: np.ascontiguousarray(weights[k], dtype=np.float32).reshape(abi.POLICY_SHAPES[k]) for k in abi.POLICY_FIELDS}
+        w = abi.NavsimPolicyWeights()
+        for k, v in self._pw.items():
+            setattr(w, k, v.ctypes.data)
+        _chk(lib().navsim_ped_policy_cpu(C.byref(self.cfg), C.byref(self.st), C.byref(w), _p(scans), _p(self.prev_actions),
+                                         _p(self.a["ped_cmd"])), "ped_policy")
+        return self.a["ped_cmd"], self.prev_actions
+
     def replan(self, max_queries=1024):
         _chk(lib().navsim_replan_cpu(C.byref(self.cfg), C.byref(self.st), max_queries), "replan")
 

@@ -434,6 +434,15 @@ def run_trace(name, ref_env, human, human_policy, S, seed, scenario, n_steps, pe
     )
     for k, v in snapshot(env).items():
         rec["init_" + k] = v
+    # what the pedestrian control block (env.py:617-662) reads besides the scans: the waypoint lists and
+    # the seed the stand-in HumanPolicy weights were drawn with (torch.manual_seed(seed) + default init)
+    wmax = max(len(h.waypoints) for h in env.humans)
+    wps = np.zeros((len(env.humans), wmax, 2))
+    for i, h in enumerate(env.humans):
+        wps[i, :len(h.waypoints)] = np.asarray(h.waypoints)
+    rec["init_ped_waypoints"] = wps
+    rec["init_ped_n_waypoints"] = np.array([len(h.waypoints) for h in env.humans], np.int32)
+    rec["policy_seed"] = np.array(seed)
     # record the (v, w) the reference hands to Human.set_vel (env.py:662)
     cmds = []
     orig = human.Human.set_vel
@@ -446,6 +455,7 @@ def run_trace(name, ref_env, human, human_policy, S, seed, scenario, n_steps, pe
     N = len(env.humans)
     acts = np.zeros((T, 2)); obs = np.zeros((T, S * B + 7)); rew = np.zeros(T); done = np.zeros(T, np.uint8)
     succ = np.zeros(T, np.float32); crash = np.zeros(T, np.float32); dist = np.zeros(T)
+    ped_mean = np.zeros((T, N, 2), np.float32)
     ped_cmd = np.zeros((T, N, 2)); snaps = {k: [] for k in ("robot_pose", "ped_pose", "ped_vel", "ped_dist")}
     # pedestrian scans (env.py:685-693, the input of HumanPolicy): latest 512-beam scan of every
     # pedestrian on a few steps (kept small; steps with a crash are skipped because those scans saw
@@ -464,6 +474,7 @@ def run_trace(name, ref_env, human, human_policy, S, seed, scenario, n_steps, pe
             acts[t] = a; obs[t] = o["observation"]; rew[t] = r; done[t] = d
             succ[t] = info["is_success"]; crash[t] = info["is_crash"]; dist[t] = info["distance"]
             ped_cmd[t] = np.array(cmds).reshape(N, 2)
+            ped_mean[t] = env.prev_human_actions                   # clip(mean) of HumanPolicy (env.py:655-658)
             if ped_scan_every and t % ped_scan_every == 0 and not info["is_crash"]:
                 ped_scan_steps.append(t)
                 ped_scans.append(np.stack([env.prev_humans_obs_queue[i][-1]["observation"][2 * 512:3 * 512]
@@ -473,7 +484,8 @@ def run_trace(name, ref_env, human, human_policy, S, seed, scenario, n_steps, pe
     finally:
         human.Human.set_vel = orig
     rec.update(actions=acts, obs_scan=obs[:, : S * B].astype(np.float32), obs_tail=obs[:, S * B:],
-               reward=rew, done=done, is_success=succ, is_crash=crash, distance=dist, ped_cmd=ped_cmd)
+               reward=rew, done=done, is_success=succ, is_crash=crash, distance=dist, ped_cmd=ped_cmd,
+               ped_mean=ped_mean)
     assert np.array_equal(rec["obs_scan"].astype(np.float64), obs[:, : S * B])   # scans are float32 values
     for k, v in snaps.items():
         rec["traj_" + k] = np.stack(v)

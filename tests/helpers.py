@@ -84,3 +84,22 @@ def finished_world(cfg, occ, field, n_peds, thresholds):
         ped_n_waypoints=np.ones((E, N), np.int32), ped_cmd=np.zeros((E, N, 2)),
         spawn_pose=np.tile(pose[:, None, :], (1, K, 1)), spawn_goal=np.tile(pose[:, None, :2], (1, K, 1)),
     )
+
+
+def policy_weights(seed):
+    """The actor weights of the stand-in HumanPolicy the golden traces were recorded with:
+    tests/golden/make_golden.py seeds torch and takes the default initialisation of the reference's
+    module (human_policy.py:19-37).  The actor's layers are created first, in this order, so the same
+    seed and the same layer shapes reproduce them without importing the reference."""
+    import torch
+    torch.manual_seed(int(seed))
+    cv1 = torch.nn.Conv1d(3, 32, kernel_size=5, stride=2, padding=1)
+    cv2 = torch.nn.Conv1d(32, 32, kernel_size=3, stride=2, padding=1)
+    fc1 = torch.nn.Linear(128 * 32, 256)
+    fc2 = torch.nn.Linear(256 + 2 + 2, 128)
+    a1 = torch.nn.Linear(128, 1)
+    a2 = torch.nn.Linear(128, 1)
+    f = lambda t: t.detach().numpy().astype(np.float32).copy()
+    return dict(cv1_w=f(cv1.weight), cv1_b=f(cv1.bias), cv2_w=f(cv2.weight), cv2_b=f(cv2.bias),
+                fc1_w=f(fc1.weight), fc1_b=f(fc1.bias), fc2_w=f(fc2.weight), fc2_b=f(fc2.bias),
+                a1_w=f(a1.weight).reshape(-1), a1_b=f(a1.bias), a2_w=f(a2.weight).reshape(-1), a2_b=f(a2.bias))

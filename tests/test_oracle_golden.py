@@ -10,6 +10,7 @@ import pytest
 
 import ref
 from helpers import load_trace, trace_setup
+from nav_gym_amd import abi
 
 
 @pytest.fixture(scope="module")
@@ -159,3 +160,45 @@ def test_path_to_waypoints(units):
     # SURVEY.md 8a row a16 [PROBE]: straight path at 0.25 m spacing, interval 2 -> first waypoint x = 2.25
     straight = np.stack([np.arange(0, 10, 0.25), np.zeros(40)], 1)
     assert ref.path_to_waypoints(straight, 2)[0, 0] == 2.25
+
+
+@pytest.mark.parametrize("name", ["random_S1", "peds_S1", "crash_S3", "success_S2"])
+def test_policy_control_block_vs_reference_trace(name):
+    """Row a10 (env.py:617-662 + human_policy.py:19-52): with the weights the traces were recorded with,
+    the oracle's control block -- pedestrian scan -> clip / scale -> actor network -> clip -> * v_pref,
+    local goal from the waypoint list -- reproduces the (v, omega) the reference handed to
+    Human.set_vel and its prev_human_actions at every step, within 1e-5 (float32 network, different
+    summation order than torch's kernels)."""
+    from helpers import policy_weights
+    tr = load_trace(name)
+    cfg, arrays, occ = trace_setup(tr, ref.default_config, ref.build_dt)
+    N = tr["init_ped_pose"].shape[0]
+    nw = tr["init_ped_n_waypoints"]
+    assert nw.max() <= abi.MAX_WAYPOINTS
+    wp = np.zeros((1, N, abi.MAX_WAYPOINTS, 2))
+    wp[0, :, :tr["init_ped_waypoints"].shape[1]] = tr["init_ped_waypoints"]
+    arrays["ped_waypoints"] = wp
+    arrays["ped_n_waypoints"] = nw[None].astype(np.int32)
+    w = policy_weights(int(tr["policy_seed"]))
+    r = ref.RefSim(cfg, arrays)
+    r.reset_obs()
+    T = tr["actions"].shape[0]
+    checked = 0
+    worst = 0.0
+    replanned = np.zeros(N, bool)     # the reference drew this pedestrian a new random path (env.py:667-680):
+    for t in range(T):                # its waypoints are no longer the recorded initial ones
+        if t > 0:                                        # the speed input is the reference's own previous output
+            r.prev_actions[0] = tr["ped_mean"][t - 1]
+        cmd, mean = r.ped_policy(w)
+        if t == 0 or not tr["is_crash"][t - 1]:          # after a crash the reference's pedestrians saw the
+            ok = ~replanned                              # robot at its pre-revert pose (env.py:685-723)
+            worst = max(worst, np.abs(cmd[0][ok] - tr["ped_cmd"][t][ok]).max(),
+                        np.abs(mean[0][ok] - tr["ped_mean"][t][ok]).max())
+            checked += int(ok.sum())
+        r.set_ped_cmd(tr["ped_cmd"][t][None])
+        r.step(tr["actions"][t][None])
+        n_now = r.a["ped_n_waypoints"][0]
+        last = r.a["ped_waypoints"][0, np.arange(N), n_now - 1]
+        replanned |= np.linalg.norm(r.a["ped_pose"][0, :, :2] - last, axis=1) < 0.5
+    assert checked >= 30 and worst < 1e-5, (checked, worst)
+    assert replanned.sum() <= 1
