@@ -297,6 +297,34 @@ class NavSim(object):
         check(self.lib.navsim_replan(C.byref(self.cfg), C.byref(self.st), max_queries, _ptr(ws), ws.numel(), _stream()),
               "navsim_replan")
 
+    def set_policy(self, weights):
+        """HumanPolicy actor weights: dict of arrays / tensors named like abi.POLICY_FIELDS, or a reference
+        state_dict (human_policy.py names, e.g. torch.load('human_policy.pth'))."""
+        import torch
+        named = {abi.POLICY_STATE_DICT.get(k, k): v for k, v in weights.items()}
+        self.policy_t = {}
+        self.policy_w = abi.NavsimPolicyWeights()
+        for k in abi.POLICY_FIELDS:
+            t = torch.as_tensor(named[k]).detach().to(device=self.device, dtype=torch.float32).reshape(abi.POLICY_SHAPES[k]).contiguous()
+            self.policy_t[k] = t
+            setattr(self.policy_w, k, t.data_ptr())
+        nbytes = self.lib.navsim_ped_policy_workspace_bytes(C.byref(self.cfg))
+        self.t["policy_ws"] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        if "policy_prev_actions" not in self.t:
+            self.t["policy_prev_actions"] = torch.zeros((self.cfg.n_envs, self.cfg.max_peds, 2), dtype=torch.float32,
+                                                        device=self.device)
+
+    def ped_policy(self, scans=None):
+        """navsim_ped_policy (env.py:617-662): pedestrian scans -> HumanPolicy actor -> ped_cmd for a
+        NAVSIM_PED_EXTERNAL step.  Returns (ped_cmd [E,N,2] float64, clip(mean) [E,N,2] float32)."""
+        if scans is None:
+            scans = self.ped_scans()
+        ws = self.t["policy_ws"]
+        check(self.lib.navsim_ped_policy(C.byref(self.cfg), C.byref(self.st), C.byref(self.policy_w), _ptr(scans),
+                                         _ptr(self.t["policy_prev_actions"]), _ptr(self.t["ped_cmd"]), _ptr(ws),
+                                         ws.numel(), _stream()), "navsim_ped_policy")
+        return self.t["ped_cmd"], self.t["policy_prev_actions"]
+
     def ped_scans(self):
         """Scan of every pedestrian (env.py:685-693) from the current state -> float32 [E, N, 512]."""
         import torch

@@ -205,9 +205,11 @@ def test_step_golden_traces(gpu, name):
         np.testing.assert_allclose(stt["ped_dist"][0], tr["traj_ped_dist"][t], rtol=0, atol=1e-10)
 
 
-def _rollout_pair(gpu, cfg, occ, n_peds, steps, seed, noise=False, **world_kw):
-    """Runs the same world through the HIP step and the oracle; yields per-step comparisons."""
+def _rollout_pair(gpu, cfg, occ, n_peds, steps, seed, noise=False, policy=None, **world_kw):
+    """Runs the same world through the HIP step and the oracle; yields per-step comparisons.
+    policy: HumanPolicy weights -> pedestrians are driven by navsim_ped_policy on both sides."""
     torch = gpu.torch
+    world_kw_policy = policy
     arrays = gpu.world.make_world(cfg, occ, n_peds=n_peds, device=gpu.dev, **world_kw)
     key = "keti"
     from nav_gym_amd import robots
@@ -218,13 +220,18 @@ def _rollout_pair(gpu, cfg, occ, n_peds, steps, seed, noise=False, **world_kw):
     g = gpu.sim.NavSim(cfg, arrays)
     r = ref.RefSim(cfg, host)
     _eq(g.reset_obs().cpu().numpy(), r.reset_obs(), "reset obs")
+    policy = world_kw_policy
     rng = np.random.default_rng(seed)
     E = cfg.n_envs
     for t in range(steps):
         act = np.stack([rng.uniform(0.0, 0.5, E), rng.uniform(-0.64, 0.64, E)], axis=1)
         if t % 7 == 3:
             act[:, 0] = 0.5; act[:, 1] = 0.0          # bursts of straight driving provoke crashes
-        if cfg.ped_model == abi.PED_EXTERNAL:
+        if policy is not None:
+            if t == 0:
+                g.set_policy(policy)
+            g.ped_policy(); r.ped_policy(policy)
+        elif cfg.ped_model == abi.PED_EXTERNAL:
             cmd = np.stack([rng.uniform(0, 0.6, (E, cfg.max_peds)), rng.uniform(-0.6, 0.6, (E, cfg.max_peds))], axis=2)
             g.set_ped_cmd(cmd); r.set_ped_cmd(cmd)
         go, gout = g.step(torch.from_numpy(act).to(gpu.dev))
@@ -374,6 +381,72 @@ def test_replan_vs_oracle(gpu, fmt):
         prev_n = n_now
     _eq(gs["costmap"], r.a["costmap"], "costmap")
     assert replans >= 5, replans
+
+
+def _policy_weights_random(seed):
+    rng = np.random.default_rng(seed)
+    fan = {"cv1": 15, "cv2": 96, "fc1": 4096, "fc2": 260, "a1": 128, "a2": 128}
+    w = {}
+    for k, shape in abi.POLICY_SHAPES.items():
+        b = 1.0 / np.sqrt(fan[k.split("_")[0]])
+        w[k] = rng.uniform(-b, b, shape).astype(np.float32)
+    return w
+
+
+@pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T])
+def test_policy_closed_loop_vs_oracle(gpu, fmt):
+    """Row a10 on the device: pedestrian scans -> HumanPolicy actor (convolutions on the vector units, the
+    4096 -> 256 layer on v_mfma_f32_32x32x2_f32) -> (v, omega) -> Human.set_vel, in closed loop for 17
+    pedestrians per arena.  The float32 network is specified as fused-multiply-add chains in index order,
+    which is what the MFMA computes, so commands, network outputs, observations and all state stay
+    bit-identical to the oracle step after step."""
+    E, size, N = 10, 240, 20
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_EXTERNAL, n_spawn=8,
+                                 auto_reset=1, seed=41, field_format=fmt)
+    gpu.world.lidar_1081(cfg)
+    occ = gpu.world.make_maps(E, size, 41)
+    w = _policy_weights_random(7)
+    first = True
+    rollout = _rollout_pair(gpu, cfg, occ, n_peds=17, steps=8, seed=9, policy=w)
+    for t, go, gout, ro, rout, g, r in rollout:
+        _eq(go, ro, "obs at step %d" % t)
+        _eq(g.t["policy_prev_actions"].cpu().numpy(), r.prev_actions, "network output at step %d" % t)
+        _eq(g.t["ped_cmd"].cpu().numpy(), r.a["ped_cmd"], "pedestrian commands at step %d" % t)
+        if t % 4 == 3:
+            gs = g.numpy_state()
+            for k, v in r.a.items():
+                if k in gs and k not in ("field", "field_overflow"):
+                    _eq(gs[k], v, "state %s at step %d" % (k, t))
+    m = r.prev_actions[:, :17]
+    assert (m[..., 0] > 0).all() and (m[..., 0] < 1).all() and np.abs(m[..., 1]).max() < 1 and m.std() > 1e-3
+
+
+@pytest.mark.parametrize("name", ["random_S1", "peds_S1"])
+def test_policy_vs_reference_trace(gpu, name):
+    """The same control block against the reference's own step(): with the weights the golden traces were
+    recorded with, the device reproduces the (v, omega) the reference handed to Human.set_vel (1e-5)."""
+    from helpers import policy_weights
+    tr = load_trace(name)
+    cfg, arrays, occ = trace_setup(tr, gpu.lib.default_config, lambda o: gpu.sim.build_dt(_t(gpu, o)).cpu().numpy())
+    N = tr["init_ped_pose"].shape[0]
+    wp = np.zeros((1, N, abi.MAX_WAYPOINTS, 2)); wp[0, :, :tr["init_ped_waypoints"].shape[1]] = tr["init_ped_waypoints"]
+    arrays["ped_waypoints"] = wp
+    arrays["ped_n_waypoints"] = tr["init_ped_n_waypoints"][None].astype(np.int32)
+    g = gpu.sim.NavSim(cfg, arrays)
+    g.reset_obs()
+    g.set_policy(policy_weights(int(tr["policy_seed"])))
+    worst, checked = 0.0, 0
+    for t in range(10):                                   # no crash and no re-plan in the first steps of these traces
+        if t > 0:
+            g.t["policy_prev_actions"][0] = _t(gpu, tr["ped_mean"][t - 1])
+        cmd, mean = g.ped_policy()
+        ok = np.ones(N, bool) if name == "random_S1" or t == 0 else np.arange(N) > 0   # peds_S1: pedestrian 0 re-plans
+        worst = max(worst, np.abs(cmd[0].cpu().numpy()[ok] - tr["ped_cmd"][t][ok]).max(),
+                    np.abs(mean[0].cpu().numpy()[ok] - tr["ped_mean"][t][ok]).max())
+        checked += int(ok.sum())
+        g.set_ped_cmd(_t(gpu, tr["ped_cmd"][t][None]))
+        g.step(_t(gpu, tr["actions"][t][None]))
+    assert checked > 50 and worst < 1e-5, (checked, worst)
 
 
 def test_config1_single_env_64_beams(gpu):
