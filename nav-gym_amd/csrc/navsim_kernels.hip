@@ -165,6 +165,16 @@ struct FieldF32S {
     __device__ __forceinline__ float at(int px, int py) const { return ovf[(size_t)py * W + px]; }
 };
 
+// How far a ray has to be marched.  The reference marches up to H*W cells (env.py:337) and clips the
+// result to range_max afterwards (env.py:434).  A hit found at parameter t lies at least t - sqrt(2) cells
+// from the origin, so once t exceeds range_max / resolution + 4 every possible outcome -- a later hit,
+// leaving the map, or the H*W limit -- clips to range_max: stopping there returns the same scan.
+__device__ __forceinline__ float march_limit(int H, int W, double range_max, double resolution) {
+    const float full = (float)((long long)H * W);
+    const float lim = (float)(floor(range_max / resolution) + 4.0);
+    return lim < full ? lim : full;
+}
+
 // FORMAT 0: float32 row-major to `field`; 1: uint16 tiles to `field` (+ float32 to `overflow` if
 // given, + saturation count)
 template <int FORMAT>
@@ -528,7 +538,7 @@ __device__ __forceinline__ void scan_beams(const navsim_config& c, const StepSha
                                            uint64_t noise_key, uint64_t genv,
                                            int& crash, int& discomfort) {
     const int B = c.n_beams, S = c.n_scan_stack, H = c.map_h, W = c.map_w;
-    const float max_range = (float)((long long)H * W);       // env.py:337
+    const float max_range = march_limit(H, W, c.range_max, c.resolution);
     const float res = (float)c.resolution;
     const float rmax = (float)c.range_max;
     const double step = nv::linspace_step(c);
@@ -904,7 +914,7 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const St
                                                 uint64_t noise_key, uint64_t genv,
                                                 int& crash, int& discomfort) {
     const int B = c.n_beams, S = c.n_scan_stack, H = c.map_h, W = c.map_w;
-    const float max_range = (float)((long long)H * W);       // env.py:337
+    const float max_range = march_limit(H, W, c.range_max, c.resolution);
     const float res = (float)c.resolution;
     const float rmax = (float)c.range_max;
     const double step = nv::linspace_step(c);
@@ -982,7 +992,7 @@ __device__ __forceinline__ void scan_beams_dyn(const navsim_config& c, StepShare
                                                uint64_t noise_key, uint64_t genv,
                                                int& crash, int& discomfort) {
     const int B = c.n_beams, H = c.map_h, W = c.map_w;
-    const float max_range = (float)((long long)H * W);       // env.py:337
+    const float max_range = march_limit(H, W, c.range_max, c.resolution);
     const double step = nv::linspace_step(c);
     const float x0 = (float)sh.i0, y0 = (float)sh.j0;
     const int tid = (int)threadIdx.x;
@@ -1080,7 +1090,7 @@ void pool_scan_kernel(navsim_config c, navsim_state st, char* __restrict__ ws_en
     const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, c.map_h, c.map_w);
     float dx, dy;
     beam_dir_k(c, st.beam_table, k, nv::linspace_step(c), (double)s->lth, s->cT, s->sT, dx, dy);
-    const float max_range = (float)((long long)c.map_h * c.map_w);
+    const float max_range = march_limit(c.map_h, c.map_w, c.range_max, c.resolution);
     ranges[(size_t)e * B + k] = march_ray(field, (float)s->i0, (float)s->j0, dx, dy, s->t1, max_range,
                                           (unsigned)c.map_w, (unsigned)c.map_h);
 }
@@ -2148,7 +2158,8 @@ __global__ __launch_bounds__(256) void policy_features_kernel(const float* __res
     }
     __syncthreads();
     {                                                           // conv2: thread = (position, half of the channels)
-        const int t = tid & 127, og = (tid >> 7) * 16;
+        const int t = tid & 127;
+        const int og = __builtin_amdgcn_readfirstlane((tid >> 7) * 16);   // wave-uniform: weights come by s_load
         float acc[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
@@ -2376,7 +2387,7 @@ __global__ __launch_bounds__(256) void ped_scan_kernel(navsim_config c, navsim_s
         }
     }
     const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, H, W);
-    const float max_range = (float)((long long)H * W);
+    const float max_range = march_limit(H, W, c.ped_range_max, c.resolution);
     const float res = (float)c.resolution, rmax = (float)c.ped_range_max;
     const double step = (PB > 1) ? (c.ped_angle_last - c.ped_angle_min) / (double)(PB - 1) : 0.0;
     const float x0 = (float)i0_s, y0 = (float)j0_s;
