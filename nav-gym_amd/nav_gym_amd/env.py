@@ -15,7 +15,9 @@ and default to the reference's behaviour for num_envs == 1:
                     randomize_maps new starts / goals are sampled on the costmap and kept only when the
                     planner joins them (env.py:342-383, 756-762).  False: straight-line goals.
                     Maps above 1000 cells per side fall back to False (the search lives in LDS).
-    pedestrian_model 'sfm' (build-defined social force), 'external' (caller supplies (v, w) per
+    pedestrian_model 'policy' (the reference's HumanPolicy actor on the device, env.py:617-662; needs
+                    policy_weights = the state_dict of human_policy.pth, a path to it, or a dict of arrays),
+                    'sfm' (build-defined social force), 'external' (caller supplies (v, w) per
                     pedestrian -- the slot the reference fills with HumanPolicy) or 'none'
     device, seed, env_index_base (global index of arena 0: sharding), auto_reset, field_format
 
@@ -103,7 +105,7 @@ class NavGymEnv(object):
                  min_goal_dist, max_goal_dist, reward_scale, reward_success_factor, reward_crash_factor,
                  reward_progress_factor, reward_forward_factor, reward_rotation_factor,
                  reward_discomfort_factor, env_param_range, *,
-                 num_envs=1, n_beams=None, lidar=None, map_size=400, pedestrian_model="sfm",
+                 num_envs=1, n_beams=None, lidar=None, map_size=400, pedestrian_model="sfm", policy_weights=None,
                  num_humans=None, device="cuda:0", seed=0, env_index_base=0, auto_reset=None,
                  field_format=abi.FIELD_U16T, n_spawn=16, randomize_maps=False, plan_paths=True):
         from . import lib
@@ -135,7 +137,11 @@ class NavGymEnv(object):
         self.plan_paths = bool(plan_paths) and int(map_size) <= 1000
         spec = robots.ROBOTS[robot_type]
         nh_hi = int(env_param_range["num_humans"][0][1]) if num_humans is None else int(num_humans)
-        ped = {"none": abi.PED_NONE, "external": abi.PED_EXTERNAL, "sfm": abi.PED_SFM}[pedestrian_model]
+        ped = {"none": abi.PED_NONE, "external": abi.PED_EXTERNAL, "sfm": abi.PED_SFM,
+               "policy": abi.PED_EXTERNAL}[pedestrian_model]
+        if pedestrian_model == "policy" and policy_weights is None:
+            raise ValueError("pedestrian_model='policy' needs policy_weights (human_policy.pth is not shipped)")
+        self._policy_weights = policy_weights
         if nh_hi == 0:
             ped = abi.PED_NONE
         cfg = lib.default_config(
@@ -237,6 +243,11 @@ class NavGymEnv(object):
                          "resolution": cfg.resolution, "width": self.map_size, "height": self.map_size}
         n0 = int(self.sim.t["n_peds"][0]) if "n_peds" in self.sim.t else 0
         self.humans = [_AgentView(self, "human", i) for i in range(n0)]
+        if self.pedestrian_model == "policy":
+            w = self._policy_weights
+            if isinstance(w, str):
+                w = torch.load(w, map_location="cpu")
+            self.sim.set_policy(w)
         self.sim.reset_obs()
         return self._obs_dict()
 
@@ -256,8 +267,13 @@ class NavGymEnv(object):
             raise RuntimeError("call reset() before step()")
         if human_actions is not None:
             self.sim.set_ped_cmd(human_actions)
+        elif self.pedestrian_model == "policy":
+            self.sim.ped_policy()                           # scans -> HumanPolicy actor -> (v, omega)
         a = np.asarray(action, dtype=np.float64).reshape(self.num_envs, 2) if not hasattr(action, "is_cuda") else action
         _, out = self.sim.step(a)
+        if self.pedestrian_model == "policy" and self.auto_reset:
+            # a new episode starts with prev_human_actions = 0 (env.py:739)
+            self.sim.t["policy_prev_actions"].mul_((out["done"] == 0).to(self.sim.t["policy_prev_actions"].dtype)[:, None, None])
         if self.randomize_maps and self.auto_reset:
             self.sim.regen()
         if "costmap" in self.sim.t:

@@ -523,6 +523,15 @@ def test_env_wrapper_gym_api(gpu):
         _, _, bd, _ = renv.step(straight)
         finished += int(bd.sum())
     assert finished > 0 and int(renv.sim.t["episode"].sum()) == finished
+    # pedestrians driven by the HumanPolicy actor on the device
+    penv = nav_gym_env.make("NavGym-v0", num_envs=8, map_size=400, num_humans=6, seed=6, pedestrian_model="policy",
+                            policy_weights=_policy_weights_random(3), indoor_ratio=0.0)
+    penv.reset()
+    p0 = penv.sim.t["ped_pose"].clone()
+    for _ in range(5):
+        penv.step(np.tile([[0.2, 0.0]], (8, 1)))
+    moved = (penv.sim.t["ped_pose"][..., :2] - p0[..., :2]).norm(dim=2)
+    assert float(moved.max()) > 0.05 and bool(gpu.torch.isfinite(penv.sim.t["ped_pose"]).all())
 
 
 @pytest.fixture(scope="module", params=["c2", "c3", "c4"])
