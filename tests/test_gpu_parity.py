@@ -523,6 +523,14 @@ def test_env_wrapper_gym_api(gpu):
         _, _, bd, _ = renv.step(straight)
         finished += int(bd.sum())
     assert finished > 0 and int(renv.sim.t["episode"].sum()) == finished
+    # one arena in the layout RosEnv puts on the wire (ros_env.py:65-185)
+    from nav_gym_amd import export
+    m = export.reset_map_fields(benv, arena=3)
+    assert m["data"].shape == (200, 200) and set(np.unique(m["data"])) <= {0, 100} and m["data"][0, 0] == 100
+    su = export.strict_update_fields(env, arena=0)
+    assert len(su["humans"]) == 5 and su["scan"]["ranges"].shape == (512,) and su["footprint"].shape == (4, 2)
+    assert abs(su["pose"]["position"][0] - env.robot.px) < 1e-12
+    assert np.allclose(su["scan"]["ranges"], env.prev_obs["observation"][:512])
     # pedestrians driven by the HumanPolicy actor on the device
     penv = nav_gym_env.make("NavGym-v0", num_envs=8, map_size=400, num_humans=6, seed=6, pedestrian_model="policy",
                             policy_weights=_policy_weights_random(3), indoor_ratio=0.0)

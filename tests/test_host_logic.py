@@ -170,3 +170,14 @@ def test_two_rank_sharding_over_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "SHARD_OK" in outs[0]
+
+
+def test_export_transform_matches_reference_utils():
+    """export._transform restates utils.transform_xys (ros_env.py:100-135 uses it for the three footprint
+    polygons); golden: the reference's own output for a translation (3.25, -1.5) and yaw 0.7."""
+    from nav_gym_amd import export
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_units.npz"))
+    got = export._transform(d["tf_xys_in"], 3.25, -1.5, 0.7)
+    assert np.abs(got - d["tf_xys_out"][:, :2]).max() < 1e-12
+    q = export._quaternion_from_yaw(0.7)
+    assert abs(q[2] - np.sin(0.35)) < 1e-15 and abs(q[3] - np.cos(0.35)) < 1e-15 and q[0] == 0.0 and q[1] == 0.0
