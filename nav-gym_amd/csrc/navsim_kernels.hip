@@ -509,8 +509,9 @@ struct PedShared {
     float disc[2 * NAVSIM_MAX_PEDS][2];
     double ax[NAVSIM_MAX_PEDS + 1], ay[NAVSIM_MAX_PEDS + 1];
     double avx[NAVSIM_MAX_PEDS + 1], avy[NAVSIM_MAX_PEDS + 1];
+    float info[6 * NAVSIM_MAX_PEDS];         // merge_prims_culled_core scratch: in-range flag per primitive
 };
-struct Prims { const float (*seg)[4]; const float (*disc)[2]; };
+struct Prims { const float (*seg)[4]; const float (*disc)[2]; float* info; };
 
 template <int BLOCK>
 __device__ __forceinline__ void finish_beams(const navsim_config& c, const StepShared& sh, const Prims pr,
@@ -796,15 +797,37 @@ __device__ __forceinline__ float march_ray(const Field& field, float x0, float y
 // three 2*pi aliases) and runs the SAME float32 seg_merge / circle_merge on those beams only;
 // results land with an LDS atomicMin on the (non-negative) float bits, so they do not depend on the
 // order of primitives.  rng[] holds metres, dir[] the beam directions.
+// One lane per primitive: can it change the clipped scan at all?  Every point of a segment is at least
+// |u| - |v - u| from the lidar (a disc: |u| - r); beyond the clip range a hit cannot matter, because
+// clip(min(r, t)) = clip(r) for t >= range_max.  info[p] < 0 marks such a primitive.
+template <int BLOCK>
+__device__ __forceinline__ void prim_in_range(int nprim, int nseg, float lx, float ly, float rcull, const Prims pr) {
+    for (int p = (int)threadIdx.x; p < nprim; p += BLOCK) {
+        bool skip;
+        if (p < nseg) {
+            float ux = pr.seg[p][0] - lx, uy = pr.seg[p][1] - ly, vx = pr.seg[p][2] - lx, vy = pr.seg[p][3] - ly;
+            skip = sqrtf(ux * ux + uy * uy) - sqrtf((vx - ux) * (vx - ux) + (vy - uy) * (vy - uy)) > rcull;
+        } else {
+            float ux = pr.disc[p - nseg][0] - lx, uy = pr.disc[p - nseg][1] - ly;
+            skip = sqrtf(ux * ux + uy * uy) - nv::kLegRadius > rcull;
+        }
+        pr.info[p] = skip ? -1.0f : 1.0f;
+    }
+}
+
 template <int BLOCK>
 __device__ __forceinline__ void merge_prims_culled_core(int B, float lx, float ly, float stepf, float beta0,
                                                         int nseg, int ndisc, const Prims pr,
-                                                        const float2* __restrict__ dir, float* __restrict__ rng) {
+                                                        const float2* __restrict__ dir, float* __restrict__ rng,
+                                                        float rcull) {
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     const float kTwoPiF = 6.2831853f;
     const float Kf = (stepf > 0.0f) ? kTwoPiF / stepf : 0.0f;
     const int nprim = nseg + ndisc;
+    prim_in_range<BLOCK>(nprim, nseg, lx, ly, rcull, pr);
+    __syncthreads();
     for (int p = wave; p < nprim; p += BLOCK / 64) {
+        if (pr.info[p] < 0.0f) continue;                            // beyond the clip range
         const bool is_seg = p < nseg;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         float ac = 0.0f, w = 0.0f;
@@ -848,7 +871,8 @@ template <int BLOCK>
 __device__ __forceinline__ void merge_prims_culled(const navsim_config& c, const StepShared& sh, const Prims pr,
                                                    const float2* __restrict__ dir, float* __restrict__ rng) {
     merge_prims_culled_core<BLOCK>(c.n_beams, sh.lx, sh.ly, (float)nv::linspace_step(c),
-                                   (float)(c.angle_min + (double)sh.lth), sh.nseg, sh.ndisc, pr, dir, rng);
+                                   (float)(c.angle_min + (double)sh.lth), sh.nseg, sh.ndisc, pr, dir, rng,
+                                   (float)c.range_max * 1.0001f + 0.01f);
 }
 
 // raw ranges (cells) -> metres, pedestrians, clip, noise, crash / discomfort flags, observation row
@@ -1120,7 +1144,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         psp = &ps_storage;
     }
     PedShared& ps = *psp;
-    const Prims prims = {PEDS ? ps.seg : nullptr, PEDS ? ps.disc : nullptr};
+    const Prims prims = {PEDS ? ps.seg : nullptr, PEDS ? ps.disc : nullptr, PEDS ? ps.info : nullptr};
     const int e = blockIdx.x;
     const int tid = threadIdx.x;
     if (tile_lds_bytes) {                                       // stage the arena's tile table (coalesced)
@@ -2348,6 +2372,7 @@ template <typename Field>
 __global__ __launch_bounds__(256) void ped_scan_kernel(navsim_config c, navsim_state st, float* __restrict__ out) {
     constexpr int BLOCK = 256;
     __shared__ float seg[4 * (NAVSIM_MAX_PEDS + 1)][4];
+    __shared__ float info_s[4 * (NAVSIM_MAX_PEDS + 1)];
     __shared__ int nseg_s, i0_s, j0_s;
     __shared__ float lx_s, ly_s, lth_s;
     extern __shared__ __attribute__((aligned(16))) char dyn[];       // float2 dir[PB], float rng[PB]
@@ -2400,8 +2425,9 @@ __global__ __launch_bounds__(256) void ped_scan_kernel(navsim_config c, navsim_s
         rng[k] = march_ray(field, x0, y0, dx, dy, 0.0f, max_range, (unsigned)W, (unsigned)H) * res;
     }
     __syncthreads();
-    const Prims pr = {seg, nullptr};
-    merge_prims_culled_core<BLOCK>(PB, lx_s, ly_s, (float)step, (float)(c.ped_angle_min + lth), nseg_s, 0, pr, dir, rng);
+    const Prims pr = {seg, nullptr, info_s};
+    merge_prims_culled_core<BLOCK>(PB, lx_s, ly_s, (float)step, (float)(c.ped_angle_min + lth), nseg_s, 0, pr, dir, rng,
+                                   rmax * 1.0001f + 0.01f);
     __syncthreads();
     float* row = out + ((size_t)e * N + i) * PB;
     for (int k = tid; k < PB; k += BLOCK) {
