@@ -43,44 +43,71 @@ __device__ unsigned long long* g_stamps = nullptr;
 // ============================================================================================
 constexpr int kDtInf = 32768;
 
-__global__ __launch_bounds__(256) void dt_columns_kernel(const uint8_t* __restrict__ occ,
-                                                         uint16_t* __restrict__ g, int H, int W,
-                                                         const int* __restrict__ n_live) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x;
-    size_t m = blockIdx.y;
+// One workgroup = 64 adjacent columns x kColSeg row segments (a wavefront per segment, so a row of loads is
+// 64 contiguous bytes).  Segments are scanned independently and stitched through LDS: the downward
+// distance entering a segment is min over the segments above of (their last local value + rows in
+// between), the upward one likewise from their first occupied row.  A single thread per column would walk
+// H rows twice with one memory latency per chunk -- 190 us when only a few maps are live (navsim_regen).
+constexpr int kColSeg = 4;
+__global__ __launch_bounds__(64 * kColSeg) void dt_columns_kernel(const uint8_t* __restrict__ occ,
+                                                                 uint16_t* __restrict__ g, int H, int W,
+                                                                 const int* __restrict__ n_live) {
+    __shared__ int down_last[kColSeg][64], up_first[kColSeg][64];
+    const int cx = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + cx;
+    const size_t m = blockIdx.y;
     if (n_live && (int)m >= *n_live) return;          // navsim_regen: only the first *n_live maps are live
-    if (x >= W) return;
+    const int rows = (H + kColSeg - 1) / kColSeg;
+    const int y0 = seg * rows < H ? seg * rows : H, y1 = (y0 + rows < H) ? y0 + rows : H;
+    const bool live = x < W;
     const uint8_t* o = occ + m * (size_t)H * W;
     uint16_t* gg = g + m * (size_t)H * W;
-    // both passes walk the column in chunks of 16 rows: the 16 loads of a chunk are independent and
-    // issued together, only the running distance is carried (a plain row-by-row walk pays one memory
-    // latency per row, which dominates when few maps are live, as in navsim_regen)
-    constexpr int CH = 16;
-    int d = kDtInf;
-    for (int y0 = 0; y0 < H; y0 += CH) {
-        uint8_t v[CH];
+    constexpr int CH = 16;                            // loads of a chunk are independent and issued together
+    int d = kDtInf, first = kDtInf;
+    if (live)
+        for (int ya = y0; ya < y1; ya += CH) {
+            uint8_t v[CH];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) v[j] = (y0 + j < H) ? o[(size_t)(y0 + j) * W + x] : 0;
+            for (int j = 0; j < CH; ++j) v[j] = (ya + j < y1) ? o[(size_t)(ya + j) * W + x] : 0;
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            if (y0 + j < H) {
-                d = v[j] ? 0 : (d >= kDtInf ? kDtInf : d + 1);
-                gg[(size_t)(y0 + j) * W + x] = (uint16_t)(d >= kDtInf ? 0xFFFF : d);
+            for (int j = 0; j < CH; ++j) {
+                if (ya + j < y1) {
+                    if (v[j] && first == kDtInf) first = ya + j - y0;
+                    d = v[j] ? 0 : (d >= kDtInf ? kDtInf : d + 1);
+                    gg[(size_t)(ya + j) * W + x] = (uint16_t)(d >= kDtInf ? 0xFFFF : d);
+                }
             }
         }
+    down_last[seg][cx] = d;
+    up_first[seg][cx] = first;
+    __syncthreads();
+    if (!live) return;
+    int cd = kDtInf, cu = kDtInf;                     // distance at the row just above / just below the segment
+    for (int s2 = 0; s2 < seg; ++s2) {
+        int r0 = s2 * rows < H ? s2 * rows : H, r1 = (r0 + rows < H) ? r0 + rows : H;
+        int through = cd >= kDtInf ? kDtInf : cd + (r1 - r0);
+        cd = down_last[s2][cx] < through ? down_last[s2][cx] : through;
     }
-    d = kDtInf;
-    for (int y1 = H - 1; y1 >= 0; y1 -= CH) {
+    for (int s2 = kColSeg - 1; s2 > seg; --s2) {
+        int r0 = s2 * rows < H ? s2 * rows : H, r1 = (r0 + rows < H) ? r0 + rows : H;
+        int through = cu >= kDtInf ? kDtInf : cu + (r1 - r0);
+        cu = up_first[s2][cx] < through ? up_first[s2][cx] : through;
+    }
+    int u = cu;
+    for (int yb = y1 - 1; yb >= y0; yb -= CH) {
         uint16_t v[CH];
 #pragma unroll
-        for (int j = 0; j < CH; ++j) v[j] = (y1 - j >= 0) ? gg[(size_t)(y1 - j) * W + x] : 0;
+        for (int j = 0; j < CH; ++j) v[j] = (yb - j >= y0) ? gg[(size_t)(yb - j) * W + x] : 0;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            if (y1 - j >= 0) {
-                int cur = (v[j] == 0xFFFF) ? kDtInf : v[j];
-                d = (cur == 0) ? 0 : (d >= kDtInf ? kDtInf : d + 1);
-                if (d < cur) gg[(size_t)(y1 - j) * W + x] = (uint16_t)d;
-                else d = cur;
+            const int y = yb - j;
+            if (y >= y0) {
+                const int cur = (v[j] == 0xFFFF) ? kDtInf : v[j];
+                u = (cur == 0) ? 0 : (u >= kDtInf ? kDtInf : u + 1);
+                const int from_above = cd >= kDtInf ? kDtInf : cd + (y - y0 + 1);
+                int best = cur < from_above ? cur : from_above;
+                best = best < u ? best : u;
+                if (best != cur) gg[(size_t)y * W + x] = (uint16_t)(best >= kDtInf ? 0xFFFF : best);
             }
         }
     }
@@ -198,12 +225,26 @@ __global__ __launch_bounds__(256) void dt_rows_kernel(const uint16_t* __restrict
     for (int x = threadIdx.x; x < W; x += blockDim.x) {
         int g0 = row[x];
         int best = g0 * g0;
-        for (int dx = 1; dx < W; ++dx) {
-            int dx2 = dx * dx;
-            if (dx2 >= best) break;
-            int xl = x - dx, xr = x + dx;
-            if (xl >= 0) { int v = row[xl]; int c = dx2 + v * v; best = c < best ? c : best; }
-            if (xr < W)  { int v = row[xr]; int c = dx2 + v * v; best = c < best ? c : best; }
+        // eight distances per round: the 16 LDS reads do not depend on `best`, only the exit test does, and
+        // candidates past the exit point (dx^2 >= best) can never win, so running a round to its end is
+        // result-neutral.  (One distance per round pays an LDS latency per step: 25 us for an open row.)
+        constexpr int UR = 8;
+        for (int dx0 = 1; dx0 < W; dx0 += UR) {
+            if (dx0 * dx0 >= best) break;
+            int vl[UR], vr[UR];
+#pragma unroll
+            for (int j = 0; j < UR; ++j) {
+                int xl = x - (dx0 + j), xr = x + (dx0 + j);
+                vl[j] = (xl >= 0) ? row[xl] : kDtInf;
+                vr[j] = (xr < W) ? row[xr] : kDtInf;
+            }
+#pragma unroll
+            for (int j = 0; j < UR; ++j) {
+                int dx2 = (dx0 + j) * (dx0 + j);
+                int cl = dx2 + vl[j] * vl[j], cr = dx2 + vr[j] * vr[j];
+                best = cl < best ? cl : best;
+                best = cr < best ? cr : best;
+            }
         }
         if (FORMAT == 0) {
             ((float*)field_v)[(m * (size_t)H + y) * W + x] = sqrtf((float)best);
@@ -1572,10 +1613,14 @@ __global__ __launch_bounds__(1024) void regen_select_kernel(const uint8_t* __res
     if (tid == 1023) *count = part[1023] < cap ? part[1023] : cap;
 }
 
-// create_outdoor_map (map_generator.py:126-143) at size x size, hash-keyed
+// create_outdoor_map (map_generator.py:126-143) at size x size, hash-keyed: kRegenSlices workgroups per map,
+// each filling its own band of rows (border wall, four cells per store) and then the parts of the obstacle
+// squares that fall into the band.
+constexpr int kRegenSlices = 8;
 __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim_state st,
                                                          const int* __restrict__ count, const int* __restrict__ list,
                                                          uint8_t* __restrict__ occ_all) {
+    __shared__ int ocx[64], ocy[64];
     const int b = blockIdx.x;
     if (b >= *count) return;
     const int e = list[b], size = c.map_w, tid = threadIdx.x;
@@ -1583,10 +1628,21 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
     const uint64_t key = nv::hash4(c.seed, (uint64_t)(c.env_index_base + e), (uint64_t)st.episode[e], 0x4D4150ULL);
     double w = c.obstacle_width_lo + (c.obstacle_width_hi - c.obstacle_width_lo) * rg_u(key, 0);
     const int hw = (int)(10.0 * w);
+    int span = size - 2 * hw - 3;
+    span = span < 1 ? 1 : span;
+    const int n_obs = c.obstacle_number < 64 ? c.obstacle_number : 64;
+    if (tid < n_obs) {
+        ocx[tid] = hw + 2 + (int)(rg_u(key, 1 + 2 * (uint64_t)tid) * span);
+        ocy[tid] = hw + 2 + (int)(rg_u(key, 2 + 2 * (uint64_t)tid) * span);
+    }
+    __syncthreads();
+    // this workgroup owns rows [r0, r1): background first, then the parts of the obstacle squares inside them
+    const int rows = (size + kRegenSlices - 1) / kRegenSlices;
+    const int r0 = blockIdx.y * rows, r1 = (r0 + rows < size) ? r0 + rows : size;
     if ((size & 3) == 0) {                                       // 4 cells per store
         const int wpr = size >> 2;
         uint32_t* occ32 = (uint32_t*)occ;
-        for (int idx = tid; idx < size * wpr; idx += 256) {
+        for (int idx = r0 * wpr + tid; idx < r1 * wpr; idx += 256) {
             int r = idx / wpr, q4 = (idx - r * wpr) * 4;
             uint32_t wv = 0;
 #pragma unroll
@@ -1597,23 +1653,39 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
             occ32[(size_t)(size - 1 - r) * wpr + (q4 >> 2)] = wv;
         }
     } else {
-        for (int idx = tid; idx < size * size; idx += 256) {
+        for (int idx = r0 * size + tid; idx < r1 * size; idx += 256) {
             int r = idx / size, q = idx - r * size;
             occ[(size_t)(size - 1 - r) * size + q] = !(r >= 5 && r < size - 5 && q >= 5 && q < size - 5);
         }
     }
     __syncthreads();
-    int span = size - 2 * hw - 3;
-    span = span < 1 ? 1 : span;
     const int side = 2 * hw + 1;
-    for (int o = 0; o < c.obstacle_number; ++o) {
-        int cx = hw + 2 + (int)(rg_u(key, 1 + 2 * (uint64_t)o) * span);
-        int cy = hw + 2 + (int)(rg_u(key, 2 + 2 * (uint64_t)o) * span);
-        for (int idx = tid; idx < side * side; idx += 256) {
-            int r = cx - hw + idx / side, q = cy - hw + idx % side;
-            if (r >= 0 && r < size && q >= 0 && q < size) occ[(size_t)(size - 1 - r) * size + q] = 1;
+    for (int o = 0; o < n_obs; ++o) {
+        const int cx = ocx[o], cy = ocy[o];
+        const int ra = (cx - hw > r0) ? cx - hw : r0, rb = (cx + hw < r1 - 1) ? cx + hw : r1 - 1;
+        for (int idx = tid; idx < (rb - ra + 1) * side; idx += 256) {
+            int r = ra + idx / side, q = cy - hw + idx % side;
+            if (q >= 0 && q < size) occ[(size_t)(size - 1 - r) * size + q] = 1;
         }
     }
+}
+
+// install the new distance field of every regenerated arena (kRegenSlices workgroups per map, 16-byte copies)
+__global__ __launch_bounds__(256) void regen_field_kernel(navsim_state st, const int* __restrict__ count,
+                                                          const int* __restrict__ list,
+                                                          const char* __restrict__ field_scratch, size_t field_bytes) {
+    const int b = blockIdx.x;
+    if (b >= *count) return;
+    const int e = list[b], tid = threadIdx.x;
+    const size_t n16 = field_bytes / 16;
+    const size_t per = (n16 + kRegenSlices - 1) / kRegenSlices;
+    const size_t lo = blockIdx.y * per, hi = (lo + per < n16) ? lo + per : n16;
+    const uint4* src = (const uint4*)(field_scratch + (size_t)b * field_bytes);
+    uint4* dst = (uint4*)((char*)st.field + (size_t)e * field_bytes);
+    for (size_t i = lo + tid; i < hi; i += 256) dst[i] = src[i];
+    if (blockIdx.y == 0)
+        for (size_t i = n16 * 16 + tid; i < field_bytes; i += 256)                      // tail bytes
+            ((char*)st.field)[(size_t)e * field_bytes + i] = field_scratch[(size_t)b * field_bytes + i];
 }
 
 template <typename Field>
@@ -1651,15 +1723,6 @@ __global__ __launch_bounds__(256) void regen_commit_kernel(navsim_config c, navs
     if (b >= *count) return;
     const int e = list[b], tid = threadIdx.x;
     const int N = c.max_peds, K = c.n_spawn, P = NAVSIM_MAX_WAYPOINTS;
-    {   // field_bytes is a multiple of 16 for both formats at square sizes used here; copy in 4-byte words
-        const uint4* src = (const uint4*)(field_scratch + (size_t)b * field_bytes);
-        uint4* dst = (uint4*)((char*)st.field + (size_t)e * field_bytes);
-        for (size_t i = tid; i < field_bytes / 16; i += 256) dst[i] = src[i];
-        for (size_t i = (field_bytes / 16) * 16 + tid; i < field_bytes; i += 256)          // tail bytes
-            ((char*)st.field)[(size_t)e * field_bytes + i] = field_scratch[(size_t)b * field_bytes + i];
-    }
-    __threadfence_block();
-    __syncthreads();
     const Field f(st.field, st.field_overflow, e, c.map_h, c.map_w);
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
     double* sp = (double*)st.spawn_pose + (size_t)e * K * 3;
@@ -1947,12 +2010,7 @@ __global__ __launch_bounds__(256) void regen_install_kernel(navsim_config c, nav
                                                             RegenPlanWs ws) {
     const int b = blockIdx.x;
     if (b >= *count) return;
-    const int e = list[b], tid = threadIdx.x;
-    const uint4* src = (const uint4*)(field_scratch + (size_t)b * field_bytes);
-    uint4* dst = (uint4*)((char*)st.field + (size_t)e * field_bytes);
-    for (size_t i = tid; i < field_bytes / 16; i += 256) dst[i] = src[i];
-    for (size_t i = (field_bytes / 16) * 16 + tid; i < field_bytes; i += 256)
-        ((char*)st.field)[(size_t)e * field_bytes + i] = field_scratch[(size_t)b * field_bytes + i];
+    const int tid = threadIdx.x;
     for (int k = tid; k < c.n_spawn; k += 256) ws.res_robot[(size_t)b * c.n_spawn + k] = 0;
     for (int i = tid; i < c.max_peds; i += 256) ws.res_ped[(size_t)b * c.max_peds + i] = 0;
 }
@@ -2716,7 +2774,7 @@ int navsim_build_field(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W,
         (void)hipMemsetAsync(field, format == NAVSIM_FIELD_U16T ? 0xFF : 0, field_per_map * (size_t)n_maps, s);
     for (int32_t m0 = 0; m0 < n_maps; m0 += (int32_t)chunk) {
         int32_t m = (n_maps - m0 < (int32_t)chunk) ? n_maps - m0 : (int32_t)chunk;
-        dt_columns_kernel<<<dim3((W + 255) / 256, m), 256, 0, s>>>(occ + (size_t)m0 * H * W,
+        dt_columns_kernel<<<dim3((W + 63) / 64, m), 64 * kColSeg, 0, s>>>(occ + (size_t)m0 * H * W,
                                                                    (uint16_t*)workspace, H, W, nullptr);
         void* f = (char*)field + field_per_map * (size_t)m0;
         float* o = overflow ? overflow + (size_t)m0 * H * W : nullptr;
@@ -2938,7 +2996,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
                  size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
     if (!c || !st || !io || !io->done || !io->obs || !workspace) return NAVSIM_E_ARG;
-    if (c->map_h != c->map_w || c->n_spawn < 1 || c->regen_cap < 1 || st->tile_table || st->field_overflow ||
+    if (c->map_h != c->map_w || c->n_spawn < 1 || c->regen_cap < 1 || c->obstacle_number > 64 || st->tile_table || st->field_overflow ||
         (c->field_format != NAVSIM_FIELD_F32 && c->field_format != NAVSIM_FIELD_U16T) || c->shared_field)
         return NAVSIM_E_UNSUPPORTED;
     if (workspace_bytes < navsim_regen_workspace_bytes(c) || !st->spawn_pose || !st->spawn_goal) return NAVSIM_E_ARG;
@@ -2966,13 +3024,14 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     char* fscratch = w + off;
     const size_t fbytes = navsim_field_bytes(1, H, W, c->field_format);
     regen_select_kernel<<<1, 1024, 0, s>>>(io->done, c->n_envs, M, count, list, mask);
-    regen_maps_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, occ);
+    regen_maps_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>(*c, *st, count, list, occ);
     if (c->field_format == NAVSIM_FIELD_U16T) (void)hipMemsetAsync(fscratch, 0xFF, fbytes * (size_t)M, s);
-    dt_columns_kernel<<<dim3((W + 255) / 256, M), 256, 0, s>>>(occ, cols, H, W, count);
+    dt_columns_kernel<<<dim3((W + 63) / 64, M), 64 * kColSeg, 0, s>>>(occ, cols, H, W, count);
     if (c->field_format == NAVSIM_FIELD_F32)
         dt_rows_kernel<0><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, nullptr, nullptr, H, W, count);
     else
         dt_rows_kernel<1><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, nullptr, nullptr, H, W, count);
+    regen_field_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>(*st, count, list, fscratch, fbytes);
     if (c->regen_plan) {
         const int Hc = H / 5, Wc = W / 5, P = NAVSIM_MAX_WAYPOINTS;
         const size_t cc = (size_t)Hc * Wc;
