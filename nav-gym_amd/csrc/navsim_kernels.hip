@@ -48,7 +48,7 @@ constexpr int kDtInf = 32768;
 // distance entering a segment is min over the segments above of (their last local value + rows in
 // between), the upward one likewise from their first occupied row.  A single thread per column would walk
 // H rows twice with one memory latency per chunk -- 190 us when only a few maps are live (navsim_regen).
-constexpr int kColSeg = 4;
+constexpr int kColSeg = 8;
 __global__ __launch_bounds__(64 * kColSeg) void dt_columns_kernel(const uint8_t* __restrict__ occ,
                                                                  uint16_t* __restrict__ g, int H, int W,
                                                                  const int* __restrict__ n_live) {
