@@ -129,6 +129,9 @@ typedef struct navsim_config {
     double ped_min_goal_dist;         /* env.py:788-791: 10 m */
     double v_pref_lo, v_pref_hi;      /* human_v_pref_range */
     double has_legs_ratio;            /* human_has_legs_ratio */
+    double regen_indoor_ratio;        /* navsim_regen: probability that a new map is a corridor map
+                                         (create_indoor_map, map_generator.py:97-123) instead of an outdoor one;
+                                         env.py:742 indoor_ratio.  0 = outdoor only */
 } navsim_config;
 
 /* ------------------------------------------------------------------------------------------

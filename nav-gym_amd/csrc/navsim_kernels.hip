@@ -1613,18 +1613,93 @@ __global__ __launch_bounds__(1024) void regen_select_kernel(const uint8_t* __res
     if (tid == 1023) *count = part[1023] < cap ? part[1023] : cap;
 }
 
+// create_indoor_map (map_generator.py:97-123; oracle regen_map_indoor): the corridor tree on the coarse grid,
+// one workgroup per regenerated arena.  The tree grows one node per iteration (nearest node by a workgroup
+// min-reduction on (L1 distance, node index), then the two corridor rectangles carved by all threads);
+// the grid lives in LDS and is written to grid_all[b] (G*G bytes, stride 100*100).  kind[b] = G for a
+// corridor map, 0 for an outdoor one (regen_maps_kernel then draws the outdoor map as before).
+__global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navsim_state st,
+                                                           const int* __restrict__ count, const int* __restrict__ list,
+                                                           uint8_t* __restrict__ grid_all, int* __restrict__ kind) {
+    __shared__ uint8_t g[100 * 100];
+    __shared__ int tx[152], ty[152];
+    __shared__ unsigned best_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= *count) return;
+    const int e = list[b], size = c.map_w;
+    const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
+    const bool indoor = c.regen_indoor_ratio > 0.0 && rg_u(nv::hash4(c.seed, genv, ep, 0x4B494E44ULL), 0) < c.regen_indoor_ratio;
+    if (!indoor) { if (tid == 0) kind[b] = 0; return; }                  // block-uniform
+    const uint64_t key = nv::hash4(c.seed, genv, ep, 0x494E44ULL);
+    uint64_t n = 0;
+    const int r = 3 + (int)(rg_u(key, n++) * 2.0);
+    const int it = 80 + (int)(rg_u(key, n++) * 71.0);
+    int G = size / 10;
+    G = G < 2 * r + 8 ? 2 * r + 8 : G;
+    G = G > 100 ? 100 : G;
+    int n_it = (it * G * G + 5000) / 10000;
+    n_it = n_it < 4 ? 4 : (n_it > 150 ? 150 : n_it);
+    for (int k = tid; k < G * G; k += 256) g[k] = 1;
+    if (tid == 0) { tx[0] = G / 2; ty[0] = G / 2; }
+    __syncthreads();
+    if (tid == 0) g[(G / 2) * G + G / 2] = 0;
+    const int span = G - 2 * r - 3;
+    for (int k = 0; k < n_it; ++k) {
+        const int px = r + 2 + (int)(rg_u(key, n) * span), py = r + 2 + (int)(rg_u(key, n + 1) * span);
+        const bool coin = rg_u(key, n + 2) >= 0.5;
+        n += 3;
+        const int nt = k + 1;
+        if (tid == 0) best_s = 0xFFFFFFFFu;
+        __syncthreads();
+        if (tid < nt) atomicMin(&best_s, ((unsigned)(abs(px - tx[tid]) + abs(py - ty[tid])) << 8) | (unsigned)tid);
+        __syncthreads();
+        const int best = (int)(best_s & 0xFFu);
+        const int qx = tx[best], qy = ty[best];
+        const int x1 = px < qx ? px : qx, x2 = px < qx ? qx : px;
+        const int y1 = py < qy ? py : qy, y2 = py < qy ? qy : py;
+        const bool constellation1 = (px > qx && py < qy) || (px < qx && py > qy);
+        const int hx = coin ? x1 : x2;
+        const int cy = coin ? (constellation1 ? y1 : y2) : (constellation1 ? y2 : y1);
+        const int wh = y2 - y1 + 2 * r + 1, hv = x2 - x1 + 2 * r + 1, side = 2 * r + 1;
+        for (int idx = tid; idx < side * wh; idx += 256) {
+            int a = hx - r + idx / wh, bq = y1 - r + idx % wh;
+            if (a >= 0 && a < G && bq >= 0 && bq < G) g[a * G + bq] = 0;
+        }
+        for (int idx = tid; idx < hv * side; idx += 256) {
+            int a = x1 - r + idx / side, bq = cy - r + idx % side;
+            if (a >= 0 && a < G && bq >= 0 && bq < G) g[a * G + bq] = 0;
+        }
+        if (tid == 0) { tx[nt] = px; ty[nt] = py; g[px * G + py] = 0; }
+        __syncthreads();
+    }
+    uint8_t* out = grid_all + (size_t)b * 10000;
+    for (int k = tid; k < G * G; k += 256) out[k] = g[k];
+    if (tid == 0) kind[b] = G;
+}
+
 // create_outdoor_map (map_generator.py:126-143) at size x size, hash-keyed: kRegenSlices workgroups per map,
 // each filling its own band of rows (border wall, four cells per store) and then the parts of the obstacle
 // squares that fall into the band.
 constexpr int kRegenSlices = 8;
 __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim_state st,
                                                          const int* __restrict__ count, const int* __restrict__ list,
-                                                         uint8_t* __restrict__ occ_all) {
+                                                         uint8_t* __restrict__ occ_all,
+                                                         const uint8_t* __restrict__ grid_all, const int* __restrict__ kind) {
     __shared__ int ocx[64], ocy[64];
     const int b = blockIdx.x;
     if (b >= *count) return;
     const int e = list[b], size = c.map_w, tid = threadIdx.x;
     uint8_t* occ = occ_all + (size_t)b * size * size;
+    if (const int G = kind[b]) {                                       // corridor map: nearest upscaling + flip
+        const uint8_t* gsrc = grid_all + (size_t)b * 10000;
+        const int rows_i = (size + kRegenSlices - 1) / kRegenSlices;
+        const int ra = blockIdx.y * rows_i, rb = (ra + rows_i < size) ? ra + rows_i : size;
+        for (int idx = ra * size + tid; idx < rb * size; idx += 256) {
+            int yy = idx / size, xx = idx - yy * size;
+            occ[(size_t)(size - 1 - yy) * size + xx] = gsrc[(int)(((long long)yy * G) / size) * G + (int)(((long long)xx * G) / size)];
+        }
+        return;
+    }
     const uint64_t key = nv::hash4(c.seed, (uint64_t)(c.env_index_base + e), (uint64_t)st.episode[e], 0x4D4150ULL);
     double w = c.obstacle_width_lo + (c.obstacle_width_hi - c.obstacle_width_lo) * rg_u(key, 0);
     const int hw = (int)(10.0 * w);
@@ -2735,6 +2810,7 @@ int navsim_default_config(navsim_config* c) {
     c->v_pref_lo = 0.0;                     // __init__.py:14
     c->v_pref_hi = 0.6;
     c->has_legs_ratio = 0.5;                // __init__.py:15
+    c->regen_indoor_ratio = 0.0;
     c->seed = 1234;
     return NAVSIM_OK;
 }
@@ -2980,6 +3056,7 @@ size_t navsim_regen_workspace_bytes(const navsim_config* c) {
     b += M * cells;                                         // occupancy scratch
     b += M * cells * sizeof(uint16_t);                      // column pass
     b += M * navsim_field_bytes(1, c->map_h, c->map_w, c->field_format);
+    b += M * (10000 + sizeof(int)) + 512;                   // corridor grids, map kinds
     if (c->regen_plan) {
         const size_t cc = (size_t)(c->map_h / 5) * (c->map_w / 5), P = NAVSIM_MAX_WAYPOINTS;
         const size_t Q = (size_t)(c->n_spawn > c->max_peds ? c->n_spawn : c->max_peds);
@@ -3023,8 +3100,16 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     off = (off + 255) & ~(size_t)255;
     char* fscratch = w + off;
     const size_t fbytes = navsim_field_bytes(1, H, W, c->field_format);
+    off += fbytes * (size_t)M;
+    off = (off + 255) & ~(size_t)255;
+    uint8_t* grids = (uint8_t*)(w + off);
+    off += (size_t)M * 10000;
+    off = (off + 255) & ~(size_t)255;
+    int* kind = (int*)(w + off);
+    off += (size_t)M * sizeof(int);
     regen_select_kernel<<<1, 1024, 0, s>>>(io->done, c->n_envs, M, count, list, mask);
-    regen_maps_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>(*c, *st, count, list, occ);
+    regen_indoor_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, grids, kind);
+    regen_maps_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>(*c, *st, count, list, occ, grids, kind);
     if (c->field_format == NAVSIM_FIELD_U16T) (void)hipMemsetAsync(fscratch, 0xFF, fbytes * (size_t)M, s);
     dt_columns_kernel<<<dim3((W + 63) / 64, M), 64 * kColSeg, 0, s>>>(occ, cols, H, W, count);
     if (c->field_format == NAVSIM_FIELD_F32)
@@ -3037,7 +3122,6 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         const size_t cc = (size_t)Hc * Wc;
         const int Q = c->n_spawn > c->max_peds ? c->n_spawn : c->max_peds;
         auto take = [&](size_t bytes) { off = (off + 255) & ~(size_t)255; char* p = w + off; off += bytes; return p; };
-        off += fbytes * (size_t)M;
         RegenPlanWs ws;
         ws.Q = Q;
         ws.cost = (uint8_t*)take((size_t)M * cc);

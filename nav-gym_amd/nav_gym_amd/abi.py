@@ -91,6 +91,7 @@ class NavsimConfig(C.Structure):
         ("v_pref_lo", C.c_double),
         ("v_pref_hi", C.c_double),
         ("has_legs_ratio", C.c_double),
+        ("regen_indoor_ratio", C.c_double),
     ]
 
     def copy(self):

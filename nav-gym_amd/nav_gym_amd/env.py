@@ -151,6 +151,7 @@ class NavGymEnv(object):
             time_step=time_step, axle_offset=spec["axle_offset"], min_turning_radius=float(min_turning_radius),
             distance_threshold=distance_threshold, range_max=spec["range_max"], seed=self.seed_value)
         cfg.regen_plan = int(self.randomize_maps and self.plan_paths)
+        cfg.regen_indoor_ratio = float(indoor_ratio) if self.randomize_maps else 0.0     # env.py:742
         room = self.map_size * cfg.resolution                # per-episode ranges used by navsim_regen
         cfg.min_goal_dist = float(min(min_goal_dist, 0.4 * room))
         cfg.max_goal_dist = float(min(max_goal_dist, 0.8 * room))

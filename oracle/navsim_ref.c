@@ -85,6 +85,7 @@ int navsim_default_config_cpu(navsim_config* c) {
     c->v_pref_lo = 0.0;                     /* __init__.py:14 */
     c->v_pref_hi = 0.6;
     c->has_legs_ratio = 0.5;                /* __init__.py:15 */
+    c->regen_indoor_ratio = 0.0;
     c->seed = 1234;
     return NAVSIM_OK;
 }
@@ -1031,6 +1032,61 @@ static void regen_map(const navsim_config* c, uint64_t genv, uint64_t ep, uint8_
     }
 }
 
+/* create_indoor_map (map_generator.py:97-123) at size x size, hash-keyed: a random tree of corridors on a
+ * coarse grid of G = size/10 cells (0.5 m, the reference's scale for its 1000-cell maps), L1-nearest node,
+ * L-shaped paths of half-width r in {3, 4} (env_param corridor_width), iterations in [80, 150] scaled with
+ * the area, nearest-neighbour upscaling, vertical flip. */
+static void regen_map_indoor(const navsim_config* c, uint64_t genv, uint64_t ep, uint8_t* occ) {
+    const int size = c->map_w;
+    const uint64_t key = nvr_hash4(c->seed, genv, ep, 0x494E44ULL);
+    uint64_t n = 0;
+    const int r = 3 + (int)(rg_u(key, n++) * 2.0);
+    const int it = 80 + (int)(rg_u(key, n++) * 71.0);
+    int G = size / 10;
+    if (G < 2 * r + 8) G = 2 * r + 8;
+    if (G > 100) G = 100;
+    int n_it = (it * G * G + 5000) / 10000;
+    if (n_it < 4) n_it = 4;
+    if (n_it > 150) n_it = 150;
+    static __thread uint8_t g[100 * 100];
+    int tx[152], ty[152], nt = 1;
+    memset(g, 1, (size_t)G * G);
+    tx[0] = G / 2; ty[0] = G / 2;
+    g[(G / 2) * G + G / 2] = 0;
+    const int span = G - 2 * r - 3;                                    /* range(r + 2, G - r - 1) */
+    for (int k = 0; k < n_it; ++k) {
+        int px = r + 2 + (int)(rg_u(key, n++) * span), py = r + 2 + (int)(rg_u(key, n++) * span);
+        int coin = rg_u(key, n++) >= 0.5;
+        int best = 0, bd = 1 << 30;
+        for (int t = 0; t < nt; ++t) {                                  /* first L1-nearest node */
+            int dd = abs(px - tx[t]) + abs(py - ty[t]);
+            if (dd < bd) { bd = dd; best = t; }
+        }
+        int qx = tx[best], qy = ty[best];
+        tx[nt] = px; ty[nt] = py; ++nt;
+        g[px * G + py] = 0;
+        int x1 = px < qx ? px : qx, x2 = px < qx ? qx : px;
+        int y1 = py < qy ? py : qy, y2 = py < qy ? qy : py;
+        int constellation1 = (px > qx && py < qy) || (px < qx && py > qy);   /* map_generator.py:43-57 */
+        int hx, cy;                                                     /* horizontal leg row, vertical leg column */
+        if (coin) { hx = x1; cy = constellation1 ? y1 : y2; }
+        else      { hx = x2; cy = constellation1 ? y2 : y1; }
+        for (int a = hx - r; a <= hx + r; ++a)
+            for (int b = y1 - r; b <= y2 + r; ++b)
+                if (a >= 0 && a < G && b >= 0 && b < G) g[a * G + b] = 0;
+        for (int a = x1 - r; a <= x2 + r; ++a)
+            for (int b = cy - r; b <= cy + r; ++b)
+                if (a >= 0 && a < G && b >= 0 && b < G) g[a * G + b] = 0;
+    }
+    for (int yy = 0; yy < size; ++yy) {
+        int gy = (int)(((long long)yy * G) / size);
+        for (int xx = 0; xx < size; ++xx) {
+            int gx = (int)(((long long)xx * G) / size);
+            occ[(size_t)(size - 1 - yy) * size + xx] = g[gy * G + gx];
+        }
+    }
+}
+
 static inline void rg_cell_xy(const navsim_config* c, int i, int j, double* x, double* y) {
     *x = ((double)i + 0.5) * c->resolution + c->origin_x;                  /* env.py:1218-1219 */
     *y = ((double)j + 0.5) * c->resolution + c->origin_y;
@@ -1307,7 +1363,10 @@ int navsim_regen_cpu(const navsim_config* c, const navsim_state* st, const navsi
         mask[e] = 1;
         const uint64_t genv = (uint64_t)(c->env_index_base + e), ep = (uint64_t)st->episode[e];
         float* f = (float*)st->field + (size_t)e * H * W;
-        regen_map(c, genv, ep, occ);
+        if (c->regen_indoor_ratio > 0.0 && rg_u(nvr_hash4(c->seed, genv, ep, 0x4B494E44ULL), 0) < c->regen_indoor_ratio)
+            regen_map_indoor(c, genv, ep, occ);
+        else
+            regen_map(c, genv, ep, occ);
         navsim_build_dt_cpu(occ, 1, H, W, f);
         if (st->costmap) navsim_costmap_cpu(occ, 1, H, W, st->costmap + (size_t)e * (H / 5) * (W / 5));
         if (c->regen_plan) { regen_planned(c, st, e, genv, ep, occ); continue; }

@@ -325,7 +325,7 @@ def test_regen_vs_oracle(gpu, fmt, ped_model, plan):
     cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=ped_model, n_spawn=6,
                                  auto_reset=1, seed=17, field_format=fmt, regen_cap=5, min_goal_dist=3.0,
                                  max_goal_dist=8.0, spawn_clearance=0.9, ped_min_robot_dist=2.0, ped_min_goal_dist=4.0,
-                                 regen_plan=plan)
+                                 regen_plan=plan, regen_indoor_ratio=0.5 if fmt == abi.FIELD_U16T else 0.0)
     gpu.world.lidar_1081(cfg)
     occ = gpu.world.make_maps(E, size, 17)
     regenerated = capped = 0
@@ -350,6 +350,9 @@ def test_regen_vs_oracle(gpu, fmt, ped_model, plan):
     # a regenerated arena has a valid closed map: 5-cell border, obstacles inside
     f = r.a["field"]
     assert (f[:, :5] == 0).all() and (f[:, :, -5:] == 0).all()
+    if fmt == abi.FIELD_U16T:          # half of the new maps are corridor maps (walls fill most of the arena)
+        occupied = (f == 0).mean(axis=(1, 2))
+        assert (occupied > 0.3).any() and (occupied < 0.2).any()
 
 
 @pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T])

@@ -242,3 +242,35 @@ def test_regen_with_planning_properties():
                     assert np.linalg.norm(p - s) >= 2.0 and np.linalg.norm(w[n - 1] - p) > 4.0
         assert (r.a["ped_n_waypoints"][e, 5:] == 1).all()
     assert robots_ok >= E - 1 and planned_peds >= 3 * E
+
+
+def test_regen_indoor_maps_are_one_corridor_tree():
+    """cfg.regen_indoor_ratio = 1: every regenerated map is a corridor map (create_indoor_map,
+    map_generator.py:97-123): free space is ONE 4-connected component (a tree of L-shaped corridors grown
+    from the centre), corridors are 3.5-4.5 m wide, walls fill the rest; robot and goal lie in free space."""
+    from nav_gym_amd import abi, robots
+    from helpers import finished_world
+    E, size = 6, 400
+    cfg = ref.default_config(n_envs=E, map_h=size, map_w=size, max_peds=1, ped_model=abi.PED_NONE, n_spawn=6,
+                             auto_reset=1, seed=9, regen_cap=8, min_goal_dist=3.0, max_goal_dist=8.0,
+                             regen_indoor_ratio=1.0)
+    rng = np.random.default_rng(0)
+    occ = np.stack([outdoor_map(rng, size) for _ in range(E)])
+    thr = ref.scan_threshold(cfg, robots.footprint_array("keti", "threshold_footprint"))
+    dthr = ref.scan_threshold(cfg, robots.footprint_array("keti", "discomfort_threshold_footprint"))
+    r = ref.RefSim(cfg, finished_world(cfg, occ, ref.build_dt(occ), 0, (thr, dthr)))
+    r.reset_obs()
+    _, out = r.step(np.zeros((E, 2)))
+    assert out["done"].all()
+    r.regen()
+    fracs = []
+    for e in range(E):
+        free = r.a["field"][e] > 0
+        lab, n = ndi.label(free)
+        assert n == 1, "free space of arena %d falls into %d pieces" % (e, n)
+        fracs.append(free.mean())
+        # sample() keeps 2 coarse cells of wall at the low end and 1 at the high end; rows are flipped afterwards
+        assert not free[:10].any() and not free[-20:].any() and not free[:, :20].any() and not free[:, -10:].any()
+        i, j = int(r.a["robot_pose"][e, 0] / 0.05), int(r.a["robot_pose"][e, 1] / 0.05)
+        assert free[j, i]
+    assert 0.05 < min(fracs) and max(fracs) < 0.9 and len({round(f, 4) for f in fracs}) > 1
