@@ -143,7 +143,9 @@ __device__ __forceinline__ double exp_neg(double x) {
 
 // Python float % (2*pi)
 __device__ __forceinline__ double mod_2pi(double x) {
-    double m = fmod(x, kTwoPi);          // fmod is exact in IEEE arithmetic
+    // fmod is exact in IEEE arithmetic and returns x itself for |x| < 2*pi -- the usual case (a heading in
+    // [0, 2*pi) plus one step of rotation), which then skips the library's iterative reduction
+    double m = (__builtin_fabs(x) < kTwoPi) ? x : fmod(x, kTwoPi);
     if (m != 0.0 && m < 0.0) m += kTwoPi;
     return m;
 }
