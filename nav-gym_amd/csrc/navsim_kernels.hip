@@ -1752,15 +1752,21 @@ __global__ __launch_bounds__(256) void regen_field_kernel(navsim_state st, const
     const int b = blockIdx.x;
     if (b >= *count) return;
     const int e = list[b], tid = threadIdx.x;
-    const size_t n16 = field_bytes / 16;
-    const size_t per = (n16 + kRegenSlices - 1) / kRegenSlices;
-    const size_t lo = blockIdx.y * per, hi = (lo + per < n16) ? lo + per : n16;
-    const uint4* src = (const uint4*)(field_scratch + (size_t)b * field_bytes);
-    uint4* dst = (uint4*)((char*)st.field + (size_t)e * field_bytes);
-    for (size_t i = lo + tid; i < hi; i += 256) dst[i] = src[i];
-    if (blockIdx.y == 0)
-        for (size_t i = n16 * 16 + tid; i < field_bytes; i += 256)                      // tail bytes
-            ((char*)st.field)[(size_t)e * field_bytes + i] = field_scratch[(size_t)b * field_bytes + i];
+    const char* src_b = field_scratch + (size_t)b * field_bytes;
+    char* dst_b = (char*)st.field + (size_t)e * field_bytes;
+    if (((field_bytes | (size_t)(uintptr_t)src_b | (size_t)(uintptr_t)dst_b) & 15) == 0) {
+        const size_t n16 = field_bytes / 16;
+        const size_t per = (n16 + kRegenSlices - 1) / kRegenSlices;
+        const size_t lo = blockIdx.y * per, hi = (lo + per < n16) ? lo + per : n16;
+        const uint4* src = (const uint4*)src_b;
+        uint4* dst = (uint4*)dst_b;
+        for (size_t i = lo + tid; i < hi; i += 256) dst[i] = src[i];
+    } else {                                              // odd map sizes: every field format is 2-byte granular
+        const size_t n2 = field_bytes / 2;
+        const size_t per = (n2 + kRegenSlices - 1) / kRegenSlices;
+        const size_t lo = blockIdx.y * per, hi = (lo + per < n2) ? lo + per : n2;
+        for (size_t i = lo + tid; i < hi; i += 256) ((uint16_t*)dst_b)[i] = ((const uint16_t*)src_b)[i];
+    }
 }
 
 template <typename Field>

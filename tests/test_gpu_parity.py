@@ -356,6 +356,30 @@ def test_regen_vs_oracle(gpu, fmt, ped_model, plan):
 
 
 @pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T])
+def test_regen_odd_map_size(gpu, fmt):
+    """navsim_regen on 205 x 205 maps: per-arena field sizes that are not multiples of 16 bytes (float32)
+    and ragged edge tiles (uint16), corridor and outdoor maps mixed."""
+    E, size = 12, 205
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=3, ped_model=abi.PED_SFM, n_spawn=4,
+                                 auto_reset=1, seed=29, field_format=fmt, regen_cap=4, min_goal_dist=2.0,
+                                 max_goal_dist=6.0, spawn_clearance=0.8, ped_min_robot_dist=1.5, ped_min_goal_dist=3.0,
+                                 regen_indoor_ratio=0.5)
+    gpu.world.lidar_full_circle(cfg, 90)
+    occ = gpu.world.make_maps(E, size, 29)
+    regenerated = 0
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=3, steps=30, seed=3):
+        regenerated += min(int(rout["done"].sum()), 4)
+        _eq(g.regen().cpu().numpy(), r.regen(), "obs after regen at step %d" % t)
+    gs = g.numpy_state()
+    for k, v in r.a.items():
+        if k in gs and k not in ("field", "field_overflow"):
+            _eq(gs[k], v, "state %s" % k)
+    if fmt == abi.FIELD_F32:
+        _eq(gs["field"], r.a["field"], "field")
+    assert regenerated > 3
+
+
+@pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T])
 def test_replan_vs_oracle(gpu, fmt):
     """navsim_replan (env.py:667-680): pedestrians that reach their final waypoint get a new planned path;
     waypoints, counts and everything downstream stay bit-identical to the oracle over a rollout, including
