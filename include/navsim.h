@@ -185,6 +185,14 @@ typedef struct navsim_state {
      * drawing a straight-line goal from the spawn table, and navsim_regen refreshes it (regen_plan). */
     uint8_t* costmap;
 
+    /* Scheduling hints for the fused step, both optional and without effect on any result.  arena_cost [E]:
+     * the step writes how long each arena's workgroup lived (ticks of the chip-wide 100 MHz clock).
+     * launch_order [E]: a permutation of the arenas; workgroup b then works on arena launch_order[b].
+     * navsim_launch_order sorts arenas by descending cost, so that the longest ones start first and the
+     * kernel does not end on a few stragglers. */
+    uint32_t*      arena_cost;
+    const int32_t* launch_order;
+
     /* scratch of navsim_step_workspace_bytes(cfg) bytes.  Non-NULL selects the pooled schedule
      * (per-arena prologue -> one flat pool of 64-beam march tasks -> per-arena epilogue, DESIGN.md
      * section 6); NULL runs the whole step as one launch.  Results are identical. */
@@ -372,6 +380,10 @@ size_t navsim_ped_policy_workspace_bytes(const navsim_config* cfg);
 int    navsim_ped_policy(const navsim_config* cfg, const navsim_state* st, const navsim_policy_weights* w,
                          const float* ped_scans, float* prev_actions, double* ped_cmd, void* workspace,
                          size_t workspace_bytes, void* stream);
+
+/* order[0..n) = the arenas sorted by descending cost (ties in unspecified order): longest-first launch order
+ * for navsim_step (navsim_state.launch_order).  cost is what the step wrote to navsim_state.arena_cost. */
+int navsim_launch_order(const uint32_t* cost, int32_t* order, int32_t n, void* stream);
 
 /* First observation after reset() (env.py:822-831): scan at the current robot pose, stack filled
  * with copies, prev_pose = pose, vel = 0; sets prev_pose/prev_action/n_hist.  `mask` [E] uint8 or

@@ -29,7 +29,11 @@ constexpr int kMaxWaves = 16;
 // is built without it (no stamp executes in the measured kernel).
 #ifdef NAVSIM_STAMPS
 __device__ unsigned long long* g_stamps = nullptr;
+#ifdef NAVSIM_STAMPS_REALTIME      // chip-wide 100 MHz clock (comparable across XCDs) instead of the per-XCD shader clock
+#define NAVSIM_STAMP(i) do { if (threadIdx.x == 0 && g_stamps) g_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
 #define NAVSIM_STAMP(i) do { if (threadIdx.x == 0 && g_stamps) g_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #else
 #define NAVSIM_STAMP(i) do { } while (0)
 #endif
@@ -1193,8 +1197,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     }
     PedShared& ps = *psp;
     const Prims prims = {PEDS ? ps.seg : nullptr, PEDS ? ps.disc : nullptr, PEDS ? ps.info : nullptr};
-    const int e = blockIdx.x;
+    // longest-first launch order (a scheduling hint: which arena a workgroup takes never changes a result)
+    const int e = (MODE == kModeFused && st.launch_order) ? st.launch_order[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x;
+    unsigned long long t_begin = 0;
+    if (MODE == kModeFused && st.arena_cost && tid == 0) t_begin = __builtin_amdgcn_s_memrealtime();
     if (tile_lds_bytes) {                                       // stage the arena's tile table (coalesced)
         const uint4* src = (const uint4*)((const char*)st.tile_table + (size_t)(c.shared_field ? 0 : e) * tile_lds_bytes);
         uint4* dst = (uint4*)dyn_lds_all;
@@ -1573,8 +1580,41 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         else       { pa_g[0] = sh.act[0]; pa_g[1] = sh.act[1]; st.n_hist[e] = (n_hist + 1 < S - 1) ? n_hist + 1 : S - 1; }
         if (reset_only) st.steps[e] = 0;
         pv_g[0] = sh.rp[0]; pv_g[1] = sh.rp[1]; pv_g[2] = yaw;
+        if (MODE == kModeFused && st.arena_cost && !reset_only)
+            st.arena_cost[e] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_begin);
     }
     NAVSIM_STAMP(6);
+}
+
+// navsim_launch_order: arenas by descending cost.  One workgroup: maximum, 1024-bucket histogram on the cost
+// scaled to the maximum, exclusive scan from the expensive end, scatter.  Order inside a bucket is free.
+__global__ __launch_bounds__(1024) void launch_order_kernel(const uint32_t* __restrict__ cost, int32_t* __restrict__ order,
+                                                            int n) {
+    __shared__ unsigned hist[1024], base[1024];
+    __shared__ unsigned max_s;
+    const int tid = threadIdx.x;
+    hist[tid] = 0;
+    if (tid == 0) max_s = 1;
+    __syncthreads();
+    unsigned mx = 0;
+    for (int e = tid; e < n; e += 1024) mx = cost[e] > mx ? cost[e] : mx;
+    atomicMax(&max_s, mx);
+    __syncthreads();
+    const unsigned long long m = max_s;
+    auto bucket = [&](unsigned cst) { return 1023 - (int)(((unsigned long long)cst * 1023ull) / m); };   // 0 = costliest
+    for (int e = tid; e < n; e += 1024) atomicAdd(&hist[bucket(cost[e])], 1u);
+    __syncthreads();
+    base[tid] = hist[tid];
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                 // inclusive scan
+        unsigned v = (tid >= off) ? base[tid - off] : 0;
+        __syncthreads();
+        base[tid] += v;
+        __syncthreads();
+    }
+    base[tid] -= hist[tid];                                    // exclusive
+    __syncthreads();
+    for (int e = tid; e < n; e += 1024) order[atomicAdd(&base[bucket(cost[e])], 1u)] = e;
 }
 
 // ============================================================================================
@@ -3233,6 +3273,14 @@ int navsim_ped_policy(const navsim_config* c, const navsim_state* st, const navs
         policy_fc1_kernel<<<dim3((n + 127) / 128, 2), 256, fc1_lds, s>>>(feat, n, w->fc1_w, w->fc1_b, h1);
         policy_head_kernel<<<n, 128, 0, s>>>(*c, *st, (int)p0, n, h1, w2t, *w, prev_actions, ped_cmd);
     }
+    return launch_status();
+}
+
+int navsim_launch_order(const uint32_t* cost, int32_t* order, int32_t n, void* stream) {
+    (void)hipGetLastError();
+    if (!cost || !order || n < 0) return NAVSIM_E_ARG;
+    if (n == 0) return NAVSIM_OK;
+    launch_order_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(cost, order, n);
     return launch_status();
 }
 

@@ -109,7 +109,7 @@ class NavsimState(C.Structure):
         "robot_pose", "robot_goal", "prev_action", "prev_pose", "n_hist", "episode", "steps",
         "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist", "ped_v_pref", "ped_has_legs",
         "ped_waypoints", "ped_n_waypoints", "ped_cmd",
-        "spawn_pose", "spawn_goal", "costmap", "workspace",
+        "spawn_pose", "spawn_goal", "costmap", "arena_cost", "launch_order", "workspace",
     )]
 
 
@@ -164,6 +164,8 @@ STATE_LAYOUT = {
     "spawn_pose": ("float64", ("E", "K", 3)),
     "spawn_goal": ("float64", ("E", "K", 2)),
     "costmap": ("uint8", ("E", "Hc", "Wc")),
+    "arena_cost": ("int32", ("E",)),
+    "launch_order": ("int32", ("E",)),
 }
 
 IO_LAYOUT = {
@@ -234,6 +236,7 @@ def declare(lib, suffix=""):
     else:
         sig("navsim_ped_policy_workspace_bytes", [cfgp], C.c_size_t)
         sig("navsim_ped_policy", [cfgp, stp, C.POINTER(NavsimPolicyWeights), _P, _P, _P, _P, C.c_size_t, _P])
+        sig("navsim_launch_order", [_P, _P, i32, _P])
         sig("navsim_replan_workspace_bytes", [cfgp, i32], C.c_size_t)
         sig("navsim_replan", [cfgp, stp, i32, _P, C.c_size_t, _P])
         sig("navsim_costmap", [_P, i32, i32, i32, _P, _P])
@@ -254,7 +257,7 @@ EXPORTS = (
     "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
     "navsim_scan_threshold", "navsim_beam_table", "navsim_step_workspace_bytes", "navsim_ped_scans", "navsim_regen_workspace_bytes", "navsim_regen",
-    "navsim_costmap", "navsim_plan_workspace_bytes", "navsim_plan", "navsim_replan_workspace_bytes", "navsim_replan", "navsim_ped_policy_workspace_bytes", "navsim_ped_policy",
+    "navsim_costmap", "navsim_plan_workspace_bytes", "navsim_plan", "navsim_launch_order", "navsim_replan_workspace_bytes", "navsim_replan", "navsim_ped_policy_workspace_bytes", "navsim_ped_policy",
     "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math",
 )

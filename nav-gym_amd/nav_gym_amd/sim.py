@@ -230,6 +230,15 @@ class NavSim(object):
             nbytes = self.lib.navsim_step_workspace_bytes(C.byref(self.cfg))
             self.t["workspace"] = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=self.device)
             self.st.workspace = self.t["workspace"].data_ptr()
+        # longest-first launch order (navsim_launch_order): the step measures every arena's workgroup, every
+        # few steps the arenas are re-sorted so that the slow ones start first (NAVSIM_LPT=0 disables)
+        self.lpt_period = int(os.environ.get("NAVSIM_LPT", "8"))
+        self._steps_launched = 0
+        if self.lpt_period > 0 and self.cfg.n_envs > 1 and "arena_cost" not in self.t:
+            self.t["arena_cost"] = torch.zeros(self.cfg.n_envs, dtype=torch.int32, device=self.device)
+            self.t["launch_order"] = torch.arange(self.cfg.n_envs, dtype=torch.int32, device=self.device)
+            self.st.arena_cost = self.t["arena_cost"].data_ptr()
+            self.st.launch_order = self.t["launch_order"].data_ptr()
         E = self.cfg.n_envs
         D = self.cfg.n_scan_stack * self.cfg.n_beams + abi.OBS_TAIL
         self.obs_buf = [torch.zeros((E, D), dtype=torch.float32, device=self.device) for _ in range(2)]
@@ -262,10 +271,17 @@ class NavSim(object):
         self.cur = 1 - self.cur
         return self.obs
 
+    def _reorder(self):
+        self._steps_launched += 1
+        if "launch_order" in self.t and self._steps_launched % self.lpt_period == 0:
+            check(self.lib.navsim_launch_order(_ptr(self.t["arena_cost"]), _ptr(self.t["launch_order"]), self.cfg.n_envs,
+                                               _stream()), "navsim_launch_order")
+
     def step(self, action=None):
         """One fused launch: NavGymEnv.step for all E arenas.  `action` [E,2] (v, omega)."""
         if action is not None:
             self.action.copy_(self._as(action, self.action))
+        self._reorder()
         self._flip()
         check(self.lib.navsim_step(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), _stream()), "navsim_step")
         self.cur = 1 - self.cur
@@ -335,6 +351,7 @@ class NavSim(object):
 
     def launch_step(self):
         """step() without the action copy: inputs already resident (bench inner loop)."""
+        self._reorder()
         self._flip()
         rc = self.lib.navsim_step(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), _stream())
         if rc:

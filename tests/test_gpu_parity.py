@@ -597,7 +597,7 @@ def test_full_size_c2_properties_and_sampled_oracle(gpu, full_c2):
         c1 = sub_cfg.copy(); c1.env_index_base = int(e)
         host = {}
         for k, t in sim.t.items():
-            if k in ("field", "field_overflow", "workspace", "beam_table"):
+            if k in ("field", "field_overflow", "workspace", "beam_table", "arena_cost", "launch_order"):
                 continue
             a = t.detach().cpu().numpy()
             host[k] = a if k in ("scan_threshold", "scan_discomfort") else a[e:e + 1]
@@ -647,7 +647,7 @@ def test_full_size_c2_determinism_and_shard_invariance(gpu, full_c2):
         c = cfg.copy(); c.n_envs = hi - lo; c.env_index_base = base
         arr = {}
         for k, v in state0.items():
-            if k in ("workspace",):
+            if k in ("workspace", "arena_cost", "launch_order"):      # scheduling hints: each NavSim owns its own
                 continue
             if k == "field":
                 per = v.numel() // E
