@@ -232,7 +232,7 @@ class NavSim(object):
             self.st.workspace = self.t["workspace"].data_ptr()
         # longest-first launch order (navsim_launch_order): the step measures every arena's workgroup, every
         # few steps the arenas are re-sorted so that the slow ones start first (NAVSIM_LPT=0 disables)
-        self.lpt_period = int(os.environ.get("NAVSIM_LPT", "8"))
+        self.lpt_period = int(os.environ.get("NAVSIM_LPT", "4"))
         self._steps_launched = 0
         if self.lpt_period > 0 and self.cfg.n_envs > 1 and "arena_cost" not in self.t:
             self.t["arena_cost"] = torch.zeros(self.cfg.n_envs, dtype=torch.int32, device=self.device)

@@ -13,8 +13,8 @@ buf = torch.zeros((E, 8), dtype=torch.int64, device="cuda:0")
 L.navsim_debug_set_stamps.argtypes = [C.c_void_p]
 assert L.navsim_debug_set_stamps(C.c_void_p(buf.data_ptr())) == 0
 g = torch.Generator(device="cuda:0"); g.manual_seed(5)
-acts = torch.rand((12, E, 2), generator=g, device="cuda:0", dtype=torch.float64); acts[..., 0] *= 0.5; acts[..., 1] = acts[..., 1] * 1.28 - 0.64
-for t in range(12):
+acts = torch.rand((20, E, 2), generator=g, device="cuda:0", dtype=torch.float64); acts[..., 0] *= 0.5; acts[..., 1] = acts[..., 1] * 1.28 - 0.64
+for t in range(20):
     sim.io.action = acts[t].data_ptr(); sim.launch_step(); torch.cuda.synchronize()
 b = buf.cpu().numpy()
 s, e = b[:, 0].astype(np.float64), b[:, 6].astype(np.float64)
