@@ -476,6 +476,50 @@ def test_policy_vs_reference_trace(gpu, name):
     assert checked > 50 and worst < 1e-5, (checked, worst)
 
 
+def test_launch_order_is_result_neutral(gpu, monkeypatch):
+    """navsim_launch_order returns the arenas by descending cost, and stepping with an arbitrary launch order
+    (here: reversed, then the measured longest-first order) gives bit-identical outputs and state to the
+    identity order -- which workgroup takes an arena is a scheduling hint only."""
+    torch = gpu.torch
+    cost = torch.randint(0, 50000, (5000,), dtype=torch.int32, device=gpu.dev)
+    order = torch.empty(5000, dtype=torch.int32, device=gpu.dev)
+    gpu.lib.check(gpu.lib.load().navsim_launch_order(cost.data_ptr(), order.data_ptr(), 5000, None), "launch_order")
+    o = order.cpu().numpy()
+    assert np.array_equal(np.sort(o), np.arange(5000))
+    c = cost.cpu().numpy()[o].astype(np.int64)
+    assert (np.diff(c) <= c.max() // 1023 + 1).all()              # descending up to one histogram bucket
+    E, size = 64, 240
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=6, ped_model=abi.PED_SFM, n_spawn=8,
+                                 auto_reset=1, seed=5, field_format=abi.FIELD_U16T)
+    gpu.world.lidar_1081(cfg)
+    occ = gpu.world.make_maps(E, size, 5)
+    arrays = gpu.world.make_world(cfg, occ, n_peds=5, device=gpu.dev)
+    from nav_gym_amd import robots
+    for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
+        arrays[key] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array("keti", name)))
+    monkeypatch.setenv("NAVSIM_LPT", "0")
+    plain = gpu.sim.NavSim(cfg, arrays)
+    monkeypatch.setenv("NAVSIM_LPT", "3")
+    lpt = gpu.sim.NavSim(cfg, arrays)
+    lpt.t["launch_order"].copy_(torch.arange(E - 1, -1, -1, dtype=torch.int32, device=gpu.dev))
+    assert "launch_order" not in plain.t
+    _eq(plain.reset_obs().cpu().numpy(), lpt.reset_obs().cpu().numpy(), "reset obs")
+    g = torch.Generator(device=gpu.dev); g.manual_seed(2)
+    for t in range(10):
+        act = torch.rand((E, 2), generator=g, device=gpu.dev, dtype=torch.float64)
+        act[:, 0] *= 0.5; act[:, 1] = act[:, 1] * 1.28 - 0.64
+        o1, out1 = plain.step(act)
+        o2, out2 = lpt.step(act)
+        assert torch.equal(o1, o2), t
+        for k in out1:
+            assert torch.equal(out1[k], out2[k]), (k, t)
+    s1, s2 = plain.numpy_state(), lpt.numpy_state()
+    for k in s1:
+        _eq(s1[k], s2[k], "state %s" % k)
+    assert (lpt.t["arena_cost"] > 0).all()
+    assert not np.array_equal(lpt.t["launch_order"].cpu().numpy(), np.arange(E - 1, -1, -1))      # re-sorted by now
+
+
 def test_config1_single_env_64_beams(gpu):
     """BASELINE config 1: 1 env, 64-beam lidar, 100x100 static map, no pedestrians."""
     cfg = gpu.lib.default_config(n_envs=1, map_h=100, map_w=100, n_spawn=4, auto_reset=0, seed=7)
