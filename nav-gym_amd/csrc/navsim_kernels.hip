@@ -2753,9 +2753,27 @@ int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_s
     const char* v = getenv("NAVSIM_STEP_VARIANT");
     if (v && sscanf(v, "%dx%d", &block, &rays) != 2) { block = 0; rays = 0; }
     if (!block) {
+        // Threads per arena.  With >= 12 arenas per CU the chip is kept full by 256-thread workgroups (8 per
+        // CU, several generations).  With fewer arenas a launch is one generation whose length is a
+        // workgroup's own march, i.e. beams per thread: wider workgroups shorten it (measured, c2 world:
+        // 2048 arenas 14.4 / 16.4 / 13.7 M env-steps/s for 256 / 512 / 1024 threads; 1024 arenas
+        // 8.8 / 11.3 / 11.6; 512 arenas 5.2 / 6.7 / 7.3; 4096 arenas 19.5 / 17.4 / -).
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0, v2 = 0;
+            if (hipGetDevice(&dev) == hipSuccess &&
+                hipDeviceGetAttribute(&v2, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v2 > 0)
+                n_cu = v2;
+            else
+                n_cu = 256;
+        }
         const int B = c->n_beams;
-        if (B <= 64) { block = 64; rays = 1; }
-        else { block = 256; rays = 1; }               // profiles/tune_variants.py
+        const long per_cu_x2 = 2L * c->n_envs / n_cu;            // arenas per CU, doubled
+        rays = 1;
+        if (B <= 64) block = 64;
+        else if (per_cu_x2 >= 24 || B <= 256) block = 256;
+        else if (per_cu_x2 >= 12 || B <= 512) block = 512;
+        else block = 1024;
     }
 #define NAVSIM_VARIANT(BK, RR) if (block == BK && rays == RR) { launch_step<BK, RR, kModeFused>(c, st, io, reset_only, mask, nullptr, nullptr, nullptr, s); return launch_status(); }
     NAVSIM_VARIANT(64, 1)
@@ -2769,6 +2787,8 @@ int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_s
     NAVSIM_VARIANT(256, 2)
     NAVSIM_VARIANT(256, 5)
     NAVSIM_VARIANT(512, 0)
+    NAVSIM_VARIANT(768, 1)
+    NAVSIM_VARIANT(1024, 1)
 #undef NAVSIM_VARIANT
     return NAVSIM_E_UNSUPPORTED;
 }
