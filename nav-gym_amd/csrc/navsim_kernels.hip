@@ -548,14 +548,26 @@ struct StepShared {
 };
 constexpr size_t kPoolEnvBytes = 512;     // StepShared slot per arena in the step workspace
 static_assert(sizeof(StepShared) <= kPoolEnvBytes, "StepShared must fit its workspace slot");
-// only instantiated by the pedestrian variants of the kernel (LDS budget: 8 arenas per CU without)
+// Pedestrian scratch of the pedestrian variants of the kernel, carved out of dynamic LDS behind the scan's
+// dir / rng area and sized by cfg.max_peds (N), not by the compiled maximum: 136 N + 32 bytes, so that a
+// 20-pedestrian world still fits 8 arenas per CU (the static 64-pedestrian layout allowed 7).
 struct PedShared {
-    float seg[4 * NAVSIM_MAX_PEDS][4];
-    float disc[2 * NAVSIM_MAX_PEDS][2];
-    double ax[NAVSIM_MAX_PEDS + 1], ay[NAVSIM_MAX_PEDS + 1];
-    double avx[NAVSIM_MAX_PEDS + 1], avy[NAVSIM_MAX_PEDS + 1];
-    float info[6 * NAVSIM_MAX_PEDS];         // merge_prims_culled_core scratch: in-range flag per primitive
+    double *ax, *ay, *avx, *avy;             // [N + 1] agent positions / velocities at time t (robot last)
+    float (*seg)[4];                         // [4 N] rectangle edges seen by the lidar ...
+    float (*disc)[2];                        // [2 N] ... leg discs (stored right behind seg)
+    float* info;                             // [6 N] merge_prims_culled_core scratch: in-range flag per primitive
 };
+__host__ __device__ inline size_t ped_lds_bytes(int N) { return (size_t)136 * N + 32; }
+__device__ __forceinline__ PedShared ped_lds_carve(char* base, int N) {
+    PedShared ps;
+    double* d = (double*)base;
+    ps.ax = d; ps.ay = d + (N + 1); ps.avx = d + 2 * (N + 1); ps.avy = d + 3 * (N + 1);
+    float* f = (float*)(d + 4 * (N + 1));
+    ps.seg = (float(*)[4])f;
+    ps.disc = (float(*)[2])(f + 16 * N);
+    ps.info = f + 20 * N;
+    return ps;
+}
 struct Prims { const float (*seg)[4]; const float (*disc)[2]; float* info; };
 
 template <int BLOCK>
@@ -1190,13 +1202,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     extern __shared__ __attribute__((aligned(16))) char dyn_lds_all[];
     char* dyn_lds = dyn_lds_all + tile_lds_bytes;
     const uint32_t* tiles_lds = tile_lds_bytes ? (const uint32_t*)dyn_lds_all : nullptr;
-    PedShared* psp = nullptr;
-    if constexpr (PEDS) {
-        __shared__ PedShared ps_storage;
-        psp = &ps_storage;
-    }
-    PedShared& ps = *psp;
-    const Prims prims = {PEDS ? ps.seg : nullptr, PEDS ? ps.disc : nullptr, PEDS ? ps.info : nullptr};
+    PedShared ps = {};
+    if constexpr (PEDS) ps = ped_lds_carve(dyn_lds + ((dyn_lds_bytes + 15u) & ~15u), c.max_peds);
+    const Prims prims = {ps.seg, ps.disc, ps.info};
     // longest-first launch order (a scheduling hint: which arena a workgroup takes never changes a result)
     const int e = (MODE == kModeFused && st.launch_order) ? st.launch_order[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x;
@@ -1232,7 +1240,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         for (int i = tid; i < (int)(sizeof(StepShared) / 4); i += BLOCK) ((int*)&sh)[i] = ((const int*)slot)[i];
         if constexpr (PEDS) {
             const int* src = (const int*)(ws_prims + (size_t)e * kPrimWords * 4);
-            for (int i = tid; i < kPrimWords; i += BLOCK) ((int*)&ps)[i] = src[i];     // seg, then disc
+            for (int i = tid; i < 20 * c.max_peds; i += BLOCK) ((int*)ps.seg)[i] = src[i];   // seg, then disc
         }
         __syncthreads();
     }
@@ -1452,7 +1460,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         for (int i = tid; i < (int)(sizeof(StepShared) / 4); i += BLOCK) ((int*)slot)[i] = ((const int*)&sh)[i];
         if constexpr (PEDS) {
             int* dst = (int*)(ws_prims + (size_t)e * kPrimWords * 4);
-            for (int i = tid; i < kPrimWords; i += BLOCK) dst[i] = ((const int*)&ps)[i];
+            for (int i = tid; i < 20 * c.max_peds; i += BLOCK) dst[i] = ((const int*)ps.seg)[i];
         }
         return;
     }
@@ -2697,6 +2705,7 @@ void launch_step(const navsim_config* c, const navsim_state* st, const navsim_st
     }
     const size_t lds_scan = lds;
     lds += tile_bytes;
+    if (peds) lds = ((lds + 15) & ~(size_t)15) + ped_lds_bytes(c->max_peds);       // PedShared behind dir / rng
     if (const char* pad = getenv("NAVSIM_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments only
     if (c->field_format == NAVSIM_FIELD_U16T) {
         if (peds) navsim_step_kernel<BLOCK, R, true, FieldU16T, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds_scan, (unsigned)tile_bytes);
