@@ -1190,6 +1190,163 @@ void pool_scan_kernel(navsim_config c, navsim_state st, char* __restrict__ ws_en
 // the observation row and state; 3 = the same tail for re-scanned arenas.
 enum { kModeFused = 0, kModePre = 1, kModePost = 2, kModeFinal = 3 };
 
+// Phase 1 for the pedestrians of one arena (env.py:617-693 with the build-defined social force or external
+// commands): waypoint pop, forces / integration, new goal, leg odometry, state.  Called by every thread of the
+// workgroup (it synchronises); pedestrian i lives on thread i.  Shared by the fused step kernel and by
+// ped_update_kernel, which runs it on one wavefront per arena ahead of the step.
+template <int BLOCK, typename Field>
+__device__ __forceinline__ void ped_phase(const navsim_config& c, const navsim_state& st, const Field& field, int e,
+                                          int n, int tid, bool is_ped, size_t pq, double dt, uint64_t genv,
+                                          uint64_t steps_now, const double* old_rp, double prev_v, const PedShared& ps,
+                                          char* pair_scratch, unsigned pair_bytes, double (&pp)[3], double (&pvel)[2]) {
+    const int N = c.max_peds, P = NAVSIM_MAX_WAYPOINTS;
+    (void)N;
+    double* wp = st.ped_waypoints ? st.ped_waypoints + (pq * P) * 2 : nullptr;
+    int nw = 1;
+    if (is_ped) {
+        nw = st.ped_n_waypoints[pq];
+        while (nw > 1) {                                   // env.py:633-642
+            double ddx = pp[0] - wp[0], ddy = pp[1] - wp[1];
+            if (sqrt(ddx * ddx + ddy * ddy) < 1.0) {
+                for (int k = 0; k + 1 < nw; ++k) { wp[2 * k] = wp[2 * k + 2]; wp[2 * k + 1] = wp[2 * k + 3]; }
+                nw -= 1;
+            } else break;
+        }
+    }
+    if (c.ped_model == NAVSIM_PED_SFM) {
+        // stage every agent's position / velocity at time t (pedestrians, then the robot)
+        if (is_ped) { ps.ax[tid] = pp[0]; ps.ay[tid] = pp[1]; ps.avx[tid] = pvel[0]; ps.avy[tid] = pvel[1]; }
+        if (tid == 0) {
+            double s, cs;
+            nv::sincos(old_rp[2], s, cs);
+            ps.ax[n] = old_rp[0]; ps.ay[n] = old_rp[1];
+            ps.avx[n] = prev_v * cs; ps.avy[n] = prev_v * s;
+        }
+        __syncthreads();
+        // the n*(n+1) pair terms are independent: spread them over the whole workgroup (LDS scratch
+        // = the scan's dir/rng area, free until the march), then every pedestrian adds its row in
+        // partner order -- the same sums, in the same order, as a sequential loop
+        double2* pair = (double2*)pair_scratch;
+        const bool pair_par = pair_bytes >= (unsigned)(n * (n + 1)) * sizeof(double2) && n > 1;
+        if (pair_par) {
+            for (int t = tid; t < n * (n + 1); t += BLOCK) {
+                int i = t / (n + 1), j = t - i * (n + 1);
+                double fx = 0.0, fy = 0.0;
+                if (j != i)
+                    sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
+                pair[t] = make_double2(fx, fy);
+            }
+            __syncthreads();
+        }
+        if (is_ped) {
+            const int i = tid;
+            double vpref = st.ped_v_pref[pq];
+            double ex = wp[0] - ps.ax[i], ey = wp[1] - ps.ay[i];
+            double L = sqrt(ex * ex + ey * ey);
+            if (L > 1e-9) { ex = ex / L; ey = ey / L; } else { ex = 0.0; ey = 0.0; }
+            double fdx = (vpref * ex - ps.avx[i]) / c.sfm_tau;
+            double fdy = (vpref * ey - ps.avy[i]) / c.sfm_tau;
+            double fsx = 0.0, fsy = 0.0;
+            for (int j = 0; j <= n; ++j) {
+                if (j == i) continue;
+                double fx, fy;
+                if (pair_par) { double2 f = pair[i * (n + 1) + j]; fx = f.x; fy = f.y; }
+                else sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
+                fsx += fx;
+                fsy += fy;
+            }
+            double fox = 0.0, foy = 0.0;
+            {
+                const int H = c.map_h, W = c.map_w;
+                int ci, cj;
+                nv::xy_to_ij(ps.ax[i], ps.ay[i], c, ci, cj);
+                ci = ci > W - 1 ? W - 1 : ci;
+                cj = cj > H - 1 ? H - 1 : cj;
+                int il_ = ci > 0 ? ci - 1 : 0, ir = ci < W - 1 ? ci + 1 : W - 1;
+                int jl = cj > 0 ? cj - 1 : 0, jr = cj < H - 1 ? cj + 1 : H - 1;
+                double d = (double)field.at(ci, cj) * c.resolution;
+                double gx = (double)field.at(ir, cj) - (double)field.at(il_, cj);
+                double gy = (double)field.at(ci, jr) - (double)field.at(ci, jl);
+                double gl = sqrt(gx * gx + gy * gy);
+                if (gl > 0.0) {
+                    double mag = nv::exp_neg(-(d - c.sfm_agent_radius) / c.sfm_sigma_obstacle);
+                    fox = mag * (gx / gl);
+                    foy = mag * (gy / gl);
+                }
+            }
+            double accx = c.sfm_k_desired * fdx + c.sfm_k_social * fsx + c.sfm_k_obstacle * fox;
+            double accy = c.sfm_k_desired * fdy + c.sfm_k_social * fsy + c.sfm_k_obstacle * foy;
+            double vx = ps.avx[i] + accx * dt;
+            double vy = ps.avy[i] + accy * dt;
+            double sp = sqrt(vx * vx + vy * vy);
+            if (sp > vpref) {
+                double k = (sp > 0.0) ? vpref / sp : 0.0;
+                vx = vx * k; vy = vy * k;
+            }
+            pp[0] = pp[0] + vx * dt;
+            pp[1] = pp[1] + vy * dt;
+            double sp2 = sqrt(vx * vx + vy * vy);
+            if (sp2 > 1e-6) pp[2] = nv::mod_2pi(nv::atan2_(vy, vx));
+            pvel[0] = vx; pvel[1] = vy;
+        }
+    } else if (c.ped_model == NAVSIM_PED_EXTERNAL && is_ped) {
+        const double* cmd = st.ped_cmd + pq * 2;
+        nv::set_vel(pp, cmd[0], cmd[1], dt, 0.0, pvel);     // env.py:662
+    }
+    if (is_ped) {
+        // ---- new goal at the final waypoint (env.py:667-680): table draw, or wait for navsim_replan
+        double ddx = pp[0] - wp[2 * (nw - 1)], ddy = pp[1] - wp[2 * (nw - 1) + 1];
+        if (sqrt(ddx * ddx + ddy * ddy) < 0.5 && c.n_spawn > 0 && st.spawn_pose && !st.costmap) {
+            uint64_t h = nv::hash4(c.seed, genv, (uint64_t)tid + 1000, steps_now);
+            for (int tries = 0; tries < c.n_spawn; ++tries) {
+                int idx = (int)((h + (uint64_t)tries) % (uint64_t)c.n_spawn);
+                const double* cand = st.spawn_pose + ((size_t)e * c.n_spawn + idx) * 3;
+                double gx = cand[0] - pp[0], gy = cand[1] - pp[1];
+                if (sqrt(gx * gx + gy * gy) > 10.0) {
+                    wp[0] = cand[0]; wp[1] = cand[1]; nw = 1;
+                    break;
+                }
+            }
+        }
+        st.ped_n_waypoints[pq] = nw;
+        // ---- leg odometry, then the pedestrian's obs yaw (env.py:683-693)
+        double dist[3] = {st.ped_dist[pq * 3], st.ped_dist[pq * 3 + 1], st.ped_dist[pq * 3 + 2]};
+        nv::leg_odometry(pp, pvel, st.ped_prev_yaw[pq], dt, dist);
+        st.ped_dist[pq * 3] = dist[0]; st.ped_dist[pq * 3 + 1] = dist[1]; st.ped_dist[pq * 3 + 2] = dist[2];
+        st.ped_prev_yaw[pq] = nv::wrap_pi(pp[2]);
+        st.ped_pose[pq * 3] = pp[0]; st.ped_pose[pq * 3 + 1] = pp[1]; st.ped_pose[pq * 3 + 2] = pp[2];
+        st.ped_vel[pq * 2] = pvel[0]; st.ped_vel[pq * 2 + 1] = pvel[1];
+    }
+}
+
+// The pedestrians of every arena, one wavefront per arena, launched ahead of the fused step.  Inside the step
+// this phase is a third of a workgroup's lifetime during which three of its four wavefronts only hold their
+// slots; here an arena costs one wavefront.  Same device function, same results.
+template <typename Field>
+__global__ __launch_bounds__(64) void ped_update_kernel(navsim_config c, navsim_state st) {
+    extern __shared__ __attribute__((aligned(16))) char ped_dyn[];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const int N = c.max_peds;
+    int n = st.n_peds[e];
+    n = n > N ? N : n;
+    if (n <= 0) return;
+    const unsigned pair_bytes = (unsigned)(((size_t)N * (N + 1) * sizeof(double2) + 15) & ~(size_t)15);
+    const PedShared ps = ped_lds_carve(ped_dyn + pair_bytes, N);
+    const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, c.map_h, c.map_w);
+    const double old_rp[3] = {st.robot_pose[3 * (size_t)e], st.robot_pose[3 * (size_t)e + 1], st.robot_pose[3 * (size_t)e + 2]};
+    const double prev_v = st.prev_action[2 * (size_t)e];
+    const size_t pq = (size_t)e * N + (tid < n ? tid : 0);
+    const bool is_ped = tid < n;
+    double pp[3] = {0.0, 0.0, 0.0}, pvel[2] = {0.0, 0.0};
+    if (is_ped) {
+        pp[0] = st.ped_pose[pq * 3]; pp[1] = st.ped_pose[pq * 3 + 1]; pp[2] = st.ped_pose[pq * 3 + 2];
+        pvel[0] = st.ped_vel[pq * 2]; pvel[1] = st.ped_vel[pq * 2 + 1];
+    }
+    // the step increments steps[e] before anything else (env.py:592); it has not run yet
+    ped_phase<64, Field>(c, st, field, e, n, tid, is_ped, pq, c.time_step, (uint64_t)(c.env_index_base + e),
+                         (uint64_t)st.steps[e] + 1, old_rp, prev_v, ps, ped_dyn, pair_bytes, pp, pvel);
+}
+
 template <int BLOCK, int R, bool PEDS, typename Field, int MODE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void navsim_step_kernel(navsim_config c, navsim_state st,
                                                             navsim_step_io io, int reset_only,
@@ -1198,6 +1355,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                                             float* __restrict__ ws_ranges, unsigned dyn_lds_bytes,
                                                             unsigned tile_lds_bytes) {
     __shared__ StepShared sh;
+    const int peds_done = (reset_only >> 1) & 1;     // the pedestrians were advanced by ped_update_kernel
+    reset_only &= 1;
     // dynamic LDS: [analytic tile table of the arena, tile_lds_bytes][float2 dir[B], float rng[B]]
     extern __shared__ __attribute__((aligned(16))) char dyn_lds_all[];
     char* dyn_lds = dyn_lds_all + tile_lds_bytes;
@@ -1217,7 +1376,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         // visibility: every path reaches a __syncthreads() before the first scan
     }
     const int B = c.n_beams, S = c.n_scan_stack, N = c.max_peds, D = S * B + 7;
-    const int P = NAVSIM_MAX_WAYPOINTS;
     const double dt = c.time_step;
     const uint64_t genv = (uint64_t)(c.env_index_base + e);
     const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, c.map_h, c.map_w);
@@ -1285,127 +1443,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             sh.rp[0] = p[0]; sh.rp[1] = p[1]; sh.rp[2] = p[2];
         }
     } else if (!reset_only) {
-        double* wp = st.ped_waypoints ? st.ped_waypoints + (pq * P) * 2 : nullptr;
-        int nw = 1;
-        if (is_ped) {
-            nw = st.ped_n_waypoints[pq];
-            while (nw > 1) {                                   // env.py:633-642
-                double ddx = pp[0] - wp[0], ddy = pp[1] - wp[1];
-                if (sqrt(ddx * ddx + ddy * ddy) < 1.0) {
-                    for (int k = 0; k + 1 < nw; ++k) { wp[2 * k] = wp[2 * k + 2]; wp[2 * k + 1] = wp[2 * k + 3]; }
-                    nw -= 1;
-                } else break;
-            }
-        }
-        if (c.ped_model == NAVSIM_PED_SFM) {
-            // stage every agent's position / velocity at time t (pedestrians, then the robot)
-            if (is_ped) { ps.ax[tid] = pp[0]; ps.ay[tid] = pp[1]; ps.avx[tid] = pvel[0]; ps.avy[tid] = pvel[1]; }
-            if (tid == 0) {
-                double s, cs;
-                nv::sincos(sh.old_rp[2], s, cs);
-                ps.ax[n] = sh.old_rp[0]; ps.ay[n] = sh.old_rp[1];
-                ps.avx[n] = pa_g[0] * cs; ps.avy[n] = pa_g[0] * s;
-            }
-            __syncthreads();
-            // the n*(n+1) pair terms are independent: spread them over the whole workgroup (LDS scratch
-            // = the scan's dir/rng area, free until the march), then every pedestrian adds its row in
-            // partner order -- the same sums, in the same order, as a sequential loop
-            double2* pair = (double2*)dyn_lds;
-            const bool pair_par = dyn_lds_bytes >= (unsigned)(n * (n + 1)) * sizeof(double2) && n > 1;
-            if (pair_par) {
-                for (int t = tid; t < n * (n + 1); t += BLOCK) {
-                    int i = t / (n + 1), j = t - i * (n + 1);
-                    double fx = 0.0, fy = 0.0;
-                    if (j != i)
-                        sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
-                    pair[t] = make_double2(fx, fy);
-                }
-                __syncthreads();
-            }
-            if (is_ped) {
-                const int i = tid;
-                double vpref = st.ped_v_pref[pq];
-                double ex = wp[0] - ps.ax[i], ey = wp[1] - ps.ay[i];
-                double L = sqrt(ex * ex + ey * ey);
-                if (L > 1e-9) { ex = ex / L; ey = ey / L; } else { ex = 0.0; ey = 0.0; }
-                double fdx = (vpref * ex - ps.avx[i]) / c.sfm_tau;
-                double fdy = (vpref * ey - ps.avy[i]) / c.sfm_tau;
-                double fsx = 0.0, fsy = 0.0;
-                for (int j = 0; j <= n; ++j) {
-                    if (j == i) continue;
-                    double fx, fy;
-                    if (pair_par) { double2 f = pair[i * (n + 1) + j]; fx = f.x; fy = f.y; }
-                    else sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
-                    fsx += fx;
-                    fsy += fy;
-                }
-                double fox = 0.0, foy = 0.0;
-                {
-                    const int H = c.map_h, W = c.map_w;
-                    int ci, cj;
-                    nv::xy_to_ij(ps.ax[i], ps.ay[i], c, ci, cj);
-                    ci = ci > W - 1 ? W - 1 : ci;
-                    cj = cj > H - 1 ? H - 1 : cj;
-                    int il_ = ci > 0 ? ci - 1 : 0, ir = ci < W - 1 ? ci + 1 : W - 1;
-                    int jl = cj > 0 ? cj - 1 : 0, jr = cj < H - 1 ? cj + 1 : H - 1;
-                    double d = (double)field.at(ci, cj) * c.resolution;
-                    double gx = (double)field.at(ir, cj) - (double)field.at(il_, cj);
-                    double gy = (double)field.at(ci, jr) - (double)field.at(ci, jl);
-                    double gl = sqrt(gx * gx + gy * gy);
-                    if (gl > 0.0) {
-                        double mag = nv::exp_neg(-(d - c.sfm_agent_radius) / c.sfm_sigma_obstacle);
-                        fox = mag * (gx / gl);
-                        foy = mag * (gy / gl);
-                    }
-                }
-                double accx = c.sfm_k_desired * fdx + c.sfm_k_social * fsx + c.sfm_k_obstacle * fox;
-                double accy = c.sfm_k_desired * fdy + c.sfm_k_social * fsy + c.sfm_k_obstacle * foy;
-                double vx = ps.avx[i] + accx * dt;
-                double vy = ps.avy[i] + accy * dt;
-                double sp = sqrt(vx * vx + vy * vy);
-                if (sp > vpref) {
-                    double k = (sp > 0.0) ? vpref / sp : 0.0;
-                    vx = vx * k; vy = vy * k;
-                }
-                pp[0] = pp[0] + vx * dt;
-                pp[1] = pp[1] + vy * dt;
-                double sp2 = sqrt(vx * vx + vy * vy);
-                if (sp2 > 1e-6) pp[2] = nv::mod_2pi(nv::atan2_(vy, vx));
-                pvel[0] = vx; pvel[1] = vy;
-            }
-        } else if (c.ped_model == NAVSIM_PED_EXTERNAL && is_ped) {
-            const double* cmd = st.ped_cmd + pq * 2;
-            nv::set_vel(pp, cmd[0], cmd[1], dt, 0.0, pvel);     // env.py:662
-        }
+        if (!peds_done)
+            ped_phase<BLOCK, Field>(c, st, field, e, n, tid, is_ped, pq, dt, genv, (uint64_t)st.steps[e], sh.old_rp, pa_g[0],
+                                    ps, dyn_lds, dyn_lds_bytes, pp, pvel);
         // ---- robot (env.py:664)
         if (tid == 0) {
             double p[3] = {sh.old_rp[0], sh.old_rp[1], sh.old_rp[2]};
             nv::set_vel(p, sh.act[0], sh.act[1], dt, c.axle_offset, nullptr);
             sh.rp[0] = p[0]; sh.rp[1] = p[1]; sh.rp[2] = p[2];
-        }
-        if (is_ped) {
-            // ---- new goal at the final waypoint (env.py:667-680): table draw, or wait for navsim_replan
-            double ddx = pp[0] - wp[2 * (nw - 1)], ddy = pp[1] - wp[2 * (nw - 1) + 1];
-            if (sqrt(ddx * ddx + ddy * ddy) < 0.5 && c.n_spawn > 0 && st.spawn_pose && !st.costmap) {
-                uint64_t h = nv::hash4(c.seed, genv, (uint64_t)tid + 1000, (uint64_t)st.steps[e]);
-                for (int tries = 0; tries < c.n_spawn; ++tries) {
-                    int idx = (int)((h + (uint64_t)tries) % (uint64_t)c.n_spawn);
-                    const double* cand = st.spawn_pose + ((size_t)e * c.n_spawn + idx) * 3;
-                    double gx = cand[0] - pp[0], gy = cand[1] - pp[1];
-                    if (sqrt(gx * gx + gy * gy) > 10.0) {
-                        wp[0] = cand[0]; wp[1] = cand[1]; nw = 1;
-                        break;
-                    }
-                }
-            }
-            st.ped_n_waypoints[pq] = nw;
-            // ---- leg odometry, then the pedestrian's obs yaw (env.py:683-693)
-            double dist[3] = {st.ped_dist[pq * 3], st.ped_dist[pq * 3 + 1], st.ped_dist[pq * 3 + 2]};
-            nv::leg_odometry(pp, pvel, st.ped_prev_yaw[pq], dt, dist);
-            st.ped_dist[pq * 3] = dist[0]; st.ped_dist[pq * 3 + 1] = dist[1]; st.ped_dist[pq * 3 + 2] = dist[2];
-            st.ped_prev_yaw[pq] = nv::wrap_pi(pp[2]);
-            st.ped_pose[pq * 3] = pp[0]; st.ped_pose[pq * 3 + 1] = pp[1]; st.ped_pose[pq * 3 + 2] = pp[2];
-            st.ped_vel[pq * 2] = pvel[0]; st.ped_vel[pq * 2 + 1] = pvel[1];
         }
     } else {
         if (tid == 0) { sh.rp[0] = sh.old_rp[0]; sh.rp[1] = sh.old_rp[1]; sh.rp[2] = sh.old_rp[2]; }
@@ -2707,6 +2752,21 @@ void launch_step(const navsim_config* c, const navsim_state* st, const navsim_st
     lds += tile_bytes;
     if (peds) lds = ((lds + 15) & ~(size_t)15) + ped_lds_bytes(c->max_peds);       // PedShared behind dir / rng
     if (const char* pad = getenv("NAVSIM_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments only
+    // pedestrians ahead of the step, one wavefront per arena (NAVSIM_PED_SPLIT=0: inside the step as before)
+    // (pays when the chip runs several generations of arenas: c3 13.2 -> 14.0 M env-steps/s; a 512-arena
+    // launch is latency-bound and loses 2 % to the extra kernel, so small batches keep the fused form)
+    if (MODE == kModeFused && peds && !reset_only && c->max_peds <= 56) {                        // <= 64 KB of LDS
+        const char* v = getenv("NAVSIM_PED_SPLIT");             // "0" never, "1" always, unset: large batches
+        const int split = v ? (v[0] != '0') : (c->n_envs >= 3072);
+        if (split) {
+            const size_t pl = (((size_t)c->max_peds * (c->max_peds + 1) * sizeof(double2) + 15) & ~(size_t)15) +
+                              ped_lds_bytes(c->max_peds);
+            if (c->field_format == NAVSIM_FIELD_U16T)      ped_update_kernel<FieldU16T><<<c->n_envs, 64, pl, s>>>(*c, *st);
+            else if (c->field_format == NAVSIM_FIELD_F32S) ped_update_kernel<FieldF32S><<<c->n_envs, 64, pl, s>>>(*c, *st);
+            else                                           ped_update_kernel<FieldF32><<<c->n_envs, 64, pl, s>>>(*c, *st);
+            reset_only |= 2;
+        }
+    }
     if (c->field_format == NAVSIM_FIELD_U16T) {
         if (peds) navsim_step_kernel<BLOCK, R, true, FieldU16T, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds_scan, (unsigned)tile_bytes);
         else      navsim_step_kernel<BLOCK, R, false, FieldU16T, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds_scan, (unsigned)tile_bytes);

@@ -265,6 +265,26 @@ def test_step_rollout_vs_oracle(gpu, ped_model, S, auto_reset, fmt):
     assert resets > 0
 
 
+@pytest.mark.parametrize("ped_model", [abi.PED_SFM, abi.PED_EXTERNAL])
+def test_step_rollout_with_split_pedestrian_kernel(gpu, ped_model, monkeypatch):
+    """Large batches advance the pedestrians in ped_update_kernel ahead of the fused step (one wavefront per
+    arena); forced here on a small batch: every output and state array still equals the oracle's."""
+    monkeypatch.setenv("NAVSIM_PED_SPLIT", "1")
+    E, size, N = 24, 240, 8
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, n_scan_stack=2, ped_model=ped_model,
+                                 auto_reset=1, n_spawn=8, seed=13, field_format=abi.FIELD_U16T)
+    gpu.world.lidar_1081(cfg)
+    occ = gpu.world.make_maps(E, size, 13)
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=7, steps=40, seed=5):
+        for k in rout:
+            _eq(gout[k], rout[k], "%s at step %d" % (k, t))
+        _eq(go, ro, "obs at step %d" % t)
+    gs = g.numpy_state()
+    for k, v in r.a.items():
+        if k in gs and k not in ("field", "field_overflow"):
+            _eq(gs[k], v, "state %s" % k)
+
+
 def test_packed_field_decodes_to_float_field(gpu):
     """uint16 tiles: sqrtf(d2) must be the float32 field bit for bit; odd sizes exercise edge tiles."""
     for size, n in ((100, 2), (253, 2), (500, 1)):
