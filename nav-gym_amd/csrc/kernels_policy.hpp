@@ -1,0 +1,229 @@
+// kernels_policy.hpp -- pedestrian control block with the HumanPolicy actor (row a10).
+// Part of the single translation unit navsim_kernels.hip (included inside its anonymous namespace;
+// not a standalone header).
+
+// ============================================================================================
+// Pedestrian control block with the HumanPolicy actor (env.py:617-662, human_policy.py:19-52).
+// Specification: oracle/navsim_ref.c policy_actor -- every dot product is a float32 fused-multiply-add
+// chain in index order from 0, bias added last.  That is exactly what v_mfma_f32_32x32x2_f32 computes
+// along k, so the 4096 -> 256 layer runs on the matrix cores and still equals the oracle bit for bit.
+//   policy_features_kernel   one workgroup per pedestrian: clip / scale, conv1 + ReLU, conv2 + ReLU
+//   policy_fc1_kernel        [P,4096] x [4096,256] on MFMA (128 x 128 tiles, LDS double buffer)
+//   policy_head_kernel       waypoint pop, local goal, 260 -> 128, the two heads, clip, * v_pref
+// ============================================================================================
+constexpr int kPolFeat = 4096, kPolH1 = 256, kPolH2 = 128, kPolIn2 = 260;
+
+__global__ __launch_bounds__(256) void policy_features_kernel(const float* __restrict__ scans, int p0, int n_ped,
+                                                              const float* __restrict__ w1, const float* __restrict__ b1,
+                                                              const float* __restrict__ w2, const float* __restrict__ b2,
+                                                              float* __restrict__ feat) {
+    __shared__ float x[520];                 // x[1 + i] = input i, x[0] = left padding
+    __shared__ float o1[32][258];            // o1[c][1 + t], zero padding at both ends
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x;
+    if (p >= n_ped) return;
+    const float* scan = scans + (size_t)(p0 + p) * 512;
+    for (int k = tid; k < 512; k += 256) {                      // env.py:629-630
+        double v = (double)scan[k];
+        v = v < 0.0 ? 0.0 : (v > 6.0 ? 6.0 : v);
+        x[1 + k] = (float)(v / 6.0 - 0.5);
+    }
+    if (tid == 0) x[0] = 0.0f;
+    if (tid < 32) { o1[tid][0] = 0.0f; o1[tid][256] = 0.0f; o1[tid][257] = 0.0f; }
+    __syncthreads();
+    if (tid < 255) {                                            // conv1: thread = output position
+        float xv[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) xv[k] = x[2 * tid + k];     // input index 2t + k - 1
+        for (int o = 0; o < 32; ++o) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) acc = __builtin_fmaf(w1[(o * 3 + ch) * 5 + k], xv[k], acc);
+            acc = acc + b1[o];
+            o1[o][1 + tid] = acc > 0.0f ? acc : 0.0f;
+        }
+    }
+    __syncthreads();
+    {                                                           // conv2: thread = (position, half of the channels)
+        const int t = tid & 127;
+        const int og = __builtin_amdgcn_readfirstlane((tid >> 7) * 16);   // wave-uniform: weights come by s_load
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+        for (int c = 0; c < 32; ++c) {
+            const float i0 = o1[c][2 * t], i1 = o1[c][2 * t + 1], i2 = o1[c][2 * t + 2];   // index 2t + k - 1
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float* ww = w2 + ((og + j) * 32 + c) * 3;         // wave-uniform: scalar loads
+                acc[j] = __builtin_fmaf(ww[0], i0, acc[j]);
+                acc[j] = __builtin_fmaf(ww[1], i1, acc[j]);
+                acc[j] = __builtin_fmaf(ww[2], i2, acc[j]);
+            }
+        }
+        float* f = feat + (size_t)p * kPolFeat;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float v = acc[j] + b2[og + j];
+            f[(og + j) * 128 + t] = v > 0.0f ? v : 0.0f;
+        }
+    }
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// h1[p][n] = relu(bias[n] + sum_k feat[p][k] * W[n][k]); one accumulator per output, k ascending
+__global__ __launch_bounds__(256) void policy_fc1_kernel(const float* __restrict__ feat, int n_ped,
+                                                         const float* __restrict__ W, const float* __restrict__ bias,
+                                                         float* __restrict__ h1) {
+    constexpr int MT = 128, NT = 128, KT = 32, LD = KT + 1;     // +1: rows land in different banks
+    extern __shared__ float lds_f[];                            // [2][MT*LD] A, then [2][NT*LD] B
+    float* As = lds_f;
+    float* Bs = lds_f + 2 * MT * LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * MT, n0 = blockIdx.y * NT;
+    const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
+    // global -> register staging: 128 rows x 32 floats per operand = 1024 float4, 4 per thread
+    float4 ra[4], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int idx = tid + i * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+            int m = m0 + row; m = m < n_ped ? m : n_ped - 1;
+            ra[i] = *(const float4*)(feat + (size_t)m * kPolFeat + k0 + c4);
+            rb[i] = *(const float4*)(W + (size_t)(n0 + row) * kPolFeat + k0 + c4);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int idx = tid + i * 256, row = idx >> 3, c4 = (idx & 7) * 4;
+            float* a = As + buf * MT * LD + row * LD + c4;
+            float* b = Bs + buf * NT * LD + row * LD + c4;
+            a[0] = ra[i].x; a[1] = ra[i].y; a[2] = ra[i].z; a[3] = ra[i].w;
+            b[0] = rb[i].x; b[1] = rb[i].y; b[2] = rb[i].z; b[3] = rb[i].w;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int lr = lane & 31, lk = lane >> 5;
+    for (int k0 = 0, buf = 0; k0 < kPolFeat; k0 += KT, buf ^= 1) {
+        const bool more = k0 + KT < kPolFeat;
+        if (more) fetch(k0 + KT);
+        const float* a_ = As + buf * MT * LD + (wm + lr) * LD + lk;
+        const float* b_ = Bs + buf * NT * LD + (wn + lr) * LD + lk;
+#pragma unroll
+        for (int kk = 0; kk < KT; kk += 2) {
+            const float a0 = a_[kk], a1 = a_[32 * LD + kk];
+            const float b0 = b_[kk], b1 = b_[32 * LD + kk];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + j * 32 + lr;
+            const float bn = bias[n];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                float v = acc[i][j][r] + bn;
+                if (m < n_ped) h1[(size_t)m * kPolH1 + n] = v > 0.0f ? v : 0.0f;
+            }
+        }
+}
+
+// W2t[k][j] = W2[j][k]: coalesced rows for the head kernel
+__global__ __launch_bounds__(256) void policy_transpose_kernel(const float* __restrict__ w2, float* __restrict__ w2t) {
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= kPolH2 * kPolIn2) return;
+    int j = idx / kPolIn2, k = idx - j * kPolIn2;
+    w2t[k * kPolH2 + j] = w2[idx];
+}
+
+__global__ __launch_bounds__(128) void policy_head_kernel(navsim_config c, navsim_state st, int p0, int n_ped,
+                                                          const float* __restrict__ h1, const float* __restrict__ w2t,
+                                                          navsim_policy_weights w, float* __restrict__ prev_actions,
+                                                          double* __restrict__ ped_cmd) {
+    __shared__ float z[kPolIn2];
+    __shared__ float h2[kPolH2];
+    __shared__ float head[2];
+    const int tid = threadIdx.x, N = c.max_peds, P = NAVSIM_MAX_WAYPOINTS;
+    const int p = blockIdx.x;
+    if (p >= n_ped) return;
+    const size_t q = (size_t)(p0 + p);
+    const int e = (int)(q / N), i = (int)(q - (size_t)e * N);
+    int n = st.n_peds[e];
+    n = n > N ? N : n;
+    if (i >= n) {                                              // block-uniform
+        if (tid == 0) { ped_cmd[2 * q] = 0.0; ped_cmd[2 * q + 1] = 0.0; }
+        return;
+    }
+    z[tid] = h1[(size_t)p * kPolH1 + tid];
+    z[tid + 128] = h1[(size_t)p * kPolH1 + tid + 128];
+    if (tid == 0) {
+        const double* pp = st.ped_pose + q * 3;
+        double* wp = st.ped_waypoints + (q * P) * 2;
+        int nw = st.ped_n_waypoints[q];
+        while (nw > 1) {                                       // env.py:633-640
+            double ddx = pp[0] - wp[0], ddy = pp[1] - wp[1];
+            if (sqrt(ddx * ddx + ddy * ddy) < 1.0) {
+                for (int k = 0; k + 1 < nw; ++k) { wp[2 * k] = wp[2 * k + 2]; wp[2 * k + 1] = wp[2 * k + 3]; }
+                nw -= 1;
+            } else break;
+        }
+        st.ped_n_waypoints[q] = nw;
+        double s, cs;
+        nv::sincos(pp[2], s, cs);                              // env.py:644-645
+        double gx = wp[0] - pp[0], gy = wp[1] - pp[1];
+        z[256] = (float)(gx * cs + gy * s);
+        z[257] = (float)(-gx * s + gy * cs);
+        z[258] = prev_actions[2 * q];
+        z[259] = prev_actions[2 * q + 1];
+    }
+    __syncthreads();
+    {
+        float acc = 0.0f;
+        for (int k = 0; k < kPolIn2; ++k) acc = __builtin_fmaf(w2t[k * kPolH2 + tid], z[k], acc);
+        acc = acc + w.fc2_b[tid];
+        h2[tid] = acc > 0.0f ? acc : 0.0f;
+    }
+    __syncthreads();
+    if (tid == 0 || tid == 64) {                               // one head per wavefront
+        const float* aw = tid == 0 ? w.a1_w : w.a2_w;
+        float acc = 0.0f;
+        for (int k = 0; k < kPolH2; ++k) acc = __builtin_fmaf(aw[k], h2[k], acc);
+        head[tid >> 6] = acc + (tid == 0 ? w.a1_b[0] : w.a2_b[0]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double x1 = (double)head[0], m1;                       // sigmoid, tanh in float64 on the shared exp
+        if (x1 >= 0.0) m1 = 1.0 / (1.0 + nv::exp_neg(-x1));
+        else { double ex = nv::exp_neg(x1); m1 = ex / (1.0 + ex); }
+        double a2 = fabs((double)head[1]);
+        double ex2 = nv::exp_neg(-2.0 * a2);
+        double t2 = (1.0 - ex2) / (1.0 + ex2);
+        float mean0 = (float)m1, mean1 = (float)(head[1] < 0.0f ? -t2 : t2);
+        mean0 = mean0 < 0.0f ? 0.0f : (mean0 > 1.0f ? 1.0f : mean0);          // env.py:656-657
+        mean1 = mean1 < -1.0f ? -1.0f : (mean1 > 1.0f ? 1.0f : mean1);
+        prev_actions[2 * q] = mean0; prev_actions[2 * q + 1] = mean1;
+        const double vp = st.ped_v_pref[q];
+        ped_cmd[2 * q] = (double)mean0 * vp;                   // env.py:659-662
+        ped_cmd[2 * q + 1] = (double)mean1 * vp;
+    }
+}

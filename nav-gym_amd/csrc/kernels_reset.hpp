@@ -1,0 +1,709 @@
+// kernels_reset.hpp -- reset path on the device: navsim_regen, costmap, planner, navsim_replan.
+// Part of the single translation unit navsim_kernels.hip (included inside its anonymous namespace;
+// not a standalone header).
+
+// ============================================================================================
+// navsim_regen: reset() of finished arenas on the device with a new random map.
+// Specification: oracle/navsim_ref.c navsim_regen_cpu (same hash-keyed uniforms, same tries).
+// ============================================================================================
+__device__ __forceinline__ double rg_u(uint64_t key, uint64_t i) {
+    return (double)(nv::mix64(key + i * 0x9E3779B97F4A7C15ULL) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// ordered compaction of the arenas that finished in this step: list[0..count), mask[e]
+__global__ __launch_bounds__(1024) void regen_select_kernel(const uint8_t* __restrict__ done, int E, int cap,
+                                                            int* __restrict__ count, int* __restrict__ list,
+                                                            uint8_t* __restrict__ mask) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (E + 1023) / 1024;
+    const int lo = tid * per, hi = (lo + per < E) ? lo + per : E;
+    int n = 0;
+    for (int e = lo; e < hi; ++e) n += done[e] != 0;
+    part[tid] = n;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                 // inclusive scan
+        int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int pos = part[tid] - n;
+    for (int e = lo; e < hi; ++e) {
+        bool take = done[e] != 0 && pos < cap;
+        mask[e] = take ? 1 : 0;
+        if (take) list[pos] = e;
+        pos += done[e] != 0;
+    }
+    if (tid == 1023) *count = part[1023] < cap ? part[1023] : cap;
+}
+
+// create_indoor_map (map_generator.py:97-123; oracle regen_map_indoor): the corridor tree on the coarse grid,
+// one workgroup per regenerated arena.  The tree grows one node per iteration (nearest node by a workgroup
+// min-reduction on (L1 distance, node index), then the two corridor rectangles carved by all threads);
+// the grid lives in LDS and is written to grid_all[b] (G*G bytes, stride 100*100).  kind[b] = G for a
+// corridor map, 0 for an outdoor one (regen_maps_kernel then draws the outdoor map as before).
+__global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navsim_state st,
+                                                           const int* __restrict__ count, const int* __restrict__ list,
+                                                           uint8_t* __restrict__ grid_all, int* __restrict__ kind) {
+    __shared__ uint8_t g[100 * 100];
+    __shared__ int tx[152], ty[152];
+    __shared__ unsigned best_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= *count) return;
+    const int e = list[b], size = c.map_w;
+    const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
+    const bool indoor = c.regen_indoor_ratio > 0.0 && rg_u(nv::hash4(c.seed, genv, ep, 0x4B494E44ULL), 0) < c.regen_indoor_ratio;
+    if (!indoor) { if (tid == 0) kind[b] = 0; return; }                  // block-uniform
+    const uint64_t key = nv::hash4(c.seed, genv, ep, 0x494E44ULL);
+    uint64_t n = 0;
+    const int r = 3 + (int)(rg_u(key, n++) * 2.0);
+    const int it = 80 + (int)(rg_u(key, n++) * 71.0);
+    int G = size / 10;
+    G = G < 2 * r + 8 ? 2 * r + 8 : G;
+    G = G > 100 ? 100 : G;
+    int n_it = (it * G * G + 5000) / 10000;
+    n_it = n_it < 4 ? 4 : (n_it > 150 ? 150 : n_it);
+    for (int k = tid; k < G * G; k += 256) g[k] = 1;
+    if (tid == 0) { tx[0] = G / 2; ty[0] = G / 2; }
+    __syncthreads();
+    if (tid == 0) g[(G / 2) * G + G / 2] = 0;
+    const int span = G - 2 * r - 3;
+    for (int k = 0; k < n_it; ++k) {
+        const int px = r + 2 + (int)(rg_u(key, n) * span), py = r + 2 + (int)(rg_u(key, n + 1) * span);
+        const bool coin = rg_u(key, n + 2) >= 0.5;
+        n += 3;
+        const int nt = k + 1;
+        if (tid == 0) best_s = 0xFFFFFFFFu;
+        __syncthreads();
+        if (tid < nt) atomicMin(&best_s, ((unsigned)(abs(px - tx[tid]) + abs(py - ty[tid])) << 8) | (unsigned)tid);
+        __syncthreads();
+        const int best = (int)(best_s & 0xFFu);
+        const int qx = tx[best], qy = ty[best];
+        const int x1 = px < qx ? px : qx, x2 = px < qx ? qx : px;
+        const int y1 = py < qy ? py : qy, y2 = py < qy ? qy : py;
+        const bool constellation1 = (px > qx && py < qy) || (px < qx && py > qy);
+        const int hx = coin ? x1 : x2;
+        const int cy = coin ? (constellation1 ? y1 : y2) : (constellation1 ? y2 : y1);
+        const int wh = y2 - y1 + 2 * r + 1, hv = x2 - x1 + 2 * r + 1, side = 2 * r + 1;
+        for (int idx = tid; idx < side * wh; idx += 256) {
+            int a = hx - r + idx / wh, bq = y1 - r + idx % wh;
+            if (a >= 0 && a < G && bq >= 0 && bq < G) g[a * G + bq] = 0;
+        }
+        for (int idx = tid; idx < hv * side; idx += 256) {
+            int a = x1 - r + idx / side, bq = cy - r + idx % side;
+            if (a >= 0 && a < G && bq >= 0 && bq < G) g[a * G + bq] = 0;
+        }
+        if (tid == 0) { tx[nt] = px; ty[nt] = py; g[px * G + py] = 0; }
+        __syncthreads();
+    }
+    uint8_t* out = grid_all + (size_t)b * 10000;
+    for (int k = tid; k < G * G; k += 256) out[k] = g[k];
+    if (tid == 0) kind[b] = G;
+}
+
+// create_outdoor_map (map_generator.py:126-143) at size x size, hash-keyed: kRegenSlices workgroups per map,
+// each filling its own band of rows (border wall, four cells per store) and then the parts of the obstacle
+// squares that fall into the band.
+constexpr int kRegenSlices = 8;
+__global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim_state st,
+                                                         const int* __restrict__ count, const int* __restrict__ list,
+                                                         uint8_t* __restrict__ occ_all,
+                                                         const uint8_t* __restrict__ grid_all, const int* __restrict__ kind) {
+    __shared__ int ocx[64], ocy[64];
+    const int b = blockIdx.x;
+    if (b >= *count) return;
+    const int e = list[b], size = c.map_w, tid = threadIdx.x;
+    uint8_t* occ = occ_all + (size_t)b * size * size;
+    if (const int G = kind[b]) {                                       // corridor map: nearest upscaling + flip
+        const uint8_t* gsrc = grid_all + (size_t)b * 10000;
+        const int rows_i = (size + kRegenSlices - 1) / kRegenSlices;
+        const int ra = blockIdx.y * rows_i, rb = (ra + rows_i < size) ? ra + rows_i : size;
+        for (int idx = ra * size + tid; idx < rb * size; idx += 256) {
+            int yy = idx / size, xx = idx - yy * size;
+            occ[(size_t)(size - 1 - yy) * size + xx] = gsrc[(int)(((long long)yy * G) / size) * G + (int)(((long long)xx * G) / size)];
+        }
+        return;
+    }
+    const uint64_t key = nv::hash4(c.seed, (uint64_t)(c.env_index_base + e), (uint64_t)st.episode[e], 0x4D4150ULL);
+    double w = c.obstacle_width_lo + (c.obstacle_width_hi - c.obstacle_width_lo) * rg_u(key, 0);
+    const int hw = (int)(10.0 * w);
+    int span = size - 2 * hw - 3;
+    span = span < 1 ? 1 : span;
+    const int n_obs = c.obstacle_number < 64 ? c.obstacle_number : 64;
+    if (tid < n_obs) {
+        ocx[tid] = hw + 2 + (int)(rg_u(key, 1 + 2 * (uint64_t)tid) * span);
+        ocy[tid] = hw + 2 + (int)(rg_u(key, 2 + 2 * (uint64_t)tid) * span);
+    }
+    __syncthreads();
+    // this workgroup owns rows [r0, r1): background first, then the parts of the obstacle squares inside them
+    const int rows = (size + kRegenSlices - 1) / kRegenSlices;
+    const int r0 = blockIdx.y * rows, r1 = (r0 + rows < size) ? r0 + rows : size;
+    if ((size & 3) == 0) {                                       // 4 cells per store
+        const int wpr = size >> 2;
+        uint32_t* occ32 = (uint32_t*)occ;
+        for (int idx = r0 * wpr + tid; idx < r1 * wpr; idx += 256) {
+            int r = idx / wpr, q4 = (idx - r * wpr) * 4;
+            uint32_t wv = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int q = q4 + j;
+                wv |= (uint32_t)(!(r >= 5 && r < size - 5 && q >= 5 && q < size - 5)) << (8 * j);
+            }
+            occ32[(size_t)(size - 1 - r) * wpr + (q4 >> 2)] = wv;
+        }
+    } else {
+        for (int idx = r0 * size + tid; idx < r1 * size; idx += 256) {
+            int r = idx / size, q = idx - r * size;
+            occ[(size_t)(size - 1 - r) * size + q] = !(r >= 5 && r < size - 5 && q >= 5 && q < size - 5);
+        }
+    }
+    __syncthreads();
+    const int side = 2 * hw + 1;
+    for (int o = 0; o < n_obs; ++o) {
+        const int cx = ocx[o], cy = ocy[o];
+        const int ra = (cx - hw > r0) ? cx - hw : r0, rb = (cx + hw < r1 - 1) ? cx + hw : r1 - 1;
+        for (int idx = tid; idx < (rb - ra + 1) * side; idx += 256) {
+            int r = ra + idx / side, q = cy - hw + idx % side;
+            if (q >= 0 && q < size) occ[(size_t)(size - 1 - r) * size + q] = 1;
+        }
+    }
+}
+
+// install the new distance field of every regenerated arena (kRegenSlices workgroups per map, 16-byte copies)
+__global__ __launch_bounds__(256) void regen_field_kernel(navsim_state st, const int* __restrict__ count,
+                                                          const int* __restrict__ list,
+                                                          const char* __restrict__ field_scratch, size_t field_bytes) {
+    const int b = blockIdx.x;
+    if (b >= *count) return;
+    const int e = list[b], tid = threadIdx.x;
+    const char* src_b = field_scratch + (size_t)b * field_bytes;
+    char* dst_b = (char*)st.field + (size_t)e * field_bytes;
+    if (((field_bytes | (size_t)(uintptr_t)src_b | (size_t)(uintptr_t)dst_b) & 15) == 0) {
+        const size_t n16 = field_bytes / 16;
+        const size_t per = (n16 + kRegenSlices - 1) / kRegenSlices;
+        const size_t lo = blockIdx.y * per, hi = (lo + per < n16) ? lo + per : n16;
+        const uint4* src = (const uint4*)src_b;
+        uint4* dst = (uint4*)dst_b;
+        for (size_t i = lo + tid; i < hi; i += 256) dst[i] = src[i];
+    } else {                                              // odd map sizes: every field format is 2-byte granular
+        const size_t n2 = field_bytes / 2;
+        const size_t per = (n2 + kRegenSlices - 1) / kRegenSlices;
+        const size_t lo = blockIdx.y * per, hi = (lo + per < n2) ? lo + per : n2;
+        for (size_t i = lo + tid; i < hi; i += 256) ((uint16_t*)dst_b)[i] = ((const uint16_t*)src_b)[i];
+    }
+}
+
+template <typename Field>
+__device__ __forceinline__ void rg_sample(const navsim_config& c, const Field& f, uint64_t key, uint64_t& n,
+                                          double clr, bool use_ref, double rx, double ry, double dmin, double dmax,
+                                          double& x, double& y) {
+    const int W = c.map_w, H = c.map_h;
+    int bi = 0, bj = 0;
+    float bd = -1.0f;
+    for (int t = 0; t < 64; ++t) {
+        int i = (int)(rg_u(key, n++) * W), j = (int)(rg_u(key, n++) * H);
+        float d = f.at(i, j);
+        double px = ((double)i + 0.5) * c.resolution + c.origin_x;
+        double py = ((double)j + 0.5) * c.resolution + c.origin_y;
+        bool ok = (double)d >= clr;
+        if (ok && use_ref) {
+            double ddx = px - rx, ddy = py - ry;
+            double dist = sqrt(ddx * ddx + ddy * ddy);
+            ok = dist > dmin && dist < dmax;
+        }
+        if (ok) { x = px; y = py; return; }
+        if (d > bd) { bd = d; bi = i; bj = j; }
+    }
+    x = ((double)bi + 0.5) * c.resolution + c.origin_x;
+    y = ((double)bj + 0.5) * c.resolution + c.origin_y;
+}
+
+// install the new field, draw the start / goal table, the robot and the pedestrians
+template <typename Field>
+__global__ __launch_bounds__(256) void regen_commit_kernel(navsim_config c, navsim_state st,
+                                                           const int* __restrict__ count, const int* __restrict__ list,
+                                                           const char* __restrict__ field_scratch, size_t field_bytes) {
+    __shared__ double robot_xy[2];
+    const int b = blockIdx.x;
+    if (b >= *count) return;
+    const int e = list[b], tid = threadIdx.x;
+    const int N = c.max_peds, K = c.n_spawn, P = NAVSIM_MAX_WAYPOINTS;
+    const Field f(st.field, st.field_overflow, e, c.map_h, c.map_w);
+    const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
+    double* sp = (double*)st.spawn_pose + (size_t)e * K * 3;
+    double* sg = (double*)st.spawn_goal + (size_t)e * K * 2;
+    const double clr = c.spawn_clearance / c.resolution;
+    for (int k = tid; k < K; k += 256) {
+        uint64_t key = nv::hash4(c.seed, genv, ep, 0x53504157ULL + (uint64_t)k), n = 0;
+        double x, y, gx, gy;
+        rg_sample(c, f, key, n, clr, false, 0, 0, 0, 0, x, y);
+        double th = nv::kTwoPi * rg_u(key, n++);
+        rg_sample(c, f, key, n, clr, true, x, y, c.min_goal_dist, c.max_goal_dist, gx, gy);
+        sp[3 * k] = x; sp[3 * k + 1] = y; sp[3 * k + 2] = th;
+        sg[2 * k] = gx; sg[2 * k + 1] = gy;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        int idx = (int)(nv::hash4(c.seed, genv, ep, 0x5eedULL) % (uint64_t)K);
+        double* rp = st.robot_pose + 3 * (size_t)e;
+        rp[0] = sp[3 * idx]; rp[1] = sp[3 * idx + 1]; rp[2] = sp[3 * idx + 2];
+        st.robot_goal[2 * e] = sg[2 * idx]; st.robot_goal[2 * e + 1] = sg[2 * idx + 1];
+        robot_xy[0] = rp[0]; robot_xy[1] = rp[1];
+    }
+    __syncthreads();
+    int n = (c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
+    n = n > N ? N : n;
+    const double pclr = c.ped_clearance / c.resolution;
+    for (int i = tid; i < n; i += 256) {
+        size_t q = (size_t)e * N + i;
+        uint64_t key = nv::hash4(c.seed, genv, ep, 0x504544ULL + (uint64_t)i), m = 0;
+        double x, y, gx, gy;
+        rg_sample(c, f, key, m, pclr, true, robot_xy[0], robot_xy[1], c.ped_min_robot_dist, 1.0e300, x, y);
+        double th = nv::kTwoPi * rg_u(key, m++);
+        rg_sample(c, f, key, m, pclr, true, x, y, c.ped_min_goal_dist, 1.0e300, gx, gy);
+        st.ped_pose[q * 3] = x; st.ped_pose[q * 3 + 1] = y; st.ped_pose[q * 3 + 2] = th;
+        st.ped_vel[q * 2] = 0.0; st.ped_vel[q * 2 + 1] = 0.0;
+        ((double*)st.ped_v_pref)[q] = c.v_pref_lo + (c.v_pref_hi - c.v_pref_lo) * rg_u(key, m++);
+        ((uint8_t*)st.ped_has_legs)[q] = rg_u(key, m++) < c.has_legs_ratio;
+        double* wp = st.ped_waypoints + (q * P) * 2;
+        wp[0] = gx; wp[1] = gy;
+        st.ped_n_waypoints[q] = 1;
+    }
+}
+
+// ============================================================================================
+// reset path: costmap (env.py:312-332), shortest path (pyastar2d at env.py:343-354), waypoints
+// (env.py:1261-1277).  Specification incl. the tie-break: oracle/navsim_ref.c.
+// ============================================================================================
+__device__ __forceinline__ int reflect101(int k, int n) {
+    if (n == 1) return 0;
+    while (k < 0 || k >= n) { if (k < 0) k = -k; if (k >= n) k = 2 * (n - 1) - k; }
+    return k;
+}
+
+__global__ __launch_bounds__(256) void costmap_kernel(const uint8_t* __restrict__ occ, int H, int W,
+                                                      uint8_t* __restrict__ cost, const int* __restrict__ n_live,
+                                                      const int* __restrict__ out_index) {
+    const int Hc = H / 5, Wc = W / 5;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t m = blockIdx.y;
+    if (n_live && (int)m >= *n_live) return;
+    if (idx >= Hc * Wc) return;
+    int J = idx / Wc, I = idx - J * Wc;
+    const uint8_t* o = occ + m * (size_t)H * W;
+    int any = 0;
+    for (int dj = -4; dj <= 4; ++dj)
+        for (int di = -4; di <= 4; ++di) {
+            int jj = reflect101(J + dj, Hc), ii = reflect101(I + di, Wc);
+            any |= o[(size_t)(jj * 5) * W + ii * 5];
+        }
+    cost[(out_index ? (size_t)out_index[m] : m) * (size_t)Hc * Wc + idx] = any ? 1 : 0;
+}
+
+// one workgroup per query: level-synchronous breadth-first distances from the goal in LDS (int16),
+// stopped at the start's level; thread 0 then walks the path (+i, -i, +j, -j order) and cuts it
+// into waypoints exactly like path_to_waypoints.
+// One query, executed by the whole 256-thread workgroup.  c = this query's costmap, w = its waypoint
+// row (max_wp x 2); n_wp / path_cells / path_len point at its slots.
+//
+// LDS: dist[n_cells] int16 (-2 blocked, -1 free and unreached, else hops from the goal) followed by
+// queue[n_cells] uint16, the breadth-first queue (every cell enters once; a level is the slice [lo, hi)).
+// A level costs O(frontier) and ONE barrier: each frontier lane claims its free unreached neighbours with
+// a 32-bit LDS atomic AND on the word holding the int16 (see `claim`), and the winner appends the cell.
+// Queue order is arbitrary; only `dist` feeds the path, so results are deterministic.
+// Thread 0 then walks the path and cuts the waypoints on the fly (nothing is stored per path cell).
+constexpr size_t kPlanLdsMax = 160 * 1024 - 256;       // LDS per CU minus the static variables
+inline size_t plan_lds(int Hc, int Wc) { return (size_t)((Hc * Wc + 1) & ~1) * 4; }
+inline bool plan_fits(int Hc, int Wc) { return (size_t)Hc * Wc <= 65535 && plan_lds(Hc, Wc) <= kPlanLdsMax; }
+
+__device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc, int Wc, double res_c, double ox,
+                                           double oy, double sx_, double sy_, double gx_, double gy_, double interval,
+                                           int max_wp, double* __restrict__ w, int32_t* __restrict__ n_wp,
+                                           int32_t* __restrict__ path_cells, double* __restrict__ path_len) {
+    extern __shared__ int16_t dist[];
+    __shared__ int cnt[3], reached;
+    const int tid = threadIdx.x;
+    const int n_cells = Hc * Wc;
+    uint16_t* queue = (uint16_t*)(dist + ((n_cells + 1) & ~1));
+    navsim_config cc = {};
+    cc.origin_x = ox; cc.origin_y = oy; cc.resolution = res_c; cc.map_h = Hc; cc.map_w = Wc;
+    int si, sj, gi, gj;
+    nv::xy_to_ij(sx_, sy_, cc, si, sj);
+    nv::xy_to_ij(gx_, gy_, cc, gi, gj);
+    bool ok = si < Wc && sj < Hc && gi < Wc && gj < Hc;
+    if (ok) ok = !c[(size_t)sj * Wc + si] && !c[(size_t)gj * Wc + gi];
+    if (tid == 0) {
+        *n_wp = 0;
+        if (path_cells) *path_cells = 0;
+        if (path_len) *path_len = 0.0;
+    }
+    if (!ok) return;                                     // uniform: depends on the query only
+    const int s_cell = sj * Wc + si, g_cell = gj * Wc + gi;
+    if ((((uintptr_t)c) & 3) == 0) {                                       // four cells per load
+        const uint32_t* c4 = (const uint32_t*)c;
+        uint2* d4 = (uint2*)dist;
+        for (int k = tid; k < n_cells / 4; k += 256) {
+            const uint32_t v = c4[k];
+            uint2 o;
+            o.x = ((v & 0xFFu) ? 0xFFFEu : 0xFFFFu) | (((v >> 8) & 0xFFu) ? 0xFFFE0000u : 0xFFFF0000u);
+            o.y = (((v >> 16) & 0xFFu) ? 0xFFFEu : 0xFFFFu) | ((v >> 24) ? 0xFFFE0000u : 0xFFFF0000u);
+            d4[k] = o;
+        }
+        for (int k = (n_cells & ~3) + tid; k < n_cells; k += 256) dist[k] = c[k] ? (int16_t)-2 : (int16_t)-1;
+    } else {
+        for (int k = tid; k < n_cells; k += 256) dist[k] = c[k] ? (int16_t)-2 : (int16_t)-1;
+    }
+    if ((n_cells & 1) && tid == 0) dist[n_cells] = -2;                    // pad half of the last 32-bit word
+    __syncthreads();
+    if (tid == 0) {
+        dist[g_cell] = 0; queue[0] = (uint16_t)g_cell;
+        cnt[0] = 0; cnt[1] = 0; cnt[2] = 0;
+        reached = (s_cell == g_cell);
+    }
+    __syncthreads();
+    uint32_t* words = (uint32_t*)dist;
+    const uint16_t* half = (const uint16_t*)dist;
+    int lo = 0, hi = 1;
+    for (int level = 1; level < 32767; ++level) {
+        if (reached || lo == hi) break;
+        const int slot = level % 3;
+        if (tid == 0) cnt[(level + 1) % 3] = 0;          // last read two barriers ago
+        // claim a neighbour for this level: one atomic AND turns an unreached half-word (0xFFFF) into
+        // `level` and leaves a half-word some other lane claimed in this level unchanged; the lane that
+        // saw 0xFFFF come back owns the cell.  Reached and blocked cells are filtered by the plain read.
+        // The four reads, then the four atomics, are issued together (independent LDS round trips).
+        for (int f = lo + tid; f < hi; f += 256) {
+            const int k = queue[f], j = k / Wc, i = k - j * Wc;
+            const int m[4] = {k + 1, k - 1, k + Wc, k - Wc};
+            const bool in[4] = {i + 1 < Wc, i > 0, j + 1 < Hc, j > 0};
+            bool want[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) want[d] = in[d] && half[in[d] ? m[d] : k] == 0xFFFFu;
+            uint32_t old[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {               // branch-free: a lane with nothing to claim ANDs all ones
+                const uint32_t sh = (uint32_t)(m[d] & 1) * 16u;
+                const uint32_t mask = want[d] ? (((uint32_t)level << sh) | (0xFFFFu << (16u - sh))) : 0xFFFFFFFFu;
+                old[d] = atomicAnd(&words[(want[d] ? m[d] : k) >> 1], mask);
+            }
+            // queue slots: one atomic per wavefront (ballot prefix), not one per lane or per cell
+            uint64_t won[4];
+            int total = 0;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                want[d] = want[d] && ((old[d] >> ((uint32_t)(m[d] & 1) * 16u)) & 0xFFFFu) == 0xFFFFu;
+                won[d] = __ballot(want[d]);
+                total += __popcll(won[d]);
+            }
+            if (total) {                                     // wave-uniform
+                const uint64_t below = (1ull << (tid & 63)) - 1ull;
+                int base = 0;
+                if ((__ballot(1) & below) == 0) base = atomicAdd(&cnt[slot], total);     // first active lane
+                base = hi + __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if (want[d]) {
+                        queue[base + __popcll(won[d] & below)] = (uint16_t)m[d];
+                        if (m[d] == s_cell) reached = 1;
+                    }
+                    base += __popcll(won[d]);
+                }
+            }
+        }
+        __syncthreads();
+        lo = hi;
+        hi += cnt[slot];
+    }
+#ifdef NAVSIM_DIAG_NO_WALK
+    return;
+#endif
+    if (tid != 0 || dist[s_cell] < 0) return;
+    int n = 0, count = 0, ci = si, cj = sj;
+    const double fx0 = ((double)si + 0.5) * res_c + ox, fy0 = ((double)sj + 0.5) * res_c + oy;
+    double fx = fx0, fy = fy0;                           // env.py:1261-1277, cut while walking
+    const double i2_hi = interval * interval * (1.0 + 1.0e-12), i2_lo = interval * interval * (1.0 - 1.0e-12);
+    for (;;) {
+        ++n;
+        const double cx = ((double)ci + 0.5) * res_c + ox, cy = ((double)cj + 0.5) * res_c + oy;
+        const double dx = fx - cx, dy = fy - cy;
+        const int k = cj * Wc + ci;
+        const int dcur = dist[k];
+        // sqrt(d2) > interval, decided on d2 unless it sits within 1e-12 of interval^2 (sqrt is monotone
+        // and correctly rounded, so the two tests agree outside that band)
+        const double d2 = dx * dx + dy * dy;
+        const bool far = (d2 > i2_hi) || (!(d2 < i2_lo) && sqrt(d2) > interval);
+        if (far) {
+            if (count < max_wp) { w[2 * count] = cx; w[2 * count + 1] = cy; }
+            ++count; fx = cx; fy = cy;
+        }
+        if (dcur == 0) {                                 // the goal cell closes the list
+            if (count < max_wp) { w[2 * count] = cx; w[2 * count + 1] = cy; }
+            ++count;
+            break;
+        }
+        const int want = dcur - 1;                       // first neighbour one hop closer, (+i, -i, +j, -j)
+        const bool e0 = ci + 1 < Wc && dist[k + 1] == want, e1 = ci > 0 && dist[k - 1] == want;
+        const bool e2 = cj + 1 < Hc && dist[k + Wc] == want;
+        if (e0) ++ci; else if (e1) --ci; else if (e2) ++cj; else --cj;
+    }
+    int nw = count < max_wp ? count : max_wp;
+    *n_wp = nw;
+    if (path_cells) *path_cells = n;
+    if (path_len) {
+        double sx = sx_ - w[0], sy = sy_ - w[1];
+        double L = sqrt(sx * sx + sy * sy);
+        for (int k = 0; k + 1 < nw; ++k) {
+            double ax = w[2 * k + 2] - w[2 * k], ay = w[2 * k + 3] - w[2 * k + 1];
+            L += sqrt(ax * ax + ay * ay);
+        }
+        *path_len = L;
+    }
+}
+
+__global__ __launch_bounds__(256) void plan_kernel(const uint8_t* __restrict__ cost, const int32_t* __restrict__ map_index,
+                                                   int Hc, int Wc, double res_c, double ox, double oy,
+                                                   const double* __restrict__ start, const double* __restrict__ goal,
+                                                   double interval, int max_wp, double* __restrict__ wp,
+                                                   int32_t* __restrict__ n_wp, int32_t* __restrict__ path_cells,
+                                                   double* __restrict__ path_len) {
+    const int q = blockIdx.x;
+    plan_query(cost + (size_t)(map_index ? map_index[q] : q) * Hc * Wc, Hc, Wc, res_c, ox, oy, start[2 * q],
+               start[2 * q + 1], goal[2 * q], goal[2 * q + 1], interval, max_wp, wp + (size_t)q * max_wp * 2, n_wp + q,
+               path_cells ? path_cells + q : nullptr, path_len ? path_len + q : nullptr);
+}
+
+// --------------------------------------------------------------------------------------------
+// navsim_regen with cfg.regen_plan = 1 (oracle/navsim_ref.c regen_planned): candidates on the costmap,
+// a path must join start and goal.  Rounds of {sample, plan, accept} kernels; no host round trip.
+// --------------------------------------------------------------------------------------------
+struct RegenPlanWs {
+    uint8_t* cost;        // [M, Hc, Wc] scratch, or the resident st.costmap (then indexed by arena)
+    int cost_by_arena;
+    double* qstart;       // [M, Q, 2]
+    double* qgoal;        // [M, Q, 2]
+    double* qwp;          // [M, Q, P, 2]   robot stage only (pedestrian paths go straight into the state)
+    int32_t* qnwp;        // [M, Q]
+    double* qlen;         // [M, Q]
+    uint8_t* active;      // [M, Q]
+    uint8_t* res_robot;   // [M, K]
+    uint8_t* res_ped;     // [M, N]
+    int Q;
+};
+
+__device__ __forceinline__ void rgp_cell(const navsim_config& c, const uint8_t* __restrict__ cost, int Hc, int Wc,
+                                         double res_c, uint64_t key, uint64_t& n, bool use_ref, double rx, double ry,
+                                         double dmin, double dmax, double& x, double& y) {
+    for (int t = 0; t < 16; ++t) {
+        int I = (int)(rg_u(key, n++) * Wc), J = (int)(rg_u(key, n++) * Hc);
+        x = ((double)I + 0.5) * res_c + c.origin_x;
+        y = ((double)J + 0.5) * res_c + c.origin_y;
+        if (cost[(size_t)J * Wc + I]) continue;
+        if (use_ref) {
+            double ddx = x - rx, ddy = y - ry;
+            double dist = sqrt(ddx * ddx + ddy * ddy);
+            if (!(dist > dmin && dist < dmax)) continue;
+        }
+        return;
+    }
+}
+
+// install the new field (same copy as regen_commit_kernel) and clear the per-slot flags
+__global__ __launch_bounds__(256) void regen_install_kernel(navsim_config c, navsim_state st,
+                                                            const int* __restrict__ count, const int* __restrict__ list,
+                                                            const char* __restrict__ field_scratch, size_t field_bytes,
+                                                            RegenPlanWs ws) {
+    const int b = blockIdx.x;
+    if (b >= *count) return;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < c.n_spawn; k += 256) ws.res_robot[(size_t)b * c.n_spawn + k] = 0;
+    for (int i = tid; i < c.max_peds; i += 256) ws.res_ped[(size_t)b * c.max_peds + i] = 0;
+}
+
+// robot stage, one round: accept what the previous round planned, then draw a new candidate for every
+// slot that is still open (round == 4: accept only, pick the robot, initialise the pedestrians)
+__global__ __launch_bounds__(256) void regen_robot_round_kernel(navsim_config c, navsim_state st,
+                                                                const int* __restrict__ count,
+                                                                const int* __restrict__ list, RegenPlanWs ws, int round) {
+    const int b = blockIdx.x;
+    if (b >= *count) return;
+    const int e = list[b], tid = threadIdx.x;
+    const int N = c.max_peds, K = c.n_spawn, Q = ws.Q;
+    const int Hc = c.map_h / 5, Wc = c.map_w / 5;
+    const double res_c = c.resolution * 5.0;
+    const uint8_t* cost = ws.cost + (size_t)(ws.cost_by_arena ? e : b) * Hc * Wc;
+    const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
+    double* sp = (double*)st.spawn_pose + (size_t)e * K * 3;
+    double* sg = (double*)st.spawn_goal + (size_t)e * K * 2;
+    for (int k = tid; k < Q; k += 256) {
+        const size_t q = (size_t)b * Q + k;
+        if (k >= K) { ws.active[q] = 0; continue; }
+        uint8_t& res = ws.res_robot[(size_t)b * K + k];
+        if (round > 0 && !res) {
+            double ddx = sg[2 * k] - sp[3 * k], ddy = sg[2 * k + 1] - sp[3 * k + 1];
+            res = ws.qnwp[q] > 0 && ws.qlen[q] <= 2.0 * sqrt(ddx * ddx + ddy * ddy);      // env.py:761
+        }
+        ws.active[q] = 0;
+        if (res || round >= 4) continue;
+        uint64_t key = nv::hash4(c.seed, genv, ep, 0x52504C00ULL + (uint64_t)round * 256 + (uint64_t)k), n = 0;
+        double x, y, gx, gy;
+        rgp_cell(c, cost, Hc, Wc, res_c, key, n, false, 0, 0, 0, 0, x, y);
+        rgp_cell(c, cost, Hc, Wc, res_c, key, n, true, x, y, c.min_goal_dist, c.max_goal_dist, gx, gy);
+        sp[3 * k] = x; sp[3 * k + 1] = y; sp[3 * k + 2] = nv::kTwoPi * rg_u(key, n++);
+        sg[2 * k] = gx; sg[2 * k + 1] = gy;
+        ws.qstart[2 * q] = x; ws.qstart[2 * q + 1] = y;
+        ws.qgoal[2 * q] = gx; ws.qgoal[2 * q + 1] = gy;
+        ws.active[q] = 1;
+    }
+    if (round < 4) return;
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        int idx = (int)(nv::hash4(c.seed, genv, ep, 0x5eedULL) % (uint64_t)K);
+        const uint8_t* res = ws.res_robot + (size_t)b * K;
+        if (!res[idx])
+            for (int s_ = 1; s_ < K; ++s_) { int j = (idx + s_) % K; if (res[j]) { idx = j; break; } }
+        double* rp = st.robot_pose + 3 * (size_t)e;
+        rp[0] = sp[3 * idx]; rp[1] = sp[3 * idx + 1]; rp[2] = sp[3 * idx + 2];
+        st.robot_goal[2 * e] = sg[2 * idx]; st.robot_goal[2 * e + 1] = sg[2 * idx + 1];
+    }
+    int n = (c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
+    n = n > N ? N : n;
+    for (int i = tid; i < n; i += 256) {
+        size_t q = (size_t)e * N + i;
+        uint64_t k0 = nv::hash4(c.seed, genv, ep, 0x504544ULL + (uint64_t)i), m = 0;
+        st.ped_pose[q * 3 + 2] = nv::kTwoPi * rg_u(k0, m++);
+        ((double*)st.ped_v_pref)[q] = c.v_pref_lo + (c.v_pref_hi - c.v_pref_lo) * rg_u(k0, m++);
+        ((uint8_t*)st.ped_has_legs)[q] = rg_u(k0, m++) < c.has_legs_ratio;
+        st.ped_vel[q * 2] = 0.0; st.ped_vel[q * 2 + 1] = 0.0;
+    }
+}
+
+// pedestrian stage, one round (round == 4: accept only)
+__global__ __launch_bounds__(256) void regen_ped_round_kernel(navsim_config c, navsim_state st,
+                                                              const int* __restrict__ count,
+                                                              const int* __restrict__ list, RegenPlanWs ws, int round) {
+    const int b = blockIdx.x;
+    if (b >= *count) return;
+    const int e = list[b], tid = threadIdx.x;
+    const int N = c.max_peds, Q = ws.Q, P = NAVSIM_MAX_WAYPOINTS;
+    const int Hc = c.map_h / 5, Wc = c.map_w / 5;
+    const double res_c = c.resolution * 5.0;
+    const uint8_t* cost = ws.cost + (size_t)(ws.cost_by_arena ? e : b) * Hc * Wc;
+    const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
+    const double rx = st.robot_pose[3 * (size_t)e], ry = st.robot_pose[3 * (size_t)e + 1];
+    int n = (c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
+    n = n > N ? N : n;
+    for (int i = tid; i < Q; i += 256) {
+        const size_t q = (size_t)b * Q + i;
+        if (i >= n) { ws.active[q] = 0; continue; }
+        const size_t pq = (size_t)e * N + i;
+        uint8_t& res = ws.res_ped[(size_t)b * N + i];
+        if (round > 0 && !res && ws.qnwp[q] > 0) { st.ped_n_waypoints[pq] = ws.qnwp[q]; res = 1; }
+        ws.active[q] = 0;
+        if (res || round >= 4) continue;
+        uint64_t key = nv::hash4(c.seed, genv, ep, 0x50504C00ULL + (uint64_t)round * 256 + (uint64_t)i), nn = 0;
+        double x, y, gx, gy;
+        rgp_cell(c, cost, Hc, Wc, res_c, key, nn, true, rx, ry, c.ped_min_robot_dist, 1.0e300, x, y);
+        rgp_cell(c, cost, Hc, Wc, res_c, key, nn, true, x, y, c.ped_min_goal_dist, 1.0e300, gx, gy);
+        st.ped_pose[pq * 3] = x; st.ped_pose[pq * 3 + 1] = y;
+        double* w = st.ped_waypoints + (pq * P) * 2;
+        w[0] = gx; w[1] = gy;
+        st.ped_n_waypoints[pq] = 1;
+        ws.qstart[2 * q] = x; ws.qstart[2 * q + 1] = y;
+        ws.qgoal[2 * q] = gx; ws.qgoal[2 * q + 1] = gy;
+        ws.active[q] = 1;
+    }
+}
+
+// plan every active query of the round; ped_stage: waypoints go straight into st.ped_waypoints
+__global__ __launch_bounds__(256) void regen_plan_kernel(navsim_config c, navsim_state st, const int* __restrict__ count,
+                                                         const int* __restrict__ list, RegenPlanWs ws, int ped_stage) {
+    const int q = blockIdx.x, b = q / ws.Q, k = q - b * ws.Q;
+    if (b >= *count || !ws.active[q]) return;            // uniform per workgroup
+    const int Hc = c.map_h / 5, Wc = c.map_w / 5, P = NAVSIM_MAX_WAYPOINTS;
+    double* w = ped_stage ? st.ped_waypoints + (((size_t)list[b] * c.max_peds + k) * P) * 2
+                          : ws.qwp + (size_t)q * P * 2;
+    plan_query(ws.cost + (size_t)(ws.cost_by_arena ? list[b] : b) * Hc * Wc, Hc, Wc, c.resolution * 5.0, c.origin_x, c.origin_y, ws.qstart[2 * q],
+               ws.qstart[2 * q + 1], ws.qgoal[2 * q], ws.qgoal[2 * q + 1], ped_stage ? 2.0 : 5.0, P, w, ws.qnwp + q,
+               nullptr, ped_stage ? nullptr : ws.qlen + q);
+}
+
+// --------------------------------------------------------------------------------------------
+// navsim_replan (env.py:667-680; oracle navsim_replan_cpu): ordered list of the pedestrians standing on
+// their final waypoint, then one workgroup per listed pedestrian: draw a goal, plan, up to 4 rounds.
+// --------------------------------------------------------------------------------------------
+// one wavefront per arena: bit i of due[e] = pedestrian i stands within 0.5 m of its final waypoint
+__global__ __launch_bounds__(64) void replan_flag_kernel(navsim_config c, navsim_state st, uint64_t* __restrict__ due) {
+    const int e = blockIdx.x, i = threadIdx.x, N = c.max_peds, P = NAVSIM_MAX_WAYPOINTS;
+    bool flag = false;
+    if (i < N && i < st.n_peds[e]) {
+        const size_t q = (size_t)e * N + i;
+        const double* pp = st.ped_pose + q * 3;
+        const double* w = st.ped_waypoints + (q * P) * 2;
+        int nw = st.ped_n_waypoints[q];
+        double ddx = pp[0] - w[2 * (nw - 1)], ddy = pp[1] - w[2 * (nw - 1) + 1];
+        flag = sqrt(ddx * ddx + ddy * ddy) < 0.5;
+    }
+    uint64_t m = __ballot(flag);
+    if (i == 0) due[e] = m;
+}
+
+// ordered compaction of the set bits, (arena, pedestrian) order, at most cap entries
+__global__ __launch_bounds__(1024) void replan_select_kernel(const uint64_t* __restrict__ due, int E, int N, int cap,
+                                                             int* __restrict__ count, int* __restrict__ list) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (E + 1023) / 1024;
+    const int lo = tid * per, hi = (lo + per < E) ? lo + per : E;
+    int n = 0;
+    for (int e = lo; e < hi; ++e) n += __popcll(due[e]);
+    part[tid] = n;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int pos = part[tid] - n;
+    if (n)
+        for (int e = lo; e < hi && pos < cap; ++e)
+            for (uint64_t m = due[e]; m && pos < cap; m &= m - 1) list[pos++] = e * N + (__ffsll((unsigned long long)m) - 1);
+    if (tid == 1023) *count = part[1023] < cap ? part[1023] : cap;
+}
+
+__global__ __launch_bounds__(256) void replan_kernel(navsim_config c, navsim_state st, const int* __restrict__ count,
+                                                     const int* __restrict__ list) {
+    __shared__ double goal_s[2];
+    __shared__ int32_t nwp_s;
+    const int b = blockIdx.x;
+    if (b >= *count) return;
+    const int q = list[b], N = c.max_peds, P = NAVSIM_MAX_WAYPOINTS, tid = threadIdx.x;
+    const int e = q / N, i = q - e * N;
+    const int Hc = c.map_h / 5, Wc = c.map_w / 5;
+    const double res_c = c.resolution * 5.0;
+    const uint8_t* cost = st.costmap + (size_t)(c.shared_field ? 0 : e) * Hc * Wc;
+    const uint64_t genv = (uint64_t)(c.env_index_base + e);
+    const uint64_t when = (uint64_t)st.steps[e] + ((uint64_t)st.episode[e] << 40);
+    const double px = st.ped_pose[(size_t)q * 3], py = st.ped_pose[(size_t)q * 3 + 1];
+    double* w = st.ped_waypoints + ((size_t)q * P) * 2;
+    for (int round = 0; round < 4; ++round) {
+        if (tid == 0) {
+            uint64_t key = nv::hash4(c.seed, genv, when, 0x52504E00ULL + (uint64_t)round * 256 + (uint64_t)i), m = 0;
+            double gx, gy;
+            rgp_cell(c, cost, Hc, Wc, res_c, key, m, true, px, py, c.ped_min_goal_dist, 1.0e300, gx, gy);
+            goal_s[0] = gx; goal_s[1] = gy;
+        }
+        __syncthreads();
+        plan_query(cost, Hc, Wc, res_c, c.origin_x, c.origin_y, px, py, goal_s[0], goal_s[1], 2.0, P, w, &nwp_s,
+                   nullptr, nullptr);
+        __syncthreads();
+        if (nwp_s > 0) {
+            if (tid == 0) st.ped_n_waypoints[q] = nwp_s;
+            break;
+        }
+        __syncthreads();                                 // nwp_s is rewritten by the next round
+    }
+}

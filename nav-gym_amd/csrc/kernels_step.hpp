@@ -1,0 +1,1145 @@
+// kernels_step.hpp -- the fused step: scan, pedestrian merge, pedestrian phase, step kernel (rows a1, a2, a7, a10 SFM, a11, a16 pop).
+// Part of the single translation unit navsim_kernels.hip (included inside its anonymous namespace;
+// not a standalone header).
+
+// ============================================================================================
+// a1: the fused step.  One workgroup = one arena.
+// ============================================================================================
+struct StepShared {
+    double rp[3];                 // robot pose being scanned
+    double old_rp[3];             // robot pose at the start of the step (social force input)
+    double act[2];                // action after the turning-radius clamp
+    float lx, ly, lth;            // float32 lidar pose (env.py:386)
+    double cT, sT;                // cos / sin of (double)lth for the beam-table fast path
+    int i0, j0;                   // integer ray origin (env.py:419)
+    int nseg, ndisc;
+    int rescan;
+    int respawn;
+    float t1;                     // march parameter after the shared first probe (origin cell)
+    float r_all;                  // >= 0: every beam has this raw range (origin occupied / no march)
+    unsigned long long step_key;  // scan-noise counter of this step
+    double wave_ratio[kMaxWaves];
+};
+constexpr size_t kPoolEnvBytes = 512;     // StepShared slot per arena in the step workspace
+static_assert(sizeof(StepShared) <= kPoolEnvBytes, "StepShared must fit its workspace slot");
+// Pedestrian scratch of the pedestrian variants of the kernel, carved out of dynamic LDS behind the scan's
+// dir / rng area and sized by cfg.max_peds (N), not by the compiled maximum: 136 N + 32 bytes, so that a
+// 20-pedestrian world still fits 8 arenas per CU (the static 64-pedestrian layout allowed 7).
+struct PedShared {
+    double *ax, *ay, *avx, *avy;             // [N + 1] agent positions / velocities at time t (robot last)
+    float (*seg)[4];                         // [4 N] rectangle edges seen by the lidar ...
+    float (*disc)[2];                        // [2 N] ... leg discs (stored right behind seg)
+    float* info;                             // [6 N] merge_prims_culled_core scratch: in-range flag per primitive
+};
+__host__ __device__ inline size_t ped_lds_bytes(int N) { return (size_t)136 * N + 32; }
+__device__ __forceinline__ PedShared ped_lds_carve(char* base, int N) {
+    PedShared ps;
+    double* d = (double*)base;
+    ps.ax = d; ps.ay = d + (N + 1); ps.avx = d + 2 * (N + 1); ps.avy = d + 3 * (N + 1);
+    float* f = (float*)(d + 4 * (N + 1));
+    ps.seg = (float(*)[4])f;
+    ps.disc = (float(*)[2])(f + 16 * N);
+    ps.info = f + 20 * N;
+    return ps;
+}
+struct Prims { const float (*seg)[4]; const float (*disc)[2]; float* info; };
+
+template <int BLOCK>
+__device__ __forceinline__ void finish_beams(const navsim_config& c, const StepShared& sh, const Prims pr,
+                                             const double* __restrict__ tab, const float2* __restrict__ dir,
+                                             const float* __restrict__ rng, float* __restrict__ rng_rw,
+                                             const float* __restrict__ thr, const float* __restrict__ dthr,
+                                             float* __restrict__ obs_row, int n_hist, float noise_std,
+                                             uint64_t noise_key, uint64_t genv, int& crash, int& discomfort);
+
+// robot scan (env.py:385-441 with other_agents = all pedestrians).  Writes the latest-scan slot
+// of the observation row and every "not yet filled" stack slot (env.py:262-265).
+//
+// The march is latency-bound (each probe of the distance field is a dependent HBM/L2 access), so
+// every thread advances R independent rays in lock-step: the R loads of one round are issued back
+// to back before any of them is consumed, which multiplies the lines in flight per CU by R.
+// Beam k of round-slot q is base + q*BLOCK + tid, so lanes of a wave hold adjacent beams (their
+// probes fall on neighbouring cells and their range stores coalesce).
+template <int BLOCK, int R, typename Field, bool TO_LDS>
+__device__ __forceinline__ void scan_beams(const navsim_config& c, const StepShared& sh,
+                                           const Field& field, const double* __restrict__ tab,
+                                           const Prims pr, float2* __restrict__ dir_lds, float* __restrict__ rng_lds,
+                                           const uint32_t* __restrict__ tiles,
+                                           const float* __restrict__ thr, const float* __restrict__ dthr,
+                                           float* __restrict__ obs_row, int n_hist, float noise_std,
+                                           uint64_t noise_key, uint64_t genv,
+                                           int& crash, int& discomfort) {
+    const int B = c.n_beams, S = c.n_scan_stack, H = c.map_h, W = c.map_w;
+    const float max_range = march_limit(H, W, c.range_max, c.resolution);
+    const float res = (float)c.resolution;
+    const float rmax = (float)c.range_max;
+    const double step = nv::linspace_step(c);
+    const float x0 = (float)sh.i0, y0 = (float)sh.j0;
+    const float lx = sh.lx, ly = sh.ly;
+    const double lth = (double)sh.lth;
+    const int nseg = sh.nseg, ndisc = sh.ndisc;
+    int cr = 0, dc = 0;
+#ifdef NAVSIM_CONTIGUOUS_FANS
+    // each wave owns ONE contiguous fan of beams and walks it in 64-beam slices
+    const int n_waves = BLOCK / 64;
+    const int per_wave = (B + n_waves - 1) / n_waves;
+    const int fan0 = ((int)threadIdx.x >> 6) * per_wave;
+    const int fan1 = (fan0 + per_wave < B) ? fan0 + per_wave : B;
+#define NAVSIM_BEAM_OF(base_, q_) (fan0 + (base_) / n_waves + (q_) * 64 + ((int)threadIdx.x & 63))
+#define NAVSIM_BEAM_OK(k_) ((k_) < fan1)
+    for (int base = 0; base < per_wave * n_waves; base += BLOCK * R) {
+#else
+#define NAVSIM_BEAM_OF(base_, q_) ((base_) + (q_) * BLOCK + (int)threadIdx.x)
+#define NAVSIM_BEAM_OK(k_) ((k_) < B)
+    for (int base = 0; base < B; base += BLOCK * R) {
+#endif
+        float dx[R], dy[R], t[R], r[R];
+        unsigned active = 0;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            int k = NAVSIM_BEAM_OF(base, q);
+            bool valid = NAVSIM_BEAM_OK(k);
+            const int kk = valid ? k : 0;
+            const double lin = nv::linspace_k(c, kk, step);
+            double ang = lin + lth;                                     // env.py:388-390
+            float heading = (float)ang;                                 // env.py:424
+            bool fast = false;
+            if (tab) {
+                // heading = lin + lth + delta EXACTLY: (heading - ang) is exact (Sterbenz), and the
+                // rounding error of the float64 sum is recovered by TwoSum
+                double bb = ang - lin;
+                double eps = (lin - (ang - bb)) + (lth - bb);
+                double delta = ((double)heading - ang) + eps;
+                double2 cs = ((const double2*)tab)[kk];
+                fast = nv::beam_dir_from_table(cs.x, cs.y, sh.cT, sh.sT, delta, dx[q], dy[q]);
+            }
+            if (!fast) nv::beam_dir(heading, dx[q], dy[q]);
+            t[q] = sh.t1;                              // the t = 0 probe (origin cell) was taken once
+            r[q] = (sh.r_all >= 0.0f) ? sh.r_all : max_range;
+            active |= (valid && sh.r_all < 0.0f) ? (1u << q) : 0u;
+        }
+        // range_libc RayMarching::calc_range (env.py:425), R rays per thread in lock-step.  The hit
+        // distance is evaluated once after the march (hx, hy), not speculatively in every round.
+        int hx[R], hy[R];
+        unsigned hit = 0;
+        const unsigned uW = (unsigned)W, uH = (unsigned)H;
+        if (R == 1 && tiles) {                               // LDS tile table: two-phase march
+            r[0] = march_ray_tiles(field, tiles, (W + 7) >> 3, x0, y0, dx[0], dy[0], t[0], max_range, uW, uH,
+                                   (active & 1u) != 0u);
+            if (sh.r_all >= 0.0f) r[0] = sh.r_all;
+            active = 0;
+        }
+        while (active) {
+            int px[R], py[R];
+            typename Field::raw_t raw[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                float fx = x0 + dx[q] * t[q];
+                float fy = y0 + dy[q] * t[q];
+                px[q] = (int)fx;
+                py[q] = (int)fy;
+                // px >= W || px < 0 || py < 0 || py >= H, as two unsigned compares
+                bool inb = ((unsigned)px[q] < uW) & ((unsigned)py[q] < uH);
+                bool a = (active >> q) & 1u;
+                if (a && !inb) active &= ~(1u << q);                    // left the map: max_range
+                bool live = a && inb;
+                px[q] = live ? px[q] : 0;
+                py[q] = live ? py[q] : 0;
+                raw[q] = field.load(px[q], py[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                if ((active >> q) & 1u) {
+                    if (field.occupied(raw[q])) {
+                        hx[q] = px[q]; hy[q] = py[q];
+                        hit |= 1u << q;
+                        active &= ~(1u << q);
+                    } else {
+                        t[q] += field.step_of(raw[q], px[q], py[q]);
+                        if (!(t[q] < max_range)) active &= ~(1u << q);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            if ((hit >> q) & 1u) {
+                float xd = (float)hx[q] - x0;
+                float yd = (float)hy[q] - y0;
+                r[q] = sqrtf(xd * xd + yd * yd);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            int k = NAVSIM_BEAM_OF(base, q);
+            if (TO_LDS) {                                               // pedestrian variants: merge later, culled
+                if (NAVSIM_BEAM_OK(k)) { rng_lds[k] = r[q]; dir_lds[k] = make_float2(dx[q], dy[q]); }
+            } else if (NAVSIM_BEAM_OK(k)) {
+                float rr = r[q] * res;                                  // env.py:426
+                for (int p = 0; p < nseg; ++p)
+                    nv::seg_merge(rr, lx, ly, dx[q], dy[q], pr.seg[p][0], pr.seg[p][1], pr.seg[p][2], pr.seg[p][3]);
+                for (int p = 0; p < ndisc; ++p)
+                    nv::circle_merge(rr, lx, ly, dx[q], dy[q], pr.disc[p][0], pr.disc[p][1], nv::kLegRadius);
+                rr = rr < 0.0f ? 0.0f : rr;                             // env.py:435
+                rr = rr > rmax ? rmax : rr;
+                if (noise_std > 0.0f && rr != rmax)                     // env.py:437-440
+                    rr = rr + noise_std * nv::gauss_noise(c.seed ^ noise_key, genv, noise_key, (uint32_t)k);
+                cr |= (rr < thr[k]);
+                dc |= (rr < dthr[k]);
+                obs_row[(size_t)(S - 1) * B + k] = rr;
+                for (int j = 0; j < S - 1; ++j)
+                    if (S - 1 - j > n_hist) obs_row[(size_t)j * B + k] = rr;
+            }
+        }
+    }
+    if (TO_LDS) {
+        __syncthreads();
+        finish_beams<BLOCK>(c, sh, pr, tab, dir_lds, rng_lds, rng_lds, thr, dthr, obs_row, n_hist, noise_std,
+                            noise_key, genv, cr, dc);
+    }
+    crash = cr;
+    discomfort = dc;
+}
+
+// one social-force term of the build-defined pedestrian model: force on agent
+// i from agent j; (0, 0) when the pair is skipped
+__device__ __forceinline__ void sfm_pair(const navsim_config& c, double xi, double yi, double vxi, double vyi,
+                                         double xj, double yj, double vxj, double vyj, double& fx, double& fy) {
+    fx = 0.0; fy = 0.0;
+    double dxx = xj - xi, dyy = yj - yi;
+    double dist = sqrt(dxx * dxx + dyy * dyy);
+    if (dist < 1e-9) return;
+    double ddx = dxx / dist, ddy = dyy / dist;
+    double ivx = c.sfm_lambda * (vxi - vxj) + ddx;
+    double ivy = c.sfm_lambda * (vyi - vyj) + ddy;
+    double il = sqrt(ivx * ivx + ivy * ivy);
+    if (il < 1e-9) return;
+    double idx = ivx / il, idy = ivy / il;
+    double theta = nv::atan2_(idx * ddy - idy * ddx, idx * ddx + idy * ddy);
+    double Bq = c.sfm_gamma * il;
+    double a1 = c.sfm_n_prime * Bq * theta;
+    double a2 = c.sfm_n * Bq * theta;
+    double fv = -nv::exp_neg(-dist / Bq - a1 * a1);
+    double sgn = (theta > 0.0) ? 1.0 : ((theta < 0.0) ? -1.0 : 0.0);
+    double fa = -sgn * nv::exp_neg(-dist / Bq - a2 * a2);
+    fx = fv * idx + fa * (-idy);
+    fy = fv * idy + fa * idx;
+}
+
+// direction of beam k (env.py:388-390, 424): table fast path with proven rounding, else full sincos
+__device__ __forceinline__ void beam_dir_k(const navsim_config& c, const double* __restrict__ tab, int k,
+                                           double step, double lth, double cT, double sT,
+                                           float& dx, float& dy) {
+    const double lin = nv::linspace_k(c, k, step);
+    double ang = lin + lth;
+    float heading = (float)ang;
+    bool fast = false;
+    if (tab) {
+        // heading = lin + lth + delta EXACTLY: (heading - ang) is exact (Sterbenz), and the
+        // rounding error of the float64 sum is recovered by TwoSum
+        double bb = ang - lin;
+        double eps = (lin - (ang - bb)) + (lth - bb);
+        double delta = ((double)heading - ang) + eps;
+        double2 cs = ((const double2*)tab)[k];
+        fast = nv::beam_dir_from_table(cs.x, cs.y, cT, sT, delta, dx, dy);
+    }
+    if (!fast) nv::beam_dir(heading, dx, dy);
+}
+
+// the t = 0 sample of calc_range is the origin cell for every beam: take it once per scan
+template <typename Field>
+__device__ __forceinline__ void first_probe(const Field& field, int i0, int j0, float max_range,
+                                            float& t1, float& r_all) {
+    t1 = 0.0f; r_all = -1.0f;
+    typename Field::raw_t raw0 = field.load(i0, j0);               // origin is clipped into the map
+    if (field.occupied(raw0)) { r_all = 0.0f; return; }            // sqrtf(0): starts inside an obstacle
+    float d0 = field.decode(raw0, i0, j0);
+    float stp = (float)((double)d0 * 0.999);
+    t1 = (stp > 1.0f) ? stp : 1.0f;
+    if (!(t1 < max_range)) r_all = max_range;
+}
+
+// Same march with the arena's analytic tile table in LDS (navsim_build_tiles): a probe whose tile
+// has a valid record gets its exact d2 from one LDS read and integer arithmetic; only probes in
+// mixed tiles read the field (~35 % of the probes, ~3x fewer distinct lines per arena).
+// d2 from a record is the exact integer the field holds, so the sampled sequence is unchanged.
+// (A two-phase form -- lanes run ahead through valid tiles, then load together -- was measured
+// slower: in lock-step the run-ahead iterations of a few lanes stall the whole wave.)
+template <typename Field>
+__device__ __forceinline__ float march_ray_tiles(const Field& field, const uint32_t* __restrict__ tiles, int tpr,
+                                                 float x0, float y0, float dx, float dy, float t,
+                                                 float max_range, unsigned uW, unsigned uH, bool alive) {
+    float result = max_range;
+    while (alive) {
+        float fx = x0 + dx * t;
+        float fy = y0 + dy * t;
+        int px = (int)fx, py = (int)fy;
+        if (!(((unsigned)px < uW) & ((unsigned)py < uH))) break;           // left the map
+        unsigned rec = tiles[(py >> 3) * tpr + (px >> 3)];
+        float d;
+        bool occ;
+        if (rec & kTileValid) {                                            // analytic: no memory access
+            int ddx = (rec & kTileDx0) ? 0 : px - (int)(rec & 0x3FFFu);
+            int ddy = (rec & kTileDy0) ? 0 : py - (int)((rec >> 14) & 0x3FFFu);
+            int d2 = ddx * ddx + ddy * ddy;
+            occ = d2 == 0;
+            d = nv::sqrt_small_int((float)(d2 | (int)occ));
+        } else {                                                           // mixed tile: read the field
+            typename Field::raw_t raw = field.load(px, py);
+            occ = field.occupied(raw);
+            d = occ ? 1.0f : field.decode(raw, px, py);
+        }
+        if (occ) {
+            float xd = (float)px - x0, yd = (float)py - y0;
+            result = sqrtf(xd * xd + yd * yd);
+            break;
+        }
+        float stp = (float)((double)d * 0.999);
+        t += (stp > 1.0f) ? stp : 1.0f;
+        if (!(t < max_range)) break;
+    }
+    return result;
+}
+
+// one ray of calc_range from t = t1 on (env.py:425); returns the raw range in cells
+template <typename Field>
+__device__ __forceinline__ float march_ray(const Field& field, float x0, float y0, float dx, float dy,
+                                           float t, float max_range, unsigned uW, unsigned uH) {
+    for (;;) {
+        float fx = x0 + dx * t;
+        float fy = y0 + dy * t;
+        int px = (int)fx, py = (int)fy;
+        if (!(((unsigned)px < uW) & ((unsigned)py < uH))) return max_range;     // left the map
+        typename Field::raw_t raw = field.load(px, py);
+        if (field.occupied(raw)) {
+            float xd = (float)px - x0;
+            float yd = (float)py - y0;
+            return sqrtf(xd * xd + yd * yd);
+        }
+        t += field.step_of(raw, px, py);
+        if (!(t < max_range)) return max_range;
+    }
+}
+
+// Pedestrians into the scan (env.py:428-432), culled by bearing.  A rectangle side or a leg disc is
+// seen under a small angle, so instead of testing every beam against every primitive (B x P ray
+// tests: 3x the cost of the whole map march at 20 pedestrians) each wave takes one primitive, derives
+// the beam-index interval that can possibly hit it (bearing +- half-width, two beams of margin, all
+// three 2*pi aliases) and runs the SAME float32 seg_merge / circle_merge on those beams only;
+// results land with an LDS atomicMin on the (non-negative) float bits, so they do not depend on the
+// order of primitives.  rng[] holds metres, dir[] the beam directions.
+// One lane per primitive: can it change the clipped scan at all?  Every point of a segment is at least
+// |u| - |v - u| from the lidar (a disc: |u| - r); beyond the clip range a hit cannot matter, because
+// clip(min(r, t)) = clip(r) for t >= range_max.  info[p] < 0 marks such a primitive.
+template <int BLOCK>
+__device__ __forceinline__ void prim_in_range(int nprim, int nseg, float lx, float ly, float rcull, const Prims pr) {
+    for (int p = (int)threadIdx.x; p < nprim; p += BLOCK) {
+        bool skip;
+        if (p < nseg) {
+            float ux = pr.seg[p][0] - lx, uy = pr.seg[p][1] - ly, vx = pr.seg[p][2] - lx, vy = pr.seg[p][3] - ly;
+            skip = sqrtf(ux * ux + uy * uy) - sqrtf((vx - ux) * (vx - ux) + (vy - uy) * (vy - uy)) > rcull;
+        } else {
+            float ux = pr.disc[p - nseg][0] - lx, uy = pr.disc[p - nseg][1] - ly;
+            skip = sqrtf(ux * ux + uy * uy) - nv::kLegRadius > rcull;
+        }
+        pr.info[p] = skip ? -1.0f : 1.0f;
+    }
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void merge_prims_culled_core(int B, float lx, float ly, float stepf, float beta0,
+                                                        int nseg, int ndisc, const Prims pr,
+                                                        const float2* __restrict__ dir, float* __restrict__ rng,
+                                                        float rcull) {
+    const int lane = (int)threadIdx.x & 63;
+    const float kTwoPiF = 6.2831853f;
+    const float Kf = (stepf > 0.0f) ? kTwoPiF / stepf : 0.0f;
+    const int nprim = nseg + ndisc;
+    prim_in_range<BLOCK>(nprim, nseg, lx, ly, rcull, pr);
+    __syncthreads();
+    // eight lanes per primitive, eight primitives per wavefront at a time (a pedestrian a few metres away
+    // spans 10-50 beams; measured 4 / 8 / 16 / 32 / 64 lanes: c3 11.81 / 11.80 / 11.68 / 11.13 / 10.26 M env-steps/s)
+#ifndef NAVSIM_MERGE_G
+#define NAVSIM_MERGE_G 8
+#endif
+    constexpr int G = NAVSIM_MERGE_G;
+    const int sub = lane & (G - 1);
+    for (int p = ((int)threadIdx.x) / G; p < nprim; p += BLOCK / G) {
+        if (pr.info[p] < 0.0f) continue;                            // beyond the clip range
+        const bool is_seg = p < nseg;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float ac = 0.0f, w = 0.0f;
+        bool full = (stepf <= 0.0f);
+        if (is_seg) {
+            a0 = pr.seg[p][0]; a1 = pr.seg[p][1]; a2 = pr.seg[p][2]; a3 = pr.seg[p][3];
+            float ux = a0 - lx, uy = a1 - ly, vx = a2 - lx, vy = a3 - ly;
+            float b1 = atan2f(uy, ux), b2 = atan2f(vy, vx);
+            float d = b2 - b1;
+            d -= kTwoPiF * floorf(d / kTwoPiF + 0.5f);              // (-pi, pi]
+            ac = b1 + 0.5f * d;
+            w = 0.5f * fabsf(d);
+            if (fabsf(d) > 3.0f || ux * ux + uy * uy < 1e-6f || vx * vx + vy * vy < 1e-6f) full = true;
+        } else {
+            a0 = pr.disc[p - nseg][0]; a1 = pr.disc[p - nseg][1];
+            float ux = a0 - lx, uy = a1 - ly;
+            float dist = sqrtf(ux * ux + uy * uy);
+            if (dist <= nv::kLegRadius * 1.05f) full = true;
+            else { ac = atan2f(uy, ux); w = asinf(fminf(1.0f, nv::kLegRadius / dist)); }
+        }
+        float rel = ac - beta0;
+        rel -= kTwoPiF * floorf(rel / kTwoPiF + 0.5f);              // [-pi, pi)
+        const float klo = (rel - w) / stepf - 2.0f, khi = (rel + w) / stepf + 2.0f;
+        for (int m = full ? 0 : -1; m <= (full ? 0 : 1); ++m) {
+            int k0 = full ? 0 : (int)floorf(klo + (float)m * Kf);
+            int k1 = full ? B - 1 : (int)ceilf(khi + (float)m * Kf);
+            k0 = k0 < 0 ? 0 : k0;
+            k1 = k1 > B - 1 ? B - 1 : k1;
+            for (int k = k0 + sub; k <= k1; k += G) {
+                float2 d = dir[k];
+                float old = rng[k], rr = old;
+                if (is_seg) nv::seg_merge(rr, lx, ly, d.x, d.y, a0, a1, a2, a3);
+                else        nv::circle_merge(rr, lx, ly, d.x, d.y, a0, a1, nv::kLegRadius);
+                if (rr < old) atomicMin((int*)&rng[k], __float_as_int(rr));
+            }
+        }
+    }
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void merge_prims_culled(const navsim_config& c, const StepShared& sh, const Prims pr,
+                                                   const float2* __restrict__ dir, float* __restrict__ rng) {
+    merge_prims_culled_core<BLOCK>(c.n_beams, sh.lx, sh.ly, (float)nv::linspace_step(c),
+                                   (float)(c.angle_min + (double)sh.lth), sh.nseg, sh.ndisc, pr, dir, rng,
+                                   (float)c.range_max * 1.0001f + 0.01f);
+}
+
+// raw ranges (cells) -> metres, pedestrians, clip, noise, crash / discomfort flags, observation row
+// (env.py:426-440 + the stack fill of env.py:262-265).  `dir` may be NULL: directions are then
+// recomputed (same function, same values) for the beams that need them.
+template <int BLOCK>
+__device__ __forceinline__ void finish_beams(const navsim_config& c, const StepShared& sh, const Prims pr,
+                                             const double* __restrict__ tab, const float2* __restrict__ dir,
+                                             const float* __restrict__ rng, float* __restrict__ rng_rw,
+                                             const float* __restrict__ thr, const float* __restrict__ dthr,
+                                             float* __restrict__ obs_row, int n_hist, float noise_std,
+                                             uint64_t noise_key, uint64_t genv, int& crash, int& discomfort) {
+    const int B = c.n_beams, S = c.n_scan_stack;
+    const float res = (float)c.resolution;
+    const float rmax = (float)c.range_max;
+    const double step = nv::linspace_step(c);
+    const float lx = sh.lx, ly = sh.ly;
+    const int nseg = sh.nseg, ndisc = sh.ndisc;
+    const float r_all = sh.r_all;
+    int cr = 0, dc = 0;
+    const bool culled = dir && rng_rw && (nseg | ndisc);           // LDS-resident: bearing-culled merge
+    if (culled) {
+        for (int k = (int)threadIdx.x; k < B; k += BLOCK)
+            rng_rw[k] = ((r_all >= 0.0f) ? r_all : rng[k]) * res;   // env.py:426
+        __syncthreads();
+        merge_prims_culled<BLOCK>(c, sh, pr, dir, rng_rw);
+        __syncthreads();
+    }
+    for (int k = (int)threadIdx.x; k < B; k += BLOCK) {
+        float rr = culled ? rng[k] : ((r_all >= 0.0f) ? r_all : rng[k]) * res;
+        if (!culled && (nseg | ndisc)) {
+            float dx, dy;
+            if (dir) { float2 d = dir[k]; dx = d.x; dy = d.y; }
+            else beam_dir_k(c, tab, k, step, (double)sh.lth, sh.cT, sh.sT, dx, dy);
+            for (int p = 0; p < nseg; ++p)
+                nv::seg_merge(rr, lx, ly, dx, dy, pr.seg[p][0], pr.seg[p][1], pr.seg[p][2], pr.seg[p][3]);
+            for (int p = 0; p < ndisc; ++p)
+                nv::circle_merge(rr, lx, ly, dx, dy, pr.disc[p][0], pr.disc[p][1], nv::kLegRadius);
+        }
+        rr = rr < 0.0f ? 0.0f : rr;                                 // env.py:435
+        rr = rr > rmax ? rmax : rr;
+        if (noise_std > 0.0f && rr != rmax)                         // env.py:437-440
+            rr = rr + noise_std * nv::gauss_noise(c.seed ^ noise_key, genv, noise_key, (uint32_t)k);
+        cr |= (rr < thr[k]);
+        dc |= (rr < dthr[k]);
+        obs_row[(size_t)(S - 1) * B + k] = rr;
+        for (int j = 0; j < S - 1; ++j)
+            if (S - 1 - j > n_hist) obs_row[(size_t)j * B + k] = rr;
+    }
+    crash = cr;
+    discomfort = dc;
+}
+
+// Predicated one-ray-per-lane scan (R == 11 variant): the march loop has ONE wave-level branch
+// (any lane still marching?) instead of a divergent if-ladder per probe; finished or out-of-map
+// lanes keep executing with their updates masked off.  Same results as scan_beams.
+template <int BLOCK, typename Field>
+__device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const StepShared& sh,
+                                                const Field& field, const double* __restrict__ tab,
+                                                const Prims pr,
+                                                const float* __restrict__ thr, const float* __restrict__ dthr,
+                                                float* __restrict__ obs_row, int n_hist, float noise_std,
+                                                uint64_t noise_key, uint64_t genv,
+                                                int& crash, int& discomfort) {
+    const int B = c.n_beams, S = c.n_scan_stack, H = c.map_h, W = c.map_w;
+    const float max_range = march_limit(H, W, c.range_max, c.resolution);
+    const float res = (float)c.resolution;
+    const float rmax = (float)c.range_max;
+    const double step = nv::linspace_step(c);
+    const float x0 = (float)sh.i0, y0 = (float)sh.j0;
+    const float lx = sh.lx, ly = sh.ly;
+    const int nseg = sh.nseg, ndisc = sh.ndisc;
+    const unsigned uW = (unsigned)W, uH = (unsigned)H;
+    const float t1 = sh.t1, r_all = sh.r_all;
+    int cr = 0, dc = 0;
+    for (int k = (int)threadIdx.x; k < B; k += BLOCK) {
+        float dx, dy;
+        beam_dir_k(c, tab, k, step, (double)sh.lth, sh.cT, sh.sT, dx, dy);
+        float t = t1;
+        bool active = r_all < 0.0f;
+        bool hit = false;
+        int hx = 0, hy = 0;
+        while (__any(active)) {
+            float fx = x0 + dx * t;
+            float fy = y0 + dy * t;
+            int px = (int)fx, py = (int)fy;
+            bool live = active & ((unsigned)px < uW) & ((unsigned)py < uH);
+            px = live ? px : 0;
+            py = live ? py : 0;
+            typename Field::raw_t raw = field.load(px, py);
+            bool occ = live & field.occupied(raw);
+            hx = occ ? px : hx;
+            hy = occ ? py : hy;
+            hit |= occ;
+            float tn = t + field.step_of(raw, px, py);
+            bool go = live & !occ;
+            t = go ? tn : t;
+            active = go & (tn < max_range);
+        }
+        float rr = (r_all >= 0.0f) ? r_all : max_range;
+        if (hit) {
+            float xd = (float)hx - x0;
+            float yd = (float)hy - y0;
+            rr = sqrtf(xd * xd + yd * yd);
+        }
+        rr = rr * res;                                          // env.py:426
+        for (int p = 0; p < nseg; ++p)
+            nv::seg_merge(rr, lx, ly, dx, dy, pr.seg[p][0], pr.seg[p][1], pr.seg[p][2], pr.seg[p][3]);
+        for (int p = 0; p < ndisc; ++p)
+            nv::circle_merge(rr, lx, ly, dx, dy, pr.disc[p][0], pr.disc[p][1], nv::kLegRadius);
+        rr = rr < 0.0f ? 0.0f : rr;                             // env.py:435
+        rr = rr > rmax ? rmax : rr;
+        if (noise_std > 0.0f && rr != rmax)                     // env.py:437-440
+            rr = rr + noise_std * nv::gauss_noise(c.seed ^ noise_key, genv, noise_key, (uint32_t)k);
+        cr |= (rr < thr[k]);
+        dc |= (rr < dthr[k]);
+        obs_row[(size_t)(S - 1) * B + k] = rr;
+        for (int j = 0; j < S - 1; ++j)
+            if (S - 1 - j > n_hist) obs_row[(size_t)j * B + k] = rr;
+    }
+    crash = cr;
+    discomfort = dc;
+}
+
+// Wave-dynamic robot scan (R == 0 variants; the default).  Same results as scan_beams, different
+// schedule, built on what the profiles showed (profiles/README.md):
+//   * lanes of a wave finish their rays after very different numbers of probes (mean 7.9, wave
+//     maximum 13.5), so with one fixed ray per lane 45 % of the issue slots idle.  Here every wave
+//     owns a contiguous fan of beams and a lane that finishes a ray immediately takes the next
+//     unassigned beam of its wave (ballot + popcount, no atomics) -- "persistent lanes";
+//   * beam directions are produced once per scan by a coalesced pass into LDS, so a refill is one
+//     ds_read_b64; ranges go back to LDS and a second coalesced pass merges pedestrians, clips,
+//     adds noise, raises the crash / discomfort flags and stores the observation row;
+//   * the first probe (the robot's own cell) is identical for every beam and is taken once.
+template <int BLOCK, typename Field>
+__device__ __forceinline__ void scan_beams_dyn(const navsim_config& c, StepShared& sh,
+                                               const Field& field, const double* __restrict__ tab,
+                                               const Prims pr, float2* __restrict__ dir, float* __restrict__ rng,
+                                               const float* __restrict__ thr, const float* __restrict__ dthr,
+                                               float* __restrict__ obs_row, int n_hist, float noise_std,
+                                               uint64_t noise_key, uint64_t genv,
+                                               int& crash, int& discomfort) {
+    const int B = c.n_beams, H = c.map_h, W = c.map_w;
+    const float max_range = march_limit(H, W, c.range_max, c.resolution);
+    const double step = nv::linspace_step(c);
+    const float x0 = (float)sh.i0, y0 = (float)sh.j0;
+    const int tid = (int)threadIdx.x;
+
+    // ---- pass 1: beam directions -> LDS
+    for (int k = tid; k < B; k += BLOCK) {
+        float dx, dy;
+        beam_dir_k(c, tab, k, step, (double)sh.lth, sh.cT, sh.sT, dx, dy);
+        dir[k] = make_float2(dx, dy);
+    }
+    const float t1 = sh.t1, r_all = sh.r_all;                // first probe, taken by thread 0 earlier
+    __syncthreads();
+
+    // ---- pass 2: march (env.py:425), persistent lanes
+    if (r_all < 0.0f) {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int per = (B + (BLOCK / 64) - 1) / (BLOCK / 64);
+        int next = wave * per;
+        const int end = (next + per < B) ? next + per : B;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const unsigned uW = (unsigned)W, uH = (unsigned)H;
+        bool active = false;
+        int k = 0;
+        float t = 0.0f, dx = 0.0f, dy = 0.0f;
+        for (;;) {
+            unsigned long long idle = __ballot(!active);
+            if (next < end && idle) {
+                int my = next + __popcll(idle & lt);
+                if (!active && my < end) {
+                    k = my;
+                    float2 d = dir[k];
+                    dx = d.x; dy = d.y;
+                    t = t1;
+                    active = true;
+                }
+                next += __popcll(idle);
+            }
+            if (!__any(active)) break;
+            if (active) {
+                float fx = x0 + dx * t;
+                float fy = y0 + dy * t;
+                int px = (int)fx, py = (int)fy;
+                if (!(((unsigned)px < uW) & ((unsigned)py < uH))) {
+                    rng[k] = max_range;                             // left the map
+                    active = false;
+                } else {
+                    typename Field::raw_t raw = field.load(px, py);
+                    if (field.occupied(raw)) {
+                        float xd = (float)px - x0;
+                        float yd = (float)py - y0;
+                        rng[k] = sqrtf(xd * xd + yd * yd);
+                        active = false;
+                    } else {
+                        t += field.step_of(raw, px, py);
+                        if (!(t < max_range)) { rng[k] = max_range; active = false; }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 3
+    finish_beams<BLOCK>(c, sh, pr, tab, dir, rng, rng, thr, dthr, obs_row, n_hist, noise_std, noise_key, genv,
+                        crash, discomfort);
+}
+
+// ============================================================================================
+// Pool scan: the march of ALL arenas as one flat pool of 64-beam wave tasks.  No workgroup barrier,
+// no idle waves waiting for an arena's slowest fan: a CU always holds 32 marching waves, whatever
+// the number of arenas.  Reads each arena's scan request (StepShared slot in the workspace), writes
+// raw ranges in cells.  `only_flagged`: the re-scan after a crash revert / respawn (env.py:718-723).
+// ============================================================================================
+template <typename Field>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void pool_scan_kernel(navsim_config c, navsim_state st, char* __restrict__ ws_env, float* __restrict__ ranges,
+                      int only_flagged, unsigned n_blocks_logical) {
+    // XCD-aware block order: consecutive logical blocks (the fans of one arena) share an XCD's L2
+    const unsigned nb = gridDim.x;
+    unsigned bid = blockIdx.x;
+    if ((nb & 7u) == 0u) bid = (bid & 7u) * (nb >> 3) + (bid >> 3);
+    if (bid >= n_blocks_logical) return;
+    const int B = c.n_beams;
+    const int G = (B + 63) >> 6;
+    const unsigned task = bid * 4u + (threadIdx.x >> 6);
+    const int e = (int)(task / (unsigned)G);
+    if (e >= c.n_envs) return;
+    const int g = (int)(task - (unsigned)e * (unsigned)G);
+    const StepShared* __restrict__ s = (const StepShared*)(ws_env + (size_t)e * kPoolEnvBytes);
+    if (only_flagged && !s->rescan) return;
+    const float r_all = s->r_all;
+    if (r_all >= 0.0f) return;                                   // finish_beams supplies the range
+    const int k = g * 64 + (int)(threadIdx.x & 63);
+    if (k >= B) return;
+    const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, c.map_h, c.map_w);
+    float dx, dy;
+    beam_dir_k(c, st.beam_table, k, nv::linspace_step(c), (double)s->lth, s->cT, s->sT, dx, dy);
+    const float max_range = march_limit(c.map_h, c.map_w, c.range_max, c.resolution);
+    ranges[(size_t)e * B + k] = march_ray(field, (float)s->i0, (float)s->j0, dx, dy, s->t1, max_range,
+                                          (unsigned)c.map_w, (unsigned)c.map_h);
+}
+
+// MODE 0: the whole step in one launch.  MODE 1 / 2 / 3: the same code cut at the scan, for the
+// pooled schedule (navsim_step with a workspace): 1 = everything before the scan, then the arena's
+// StepShared (+ pedestrian primitives) is parked in the workspace; pool_scan_kernel marches;
+// 2 = flags, reward / done / info, relocation decision and -- unless the arena must be re-scanned --
+// the observation row and state; 3 = the same tail for re-scanned arenas.
+enum { kModeFused = 0, kModePre = 1, kModePost = 2, kModeFinal = 3 };
+
+// Phase 1 for the pedestrians of one arena (env.py:617-693 with the build-defined social force or external
+// commands): waypoint pop, forces / integration, new goal, leg odometry, state.  Called by every thread of the
+// workgroup (it synchronises); pedestrian i lives on thread i.  Shared by the fused step kernel and by
+// ped_update_kernel, which runs it on one wavefront per arena ahead of the step.
+template <int BLOCK, typename Field>
+__device__ __forceinline__ void ped_phase(const navsim_config& c, const navsim_state& st, const Field& field, int e,
+                                          int n, int tid, bool is_ped, size_t pq, double dt, uint64_t genv,
+                                          uint64_t steps_now, const double* old_rp, double prev_v, const PedShared& ps,
+                                          char* pair_scratch, unsigned pair_bytes, double (&pp)[3], double (&pvel)[2]) {
+    const int N = c.max_peds, P = NAVSIM_MAX_WAYPOINTS;
+    (void)N;
+    double* wp = st.ped_waypoints ? st.ped_waypoints + (pq * P) * 2 : nullptr;
+    int nw = 1;
+    if (is_ped) {
+        nw = st.ped_n_waypoints[pq];
+        while (nw > 1) {                                   // env.py:633-642
+            double ddx = pp[0] - wp[0], ddy = pp[1] - wp[1];
+            if (sqrt(ddx * ddx + ddy * ddy) < 1.0) {
+                for (int k = 0; k + 1 < nw; ++k) { wp[2 * k] = wp[2 * k + 2]; wp[2 * k + 1] = wp[2 * k + 3]; }
+                nw -= 1;
+            } else break;
+        }
+    }
+    if (c.ped_model == NAVSIM_PED_SFM) {
+        // stage every agent's position / velocity at time t (pedestrians, then the robot)
+        if (is_ped) { ps.ax[tid] = pp[0]; ps.ay[tid] = pp[1]; ps.avx[tid] = pvel[0]; ps.avy[tid] = pvel[1]; }
+        if (tid == 0) {
+            double s, cs;
+            nv::sincos(old_rp[2], s, cs);
+            ps.ax[n] = old_rp[0]; ps.ay[n] = old_rp[1];
+            ps.avx[n] = prev_v * cs; ps.avy[n] = prev_v * s;
+        }
+        __syncthreads();
+        // the n*(n+1) pair terms are independent: spread them over the whole workgroup (LDS scratch
+        // = the scan's dir/rng area, free until the march), then every pedestrian adds its row in
+        // partner order -- the same sums, in the same order, as a sequential loop
+        double2* pair = (double2*)pair_scratch;
+        const bool pair_par = pair_bytes >= (unsigned)(n * (n + 1)) * sizeof(double2) && n > 1;
+        if (pair_par) {
+            for (int t = tid; t < n * (n + 1); t += BLOCK) {
+                int i = t / (n + 1), j = t - i * (n + 1);
+                double fx = 0.0, fy = 0.0;
+                if (j != i)
+                    sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
+                pair[t] = make_double2(fx, fy);
+            }
+            __syncthreads();
+        }
+        if (is_ped) {
+            const int i = tid;
+            double vpref = st.ped_v_pref[pq];
+            double ex = wp[0] - ps.ax[i], ey = wp[1] - ps.ay[i];
+            double L = sqrt(ex * ex + ey * ey);
+            if (L > 1e-9) { ex = ex / L; ey = ey / L; } else { ex = 0.0; ey = 0.0; }
+            double fdx = (vpref * ex - ps.avx[i]) / c.sfm_tau;
+            double fdy = (vpref * ey - ps.avy[i]) / c.sfm_tau;
+            double fsx = 0.0, fsy = 0.0;
+            for (int j = 0; j <= n; ++j) {
+                if (j == i) continue;
+                double fx, fy;
+                if (pair_par) { double2 f = pair[i * (n + 1) + j]; fx = f.x; fy = f.y; }
+                else sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
+                fsx += fx;
+                fsy += fy;
+            }
+            double fox = 0.0, foy = 0.0;
+            {
+                const int H = c.map_h, W = c.map_w;
+                int ci, cj;
+                nv::xy_to_ij(ps.ax[i], ps.ay[i], c, ci, cj);
+                ci = ci > W - 1 ? W - 1 : ci;
+                cj = cj > H - 1 ? H - 1 : cj;
+                int il_ = ci > 0 ? ci - 1 : 0, ir = ci < W - 1 ? ci + 1 : W - 1;
+                int jl = cj > 0 ? cj - 1 : 0, jr = cj < H - 1 ? cj + 1 : H - 1;
+                double d = (double)field.at(ci, cj) * c.resolution;
+                double gx = (double)field.at(ir, cj) - (double)field.at(il_, cj);
+                double gy = (double)field.at(ci, jr) - (double)field.at(ci, jl);
+                double gl = sqrt(gx * gx + gy * gy);
+                if (gl > 0.0) {
+                    double mag = nv::exp_neg(-(d - c.sfm_agent_radius) / c.sfm_sigma_obstacle);
+                    fox = mag * (gx / gl);
+                    foy = mag * (gy / gl);
+                }
+            }
+            double accx = c.sfm_k_desired * fdx + c.sfm_k_social * fsx + c.sfm_k_obstacle * fox;
+            double accy = c.sfm_k_desired * fdy + c.sfm_k_social * fsy + c.sfm_k_obstacle * foy;
+            double vx = ps.avx[i] + accx * dt;
+            double vy = ps.avy[i] + accy * dt;
+            double sp = sqrt(vx * vx + vy * vy);
+            if (sp > vpref) {
+                double k = (sp > 0.0) ? vpref / sp : 0.0;
+                vx = vx * k; vy = vy * k;
+            }
+            pp[0] = pp[0] + vx * dt;
+            pp[1] = pp[1] + vy * dt;
+            double sp2 = sqrt(vx * vx + vy * vy);
+            if (sp2 > 1e-6) pp[2] = nv::mod_2pi(nv::atan2_(vy, vx));
+            pvel[0] = vx; pvel[1] = vy;
+        }
+    } else if (c.ped_model == NAVSIM_PED_EXTERNAL && is_ped) {
+        const double* cmd = st.ped_cmd + pq * 2;
+        nv::set_vel(pp, cmd[0], cmd[1], dt, 0.0, pvel);     // env.py:662
+    }
+    if (is_ped) {
+        // ---- new goal at the final waypoint (env.py:667-680): table draw, or wait for navsim_replan
+        double ddx = pp[0] - wp[2 * (nw - 1)], ddy = pp[1] - wp[2 * (nw - 1) + 1];
+        if (sqrt(ddx * ddx + ddy * ddy) < 0.5 && c.n_spawn > 0 && st.spawn_pose && !st.costmap) {
+            uint64_t h = nv::hash4(c.seed, genv, (uint64_t)tid + 1000, steps_now);
+            for (int tries = 0; tries < c.n_spawn; ++tries) {
+                int idx = (int)((h + (uint64_t)tries) % (uint64_t)c.n_spawn);
+                const double* cand = st.spawn_pose + ((size_t)e * c.n_spawn + idx) * 3;
+                double gx = cand[0] - pp[0], gy = cand[1] - pp[1];
+                if (sqrt(gx * gx + gy * gy) > 10.0) {
+                    wp[0] = cand[0]; wp[1] = cand[1]; nw = 1;
+                    break;
+                }
+            }
+        }
+        st.ped_n_waypoints[pq] = nw;
+        // ---- leg odometry, then the pedestrian's obs yaw (env.py:683-693)
+        double dist[3] = {st.ped_dist[pq * 3], st.ped_dist[pq * 3 + 1], st.ped_dist[pq * 3 + 2]};
+        nv::leg_odometry(pp, pvel, st.ped_prev_yaw[pq], dt, dist);
+        st.ped_dist[pq * 3] = dist[0]; st.ped_dist[pq * 3 + 1] = dist[1]; st.ped_dist[pq * 3 + 2] = dist[2];
+        st.ped_prev_yaw[pq] = nv::wrap_pi(pp[2]);
+        st.ped_pose[pq * 3] = pp[0]; st.ped_pose[pq * 3 + 1] = pp[1]; st.ped_pose[pq * 3 + 2] = pp[2];
+        st.ped_vel[pq * 2] = pvel[0]; st.ped_vel[pq * 2 + 1] = pvel[1];
+    }
+}
+
+// The pedestrians of every arena, one wavefront per arena, launched ahead of the fused step.  Inside the step
+// this phase is a third of a workgroup's lifetime during which three of its four wavefronts only hold their
+// slots; here an arena costs one wavefront.  Same device function, same results.
+template <typename Field>
+__global__ __launch_bounds__(64) void ped_update_kernel(navsim_config c, navsim_state st) {
+    extern __shared__ __attribute__((aligned(16))) char ped_dyn[];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const int N = c.max_peds;
+    int n = st.n_peds[e];
+    n = n > N ? N : n;
+    if (n <= 0) return;
+    const unsigned pair_bytes = (unsigned)(((size_t)N * (N + 1) * sizeof(double2) + 15) & ~(size_t)15);
+    const PedShared ps = ped_lds_carve(ped_dyn + pair_bytes, N);
+    const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, c.map_h, c.map_w);
+    const double old_rp[3] = {st.robot_pose[3 * (size_t)e], st.robot_pose[3 * (size_t)e + 1], st.robot_pose[3 * (size_t)e + 2]};
+    const double prev_v = st.prev_action[2 * (size_t)e];
+    const size_t pq = (size_t)e * N + (tid < n ? tid : 0);
+    const bool is_ped = tid < n;
+    double pp[3] = {0.0, 0.0, 0.0}, pvel[2] = {0.0, 0.0};
+    if (is_ped) {
+        pp[0] = st.ped_pose[pq * 3]; pp[1] = st.ped_pose[pq * 3 + 1]; pp[2] = st.ped_pose[pq * 3 + 2];
+        pvel[0] = st.ped_vel[pq * 2]; pvel[1] = st.ped_vel[pq * 2 + 1];
+    }
+    // the step increments steps[e] before anything else (env.py:592); it has not run yet
+    ped_phase<64, Field>(c, st, field, e, n, tid, is_ped, pq, c.time_step, (uint64_t)(c.env_index_base + e),
+                         (uint64_t)st.steps[e] + 1, old_rp, prev_v, ps, ped_dyn, pair_bytes, pp, pvel);
+}
+
+template <int BLOCK, int R, bool PEDS, typename Field, int MODE>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void navsim_step_kernel(navsim_config c, navsim_state st,
+                                                            navsim_step_io io, int reset_only,
+                                                            const uint8_t* __restrict__ reset_mask,
+                                                            char* __restrict__ ws_env, char* __restrict__ ws_prims,
+                                                            float* __restrict__ ws_ranges, unsigned dyn_lds_bytes,
+                                                            unsigned tile_lds_bytes) {
+    __shared__ StepShared sh;
+    const int peds_done = (reset_only >> 1) & 1;     // the pedestrians were advanced by ped_update_kernel
+    reset_only &= 1;
+    // dynamic LDS: [analytic tile table of the arena, tile_lds_bytes][float2 dir[B], float rng[B]]
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds_all[];
+    char* dyn_lds = dyn_lds_all + tile_lds_bytes;
+    const uint32_t* tiles_lds = tile_lds_bytes ? (const uint32_t*)dyn_lds_all : nullptr;
+    PedShared ps = {};
+    if constexpr (PEDS) ps = ped_lds_carve(dyn_lds + ((dyn_lds_bytes + 15u) & ~15u), c.max_peds);
+    const Prims prims = {ps.seg, ps.disc, ps.info};
+    // longest-first launch order (a scheduling hint: which arena a workgroup takes never changes a result)
+    const int e = (MODE == kModeFused && st.launch_order) ? st.launch_order[blockIdx.x] : (int)blockIdx.x;
+    const int tid = threadIdx.x;
+    unsigned long long t_begin = 0;
+    if (MODE == kModeFused && st.arena_cost && tid == 0) t_begin = __builtin_amdgcn_s_memrealtime();
+    if (tile_lds_bytes) {                                       // stage the arena's tile table (coalesced)
+        const uint4* src = (const uint4*)((const char*)st.tile_table + (size_t)(c.shared_field ? 0 : e) * tile_lds_bytes);
+        uint4* dst = (uint4*)dyn_lds_all;
+        for (int i = tid; i < (int)(tile_lds_bytes / 16); i += BLOCK) dst[i] = src[i];
+        // visibility: every path reaches a __syncthreads() before the first scan
+    }
+    const int B = c.n_beams, S = c.n_scan_stack, N = c.max_peds, D = S * B + 7;
+    const double dt = c.time_step;
+    const uint64_t genv = (uint64_t)(c.env_index_base + e);
+    const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, c.map_h, c.map_w);
+    float* obs_row = io.obs + (size_t)e * D;
+    const float* obs_prev = io.obs_prev ? io.obs_prev + (size_t)e * D : nullptr;
+    double* rp_g = st.robot_pose + 3 * (size_t)e;
+    double* goal_g = st.robot_goal + 2 * (size_t)e;
+    double* pa_g = st.prev_action + 2 * (size_t)e;
+    double* pv_g = st.prev_pose + 3 * (size_t)e;
+
+    if (reset_only && reset_mask && !reset_mask[e]) {          // untouched env: carry the row over
+        if ((MODE == kModeFused || MODE == kModePre) && obs_prev)
+            for (int k = tid; k < D; k += BLOCK) obs_row[k] = obs_prev[k];
+        return;
+    }
+    StepShared* slot = (MODE == kModeFused) ? nullptr : (StepShared*)(ws_env + (size_t)e * kPoolEnvBytes);
+    constexpr int kPrimWords = (int)((sizeof(float) * 4 * 4 * NAVSIM_MAX_PEDS + sizeof(float) * 2 * 2 * NAVSIM_MAX_PEDS) / 4);
+    if constexpr (MODE == kModePost || MODE == kModeFinal) {
+        if (MODE == kModeFinal && !slot->rescan) return;        // nothing was re-scanned for this arena
+        for (int i = tid; i < (int)(sizeof(StepShared) / 4); i += BLOCK) ((int*)&sh)[i] = ((const int*)slot)[i];
+        if constexpr (PEDS) {
+            const int* src = (const int*)(ws_prims + (size_t)e * kPrimWords * 4);
+            for (int i = tid; i < 20 * c.max_peds; i += BLOCK) ((int*)ps.seg)[i] = src[i];   // seg, then disc
+        }
+        __syncthreads();
+    }
+
+    int n = (!PEDS || c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
+    n = n > N ? N : n;
+    const float noise_std = (c.add_scan_noise && st.scan_noise_std) ? st.scan_noise_std[e] : 0.0f;
+
+    NAVSIM_STAMP(0);
+    if constexpr (MODE == kModeFused || MODE == kModePre) {
+    // ---------------------------------------------------------------- phase 0: scalars
+    if (tid == 0) {
+        sh.old_rp[0] = rp_g[0]; sh.old_rp[1] = rp_g[1]; sh.old_rp[2] = rp_g[2];
+        sh.nseg = 0; sh.ndisc = 0; sh.rescan = 0; sh.respawn = 0;
+        if (!reset_only) {
+            double a0 = io.action[2 * e], a1 = io.action[2 * e + 1];
+            st.steps[e] += 1;                                  // env.py:592
+            if (c.min_turning_radius > 0.0) {                  // env.py:595-600
+                double lim = fabs(a1) * c.min_turning_radius;
+                if (a0 >= 0.0) a0 = (a0 > lim) ? a0 : lim;
+                else           a0 = (a0 < -lim) ? a0 : -lim;
+            }
+            sh.act[0] = a0; sh.act[1] = a1;
+        }
+    }
+    __syncthreads();
+
+    NAVSIM_STAMP(1);
+    // ---------------------------------------------------------------- phase 1: pedestrians
+    double pp[3] = {0.0, 0.0, 0.0};
+    double pvel[2] = {0.0, 0.0};
+    const size_t pq = (size_t)e * N + (tid < n ? tid : 0);
+    const bool is_ped = PEDS && tid < n;
+    if (is_ped) {
+        pp[0] = st.ped_pose[pq * 3]; pp[1] = st.ped_pose[pq * 3 + 1]; pp[2] = st.ped_pose[pq * 3 + 2];
+        pvel[0] = st.ped_vel[pq * 2]; pvel[1] = st.ped_vel[pq * 2 + 1];
+    }
+    if (!reset_only && !PEDS) {
+        if (tid == 0) {                                         // env.py:664
+            double p[3] = {sh.old_rp[0], sh.old_rp[1], sh.old_rp[2]};
+            nv::set_vel(p, sh.act[0], sh.act[1], dt, c.axle_offset, nullptr);
+            sh.rp[0] = p[0]; sh.rp[1] = p[1]; sh.rp[2] = p[2];
+        }
+    } else if (!reset_only) {
+        if (!peds_done)
+            ped_phase<BLOCK, Field>(c, st, field, e, n, tid, is_ped, pq, dt, genv, (uint64_t)st.steps[e], sh.old_rp, pa_g[0],
+                                    ps, dyn_lds, dyn_lds_bytes, pp, pvel);
+        // ---- robot (env.py:664)
+        if (tid == 0) {
+            double p[3] = {sh.old_rp[0], sh.old_rp[1], sh.old_rp[2]};
+            nv::set_vel(p, sh.act[0], sh.act[1], dt, c.axle_offset, nullptr);
+            sh.rp[0] = p[0]; sh.rp[1] = p[1]; sh.rp[2] = p[2];
+        }
+    } else {
+        if (tid == 0) { sh.rp[0] = sh.old_rp[0]; sh.rp[1] = sh.old_rp[1]; sh.rp[2] = sh.old_rp[2]; }
+        if (is_ped) {                                           // env.py:809, 812-820
+            st.ped_dist[pq * 3] = 0.0; st.ped_dist[pq * 3 + 1] = 0.0; st.ped_dist[pq * 3 + 2] = 0.0;
+            st.ped_prev_yaw[pq] = nv::wrap_pi(pp[2]);
+        }
+    }
+
+    // ---------------------------------------------------------------- phase 2: what the lidar sees
+    if (is_ped) {                                               // env.py:392-414
+        float dist3[3];
+        if (reset_only) { dist3[0] = dist3[1] = dist3[2] = 0.0f; }
+        else { dist3[0] = (float)st.ped_dist[pq * 3]; dist3[1] = (float)st.ped_dist[pq * 3 + 1];
+               dist3[2] = (float)st.ped_dist[pq * 3 + 2]; }
+        if (st.ped_has_legs[pq] && c.lidar_legs) {
+            float cc[4];
+            nv::leg_centres((float)pp[0], (float)pp[1], (float)pp[2], dist3[0], dist3[1], dist3[2], cc);
+            int q = atomicAdd(&sh.ndisc, 2);
+            ps.disc[q][0] = cc[0]; ps.disc[q][1] = cc[1];
+            ps.disc[q + 1][0] = cc[2]; ps.disc[q + 1][1] = cc[3];
+        } else {
+            const double fpx[4] = {0.22, -0.22, -0.22, 0.22};   // human.py:5-10
+            const double fpy[4] = {0.19, 0.19, -0.19, -0.19};
+            double s, cs;
+            nv::sincos(pp[2], s, cs);
+            float vx[4], vy[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                vx[v] = (float)((cs * fpx[v] - s * fpy[v]) + pp[0]);
+                vy[v] = (float)((s * fpx[v] + cs * fpy[v]) + pp[1]);
+            }
+            int q = atomicAdd(&sh.nseg, 4);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                int w = (v + 1) & 3;
+                ps.seg[q + v][0] = vx[v]; ps.seg[q + v][1] = vy[v];
+                ps.seg[q + v][2] = vx[w]; ps.seg[q + v][3] = vy[w];
+            }
+        }
+    }
+    if (tid == 0) {
+        sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];   // env.py:386
+        nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);                              // env.py:419
+        nv::sincos((double)sh.lth, sh.sT, sh.cT);
+        first_probe(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
+        sh.step_key = (unsigned long long)st.episode[e] * 0x100000000ULL +
+                      (unsigned long long)(reset_only ? 0 : st.steps[e]) * 2ULL;
+    }
+    __syncthreads();
+    if constexpr (MODE == kModePre) {                           // park the arena, the pool marches next
+        for (int i = tid; i < (int)(sizeof(StepShared) / 4); i += BLOCK) ((int*)slot)[i] = ((const int*)&sh)[i];
+        if constexpr (PEDS) {
+            int* dst = (int*)(ws_prims + (size_t)e * kPrimWords * 4);
+            for (int i = tid; i < 20 * c.max_peds; i += BLOCK) dst[i] = ((const int*)ps.seg)[i];
+        }
+        return;
+    }
+    }   // MODE fused / pre
+
+    NAVSIM_STAMP(2);
+    // ---------------------------------------------------------------- phase 3: scan A
+    int n_hist = reset_only ? 0 : st.n_hist[e];
+    if (MODE == kModeFinal && sh.respawn) n_hist = 0;
+    int crash = 0, discomfort = 0;
+    const uint64_t step_key = sh.step_key + (MODE == kModeFinal ? 1 : 0);
+    float2* dir_lds = (float2*)dyn_lds;
+    float* rng_lds = (float*)(dyn_lds + sizeof(float2) * (size_t)B);
+    if constexpr (MODE != kModeFused)
+        finish_beams<BLOCK>(c, sh, prims, st.beam_table, nullptr, ws_ranges + (size_t)e * B, nullptr, st.scan_threshold,
+                            st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
+    else if constexpr (R == 11)
+        scan_beams_pred<BLOCK, Field>(c, sh, field, st.beam_table, prims, st.scan_threshold, st.scan_discomfort,
+                                      obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
+    else if constexpr (R == 0)
+        scan_beams_dyn<BLOCK, Field>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
+                                     st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
+    else
+        scan_beams<BLOCK, R, Field, PEDS>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, tiles_lds, st.scan_threshold,
+                                          st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
+
+    NAVSIM_STAMP(3);
+    if (!reset_only && MODE != kModeFinal) {
+        crash = __syncthreads_or(crash);
+        discomfort = __syncthreads_or(discomfort);
+        double rmin = 1.0e300;
+        if (discomfort && !crash) {                             // env.py:563-569
+            for (int k = tid; k < B; k += BLOCK)
+            {
+                double ratio = nv::discomfort_ratio((double)obs_row[(size_t)(S - 1) * B + k],
+                                                    st.scan_threshold[k], st.scan_discomfort[k]);
+                rmin = ratio < rmin ? ratio : rmin;
+            }
+            rmin = wave_min_f64(rmin);
+            if ((tid & 63) == 0) sh.wave_ratio[tid >> 6] = rmin;
+            __syncthreads();
+        }
+        NAVSIM_STAMP(4);
+        // ------------------------------------------------------------ phase 4: reward / done / info
+        if (tid == 0) {
+            if (discomfort && !crash)
+                for (int w = 1; w < (BLOCK + 63) / 64; ++w) rmin = sh.wave_ratio[w] < rmin ? sh.wave_ratio[w] : rmin;
+            double prev_xy[2] = {pv_g[0], pv_g[1]};
+            double pose[2] = {sh.rp[0], sh.rp[1]};
+            double vel[2] = {pa_g[0], pa_g[1]};                 // env.py:453: the PREVIOUS action
+            double goal[2] = {goal_g[0], goal_g[1]};
+            nv::RewardOut o = nv::reward_scalar(c, prev_xy, pose, vel, goal, crash != 0, discomfort != 0, rmin);
+            io.reward[e] = o.reward;
+            io.done[e] = (uint8_t)o.done;
+            io.is_success[e] = o.success;
+            io.is_crash[e] = o.crash;
+            io.distance[e] = o.distance;
+            if (o.done && c.auto_reset && c.n_spawn > 0) {      // build-defined respawn
+                uint64_t h = nv::hash4(c.seed, genv, (uint64_t)st.episode[e], 0x5eedULL);
+                int idx = (int)(h % (uint64_t)c.n_spawn);
+                const double* sp = st.spawn_pose + ((size_t)e * c.n_spawn + idx) * 3;
+                const double* sg = st.spawn_goal + ((size_t)e * c.n_spawn + idx) * 2;
+                sh.rp[0] = sp[0]; sh.rp[1] = sp[1]; sh.rp[2] = sp[2];
+                goal_g[0] = sg[0]; goal_g[1] = sg[1];
+                st.episode[e] += 1;
+                st.steps[e] = 0;
+                sh.respawn = 1; sh.rescan = 1;
+            } else if (o.crash != 0.0f) {                       // env.py:707-717
+                sh.rp[0] = pv_g[0]; sh.rp[1] = pv_g[1]; sh.rp[2] = pv_g[2];
+                sh.rescan = 1;
+            }
+            if (sh.rescan) {
+                sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];
+                nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);
+                nv::sincos((double)sh.lth, sh.sT, sh.cT);
+                first_probe(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
+            }
+        }
+        __syncthreads();
+        if constexpr (MODE == kModePost) {
+            if (sh.rescan) {                                    // hand the arena back to the pool
+                for (int i = tid; i < (int)(sizeof(StepShared) / 4); i += BLOCK) ((int*)slot)[i] = ((const int*)&sh)[i];
+                return;
+            }
+        }
+        // ------------------------------------------------------------ phase 5: scan B (env.py:718-723)
+        if (MODE == kModeFused && sh.rescan) {
+            if (sh.respawn) n_hist = 0;
+            int c2, d2;
+            if constexpr (R == 11)
+                scan_beams_pred<BLOCK, Field>(c, sh, field, st.beam_table, prims, st.scan_threshold, st.scan_discomfort,
+                                              obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
+            else if constexpr (R == 0)
+                scan_beams_dyn<BLOCK, Field>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
+                                             st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
+            else
+                scan_beams<BLOCK, R, Field, PEDS>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, tiles_lds, st.scan_threshold,
+                                                  st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
+        }
+    }
+
+    NAVSIM_STAMP(5);
+    // ---------------------------------------------------------------- phase 6: pack the observation
+    const bool fresh = reset_only || sh.respawn;                // first obs of an episode
+    if (!fresh && obs_prev) {                                   // env.py:267-274: shift the stack
+        for (int j = 0; j < S - 1; ++j)
+            if (S - 1 - j <= n_hist)
+                for (int k = tid; k < B; k += BLOCK) obs_row[(size_t)j * B + k] = obs_prev[(size_t)(j + 1) * B + k];
+    }
+    if (tid == 0) {
+        float* tail = obs_row + (size_t)S * B;
+        double yaw = nv::wrap_pi(sh.rp[2]);                     // env.py:454
+        double pxy0 = fresh ? sh.rp[0] : pv_g[0];               // env.py:449-452
+        double pxy1 = fresh ? sh.rp[1] : pv_g[1];
+        double v0 = fresh ? 0.0 : pa_g[0], v1 = fresh ? 0.0 : pa_g[1];
+        tail[0] = (float)pxy0; tail[1] = (float)pxy1;
+        tail[2] = (float)sh.rp[0]; tail[3] = (float)sh.rp[1];
+        tail[4] = (float)v0; tail[5] = (float)v1;
+        tail[6] = (float)yaw;
+        if (io.achieved_goal) { io.achieved_goal[2 * e] = (float)sh.rp[0]; io.achieved_goal[2 * e + 1] = (float)sh.rp[1]; }
+        if (io.desired_goal) { io.desired_goal[2 * e] = (float)goal_g[0]; io.desired_goal[2 * e + 1] = (float)goal_g[1]; }
+        // state for the next step (env.py:725-727)
+        rp_g[0] = sh.rp[0]; rp_g[1] = sh.rp[1]; rp_g[2] = sh.rp[2];
+        if (fresh) { pa_g[0] = 0.0; pa_g[1] = 0.0; st.n_hist[e] = (S - 1 < 1) ? S - 1 : 1; }
+        else       { pa_g[0] = sh.act[0]; pa_g[1] = sh.act[1]; st.n_hist[e] = (n_hist + 1 < S - 1) ? n_hist + 1 : S - 1; }
+        if (reset_only) st.steps[e] = 0;
+        pv_g[0] = sh.rp[0]; pv_g[1] = sh.rp[1]; pv_g[2] = yaw;
+        if (MODE == kModeFused && st.arena_cost && !reset_only)
+            st.arena_cost[e] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_begin);
+    }
+    NAVSIM_STAMP(6);
+}
+
+// navsim_launch_order: arenas by descending cost.  One workgroup: maximum, 1024-bucket histogram on the cost
+// scaled to the maximum, exclusive scan from the expensive end, scatter.  Order inside a bucket is free.
+__global__ __launch_bounds__(1024) void launch_order_kernel(const uint32_t* __restrict__ cost, int32_t* __restrict__ order,
+                                                            int n) {
+    __shared__ unsigned hist[1024], base[1024];
+    __shared__ unsigned max_s;
+    const int tid = threadIdx.x;
+    hist[tid] = 0;
+    if (tid == 0) max_s = 1;
+    __syncthreads();
+    unsigned mx = 0;
+    for (int e = tid; e < n; e += 1024) mx = cost[e] > mx ? cost[e] : mx;
+    atomicMax(&max_s, mx);
+    __syncthreads();
+    const unsigned long long m = max_s;
+    auto bucket = [&](unsigned cst) { return 1023 - (int)(((unsigned long long)cst * 1023ull) / m); };   // 0 = costliest
+    for (int e = tid; e < n; e += 1024) atomicAdd(&hist[bucket(cost[e])], 1u);
+    __syncthreads();
+    base[tid] = hist[tid];
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                 // inclusive scan
+        unsigned v = (tid >= off) ? base[tid - off] : 0;
+        __syncthreads();
+        base[tid] += v;
+        __syncthreads();
+    }
+    base[tid] -= hist[tid];                                    // exclusive
+    __syncthreads();
+    for (int e = tid; e < n; e += 1024) order[atomicAdd(&base[bucket(cost[e])], 1u)] = e;
+}
