@@ -15,7 +15,7 @@ constexpr int kPolFeat = 4096, kPolH1 = 256, kPolH2 = 128, kPolIn2 = 260;
 
 __global__ __launch_bounds__(256) void policy_features_kernel(const float* __restrict__ scans, int p0, int n_ped,
                                                               const float* __restrict__ w1, const float* __restrict__ b1,
-                                                              const float* __restrict__ w2, const float* __restrict__ b2,
+                                                              const float* __restrict__ w2t, const float* __restrict__ b2,
                                                               float* __restrict__ feat) {
     __shared__ float x[520];                 // x[1 + i] = input i, x[0] = left padding
     __shared__ float o1[32][258];            // o1[c][1 + t], zero padding at both ends
@@ -54,12 +54,13 @@ __global__ __launch_bounds__(256) void policy_features_kernel(const float* __res
         for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
         for (int c = 0; c < 32; ++c) {
             const float i0 = o1[c][2 * t], i1 = o1[c][2 * t + 1], i2 = o1[c][2 * t + 2];   // index 2t + k - 1
+            // w2t[c][k][o]: the 16 channels of this half are contiguous -> one scalar s_load_dwordx16 per k
+            const float* ww = w2t + (c * 3) * 32 + og;                  // wave-uniform
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const float* ww = w2 + ((og + j) * 32 + c) * 3;         // wave-uniform: scalar loads
-                acc[j] = __builtin_fmaf(ww[0], i0, acc[j]);
-                acc[j] = __builtin_fmaf(ww[1], i1, acc[j]);
-                acc[j] = __builtin_fmaf(ww[2], i2, acc[j]);
+                acc[j] = __builtin_fmaf(ww[j], i0, acc[j]);
+                acc[j] = __builtin_fmaf(ww[32 + j], i1, acc[j]);
+                acc[j] = __builtin_fmaf(ww[64 + j], i2, acc[j]);
             }
         }
         float* f = feat + (size_t)p * kPolFeat;
@@ -148,12 +149,19 @@ __global__ __launch_bounds__(256) void policy_fc1_kernel(const float* __restrict
         }
 }
 
-// W2t[k][j] = W2[j][k]: coalesced rows for the head kernel
-__global__ __launch_bounds__(256) void policy_transpose_kernel(const float* __restrict__ w2, float* __restrict__ w2t) {
+// W2t[k][j] = W2[j][k]: coalesced rows for the head kernel; cv2t[c][k][o] = cv2_w[o][c][k]: the conv2 weights
+// of 16 adjacent output channels contiguous, so that the features kernel fetches them with wide scalar loads
+__global__ __launch_bounds__(256) void policy_transpose_kernel(const float* __restrict__ w2, float* __restrict__ w2t,
+                                                               const float* __restrict__ cv2, float* __restrict__ cv2t) {
     int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= kPolH2 * kPolIn2) return;
-    int j = idx / kPolIn2, k = idx - j * kPolIn2;
-    w2t[k * kPolH2 + j] = w2[idx];
+    if (idx < kPolH2 * kPolIn2) {
+        int j = idx / kPolIn2, k = idx - j * kPolIn2;
+        w2t[k * kPolH2 + j] = w2[idx];
+    }
+    if (idx < 32 * 32 * 3) {
+        int o = idx / 96, c = (idx - o * 96) / 3, k = idx % 3;
+        cv2t[(c * 3 + k) * 32 + o] = cv2[idx];
+    }
 }
 
 __global__ __launch_bounds__(128) void policy_head_kernel(navsim_config c, navsim_state st, int p0, int n_ped,

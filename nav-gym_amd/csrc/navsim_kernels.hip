@@ -654,7 +654,7 @@ size_t navsim_ped_policy_workspace_bytes(const navsim_config* c) {
     if (!c) return 0;
     size_t P = (size_t)c->n_envs * (size_t)c->max_peds;
     size_t chunk = P < (size_t)kPolicyChunk ? P : (size_t)kPolicyChunk;
-    return 1024 + (size_t)kPolH2 * kPolIn2 * sizeof(float) + chunk * (size_t)(kPolFeat + kPolH1) * sizeof(float);
+    return 2048 + (size_t)(kPolH2 * kPolIn2 + 32 * 32 * 3) * sizeof(float) + chunk * (size_t)(kPolFeat + kPolH1) * sizeof(float);
 }
 
 int navsim_ped_policy(const navsim_config* c, const navsim_state* st, const navsim_policy_weights* w,
@@ -673,15 +673,16 @@ int navsim_ped_policy(const navsim_config* c, const navsim_state* st, const navs
     if (P == 0) return NAVSIM_OK;
     hipStream_t s = (hipStream_t)stream;
     float* w2t = (float*)workspace;
-    float* feat = (float*)((char*)workspace + ((kPolH2 * kPolIn2 * sizeof(float) + 1023) & ~(size_t)1023));
+    float* cv2t = (float*)((char*)workspace + ((kPolH2 * kPolIn2 * sizeof(float) + 255) & ~(size_t)255));
+    float* feat = (float*)((char*)cv2t + ((32 * 32 * 3 * sizeof(float) + 1023) & ~(size_t)1023));
     const size_t chunk = P < (size_t)kPolicyChunk ? P : (size_t)kPolicyChunk;
     float* h1 = feat + chunk * kPolFeat;
     constexpr size_t fc1_lds = (size_t)2 * (128 + 128) * 33 * sizeof(float);       // 67,584 B
     if (allow_lds((const void*)policy_fc1_kernel, fc1_lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
-    policy_transpose_kernel<<<(kPolH2 * kPolIn2 + 255) / 256, 256, 0, s>>>(w->fc2_w, w2t);
+    policy_transpose_kernel<<<(kPolH2 * kPolIn2 + 255) / 256, 256, 0, s>>>(w->fc2_w, w2t, w->cv2_w, cv2t);
     for (size_t p0 = 0; p0 < P; p0 += chunk) {
         const int n = (int)(P - p0 < chunk ? P - p0 : chunk);
-        policy_features_kernel<<<n, 256, 0, s>>>(ped_scans, (int)p0, n, w->cv1_w, w->cv1_b, w->cv2_w, w->cv2_b, feat);
+        policy_features_kernel<<<n, 256, 0, s>>>(ped_scans, (int)p0, n, w->cv1_w, w->cv1_b, cv2t, w->cv2_b, feat);
         policy_fc1_kernel<<<dim3((n + 127) / 128, 2), 256, fc1_lds, s>>>(feat, n, w->fc1_w, w->fc1_b, h1);
         policy_head_kernel<<<n, 128, 0, s>>>(*c, *st, (int)p0, n, h1, w2t, *w, prev_actions, ped_cmd);
     }

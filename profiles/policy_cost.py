@@ -39,7 +39,6 @@ def full():
 rows["full_step_ms"] = timed(full)
 P = E * cfg.max_peds
 rows["pedestrians"] = P
-rows["fc1_tflops"] = None
 rows["env_steps_per_s"] = E / (rows["full_step_ms"] * 1e-3)
 print(json.dumps(rows, indent=1))
 os.makedirs("gpurun_out", exist_ok=True)
