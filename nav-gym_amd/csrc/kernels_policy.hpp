@@ -164,69 +164,90 @@ __global__ __launch_bounds__(256) void policy_transpose_kernel(const float* __re
     }
 }
 
+// Eight pedestrians per workgroup: the 133 KB second layer is streamed once per eight of them (one pedestrian
+// per workgroup made this kernel L2-bandwidth bound at 22 TB/s), thread j owns hidden unit j of all eight.
+constexpr int kHeadPeds = 8;
 __global__ __launch_bounds__(128) void policy_head_kernel(navsim_config c, navsim_state st, int p0, int n_ped,
                                                           const float* __restrict__ h1, const float* __restrict__ w2t,
                                                           navsim_policy_weights w, float* __restrict__ prev_actions,
                                                           double* __restrict__ ped_cmd) {
-    __shared__ float z[kPolIn2];
-    __shared__ float h2[kPolH2];
-    __shared__ float head[2];
+    __shared__ float z[kHeadPeds][kPolIn2];
+    __shared__ float h2[kHeadPeds][kPolH2];
+    __shared__ float head[kHeadPeds][2];
+    __shared__ int live_s[kHeadPeds];
     const int tid = threadIdx.x, N = c.max_peds, P = NAVSIM_MAX_WAYPOINTS;
-    const int p = blockIdx.x;
-    if (p >= n_ped) return;
-    const size_t q = (size_t)(p0 + p);
-    const int e = (int)(q / N), i = (int)(q - (size_t)e * N);
-    int n = st.n_peds[e];
-    n = n > N ? N : n;
-    if (i >= n) {                                              // block-uniform
-        if (tid == 0) { ped_cmd[2 * q] = 0.0; ped_cmd[2 * q + 1] = 0.0; }
-        return;
+    const int pb = blockIdx.x * kHeadPeds;
+    for (int idx = tid; idx < kHeadPeds * kPolH1; idx += 128) {
+        const int s = idx / kPolH1, k = idx - s * kPolH1;
+        z[s][k] = (pb + s < n_ped) ? h1[(size_t)(pb + s) * kPolH1 + k] : 0.0f;
     }
-    z[tid] = h1[(size_t)p * kPolH1 + tid];
-    z[tid + 128] = h1[(size_t)p * kPolH1 + tid + 128];
-    if (tid == 0) {
-        const double* pp = st.ped_pose + q * 3;
-        double* wp = st.ped_waypoints + (q * P) * 2;
-        int nw = st.ped_n_waypoints[q];
-        while (nw > 1) {                                       // env.py:633-640
-            double ddx = pp[0] - wp[0], ddy = pp[1] - wp[1];
-            if (sqrt(ddx * ddx + ddy * ddy) < 1.0) {
-                for (int k = 0; k + 1 < nw; ++k) { wp[2 * k] = wp[2 * k + 2]; wp[2 * k + 1] = wp[2 * k + 3]; }
-                nw -= 1;
-            } else break;
+    if (tid < kHeadPeds) {                                     // one lane per pedestrian: the glue of env.py:633-645
+        const int s = tid;
+        int live = 0;
+        z[s][256] = 0.0f; z[s][257] = 0.0f; z[s][258] = 0.0f; z[s][259] = 0.0f;
+        if (pb + s < n_ped) {
+            const size_t q = (size_t)(p0 + pb + s);
+            const int e = (int)(q / N), i = (int)(q - (size_t)e * N);
+            int n = st.n_peds[e];
+            n = n > N ? N : n;
+            if (i >= n) { ped_cmd[2 * q] = 0.0; ped_cmd[2 * q + 1] = 0.0; }
+            else {
+                live = 1;
+                const double* pp = st.ped_pose + q * 3;
+                double* wp = st.ped_waypoints + (q * P) * 2;
+                int nw = st.ped_n_waypoints[q];
+                while (nw > 1) {                               // env.py:633-640
+                    double ddx = pp[0] - wp[0], ddy = pp[1] - wp[1];
+                    if (sqrt(ddx * ddx + ddy * ddy) < 1.0) {
+                        for (int k = 0; k + 1 < nw; ++k) { wp[2 * k] = wp[2 * k + 2]; wp[2 * k + 1] = wp[2 * k + 3]; }
+                        nw -= 1;
+                    } else break;
+                }
+                st.ped_n_waypoints[q] = nw;
+                double sn, cs;
+                nv::sincos(pp[2], sn, cs);                     // env.py:644-645
+                double gx = wp[0] - pp[0], gy = wp[1] - pp[1];
+                z[s][256] = (float)(gx * cs + gy * sn);
+                z[s][257] = (float)(-gx * sn + gy * cs);
+                z[s][258] = prev_actions[2 * q];
+                z[s][259] = prev_actions[2 * q + 1];
+            }
         }
-        st.ped_n_waypoints[q] = nw;
-        double s, cs;
-        nv::sincos(pp[2], s, cs);                              // env.py:644-645
-        double gx = wp[0] - pp[0], gy = wp[1] - pp[1];
-        z[256] = (float)(gx * cs + gy * s);
-        z[257] = (float)(-gx * s + gy * cs);
-        z[258] = prev_actions[2 * q];
-        z[259] = prev_actions[2 * q + 1];
+        live_s[s] = live;
     }
     __syncthreads();
     {
-        float acc = 0.0f;
-        for (int k = 0; k < kPolIn2; ++k) acc = __builtin_fmaf(w2t[k * kPolH2 + tid], z[k], acc);
-        acc = acc + w.fc2_b[tid];
-        h2[tid] = acc > 0.0f ? acc : 0.0f;
+        float acc[kHeadPeds];
+#pragma unroll
+        for (int s = 0; s < kHeadPeds; ++s) acc[s] = 0.0f;
+        for (int k = 0; k < kPolIn2; ++k) {
+            const float wv = w2t[k * kPolH2 + tid];
+#pragma unroll
+            for (int s = 0; s < kHeadPeds; ++s) acc[s] = __builtin_fmaf(wv, z[s][k], acc[s]);
+        }
+        const float bj = w.fc2_b[tid];
+#pragma unroll
+        for (int s = 0; s < kHeadPeds; ++s) { float v = acc[s] + bj; h2[s][tid] = v > 0.0f ? v : 0.0f; }
     }
     __syncthreads();
-    if (tid == 0 || tid == 64) {                               // one head per wavefront
-        const float* aw = tid == 0 ? w.a1_w : w.a2_w;
+    if (tid < 2 * kHeadPeds) {                                 // lane = (pedestrian, head)
+        const int s = tid >> 1, hd = tid & 1;
+        const float* aw = hd ? w.a2_w : w.a1_w;
         float acc = 0.0f;
-        for (int k = 0; k < kPolH2; ++k) acc = __builtin_fmaf(aw[k], h2[k], acc);
-        head[tid >> 6] = acc + (tid == 0 ? w.a1_b[0] : w.a2_b[0]);
+        for (int k = 0; k < kPolH2; ++k) acc = __builtin_fmaf(aw[k], h2[s][k], acc);
+        head[s][hd] = acc + (hd ? w.a2_b[0] : w.a1_b[0]);
     }
     __syncthreads();
-    if (tid == 0) {
-        double x1 = (double)head[0], m1;                       // sigmoid, tanh in float64 on the shared exp
+    if (tid < kHeadPeds && live_s[tid]) {
+        const int s = tid;
+        const size_t q = (size_t)(p0 + pb + s);
+        double x1 = (double)head[s][0], m1;                    // sigmoid, tanh in float64 on the shared exp
         if (x1 >= 0.0) m1 = 1.0 / (1.0 + nv::exp_neg(-x1));
         else { double ex = nv::exp_neg(x1); m1 = ex / (1.0 + ex); }
-        double a2 = fabs((double)head[1]);
+        double a2 = fabs((double)head[s][1]);
         double ex2 = nv::exp_neg(-2.0 * a2);
         double t2 = (1.0 - ex2) / (1.0 + ex2);
-        float mean0 = (float)m1, mean1 = (float)(head[1] < 0.0f ? -t2 : t2);
+        float mean0 = (float)m1, mean1 = (float)(head[s][1] < 0.0f ? -t2 : t2);
         mean0 = mean0 < 0.0f ? 0.0f : (mean0 > 1.0f ? 1.0f : mean0);          // env.py:656-657
         mean1 = mean1 < -1.0f ? -1.0f : (mean1 > 1.0f ? 1.0f : mean1);
         prev_actions[2 * q] = mean0; prev_actions[2 * q + 1] = mean1;

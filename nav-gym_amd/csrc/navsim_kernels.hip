@@ -684,7 +684,7 @@ int navsim_ped_policy(const navsim_config* c, const navsim_state* st, const navs
         const int n = (int)(P - p0 < chunk ? P - p0 : chunk);
         policy_features_kernel<<<n, 256, 0, s>>>(ped_scans, (int)p0, n, w->cv1_w, w->cv1_b, cv2t, w->cv2_b, feat);
         policy_fc1_kernel<<<dim3((n + 127) / 128, 2), 256, fc1_lds, s>>>(feat, n, w->fc1_w, w->fc1_b, h1);
-        policy_head_kernel<<<n, 128, 0, s>>>(*c, *st, (int)p0, n, h1, w2t, *w, prev_actions, ped_cmd);
+        policy_head_kernel<<<(n + kHeadPeds - 1) / kHeadPeds, 128, 0, s>>>(*c, *st, (int)p0, n, h1, w2t, *w, prev_actions, ped_cmd);
     }
     return launch_status();
 }
