@@ -7,9 +7,8 @@
 // HumanPolicy).  One workgroup per (pedestrian, arena): rectangles of the other agents in LDS,
 // march from the pedestrian's integer cell, bearing-culled polygon merge, clip to 6 m.
 // ============================================================================================
-template <typename Field>
-__global__ __launch_bounds__(256) void ped_scan_kernel(navsim_config c, navsim_state st, float* __restrict__ out) {
-    constexpr int BLOCK = 256;
+template <typename Field, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim_state st, float* __restrict__ out) {
     __shared__ float seg[4 * (NAVSIM_MAX_PEDS + 1)][4];
     __shared__ float info_s[4 * (NAVSIM_MAX_PEDS + 1)];
     __shared__ int nseg_s, i0_s, j0_s;
