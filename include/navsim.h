@@ -385,6 +385,32 @@ int    navsim_ped_policy(const navsim_config* cfg, const navsim_state* st, const
  * for navsim_step (navsim_state.launch_order).  cost is what the step wrote to navsim_state.arena_cost. */
 int navsim_launch_order(const uint32_t* cost, int32_t* order, int32_t n, void* stream);
 
+/* ---- CrowdSim-v0: collision tests, goal test and reward / info selection of CrowdSim.step
+ *      (nav_gym/src/crowd_sim/envs/crowd_sim.py:808-945, phase != 'test', border = None) -------------- */
+typedef struct navsim_crowd_params {
+    double time_step, discomfort_dist, map_size_m, map_resolution;
+    double success_reward, collision_penalty, discomfort_penalty_factor, rotation_penalty_factor, timeout_penalty;
+    double time_limit;
+} navsim_crowd_params;
+#define NAVSIM_CROWD_NOTHING 0
+#define NAVSIM_CROWD_TIMEOUT 1
+#define NAVSIM_CROWD_REACH_GOAL 2
+#define NAVSIM_CROWD_COLLISION 3
+#define NAVSIM_CROWD_COLLISION_OTHER 4
+#define NAVSIM_CROWD_DANGER 5
+/* Per env: closest approach of every agent to the robot over the step (point_to_segment_dist,
+ * crowd_sim/envs/utils/utils.py:4-26, minus both radii: crowd_sim.py:808-826), the occupancy-grid windows
+ * around the robot's next position (collision: half-width ceil(r / sqrt 2 / res) cells, crowd_sim.py:831-861;
+ * discomfort: ceil((r + discomfort_dist) / res), crowd_sim.py:872-896), the goal test (crowd_sim.py:909-915)
+ * and the reward / done / info cascade (crowd_sim.py:917-949).
+ * free_map [E,G,G] uint8, 1 = free, indexed [x][y] like CrowdSim.map; robot [E,10] = px, py, next_px, next_py,
+ * next_vx, next_vy, gx, gy, radius, action.r; agents [E,A,5] = px, py, vx, vy, radius; n_agents [E] or NULL
+ * (= A); global_time [E].  Outputs reward [E], done [E], info [E] (NAVSIM_CROWD_*), min_dist [E] (Danger). */
+int navsim_crowd_check(const navsim_crowd_params* p, int32_t n_envs, int32_t max_agents, int32_t grid,
+                       const uint8_t* free_map, const double* robot, const double* agents, const int32_t* n_agents,
+                       const double* global_time, double* reward, uint8_t* done, int32_t* info, double* min_dist,
+                       void* stream);
+
 /* First observation after reset() (env.py:822-831): scan at the current robot pose, stack filled
  * with copies, prev_pose = pose, vel = 0; sets prev_pose/prev_action/n_hist.  `mask` [E] uint8 or
  * NULL selects which envs are (re)initialised; others keep obs_prev -> obs copied through. */

@@ -76,6 +76,90 @@ __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim
     }
 }
 
+// ============================================================================================
+// CrowdSim-v0 (crowd_sim.py:808-949; oracle navsim_crowd_check_cpu): one wavefront per env.  Lanes take the
+// agents (closest approach over the step, wave min / any) and then the cells of the two occupancy-grid
+// windows around the robot's next position; lane 0 runs the reward / info cascade.  float64, Python order.
+// ============================================================================================
+__device__ __forceinline__ double crowd_p2s(double x1, double y1, double x2, double y2, double x3, double y3) {
+    double px = x2 - x1, py = y2 - y1;                          // crowd_sim/envs/utils/utils.py:4-26
+    if (px == 0.0 && py == 0.0) { double a = x3 - x1, b = y3 - y1; return sqrt(a * a + b * b); }
+    double u = ((x3 - x1) * px + (y3 - y1) * py) / (px * px + py * py);
+    if (u > 1.0) u = 1.0; else if (u < 0.0) u = 0.0;
+    double x = x1 + u * px, y = y1 + u * py;
+    double a = x - x3, b = y - y3;
+    return sqrt(a * a + b * b);
+}
+
+__device__ __forceinline__ bool crowd_window_hits(const uint8_t* __restrict__ m, int G, int n_cells, int ix, int iy,
+                                                  int half, int lane) {
+    int sx = ix - half, ex = sx + half * 2, sy = iy - half, ey = sy + half * 2;   // crowd_sim.py:843-861
+    sx = sx < 0 ? 0 : sx; ex = ex > n_cells ? n_cells : ex;
+    sy = sy < 0 ? 0 : sy; ey = ey > n_cells ? n_cells : ey;
+    bool hit = false;
+    if (ex > sx && ey > sy) {
+        const int w = ey - sy, cells = (ex - sx) * w;
+        for (int k = lane; k < cells; k += 64) {
+            int x = sx + k / w, y = sy + k % w;
+            if (x < G && y < G && !m[(size_t)x * G + y]) hit = true;
+        }
+    }
+    return __ballot(hit) != 0;
+}
+
+__global__ __launch_bounds__(64) void crowd_check_kernel(navsim_crowd_params p, int max_agents, int grid,
+                                                         const uint8_t* __restrict__ free_map,
+                                                         const double* __restrict__ robot,
+                                                         const double* __restrict__ agents,
+                                                         const int32_t* __restrict__ n_agents,
+                                                         const double* __restrict__ global_time,
+                                                         double* __restrict__ reward, uint8_t* __restrict__ done,
+                                                         int32_t* __restrict__ info, double* __restrict__ min_dist) {
+    const int e = blockIdx.x, lane = threadIdx.x;
+    const double* r = robot + (size_t)e * 10;
+    const double radius = r[8];
+    int na = n_agents ? n_agents[e] : max_agents;
+    na = na > max_agents ? max_agents : na;
+    double dmin = INFINITY;
+    bool coll = false;
+    for (int a = lane; a < na; a += 64) {                           // crowd_sim.py:808-826
+        const double* g = agents + ((size_t)e * max_agents + a) * 5;
+        double px = g[0] - r[0], py = g[1] - r[1];
+        double vx = g[2] - r[4], vy = g[3] - r[5];
+        double ex = px + vx * p.time_step, ey = py + vy * p.time_step;
+        double closest = crowd_p2s(px, py, ex, ey, 0.0, 0.0) - g[4] - radius;
+        if (closest < 0.0) coll = true;
+        else if (closest < dmin) dmin = closest;
+    }
+    for (int off = 32; off > 0; off >>= 1) {                        // exact: min of float64 values
+        double o = __shfl_xor(dmin, off);
+        dmin = o < dmin ? o : dmin;
+    }
+    bool collision = __ballot(coll) != 0;
+    const int n_cells = (int)__builtin_rint(p.map_size_m / p.map_resolution);
+    const uint8_t* m = free_map + (size_t)e * grid * grid;
+    const int ix = (int)__builtin_rint((r[2] + p.map_size_m / 2.0) / p.map_resolution);   // int(round(.)): half to even
+    const int iy = (int)__builtin_rint((r[3] + p.map_size_m / 2.0) / p.map_resolution);
+    const int half = (int)ceil(radius / sqrt(2.0) / p.map_resolution);
+    if (crowd_window_hits(m, grid, n_cells, ix, iy, half, lane)) collision = true;
+    const int half2 = (int)ceil((radius + p.discomfort_dist) / p.map_resolution);
+    const bool close_to_obstacle = crowd_window_hits(m, grid, n_cells, ix, iy, half2, lane);
+    if (lane != 0) return;
+    double gx = r[2] - r[6], gy = r[3] - r[7];
+    const bool reaching_goal = sqrt(gx * gx + gy * gy) < radius;
+    double rew, md = INFINITY;
+    int dn, code;
+    if (global_time[e] >= p.time_limit) { rew = p.timeout_penalty; dn = 1; code = NAVSIM_CROWD_TIMEOUT; }
+    else if (reaching_goal) { rew = p.success_reward; dn = 1; code = NAVSIM_CROWD_REACH_GOAL; }
+    else if (collision) { rew = p.collision_penalty; dn = 1; code = NAVSIM_CROWD_COLLISION; }
+    else if (close_to_obstacle) { rew = -p.discomfort_penalty_factor * p.time_step * 0.1; dn = 0; code = NAVSIM_CROWD_DANGER; md = 0.1; }
+    else if (dmin < p.discomfort_dist) { rew = (dmin - p.discomfort_dist) * p.discomfort_penalty_factor * p.time_step; dn = 0; code = NAVSIM_CROWD_DANGER; md = dmin; }
+    else if (fabs(r[9]) > 0.0) { rew = fabs(r[9]) * p.rotation_penalty_factor; dn = 0; code = NAVSIM_CROWD_NOTHING; }
+    else { rew = 0.0; dn = 0; code = NAVSIM_CROWD_NOTHING; }
+    reward[e] = rew; done[e] = (uint8_t)dn; info[e] = code;
+    if (min_dist) min_dist[e] = md;
+}
+
 __global__ __launch_bounds__(256) void beam_table_kernel(navsim_config c, double* __restrict__ tab) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= c.n_beams) return;

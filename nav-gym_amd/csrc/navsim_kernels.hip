@@ -697,6 +697,20 @@ int navsim_ped_policy(const navsim_config* c, const navsim_state* st, const navs
     return launch_status();
 }
 
+int navsim_crowd_check(const navsim_crowd_params* p, int32_t n_envs, int32_t max_agents, int32_t grid,
+                       const uint8_t* free_map, const double* robot, const double* agents, const int32_t* n_agents,
+                       const double* global_time, double* reward, uint8_t* done, int32_t* info, double* min_dist,
+                       void* stream) {
+    (void)hipGetLastError();
+    if (!p || !free_map || !robot || !global_time || !reward || !done || !info || n_envs < 0 || max_agents < 0 ||
+        grid < 1 || (max_agents > 0 && !agents))
+        return NAVSIM_E_ARG;
+    if (n_envs == 0) return NAVSIM_OK;
+    crowd_check_kernel<<<n_envs, 64, 0, (hipStream_t)stream>>>(*p, max_agents, grid, free_map, robot, agents, n_agents,
+                                                               global_time, reward, done, info, min_dist);
+    return launch_status();
+}
+
 int navsim_launch_order(const uint32_t* cost, int32_t* order, int32_t n, void* stream) {
     (void)hipGetLastError();
     if (!cost || !order || n < 0) return NAVSIM_E_ARG;

@@ -128,6 +128,15 @@ class NavsimPolicyWeights(C.Structure):
     _fields_ = [(name, _P) for name in POLICY_FIELDS]
 
 
+class NavsimCrowdParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in (
+        "time_step", "discomfort_dist", "map_size_m", "map_resolution", "success_reward", "collision_penalty",
+        "discomfort_penalty_factor", "rotation_penalty_factor", "timeout_penalty", "time_limit")]
+
+
+CROWD_INFO = ("Nothing", "Timeout", "ReachGoal", "Collision", "CollisionOtherAgent", "Danger")
+
+
 class NavsimStepIO(C.Structure):
     _fields_ = [(name, _P) for name in (
         "action", "obs_prev", "obs", "achieved_goal", "desired_goal",
@@ -244,6 +253,7 @@ def declare(lib, suffix=""):
         sig("navsim_plan", [_P, _P, i32, i32, i32, f64, f64, f64, _P, _P, f64, i32, _P, _P, _P, _P, _P, C.c_size_t, _P])
         sig("navsim_regen_workspace_bytes", [cfgp], C.c_size_t)
         sig("navsim_regen", [cfgp, stp, iop, _P, C.c_size_t, _P])
+    sig("navsim_crowd_check", [C.POINTER(NavsimCrowdParams), i32, i32, i32, _P, _P, _P, _P, _P, _P, _P, _P, _P] + stream)
     sig("navsim_step", [cfgp, stp, iop] + stream)
     sig("navsim_reset_obs", [cfgp, stp, iop, _P] + stream)
     return lib
@@ -258,6 +268,6 @@ EXPORTS = (
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
     "navsim_scan_threshold", "navsim_beam_table", "navsim_step_workspace_bytes", "navsim_ped_scans", "navsim_regen_workspace_bytes", "navsim_regen",
     "navsim_costmap", "navsim_plan_workspace_bytes", "navsim_plan", "navsim_launch_order", "navsim_replan_workspace_bytes", "navsim_replan", "navsim_ped_policy_workspace_bytes", "navsim_ped_policy",
-    "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
+    "navsim_crowd_check", "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math",
 )

@@ -178,6 +178,27 @@ def plan(cost, start, goal, interval, max_wp=8, res_c=0.25, origin=(0.0, 0.0), m
     return wp, n_wp, cells, plen
 
 
+def crowd_check(params, free_map, robot, agents, global_time, n_agents=None):
+    """navsim_crowd_check: CrowdSim.step's collision / goal / reward block (crowd_sim.py:808-949) for E envs.
+    params: dict with the fields of navsim_crowd_params; tensors on the GPU.  -> reward, done, info, min_dist."""
+    torch = require_gpu()
+    L = load()
+    p = abi.NavsimCrowdParams(**{k: float(v) for k, v in params.items()})
+    free_map = free_map.to(torch.uint8).contiguous()
+    E, G = free_map.shape[0], free_map.shape[1]
+    dev = free_map.device
+    robot = robot.to(torch.float64).contiguous().reshape(E, 10)
+    agents = agents.to(torch.float64).contiguous().reshape(E, -1, 5)
+    A = agents.shape[1]
+    gt = global_time.to(torch.float64).contiguous().reshape(E)
+    na = None if n_agents is None else n_agents.to(device=dev, dtype=torch.int32).contiguous()
+    reward = torch.zeros(E, dtype=torch.float64, device=dev); done = torch.zeros(E, dtype=torch.uint8, device=dev)
+    info = torch.zeros(E, dtype=torch.int32, device=dev); md = torch.zeros(E, dtype=torch.float64, device=dev)
+    check(L.navsim_crowd_check(C.byref(p), E, A, G, _ptr(free_map), _ptr(robot), _ptr(agents), _ptr(na), _ptr(gt),
+                               _ptr(reward), _ptr(done), _ptr(info), _ptr(md), _stream()), "navsim_crowd_check")
+    return reward, done, info, md
+
+
 def debug_math(fn, x, x2=None):
     torch = require_gpu()
     out = torch.empty_like(x)

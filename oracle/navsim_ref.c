@@ -1564,3 +1564,77 @@ int navsim_math_cpu(int32_t fn, const double* x, const double* x2, double* out, 
     }
     return NAVSIM_OK;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * CrowdSim-v0 termination block (crowd_sim.py:808-949), float64 in Python operator order.
+ * ------------------------------------------------------------------------------------------- */
+/* crowd_sim/envs/utils/utils.py:4-26 */
+static double point_to_segment_dist(double x1, double y1, double x2, double y2, double x3, double y3) {
+    double px = x2 - x1, py = y2 - y1;
+    if (px == 0.0 && py == 0.0) { double a = x3 - x1, b = y3 - y1; return sqrt(a * a + b * b); }
+    double u = ((x3 - x1) * px + (y3 - y1) * py) / (px * px + py * py);
+    if (u > 1.0) u = 1.0; else if (u < 0.0) u = 0.0;
+    double x = x1 + u * px, y = y1 + u * py;
+    double a = x - x3, b = y - y3;
+    return sqrt(a * a + b * b);
+}
+
+/* does the window of half-width `half` cells around (ix, iy) contain an occupied cell?  crowd_sim.py:843-861 */
+static int crowd_window_hits(const uint8_t* m, int G, int n_cells, int ix, int iy, int half) {
+    int sx = ix - half, ex = sx + half * 2, sy = iy - half, ey = sy + half * 2;
+    if (sx < 0) sx = 0;
+    if (ex > n_cells) ex = n_cells;
+    if (sy < 0) sy = 0;
+    if (ey > n_cells) ey = n_cells;
+    if (!(ex > sx && ey > sy)) return 0;
+    for (int x = sx; x < ex; ++x)
+        for (int y = sy; y < ey; ++y)
+            if (x < G && y < G && !m[(size_t)x * G + y]) return 1;
+    return 0;
+}
+
+int navsim_crowd_check_cpu(const navsim_crowd_params* p, int32_t n_envs, int32_t max_agents, int32_t grid,
+                           const uint8_t* free_map, const double* robot, const double* agents, const int32_t* n_agents,
+                           const double* global_time, double* reward, uint8_t* done, int32_t* info, double* min_dist) {
+    if (!p || !free_map || !robot || !global_time || !reward || !done || !info || n_envs < 0 || max_agents < 0 ||
+        grid < 1 || (max_agents > 0 && !agents))
+        return NAVSIM_E_ARG;
+    const int n_cells = (int)nearbyint(p->map_size_m / p->map_resolution);
+    for (int e = 0; e < n_envs; ++e) {
+        const double* r = robot + (size_t)e * 10;
+        const double radius = r[8];
+        int na = n_agents ? n_agents[e] : max_agents;
+        if (na > max_agents) na = max_agents;
+        double dmin = INFINITY;
+        int collision = 0;
+        for (int a = 0; a < na; ++a) {                                   /* crowd_sim.py:808-826 */
+            const double* g = agents + ((size_t)e * max_agents + a) * 5;
+            double px = g[0] - r[0], py = g[1] - r[1];
+            double vx = g[2] - r[4], vy = g[3] - r[5];
+            double ex = px + vx * p->time_step, ey = py + vy * p->time_step;
+            double closest = point_to_segment_dist(px, py, ex, ey, 0.0, 0.0) - g[4] - radius;
+            if (closest < 0.0) { collision = 1; break; }
+            else if (closest < dmin) dmin = closest;
+        }
+        const uint8_t* m = free_map + (size_t)e * grid * grid;
+        const int ix = (int)nearbyint((r[2] + p->map_size_m / 2.0) / p->map_resolution);   /* int(round(.)) */
+        const int iy = (int)nearbyint((r[3] + p->map_size_m / 2.0) / p->map_resolution);
+        const int half = (int)ceil(radius / sqrt(2.0) / p->map_resolution);
+        if (crowd_window_hits(m, grid, n_cells, ix, iy, half)) collision = 1;
+        const int half2 = (int)ceil((radius + p->discomfort_dist) / p->map_resolution);
+        const int close_to_obstacle = crowd_window_hits(m, grid, n_cells, ix, iy, half2);
+        double gx = r[2] - r[6], gy = r[3] - r[7];
+        const int reaching_goal = sqrt(gx * gx + gy * gy) < radius;
+        double rew; int dn, code; double md = INFINITY;
+        if (global_time[e] >= p->time_limit) { rew = p->timeout_penalty; dn = 1; code = NAVSIM_CROWD_TIMEOUT; }
+        else if (reaching_goal) { rew = p->success_reward; dn = 1; code = NAVSIM_CROWD_REACH_GOAL; }
+        else if (collision) { rew = p->collision_penalty; dn = 1; code = NAVSIM_CROWD_COLLISION; }
+        else if (close_to_obstacle) { rew = -p->discomfort_penalty_factor * p->time_step * 0.1; dn = 0; code = NAVSIM_CROWD_DANGER; md = 0.1; }
+        else if (dmin < p->discomfort_dist) { rew = (dmin - p->discomfort_dist) * p->discomfort_penalty_factor * p->time_step; dn = 0; code = NAVSIM_CROWD_DANGER; md = dmin; }
+        else if (fabs(r[9]) > 0.0) { rew = fabs(r[9]) * p->rotation_penalty_factor; dn = 0; code = NAVSIM_CROWD_NOTHING; }
+        else { rew = 0.0; dn = 0; code = NAVSIM_CROWD_NOTHING; }
+        reward[e] = rew; done[e] = (uint8_t)dn; info[e] = code;
+        if (min_dist) min_dist[e] = md;
+    }
+    return NAVSIM_OK;
+}

@@ -69,6 +69,9 @@ int navsim_ped_scans_cpu(const navsim_config* cfg, const navsim_state* st, float
 int navsim_regen_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io);
 int navsim_ped_policy_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_policy_weights* w,
                           const float* ped_scans, float* prev_actions, double* ped_cmd);
+int navsim_crowd_check_cpu(const navsim_crowd_params* p, int32_t n_envs, int32_t max_agents, int32_t grid,
+                           const uint8_t* free_map, const double* robot, const double* agents, const int32_t* n_agents,
+                           const double* global_time, double* reward, uint8_t* done, int32_t* info, double* min_dist);
 int navsim_replan_cpu(const navsim_config* cfg, const navsim_state* st, int32_t max_queries);
 
 /* costmap (env.py:312-332), shortest 4-connected path (env.py:343-354) and path_to_waypoints

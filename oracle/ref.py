@@ -226,6 +226,22 @@ def plan(cost, start, goal, interval, max_wp=8, res_c=0.25, origin=(0.0, 0.0), m
     return wp, n_wp, cells, plen
 
 
+def crowd_check(params, free_map, robot, agents, global_time, n_agents=None):
+    """navsim_crowd_check_cpu: CrowdSim.step's collision / goal / reward block (crowd_sim.py:808-949)."""
+    p = abi.NavsimCrowdParams(**{k: float(v) for k, v in params.items()})
+    free_map = np.ascontiguousarray(free_map, dtype=np.uint8)
+    E, G = free_map.shape[0], free_map.shape[1]
+    robot = np.ascontiguousarray(robot, dtype=np.float64).reshape(E, 10)
+    agents = np.ascontiguousarray(agents, dtype=np.float64).reshape(E, -1, 5)
+    A = agents.shape[1]
+    gt = np.ascontiguousarray(global_time, dtype=np.float64).reshape(E)
+    na = None if n_agents is None else np.ascontiguousarray(n_agents, dtype=np.int32)
+    reward = np.zeros(E); done = np.zeros(E, np.uint8); info = np.zeros(E, np.int32); md = np.zeros(E)
+    _chk(lib().navsim_crowd_check_cpu(C.byref(p), E, A, G, _p(free_map), _p(robot), _p(agents), _p(na), _p(gt),
+                                      _p(reward), _p(done), _p(info), _p(md)), "crowd_check")
+    return reward, done, info, md
+
+
 def math_fn(fn, x, x2=None):
     x = np.ascontiguousarray(x, dtype=np.float64)
     x2a = None if x2 is None else np.ascontiguousarray(x2, dtype=np.float64)

@@ -496,6 +496,113 @@ def run_trace(name, ref_env, human, human_policy, S, seed, scenario, n_steps, pe
     print("golden_trace_%s.npz: T=%d N=%d crashes=%d successes=%d" % (name, T, N, int(crash.sum()), int(succ.sum())))
 
 
+
+# --------------------------------------------------------------------------------------------
+# CrowdSim-v0 termination / reward block (crowd_sim.py:808-945): SURVEY.md 8f #4
+# --------------------------------------------------------------------------------------------
+def make_crowd():
+    """Runs the reference's own CrowdSim.step(update=False) on stub agents: the collision tests
+    (point_to_segment_dist against every agent, occupancy-grid windows around the robot), goal test and
+    reward / info selection for 600 random situations.  gym, rvo2, tensorflow and the policy factory are
+    import-only stand-ins; nothing of them executes in that block."""
+    import importlib
+    from collections import namedtuple
+    for name in ("gym", "gym.envs", "gym.envs.registration", "rvo2", "cv2", "tensorflow", "PIL", "matplotlib",
+                 "crowd_nav", "crowd_nav.policy", "crowd_nav.policy.policy_factory"):
+        try:
+            importlib.import_module(name)
+        except Exception:
+            sys.modules[name] = types.ModuleType(name)
+    if not hasattr(sys.modules["gym"], "Env"):
+        sys.modules["gym"].Env = object
+    if not hasattr(sys.modules["gym.envs.registration"], "register"):
+        sys.modules["gym.envs.registration"].register = lambda **k: None
+    sys.modules["crowd_nav.policy.policy_factory"].policy_factory = {}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from crowd_sim.envs import crowd_sim as cs
+    codes = {"Nothing": 0, "Timeout": 1, "ReachGoal": 2, "Collision": 3, "CollisionOtherAgent": 4, "Danger": 5}
+    Action = namedtuple("Action", ["v", "r"])
+
+    class Pol(object):
+        name = "SARL"
+        def human_state_in_FOV(self, robot, agent):
+            return True
+
+    class Rob(object):
+        policy = Pol()
+        def compute_velocity(self, a):
+            return self.nv
+        def compute_position(self, a, dt):
+            return self.npos
+        def get_goal_position(self):
+            return self.goal
+
+    class Hum(object):
+        robot_visible = False
+        def get_observable_state(self):
+            return None
+        def act(self, ob):
+            return None
+        def get_next_observable_state(self, a):
+            return None
+
+    rng = np.random.default_rng(21)
+    n, A, G = 600, 4, 200
+    P = dict(time_step=0.25, discomfort_dist=0.2, map_size_m=20.0, map_resolution=0.1, success_reward=1.0,
+             collision_penalty=-0.25, discomfort_penalty_factor=0.5, rotation_penalty_factor=-0.01,
+             timeout_penalty=-0.125, time_limit=25.0)
+    maps = np.ones((n, G, G), np.uint8)
+    robot = np.zeros((n, 10)); agents = np.zeros((n, A, 5)); gtime = np.zeros(n)
+    reward = np.zeros(n); done = np.zeros(n, np.uint8); code = np.zeros(n, np.int32); dmin = np.full(n, np.inf)
+    for k in range(n):
+        for _ in range(rng.integers(0, 4)):
+            x0, y0 = rng.integers(0, G - 30, 2); w, h = rng.integers(2, 30, 2)
+            maps[k, x0:x0 + w, y0:y0 + h] = 0
+        pos = rng.uniform(-9.5, 9.5, 2)
+        if k % 7 == 0:                                   # next to an occupied block
+            occ = np.argwhere(maps[k] == 0)
+            if len(occ):
+                c = occ[rng.integers(len(occ))]
+                pos = (c + rng.uniform(-4, 4, 2)) * 0.1 - 10.0
+        nv = rng.uniform(-1, 1, 2)
+        npos = pos + nv * 0.25
+        goal = npos + rng.uniform(-0.25, 0.25, 2) if k % 11 == 0 else rng.uniform(-9, 9, 2)
+        radius = 0.3
+        r_act = 0.0 if k % 3 == 0 else rng.uniform(-1, 1)
+        robot[k] = [pos[0], pos[1], npos[0], npos[1], nv[0], nv[1], goal[0], goal[1], radius, r_act]
+        for a in range(A):
+            far = rng.random() < 0.5
+            off = rng.uniform(-6, 6, 2) if far else rng.uniform(-0.9, 0.9, 2)
+            agents[k, a] = [pos[0] + off[0], pos[1] + off[1], rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(0.2, 0.4)]
+        if k % 13 == 5:
+            agents[k, 1, 2:4] = nv                       # zero relative velocity: the point-distance branch
+        gtime[k] = rng.uniform(0, 25.4)
+        env = object.__new__(cs.CrowdSim)
+        rb = Rob(); rb.px, rb.py, rb.radius = pos[0], pos[1], radius
+        rb.nv, rb.npos, rb.goal = (nv[0], nv[1]), (npos[0], npos[1]), (goal[0], goal[1])
+        hs = []
+        for a in range(A):
+            h = Hum(); h.px, h.py, h.vx, h.vy, h.radius = agents[k, a]
+            hs.append(h)
+        env.humans, env.other_robots, env.robot = hs, [], rb
+        env.human_policy, env.use_grid_map, env.phase = "none", False, "train"
+        env.map = maps[k].astype(np.float64)
+        env.global_time = gtime[k]
+        env.static_obstacles_as_pedestrians = []
+        for kk, v in P.items():
+            setattr(env, kk, v)
+        _, _, rew, dn, info = cs.CrowdSim.step(env, Action(0.0, r_act), update=False, compute_local_map=False)
+        reward[k], done[k], code[k] = rew, dn, codes[type(info).__name__]
+        if code[k] == 5:
+            dmin[k] = info.min_dist
+    np.savez_compressed(os.path.join(HERE, "golden_crowd.npz"), maps=np.packbits(maps), map_shape=np.array(maps.shape),
+                        robot=robot, agents=agents, global_time=gtime, reward=reward, done=done, info=code, dmin=dmin,
+                        params=np.array([P[k] for k in sorted(P)]), param_names=np.array(sorted(P)))
+    print("golden_crowd.npz: n=%d" % n, {k: int((code == v).sum()) for k, v in codes.items()})
+
+
 def main():
     ref_env, human, keti_robot, ref_utils, human_policy = import_reference()
     make_units(ref_env, human, keti_robot, ref_utils)
@@ -503,6 +610,7 @@ def main():
     run_trace("peds_S1", ref_env, human, human_policy, S=1, seed=12, scenario="peds", n_steps=30, ped_scan_every=3)
     run_trace("crash_S3", ref_env, human, human_policy, S=3, seed=13, scenario="crash", n_steps=24)
     run_trace("success_S2", ref_env, human, human_policy, S=2, seed=14, scenario="success", n_steps=12)
+    make_crowd()
 
 
 if __name__ == "__main__":

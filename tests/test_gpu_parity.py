@@ -540,6 +540,37 @@ def test_launch_order_is_result_neutral(gpu, monkeypatch):
     assert not np.array_equal(lpt.t["launch_order"].cpu().numpy(), np.arange(E - 1, -1, -1))      # re-sorted by now
 
 
+def test_crowd_check_vs_reference_and_oracle(gpu):
+    """CrowdSim-v0's collision / goal / reward block (crowd_sim.py:808-949) on the device:
+    equal to the oracle bit for bit, and to the reference's own CrowdSim.step on the 600 golden situations;
+    plus a larger random batch with ragged agent counts against the oracle."""
+    from test_oracle_golden import _crowd_golden
+    d, maps, params = _crowd_golden()
+    got = gpu.sim.crowd_check(params, _t(gpu, maps), _t(gpu, d["robot"]), _t(gpu, d["agents"]), _t(gpu, d["global_time"]))
+    reward, done, info, md = [x.cpu().numpy() for x in got]
+    assert np.array_equal(info, d["info"]) and np.array_equal(done, d["done"])
+    assert np.abs(reward - d["reward"]).max() < 1e-12
+    exp = ref.crowd_check(params, maps, d["robot"], d["agents"], d["global_time"])
+    for a, b, what in zip((reward, done, info, md), exp, ("reward", "done", "info", "min_dist")):
+        _eq(a, b, what)
+    rng = np.random.default_rng(8)
+    E, A, G = 3000, 70, 128
+    params2 = dict(params, map_size_m=12.8, map_resolution=0.1)
+    fm = (rng.random((E, G, G)) > 0.01).astype(np.uint8)
+    robot = np.zeros((E, 10)); robot[:, :2] = rng.uniform(-6.2, 6.2, (E, 2))
+    robot[:, 4:6] = rng.uniform(-1, 1, (E, 2)); robot[:, 2:4] = robot[:, :2] + robot[:, 4:6] * 0.25
+    robot[:, 6:8] = rng.uniform(-6, 6, (E, 2)); robot[:, 8] = rng.uniform(0.2, 0.5, E); robot[:, 9] = rng.uniform(-1, 1, E)
+    agents = np.zeros((E, A, 5)); agents[..., :2] = robot[:, None, :2] + rng.uniform(-5, 5, (E, A, 2))
+    agents[..., 2:4] = rng.uniform(-1, 1, (E, A, 2)); agents[..., 4] = rng.uniform(0.2, 0.4, (E, A))
+    na = rng.integers(0, A + 1, E).astype(np.int32)
+    gt = rng.uniform(0, 26, E)
+    got = gpu.sim.crowd_check(params2, _t(gpu, fm), _t(gpu, robot), _t(gpu, agents), _t(gpu, gt), _t(gpu, na))
+    exp = ref.crowd_check(params2, fm, robot, agents, gt, na)
+    for a, b, what in zip(got, exp, ("reward", "done", "info", "min_dist")):
+        _eq(a.cpu().numpy(), b, what + " (random batch)")
+    assert len(np.unique(exp[2])) >= 4
+
+
 def test_config1_single_env_64_beams(gpu):
     """BASELINE config 1: 1 env, 64-beam lidar, 100x100 static map, no pedestrians."""
     cfg = gpu.lib.default_config(n_envs=1, map_h=100, map_w=100, n_spawn=4, auto_reset=0, seed=7)

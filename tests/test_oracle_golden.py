@@ -202,3 +202,24 @@ def test_policy_control_block_vs_reference_trace(name):
         replanned |= np.linalg.norm(r.a["ped_pose"][0, :, :2] - last, axis=1) < 0.5
     assert checked >= 30 and worst < 1e-5, (checked, worst)
     assert replanned.sum() <= 1
+
+
+def _crowd_golden():
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_crowd.npz"))
+    shape = tuple(int(x) for x in d["map_shape"])
+    maps = np.unpackbits(d["maps"])[: int(np.prod(shape))].reshape(shape)
+    params = {str(k): float(v) for k, v in zip(d["param_names"], d["params"])}
+    return d, maps, params
+
+
+def test_crowd_check_vs_reference_step():
+    """the collision / goal / reward block of the reference's own CrowdSim.step
+    (crowd_sim.py:808-949) on 600 random situations: info class and done flag exact, reward and Danger
+    distance to 1e-12."""
+    d, maps, params = _crowd_golden()
+    reward, done, info, md = ref.crowd_check(params, maps, d["robot"], d["agents"], d["global_time"])
+    assert np.array_equal(info, d["info"]) and np.array_equal(done, d["done"])
+    assert np.abs(reward - d["reward"]).max() < 1e-12
+    danger = d["info"] == 5
+    assert np.abs(md[danger] - d["dmin"][danger]).max() < 1e-12
+    assert set(np.unique(info)) >= {0, 1, 2, 3, 5}
