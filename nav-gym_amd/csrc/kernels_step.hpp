@@ -1119,16 +1119,26 @@ __global__ __launch_bounds__(1024) void launch_order_kernel(const uint32_t* __re
                                                             int n) {
     __shared__ unsigned hist[1024], base[1024];
     __shared__ unsigned max_s;
+    __shared__ unsigned long long sum_s;
     const int tid = threadIdx.x;
     hist[tid] = 0;
-    if (tid == 0) max_s = 1;
+    if (tid == 0) { max_s = 1; sum_s = 0; }
     __syncthreads();
     unsigned mx = 0;
-    for (int e = tid; e < n; e += 1024) mx = cost[e] > mx ? cost[e] : mx;
+    unsigned long long sm = 0;
+    for (int e = tid; e < n; e += 1024) { mx = cost[e] > mx ? cost[e] : mx; sm += cost[e]; }
     atomicMax(&max_s, mx);
+    atomicAdd(&sum_s, sm);
     __syncthreads();
-    const unsigned long long m = max_s;
-    auto bucket = [&](unsigned cst) { return 1023 - (int)(((unsigned long long)cst * 1023ull) / m); };   // 0 = costliest
+    // buckets span [0, min(max, 4 * mean)]: one outlier (a workgroup that was held up) must not squeeze every
+    // other arena into a handful of buckets
+    unsigned long long m = max_s;
+    const unsigned long long cap = 4ull * (sum_s / (unsigned long long)n) + 1ull;
+    m = m < cap ? m : cap;
+    auto bucket = [&](unsigned cst) {                                                                  // 0 = costliest
+        const unsigned long long cc = cst < m ? cst : m;
+        return 1023 - (int)((cc * 1023ull) / m);
+    };
     for (int e = tid; e < n; e += 1024) atomicAdd(&hist[bucket(cost[e])], 1u);
     __syncthreads();
     base[tid] = hist[tid];

@@ -508,6 +508,13 @@ def test_launch_order_is_result_neutral(gpu, monkeypatch):
     assert np.array_equal(np.sort(o), np.arange(5000))
     c = cost.cpu().numpy()[o].astype(np.int64)
     assert (np.diff(c) <= c.max() // 1023 + 1).all()              # descending up to one histogram bucket
+    cost[17] = 2_000_000_000                                      # one held-up workgroup must not flatten the rest
+    gpu.lib.check(gpu.lib.load().navsim_launch_order(cost.data_ptr(), order.data_ptr(), 5000, None), "launch_order")
+    o = order.cpu().numpy()
+    assert np.array_equal(np.sort(o), np.arange(5000)) and 17 in o[:50]
+    c = cost.cpu().numpy()[o].astype(np.int64)
+    rest = c[c < 2_000_000_000]
+    assert (np.diff(rest) <= 4 * int(cost.cpu().numpy().astype(np.int64).mean()) // 1023 + 2).all()
     E, size = 64, 240
     cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=6, ped_model=abi.PED_SFM, n_spawn=8,
                                  auto_reset=1, seed=5, field_format=abi.FIELD_U16T)
