@@ -50,6 +50,8 @@ def build_sim(wl, rank, world_size, seed=1234, device="cuda:0"):
         world.lidar_1081(cfg)
     else:
         world.lidar_full_circle(cfg, wl["beams"])
+    if wl.get("regen"):
+        cfg.regen_cap = max(16, E // 16)          # arenas regenerated per step at most (c5: ~5 finish per step)
     occ = world.make_maps(E, wl["size"], seed, env_index_base=rank * E)
     goal = (10.0, 20.0) if wl["size"] >= 400 else (2.0, 4.0)
     arrays = world.make_world(cfg, occ, n_peds=wl["peds"], device=device, min_goal_dist=goal[0], max_goal_dist=goal[1],

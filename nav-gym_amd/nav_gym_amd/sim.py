@@ -255,7 +255,16 @@ class NavSim(object):
         # few steps the arenas are re-sorted so that the slow ones start first (NAVSIM_LPT=0 disables)
         self.lpt_period = int(os.environ.get("NAVSIM_LPT", "4"))
         self._steps_launched = 0
-        if self.lpt_period > 0 and self.cfg.n_envs > 1 and "arena_cost" not in self.t:
+        # only when a launch runs several generations of workgroups: with one generation everything starts
+        # at once and the order is irrelevant (threads per arena as dispatch_step picks them)
+        n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count or 256
+        per_cu_x2 = 2 * self.cfg.n_envs // n_cu
+        block = 64 if self.cfg.n_beams <= 64 else (256 if per_cu_x2 >= 24 or self.cfg.n_beams <= 256 else
+                                                    (512 if per_cu_x2 >= 12 or self.cfg.n_beams <= 512 else 1024))
+        generations = self.cfg.n_envs * (block // 64) / float(32 * n_cu)
+        if os.environ.get("NAVSIM_LPT_FORCE") == "1":
+            generations = 2.0
+        if self.lpt_period > 0 and generations > 1.25 and "arena_cost" not in self.t:
             self.t["arena_cost"] = torch.zeros(self.cfg.n_envs, dtype=torch.int32, device=self.device)
             self.t["launch_order"] = torch.arange(self.cfg.n_envs, dtype=torch.int32, device=self.device)
             self.st.arena_cost = self.t["arena_cost"].data_ptr()

@@ -527,6 +527,7 @@ def test_launch_order_is_result_neutral(gpu, monkeypatch):
     monkeypatch.setenv("NAVSIM_LPT", "0")
     plain = gpu.sim.NavSim(cfg, arrays)
     monkeypatch.setenv("NAVSIM_LPT", "3")
+    monkeypatch.setenv("NAVSIM_LPT_FORCE", "1")       # a 64-arena launch is one generation: off by default
     lpt = gpu.sim.NavSim(cfg, arrays)
     lpt.t["launch_order"].copy_(torch.arange(E - 1, -1, -1, dtype=torch.int32, device=gpu.dev))
     assert "launch_order" not in plain.t
