@@ -468,6 +468,39 @@ def test_policy_closed_loop_vs_oracle(gpu, fmt):
     assert (m[..., 0] > 0).all() and (m[..., 0] < 1).all() and np.abs(m[..., 1]).max() < 1 and m.std() > 1e-3
 
 
+def test_policy_large_batch_is_chunk_invariant(gpu):
+    """navsim_ped_policy processes the pedestrians in passes of 32 768 (feature scratch); 34 000 pedestrians
+    built from a 10-arena world repeated 170 times: every copy gets the values of the original, whichever
+    pass and tile it falls into, and the original equals the oracle."""
+    torch = gpu.torch
+    E0, rep, size, N = 10, 170, 120, 20
+    cfg0 = gpu.lib.default_config(n_envs=E0, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_EXTERNAL, n_spawn=4,
+                                  auto_reset=1, seed=3, field_format=abi.FIELD_F32)
+    gpu.world.lidar_full_circle(cfg0, 64)
+    occ = gpu.world.make_maps(E0, size, 3)
+    base = gpu.world.make_world(cfg0, occ, n_peds=18, device=gpu.dev, min_goal_dist=2.0, max_goal_dist=4.0, robot_clearance=0.6)
+    from nav_gym_amd import robots
+    for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
+        base[key] = gpu.sim.scan_threshold(cfg0, _t(gpu, robots.footprint_array("keti", name)))
+    rng = np.random.default_rng(1)
+    scans0 = rng.uniform(0.0, 7.0, (E0, N, 512)).astype(np.float32)
+    w = _policy_weights_random(11)
+    host = {k: v.cpu().numpy() for k, v in base.items()}
+    r = ref.RefSim(cfg0, host)
+    rc, rm = r.ped_policy(w, scans0)
+    cfg = cfg0.copy(); cfg.n_envs = E0 * rep
+    shared = ("scan_threshold", "scan_discomfort", "beam_table")
+    big = {k: (v if k in shared else v.repeat((rep,) + (1,) * (v.dim() - 1))) for k, v in base.items()}
+    g = gpu.sim.NavSim(cfg, big)
+    g.set_policy(w)
+    cmd, mean = g.ped_policy(_t(gpu, scans0).repeat(rep, 1, 1))
+    cmd = cmd.cpu().numpy().reshape(rep, E0, N, 2); mean = mean.cpu().numpy().reshape(rep, E0, N, 2)
+    _eq(cmd[0], rc, "commands of the first copy vs oracle")
+    _eq(mean[0], rm, "network output of the first copy vs oracle")
+    assert (cmd == cmd[:1]).all() and (mean == mean[:1]).all()
+    assert np.abs(mean[0, :, :18]).max() > 0
+
+
 @pytest.mark.parametrize("name", ["random_S1", "peds_S1"])
 def test_policy_vs_reference_trace(gpu, name):
     """The same control block against the reference's own step(): with the weights the golden traces were
