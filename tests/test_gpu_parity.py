@@ -285,6 +285,45 @@ def test_step_rollout_with_split_pedestrian_kernel(gpu, ped_model, monkeypatch):
             _eq(gs[k], v, "state %s" % k)
 
 
+@pytest.mark.parametrize("seed", list(range(101, 117)))
+def test_step_fuzzed_configurations(gpu, seed):
+    """Random launch shapes: map size (incl. odd), beam count and field of view, stack depth, pedestrian
+    count and model, field format, arena count (which also moves the threads-per-arena heuristic), robot
+    type, turning radius.  Eight steps each, every output and the final state against the oracle."""
+    rng = np.random.default_rng(seed)
+    size = int(rng.choice([97, 128, 200, 253, 320]))
+    E = int(rng.choice([1, 3, 17, 40]))
+    N = int(rng.choice([1, 4, 11]))
+    ped_model = int(rng.choice([abi.PED_NONE, abi.PED_SFM, abi.PED_EXTERNAL]))
+    fmt = int(rng.choice([abi.FIELD_F32, abi.FIELD_U16T, abi.FIELD_F32S]))
+    S = int(rng.choice([1, 2, 5]))
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, n_scan_stack=S, ped_model=ped_model,
+                                 auto_reset=int(rng.integers(0, 2)), n_spawn=int(rng.choice([1, 5])), seed=seed,
+                                 field_format=fmt, min_turning_radius=float(rng.choice([0.0, 0.3])),
+                                 lidar_legs=int(rng.integers(0, 2)))
+    nb = int(rng.choice([33, 64, 180, 512, 1081, 1300]))
+    if nb == 1081:
+        gpu.world.lidar_1081(cfg)
+    else:
+        cfg.n_beams = nb
+        cfg.angle_min = float(rng.uniform(-3.1, -0.5)); cfg.angle_last = float(rng.uniform(0.5, 3.1))
+    if rng.random() < 0.5:
+        from nav_gym_amd import robots
+        cfg.axle_offset = robots.ROBOTS["husky"]["axle_offset"]
+    occ = gpu.world.make_maps(E, size, seed)
+    n_peds = 0 if ped_model == abi.PED_NONE else int(rng.integers(0, N + 1))
+    goal = (1.0, 3.0) if size < 200 else (2.0, 5.0)
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=n_peds, steps=8, seed=seed,
+                                                     min_goal_dist=goal[0], max_goal_dist=goal[1], robot_clearance=0.5):
+        for k in rout:
+            _eq(gout[k], rout[k], "%s at step %d" % (k, t))
+        _eq(go, ro, "obs at step %d" % t)
+    gs = g.numpy_state()
+    for k, v in r.a.items():
+        if k in gs and k not in ("field", "field_overflow"):
+            _eq(gs[k], v, "state %s" % k)
+
+
 def test_packed_field_decodes_to_float_field(gpu):
     """uint16 tiles: sqrtf(d2) must be the float32 field bit for bit; odd sizes exercise edge tiles."""
     for size, n in ((100, 2), (253, 2), (500, 1)):
