@@ -414,6 +414,47 @@ def test_regen_vs_oracle(gpu, fmt, ped_model, plan):
         assert (occupied > 0.3).any() and (occupied < 0.2).any()
 
 
+@pytest.mark.parametrize("seed", list(range(201, 213)))
+def test_reset_path_fuzzed(gpu, seed):
+    """navsim_regen (+ planning, corridor maps, resident costmap) and navsim_replan at random sizes, formats,
+    caps and pedestrian counts: state and observations stay bit-identical to the oracle."""
+    rng = np.random.default_rng(seed)
+    size = int(rng.choice([150, 205, 260, 300]))
+    E = int(rng.choice([6, 20, 33]))
+    N = int(rng.choice([2, 5, 9]))
+    ped_model = int(rng.choice([abi.PED_NONE, abi.PED_SFM]))
+    fmt = int(rng.choice([abi.FIELD_F32, abi.FIELD_U16T]))
+    plan = int(rng.integers(0, 2))
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=ped_model,
+                                 n_spawn=int(rng.choice([2, 6])), auto_reset=1, seed=seed, field_format=fmt,
+                                 regen_cap=int(rng.choice([1, 3, 40])), min_goal_dist=2.0, max_goal_dist=6.0,
+                                 spawn_clearance=0.7, ped_min_robot_dist=1.5, ped_min_goal_dist=3.0, regen_plan=plan,
+                                 regen_indoor_ratio=float(rng.choice([0.0, 0.5, 1.0])), obstacle_number=int(rng.choice([3, 10])))
+    gpu.world.lidar_full_circle(cfg, int(rng.choice([60, 180])))
+    occ = gpu.world.make_maps(E, size, seed)
+    with_costmap = bool(plan) and ped_model != abi.PED_NONE
+    regenerated = 0
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=N - 1, steps=22, seed=seed,
+                                                     min_goal_dist=2.0, max_goal_dist=5.0, robot_clearance=0.6,
+                                                     plan_paths=with_costmap):
+        _eq(go, ro, "obs at step %d" % t)
+        regenerated += int(rout["done"].sum())
+        _eq(g.regen().cpu().numpy(), r.regen(), "obs after regen at step %d" % t)
+        if with_costmap:
+            g.replan(4); r.replan(4)
+    gs = g.numpy_state()
+    for k, v in r.a.items():
+        if k in gs and k not in ("field", "field_overflow"):
+            if k == "ped_waypoints":
+                live = np.arange(abi.MAX_WAYPOINTS)[None, None, :] < r.a["ped_n_waypoints"][..., None]
+                _eq(gs[k][live], v[live], "state %s" % k)
+            else:
+                _eq(gs[k], v, "state %s" % k)
+    if fmt == abi.FIELD_F32:
+        _eq(gs["field"], r.a["field"], "field")
+    assert regenerated > 0
+
+
 @pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T])
 def test_regen_odd_map_size(gpu, fmt):
     """navsim_regen on 205 x 205 maps: per-arena field sizes that are not multiples of 16 bytes (float32)
