@@ -110,10 +110,46 @@ def cpu_baseline(wl, seconds=15.0):
         one()
         n += 1
     dt = time.perf_counter() - t0
+    # SURVEY.md 8d extras, bounded to a few seconds each: the same oracle on ONE thread, and a
+    # "reference-shaped" step (1 arena, 512 beams over 2*pi, 1000x1000 map, 10 pedestrians, every
+    # pedestrian's own 512-beam scan computed each step as env.py:685-693 does)
+    t1 = time.perf_counter()
+    m = 0
+    while time.perf_counter() - t1 < 3.0 and m < 2000:
+        act = np.stack([rng.uniform(0, 0.5, E), rng.uniform(-0.64, 0.64, E)], axis=1)
+        r.step_threads(act, pool, 1)
+        m += 1
+    one_thread = E * m / (time.perf_counter() - t1)
     pool.shutdown()
+    ref_shaped_us = None
+    try:
+        c1 = lib.default_config(n_envs=1, map_h=1000, map_w=1000, max_peds=10, ped_model=abi.PED_SFM, n_spawn=4,
+                                auto_reset=1, seed=77)
+        world.lidar_full_circle(c1, 512)
+        occ1 = world.make_maps(1, 1000, 77)
+        f1 = torch.from_numpy(ref.build_dt(occ1))
+        a1 = world.make_world(c1, occ1, n_peds=10, device="cpu", field=f1)
+        h1 = {k: v.numpy() for k, v in a1.items()}
+        h1["scan_threshold"] = ref.scan_threshold(c1, robots.footprint_array("keti", "threshold_footprint"))
+        h1["scan_discomfort"] = ref.scan_threshold(c1, robots.footprint_array("keti", "discomfort_threshold_footprint"))
+        r1 = ref.RefSim(c1, h1)
+        r1.reset_obs()
+        t2 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t2 < 2.0 and k < 5000:
+            r1.step(np.array([[rng.uniform(0, 0.5), rng.uniform(-0.64, 0.64)]]))
+            r1.ped_scans()
+            k += 1
+        ref_shaped_us = (time.perf_counter() - t2) / k * 1e6
+    except Exception:
+        pass
     return dict(value=E * n / dt, unit="env-steps/s", cores=nthr, kind="port",
                 sample="%d arenas x %d steps of the same workload (oracle/navsim_ref.c, %d threads, %.1f s)"
-                       % (E, n, nthr, dt))
+                       % (E, n, nthr, dt),
+                value_1_thread=one_thread,
+                reference_shaped_us_per_step=ref_shaped_us,
+                reference_shaped="1 arena, 512 beams, 1000x1000 map, 10 pedestrians + their 512-beam scans, 1 thread "
+                                 "(restatement, not the reference binary)")
 
 
 def main():
