@@ -467,10 +467,10 @@ __device__ __forceinline__ void finish_beams(const navsim_config& c, const StepS
 // Predicated one-ray-per-lane scan (R == 11 variant): the march loop has ONE wave-level branch
 // (any lane still marching?) instead of a divergent if-ladder per probe; finished or out-of-map
 // lanes keep executing with their updates masked off.  Same results as scan_beams.
-template <int BLOCK, typename Field>
+template <int BLOCK, typename Field, bool TO_LDS>
 __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const StepShared& sh,
                                                 const Field& field, const double* __restrict__ tab,
-                                                const Prims pr,
+                                                const Prims pr, float2* __restrict__ dir_lds, float* __restrict__ rng_lds,
                                                 const float* __restrict__ thr, const float* __restrict__ dthr,
                                                 float* __restrict__ obs_row, int n_hist, float noise_std,
                                                 uint64_t noise_key, uint64_t genv,
@@ -516,6 +516,11 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const St
             float yd = (float)hy - y0;
             rr = sqrtf(xd * xd + yd * yd);
         }
+        if (TO_LDS) {                                           // pedestrians: culled merge on the LDS copy
+            rng_lds[k] = rr;
+            dir_lds[k] = make_float2(dx, dy);
+            continue;
+        }
         rr = rr * res;                                          // env.py:426
         for (int p = 0; p < nseg; ++p)
             nv::seg_merge(rr, lx, ly, dx, dy, pr.seg[p][0], pr.seg[p][1], pr.seg[p][2], pr.seg[p][3]);
@@ -530,6 +535,11 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const St
         obs_row[(size_t)(S - 1) * B + k] = rr;
         for (int j = 0; j < S - 1; ++j)
             if (S - 1 - j > n_hist) obs_row[(size_t)j * B + k] = rr;
+    }
+    if (TO_LDS) {
+        __syncthreads();
+        finish_beams<BLOCK>(c, sh, pr, tab, dir_lds, rng_lds, rng_lds, thr, dthr, obs_row, n_hist, noise_std,
+                            noise_key, genv, cr, dc);
     }
     crash = cr;
     discomfort = dc;
@@ -997,8 +1007,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         finish_beams<BLOCK>(c, sh, prims, st.beam_table, nullptr, ws_ranges + (size_t)e * B, nullptr, st.scan_threshold,
                             st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
     else if constexpr (R == 11)
-        scan_beams_pred<BLOCK, Field>(c, sh, field, st.beam_table, prims, st.scan_threshold, st.scan_discomfort,
-                                      obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
+        scan_beams_pred<BLOCK, Field, PEDS>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
+                                            st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
     else if constexpr (R == 0)
         scan_beams_dyn<BLOCK, Field>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
                                      st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
@@ -1070,8 +1080,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             if (sh.respawn) n_hist = 0;
             int c2, d2;
             if constexpr (R == 11)
-                scan_beams_pred<BLOCK, Field>(c, sh, field, st.beam_table, prims, st.scan_threshold, st.scan_discomfort,
-                                              obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
+                scan_beams_pred<BLOCK, Field, PEDS>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
+                                                    st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
             else if constexpr (R == 0)
                 scan_beams_dyn<BLOCK, Field>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
                                              st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
