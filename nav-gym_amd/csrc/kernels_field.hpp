@@ -105,9 +105,12 @@ struct FieldF32 {
         return (stp > 1.0f) ? stp : 1.0f;
     }
 };
-struct FieldU16T {
+// OVF = false: the caller guarantees that no cell is saturated (navsim_build_field reported none and gave no
+// overflow plane), so decoding needs no test for the 0xFFFF escape -- one divergent branch less per probe
+template <bool OVF>
+struct FieldU16TT {
     const uint16_t* p; const float* ovf; int W, tpr;
-    __device__ __forceinline__ FieldU16T(const void* base, const float* overflow, int e, int H, int W_)
+    __device__ __forceinline__ FieldU16TT(const void* base, const float* overflow, int e, int H, int W_)
         : W(W_), tpr((W_ + 7) >> 3) {
         size_t per_map = (size_t)((H + 7) >> 3) * tpr * 64;
         p = (const uint16_t*)base + (size_t)e * per_map;
@@ -126,7 +129,7 @@ struct FieldU16T {
     }
     __device__ __forceinline__ bool occupied(raw_t v) const { return v == 0u; }
     __device__ __forceinline__ float decode(raw_t v, int px, int py) const {
-        if (v == 0xFFFFu) return ovf[(size_t)py * W + px];      // d2 >= 65535: exact float plane
+        if (OVF && v == 0xFFFFu) return ovf[(size_t)py * W + px];      // d2 >= 65535: exact float plane
         return nv::sqrt_small_int((float)v);
     }
     __device__ __forceinline__ float at(int px, int py) const { return decode(load(px, py), px, py); }
@@ -135,6 +138,8 @@ struct FieldU16T {
         return (stp > 1.0f) ? stp : 1.0f;
     }
 };
+typedef FieldU16TT<true> FieldU16T;
+typedef FieldU16TT<false> FieldU16TN;
 // float32 march steps in 8x4-cell tiles (one tile = one 128-B line): the loop adds the loaded value
 struct FieldF32S {
     const float* p; const float* ovf; int W, tpr;

@@ -90,7 +90,10 @@ void launch_step(const navsim_config* c, const navsim_state* st, const navsim_st
             reset_only |= 2;
         }
     }
-    if (c->field_format == NAVSIM_FIELD_U16T) {
+    if (c->field_format == NAVSIM_FIELD_U16T && !st->field_overflow) {          // no saturated cell anywhere
+        if (peds) navsim_step_kernel<BLOCK, R, true, FieldU16TN, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds_scan, (unsigned)tile_bytes);
+        else      navsim_step_kernel<BLOCK, R, false, FieldU16TN, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds_scan, (unsigned)tile_bytes);
+    } else if (c->field_format == NAVSIM_FIELD_U16T) {
         if (peds) navsim_step_kernel<BLOCK, R, true, FieldU16T, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds_scan, (unsigned)tile_bytes);
         else      navsim_step_kernel<BLOCK, R, false, FieldU16T, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds_scan, (unsigned)tile_bytes);
     } else if (c->field_format == NAVSIM_FIELD_F32S) {
