@@ -492,7 +492,6 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const St
         float t = t1;
         bool active = r_all < 0.0f;
         bool hit = false;
-        int hx = 0, hy = 0;
         while (__any(active)) {
             float fx = x0 + dx * t;
             float fy = y0 + dy * t;
@@ -502,18 +501,16 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const St
             py = live ? py : 0;
             typename Field::raw_t raw = field.load(px, py);
             bool occ = live & field.occupied(raw);
-            hx = occ ? px : hx;
-            hy = occ ? py : hy;
             hit |= occ;
             float tn = t + field.step_of(raw, px, py);
             bool go = live & !occ;
-            t = go ? tn : t;
+            t = go ? tn : t;                                    // a lane that hit keeps the t of its hit probe
             active = go & (tn < max_range);
         }
         float rr = (r_all >= 0.0f) ? r_all : max_range;
-        if (hit) {
-            float xd = (float)hx - x0;
-            float yd = (float)hy - y0;
+        if (hit) {                                              // the hit cell, recomputed from that t
+            float xd = (float)(int)(x0 + dx * t) - x0;
+            float yd = (float)(int)(y0 + dy * t) - y0;
             rr = sqrtf(xd * xd + yd * yd);
         }
         if (TO_LDS) {                                           // pedestrians: culled merge on the LDS copy
