@@ -212,9 +212,14 @@ def main():
     acts[..., 0] *= lin_hi / 0.5
     acts[..., 1] *= rot_hi / 0.64
 
-    def run(t):
+    def run(t, ev=None):
         sim.io.action = acts[t].data_ptr()
-        sim.launch_step()
+        sim._reorder()                  # longest-first launch order, re-sorted every few steps (inside the timed region)
+        if ev is not None:
+            ev[0].record()              # HIP events bracket the step launch itself
+        sim.launch_step(reorder=False)
+        if ev is not None:
+            ev[1].record()
         if regen:                       # finished arenas restart on a freshly generated map, on the device
             sim.regen()
         if gather_buf is not None:
@@ -256,9 +261,7 @@ def main():
         ev[0][1].record()
     else:
         for t in range(K):
-            ev[t][0].record()
-            run(Wm + t)
-            ev[t][1].record()
+            run(Wm + t, ev[t])
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -379,9 +379,11 @@ class NavSim(object):
         check(self.lib.navsim_ped_scans(C.byref(self.cfg), C.byref(self.st), _ptr(out), _stream()), "navsim_ped_scans")
         return out
 
-    def launch_step(self):
-        """step() without the action copy: inputs already resident (bench inner loop)."""
-        self._reorder()
+    def launch_step(self, reorder=True):
+        """step() without the action copy: inputs already resident (bench inner loop).  reorder=False: the
+        caller has already called _reorder() (bench.py keeps it outside its per-kernel events)."""
+        if reorder:
+            self._reorder()
         self._flip()
         rc = self.lib.navsim_step(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), _stream())
         if rc:
