@@ -5,9 +5,10 @@
 
 N = 1: BASELINE.json configs[1] -- 4096 arenas, 1081-beam lidar, 500x500 static occupancy map,
 diff-drive (KetiRobot kinematics), no pedestrians, auto-respawn of finished arenas in place.
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns its own 4096 arenas
-(weak scaling, arenas keyed by global env index); the step has no exchange, so there is no
-data-path collective (`--gather all` adds the optional RCCL all_gather of observations).
+N > 1: one rank per GPU -- either launched by torch.distributed.run (WORLD_SIZE set), or, when called plainly
+as `python bench.py --gpus N`, this script spawns the N ranks itself before touching the GPU.  Every rank owns
+its own 4096 arenas (weak scaling, arenas keyed by global env index); the step has no exchange, so there is
+no data-path collective (`--gather all` adds the optional RCCL all_gather of observations).
 
 One "step" = one launch of navsim_step over all local arenas, inputs resident in HBM.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
@@ -45,7 +46,7 @@ def build_sim(wl, rank, world_size, seed=1234, device="cuda:0"):
     cfg = lib.default_config(n_envs=E, map_h=wl["size"], map_w=wl["size"], max_peds=max(wl["peds"], 1),
                              ped_model=abi.PED_SFM if wl["peds"] else abi.PED_NONE,
                              n_spawn=16, auto_reset=1, seed=seed, env_index_base=rank * E,
-                             field_format={"f32": abi.FIELD_F32, "f32s": abi.FIELD_F32S}.get(wl.get("field"), abi.FIELD_U16T))
+                             field_format={"f32": abi.FIELD_F32}.get(wl.get("field"), abi.FIELD_U16T))
     if wl["beams"] == 1081:
         world.lidar_1081(cfg)
     else:
@@ -152,6 +153,68 @@ def cpu_baseline(wl, seconds=15.0):
                                  "(restatement, not the reference binary)")
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh worker processes, one per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set like torch.distributed.run does), BEFORE this process has
+    touched torch or the GPU; relay rank 0's JSON line; fail if any rank fails."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    # a rank that dies leaves its peers waiting in a collective: once one has failed, the others get 30 s
+    # to finish on their own and are then terminated (exact PIDs, never by pattern)
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > 30.0:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    reader.join(5.0)
+    sys.stdout.write(b"".join(out0).decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        raise SystemExit("bench.py: rank(s) failed: %s" % ", ".join("rank %d exit %d" % rc for rc in bad))
+
+
+def profiled_traffic(workload, E, field):
+    """HBM bytes per launch of the step kernel from the committed PMC profile of this workload (rocprofv3 --pmc
+    passes, profiles/pmc_pass.sh), NOT a reading of this run: counters cannot be collected inside the timed
+    process.  -> (bytes or None, 'file@commit' or None)"""
+    for rnd in ("r02", "r01"):
+        tp = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, workload), "traffic.json")
+        if not os.path.exists(tp):
+            continue
+        try:
+            t = json.load(open(tp))
+        except Exception:
+            continue
+        if t.get("envs_per_gpu", WORKLOADS[workload]["envs"]) != E or field != "u16t":
+            return None, None                       # another launch shape: the stored figure does not apply
+        return t.get("hbm_bytes_per_launch"), "profiles/%s_%s/traffic.json@%s" % (rnd, workload, t.get("commit", "?"))
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,23 +223,39 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=0, help="override arenas per GPU")
     ap.add_argument("--gather", default="none", choices=["none", "all"])
-    ap.add_argument("--field", default="u16t", choices=["u16t", "f32", "f32s"], help="distance-field storage")
+    ap.add_argument("--field", default="u16t", choices=["u16t", "f32"], help="distance-field storage")
+    ap.add_argument("--noise-std", type=float, default=0.02,
+                    help="scan_noise_std of every arena in the timed steps (SURVEY.md 8d: 0.02 for throughput runs)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed repeats of K steps (the first one is `value`)")
+    ap.add_argument("--no-noise-off-pass", action="store_true",
+                    help="skip the extra K steps timed with scan noise off (profiling runs: one kind of launch only)")
+    ap.add_argument("--step-block", type=int, default=0, help="threads per arena (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", default="off", choices=["auto", "on", "off"],
                     help="replay the K timed steps as one captured hipGraph (measured: c2 +0 %, c5 +2.5 %; off by default)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / reduction control flow only, no GPU work (tests/test_host_logic.py)")
     args = ap.parse_args()
 
-    import torch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
+    if world_size != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world_size))
     # NAVSIM_BENCH_BACKEND=gloo + NAVSIM_BENCH_ONE_GPU=1: control-flow test of the N > 1 path with
     # several ranks sharing one GPU (the driver's real runs use nccl = RCCL, one rank per GPU)
     backend = os.environ.get("NAVSIM_BENCH_BACKEND", "nccl")
+    if args.dry_run:
+        return dry_run(args, rank, world_size, backend)
+
+    import torch
+    dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
     if os.environ.get("NAVSIM_BENCH_ONE_GPU"):
         local_rank = 0
     device = "cuda:%d" % local_rank
@@ -188,6 +267,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus
     coll_dev = device if backend == "nccl" else "cpu"
 
     wl = dict(WORKLOADS[args.workload])
@@ -195,7 +275,12 @@ def main():
         wl["envs"] = args.envs
     wl["field"] = args.field
     cfg, sim, arrays, _ = build_sim(wl, rank, world_size, device=device)
+    if args.step_block:
+        sim.cfg.step_block = args.step_block
     E, K, Wm = cfg.n_envs, args.steps, args.warmup
+    # scan noise of the timed steps (env.py:437-440): every arena at --noise-std, counter-based Gaussian per beam
+    sim.t["scan_noise_std"].fill_(args.noise_std)
+    sim.cfg.add_scan_noise = int(args.noise_std > 0)
 
     # pre-generated in-range actions, resident in HBM; step t reads slice t (no copies in the loop)
     g = torch.Generator(device=device)
@@ -225,14 +310,17 @@ def main():
         if gather_buf is not None:
             dist.all_gather_into_tensor(gather_buf, sim.obs)
 
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for t in range(Wm):
         run(t)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # The K timed steps are launch-bound between kernels (~5 us of host gap per 220 us kernel): capture them
-    # once as a hipGraph and replay it.  Every node keeps its own action slice and observation buffers.
+    fence()
+    # The K timed steps are launch-bound between kernels (~5 us of host gap per 220 us kernel): optionally capture
+    # them once as a hipGraph and replay it.  Every node keeps its own action slice and observation buffers.
     graph = None
     if args.graph != "off" and gather_buf is None:
         try:
@@ -249,46 +337,48 @@ def main():
             torch.cuda.synchronize()
             if rank == 0:
                 print("bench: hipGraph capture failed (%s); timing plain launches" % type(exc).__name__, file=sys.stderr)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(1 if graph else K)]
-    t0 = time.perf_counter()
-    if graph is not None:
-        ev[0][0].record()
-        graph.replay()
-        ev[0][1].record()
-    else:
-        for t in range(K):
-            run(Wm + t, ev[t])
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    # HIP events on the launch stream: per step, or over the replayed graph / K (then it includes the
-    # few hundred nanoseconds between nodes: a slightly conservative kernel time)
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / K
+
+    def timed():
+        """EXACTLY K steps between barrier + synchronize on both sides; max over ranks; HIP events on the launch
+        stream around every step launch (or around the replayed graph)."""
+        fence()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(1 if graph else K)]
+        t0 = time.perf_counter()
+        if graph is not None:
+            ev[0][0].record()
+            graph.replay()
+            ev[0][1].record()
+        else:
+            for t in range(K):
+                run(Wm + t, ev[t])
+        fence()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        # per step, or over the replayed graph / K (then it includes the few hundred nanoseconds between nodes)
+        return elapsed, sum(a.elapsed_time(b) for a, b in ev) / K
+
+    elapsed, kernel_ms = timed()                     # THE measurement (`value`)
+    more = [timed() for _ in range(max(args.repeats - 1, 0))]
+    noise_off = None
+    if args.noise_std > 0 and not args.no_noise_off_pass:   # the same K steps without the per-beam Gaussian, beside it
+        sim.cfg.add_scan_noise = 0
+        noise_off = timed()
+        sim.cfg.add_scan_noise = 1
 
     if rank == 0:
+        import statistics
         n_done = int(sim.t["episode"].sum().item())
         # s_map = 1: the arena's occupancy grid as the reference stores it (int8 map_info['data'],
         # map_generator.py:136) read once per env-step -- BASELINE.md section 3's definition.  The
         # on-device distance-field encoding is an implementation choice, not algorithmic bytes.
         A = algorithmic_bytes_per_env_step(cfg.map_h, cfg.map_w, cfg.n_beams, cfg.n_scan_stack, wl["peds"], 1)
         achieved = A * E / (kernel_ms * 1e-3) / 1e9                # GB/s
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if os.path.exists(tp) and E == WORKLOADS[args.workload]["envs"] and args.field == "u16t":   # same launch only
-            try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        frac = achieved / 8000.0
+        tbytes, tsrc = profiled_traffic(args.workload, E, args.field)
+        all_values = [world_size * E * K / el for el, _ in [(elapsed, kernel_ms)] + more]
         out = {
             "metric": "env steps/sec (whole node), 4096 envs x 1081-beam lidar",
             "value": world_size * E * K / elapsed,
@@ -304,23 +394,64 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%s: %d arenas/GPU x %d-beam lidar, %dx%d per-arena occupancy maps (%s distance "
-                            "field), %d pedestrians/arena, %s kinematics, %s"
+                            "field), %d pedestrians/arena, %s kinematics, %s, scan_noise_std %.3g"
                             % (args.workload, E, cfg.n_beams, cfg.map_h, cfg.map_w, args.field, wl["peds"],
                                wl.get("robot", "keti"),
-                               "new random map per episode (navsim_regen)" if regen else "auto-respawn in place"),
+                               "new random map per episode (navsim_regen)" if regen else "auto-respawn in place",
+                               args.noise_std),
                 "envs_per_gpu": E, "n_beams": cfg.n_beams, "map": [cfg.map_h, cfg.map_w],
                 "pedestrians": wl["peds"], "obs_gather": args.gather, "episodes_finished_rank0": n_done,
                 "launch": "hipGraph replay of the K steps" if graph is not None else "one launch per step",
+                "ranks": world_size, "collective_backend": (backend if world_size > 1 else None),
+                "scan_noise_std": args.noise_std,
             },
+            "repeats": {"n": len(all_values), "values": all_values, "median": statistics.median(all_values)},
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": traffic, "kernel": "navsim_step_kernel", "kernel_ms": kernel_ms,
+                # SURVEY.md 8d figure: algorithmic bytes (whole occupancy grid once per arena-step) / kernel time.
+                # A march touches only part of the grid, so on large maps the formula can exceed 1: then it says
+                # nothing about the kernel and hbm_frac_measured (counter bytes) is the figure to read.
+                "bound": "hbm" if frac <= 1.0 else "hbm: 8d formula > 1 (counts the whole grid, a march touches a "
+                                                   "fraction of it); read hbm_frac_measured",
+                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": frac,
+                "traffic": None,                # not measured in this process (PMC needs rocprofv3)
+                "traffic_profiled": tbytes, "traffic_profile": tsrc,
+                "hbm_frac_measured": (tbytes / (kernel_ms * 1e-3) / 8.0e12) if tbytes else None,
+                "kernel": "navsim_step_kernel", "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_env_step": A, "s_map": 1,
             },
         }
+        if noise_off is not None:
+            out["noise_off"] = {"value": world_size * E * K / noise_off[0], "ms_per_step": noise_off[0] / K * 1e3,
+                                "kernel_ms": noise_off[1]}
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
         print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def dry_run(args, rank, world_size, backend):
+    """Launcher / rendezvous / max-over-ranks control flow without a GPU (CPU test of `--gpus N`): every rank
+    joins the process group, contributes a fake per-rank time, rank 0 prints the line shape with n_gpus = the
+    process group's size.  Measures nothing."""
+    dist = None
+    elapsed = 1.0 + rank
+    if world_size > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if backend == "nccl" else backend)
+        assert dist.get_world_size() == args.gpus
+        dist.barrier()
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if os.environ.get("NAVSIM_BENCH_FAIL_RANK") == str(rank):      # failure-propagation test
+        raise SystemExit(3)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (no GPU work, control flow only)", "value": None, "n_gpus": world_size,
+                          "steps": args.steps, "warmup": args.warmup, "max_rank_time": elapsed, "dry_run": True}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NAVSIM_ABI_VERSION 1
+#define NAVSIM_ABI_VERSION 2
 
 /* error codes */
 #define NAVSIM_OK            0
@@ -48,10 +48,14 @@ extern "C" {
 #define NAVSIM_FIELD_U16T    1   /* uint16 squared distance in 8x8-cell tiles (128-B lines), 0xFFFF =
                                     "d2 >= 65535, read the float32 overflow plane"; d = sqrtf(d2) is
                                     bit-identical to the float32 field */
-#define NAVSIM_FIELD_F32S    2   /* float32 march step max(fl32(fl64(d)*0.999), 1) (0 = occupied) in tiles of
-                                    8x4 cells (128-B lines): no decode in the march loop, twice the bytes;
-                                    the float32 overflow plane (exact d) is REQUIRED by the social force */
 #define NAVSIM_FIELD_TILE    8
+
+/* how the sphere-tracing step 0.999 * d of range_libc's RayMarching::calc_range (env.py:425) is rounded
+ * (navsim_config.march_rule).  The package's source is not in the reference tree, so which of the two the
+ * upstream binary computes is UNPINNED; both are implemented on both sides and the
+ * switch is this one field.  DESIGN.md records how many rays change their hit cell between them. */
+#define NAVSIM_MARCH_F64     0   /* t += max(fl32(fl64(d) * 0.999), 1): a double coefficient (default) */
+#define NAVSIM_MARCH_F32     1   /* t += max(d * 0.999f, 1): a float member `step_coeff` */
 
 /* compiled limits */
 #define NAVSIM_MAX_PEDS      64
@@ -132,6 +136,14 @@ typedef struct navsim_config {
     double regen_indoor_ratio;        /* navsim_regen: probability that a new map is a corridor map
                                          (create_indoor_map, map_generator.py:97-123) instead of an outdoor one;
                                          env.py:742 indoor_ratio.  0 = outdoor only */
+
+    int32_t march_rule;               /* NAVSIM_MARCH_* */
+    /* Launch geometry of the fused step.  Validated plain data: the library reads no environment variable. */
+    int32_t step_block;               /* threads per arena: 0 = chosen from the batch size,
+                                         else 64, 256, 512 or 1024 */
+    int32_t ped_split;                /* pedestrian update in its own one-wavefront-per-arena kernel ahead of the
+                                         step: 0 = for large batches (>= 3072 arenas), 1 = never, 2 = always */
+    int32_t reserved0;
 } navsim_config;
 
 /* ------------------------------------------------------------------------------------------
@@ -146,9 +158,6 @@ typedef struct navsim_state {
     const float*  field_overflow;   /* [E,H,W] float32 distances, read only where the packed field
                                        holds 0xFFFF; may be NULL when navsim_build_field reported
                                        no saturated cell (NAVSIM_FIELD_U16T only) */
-    const uint32_t* tile_table;     /* [E, ceil(H/8)*ceil(W/8)] analytic 8x8-tile records (navsim_build_tiles);
-                                       optional accelerator staged in LDS by the step, NULL = every probe reads
-                                       the field.  Results are unchanged. */
     const double* beam_table;       /* [B,2] cos, sin of the robot-frame beam angles (navsim_beam_table);
                                        optional accelerator, NULL = evaluate every beam direction in full */
     const float*  scan_threshold;   /* [B] env.py:162-170 */
@@ -192,11 +201,6 @@ typedef struct navsim_state {
      * kernel does not end on a few stragglers. */
     uint32_t*      arena_cost;
     const int32_t* launch_order;
-
-    /* scratch of navsim_step_workspace_bytes(cfg) bytes.  Non-NULL selects the pooled schedule
-     * (per-arena prologue -> one flat pool of 64-beam march tasks -> per-arena epilogue, DESIGN.md
-     * section 6); NULL runs the whole step as one launch.  Results are identical. */
-    void* workspace;
 } navsim_state;
 
 /* What step() returns (env.py:728) with a leading env axis. */
@@ -238,22 +242,11 @@ int    navsim_build_field(const uint8_t* occ, int32_t n_maps, int32_t map_h, int
                           void* field, float* overflow, int32_t* n_saturated,
                           void* workspace, size_t workspace_bytes, void* stream);
 
-/* Analytic tile records.  In an 8x8-cell tile whose cells all have their nearest obstacle on ONE
- * axis-aligned feature (a wall row, a wall column, a corner cell, or the tile is solid), the squared
- * distance is (px-ox)^2 [or 0] + (py-oy)^2 [or 0] with one (ox, oy) for the whole tile.  The builder
- * derives the feature from the exact transform and VERIFIES the formula on all 64 cells before
- * marking the tile valid, so a valid record reproduces the field exactly; the step keeps the table
- * of an arena in LDS (4 B per tile) and reads HBM only for probes in the remaining mixed tiles.
- * Record: bit 31 valid, bit 30 dx == 0, bit 29 dy == 0, bits 27..14 oy, bits 13..0 ox. */
-size_t navsim_tile_table_bytes(int32_t n_maps, int32_t map_h, int32_t map_w);
-size_t navsim_build_tiles_workspace_bytes(int32_t n_maps, int32_t map_h, int32_t map_w);
-int    navsim_build_tiles(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t map_w,
-                          uint32_t* tiles, void* workspace, size_t workspace_bytes, void* stream);
-
 /* ---- a4: PyRayMarching.calc_range_many (env.py:425) ------------------------------------- */
-/* queries [E, n_per_env, 3] float32 (x, y, theta) in cell units, out [E, n_per_env] in cells. */
+/* queries [E, n_per_env, 3] float32 (x, y, theta) in cell units, out [E, n_per_env] in cells;
+ * march_rule = NAVSIM_MARCH_*. */
 int navsim_cast_static(const float* field, int32_t n_envs, int32_t map_h, int32_t map_w,
-                       const float* queries, int32_t n_per_env, float max_range,
+                       const float* queries, int32_t n_per_env, float max_range, int32_t march_rule,
                        float* out, void* stream);
 
 /* ---- a5: CMap2D.flatten_contours + render_contours_in_lidar (env.py:430-431) ------------ */
@@ -300,8 +293,6 @@ int navsim_beam_table(const navsim_config* cfg, double* table, void* stream);
 int navsim_step(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                 void* stream);
 
-size_t navsim_step_workspace_bytes(const navsim_config* cfg);
-
 /* ---- env.py:685-693: the scan of every pedestrian (input of the reference's HumanPolicy) --------- */
 /* out [E, N, ped_n_beams] float32 metres: static map from the pedestrian's integer cell, the robot as its
  * threshold footprint and the other pedestrians as footprint rectangles (lidar_legs=False), clipped to
@@ -317,7 +308,9 @@ int navsim_ped_scans(const navsim_config* cfg, const navsim_state* st, float* ou
  * (start >= 4 m from the robot, goal >= 10 m away, v_pref, has_legs: env.py:786-806) and the first
  * observation of the new episode (env.py:808-831) written to io->obs.  Call it right after navsim_step on
  * the same stream with the same io.  Mutates field, spawn tables and pedestrian parameters in place.
- * Square maps, FIELD_F32 or FIELD_U16T without an overflow plane or tile table.
+ * Square maps; FIELD_F32, or FIELD_U16T on maps of at most 520 cells per side (no cell of such a map can be
+ * 256 cells from every obstacle, so a regenerated packed field never needs the overflow plane; larger
+ * packed maps return NAVSIM_E_UNSUPPORTED).
  * cfg->regen_plan = 1: starts and goals are centres of free COSTMAP cells and a pair is kept only when the
  * planner joins it (robot: path no longer than twice the straight line, env.py:756-762; pedestrians get the
  * path's waypoints every 2 m, env.py:804); four rounds of candidates, the last one stays if none passes. */
@@ -333,12 +326,11 @@ int navsim_costmap(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t ma
  * cells of start[q] and goal[q] (build-defined tie-break), cut into waypoints every
  * `interval` metres.  wp [n,max_wp,2], n_wp [n] (0 = no path), path_cells [n], path_len [n] (env.py:757-759);
  * the last three may be NULL.  The search runs in LDS (4 bytes per costmap cell: up to 200 x 200 cells,
- * i.e. 1000 x 1000 maps); `workspace` is unused (navsim_plan_workspace_bytes returns 0) and may be NULL. */
-size_t navsim_plan_workspace_bytes(int32_t n_queries, int32_t cost_h, int32_t cost_w);
+ * i.e. 1000 x 1000 maps; larger costmaps return NAVSIM_E_UNSUPPORTED). */
 int    navsim_plan(const uint8_t* cost, const int32_t* map_index, int32_t n_queries, int32_t cost_h, int32_t cost_w,
                    double cost_resolution, double origin_x, double origin_y, const double* start, const double* goal,
                    double interval, int32_t max_wp, double* wp, int32_t* n_wp, int32_t* path_cells, double* path_len,
-                   void* workspace, size_t workspace_bytes, void* stream);
+                   void* stream);
 
 /* env.py:667-680: every pedestrian within 0.5 m of its final waypoint gets a new goal -- a free costmap cell
  * more than cfg->ped_min_goal_dist away (up to 4 rounds of 16 draws) -- and the waypoints of the shortest
@@ -428,6 +420,9 @@ size_t navsim_sizeof_step_io(void);
  * 4 angle_correction (utils.py:5-9), 5 python-float % 2pi, 6 the packed field's sqrtf on integers.
  * x, x2, out are device float64 [n]. */
 int navsim_debug_math(int32_t fn, const double* x, const double* x2, double* out, int32_t n, void* stream);
+/* batch_xy_to_ij (env.py:1228-1253) exactly as the scan evaluates it: xy [n,2] float64 in, ij [n,2] int32 out;
+ * as_f32 = 1 rounds the inputs to float32 first and divides in float32 (the lidar origin, env.py:386, 419). */
+int navsim_debug_xy_to_ij(const navsim_config* cfg, const double* xy, int32_t as_f32, int32_t* ij, int32_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,16 @@ __global__ __launch_bounds__(64 * kColSeg) void dt_columns_kernel(const uint8_t*
     }
 }
 
+// The march step of a free sample at distance d (cells): t += max(0.999 * d, 1), RayMarching::calc_range of
+// range_libc (env.py:425).  How the product is rounded is NOT pinned by anything in /root/reference (the
+// package's source is absent; oracle/navsim_ref.c states the two candidates): NAVSIM_MARCH_F64 keeps the
+// coefficient a double, fl32(fl64(d) * 0.999); NAVSIM_MARCH_F32 keeps it a float member, d * 0.999f.
+template <int RULE>
+__device__ __forceinline__ float march_step(float d) {
+    const float stp = (RULE == NAVSIM_MARCH_F32) ? d * 0.999f : (float)((double)d * 0.999);
+    return (stp > 1.0f) ? stp : 1.0f;
+}
+
 // distance-field accessors -------------------------------------------------------------------
 // FieldF32: float32 row-major (what range_libc keeps).  FieldU16T: uint16 squared distances in
 // 8x8-cell tiles, one tile = one 128-B line = one HBM fill (profiles/gather_granularity.py): a
@@ -99,11 +109,6 @@ struct FieldF32 {
     __device__ __forceinline__ bool occupied(raw_t v) const { return v <= 0.0f; }
     __device__ __forceinline__ float decode(raw_t v, int, int) const { return v; }
     __device__ __forceinline__ float at(int px, int py) const { return load(px, py); }
-    // march step of a non-occupied sample: t += max(fl32(fl64(d) * 0.999), 1)
-    __device__ __forceinline__ float step_of(raw_t v, int, int) const {
-        float stp = (float)((double)v * 0.999);
-        return (stp > 1.0f) ? stp : 1.0f;
-    }
 };
 // OVF = false: the caller guarantees that no cell is saturated (navsim_build_field reported none and gave no
 // overflow plane), so decoding needs no test for the 0xFFFF escape -- one divergent branch less per probe
@@ -133,38 +138,9 @@ struct FieldU16TT {
         return nv::sqrt_small_int((float)v);
     }
     __device__ __forceinline__ float at(int px, int py) const { return decode(load(px, py), px, py); }
-    __device__ __forceinline__ float step_of(raw_t v, int px, int py) const {
-        float stp = (float)((double)decode(v, px, py) * 0.999);
-        return (stp > 1.0f) ? stp : 1.0f;
-    }
 };
 typedef FieldU16TT<true> FieldU16T;
 typedef FieldU16TT<false> FieldU16TN;
-// float32 march steps in 8x4-cell tiles (one tile = one 128-B line): the loop adds the loaded value
-struct FieldF32S {
-    const float* p; const float* ovf; int W, tpr;
-    __device__ __forceinline__ FieldF32S(const void* base, const float* overflow, int e, int H, int W_)
-        : W(W_), tpr((W_ + 7) >> 3) {
-        size_t per_map = (size_t)((H + 3) >> 2) * tpr * 32;
-        p = (const float*)base + (size_t)e * per_map;
-        ovf = overflow ? overflow + (size_t)e * H * W_ : nullptr;
-    }
-    __device__ __forceinline__ static size_t index(int px, int py, int tpr) {
-        return ((size_t)((py >> 2) * tpr + (px >> 3)) << 5) + ((py & 3) << 3) + (px & 7);
-    }
-    typedef float raw_t;
-    __device__ __forceinline__ raw_t load(int px, int py) const {
-        unsigned upx = (unsigned)px, upy = (unsigned)py;
-        unsigned off = ((((upy >> 2) * (unsigned)tpr + (upx >> 3)) << 5) | ((upy & 3u) << 3) | (upx & 7u)) * 4u;
-        return *(const float*)((const char*)p + off);
-    }
-    __device__ __forceinline__ bool occupied(raw_t v) const { return v == 0.0f; }
-    __device__ __forceinline__ float step_of(raw_t v, int, int) const { return v; }
-    // exact distance (first probe, social force): from the float32 plane
-    __device__ __forceinline__ float decode(raw_t, int px, int py) const { return ovf[(size_t)py * W + px]; }
-    __device__ __forceinline__ float at(int px, int py) const { return ovf[(size_t)py * W + px]; }
-};
-
 // How far a ray has to be marched.  The reference marches up to H*W cells (env.py:337) and clips the
 // result to range_max afterwards (env.py:434).  A hit found at parameter t lies at least t - sqrt(2) cells
 // from the origin, so once t exceeds range_max / resolution + 4 every possible outcome -- a later hit,
@@ -226,106 +202,9 @@ __global__ __launch_bounds__(256) void dt_rows_kernel(const uint16_t* __restrict
             out[FieldU16T::index(x, y, tpr)] = (uint16_t)(best >= 65535 ? 0xFFFF : best);
             if (overflow) overflow[(m * (size_t)H + y) * W + x] = sqrtf((float)best);
             sat += best >= 65535;
-        } else {
-            const size_t per_map_s = (size_t)((H + 3) >> 2) * tpr * 32;
-            float d = sqrtf((float)best);
-            float stp = (float)((double)d * 0.999);
-            stp = (stp > 1.0f) ? stp : 1.0f;
-            ((float*)field_v)[m * per_map_s + FieldF32S::index(x, y, tpr)] = (best == 0) ? 0.0f : stp;
-            if (overflow) overflow[(m * (size_t)H + y) * W + x] = d;
-            sat += 1;                                  // "saturated": the overflow plane is always needed
         }
     }
     if (FORMAT != 0 && n_saturated && sat) atomicAdd(n_saturated, sat);
-}
-
-// ============================================================================================
-// analytic tile records (navsim_build_tiles): feature transform + per-tile verification
-// ============================================================================================
-constexpr unsigned kTileValid = 1u << 31, kTileDx0 = 1u << 30, kTileDy0 = 1u << 29;
-
-// nearest occupied row per cell of a column (-1: none); ties go to the row above
-__global__ __launch_bounds__(256) void ft_columns_kernel(const uint8_t* __restrict__ occ,
-                                                         int16_t* __restrict__ nr, int H, int W) {
-    int x = blockIdx.x * blockDim.x + threadIdx.x;
-    size_t m = blockIdx.y;
-    if (x >= W) return;
-    const uint8_t* o = occ + m * (size_t)H * W;
-    int16_t* r = nr + m * (size_t)H * W;
-    int last = -1;
-    for (int y = 0; y < H; ++y) {
-        if (o[(size_t)y * W + x]) last = y;
-        r[(size_t)y * W + x] = (int16_t)last;
-    }
-    last = -1;
-    for (int y = H - 1; y >= 0; --y) {
-        if (o[(size_t)y * W + x]) last = y;
-        int up = r[(size_t)y * W + x];
-        if (last >= 0 && (up < 0 || last - y < y - up)) r[(size_t)y * W + x] = (int16_t)last;
-    }
-}
-
-// per row: exact d2 and the obstacle cell (ox, oy) that realises it
-__global__ __launch_bounds__(256) void ft_rows_kernel(const int16_t* __restrict__ nr, int32_t* __restrict__ d2out,
-                                                      int16_t* __restrict__ oxy, int H, int W) {
-    extern __shared__ int32_t row[];                 // vertical distance g(i) of this row
-    size_t m = blockIdx.y;
-    int y = blockIdx.x;
-    const int16_t* r = nr + (m * (size_t)H + y) * W;
-    for (int x = threadIdx.x; x < W; x += blockDim.x) {
-        int v = r[x];
-        row[x] = (v < 0) ? kDtInf : (v > y ? v - y : y - v);
-    }
-    __syncthreads();
-    for (int x = threadIdx.x; x < W; x += blockDim.x) {
-        int g0 = row[x];
-        int best = g0 * g0, arg = x;
-        for (int dx = 1; dx < W; ++dx) {
-            int dx2 = dx * dx;
-            if (dx2 >= best) break;
-            int xl = x - dx, xr = x + dx;
-            if (xl >= 0) { int v = row[xl]; int c = dx2 + v * v; if (c < best) { best = c; arg = xl; } }
-            if (xr < W)  { int v = row[xr]; int c = dx2 + v * v; if (c < best) { best = c; arg = xr; } }
-        }
-        size_t i = (m * (size_t)H + y) * W + x;
-        d2out[i] = best;
-        oxy[2 * i] = (int16_t)arg;
-        oxy[2 * i + 1] = r[arg];
-    }
-}
-
-// one wave per tile, one lane per cell: try the four forms with the feature of the tile's first
-// cell and keep the first that reproduces d2 on every in-map cell of the tile
-__global__ __launch_bounds__(64) void tile_table_kernel(const int32_t* __restrict__ d2in,
-                                                        const int16_t* __restrict__ oxy,
-                                                        uint32_t* __restrict__ tiles, int H, int W) {
-    const int tpr = (W + 7) >> 3, tpc = (H + 7) >> 3;
-    size_t m = blockIdx.y;
-    int tile = blockIdx.x;
-    int ty = tile / tpr, tx = tile - ty * tpr;
-    int lane = threadIdx.x;
-    int px = tx * 8 + (lane & 7), py = ty * 8 + (lane >> 3);
-    bool in_map = px < W && py < H;
-    size_t base = m * (size_t)H * W;
-    size_t i0 = base + (size_t)(ty * 8) * W + tx * 8;                      // first cell is always in the map
-    int ox = oxy[2 * i0], oy = oxy[2 * i0 + 1];
-    int d2 = in_map ? d2in[base + (size_t)py * W + px] : 0;
-    uint32_t rec = 0;
-    if (ox >= 0 && oy >= 0 && d2in[i0] < kDtInf * kDtInf) {
-        int ddx = px - ox, ddy = py - oy;
-        bool ok00 = !in_map || d2 == 0;                                    // solid tile
-        bool ok01 = !in_map || d2 == ddy * ddy;                            // horizontal wall: dx == 0
-        bool ok10 = !in_map || d2 == ddx * ddx;                            // vertical wall:   dy == 0
-        bool ok11 = !in_map || d2 == ddx * ddx + ddy * ddy;                // corner cell
-        const unsigned long long full = ~0ull;
-        uint32_t feat = ((uint32_t)oy << 14) | (uint32_t)ox;
-        if (__ballot(ok00) == full)      rec = kTileValid | kTileDx0 | kTileDy0;
-        else if (__ballot(ok01) == full) rec = kTileValid | kTileDx0 | feat;
-        else if (__ballot(ok10) == full) rec = kTileValid | kTileDy0 | feat;
-        else if (__ballot(ok11) == full) rec = kTileValid | feat;
-    }
-    const size_t stride = ((size_t)tpr * tpc + 3) & ~(size_t)3;             // 16-byte granular per arena
-    if (lane == 0) tiles[m * stride + tile] = rec;
 }
 
 // ============================================================================================
@@ -333,7 +212,7 @@ __global__ __launch_bounds__(64) void tile_table_kernel(const int32_t* __restric
 // ============================================================================================
 __global__ __launch_bounds__(256) void cast_static_kernel(const float* __restrict__ field, int H, int W,
                                                           const float* __restrict__ q, int n_per_env,
-                                                          long long n_total, float max_range,
+                                                          long long n_total, float max_range, int march_rule,
                                                           float* __restrict__ out) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_total) return;
@@ -341,7 +220,7 @@ __global__ __launch_bounds__(256) void cast_static_kernel(const float* __restric
     const float* f = field + (size_t)e * H * W;
     float dx, dy;
     nv::beam_dir(q[3 * i + 2], dx, dy);
-    out[i] = nv::trace_ray(f, H, W, q[3 * i], q[3 * i + 1], dx, dy, max_range);
+    out[i] = nv::trace_ray(f, H, W, q[3 * i], q[3 * i + 1], dx, dy, max_range, march_rule);
 }
 
 // ============================================================================================

@@ -60,7 +60,9 @@ __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim
         float dx, dy;
         nv::beam_dir((float)(lin + lth), dx, dy);
         dir[k] = make_float2(dx, dy);
-        rng[k] = march_ray(field, x0, y0, dx, dy, 0.0f, max_range, (unsigned)W, (unsigned)H) * res;
+        rng[k] = ((c.march_rule == NAVSIM_MARCH_F32)
+                      ? march_ray<NAVSIM_MARCH_F32>(field, x0, y0, dx, dy, 0.0f, max_range, (unsigned)W, (unsigned)H)
+                      : march_ray<NAVSIM_MARCH_F64>(field, x0, y0, dx, dy, 0.0f, max_range, (unsigned)W, (unsigned)H)) * res;
     }
     __syncthreads();
     const Prims pr = {seg, nullptr, info_s};
@@ -184,6 +186,16 @@ __global__ void math_kernel(int fn, const double* x, const double* x2, double* o
         case 6: out[i] = (double)nv::sqrt_small_int((float)x[i]); break;
         default: out[i] = 0.0;
     }
+}
+
+__global__ __launch_bounds__(256) void xy_to_ij_kernel(navsim_config c, const double* __restrict__ xy, int as_f32,
+                                                       int32_t* __restrict__ ij, int n) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    int i, j;
+    if (as_f32) nv::xy_to_ij_f32((float)xy[2 * t], (float)xy[2 * t + 1], c, i, j);
+    else        nv::xy_to_ij(xy[2 * t], xy[2 * t + 1], c, i, j);
+    ij[2 * t] = i; ij[2 * t + 1] = j;
 }
 
 // microbenchmark (profiles/gather_granularity.py): random 4-byte gathers over a large buffer.

@@ -20,8 +20,6 @@ struct StepShared {
     unsigned long long step_key;  // scan-noise counter of this step
     double wave_ratio[kMaxWaves];
 };
-constexpr size_t kPoolEnvBytes = 512;     // StepShared slot per arena in the step workspace
-static_assert(sizeof(StepShared) <= kPoolEnvBytes, "StepShared must fit its workspace slot");
 // Pedestrian scratch of the pedestrian variants of the kernel, carved out of dynamic LDS behind the scan's
 // dir / rng area and sized by cfg.max_peds (N), not by the compiled maximum: 136 N + 32 bytes, so that a
 // 20-pedestrian world still fits 8 arenas per CU (the static 64-pedestrian layout allowed 7).
@@ -51,155 +49,6 @@ __device__ __forceinline__ void finish_beams(const navsim_config& c, const StepS
                                              const float* __restrict__ thr, const float* __restrict__ dthr,
                                              float* __restrict__ obs_row, int n_hist, float noise_std,
                                              uint64_t noise_key, uint64_t genv, int& crash, int& discomfort);
-
-// robot scan (env.py:385-441 with other_agents = all pedestrians).  Writes the latest-scan slot
-// of the observation row and every "not yet filled" stack slot (env.py:262-265).
-//
-// The march is latency-bound (each probe of the distance field is a dependent HBM/L2 access), so
-// every thread advances R independent rays in lock-step: the R loads of one round are issued back
-// to back before any of them is consumed, which multiplies the lines in flight per CU by R.
-// Beam k of round-slot q is base + q*BLOCK + tid, so lanes of a wave hold adjacent beams (their
-// probes fall on neighbouring cells and their range stores coalesce).
-template <int BLOCK, int R, typename Field, bool TO_LDS>
-__device__ __forceinline__ void scan_beams(const navsim_config& c, const StepShared& sh,
-                                           const Field& field, const double* __restrict__ tab,
-                                           const Prims pr, float2* __restrict__ dir_lds, float* __restrict__ rng_lds,
-                                           const uint32_t* __restrict__ tiles,
-                                           const float* __restrict__ thr, const float* __restrict__ dthr,
-                                           float* __restrict__ obs_row, int n_hist, float noise_std,
-                                           uint64_t noise_key, uint64_t genv,
-                                           int& crash, int& discomfort) {
-    const int B = c.n_beams, S = c.n_scan_stack, H = c.map_h, W = c.map_w;
-    const float max_range = march_limit(H, W, c.range_max, c.resolution);
-    const float res = (float)c.resolution;
-    const float rmax = (float)c.range_max;
-    const double step = nv::linspace_step(c);
-    const float x0 = (float)sh.i0, y0 = (float)sh.j0;
-    const float lx = sh.lx, ly = sh.ly;
-    const double lth = (double)sh.lth;
-    const int nseg = sh.nseg, ndisc = sh.ndisc;
-    int cr = 0, dc = 0;
-#ifdef NAVSIM_CONTIGUOUS_FANS
-    // each wave owns ONE contiguous fan of beams and walks it in 64-beam slices
-    const int n_waves = BLOCK / 64;
-    const int per_wave = (B + n_waves - 1) / n_waves;
-    const int fan0 = ((int)threadIdx.x >> 6) * per_wave;
-    const int fan1 = (fan0 + per_wave < B) ? fan0 + per_wave : B;
-#define NAVSIM_BEAM_OF(base_, q_) (fan0 + (base_) / n_waves + (q_) * 64 + ((int)threadIdx.x & 63))
-#define NAVSIM_BEAM_OK(k_) ((k_) < fan1)
-    for (int base = 0; base < per_wave * n_waves; base += BLOCK * R) {
-#else
-#define NAVSIM_BEAM_OF(base_, q_) ((base_) + (q_) * BLOCK + (int)threadIdx.x)
-#define NAVSIM_BEAM_OK(k_) ((k_) < B)
-    for (int base = 0; base < B; base += BLOCK * R) {
-#endif
-        float dx[R], dy[R], t[R], r[R];
-        unsigned active = 0;
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            int k = NAVSIM_BEAM_OF(base, q);
-            bool valid = NAVSIM_BEAM_OK(k);
-            const int kk = valid ? k : 0;
-            const double lin = nv::linspace_k(c, kk, step);
-            double ang = lin + lth;                                     // env.py:388-390
-            float heading = (float)ang;                                 // env.py:424
-            bool fast = false;
-            if (tab) {
-                // heading = lin + lth + delta EXACTLY: (heading - ang) is exact (Sterbenz), and the
-                // rounding error of the float64 sum is recovered by TwoSum
-                double bb = ang - lin;
-                double eps = (lin - (ang - bb)) + (lth - bb);
-                double delta = ((double)heading - ang) + eps;
-                double2 cs = ((const double2*)tab)[kk];
-                fast = nv::beam_dir_from_table(cs.x, cs.y, sh.cT, sh.sT, delta, dx[q], dy[q]);
-            }
-            if (!fast) nv::beam_dir(heading, dx[q], dy[q]);
-            t[q] = sh.t1;                              // the t = 0 probe (origin cell) was taken once
-            r[q] = (sh.r_all >= 0.0f) ? sh.r_all : max_range;
-            active |= (valid && sh.r_all < 0.0f) ? (1u << q) : 0u;
-        }
-        // range_libc RayMarching::calc_range (env.py:425), R rays per thread in lock-step.  The hit
-        // distance is evaluated once after the march (hx, hy), not speculatively in every round.
-        int hx[R], hy[R];
-        unsigned hit = 0;
-        const unsigned uW = (unsigned)W, uH = (unsigned)H;
-        if (R == 1 && tiles) {                               // LDS tile table: two-phase march
-            r[0] = march_ray_tiles(field, tiles, (W + 7) >> 3, x0, y0, dx[0], dy[0], t[0], max_range, uW, uH,
-                                   (active & 1u) != 0u);
-            if (sh.r_all >= 0.0f) r[0] = sh.r_all;
-            active = 0;
-        }
-        while (active) {
-            int px[R], py[R];
-            typename Field::raw_t raw[R];
-#pragma unroll
-            for (int q = 0; q < R; ++q) {
-                float fx = x0 + dx[q] * t[q];
-                float fy = y0 + dy[q] * t[q];
-                px[q] = (int)fx;
-                py[q] = (int)fy;
-                // px >= W || px < 0 || py < 0 || py >= H, as two unsigned compares
-                bool inb = ((unsigned)px[q] < uW) & ((unsigned)py[q] < uH);
-                bool a = (active >> q) & 1u;
-                if (a && !inb) active &= ~(1u << q);                    // left the map: max_range
-                bool live = a && inb;
-                px[q] = live ? px[q] : 0;
-                py[q] = live ? py[q] : 0;
-                raw[q] = field.load(px[q], py[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < R; ++q) {
-                if ((active >> q) & 1u) {
-                    if (field.occupied(raw[q])) {
-                        hx[q] = px[q]; hy[q] = py[q];
-                        hit |= 1u << q;
-                        active &= ~(1u << q);
-                    } else {
-                        t[q] += field.step_of(raw[q], px[q], py[q]);
-                        if (!(t[q] < max_range)) active &= ~(1u << q);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            if ((hit >> q) & 1u) {
-                float xd = (float)hx[q] - x0;
-                float yd = (float)hy[q] - y0;
-                r[q] = sqrtf(xd * xd + yd * yd);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            int k = NAVSIM_BEAM_OF(base, q);
-            if (TO_LDS) {                                               // pedestrian variants: merge later, culled
-                if (NAVSIM_BEAM_OK(k)) { rng_lds[k] = r[q]; dir_lds[k] = make_float2(dx[q], dy[q]); }
-            } else if (NAVSIM_BEAM_OK(k)) {
-                float rr = r[q] * res;                                  // env.py:426
-                for (int p = 0; p < nseg; ++p)
-                    nv::seg_merge(rr, lx, ly, dx[q], dy[q], pr.seg[p][0], pr.seg[p][1], pr.seg[p][2], pr.seg[p][3]);
-                for (int p = 0; p < ndisc; ++p)
-                    nv::circle_merge(rr, lx, ly, dx[q], dy[q], pr.disc[p][0], pr.disc[p][1], nv::kLegRadius);
-                rr = rr < 0.0f ? 0.0f : rr;                             // env.py:435
-                rr = rr > rmax ? rmax : rr;
-                if (noise_std > 0.0f && rr != rmax)                     // env.py:437-440
-                    rr = rr + noise_std * nv::gauss_noise(c.seed ^ noise_key, genv, noise_key, (uint32_t)k);
-                cr |= (rr < thr[k]);
-                dc |= (rr < dthr[k]);
-                obs_row[(size_t)(S - 1) * B + k] = rr;
-                for (int j = 0; j < S - 1; ++j)
-                    if (S - 1 - j > n_hist) obs_row[(size_t)j * B + k] = rr;
-            }
-        }
-    }
-    if (TO_LDS) {
-        __syncthreads();
-        finish_beams<BLOCK>(c, sh, pr, tab, dir_lds, rng_lds, rng_lds, thr, dthr, obs_row, n_hist, noise_std,
-                            noise_key, genv, cr, dc);
-    }
-    crash = cr;
-    discomfort = dc;
-}
 
 // one social-force term of the build-defined pedestrian model: force on agent
 // i from agent j; (0, 0) when the pair is skipped
@@ -247,62 +96,18 @@ __device__ __forceinline__ void beam_dir_k(const navsim_config& c, const double*
 }
 
 // the t = 0 sample of calc_range is the origin cell for every beam: take it once per scan
-template <typename Field>
+template <int RULE, typename Field>
 __device__ __forceinline__ void first_probe(const Field& field, int i0, int j0, float max_range,
                                             float& t1, float& r_all) {
     t1 = 0.0f; r_all = -1.0f;
     typename Field::raw_t raw0 = field.load(i0, j0);               // origin is clipped into the map
     if (field.occupied(raw0)) { r_all = 0.0f; return; }            // sqrtf(0): starts inside an obstacle
-    float d0 = field.decode(raw0, i0, j0);
-    float stp = (float)((double)d0 * 0.999);
-    t1 = (stp > 1.0f) ? stp : 1.0f;
+    t1 = march_step<RULE>(field.decode(raw0, i0, j0));
     if (!(t1 < max_range)) r_all = max_range;
 }
 
-// Same march with the arena's analytic tile table in LDS (navsim_build_tiles): a probe whose tile
-// has a valid record gets its exact d2 from one LDS read and integer arithmetic; only probes in
-// mixed tiles read the field (~35 % of the probes, ~3x fewer distinct lines per arena).
-// d2 from a record is the exact integer the field holds, so the sampled sequence is unchanged.
-// (A two-phase form -- lanes run ahead through valid tiles, then load together -- was measured
-// slower: in lock-step the run-ahead iterations of a few lanes stall the whole wave.)
-template <typename Field>
-__device__ __forceinline__ float march_ray_tiles(const Field& field, const uint32_t* __restrict__ tiles, int tpr,
-                                                 float x0, float y0, float dx, float dy, float t,
-                                                 float max_range, unsigned uW, unsigned uH, bool alive) {
-    float result = max_range;
-    while (alive) {
-        float fx = x0 + dx * t;
-        float fy = y0 + dy * t;
-        int px = (int)fx, py = (int)fy;
-        if (!(((unsigned)px < uW) & ((unsigned)py < uH))) break;           // left the map
-        unsigned rec = tiles[(py >> 3) * tpr + (px >> 3)];
-        float d;
-        bool occ;
-        if (rec & kTileValid) {                                            // analytic: no memory access
-            int ddx = (rec & kTileDx0) ? 0 : px - (int)(rec & 0x3FFFu);
-            int ddy = (rec & kTileDy0) ? 0 : py - (int)((rec >> 14) & 0x3FFFu);
-            int d2 = ddx * ddx + ddy * ddy;
-            occ = d2 == 0;
-            d = nv::sqrt_small_int((float)(d2 | (int)occ));
-        } else {                                                           // mixed tile: read the field
-            typename Field::raw_t raw = field.load(px, py);
-            occ = field.occupied(raw);
-            d = occ ? 1.0f : field.decode(raw, px, py);
-        }
-        if (occ) {
-            float xd = (float)px - x0, yd = (float)py - y0;
-            result = sqrtf(xd * xd + yd * yd);
-            break;
-        }
-        float stp = (float)((double)d * 0.999);
-        t += (stp > 1.0f) ? stp : 1.0f;
-        if (!(t < max_range)) break;
-    }
-    return result;
-}
-
 // one ray of calc_range from t = t1 on (env.py:425); returns the raw range in cells
-template <typename Field>
+template <int RULE, typename Field>
 __device__ __forceinline__ float march_ray(const Field& field, float x0, float y0, float dx, float dy,
                                            float t, float max_range, unsigned uW, unsigned uH) {
     for (;;) {
@@ -316,7 +121,7 @@ __device__ __forceinline__ float march_ray(const Field& field, float x0, float y
             float yd = (float)py - y0;
             return sqrtf(xd * xd + yd * yd);
         }
-        t += field.step_of(raw, px, py);
+        t += march_step<RULE>(field.decode(raw, px, py));
         if (!(t < max_range)) return max_range;
     }
 }
@@ -464,10 +269,10 @@ __device__ __forceinline__ void finish_beams(const navsim_config& c, const StepS
     discomfort = dc;
 }
 
-// Predicated one-ray-per-lane scan (R == 11 variant): the march loop has ONE wave-level branch
+// Predicated one-ray-per-lane scan: the march loop has ONE wave-level branch
 // (any lane still marching?) instead of a divergent if-ladder per probe; finished or out-of-map
 // lanes keep executing with their updates masked off.  Same results as scan_beams.
-template <int BLOCK, typename Field, bool TO_LDS>
+template <int BLOCK, typename Field, bool TO_LDS, int RULE>
 __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const StepShared& sh,
                                                 const Field& field, const double* __restrict__ tab,
                                                 const Prims pr, float2* __restrict__ dir_lds, float* __restrict__ rng_lds,
@@ -502,7 +307,7 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const St
             typename Field::raw_t raw = field.load(px, py);
             bool occ = live & field.occupied(raw);
             hit |= occ;
-            float tn = t + field.step_of(raw, px, py);
+            float tn = t + march_step<RULE>(field.decode(raw, px, py));
             bool go = live & !occ;
             t = go ? tn : t;                                    // a lane that hit keeps the t of its hit probe
             active = go & (tn < max_range);
@@ -541,135 +346,6 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const St
     crash = cr;
     discomfort = dc;
 }
-
-// Wave-dynamic robot scan (R == 0 variants; the default).  Same results as scan_beams, different
-// schedule, built on what the profiles showed (profiles/README.md):
-//   * lanes of a wave finish their rays after very different numbers of probes (mean 7.9, wave
-//     maximum 13.5), so with one fixed ray per lane 45 % of the issue slots idle.  Here every wave
-//     owns a contiguous fan of beams and a lane that finishes a ray immediately takes the next
-//     unassigned beam of its wave (ballot + popcount, no atomics) -- "persistent lanes";
-//   * beam directions are produced once per scan by a coalesced pass into LDS, so a refill is one
-//     ds_read_b64; ranges go back to LDS and a second coalesced pass merges pedestrians, clips,
-//     adds noise, raises the crash / discomfort flags and stores the observation row;
-//   * the first probe (the robot's own cell) is identical for every beam and is taken once.
-template <int BLOCK, typename Field>
-__device__ __forceinline__ void scan_beams_dyn(const navsim_config& c, StepShared& sh,
-                                               const Field& field, const double* __restrict__ tab,
-                                               const Prims pr, float2* __restrict__ dir, float* __restrict__ rng,
-                                               const float* __restrict__ thr, const float* __restrict__ dthr,
-                                               float* __restrict__ obs_row, int n_hist, float noise_std,
-                                               uint64_t noise_key, uint64_t genv,
-                                               int& crash, int& discomfort) {
-    const int B = c.n_beams, H = c.map_h, W = c.map_w;
-    const float max_range = march_limit(H, W, c.range_max, c.resolution);
-    const double step = nv::linspace_step(c);
-    const float x0 = (float)sh.i0, y0 = (float)sh.j0;
-    const int tid = (int)threadIdx.x;
-
-    // ---- pass 1: beam directions -> LDS
-    for (int k = tid; k < B; k += BLOCK) {
-        float dx, dy;
-        beam_dir_k(c, tab, k, step, (double)sh.lth, sh.cT, sh.sT, dx, dy);
-        dir[k] = make_float2(dx, dy);
-    }
-    const float t1 = sh.t1, r_all = sh.r_all;                // first probe, taken by thread 0 earlier
-    __syncthreads();
-
-    // ---- pass 2: march (env.py:425), persistent lanes
-    if (r_all < 0.0f) {
-        const int lane = tid & 63, wave = tid >> 6;
-        const int per = (B + (BLOCK / 64) - 1) / (BLOCK / 64);
-        int next = wave * per;
-        const int end = (next + per < B) ? next + per : B;
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        const unsigned uW = (unsigned)W, uH = (unsigned)H;
-        bool active = false;
-        int k = 0;
-        float t = 0.0f, dx = 0.0f, dy = 0.0f;
-        for (;;) {
-            unsigned long long idle = __ballot(!active);
-            if (next < end && idle) {
-                int my = next + __popcll(idle & lt);
-                if (!active && my < end) {
-                    k = my;
-                    float2 d = dir[k];
-                    dx = d.x; dy = d.y;
-                    t = t1;
-                    active = true;
-                }
-                next += __popcll(idle);
-            }
-            if (!__any(active)) break;
-            if (active) {
-                float fx = x0 + dx * t;
-                float fy = y0 + dy * t;
-                int px = (int)fx, py = (int)fy;
-                if (!(((unsigned)px < uW) & ((unsigned)py < uH))) {
-                    rng[k] = max_range;                             // left the map
-                    active = false;
-                } else {
-                    typename Field::raw_t raw = field.load(px, py);
-                    if (field.occupied(raw)) {
-                        float xd = (float)px - x0;
-                        float yd = (float)py - y0;
-                        rng[k] = sqrtf(xd * xd + yd * yd);
-                        active = false;
-                    } else {
-                        t += field.step_of(raw, px, py);
-                        if (!(t < max_range)) { rng[k] = max_range; active = false; }
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- pass 3
-    finish_beams<BLOCK>(c, sh, pr, tab, dir, rng, rng, thr, dthr, obs_row, n_hist, noise_std, noise_key, genv,
-                        crash, discomfort);
-}
-
-// ============================================================================================
-// Pool scan: the march of ALL arenas as one flat pool of 64-beam wave tasks.  No workgroup barrier,
-// no idle waves waiting for an arena's slowest fan: a CU always holds 32 marching waves, whatever
-// the number of arenas.  Reads each arena's scan request (StepShared slot in the workspace), writes
-// raw ranges in cells.  `only_flagged`: the re-scan after a crash revert / respawn (env.py:718-723).
-// ============================================================================================
-template <typename Field>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void pool_scan_kernel(navsim_config c, navsim_state st, char* __restrict__ ws_env, float* __restrict__ ranges,
-                      int only_flagged, unsigned n_blocks_logical) {
-    // XCD-aware block order: consecutive logical blocks (the fans of one arena) share an XCD's L2
-    const unsigned nb = gridDim.x;
-    unsigned bid = blockIdx.x;
-    if ((nb & 7u) == 0u) bid = (bid & 7u) * (nb >> 3) + (bid >> 3);
-    if (bid >= n_blocks_logical) return;
-    const int B = c.n_beams;
-    const int G = (B + 63) >> 6;
-    const unsigned task = bid * 4u + (threadIdx.x >> 6);
-    const int e = (int)(task / (unsigned)G);
-    if (e >= c.n_envs) return;
-    const int g = (int)(task - (unsigned)e * (unsigned)G);
-    const StepShared* __restrict__ s = (const StepShared*)(ws_env + (size_t)e * kPoolEnvBytes);
-    if (only_flagged && !s->rescan) return;
-    const float r_all = s->r_all;
-    if (r_all >= 0.0f) return;                                   // finish_beams supplies the range
-    const int k = g * 64 + (int)(threadIdx.x & 63);
-    if (k >= B) return;
-    const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, c.map_h, c.map_w);
-    float dx, dy;
-    beam_dir_k(c, st.beam_table, k, nv::linspace_step(c), (double)s->lth, s->cT, s->sT, dx, dy);
-    const float max_range = march_limit(c.map_h, c.map_w, c.range_max, c.resolution);
-    ranges[(size_t)e * B + k] = march_ray(field, (float)s->i0, (float)s->j0, dx, dy, s->t1, max_range,
-                                          (unsigned)c.map_w, (unsigned)c.map_h);
-}
-
-// MODE 0: the whole step in one launch.  MODE 1 / 2 / 3: the same code cut at the scan, for the
-// pooled schedule (navsim_step with a workspace): 1 = everything before the scan, then the arena's
-// StepShared (+ pedestrian primitives) is parked in the workspace; pool_scan_kernel marches;
-// 2 = flags, reward / done / info, relocation decision and -- unless the arena must be re-scanned --
-// the observation row and state; 3 = the same tail for re-scanned arenas.
-enum { kModeFused = 0, kModePre = 1, kModePost = 2, kModeFinal = 3 };
 
 // Phase 1 for the pedestrians of one arena (env.py:617-693 with the build-defined social force or external
 // commands): waypoint pop, forces / integration, new goal, leg odometry, state.  Called by every thread of the
@@ -828,34 +504,27 @@ __global__ __launch_bounds__(64) void ped_update_kernel(navsim_config c, navsim_
                          (uint64_t)st.steps[e] + 1, old_rp, prev_v, ps, ped_dyn, pair_bytes, pp, pvel);
 }
 
-template <int BLOCK, int R, bool PEDS, typename Field, int MODE>
+// The fused step.  BLOCK threads = one arena; PEDS: the pedestrian variants (primitives + culled merge in LDS);
+// RULE: the march step rule (NAVSIM_MARCH_*), a compile-time copy of cfg.march_rule so that the probe loop
+// carries no select.
+template <int BLOCK, bool PEDS, typename Field, int RULE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void navsim_step_kernel(navsim_config c, navsim_state st,
                                                             navsim_step_io io, int reset_only,
                                                             const uint8_t* __restrict__ reset_mask,
-                                                            char* __restrict__ ws_env, char* __restrict__ ws_prims,
-                                                            float* __restrict__ ws_ranges, unsigned dyn_lds_bytes,
-                                                            unsigned tile_lds_bytes) {
+                                                            unsigned dyn_lds_bytes) {
     __shared__ StepShared sh;
     const int peds_done = (reset_only >> 1) & 1;     // the pedestrians were advanced by ped_update_kernel
     reset_only &= 1;
-    // dynamic LDS: [analytic tile table of the arena, tile_lds_bytes][float2 dir[B], float rng[B]]
-    extern __shared__ __attribute__((aligned(16))) char dyn_lds_all[];
-    char* dyn_lds = dyn_lds_all + tile_lds_bytes;
-    const uint32_t* tiles_lds = tile_lds_bytes ? (const uint32_t*)dyn_lds_all : nullptr;
+    // dynamic LDS (pedestrian variants only): [float2 dir[B], float rng[B]][PedShared]
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     PedShared ps = {};
     if constexpr (PEDS) ps = ped_lds_carve(dyn_lds + ((dyn_lds_bytes + 15u) & ~15u), c.max_peds);
     const Prims prims = {ps.seg, ps.disc, ps.info};
     // longest-first launch order (a scheduling hint: which arena a workgroup takes never changes a result)
-    const int e = (MODE == kModeFused && st.launch_order) ? st.launch_order[blockIdx.x] : (int)blockIdx.x;
+    const int e = st.launch_order ? st.launch_order[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x;
     unsigned long long t_begin = 0;
-    if (MODE == kModeFused && st.arena_cost && tid == 0) t_begin = __builtin_amdgcn_s_memrealtime();
-    if (tile_lds_bytes) {                                       // stage the arena's tile table (coalesced)
-        const uint4* src = (const uint4*)((const char*)st.tile_table + (size_t)(c.shared_field ? 0 : e) * tile_lds_bytes);
-        uint4* dst = (uint4*)dyn_lds_all;
-        for (int i = tid; i < (int)(tile_lds_bytes / 16); i += BLOCK) dst[i] = src[i];
-        // visibility: every path reaches a __syncthreads() before the first scan
-    }
+    if (st.arena_cost && tid == 0) t_begin = __builtin_amdgcn_s_memrealtime();
     const int B = c.n_beams, S = c.n_scan_stack, N = c.max_peds, D = S * B + 7;
     const double dt = c.time_step;
     const uint64_t genv = (uint64_t)(c.env_index_base + e);
@@ -868,20 +537,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     double* pv_g = st.prev_pose + 3 * (size_t)e;
 
     if (reset_only && reset_mask && !reset_mask[e]) {          // untouched env: carry the row over
-        if ((MODE == kModeFused || MODE == kModePre) && obs_prev)
+        if (obs_prev)
             for (int k = tid; k < D; k += BLOCK) obs_row[k] = obs_prev[k];
         return;
-    }
-    StepShared* slot = (MODE == kModeFused) ? nullptr : (StepShared*)(ws_env + (size_t)e * kPoolEnvBytes);
-    constexpr int kPrimWords = (int)((sizeof(float) * 4 * 4 * NAVSIM_MAX_PEDS + sizeof(float) * 2 * 2 * NAVSIM_MAX_PEDS) / 4);
-    if constexpr (MODE == kModePost || MODE == kModeFinal) {
-        if (MODE == kModeFinal && !slot->rescan) return;        // nothing was re-scanned for this arena
-        for (int i = tid; i < (int)(sizeof(StepShared) / 4); i += BLOCK) ((int*)&sh)[i] = ((const int*)slot)[i];
-        if constexpr (PEDS) {
-            const int* src = (const int*)(ws_prims + (size_t)e * kPrimWords * 4);
-            for (int i = tid; i < 20 * c.max_peds; i += BLOCK) ((int*)ps.seg)[i] = src[i];   // seg, then disc
-        }
-        __syncthreads();
     }
 
     int n = (!PEDS || c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
@@ -889,7 +547,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const float noise_std = (c.add_scan_noise && st.scan_noise_std) ? st.scan_noise_std[e] : 0.0f;
 
     NAVSIM_STAMP(0);
-    if constexpr (MODE == kModeFused || MODE == kModePre) {
     // ---------------------------------------------------------------- phase 0: scalars
     if (tid == 0) {
         sh.old_rp[0] = rp_g[0]; sh.old_rp[1] = rp_g[1]; sh.old_rp[2] = rp_g[2];
@@ -977,44 +634,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];   // env.py:386
         nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);                              // env.py:419
         nv::sincos((double)sh.lth, sh.sT, sh.cT);
-        first_probe(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
+        first_probe<RULE>(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
         sh.step_key = (unsigned long long)st.episode[e] * 0x100000000ULL +
                       (unsigned long long)(reset_only ? 0 : st.steps[e]) * 2ULL;
     }
     __syncthreads();
-    if constexpr (MODE == kModePre) {                           // park the arena, the pool marches next
-        for (int i = tid; i < (int)(sizeof(StepShared) / 4); i += BLOCK) ((int*)slot)[i] = ((const int*)&sh)[i];
-        if constexpr (PEDS) {
-            int* dst = (int*)(ws_prims + (size_t)e * kPrimWords * 4);
-            for (int i = tid; i < 20 * c.max_peds; i += BLOCK) dst[i] = ((const int*)ps.seg)[i];
-        }
-        return;
-    }
-    }   // MODE fused / pre
 
     NAVSIM_STAMP(2);
     // ---------------------------------------------------------------- phase 3: scan A
     int n_hist = reset_only ? 0 : st.n_hist[e];
-    if (MODE == kModeFinal && sh.respawn) n_hist = 0;
     int crash = 0, discomfort = 0;
-    const uint64_t step_key = sh.step_key + (MODE == kModeFinal ? 1 : 0);
+    const uint64_t step_key = sh.step_key;
     float2* dir_lds = (float2*)dyn_lds;
     float* rng_lds = (float*)(dyn_lds + sizeof(float2) * (size_t)B);
-    if constexpr (MODE != kModeFused)
-        finish_beams<BLOCK>(c, sh, prims, st.beam_table, nullptr, ws_ranges + (size_t)e * B, nullptr, st.scan_threshold,
-                            st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
-    else if constexpr (R == 11)
-        scan_beams_pred<BLOCK, Field, PEDS>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
-                                            st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
-    else if constexpr (R == 0)
-        scan_beams_dyn<BLOCK, Field>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
-                                     st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
-    else
-        scan_beams<BLOCK, R, Field, PEDS>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, tiles_lds, st.scan_threshold,
-                                          st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
+    scan_beams_pred<BLOCK, Field, PEDS, RULE>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
+                                              st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
 
     NAVSIM_STAMP(3);
-    if (!reset_only && MODE != kModeFinal) {
+    if (!reset_only) {
         crash = __syncthreads_or(crash);
         discomfort = __syncthreads_or(discomfort);
         double rmin = 1.0e300;
@@ -1062,29 +699,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];
                 nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);
                 nv::sincos((double)sh.lth, sh.sT, sh.cT);
-                first_probe(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
+                first_probe<RULE>(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
             }
         }
         __syncthreads();
-        if constexpr (MODE == kModePost) {
-            if (sh.rescan) {                                    // hand the arena back to the pool
-                for (int i = tid; i < (int)(sizeof(StepShared) / 4); i += BLOCK) ((int*)slot)[i] = ((const int*)&sh)[i];
-                return;
-            }
-        }
         // ------------------------------------------------------------ phase 5: scan B (env.py:718-723)
-        if (MODE == kModeFused && sh.rescan) {
+        if (sh.rescan) {
             if (sh.respawn) n_hist = 0;
             int c2, d2;
-            if constexpr (R == 11)
-                scan_beams_pred<BLOCK, Field, PEDS>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
-                                                    st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
-            else if constexpr (R == 0)
-                scan_beams_dyn<BLOCK, Field>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
-                                             st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
-            else
-                scan_beams<BLOCK, R, Field, PEDS>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, tiles_lds, st.scan_threshold,
-                                                  st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
+            scan_beams_pred<BLOCK, Field, PEDS, RULE>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
+                                                      st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
         }
     }
 
@@ -1114,7 +738,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         else       { pa_g[0] = sh.act[0]; pa_g[1] = sh.act[1]; st.n_hist[e] = (n_hist + 1 < S - 1) ? n_hist + 1 : S - 1; }
         if (reset_only) st.steps[e] = 0;
         pv_g[0] = sh.rp[0]; pv_g[1] = sh.rp[1]; pv_g[2] = yaw;
-        if (MODE == kModeFused && st.arena_cost && !reset_only)
+        if (st.arena_cost && !reset_only)
             st.arena_cost[e] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_begin);
     }
     NAVSIM_STAMP(6);

@@ -66,7 +66,7 @@ __device__ __forceinline__ bool beam_dir_from_table(double ct, double st, double
 // range_libc RayMarching::calc_range (PyRayMarching.calc_range_many, env.py:425): sphere tracing
 // through the distance field, float32, C truncation of the sample position.
 __device__ __forceinline__ float trace_ray(const float* __restrict__ f, int H, int W, float x0, float y0,
-                                           float dx, float dy, float max_range) {
+                                           float dx, float dy, float max_range, int march_rule) {
     float t = 0.0f;
     while (t < max_range) {
         float fx = x0 + dx * t;
@@ -80,7 +80,7 @@ __device__ __forceinline__ float trace_ray(const float* __restrict__ f, int H, i
             float yd = (float)py - y0;
             return sqrtf(xd * xd + yd * yd);
         }
-        float step = (float)((double)d * 0.999);
+        float step = (march_rule == NAVSIM_MARCH_F32) ? d * 0.999f : (float)((double)d * 0.999);
         t += (step > 1.0f) ? step : 1.0f;
     }
     return max_range;

@@ -23,6 +23,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/navsim.h"
 #include "navmath.hpp"
 #include "navsim_device.hpp"
@@ -32,6 +34,7 @@
 namespace {
 
 constexpr int kMaxWaves = 16;
+constexpr int kRegenMaxPackedSide = 520;    // see navsim_regen
 
 // Diagnostic build only (-DNAVSIM_STAMPS, profiles/stamp_phases.py): s_memtime at the phase
 // boundaries of each arena's workgroup, written to a buffer nothing else reads.  The shipped library
@@ -53,143 +56,109 @@ __device__ unsigned long long* g_stamps = nullptr;
 #include "kernels_policy.hpp"
 #include "kernels_pedscan.hpp"
 
-// Launch geometry: BLOCK threads per arena, R rays per thread (R = 0: wave-dynamic scan).
-// NAVSIM_STEP_VARIANT="<block>x<rays>" overrides the default of the one-launch schedule (tuning).
-template <int BLOCK, int R, int MODE>
-void launch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
-                 int reset_only, const uint8_t* mask, char* ws_env, char* ws_prims, float* ws_ranges,
-                 hipStream_t s) {
-    const bool peds = c->ped_model != NAVSIM_PED_NONE;
-    const bool peds_ = c->ped_model != NAVSIM_PED_NONE;
-    size_t lds = ((R == 0 || peds_) && MODE == kModeFused)
-                     ? (size_t)c->n_beams * (sizeof(float2) + sizeof(float)) : 0;      // dir + rng
-    // analytic tile table in LDS: one-launch schedule, 1 ray per thread, packed field, table <= 40 KiB and
-    // 16-byte granular per arena (so arena e's table starts at e * tile_bytes)
-    size_t tile_bytes = 0;
-    if (MODE == kModeFused && R == 1 && st->tile_table && c->field_format == NAVSIM_FIELD_U16T &&
-        !getenv("NAVSIM_NO_TILES")) {
-        size_t tb = navsim_tile_table_bytes(1, c->map_h, c->map_w);
-        if (tb <= 40960) tile_bytes = tb;
+// kernels that want more than 64 KB of dynamic LDS must say so once; more than the CU has is refused
+constexpr size_t kLdsPerCu = 160 * 1024;
+int allow_lds(const void* kernel, size_t lds) {
+    if (lds <= 64 * 1024) return NAVSIM_OK;
+    if (lds > kLdsPerCu) return NAVSIM_E_UNSUPPORTED;
+    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess
+               ? NAVSIM_OK : NAVSIM_E_UNSUPPORTED;
+}
+
+// compute units of the CURRENT device (cached per device ordinal; idempotent, so a race only repeats the query)
+int device_cu_count() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cache[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+
+// dynamic LDS of the fused step: beam directions + ranges (pedestrian variants merge from LDS) and PedShared
+size_t step_lds_scan_bytes(const navsim_config* c) {
+    return c->ped_model != NAVSIM_PED_NONE ? (size_t)c->n_beams * (sizeof(float2) + sizeof(float)) : 0;
+}
+size_t step_lds_bytes(const navsim_config* c) {
+    size_t lds = step_lds_scan_bytes(c);
+    if (c->ped_model != NAVSIM_PED_NONE) lds = ((lds + 15) & ~(size_t)15) + ped_lds_bytes(c->max_peds);
+    return lds;
+}
+size_t ped_update_lds_bytes(const navsim_config* c) {
+    return (((size_t)c->max_peds * (c->max_peds + 1) * sizeof(double2) + 15) & ~(size_t)15) + ped_lds_bytes(c->max_peds);
+}
+
+// Threads per arena (cfg.step_block = 0).  With >= 12 arenas per CU the chip is kept full by 256-thread
+// workgroups (8 per CU, several generations).  With fewer arenas a launch is one generation whose length is a
+// workgroup's own march, i.e. beams per thread: wider workgroups shorten it (measured, c2 world: 2048 arenas
+// 14.4 / 16.4 / 13.7 M env-steps/s for 256 / 512 / 1024 threads; 1024 arenas 8.8 / 11.3 / 11.6; 512 arenas
+// 5.2 / 6.7 / 7.3; 4096 arenas 19.5 / 17.4 / -).
+int pick_step_block(const navsim_config* c) {
+    if (c->step_block) return c->step_block;
+    const int B = c->n_beams;
+    const long per_cu_x2 = 2L * c->n_envs / device_cu_count();           // arenas per CU, doubled
+    if (B <= 64) return 64;
+    if (per_cu_x2 >= 24 || B <= 256) return 256;
+    if (per_cu_x2 >= 12 || B <= 512) return 512;
+    return 1024;
+}
+
+template <int BLOCK, bool PEDS, typename Field>
+int launch_step_rule(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
+                     const uint8_t* mask, size_t lds, hipStream_t s) {
+    const unsigned lds_scan = (unsigned)step_lds_scan_bytes(c);
+    if (c->march_rule == NAVSIM_MARCH_F32) {
+        if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, NAVSIM_MARCH_F32>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
+        navsim_step_kernel<BLOCK, PEDS, Field, NAVSIM_MARCH_F32><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, lds_scan);
+    } else {
+        if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, NAVSIM_MARCH_F64>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
+        navsim_step_kernel<BLOCK, PEDS, Field, NAVSIM_MARCH_F64><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, lds_scan);
     }
-    const size_t lds_scan = lds;
-    lds += tile_bytes;
-    if (peds) lds = ((lds + 15) & ~(size_t)15) + ped_lds_bytes(c->max_peds);       // PedShared behind dir / rng
-    if (const char* pad = getenv("NAVSIM_LDS_PAD")) lds += (size_t)atoi(pad);   // occupancy experiments only
-    // pedestrians ahead of the step, one wavefront per arena (NAVSIM_PED_SPLIT=0: inside the step as before)
-    // (pays when the chip runs several generations of arenas: c3 13.2 -> 14.0 M env-steps/s; a 512-arena
-    // launch is latency-bound and loses 2 % to the extra kernel, so small batches keep the fused form)
-    if (MODE == kModeFused && peds && !reset_only && c->max_peds <= 56) {                        // <= 64 KB of LDS
-        const char* v = getenv("NAVSIM_PED_SPLIT");             // "0" never, "1" always, unset: large batches
-        const int split = v ? (v[0] != '0') : (c->n_envs >= 3072);
+    return NAVSIM_OK;
+}
+
+template <int BLOCK>
+int launch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
+                const uint8_t* mask, hipStream_t s) {
+    const bool peds = c->ped_model != NAVSIM_PED_NONE;
+    const size_t lds = step_lds_bytes(c);
+    // pedestrians ahead of the step, one wavefront per arena (pays when the chip runs several generations of
+    // arenas: c3 13.2 -> 14.0 M env-steps/s; a 512-arena launch is latency-bound and loses 2 % to the extra
+    // kernel, so small batches keep the fused form)
+    if (peds && !reset_only && ped_update_lds_bytes(c) <= 64 * 1024) {
+        const bool split = c->ped_split == 2 || (c->ped_split == 0 && c->n_envs >= 3072);
         if (split) {
-            const size_t pl = (((size_t)c->max_peds * (c->max_peds + 1) * sizeof(double2) + 15) & ~(size_t)15) +
-                              ped_lds_bytes(c->max_peds);
-            if (c->field_format == NAVSIM_FIELD_U16T)      ped_update_kernel<FieldU16T><<<c->n_envs, 64, pl, s>>>(*c, *st);
-            else if (c->field_format == NAVSIM_FIELD_F32S) ped_update_kernel<FieldF32S><<<c->n_envs, 64, pl, s>>>(*c, *st);
-            else                                           ped_update_kernel<FieldF32><<<c->n_envs, 64, pl, s>>>(*c, *st);
+            const size_t pl = ped_update_lds_bytes(c);
+            if (c->field_format == NAVSIM_FIELD_U16T) ped_update_kernel<FieldU16T><<<c->n_envs, 64, pl, s>>>(*c, *st);
+            else                                      ped_update_kernel<FieldF32><<<c->n_envs, 64, pl, s>>>(*c, *st);
             reset_only |= 2;
         }
     }
     if (c->field_format == NAVSIM_FIELD_U16T && !st->field_overflow) {          // no saturated cell anywhere
-        if (peds) navsim_step_kernel<BLOCK, R, true, FieldU16TN, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds_scan, (unsigned)tile_bytes);
-        else      navsim_step_kernel<BLOCK, R, false, FieldU16TN, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds_scan, (unsigned)tile_bytes);
+        return peds ? launch_step_rule<BLOCK, true, FieldU16TN>(c, st, io, reset_only, mask, lds, s)
+                    : launch_step_rule<BLOCK, false, FieldU16TN>(c, st, io, reset_only, mask, lds, s);
     } else if (c->field_format == NAVSIM_FIELD_U16T) {
-        if (peds) navsim_step_kernel<BLOCK, R, true, FieldU16T, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds_scan, (unsigned)tile_bytes);
-        else      navsim_step_kernel<BLOCK, R, false, FieldU16T, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds_scan, (unsigned)tile_bytes);
-    } else if (c->field_format == NAVSIM_FIELD_F32S) {
-        if (peds) navsim_step_kernel<BLOCK, R, true, FieldF32S, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds_scan, (unsigned)tile_bytes);
-        else      navsim_step_kernel<BLOCK, R, false, FieldF32S, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds_scan, (unsigned)tile_bytes);
-    } else {
-        if (peds) navsim_step_kernel<BLOCK, R, true, FieldF32, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds_scan, (unsigned)tile_bytes);
-        else      navsim_step_kernel<BLOCK, R, false, FieldF32, MODE><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, ws_env, ws_prims, ws_ranges, (unsigned)lds_scan, (unsigned)tile_bytes);
+        return peds ? launch_step_rule<BLOCK, true, FieldU16T>(c, st, io, reset_only, mask, lds, s)
+                    : launch_step_rule<BLOCK, false, FieldU16T>(c, st, io, reset_only, mask, lds, s);
     }
-}
-
-constexpr size_t kPrimBytes = sizeof(float) * 4 * 4 * NAVSIM_MAX_PEDS + sizeof(float) * 2 * 2 * NAVSIM_MAX_PEDS;
-
-size_t workspace_bytes(const navsim_config* c) {
-    size_t E = (size_t)c->n_envs;
-    size_t b = E * kPoolEnvBytes + E * (size_t)c->n_beams * sizeof(float);
-    if (c->ped_model != NAVSIM_PED_NONE) b += E * kPrimBytes;
-    return b;
-}
-
-// pooled schedule: prologue per arena, one flat pool of march tasks, epilogue per arena, and the
-// same pair again for the (few) arenas that were reverted / respawned
-int run_pooled(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
-               const uint8_t* mask, hipStream_t s) {
-    const size_t E = (size_t)c->n_envs;
-    char* ws_env = (char*)st->workspace;
-    float* ws_ranges = (float*)(ws_env + E * kPoolEnvBytes);
-    char* ws_prims = (char*)(ws_ranges + E * (size_t)c->n_beams);
-    const unsigned G = (unsigned)((c->n_beams + 63) / 64);
-    const unsigned n_logical = (unsigned)((E * G + 3) / 4);
-    const unsigned grid = (n_logical + 7u) & ~7u;
-    launch_step<64, 1, kModePre>(c, st, io, reset_only, mask, ws_env, ws_prims, ws_ranges, s);
-    for (int pass = 0; pass < (reset_only ? 1 : 2); ++pass) {
-        if (c->field_format == NAVSIM_FIELD_U16T)
-            pool_scan_kernel<FieldU16T><<<grid, 256, 0, s>>>(*c, *st, ws_env, ws_ranges, pass, n_logical);
-        else if (c->field_format == NAVSIM_FIELD_F32S)
-            pool_scan_kernel<FieldF32S><<<grid, 256, 0, s>>>(*c, *st, ws_env, ws_ranges, pass, n_logical);
-        else
-            pool_scan_kernel<FieldF32><<<grid, 256, 0, s>>>(*c, *st, ws_env, ws_ranges, pass, n_logical);
-        if (pass == 0) launch_step<256, 1, kModePost>(c, st, io, reset_only, mask, ws_env, ws_prims, ws_ranges, s);
-        else           launch_step<256, 1, kModeFinal>(c, st, io, reset_only, mask, ws_env, ws_prims, ws_ranges, s);
-    }
-    return launch_status();
+    return peds ? launch_step_rule<BLOCK, true, FieldF32>(c, st, io, reset_only, mask, lds, s)
+                : launch_step_rule<BLOCK, false, FieldF32>(c, st, io, reset_only, mask, lds, s);
 }
 
 int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
                   int reset_only, const uint8_t* mask, hipStream_t s) {
-    const char* mode = getenv("NAVSIM_STEP_MODE");
-    if (st->workspace && mode && strcmp(mode, "pool") == 0)      // opt-in: measured slower than one launch
-        return run_pooled(c, st, io, reset_only, mask, s);
-    int block = 0, rays = 0;
-    const char* v = getenv("NAVSIM_STEP_VARIANT");
-    if (v && sscanf(v, "%dx%d", &block, &rays) != 2) { block = 0; rays = 0; }
-    if (!block) {
-        // Threads per arena.  With >= 12 arenas per CU the chip is kept full by 256-thread workgroups (8 per
-        // CU, several generations).  With fewer arenas a launch is one generation whose length is a
-        // workgroup's own march, i.e. beams per thread: wider workgroups shorten it (measured, c2 world:
-        // 2048 arenas 14.4 / 16.4 / 13.7 M env-steps/s for 256 / 512 / 1024 threads; 1024 arenas
-        // 8.8 / 11.3 / 11.6; 512 arenas 5.2 / 6.7 / 7.3; 4096 arenas 19.5 / 17.4 / -).
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0, v2 = 0;
-            if (hipGetDevice(&dev) == hipSuccess &&
-                hipDeviceGetAttribute(&v2, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v2 > 0)
-                n_cu = v2;
-            else
-                n_cu = 256;
-        }
-        const int B = c->n_beams;
-        const long per_cu_x2 = 2L * c->n_envs / n_cu;            // arenas per CU, doubled
-        // rays = 11: the predicated march (one wave-level branch per probe round instead of a divergent
-        // if-ladder): +3-4 % on every workload in same-box A/B runs
-        rays = 11;
-        if (B <= 64) { block = 64; rays = 1; }
-        else if (per_cu_x2 >= 24 || B <= 256) block = 256;
-        else if (per_cu_x2 >= 12 || B <= 512) block = 512;
-        else block = 1024;
+    int rc;
+    switch (pick_step_block(c)) {
+        case 64:   rc = launch_step<64>(c, st, io, reset_only, mask, s); break;
+        case 256:  rc = launch_step<256>(c, st, io, reset_only, mask, s); break;
+        case 512:  rc = launch_step<512>(c, st, io, reset_only, mask, s); break;
+        case 1024: rc = launch_step<1024>(c, st, io, reset_only, mask, s); break;
+        default:   return NAVSIM_E_UNSUPPORTED;
     }
-#define NAVSIM_VARIANT(BK, RR) if (block == BK && rays == RR) { launch_step<BK, RR, kModeFused>(c, st, io, reset_only, mask, nullptr, nullptr, nullptr, s); return launch_status(); }
-    NAVSIM_VARIANT(64, 1)
-    NAVSIM_VARIANT(256, 0)
-    NAVSIM_VARIANT(256, 1)
-    NAVSIM_VARIANT(320, 1)
-    NAVSIM_VARIANT(384, 1)
-    NAVSIM_VARIANT(512, 1)
-    NAVSIM_VARIANT(192, 1)
-    NAVSIM_VARIANT(256, 11)
-    NAVSIM_VARIANT(256, 2)
-    NAVSIM_VARIANT(256, 5)
-    NAVSIM_VARIANT(512, 0)
-    NAVSIM_VARIANT(768, 1)
-    NAVSIM_VARIANT(1024, 1)
-    NAVSIM_VARIANT(512, 11)
-    NAVSIM_VARIANT(1024, 11)
-#undef NAVSIM_VARIANT
-    return NAVSIM_E_UNSUPPORTED;
+    return rc != NAVSIM_OK ? rc : launch_status();
 }
 
 }  // namespace
@@ -197,13 +166,6 @@ int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_s
 // ============================================================================================
 // C ABI
 // ============================================================================================
-// kernels that want more than 64 KB of dynamic LDS must say so once
-static int allow_lds(const void* kernel, size_t lds) {
-    if (lds <= 64 * 1024) return NAVSIM_OK;
-    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess
-               ? NAVSIM_OK : NAVSIM_E_UNSUPPORTED;
-}
-
 extern "C" {
 
 int navsim_abi_version(void) { return NAVSIM_ABI_VERSION; }
@@ -276,6 +238,9 @@ int navsim_default_config(navsim_config* c) {
     c->v_pref_hi = 0.6;
     c->has_legs_ratio = 0.5;                // __init__.py:15
     c->regen_indoor_ratio = 0.0;
+    c->march_rule = NAVSIM_MARCH_F64;
+    c->step_block = 0;
+    c->ped_split = 0;
     c->seed = 1234;
     return NAVSIM_OK;
 }
@@ -293,7 +258,6 @@ size_t navsim_field_bytes(int32_t n_maps, int32_t H, int32_t W, int32_t format) 
     if (n_maps <= 0 || H <= 0 || W <= 0) return 0;
     if (format == NAVSIM_FIELD_F32) return (size_t)n_maps * H * W * sizeof(float);
     if (format == NAVSIM_FIELD_U16T) return (size_t)n_maps * ((H + 7) / 8) * ((W + 7) / 8) * 64 * sizeof(uint16_t);
-    if (format == NAVSIM_FIELD_F32S) return (size_t)n_maps * ((H + 3) / 4) * ((W + 7) / 8) * 32 * sizeof(float);
     return 0;
 }
 
@@ -302,8 +266,7 @@ int navsim_build_field(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W,
                        void* stream) {
     (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     if (!occ || !field || !workspace || n_maps < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
-    if (format != NAVSIM_FIELD_F32 && format != NAVSIM_FIELD_U16T && format != NAVSIM_FIELD_F32S) return NAVSIM_E_UNSUPPORTED;
-    if (format == NAVSIM_FIELD_F32S && !overflow) return NAVSIM_E_ARG;
+    if (format != NAVSIM_FIELD_F32 && format != NAVSIM_FIELD_U16T) return NAVSIM_E_UNSUPPORTED;
     if (H >= kDtInf || W >= kDtInf || (size_t)W * 4 > 64 * 1024) return NAVSIM_E_UNSUPPORTED;
     size_t per_map = (size_t)H * W * sizeof(uint16_t);
     size_t chunk = workspace_bytes / per_map;
@@ -312,7 +275,7 @@ int navsim_build_field(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W,
     hipStream_t s = (hipStream_t)stream;
     const size_t field_per_map = navsim_field_bytes(1, H, W, format);
     if (format != NAVSIM_FIELD_F32)        // padding cells of edge tiles are never read; keep them defined
-        (void)hipMemsetAsync(field, format == NAVSIM_FIELD_U16T ? 0xFF : 0, field_per_map * (size_t)n_maps, s);
+        (void)hipMemsetAsync(field, 0xFF, field_per_map * (size_t)n_maps, s);
     for (int32_t m0 = 0; m0 < n_maps; m0 += (int32_t)chunk) {
         int32_t m = (n_maps - m0 < (int32_t)chunk) ? n_maps - m0 : (int32_t)chunk;
         dt_columns_kernel<<<dim3((W + 63) / 64, m), 64 * kColSeg, 0, s>>>(occ + (size_t)m0 * H * W,
@@ -321,44 +284,8 @@ int navsim_build_field(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W,
         float* o = overflow ? overflow + (size_t)m0 * H * W : nullptr;
         if (format == NAVSIM_FIELD_F32)
             dt_rows_kernel<0><<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace, f, nullptr, nullptr, H, W, nullptr);
-        else if (format == NAVSIM_FIELD_U16T)
-            dt_rows_kernel<1><<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace, f, o, n_saturated, H, W, nullptr);
         else
-            dt_rows_kernel<2><<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace, f, o, n_saturated, H, W, nullptr);
-    }
-    return launch_status();
-}
-
-size_t navsim_tile_table_bytes(int32_t n_maps, int32_t H, int32_t W) {
-    if (n_maps <= 0 || H <= 0 || W <= 0) return 0;
-    size_t n_tiles = (size_t)((H + 7) / 8) * ((W + 7) / 8);
-    return (size_t)n_maps * ((n_tiles + 3) & ~(size_t)3) * sizeof(uint32_t);     // 16-byte granular per arena
-}
-
-size_t navsim_build_tiles_workspace_bytes(int32_t n_maps, int32_t H, int32_t W) {
-    if (n_maps <= 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)n_maps * H * W * 10;               // nearest row int16 + d2 int32 + (ox, oy) int16 x 2
-}
-
-int navsim_build_tiles(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, uint32_t* tiles,
-                       void* workspace, size_t workspace_bytes, void* stream) {
-    (void)hipGetLastError();
-    if (!occ || !tiles || !workspace || n_maps < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
-    if (H > 16383 || W > 16383 || (size_t)W * 4 > 64 * 1024) return NAVSIM_E_UNSUPPORTED;
-    const size_t cells = (size_t)H * W;
-    size_t chunk = workspace_bytes / (cells * 10);
-    if (chunk == 0) return NAVSIM_E_ARG;
-    if (chunk > 65535) chunk = 65535;
-    hipStream_t s = (hipStream_t)stream;
-    const int n_tiles = ((H + 7) / 8) * ((W + 7) / 8);
-    for (int32_t m0 = 0; m0 < n_maps; m0 += (int32_t)chunk) {
-        int32_t m = (n_maps - m0 < (int32_t)chunk) ? n_maps - m0 : (int32_t)chunk;
-        int32_t* d2 = (int32_t*)workspace;
-        int16_t* oxy = (int16_t*)(d2 + (size_t)m * cells);
-        int16_t* nr = oxy + 2 * (size_t)m * cells;
-        ft_columns_kernel<<<dim3((W + 255) / 256, m), 256, 0, s>>>(occ + (size_t)m0 * cells, nr, H, W);
-        ft_rows_kernel<<<dim3(H, m), 256, (size_t)W * 4, s>>>(nr, d2, oxy, H, W);
-        tile_table_kernel<<<dim3(n_tiles, m), 64, 0, s>>>(d2, oxy, tiles + (size_t)m0 * ((n_tiles + 3) & ~3), H, W);
+            dt_rows_kernel<1><<<dim3(H, m), 256, (size_t)W * 4, s>>>((const uint16_t*)workspace, f, o, n_saturated, H, W, nullptr);
     }
     return launch_status();
 }
@@ -370,14 +297,15 @@ int navsim_build_dt(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, fl
 }
 
 int navsim_cast_static(const float* field, int32_t E, int32_t H, int32_t W, const float* q,
-                       int32_t n_per_env, float max_range, float* out, void* stream) {
+                       int32_t n_per_env, float max_range, int32_t march_rule, float* out, void* stream) {
     (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     if (!field || E < 0 || n_per_env < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
+    if (march_rule != NAVSIM_MARCH_F64 && march_rule != NAVSIM_MARCH_F32) return NAVSIM_E_ARG;
     long long total = (long long)E * n_per_env;
     if (total == 0) return NAVSIM_OK;
     if (!q || !out) return NAVSIM_E_ARG;
     cast_static_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        field, H, W, q, n_per_env, total, max_range, out);
+        field, H, W, q, n_per_env, total, max_range, march_rule, out);
     return launch_status();
 }
 
@@ -444,9 +372,13 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
     if (!c || !st || !io) return NAVSIM_E_ARG;
     if (c->n_envs < 0 || c->n_beams < 1 || c->n_scan_stack < 1 || c->map_h < 1 || c->map_w < 1) return NAVSIM_E_ARG;
     if (c->max_peds > NAVSIM_MAX_PEDS) return NAVSIM_E_UNSUPPORTED;
-    if (c->field_format != NAVSIM_FIELD_F32 && c->field_format != NAVSIM_FIELD_U16T &&
-        c->field_format != NAVSIM_FIELD_F32S) return NAVSIM_E_UNSUPPORTED;
-    if (c->field_format == NAVSIM_FIELD_F32S && !st->field_overflow) return NAVSIM_E_ARG;
+    if (c->field_format != NAVSIM_FIELD_F32 && c->field_format != NAVSIM_FIELD_U16T) return NAVSIM_E_UNSUPPORTED;
+    if (c->march_rule != NAVSIM_MARCH_F64 && c->march_rule != NAVSIM_MARCH_F32) return NAVSIM_E_ARG;
+    if (c->step_block != 0 && c->step_block != 64 && c->step_block != 256 && c->step_block != 512 &&
+        c->step_block != 1024) return NAVSIM_E_ARG;
+    if (c->ped_split < 0 || c->ped_split > 2) return NAVSIM_E_ARG;
+    if (c->ped_model != NAVSIM_PED_NONE && c->max_peds < 1) return NAVSIM_E_ARG;
+    if (step_lds_bytes(c) > kLdsPerCu) return NAVSIM_E_UNSUPPORTED;       // beams x pedestrians beyond one CU's LDS
     if (!st->field || !st->scan_threshold || !st->scan_discomfort || !st->robot_pose || !st->robot_goal ||
         !st->prev_action || !st->prev_pose || !st->n_hist || !st->episode || !st->steps || !io->obs)
         return NAVSIM_E_ARG;
@@ -470,24 +402,15 @@ int navsim_ped_scans(const navsim_config* c, const navsim_state* st, float* out,
     if (!c || !st || !out || c->ped_model == NAVSIM_PED_NONE || !st->n_peds || !st->ped_pose || !st->robot_pose ||
         !st->field || c->ped_n_beams < 1 || c->max_peds < 1) return NAVSIM_E_ARG;
     if (c->max_peds > NAVSIM_MAX_PEDS || c->ped_n_beams > 4096) return NAVSIM_E_UNSUPPORTED;
-    if (c->field_format == NAVSIM_FIELD_F32S && !st->field_overflow) return NAVSIM_E_ARG;
     if (c->n_envs == 0) return NAVSIM_OK;
     dim3 grid(c->max_peds, c->n_envs);
     size_t lds = (size_t)c->ped_n_beams * (sizeof(float2) + sizeof(float));
     hipStream_t s = (hipStream_t)stream;
-    const char* bv = getenv("NAVSIM_PED_SCAN_BLOCK");
-    const int blk = bv ? atoi(bv) : 128;        // measured 64 / 128 / 256 / 512 threads: 1.11 / 0.78 / 0.93 / 1.50 ms (c3)
-#define NAVSIM_PSCAN(BK) \
-    if (blk == BK) { \
-        if (c->field_format == NAVSIM_FIELD_U16T)      ped_scan_kernel<FieldU16T, BK><<<grid, BK, lds, s>>>(*c, *st, out); \
-        else if (c->field_format == NAVSIM_FIELD_F32S) ped_scan_kernel<FieldF32S, BK><<<grid, BK, lds, s>>>(*c, *st, out); \
-        else if (c->field_format == NAVSIM_FIELD_F32)  ped_scan_kernel<FieldF32, BK><<<grid, BK, lds, s>>>(*c, *st, out); \
-        else return NAVSIM_E_UNSUPPORTED; \
-        return launch_status(); \
-    }
-    NAVSIM_PSCAN(64) NAVSIM_PSCAN(128) NAVSIM_PSCAN(256) NAVSIM_PSCAN(512)
-#undef NAVSIM_PSCAN
-    return NAVSIM_E_UNSUPPORTED;
+    // 128 threads per pedestrian (measured 64 / 128 / 256 / 512: 1.11 / 0.78 / 0.93 / 1.50 ms on c3)
+    if (c->field_format == NAVSIM_FIELD_U16T)     ped_scan_kernel<FieldU16T, 128><<<grid, 128, lds, s>>>(*c, *st, out);
+    else if (c->field_format == NAVSIM_FIELD_F32) ped_scan_kernel<FieldF32, 128><<<grid, 128, lds, s>>>(*c, *st, out);
+    else return NAVSIM_E_UNSUPPORTED;
+    return launch_status();
 }
 
 int navsim_costmap(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, uint8_t* cost, void* stream) {
@@ -500,17 +423,10 @@ int navsim_costmap(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, uin
     return launch_status();
 }
 
-size_t navsim_plan_workspace_bytes(int32_t n_queries, int32_t Hc, int32_t Wc) {
-    (void)n_queries; (void)Hc; (void)Wc;
-    return 0;                                              // the search lives in LDS; kept for ABI stability
-}
-
 int navsim_plan(const uint8_t* cost, const int32_t* map_index, int32_t n, int32_t Hc, int32_t Wc, double res_c,
                 double ox, double oy, const double* start, const double* goal, double interval, int32_t max_wp,
-                double* wp, int32_t* n_wp, int32_t* path_cells, double* path_len, void* workspace,
-                size_t workspace_bytes, void* stream) {
+                double* wp, int32_t* n_wp, int32_t* path_cells, double* path_len, void* stream) {
     (void)hipGetLastError();
-    (void)workspace; (void)workspace_bytes;
     if (!cost || !start || !goal || !wp || !n_wp || n < 0 || Hc <= 0 || Wc <= 0 || max_wp < 1) return NAVSIM_E_ARG;
     if (!plan_fits(Hc, Wc)) return NAVSIM_E_UNSUPPORTED;                // LDS-resident search
     if (n == 0) return NAVSIM_OK;
@@ -546,9 +462,13 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
                  size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
     if (!c || !st || !io || !io->done || !io->obs || !workspace) return NAVSIM_E_ARG;
-    if (c->map_h != c->map_w || c->n_spawn < 1 || c->regen_cap < 1 || c->obstacle_number > 64 || st->tile_table || st->field_overflow ||
+    if (c->map_h != c->map_w || c->n_spawn < 1 || c->regen_cap < 1 || c->obstacle_number > 64 || st->field_overflow ||
         (c->field_format != NAVSIM_FIELD_F32 && c->field_format != NAVSIM_FIELD_U16T) || c->shared_field)
         return NAVSIM_E_UNSUPPORTED;
+    // A packed field regenerated here has no overflow plane, so no cell may reach d2 >= 65535.  Every map this
+    // function draws has a 5-cell border wall: the farthest a cell can be from it is map_h / 2 - 5 cells, which
+    // stays below 255.99 up to 520 cells per side.  Larger packed maps must use NAVSIM_FIELD_F32.
+    if (c->field_format == NAVSIM_FIELD_U16T && c->map_h > kRegenMaxPackedSide) return NAVSIM_E_UNSUPPORTED;
     if (workspace_bytes < navsim_regen_workspace_bytes(c) || !st->spawn_pose || !st->spawn_goal) return NAVSIM_E_ARG;
     if (c->regen_plan && (c->n_spawn > 256 || c->map_h < 5 || !plan_fits(c->map_h / 5, c->map_w / 5) ||
                           allow_lds((const void*)regen_plan_kernel, plan_lds(c->map_h / 5, c->map_w / 5)) != NAVSIM_OK))
@@ -726,8 +646,6 @@ int navsim_launch_order(const uint32_t* cost, int32_t* order, int32_t n, void* s
     return launch_status();
 }
 
-size_t navsim_step_workspace_bytes(const navsim_config* c) { return c ? workspace_bytes(c) : 0; }
-
 int navsim_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, void* stream) {
     (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     int rc = check_step_args(c, st, io, 0);
@@ -753,6 +671,16 @@ int navsim_debug_math(int32_t fn, const double* x, const double* x2, double* out
     if (!x || !out || n < 0) return NAVSIM_E_ARG;
     if (n == 0) return NAVSIM_OK;
     math_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(fn, x, x2, out, n);
+    return launch_status();
+}
+
+// test hook: batch_xy_to_ij (env.py:1228-1253) as the scan uses it.  as_f32 = 1: the inputs are first rounded to
+// float32 and divided in float32 (the lidar origin, env.py:386, 419); 0: float64 inputs (env.py:348-349).
+int navsim_debug_xy_to_ij(const navsim_config* c, const double* xy, int32_t as_f32, int32_t* ij, int32_t n, void* stream) {
+    (void)hipGetLastError();
+    if (!c || !xy || !ij || n < 0) return NAVSIM_E_ARG;
+    if (n == 0) return NAVSIM_OK;
+    xy_to_ij_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(*c, xy, as_f32, ij, n);
     return launch_status();
 }
 

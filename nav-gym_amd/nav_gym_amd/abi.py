@@ -6,7 +6,7 @@ Field order and types must match include/navsim.h exactly; tests/test_abi.py com
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK = 0
 E_ARG = -1
@@ -24,8 +24,10 @@ OBS_TAIL = 7
 
 FIELD_F32 = 0
 FIELD_U16T = 1
-FIELD_F32S = 2
 FIELD_TILE = 8
+
+MARCH_F64 = 0          # t += max(fl32(fl64(d) * 0.999), 1)
+MARCH_F32 = 1          # t += max(d * 0.999f, 1)
 
 
 class NavsimConfig(C.Structure):
@@ -92,6 +94,10 @@ class NavsimConfig(C.Structure):
         ("v_pref_hi", C.c_double),
         ("has_legs_ratio", C.c_double),
         ("regen_indoor_ratio", C.c_double),
+        ("march_rule", C.c_int32),
+        ("step_block", C.c_int32),
+        ("ped_split", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
     def copy(self):
@@ -105,11 +111,11 @@ _P = C.c_void_p
 
 class NavsimState(C.Structure):
     _fields_ = [(name, _P) for name in (
-        "field", "field_overflow", "tile_table", "beam_table", "scan_threshold", "scan_discomfort", "scan_noise_std",
+        "field", "field_overflow", "beam_table", "scan_threshold", "scan_discomfort", "scan_noise_std",
         "robot_pose", "robot_goal", "prev_action", "prev_pose", "n_hist", "episode", "steps",
         "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist", "ped_v_pref", "ped_has_legs",
         "ped_waypoints", "ped_n_waypoints", "ped_cmd",
-        "spawn_pose", "spawn_goal", "costmap", "arena_cost", "launch_order", "workspace",
+        "spawn_pose", "spawn_goal", "costmap", "arena_cost", "launch_order",
     )]
 
 
@@ -148,7 +154,6 @@ class NavsimStepIO(C.Structure):
 STATE_LAYOUT = {
     "field": ("float32", ("E", "H", "W")),          # FIELD_F32; a uint8 blob for packed formats
     "field_overflow": ("float32", ("E", "H", "W")),
-    "tile_table": ("int32", ("E", "T")),
     "beam_table": ("float64", ("B", 2)),
     "scan_threshold": ("float32", ("B",)),
     "scan_discomfort": ("float32", ("B",)),
@@ -197,7 +202,6 @@ def resolve_shape(shape, cfg):
         "E": cfg.n_envs, "N": cfg.max_peds, "B": cfg.n_beams, "S": cfg.n_scan_stack,
         "K": max(cfg.n_spawn, 1), "P": MAX_WAYPOINTS, "H": cfg.map_h, "W": cfg.map_w,
         "D": cfg.n_scan_stack * cfg.n_beams + OBS_TAIL, "Hc": cfg.map_h // 5, "Wc": cfg.map_w // 5,
-        "T": (((cfg.map_h + 7) // 8) * ((cfg.map_w + 7) // 8) + 3) // 4 * 4,
     }
     return tuple(sym[s] if isinstance(s, str) else s for s in shape)
 
@@ -224,11 +228,8 @@ def declare(lib, suffix=""):
         sig("navsim_build_dt", [_P, i32, i32, i32, _P, _P, C.c_size_t, _P])
     if not suffix:
         sig("navsim_field_bytes", [i32, i32, i32, i32], C.c_size_t)
-        sig("navsim_tile_table_bytes", [i32, i32, i32], C.c_size_t)
-        sig("navsim_build_tiles_workspace_bytes", [i32, i32, i32], C.c_size_t)
-        sig("navsim_build_tiles", [_P, i32, i32, i32, _P, _P, C.c_size_t, _P])
         sig("navsim_build_field", [_P, i32, i32, i32, i32, _P, _P, _P, _P, C.c_size_t, _P])
-    sig("navsim_cast_static", [_P, i32, i32, i32, _P, i32, f32, _P] + stream)
+    sig("navsim_cast_static", [_P, i32, i32, i32, _P, i32, f32, i32, _P] + stream)
     sig("navsim_render_polys", [_P, _P, i32, i32, _P, _P, i32, _P] + stream)
     sig("navsim_render_legs", [_P, _P, i32, i32, _P, _P, i32, _P] + stream)
     sig("navsim_integrate", [_P, _P, _P, i32, f64, f64] + stream)
@@ -236,7 +237,7 @@ def declare(lib, suffix=""):
     sig("navsim_scan_threshold", [cfgp, _P, i32, _P] + stream)
     if not suffix:
         sig("navsim_beam_table", [cfgp, _P, _P])
-        sig("navsim_step_workspace_bytes", [cfgp], C.c_size_t)
+        sig("navsim_debug_xy_to_ij", [cfgp, _P, i32, _P, i32, _P])
     sig("navsim_ped_scans", [cfgp, stp, _P] + stream)
     if suffix:
         sig("navsim_regen", [cfgp, stp, iop])
@@ -249,8 +250,7 @@ def declare(lib, suffix=""):
         sig("navsim_replan_workspace_bytes", [cfgp, i32], C.c_size_t)
         sig("navsim_replan", [cfgp, stp, i32, _P, C.c_size_t, _P])
         sig("navsim_costmap", [_P, i32, i32, i32, _P, _P])
-        sig("navsim_plan_workspace_bytes", [i32, i32, i32], C.c_size_t)
-        sig("navsim_plan", [_P, _P, i32, i32, i32, f64, f64, f64, _P, _P, f64, i32, _P, _P, _P, _P, _P, C.c_size_t, _P])
+        sig("navsim_plan", [_P, _P, i32, i32, i32, f64, f64, f64, _P, _P, f64, i32, _P, _P, _P, _P, _P])
         sig("navsim_regen_workspace_bytes", [cfgp], C.c_size_t)
         sig("navsim_regen", [cfgp, stp, iop, _P, C.c_size_t, _P])
     sig("navsim_crowd_check", [C.POINTER(NavsimCrowdParams), i32, i32, i32, _P, _P, _P, _P, _P, _P, _P, _P, _P] + stream)
@@ -263,11 +263,10 @@ def declare(lib, suffix=""):
 EXPORTS = (
     "navsim_abi_version", "navsim_error_string", "navsim_last_hip_error", "navsim_default_config",
     "navsim_build_dt_workspace_bytes", "navsim_build_dt", "navsim_field_bytes", "navsim_build_field",
-    "navsim_tile_table_bytes", "navsim_build_tiles_workspace_bytes", "navsim_build_tiles",
     "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
-    "navsim_scan_threshold", "navsim_beam_table", "navsim_step_workspace_bytes", "navsim_ped_scans", "navsim_regen_workspace_bytes", "navsim_regen",
-    "navsim_costmap", "navsim_plan_workspace_bytes", "navsim_plan", "navsim_launch_order", "navsim_replan_workspace_bytes", "navsim_replan", "navsim_ped_policy_workspace_bytes", "navsim_ped_policy",
+    "navsim_scan_threshold", "navsim_beam_table", "navsim_ped_scans", "navsim_regen_workspace_bytes", "navsim_regen",
+    "navsim_costmap", "navsim_plan", "navsim_launch_order", "navsim_replan_workspace_bytes", "navsim_replan", "navsim_ped_policy_workspace_bytes", "navsim_ped_policy",
     "navsim_crowd_check", "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
-    "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math",
+    "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math", "navsim_debug_xy_to_ij",
 )

@@ -9,7 +9,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("NAVSIM_LIB", os.path.join(_HERE, "libnavsim_hip.so"))   # override: diagnostic builds
+LIB_PATH = os.environ.get("NAVSIM_LIB", os.path.join(_HERE, "libnavsim_hip.so"))   # override: diagnostic / A-B builds
 _LIB = None
 
 

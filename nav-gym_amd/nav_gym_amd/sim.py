@@ -71,28 +71,13 @@ def build_field(occ, fmt=abi.FIELD_U16T, keep_overflow=None):
     return field, overflow, int(nsat.item())          # reset path: a sync is fine here
 
 
-def build_tiles(occ):
-    """occ: uint8 CUDA tensor [E,H,W] -> int32 [E,T] analytic tile records (navsim_build_tiles)."""
-    torch = require_gpu()
-    L = load()
-    occ = occ.contiguous()
-    E, H, W = occ.shape
-    per = L.navsim_tile_table_bytes(1, H, W) // 4
-    tiles = torch.zeros((E, per), dtype=torch.int32, device=occ.device)
-    per_ws = L.navsim_build_tiles_workspace_bytes(1, H, W)
-    chunk = max(1, min(E, (512 << 20) // max(per_ws, 1)))
-    ws = torch.empty(per_ws * chunk, dtype=torch.uint8, device=occ.device)
-    check(L.navsim_build_tiles(_ptr(occ), E, H, W, _ptr(tiles), _ptr(ws), ws.numel(), _stream()), "navsim_build_tiles")
-    return tiles
-
-
-def cast_static(field, queries, max_range):
+def cast_static(field, queries, max_range, march_rule=abi.MARCH_F64):
     torch = require_gpu()
     E, H, W = field.shape
     q = queries.contiguous()
     out = torch.empty(q.shape[:2], dtype=torch.float32, device=field.device)
-    check(load().navsim_cast_static(_ptr(field), E, H, W, _ptr(q), q.shape[1], float(max_range), _ptr(out),
-                                    _stream()), "navsim_cast_static")
+    check(load().navsim_cast_static(_ptr(field), E, H, W, _ptr(q), q.shape[1], float(max_range), int(march_rule),
+                                    _ptr(out), _stream()), "navsim_cast_static")
     return out
 
 
@@ -171,10 +156,9 @@ def plan(cost, start, goal, interval, max_wp=8, res_c=0.25, origin=(0.0, 0.0), m
     n_wp = torch.zeros(n, dtype=torch.int32, device=dev)
     cells = torch.zeros(n, dtype=torch.int32, device=dev)
     plen = torch.zeros(n, dtype=torch.float64, device=dev)
-    ws = torch.empty(max(L.navsim_plan_workspace_bytes(n, Hc, Wc), 16), dtype=torch.uint8, device=dev)
     check(L.navsim_plan(_ptr(cost), _ptr(mi), n, Hc, Wc, float(res_c), float(origin[0]), float(origin[1]), _ptr(start),
-                        _ptr(goal), float(interval), max_wp, _ptr(wp), _ptr(n_wp), _ptr(cells), _ptr(plen), _ptr(ws),
-                        ws.numel(), _stream()), "navsim_plan")
+                        _ptr(goal), float(interval), max_wp, _ptr(wp), _ptr(n_wp), _ptr(cells), _ptr(plen), _stream()),
+          "navsim_plan")
     return wp, n_wp, cells, plen
 
 
@@ -199,6 +183,16 @@ def crowd_check(params, free_map, robot, agents, global_time, n_agents=None):
     return reward, done, info, md
 
 
+def debug_xy_to_ij(cfg, xy, as_f32):
+    """Device batch_xy_to_ij (env.py:1228-1253): xy float64 CUDA [n,2] -> int32 [n,2] (i, j)."""
+    torch = require_gpu()
+    xy = xy.to(torch.float64).contiguous()
+    out = torch.empty((xy.shape[0], 2), dtype=torch.int32, device=xy.device)
+    check(load().navsim_debug_xy_to_ij(C.byref(cfg), _ptr(xy), int(bool(as_f32)), _ptr(out), xy.shape[0], _stream()),
+          "navsim_debug_xy_to_ij")
+    return out
+
+
 def debug_math(fn, x, x2=None):
     torch = require_gpu()
     out = torch.empty_like(x)
@@ -210,7 +204,9 @@ class NavSim(object):
     """E arenas resident on one GPU.  `arrays` maps navsim_state field names to numpy arrays or
     torch tensors (host or device); missing optional fields stay NULL."""
 
-    def __init__(self, cfg, arrays, device="cuda:0"):
+    def __init__(self, cfg, arrays, device="cuda:0", launch_order=None):
+        """launch_order: None = longest-first launch order when a launch runs several generations of
+        workgroups, True / False = force it on / off (a scheduling hint: results never depend on it)."""
         torch = require_gpu()
         self.lib = load()
         self.cfg = cfg.copy()
@@ -246,25 +242,19 @@ class NavSim(object):
             check(self.lib.navsim_beam_table(C.byref(self.cfg), _ptr(tab), _stream()), "navsim_beam_table")
             self.t["beam_table"] = tab
             self.st.beam_table = tab.data_ptr()
-        import os
-        if os.environ.get("NAVSIM_STEP_MODE", "fused") == "pool":   # the pooled schedule needs scratch
-            nbytes = self.lib.navsim_step_workspace_bytes(C.byref(self.cfg))
-            self.t["workspace"] = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=self.device)
-            self.st.workspace = self.t["workspace"].data_ptr()
         # longest-first launch order (navsim_launch_order): the step measures every arena's workgroup, every
-        # few steps the arenas are re-sorted so that the slow ones start first (NAVSIM_LPT=0 disables)
-        self.lpt_period = int(os.environ.get("NAVSIM_LPT", "4"))
+        # few steps the arenas are re-sorted so that the slow ones start first (lpt_period = 0 disables)
+        self.lpt_period = 4
         self._steps_launched = 0
         # only when a launch runs several generations of workgroups: with one generation everything starts
         # at once and the order is irrelevant (threads per arena as dispatch_step picks them)
         n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count or 256
         per_cu_x2 = 2 * self.cfg.n_envs // n_cu
-        block = 64 if self.cfg.n_beams <= 64 else (256 if per_cu_x2 >= 24 or self.cfg.n_beams <= 256 else
-                                                    (512 if per_cu_x2 >= 12 or self.cfg.n_beams <= 512 else 1024))
+        block = self.cfg.step_block or (
+            64 if self.cfg.n_beams <= 64 else (256 if per_cu_x2 >= 24 or self.cfg.n_beams <= 256 else
+                                               (512 if per_cu_x2 >= 12 or self.cfg.n_beams <= 512 else 1024)))
         generations = self.cfg.n_envs * (block // 64) / float(32 * n_cu)
-        if os.environ.get("NAVSIM_LPT_FORCE") == "1":
-            generations = 2.0
-        if self.lpt_period > 0 and generations > 1.25 and "arena_cost" not in self.t:
+        if (launch_order is True or (launch_order is None and generations > 1.25)) and "arena_cost" not in self.t:
             self.t["arena_cost"] = torch.zeros(self.cfg.n_envs, dtype=torch.int32, device=self.device)
             self.t["launch_order"] = torch.arange(self.cfg.n_envs, dtype=torch.int32, device=self.device)
             self.st.arena_cost = self.t["arena_cost"].data_ptr()

@@ -1,9 +1,9 @@
 """Reset-path world generation (host + torch plumbing; NOT the hot path).
 
 Restates what NavGymEnv.reset() needs before the first step (env.py:730-831) for E arenas at once:
-occupancy maps, the distance field (navsim_build_dt on the GPU), start / goal tables and
-pedestrians.  A* path planning (pyastar2d, env.py:342-383) is out of scope for this round
-(SURVEY.md 8f #1): goals are accepted on straight-line distance only.
+occupancy maps, the distance field (navsim_build_field on the GPU), start / goal tables and
+pedestrians; with plan_paths the planning costmap (env.py:312-332) and planned first paths
+(navsim_plan, env.py:342-383).
 
 Everything is keyed by the GLOBAL env index (seed + env_index_base + e), so a sharded run over
 G GPUs builds bit-identical arenas to a single-GPU run.
@@ -143,14 +143,8 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
         else:
             field = f32                                   # float32 plane: spawn sampling below
             a["field"] = packed
-            if nsat > 0:                                  # U16T: some cell >= 256 cells from any obstacle;
-                a["field_overflow"] = f32                 # F32S: always (exact distances live here)
-            # analytic tile records (LDS-resident accelerator): exact, but measured no faster than the
-            # plain march on c2 (profiles/README.md), so opt-in
-            import os
-            if (os.environ.get("NAVSIM_TILES") == "1" and cfg.field_format == abi.FIELD_U16T
-                    and sim.load().navsim_tile_table_bytes(1, H0, W0) <= 40960):
-                a["tile_table"] = sim.build_tiles(occ_t)
+            if nsat > 0:                                  # some cell >= 256 cells from every obstacle
+                a["field_overflow"] = f32
         if plan_paths:
             a["costmap"] = sim.costmap(occ_t)
         del occ_t

@@ -164,14 +164,19 @@ int navsim_build_dt_cpu(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W
  *         if px or py outside the grid: return max_range
  *         d = distance_field[px][py]
  *         if d <= 0: return sqrtf((px-x)^2 + (py-y)^2)
- *         t += max(d * 0.999, 1.0)                                (0.999 is a double literal)
+ *         t += max(d * step_coeff, 1.0)
  *     return max_range
+ * The rounding of `d * step_coeff` is the one thing recall cannot settle: with a double literal 0.999 the
+ * product is fl32(fl64(d) * 0.999) (NAVSIM_MARCH_F64, the default here); if upstream keeps `step_coeff` as a
+ * float member it is the float32 product d * 0.999f (NAVSIM_MARCH_F32).  Both are implemented, selected by
+ * navsim_config.march_rule (`march_rule` argument of the mirror primitive); tests/test_oracle_crosscheck.py
+ * counts how many rays change their hit cell between them and DESIGN.md records the number.
  * Assumptions stated: no ROS world<->grid conversion (numpy-constructed map), grid[x][y] is
  * occupancy[y][x]; cosf/sinf are replaced by the specified nvr_cos/nvr_sin evaluated in double on
  * the float32 heading and rounded once to float32.
  * ======================================================================================= */
 static float trace_ray(const float* f, int H, int W, float x0, float y0, float dx, float dy,
-                       float max_range) {
+                       float max_range, int march_rule) {
     float t = 0.0f;
     while (t < max_range) {
         float fx = x0 + dx * t;
@@ -186,7 +191,7 @@ static float trace_ray(const float* f, int H, int W, float x0, float y0, float d
             float yd = (float)py - y0;
             return sqrtf(xd * xd + yd * yd);
         }
-        float step = (float)((double)d * 0.999);
+        float step = (march_rule == NAVSIM_MARCH_F32) ? d * 0.999f : (float)((double)d * 0.999);
         t += (step > 1.0f) ? step : 1.0f;
     }
     return max_range;
@@ -200,15 +205,16 @@ static inline void beam_dir(float heading, float* dx, float* dy) {
 }
 
 int navsim_cast_static_cpu(const float* field, int32_t E, int32_t H, int32_t W,
-                           const float* q, int32_t n, float max_range, float* out) {
+                           const float* q, int32_t n, float max_range, int32_t march_rule, float* out) {
     if (!field || !q || !out || E < 0 || n < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
+    if (march_rule != NAVSIM_MARCH_F64 && march_rule != NAVSIM_MARCH_F32) return NAVSIM_E_ARG;
     for (int e = 0; e < E; ++e) {
         const float* f = field + (size_t)e * H * W;
         for (int k = 0; k < n; ++k) {
             const float* qq = q + ((size_t)e * n + k) * 3;
             float dx, dy;
             beam_dir(qq[2], &dx, &dy);
-            out[(size_t)e * n + k] = trace_ray(f, H, W, qq[0], qq[1], dx, dy, max_range);
+            out[(size_t)e * n + k] = trace_ray(f, H, W, qq[0], qq[1], dx, dy, max_range, march_rule);
         }
     }
     return NAVSIM_OK;
@@ -544,7 +550,7 @@ static void robot_scan(const navsim_config* c, const navsim_state* st, int e, in
         float heading = (float)ang;                                            /* env.py:424 */
         float dx, dy;
         beam_dir(heading, &dx, &dy);
-        float r = trace_ray(f, H, W, (float)i0, (float)j0, dx, dy, max_range); /* env.py:425 */
+        float r = trace_ray(f, H, W, (float)i0, (float)j0, dx, dy, max_range, c->march_rule); /* env.py:425 */
         r = r * res;                                                           /* env.py:426 */
         for (int q = 0; q < nseg; ++q)
             seg_merge(&r, lx, ly, dx, dy, segs[q].px, segs[q].py, segs[q].qx, segs[q].qy);
@@ -591,7 +597,7 @@ int navsim_ped_scans_cpu(const navsim_config* c, const navsim_state* st, float* 
                 float heading = (float)(lin + (double)lth);
                 float dx, dy;
                 beam_dir(heading, &dx, &dy);
-                float r = trace_ray(f, H, W, (float)i0, (float)j0, dx, dy, max_range) * res;
+                float r = trace_ray(f, H, W, (float)i0, (float)j0, dx, dy, max_range, c->march_rule) * res;
                 for (int a = 0; a <= n; ++a) {
                     if (a == i) continue;
                     for (int v = 0; v < 4; ++v) {

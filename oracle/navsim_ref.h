@@ -34,7 +34,8 @@ int navsim_default_config_cpu(navsim_config* cfg);
 int navsim_build_dt_cpu(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t map_w, float* field);
 
 int navsim_cast_static_cpu(const float* field, int32_t n_envs, int32_t map_h, int32_t map_w,
-                           const float* queries, int32_t n_per_env, float max_range, float* out);
+                           const float* queries, int32_t n_per_env, float max_range, int32_t march_rule,
+                           float* out);
 
 /* brute-force reference of the same ray rule, used only to cross-check the sphere trace:
  * walks t = 0, 1, 2, ... (unit steps) and reports the first occupied cell. */

@@ -81,13 +81,13 @@ def build_dt(occ):
     return out
 
 
-def cast_static(field, queries, max_range):
+def cast_static(field, queries, max_range, march_rule=0):
     field = np.ascontiguousarray(field, dtype=np.float32)
     q = np.ascontiguousarray(queries, dtype=np.float32)
     E, H, W = field.shape
     assert q.shape[0] == E and q.shape[2] == 3
     out = np.empty(q.shape[:2], dtype=np.float32)
-    _chk(lib().navsim_cast_static_cpu(_p(field), E, H, W, _p(q), q.shape[1], max_range, _p(out)), "cast_static")
+    _chk(lib().navsim_cast_static_cpu(_p(field), E, H, W, _p(q), q.shape[1], max_range, int(march_rule), _p(out)), "cast_static")
     return out
 
 

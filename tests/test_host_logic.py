@@ -172,6 +172,48 @@ def test_two_rank_sharding_over_gloo(tmp_path):
     assert "SHARD_OK" in outs[0]
 
 
+def _bench(args, **env):
+    e = dict(os.environ, OMP_NUM_THREADS="1", **env)
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=240)
+
+
+def test_bench_gpus_flag_spawns_ranks():
+    """`python bench.py --gpus 2` with no launcher around it spawns two ranks itself (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*), they rendezvous (gloo here, RCCL on the GPU box), the max over ranks is taken and
+    rank 0's line says n_gpus = 2.  --dry-run: control flow only, no GPU work (there is no GPU here)."""
+    import json
+    r = _bench(["--gpus", "2", "--dry-run", "--steps", "7"], NAVSIM_BENCH_BACKEND="gloo")
+    assert r.returncode == 0, r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 7 and out["dry_run"] is True
+    assert out["max_rank_time"] == 2.0                    # rank 1 reports 2.0, rank 0 1.0: MAX over ranks
+
+
+def test_bench_launcher_propagates_a_failed_rank():
+    r = _bench(["--gpus", "2", "--dry-run"], NAVSIM_BENCH_BACKEND="gloo", NAVSIM_BENCH_FAIL_RANK="1")
+    assert r.returncode != 0 and "rank 1 exit 3" in r.stderr
+
+
+def test_bench_rejects_mismatched_world_size():
+    e = dict(os.environ, WORLD_SIZE="2", RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], env=e,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_without_gpu_fails_loudly():
+    """The product path has no CPU fallback: bench.py refuses to run without a MI355X."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    r = _bench(["--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
 def test_export_transform_matches_reference_utils():
     """export._transform restates utils.transform_xys (ros_env.py:100-135 uses it for the three footprint
     polygons); golden: the reference's own output for a translation (3.25, -1.5) and yaw 0.7."""

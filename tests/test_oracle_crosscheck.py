@@ -1,12 +1,15 @@
 """CPU: independent cross-checks of the UNPINNED oracle rows (a3-a6), SURVEY.md section 8c:
 SciPy EDT vs the oracle's distance transform, unit-step ray walk vs sphere trace, closed-form
 ray/rectangle and ray/circle cases, and the deterministic math against numpy."""
+import os
+
 import numpy as np
 import pytest
 from scipy import ndimage as ndi
 
 import ref
 from helpers import outdoor_map
+from nav_gym_amd import abi
 
 
 def _ulp(a, b):
@@ -80,6 +83,52 @@ def test_sphere_trace_vs_unit_steps():
     # both report exact cell-centre distances: every finite range is sqrt(integer)
     fin = a < 200.0 * 200.0
     assert np.allclose(np.rint(a[fin].astype(np.float64) ** 2), a[fin].astype(np.float64) ** 2, atol=2e-2)
+
+
+def march_rule_sensitivity(n_rays, size=500, n_maps=8, seed=3, keep=None):
+    """How many rays of calc_range change their result between the two candidate step roundings
+    (NAVSIM_MARCH_F64: fl32(fl64(d) * 0.999) vs NAVSIM_MARCH_F32: d * 0.999f), on outdoor maps of the
+    bench's shape with origins on free integer cells (env.py:419) and uniform headings.  Ranges are exact
+    cell-centre distances, so a changed range IS a changed hit cell.  -> (n_rays, n_changed, max |delta| cells);
+    `keep` (a list) collects (occ, queries, ranges_f64, ranges_f32) of the maps holding a changed ray."""
+    rng = np.random.default_rng(seed)
+    per = n_rays // n_maps
+    changed, worst = 0, 0.0
+    for _ in range(n_maps):
+        occ = outdoor_map(rng, size)
+        f = ref.build_dt(occ[None])
+        q = _random_queries(rng, occ, per)
+        a = ref.cast_static(f, q[None], float(size * size), abi.MARCH_F64)[0]
+        b = ref.cast_static(f, q[None], float(size * size), abi.MARCH_F32)[0]
+        diff = a != b
+        changed += int(diff.sum())
+        if diff.any():
+            worst = max(worst, float(np.abs(a[diff] - b[diff]).max()))
+            if keep is not None:
+                pick = np.concatenate([np.where(diff)[0], np.arange(8)])       # the changed rays + a few unchanged
+                keep.append((occ, q[pick], a[pick], b[pick]))
+    return per * n_maps, changed, worst
+
+
+def test_march_rule_cases(golden_dir):
+    """The unpinned rounding of range_libc's step (oracle/navsim_ref.c, row a4) is a documented switch.  The two
+    rules give different probe sequences for about 3 rays in 10^6 (`python tests/test_oracle_crosscheck.py`
+    measures 10^7 and writes this fixture); a changed ray lands on another cell (0.05 m >> 1e-5 m), which is
+    why the rule has to be a switch and not a tolerance.  The fixture holds rays where they DO differ: the
+    oracle reproduces both recorded answers (tests/test_gpu_parity.py asks the same of the device)."""
+    d = np.load(os.path.join(golden_dir, "march_rule_cases.npz"))
+    n_maps = int(d["n_maps"])
+    total_changed = 0
+    for m in range(n_maps):
+        H, W = [int(x) for x in d["shape_%d" % m]]
+        occ = np.unpackbits(d["occ_%d" % m])[: H * W].reshape(H, W)
+        f = ref.build_dt(occ[None])
+        q = d["q_%d" % m]
+        a = ref.cast_static(f, q[None], float(H * W), abi.MARCH_F64)[0]
+        b = ref.cast_static(f, q[None], float(H * W), abi.MARCH_F32)[0]
+        assert np.array_equal(a, d["r64_%d" % m]) and np.array_equal(b, d["r32_%d" % m])
+        total_changed += int((a != b).sum())
+    assert total_changed >= 3
 
 
 def test_cast_static_edges():
@@ -274,3 +323,19 @@ def test_regen_indoor_maps_are_one_corridor_tree():
         i, j = int(r.a["robot_pose"][e, 0] / 0.05), int(r.a["robot_pose"][e, 1] / 0.05)
         assert free[j, i]
     assert 0.05 < min(fracs) and max(fracs) < 0.9 and len({round(f, 4) for f in fracs}) > 1
+
+
+if __name__ == "__main__":          # the figure quoted in DESIGN.md section 2 + tests/golden/march_rule_cases.npz
+    _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    kept = []
+    n, changed, worst = march_rule_sensitivity(10_000_000, n_maps=20, keep=kept)
+    print("march rule F64 vs F32: %d of %d rays change their hit cell (%.4f %%), largest change %.2f cells"
+          % (changed, n, 100.0 * changed / n, worst))
+    out = {"n_maps": np.int32(min(len(kept), 3))}
+    for m, (occ, q, a, b) in enumerate(kept[:3]):
+        out["shape_%d" % m] = np.array(occ.shape, np.int32)
+        out["occ_%d" % m] = np.packbits(occ.astype(np.uint8).reshape(-1))
+        out["q_%d" % m] = q
+        out["r64_%d" % m] = a
+        out["r32_%d" % m] = b
+    np.savez_compressed(os.path.join(_root, "tests", "golden", "march_rule_cases.npz"), **out)
