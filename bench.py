@@ -56,7 +56,7 @@ def build_sim(wl, rank, world_size, seed=1234, device="cuda:0"):
     occ = world.make_maps(E, wl["size"], seed, env_index_base=rank * E)
     goal = (10.0, 20.0) if wl["size"] >= 400 else (2.0, 4.0)
     arrays = world.make_world(cfg, occ, n_peds=wl["peds"], device=device, min_goal_dist=goal[0], max_goal_dist=goal[1],
-                              robot_clearance=1.2 if wl["size"] >= 400 else 0.9)
+                              robot_clearance=1.2 if wl["size"] >= 400 else 0.9, rect_table=wl.get("rects"))
     dev = torch.device(device)
     robot = wl.get("robot", "keti")
     cfg.axle_offset = robots.ROBOTS[robot]["axle_offset"]
@@ -230,6 +230,8 @@ def main():
     ap.add_argument("--no-noise-off-pass", action="store_true",
                     help="skip the extra K steps timed with scan noise off (profiling runs: one kind of launch only)")
     ap.add_argument("--step-block", type=int, default=0, help="threads per arena (0 = library default)")
+    ap.add_argument("--no-rects", action="store_true",
+                    help="march through the packed field only, without the two-rectangle tile records (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", default="off", choices=["auto", "on", "off"],
                     help="replay the K timed steps as one captured hipGraph (measured: c2 +0 %, c5 +2.5 %; off by default)")
@@ -274,6 +276,8 @@ def main():
     if args.envs:
         wl["envs"] = args.envs
     wl["field"] = args.field
+    if args.no_rects:
+        wl["rects"] = False
     cfg, sim, arrays, _ = build_sim(wl, rank, world_size, device=device)
     if args.step_block:
         sim.cfg.step_block = args.step_block
@@ -403,7 +407,7 @@ def main():
                 "pedestrians": wl["peds"], "obs_gather": args.gather, "episodes_finished_rank0": n_done,
                 "launch": "hipGraph replay of the K steps" if graph is not None else "one launch per step",
                 "ranks": world_size, "collective_backend": (backend if world_size > 1 else None),
-                "scan_noise_std": args.noise_std,
+                "scan_noise_std": args.noise_std, "rect_table": "rect_table" in sim.t,
             },
             "repeats": {"n": len(all_values), "values": all_values, "median": statistics.median(all_values)},
             "roofline": {

@@ -158,6 +158,11 @@ typedef struct navsim_state {
     const float*  field_overflow;   /* [E,H,W] float32 distances, read only where the packed field
                                        holds 0xFFFF; may be NULL when navsim_build_field reported
                                        no saturated cell (NAVSIM_FIELD_U16T only) */
+    const void*   rect_table;       /* [E, ceil(H/8)*ceil(W/8)] 16-byte two-rectangle records of the 8x8-cell tiles
+                                       (navsim_build_rects); optional accelerator of the packed field
+                                       (NAVSIM_FIELD_U16T only): a probe in a tile with a valid record gets its
+                                       exact integer d2 from the record instead of the field.  NULL = every probe
+                                       reads the field.  Results are unchanged.  navsim_regen keeps it current. */
     const double* beam_table;       /* [B,2] cos, sin of the robot-frame beam angles (navsim_beam_table);
                                        optional accelerator, NULL = evaluate every beam direction in full */
     const float*  scan_threshold;   /* [B] env.py:162-170 */
@@ -241,6 +246,20 @@ size_t navsim_field_bytes(int32_t n_maps, int32_t map_h, int32_t map_w, int32_t 
 int    navsim_build_field(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t map_w, int32_t format,
                           void* field, float* overflow, int32_t* n_saturated,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* Two-rectangle records of the distance field's 8x8-cell tiles (navsim_state.rect_table).  Obstacles of the
+ * reference's maps are unions of axis-aligned rectangles of cells (map_generator.py:97-143), and the squared
+ * distance of a cell to such a rectangle is max(x0-px, px-x1, 0)^2 + max(y0-py, py-y1, 0)^2.  A record holds two
+ * rectangles of occupied cells (4 x int16 each: x0, y0, x1, y1) with d2(cell) = min over the two for EVERY in-map
+ * cell of the tile -- the builder checks that cell by cell against `field` and marks the tile invalid (x0 of the
+ * first rectangle = 0x7FFF) when no such pair is found.  Any map is accepted; maps that are not rectangle unions
+ * just get fewer valid records.  `field` / `format` / `overflow` as produced by navsim_build_field for the same
+ * occupancy grids (overflow may be NULL: tiles holding a saturated cell are then invalid).  H, W <= 1024. */
+size_t navsim_rect_table_bytes(int32_t n_maps, int32_t map_h, int32_t map_w);
+size_t navsim_build_rects_workspace_bytes(int32_t n_maps, int32_t map_h, int32_t map_w);
+int    navsim_build_rects(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t map_w, const void* field,
+                          int32_t format, const float* overflow, void* table, void* workspace, size_t workspace_bytes,
+                          void* stream);
 
 /* ---- a4: PyRayMarching.calc_range_many (env.py:425) ------------------------------------- */
 /* queries [E, n_per_env, 3] float32 (x, y, theta) in cell units, out [E, n_per_env] in cells;

@@ -109,6 +109,8 @@ struct FieldF32 {
     __device__ __forceinline__ bool occupied(raw_t v) const { return v <= 0.0f; }
     __device__ __forceinline__ float decode(raw_t v, int, int) const { return v; }
     __device__ __forceinline__ float at(int px, int py) const { return load(px, py); }
+    // the float this field holds for an integer squared distance (dt_rows_kernel: sqrtf((float)d2))
+    __device__ __forceinline__ static float sqrt_d2(int d2) { return sqrtf((float)d2); }
 };
 // OVF = false: the caller guarantees that no cell is saturated (navsim_build_field reported none and gave no
 // overflow plane), so decoding needs no test for the 0xFFFF escape -- one divergent branch less per probe
@@ -138,6 +140,11 @@ struct FieldU16TT {
         return nv::sqrt_small_int((float)v);
     }
     __device__ __forceinline__ float at(int px, int py) const { return decode(load(px, py), px, py); }
+    // d of an integer squared distance, as decode() would give it: without an overflow plane every d2 of the
+    // arena is below 65535 and the short exact sqrt applies; with one, d2 may be larger: IEEE sqrtf
+    __device__ __forceinline__ static float sqrt_d2(int d2) {
+        return OVF ? sqrtf((float)d2) : nv::sqrt_small_int((float)d2);
+    }
 };
 typedef FieldU16TT<true> FieldU16T;
 typedef FieldU16TT<false> FieldU16TN;

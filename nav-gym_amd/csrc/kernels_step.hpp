@@ -271,10 +271,11 @@ __device__ __forceinline__ void finish_beams(const navsim_config& c, const StepS
 
 // Predicated one-ray-per-lane scan: the march loop has ONE wave-level branch
 // (any lane still marching?) instead of a divergent if-ladder per probe; finished or out-of-map
-// lanes keep executing with their updates masked off.  Same results as scan_beams.
-template <int BLOCK, typename Field, bool TO_LDS, int RULE>
+// lanes keep executing with their updates masked off.
+template <int BLOCK, typename Field, bool TO_LDS, int RULE, bool RECT>
 __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const StepShared& sh,
-                                                const Field& field, const double* __restrict__ tab,
+                                                const Field& field, const uint4* __restrict__ rects,
+                                                const double* __restrict__ tab,
                                                 const Prims pr, float2* __restrict__ dir_lds, float* __restrict__ rng_lds,
                                                 const float* __restrict__ thr, const float* __restrict__ dthr,
                                                 float* __restrict__ obs_row, int n_hist, float noise_std,
@@ -289,6 +290,8 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const St
     const float lx = sh.lx, ly = sh.ly;
     const int nseg = sh.nseg, ndisc = sh.ndisc;
     const unsigned uW = (unsigned)W, uH = (unsigned)H;
+    const unsigned tpr = (unsigned)((W + 7) >> kRectShift);
+    (void)tpr;
     const float t1 = sh.t1, r_all = sh.r_all;
     int cr = 0, dc = 0;
     for (int k = (int)threadIdx.x; k < B; k += BLOCK) {
@@ -304,10 +307,30 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const St
             bool live = active & ((unsigned)px < uW) & ((unsigned)py < uH);
             px = live ? px : 0;
             py = live ? py : 0;
-            typename Field::raw_t raw = field.load(px, py);
-            bool occ = live & field.occupied(raw);
+            bool occ;
+            float d;
+            if constexpr (RECT) {
+                // the tile's two-rectangle record (kernels_rect.hpp): exact integer d2 without touching the field;
+                // the rare probe in a tile without a valid record reads the field
+                const uint4 rec = rects[((unsigned)py >> kRectShift) * tpr + ((unsigned)px >> kRectShift)];
+                const int d2 = rect_record_d2(rec, px, py);
+                const bool inval = live & rect_record_invalid(rec);
+                occ = live & (d2 == 0);
+                d = Field::sqrt_d2(d2);
+                if (__any(inval)) {
+                    if (inval) {
+                        typename Field::raw_t raw = field.load(px, py);
+                        occ = field.occupied(raw);
+                        d = field.decode(raw, px, py);
+                    }
+                }
+            } else {
+                typename Field::raw_t raw = field.load(px, py);
+                occ = live & field.occupied(raw);
+                d = field.decode(raw, px, py);
+            }
             hit |= occ;
-            float tn = t + march_step<RULE>(field.decode(raw, px, py));
+            float tn = t + march_step<RULE>(d);
             bool go = live & !occ;
             t = go ? tn : t;                                    // a lane that hit keeps the t of its hit probe
             active = go & (tn < max_range);
@@ -507,7 +530,7 @@ __global__ __launch_bounds__(64) void ped_update_kernel(navsim_config c, navsim_
 // The fused step.  BLOCK threads = one arena; PEDS: the pedestrian variants (primitives + culled merge in LDS);
 // RULE: the march step rule (NAVSIM_MARCH_*), a compile-time copy of cfg.march_rule so that the probe loop
 // carries no select.
-template <int BLOCK, bool PEDS, typename Field, int RULE>
+template <int BLOCK, bool PEDS, typename Field, int RULE, bool RECT>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void navsim_step_kernel(navsim_config c, navsim_state st,
                                                             navsim_step_io io, int reset_only,
                                                             const uint8_t* __restrict__ reset_mask,
@@ -529,6 +552,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const double dt = c.time_step;
     const uint64_t genv = (uint64_t)(c.env_index_base + e);
     const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, c.map_h, c.map_w);
+    const uint4* rects = RECT ? (const uint4*)st.rect_table + (size_t)(c.shared_field ? 0 : e) * rect_tiles_per_map(c.map_h, c.map_w)
+                              : nullptr;
     float* obs_row = io.obs + (size_t)e * D;
     const float* obs_prev = io.obs_prev ? io.obs_prev + (size_t)e * D : nullptr;
     double* rp_g = st.robot_pose + 3 * (size_t)e;
@@ -647,8 +672,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const uint64_t step_key = sh.step_key;
     float2* dir_lds = (float2*)dyn_lds;
     float* rng_lds = (float*)(dyn_lds + sizeof(float2) * (size_t)B);
-    scan_beams_pred<BLOCK, Field, PEDS, RULE>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
-                                              st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
+    scan_beams_pred<BLOCK, Field, PEDS, RULE, RECT>(c, sh, field, rects, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
+                                                    st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
 
     NAVSIM_STAMP(3);
     if (!reset_only) {
@@ -707,8 +732,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         if (sh.rescan) {
             if (sh.respawn) n_hist = 0;
             int c2, d2;
-            scan_beams_pred<BLOCK, Field, PEDS, RULE>(c, sh, field, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
-                                                      st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
+            scan_beams_pred<BLOCK, Field, PEDS, RULE, RECT>(c, sh, field, rects, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
+                                                            st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
         }
     }
 

@@ -51,6 +51,7 @@ __device__ unsigned long long* g_stamps = nullptr;
 #endif
 
 #include "kernels_field.hpp"
+#include "kernels_rect.hpp"
 #include "kernels_step.hpp"
 #include "kernels_reset.hpp"
 #include "kernels_policy.hpp"
@@ -106,18 +107,25 @@ int pick_step_block(const navsim_config* c) {
     return 1024;
 }
 
-template <int BLOCK, bool PEDS, typename Field>
+template <int BLOCK, bool PEDS, typename Field, bool RECT>
 int launch_step_rule(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
                      const uint8_t* mask, size_t lds, hipStream_t s) {
     const unsigned lds_scan = (unsigned)step_lds_scan_bytes(c);
     if (c->march_rule == NAVSIM_MARCH_F32) {
-        if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, NAVSIM_MARCH_F32>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
-        navsim_step_kernel<BLOCK, PEDS, Field, NAVSIM_MARCH_F32><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, lds_scan);
+        if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, NAVSIM_MARCH_F32, RECT>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
+        navsim_step_kernel<BLOCK, PEDS, Field, NAVSIM_MARCH_F32, RECT><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, lds_scan);
     } else {
-        if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, NAVSIM_MARCH_F64>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
-        navsim_step_kernel<BLOCK, PEDS, Field, NAVSIM_MARCH_F64><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, lds_scan);
+        if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, NAVSIM_MARCH_F64, RECT>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
+        navsim_step_kernel<BLOCK, PEDS, Field, NAVSIM_MARCH_F64, RECT><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, lds_scan);
     }
     return NAVSIM_OK;
+}
+
+template <int BLOCK, bool PEDS, typename Field>
+int launch_step_field(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
+                      const uint8_t* mask, size_t lds, hipStream_t s) {
+    return st->rect_table ? launch_step_rule<BLOCK, PEDS, Field, true>(c, st, io, reset_only, mask, lds, s)
+                          : launch_step_rule<BLOCK, PEDS, Field, false>(c, st, io, reset_only, mask, lds, s);
 }
 
 template <int BLOCK>
@@ -138,14 +146,14 @@ int launch_step(const navsim_config* c, const navsim_state* st, const navsim_ste
         }
     }
     if (c->field_format == NAVSIM_FIELD_U16T && !st->field_overflow) {          // no saturated cell anywhere
-        return peds ? launch_step_rule<BLOCK, true, FieldU16TN>(c, st, io, reset_only, mask, lds, s)
-                    : launch_step_rule<BLOCK, false, FieldU16TN>(c, st, io, reset_only, mask, lds, s);
+        return peds ? launch_step_field<BLOCK, true, FieldU16TN>(c, st, io, reset_only, mask, lds, s)
+                    : launch_step_field<BLOCK, false, FieldU16TN>(c, st, io, reset_only, mask, lds, s);
     } else if (c->field_format == NAVSIM_FIELD_U16T) {
-        return peds ? launch_step_rule<BLOCK, true, FieldU16T>(c, st, io, reset_only, mask, lds, s)
-                    : launch_step_rule<BLOCK, false, FieldU16T>(c, st, io, reset_only, mask, lds, s);
+        return peds ? launch_step_field<BLOCK, true, FieldU16T>(c, st, io, reset_only, mask, lds, s)
+                    : launch_step_field<BLOCK, false, FieldU16T>(c, st, io, reset_only, mask, lds, s);
     }
-    return peds ? launch_step_rule<BLOCK, true, FieldF32>(c, st, io, reset_only, mask, lds, s)
-                : launch_step_rule<BLOCK, false, FieldF32>(c, st, io, reset_only, mask, lds, s);
+    return peds ? launch_step_rule<BLOCK, true, FieldF32, false>(c, st, io, reset_only, mask, lds, s)
+                : launch_step_rule<BLOCK, false, FieldF32, false>(c, st, io, reset_only, mask, lds, s);
 }
 
 int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
@@ -290,6 +298,60 @@ int navsim_build_field(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W,
     return launch_status();
 }
 
+size_t navsim_rect_table_bytes(int32_t n_maps, int32_t H, int32_t W) {
+    if (n_maps <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)n_maps * rect_tiles_per_map(H, W) * sizeof(uint4);
+}
+
+// scratch per map: transposed occupancy (1 byte per cell) + four int16 run arrays
+constexpr size_t kRectWsPerCell = 1 + 4 * sizeof(int16_t);
+size_t navsim_build_rects_workspace_bytes(int32_t n_maps, int32_t H, int32_t W) {
+    if (n_maps <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)n_maps * (((size_t)H * W * kRectWsPerCell + 255) & ~(size_t)255);
+}
+
+// the three builder passes for `m` maps whose occupancy / field start at occ / field (per-map strides cells /
+// field_stride); n_live + list: navsim_regen's slot indirection (see rect_tiles_kernel)
+static void launch_build_rects(const uint8_t* occ, int m, int H, int W, const void* field, size_t field_stride,
+                               int format, const float* overflow, uint4* table, char* ws, const int* n_live,
+                               const int* list, hipStream_t s) {
+    const size_t cells = (size_t)H * W;
+    uint8_t* occT = (uint8_t*)ws;
+    int16_t* hl = (int16_t*)(ws + (((size_t)m * cells + 255) & ~(size_t)255));
+    int16_t* hr = hl + (size_t)m * cells;
+    int16_t* vt = hr + (size_t)m * cells;
+    int16_t* vb = vt + (size_t)m * cells;
+    rect_transpose_kernel<<<dim3((W + 31) / 32, (H + 31) / 32, m), 256, 0, s>>>(occ, occT, H, W, n_live);
+    rect_runs_kernel<<<dim3(H, m), 256, (size_t)W * 2 * sizeof(int16_t), s>>>(occ, hl, hr, H, W, n_live);
+    rect_runs_kernel<<<dim3(W, m), 256, (size_t)H * 2 * sizeof(int16_t), s>>>(occT, vt, vb, W, H, n_live);
+    const int n_tiles = (int)rect_tiles_per_map(H, W);
+    rect_tiles_kernel<<<dim3((n_tiles + 3) / 4, m), 256, 0, s>>>(occ, hl, hr, vt, vb, H, W, field, overflow, format,
+                                                                field_stride, table, n_live, list);
+}
+
+int navsim_build_rects(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, const void* field, int32_t format,
+                       const float* overflow, void* table, void* workspace, size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
+    if (!occ || !field || !table || !workspace || n_maps < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
+    if (format != NAVSIM_FIELD_F32 && format != NAVSIM_FIELD_U16T) return NAVSIM_E_UNSUPPORTED;
+    if (H > 1024 || W > 1024) return NAVSIM_E_UNSUPPORTED;                 // int16 runs, 4 cells per thread in the scans
+    const size_t cells = (size_t)H * W;
+    const size_t per_map = navsim_build_rects_workspace_bytes(1, H, W) + 256;
+    size_t chunk = workspace_bytes / per_map;
+    if (chunk == 0) return NAVSIM_E_ARG;
+    if (chunk > 32768) chunk = 32768;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t fstride = navsim_field_bytes(1, H, W, format);
+    const size_t n_tiles = rect_tiles_per_map(H, W);
+    for (int32_t m0 = 0; m0 < n_maps; m0 += (int32_t)chunk) {
+        const int32_t m = (n_maps - m0 < (int32_t)chunk) ? n_maps - m0 : (int32_t)chunk;
+        launch_build_rects(occ + (size_t)m0 * cells, m, H, W, (const char*)field + fstride * (size_t)m0, fstride, format,
+                           overflow ? overflow + (size_t)m0 * cells : nullptr, (uint4*)table + (size_t)m0 * n_tiles,
+                           (char*)workspace, nullptr, nullptr, s);
+    }
+    return launch_status();
+}
+
 int navsim_build_dt(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, float* field,
                     void* workspace, size_t workspace_bytes, void* stream) {
     return navsim_build_field(occ, n_maps, H, W, NAVSIM_FIELD_F32, field, nullptr, nullptr, workspace,
@@ -374,6 +436,7 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
     if (c->max_peds > NAVSIM_MAX_PEDS) return NAVSIM_E_UNSUPPORTED;
     if (c->field_format != NAVSIM_FIELD_F32 && c->field_format != NAVSIM_FIELD_U16T) return NAVSIM_E_UNSUPPORTED;
     if (c->march_rule != NAVSIM_MARCH_F64 && c->march_rule != NAVSIM_MARCH_F32) return NAVSIM_E_ARG;
+    if (st->rect_table && c->field_format != NAVSIM_FIELD_U16T) return NAVSIM_E_UNSUPPORTED;
     if (c->step_block != 0 && c->step_block != 64 && c->step_block != 256 && c->step_block != 512 &&
         c->step_block != 1024) return NAVSIM_E_ARG;
     if (c->ped_split < 0 || c->ped_split > 2) return NAVSIM_E_ARG;
@@ -445,6 +508,8 @@ size_t navsim_regen_workspace_bytes(const navsim_config* c) {
     b += M * cells;                                         // occupancy scratch
     b += M * cells * sizeof(uint16_t);                      // column pass
     b += M * navsim_field_bytes(1, c->map_h, c->map_w, c->field_format);
+    if (c->field_format == NAVSIM_FIELD_U16T)               // rect records of the regenerated arenas
+        b += navsim_build_rects_workspace_bytes((int32_t)M, c->map_h, c->map_w) + 512;
     b += M * (10000 + sizeof(int)) + 512;                   // corridor grids, map kinds
     if (c->regen_plan) {
         const size_t cc = (size_t)(c->map_h / 5) * (c->map_w / 5), P = NAVSIM_MAX_WAYPOINTS;
@@ -469,6 +534,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     // function draws has a 5-cell border wall: the farthest a cell can be from it is map_h / 2 - 5 cells, which
     // stays below 255.99 up to 520 cells per side.  Larger packed maps must use NAVSIM_FIELD_F32.
     if (c->field_format == NAVSIM_FIELD_U16T && c->map_h > kRegenMaxPackedSide) return NAVSIM_E_UNSUPPORTED;
+    if (st->rect_table && (c->field_format != NAVSIM_FIELD_U16T || c->map_h > 1024)) return NAVSIM_E_UNSUPPORTED;
     if (workspace_bytes < navsim_regen_workspace_bytes(c) || !st->spawn_pose || !st->spawn_goal) return NAVSIM_E_ARG;
     if (c->regen_plan && (c->n_spawn > 256 || c->map_h < 5 || !plan_fits(c->map_h / 5, c->map_w / 5) ||
                           allow_lds((const void*)regen_plan_kernel, plan_lds(c->map_h / 5, c->map_w / 5)) != NAVSIM_OK))
@@ -509,6 +575,13 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         dt_rows_kernel<0><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, nullptr, nullptr, H, W, count);
     else
         dt_rows_kernel<1><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, nullptr, nullptr, H, W, count);
+    if (st->rect_table) {                                   // keep the rect records of the regenerated arenas current
+        off = (off + 255) & ~(size_t)255;
+        char* rect_ws = w + off;
+        off += navsim_build_rects_workspace_bytes(M, H, W) + 256;
+        launch_build_rects(occ, M, H, W, fscratch, fbytes, c->field_format, nullptr, (uint4*)st->rect_table, rect_ws,
+                           count, list, s);
+    }
     regen_field_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>(*st, count, list, fscratch, fbytes);
     if (c->regen_plan) {
         const int Hc = H / 5, Wc = W / 5, P = NAVSIM_MAX_WAYPOINTS;

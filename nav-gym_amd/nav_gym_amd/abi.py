@@ -111,7 +111,7 @@ _P = C.c_void_p
 
 class NavsimState(C.Structure):
     _fields_ = [(name, _P) for name in (
-        "field", "field_overflow", "beam_table", "scan_threshold", "scan_discomfort", "scan_noise_std",
+        "field", "field_overflow", "rect_table", "beam_table", "scan_threshold", "scan_discomfort", "scan_noise_std",
         "robot_pose", "robot_goal", "prev_action", "prev_pose", "n_hist", "episode", "steps",
         "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist", "ped_v_pref", "ped_has_legs",
         "ped_waypoints", "ped_n_waypoints", "ped_cmd",
@@ -154,6 +154,7 @@ class NavsimStepIO(C.Structure):
 STATE_LAYOUT = {
     "field": ("float32", ("E", "H", "W")),          # FIELD_F32; a uint8 blob for packed formats
     "field_overflow": ("float32", ("E", "H", "W")),
+    "rect_table": ("int32", ("E", "T", 4)),         # 16-byte two-rectangle records of the 8x8 tiles
     "beam_table": ("float64", ("B", 2)),
     "scan_threshold": ("float32", ("B",)),
     "scan_discomfort": ("float32", ("B",)),
@@ -202,6 +203,7 @@ def resolve_shape(shape, cfg):
         "E": cfg.n_envs, "N": cfg.max_peds, "B": cfg.n_beams, "S": cfg.n_scan_stack,
         "K": max(cfg.n_spawn, 1), "P": MAX_WAYPOINTS, "H": cfg.map_h, "W": cfg.map_w,
         "D": cfg.n_scan_stack * cfg.n_beams + OBS_TAIL, "Hc": cfg.map_h // 5, "Wc": cfg.map_w // 5,
+        "T": ((cfg.map_h + 7) // 8) * ((cfg.map_w + 7) // 8),
     }
     return tuple(sym[s] if isinstance(s, str) else s for s in shape)
 
@@ -229,6 +231,9 @@ def declare(lib, suffix=""):
     if not suffix:
         sig("navsim_field_bytes", [i32, i32, i32, i32], C.c_size_t)
         sig("navsim_build_field", [_P, i32, i32, i32, i32, _P, _P, _P, _P, C.c_size_t, _P])
+        sig("navsim_rect_table_bytes", [i32, i32, i32], C.c_size_t)
+        sig("navsim_build_rects_workspace_bytes", [i32, i32, i32], C.c_size_t)
+        sig("navsim_build_rects", [_P, i32, i32, i32, _P, i32, _P, _P, _P, C.c_size_t, _P])
     sig("navsim_cast_static", [_P, i32, i32, i32, _P, i32, f32, i32, _P] + stream)
     sig("navsim_render_polys", [_P, _P, i32, i32, _P, _P, i32, _P] + stream)
     sig("navsim_render_legs", [_P, _P, i32, i32, _P, _P, i32, _P] + stream)
@@ -263,6 +268,7 @@ def declare(lib, suffix=""):
 EXPORTS = (
     "navsim_abi_version", "navsim_error_string", "navsim_last_hip_error", "navsim_default_config",
     "navsim_build_dt_workspace_bytes", "navsim_build_dt", "navsim_field_bytes", "navsim_build_field",
+    "navsim_rect_table_bytes", "navsim_build_rects_workspace_bytes", "navsim_build_rects",
     "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
     "navsim_scan_threshold", "navsim_beam_table", "navsim_ped_scans", "navsim_regen_workspace_bytes", "navsim_regen",

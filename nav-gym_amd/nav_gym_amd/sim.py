@@ -71,6 +71,23 @@ def build_field(occ, fmt=abi.FIELD_U16T, keep_overflow=None):
     return field, overflow, int(nsat.item())          # reset path: a sync is fine here
 
 
+def build_rects(occ, field, fmt, overflow=None):
+    """navsim_build_rects: occ uint8 CUDA [E,H,W] + the distance field built from it (build_field's `field`, and
+    its float32 plane when cells are saturated) -> int32 [E, T, 4] two-rectangle records of the 8x8 tiles."""
+    torch = require_gpu()
+    L = load()
+    occ = occ.contiguous()
+    E, H, W = occ.shape
+    T = ((H + 7) // 8) * ((W + 7) // 8)
+    table = torch.empty((E, T, 4), dtype=torch.int32, device=occ.device)
+    per = L.navsim_build_rects_workspace_bytes(1, H, W) + 256
+    chunk = max(1, min(E, (1 << 30) // per))                      # <= 1 GiB of scratch
+    ws = torch.empty(per * chunk, dtype=torch.uint8, device=occ.device)
+    check(L.navsim_build_rects(_ptr(occ), E, H, W, _ptr(field), int(fmt), _ptr(overflow), _ptr(table), _ptr(ws),
+                               ws.numel(), _stream()), "navsim_build_rects")
+    return table
+
+
 def cast_static(field, queries, max_range, march_rule=abi.MARCH_F64):
     torch = require_gpu()
     E, H, W = field.shape

@@ -119,13 +119,16 @@ def cells_to_xy(cells, W, resolution, origin):
 
 def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=20.0,
                robot_clearance=1.2, ped_clearance=0.5, noise_std_range=(0.0, 0.0),
-               has_legs_ratio=0.5, v_pref_range=(0.0, 0.6), device="cuda:0", field=None, plan_paths=False):
+               has_legs_ratio=0.5, v_pref_range=(0.0, 0.6), device="cuda:0", field=None, plan_paths=False,
+               rect_table=None):
     """Builds every navsim_state array for cfg.n_envs arenas on `device`.
 
     occ: uint8 numpy/torch [E,H,W].  Returns dict name -> torch tensor (see abi.STATE_LAYOUT).
     plan_paths: also keep the planning costmap of every arena resident (env.py:312-332) and give the
     pedestrians the waypoints of a planned path to their first goal (env.py:788-804); pedestrians
-    then re-plan through NavSim.replan() (env.py:667-680)."""
+    then re-plan through NavSim.replan() (env.py:667-680).
+    rect_table: build the two-rectangle tile records of the packed field (navsim_build_rects), the march's
+    exact shortcut around most field reads; None = whenever the format allows it (FIELD_U16T, side <= 1024)."""
     import torch
     from . import sim
     seed = int(cfg.seed if seed is None else seed)
@@ -145,6 +148,10 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
             a["field"] = packed
             if nsat > 0:                                  # some cell >= 256 cells from every obstacle
                 a["field_overflow"] = f32
+            if rect_table is None:
+                rect_table = max(H0, W0) <= 1024
+            if rect_table and cfg.field_format == abi.FIELD_U16T:
+                a["rect_table"] = sim.build_rects(occ_t, packed, cfg.field_format, f32)
         if plan_paths:
             a["costmap"] = sim.costmap(occ_t)
         del occ_t

@@ -264,7 +264,7 @@ def _rollout_pair(gpu, cfg, occ, n_peds, steps, seed, noise=False, policy=None, 
     from nav_gym_amd import robots
     arrays["scan_threshold"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array(key, "threshold_footprint")))
     arrays["scan_discomfort"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array(key, "discomfort_threshold_footprint")))
-    host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow")}
+    host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "rect_table")}
     host["field"] = ref.build_dt(occ)                 # the oracle always reads its own float32 field
     g = gpu.sim.NavSim(cfg, arrays)
     r = ref.RefSim(cfg, host)
@@ -288,19 +288,24 @@ def _rollout_pair(gpu, cfg, occ, n_peds, steps, seed, noise=False, policy=None, 
         yield t, go.cpu().numpy(), {k: v.cpu().numpy() for k, v in gout.items()}, ro, rout, g, r
 
 
-@pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T])
+@pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T, "u16t-no-rects"])
 @pytest.mark.parametrize("ped_model,S,auto_reset", [(abi.PED_NONE, 1, 1), (abi.PED_SFM, 2, 1), (abi.PED_EXTERNAL, 3, 0)])
 def test_step_rollout_vs_oracle(gpu, ped_model, S, auto_reset, fmt):
     """48 arenas x 60 steps on 240x240 maps, 1081 beams: every output and every state array of the
     fused kernel equals the oracle's, bit for bit, including crash reverts and respawns -- for the
-    float32 field and for the packed uint16 tile field the bench streams."""
+    float32 field, for the packed uint16 tile field with the two-rectangle tile records the bench marches
+    through (navsim_build_rects), and for the packed field alone."""
+    world_kw = {}
+    if fmt == "u16t-no-rects":
+        fmt, world_kw = abi.FIELD_U16T, {"rect_table": False}
     E, size, N = 48, 240, 8
     cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, n_scan_stack=S, ped_model=ped_model,
                                  auto_reset=auto_reset, n_spawn=8, seed=4242, field_format=fmt)
     gpu.world.lidar_1081(cfg)
     occ = gpu.world.make_maps(E, size, 4242)
     crashes = resets = 0
-    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=6, steps=60, seed=1):
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=6, steps=60, seed=1, **world_kw):
+        assert ("rect_table" in g.t) == (fmt == abi.FIELD_U16T and not world_kw)
         for k in rout:
             _eq(gout[k], rout[k], "%s at step %d" % (k, t))
         _eq(go, ro, "obs at step %d" % t)
@@ -308,7 +313,7 @@ def test_step_rollout_vs_oracle(gpu, ped_model, S, auto_reset, fmt):
         if t % 10 == 9:
             gs = g.numpy_state()
             for k, v in r.a.items():
-                if k in gs and k not in ("field", "field_overflow"):
+                if k in gs and k not in ("field", "field_overflow", "rect_table"):
                     _eq(gs[k], v, "state %s at step %d" % (k, t))
     assert crashes > 0, "rollout never exercised the crash-revert branch"
     assert resets > 0
@@ -330,7 +335,7 @@ def test_step_rollout_with_split_pedestrian_kernel(gpu, ped_model):
         _eq(go, ro, "obs at step %d" % t)
     gs = g.numpy_state()
     for k, v in r.a.items():
-        if k in gs and k not in ("field", "field_overflow"):
+        if k in gs and k not in ("field", "field_overflow", "rect_table"):
             _eq(gs[k], v, "state %s" % k)
 
 
@@ -370,7 +375,7 @@ def test_step_fuzzed_configurations(gpu, seed):
         _eq(go, ro, "obs at step %d" % t)
     gs = g.numpy_state()
     for k, v in r.a.items():
-        if k in gs and k not in ("field", "field_overflow"):
+        if k in gs and k not in ("field", "field_overflow", "rect_table"):
             _eq(gs[k], v, "state %s" % k)
 
 
@@ -449,11 +454,15 @@ def test_regen_vs_oracle(gpu, fmt, ped_model, plan):
         if n_done:
             gs = g.numpy_state()
             for k, v in r.a.items():
-                if k in gs and k not in ("field", "field_overflow"):
+                if k in gs and k not in ("field", "field_overflow", "rect_table"):
                     _eq(gs[k], v, "state %s after regen at step %d" % (k, t))
             if fmt == abi.FIELD_F32:
                 _eq(gs["field"], r.a["field"], "field after regen at step %d" % t)
     assert regenerated > 5
+    if fmt == abi.FIELD_U16T:           # navsim_regen keeps the two-rectangle tile records of the new maps current
+        d2, valid = _decode_rect_table(g.t["rect_table"].cpu().numpy(), size, size)
+        exact = np.rint(r.a["field"].astype(np.float64) ** 2).astype(np.int64)
+        assert np.array_equal(d2[valid], exact[valid]) and valid.mean() > 0.9
     if plan and ped_model != abi.PED_NONE:
         assert (r.a["ped_n_waypoints"] > 1).any(), "no pedestrian ever received a planned path"
     # a regenerated arena has a valid closed map: 5-cell border, obstacles inside
@@ -494,7 +503,7 @@ def test_reset_path_fuzzed(gpu, seed):
             g.replan(4); r.replan(4)
     gs = g.numpy_state()
     for k, v in r.a.items():
-        if k in gs and k not in ("field", "field_overflow"):
+        if k in gs and k not in ("field", "field_overflow", "rect_table"):
             if k == "ped_waypoints":
                 live = np.arange(abi.MAX_WAYPOINTS)[None, None, :] < r.a["ped_n_waypoints"][..., None]
                 _eq(gs[k][live], v[live], "state %s" % k)
@@ -522,7 +531,7 @@ def test_regen_odd_map_size(gpu, fmt):
         _eq(g.regen().cpu().numpy(), r.regen(), "obs after regen at step %d" % t)
     gs = g.numpy_state()
     for k, v in r.a.items():
-        if k in gs and k not in ("field", "field_overflow"):
+        if k in gs and k not in ("field", "field_overflow", "rect_table"):
             _eq(gs[k], v, "state %s" % k)
     if fmt == abi.FIELD_F32:
         _eq(gs["field"], r.a["field"], "field")
@@ -592,7 +601,7 @@ def test_policy_closed_loop_vs_oracle(gpu, fmt):
         if t % 4 == 3:
             gs = g.numpy_state()
             for k, v in r.a.items():
-                if k in gs and k not in ("field", "field_overflow"):
+                if k in gs and k not in ("field", "field_overflow", "rect_table"):
                     _eq(gs[k], v, "state %s at step %d" % (k, t))
     m = r.prev_actions[:, :17]
     assert (m[..., 0] > 0).all() and (m[..., 0] < 1).all() and np.abs(m[..., 1]).max() < 1 and m.std() > 1e-3
@@ -871,7 +880,7 @@ def test_full_size_c2_properties_and_sampled_oracle(gpu, full_c2):
         c1 = sub_cfg.copy(); c1.env_index_base = int(e)
         host = {}
         for k, t in sim.t.items():
-            if k in ("field", "field_overflow", "beam_table", "arena_cost", "launch_order", "regen_ws"):
+            if k in ("field", "field_overflow", "rect_table", "beam_table", "arena_cost", "launch_order", "regen_ws"):
                 continue
             a = t.detach().cpu().numpy()
             host[k] = a if k in ("scan_threshold", "scan_discomfort") else a[e:e + 1]
@@ -963,6 +972,93 @@ def test_full_size_c2_determinism_and_shard_invariance(gpu, full_c2):
             assert torch.equal(full[t][1][k], torch.cat([a[t][1][k], b[t][1][k]])), k
 
 
+def _decode_rect_table(table, H, W):
+    """Host evaluation of navsim_build_rects records: -> (d2 int64 [E,H,W], valid bool [E,H,W])."""
+    E = table.shape[0]
+    tpr = (W + 7) // 8
+    rec = table.view(np.uint32).reshape(E, -1, 4)
+    yy, xx = np.mgrid[0:H, 0:W]
+    tile = (yy // 8) * tpr + (xx // 8)
+    r = rec[:, tile]                                            # [E,H,W,4]
+    def sx(w): return (w & 0xFFFF).astype(np.int16).astype(np.int64)
+    def sy(w): return (w >> 16).astype(np.int16).astype(np.int64)
+    def dist2(lo, hi):
+        ddx = np.maximum(0, np.maximum(sx(lo) - xx, xx - sx(hi)))
+        ddy = np.maximum(0, np.maximum(sy(lo) - yy, yy - sy(hi)))
+        return ddx * ddx + ddy * ddy
+    d2 = np.minimum(dist2(r[..., 0], r[..., 1]), dist2(r[..., 2], r[..., 3]))
+    valid = (r[..., 0] & 0xFFFF) != 0x7FFF
+    return d2, valid
+
+
+@pytest.mark.parametrize("size,indoor,fmt", [(100, 0.0, abi.FIELD_U16T), (253, 0.5, abi.FIELD_U16T), (500, 0.0, abi.FIELD_U16T),
+                                             (500, 1.0, abi.FIELD_F32), (1000, 0.0, abi.FIELD_U16T)])
+def test_rect_table_reproduces_field(gpu, size, indoor, fmt):
+    """navsim_build_rects: every VALID record gives the exact squared distance on all in-map cells of its 8x8
+    tile (min over its two rectangles); both rectangles consist of occupied cells only; tiles without such a
+    pair are marked invalid (the march then reads the field).  On the reference's kind of maps (unions of
+    boxes / corridors) nearly every tile is valid.  1000x1000 outdoor maps have saturated cells (d2 >= 65535):
+    the float32 plane supplies their exact distance."""
+    n = 3 if size <= 500 else 1
+    occ = gpu.world.make_maps(n, size, 31, indoor_ratio=indoor)
+    field, f32, nsat = gpu.sim.build_field(_t(gpu, occ), fmt)
+    table = gpu.sim.build_rects(_t(gpu, occ), field, fmt, f32 if fmt == abi.FIELD_U16T else None).cpu().numpy()
+    d2, valid = _decode_rect_table(table, size, size)
+    exact = np.rint(ref.build_dt(occ).astype(np.float64) ** 2).astype(np.int64)
+    assert np.array_equal(d2[valid], exact[valid]), "a valid record disagrees with the exact field"
+    frac = valid.mean()                     # small maps: a larger share of the tiles sits between several obstacles
+    assert frac > (0.8 if size <= 100 else 0.93), "only %.3f of the cells lie in tiles with a valid record" % frac
+    # rectangles are made of occupied cells (the upper-bound argument of kernels_rect.hpp relies on it)
+    rec = table.view(np.uint32).reshape(n, -1, 4)
+    rng = np.random.default_rng(0)
+    for m in range(n):
+        ok = np.where((rec[m, :, 0] & 0xFFFF) != 0x7FFF)[0]
+        for t in rng.choice(ok, 200):
+            for lo, hi in ((rec[m, t, 0], rec[m, t, 1]), (rec[m, t, 2], rec[m, t, 3])):
+                x0, y0, x1, y1 = int(lo & 0xFFFF), int(lo >> 16), int(hi & 0xFFFF), int(hi >> 16)
+                assert 0 <= x0 <= x1 < size and 0 <= y0 <= y1 < size
+                assert occ[m, y0:y1 + 1, x0:x1 + 1].all()
+    if size == 1000 and fmt == abi.FIELD_U16T:
+        assert nsat > 0
+        # without the float plane the tiles holding a saturated cell must come out invalid, never wrong
+        t2 = gpu.sim.build_rects(_t(gpu, occ), field, fmt, None).cpu().numpy()
+        d2b, validb = _decode_rect_table(t2, size, size)
+        assert np.array_equal(d2b[validb], exact[validb]) and validb.sum() < valid.sum()
+
+
+def test_rect_table_on_arbitrary_maps(gpu):
+    """Maps that are NOT rectangle unions (random speckle, a disc, diagonal walls): fewer valid records, never a
+    wrong one, and the fused step through such a table still equals the oracle bit for bit."""
+    size, E = 160, 6
+    rng = np.random.default_rng(5)
+    occ = np.zeros((E, size, size), np.uint8)
+    occ[:, :3] = 1; occ[:, -3:] = 1; occ[:, :, :3] = 1; occ[:, :, -3:] = 1
+    yy, xx = np.mgrid[0:size, 0:size]
+    occ[0][rng.random((size, size)) < 0.01] = 1
+    occ[1][(yy - 80) ** 2 + (xx - 70) ** 2 < 30 ** 2] = 1
+    occ[2][np.abs(yy - xx) < 2] = 1
+    occ[3][(np.abs(yy + xx - size) < 2) & (xx > 40)] = 1
+    occ[4][rng.random((size, size)) < 0.002] = 1
+    occ[5][60:100, 50:120] = 1
+    for e in range(E):                                   # keep a free patch for the robots
+        occ[e, 20:45, 20:45] = 0
+    field, f32, _ = gpu.sim.build_field(_t(gpu, occ), abi.FIELD_U16T)
+    table = gpu.sim.build_rects(_t(gpu, occ), field, abi.FIELD_U16T, f32).cpu().numpy()
+    d2, valid = _decode_rect_table(table, size, size)
+    exact = np.rint(ref.build_dt(occ).astype(np.float64) ** 2).astype(np.int64)
+    assert np.array_equal(d2[valid], exact[valid])
+    assert valid[5].mean() > 0.95 and valid[0].mean() < 0.9          # a box: valid; speckle: mostly not
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, n_spawn=4, auto_reset=1, seed=8,
+                                 field_format=abi.FIELD_U16T)
+    gpu.world.lidar_1081(cfg)
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=0, steps=25, seed=2, min_goal_dist=1.0,
+                                                     max_goal_dist=3.0, robot_clearance=0.4):
+        assert "rect_table" in g.t
+        _eq(go, ro, "obs at step %d" % t)
+        for k in rout:
+            _eq(gout[k], rout[k], "%s at step %d" % (k, t))
+
+
 @pytest.mark.parametrize("size,indoor", [(400, 0.0), (500, 1.0), (1000, 1.0)])
 def test_costmap_and_planner_vs_oracle(gpu, size, indoor):
     """Reset path: costmap (env.py:312-332) and shortest-path waypoints (env.py:343-354, 1261-1277) on
@@ -1032,7 +1128,7 @@ def test_edge_shapes(gpu):
     from nav_gym_amd import robots
     arrays["scan_threshold"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array("keti", "threshold_footprint")))
     arrays["scan_discomfort"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array("keti", "discomfort_threshold_footprint")))
-    host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow")}
+    host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "rect_table")}
     host["field"] = ref.build_dt(occ)
     g = gpu.sim.NavSim(cfg, arrays); r = ref.RefSim(cfg, host)
     _eq(g.reset_obs().cpu().numpy(), r.reset_obs(), "reset obs")
