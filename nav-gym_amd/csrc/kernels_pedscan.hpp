@@ -7,7 +7,7 @@
 // HumanPolicy).  One workgroup per (pedestrian, arena): rectangles of the other agents in LDS,
 // march from the pedestrian's integer cell, bearing-culled polygon merge, clip to 6 m.
 // ============================================================================================
-template <typename Field, int BLOCK>
+template <typename Field, int BLOCK, int RULE, bool RECT>
 __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim_state st, float* __restrict__ out) {
     __shared__ float seg[4 * (NAVSIM_MAX_PEDS + 1)][4];
     __shared__ float info_s[4 * (NAVSIM_MAX_PEDS + 1)];
@@ -50,6 +50,9 @@ __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim
         }
     }
     const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, H, W);
+    const char* rects = RECT ? (const char*)st.rect_table + (size_t)(c.shared_field ? 0 : e) * rect_tiles_per_map(H, W) * sizeof(uint4)
+                             : nullptr;
+    const unsigned tpr = (unsigned)((W + 7) >> kRectShift);
     const float max_range = march_limit(H, W, c.ped_range_max, c.resolution);
     const float res = (float)c.resolution, rmax = (float)c.ped_range_max;
     const double step = (PB > 1) ? (c.ped_angle_last - c.ped_angle_min) / (double)(PB - 1) : 0.0;
@@ -60,9 +63,11 @@ __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim
         float dx, dy;
         nv::beam_dir((float)(lin + lth), dx, dy);
         dir[k] = make_float2(dx, dy);
-        rng[k] = ((c.march_rule == NAVSIM_MARCH_F32)
-                      ? march_ray<NAVSIM_MARCH_F32>(field, x0, y0, dx, dy, 0.0f, max_range, (unsigned)W, (unsigned)H)
-                      : march_ray<NAVSIM_MARCH_F64>(field, x0, y0, dx, dy, 0.0f, max_range, (unsigned)W, (unsigned)H)) * res;
+        float t = 0.0f;
+        bool active = true, hit = false;
+        while (wave_any(active))
+            probe_round<Field, RULE, RECT>(field, rects, tpr, x0, y0, dx, dy, (unsigned)W, (unsigned)H, max_range, t, active, hit);
+        rng[k] = ray_result(hit, x0, y0, dx, dy, t, max_range) * res;
     }
     __syncthreads();
     const Prims pr = {seg, nullptr, info_s};

@@ -106,26 +106,6 @@ __device__ __forceinline__ void first_probe(const Field& field, int i0, int j0, 
     if (!(t1 < max_range)) r_all = max_range;
 }
 
-// one ray of calc_range from t = t1 on (env.py:425); returns the raw range in cells
-template <int RULE, typename Field>
-__device__ __forceinline__ float march_ray(const Field& field, float x0, float y0, float dx, float dy,
-                                           float t, float max_range, unsigned uW, unsigned uH) {
-    for (;;) {
-        float fx = x0 + dx * t;
-        float fy = y0 + dy * t;
-        int px = (int)fx, py = (int)fy;
-        if (!(((unsigned)px < uW) & ((unsigned)py < uH))) return max_range;     // left the map
-        typename Field::raw_t raw = field.load(px, py);
-        if (field.occupied(raw)) {
-            float xd = (float)px - x0;
-            float yd = (float)py - y0;
-            return sqrtf(xd * xd + yd * yd);
-        }
-        t += march_step<RULE>(field.decode(raw, px, py));
-        if (!(t < max_range)) return max_range;
-    }
-}
-
 // Pedestrians into the scan (env.py:428-432), culled by bearing.  A rectangle side or a leg disc is
 // seen under a small angle, so instead of testing every beam against every primitive (B x P ray
 // tests: 3x the cost of the whole map march at 20 pedestrians) each wave takes one primitive, derives
@@ -236,6 +216,7 @@ __device__ __forceinline__ void finish_beams(const navsim_config& c, const StepS
     const int nseg = sh.nseg, ndisc = sh.ndisc;
     const float r_all = sh.r_all;
     int cr = 0, dc = 0;
+    const uint64_t nkey = (noise_std > 0.0f) ? nv::noise_stream(c.seed, genv, noise_key) : 0;
     const bool culled = dir && rng_rw && (nseg | ndisc);           // LDS-resident: bearing-culled merge
     if (culled) {
         for (int k = (int)threadIdx.x; k < B; k += BLOCK)
@@ -258,7 +239,7 @@ __device__ __forceinline__ void finish_beams(const navsim_config& c, const StepS
         rr = rr < 0.0f ? 0.0f : rr;                                 // env.py:435
         rr = rr > rmax ? rmax : rr;
         if (noise_std > 0.0f && rr != rmax)                         // env.py:437-440
-            rr = rr + noise_std * nv::gauss_noise(c.seed ^ noise_key, genv, noise_key, (uint32_t)k);
+            rr = rr + noise_std * nv::gauss_noise(nkey, (uint32_t)k);
         cr |= (rr < thr[k]);
         dc |= (rr < dthr[k]);
         obs_row[(size_t)(S - 1) * B + k] = rr;
@@ -267,6 +248,59 @@ __device__ __forceinline__ void finish_beams(const navsim_config& c, const StepS
     }
     crash = cr;
     discomfort = dc;
+}
+
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+// One probe of calc_range (env.py:425) for every lane with `active` set: sample position, distance there, hit test,
+// step.  Lanes that are finished or outside the map run along with their updates masked off.  A lane that hits
+// keeps the t of its hit probe (the hit cell is recomputed from it after the march).
+template <typename Field, int RULE, bool RECT>
+__device__ __forceinline__ void probe_round(const Field& field, const char* __restrict__ rects, unsigned tpr,
+                                            float x0, float y0, float dx, float dy, unsigned uW, unsigned uH,
+                                            float max_range, float& t, bool& active, bool& hit) {
+    const float fx = x0 + dx * t;
+    const float fy = y0 + dy * t;
+    int px = (int)fx, py = (int)fy;
+    const bool live = active & ((unsigned)px < uW) & ((unsigned)py < uH);
+    px = live ? px : 0;
+    py = live ? py : 0;
+    bool occ;
+    float d;
+    if constexpr (RECT) {
+        // the tile's two-rectangle record (kernels_rect.hpp): exact integer d2 without touching the field; the
+        // rare probe in a tile without a valid record reads the field.  32-bit lane offset on a uniform base.
+        const unsigned off = (((unsigned)py >> kRectShift) * tpr + ((unsigned)px >> kRectShift)) * (unsigned)sizeof(uint4);
+        const uint4 rec = *(const uint4*)(rects + off);
+        const int d2 = rect_record_d2(rec, px, py);
+        const bool inval = live & rect_record_invalid(rec);
+        occ = live & (d2 == 0);
+        d = Field::sqrt_d2(d2);
+        if (wave_any(inval)) {
+            if (inval) {
+                typename Field::raw_t raw = field.load(px, py);
+                occ = field.occupied(raw);
+                d = field.decode(raw, px, py);
+            }
+        }
+    } else {
+        typename Field::raw_t raw = field.load(px, py);
+        occ = live & field.occupied(raw);
+        d = field.decode(raw, px, py);
+    }
+    hit |= occ;
+    const float tn = t + march_step<RULE>(d);
+    const bool go = live & !occ;
+    t = go ? tn : t;
+    active = go & (tn < max_range);
+}
+
+// raw range (cells) of a finished ray: the hit cell recomputed from the t of the hit probe
+__device__ __forceinline__ float ray_result(bool hit, float x0, float y0, float dx, float dy, float t, float miss) {
+    if (!hit) return miss;
+    const float xd = (float)(int)(x0 + dx * t) - x0;
+    const float yd = (float)(int)(y0 + dy * t) - y0;
+    return sqrtf(xd * xd + yd * yd);
 }
 
 // Predicated one-ray-per-lane scan: the march loop has ONE wave-level branch
@@ -291,8 +325,8 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const St
     const int nseg = sh.nseg, ndisc = sh.ndisc;
     const unsigned uW = (unsigned)W, uH = (unsigned)H;
     const unsigned tpr = (unsigned)((W + 7) >> kRectShift);
-    (void)tpr;
     const float t1 = sh.t1, r_all = sh.r_all;
+    const uint64_t nkey = (noise_std > 0.0f) ? nv::noise_stream(c.seed, genv, noise_key) : 0;
     int cr = 0, dc = 0;
     for (int k = (int)threadIdx.x; k < B; k += BLOCK) {
         float dx, dy;
@@ -300,47 +334,9 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const St
         float t = t1;
         bool active = r_all < 0.0f;
         bool hit = false;
-        while (__any(active)) {
-            float fx = x0 + dx * t;
-            float fy = y0 + dy * t;
-            int px = (int)fx, py = (int)fy;
-            bool live = active & ((unsigned)px < uW) & ((unsigned)py < uH);
-            px = live ? px : 0;
-            py = live ? py : 0;
-            bool occ;
-            float d;
-            if constexpr (RECT) {
-                // the tile's two-rectangle record (kernels_rect.hpp): exact integer d2 without touching the field;
-                // the rare probe in a tile without a valid record reads the field
-                const uint4 rec = rects[((unsigned)py >> kRectShift) * tpr + ((unsigned)px >> kRectShift)];
-                const int d2 = rect_record_d2(rec, px, py);
-                const bool inval = live & rect_record_invalid(rec);
-                occ = live & (d2 == 0);
-                d = Field::sqrt_d2(d2);
-                if (__any(inval)) {
-                    if (inval) {
-                        typename Field::raw_t raw = field.load(px, py);
-                        occ = field.occupied(raw);
-                        d = field.decode(raw, px, py);
-                    }
-                }
-            } else {
-                typename Field::raw_t raw = field.load(px, py);
-                occ = live & field.occupied(raw);
-                d = field.decode(raw, px, py);
-            }
-            hit |= occ;
-            float tn = t + march_step<RULE>(d);
-            bool go = live & !occ;
-            t = go ? tn : t;                                    // a lane that hit keeps the t of its hit probe
-            active = go & (tn < max_range);
-        }
-        float rr = (r_all >= 0.0f) ? r_all : max_range;
-        if (hit) {                                              // the hit cell, recomputed from that t
-            float xd = (float)(int)(x0 + dx * t) - x0;
-            float yd = (float)(int)(y0 + dy * t) - y0;
-            rr = sqrtf(xd * xd + yd * yd);
-        }
+        while (wave_any(active))
+            probe_round<Field, RULE, RECT>(field, (const char*)rects, tpr, x0, y0, dx, dy, uW, uH, max_range, t, active, hit);
+        float rr = ray_result(hit, x0, y0, dx, dy, t, (r_all >= 0.0f) ? r_all : max_range);
         if (TO_LDS) {                                           // pedestrians: culled merge on the LDS copy
             rng_lds[k] = rr;
             dir_lds[k] = make_float2(dx, dy);
@@ -354,7 +350,7 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const St
         rr = rr < 0.0f ? 0.0f : rr;                             // env.py:435
         rr = rr > rmax ? rmax : rr;
         if (noise_std > 0.0f && rr != rmax)                     // env.py:437-440
-            rr = rr + noise_std * nv::gauss_noise(c.seed ^ noise_key, genv, noise_key, (uint32_t)k);
+            rr = rr + noise_std * nv::gauss_noise(nkey, (uint32_t)k);
         cr |= (rr < thr[k]);
         dc |= (rr < dthr[k]);
         obs_row[(size_t)(S - 1) * B + k] = rr;
@@ -673,7 +669,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     float2* dir_lds = (float2*)dyn_lds;
     float* rng_lds = (float*)(dyn_lds + sizeof(float2) * (size_t)B);
     scan_beams_pred<BLOCK, Field, PEDS, RULE, RECT>(c, sh, field, rects, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
-                                                    st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
+                                                         st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
 
     NAVSIM_STAMP(3);
     if (!reset_only) {
@@ -733,7 +729,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             if (sh.respawn) n_hist = 0;
             int c2, d2;
             scan_beams_pred<BLOCK, Field, PEDS, RULE, RECT>(c, sh, field, rects, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
-                                                            st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
+                                                                 st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
         }
     }
 

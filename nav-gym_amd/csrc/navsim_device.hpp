@@ -217,10 +217,14 @@ __device__ __forceinline__ double discomfort_ratio(double s, float thr, float dt
     return (s - (double)thr) / (double)den;
 }
 
-// Gaussian scan noise (env.py:437-440).  Counter-based, so results do not depend on the launch
-// geometry; not bit-comparable with numpy's global Mersenne stream (tested statistically).
-__device__ __forceinline__ float gauss_noise(uint64_t seed, uint64_t genv, uint64_t step, uint32_t beam) {
-    uint64_t h = hash4(seed, genv, step, (uint64_t)beam);
+// Gaussian scan noise (env.py:437-440).  Counter-based -- keyed by (seed, global arena, episode / step / scan, beam)
+// -- so results do not depend on the launch geometry; not bit-comparable with numpy's global Mersenne stream
+// (tested statistically).  noise_stream() is the per-scan part of the key, evaluated once per thread.
+__device__ __forceinline__ uint64_t noise_stream(uint64_t seed, uint64_t genv, uint64_t scan_key) {
+    return hash4(seed ^ scan_key, genv, scan_key, 0x6E6F697365ULL);
+}
+__device__ __forceinline__ float gauss_noise(uint64_t stream, uint32_t beam) {
+    uint64_t h = mix64(stream + (uint64_t)beam * 0x9E3779B97F4A7C15ULL);
     float u1 = ((float)((h >> 40) & 0xFFFFFF) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
     float u2 = (float)((h >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);
     return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530718f * u2);

@@ -470,9 +470,18 @@ int navsim_ped_scans(const navsim_config* c, const navsim_state* st, float* out,
     size_t lds = (size_t)c->ped_n_beams * (sizeof(float2) + sizeof(float));
     hipStream_t s = (hipStream_t)stream;
     // 128 threads per pedestrian (measured 64 / 128 / 256 / 512: 1.11 / 0.78 / 0.93 / 1.50 ms on c3)
-    if (c->field_format == NAVSIM_FIELD_U16T)     ped_scan_kernel<FieldU16T, 128><<<grid, 128, lds, s>>>(*c, *st, out);
-    else if (c->field_format == NAVSIM_FIELD_F32) ped_scan_kernel<FieldF32, 128><<<grid, 128, lds, s>>>(*c, *st, out);
-    else return NAVSIM_E_UNSUPPORTED;
+    const bool f32rule = c->march_rule == NAVSIM_MARCH_F32;
+#define NAVSIM_PSCAN(F, RECT) \
+    do { if (f32rule) ped_scan_kernel<F, 128, NAVSIM_MARCH_F32, RECT><<<grid, 128, lds, s>>>(*c, *st, out); \
+         else         ped_scan_kernel<F, 128, NAVSIM_MARCH_F64, RECT><<<grid, 128, lds, s>>>(*c, *st, out); } while (0)
+    if (c->field_format == NAVSIM_FIELD_U16T) {
+        if (st->rect_table) NAVSIM_PSCAN(FieldU16T, true); else NAVSIM_PSCAN(FieldU16T, false);
+    } else if (c->field_format == NAVSIM_FIELD_F32) {
+        NAVSIM_PSCAN(FieldF32, false);
+    } else {
+        return NAVSIM_E_UNSUPPORTED;
+    }
+#undef NAVSIM_PSCAN
     return launch_status();
 }
 
