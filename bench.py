@@ -56,7 +56,11 @@ def build_sim(wl, rank, world_size, seed=1234, device="cuda:0"):
     occ = world.make_maps(E, wl["size"], seed, env_index_base=rank * E)
     goal = (10.0, 20.0) if wl["size"] >= 400 else (2.0, 4.0)
     arrays = world.make_world(cfg, occ, n_peds=wl["peds"], device=device, min_goal_dist=goal[0], max_goal_dist=goal[1],
-                              robot_clearance=1.2 if wl["size"] >= 400 else 0.9, rect_table=wl.get("rects"))
+                              robot_clearance=1.2 if wl["size"] >= 400 else 0.9,
+                              # rect records: the march's shortcut around most field reads.  Not with navsim_regen every
+                              # step: rebuilding the records of a handful of new maps is latency-bound (~0.1 ms per
+                              # step) and costs more than it saves there (c5: 2.14 M env-steps/s without, 1.54 M with)
+                              rect_table=wl.get("rects", False if wl.get("regen") else None))
     dev = torch.device(device)
     robot = wl.get("robot", "keti")
     cfg.axle_offset = robots.ROBOTS[robot]["axle_offset"]

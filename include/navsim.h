@@ -137,6 +137,19 @@ typedef struct navsim_config {
                                          (create_indoor_map, map_generator.py:97-123) instead of an outdoor one;
                                          env.py:742 indoor_ratio.  0 = outdoor only */
 
+    /* The other per-episode ranges of env_param_range (__init__.py:28-37), drawn by navsim_regen for every new
+     * episode like _sample_env_param does (env.py:281-292: 'int' = uniform over lo..hi inclusive, 'float' =
+     * uniform(lo, hi)), hash-keyed by (seed, global arena, episode). */
+    int32_t obstacle_number_hi;       /* 'obstacle_number' = obstacle_number .. obstacle_number_hi boxes (<= 64);
+                                         below obstacle_number (the default 0): always obstacle_number */
+    int32_t corridor_width_lo, corridor_width_hi;   /* 'corridor_width' (3, 4) */
+    int32_t iterations_lo, iterations_hi;           /* 'iterations' (80, 150) */
+    int32_t num_humans_lo, num_humans_hi;           /* 'num_humans': navsim_regen rewrites n_peds[e] (clipped to
+                                                       max_peds); hi = 0: n_peds[e] is kept */
+    int32_t reserved1;
+    double scan_noise_std_lo, scan_noise_std_hi;    /* 'scan_noise_std': navsim_regen rewrites scan_noise_std[e];
+                                                       hi < 0: kept */
+
     int32_t march_rule;               /* NAVSIM_MARCH_* */
     /* Launch geometry of the fused step.  Validated plain data: the library reads no environment variable. */
     int32_t step_block;               /* threads per arena: 0 = chosen from the batch size,
@@ -167,7 +180,8 @@ typedef struct navsim_state {
                                        optional accelerator, NULL = evaluate every beam direction in full */
     const float*  scan_threshold;   /* [B] env.py:162-170 */
     const float*  scan_discomfort;  /* [B] env.py:172-180 */
-    const float*  scan_noise_std;   /* [E] env_param['scan_noise_std'] (env.py:439) */
+    float*        scan_noise_std;   /* [E] env_param['scan_noise_std'] (env.py:439); navsim_regen redraws it per episode
+                                       when cfg.scan_noise_std_hi >= 0 */
 
     /* robot */
     double*  robot_pose;            /* [E,3] px, py, theta in [0, 2pi) */
@@ -179,7 +193,8 @@ typedef struct navsim_state {
     int64_t* steps;                 /* [E] steps_since_reset */
 
     /* pedestrians (ignored when ped_model == NAVSIM_PED_NONE) */
-    const int32_t* n_peds;          /* [E] live pedestrians, <= N */
+    int32_t* n_peds;                /* [E] live pedestrians, <= N; navsim_regen redraws it per episode when
+                                       cfg.num_humans_hi > 0 (env_param['num_humans'], env.py:786) */
     double*  ped_pose;              /* [E,N,3] */
     double*  ped_vel;               /* [E,N,2] world vx, vy (human.py:35-36) */
     double*  ped_prev_yaw;          /* [E,N] wrapped yaw of the pedestrian's previous obs (env.py:245-247) */

@@ -67,13 +67,21 @@ __global__ __launch_bounds__(256) void rect_transpose_kernel(const uint8_t* __re
 // ---- builder pass 2: maximal runs of occupied cells along a row.  One workgroup per row; run_lo[x] / run_hi[x] =
 // first / last cell of the run containing x, or (32767, -1) for a free cell.  Parallel: every occupied cell
 // looks for the nearest free cell on either side with two max / min scans in LDS.
-__global__ __launch_bounds__(256) void rect_runs_kernel(const uint8_t* __restrict__ occ, int16_t* __restrict__ run_lo,
-                                                        int16_t* __restrict__ run_hi, int n_rows, int len,
-                                                        const int* __restrict__ n_live) {
+__global__ __launch_bounds__(256) void rect_runs_kernel(const uint8_t* __restrict__ occ_h, int16_t* __restrict__ lo_h,
+                                                        int16_t* __restrict__ hi_h, const uint8_t* __restrict__ occ_v,
+                                                        int16_t* __restrict__ lo_v, int16_t* __restrict__ hi_v,
+                                                        int H, int W, const int* __restrict__ n_live) {
     extern __shared__ int16_t runs_lds[];                                // [2][len]: last free <= x, first free >= x
     const size_t m = blockIdx.y;
     if (n_live && (int)m >= *n_live) return;
+    // blockIdx.z = 0: rows of the grid (horizontal runs); 1: rows of the transposed grid (vertical runs)
+    const bool vert = blockIdx.z != 0;
+    const uint8_t* occ = vert ? occ_v : occ_h;
+    int16_t* run_lo = vert ? lo_v : lo_h;
+    int16_t* run_hi = vert ? hi_v : hi_h;
+    const int n_rows = vert ? W : H, len = vert ? H : W;
     const int row = blockIdx.x;
+    if (row >= n_rows) return;
     const uint8_t* o = occ + (m * (size_t)n_rows + row) * len;
     int16_t* lastf = runs_lds;
     int16_t* nextf = runs_lds + len;
@@ -238,7 +246,13 @@ __device__ __forceinline__ void rect_tile_build(const D2Src& src, const RectRunA
             const int lpx = __shfl(px, leader, 64), lpy = __shfl(py, leader, 64), ld2 = __shfl(d2, leader, 64);
             int ox, oy;
             if (!rect_nearest_obstacle(r, lpx, lpy, ld2, lane, ox, oy)) { fail = true; break; }
-            for (int order = 0; order < 2; ++order) {
+            // start with the growth order whose RUN is the longer one: the other direction is then a wall's
+            // thickness (one round of the growth loop) instead of its length (one round per 32 cells)
+            const int hlen = r.hr[(size_t)oy * r.W + ox] - r.hl[(size_t)oy * r.W + ox];
+            const int vlen = r.vb[(size_t)ox * r.H + oy] - r.vt[(size_t)ox * r.H + oy];
+            const int first_order = (hlen >= vlen) ? 0 : 1;
+            for (int oi = 0; oi < 2; ++oi) {
+                const int order = first_order ^ oi;
                 int x0, x1, y0, y1;
                 rect_grow(r, ox, oy, order, lane, x0, x1, y0, y1);
                 const unsigned lo = ((unsigned)y0 << 16) | (unsigned)x0, hi = ((unsigned)y1 << 16) | (unsigned)x1;

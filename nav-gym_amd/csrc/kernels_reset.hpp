@@ -53,12 +53,21 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
     if (b >= *count) return;
     const int e = list[b], size = c.map_w;
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
+    if (tid == 0) {                 // per-episode env_param draws that are plain state (env.py:281-292, 786, 439)
+        const uint64_t pk = nv::hash4(c.seed, genv, ep, 0x50524DULL);
+        if (c.num_humans_hi > 0 && c.ped_model != NAVSIM_PED_NONE && st.n_peds) {
+            int n = c.num_humans_lo + (int)(rg_u(pk, 1) * (double)(c.num_humans_hi - c.num_humans_lo + 1));
+            st.n_peds[e] = n > c.max_peds ? c.max_peds : n;
+        }
+        if (c.scan_noise_std_hi >= 0.0 && st.scan_noise_std)
+            st.scan_noise_std[e] = (float)(c.scan_noise_std_lo + (c.scan_noise_std_hi - c.scan_noise_std_lo) * rg_u(pk, 2));
+    }
     const bool indoor = c.regen_indoor_ratio > 0.0 && rg_u(nv::hash4(c.seed, genv, ep, 0x4B494E44ULL), 0) < c.regen_indoor_ratio;
     if (!indoor) { if (tid == 0) kind[b] = 0; return; }                  // block-uniform
     const uint64_t key = nv::hash4(c.seed, genv, ep, 0x494E44ULL);
     uint64_t n = 0;
-    const int r = 3 + (int)(rg_u(key, n++) * 2.0);
-    const int it = 80 + (int)(rg_u(key, n++) * 71.0);
+    const int r = c.corridor_width_lo + (int)(rg_u(key, n++) * (double)(c.corridor_width_hi - c.corridor_width_lo + 1));
+    const int it = c.iterations_lo + (int)(rg_u(key, n++) * (double)(c.iterations_hi - c.iterations_lo + 1));
     int G = size / 10;
     G = G < 2 * r + 8 ? 2 * r + 8 : G;
     G = G > 100 ? 100 : G;
@@ -130,7 +139,10 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
     const int hw = (int)(10.0 * w);
     int span = size - 2 * hw - 3;
     span = span < 1 ? 1 : span;
-    const int n_obs = c.obstacle_number < 64 ? c.obstacle_number : 64;
+    const int obs_hi = c.obstacle_number_hi > c.obstacle_number ? c.obstacle_number_hi : c.obstacle_number;
+    int n_obs = c.obstacle_number + (int)(rg_u(nv::hash4(c.seed, (uint64_t)(c.env_index_base + e), (uint64_t)st.episode[e], 0x50524DULL), 0) *
+                                          (double)(obs_hi - c.obstacle_number + 1));
+    n_obs = n_obs < 64 ? n_obs : 64;
     if (tid < n_obs) {
         ocx[tid] = hw + 2 + (int)(rg_u(key, 1 + 2 * (uint64_t)tid) * span);
         ocy[tid] = hw + 2 + (int)(rg_u(key, 2 + 2 * (uint64_t)tid) * span);

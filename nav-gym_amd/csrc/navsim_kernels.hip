@@ -246,6 +246,11 @@ int navsim_default_config(navsim_config* c) {
     c->v_pref_hi = 0.6;
     c->has_legs_ratio = 0.5;                // __init__.py:15
     c->regen_indoor_ratio = 0.0;
+    c->obstacle_number_hi = 0;              // = obstacle_number: __init__.py:34 is [10, 10]
+    c->corridor_width_lo = 3; c->corridor_width_hi = 4;      // __init__.py:32
+    c->iterations_lo = 80; c->iterations_hi = 150;           // __init__.py:33
+    c->num_humans_lo = 0; c->num_humans_hi = 0;              // 0: navsim_regen keeps n_peds
+    c->scan_noise_std_lo = 0.0; c->scan_noise_std_hi = -1.0; // < 0: navsim_regen keeps scan_noise_std
     c->march_rule = NAVSIM_MARCH_F64;
     c->step_block = 0;
     c->ped_split = 0;
@@ -322,8 +327,8 @@ static void launch_build_rects(const uint8_t* occ, int m, int H, int W, const vo
     int16_t* vt = hr + (size_t)m * cells;
     int16_t* vb = vt + (size_t)m * cells;
     rect_transpose_kernel<<<dim3((W + 31) / 32, (H + 31) / 32, m), 256, 0, s>>>(occ, occT, H, W, n_live);
-    rect_runs_kernel<<<dim3(H, m), 256, (size_t)W * 2 * sizeof(int16_t), s>>>(occ, hl, hr, H, W, n_live);
-    rect_runs_kernel<<<dim3(W, m), 256, (size_t)H * 2 * sizeof(int16_t), s>>>(occT, vt, vb, W, H, n_live);
+    rect_runs_kernel<<<dim3(H > W ? H : W, m, 2), 256, (size_t)(H > W ? H : W) * 2 * sizeof(int16_t), s>>>(
+        occ, hl, hr, occT, vt, vb, H, W, n_live);
     const int n_tiles = (int)rect_tiles_per_map(H, W);
     rect_tiles_kernel<<<dim3((n_tiles + 3) / 4, m), 256, 0, s>>>(occ, hl, hr, vt, vb, H, W, field, overflow, format,
                                                                 field_stride, table, n_live, list);
@@ -536,7 +541,12 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
                  size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
     if (!c || !st || !io || !io->done || !io->obs || !workspace) return NAVSIM_E_ARG;
-    if (c->map_h != c->map_w || c->n_spawn < 1 || c->regen_cap < 1 || c->obstacle_number > 64 || st->field_overflow ||
+    if (c->obstacle_number < 0 || c->corridor_width_lo < 1 ||
+        c->corridor_width_hi < c->corridor_width_lo || c->iterations_lo < 1 || c->iterations_hi < c->iterations_lo ||
+        c->num_humans_lo < 0 || (c->num_humans_hi > 0 && c->num_humans_hi < c->num_humans_lo))
+        return NAVSIM_E_ARG;
+    if (c->map_h != c->map_w || c->n_spawn < 1 || c->regen_cap < 1 || c->obstacle_number > 64 || c->obstacle_number_hi > 64 || st->field_overflow ||
+        c->corridor_width_hi > 16 ||
         (c->field_format != NAVSIM_FIELD_F32 && c->field_format != NAVSIM_FIELD_U16T) || c->shared_field)
         return NAVSIM_E_UNSUPPORTED;
     // A packed field regenerated here has no overflow plane, so no cell may reach d2 >= 65535.  Every map this

@@ -94,6 +94,16 @@ class NavsimConfig(C.Structure):
         ("v_pref_hi", C.c_double),
         ("has_legs_ratio", C.c_double),
         ("regen_indoor_ratio", C.c_double),
+        ("obstacle_number_hi", C.c_int32),
+        ("corridor_width_lo", C.c_int32),
+        ("corridor_width_hi", C.c_int32),
+        ("iterations_lo", C.c_int32),
+        ("iterations_hi", C.c_int32),
+        ("num_humans_lo", C.c_int32),
+        ("num_humans_hi", C.c_int32),
+        ("reserved1", C.c_int32),
+        ("scan_noise_std_lo", C.c_double),
+        ("scan_noise_std_hi", C.c_double),
         ("march_rule", C.c_int32),
         ("step_block", C.c_int32),
         ("ped_split", C.c_int32),

@@ -135,6 +135,10 @@ class NavGymEnv(object):
         self.randomize_maps = bool(randomize_maps)
         self.replan_cap = 1024                              # pedestrians re-planned per step, at most
         self.plan_paths = bool(plan_paths) and int(map_size) <= 1000
+        if field_format == abi.FIELD_U16T and int(map_size) > 520:
+            # reset() regenerates the maps on the device; a packed field regenerated there carries no overflow
+            # plane, which maps above 520 cells per side can need (include/navsim.h, navsim_regen)
+            field_format = abi.FIELD_F32
         spec = robots.ROBOTS[robot_type]
         nh_hi = int(env_param_range["num_humans"][0][1]) if num_humans is None else int(num_humans)
         ped = {"none": abi.PED_NONE, "external": abi.PED_EXTERNAL, "sfm": abi.PED_SFM,
@@ -150,15 +154,26 @@ class NavGymEnv(object):
             n_spawn=n_spawn, add_scan_noise=1, env_index_base=env_index_base, field_format=field_format,
             time_step=time_step, axle_offset=spec["axle_offset"], min_turning_radius=float(min_turning_radius),
             distance_threshold=distance_threshold, range_max=spec["range_max"], seed=self.seed_value)
-        cfg.regen_plan = int(self.randomize_maps and self.plan_paths)
-        cfg.regen_indoor_ratio = float(indoor_ratio) if self.randomize_maps else 0.0     # env.py:742
-        room = self.map_size * cfg.resolution                # per-episode ranges used by navsim_regen
+        # reset() -- of the whole batch and, with randomize_maps, of every finished arena -- runs on the device
+        # (navsim_regen): planning on the costmap as env.py:342-383 when plan_paths, the map kind by indoor_ratio
+        # (env.py:295), and the per-episode draws of env_param_range (env.py:281-292)
+        cfg.regen_plan = int(self.plan_paths)
+        cfg.regen_indoor_ratio = float(indoor_ratio)
+        room = self.map_size * cfg.resolution
         cfg.min_goal_dist = float(min(min_goal_dist, 0.4 * room))
         cfg.max_goal_dist = float(min(max_goal_dist, 0.8 * room))
         cfg.v_pref_lo, cfg.v_pref_hi = float(human_v_pref_range[0]), float(human_v_pref_range[1])
         cfg.has_legs_ratio = float(human_has_legs_ratio)
-        cfg.obstacle_number = int(env_param_range["obstacle_number"][0][0])
-        cfg.obstacle_width_lo, cfg.obstacle_width_hi = [float(x) for x in env_param_range["obstacle_width"][0]]
+        epr = env_param_range
+        cfg.obstacle_number, cfg.obstacle_number_hi = [int(x) for x in epr["obstacle_number"][0]]
+        cfg.obstacle_width_lo, cfg.obstacle_width_hi = [float(x) for x in epr["obstacle_width"][0]]
+        cfg.corridor_width_lo, cfg.corridor_width_hi = [int(x) for x in epr["corridor_width"][0]]
+        cfg.iterations_lo, cfg.iterations_hi = [int(x) for x in epr["iterations"][0]]
+        cfg.scan_noise_std_lo, cfg.scan_noise_std_hi = [float(x) for x in epr["scan_noise_std"][0]]
+        if num_humans is None:
+            cfg.num_humans_lo, cfg.num_humans_hi = [int(x) for x in epr["num_humans"][0]]
+        else:
+            cfg.num_humans_lo = cfg.num_humans_hi = int(num_humans)
         for i, v in enumerate(np.asarray(spec["threshold_footprint"], dtype=np.float64).reshape(-1)):
             cfg.robot_seen_footprint[i] = float(v)
         if lidar is not None:                         # (angle_min, angle_last, n_beams)
@@ -211,45 +226,40 @@ class NavGymEnv(object):
 
     # ---- reset (env.py:730-831), all arenas ---------------------------------------------------------
     def reset(self):
+        """reset() of every arena (env.py:730-831).  Nothing is generated on the host: maps, distance fields,
+        costmaps, start / goal pairs (joined by a planned path when plan_paths), pedestrians, the per-episode
+        env_param draws and the first observations all come from navsim_regen with every arena marked
+        finished (NavSim.regenerate_all)."""
         from . import lib
         lib.require_gpu()                                 # no CPU fallback: fail before any work
         import torch
         from . import sim as simmod
         cfg = self.cfg
-        seed = self.seed_value + 7919 * self._episode_batch
+        first = self.sim is None
+        if first:
+            dev = torch.device(self.device)
+            with_rects = (cfg.field_format == abi.FIELD_U16T and not self.randomize_maps and self.map_size <= 1024)
+            arrays = world.empty_world(cfg, device=self.device,
+                                       plan_paths=self.plan_paths and cfg.ped_model != abi.PED_NONE,
+                                       rect_table=with_rects)
+            for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
+                arrays[key] = simmod.scan_threshold(cfg, torch.from_numpy(robots.footprint_array(self.robot_type, name)).to(dev))
+            self.sim = simmod.NavSim(cfg, arrays, device=self.device)
+            self.scan_threshold = arrays["scan_threshold"]
+            self.scan_discomfort_threshold = arrays["scan_discomfort"]
+            if self.pedestrian_model == "policy":
+                w = self._policy_weights
+                if isinstance(w, str):
+                    w = torch.load(w, map_location="cpu")
+                self.sim.set_policy(w)
+        elif "policy_prev_actions" in self.sim.t:
+            self.sim.t["policy_prev_actions"].zero_()           # env.py:739
         self._episode_batch += 1
-        rng = np.random.default_rng(seed)
-        occ = world.make_maps(cfg.n_envs, self.map_size, seed, env_index_base=cfg.env_index_base,
-                              indoor_ratio=self.indoor_ratio)
-        lo, hi = self.env_param_range["num_humans"][0]
-        if self._num_humans_fixed is not None:
-            n_peds = int(self._num_humans_fixed)
-        else:
-            n_peds = torch.from_numpy(rng.integers(lo, hi + 1, cfg.n_envs).astype(np.int32))
-        nlo, nhi = self.env_param_range["scan_noise_std"][0]
-        room = self.map_size * cfg.resolution
-        arrays = world.make_world(
-            cfg, occ, seed=seed, n_peds=n_peds if cfg.ped_model != abi.PED_NONE else 0,
-            min_goal_dist=min(self.min_goal_dist, 0.4 * room), max_goal_dist=min(self.max_goal_dist, 0.8 * room),
-            noise_std_range=(nlo, nhi), has_legs_ratio=self.human_has_legs_ratio,
-            v_pref_range=tuple(self.human_v_pref_range), device=self.device,
-            plan_paths=self.plan_paths and cfg.ped_model != abi.PED_NONE)
-        dev = torch.device(self.device)
-        for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
-            arrays[key] = simmod.scan_threshold(cfg, torch.from_numpy(robots.footprint_array(self.robot_type, name)).to(dev))
-        self.sim = simmod.NavSim(cfg, arrays, device=self.device)
-        self.scan_threshold = arrays["scan_threshold"]
-        self.scan_discomfort_threshold = arrays["scan_discomfort"]
-        self.map_info = {"data": (occ[0].astype(np.int8) * 100), "origin": (cfg.origin_x, cfg.origin_y),
+        self.sim.regenerate_all(new_episode=not first)
+        self.map_info = {"data": (self.sim.occupancy(0).astype(np.int8) * 100), "origin": (cfg.origin_x, cfg.origin_y),
                          "resolution": cfg.resolution, "width": self.map_size, "height": self.map_size}
         n0 = int(self.sim.t["n_peds"][0]) if "n_peds" in self.sim.t else 0
         self.humans = [_AgentView(self, "human", i) for i in range(n0)]
-        if self.pedestrian_model == "policy":
-            w = self._policy_weights
-            if isinstance(w, str):
-                w = torch.load(w, map_location="cpu")
-            self.sim.set_policy(w)
-        self.sim.reset_obs()
         return self._obs_dict()
 
     def _obs_dict(self):

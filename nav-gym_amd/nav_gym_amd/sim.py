@@ -338,6 +338,50 @@ class NavSim(object):
               "navsim_regen")
         return self.obs
 
+    def regenerate_all(self, new_episode=False, scratch_bytes=4 << 30):
+        """reset() of EVERY arena on the device (env.py:730-831 for the whole batch): navsim_regen with all arenas
+        marked finished -- a new map per arena (indoor / outdoor by cfg.regen_indoor_ratio), its distance field
+        (and rect records / costmap when those buffers exist), start / goal table, robot, pedestrians, the
+        per-episode env_param draws and the first observation.  Runs in chunks of arenas so that the scratch
+        stays below `scratch_bytes`.  new_episode: bump every arena's episode counter first (a second reset()
+        must not reproduce the maps of the first)."""
+        import torch
+        E = self.cfg.n_envs
+        if new_episode:
+            self.t["episode"] += 1
+        cfg = self.cfg.copy()
+        cfg.regen_cap = 1
+        per = self.lib.navsim_regen_workspace_bytes(C.byref(cfg))
+        cfg.regen_cap = 2
+        per = max(self.lib.navsim_regen_workspace_bytes(C.byref(cfg)) - per, 1)
+        chunk = int(max(1, min(E, scratch_bytes // per)))
+        cfg.regen_cap = chunk
+        ws = torch.empty(self.lib.navsim_regen_workspace_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
+        done = torch.zeros(E, dtype=torch.uint8, device=self.device)
+        io = abi.NavsimStepIO()
+        C.memmove(C.byref(io), C.byref(self.io), C.sizeof(io))
+        io.obs = self.obs_buf[self.cur].data_ptr()
+        io.done = done.data_ptr()
+        for a in range(0, E, chunk):
+            done.zero_()
+            done[a:a + chunk] = 1
+            check(self.lib.navsim_regen(C.byref(cfg), C.byref(self.st), C.byref(io), _ptr(ws), ws.numel(), _stream()),
+                  "navsim_regen (reset of all arenas)")
+        torch.cuda.current_stream().synchronize()          # `ws` and `done` are released on return
+        return self.obs
+
+    def occupancy(self, e=0):
+        """uint8 [H, W] occupancy grid (1 = occupied) of arena e, read back from its distance field
+        (a cell is occupied exactly when its distance is 0)."""
+        H, W = self.cfg.map_h, self.cfg.map_w
+        if self.cfg.field_format == abi.FIELD_F32:
+            return (self.t["field"][e] == 0).to(_dtype("uint8")).cpu().numpy()
+        tpr, tpc = (W + 7) // 8, (H + 7) // 8
+        per = tpr * tpc * 64
+        blob = self.t["field"].reshape(-1)[e * per:(e + 1) * per].cpu().numpy().view(np.uint16)
+        tiles = blob.reshape(tpc, tpr, 8, 8).transpose(0, 2, 1, 3).reshape(tpc * 8, tpr * 8)
+        return (tiles[:H, :W] == 0).astype(np.uint8)
+
     def replan(self, max_queries=1024):
         """navsim_replan (env.py:667-680): pedestrians standing on their final waypoint get a new goal and
         the waypoints of a planned path.  Needs the resident costmap (world.make_world(plan_paths=True))."""

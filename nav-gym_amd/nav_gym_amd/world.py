@@ -249,6 +249,49 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
     return a
 
 
+def empty_world(cfg, device="cuda:0", plan_paths=False, rect_table=False):
+    """Zero-initialised navsim_state arrays for cfg.n_envs arenas: the buffers NavSim.regenerate_all() fills on the
+    device (maps, distance fields, spawn tables, robots, pedestrians, first observations -- navsim_regen with
+    every arena marked finished).  No map is generated on the host."""
+    import torch
+    from . import sim
+    dev = torch.device(device)
+    E, N, K, H, W = cfg.n_envs, cfg.max_peds, max(cfg.n_spawn, 1), cfg.map_h, cfg.map_w
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+    a = {}
+    if cfg.field_format == abi.FIELD_F32:
+        a["field"] = z((E, H, W), torch.float32)
+    else:
+        a["field"] = z(sim.load().navsim_field_bytes(E, H, W, cfg.field_format) // 2, torch.int16)
+        if rect_table:
+            a["rect_table"] = z((E, ((H + 7) // 8) * ((W + 7) // 8), 4), torch.int32)
+            a["rect_table"][:, :, 0] = 0x7FFF                  # "no valid record" until the builder has run
+    if plan_paths:
+        a["costmap"] = z((E, H // 5, W // 5), torch.uint8)
+    a["spawn_pose"] = z((E, K, 3), torch.float64)
+    a["spawn_goal"] = z((E, K, 2), torch.float64)
+    a["robot_pose"] = z((E, 3), torch.float64)
+    a["robot_goal"] = z((E, 2), torch.float64)
+    a["prev_action"] = z((E, 2), torch.float64)
+    a["prev_pose"] = z((E, 3), torch.float64)
+    a["n_hist"] = z(E, torch.int32)
+    a["episode"] = z(E, torch.int64)
+    a["steps"] = z(E, torch.int64)
+    a["scan_noise_std"] = z(E, torch.float32)
+    if cfg.ped_model != abi.PED_NONE:
+        a["n_peds"] = z(E, torch.int32)
+        a["ped_pose"] = z((E, N, 3), torch.float64)
+        a["ped_vel"] = z((E, N, 2), torch.float64)
+        a["ped_prev_yaw"] = z((E, N), torch.float64)
+        a["ped_dist"] = z((E, N, 3), torch.float64)
+        a["ped_v_pref"] = z((E, N), torch.float64)
+        a["ped_has_legs"] = z((E, N), torch.uint8)
+        a["ped_waypoints"] = z((E, N, abi.MAX_WAYPOINTS, 2), torch.float64)
+        a["ped_n_waypoints"] = torch.ones((E, N), dtype=torch.int32, device=dev)
+        a["ped_cmd"] = z((E, N, 2), torch.float64)
+    return a
+
+
 def lidar_1081(cfg):
     """270 deg / 0.25 deg planar lidar of the BASELINE configs: beams at -135 .. +135 deg inclusive."""
     cfg.n_beams = 1081

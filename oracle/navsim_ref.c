@@ -86,6 +86,11 @@ int navsim_default_config_cpu(navsim_config* c) {
     c->v_pref_hi = 0.6;
     c->has_legs_ratio = 0.5;                /* __init__.py:15 */
     c->regen_indoor_ratio = 0.0;
+    c->obstacle_number_hi = 0;
+    c->corridor_width_lo = 3; c->corridor_width_hi = 4;
+    c->iterations_lo = 80; c->iterations_hi = 150;
+    c->num_humans_lo = 0; c->num_humans_hi = 0;
+    c->scan_noise_std_lo = 0.0; c->scan_noise_std_hi = -1.0;
     c->seed = 1234;
     return NAVSIM_OK;
 }
@@ -1029,7 +1034,12 @@ static void regen_map(const navsim_config* c, uint64_t genv, uint64_t ep, uint8_
             occ[(size_t)(size - 1 - r) * size + q] = !(r >= 5 && r < size - 5 && q >= 5 && q < size - 5);
     int span = size - 2 * hw - 3;                                          /* range(hw+2, size-hw-1) */
     if (span < 1) span = 1;
-    for (int o = 0; o < c->obstacle_number; ++o) {
+    /* env_param['obstacle_number'] (env.py:281-292): uniform over lo..hi inclusive, its own key */
+    const int obs_hi = c->obstacle_number_hi > c->obstacle_number ? c->obstacle_number_hi : c->obstacle_number;
+    int n_obs = c->obstacle_number + (int)(rg_u(nvr_hash4(c->seed, genv, ep, 0x50524DULL), 0) *
+                                           (double)(obs_hi - c->obstacle_number + 1));
+    if (n_obs > 64) n_obs = 64;
+    for (int o = 0; o < n_obs; ++o) {
         int cx = hw + 2 + (int)(rg_u(key, n++) * span);
         int cy = hw + 2 + (int)(rg_u(key, n++) * span);
         for (int r = cx - hw; r <= cx + hw; ++r)
@@ -1046,8 +1056,8 @@ static void regen_map_indoor(const navsim_config* c, uint64_t genv, uint64_t ep,
     const int size = c->map_w;
     const uint64_t key = nvr_hash4(c->seed, genv, ep, 0x494E44ULL);
     uint64_t n = 0;
-    const int r = 3 + (int)(rg_u(key, n++) * 2.0);
-    const int it = 80 + (int)(rg_u(key, n++) * 71.0);
+    const int r = c->corridor_width_lo + (int)(rg_u(key, n++) * (double)(c->corridor_width_hi - c->corridor_width_lo + 1));
+    const int it = c->iterations_lo + (int)(rg_u(key, n++) * (double)(c->iterations_hi - c->iterations_lo + 1));
     int G = size / 10;
     if (G < 2 * r + 8) G = 2 * r + 8;
     if (G > 100) G = 100;
@@ -1368,6 +1378,15 @@ int navsim_regen_cpu(const navsim_config* c, const navsim_state* st, const navsi
         ++taken;
         mask[e] = 1;
         const uint64_t genv = (uint64_t)(c->env_index_base + e), ep = (uint64_t)st->episode[e];
+        {   /* per-episode env_param draws that are plain state (env.py:281-292, 786, 439) */
+            const uint64_t pk = nvr_hash4(c->seed, genv, ep, 0x50524DULL);
+            if (c->num_humans_hi > 0 && c->ped_model != NAVSIM_PED_NONE && st->n_peds) {
+                int nh = c->num_humans_lo + (int)(rg_u(pk, 1) * (double)(c->num_humans_hi - c->num_humans_lo + 1));
+                st->n_peds[e] = nh > N ? N : nh;
+            }
+            if (c->scan_noise_std_hi >= 0.0 && st->scan_noise_std)
+                st->scan_noise_std[e] = (float)(c->scan_noise_std_lo + (c->scan_noise_std_hi - c->scan_noise_std_lo) * rg_u(pk, 2));
+        }
         float* f = (float*)st->field + (size_t)e * H * W;
         if (c->regen_indoor_ratio > 0.0 && rg_u(nvr_hash4(c->seed, genv, ep, 0x4B494E44ULL), 0) < c->regen_indoor_ratio)
             regen_map_indoor(c, genv, ep, occ);

@@ -41,5 +41,5 @@ P = E * cfg.max_peds
 rows["pedestrians"] = P
 rows["env_steps_per_s"] = E / (rows["full_step_ms"] * 1e-3)
 print(json.dumps(rows, indent=1))
-os.makedirs("gpurun_out", exist_ok=True)
-json.dump(rows, open("gpurun_out/policy_cost.json", "w"), indent=1)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "policy_cost.json"), "w"), indent=1)

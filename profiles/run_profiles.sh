@@ -21,4 +21,9 @@ rocprofv3 --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TA_TA_BUSY_sum 
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq2" -o pmc -- python3 "$R/bench.py" $ARGS --no-cpu-baseline > "$OUT/pmc_sq2.log" 2>&1
 fi
 python3 "$R/profiles/summarize.py" "$OUT" > "$OUT/summary.txt" 2>&1
+# keep what is judged (stats csv, summary, traffic / pmc json, the bench line), drop the per-dispatch raw csvs:
+# gpurun only copies back 64 MiB
+cp "$OUT"/trace/*/*kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null || cp "$OUT"/trace/*kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null
+grep -h '^{"metric"' "$OUT/trace.log" | tail -1 > "$OUT/bench.json"
+rm -rf "$OUT"/trace "$OUT"/pmc_*/
 cat "$OUT/summary.txt"

@@ -842,6 +842,61 @@ def test_env_wrapper_gym_api(gpu):
     assert float(moved.max()) > 0.05 and bool(gpu.torch.isfinite(penv.sim.t["ped_pose"]).all())
 
 
+def test_env_reset_runs_on_the_device_and_matches_the_oracle(gpu, monkeypatch):
+    """NavGymEnv.reset() of 4096 arenas x 500x500 maps: no map is generated on the host (world.make_maps must not
+    be called); maps, fields, start / goal pairs joined by planned paths, pedestrians with planned waypoints, the
+    per-episode env_param draws (num_humans, obstacle_number, corridor_width, iterations, scan_noise_std:
+    env.py:281-292) and the first observations of sampled arenas equal navsim_regen_cpu run on ONE arena with
+    the same global index, bit for bit.  A second reset() draws new maps."""
+    import nav_gym_amd
+    from nav_gym_amd import world
+    def boom(*a, **k):
+        raise AssertionError("reset() generated maps on the host")
+    monkeypatch.setattr(world, "make_maps", boom)
+    monkeypatch.setattr(world, "make_world", boom)
+    kw = dict(nav_gym_amd.DEFAULT_KWARGS)
+    kw["env_param_range"] = dict(kw["env_param_range"], obstacle_number=([6, 12], 'int'))
+    E, size = 4096, 500
+    env = nav_gym_amd.NavGymEnv(num_envs=E, n_beams=1081, map_size=size, seed=11, n_spawn=8, **kw)
+    obs = env.reset()
+    o = obs["observation"].cpu().numpy()
+    assert o.shape == (E, 1088) and np.isfinite(o).all()
+    st = env.sim.numpy_state("robot_pose", "robot_goal", "spawn_pose", "spawn_goal", "n_peds", "ped_pose", "ped_v_pref",
+                             "ped_has_legs", "ped_waypoints", "ped_n_waypoints", "scan_noise_std", "episode")
+    assert st["n_peds"].min() >= 5 and st["n_peds"].max() <= 15 and len(np.unique(st["n_peds"])) > 5
+    assert 0.0 <= st["scan_noise_std"].min() and st["scan_noise_std"].max() <= 0.05 and st["scan_noise_std"].std() > 0.005
+    occupied = np.array([env.sim.occupancy(e).mean() for e in range(24)])
+    assert (occupied > 0.3).any() and (occupied < 0.2).any()          # indoor_ratio 0.5: both kinds of map
+    d = np.linalg.norm(st["robot_goal"] - st["robot_pose"][:, :2], axis=1)
+    assert np.mean((d > 10.0) & (d < 20.0)) > 0.9                      # env.py:748-783 (fallbacks are rare)
+    assert "rect_table" in env.sim.t and (st["ped_n_waypoints"] > 1).mean() > 0.5
+    # the scans of `o` carry each arena's freshly drawn scan noise (env.py:437-440; the oracle has no noise
+    # generator): compare the noise-free first observation of the same state
+    env.sim.cfg.add_scan_noise = 0
+    o_clean = env.sim.reset_obs().cpu().numpy()
+    env.sim.cfg.add_scan_noise = 1
+    assert np.array_equal(o[:, 1081:], o_clean[:, 1081:]) and 0 < np.abs(o[:, :1081] - o_clean[:, :1081]).max() < 0.5
+    cfg = env.sim.cfg
+    for e in (0, 1, 777, 2048, 4095):
+        c1 = cfg.copy(); c1.n_envs = 1; c1.env_index_base = int(e); c1.regen_cap = 1
+        host = {k: v.cpu().numpy() for k, v in gpu.world.empty_world(c1, device="cpu", plan_paths=True).items()}
+        host["field"] = np.zeros((1, size, size), np.float32)
+        host["scan_threshold"] = env.scan_threshold.cpu().numpy(); host["scan_discomfort"] = env.scan_discomfort_threshold.cpu().numpy()
+        r = ref.RefSim(c1, host)
+        r.out["done"][:] = 1
+        ro = r.regen()
+        _eq(o_clean[e:e + 1], ro, "first observation of arena %d" % e)
+        for k, v in st.items():
+            _eq(v[e:e + 1], r.a[k], "arena %d state %s" % (e, k))
+        _eq(env.sim.occupancy(e), (r.a["field"][0] == 0).astype(np.uint8), "arena %d map" % e)
+    first_maps = [env.sim.occupancy(e) for e in range(4)]
+    env.reset()
+    assert all(not np.array_equal(env.sim.occupancy(e), first_maps[e]) for e in range(4))
+    assert (env.sim.t["episode"] == 1).all()
+    out = env.step(np.tile([[0.3, 0.1]], (E, 1)))
+    assert out[0]["observation"].shape == (E, 1088)
+
+
 @pytest.fixture(scope="module", params=["c2", "c3", "c4", "c5"])
 def full_c2(gpu, request):
     """BASELINE configs at full per-GPU size, exactly as bench.py builds them (built once each):
