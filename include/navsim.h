@@ -437,6 +437,28 @@ int navsim_crowd_check(const navsim_crowd_params* p, int32_t n_envs, int32_t max
                        const double* global_time, double* reward, uint8_t* done, int32_t* info, double* min_dist,
                        void* stream);
 
+/* ---- CrowdSim-v0 local maps (crowd_sim.py:999-1186) ------------------------------------------------ */
+#define NAVSIM_CROWD_MAX_VERTS 8
+typedef struct navsim_crowd_map_params {
+    double angular_min, angular_max;    /* angular_map_min_angle / max_angle (config angle_min / angle_max x pi) */
+    double angular_max_range;           /* angular_map_max_range */
+    int32_t angular_dim;                /* angular_map_dim */
+    int32_t normalize;                  /* get_local_map_angular(normalize=True) */
+    double map_size_m, map_resolution, submap_size_m;     /* get_local_map */
+} navsim_crowd_map_params;
+/* get_local_map_angular (crowd_sim.py:1055-1102) with calculate_angular_map_distances (crowd_sim.py:999-1053): per
+ * env the distance to the closest obstacle outline in each of angular_dim sectors of the robot frame, float64.
+ * robot [E,4] = px, py, theta, radius; verts [E, max_obst, n_vert, 2] (n_vert <= NAVSIM_CROWD_MAX_VERTS, the
+ * reference's obstacles have 4: crowd_sim.py:250-258); n_obst [E] or NULL (= max_obst); out [E, angular_dim]. */
+int navsim_crowd_angular_map(const navsim_crowd_map_params* p, int32_t n_envs, int32_t max_obst, int32_t n_vert,
+                             const double* robot, const double* verts, const int32_t* n_obst, double* out, void* stream);
+/* get_local_map (crowd_sim.py:1104-1166): the binary submap of submap_size_m around the robot, rotated into its
+ * heading (rotate_grid_around_center, crowd_sim.py:1168-1186; rotate = 0 skips the rotation) and thresholded at
+ * 0.9.  free_map [E,G,G] uint8 (1 = free) indexed [x][y] like CrowdSim.map; robot as above; out [E,S,S] uint8 with
+ * S = round(submap_size_m / map_resolution). */
+int navsim_crowd_local_map(const navsim_crowd_map_params* p, int32_t n_envs, int32_t grid, const uint8_t* free_map,
+                           const double* robot, int32_t rotate, uint8_t* out, void* stream);
+
 /* First observation after reset() (env.py:822-831): scan at the current robot pose, stack filled
  * with copies, prev_pose = pose, vel = 0; sets prev_pose/prev_action/n_hist.  `mask` [E] uint8 or
  * NULL selects which envs are (re)initialised; others keep obs_prev -> obs copied through. */

@@ -21,6 +21,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 #include <atomic>
@@ -56,6 +57,7 @@ __device__ unsigned long long* g_stamps = nullptr;
 #include "kernels_reset.hpp"
 #include "kernels_policy.hpp"
 #include "kernels_pedscan.hpp"
+#include "kernels_crowd_maps.hpp"
 
 // kernels that want more than 64 KB of dynamic LDS must say so once; more than the CU has is refused
 constexpr size_t kLdsPerCu = 160 * 1024;
@@ -727,6 +729,30 @@ int navsim_crowd_check(const navsim_crowd_params* p, int32_t n_envs, int32_t max
     if (n_envs == 0) return NAVSIM_OK;
     crowd_check_kernel<<<n_envs, 64, 0, (hipStream_t)stream>>>(*p, max_agents, grid, free_map, robot, agents, n_agents,
                                                                global_time, reward, done, info, min_dist);
+    return launch_status();
+}
+
+int navsim_crowd_angular_map(const navsim_crowd_map_params* p, int32_t n_envs, int32_t max_obst, int32_t n_vert,
+                             const double* robot, const double* verts, const int32_t* n_obst, double* out, void* stream) {
+    (void)hipGetLastError();
+    if (!p || !robot || !out || n_envs < 0 || max_obst < 0 || n_vert < 1 || n_vert > NAVSIM_CROWD_MAX_VERTS ||
+        p->angular_dim < 1 || (max_obst > 0 && !verts))
+        return NAVSIM_E_ARG;
+    if (p->angular_dim > 4096) return NAVSIM_E_UNSUPPORTED;
+    if (n_envs == 0) return NAVSIM_OK;
+    crowd_angular_map_kernel<<<n_envs, 64, (size_t)p->angular_dim * sizeof(unsigned long long), (hipStream_t)stream>>>(
+        *p, max_obst, n_vert, robot, verts, n_obst, out);
+    return launch_status();
+}
+
+int navsim_crowd_local_map(const navsim_crowd_map_params* p, int32_t n_envs, int32_t grid, const uint8_t* free_map,
+                           const double* robot, int32_t rotate, uint8_t* out, void* stream) {
+    (void)hipGetLastError();
+    if (!p || !free_map || !robot || !out || n_envs < 0 || grid < 1) return NAVSIM_E_ARG;
+    const int S = (int)nearbyint(p->submap_size_m / p->map_resolution);
+    if (S < 1 || (size_t)S * S > 64 * 1024) return NAVSIM_E_UNSUPPORTED;           // the window lives in LDS
+    if (n_envs == 0) return NAVSIM_OK;
+    crowd_local_map_kernel<<<n_envs, 256, (size_t)S * S, (hipStream_t)stream>>>(*p, grid, S, free_map, robot, rotate, out);
     return launch_status();
 }
 

@@ -150,6 +150,13 @@ class NavsimCrowdParams(C.Structure):
         "discomfort_penalty_factor", "rotation_penalty_factor", "timeout_penalty", "time_limit")]
 
 
+class NavsimCrowdMapParams(C.Structure):
+    _fields_ = [("angular_min", C.c_double), ("angular_max", C.c_double), ("angular_max_range", C.c_double),
+                ("angular_dim", C.c_int32), ("normalize", C.c_int32), ("map_size_m", C.c_double),
+                ("map_resolution", C.c_double), ("submap_size_m", C.c_double)]
+
+
+CROWD_MAX_VERTS = 8
 CROWD_INFO = ("Nothing", "Timeout", "ReachGoal", "Collision", "CollisionOtherAgent", "Danger")
 
 
@@ -269,6 +276,9 @@ def declare(lib, suffix=""):
         sig("navsim_regen_workspace_bytes", [cfgp], C.c_size_t)
         sig("navsim_regen", [cfgp, stp, iop, _P, C.c_size_t, _P])
     sig("navsim_crowd_check", [C.POINTER(NavsimCrowdParams), i32, i32, i32, _P, _P, _P, _P, _P, _P, _P, _P, _P] + stream)
+    mpp = C.POINTER(NavsimCrowdMapParams)
+    sig("navsim_crowd_angular_map", [mpp, i32, i32, i32, _P, _P, _P, _P] + stream)
+    sig("navsim_crowd_local_map", [mpp, i32, i32, _P, _P, i32, _P] + stream)
     sig("navsim_step", [cfgp, stp, iop] + stream)
     sig("navsim_reset_obs", [cfgp, stp, iop, _P] + stream)
     return lib
@@ -283,6 +293,6 @@ EXPORTS = (
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
     "navsim_scan_threshold", "navsim_beam_table", "navsim_ped_scans", "navsim_regen_workspace_bytes", "navsim_regen",
     "navsim_costmap", "navsim_plan", "navsim_launch_order", "navsim_replan_workspace_bytes", "navsim_replan", "navsim_ped_policy_workspace_bytes", "navsim_ped_policy",
-    "navsim_crowd_check", "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
+    "navsim_crowd_check", "navsim_crowd_angular_map", "navsim_crowd_local_map", "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math", "navsim_debug_xy_to_ij",
 )

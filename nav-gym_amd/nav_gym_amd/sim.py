@@ -200,6 +200,43 @@ def crowd_check(params, free_map, robot, agents, global_time, n_agents=None):
     return reward, done, info, md
 
 
+def _crowd_map_params(params):
+    p = abi.NavsimCrowdMapParams()
+    for k, v in params.items():
+        setattr(p, k, int(v) if k in ("angular_dim", "normalize") else float(v))
+    return p
+
+
+def crowd_angular_map(params, robot, verts, n_obst=None):
+    """navsim_crowd_angular_map: CrowdSim.get_local_map_angular (crowd_sim.py:1055-1102) for E envs.
+    robot [E,4] px, py, theta, radius; verts [E,O,V,2]; -> float64 [E, angular_dim]."""
+    torch = require_gpu()
+    p = _crowd_map_params(params)
+    robot = robot.to(torch.float64).contiguous()
+    E = robot.shape[0]
+    verts = verts.to(torch.float64).contiguous()
+    O, V = (verts.shape[1], verts.shape[2]) if verts.numel() else (0, 4)
+    no = None if n_obst is None else n_obst.to(device=robot.device, dtype=torch.int32).contiguous()
+    out = torch.empty((E, p.angular_dim), dtype=torch.float64, device=robot.device)
+    check(load().navsim_crowd_angular_map(C.byref(p), E, O, V, _ptr(robot), _ptr(verts) if O else None, _ptr(no), _ptr(out),
+                                          _stream()), "navsim_crowd_angular_map")
+    return out
+
+
+def crowd_local_map(params, free_map, robot, rotate=True):
+    """navsim_crowd_local_map: CrowdSim.get_local_map (crowd_sim.py:1104-1186) for E envs -> uint8 [E,S,S]."""
+    torch = require_gpu()
+    p = _crowd_map_params(params)
+    free_map = free_map.to(torch.uint8).contiguous()
+    E, G = free_map.shape[0], free_map.shape[1]
+    robot = robot.to(torch.float64).contiguous()
+    S = int(round(p.submap_size_m / p.map_resolution))
+    out = torch.empty((E, S, S), dtype=torch.uint8, device=free_map.device)
+    check(load().navsim_crowd_local_map(C.byref(p), E, G, _ptr(free_map), _ptr(robot), int(bool(rotate)), _ptr(out),
+                                        _stream()), "navsim_crowd_local_map")
+    return out
+
+
 def debug_xy_to_ij(cfg, xy, as_f32):
     """Device batch_xy_to_ij (env.py:1228-1253): xy float64 CUDA [n,2] -> int32 [n,2] (i, j)."""
     torch = require_gpu()

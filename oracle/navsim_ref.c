@@ -1663,3 +1663,179 @@ int navsim_crowd_check_cpu(const navsim_crowd_params* p, int32_t n_envs, int32_t
     }
     return NAVSIM_OK;
 }
+
+/* =========================================================================================
+ * CrowdSim-v0 local maps (nav_gym/src/crowd_sim/envs/crowd_sim.py:999-1186), SURVEY.md 8f #4.
+ *
+ * get_local_map_angular + calculate_angular_map_distances (crowd_sim.py:999-1102): pure NumPy / math in
+ * the reference, float64, restated call by call; pinned by tests/golden/golden_crowd_maps.npz (recorded
+ * from the reference's own functions).  cos / sin / atan2 are the deterministic nvr_* functions (<= 1 ulp
+ * from libm): values agree with the goldens to 1e-12.
+ * ======================================================================================= */
+typedef struct { int idx; double x, y; } amap_seen;
+
+static void amap_min(double* rdv, int j, double v) { if (v < rdv[j]) rdv[j] = v; }
+
+/* calculate_angular_map_distances (crowd_sim.py:999-1053): `seen` is (rad_indeces, locations) */
+static void amap_calc(const navsim_crowd_map_params* p, double vx, double vy, double ex, double ey, double ct, double st,
+                      double* rdv, amap_seen* seen, int* n_seen) {
+    const int dim = p->angular_dim;
+    const double res = (p->angular_max - p->angular_min) / (double)dim;
+    double px = (vx - ex) * ct + (vy - ey) * st;
+    double py = (vy - ey) * ct - (vx - ex) * st;
+    const double phi = nvr_atan2(py, px);
+    const int rad_idx = (int)((phi - p->angular_min) / res);               /* int(): toward zero */
+    const double distance = sqrt(px * px + py * py);
+    if (rad_idx >= 0 && rad_idx < dim) amap_min(rdv, rad_idx, distance);
+    for (int s = 0; s < *n_seen; ++s) {
+        const int old = seen[s].idx;
+        const double lx = seen[s].x, ly = seen[s].y;
+        int wrapped, idx_diff;
+        if ((double)abs(rad_idx - old) > NVR_PI / res) {
+            wrapped = 1;
+            idx_diff = (rad_idx > old) ? dim - rad_idx + old : dim - old + rad_idx;
+        } else {
+            wrapped = 0;
+            idx_diff = abs(rad_idx - old);
+        }
+        for (int i = 0; i < idx_diff; ++i) {
+            const double f = (double)i / (double)idx_diff;
+            if ((rad_idx < old && !wrapped) || (rad_idx > old && wrapped)) {
+                if (rad_idx + i >= 0 && rad_idx + i < dim) {
+                    const double X = vx + f * (lx - vx) - ex, Y = vy + f * (ly - vy) - ey;
+                    px = X * ct + Y * st;
+                    py = Y * ct - X * st;
+                    amap_min(rdv, (rad_idx + i) % dim, sqrt(px * px + py * py));
+                }
+            } else {
+                if (old + i >= 0 && old + i < dim) {
+                    const double X = lx + f * (vx - lx) - ex, Y = ly + f * (vy - ly) - ey;
+                    px = X * ct + Y * st;
+                    py = Y * ct - X * st;
+                    amap_min(rdv, (old + i) % dim, sqrt(px * px + py * py));
+                }
+            }
+        }
+    }
+    seen[*n_seen].idx = rad_idx; seen[*n_seen].x = vx; seen[*n_seen].y = vy;
+    ++*n_seen;
+}
+
+/* robot [E,4] = px, py, theta, radius; verts [E, max_obst, n_vert, 2]; n_obst [E] or NULL (= max_obst);
+ * out [E, angular_dim] */
+int navsim_crowd_angular_map_cpu(const navsim_crowd_map_params* p, int32_t n_envs, int32_t max_obst, int32_t n_vert,
+                                 const double* robot, const double* verts, const int32_t* n_obst, double* out) {
+    if (!p || !robot || !out || n_envs < 0 || max_obst < 0 || n_vert < 1 || n_vert > NAVSIM_CROWD_MAX_VERTS ||
+        p->angular_dim < 1 || (max_obst > 0 && !verts))
+        return NAVSIM_E_ARG;
+    const int dim = p->angular_dim;
+    static const int s1[4] = {-1, 1, -1, 1}, s2[4] = {-1, -1, 1, 1};       /* crowd_sim.py:1073 */
+    for (int e = 0; e < n_envs; ++e) {
+        const double* r = robot + (size_t)e * 4;
+        double* rdv = out + (size_t)e * dim;
+        for (int k = 0; k < dim; ++k) rdv[k] = p->angular_max_range;
+        double st, ct;
+        nvr_sincos(r[2], &st, &ct);
+        double edge[4][2];
+        for (int k = 0; k < 4; ++k) { edge[k][0] = r[0] + s1[k] * r[3]; edge[k][1] = r[1] + s2[k] * r[3]; }
+        int no = n_obst ? n_obst[e] : max_obst;
+        if (no > max_obst) no = max_obst;
+        amap_seen seen[NAVSIM_CROWD_MAX_VERTS > 4 ? NAVSIM_CROWD_MAX_VERTS : 4];
+        for (int o = 0; o < no; ++o) {                                     /* crowd_sim.py:1077-1083 */
+            const double* vv = verts + ((size_t)e * max_obst + o) * n_vert * 2;
+            for (int k = 0; k < 4; ++k) {
+                int ns = 0;
+                for (int v = 0; v < n_vert; ++v)
+                    amap_calc(p, vv[2 * v], vv[2 * v + 1], edge[k][0], edge[k][1], ct, st, rdv, seen, &ns);
+            }
+        }
+        for (int o = 0; o < no; ++o) {                                     /* crowd_sim.py:1085-1091 */
+            const double* vv = verts + ((size_t)e * max_obst + o) * n_vert * 2;
+            for (int v = 0; v < n_vert; ++v) {
+                int ns = 0;
+                for (int k = 0; k < 4; ++k)
+                    amap_calc(p, vv[2 * v], vv[2 * v + 1], edge[k][0], edge[k][1], ct, st, rdv, seen, &ns);
+            }
+        }
+        if (p->normalize)                                                  /* crowd_sim.py:1093-1094 */
+            for (int k = 0; k < dim; ++k) rdv[k] = rdv[k] / p->angular_max_range;
+    }
+    return NAVSIM_OK;
+}
+
+/* get_local_map + rotate_grid_around_center (crowd_sim.py:1104-1186).
+ *   Window (pure Python in the reference, pinned by goldens recorded with an identity stand-in for the
+ *   rotation): centre cell int(round((p + map_size_m/2) / res)) with Python's round-half-even, size
+ *   int(round(submap_size_m / res)), one-sided clipping at the map border, and the reference's exclusive
+ *   slice ends -- the copied block is (size - 1) cells wide, the last row / column of the grid stays 1.
+ *   Rotation: cv2.getRotationMatrix2D(center = (rows/2, cols/2), angle in degrees, 1) + cv2.warpAffine(grid, M,
+ *   (rows, cols), borderValue = 1) with the defaults INTER_LINEAR / BORDER_CONSTANT.  cv2 is not installed here:
+ *   [UPSTREAM-RECALL, unpinned] OpenCV inverts M, walks the destination pixels with 10-bit fixed-point source
+ *   coordinates (AB_BITS = 10, rounded to 1/32 pixel: INTER_BITS = 5) and blends the four neighbours with the
+ *   weights (1-fx)(1-fy), fx(1-fy), (1-fx)fy, fx fy; a neighbour outside the source reads borderValue.  Source
+ *   values are 0 / 1 and the weights multiples of 1/1024, so the blend is exact and the 0.9 threshold sharp.
+ *   free_map [E,G,G] uint8 (1 = free) indexed [x][y] like CrowdSim.map; out [E,S,S] uint8 (1 = free). */
+static inline int py_round_int(double v) { return (int)nearbyint(v); }     /* default rounding mode: half-even */
+
+int navsim_crowd_local_map_cpu(const navsim_crowd_map_params* p, int32_t n_envs, int32_t grid, const uint8_t* free_map,
+                               const double* robot, int32_t rotate, uint8_t* out) {
+    if (!p || !free_map || !robot || !out || n_envs < 0 || grid < 1) return NAVSIM_E_ARG;
+    const int S = py_round_int(p->submap_size_m / p->map_resolution);
+    if (S < 1 || S > 1024) return NAVSIM_E_UNSUPPORTED;
+    double* g = (double*)malloc((size_t)S * S * sizeof(double));
+    for (int e = 0; e < n_envs; ++e) {
+        const double* r = robot + (size_t)e * 4;
+        const uint8_t* m = free_map + (size_t)e * grid * grid;
+        uint8_t* o = out + (size_t)e * S * S;
+        const int cx = py_round_int((r[0] + p->map_size_m / 2.0) / p->map_resolution);
+        const int cy = py_round_int((r[1] + p->map_size_m / 2.0) / p->map_resolution);
+        int sx = py_round_int((double)cx - floor((double)S / 2.0)), sy = py_round_int((double)cy - floor((double)S / 2.0));
+        int ex = sx + S - 1, ey = sy + S - 1;
+        const int mx = grid - 1, my = grid - 1;
+        int gsx = 0, gsy = 0, gex = S - 1, gey = S - 1;
+        if (sx < 0) { gsx = -sx; sx = 0; } else if (ex > mx) { gex = gex - (ex - mx); ex = mx; }
+        if (sy < 0) { gsy = -sy; sy = 0; } else if (ey > my) { gey = gey - (ey - my); ey = my; }
+        for (int k = 0; k < S * S; ++k) g[k] = 1.0;
+        if (gsy > gey || sy > ey || sx > ex || gsx > gex) {                /* crowd_sim.py:1152-1154: all ones */
+            for (int k = 0; k < S * S; ++k) o[k] = 1;
+            continue;
+        }
+        for (int a = 0; a < gex - gsx && a < ex - sx; ++a)                 /* exclusive slice ends */
+            for (int b = 0; b < gey - gsy && b < ey - sy; ++b)
+                g[(size_t)(gsx + a) * S + (gsy + b)] = (double)m[(size_t)(sx + a) * grid + (sy + b)];
+        if (!rotate) {
+            for (int k = 0; k < S * S; ++k) o[k] = g[k] > 0.9;
+            continue;
+        }
+        /* getRotationMatrix2D: angle in degrees, positive = counter-clockwise (image coordinates) */
+        const double angle = (-r[2] + NVR_PI / 2.0) * 180.0 / NVR_PI;
+        double sa, ca;
+        nvr_sincos(angle * NVR_PI / 180.0, &sa, &ca);
+        const double cxr = (double)S / 2.0, cyr = (double)S / 2.0;
+        double M[6] = {ca, sa, (1.0 - ca) * cxr - sa * cyr, -sa, ca, sa * cxr + (1.0 - ca) * cyr};
+        /* warpAffine: invert M (it maps source -> destination) */
+        double D = M[0] * M[4] - M[1] * M[3];
+        D = D != 0.0 ? 1.0 / D : 0.0;
+        const double A11 = M[4] * D, A22 = M[0] * D;
+        const double i0 = A11, i1 = M[1] * (-D), i3 = M[3] * (-D), i4 = A22;
+        const double b1 = -i0 * M[2] - i1 * M[5], b2 = -i3 * M[2] - i4 * M[5];
+        for (int y = 0; y < S; ++y) {                                      /* dst(y, x): row y, column x */
+            const int X0 = (int)lrint((i1 * y + b1) * 1024.0) + 16, Y0 = (int)lrint((i4 * y + b2) * 1024.0) + 16;
+            for (int x = 0; x < S; ++x) {
+                const int X = ((int)lrint(i0 * x * 1024.0) + X0) >> 5, Y = ((int)lrint(i3 * x * 1024.0) + Y0) >> 5;
+                const int ix = X >> 5, iy = Y >> 5;
+                const double fx = (double)(X & 31) / 32.0, fy = (double)(Y & 31) / 32.0;
+                double v[4];
+                for (int t = 0; t < 4; ++t) {
+                    const int xx = ix + (t & 1), yy = iy + (t >> 1);
+                    v[t] = (xx >= 0 && xx < S && yy >= 0 && yy < S) ? g[(size_t)yy * S + xx] : 1.0;
+                }
+                const double val = v[0] * ((1.0 - fx) * (1.0 - fy)) + v[1] * (fx * (1.0 - fy)) + v[2] * ((1.0 - fx) * fy) +
+                                   v[3] * (fx * fy);
+                o[(size_t)y * S + x] = val > 0.9;
+            }
+        }
+    }
+    free(g);
+    return NAVSIM_OK;
+}

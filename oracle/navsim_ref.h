@@ -107,6 +107,12 @@ int navsim_leg_odometry_cpu(const double* pose, const double* vel, const double*
  * 3 exp_neg, 4 wrap_pi, 5 mod_2pi */
 int navsim_math_cpu(int32_t fn, const double* x, const double* x2, double* out, int32_t n);
 
+/* CrowdSim-v0 local maps (crowd_sim.py:999-1186); see include/navsim.h navsim_crowd_angular_map / _local_map */
+int navsim_crowd_angular_map_cpu(const navsim_crowd_map_params* p, int32_t n_envs, int32_t max_obst, int32_t n_vert,
+                                 const double* robot, const double* verts, const int32_t* n_obst, double* out);
+int navsim_crowd_local_map_cpu(const navsim_crowd_map_params* p, int32_t n_envs, int32_t grid, const uint8_t* free_map,
+                               const double* robot, int32_t rotate, uint8_t* out);
+
 /* statistics for DESIGN.md: distance-field probes of the last cast/step on this thread */
 int64_t navsim_probe_count_cpu(int32_t reset);
 

@@ -242,6 +242,38 @@ def crowd_check(params, free_map, robot, agents, global_time, n_agents=None):
     return reward, done, info, md
 
 
+def _crowd_map_params(params):
+    p = abi.NavsimCrowdMapParams()
+    for k, v in params.items():
+        setattr(p, k, int(v) if k in ("angular_dim", "normalize") else float(v))
+    return p
+
+
+def crowd_angular_map(params, robot, verts, n_obst=None):
+    p = _crowd_map_params(params)
+    robot = np.ascontiguousarray(robot, dtype=np.float64).reshape(-1, 4)
+    E = robot.shape[0]
+    verts = np.ascontiguousarray(verts, dtype=np.float64)
+    O, V = (verts.shape[1], verts.shape[2]) if verts.size else (0, 4)
+    no = None if n_obst is None else np.ascontiguousarray(n_obst, dtype=np.int32)
+    out = np.zeros((E, p.angular_dim))
+    _chk(lib().navsim_crowd_angular_map_cpu(C.byref(p), E, O, V, _p(robot), _p(verts) if O else None, _p(no), _p(out)),
+         "crowd_angular_map")
+    return out
+
+
+def crowd_local_map(params, free_map, robot, rotate=True):
+    p = _crowd_map_params(params)
+    free_map = np.ascontiguousarray(free_map, dtype=np.uint8)
+    E, G = free_map.shape[0], free_map.shape[1]
+    robot = np.ascontiguousarray(robot, dtype=np.float64).reshape(E, 4)
+    S = int(round(p.submap_size_m / p.map_resolution))
+    out = np.zeros((E, S, S), np.uint8)
+    _chk(lib().navsim_crowd_local_map_cpu(C.byref(p), E, G, _p(free_map), _p(robot), int(bool(rotate)), _p(out)),
+         "crowd_local_map")
+    return out
+
+
 def math_fn(fn, x, x2=None):
     x = np.ascontiguousarray(x, dtype=np.float64)
     x2a = None if x2 is None else np.ascontiguousarray(x2, dtype=np.float64)

@@ -603,7 +603,88 @@ def make_crowd():
     print("golden_crowd.npz: n=%d" % n, {k: int((code == v).sum()) for k, v in codes.items()})
 
 
+# --------------------------------------------------------------------------------------------
+# CrowdSim-v0 local maps (crowd_sim.py:999-1186): SURVEY.md 8f #4
+# --------------------------------------------------------------------------------------------
+def make_crowd_maps():
+    """get_local_map_angular (+ calculate_angular_map_distances) of the reference itself on 400 random situations
+    (1-5 axis-aligned obstacles with the reference's vertex order, crowd_sim.py:250-258, robots anywhere incl.
+    next to and inside obstacles' bounding boxes), and get_local_map's window logic (centre cell, clipping at the
+    map border, exclusive slice ends, 0.9 threshold) on 200 situations with rotate_grid_around_center replaced by
+    the identity (cv2 is not installed; the rotation is restated from OpenCV's documented algorithm and is
+    UNPINNED: oracle/navsim_ref.c)."""
+    import importlib
+    from collections import namedtuple
+    for name in ("gym", "gym.envs", "gym.envs.registration", "rvo2", "cv2", "tensorflow", "PIL", "matplotlib",
+                 "crowd_nav", "crowd_nav.policy", "crowd_nav.policy.policy_factory"):
+        try:
+            importlib.import_module(name)
+        except Exception:
+            sys.modules[name] = types.ModuleType(name)
+    if not hasattr(sys.modules["gym"], "Env"):
+        sys.modules["gym"].Env = object
+    if not hasattr(sys.modules["gym.envs.registration"], "register"):
+        sys.modules["gym.envs.registration"].register = lambda **k: None
+    sys.modules["crowd_nav.policy.policy_factory"].policy_factory = {}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from crowd_sim.envs import crowd_sim as cs
+    State = namedtuple("State", ["px", "py", "theta", "radius"])
+    rng = np.random.default_rng(33)
+    n, O, dim = 400, 5, 72
+    P = dict(angular_min=-np.pi, angular_max=np.pi, angular_max_range=6.0, angular_dim=dim, normalize=1,
+             map_size_m=14.0, map_resolution=0.1, submap_size_m=6.0)          # test_soadrl_static.config [map]
+    robot = np.zeros((n, 4)); verts = np.zeros((n, O, 4, 2)); n_obst = np.zeros(n, np.int32)
+    amap = np.zeros((n, dim))
+    for k in range(n):
+        no = int(rng.integers(1, O + 1))
+        n_obst[k] = no
+        obst = []
+        for o in range(no):
+            cx, cy = rng.uniform(-5, 5, 2); hx, hy = rng.uniform(0.15, 1.6, 2)
+            vs = [(cx + hx, cy + hy), (cx - hx, cy + hy), (cx - hx, cy - hy), (cx + hx, cy - hy)]
+            verts[k, o] = vs
+            obst.append(vs)
+        pos = rng.uniform(-6, 6, 2)
+        if k % 5 == 0:                                       # close to an obstacle corner
+            pos = verts[k, 0, rng.integers(4)] + rng.uniform(-0.6, 0.6, 2)
+        robot[k] = [pos[0], pos[1], rng.uniform(-np.pi, np.pi), rng.uniform(0.2, 0.4)]
+        env = object.__new__(cs.CrowdSim)
+        env.angular_map_max_range, env.angular_map_dim = P["angular_max_range"], dim
+        env.angular_map_min_angle, env.angular_map_max_angle = P["angular_min"], P["angular_max"]
+        env.obstacle_vertices = obst
+        env.local_maps_angular = []
+        amap[k] = cs.CrowdSim.get_local_map_angular(env, State(*robot[k]))
+    # get_local_map window logic, identity rotation
+    m, G = 200, 140
+    S = int(round(P["submap_size_m"] / P["map_resolution"]))
+    maps = np.ones((m, G, G), np.uint8); rob2 = np.zeros((m, 4)); lmap = np.zeros((m, S, S), np.uint8)
+    for k in range(m):
+        for _ in range(rng.integers(1, 6)):
+            x0, y0 = rng.integers(0, G - 20, 2); w, h = rng.integers(2, 25, 2)
+            maps[k, x0:x0 + w, y0:y0 + h] = 0
+        pos = rng.uniform(-6.9, 6.9, 2) if k % 2 else rng.uniform(-3.9, 3.9, 2)     # odd k: windows clipped by the border
+        if k % 10 == 0:
+            pos = np.round(pos, 1) + 0.05                    # ties of Python's round-half-even
+        rob2[k] = [pos[0], pos[1], rng.uniform(-np.pi, np.pi), 0.3]
+        env = object.__new__(cs.CrowdSim)
+        env.map = maps[k].astype(np.float64)
+        env.map_size_m, env.map_resolution, env.submap_size_m = P["map_size_m"], P["map_resolution"], P["submap_size_m"]
+        env.local_maps = []
+        env.rotate_grid_around_center = lambda grid, angle: grid          # stand-in: cv2 absent
+        lmap[k] = cs.CrowdSim.get_local_map(env, State(*rob2[k]))
+    np.savez_compressed(os.path.join(HERE, "golden_crowd_maps.npz"), robot=robot, verts=verts, n_obst=n_obst, amap=amap,
+                        params=np.array([P[k] for k in sorted(P)]), param_names=np.array(sorted(P)),
+                        maps=np.packbits(maps), map_shape=np.array(maps.shape), robot2=rob2, lmap=np.packbits(lmap),
+                        lmap_shape=np.array(lmap.shape))
+    print("golden_crowd_maps.npz: angular n=%d (%.1f %% of sectors below max range), windows m=%d (%.1f %% occupied)"
+          % (n, 100 * (amap < 1.0).mean(), m, 100 * (lmap == 0).mean()))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "crowd_maps":      # only this fixture (the others stay byte-identical)
+        return make_crowd_maps()
     ref_env, human, keti_robot, ref_utils, human_policy = import_reference()
     make_units(ref_env, human, keti_robot, ref_utils)
     run_trace("random_S1", ref_env, human, human_policy, S=1, seed=11, scenario="random", n_steps=40, ped_scan_every=5)
@@ -611,6 +692,7 @@ def main():
     run_trace("crash_S3", ref_env, human, human_policy, S=3, seed=13, scenario="crash", n_steps=24)
     run_trace("success_S2", ref_env, human, human_policy, S=2, seed=14, scenario="success", n_steps=12)
     make_crowd()
+    make_crowd_maps()
 
 
 if __name__ == "__main__":

@@ -749,6 +749,41 @@ def test_crowd_check_vs_reference_and_oracle(gpu):
     assert len(np.unique(exp[2])) >= 4
 
 
+def test_crowd_local_maps_vs_reference_and_oracle(gpu, golden_dir):
+    """CrowdSim-v0 local maps on the device: get_local_map_angular equals the oracle bit for
+    bit (same deterministic math, order-independent min) and the reference's recorded maps to 1e-12; get_local_map's
+    window equals the reference's recorded windows exactly; with the rotation (restated from OpenCV, unpinned) the
+    device equals the oracle on random headings, ragged obstacle counts and windows clipped by the map border."""
+    d = np.load(os.path.join(golden_dir, "golden_crowd_maps.npz"))
+    P = {str(k): float(v) for k, v in zip(d["param_names"], d["params"])}
+    maps = np.unpackbits(d["maps"])[: int(np.prod(d["map_shape"]))].reshape(d["map_shape"])
+    lmap = np.unpackbits(d["lmap"])[: int(np.prod(d["lmap_shape"]))].reshape(d["lmap_shape"])
+    got = gpu.sim.crowd_angular_map(P, _t(gpu, d["robot"]), _t(gpu, d["verts"]), _t(gpu, d["n_obst"])).cpu().numpy()
+    _eq(got, ref.crowd_angular_map(P, d["robot"], d["verts"], d["n_obst"]), "angular map vs oracle")
+    np.testing.assert_allclose(got, d["amap"], rtol=0, atol=1e-12)
+    w = gpu.sim.crowd_local_map(P, _t(gpu, maps), _t(gpu, d["robot2"]), rotate=False).cpu().numpy()
+    _eq(w, lmap, "local-map window vs the reference")
+    r = gpu.sim.crowd_local_map(P, _t(gpu, maps), _t(gpu, d["robot2"]), rotate=True).cpu().numpy()
+    _eq(r, ref.crowd_local_map(P, maps, d["robot2"], rotate=True), "rotated local map vs oracle")
+    assert not np.array_equal(r, w)
+    # a larger random batch, other parameters: 5000 envs, 36 sectors over the front half plane, 8-vertex outlines
+    rng = np.random.default_rng(9)
+    E, O, V = 5000, 7, 8
+    P2 = dict(P, angular_dim=36, angular_min=-np.pi / 2, angular_max=np.pi / 2, angular_max_range=4.0, normalize=0,
+              submap_size_m=4.0, map_size_m=10.0)
+    robot = np.concatenate([rng.uniform(-5, 5, (E, 2)), rng.uniform(-np.pi, np.pi, (E, 1)), rng.uniform(0.2, 0.5, (E, 1))], axis=1)
+    ang = np.sort(rng.uniform(0, 2 * np.pi, (E, O, V)), axis=2)
+    ctr = rng.uniform(-4, 4, (E, O, 1, 2)); rad = rng.uniform(0.2, 1.5, (E, O, V, 1))
+    verts = ctr + rad * np.stack([np.cos(ang), np.sin(ang)], axis=3)
+    n_obst = rng.integers(0, O + 1, E).astype(np.int32)
+    _eq(gpu.sim.crowd_angular_map(P2, _t(gpu, robot), _t(gpu, verts), _t(gpu, n_obst)).cpu().numpy(),
+        ref.crowd_angular_map(P2, robot, verts, n_obst), "angular map, random batch")
+    G = 100
+    fm = (rng.random((600, G, G)) > 0.08).astype(np.uint8)
+    _eq(gpu.sim.crowd_local_map(P2, _t(gpu, fm), _t(gpu, robot[:600]), rotate=True).cpu().numpy(),
+        ref.crowd_local_map(P2, fm, robot[:600], rotate=True), "rotated local map, random batch")
+
+
 def test_config1_single_env_64_beams(gpu):
     """BASELINE config 1: 1 env, 64-beam lidar, 100x100 static map, no pedestrians."""
     cfg = gpu.lib.default_config(n_envs=1, map_h=100, map_w=100, n_spawn=4, auto_reset=0, seed=7)
