@@ -98,7 +98,7 @@ class _AgentView(object):
 
 
 class NavGymEnv(object):
-    metadata = {"render.modes": []}
+    metadata = {"render.modes": ["human", "rgb_array"]}
 
     def __init__(self, robot_type, time_step, min_turning_radius, distance_threshold, num_scan_stack,
                  linvel_range, rotvel_range, human_v_pref_range, human_has_legs_ratio, indoor_ratio,
@@ -333,8 +333,36 @@ class NavGymEnv(object):
         return {"is_success": np.float32(r["is_success"][0].item()), "is_crash": np.float32(r["is_crash"][0].item()),
                 "distance": float(r["distance"][0].item())}
 
-    def render(self, mode="human"):
-        raise NotImplementedError("render() (env.py:833-1212) is out of scope: SURVEY.md section 8f #3")
+    def render(self, mode="human", arena=0):
+        """The reference's picture of ONE arena (env.py:833-1050) as a float32 BGR array [800, 800, 3] in [0, 1]:
+        map, goal, pedestrians with local goals, robot with its three rectangles, lidar returns.  Host-side NumPy
+        (render.py); the reference's OpenCV window and text overlay are not reproduced -- both modes return the
+        image.  `arena` selects which arena of the batch is drawn."""
+        if self.sim is None:
+            raise RuntimeError("call reset() before render()")
+        from . import render as rd
+        t, e, cfg = self.sim.t, int(arena), self.cfg
+        occ = self.sim.occupancy(e)
+        map_info = {"data": occ.astype(np.int8) * 100, "origin": (cfg.origin_x, cfg.origin_y),
+                    "resolution": cfg.resolution, "width": self.map_size, "height": self.map_size}
+        spec = robots.ROBOTS[self.robot_type]
+        rp = t["robot_pose"][e].cpu().numpy()
+        goal = t["robot_goal"][e].cpu().numpy()
+        robot = dict(px=rp[0], py=rp[1], theta=rp[2], gx=goal[0], gy=goal[1], footprint=spec["footprint"],
+                     threshold_footprint=spec["threshold_footprint"],
+                     discomfort_threshold_footprint=spec["discomfort_threshold_footprint"])
+        humans = []
+        if "n_peds" in t:
+            pp = t["ped_pose"][e].cpu().numpy()
+            wp = t["ped_waypoints"][e, :, 0].cpu().numpy()
+            for i in range(int(t["n_peds"][e])):
+                humans.append(dict(px=pp[i, 0], py=pp[i, 1], theta=pp[i, 2], gx=wp[i, 0], gy=wp[i, 1],
+                                   footprint=robots.HUMAN["footprint"]))
+        o = self.sim.obs[e].cpu().numpy()
+        B = cfg.n_beams
+        scan = o[(cfg.n_scan_stack - 1) * B: cfg.n_scan_stack * B]
+        return rd.render_arena(map_info, robot, humans, scan, float(o[-1]),
+                               dict(angle_min=cfg.angle_min, angle_last=cfg.angle_last, range_max=np.float32(cfg.range_max)))
 
     def close(self):
         self.sim = None

@@ -833,6 +833,11 @@ def test_env_wrapper_gym_api(gpu):
     assert env.compute_done(o2) == d
     assert abs(env.compute_info(o2)["distance"] - info["distance"]) < 1e-4
     assert abs(env.robot.px - o2["achieved_goal"][0]) < 1e-5
+    img = env.render(mode="rgb_array")                      # env.py:833-1050 for the arena (render.py)
+    assert img.shape == (800, 800, 3) and img.dtype == np.float32 and (img == 0).any() and (img == 1).any()
+    from nav_gym_amd import export                          # ros_env.py:65-185 field lists
+    assert export.reset_map_fields(env)["data"].shape == (400, 400)
+    assert len(export.strict_update_fields(env)["humans"]) == 5
     # batched
     benv = nav_gym_env.make("NavGym-v0", num_envs=32, map_size=200, n_beams=1081, num_scan_stack=2, seed=4)
     bo = benv.reset()
@@ -841,6 +846,7 @@ def test_env_wrapper_gym_api(gpu):
     for _ in range(5):
         bo, br, bd, binfo = benv.step(acts)
     assert tuple(br.shape) == (32,) and bd.dtype == gpu.torch.bool
+    assert benv.render(arena=17).shape == (800, 800, 3)
     rr = benv.compute_rewards(acts, {k: v for k, v in bo.items()})
     assert rr.shape == (32,)
     done_again = benv.compute_terminals(bo)

@@ -223,3 +223,85 @@ def test_export_transform_matches_reference_utils():
     assert np.abs(got - d["tf_xys_out"][:, :2]).max() < 1e-12
     q = export._quaternion_from_yaw(0.7)
     assert abs(q[2] - np.sin(0.35)) < 1e-15 and abs(q[3] - np.cos(0.35)) < 1e-15 and q[0] == 0.0 and q[1] == 0.0
+
+
+class _FakeSim(object):
+    def __init__(self, t, obs):
+        self.t, self.obs = t, obs
+
+
+def _fake_env(n_peds=3):
+    """An env-shaped namespace over CPU tensors: what export.py / render() read, without a GPU."""
+    import types
+    import torch
+    from nav_gym_amd import lib, robots
+    H = 60
+    cfg = lib.default_config(n_envs=2, map_h=H, map_w=H, max_peds=4, n_beams=64, ped_model=abi.PED_SFM)
+    field = torch.ones((2, H, H), dtype=torch.float32)
+    field[:, :3] = 0; field[:, -3:] = 0; field[:, :, :3] = 0; field[:, :, -3:] = 0
+    field[1, 20:30, 40:50] = 0
+    t = {"field": field,
+         "robot_pose": torch.tensor([[1.0, 1.0, 0.0], [1.5, 1.0, 0.7]], dtype=torch.float64),
+         "robot_goal": torch.tensor([[2.0, 2.0], [2.5, 0.5]], dtype=torch.float64),
+         "n_peds": torch.tensor([0, n_peds], dtype=torch.int32),
+         "ped_pose": torch.rand((2, 4, 3), dtype=torch.float64) * 2 + 0.3,
+         "ped_vel": torch.rand((2, 4, 2), dtype=torch.float64),
+         "ped_waypoints": torch.rand((2, 4, abi.MAX_WAYPOINTS, 2), dtype=torch.float64) * 2 + 0.3}
+    obs = torch.full((2, 64 + 7), 25.0, dtype=torch.float32)
+    obs[1, :32] = 0.8                                       # half of the beams return at 0.8 m
+    obs[1, -1] = 0.7
+    env = types.SimpleNamespace(cfg=cfg, sim=_FakeSim(t, obs), robot_type="keti", map_size=H)
+    return env
+
+
+def test_export_fields_follow_ros_env():
+    """export.reset_map_fields / strict_update_fields against the field list of the reference's RosEnv
+    (ros_env.py:65-185; nav_gym/srv/ResetMap.srv:1-6, StrictUpdate.srv:1-9): the same request fields, the same
+    attributes filled, the reference's width <- height swap (ros_env.py:72-73), the latest scan of the stack."""
+    from nav_gym_amd import export, robots
+    env = _fake_env()
+    m = export.reset_map_fields(env, arena=1)
+    assert set(m) == {"data", "resolution", "width", "height", "origin_position", "origin_orientation"}
+    assert m["data"].dtype == np.int8 and set(np.unique(m["data"])) == {0, 100} and m["data"][25, 45] == 100
+    assert m["origin_orientation"] == (0.0, 0.0, 0.0, 1.0) and m["resolution"] == 0.05
+    u = export.strict_update_fields(env, arena=1)
+    assert set(u) == {"humans", "pose", "footprint", "threshold_footprint", "discomfort_threshold_footprint", "scan"}
+    assert set(u["pose"]) == {"frame_id", "position", "orientation"} and u["pose"]["frame_id"] == "map"   # ros_env.py:94-103
+    assert set(u["scan"]) == {"frame_id", "angle_min", "angle_max", "angle_increment", "range_max", "ranges"}  # :139-151
+    assert u["scan"]["frame_id"] == "laser_link" and len(u["scan"]["ranges"]) == 64
+    assert len(u["humans"]) == 3 and set(u["humans"][0]) == {"track_id", "detection_id", "position", "orientation", "linear"}
+    for key in ("footprint", "threshold_footprint", "discomfort_threshold_footprint"):      # ros_env.py:105-137
+        exp = export._transform(robots.KETI[key], 1.5, 1.0, 0.7)
+        assert np.allclose(u[key], exp) and u[key].shape == (4, 2)
+    assert export.strict_update_fields(env, arena=0)["humans"] == []
+
+
+def test_render_arena_picture():
+    """render() (env.py:833-1050) as a NumPy rasteriser: 800 x 800 x 3 float32 BGR in [0, 1]; obstacles black, free
+    space white, the goal a blue 1 m square, lidar returns below range_max green discs (none for beams at
+    range_max), drawn in the reference's flipped (world) orientation."""
+    from nav_gym_amd import render as rd, robots
+    H = 100
+    data = np.zeros((H, H), np.int8)
+    data[:5] = 100; data[-5:] = 100; data[:, :5] = 100; data[:, -5:] = 100
+    mi = {"data": data, "origin": (0.0, 0.0), "resolution": 0.05, "width": H, "height": H}
+    robot = dict(px=2.0, py=1.5, theta=0.3, gx=3.5, gy=3.5, footprint=robots.KETI["footprint"],
+                 threshold_footprint=robots.KETI["threshold_footprint"],
+                 discomfort_threshold_footprint=robots.KETI["discomfort_threshold_footprint"])
+    humans = [dict(px=1.0, py=3.0, theta=1.0, gx=1.2, gy=4.0, footprint=robots.HUMAN["footprint"])]
+    scan = np.full(64, 25.0, np.float32); scan[:16] = 1.0
+    lidar = dict(angle_min=-np.pi, angle_last=np.pi - 2 * np.pi / 64, range_max=np.float32(25.0))
+    img = rd.render_arena(mi, robot, humans, scan, 0.3, lidar)
+    assert img.shape == (800, 800, 3) and img.dtype == np.float32 and img.min() >= 0.0 and img.max() <= 1.0
+    px = lambda x, y: img[799 - int(y / 0.05 * 8) - 4, int(x / 0.05 * 8) + 4]          # world (x, y) -> pixel (flipped rows)
+    assert tuple(px(0.1, 0.1)) == (0.0, 0.0, 0.0) and tuple(px(0.6, 4.4)) == (1.0, 1.0, 1.0)
+    assert tuple(px(3.5, 3.5)) == (0.0, 0.0, 1.0)                                       # goal: BGR (0, 0, 1)
+    assert tuple(px(1.2, 4.0)) == (1.0, 1.0, 0.0)                                       # pedestrian's local goal
+    green = (img[..., 0] == 0) & (img[..., 1] == 1) & (img[..., 2] == 0)
+    assert green.sum() > 16 * 20
+    none = rd.render_arena(mi, robot, [], np.full(64, 25.0, np.float32), 0.3, lidar)
+    assert not ((none[..., 0] == 0) & (none[..., 1] == 1) & (none[..., 2] == 0)).any()
+    # xy_to_ij of the renderer is the reference's batch_xy_to_ij (golden vectors)
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_units.npz"))
+    mi500 = {"origin": (0.0, 0.0), "resolution": 0.05, "width": 500, "height": 500}
+    assert np.array_equal(rd.xy_to_ij(d["xy_500"], mi500), d["ij_500"])
