@@ -473,7 +473,8 @@ size_t navsim_sizeof_config(void);
 size_t navsim_sizeof_state(void);
 size_t navsim_sizeof_step_io(void);
 /* deterministic device math of DESIGN.md section 4: fn 0 sin, 1 cos, 2 atan2(x, x2), 3 exp(x<=0),
- * 4 angle_correction (utils.py:5-9), 5 python-float % 2pi, 6 the packed field's sqrtf on integers.
+ * 4 angle_correction (utils.py:5-9), 5 python-float % 2pi, 6 the packed field's sqrtf on integers, 11 / 12 the
+ * march step of sqrtf(x) under NAVSIM_MARCH_F64 in its float64 form / in its float32-only form (7-10: diagnostics).
  * x, x2, out are device float64 [n]. */
 int navsim_debug_math(int32_t fn, const double* x, const double* x2, double* out, int32_t n, void* stream);
 /* batch_xy_to_ij (env.py:1228-1253) exactly as the scan evaluates it: xy [n,2] float64 in, ij [n,2] int32 out;

@@ -85,9 +85,25 @@ __global__ __launch_bounds__(64 * kColSeg) void dt_columns_kernel(const uint8_t*
 // range_libc (env.py:425).  How the product is rounded is NOT pinned by anything in /root/reference (the
 // package's source is absent; oracle/navsim_ref.c states the two candidates): NAVSIM_MARCH_F64 keeps the
 // coefficient a double, fl32(fl64(d) * 0.999); NAVSIM_MARCH_F32 keeps it a float member, d * 0.999f.
+//
+// kMarchF64Exact32 is the SAME function as NAVSIM_MARCH_F64 evaluated without float64 instructions (v_cvt_f64_f32,
+// v_mul_f64, v_cvt_f32_f64 cost the probe loop 5 % of the c2 step): 0.999 = c_hi + c_lo in float32, the product's
+// rounding error recovered exactly by an FMA, one final addition.  Identical to the float64 form for every
+// d = sqrtf(n), n an integer below 2^22 (exhaustive device check in tests/test_gpu_parity.py), which is every
+// distance the packed field or a rect record can produce on maps up to 1448 cells per side; the host selects it
+// only there (march_rule_variant).  Not identical for arbitrary floats, so the float32 field (caller-supplied
+// values) and larger maps keep the float64 instructions.
+constexpr int kMarchF64Exact32 = 2;
 template <int RULE>
 __device__ __forceinline__ float march_step(float d) {
-    const float stp = (RULE == NAVSIM_MARCH_F32) ? d * 0.999f : (float)((double)d * 0.999);
+    float stp;
+    if (RULE == kMarchF64Exact32) {
+        const float c_hi = 0.999f, c_lo = (float)(0.999 - (double)0.999f);
+        const float hi = d * c_hi;
+        stp = hi + __builtin_fmaf(d, c_lo, __builtin_fmaf(d, c_hi, -hi));
+    } else {
+        stp = (RULE == NAVSIM_MARCH_F32) ? d * 0.999f : (float)((double)d * 0.999);
+    }
     return (stp > 1.0f) ? stp : 1.0f;
 }
 
@@ -108,6 +124,7 @@ struct FieldF32 {
     }
     __device__ __forceinline__ bool occupied(raw_t v) const { return v <= 0.0f; }
     __device__ __forceinline__ float decode(raw_t v, int, int) const { return v; }
+    __device__ __forceinline__ float decode_nz(raw_t v, int, int) const { return v; }
     __device__ __forceinline__ float at(int px, int py) const { return load(px, py); }
     // the float this field holds for an integer squared distance (dt_rows_kernel: sqrtf((float)d2))
     __device__ __forceinline__ static float sqrt_d2(int d2) { return sqrtf((float)d2); }
@@ -139,12 +156,15 @@ struct FieldU16TT {
         if (OVF && v == 0xFFFFu) return ovf[(size_t)py * W + px];      // d2 >= 65535: exact float plane
         return nv::sqrt_small_int((float)v);
     }
-    __device__ __forceinline__ float at(int px, int py) const { return decode(load(px, py), px, py); }
-    // d of an integer squared distance, as decode() would give it: without an overflow plane every d2 of the
-    // arena is below 65535 and the short exact sqrt applies; with one, d2 may be larger: IEEE sqrtf
-    __device__ __forceinline__ static float sqrt_d2(int d2) {
-        return OVF ? sqrtf((float)d2) : nv::sqrt_small_int((float)d2);
+    // the march's form: the value of an OCCUPIED sample (v = 0) is never used there, so the 0 guard is dropped
+    __device__ __forceinline__ float decode_nz(raw_t v, int px, int py) const {
+        if (OVF && v == 0xFFFFu) return ovf[(size_t)py * W + px];
+        return nv::sqrt_small_int_nz((float)v);
     }
+    __device__ __forceinline__ float at(int px, int py) const { return decode(load(px, py), px, py); }
+    // d of an integer squared distance from a rect record, as decode() would give it (the exact short sqrt holds
+    // for every integer below 2^22, i.e. maps up to 1024 cells per side); NaN at d2 = 0, which the march never uses
+    __device__ __forceinline__ static float sqrt_d2(int d2) { return nv::sqrt_small_int_nz((float)d2); }
 };
 typedef FieldU16TT<true> FieldU16T;
 typedef FieldU16TT<false> FieldU16TN;

@@ -189,6 +189,28 @@ __global__ void math_kernel(int fn, const double* x, const double* x2, double* o
         case 4: out[i] = nv::wrap_pi(x[i]); break;
         case 5: out[i] = nv::mod_2pi(x[i]); break;
         case 6: out[i] = (double)nv::sqrt_small_int((float)x[i]); break;
+        case 7: out[i] = (double)__builtin_amdgcn_sqrtf((float)x[i]); break;        // raw v_sqrt_f32 (diagnostic)
+        case 8: out[i] = (double)sqrtf((float)x[i]); break;                          // compiler's IEEE sqrtf
+        case 9: {                                                                     // rsq + one residual step (diagnostic)
+            const float xf = (float)x[i];
+            const float y = __builtin_amdgcn_rsqf(xf);
+            float sq = xf * y;
+            const float r = __builtin_fmaf(-sq, sq, xf);
+            sq = __builtin_fmaf(r * 0.5f, y, sq);
+            out[i] = (double)(xf == 0.0f ? 0.0f : sq);
+            break;
+        }
+        case 11: out[i] = (double)march_step<NAVSIM_MARCH_F64>(nv::sqrt_small_int((float)x[i])); break;
+        case 12: out[i] = (double)march_step<kMarchF64Exact32>(nv::sqrt_small_int((float)x[i])); break;
+        case 10: {                                                                    // v_sqrt + one residual step via rcp-free half
+            const float xf = (float)x[i];
+            float sq = __builtin_amdgcn_sqrtf(xf);
+            const float y = __builtin_amdgcn_rsqf(xf);
+            const float r = __builtin_fmaf(-sq, sq, xf);
+            sq = __builtin_fmaf(r * 0.5f, y, sq);
+            out[i] = (double)(xf == 0.0f ? 0.0f : sq);
+            break;
+        }
         default: out[i] = 0.0;
     }
 }

@@ -33,7 +33,10 @@ __device__ __forceinline__ int rect_dist2(unsigned lo, unsigned hi, unsigned p) 
     rect_s2 m = __builtin_elementwise_max(L - P, P - Hh);
     const rect_s2 z = {0, 0};
     m = __builtin_elementwise_max(m, z);
-    return __builtin_amdgcn_sdot2(m, m, 0, false);
+    // v_dot2_i32_i16 with the accumulator as an inline 0 (the builtin selects v_dot2c + a v_mov of the zero)
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(r) : "v"(__builtin_bit_cast(unsigned, m)));
+    return r;
 }
 __device__ __forceinline__ int rect_record_d2(const uint4 rec, int px, int py) {
     const unsigned p = ((unsigned)py << 16) | (unsigned)px;

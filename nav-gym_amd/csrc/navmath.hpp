@@ -157,22 +157,25 @@ __device__ __forceinline__ double wrap_pi(double a) {
     return atan2_(s, c);
 }
 
-// Correctly rounded sqrtf for 1 <= x <= 2^24 (integers from the packed distance field): the raw
-// v_sqrt_f32 is within 1 ulp, and the two exact FMA residuals pick the neighbour whose square
-// brackets x (the same correction hipcc emits for sqrtf, minus the denormal scaling and the class
-// test, which cannot trigger in this range).  tests/test_gpu_parity.py checks all 65,535 inputs.
-__device__ __forceinline__ float sqrt_small_int(float x) {
+// sqrtf of a non-negative INTEGER below 2^22 held in a float, correctly rounded, in five full-rate-or-
+// transcendental instructions: y = v_rsq_f32(x) (1 ulp), s = x * y, one residual step s + (x - s*s) * y / 2 with
+// the residual taken exactly by an FMA.  Not correctly rounded in general; on gfx950 it IS for every integer in
+// [1, 2^22) -- checked exhaustively against IEEE sqrt on the device (tests/test_gpu_parity.py, all 4 194 303
+// inputs; profiles/_diag/sqrt_probe.py also shows raw v_sqrt_f32 alone is off by an ulp on 15 % of them).  The
+// packed field's d2 (< 65536) and the rect records' d2 (< 2^21 on maps up to 1024 cells) are such integers.
+// _nz: x = 0 gives NaN (0 * inf); callers that may see 0 and use the value take sqrt_small_int.
+__device__ __forceinline__ float sqrt_small_int_nz(float x) {
 #ifdef NAVSIM_DIAG_RAW_SQRT          // diagnostic build only: how much of the step is the sqrt correction?
     return __builtin_amdgcn_sqrtf(x);
 #endif
-    float s = __builtin_amdgcn_sqrtf(x);
-    float sm = __uint_as_float(__float_as_uint(s) - 1u);
-    float sp = __uint_as_float(__float_as_uint(s) + 1u);
-    float em = __builtin_fmaf(-sm, s, x);
-    float ep = __builtin_fmaf(-sp, s, x);
-    s = (em <= 0.0f) ? sm : s;
-    s = (ep > 0.0f) ? sp : s;
-    return s;
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s = x * y;
+    const float r = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(r * 0.5f, y, s);
+}
+__device__ __forceinline__ float sqrt_small_int(float x) {
+    const float s = sqrt_small_int_nz(x);
+    return x == 0.0f ? 0.0f : s;
 }
 
 __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {

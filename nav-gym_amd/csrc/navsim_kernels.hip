@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "../../include/navsim.h"
 #include "navmath.hpp"
@@ -109,18 +110,34 @@ int pick_step_block(const navsim_config* c) {
     return 1024;
 }
 
+// which compiled form of the march step serves cfg.march_rule (kernels_field.hpp march_step): the float32-only
+// evaluation of NAVSIM_MARCH_F64 where every distance is sqrtf of an integer below 2^22
+int march_rule_variant(const navsim_config* c) {
+    if (c->march_rule == NAVSIM_MARCH_F32) return NAVSIM_MARCH_F32;
+    const int side = c->map_h > c->map_w ? c->map_h : c->map_w;
+    return (c->field_format == NAVSIM_FIELD_U16T && side <= 1448) ? kMarchF64Exact32 : NAVSIM_MARCH_F64;
+}
+
+template <int BLOCK, bool PEDS, typename Field, bool RECT, int RULE>
+int launch_step_kernel(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
+                       const uint8_t* mask, size_t lds, hipStream_t s) {
+    if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
+    navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask,
+                                                                                    (unsigned)step_lds_scan_bytes(c));
+    return NAVSIM_OK;
+}
+
 template <int BLOCK, bool PEDS, typename Field, bool RECT>
 int launch_step_rule(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
                      const uint8_t* mask, size_t lds, hipStream_t s) {
-    const unsigned lds_scan = (unsigned)step_lds_scan_bytes(c);
-    if (c->march_rule == NAVSIM_MARCH_F32) {
-        if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, NAVSIM_MARCH_F32, RECT>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
-        navsim_step_kernel<BLOCK, PEDS, Field, NAVSIM_MARCH_F32, RECT><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, lds_scan);
-    } else {
-        if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, NAVSIM_MARCH_F64, RECT>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
-        navsim_step_kernel<BLOCK, PEDS, Field, NAVSIM_MARCH_F64, RECT><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask, lds_scan);
+    switch (march_rule_variant(c)) {
+        case NAVSIM_MARCH_F32: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F32>(c, st, io, reset_only, mask, lds, s);
+        case kMarchF64Exact32:
+            if constexpr (!std::is_same<Field, FieldF32>::value)
+                return launch_step_kernel<BLOCK, PEDS, Field, RECT, kMarchF64Exact32>(c, st, io, reset_only, mask, lds, s);
+            [[fallthrough]];
+        default: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F64>(c, st, io, reset_only, mask, lds, s);
     }
-    return NAVSIM_OK;
 }
 
 template <int BLOCK, bool PEDS, typename Field>
@@ -443,7 +460,7 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
     if (c->max_peds > NAVSIM_MAX_PEDS) return NAVSIM_E_UNSUPPORTED;
     if (c->field_format != NAVSIM_FIELD_F32 && c->field_format != NAVSIM_FIELD_U16T) return NAVSIM_E_UNSUPPORTED;
     if (c->march_rule != NAVSIM_MARCH_F64 && c->march_rule != NAVSIM_MARCH_F32) return NAVSIM_E_ARG;
-    if (st->rect_table && c->field_format != NAVSIM_FIELD_U16T) return NAVSIM_E_UNSUPPORTED;
+    if (st->rect_table && (c->field_format != NAVSIM_FIELD_U16T || c->map_h > 1024 || c->map_w > 1024)) return NAVSIM_E_UNSUPPORTED;
     if (c->step_block != 0 && c->step_block != 64 && c->step_block != 256 && c->step_block != 512 &&
         c->step_block != 1024) return NAVSIM_E_ARG;
     if (c->ped_split < 0 || c->ped_split > 2) return NAVSIM_E_ARG;
@@ -477,10 +494,12 @@ int navsim_ped_scans(const navsim_config* c, const navsim_state* st, float* out,
     size_t lds = (size_t)c->ped_n_beams * (sizeof(float2) + sizeof(float));
     hipStream_t s = (hipStream_t)stream;
     // 128 threads per pedestrian (measured 64 / 128 / 256 / 512: 1.11 / 0.78 / 0.93 / 1.50 ms on c3)
-    const bool f32rule = c->march_rule == NAVSIM_MARCH_F32;
+    const int rule = march_rule_variant(c);
 #define NAVSIM_PSCAN(F, RECT) \
-    do { if (f32rule) ped_scan_kernel<F, 128, NAVSIM_MARCH_F32, RECT><<<grid, 128, lds, s>>>(*c, *st, out); \
-         else         ped_scan_kernel<F, 128, NAVSIM_MARCH_F64, RECT><<<grid, 128, lds, s>>>(*c, *st, out); } while (0)
+    do { if (rule == NAVSIM_MARCH_F32)      ped_scan_kernel<F, 128, NAVSIM_MARCH_F32, RECT><<<grid, 128, lds, s>>>(*c, *st, out); \
+         else if (rule == kMarchF64Exact32 && !std::is_same<F, FieldF32>::value) \
+                                            ped_scan_kernel<F, 128, kMarchF64Exact32, RECT><<<grid, 128, lds, s>>>(*c, *st, out); \
+         else                               ped_scan_kernel<F, 128, NAVSIM_MARCH_F64, RECT><<<grid, 128, lds, s>>>(*c, *st, out); } while (0)
     if (c->field_format == NAVSIM_FIELD_U16T) {
         if (st->rect_table) NAVSIM_PSCAN(FieldU16T, true); else NAVSIM_PSCAN(FieldU16T, false);
     } else if (c->field_format == NAVSIM_FIELD_F32) {

@@ -55,11 +55,20 @@ def test_device_math_bit_exact(gpu):
 
 
 def test_packed_field_sqrt_is_correctly_rounded(gpu):
-    """The packed field decodes d = sqrtf(d2) with a hand-rolled correction of v_sqrt_f32: check it
-    against IEEE sqrt for EVERY encodable value and a sample of larger integers."""
-    v = np.concatenate([np.arange(1, 65536), np.random.default_rng(0).integers(65536, 1 << 24, 200000)]).astype(np.float64)
-    got = gpu.sim.debug_math(6, _t(gpu, v)).cpu().numpy()
-    _eq(got.astype(np.float32), np.sqrt(v.astype(np.float32)), "sqrt_small_int")
+    """nv::sqrt_small_int (v_rsq_f32 + one exact-residual step, 5 instructions) against IEEE sqrt for EVERY integer the
+    packed field or a rect record can hold: all of [0, 2^22) -- the packed field's d2 < 65536, a record's d2 < 2^21 on
+    maps up to 1024 cells per side."""
+    n = 1 << 22
+    x = gpu.torch.arange(n, dtype=gpu.torch.float64, device=gpu.dev)
+    got = gpu.sim.debug_math(6, x).cpu().numpy()
+    exp = np.sqrt(np.arange(n, dtype=np.float32)).astype(np.float64)
+    _eq(got, exp, "exact integer sqrt")
+    # the march step fl32(fl64(d) * 0.999) and its float32-only evaluation (kernels_field.hpp march_step) agree on
+    # every d = sqrtf(n), n < 2^22, and both equal NumPy's float64 computation
+    a, b = gpu.sim.debug_math(11, x).cpu().numpy(), gpu.sim.debug_math(12, x).cpu().numpy()
+    ref_step = np.maximum((exp * 0.999).astype(np.float32), np.float32(1.0)).astype(np.float64)
+    _eq(a, ref_step, "march step, float64 form")
+    _eq(b, ref_step, "march step, float32-only form")
 
 
 @pytest.mark.parametrize("size,n", [(100, 3), (400, 2), (500, 2), (1000, 1)])
