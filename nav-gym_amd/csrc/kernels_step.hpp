@@ -481,12 +481,26 @@ __device__ __forceinline__ void ped_phase(const navsim_config& c, const navsim_s
         double2* pair = (double2*)pair_scratch;
         const bool pair_par = pair_bytes >= (unsigned)(n * (n + 1)) * sizeof(double2) && n > 1;
         if (pair_par) {
-            for (int t = tid; t < n * (n + 1); t += BLOCK) {
-                int i = t / (n + 1), j = t - i * (n + 1);
-                double fx = 0.0, fy = 0.0;
-                if (j != i)
-                    sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
-                pair[t] = make_double2(fx, fy);
+            // The term on pedestrian j from pedestrian i is EXACTLY minus the term on i from j: every operand
+            // of sfm_pair changes sign or stays (differences, their squares, quotients, the odd atan2 of two
+            // sign-symmetric products), and round-to-nearest is symmetric under negation.  So each unordered
+            // pedestrian pair is evaluated once and stored twice; the robot (index n) only acts, it receives
+            // nothing.  n (n - 1) / 2 + n evaluations instead of n (n + 1).
+            const int n_pp = n * (n - 1) / 2;
+            for (int t = tid; t < n_pp + n; t += BLOCK) {
+                int i, j;
+                if (t < n_pp) {                                 // row-major walk of the strict upper triangle
+                    i = 0;
+                    int rem = t;
+                    while (rem >= n - 1 - i) { rem -= n - 1 - i; ++i; }
+                    j = i + 1 + rem;
+                } else {
+                    i = t - n_pp; j = n;
+                }
+                double fx, fy;
+                sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
+                pair[i * (n + 1) + j] = make_double2(fx, fy);
+                if (j < n) pair[j * (n + 1) + i] = make_double2(-fx, -fy);
             }
             __syncthreads();
         }
