@@ -23,7 +23,7 @@ for nq in (64, 256, 1024, 4096):
     cells = torch.zeros(nq, dtype=torch.int32, device="cuda"); plen = torch.zeros(nq, dtype=torch.float64, device="cuda")
     def go():
         rc = L.navsim_plan(cost.data_ptr(), M.data_ptr(), nq, 100, 100, 0.25, 0.0, 0.0, S.data_ptr(), G.data_ptr(), 2.0, 16,
-                           wp.data_ptr(), nw.data_ptr(), cells.data_ptr(), plen.data_ptr(), None, 0, None)
+                           wp.data_ptr(), nw.data_ptr(), cells.data_ptr(), plen.data_ptr(), None)
         assert rc == 0
     for _ in range(3): go()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
