@@ -9,7 +9,7 @@ import time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "nav-gym_amd"))
 import nav_gym_env  # noqa: E402  registers 'NavGym-v0'
 
-# ---- exactly the reference's loop (render() is out of scope here) ---------------------------------------
+# ---- exactly the reference's loop ---------------------------------------------------------------------
 env = nav_gym_env.make("NavGym-v0")
 obs = env.reset()
 done, steps = False, 0
@@ -18,6 +18,8 @@ while not done and steps < 200:
     obs, reward, done, info = env.step(action)
     steps += 1
 print("single arena: %d steps, last reward %.3f, info %s" % (steps, reward, info))
+img = env.render(mode="rgb_array")                # env.py:833-1050: float32 BGR [800, 800, 3] (no window here)
+print("render:", img.shape, img.dtype)
 
 # ---- 4096 arenas per call --------------------------------------------------------------------------------
 import torch  # noqa: E402

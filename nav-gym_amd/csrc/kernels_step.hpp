@@ -79,6 +79,9 @@ __device__ __forceinline__ void sfm_pair(const navsim_config& c, double xi, doub
 __device__ __forceinline__ void beam_dir_k(const navsim_config& c, const double* __restrict__ tab, int k,
                                            double step, double lth, double cT, double sT,
                                            float& dx, float& dy) {
+#ifdef NAVSIM_DIAG_CHEAP_DIR     // diagnostic build only (wrong directions): what does the exact direction cost?
+    { float h = (float)c.angle_min + (float)k * (float)step + (float)lth; dx = __cosf(h); dy = __sinf(h); return; }
+#endif
     const double lin = nv::linspace_k(c, k, step);
     double ang = lin + lth;
     float heading = (float)ang;
@@ -252,10 +255,6 @@ __device__ __forceinline__ void finish_beams(const navsim_config& c, const StepS
 
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
-#ifndef NAVSIM_RAYS_PER_LANE
-#define NAVSIM_RAYS_PER_LANE 1
-#endif
-constexpr int kRaysPerLane = NAVSIM_RAYS_PER_LANE;      // 2: two rays of a lane probed together (rect records only)
 
 // One probe of calc_range (env.py:425) for every lane with `active` set: sample position, distance there, hit test,
 // step.  Lanes that are finished or outside the map run along with their updates masked off.  A lane that hits
@@ -300,56 +299,6 @@ __device__ __forceinline__ void probe_round(const Field& field, const char* __re
     const bool go = live & !occ;
     t = go ? tn : t;
     active = go & (tn < max_range);
-}
-
-// Two independent rays of one lane probed together (rect records only): both record loads are issued before either
-// is consumed, so each wavefront carries two dependency chains and the vector unit works on one ray while the other
-// ray's load is in flight.  Same arithmetic per ray as probe_round.
-template <typename Field, int RULE>
-__device__ __forceinline__ void probe_round2(const Field& field, const char* __restrict__ rects, unsigned tpr,
-                                             float x0, float y0, const float (&dx)[2], const float (&dy)[2],
-                                             unsigned uW, unsigned uH, float max_range, float (&t)[2],
-                                             bool (&active)[2], bool (&hit)[2]) {
-    int px[2], py[2];
-    bool live[2];
-    uint4 rec[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const float fx = x0 + dx[q] * t[q];
-        const float fy = y0 + dy[q] * t[q];
-        px[q] = (int)fx; py[q] = (int)fy;
-        live[q] = active[q] & ((unsigned)px[q] < uW) & ((unsigned)py[q] < uH);
-        px[q] = live[q] ? px[q] : 0;
-        py[q] = live[q] ? py[q] : 0;
-        const unsigned off = (((unsigned)py[q] >> kRectShift) * tpr + ((unsigned)px[q] >> kRectShift)) * (unsigned)sizeof(uint4);
-        rec[q] = *(const uint4*)(rects + off);
-    }
-    bool occ[2], inval[2];
-    float d[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int d2 = rect_record_d2(rec[q], px[q], py[q]);
-        inval[q] = live[q] & rect_record_invalid(rec[q]);
-        occ[q] = live[q] & (d2 == 0);
-        d[q] = Field::sqrt_d2(d2);
-    }
-    if (wave_any(inval[0] | inval[1])) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-            if (inval[q]) {
-                typename Field::raw_t raw = field.load(px[q], py[q]);
-                occ[q] = field.occupied(raw);
-                d[q] = field.decode_nz(raw, px[q], py[q]);
-            }
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        hit[q] |= occ[q];
-        const float tn = t[q] + march_step<RULE>(d[q]);
-        const bool go = live[q] & !occ[q];
-        t[q] = go ? tn : t[q];
-        active[q] = go & (tn < max_range);
-    }
 }
 
 // raw range (cells) of a finished ray: the hit cell recomputed from the t of the hit probe
@@ -408,20 +357,7 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const St
             if (S - 1 - j > n_hist) obs_row[(size_t)j * B + k] = rr;
     };
     const float miss = (r_all >= 0.0f) ? r_all : max_range;
-    if constexpr (RECT && kRaysPerLane == 2) {
-        for (int k0 = (int)threadIdx.x; k0 < B; k0 += 2 * BLOCK) {
-            const int k1 = k0 + BLOCK;
-            const bool two = k1 < B;
-            float dx[2], dy[2], t[2] = {t1, t1};
-            beam_dir_k(c, tab, k0, step, (double)sh.lth, sh.cT, sh.sT, dx[0], dy[0]);
-            beam_dir_k(c, tab, two ? k1 : k0, step, (double)sh.lth, sh.cT, sh.sT, dx[1], dy[1]);
-            bool active[2] = {r_all < 0.0f, two && r_all < 0.0f}, hit[2] = {false, false};
-            while (wave_any(active[0] | active[1]))
-                probe_round2<Field, RULE>(field, (const char*)rects, tpr, x0, y0, dx, dy, uW, uH, max_range, t, active, hit);
-            finish(k0, dx[0], dy[0], ray_result(hit[0], x0, y0, dx[0], dy[0], t[0], miss));
-            if (two) finish(k1, dx[1], dy[1], ray_result(hit[1], x0, y0, dx[1], dy[1], t[1], miss));
-        }
-    } else {
+    {
         for (int k = (int)threadIdx.x; k < B; k += BLOCK) {
             float dx, dy;
             beam_dir_k(c, tab, k, step, (double)sh.lth, sh.cT, sh.sT, dx, dy);

@@ -9,11 +9,13 @@
 // layer of the widened rows, HumanPolicy's 4096 -> 256, runs on v_mfma_f32_32x32x2_f32 (kernels_policy.hpp).
 //
 // One translation unit, in sections:
-//   kernels_field.hpp    distance transform, field formats, tile table, mirror primitives
-//   kernels_step.hpp     scan / merge / pedestrian phase / the fused step kernel
+//   kernels_field.hpp    distance transform, field formats, march step, mirror primitives
+//   kernels_rect.hpp     two-rectangle records of the field's 8x8 tiles: builder and decode
+//   kernels_step.hpp     probe round / scan / merge / pedestrian phase / the fused step kernel
 //   kernels_reset.hpp    navsim_regen, costmap, planner, navsim_replan
 //   kernels_policy.hpp   pedestrian control block with the HumanPolicy actor
-//   kernels_pedscan.hpp  pedestrian scans, beam table, test hooks
+//   kernels_pedscan.hpp  pedestrian scans, CrowdSim collision block, beam table, test hooks
+//   kernels_crowd_maps.hpp  CrowdSim local maps
 //   this file            launch geometry / dispatch and the C ABI
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see nav-gym_amd/csrc/build.sh).

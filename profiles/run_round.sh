@@ -6,7 +6,7 @@
 set -u
 TAG="$1"
 R="${GRAFT_REPO_ROOT:-/root/repo}"
-for W in c2 c3 c4; do
+for W in c1 c2 c3 c4; do
   bash "$R/profiles/run_profiles.sh" "${TAG}_$W" --workload $W --steps 100 > /dev/null 2>&1
 done
 NAVSIM_PROFILE_MAXHALF=1 bash "$R/profiles/run_profiles.sh" "${TAG}_c5" --workload c5 --steps 100 > /dev/null 2>&1
@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace --
 cd "$R"
 cp "$OUT"/trace/*/*kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null || cp "$OUT"/trace/*kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null
 cp gpurun_out/policy_cost.json "$OUT/policy_cost.json" 2>/dev/null
-for W in c2 c3 c4 c5; do echo "== $W"; grep -E "navsim_step_kernel launches|HBM read bytes|L2 hit" "gpurun_out/prof_${TAG}_$W/summary.txt"; done
+for W in c1 c2 c3 c4 c5; do echo "== $W"; grep -E "navsim_step_kernel launches|HBM read bytes|L2 hit" "gpurun_out/prof_${TAG}_$W/summary.txt"; done
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 for f in glob.glob(os.path.join(sys.argv[1], "kernel_stats.csv")):
