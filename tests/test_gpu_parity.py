@@ -1196,6 +1196,31 @@ def test_costmap_and_planner_vs_oracle(gpu, size, indoor):
             assert (rn[1:] > 0).sum() > len(rn) // 3, rn
 
 
+def test_sharded_envs_reproduce_the_single_shard(gpu):
+    """sharding.make_sharded_env: two shards of 24 arenas (ranks 0 and 1 of a world of 2, built one after the other
+    on this box's GPU) reset and step exactly like the first and second half of ONE 48-arena env: maps, spawns,
+    pedestrians, per-episode draws and noise are keyed by the global arena index."""
+    from nav_gym_amd import sharding
+    import nav_gym_amd
+    torch = gpu.torch
+    kw = dict(map_size=200, n_beams=512, seed=21, num_humans=4, min_goal_dist=3, max_goal_dist=7, device=gpu.dev)
+    full = nav_gym_amd.NavGymEnv(num_envs=48, **dict(nav_gym_amd.DEFAULT_KWARGS, **kw))
+    shards = [sharding.make_sharded_env(48, rank=r, world_size=2, **kw) for r in (0, 1)]
+    assert [s.cfg.env_index_base for s in shards] == [0, 24] and [s.num_envs for s in shards] == [24, 24]
+    of = full.reset()["observation"]
+    os_ = torch.cat([s.reset()["observation"] for s in shards])
+    assert torch.equal(of, os_)
+    g = torch.Generator(device=gpu.dev); g.manual_seed(1)
+    for t in range(8):
+        act = torch.rand((48, 2), generator=g, device=gpu.dev, dtype=torch.float64)
+        act[:, 0] *= 0.5; act[:, 1] = act[:, 1] * 1.28 - 0.64
+        o, r, d, info = full.step(act)
+        parts = [s.step(act[24 * i:24 * i + 24]) for i, s in enumerate(shards)]
+        assert torch.equal(o["observation"], torch.cat([p[0]["observation"] for p in parts])), t
+        assert torch.equal(r, torch.cat([p[1] for p in parts])) and torch.equal(d, torch.cat([p[2] for p in parts]))
+    assert torch.equal(full.sim.t["ped_pose"], torch.cat([s.sim.t["ped_pose"] for s in shards]))
+
+
 def test_bench_two_ranks_on_one_gpu(gpu):
     """bench.py --gpus 2 end to end through the HIP library: the script spawns both ranks itself; they share
     this box's only GPU (NAVSIM_BENCH_ONE_GPU) and rendezvous over gloo (the driver's 8-GPU runs use RCCL, one
