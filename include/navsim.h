@@ -342,9 +342,9 @@ int navsim_ped_scans(const navsim_config* cfg, const navsim_state* st, float* ou
  * (start >= 4 m from the robot, goal >= 10 m away, v_pref, has_legs: env.py:786-806) and the first
  * observation of the new episode (env.py:808-831) written to io->obs.  Call it right after navsim_step on
  * the same stream with the same io.  Mutates field, spawn tables and pedestrian parameters in place.
- * Square maps; FIELD_F32, or FIELD_U16T on maps of at most 520 cells per side (no cell of such a map can be
- * 256 cells from every obstacle, so a regenerated packed field never needs the overflow plane; larger
- * packed maps return NAVSIM_E_UNSUPPORTED).
+ * Square maps; FIELD_F32, or FIELD_U16T.  A packed world of at most 520 cells per side has no overflow plane (no
+ * cell of such a map can be 256 cells from every obstacle) and must not be given one; a larger packed world MUST
+ * carry st->field_overflow, which is regenerated together with the field (NAVSIM_E_UNSUPPORTED otherwise).
  * cfg->regen_plan = 1: starts and goals are centres of free COSTMAP cells and a pair is kept only when the
  * planner joins it (robot: path no longer than twice the straight line, env.py:756-762; pedestrians get the
  * path's waypoints every 2 m, env.py:804); four rounds of candidates, the last one stays if none passes. */

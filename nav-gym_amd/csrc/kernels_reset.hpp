@@ -183,14 +183,14 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
 }
 
 // install the new distance field of every regenerated arena (kRegenSlices workgroups per map, 16-byte copies)
-__global__ __launch_bounds__(256) void regen_field_kernel(navsim_state st, const int* __restrict__ count,
+__global__ __launch_bounds__(256) void regen_field_kernel(char* __restrict__ dst_base, const int* __restrict__ count,
                                                           const int* __restrict__ list,
                                                           const char* __restrict__ field_scratch, size_t field_bytes) {
     const int b = blockIdx.x;
     if (b >= *count) return;
     const int e = list[b], tid = threadIdx.x;
     const char* src_b = field_scratch + (size_t)b * field_bytes;
-    char* dst_b = (char*)st.field + (size_t)e * field_bytes;
+    char* dst_b = dst_base + (size_t)e * field_bytes;
     if (((field_bytes | (size_t)(uintptr_t)src_b | (size_t)(uintptr_t)dst_b) & 15) == 0) {
         const size_t n16 = field_bytes / 16;
         const size_t per = (n16 + kRegenSlices - 1) / kRegenSlices;

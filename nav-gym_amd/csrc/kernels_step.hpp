@@ -225,7 +225,9 @@ __device__ __forceinline__ void finish_beams(const navsim_config& c, const StepS
         for (int k = (int)threadIdx.x; k < B; k += BLOCK)
             rng_rw[k] = ((r_all >= 0.0f) ? r_all : rng[k]) * res;   // env.py:426
         __syncthreads();
+#ifndef NAVSIM_DIAG_NO_MERGE          // diagnostic build only (pedestrians invisible): what does the merge cost?
         merge_prims_culled<BLOCK>(c, sh, pr, dir, rng_rw);
+#endif
         __syncthreads();
     }
     for (int k = (int)threadIdx.x; k < B; k += BLOCK) {

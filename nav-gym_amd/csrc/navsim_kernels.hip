@@ -545,8 +545,10 @@ size_t navsim_regen_workspace_bytes(const navsim_config* c) {
     b += M * cells;                                         // occupancy scratch
     b += M * cells * sizeof(uint16_t);                      // column pass
     b += M * navsim_field_bytes(1, c->map_h, c->map_w, c->field_format);
-    if (c->field_format == NAVSIM_FIELD_U16T)               // rect records of the regenerated arenas
-        b += navsim_build_rects_workspace_bytes((int32_t)M, c->map_h, c->map_w) + 512;
+    if (c->field_format == NAVSIM_FIELD_U16T) {             // rect records of the regenerated arenas; the exact
+        b += navsim_build_rects_workspace_bytes((int32_t)M, c->map_h, c->map_w) + 512;      // float plane of maps
+        if (c->map_h > kRegenMaxPackedSide) b += M * cells * sizeof(float) + 256;           // that can saturate
+    }
     b += M * (10000 + sizeof(int)) + 512;                   // corridor grids, map kinds
     if (c->regen_plan) {
         const size_t cc = (size_t)(c->map_h / 5) * (c->map_w / 5), P = NAVSIM_MAX_WAYPOINTS;
@@ -568,14 +570,17 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         c->corridor_width_hi < c->corridor_width_lo || c->iterations_lo < 1 || c->iterations_hi < c->iterations_lo ||
         c->num_humans_lo < 0 || (c->num_humans_hi > 0 && c->num_humans_hi < c->num_humans_lo))
         return NAVSIM_E_ARG;
-    if (c->map_h != c->map_w || c->n_spawn < 1 || c->regen_cap < 1 || c->obstacle_number > 64 || c->obstacle_number_hi > 64 || st->field_overflow ||
+    if (c->map_h != c->map_w || c->n_spawn < 1 || c->regen_cap < 1 || c->obstacle_number > 64 || c->obstacle_number_hi > 64 ||
         c->corridor_width_hi > 16 ||
         (c->field_format != NAVSIM_FIELD_F32 && c->field_format != NAVSIM_FIELD_U16T) || c->shared_field)
         return NAVSIM_E_UNSUPPORTED;
-    // A packed field regenerated here has no overflow plane, so no cell may reach d2 >= 65535.  Every map this
-    // function draws has a 5-cell border wall: the farthest a cell can be from it is map_h / 2 - 5 cells, which
-    // stays below 255.99 up to 520 cells per side.  Larger packed maps must use NAVSIM_FIELD_F32.
-    if (c->field_format == NAVSIM_FIELD_U16T && c->map_h > kRegenMaxPackedSide) return NAVSIM_E_UNSUPPORTED;
+    // A packed field needs its float32 overflow plane wherever a cell reaches d2 >= 65535.  Every map this function
+    // draws has a 5-cell border wall: the farthest a cell can be from it is map_h / 2 - 5 cells, which stays below
+    // 255.99 up to 520 cells per side -- such worlds never have a plane (and must not: the step then uses the
+    // decoder without the escape test).  Larger packed maps MUST come with the plane; it is regenerated with the field.
+    const bool big = c->map_h > kRegenMaxPackedSide;
+    if (c->field_format == NAVSIM_FIELD_U16T && (big != (st->field_overflow != nullptr))) return NAVSIM_E_UNSUPPORTED;
+    if (c->field_format == NAVSIM_FIELD_F32 && st->field_overflow) return NAVSIM_E_UNSUPPORTED;
     if (st->rect_table && (c->field_format != NAVSIM_FIELD_U16T || c->map_h > 1024)) return NAVSIM_E_UNSUPPORTED;
     if (workspace_bytes < navsim_regen_workspace_bytes(c) || !st->spawn_pose || !st->spawn_goal) return NAVSIM_E_ARG;
     if (c->regen_plan && (c->n_spawn > 256 || c->map_h < 5 || !plan_fits(c->map_h / 5, c->map_w / 5) ||
@@ -611,20 +616,29 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     regen_select_kernel<<<1, 1024, 0, s>>>(io->done, c->n_envs, M, count, list, mask);
     regen_indoor_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, grids, kind);
     regen_maps_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>(*c, *st, count, list, occ, grids, kind);
+    float* ovf_scratch = nullptr;                           // exact float plane of the new maps (large packed maps)
+    if (c->field_format == NAVSIM_FIELD_U16T && st->field_overflow) {
+        off = (off + 255) & ~(size_t)255;
+        ovf_scratch = (float*)(w + off);
+        off += (size_t)M * cells * sizeof(float);
+    }
     if (c->field_format == NAVSIM_FIELD_U16T) (void)hipMemsetAsync(fscratch, 0xFF, fbytes * (size_t)M, s);
     dt_columns_kernel<<<dim3((W + 63) / 64, M), 64 * kColSeg, 0, s>>>(occ, cols, H, W, count);
     if (c->field_format == NAVSIM_FIELD_F32)
         dt_rows_kernel<0><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, nullptr, nullptr, H, W, count);
     else
-        dt_rows_kernel<1><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, nullptr, nullptr, H, W, count);
+        dt_rows_kernel<1><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, ovf_scratch, nullptr, H, W, count);
     if (st->rect_table) {                                   // keep the rect records of the regenerated arenas current
         off = (off + 255) & ~(size_t)255;
         char* rect_ws = w + off;
         off += navsim_build_rects_workspace_bytes(M, H, W) + 256;
-        launch_build_rects(occ, M, H, W, fscratch, fbytes, c->field_format, nullptr, (uint4*)st->rect_table, rect_ws,
+        launch_build_rects(occ, M, H, W, fscratch, fbytes, c->field_format, ovf_scratch, (uint4*)st->rect_table, rect_ws,
                            count, list, s);
     }
-    regen_field_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>(*st, count, list, fscratch, fbytes);
+    regen_field_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>((char*)st->field, count, list, fscratch, fbytes);
+    if (ovf_scratch)
+        regen_field_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>((char*)st->field_overflow, count, list,
+                                                                (const char*)ovf_scratch, cells * sizeof(float));
     if (c->regen_plan) {
         const int Hc = H / 5, Wc = W / 5, P = NAVSIM_MAX_WAYPOINTS;
         const size_t cc = (size_t)Hc * Wc;

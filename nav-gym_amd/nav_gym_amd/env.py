@@ -135,10 +135,8 @@ class NavGymEnv(object):
         self.randomize_maps = bool(randomize_maps)
         self.replan_cap = 1024                              # pedestrians re-planned per step, at most
         self.plan_paths = bool(plan_paths) and int(map_size) <= 1000
-        if field_format == abi.FIELD_U16T and int(map_size) > 520:
-            # reset() regenerates the maps on the device; a packed field regenerated there carries no overflow
-            # plane, which maps above 520 cells per side can need (include/navsim.h, navsim_regen)
-            field_format = abi.FIELD_F32
+        if field_format == abi.FIELD_U16T and int(map_size) > 1024:
+            field_format = abi.FIELD_F32     # beyond the rect records' and the packed regeneration's tested range
         spec = robots.ROBOTS[robot_type]
         nh_hi = int(env_param_range["num_humans"][0][1]) if num_humans is None else int(num_humans)
         ped = {"none": abi.PED_NONE, "external": abi.PED_EXTERNAL, "sfm": abi.PED_SFM,

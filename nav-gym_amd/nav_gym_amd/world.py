@@ -263,6 +263,8 @@ def empty_world(cfg, device="cuda:0", plan_paths=False, rect_table=False):
         a["field"] = z((E, H, W), torch.float32)
     else:
         a["field"] = z(sim.load().navsim_field_bytes(E, H, W, cfg.field_format) // 2, torch.int16)
+        if max(H, W) > 520:             # cells of such maps can be >= 256 cells from every obstacle (d2 >= 65535): the
+            a["field_overflow"] = z((E, H, W), torch.float32)      # packed field escapes to this exact float plane
         if rect_table:
             a["rect_table"] = z((E, ((H + 7) // 8) * ((W + 7) // 8), 4), torch.int32)
             a["rect_table"][:, :, 0] = 0x7FFF                  # "no valid record" until the builder has run

@@ -482,6 +482,46 @@ def test_regen_vs_oracle(gpu, fmt, ped_model, plan):
         assert (occupied > 0.3).any() and (occupied < 0.2).any()
 
 
+def test_env_reset_at_the_reference_map_size(gpu):
+    """1000 x 1000 cells is the reference's own indoor map size (map_generator.py:108-122).  Such a packed world
+    carries the float32 overflow plane (cells >= 256 cells from every obstacle), regenerated with the field, and
+    its rect records (d2 up to 2 * 10^6): reset() and steps of sampled arenas equal the oracle bit for bit."""
+    import nav_gym_amd
+    kw = dict(nav_gym_amd.DEFAULT_KWARGS)
+    E, size = 12, 1000
+    env = nav_gym_amd.NavGymEnv(num_envs=E, map_size=size, seed=5, n_spawn=4, num_humans=6, **kw)
+    env.reset()
+    assert env.cfg.field_format == abi.FIELD_U16T and "field_overflow" in env.sim.t and "rect_table" in env.sim.t
+    ovf = env.sim.t["field_overflow"].cpu().numpy()
+    assert (ovf >= 256.0).any(), "no saturated cell: the overflow path was not exercised"
+    env.sim.cfg.add_scan_noise = 0
+    o = env.sim.reset_obs().cpu().numpy()
+    cfg = env.sim.cfg
+    refs = []
+    for e in (0, 5, 11):
+        c1 = cfg.copy(); c1.n_envs = 1; c1.env_index_base = int(e); c1.regen_cap = 1
+        host = {k: v.cpu().numpy() for k, v in gpu.world.empty_world(c1, device="cpu", plan_paths=True).items()
+                if k not in ("field", "field_overflow", "rect_table")}
+        host["field"] = np.zeros((1, size, size), np.float32)
+        host["scan_threshold"] = env.scan_threshold.cpu().numpy(); host["scan_discomfort"] = env.scan_discomfort_threshold.cpu().numpy()
+        r = ref.RefSim(c1, host)
+        r.out["done"][:] = 1
+        _eq(o[e:e + 1], r.regen(), "first observation of arena %d" % e)
+        _eq(ovf[e], r.a["field"][0], "float plane of arena %d" % e)
+        refs.append((e, r))
+    d2, valid = _decode_rect_table(env.sim.t["rect_table"].cpu().numpy()[:2], size, size)
+    assert np.array_equal(d2[valid], np.rint(ovf[:2].astype(np.float64) ** 2).astype(np.int64)[valid]) and valid.mean() > 0.9
+    rng = np.random.default_rng(3)
+    for t in range(6):
+        act = np.stack([rng.uniform(0, 0.5, E), rng.uniform(-0.64, 0.64, E)], axis=1)
+        obs, _, _, _ = env.step(act)
+        og = obs["observation"].cpu().numpy()
+        for e, r in refs:
+            ro, _ = r.step(act[e:e + 1])
+            r.replan(1024)
+            _eq(og[e:e + 1], ro, "arena %d obs at step %d" % (e, t))
+
+
 @pytest.mark.parametrize("seed", list(range(201, 213)))
 def test_reset_path_fuzzed(gpu, seed):
     """navsim_regen (+ planning, corridor maps, resident costmap) and navsim_replan at random sizes, formats,
