@@ -526,8 +526,12 @@ __device__ __forceinline__ void ped_phase(const navsim_config& c, const navsim_s
 // The pedestrians of every arena, one wavefront per arena, launched ahead of the fused step.  Inside the step
 // this phase is a third of a workgroup's lifetime during which three of its four wavefronts only hold their
 // slots; here an arena costs one wavefront.  Same device function, same results.
+#ifndef NAVSIM_PED_UPDATE_BLOCK
+#define NAVSIM_PED_UPDATE_BLOCK 64
+#endif
+constexpr int kPedUpdateBlock = NAVSIM_PED_UPDATE_BLOCK;
 template <typename Field>
-__global__ __launch_bounds__(64) void ped_update_kernel(navsim_config c, navsim_state st) {
+__global__ __launch_bounds__(kPedUpdateBlock) void ped_update_kernel(navsim_config c, navsim_state st) {
     extern __shared__ __attribute__((aligned(16))) char ped_dyn[];
     const int e = blockIdx.x, tid = threadIdx.x;
     const int N = c.max_peds;
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(64) void ped_update_kernel(navsim_config c, navsim_
         pvel[0] = st.ped_vel[pq * 2]; pvel[1] = st.ped_vel[pq * 2 + 1];
     }
     // the step increments steps[e] before anything else (env.py:592); it has not run yet
-    ped_phase<64, Field>(c, st, field, e, n, tid, is_ped, pq, c.time_step, (uint64_t)(c.env_index_base + e),
+    ped_phase<kPedUpdateBlock, Field>(c, st, field, e, n, tid, is_ped, pq, c.time_step, (uint64_t)(c.env_index_base + e),
                          (uint64_t)st.steps[e] + 1, old_rp, prev_v, ps, ped_dyn, pair_bytes, pp, pvel);
 }
 

@@ -161,8 +161,8 @@ int launch_step(const navsim_config* c, const navsim_state* st, const navsim_ste
         const bool split = c->ped_split == 2 || (c->ped_split == 0 && c->n_envs >= 3072);
         if (split) {
             const size_t pl = ped_update_lds_bytes(c);
-            if (c->field_format == NAVSIM_FIELD_U16T) ped_update_kernel<FieldU16T><<<c->n_envs, 64, pl, s>>>(*c, *st);
-            else                                      ped_update_kernel<FieldF32><<<c->n_envs, 64, pl, s>>>(*c, *st);
+            if (c->field_format == NAVSIM_FIELD_U16T) ped_update_kernel<FieldU16T><<<c->n_envs, kPedUpdateBlock, pl, s>>>(*c, *st);
+            else                                      ped_update_kernel<FieldF32><<<c->n_envs, kPedUpdateBlock, pl, s>>>(*c, *st);
             reset_only |= 2;
         }
     }
