@@ -19,12 +19,14 @@ constexpr int kDtInf = 32768;
 constexpr int kColSeg = 8;
 __global__ __launch_bounds__(64 * kColSeg) void dt_columns_kernel(const uint8_t* __restrict__ occ,
                                                                  uint16_t* __restrict__ g, int H, int W,
-                                                                 const int* __restrict__ n_live) {
+                                                                 const int* __restrict__ n_live,
+                                                                 const int* __restrict__ kind = nullptr) {
     __shared__ int down_last[kColSeg][64], up_first[kColSeg][64];
     const int cx = threadIdx.x & 63, seg = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + cx;
     const size_t m = blockIdx.y;
     if (n_live && (int)m >= *n_live) return;          // navsim_regen: only the first *n_live maps are live
+    if (kind && kind[m] == 0) return;                 // ... and outdoor maps got their field from the geometry
     const int rows = (H + kColSeg - 1) / kColSeg;
     const int y0 = seg * rows < H ? seg * rows : H, y1 = (y0 + rows < H) ? y0 + rows : H;
     const bool live = x < W;
@@ -184,10 +186,12 @@ template <int FORMAT>
 __global__ __launch_bounds__(256) void dt_rows_kernel(const uint16_t* __restrict__ g,
                                                       void* __restrict__ field_v, float* __restrict__ overflow,
                                                       int32_t* __restrict__ n_saturated, int H, int W,
-                                                      const int* __restrict__ n_live) {
+                                                      const int* __restrict__ n_live,
+                                                      const int* __restrict__ kind = nullptr) {
     extern __shared__ int32_t row[];                 // W entries of g(i)^2-ready distances
     size_t m = blockIdx.y;
     if (n_live && (int)m >= *n_live) return;
+    if (kind && kind[m] == 0) return;
     int y = blockIdx.x;
     const uint16_t* gr = g + (m * (size_t)H + y) * W;
     for (int x = threadIdx.x; x < W; x += blockDim.x) {

@@ -114,11 +114,18 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
 // create_outdoor_map (map_generator.py:126-143) at size x size, hash-keyed: kRegenSlices workgroups per map,
 // each filling its own band of rows (border wall, four cells per store) and then the parts of the obstacle
 // squares that fall into the band.
-constexpr int kRegenSlices = 8;
+constexpr int kRegenSlices = 32;
+// For an OUTDOOR map the kernel also writes the exact distance field straight from the generator's geometry: the
+// obstacles are the border frame and n boxes, and the squared distance of a cell to a rectangle of occupied cells is
+// max(x0 - x, x - x1, 0)^2 + max(y0 - y, y - y1, 0)^2, so d2 = min over them -- the same integers the distance
+// transform finds, with no dependent scan (the two transform kernels then skip the slot: their column / row
+// searches are latency-bound with a handful of live maps, 75 us per step of c5).
 __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim_state st,
                                                          const int* __restrict__ count, const int* __restrict__ list,
                                                          uint8_t* __restrict__ occ_all,
-                                                         const uint8_t* __restrict__ grid_all, const int* __restrict__ kind) {
+                                                         const uint8_t* __restrict__ grid_all, const int* __restrict__ kind,
+                                                         char* __restrict__ field_scratch, size_t field_bytes,
+                                                         float* __restrict__ ovf_scratch) {
     __shared__ int ocx[64], ocy[64];
     const int b = blockIdx.x;
     if (b >= *count) return;
@@ -178,6 +185,52 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
         for (int idx = tid; idx < (rb - ra + 1) * side; idx += 256) {
             int r = ra + idx / side, q = cy - hw + idx % side;
             if (q >= 0 && q < size) occ[(size_t)(size - 1 - r) * size + q] = 1;
+        }
+    }
+    // the exact field of this band of rows, from the geometry
+    char* fs = field_scratch + (size_t)b * field_bytes;
+    float* ov = ovf_scratch ? ovf_scratch + (size_t)b * size * size : nullptr;
+    const int tpr = (size + 7) >> 3;
+    // eight cells per thread at a time, boxes in the outer loop: a box is read from LDS once per eight cells
+    constexpr int CH = 8;
+    for (int base = r0 * size; base < r1 * size; base += 256 * CH) {
+        int rr[CH], qq[CH], d2[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int idx = base + j * 256 + tid;
+            const int r = idx / size, q = idx - r * size;
+            rr[j] = r; qq[j] = q;
+            int m = r - 4;
+            m = (size - 5 - r) < m ? (size - 5 - r) : m;
+            m = (q - 4) < m ? (q - 4) : m;
+            m = (size - 5 - q) < m ? (size - 5 - q) : m;
+            d2[j] = (m > 0) ? m * m : 0;                                        // border frame: m <= 0
+        }
+        for (int o = 0; o < n_obs; ++o) {
+            int x0 = ocx[o] - hw, x1 = ocx[o] + hw, y0 = ocy[o] - hw, y1 = ocy[o] + hw;
+            x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0;                        // boxes are drawn clipped to the map
+            x1 = x1 > size - 1 ? size - 1 : x1; y1 = y1 > size - 1 ? size - 1 : y1;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                int dr = x0 - rr[j] > rr[j] - x1 ? x0 - rr[j] : rr[j] - x1;
+                dr = dr < 0 ? 0 : dr;
+                int dq = y0 - qq[j] > qq[j] - y1 ? y0 - qq[j] : qq[j] - y1;
+                dq = dq < 0 ? 0 : dq;
+                const int v = dr * dr + dq * dq;
+                d2[j] = v < d2[j] ? v : d2[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int idx = base + j * 256 + tid;
+            if (idx >= r1 * size) continue;
+            const int y = size - 1 - rr[j], x = qq[j];                          // the stored orientation (flipud)
+            if (c.field_format == NAVSIM_FIELD_F32) {
+                ((float*)fs)[(size_t)y * size + x] = sqrtf((float)d2[j]);
+            } else {
+                ((uint16_t*)fs)[FieldU16T::index(x, y, tpr)] = (uint16_t)(d2[j] >= 65535 ? 0xFFFF : d2[j]);
+                if (ov) ov[(size_t)y * size + x] = sqrtf((float)d2[j]);
+            }
         }
     }
 }

@@ -615,7 +615,6 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     off += (size_t)M * sizeof(int);
     regen_select_kernel<<<1, 1024, 0, s>>>(io->done, c->n_envs, M, count, list, mask);
     regen_indoor_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, grids, kind);
-    regen_maps_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>(*c, *st, count, list, occ, grids, kind);
     float* ovf_scratch = nullptr;                           // exact float plane of the new maps (large packed maps)
     if (c->field_format == NAVSIM_FIELD_U16T && st->field_overflow) {
         off = (off + 255) & ~(size_t)255;
@@ -623,11 +622,16 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         off += (size_t)M * cells * sizeof(float);
     }
     if (c->field_format == NAVSIM_FIELD_U16T) (void)hipMemsetAsync(fscratch, 0xFF, fbytes * (size_t)M, s);
-    dt_columns_kernel<<<dim3((W + 63) / 64, M), 64 * kColSeg, 0, s>>>(occ, cols, H, W, count);
-    if (c->field_format == NAVSIM_FIELD_F32)
-        dt_rows_kernel<0><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, nullptr, nullptr, H, W, count);
-    else
-        dt_rows_kernel<1><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, ovf_scratch, nullptr, H, W, count);
+    // maps and, for outdoor maps, their exact field from the geometry; corridor maps go through the distance transform
+    regen_maps_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>(*c, *st, count, list, occ, grids, kind, fscratch, fbytes,
+                                                            ovf_scratch);
+    if (c->regen_indoor_ratio > 0.0) {
+        dt_columns_kernel<<<dim3((W + 63) / 64, M), 64 * kColSeg, 0, s>>>(occ, cols, H, W, count, kind);
+        if (c->field_format == NAVSIM_FIELD_F32)
+            dt_rows_kernel<0><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, nullptr, nullptr, H, W, count, kind);
+        else
+            dt_rows_kernel<1><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, ovf_scratch, nullptr, H, W, count, kind);
+    }
     if (st->rect_table) {                                   // keep the rect records of the regenerated arenas current
         off = (off + 255) & ~(size_t)255;
         char* rect_ws = w + off;
