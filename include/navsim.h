@@ -459,6 +459,35 @@ int navsim_crowd_angular_map(const navsim_crowd_map_params* p, int32_t n_envs, i
 int navsim_crowd_local_map(const navsim_crowd_map_params* p, int32_t n_envs, int32_t grid, const uint8_t* free_map,
                            const double* robot, int32_t rotate, uint8_t* out, void* stream);
 
+/* ---- CrowdSim-v0 pedestrians: ORCA through rvo2 (crowd_sim/envs/policy/orca.py:85-135) and Agent.step
+ *      (crowd_sim/envs/utils/agent.py:108-141) -------------------------------------------------------------- */
+#define NAVSIM_ORCA_MAX_AGENTS 64      /* agents per query incl. agent 0 */
+#define NAVSIM_ORCA_MAX_EDGES  128     /* obstacle edges per polygon set (max_obst * n_vert) */
+typedef struct navsim_orca_params {
+    float time_step;            /* CrowdSim.time_step (rvo2.PyRVOSimulator(time_step, ...)) */
+    float neighbor_dist;        /* orca.py:62 10 */
+    float time_horizon;         /* orca.py:64 5 */
+    float time_horizon_obst;    /* orca.py:65 5 */
+    int32_t max_neighbors;      /* orca.py:63 10 */
+} navsim_orca_params;
+/* What ORCA.predict does per pedestrian, for Q pedestrians at once: an RVO2 simulator holding agent 0 (the
+ * pedestrian itself: position, velocity, radius + 0.01 + safety_space, max speed v_pref, preferred velocity toward
+ * its goal) and the other agents it sees (preferred velocity 0), plus the static obstacle polygons; one doStep();
+ * the new velocity of agent 0 and the ActionRot(v, r = atan2(vy, vx) - theta) made of it.  Only agent 0's
+ * velocity is read back, so only it is computed.  rvo2's source is not in the reference tree: the RVO2 Library 2.0
+ * algorithm is restated (oracle/navsim_ref.c says where it knowingly differs: no kd-trees) -- UNPINNED.
+ * agents [Q, A, 6] float64 = px, py, vx, vy, radius, max_speed (A <= NAVSIM_ORCA_MAX_AGENTS); n_agents [Q] or NULL;
+ * pref_vel [Q,2]; verts [S, O, V, 2] counter-clockwise polygons (O * V <= NAVSIM_ORCA_MAX_EDGES), n_obst [S] or
+ * NULL, obst_set [Q] polygon set of each query or NULL (= set 0); theta [Q] or NULL; out_vel [Q,2]; out_action
+ * [Q,2] or NULL.  float32 arithmetic like the library's. */
+int navsim_crowd_orca(const navsim_orca_params* p, int32_t n_queries, int32_t max_agents, const double* agents,
+                      const int32_t* n_agents, const double* pref_vel, int32_t max_obst, int32_t n_vert,
+                      const double* verts, const int32_t* n_obst, const int32_t* obst_set, const double* theta,
+                      double* out_vel, double* out_action, void* stream);
+/* Agent.step with an ActionRot (agent.py:108-141): theta' = theta + r; p += (cos, sin)(theta') * v * dt;
+ * vel = v * (cos, sin)(theta'); theta = theta' mod 2 pi.  pose [n,3] in/out, action [n,2], vel [n,2] or NULL. */
+int navsim_crowd_agent_step(double* pose, const double* action, double* vel, int32_t n, double time_step, void* stream);
+
 /* First observation after reset() (env.py:822-831): scan at the current robot pose, stack filled
  * with copies, prev_pose = pose, vel = 0; sets prev_pose/prev_action/n_hist.  `mask` [E] uint8 or
  * NULL selects which envs are (re)initialised; others keep obs_prev -> obs copied through. */

@@ -15,7 +15,7 @@
 //   kernels_reset.hpp    navsim_regen, costmap, planner, navsim_replan
 //   kernels_policy.hpp   pedestrian control block with the HumanPolicy actor
 //   kernels_pedscan.hpp  pedestrian scans, CrowdSim collision block, beam table, test hooks
-//   kernels_crowd_maps.hpp  CrowdSim local maps
+//   kernels_crowd_maps.hpp  CrowdSim local maps;  kernels_crowd_orca.hpp  CrowdSim pedestrians (ORCA, Agent.step)
 //   this file            launch geometry / dispatch and the C ABI
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see nav-gym_amd/csrc/build.sh).
@@ -61,6 +61,7 @@ __device__ unsigned long long* g_stamps = nullptr;
 #include "kernels_policy.hpp"
 #include "kernels_pedscan.hpp"
 #include "kernels_crowd_maps.hpp"
+#include "kernels_crowd_orca.hpp"
 
 // kernels that want more than 64 KB of dynamic LDS must say so once; more than the CU has is refused
 constexpr size_t kLdsPerCu = 160 * 1024;
@@ -792,6 +793,29 @@ int navsim_crowd_local_map(const navsim_crowd_map_params* p, int32_t n_envs, int
     if (S < 1 || (size_t)S * S > 64 * 1024) return NAVSIM_E_UNSUPPORTED;           // the window lives in LDS
     if (n_envs == 0) return NAVSIM_OK;
     crowd_local_map_kernel<<<n_envs, 256, (size_t)S * S, (hipStream_t)stream>>>(*p, grid, S, free_map, robot, rotate, out);
+    return launch_status();
+}
+
+int navsim_crowd_orca(const navsim_orca_params* p, int32_t n_queries, int32_t max_agents, const double* agents,
+                      const int32_t* n_agents, const double* pref_vel, int32_t max_obst, int32_t n_vert,
+                      const double* verts, const int32_t* n_obst, const int32_t* obst_set, const double* theta,
+                      double* out_vel, double* out_action, void* stream) {
+    (void)hipGetLastError();
+    if (!p || !agents || !pref_vel || !out_vel || n_queries < 0 || max_agents < 1 || max_agents > NAVSIM_ORCA_MAX_AGENTS ||
+        max_obst < 0 || n_vert < 2 || (size_t)max_obst * n_vert > NAVSIM_ORCA_MAX_EDGES || (max_obst > 0 && !verts))
+        return NAVSIM_E_ARG;
+    if (n_queries == 0) return NAVSIM_OK;
+    crowd_orca_kernel<<<(n_queries + 63) / 64, 64, 0, (hipStream_t)stream>>>(*p, n_queries, max_agents, agents, n_agents,
+                                                                          pref_vel, max_obst, n_vert, verts, n_obst,
+                                                                          obst_set, theta, out_vel, out_action);
+    return launch_status();
+}
+
+int navsim_crowd_agent_step(double* pose, const double* action, double* vel, int32_t n, double time_step, void* stream) {
+    (void)hipGetLastError();
+    if (!pose || !action || n < 0) return NAVSIM_E_ARG;
+    if (n == 0) return NAVSIM_OK;
+    crowd_agent_step_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(pose, action, vel, n, time_step);
     return launch_status();
 }
 

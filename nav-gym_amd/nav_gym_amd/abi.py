@@ -156,6 +156,13 @@ class NavsimCrowdMapParams(C.Structure):
                 ("map_resolution", C.c_double), ("submap_size_m", C.c_double)]
 
 
+class NavsimOrcaParams(C.Structure):
+    _fields_ = [("time_step", C.c_float), ("neighbor_dist", C.c_float), ("time_horizon", C.c_float),
+                ("time_horizon_obst", C.c_float), ("max_neighbors", C.c_int32)]
+
+
+ORCA_MAX_AGENTS = 64
+ORCA_MAX_EDGES = 128
 CROWD_MAX_VERTS = 8
 CROWD_INFO = ("Nothing", "Timeout", "ReachGoal", "Collision", "CollisionOtherAgent", "Danger")
 
@@ -279,6 +286,8 @@ def declare(lib, suffix=""):
     mpp = C.POINTER(NavsimCrowdMapParams)
     sig("navsim_crowd_angular_map", [mpp, i32, i32, i32, _P, _P, _P, _P] + stream)
     sig("navsim_crowd_local_map", [mpp, i32, i32, _P, _P, i32, _P] + stream)
+    sig("navsim_crowd_orca", [C.POINTER(NavsimOrcaParams), i32, i32, _P, _P, _P, i32, i32, _P, _P, _P, _P, _P, _P] + stream)
+    sig("navsim_crowd_agent_step", [_P, _P, _P, i32, f64] + stream)
     sig("navsim_step", [cfgp, stp, iop] + stream)
     sig("navsim_reset_obs", [cfgp, stp, iop, _P] + stream)
     return lib
@@ -293,6 +302,7 @@ EXPORTS = (
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
     "navsim_scan_threshold", "navsim_beam_table", "navsim_ped_scans", "navsim_regen_workspace_bytes", "navsim_regen",
     "navsim_costmap", "navsim_plan", "navsim_launch_order", "navsim_replan_workspace_bytes", "navsim_replan", "navsim_ped_policy_workspace_bytes", "navsim_ped_policy",
-    "navsim_crowd_check", "navsim_crowd_angular_map", "navsim_crowd_local_map", "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
+    "navsim_crowd_check", "navsim_crowd_angular_map", "navsim_crowd_local_map", "navsim_crowd_orca", "navsim_crowd_agent_step",
+    "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math", "navsim_debug_xy_to_ij",
 )

@@ -237,6 +237,41 @@ def crowd_local_map(params, free_map, robot, rotate=True):
     return out
 
 
+def crowd_orca(params, agents, pref_vel, verts=None, n_agents=None, n_obst=None, obst_set=None, theta=None):
+    """navsim_crowd_orca: ORCA.predict (orca.py:85-135) for Q pedestrians: agents [Q,A,6] (agent 0 = the pedestrian),
+    pref_vel [Q,2], verts [S,O,V,2] CCW polygons -> (new velocity [Q,2], ActionRot (v, r) [Q,2]), float64 tensors."""
+    torch = require_gpu()
+    p = abi.NavsimOrcaParams(**{k: (int(v) if k == "max_neighbors" else float(v)) for k, v in params.items()})
+    agents = agents.to(torch.float64).contiguous()
+    Q, A = agents.shape[0], agents.shape[1]
+    dev = agents.device
+    pref_vel = pref_vel.to(device=dev, dtype=torch.float64).contiguous().reshape(Q, 2)
+    if verts is None or verts.numel() == 0:
+        verts, O, V = None, 0, 4
+    else:
+        verts = verts.to(device=dev, dtype=torch.float64).contiguous()
+        O, V = verts.shape[1], verts.shape[2]
+    i32 = lambda a: None if a is None else a.to(device=dev, dtype=torch.int32).contiguous()
+    na, no, os_ = i32(n_agents), i32(n_obst), i32(obst_set)
+    th = None if theta is None else theta.to(device=dev, dtype=torch.float64).contiguous()
+    vel = torch.empty((Q, 2), dtype=torch.float64, device=dev)
+    act = torch.empty((Q, 2), dtype=torch.float64, device=dev)
+    check(load().navsim_crowd_orca(C.byref(p), Q, A, _ptr(agents), _ptr(na), _ptr(pref_vel), O, V, _ptr(verts), _ptr(no),
+                                   _ptr(os_), _ptr(th), _ptr(vel), _ptr(act), _stream()), "navsim_crowd_orca")
+    return vel, act
+
+
+def crowd_agent_step(pose, action, time_step):
+    """navsim_crowd_agent_step: Agent.step with an ActionRot (agent.py:108-141) -> (pose [n,3], vel [n,2])."""
+    torch = require_gpu()
+    pose = pose.to(torch.float64).contiguous().clone()
+    action = action.to(device=pose.device, dtype=torch.float64).contiguous()
+    vel = torch.empty((pose.shape[0], 2), dtype=torch.float64, device=pose.device)
+    check(load().navsim_crowd_agent_step(_ptr(pose), _ptr(action), _ptr(vel), pose.shape[0], float(time_step), _stream()),
+          "navsim_crowd_agent_step")
+    return pose, vel
+
+
 def debug_xy_to_ij(cfg, xy, as_f32):
     """Device batch_xy_to_ij (env.py:1228-1253): xy float64 CUDA [n,2] -> int32 [n,2] (i, j)."""
     torch = require_gpu()

@@ -1839,3 +1839,353 @@ int navsim_crowd_local_map_cpu(const navsim_crowd_map_params* p, int32_t n_envs,
     free(g);
     return NAVSIM_OK;
 }
+
+/* =========================================================================================
+ * CrowdSim-v0 pedestrians: ORCA through rvo2 (crowd_sim/envs/policy/orca.py:85-135) + Agent.step
+ * (crowd_sim/envs/utils/agent.py:108-141).  SURVEY.md 8f #4.
+ *
+ * [UPSTREAM-RECALL, unpinned] `rvo2` (pip pyrvo2-danieldugas, nav_gym/setup.py:26) is not installed and its source
+ * is not in /root/reference.  What follows restates the published RVO2 Library 2.0 algorithm the binding wraps
+ * (Agent::computeNeighbors, Agent::computeNewVelocity, linearProgram1/2/3; van den Berg et al., "Reciprocal n-body
+ * collision avoidance"), float32 throughout like the library's Vector2, for the ONE agent whose velocity orca.py
+ * reads back (agent 0 of a simulator it rebuilds every step: itself + the other agents in view, their preferred
+ * velocity 0).  Stated differences from the library: neighbours are found by a linear scan in index order instead
+ * of kd-trees (same sorted bounded lists; ties may order differently), and obstacle edges are not split the way the
+ * obstacle kd-tree builder may split them -- the constraints are the same half-planes, their order can differ in
+ * degenerate (infeasible) cases.  RVO_EPSILON = 0.00001f.
+ * ======================================================================================= */
+#define ORCA_EPS 0.00001f
+#define ORCA_MAX_LINES (NAVSIM_ORCA_MAX_EDGES + NAVSIM_ORCA_MAX_AGENTS)
+typedef struct { float x, y; } ov2;
+typedef struct { ov2 point, direction; } oline;
+static inline ov2 ov(float x, float y) { ov2 r = {x, y}; return r; }
+static inline ov2 oadd(ov2 a, ov2 b) { return ov(a.x + b.x, a.y + b.y); }
+static inline ov2 osub(ov2 a, ov2 b) { return ov(a.x - b.x, a.y - b.y); }
+static inline ov2 omul(float s, ov2 a) { return ov(s * a.x, s * a.y); }
+static inline ov2 odiv(ov2 a, float s) { const float inv = 1.0f / s; return ov(a.x * inv, a.y * inv); }   /* Vector2::operator/ */
+static inline ov2 oneg(ov2 a) { return ov(-a.x, -a.y); }
+static inline float odot(ov2 a, ov2 b) { return a.x * b.x + a.y * b.y; }
+static inline float odet(ov2 a, ov2 b) { return a.x * b.y - a.y * b.x; }
+static inline float oabssq(ov2 a) { return odot(a, a); }
+static inline float oabs(ov2 a) { return sqrtf(odot(a, a)); }
+static inline ov2 onorm(ov2 a) { return odiv(a, oabs(a)); }
+static inline float osqr(float a) { return a * a; }
+
+static int orca_lp1(const oline* lines, int lineNo, float radius, ov2 optVelocity, int directionOpt, ov2* result) {
+    const float dotProduct = odot(lines[lineNo].point, lines[lineNo].direction);
+    const float discriminant = osqr(dotProduct) + osqr(radius) - oabssq(lines[lineNo].point);
+    if (discriminant < 0.0f) return 0;
+    const float sqrtDiscriminant = sqrtf(discriminant);
+    float tLeft = -dotProduct - sqrtDiscriminant;
+    float tRight = -dotProduct + sqrtDiscriminant;
+    for (int i = 0; i < lineNo; ++i) {
+        const float denominator = odet(lines[lineNo].direction, lines[i].direction);
+        const float numerator = odet(lines[i].direction, osub(lines[lineNo].point, lines[i].point));
+        if (fabsf(denominator) <= ORCA_EPS) {
+            if (numerator < 0.0f) return 0;
+            continue;
+        }
+        const float t = numerator / denominator;
+        if (denominator >= 0.0f) tRight = tRight < t ? tRight : t;
+        else                     tLeft = tLeft > t ? tLeft : t;
+        if (tLeft > tRight) return 0;
+    }
+    if (directionOpt) {
+        if (odot(optVelocity, lines[lineNo].direction) > 0.0f) *result = oadd(lines[lineNo].point, omul(tRight, lines[lineNo].direction));
+        else                                                  *result = oadd(lines[lineNo].point, omul(tLeft, lines[lineNo].direction));
+    } else {
+        const float t = odot(lines[lineNo].direction, osub(optVelocity, lines[lineNo].point));
+        if (t < tLeft)       *result = oadd(lines[lineNo].point, omul(tLeft, lines[lineNo].direction));
+        else if (t > tRight) *result = oadd(lines[lineNo].point, omul(tRight, lines[lineNo].direction));
+        else                 *result = oadd(lines[lineNo].point, omul(t, lines[lineNo].direction));
+    }
+    return 1;
+}
+
+static int orca_lp2(const oline* lines, int n, float radius, ov2 optVelocity, int directionOpt, ov2* result) {
+    if (directionOpt) *result = omul(radius, optVelocity);
+    else if (oabssq(optVelocity) > osqr(radius)) *result = omul(radius, onorm(optVelocity));
+    else *result = optVelocity;
+    for (int i = 0; i < n; ++i) {
+        if (odet(lines[i].direction, osub(lines[i].point, *result)) > 0.0f) {
+            const ov2 temp = *result;
+            if (!orca_lp1(lines, i, radius, optVelocity, directionOpt, result)) { *result = temp; return i; }
+        }
+    }
+    return n;
+}
+
+static void orca_lp3(const oline* lines, int n, int numObstLines, int beginLine, float radius, ov2* result) {
+    float distance = 0.0f;
+    oline proj[ORCA_MAX_LINES];
+    for (int i = beginLine; i < n; ++i) {
+        if (odet(lines[i].direction, osub(lines[i].point, *result)) > distance) {
+            int np = 0;
+            for (int j = 0; j < numObstLines; ++j) proj[np++] = lines[j];
+            for (int j = numObstLines; j < i; ++j) {
+                oline line;
+                const float determinant = odet(lines[i].direction, lines[j].direction);
+                if (fabsf(determinant) <= ORCA_EPS) {
+                    if (odot(lines[i].direction, lines[j].direction) > 0.0f) continue;
+                    line.point = omul(0.5f, oadd(lines[i].point, lines[j].point));
+                } else {
+                    line.point = oadd(lines[i].point, omul(odet(lines[j].direction, osub(lines[i].point, lines[j].point)) / determinant,
+                                                           lines[i].direction));
+                }
+                line.direction = onorm(osub(lines[j].direction, lines[i].direction));
+                proj[np++] = line;
+            }
+            const ov2 temp = *result;
+            if (orca_lp2(proj, np, radius, ov(-lines[i].direction.y, lines[i].direction.x), 1, result) < np) *result = temp;
+            distance = odet(lines[i].direction, osub(lines[i].point, *result));
+        }
+    }
+}
+
+/* one processed obstacle vertex (RVO2 Obstacle): point, unit direction to the next vertex, convexity, links */
+typedef struct { ov2 point, unitDir; int isConvex, next, prev; } oobst;
+
+/* agents [Q, A, 6] float64: px, py, vx, vy, radius, max_speed (agent 0 = the agent whose velocity is computed);
+ * n_agents [Q] or NULL (= A); pref_vel [Q,2]; obstacle polygons verts [S, O, V, 2] (counter-clockwise), n_obst [S] or
+ * NULL, obst_set [Q] index of the polygon set of query q (NULL: set 0 for all); theta [Q] heading of agent 0.
+ * out_vel [Q,2] = sim.getAgentVelocity(0) after doStep(); out_action [Q,2] = ActionRot(v, r) of orca.py:128-130
+ * (may be NULL). */
+int navsim_crowd_orca_cpu(const navsim_orca_params* p, int32_t n_queries, int32_t max_agents, const double* agents,
+                          const int32_t* n_agents, const double* pref_vel, int32_t max_obst, int32_t n_vert,
+                          const double* verts, const int32_t* n_obst, const int32_t* obst_set, const double* theta,
+                          double* out_vel, double* out_action) {
+    if (!p || !agents || !pref_vel || !out_vel || n_queries < 0 || max_agents < 1 || max_agents > NAVSIM_ORCA_MAX_AGENTS ||
+        max_obst < 0 || n_vert < 2 || (size_t)max_obst * n_vert > NAVSIM_ORCA_MAX_EDGES || (max_obst > 0 && !verts))
+        return NAVSIM_E_ARG;
+    for (int q = 0; q < n_queries; ++q) {
+        const double* ag = agents + (size_t)q * max_agents * 6;
+        int na = n_agents ? n_agents[q] : max_agents;
+        if (na > max_agents) na = max_agents;
+        if (na < 1) { out_vel[2 * q] = 0.0; out_vel[2 * q + 1] = 0.0; continue; }
+        const ov2 position = ov((float)ag[0], (float)ag[1]), velocity = ov((float)ag[2], (float)ag[3]);
+        const float radius = (float)ag[4], maxSpeed = (float)ag[5];
+        const ov2 prefVelocity = ov((float)pref_vel[2 * q], (float)pref_vel[2 * q + 1]);
+        /* ---- obstacles of this query's set (Simulator::addObstacle) */
+        oobst ob[NAVSIM_ORCA_MAX_EDGES];
+        int nob = 0;
+        const int set = obst_set ? obst_set[q] : 0;
+        int no = max_obst ? (n_obst ? n_obst[set] : max_obst) : 0;
+        if (no > max_obst) no = max_obst;
+        for (int o = 0; o < no; ++o) {
+            const double* vv = verts + (((size_t)set * max_obst + o) * n_vert) * 2;
+            const int base = nob;
+            for (int i = 0; i < n_vert; ++i) {
+                const int in = (i + 1) % n_vert, ip = (i + n_vert - 1) % n_vert;
+                oobst* t = &ob[nob++];
+                t->point = ov((float)vv[2 * i], (float)vv[2 * i + 1]);
+                const ov2 pn = ov((float)vv[2 * in], (float)vv[2 * in + 1]), pp = ov((float)vv[2 * ip], (float)vv[2 * ip + 1]);
+                t->unitDir = onorm(osub(pn, t->point));
+                t->isConvex = (n_vert == 2) ? 1 : (odet(osub(pp, pn), osub(t->point, pp)) >= 0.0f);   /* leftOf(prev, this, next) */
+                t->next = base + in; t->prev = base + ip;
+            }
+        }
+        /* ---- Agent::computeNeighbors: obstacle edges within range, agent on their right side, sorted by distance */
+        int obn[NAVSIM_ORCA_MAX_EDGES]; float obd[NAVSIM_ORCA_MAX_EDGES]; int nobn = 0;
+        {
+            const float rangeSq = osqr(p->time_horizon_obst * maxSpeed + radius);
+            for (int k = 0; k < nob; ++k) {
+                const ov2 a = ob[k].point, b = ob[ob[k].next].point;
+                const float agentLeftOfLine = odet(osub(a, position), osub(b, a));          /* leftOf(a, b, position) */
+                const float distSqLine = osqr(agentLeftOfLine) / oabssq(osub(b, a));
+                if (!(distSqLine < rangeSq) || !(agentLeftOfLine < 0.0f)) continue;
+                const float r = odot(osub(position, a), osub(b, a)) / oabssq(osub(b, a));    /* distSqPointLineSegment */
+                float distSq;
+                if (r < 0.0f) distSq = oabssq(osub(position, a));
+                else if (r > 1.0f) distSq = oabssq(osub(position, b));
+                else distSq = oabssq(osub(position, oadd(a, omul(r, osub(b, a)))));
+                if (distSq < rangeSq) {
+                    int i = nobn++;
+                    while (i != 0 && distSq < obd[i - 1]) { obn[i] = obn[i - 1]; obd[i] = obd[i - 1]; --i; }
+                    obn[i] = k; obd[i] = distSq;
+                }
+            }
+        }
+        int agn[NAVSIM_ORCA_MAX_AGENTS]; float agd[NAVSIM_ORCA_MAX_AGENTS]; int nagn = 0;
+        if (p->max_neighbors > 0) {
+            float rangeSq = osqr(p->neighbor_dist);
+            const int maxN = p->max_neighbors < NAVSIM_ORCA_MAX_AGENTS ? p->max_neighbors : NAVSIM_ORCA_MAX_AGENTS;
+            for (int k = 1; k < na; ++k) {
+                const ov2 op = ov((float)ag[6 * k], (float)ag[6 * k + 1]);
+                const float distSq = oabssq(osub(position, op));
+                if (distSq < rangeSq) {
+                    if (nagn < maxN) ++nagn;
+                    int i = nagn - 1;
+                    while (i != 0 && distSq < agd[i - 1]) { agn[i] = agn[i - 1]; agd[i] = agd[i - 1]; --i; }
+                    agn[i] = k; agd[i] = distSq;
+                    if (nagn == maxN) rangeSq = agd[nagn - 1];
+                }
+            }
+        }
+        /* ---- Agent::computeNewVelocity */
+        oline lines[ORCA_MAX_LINES];
+        int nl = 0;
+        const float invTimeHorizonObst = 1.0f / p->time_horizon_obst;
+        for (int i = 0; i < nobn; ++i) {
+            int o1 = obn[i], o2 = ob[o1].next;
+            const ov2 rel1 = osub(ob[o1].point, position), rel2 = osub(ob[o2].point, position);
+            int covered = 0;
+            for (int j = 0; j < nl; ++j)
+                if (odet(osub(omul(invTimeHorizonObst, rel1), lines[j].point), lines[j].direction) - invTimeHorizonObst * radius >= -ORCA_EPS &&
+                    odet(osub(omul(invTimeHorizonObst, rel2), lines[j].point), lines[j].direction) - invTimeHorizonObst * radius >= -ORCA_EPS) {
+                    covered = 1; break;
+                }
+            if (covered) continue;
+            const float distSq1 = oabssq(rel1), distSq2 = oabssq(rel2), radiusSq = osqr(radius);
+            const ov2 obstacleVector = osub(ob[o2].point, ob[o1].point);
+            const float s = odot(oneg(rel1), obstacleVector) / oabssq(obstacleVector);
+            const float distSqLine = oabssq(osub(oneg(rel1), omul(s, obstacleVector)));
+            oline line;
+            if (s < 0.0f && distSq1 <= radiusSq) {                        /* collision with the left vertex */
+                if (ob[o1].isConvex) { line.point = ov(0.0f, 0.0f); line.direction = onorm(ov(-rel1.y, rel1.x)); lines[nl++] = line; }
+                continue;
+            } else if (s > 1.0f && distSq2 <= radiusSq) {                  /* collision with the right vertex */
+                if (ob[o2].isConvex && odet(rel2, ob[o2].unitDir) >= 0.0f) {
+                    line.point = ov(0.0f, 0.0f); line.direction = onorm(ov(-rel2.y, rel2.x)); lines[nl++] = line;
+                }
+                continue;
+            } else if (s >= 0.0f && s < 1.0f && distSqLine <= radiusSq) {  /* collision with the segment */
+                line.point = ov(0.0f, 0.0f); line.direction = oneg(ob[o1].unitDir); lines[nl++] = line;
+                continue;
+            }
+            ov2 leftLeg, rightLeg;
+            if (s < 0.0f && distSqLine <= radiusSq) {                      /* viewed obliquely: the left vertex defines the VO */
+                if (!ob[o1].isConvex) continue;
+                o2 = o1;
+                const float leg1 = sqrtf(distSq1 - radiusSq);
+                leftLeg = odiv(ov(rel1.x * leg1 - rel1.y * radius, rel1.x * radius + rel1.y * leg1), distSq1);
+                rightLeg = odiv(ov(rel1.x * leg1 + rel1.y * radius, -rel1.x * radius + rel1.y * leg1), distSq1);
+            } else if (s > 1.0f && distSqLine <= radiusSq) {               /* ... the right vertex */
+                if (!ob[o2].isConvex) continue;
+                o1 = o2;
+                const float leg2 = sqrtf(distSq2 - radiusSq);
+                leftLeg = odiv(ov(rel2.x * leg2 - rel2.y * radius, rel2.x * radius + rel2.y * leg2), distSq2);
+                rightLeg = odiv(ov(rel2.x * leg2 + rel2.y * radius, -rel2.x * radius + rel2.y * leg2), distSq2);
+            } else {                                                       /* usual situation */
+                if (ob[o1].isConvex) {
+                    const float leg1 = sqrtf(distSq1 - radiusSq);
+                    leftLeg = odiv(ov(rel1.x * leg1 - rel1.y * radius, rel1.x * radius + rel1.y * leg1), distSq1);
+                } else leftLeg = oneg(ob[o1].unitDir);
+                if (ob[o2].isConvex) {
+                    const float leg2 = sqrtf(distSq2 - radiusSq);
+                    rightLeg = odiv(ov(rel2.x * leg2 + rel2.y * radius, -rel2.x * radius + rel2.y * leg2), distSq2);
+                } else rightLeg = ob[o1].unitDir;
+            }
+            const int leftNeighbor = ob[o1].prev;
+            int leftForeign = 0, rightForeign = 0;
+            if (ob[o1].isConvex && odet(leftLeg, oneg(ob[leftNeighbor].unitDir)) >= 0.0f) { leftLeg = oneg(ob[leftNeighbor].unitDir); leftForeign = 1; }
+            if (ob[o2].isConvex && odet(rightLeg, ob[o2].unitDir) <= 0.0f) { rightLeg = ob[o2].unitDir; rightForeign = 1; }
+            const ov2 leftCutoff = omul(invTimeHorizonObst, osub(ob[o1].point, position));
+            const ov2 rightCutoff = omul(invTimeHorizonObst, osub(ob[o2].point, position));
+            const ov2 cutoffVec = osub(rightCutoff, leftCutoff);
+            const float t = (o1 == o2) ? 0.5f : odot(osub(velocity, leftCutoff), cutoffVec) / oabssq(cutoffVec);
+            const float tLeft = odot(osub(velocity, leftCutoff), leftLeg);
+            const float tRight = odot(osub(velocity, rightCutoff), rightLeg);
+            if ((t < 0.0f && tLeft < 0.0f) || (o1 == o2 && tLeft < 0.0f && tRight < 0.0f)) {    /* left cut-off circle */
+                const ov2 unitW = onorm(osub(velocity, leftCutoff));
+                line.direction = ov(unitW.y, -unitW.x);
+                line.point = oadd(leftCutoff, omul(radius * invTimeHorizonObst, unitW));
+                lines[nl++] = line;
+                continue;
+            } else if (t > 1.0f && tRight < 0.0f) {                                              /* right cut-off circle */
+                const ov2 unitW = onorm(osub(velocity, rightCutoff));
+                line.direction = ov(unitW.y, -unitW.x);
+                line.point = oadd(rightCutoff, omul(radius * invTimeHorizonObst, unitW));
+                lines[nl++] = line;
+                continue;
+            }
+            const float distSqCutoff = (t < 0.0f || t > 1.0f || o1 == o2) ? INFINITY : oabssq(osub(velocity, oadd(leftCutoff, omul(t, cutoffVec))));
+            const float distSqLeft = (tLeft < 0.0f) ? INFINITY : oabssq(osub(velocity, oadd(leftCutoff, omul(tLeft, leftLeg))));
+            const float distSqRight = (tRight < 0.0f) ? INFINITY : oabssq(osub(velocity, oadd(rightCutoff, omul(tRight, rightLeg))));
+            if (distSqCutoff <= distSqLeft && distSqCutoff <= distSqRight) {                     /* cut-off line */
+                line.direction = oneg(ob[o1].unitDir);
+                line.point = oadd(leftCutoff, omul(radius * invTimeHorizonObst, ov(-line.direction.y, line.direction.x)));
+                lines[nl++] = line;
+            } else if (distSqLeft <= distSqRight) {                                              /* left leg */
+                if (leftForeign) continue;
+                line.direction = leftLeg;
+                line.point = oadd(leftCutoff, omul(radius * invTimeHorizonObst, ov(-line.direction.y, line.direction.x)));
+                lines[nl++] = line;
+            } else {                                                                             /* right leg */
+                if (rightForeign) continue;
+                line.direction = oneg(rightLeg);
+                line.point = oadd(rightCutoff, omul(radius * invTimeHorizonObst, ov(-line.direction.y, line.direction.x)));
+                lines[nl++] = line;
+            }
+        }
+        const int numObstLines = nl;
+        const float invTimeHorizon = 1.0f / p->time_horizon;
+        for (int i = 0; i < nagn; ++i) {
+            const double* o = ag + 6 * agn[i];
+            const ov2 relativePosition = osub(ov((float)o[0], (float)o[1]), position);
+            const ov2 relativeVelocity = osub(velocity, ov((float)o[2], (float)o[3]));
+            const float distSq = oabssq(relativePosition);
+            const float combinedRadius = radius + (float)o[4];
+            const float combinedRadiusSq = osqr(combinedRadius);
+            oline line;
+            ov2 u;
+            if (distSq > combinedRadiusSq) {
+                const ov2 w = osub(relativeVelocity, omul(invTimeHorizon, relativePosition));
+                const float wLengthSq = oabssq(w);
+                const float dotProduct1 = odot(w, relativePosition);
+                if (dotProduct1 < 0.0f && osqr(dotProduct1) > combinedRadiusSq * wLengthSq) {    /* cut-off circle */
+                    const float wLength = sqrtf(wLengthSq);
+                    const ov2 unitW = odiv(w, wLength);
+                    line.direction = ov(unitW.y, -unitW.x);
+                    u = omul(combinedRadius * invTimeHorizon - wLength, unitW);
+                } else {                                                                          /* legs */
+                    const float leg = sqrtf(distSq - combinedRadiusSq);
+                    if (odet(relativePosition, w) > 0.0f)
+                        line.direction = odiv(ov(relativePosition.x * leg - relativePosition.y * combinedRadius,
+                                                 relativePosition.x * combinedRadius + relativePosition.y * leg), distSq);
+                    else
+                        line.direction = oneg(odiv(ov(relativePosition.x * leg + relativePosition.y * combinedRadius,
+                                                      -relativePosition.x * combinedRadius + relativePosition.y * leg), distSq));
+                    const float dotProduct2 = odot(relativeVelocity, line.direction);
+                    u = osub(omul(dotProduct2, line.direction), relativeVelocity);
+                }
+            } else {                                                                              /* already colliding */
+                const float invTimeStep = 1.0f / p->time_step;
+                const ov2 w = osub(relativeVelocity, omul(invTimeStep, relativePosition));
+                const float wLength = oabs(w);
+                const ov2 unitW = odiv(w, wLength);
+                line.direction = ov(unitW.y, -unitW.x);
+                u = omul(combinedRadius * invTimeStep - wLength, unitW);
+            }
+            line.point = oadd(velocity, omul(0.5f, u));
+            lines[nl++] = line;
+        }
+        ov2 newVelocity;
+        const int lineFail = orca_lp2(lines, nl, maxSpeed, prefVelocity, 0, &newVelocity);
+        if (lineFail < nl) orca_lp3(lines, nl, numObstLines, lineFail, maxSpeed, &newVelocity);
+        out_vel[2 * q] = (double)newVelocity.x; out_vel[2 * q + 1] = (double)newVelocity.y;
+        if (out_action) {                                                  /* orca.py:128-130 */
+            const double vx = (double)newVelocity.x, vy = (double)newVelocity.y;
+            out_action[2 * q] = sqrt(vx * vx + vy * vy);
+            out_action[2 * q + 1] = nvr_atan2(vy, vx) - (theta ? theta[q] : 0.0);
+        }
+    }
+    return NAVSIM_OK;
+}
+
+/* Agent.step with an ActionRot (crowd_sim/envs/utils/agent.py:108-141): pose [n,3] in/out, action [n,2] = (v, r),
+ * vel [n,2] out */
+int navsim_crowd_agent_step_cpu(double* pose, const double* action, double* vel, int32_t n, double time_step) {
+    if (!pose || !action || n < 0) return NAVSIM_E_ARG;
+    for (int i = 0; i < n; ++i) {
+        double* ps = pose + 3 * i;
+        const double v = action[2 * i], r = action[2 * i + 1];
+        const double theta = ps[2] + r;
+        double s, c;
+        nvr_sincos(theta, &s, &c);
+        ps[0] = ps[0] + c * v * time_step;
+        ps[1] = ps[1] + s * v * time_step;
+        if (vel) { vel[2 * i] = v * c; vel[2 * i + 1] = v * s; }
+        ps[2] = nvr_mod_2pi(ps[2] + r);
+    }
+    return NAVSIM_OK;
+}

@@ -113,6 +113,13 @@ int navsim_crowd_angular_map_cpu(const navsim_crowd_map_params* p, int32_t n_env
 int navsim_crowd_local_map_cpu(const navsim_crowd_map_params* p, int32_t n_envs, int32_t grid, const uint8_t* free_map,
                                const double* robot, int32_t rotate, uint8_t* out);
 
+/* CrowdSim-v0 pedestrians: ORCA (RVO2 restated, unpinned) and Agent.step; see include/navsim.h */
+int navsim_crowd_orca_cpu(const navsim_orca_params* p, int32_t n_queries, int32_t max_agents, const double* agents,
+                          const int32_t* n_agents, const double* pref_vel, int32_t max_obst, int32_t n_vert,
+                          const double* verts, const int32_t* n_obst, const int32_t* obst_set, const double* theta,
+                          double* out_vel, double* out_action);
+int navsim_crowd_agent_step_cpu(double* pose, const double* action, double* vel, int32_t n, double time_step);
+
 /* statistics for DESIGN.md: distance-field probes of the last cast/step on this thread */
 int64_t navsim_probe_count_cpu(int32_t reset);
 

@@ -274,6 +274,34 @@ def crowd_local_map(params, free_map, robot, rotate=True):
     return out
 
 
+def crowd_orca(params, agents, pref_vel, verts=None, n_agents=None, n_obst=None, obst_set=None, theta=None):
+    """navsim_crowd_orca_cpu: agents [Q,A,6], pref_vel [Q,2], verts [S,O,V,2] -> (vel [Q,2], action [Q,2])."""
+    p = abi.NavsimOrcaParams(**{k: (int(v) if k == "max_neighbors" else float(v)) for k, v in params.items()})
+    agents = np.ascontiguousarray(agents, dtype=np.float64)
+    Q, A = agents.shape[0], agents.shape[1]
+    pref_vel = np.ascontiguousarray(pref_vel, dtype=np.float64).reshape(Q, 2)
+    if verts is None or np.size(verts) == 0:
+        verts, O, V = None, 0, 4
+    else:
+        verts = np.ascontiguousarray(verts, dtype=np.float64)
+        O, V = verts.shape[1], verts.shape[2]
+    i32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+    na, no, os_ = i32(n_agents), i32(n_obst), i32(obst_set)
+    th = None if theta is None else np.ascontiguousarray(theta, dtype=np.float64)
+    vel, act = np.zeros((Q, 2)), np.zeros((Q, 2))
+    _chk(lib().navsim_crowd_orca_cpu(C.byref(p), Q, A, _p(agents), _p(na), _p(pref_vel), O, V, _p(verts), _p(no), _p(os_),
+                                     _p(th), _p(vel), _p(act)), "crowd_orca")
+    return vel, act
+
+
+def crowd_agent_step(pose, action, time_step):
+    pose = np.ascontiguousarray(pose, dtype=np.float64).copy()
+    action = np.ascontiguousarray(action, dtype=np.float64)
+    vel = np.zeros((pose.shape[0], 2))
+    _chk(lib().navsim_crowd_agent_step_cpu(_p(pose), _p(action), _p(vel), pose.shape[0], float(time_step)), "crowd_agent_step")
+    return pose, vel
+
+
 def math_fn(fn, x, x2=None):
     x = np.ascontiguousarray(x, dtype=np.float64)
     x2a = None if x2 is None else np.ascontiguousarray(x2, dtype=np.float64)

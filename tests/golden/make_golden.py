@@ -682,9 +682,48 @@ def make_crowd_maps():
           % (n, 100 * (amap < 1.0).mean(), m, 100 * (lmap == 0).mean()))
 
 
+def make_crowd_agent():
+    """Agent.step with an ActionRot (crowd_sim/envs/utils/agent.py:108-141), the reference's own method on 500 random
+    states: new pose, velocity."""
+    import importlib
+    for name in ("gym", "gym.envs", "gym.envs.registration", "rvo2", "cv2", "tensorflow", "PIL", "matplotlib",
+                 "crowd_nav", "crowd_nav.policy", "crowd_nav.policy.policy_factory"):
+        try:
+            importlib.import_module(name)
+        except Exception:
+            sys.modules[name] = types.ModuleType(name)
+    if not hasattr(sys.modules["gym"], "Env"):
+        sys.modules["gym"].Env = object
+    if not hasattr(sys.modules["gym.envs.registration"], "register"):
+        sys.modules["gym.envs.registration"].register = lambda **k: None
+    sys.modules["crowd_nav.policy.policy_factory"].policy_factory = {}
+    sys.path.insert(0, REF_SRC)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from crowd_sim.envs.utils.agent import Agent
+    from crowd_sim.envs.utils.action import ActionRot
+    rng = np.random.default_rng(44)
+    n = 500
+    pose = np.concatenate([rng.uniform(-8, 8, (n, 2)), rng.uniform(0, 2 * np.pi, (n, 1))], axis=1)
+    action = np.stack([rng.uniform(0, 1.2, n), rng.uniform(-np.pi, np.pi, n)], axis=1)
+    out = np.zeros((n, 3)); vel = np.zeros((n, 2))
+    for k in range(n):
+        a = object.__new__(Agent)
+        a.px, a.py, a.theta, a.time_step = pose[k, 0], pose[k, 1], pose[k, 2], 0.25
+        a.vx = a.vy = 0.0
+        Agent.step(a, ActionRot(action[k, 0], action[k, 1]))
+        out[k] = [a.px, a.py, a.theta]; vel[k] = [a.vx, a.vy]
+    np.savez_compressed(os.path.join(HERE, "golden_crowd_agent.npz"), pose=pose, action=action, time_step=np.float64(0.25),
+                        pose_out=out, vel_out=vel)
+    print("golden_crowd_agent.npz: n=%d" % n)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "crowd_maps":      # only this fixture (the others stay byte-identical)
         return make_crowd_maps()
+    if len(sys.argv) > 1 and sys.argv[1] == "crowd_agent":
+        return make_crowd_agent()
     ref_env, human, keti_robot, ref_utils, human_policy = import_reference()
     make_units(ref_env, human, keti_robot, ref_utils)
     run_trace("random_S1", ref_env, human, human_policy, S=1, seed=11, scenario="random", n_steps=40, ped_scan_every=5)
@@ -693,6 +732,7 @@ def main():
     run_trace("success_S2", ref_env, human, human_policy, S=2, seed=14, scenario="success", n_steps=12)
     make_crowd()
     make_crowd_maps()
+    make_crowd_agent()
 
 
 if __name__ == "__main__":

@@ -833,6 +833,41 @@ def test_crowd_local_maps_vs_reference_and_oracle(gpu, golden_dir):
         ref.crowd_local_map(P2, fm, robot[:600], rotate=True), "rotated local map, random batch")
 
 
+def test_crowd_orca_and_agent_step_vs_oracle(gpu, golden_dir):
+    """CrowdSim-v0 pedestrians on the device: the restated RVO2 step (navsim_crowd_orca; rvo2 absent -> unpinned)
+    equals the oracle bit for bit on 20 000 random queries -- ragged agent counts, crowded and colliding
+    situations, box and triangle obstacles from several polygon sets -- and Agent.step equals the oracle bit for bit
+    and the reference's recorded goldens to 1e-12."""
+    rng = np.random.default_rng(17)
+    Q, A, S, O, V = 20000, 12, 7, 6, 4
+    P = dict(time_step=0.25, neighbor_dist=10, time_horizon=5, time_horizon_obst=5, max_neighbors=10)
+    ag = np.zeros((Q, A, 6))
+    ag[..., :2] = rng.uniform(-4, 4, (Q, A, 2)); ag[..., 2:4] = rng.uniform(-1, 1, (Q, A, 2))
+    ag[..., 4] = rng.uniform(0.2, 0.5, (Q, A)); ag[..., 5] = rng.uniform(0.5, 1.5, (Q, 1))
+    ag[::7, 1, :2] = ag[::7, 0, :2] + rng.uniform(-0.3, 0.3, (len(ag[::7]), 2))       # already overlapping neighbours
+    n_agents = rng.integers(1, A + 1, Q).astype(np.int32)
+    pv = rng.uniform(-1.2, 1.2, (Q, 2))
+    ctr = rng.uniform(-5, 5, (S, O, 1, 2)); half = rng.uniform(0.2, 1.5, (S, O, 1, 2))
+    sign = np.array([[1, 1], [-1, 1], [-1, -1], [1, -1]], float)                        # counter-clockwise boxes
+    verts = ctr + half * sign
+    verts[:, 0, 3] = verts[:, 0, 0] + [0.0, -0.01]                                      # a thin sliver: near-degenerate edge
+    n_obst = rng.integers(0, O + 1, S).astype(np.int32)
+    obst_set = rng.integers(0, S, Q).astype(np.int32)
+    theta = rng.uniform(0, 2 * np.pi, Q)
+    gv, ga = gpu.sim.crowd_orca(P, _t(gpu, ag), _t(gpu, pv), _t(gpu, verts), _t(gpu, n_agents), _t(gpu, n_obst),
+                                _t(gpu, obst_set), _t(gpu, theta))
+    rv, ra = ref.crowd_orca(P, ag, pv, verts, n_agents, n_obst, obst_set, theta)
+    _eq(gv.cpu().numpy(), rv, "ORCA velocity")
+    _eq(ga.cpu().numpy(), ra, "ORCA action")
+    assert (np.linalg.norm(rv, axis=1) <= ag[:, 0, 5] * (1 + 5e-3)).all()               # the speed disc (float32 LP: a few 1e-4 over)
+    assert (np.abs(rv - pv) > 1e-3).any(axis=1).mean() > 0.3                             # the constraints do bind
+    d = np.load(os.path.join(golden_dir, "golden_crowd_agent.npz"))
+    gp, gvel = gpu.sim.crowd_agent_step(_t(gpu, d["pose"]), _t(gpu, d["action"]), float(d["time_step"]))
+    rp, rvel = ref.crowd_agent_step(d["pose"], d["action"], float(d["time_step"]))
+    _eq(gp.cpu().numpy(), rp, "Agent.step pose"); _eq(gvel.cpu().numpy(), rvel, "Agent.step velocity")
+    np.testing.assert_allclose(rp, d["pose_out"], rtol=0, atol=1e-12)
+
+
 def test_config1_single_env_64_beams(gpu):
     """BASELINE config 1: 1 env, 64-beam lidar, 100x100 static map, no pedestrians."""
     cfg = gpu.lib.default_config(n_envs=1, map_h=100, map_w=100, n_spawn=4, auto_reset=0, seed=7)

@@ -277,3 +277,64 @@ def test_crowd_local_map_rotation_properties(golden_dir):
     exp = np.ones_like(plain)
     exp[:, 1:, 1:] = plain[:, :0:-1, :0:-1]
     assert np.array_equal(half, exp)
+
+
+ORCA_P = dict(time_step=0.25, neighbor_dist=10, time_horizon=5, time_horizon_obst=5, max_neighbors=10)   # orca.py:62-65
+
+
+def test_crowd_agent_step_vs_reference(golden_dir):
+    """Agent.step with an ActionRot (crowd_sim/envs/utils/agent.py:108-141) on 500 states recorded from the
+    reference's own method: pose and velocity to 1e-12 (deterministic cos / sin within an ulp of libm)."""
+    d = np.load(os.path.join(golden_dir, "golden_crowd_agent.npz"))
+    pose, vel = ref.crowd_agent_step(d["pose"], d["action"], float(d["time_step"]))
+    np.testing.assert_allclose(pose, d["pose_out"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(vel, d["vel_out"], rtol=0, atol=1e-12)
+
+
+def _orca_rollout(pos, goal, radius, v_pref, verts=None, steps=200):
+    """CrowdSim's ORCA pedestrians in closed loop: every agent builds its own query (itself first), then all move."""
+    n = len(pos)
+    pos = np.array(pos, float); vel = np.zeros((n, 2)); goal = np.array(goal, float)
+    closest, traj = np.inf, [pos.copy()]
+    for _ in range(steps):
+        ag = np.zeros((n, n, 6)); pv = np.zeros((n, 2))
+        for i in range(n):
+            for k, j in enumerate([i] + [j for j in range(n) if j != i]):
+                ag[i, k] = [pos[j, 0], pos[j, 1], vel[j, 0], vel[j, 1], radius, v_pref]
+            dvec = goal[i] - pos[i]; sp = np.linalg.norm(dvec)
+            pv[i] = dvec / sp if sp > 1 else dvec                              # orca.py:116-120
+        vel, _ = ref.crowd_orca(ORCA_P, ag, pv, verts)
+        pos = pos + vel * ORCA_P["time_step"]
+        traj.append(pos.copy())
+        for i in range(n):
+            for j in range(i + 1, n):
+                closest = min(closest, float(np.linalg.norm(pos[i] - pos[j])))
+    return pos, closest, np.array(traj)
+
+
+def test_crowd_orca_properties():
+    """rvo2 is absent (UNPINNED): what the restated RVO2 step must do regardless -- alone an agent takes its
+    preferred velocity (clipped to its maximum speed); two agents walking at each other pass without their discs
+    overlapping and reach their goals; eight agents crossing a circle never overlap; a wall in the way is never
+    entered; the mirrored problem gives the mirrored answer."""
+    v, a = ref.crowd_orca(ORCA_P, [[[0, 0, 0, 0, 0.3, 1.0]]], [[0.6, 0.0]], theta=[0.5])
+    assert np.allclose(v, [[0.6, 0.0]], atol=1e-7) and np.allclose(a, [[0.6, -0.5]], atol=1e-7)
+    v, _ = ref.crowd_orca(ORCA_P, [[[0, 0, 0, 0, 0.3, 1.0]]], [[3.0, 4.0]])
+    assert abs(np.hypot(*v[0]) - 1.0) < 1e-6
+    pos, closest, _ = _orca_rollout([[-3, 0], [3, 0.001]], [[3, 0], [-3, 0]], 0.3, 1.0)
+    assert closest >= 0.6 - 1e-4 and np.abs(pos - [[3, 0], [-3, 0]]).max() < 0.05
+    ang = np.arange(8) * 2 * np.pi / 8
+    p0 = np.stack([4 * np.cos(ang), 4 * np.sin(ang)], 1)
+    _, closest, _ = _orca_rollout(p0, -p0, 0.3, 1.0, steps=120)
+    assert closest >= 0.6 - 1e-4
+    box = np.array([[[[1, 1], [-1, 1], [-1, -1], [1, -1]]]], float)             # counter-clockwise
+    _, _, traj = _orca_rollout([[-4, 0.2]], [[4, 0]], 0.3, 1.0, verts=box, steps=200)
+    assert not ((np.abs(traj[:, 0, 0]) < 1.29) & (np.abs(traj[:, 0, 1]) < 1.29)).any()
+    rng = np.random.default_rng(1)                                               # mirror symmetry (y -> -y)
+    ag = np.zeros((50, 6, 6)); ag[..., :2] = rng.uniform(-3, 3, (50, 6, 2)); ag[..., 2:4] = rng.uniform(-1, 1, (50, 6, 2))
+    ag[..., 4] = 0.3; ag[..., 5] = 1.0
+    pv = rng.uniform(-1, 1, (50, 2))
+    v1, _ = ref.crowd_orca(ORCA_P, ag, pv)
+    m = ag.copy(); m[..., 1] *= -1; m[..., 3] *= -1
+    v2, _ = ref.crowd_orca(ORCA_P, m, pv * [1, -1])
+    assert np.allclose(v1 * [1, -1], v2, atol=1e-5)
