@@ -55,6 +55,46 @@ def test_argument_validation_without_gpu():
     assert L.navsim_build_dt_workspace_bytes(3, 10, 20) == 3 * 10 * 20 * 2
 
 
+def test_argument_validation_of_round2_entry_points():
+    """navsim_build_rects, the CrowdSim entry points and the new config fields reject bad arguments with error
+    codes before any launch (checked here without a GPU)."""
+    from nav_gym_amd import lib
+    L = lib.load()
+    assert L.navsim_rect_table_bytes(2, 500, 500) == 2 * 63 * 63 * 16
+    assert L.navsim_build_rects(None, 1, 8, 8, None, abi.FIELD_U16T, None, None, None, 0, None) == abi.E_ARG
+    one = C.c_char_p(b"x" * 64)
+    assert L.navsim_build_rects(one, 1, 2000, 2000, one, abi.FIELD_U16T, None, one, one, 1 << 30, None) == abi.E_UNSUPPORTED
+    mp = abi.NavsimCrowdMapParams(angular_min=-3.14, angular_max=3.14, angular_max_range=6.0, angular_dim=0, normalize=1,
+                                  map_size_m=14.0, map_resolution=0.1, submap_size_m=6.0)
+    assert L.navsim_crowd_angular_map(C.byref(mp), 1, 0, 4, one, None, None, one, None) == abi.E_ARG      # angular_dim 0
+    mp.angular_dim = 72
+    assert L.navsim_crowd_angular_map(C.byref(mp), 1, 1, 99, one, one, None, one, None) == abi.E_ARG      # too many vertices
+    mp.submap_size_m = 1000.0
+    assert L.navsim_crowd_local_map(C.byref(mp), 1, 140, one, one, 1, one, None) == abi.E_UNSUPPORTED     # window beyond LDS
+    op = abi.NavsimOrcaParams(time_step=0.25, neighbor_dist=10, time_horizon=5, time_horizon_obst=5, max_neighbors=10)
+    assert L.navsim_crowd_orca(C.byref(op), 1, abi.ORCA_MAX_AGENTS + 1, one, None, one, 0, 4, None, None, None, None, one,
+                               None, None) == abi.E_ARG
+    assert L.navsim_crowd_orca(C.byref(op), 1, 4, one, None, one, 40, 4, one, None, None, None, one, None, None) == abi.E_ARG
+    assert L.navsim_crowd_orca(C.byref(op), 0, 4, one, None, one, 0, 4, None, None, None, None, one, None, None) == 0
+    assert L.navsim_crowd_agent_step(None, None, None, 3, 0.25, None) == abi.E_ARG
+    # config fields that replaced the environment knobs are validated by navsim_step
+    cfg = lib.default_config()
+    assert (cfg.march_rule, cfg.step_block, cfg.ped_split) == (abi.MARCH_F64, 0, 0)
+    st, io = abi.NavsimState(), abi.NavsimStepIO()
+    for name in ("field", "scan_threshold", "scan_discomfort", "robot_pose", "robot_goal", "prev_action", "prev_pose",
+                 "n_hist", "episode", "steps"):
+        setattr(st, name, C.cast(one, C.c_void_p))
+    for name in ("action", "obs", "reward", "done", "is_success", "is_crash", "distance"):
+        setattr(io, name, C.cast(one, C.c_void_p))
+    for field, bad in (("step_block", 100), ("ped_split", 3), ("march_rule", 2)):
+        c2 = cfg.copy(); setattr(c2, field, bad)
+        assert L.navsim_step(C.byref(c2), C.byref(st), C.byref(io), None) == abi.E_ARG, field
+    c2 = cfg.copy(); c2.field_format = abi.FIELD_F32; st.rect_table = C.cast(one, C.c_void_p)
+    assert L.navsim_step(C.byref(c2), C.byref(st), C.byref(io), None) == abi.E_UNSUPPORTED       # rect records need the packed field
+    c2 = cfg.copy(); c2.n_beams = 20000; c2.ped_model = abi.PED_SFM; c2.max_peds = 64; st.rect_table = None
+    assert L.navsim_step(C.byref(c2), C.byref(st), C.byref(io), None) in (abi.E_ARG, abi.E_UNSUPPORTED)   # LDS beyond a CU
+
+
 def test_registry_and_env_surface(golden_dir):
     import nav_gym_env
     from nav_gym_amd import registry
