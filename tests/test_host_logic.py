@@ -55,6 +55,12 @@ def test_argument_validation_without_gpu():
     assert L.navsim_build_dt_workspace_bytes(3, 10, 20) == 3 * 10 * 20 * 2
 
 
+def test_graft_entry_library_check():
+    """__graft_entry__.build()'s post-build check (ABI version and export list) passes on the in-tree library."""
+    import __graft_entry__ as entry
+    entry.check_library()
+
+
 def test_argument_validation_of_round2_entry_points():
     """navsim_build_rects, the CrowdSim entry points and the new config fields reject bad arguments with error
     codes before any launch (checked here without a GPU)."""
