@@ -18,6 +18,7 @@ struct StepShared {
     float t1;                     // march parameter after the shared first probe (origin cell)
     float r_all;                  // >= 0: every beam has this raw range (origin occupied / no march)
     unsigned long long step_key;  // scan-noise counter of this step
+    int next_chunk;               // scan: next 64-beam chunk to hand to a wavefront (reset before every scan)
     double wave_ratio[kMaxWaves];
 };
 // Pedestrian scratch of the pedestrian variants of the kernel, carved out of dynamic LDS behind the scan's
@@ -314,8 +315,13 @@ __device__ __forceinline__ float ray_result(bool hit, float x0, float y0, float 
 // Predicated one-ray-per-lane scan: the march loop has ONE wave-level branch
 // (any lane still marching?) instead of a divergent if-ladder per probe; finished or out-of-map
 // lanes keep executing with their updates masked off.
+//
+// Beams are handed out in chunks of 64 adjacent beams, one chunk per wavefront at a time, from a counter in LDS:
+// 1081 beams are 16.9 chunks, so a static `k += BLOCK` walk gives wavefront 0 of every 256-thread workgroup five
+// chunks and the others four, and the workgroup lives as long as its slowest wavefront.  Which wavefront
+// marches a beam changes no result.  The caller zeroes sh.next_chunk behind a barrier before every scan.
 template <int BLOCK, typename Field, bool TO_LDS, int RULE, bool RECT>
-__device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const StepShared& sh,
+__device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShared& sh,
                                                 const Field& field, const uint4* __restrict__ rects,
                                                 const double* __restrict__ tab,
                                                 const Prims pr, float2* __restrict__ dir_lds, float* __restrict__ rng_lds,
@@ -359,17 +365,27 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, const St
             if (S - 1 - j > n_hist) obs_row[(size_t)j * B + k] = rr;
     };
     const float miss = (r_all >= 0.0f) ? r_all : max_range;
-    {
-        for (int k = (int)threadIdx.x; k < B; k += BLOCK) {
-            float dx, dy;
-            beam_dir_k(c, tab, k, step, (double)sh.lth, sh.cT, sh.sT, dx, dy);
-            float t = t1;
-            bool active = r_all < 0.0f;
-            bool hit = false;
-            while (wave_any(active))
-                probe_round<Field, RULE, RECT>(field, (const char*)rects, tpr, x0, y0, dx, dy, uW, uH, max_range, t, active, hit);
-            finish(k, dx, dy, ray_result(hit, x0, y0, dx, dy, t, miss));
+    int own_chunk = 0;                                    // one wavefront per arena: no counter needed
+    const int lane = (int)threadIdx.x & 63;
+    for (;;) {
+        int chunk = 0;
+        if (BLOCK > 64) {
+            if (lane == 0) chunk = atomicAdd(&sh.next_chunk, 1);
+            chunk = __builtin_amdgcn_readfirstlane(chunk);
+        } else {
+            chunk = own_chunk++;
         }
+        if (chunk * 64 >= B) break;
+        const int k = chunk * 64 + lane;
+        const bool valid = k < B;
+        float dx, dy;
+        beam_dir_k(c, tab, valid ? k : B - 1, step, (double)sh.lth, sh.cT, sh.sT, dx, dy);
+        float t = t1;
+        bool active = valid & (r_all < 0.0f);
+        bool hit = false;
+        while (wave_any(active))
+            probe_round<Field, RULE, RECT>(field, (const char*)rects, tpr, x0, y0, dx, dy, uW, uH, max_range, t, active, hit);
+        if (valid) finish(k, dx, dy, ray_result(hit, x0, y0, dx, dy, t, miss));
     }
     if (TO_LDS) {
         __syncthreads();
@@ -690,6 +706,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         first_probe<RULE>(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
         sh.step_key = (unsigned long long)st.episode[e] * 0x100000000ULL +
                       (unsigned long long)(reset_only ? 0 : st.steps[e]) * 2ULL;
+        sh.next_chunk = 0;
     }
     __syncthreads();
 
@@ -749,6 +766,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 sh.rescan = 1;
             }
             if (sh.rescan) {
+                sh.next_chunk = 0;
                 sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];
                 nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);
                 nv::sincos((double)sh.lth, sh.sT, sh.cT);
