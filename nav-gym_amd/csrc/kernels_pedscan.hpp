@@ -64,8 +64,8 @@ __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim
         nv::beam_dir((float)(lin + lth), dx, dy);
         dir[k] = make_float2(dx, dy);
         float t = 0.0f;
-        bool active = true, hit = false;
-        while (wave_any(active))
+        lanemask_t active = mask_of(true), hit = 0;
+        while (active != 0)
             probe_round<Field, RULE, RECT>(field, rects, tpr, x0, y0, dx, dy, (unsigned)W, (unsigned)H, max_range, t, active, hit);
         rng[k] = ray_result(hit, x0, y0, dx, dy, t, max_range) * res;
     }

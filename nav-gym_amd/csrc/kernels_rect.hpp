@@ -30,19 +30,20 @@ __host__ __device__ inline size_t rect_tiles_per_map(int H, int W) {
 // squared distance from cell p = (py << 16 | px) to the rectangle lo = (y0 << 16 | x0), hi = (y1 << 16 | x1)
 __device__ __forceinline__ int rect_dist2(unsigned lo, unsigned hi, unsigned p) {
     const rect_s2 L = __builtin_bit_cast(rect_s2, lo), Hh = __builtin_bit_cast(rect_s2, hi), P = __builtin_bit_cast(rect_s2, p);
-    rect_s2 m = __builtin_elementwise_max(L - P, P - Hh);
-    const rect_s2 z = {0, 0};
-    m = __builtin_elementwise_max(m, z);
+    // p minus p clamped into the rectangle (lo <= hi per component in every record the builder writes): per
+    // component L - P, 0 or P - H up to the sign, which the squares drop.  v_pk_max_i16, v_pk_min_i16, v_pk_sub_i16.
+    const rect_s2 m = P - __builtin_elementwise_min(__builtin_elementwise_max(P, L), Hh);
     // v_dot2_i32_i16 with the accumulator as an inline 0 (the builtin selects v_dot2c + a v_mov of the zero)
     int r;
     asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(r) : "v"(__builtin_bit_cast(unsigned, m)));
     return r;
 }
-__device__ __forceinline__ int rect_record_d2(const uint4 rec, int px, int py) {
-    const unsigned p = ((unsigned)py << 16) | (unsigned)px;
+__device__ __forceinline__ unsigned rect_cell(int px, int py) { return ((unsigned)py << 16) | (unsigned)px; }
+__device__ __forceinline__ int rect_record_d2(const uint4 rec, unsigned p) {
     const int a = rect_dist2(rec.x, rec.y, p), b = rect_dist2(rec.z, rec.w, p);
     return a < b ? a : b;
 }
+__device__ __forceinline__ int rect_record_d2(const uint4 rec, int px, int py) { return rect_record_d2(rec, rect_cell(px, py)); }
 __device__ __forceinline__ bool rect_record_invalid(const uint4 rec) { return (rec.x & 0xFFFFu) == kRectInvalid; }
 
 // ---- builder pass 1: transpose of the occupancy grid (32x32 tiles through LDS), so that the vertical runs can be

@@ -256,60 +256,81 @@ __device__ __forceinline__ void finish_beams(const navsim_config& c, const StepS
     discomfort = dc;
 }
 
-__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// ---- wave masks as scalars.  The march keeps its per-lane flags (still marching / hit) as 64-bit lane masks in
+// scalar registers and combines them with scalar instructions: a comparison writes its mask straight to an SGPR
+// pair, the loop ends on s_cmp_lg_u64, and a value is picked per lane by v_cndmask on the mask.  (Written with
+// `bool`s the compiler kept the flags as masks too, but rebuilt them through v_cndmask 0/1 + v_cmp at every
+// ballot: 4 of the ~50 vector instructions of a probe, and twice the scalar bookkeeping.)
+typedef unsigned long long lanemask_t;
+__device__ __forceinline__ lanemask_t mask_of(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ lanemask_t mask_ult(unsigned a, unsigned b) { return __builtin_amdgcn_uicmp(a, b, 36); }   // ICMP_ULT
+__device__ __forceinline__ lanemask_t mask_eq(unsigned a, unsigned b) { return __builtin_amdgcn_uicmp(a, b, 32); }    // ICMP_EQ
+__device__ __forceinline__ lanemask_t mask_flt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 4); }         // FCMP_OLT
+// lane bit of m set ? a : b
+__device__ __forceinline__ float mask_sel(lanemask_t m, float a, float b) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ int mask_sel(lanemask_t m, int a, int b) {
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ bool mask_lane(lanemask_t m) { return mask_sel(m, 1, 0) != 0; }
 
-
-// One probe of calc_range (env.py:425) for every lane with `active` set: sample position, distance there, hit test,
-// step.  Lanes that are finished or outside the map run along with their updates masked off.  A lane that hits
-// keeps the t of its hit probe (the hit cell is recomputed from it after the march).
+// One probe of calc_range (env.py:425) for every lane of `active`: sample position, distance there, hit test, step.
+// Lanes that are finished or outside the map run along with their updates masked off.  A lane that hits keeps the
+// t of its hit probe (the hit cell is recomputed from it after the march).
 template <typename Field, int RULE, bool RECT>
 __device__ __forceinline__ void probe_round(const Field& field, const char* __restrict__ rects, unsigned tpr,
                                             float x0, float y0, float dx, float dy, unsigned uW, unsigned uH,
-                                            float max_range, float& t, bool& active, bool& hit) {
+                                            float max_range, float& t, lanemask_t& active, lanemask_t& hit) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));            // v_pk_mul_f32 + v_pk_add_f32 (never fused:
     const f32x2 org = {x0, y0}, dir = {dx, dy};                          // the translation unit is -ffp-contract=off)
     const f32x2 pos = org + dir * t;
     int px = (int)pos.x, py = (int)pos.y;
-    const bool live = active & ((unsigned)px < uW) & ((unsigned)py < uH);
-    px = live ? px : 0;
-    py = live ? py : 0;
-    bool occ;
+    const lanemask_t live = active & mask_ult((unsigned)px, uW) & mask_ult((unsigned)py, uH);
+    px = mask_sel(live, px, 0);
+    py = mask_sel(live, py, 0);
+    lanemask_t occ;
     float d;
     if constexpr (RECT) {
         // the tile's two-rectangle record (kernels_rect.hpp): exact integer d2 without touching the field; the
         // rare probe in a tile without a valid record reads the field.  32-bit lane offset on a uniform base.
         // tile rows and tiles per row stay far below 2^24: the 24-bit multiply-add is a full-rate instruction
         const unsigned off = (__umul24((unsigned)py >> kRectShift, tpr) + ((unsigned)px >> kRectShift)) * (unsigned)sizeof(uint4);
+        const unsigned cell = rect_cell(px, py);
         const uint4 rec = *(const uint4*)(rects + off);
-        const int d2 = rect_record_d2(rec, px, py);
-        const bool inval = live & rect_record_invalid(rec);
-        occ = live & (d2 == 0);
+        const int d2 = rect_record_d2(rec, cell);
+        const lanemask_t inval = live & mask_eq(rec.x & 0xFFFFu, (unsigned)kRectInvalid);
+        occ = live & mask_eq((unsigned)d2, 0u);
         d = Field::sqrt_d2(d2);
-        if (wave_any(inval)) {
-            if (inval) {
-                typename Field::raw_t raw = field.load(px, py);
-                occ = field.occupied(raw);
-                d = field.decode_nz(raw, px, py);
-            }
+        if (inval != 0) {                                               // wave-uniform branch
+            // Only the load is per-lane control flow: a lane mask assigned under a divergent branch would stop
+            // being one value per wave.  Lanes with a valid record decode a dummy distance of one cell.
+            typename Field::raw_t raw = (typename Field::raw_t)1;
+            if (mask_lane(inval)) raw = field.load(px, py);
+            occ = (occ & ~inval) | (inval & mask_of(field.occupied(raw)));
+            d = mask_sel(inval, field.decode_nz(raw, px, py), d);
         }
     } else {
         typename Field::raw_t raw = field.load(px, py);
-        occ = live & field.occupied(raw);
+        occ = live & mask_of(field.occupied(raw));
         d = field.decode_nz(raw, px, py);
     }
     hit |= occ;
     const float tn = t + march_step<RULE>(d);
-    const bool go = live & !occ;
-    t = go ? tn : t;
-    active = go & (tn < max_range);
+    const lanemask_t go = live & ~occ;
+    t = mask_sel(go, tn, t);
+    active = go & mask_flt(tn, max_range);
 }
 
 // raw range (cells) of a finished ray: the hit cell recomputed from the t of the hit probe
-__device__ __forceinline__ float ray_result(bool hit, float x0, float y0, float dx, float dy, float t, float miss) {
-    if (!hit) return miss;
+__device__ __forceinline__ float ray_result(lanemask_t hit, float x0, float y0, float dx, float dy, float t, float miss) {
     const float xd = (float)(int)(x0 + dx * t) - x0;
     const float yd = (float)(int)(y0 + dy * t) - y0;
-    return sqrtf(xd * xd + yd * yd);
+    return mask_sel(hit, sqrtf(xd * xd + yd * yd), miss);
 }
 
 // Predicated one-ray-per-lane scan: the march loop has ONE wave-level branch
@@ -381,9 +402,9 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShar
         float dx, dy;
         beam_dir_k(c, tab, valid ? k : B - 1, step, (double)sh.lth, sh.cT, sh.sT, dx, dy);
         float t = t1;
-        bool active = valid & (r_all < 0.0f);
-        bool hit = false;
-        while (wave_any(active))
+        lanemask_t active = mask_of(valid & (r_all < 0.0f));
+        lanemask_t hit = 0;
+        while (active != 0)
             probe_round<Field, RULE, RECT>(field, (const char*)rects, tpr, x0, y0, dx, dy, uW, uH, max_range, t, active, hit);
         if (valid) finish(k, dx, dy, ray_result(hit, x0, y0, dx, dy, t, miss));
     }
