@@ -266,7 +266,9 @@ __device__ __forceinline__ lanemask_t mask_of(bool p) { return __builtin_amdgcn_
 __device__ __forceinline__ lanemask_t mask_ult(unsigned a, unsigned b) { return __builtin_amdgcn_uicmp(a, b, 36); }   // ICMP_ULT
 __device__ __forceinline__ lanemask_t mask_eq(unsigned a, unsigned b) { return __builtin_amdgcn_uicmp(a, b, 32); }    // ICMP_EQ
 __device__ __forceinline__ lanemask_t mask_flt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 4); }         // FCMP_OLT
-// lane bit of m set ? a : b
+// lane bit of m set ? a : b.  Pass masks that a SCALAR instruction produced (an and / or / andn2 of comparison
+// masks, as everywhere below): the compiler's hazard recognizer does not look into the asm, and a v_cndmask that
+// reads an SGPR pair written by the vector instruction right before it needs wait states on gfx950.
 __device__ __forceinline__ float mask_sel(lanemask_t m, float a, float b) {
     float r;
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
@@ -291,18 +293,27 @@ __device__ __forceinline__ void probe_round(const Field& field, const char* __re
     const f32x2 pos = org + dir * t;
     int px = (int)pos.x, py = (int)pos.y;
     const lanemask_t live = active & mask_ult((unsigned)px, uW) & mask_ult((unsigned)py, uH);
-    px = mask_sel(live, px, 0);
-    py = mask_sel(live, py, 0);
     lanemask_t occ;
     float d;
+    if constexpr (!RECT) {
+        px = mask_sel(live, px, 0);
+        py = mask_sel(live, py, 0);
+    }
     if constexpr (RECT) {
         // the tile's two-rectangle record (kernels_rect.hpp): exact integer d2 without touching the field; the
         // rare probe in a tile without a valid record reads the field.  32-bit lane offset on a uniform base.
         // tile rows and tiles per row stay far below 2^24: the 24-bit multiply-add is a full-rate instruction
-        const unsigned off = (__umul24((unsigned)py >> kRectShift, tpr) + ((unsigned)px >> kRectShift)) * (unsigned)sizeof(uint4);
+        // a lane that is not live keeps its out-of-map px, py (every result of it is masked) and reads record 0
+        const unsigned off = (unsigned)mask_sel(live, (int)((__umul24((unsigned)py >> kRectShift, tpr) + ((unsigned)px >> kRectShift)) *
+                                                               (unsigned)sizeof(uint4)), 0);
         const unsigned cell = rect_cell(px, py);
-        const uint4 rec = *(const uint4*)(rects + off);
-        const int d2 = rect_record_d2(rec, cell);
+        // The load is written out: after a compiler-generated global_load_dwordx4 the register allocator moved three
+        // of the four loaded dwords to other registers before using them (3 of 42 vector instructions per probe).
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 rec;
+        asm volatile("global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(rec) : "v"(off), "s"(rects) : "memory");
+        const int da = rect_dist2(rec.x, rec.y, cell), db = rect_dist2(rec.z, rec.w, cell);
+        const int d2 = da < db ? da : db;
         const lanemask_t inval = live & mask_eq(rec.x & 0xFFFFu, (unsigned)kRectInvalid);
         occ = live & mask_eq((unsigned)d2, 0u);
         d = Field::sqrt_d2(d2);
