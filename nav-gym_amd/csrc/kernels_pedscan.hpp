@@ -211,6 +211,20 @@ __global__ void math_kernel(int fn, const double* x, const double* x2, double* o
             out[i] = (double)(xf == 0.0f ? 0.0f : sq);
             break;
         }
+        case 13: {
+            // the beam-table fast path against the full evaluation: x = robot heading (rounded to float32 as
+            // env.py:386 does), x2 = robot-frame beam angle.  0: proven and equal, 1: not proven (the scan would
+            // evaluate beam_dir), 2: proven but DIFFERENT (must never happen)
+            const double lth = (double)(float)x[i], lin = x2 ? x2[i] : 0.0;
+            double st, ct, sT, cT;
+            nv::sincos(lin, st, ct);
+            nv::sincos(lth, sT, cT);
+            float heading, dx, dy, rx, ry;
+            const bool fast = beam_dir_fast(lin, lth, ct, st, cT, sT, heading, dx, dy);
+            nv::beam_dir(heading, rx, ry);
+            out[i] = !fast ? 1.0 : ((__float_as_uint(dx) == __float_as_uint(rx) && __float_as_uint(dy) == __float_as_uint(ry)) ? 0.0 : 2.0);
+            break;
+        }
         default: out[i] = 0.0;
     }
 }

@@ -76,7 +76,21 @@ __device__ __forceinline__ void sfm_pair(const navsim_config& c, double xi, doub
     fy = fv * idy + fa * idx;
 }
 
-// direction of beam k (env.py:388-390, 424): table fast path with proven rounding, else full sincos
+// direction of a beam at robot-frame angle lin seen from heading lth (env.py:388-390, 424) through its table entry
+// (ct, st) = cos / sin(lin) and (cT, sT) = cos / sin(lth); false: the float32 rounding could not be proven, the caller
+// evaluates beam_dir(heading).  heading = fl32(lin + lth) is returned either way.
+__device__ __forceinline__ bool beam_dir_fast(double lin, double lth, double ct, double st, double cT, double sT,
+                                              float& heading, float& dx, float& dy) {
+    const double ang = lin + lth;
+    heading = (float)ang;
+    // heading = lin + lth + delta EXACTLY: (heading - ang) is exact (Sterbenz), and the rounding error of the
+    // float64 sum is recovered by TwoSum
+    const double bb = ang - lin;
+    const double eps = (lin - (ang - bb)) + (lth - bb);
+    const double delta = ((double)heading - ang) + eps;
+    return nv::beam_dir_from_table(ct, st, cT, sT, delta, dx, dy);
+}
+// direction of beam k: table fast path with proven rounding, else full sincos
 __device__ __forceinline__ void beam_dir_k(const navsim_config& c, const double* __restrict__ tab, int k,
                                            double step, double lth, double cT, double sT,
                                            float& dx, float& dy) {
@@ -84,17 +98,11 @@ __device__ __forceinline__ void beam_dir_k(const navsim_config& c, const double*
     { float h = (float)c.angle_min + (float)k * (float)step + (float)lth; dx = __cosf(h); dy = __sinf(h); return; }
 #endif
     const double lin = nv::linspace_k(c, k, step);
-    double ang = lin + lth;
-    float heading = (float)ang;
+    float heading = (float)(lin + lth);
     bool fast = false;
     if (tab) {
-        // heading = lin + lth + delta EXACTLY: (heading - ang) is exact (Sterbenz), and the
-        // rounding error of the float64 sum is recovered by TwoSum
-        double bb = ang - lin;
-        double eps = (lin - (ang - bb)) + (lth - bb);
-        double delta = ((double)heading - ang) + eps;
-        double2 cs = ((const double2*)tab)[k];
-        fast = nv::beam_dir_from_table(cs.x, cs.y, cT, sT, delta, dx, dy);
+        const double2 cs = ((const double2*)tab)[k];
+        fast = beam_dir_fast(lin, lth, cs.x, cs.y, cT, sT, heading, dx, dy);
     }
     if (!fast) nv::beam_dir(heading, dx, dy);
 }

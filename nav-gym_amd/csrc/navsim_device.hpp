@@ -35,31 +35,34 @@ __device__ __forceinline__ void beam_dir(float heading, float& dx, float& dy) {
     dy = (float)s;
 }
 
-// Same direction from the beam table: cos/sin(lin_k + th + delta) by one angle addition, accepted
-// only when the float32 rounding is PROVABLY the one beam_dir() produces.  Error budget of the
-// candidate against the true cos/sin of the float32 heading: table entries and cos/sin(th) are within
-// 1 ulp (1.1e-16), the two products and their sum add <= 8e-16 absolute, the second-order series in
-// delta is exact to 1e-19; beam_dir() itself is within 1.1e-16.  So both round alike whenever the
-// candidate sits more than 3e-15 inside its float32 rounding interval; otherwise the caller falls
-// back to beam_dir() -- a few beams in 1e7.
+// Same direction from the beam table: cos/sin(lin_k + th + delta) by one angle addition, accepted only when the
+// float32 rounding is PROVABLY the one beam_dir() produces.  Error budget of the candidate against the true cos/sin
+// of the float32 heading (all values at most 1 in magnitude, 1 ulp = 1.1e-16): the table entries and cos/sin(th) are
+// within 1 ulp; C = fma(ct, cT, -(st sT)) inherits 2.2e-16 per product and adds one rounding each: <= 6.6e-16; the
+// second-order series in delta (|delta| <= 5e-7) is exact to 2e-20 and adds two fma roundings: <= 8.8e-16 in all;
+// beam_dir() itself is within 1.1e-16.  So both round alike whenever the candidate sits more than 3e-15 inside its
+// float32 rounding interval; otherwise the caller falls back to beam_dir() -- a few beams in 1e7.
+//
+// The interval: f = fl32(v) and r = v - f (exact).  The float32 neighbours of v are spaced 2^(e-23) apart with e the
+// binary exponent of v ITSELF (if f rounded up to the power of two above, the spacing on v's side is still that
+// of v's binade), so v is half_ulp - |r| away from the nearest rounding boundary, half_ulp = 2^(e-24), built from
+// v's exponent field.  A component below 2^-23 has half_ulp < 3e-15 and never passes; a zero exponent field (v = 0)
+// makes half_ulp a negative number and does not pass either: those beams go to beam_dir().
 __device__ __forceinline__ bool round_if_safe(double v, float& out) {
-    float f = (float)v;
-    uint32_t bits = __float_as_uint(f);
-    uint32_t eb = bits & 0x7F800000u;
-    if (eb < (40u << 23) || (bits & 0x007FFFFFu) == 0u) return false;   // tiny or a power of two
-    double half_ulp = (double)__uint_as_float(eb - (24u << 23));
-    double r = v - (double)f;
-    if (half_ulp - __builtin_fabs(r) < 3.0e-15) return false;
+    const float f = (float)v;
+    const double r = v - (double)f;
+    const int hi = __double2hiint(v);
+    const double half_ulp = __hiloint2double((hi & 0x7FF00000) - (24 << 20), 0);
     out = f;
-    return true;
+    return half_ulp - __builtin_fabs(r) >= 3.0e-15;
 }
 __device__ __forceinline__ bool beam_dir_from_table(double ct, double st, double cT, double sT, double delta,
                                                     float& dx, float& dy) {
-    double C = ct * cT - st * sT;
-    double S = st * cT + ct * sT;
-    double h = 0.5 * delta * delta;
-    double c = (C - C * h) - S * delta;
-    double s = (S - S * h) + C * delta;
+    const double C = __builtin_fma(ct, cT, -(st * sT));
+    const double S = __builtin_fma(st, cT, ct * sT);
+    const double h = (0.5 * delta) * delta;
+    const double c = __builtin_fma(-S, delta, __builtin_fma(-C, h, C));
+    const double s = __builtin_fma(C, delta, __builtin_fma(-S, h, S));
     return round_if_safe(c, dx) & round_if_safe(s, dy);
 }
 

@@ -71,6 +71,38 @@ def test_packed_field_sqrt_is_correctly_rounded(gpu):
     _eq(b, ref_step, "march step, float32-only form")
 
 
+def test_beam_table_direction_is_the_full_evaluation(gpu):
+    """The scan takes a beam's direction from the beam table by one angle addition and accepts it only when its
+    float32 rounding is provably that of beam_dir() (navsim_device.hpp round_if_safe); otherwise it evaluates
+    beam_dir().  Debug function 13 runs both on the device for (robot heading, robot-frame beam angle) pairs:
+    0 = accepted and bit-identical, 1 = not accepted, 2 = accepted but different.  4e7 random pairs plus the
+    places where the acceptance test has something to get wrong: directions along the axes (a component near 0),
+    at 60 / 120 degrees (a component at a power of two), headings far outside [-pi, pi]."""
+    torch = gpu.torch
+    g = torch.Generator(device=gpu.dev); g.manual_seed(5)
+    n = 10_000_000
+    step = 1.5 * np.pi / 1080
+    for rep in range(4):
+        lth = (torch.rand(n, generator=g, device=gpu.dev, dtype=torch.float64) * 2 - 1) * (np.pi if rep < 3 else 50.0)
+        k = torch.randint(0, 1081, (n,), generator=g, device=gpu.dev).to(torch.float64)
+        lin = k * step - 0.75 * np.pi
+        code = gpu.sim.debug_math(13, lth, lin)
+        assert int((code == 2).sum()) == 0, "table direction differs from beam_dir()"
+        assert int((code == 1).sum()) < n // 20000, "fallback rate %g" % (float((code == 1).sum()) / n)
+    # special directions: heading + beam angle on the axes and at +-60 / 120 degrees, and float32 neighbours of them
+    base = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 1 / 3, 2 / 3, 4 / 3, 5 / 3, -0.5, -1.0, -1 / 3, -2 / 3]) * np.pi
+    lin = np.repeat(np.arange(0, 1081, 7) * step - 0.75 * np.pi, len(base) * 9)
+    tgt = np.tile(np.repeat(base, 9), len(lin) // (len(base) * 9))
+    lth32 = (tgt - lin).astype(np.float32)
+    for j in range(9):                                                    # the 9 nearest float32 headings
+        sl = slice(j, None, 9)
+        for _ in range(abs(j - 4)):
+            lth32[sl] = np.nextafter(lth32[sl], np.float32(np.inf if j > 4 else -np.inf))
+    code = gpu.sim.debug_math(13, _t(gpu, lth32.astype(np.float64)), _t(gpu, lin)).cpu().numpy()
+    assert (code != 2).all(), "special directions: %d wrong" % int((code == 2).sum())
+    assert (code == 0).mean() > 0.5           # the fast path is not simply declining everything here
+
+
 @pytest.mark.parametrize("size,n", [(100, 3), (400, 2), (500, 2), (1000, 1)])
 def test_build_dt(gpu, size, n):
     occ = gpu.world.make_maps(n, size, 77 + size, indoor_ratio=0.5 if size == 1000 else 0.0)
