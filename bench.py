@@ -234,6 +234,7 @@ def main():
     ap.add_argument("--no-noise-off-pass", action="store_true",
                     help="skip the extra K steps timed with scan noise off (profiling runs: one kind of launch only)")
     ap.add_argument("--step-block", type=int, default=0, help="threads per arena (0 = library default)")
+    ap.add_argument("--lpt-period", type=int, default=0, help="steps between launch-order sorts (0 = NavSim's default)")
     ap.add_argument("--ped-split", type=int, default=0, choices=[0, 1, 2],
                     help="navsim_config.ped_split: 0 library default, 1 pedestrians inside the step, 2 ped_update_kernel first")
     ap.add_argument("--no-rects", action="store_true",
@@ -289,6 +290,8 @@ def main():
         sim.cfg.step_block = args.step_block
     if args.ped_split:
         sim.cfg.ped_split = args.ped_split
+    if args.lpt_period:
+        sim.lpt_period = args.lpt_period
     E, K, Wm = cfg.n_envs, args.steps, args.warmup
     # scan noise of the timed steps (env.py:437-440): every arena at --noise-std, counter-based Gaussian per beam
     sim.t["scan_noise_std"].fill_(args.noise_std)
