@@ -433,9 +433,12 @@ def main():
                 # SURVEY.md 8d figure: algorithmic bytes (whole occupancy grid once per arena-step) / kernel time.
                 # A march touches only part of the grid, so on large maps the formula can exceed 1: then it says
                 # nothing about the kernel and hbm_frac_measured (counter bytes) is the figure to read.
-                "bound": "hbm" if frac <= 1.0 else "hbm: 8d formula > 1 (counts the whole grid, a march touches a "
-                                                   "fraction of it); read hbm_frac_measured",
+                "bound": "hbm",
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": frac,
+                "note": (None if frac <= 1.0 else
+                         "the 8d figure counts the whole occupancy grid once per arena-step; the kernel reads an 8x smaller "
+                         "lossless description of it (rect records) and only along the rays, so achieved exceeds the peak: "
+                         "the formula has stopped being a bound here, read hbm_frac_measured (counter bytes)"),
                 "traffic": None,                # not measured in this process (PMC needs rocprofv3)
                 "traffic_profiled": tbytes, "traffic_profile": tsrc,
                 "hbm_frac_measured": (tbytes / (kernel_ms * 1e-3) / 8.0e12) if tbytes else None,
