@@ -400,6 +400,12 @@ def main():
         A = algorithmic_bytes_per_env_step(cfg.map_h, cfg.map_w, cfg.n_beams, cfg.n_scan_stack, wl["peds"], 1)
         achieved = A * E / (kernel_ms * 1e-3) / 1e9                # GB/s
         frac = achieved / 8000.0
+        # the same formula with s_map = bytes per cell of the representation the kernel actually marches on
+        # ("the map representation the kernel streams"): rect records are 16 B per 8x8 tile = 0.25,
+        # the packed distance field 2, the float32 field 4
+        from nav_gym_amd import abi
+        s_streamed = 0.25 if "rect_table" in sim.t else (2 if cfg.field_format == abi.FIELD_U16T else 4)
+        A_streamed = algorithmic_bytes_per_env_step(cfg.map_h, cfg.map_w, cfg.n_beams, cfg.n_scan_stack, wl["peds"], s_streamed)
         tbytes, tsrc = profiled_traffic(args.workload, E, args.field)
         all_values = [world_size * E * K / el for el, _ in [(elapsed, kernel_ms)] + more]
         out = {
@@ -446,6 +452,7 @@ def main():
                 "kernel_ms_from": ("one HIP event pair per step launch" if events_per_step else
                                    "one HIP event pair around the %d launches / %d (includes the gaps between launches)" % (K, K)),
                 "algorithmic_bytes_per_env_step": A, "s_map": 1,
+                "s_map_streamed": s_streamed, "frac_s_map_streamed": A_streamed * E / (kernel_ms * 1e-3) / 8.0e12,
             },
         }
         if noise_off is not None:
