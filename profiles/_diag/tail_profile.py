@@ -27,3 +27,9 @@ print("active WGs at 0,5,...,100 %% of the span:", [int(active[i]) for i in rang
 order = np.argsort(s)
 print("start-time of WG by launch index quartiles:", [int(s[order[int(q * (E - 1))]] - t0) for q in (0, .25, .5, .75, 1)])
 print("longest 5 lifetimes:", np.sort(e - s)[-5:].astype(int), " median", int(np.median(e - s)))
+# phase durations (ticks of 10 ns): stamps 0 start, 1 after the scalars, 2 before scan A, 3 after scan A, 4 after the
+# flag reduction, 5 after reward / rescan, 6 end
+d = np.diff(b[:, :7].astype(np.float64), axis=1)
+print("mean ticks per phase (0-1 scalars, 1-2 robot / lidar pose / first probe, 2-3 scan A, 3-4 reduce, 4-5 reward (+ rescan), 5-6 pack):",
+      [int(x) for x in d.mean(axis=0)])
+print("median:", [int(x) for x in np.median(d, axis=0)])
