@@ -19,6 +19,7 @@ struct StepShared {
     float r_all;                  // >= 0: every beam has this raw range (origin occupied / no march)
     unsigned long long step_key;  // scan-noise counter of this step
     int next_chunk;               // scan: next 64-beam chunk to hand to a wavefront (reset before every scan)
+    int park_count, park_next;    // scan: parked rays (written / handed out), reset with next_chunk
     double wave_ratio[kMaxWaves];
 };
 // Pedestrian scratch of the pedestrian variants of the kernel, carved out of dynamic LDS behind the scan's
@@ -352,6 +353,22 @@ __device__ __forceinline__ float ray_result(lanemask_t hit, float x0, float y0, 
     return mask_sel(hit, sqrtf(xd * xd + yd * yd), miss);
 }
 
+// Parking.  A wavefront's 64 adjacent beams need 7.9 probes on average and 13.5 for the slowest (c2): the last
+// rounds of a chunk run for a handful of lanes.  So a wavefront leaves a chunk when at most kParkLanes rays are still
+// marching, parks those (beam, t, direction: 16 bytes in LDS) and goes on; after the chunks the parked rays -- about
+// 70 per scan -- are marched 64 at a time.  Which wavefront finishes a ray, and when, changes no result.  On the c2
+// bench state (profiles/_diag/park_model.py) 0.84 of the probe rounds remain at 8 lanes and 0.82 at 16; a group of
+// parked rays points everywhere, so its record loads do not coalesce and the kernel gains less than that: c2 +4.6 % at
+// 16 lanes (+1 % at 8, 24 = 16, 32 +1 %).  The pedestrian variants gain nothing at 8 and lose 3 % at 16, and a launch
+// that is a single generation of workgroups lasts as long as its slowest workgroup and loses to the second pass
+// (c4 -8 %, c5 -4 %): parking is compiled into the 256-thread kernels without pedestrians only.
+constexpr int kParkLanesMax = 16;
+__host__ __device__ constexpr bool step_parks(int block, bool peds) { return block == 256 && !peds; }
+__host__ __device__ inline size_t park_lds_bytes(int B, int park_lanes) { return (size_t)((B + 63) / 64) * park_lanes * 16; }
+__device__ __forceinline__ int lanes_below(lanemask_t m) {          // set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
 // Predicated one-ray-per-lane scan: the march loop has ONE wave-level branch
 // (any lane still marching?) instead of a divergent if-ladder per probe; finished or out-of-map
 // lanes keep executing with their updates masked off.
@@ -365,6 +382,7 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShar
                                                 const Field& field, const uint4* __restrict__ rects,
                                                 const double* __restrict__ tab,
                                                 const Prims pr, float2* __restrict__ dir_lds, float* __restrict__ rng_lds,
+                                                float4* __restrict__ park, const int park_lanes,
                                                 const float* __restrict__ thr, const float* __restrict__ dthr,
                                                 float* __restrict__ obs_row, int n_hist, float noise_std,
                                                 uint64_t noise_key, uint64_t genv,
@@ -405,6 +423,7 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShar
             if (S - 1 - j > n_hist) obs_row[(size_t)j * B + k] = rr;
     };
     const float miss = (r_all >= 0.0f) ? r_all : max_range;
+    constexpr bool kPark = step_parks(BLOCK, TO_LDS);           // compiled in only where the host ever asks for it
     int own_chunk = 0;                                    // one wavefront per arena: no counter needed
     const int lane = (int)threadIdx.x & 63;
     for (;;) {
@@ -422,6 +441,39 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShar
         beam_dir_k(c, tab, valid ? k : B - 1, step, (double)sh.lth, sh.cT, sh.sT, dx, dy);
         float t = t1;
         lanemask_t active = mask_of(valid & (r_all < 0.0f));
+        lanemask_t hit = 0;
+        if constexpr (!kPark) {
+            while (active != 0)
+                probe_round<Field, RULE, RECT>(field, (const char*)rects, tpr, x0, y0, dx, dy, uW, uH, max_range, t, active, hit);
+            if (valid) finish(k, dx, dy, ray_result(hit, x0, y0, dx, dy, t, miss));
+        } else {
+            while ((int)__builtin_popcountll(active) > park_lanes)
+                probe_round<Field, RULE, RECT>(field, (const char*)rects, tpr, x0, y0, dx, dy, uW, uH, max_range, t, active, hit);
+            const bool marching = mask_lane(active);
+            if (active != 0) {                                   // park what is still marching
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&sh.park_count, (int)__builtin_popcountll(active));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (marching) park[base + lanes_below(active)] = make_float4(__int_as_float(k), t, dx, dy);
+            }
+            if (valid & !marching) finish(k, dx, dy, ray_result(hit, x0, y0, dx, dy, t, miss));
+        }
+    }
+    // the parked rays, 64 at a time
+    if constexpr (kPark) __syncthreads();
+    const int n_parked = kPark ? sh.park_count : 0;
+    for (;;) {
+        if (!kPark || n_parked == 0) break;
+        int g = 0;
+        if (lane == 0) g = atomicAdd(&sh.park_next, 64);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= n_parked) break;
+        const bool valid = g + lane < n_parked;
+        const float4 r = park[valid ? g + lane : g];
+        const int k = __float_as_int(r.x);
+        float t = r.y;
+        const float dx = r.z, dy = r.w;
+        lanemask_t active = mask_of(valid);
         lanemask_t hit = 0;
         while (active != 0)
             probe_round<Field, RULE, RECT>(field, (const char*)rects, tpr, x0, y0, dx, dy, uW, uH, max_range, t, active, hit);
@@ -618,7 +670,7 @@ template <int BLOCK, bool PEDS, typename Field, int RULE, bool RECT>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void navsim_step_kernel(navsim_config c, navsim_state st,
                                                             navsim_step_io io, int reset_only,
                                                             const uint8_t* __restrict__ reset_mask,
-                                                            unsigned dyn_lds_bytes) {
+                                                            unsigned dyn_lds_bytes, int park_lanes) {
     __shared__ StepShared sh;
     const int peds_done = (reset_only >> 1) & 1;     // the pedestrians were advanced by ped_update_kernel
     reset_only &= 1;
@@ -746,7 +798,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         first_probe<RULE>(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
         sh.step_key = (unsigned long long)st.episode[e] * 0x100000000ULL +
                       (unsigned long long)(reset_only ? 0 : st.steps[e]) * 2ULL;
-        sh.next_chunk = 0;
+        sh.next_chunk = 0; sh.park_count = 0; sh.park_next = 0;
     }
     __syncthreads();
 
@@ -755,9 +807,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     int n_hist = reset_only ? 0 : st.n_hist[e];
     int crash = 0, discomfort = 0;
     const uint64_t step_key = sh.step_key;
-    float2* dir_lds = (float2*)dyn_lds;
-    float* rng_lds = (float*)(dyn_lds + sizeof(float2) * (size_t)B);
-    scan_beams_pred<BLOCK, Field, PEDS, RULE, RECT>(c, sh, field, rects, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
+    // dynamic LDS: [parked rays][pedestrian variants: float2 dir[B], float rng[B]][PedShared]
+    float4* park = (float4*)dyn_lds;
+    char* scan_lds = dyn_lds + park_lds_bytes(B, park_lanes);
+    float2* dir_lds = (float2*)scan_lds;
+    float* rng_lds = (float*)(scan_lds + sizeof(float2) * (size_t)B);
+    scan_beams_pred<BLOCK, Field, PEDS, RULE, RECT>(c, sh, field, rects, st.beam_table, prims, dir_lds, rng_lds, park, park_lanes, st.scan_threshold,
                                                          st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
 
     NAVSIM_STAMP(3);
@@ -806,7 +861,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 sh.rescan = 1;
             }
             if (sh.rescan) {
-                sh.next_chunk = 0;
+                sh.next_chunk = 0; sh.park_count = 0; sh.park_next = 0;
                 sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];
                 nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);
                 nv::sincos((double)sh.lth, sh.sT, sh.cT);
@@ -818,7 +873,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         if (sh.rescan) {
             if (sh.respawn) n_hist = 0;
             int c2, d2;
-            scan_beams_pred<BLOCK, Field, PEDS, RULE, RECT>(c, sh, field, rects, st.beam_table, prims, dir_lds, rng_lds, st.scan_threshold,
+            scan_beams_pred<BLOCK, Field, PEDS, RULE, RECT>(c, sh, field, rects, st.beam_table, prims, dir_lds, rng_lds, park, park_lanes, st.scan_threshold,
                                                                  st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
         }
     }

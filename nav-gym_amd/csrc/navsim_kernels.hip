@@ -85,12 +85,18 @@ int device_cu_count() {
     return n;
 }
 
-// dynamic LDS of the fused step: beam directions + ranges (pedestrian variants merge from LDS) and PedShared
-size_t step_lds_scan_bytes(const navsim_config* c) {
-    return c->ped_model != NAVSIM_PED_NONE ? (size_t)c->n_beams * (sizeof(float2) + sizeof(float)) : 0;
+// dynamic LDS of the fused step: parked rays; beam directions + ranges (pedestrian variants merge from LDS); PedShared
+// rays a wavefront parks per chunk (kernels_step.hpp "Parking"): only where a launch runs several generations of
+// 256-thread workgroups, and not in the pedestrian variants
+int step_park_lanes(const navsim_config* c, int block) {
+    return step_parks(block, c->ped_model != NAVSIM_PED_NONE) ? kParkLanesMax : 0;
 }
-size_t step_lds_bytes(const navsim_config* c) {
-    size_t lds = step_lds_scan_bytes(c);
+size_t step_lds_scan_bytes(const navsim_config* c, int park_lanes) {
+    return park_lds_bytes(c->n_beams, park_lanes) +
+           (c->ped_model != NAVSIM_PED_NONE ? (size_t)c->n_beams * (sizeof(float2) + sizeof(float)) : 0);
+}
+size_t step_lds_bytes(const navsim_config* c, int park_lanes) {
+    size_t lds = step_lds_scan_bytes(c, park_lanes);
     if (c->ped_model != NAVSIM_PED_NONE) lds = ((lds + 15) & ~(size_t)15) + ped_lds_bytes(c->max_peds);
     return lds;
 }
@@ -125,8 +131,9 @@ template <int BLOCK, bool PEDS, typename Field, bool RECT, int RULE>
 int launch_step_kernel(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
                        const uint8_t* mask, size_t lds, hipStream_t s) {
     if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
+    const int park = step_park_lanes(c, BLOCK);
     navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask,
-                                                                                    (unsigned)step_lds_scan_bytes(c));
+                                                                                    (unsigned)step_lds_scan_bytes(c, park), park);
     return NAVSIM_OK;
 }
 
@@ -154,7 +161,7 @@ template <int BLOCK>
 int launch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
                 const uint8_t* mask, hipStream_t s) {
     const bool peds = c->ped_model != NAVSIM_PED_NONE;
-    const size_t lds = step_lds_bytes(c);
+    const size_t lds = step_lds_bytes(c, step_park_lanes(c, BLOCK));
     // pedestrians ahead of the step, one wavefront per arena (pays when the chip runs several generations of
     // arenas: c3 13.2 -> 14.0 M env-steps/s; a 512-arena launch is latency-bound and loses 2 % to the extra
     // kernel, so small batches keep the fused form)
@@ -468,7 +475,7 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
         c->step_block != 1024) return NAVSIM_E_ARG;
     if (c->ped_split < 0 || c->ped_split > 2) return NAVSIM_E_ARG;
     if (c->ped_model != NAVSIM_PED_NONE && c->max_peds < 1) return NAVSIM_E_ARG;
-    if (step_lds_bytes(c) > kLdsPerCu) return NAVSIM_E_UNSUPPORTED;       // beams x pedestrians beyond one CU's LDS
+    if (step_lds_bytes(c, step_park_lanes(c, pick_step_block(c))) > kLdsPerCu) return NAVSIM_E_UNSUPPORTED;   // beams x pedestrians beyond one CU's LDS
     if (!st->field || !st->scan_threshold || !st->scan_discomfort || !st->robot_pose || !st->robot_goal ||
         !st->prev_action || !st->prev_pose || !st->n_hist || !st->episode || !st->steps || !io->obs)
         return NAVSIM_E_ARG;

@@ -360,6 +360,34 @@ def test_step_rollout_vs_oracle(gpu, ped_model, S, auto_reset, fmt):
     assert resets > 0
 
 
+@pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T, "u16t-no-rects"])
+@pytest.mark.parametrize("S", [1, 3])
+def test_step_rollout_256_threads_parked_rays(gpu, fmt, S):
+    """The 256-thread kernels without pedestrians (what a 4096-arena launch runs) leave a 64-beam chunk when at most 16
+    of its rays are still marching, park those in LDS and march the parked rays 64 at a time afterwards
+    (kernels_step.hpp "Parking").  Forced here on a small batch (cfg.step_block = 256): every output, observation and
+    state array equals the oracle's over 80 steps with crash reverts and respawns (which scan a second time)."""
+    world_kw = {}
+    if fmt == "u16t-no-rects":
+        fmt, world_kw = abi.FIELD_U16T, {"rect_table": False}
+    E, size = 40, 260
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=1, n_scan_stack=S, ped_model=abi.PED_NONE,
+                                 auto_reset=1, n_spawn=8, seed=77, field_format=fmt, step_block=256)
+    gpu.world.lidar_1081(cfg)
+    occ = gpu.world.make_maps(E, size, 77)
+    crashes = resets = 0
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=0, steps=80, seed=3, **world_kw):
+        for k in rout:
+            _eq(gout[k], rout[k], "%s at step %d" % (k, t))
+        _eq(go, ro, "obs at step %d" % t)
+        crashes += int(rout["is_crash"].sum()); resets += int(rout["done"].sum())
+    gs = g.numpy_state()
+    for k, v in r.a.items():
+        if k in gs and k not in ("field", "field_overflow", "rect_table"):
+            _eq(gs[k], v, "state %s at the end" % k)
+    assert crashes > 0 and resets > 0
+
+
 @pytest.mark.parametrize("ped_model", [abi.PED_SFM, abi.PED_EXTERNAL])
 def test_step_rollout_with_split_pedestrian_kernel(gpu, ped_model):
     """Large batches advance the pedestrians in ped_update_kernel ahead of the fused step (one wavefront per
