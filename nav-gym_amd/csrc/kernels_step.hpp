@@ -914,7 +914,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // scaled to the maximum, exclusive scan from the expensive end, scatter.  Order inside a bucket is free.
 __global__ __launch_bounds__(1024) void launch_order_kernel(const uint32_t* __restrict__ cost, int32_t* __restrict__ order,
                                                             int n) {
-    __shared__ unsigned hist[1024], base[1024];
+    __shared__ unsigned hist[1024], base[1024], wave_tot[16];
     __shared__ unsigned max_s;
     __shared__ unsigned long long sum_s;
     const int tid = threadIdx.x;
@@ -932,21 +932,38 @@ __global__ __launch_bounds__(1024) void launch_order_kernel(const uint32_t* __re
     unsigned long long m = max_s;
     const unsigned long long cap = 4ull * (sum_s / (unsigned long long)n) + 1ull;
     m = m < cap ? m : cap;
+    // float arithmetic (a 64-bit integer division per arena and pass was a third of this kernel); any monotone map
+    // serves as long as both passes use the same one
+    const float scale = 1023.0f / (float)m;
     auto bucket = [&](unsigned cst) {                                                                  // 0 = costliest
         const unsigned long long cc = cst < m ? cst : m;
-        return 1023 - (int)((cc * 1023ull) / m);
+        const int b = (int)((float)cc * scale);
+        return 1023 - (b > 1023 ? 1023 : b);
     };
     for (int e = tid; e < n; e += 1024) atomicAdd(&hist[bucket(cost[e])], 1u);
     __syncthreads();
-    base[tid] = hist[tid];
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {                 // inclusive scan
-        unsigned v = (tid >= off) ? base[tid - off] : 0;
-        __syncthreads();
-        base[tid] += v;
-        __syncthreads();
+    // exclusive scan of the 1024 bucket counts: inside each wavefront by shuffles, the 16 wavefront totals by
+    // wavefront 0 (two barriers; the ten-step scan through LDS with its twenty barriers was half of the kernel)
+    const unsigned mine = hist[tid];
+    unsigned incl = mine;
+    const int lane = tid & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
     }
-    base[tid] -= hist[tid];                                    // exclusive
+    if (lane == 63) wave_tot[tid >> 6] = incl;
+    __syncthreads();
+    if (tid < 64) {
+        const unsigned t = tid < 16 ? wave_tot[tid] : 0u;
+        unsigned ti = t;
+        for (int off = 1; off < 16; off <<= 1) {
+            const unsigned v = __shfl_up(ti, off, 64);
+            if (tid >= off) ti += v;
+        }
+        if (tid < 16) wave_tot[tid] = ti - t;                   // exclusive over the wavefronts
+    }
+    __syncthreads();
+    base[tid] = wave_tot[tid >> 6] + incl - mine;
     __syncthreads();
     for (int e = tid; e < n; e += 1024) order[atomicAdd(&base[bucket(cost[e])], 1u)] = e;
 }
