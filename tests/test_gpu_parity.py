@@ -1440,6 +1440,35 @@ def test_bench_two_ranks_on_one_gpu(gpu):
     assert out["roofline"]["kernel_ms"] > 0 and out["noise_off"]["value"] > 0
 
 
+def test_bench_line_contract(gpu):
+    """The one-GPU bench line in the driver's shape (--steps 20 --warmup 5): every key of the contract, the roofline
+    object with its live kernel time and both readings of the SURVEY 8d figure, and the CPU baseline object."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                        "--envs", "1024", "--cpu-seconds", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    out = json.loads(lines[-1])                                  # ONE JSON line, the last thing printed
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in out, k
+    assert out["steps"] == 20 and out["warmup"] == 5 and out["n_gpus"] == 1 and out["scaling"] == "weak"
+    assert out["vs_baseline"] is None and out["data"] == "synthetic" and "workload" in out["config"]
+    roof = out["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert 0 < roof["kernel_ms"] <= out["ms_per_step"] * 1.02 and roof["kernel_ms_from"]
+    assert roof["traffic"] is None and roof["s_map"] == 1 and roof["s_map_streamed"] == 0.25
+    assert (roof["note"] is None) == (roof["frac"] <= 1.0)
+    cpu = out["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
+
+
 def test_edge_shapes(gpu):
     """Ragged / extreme shapes: odd map size (edge tiles), beam count not a multiple of 64, deep scan
     stack, the compiled maximum of 64 pedestrians with ragged n_peds (0, 1, 64), wide action range,
