@@ -1,4 +1,4 @@
-"""One-off soak: E arenas, the forced 256-thread kernel (parked rays, scalar-mask loop, table directions), many steps
+"""One-off soak (add "peds" as third argument for 20 social-force pedestrians per arena, both pedestrian-update forms): E arenas, the forced 256-thread kernel (parked rays, scalar-mask loop, table directions), many steps
 of random actions with crash reverts and respawns, every output of every step compared with the oracle bit for bit.
    python profiles/_diag/soak.py [steps] [arenas]"""
 import os, sys, time
@@ -12,12 +12,14 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 size = 500
 dev = torch.device("cuda:0")
+peds = len(sys.argv) > 3 and sys.argv[3] == "peds"
 for S, noise in ((1, 0), (2, 0)):
-    cfg = lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=1, n_scan_stack=S, ped_model=abi.PED_NONE,
+    cfg = lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=20 if peds else 1, n_scan_stack=S,
+                             ped_model=abi.PED_SFM if peds else abi.PED_NONE, ped_split=S if peds else 0,
                              auto_reset=1, n_spawn=16, seed=2024 + S, field_format=abi.FIELD_U16T, step_block=256)
     world.lidar_1081(cfg)
     occ = world.make_maps(E, size, 2024 + S)
-    arrays = world.make_world(cfg, occ, n_peds=0, device=dev)
+    arrays = world.make_world(cfg, occ, n_peds=20 if peds else 0, device=dev)
     for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
         arrays[key] = sim.scan_threshold(cfg, torch.from_numpy(robots.footprint_array("keti", name)).to(dev))
     host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "rect_table")}
