@@ -6,9 +6,13 @@
 N = 1: BASELINE.json configs[1] -- 4096 arenas, 1081-beam lidar, 500x500 static occupancy map,
 diff-drive (KetiRobot kinematics), no pedestrians, auto-respawn of finished arenas in place.
 N > 1: one rank per GPU -- either launched by torch.distributed.run (WORLD_SIZE set), or, when called plainly
-as `python bench.py --gpus N`, this script spawns the N ranks itself before touching the GPU.  Every rank owns
-its own 4096 arenas (weak scaling, arenas keyed by global env index); the step has no exchange, so there is
-no data-path collective (`--gather all` adds the optional RCCL all_gather of observations).
+as `python bench.py --gpus N`, this script spawns the N ranks itself before touching the GPU.
+`--scaling weak` (default): every rank owns the workload's per-GPU arena count (c2: 4096 per GPU; c4 / c5: 1/8 of
+their 8-GPU totals, so `--workload c4 --gpus 8` is the configured 16384 and `--workload c5 --gpus 8` the configured
+4096).  `--scaling strong`: the workload's TOTAL (c2: 4096) is split over the ranks by sharding.shard_range
+(ragged totals allowed).  Arenas are keyed by their global index either way.  The step has no exchange, so `value`
+involves no data-path collective; with N > 1 the line also carries `value_with_obs_gather`: the same K steps with the
+optional RCCL all-gather of the observation rows after every step (`--gather none` skips that pass).
 
 One "step" = one launch of navsim_step over all local arenas, inputs resident in HBM.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
@@ -23,14 +27,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "nav-gym_amd"))
 
 WORKLOADS = {
-    # name: (envs per GPU, beams, map size, pedestrians, ped model)
-    "c1": dict(envs=1, beams=64, size=100, peds=0),
-    "c2": dict(envs=4096, beams=1081, size=500, peds=0),
-    "c3": dict(envs=4096, beams=1081, size=500, peds=20),
-    "c4": dict(envs=2048, beams=1081, size=1000, peds=0),      # 16384 arenas over 8 GPUs
+    # envs = arenas per GPU (weak scaling), total = arenas of the whole job (strong scaling)
+    "c1": dict(envs=1, total=1, beams=64, size=100, peds=0),
+    "c2": dict(envs=4096, total=4096, beams=1081, size=500, peds=0),
+    "c3": dict(envs=4096, total=4096, beams=1081, size=500, peds=20),
+    "c4": dict(envs=2048, total=16384, beams=1081, size=1000, peds=0),      # 16384 arenas over 8 GPUs
     # 4096 arenas over 8 GPUs, Husky, 20 pedestrians, a NEW random map at every episode end (navsim_regen)
-    "c5": dict(envs=512, beams=1081, size=500, peds=20, robot="husky", regen=True),
+    "c5": dict(envs=512, total=4096, beams=1081, size=500, peds=20, robot="husky", regen=True),
 }
+
+
+def shard_of(wl, scaling, rank, world_size):
+    """(first global arena, arenas) of this rank.  weak: `envs` arenas per rank; strong: `total` split by
+    sharding.shard_range (the first total % world ranks take one more)."""
+    if scaling == "strong":
+        from nav_gym_amd.sharding import shard_range
+        return shard_range(wl["total"], rank, world_size)
+    return rank * wl["envs"], wl["envs"]
 
 
 def algorithmic_bytes_per_env_step(H, W, B, S, n_peds, s_map):
@@ -38,14 +51,14 @@ def algorithmic_bytes_per_env_step(H, W, B, S, n_peds, s_map):
     return H * W * s_map + 4 * B + 4 * (S * B + 7 + 2 + 2) + 96 + 96 * n_peds
 
 
-def build_sim(wl, rank, world_size, seed=1234, device="cuda:0"):
+def build_sim(wl, base, E, seed=1234, device="cuda:0"):
+    """The arenas [base, base + E) of the workload on `device`."""
     import numpy as np
     import torch
     from nav_gym_amd import abi, lib, robots, sim, world
-    E = wl["envs"]
     cfg = lib.default_config(n_envs=E, map_h=wl["size"], map_w=wl["size"], max_peds=max(wl["peds"], 1),
                              ped_model=abi.PED_SFM if wl["peds"] else abi.PED_NONE,
-                             n_spawn=16, auto_reset=1, seed=seed, env_index_base=rank * E,
+                             n_spawn=16, auto_reset=1, seed=seed, env_index_base=base,
                              field_format={"f32": abi.FIELD_F32}.get(wl.get("field"), abi.FIELD_U16T))
     if wl["beams"] == 1081:
         world.lidar_1081(cfg)
@@ -53,7 +66,8 @@ def build_sim(wl, rank, world_size, seed=1234, device="cuda:0"):
         world.lidar_full_circle(cfg, wl["beams"])
     if wl.get("regen"):
         cfg.regen_cap = max(16, E // 16)          # arenas regenerated per step at most (c5: ~5 finish per step)
-    occ = world.make_maps(E, wl["size"], seed, env_index_base=rank * E)
+    cfg.regen_indoor_ratio = float(wl.get("indoor_ratio", 0.0))
+    occ = world.make_maps(E, wl["size"], seed, env_index_base=base, indoor_ratio=wl.get("indoor_ratio", 0.0))
     goal = (10.0, 20.0) if wl["size"] >= 400 else (2.0, 4.0)
     arrays = world.make_world(cfg, occ, n_peds=wl["peds"], device=device, min_goal_dist=goal[0], max_goal_dist=goal[1],
                               robot_clearance=1.2 if wl["size"] >= 400 else 0.9,
@@ -126,6 +140,21 @@ def cpu_baseline(wl, seconds=15.0):
         m += 1
     one_thread = E * m / (time.perf_counter() - t1)
     pool.shutdown()
+    # SURVEY.md 8d work counters: distance-field probes per ray of the oracle's march (calc_range, env.py:425) on
+    # this workload's arenas -- a few steps on the calling thread (the histogram is per thread)
+    ref.probe_hist(reset=True)
+    n_probe_steps = 0
+    t3 = time.perf_counter()
+    while n_probe_steps < 3 or (time.perf_counter() - t3 < 1.5 and n_probe_steps < 50):
+        r.step(np.stack([rng.uniform(0, 0.5, E), rng.uniform(-0.64, 0.64, E)], axis=1))
+        n_probe_steps += 1
+    hist = ref.probe_hist(reset=True)
+    rays = int(hist.sum())
+    cum = np.cumsum(hist)
+    probes = dict(mean=float((hist * np.arange(256)).sum() / max(rays, 1)),
+                  p50=int(np.searchsorted(cum, 0.50 * rays)), p99=int(np.searchsorted(cum, 0.99 * rays)),
+                  max_bin=int(np.nonzero(hist)[0].max()) if rays else 0, rays=rays,
+                  sample="%d arenas x %d steps of the oracle (robot scans incl. crash re-scans)" % (E, n_probe_steps))
     ref_shaped_us = None
     try:
         c1 = lib.default_config(n_envs=1, map_h=1000, map_w=1000, max_peds=10, ped_model=abi.PED_SFM, n_spawn=4,
@@ -152,6 +181,7 @@ def cpu_baseline(wl, seconds=15.0):
                 sample="%d arenas x %d steps of the same workload (oracle/navsim_ref.c, %d threads, %.1f s)"
                        % (E, n, nthr, dt),
                 value_1_thread=one_thread,
+                probes_per_ray=probes,
                 reference_shaped_us_per_step=ref_shaped_us,
                 reference_shaped="1 arena, 512 beams, 1000x1000 map, 10 pedestrians + their 512-beam scans, 1 thread "
                                  "(restatement, not the reference binary)")
@@ -193,19 +223,24 @@ def launch_ranks(n_gpus, argv):
                     p.terminate()
         time.sleep(0.2)
     codes = [p.wait() for p in procs]
-    reader.join(5.0)
-    sys.stdout.write(b"".join(out0).decode())
+    reader.join(30.0)                       # rank 0 has exited: its pipe is at EOF, the reader ends at once
+    text = b"".join(out0).decode()
+    sys.stdout.write(text)
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
         raise SystemExit("bench.py: rank(s) failed: %s" % ", ".join("rank %d exit %d" % rc for rc in bad))
+    if not any(ln.startswith("{") for ln in text.splitlines()):
+        raise SystemExit("bench.py: every rank exited 0 but rank 0 printed no JSON line")
 
 
-def profiled_traffic(workload, E, field):
-    """HBM bytes per launch of the step kernel from the committed PMC profile of this workload (rocprofv3 --pmc
-    passes, profiles/pmc_pass.sh), NOT a reading of this run: counters cannot be collected inside the timed
-    process.  -> (bytes or None, 'file@commit' or None)"""
-    for rnd in ("r02", "r01"):
+def profiled_counters(workload, E, field, rects):
+    """Counter figures of the step kernel from the committed PMC profile of this workload (rocprofv3 --pmc passes,
+    profiles/run_profiles.sh -> traffic.json): HBM bytes per launch and the vector-issue fraction.  Counters cannot be
+    collected inside the timed process, so they are quoted -- and ONLY when the profile was taken from the same
+    library sources (lib.source_hash) and launch shape; otherwise (None, reason)."""
+    from nav_gym_amd import lib
+    for rnd in ("r03", "r02"):
         tp = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, workload), "traffic.json")
         if not os.path.exists(tp):
             continue
@@ -213,20 +248,32 @@ def profiled_traffic(workload, E, field):
             t = json.load(open(tp))
         except Exception:
             continue
-        if t.get("envs_per_gpu", WORKLOADS[workload]["envs"]) != E or field != "u16t":
-            return None, None                       # another launch shape: the stored figure does not apply
-        return t.get("hbm_bytes_per_launch"), "profiles/%s_%s/traffic.json@%s" % (rnd, workload, t.get("commit", "?"))
-    return None, None
+        src = "profiles/%s_%s/traffic.json@%s" % (rnd, workload, t.get("commit", "?"))
+        if t.get("kernel_src_sha") != lib.source_hash():
+            return None, "%s is of other kernel sources (%s, this build %s)" % (src, t.get("kernel_src_sha"), lib.source_hash())
+        if t.get("envs_per_gpu") != E or field != "u16t" or t.get("rect_table", True) != rects:
+            return None, "%s is of another launch shape" % src
+        t["source"] = src
+        return t, None
+    return None, "no committed PMC profile of this workload"
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs = ranks of ONE node (default: WORLD_SIZE when a launcher set it, else 1)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--envs", type=int, default=0, help="override arenas per GPU")
-    ap.add_argument("--gather", default="none", choices=["none", "all"])
+    ap.add_argument("--envs", type=int, default=0, help="override arenas per GPU (weak scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the workload's per-GPU arena count on every rank; strong: its TOTAL split over the ranks")
+    ap.add_argument("--total-envs", type=int, default=0, help="override the total arena count (strong scaling; may be ragged)")
+    ap.add_argument("--gather", default="auto", choices=["auto", "none", "all"],
+                    help="auto: with N > 1 time a second pass with the RCCL all-gather of the observation rows after every "
+                         "step and report it as value_with_obs_gather; all: gather inside `value` itself; none: never")
+    ap.add_argument("--indoor-ratio", type=float, default=0.0,
+                    help="fraction of corridor maps (create_indoor_map) among the arenas; the rest are outdoor maps")
     ap.add_argument("--field", default="u16t", choices=["u16t", "f32"], help="distance-field storage")
     ap.add_argument("--noise-std", type=float, default=0.02,
                     help="scan_noise_std of every arena in the timed steps (SURVEY.md 8d: 0.02 for throughput runs)")
@@ -236,6 +283,7 @@ def main():
     ap.add_argument("--step-block", type=int, default=0, help="threads per arena (0 = library default)")
     ap.add_argument("--spinup-ms", type=float, default=500.0,
                     help="untimed GPU work before the warm-up steps (leaves the idle power state); 0 = none")
+    ap.add_argument("--no-cold-pass", action="store_true", help="skip the extra K steps timed before the spin-up")
     ap.add_argument("--lpt-period", type=int, default=0, help="steps between launch-order sorts (0 = NavSim's default)")
     ap.add_argument("--ped-split", type=int, default=0, choices=[0, 1, 2],
                     help="navsim_config.ped_split: 0 library default, 1 pedestrians inside the step, 2 ped_update_kernel first")
@@ -249,13 +297,15 @@ def main():
                     help="launcher / rendezvous / reduction control flow only, no GPU work (tests/test_host_logic.py)")
     args = ap.parse_args()
 
+    if args.gpus is None:                   # `torchrun --nproc-per-node N bench.py`: the launcher's world is the answer
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus, sys.argv[1:])
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_size != args.gpus:
+    if world_size != args.gpus:             # an EXPLICIT --gpus that contradicts the launcher is an error
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world_size))
     # NAVSIM_BENCH_BACKEND=gloo + NAVSIM_BENCH_ONE_GPU=1: control-flow test of the N > 1 path with
     # several ranks sharing one GPU (the driver's real runs use nccl = RCCL, one rank per GPU)
@@ -284,10 +334,17 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.envs:
         wl["envs"] = args.envs
+    if args.total_envs:
+        wl["total"] = args.total_envs
     wl["field"] = args.field
+    wl["indoor_ratio"] = args.indoor_ratio
     if args.no_rects:
         wl["rects"] = False
-    cfg, sim, arrays, _ = build_sim(wl, rank, world_size, device=device)
+    base, E_local = shard_of(wl, args.scaling, rank, world_size)
+    E_total = wl["total"] if args.scaling == "strong" else world_size * wl["envs"]
+    if E_local < 1:
+        raise SystemExit("bench.py: rank %d owns no arena (%d arenas over %d ranks)" % (rank, E_total, world_size))
+    cfg, sim, arrays, _ = build_sim(wl, base, E_local, device=device)
     if args.step_block:
         sim.cfg.step_block = args.step_block
     if args.ped_split:
@@ -305,9 +362,15 @@ def main():
     acts = torch.rand((K + Wm, E, 2), generator=g, device=device, dtype=torch.float64)
     acts[..., 0] *= 0.5
     acts[..., 1] = acts[..., 1] * 1.28 - 0.64
-    gather_buf = None
-    if args.gather == "all" and dist is not None and backend == "nccl":
-        gather_buf = torch.empty((world_size * E, sim.obs.shape[1]), dtype=torch.float32, device=device)
+    # the optional obs gather: rows of all ranks in global arena order, one RCCL call per step
+    gatherer = None
+    if args.gather != "none" and dist is not None and backend == "nccl":
+        from nav_gym_amd.sharding import RowGather
+        if args.scaling == "strong":
+            gatherer = RowGather(E_total, sim.obs.shape[1:], torch.float32, device, rank, world_size)
+        else:                               # weak: equal shards by construction
+            gatherer = RowGather(world_size * E, sim.obs.shape[1:], torch.float32, device, rank, world_size)
+    gather_on = [args.gather == "all" and gatherer is not None]
 
     regen = bool(wl.get("regen"))
     lin_hi, rot_hi = (1.0, 2.0) if wl.get("robot") == "husky" else (0.5, 0.64)
@@ -324,8 +387,8 @@ def main():
             ev[1].record()
         if regen:                       # finished arenas restart on a freshly generated map, on the device
             sim.regen()
-        if gather_buf is not None:
-            dist.all_gather_into_tensor(gather_buf, sim.obs)
+        if gather_on[0]:
+            gatherer.run(sim.obs)
 
     def fence():
         torch.cuda.synchronize()
@@ -333,49 +396,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # 25 steps of 0.12 ms are 3 ms of GPU work: after the host-side set-up the GPU is still in its idle power state and
-    # the kernel runs 5 % slower than in a long run (measured: kernel 121 vs 116 us).  Half a second of untimed work
-    # that touches no simulator state (the library's device sincos on a scratch tensor) precedes the warm-up steps.
-    if args.spinup_ms > 0:
-        from nav_gym_amd import sim as _simmod
-        scratch = torch.rand(1 << 22, device=device, dtype=torch.float64)
-        t_end = time.perf_counter() + args.spinup_ms * 1e-3
-        while time.perf_counter() < t_end:
-            for _ in range(8):
-                _simmod.debug_math(0, scratch)
-            torch.cuda.synchronize()
-        del scratch
-    for t in range(Wm):
-        run(t)
-    fence()
-    # The K timed steps are launch-bound between kernels (~5 us of host gap per 220 us kernel): optionally capture
-    # them once as a hipGraph and replay it.  Every node keeps its own action slice and observation buffers.
     graph = None
-    if args.graph != "off" and gather_buf is None:
-        try:
-            cur0 = sim.cur
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                for t in range(K):
-                    run(Wm + t)
-        except Exception as exc:                      # capture unsupported here: plain launches
-            if args.graph == "on":
-                raise
-            graph = None
-            sim.cur = cur0
-            torch.cuda.synchronize()
-            if rank == 0:
-                print("bench: hipGraph capture failed (%s); timing plain launches" % type(exc).__name__, file=sys.stderr)
-
     # HIP events on the launch stream.  Where the step launch is the only kernel of a step (c1-c4) ONE pair brackets
     # the K launches and kernel_ms = that span / K: an upper bound of the kernel's duration (it includes the 1-2 us
     # between consecutive launches), and nothing is inserted between the launches that are being timed -- an event
     # pair per step costs 4 % of the throughput at 120 us per step.  Where other kernels run between the steps
     # (navsim_regen, the obs gather) every step launch gets its own pair.
-    events_per_step = (regen or gather_buf is not None) and graph is None
-
     def timed():
         """EXACTLY K steps between barrier + synchronize on both sides; max over ranks."""
+        events_per_step = (regen or gather_on[0]) and graph is None
         fence()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
               for _ in range(K if events_per_step else 1)]
@@ -397,8 +426,55 @@ def main():
             elapsed = float(tt.item())
         return elapsed, sum(a.elapsed_time(b) for a, b in ev) / K
 
+    # the same K steps WITHOUT the spin-up below, straight after the host-side set-up (GPU still in its idle
+    # power state), reported beside `value` as value_no_spinup
+    cold = None
+    if args.spinup_ms > 0 and not args.no_cold_pass:
+        for t in range(Wm):
+            run(t)
+        cold = timed()
+    # 25 steps of 0.12 ms are 3 ms of GPU work: after the host-side set-up the GPU is still in its idle power state and
+    # the kernel runs 5 % slower than in a long run (measured: kernel 121 vs 116 us).  Half a second of untimed work
+    # that touches no simulator state (the library's device sincos on a scratch tensor) precedes the warm-up steps.
+    if args.spinup_ms > 0:
+        from nav_gym_amd import sim as _simmod
+        scratch = torch.rand(1 << 22, device=device, dtype=torch.float64)
+        t_end = time.perf_counter() + args.spinup_ms * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                _simmod.debug_math(0, scratch)
+            torch.cuda.synchronize()
+        del scratch
+    for t in range(Wm):
+        run(t)
+    fence()
+    # The K timed steps are launch-bound between kernels (~5 us of host gap per 220 us kernel): optionally capture
+    # them once as a hipGraph and replay it.  Every node keeps its own action slice and observation buffers.
+    if args.graph != "off" and gatherer is None:
+        try:
+            cur0 = sim.cur
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for t in range(K):
+                    run(Wm + t)
+        except Exception as exc:                      # capture unsupported here: plain launches
+            if args.graph == "on":
+                raise
+            graph = None
+            sim.cur = cur0
+            torch.cuda.synchronize()
+            if rank == 0:
+                print("bench: hipGraph capture failed (%s); timing plain launches" % type(exc).__name__, file=sys.stderr)
+
     elapsed, kernel_ms = timed()                     # THE measurement (`value`)
     more = [timed() for _ in range(max(args.repeats - 1, 0))]
+    with_gather = None
+    if gatherer is not None and not gather_on[0]:    # the same K steps, every step followed by the obs all-gather
+        gather_on[0] = True
+        for t in range(min(Wm, 3)):
+            run(t)
+        with_gather = timed()
+        gather_on[0] = False
     noise_off = None
     if args.noise_std > 0 and not args.no_noise_off_pass:   # the same K steps without the per-beam Gaussian, beside it
         sim.cfg.add_scan_noise = 0
@@ -407,74 +483,115 @@ def main():
 
     if rank == 0:
         import statistics
+        from nav_gym_amd import abi, lib as _lib
         n_done = int(sim.t["episode"].sum().item())
-        # s_map = 1: the arena's occupancy grid as the reference stores it (int8 map_info['data'],
-        # map_generator.py:136) read once per env-step -- BASELINE.md section 3's definition.  The
-        # on-device distance-field encoding is an implementation choice, not algorithmic bytes.
-        A = algorithmic_bytes_per_env_step(cfg.map_h, cfg.map_w, cfg.n_beams, cfg.n_scan_stack, wl["peds"], 1)
-        achieved = A * E / (kernel_ms * 1e-3) / 1e9                # GB/s
+        rects = "rect_table" in sim.t
+        # A = H*W*s_map + 4B + 4(S*B + 11) + 96 (+ 96 N), s_map = "bytes per cell of the map representation
+        # the kernel streams once per env-step".  What this kernel reads of a map: with rect records 16 B per 8x8-cell
+        # tile = 0.25 B per cell (most probes never touch the field); the packed uint16 field alone 2; float32 4.
+        if rects:
+            s_map, s_map_of = 0.25, "two-rectangle tile records: 16 B per 8x8 cells (nav-gym_amd/csrc/kernels_rect.hpp)"
+        elif cfg.field_format == abi.FIELD_U16T:
+            s_map, s_map_of = 2, "packed uint16 squared-distance field in 8x8 tiles"
+        else:
+            s_map, s_map_of = 4, "float32 distance field (what range_libc holds)"
+        H, W, B, S = cfg.map_h, cfg.map_w, cfg.n_beams, cfg.n_scan_stack
+        A = algorithmic_bytes_per_env_step(H, W, B, S, wl["peds"], s_map)
+        A1 = algorithmic_bytes_per_env_step(H, W, B, S, wl["peds"], 1)
+        achieved = A * E / (kernel_ms * 1e-3) / 1e9                # GB/s over the kernel's own duration
         frac = achieved / 8000.0
-        # the same formula with s_map = bytes per cell of the representation the kernel actually marches on
-        # ("the map representation the kernel streams"): rect records are 16 B per 8x8 tile = 0.25,
-        # the packed distance field 2, the float32 field 4
-        from nav_gym_amd import abi
-        s_streamed = 0.25 if "rect_table" in sim.t else (2 if cfg.field_format == abi.FIELD_U16T else 4)
-        A_streamed = algorithmic_bytes_per_env_step(cfg.map_h, cfg.map_w, cfg.n_beams, cfg.n_scan_stack, wl["peds"], s_streamed)
-        tbytes, tsrc = profiled_traffic(args.workload, E, args.field)
-        all_values = [world_size * E * K / el for el, _ in [(elapsed, kernel_ms)] + more]
+        prof, why_not = profiled_counters(args.workload, E, args.field, rects)
+        tbytes = prof.get("hbm_bytes_per_launch") if prof else None
+        all_values = [E_total * K / el for el, _ in [(elapsed, kernel_ms)] + more]
+        value = E_total * K / elapsed
+        tile_frac = None
+        if rects:                           # tiles whose record reproduces the field (the others fall back to it)
+            tile_frac = float(((sim.t["rect_table"][..., 0] & 0xFFFF) != 0x7FFF).double().mean().item())
         out = {
             "metric": "env steps/sec (whole node), 4096 envs x 1081-beam lidar",
-            "value": world_size * E * K / elapsed,
+            "value": value,
             "unit": "env-steps/s",
             "n_gpus": world_size,
             "steps": K,
             "warmup": Wm,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%s: %d arenas/GPU x %d-beam lidar, %dx%d per-arena occupancy maps (%s distance "
-                            "field), %d pedestrians/arena, %s kinematics, %s, scan_noise_std %.3g"
-                            % (args.workload, E, cfg.n_beams, cfg.map_h, cfg.map_w, args.field, wl["peds"],
-                               wl.get("robot", "keti"),
+                "workload": "%s: %d arenas (%s scaling: %d on rank 0) x %d-beam lidar, %dx%d per-arena occupancy maps "
+                            "(%s distance field%s), indoor ratio %.2g, %d pedestrians/arena, %s kinematics, %s, "
+                            "scan_noise_std %.3g"
+                            % (args.workload, E_total, args.scaling, E, B, H, W, args.field,
+                               " + rect records" if rects else "", args.indoor_ratio, wl["peds"], wl.get("robot", "keti"),
                                "new random map per episode (navsim_regen)" if regen else "auto-respawn in place",
                                args.noise_std),
-                "envs_per_gpu": E, "n_beams": cfg.n_beams, "map": [cfg.map_h, cfg.map_w],
+                "envs_total": E_total, "envs_per_gpu": E, "n_beams": B, "map": [H, W],
                 "pedestrians": wl["peds"], "obs_gather": args.gather, "episodes_finished_rank0": n_done,
                 "launch": "hipGraph replay of the K steps" if graph is not None else "one launch per step",
                 "ranks": world_size, "collective_backend": (backend if world_size > 1 else None),
-                "scan_noise_std": args.noise_std, "rect_table": "rect_table" in sim.t,
+                "scan_noise_std": args.noise_std, "rect_table": rects, "rect_valid_tile_frac": tile_frac,
+                "indoor_ratio": args.indoor_ratio,
                 "gpu_spinup_ms": args.spinup_ms,     # untimed, before the warm-up steps, touches no simulator state
+                "kernel_src_sha": _lib.source_hash(),
             },
             "repeats": {"n": len(all_values), "values": all_values, "median": statistics.median(all_values)},
+            # without the spin-up: the K steps straight after set-up, GPU still in its idle power state
+            "value_no_spinup": (E_total * K / cold[0]) if cold else None,
             "roofline": {
-                # SURVEY.md 8d figure: algorithmic bytes (whole occupancy grid once per arena-step) / kernel time.
-                # A march touches only part of the grid, so on large maps the formula can exceed 1: then it says
-                # nothing about the kernel and hbm_frac_measured (counter bytes) is the figure to read.
-                "bound": "hbm",
+                # The contract's fraction: SURVEY.md 8d algorithmic bytes with the s_map of what the kernel reads, over
+                # the kernel's own duration, against the HBM peak.  It is reported as asked; what actually limits the
+                # kernel is vector issue on the dependent probe chain (issue_frac_profiled, profiles/README.md).
+                "bound": "valu-issue (profiled); hbm frac reported per contract",
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": frac,
-                "note": (None if frac <= 1.0 else
-                         "the 8d figure counts the whole occupancy grid once per arena-step; the kernel reads an 8x smaller "
-                         "lossless description of it (rect records) and only along the rays, so achieved exceeds the peak: "
-                         "the formula has stopped being a bound here, read hbm_frac_measured (counter bytes)"),
-                "traffic": None,                # not measured in this process (PMC needs rocprofv3)
-                "traffic_profiled": tbytes, "traffic_profile": tsrc,
+                "s_map": s_map, "s_map_of": s_map_of, "algorithmic_bytes_per_env_step": A,
+                "algorithmic_bytes_per_launch": A * E,
+                # the same bytes over the step's wall time (launch gaps, sort, regen included): never above `frac`
+                "frac_of_ms_per_step": A * E_total / world_size / (elapsed / K) / 8.0e12,
+                # HBM bytes per launch from the PMC counters of the committed profile of THESE sources (null otherwise)
+                "traffic": tbytes,
+                "traffic_source": (prof["source"] if prof else None), "traffic_unavailable": why_not,
                 "hbm_frac_measured": (tbytes / (kernel_ms * 1e-3) / 8.0e12) if tbytes else None,
+                "traffic_over_algorithmic": (tbytes / (A * E)) if tbytes else None,
+                # SQ_ACTIVE_INST_VALU x 4 cycles / (SIMDs x kernel cycles), same profile
+                "issue_frac_profiled": (prof.get("valu_issue_frac") if prof else None),
                 "kernel": "navsim_step_kernel", "kernel_ms": kernel_ms,
-                "kernel_ms_from": ("one HIP event pair per step launch" if events_per_step else
+                "kernel_ms_from": ("one HIP event pair per step launch" if (regen or (args.gather == "all" and gatherer is not None)) and graph is None else
                                    "one HIP event pair around the %d launches / %d (includes the gaps between launches)" % (K, K)),
-                "algorithmic_bytes_per_env_step": A, "s_map": 1,
-                "s_map_streamed": s_streamed, "frac_s_map_streamed": A_streamed * E / (kernel_ms * 1e-3) / 8.0e12,
+                # SURVEY.md 8d also prints the formula with s_map = 1 (the occupancy grid as the reference stores it, int8,
+                # once per arena-step).  This kernel does not read the grid, so that figure is not a bound on it:
+                "frac_s_map_1": A1 * E / (kernel_ms * 1e-3) / 8.0e12, "algorithmic_bytes_s_map_1": A1,
+                "note_s_map_1": "not a roofline for this kernel: it counts H*W bytes per arena-step that are never read "
+                                "(the march reads a lossless 4x..8x smaller description, and only along the rays)",
+            },
+            # SURVEY.md 8d derived work counters
+            "work": {
+                "rays_per_s": value * B,
+                "worst_case_probes_per_env_step": int(B * cfg.range_max / cfg.resolution),
             },
         }
+        if frac > 1.0:
+            out["roofline"]["note"] = ("algorithmic bytes / kernel time exceeds the HBM peak: on this workload even the s_map of "
+                                       "the streamed representation over-counts (rays touch a fraction of the tiles); read "
+                                       "hbm_frac_measured")
+        if with_gather is not None or gather_on[0]:
+            el_g = with_gather[0] if with_gather is not None else elapsed
+            out["value_with_obs_gather"] = E_total * K / el_g
+            out["obs_gather"] = {"ms_per_step": el_g / K * 1e3, "bytes_per_rank": int(sim.obs.numel() * 4),
+                                 "bytes_total": int(gatherer.out.numel() * 4), "equal_shards": gatherer.equal,
+                                 "collective": "all_gather_into_tensor (RCCL)" if gatherer.equal else "all_gather of padded rows (RCCL)"}
+        elif world_size > 1:
+            out["value_with_obs_gather"] = None
         if noise_off is not None:
-            out["noise_off"] = {"value": world_size * E * K / noise_off[0], "ms_per_step": noise_off[0] / K * 1e3,
+            out["noise_off"] = {"value": E_total * K / noise_off[0], "ms_per_step": noise_off[0] / K * 1e3,
                                 "kernel_ms": noise_off[1]}
         if not args.no_cpu_baseline and world_size == 1:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
+            pr = out["cpu_baseline"].pop("probes_per_ray")
+            out["work"].update(probes_per_ray_mean=pr["mean"], probes_per_ray_p50=pr["p50"], probes_per_ray_p99=pr["p99"],
+                               probes_per_ray_from="oracle/navsim_ref.c trace_ray (calc_range, env.py:425): " + pr["sample"])
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
@@ -482,14 +599,24 @@ def main():
 
 
 def dry_run(args, rank, world_size, backend):
-    """Launcher / rendezvous / max-over-ranks control flow without a GPU (CPU test of `--gpus N`): every rank
-    joins the process group, contributes a fake per-rank time, rank 0 prints the line shape with n_gpus = the
-    process group's size.  Measures nothing."""
+    """Launcher / rendezvous / max-over-ranks / sharding control flow without a GPU (CPU test of `--gpus N`): every
+    rank joins the process group, works out its shard of the workload exactly as the real run does, contributes a fake
+    per-rank time and -- like the obs gather -- one row per owned arena holding that arena's GLOBAL index through
+    sharding.RowGather; rank 0 prints the line shape.  Measures nothing."""
     dist = None
     elapsed = 1.0 + rank
+    wl = dict(WORKLOADS[args.workload])
+    if args.envs:
+        wl["envs"] = args.envs
+    if args.total_envs:
+        wl["total"] = args.total_envs
+    base, count = shard_of(wl, args.scaling, rank, world_size)
+    E_total = wl["total"] if args.scaling == "strong" else world_size * wl["envs"]
+    gathered_ok = None
     if world_size > 1:
         import torch
         import torch.distributed as dist
+        from nav_gym_amd.sharding import RowGather
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if backend == "nccl" else backend)
         assert dist.get_world_size() == args.gpus
@@ -497,11 +624,20 @@ def dry_run(args, rank, world_size, backend):
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        if args.gather != "none":
+            g = RowGather(E_total, (3,), torch.float32, "cpu", rank, world_size)
+            rows = (torch.arange(base, base + count, dtype=torch.float32)[:, None] * torch.ones(3)).contiguous()
+            got = g.run(rows)
+            gathered_ok = bool(torch.equal(got[:, 0], torch.arange(E_total, dtype=torch.float32)))
     if os.environ.get("NAVSIM_BENCH_FAIL_RANK") == str(rank):      # failure-propagation test
         raise SystemExit(3)
     if rank == 0:
+        from nav_gym_amd.sharding import shard_range
+        shards = [list(shard_of(wl, args.scaling, r, world_size)) for r in range(world_size)]
         print(json.dumps({"metric": "dry-run (no GPU work, control flow only)", "value": None, "n_gpus": world_size,
-                          "steps": args.steps, "warmup": args.warmup, "max_rank_time": elapsed, "dry_run": True}))
+                          "steps": args.steps, "warmup": args.warmup, "max_rank_time": elapsed, "dry_run": True,
+                          "scaling": args.scaling, "envs_total": E_total, "shards": shards,
+                          "gather_in_global_order": gathered_ok}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -510,6 +510,18 @@ int navsim_debug_math(int32_t fn, const double* x, const double* x2, double* out
  * as_f32 = 1 rounds the inputs to float32 first and divides in float32 (the lidar origin, env.py:386, 419). */
 int navsim_debug_xy_to_ij(const navsim_config* cfg, const double* xy, int32_t as_f32, int32_t* ij, int32_t n, void* stream);
 
+/* ---- measurement hooks (used by profiles/ only; nothing of the hot path calls them) ---------- */
+/* Scattered-read microbenchmark behind DESIGN.md section 6's "a scattered 4-byte read costs a 128-byte fill"
+ * (profiles/gather_granularity.py): n_threads lanes each read `iters` pseudo-random words of x[n_words];
+ * mode selects the access width / stride pattern; out[n_threads] keeps the loads alive. */
+int navsim_debug_gather(const float* x, uint64_t n_words, int32_t mode, int32_t iters, int32_t n_threads,
+                        float* out, void* stream);
+/* Phase time stamps of the fused step (profiles/_r01_tools/stamp_phases.py, profiles/_diag/tail_profile.py):
+ * device buffer of 8 x n_envs uint64 receiving s_memtime / s_memrealtime at the phase boundaries of every arena's
+ * workgroup; NULL disables.  Only a library built with -DNAVSIM_STAMPS records anything; the shipped build
+ * compiles no stamp into the kernel and returns NAVSIM_E_UNSUPPORTED. */
+int navsim_debug_set_stamps(unsigned long long* buf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,13 @@
 
 #pragma clang fp contract(off)
 
+// gfx950 only: bit-identity of the scans rests on properties of THIS ISA that are proven by exhaustive
+// device tests -- v_rsq_f32's rounding inside sqrt_small_int, the float32-only march step (navmath.hpp) -- and on
+// v_dot2_i32_i16 / v_pk_* forms that other targets lack.  Another offload arch must not compile silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "navsim_kernels.hip is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+
 namespace {
 
 constexpr int kMaxWaves = 16;

@@ -305,4 +305,5 @@ EXPORTS = (
     "navsim_crowd_check", "navsim_crowd_angular_map", "navsim_crowd_local_map", "navsim_crowd_orca", "navsim_crowd_agent_step",
     "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math", "navsim_debug_xy_to_ij",
+    "navsim_debug_gather", "navsim_debug_set_stamps",
 )

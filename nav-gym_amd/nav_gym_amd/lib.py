@@ -29,6 +29,22 @@ def build_library(verbose=False):
     return LIB_PATH
 
 
+def source_hash():
+    """First 16 hex digits of the SHA-256 over the library's sources (csrc/*.hip, *.hpp and include/navsim.h, in
+    name order).  Profiles record it (profiles/summarize.py) and bench.py only quotes counter figures of a profile
+    taken from the same sources."""
+    import glob
+    import hashlib
+    csrc = os.path.join(os.path.dirname(_HERE), "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")))
+    files.append(os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "navsim.h"))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load():
     """Returns the ctypes handle with argtypes attached.  Raises NavsimError if the .so is absent."""
     global _LIB

@@ -38,6 +38,43 @@ def gather_rows(local, group=None):
     return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
 
 
+class RowGather(object):
+    """The optional obs gather as a resident operation: shard sizes follow from (n_total, world_size) alone, so
+    the output (and, for ragged shards, the padded per-rank parts) is allocated once and every call is ONE
+    collective with no host synchronisation -- all_gather_into_tensor (RCCL: a single ncclAllGather) when the shards
+    are equal, all_gather of rows padded to the largest shard otherwise.  `out` holds the rows in global arena
+    order after run()."""
+
+    def __init__(self, n_total, row_shape, dtype, device, rank, world_size, group=None):
+        import torch
+        self.group = group
+        self.counts = [shard_range(n_total, r, world_size)[1] for r in range(world_size)]
+        self.start = shard_range(n_total, rank, world_size)[0]
+        self.count = self.counts[rank]
+        self.equal = len(set(self.counts)) == 1
+        row_shape = tuple(row_shape)
+        self.out = torch.empty((int(n_total),) + row_shape, dtype=dtype, device=device)
+        if not self.equal:
+            m = max(self.counts)
+            self.pad = torch.zeros((m,) + row_shape, dtype=dtype, device=device)
+            self.parts = [torch.empty_like(self.pad) for _ in range(world_size)]
+
+    def run(self, local):
+        import torch.distributed as dist
+        if local.shape[0] != self.count:
+            raise ValueError("this rank owns %d rows, got %d" % (self.count, local.shape[0]))
+        if self.equal:
+            dist.all_gather_into_tensor(self.out, local.contiguous(), group=self.group)
+            return self.out
+        self.pad[: self.count].copy_(local)
+        dist.all_gather(self.parts, self.pad, group=self.group)
+        at = 0
+        for part, c in zip(self.parts, self.counts):
+            self.out[at:at + c].copy_(part[:c])
+            at += c
+        return self.out
+
+
 def make_sharded_env(n_total, rank=None, world_size=None, **kwargs):
     """NavGymEnv over this rank's block of `n_total` global arenas on cuda:LOCAL_RANK."""
     import os

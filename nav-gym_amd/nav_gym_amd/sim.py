@@ -383,7 +383,8 @@ class NavSim(object):
     def _reorder(self):
         # re-sort before steps 2..5 (short runs profit from the very first measured costs), then every lpt_period-th
         self._steps_launched += 1
-        if "launch_order" in self.t and (2 <= self._steps_launched <= 5 or self._steps_launched % self.lpt_period == 0):
+        n = self._steps_launched
+        if "launch_order" in self.t and self.lpt_period > 0 and (2 <= n <= 5 or n % self.lpt_period == 0):
             check(self.lib.navsim_launch_order(_ptr(self.t["arena_cost"]), _ptr(self.t["launch_order"]), self.cfg.n_envs,
                                                _stream()), "navsim_launch_order")
 

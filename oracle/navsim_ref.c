@@ -15,6 +15,7 @@
 
 
 static __thread int64_t g_probe_count = 0;
+static __thread int64_t g_probe_hist[256];      /* rays by number of probes (last bin: >= 255), SURVEY.md 8d work counters */
 int navsim_costmap_cpu(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, uint8_t* cost);
 int navsim_plan_cpu(const uint8_t* cost, const int32_t* map_index, int32_t n_maps, int32_t Hc, int32_t Wc,
                     double res_c, double ox, double oy, const double* start, const double* goal, double interval,
@@ -24,6 +25,13 @@ int64_t navsim_probe_count_cpu(int32_t reset) {
     int64_t v = g_probe_count;
     if (reset) g_probe_count = 0;
     return v;
+}
+
+/* rays traced on this thread since the last reset, binned by the number of distance-field probes each one made */
+int navsim_probe_hist_cpu(int64_t* hist256, int32_t reset) {
+    if (hist256) memcpy(hist256, g_probe_hist, sizeof(g_probe_hist));
+    if (reset) memset(g_probe_hist, 0, sizeof(g_probe_hist));
+    return NAVSIM_OK;
 }
 
 /* =========================================================================================
@@ -180,8 +188,8 @@ int navsim_build_dt_cpu(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W
  * occupancy[y][x]; cosf/sinf are replaced by the specified nvr_cos/nvr_sin evaluated in double on
  * the float32 heading and rounded once to float32.
  * ======================================================================================= */
-static float trace_ray(const float* f, int H, int W, float x0, float y0, float dx, float dy,
-                       float max_range, int march_rule) {
+static float trace_ray_counted(const float* f, int H, int W, float x0, float y0, float dx, float dy,
+                               float max_range, int march_rule, int* n_probes) {
     float t = 0.0f;
     while (t < max_range) {
         float fx = x0 + dx * t;
@@ -191,6 +199,7 @@ static float trace_ray(const float* f, int H, int W, float x0, float y0, float d
         if (px >= W || px < 0 || py < 0 || py >= H) return max_range;
         float d = f[(size_t)py * W + px];
         ++g_probe_count;
+        ++*n_probes;
         if (d <= 0.0f) {
             float xd = (float)px - x0;
             float yd = (float)py - y0;
@@ -200,6 +209,13 @@ static float trace_ray(const float* f, int H, int W, float x0, float y0, float d
         t += (step > 1.0f) ? step : 1.0f;
     }
     return max_range;
+}
+static float trace_ray(const float* f, int H, int W, float x0, float y0, float dx, float dy,
+                       float max_range, int march_rule) {
+    int n = 0;
+    float r = trace_ray_counted(f, H, W, x0, y0, dx, dy, max_range, march_rule, &n);
+    ++g_probe_hist[n < 255 ? n : 255];
+    return r;
 }
 
 static inline void beam_dir(float heading, float* dx, float* dy) {

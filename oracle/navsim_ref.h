@@ -122,6 +122,8 @@ int navsim_crowd_agent_step_cpu(double* pose, const double* action, double* vel,
 
 /* statistics for DESIGN.md: distance-field probes of the last cast/step on this thread */
 int64_t navsim_probe_count_cpu(int32_t reset);
+/* rays traced on this thread since the last reset by number of probes: hist256[n], n = 255 collects >= 255 */
+int navsim_probe_hist_cpu(int64_t* hist256, int32_t reset);
 
 #ifdef __cplusplus
 }

@@ -49,6 +49,7 @@ def lib():
                                             C.POINTER(abi.NavsimStepIO), C.c_int32, C.c_int32]
         L.navsim_probe_count_cpu.argtypes = [C.c_int32]
         L.navsim_probe_count_cpu.restype = C.c_int64
+        L.navsim_probe_hist_cpu.argtypes = [C.c_void_p, C.c_int32]
         _LIB = L
     return _LIB
 
@@ -312,6 +313,14 @@ def math_fn(fn, x, x2=None):
 
 def probe_count(reset=True):
     return int(lib().navsim_probe_count_cpu(int(reset)))
+
+
+def probe_hist(reset=True):
+    """int64 [256]: rays traced on THIS thread since the last reset, by the number of distance-field probes each
+    one made (bin 255 collects >= 255).  SURVEY.md 8d work counters (probes per ray mean / p99)."""
+    h = np.zeros(256, np.int64)
+    _chk(lib().navsim_probe_hist_cpu(_p(h), int(reset)), "probe_hist")
+    return h
 
 
 class RefSim(object):

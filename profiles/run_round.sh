@@ -9,7 +9,7 @@ R="${GRAFT_REPO_ROOT:-/root/repo}"
 for W in c1 c2 c3 c4; do
   bash "$R/profiles/run_profiles.sh" "${TAG}_$W" --workload $W --steps 100 > /dev/null 2>&1
 done
-NAVSIM_PROFILE_MAXHALF=1 bash "$R/profiles/run_profiles.sh" "${TAG}_c5" --workload c5 --steps 100 > /dev/null 2>&1
+bash "$R/profiles/run_profiles.sh" "${TAG}_c5" --workload c5 --steps 100 > /dev/null 2>&1
 OUT="$R/gpurun_out/prof_${TAG}_policy"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 "$R/profiles/policy_cost.py" > "$OUT/trace.log" 2>&1

@@ -1,0 +1,55 @@
+"""Soak of the fused step against the oracle (test infrastructure; profiles/_diag/soak.py runs it at full length).
+
+E arenas on 500 x 500 maps, 1081 beams, the forced 256-thread kernel (parked rays, scalar-mask loop, table
+directions), `steps` steps of random actions with crash reverts and respawns; EVERY output of EVERY step is compared
+with the oracle bit for bit.  peds: 20 social-force pedestrians per arena, once with the pedestrian update inside the
+step (ped_split 1) and once ahead of it in ped_update_kernel (ped_split 2)."""
+import time
+
+import numpy as np
+
+
+def run_soak(steps, E, peds=False, size=500, log=None):
+    """-> list of (S, crashes, episodes ended) per pass; raises AssertionError at the first difference."""
+    import torch
+    from nav_gym_amd import abi, lib, robots, sim, world
+    import ref
+    dev = torch.device("cuda:0")
+    passes = []
+    for S in (1, 2):
+        cfg = lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=20 if peds else 1, n_scan_stack=S,
+                                 ped_model=abi.PED_SFM if peds else abi.PED_NONE, ped_split=S if peds else 0,
+                                 auto_reset=1, n_spawn=16, seed=2024 + S, field_format=abi.FIELD_U16T, step_block=256)
+        world.lidar_1081(cfg)
+        occ = world.make_maps(E, size, 2024 + S)
+        arrays = world.make_world(cfg, occ, n_peds=20 if peds else 0, device=dev)
+        for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
+            arrays[key] = sim.scan_threshold(cfg, torch.from_numpy(robots.footprint_array("keti", name)).to(dev))
+        host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "rect_table")}
+        host["field"] = ref.build_dt(occ)
+        g = sim.NavSim(cfg, arrays)
+        r = ref.RefSim(cfg, host)
+        assert np.array_equal(g.reset_obs().cpu().numpy(), r.reset_obs()), "first observation differs"
+        rng = np.random.default_rng(7)
+        crashes = dones = 0
+        t0 = time.time()
+        for t in range(steps):
+            act = np.stack([rng.uniform(0.0, 0.5, E), rng.uniform(-0.64, 0.64, E)], axis=1)
+            if t % 11 == 5:
+                act[:, 0] = 0.5
+                act[:, 1] = 0.0
+            go, gout = g.step(torch.from_numpy(act).to(dev))
+            ro, rout = r.step(act)
+            got = go.cpu().numpy()
+            if not np.array_equal(got, ro):
+                bad = np.argwhere(got != ro)
+                raise AssertionError("S=%d step %d: %d observation entries differ, first at %s" % (S, t, len(bad), bad[:5]))
+            for k in rout:
+                assert np.array_equal(gout[k].cpu().numpy(), rout[k]), "S=%d step %d: %s differs" % (S, t, k)
+            crashes += int(rout["is_crash"].sum())
+            dones += int(rout["done"].sum())
+        if log:
+            log("S=%d: %d steps x %d arenas identical to the oracle (%d crashes, %d episodes ended, %.0f s)"
+                % (S, steps, E, crashes, dones, time.time() - t0))
+        passes.append((S, crashes, dones))
+    return passes

@@ -251,6 +251,49 @@ def test_bench_rejects_mismatched_world_size():
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
 
 
+def test_bench_takes_world_size_from_the_launcher():
+    """`torchrun --nproc-per-node 2 bench.py` without --gpus: the launcher's WORLD_SIZE is the rank count."""
+    import json
+    port = str(29600 + (os.getpid() % 2000))
+    procs = []
+    for r in range(2):
+        e = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                 NAVSIM_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    out = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2
+
+
+def test_bench_strong_scaling_splits_the_configured_totals():
+    """--scaling strong shards the workload's TOTAL (c2: 4096, c4: 16384, c5: 4096) by sharding.shard_range; weak
+    keeps the per-GPU count.  Two gloo ranks; the gathered rows (one per arena, holding its global index) must arrive
+    in global arena order."""
+    import json
+    for wl, total in (("c2", 4096), ("c4", 16384), ("c5", 4096)):
+        r = _bench(["--gpus", "2", "--dry-run", "--scaling", "strong", "--workload", wl], NAVSIM_BENCH_BACKEND="gloo")
+        assert r.returncode == 0, r.stderr
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert out["scaling"] == "strong" and out["envs_total"] == total
+        assert out["shards"] == [[0, total // 2], [total // 2, total // 2]] and out["gather_in_global_order"] is True
+    r = _bench(["--gpus", "2", "--dry-run", "--workload", "c4"], NAVSIM_BENCH_BACKEND="gloo")
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["scaling"] == "weak" and out["shards"] == [[0, 2048], [2048, 2048]] and out["envs_total"] == 4096
+
+
+def test_bench_strong_scaling_ragged_split():
+    """A total that does not divide: the first total % world ranks own one more arena, every arena is owned exactly
+    once, and the padded all_gather of ragged shards still returns the rows in global order."""
+    import json
+    r = _bench(["--gpus", "3", "--dry-run", "--scaling", "strong", "--total-envs", "4099"], NAVSIM_BENCH_BACKEND="gloo")
+    assert r.returncode == 0, r.stderr
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["shards"] == [[0, 1367], [1367, 1366], [2733, 1366]] and out["envs_total"] == 4099
+    assert out["gather_in_global_order"] is True
+
+
 def test_bench_without_gpu_fails_loudly():
     """The product path has no CPU fallback: bench.py refuses to run without a MI355X."""
     import torch
