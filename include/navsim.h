@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NAVSIM_ABI_VERSION 2
+#define NAVSIM_ABI_VERSION 3
 
 /* error codes */
 #define NAVSIM_OK            0
@@ -146,7 +146,10 @@ typedef struct navsim_config {
     int32_t iterations_lo, iterations_hi;           /* 'iterations' (80, 150) */
     int32_t num_humans_lo, num_humans_hi;           /* 'num_humans': navsim_regen rewrites n_peds[e] (clipped to
                                                        max_peds); hi = 0: n_peds[e] is kept */
-    int32_t reserved1;
+    int32_t outdoor_map_size;         /* navsim_regen: side of an OUTDOOR map in cells when it differs from the arena's
+                                         allocation (the reference draws outdoor maps at 400 x 400 and corridor maps at
+                                         1000 x 1000, map_generator.py:108-142): the map occupies cells [0, size)^2 of the
+                                         map_h x map_w arena, the rest is occupied.  0 = map_w */
     double scan_noise_std_lo, scan_noise_std_hi;    /* 'scan_noise_std': navsim_regen rewrites scan_noise_std[e];
                                                        hi < 0: kept */
 
@@ -156,7 +159,9 @@ typedef struct navsim_config {
                                          else 64, 256, 512 or 1024 */
     int32_t ped_split;                /* pedestrian update in its own one-wavefront-per-arena kernel ahead of the
                                          step: 0 = for large batches (>= 3072 arenas), 1 = never, 2 = always */
-    int32_t reserved0;
+    int32_t regen_check_discomfort;   /* navsim_regen: 1 (default) = a robot start whose FIRST scan (no pedestrians, no noise) has a
+                                         beam inside the discomfort zone is dropped and the next start / goal pair of the
+                                         spawn table takes its place, like reset() re-draws the robot (env.py:776-781) */
 } navsim_config;
 
 /* ------------------------------------------------------------------------------------------
@@ -221,7 +226,25 @@ typedef struct navsim_state {
      * kernel does not end on a few stragglers. */
     uint32_t*      arena_cost;
     const int32_t* launch_order;
+
+    /* TESTS ONLY ("draws supplied"): [E, NAVSIM_DRAWS_PER_ARENA] uniforms in [0, 1) that navsim_regen uses INSTEAD of
+     * its hash-keyed ones for the per-episode parameters and the map generators, laid out as NAVSIM_DRAW_* below, so
+     * that the reference's own generators can be replayed on the same draws (tests/golden/make_golden.py reset).
+     * NULL (always, outside those tests) = hash-keyed draws. */
+    const double* regen_draws;
 } navsim_state;
+
+#define NAVSIM_DRAWS_PER_ARENA      464
+#define NAVSIM_DRAW_KIND            0   /* np.random.random() < indoor_ratio             (env.py:295) */
+#define NAVSIM_DRAW_OBSTACLE_NUMBER 1   /* env_param 'obstacle_number', 'int'            (env.py:281-292) */
+#define NAVSIM_DRAW_NUM_HUMANS      2   /* env_param 'num_humans', 'int' */
+#define NAVSIM_DRAW_SCAN_NOISE_STD  3   /* env_param 'scan_noise_std', 'float' */
+#define NAVSIM_DRAW_OBSTACLE_WIDTH  4   /* env_param 'obstacle_width', 'float' */
+#define NAVSIM_DRAW_CORRIDOR_WIDTH  5   /* env_param 'corridor_width', 'int' */
+#define NAVSIM_DRAW_ITERATIONS      6   /* env_param 'iterations', 'int' */
+#define NAVSIM_DRAW_MAP             8   /* the generator's own draws in its own order: create_outdoor_map (x, y) per
+                                           obstacle (map_generator.py:129-131); create_indoor_map (x, y, coin) per
+                                           iteration (map_generator.py:101-106, 61) */
 
 /* What step() returns (env.py:728) with a leading env axis. */
 typedef struct navsim_step_io {
@@ -509,6 +532,18 @@ int navsim_debug_math(int32_t fn, const double* x, const double* x2, double* out
 /* batch_xy_to_ij (env.py:1228-1253) exactly as the scan evaluates it: xy [n,2] float64 in, ij [n,2] int32 out;
  * as_f32 = 1 rounds the inputs to float32 first and divides in float32 (the lidar origin, env.py:386, 419). */
 int navsim_debug_xy_to_ij(const navsim_config* cfg, const double* xy, int32_t as_f32, int32_t* ij, int32_t n, void* stream);
+
+/* The spawn loops' acceptance rules (env.py:366-383, 748-762, 786-793) on SUPPLIED candidates -- the very device
+ * functions navsim_regen's samplers call -- so that tests can compare them with the decisions the reference's own
+ * _sample_start_goal_path / reset() took on the same candidates (tests/golden/golden_reset.npz).
+ * cost [Hc,Wc] uint8 costmap (nonzero = blocked); kind [n]: 0 = the robot's pair, 1 = a pedestrian's; start, goal
+ * [n,2] metres; robot [n,2] the robot's xy for kind 1 (may be NULL); wp_scratch [n, NAVSIM_MAX_WAYPOINTS, 2].
+ * code [n]: 0 kept, 1 start closer than cfg.ped_min_robot_dist to the robot, 2 goal distance outside its interval
+ * (robot: cfg.min_goal_dist < d < cfg.max_goal_dist; pedestrian: d > cfg.ped_min_goal_dist), 3 no path, 4 (robot)
+ * path_distance > 2 |goal - start|. */
+int navsim_debug_spawn_decisions(const navsim_config* cfg, const uint8_t* cost, int32_t Hc, int32_t Wc, int32_t n,
+                                 const int32_t* kind, const double* start, const double* goal, const double* robot,
+                                 double* wp_scratch, int32_t* code, void* stream);
 
 /* ---- measurement hooks (used by profiles/ only; nothing of the hot path calls them) ---------- */
 /* Scattered-read microbenchmark behind DESIGN.md section 6's "a scattered 4-byte read costs a 128-byte fill"

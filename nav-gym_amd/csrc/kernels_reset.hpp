@@ -9,6 +9,21 @@
 __device__ __forceinline__ double rg_u(uint64_t key, uint64_t i) {
     return (double)(nv::mix64(key + i * 0x9E3779B97F4A7C15ULL) >> 11) * (1.0 / 9007199254740992.0);
 }
+// a draw: the supplied one (tests only: navsim_state.regen_draws, NAVSIM_DRAW_* layout) or the hash-keyed one
+__device__ __forceinline__ double rg_t(const double* __restrict__ tape, int slot, uint64_t key, uint64_t i) {
+    return tape ? tape[slot] : rg_u(key, i);
+}
+__device__ __forceinline__ const double* rg_tape(const navsim_state& st, int e) {
+    return st.regen_draws ? st.regen_draws + (size_t)e * NAVSIM_DRAWS_PER_ARENA : nullptr;
+}
+// side of the map an outdoor episode draws (cfg.outdoor_map_size; the reference: 400 inside its 1000-cell arenas)
+__host__ __device__ inline int outdoor_size(const navsim_config& c) {
+    return (c.outdoor_map_size > 0 && c.outdoor_map_size < c.map_w) ? c.outdoor_map_size : c.map_w;
+}
+// side of the live map of regenerated slot b: kind[b] = G > 0 for a corridor map (the whole arena), 0 for an outdoor one
+__device__ __forceinline__ int live_size(const navsim_config& c, const int* __restrict__ kind, int b) {
+    return kind[b] ? c.map_w : outdoor_size(c);
+}
 
 // ordered compaction of the arenas that finished in this step: list[0..count), mask[e]
 __global__ __launch_bounds__(1024) void regen_select_kernel(const uint8_t* __restrict__ done, int E, int cap,
@@ -53,21 +68,25 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
     if (b >= *count) return;
     const int e = list[b], size = c.map_w;
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
+    const double* tape = rg_tape(st, e);
     if (tid == 0) {                 // per-episode env_param draws that are plain state (env.py:281-292, 786, 439)
         const uint64_t pk = nv::hash4(c.seed, genv, ep, 0x50524DULL);
         if (c.num_humans_hi > 0 && c.ped_model != NAVSIM_PED_NONE && st.n_peds) {
-            int n = c.num_humans_lo + (int)(rg_u(pk, 1) * (double)(c.num_humans_hi - c.num_humans_lo + 1));
+            int n = c.num_humans_lo + (int)(rg_t(tape, NAVSIM_DRAW_NUM_HUMANS, pk, 1) * (double)(c.num_humans_hi - c.num_humans_lo + 1));
             st.n_peds[e] = n > c.max_peds ? c.max_peds : n;
         }
         if (c.scan_noise_std_hi >= 0.0 && st.scan_noise_std)
-            st.scan_noise_std[e] = (float)(c.scan_noise_std_lo + (c.scan_noise_std_hi - c.scan_noise_std_lo) * rg_u(pk, 2));
+            st.scan_noise_std[e] = (float)(c.scan_noise_std_lo + (c.scan_noise_std_hi - c.scan_noise_std_lo) *
+                                                                     rg_t(tape, NAVSIM_DRAW_SCAN_NOISE_STD, pk, 2));
     }
-    const bool indoor = c.regen_indoor_ratio > 0.0 && rg_u(nv::hash4(c.seed, genv, ep, 0x4B494E44ULL), 0) < c.regen_indoor_ratio;
+    const bool indoor = c.regen_indoor_ratio > 0.0 &&       // env.py:295
+                        rg_t(tape, NAVSIM_DRAW_KIND, nv::hash4(c.seed, genv, ep, 0x4B494E44ULL), 0) < c.regen_indoor_ratio;
     if (!indoor) { if (tid == 0) kind[b] = 0; return; }                  // block-uniform
     const uint64_t key = nv::hash4(c.seed, genv, ep, 0x494E44ULL);
     uint64_t n = 0;
-    const int r = c.corridor_width_lo + (int)(rg_u(key, n++) * (double)(c.corridor_width_hi - c.corridor_width_lo + 1));
-    const int it = c.iterations_lo + (int)(rg_u(key, n++) * (double)(c.iterations_hi - c.iterations_lo + 1));
+    const int r = c.corridor_width_lo + (int)(rg_t(tape, NAVSIM_DRAW_CORRIDOR_WIDTH, key, n) * (double)(c.corridor_width_hi - c.corridor_width_lo + 1));
+    const int it = c.iterations_lo + (int)(rg_t(tape, NAVSIM_DRAW_ITERATIONS, key, n + 1) * (double)(c.iterations_hi - c.iterations_lo + 1));
+    n += 2;
     int G = size / 10;
     G = G < 2 * r + 8 ? 2 * r + 8 : G;
     G = G > 100 ? 100 : G;
@@ -79,8 +98,9 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
     if (tid == 0) g[(G / 2) * G + G / 2] = 0;
     const int span = G - 2 * r - 3;
     for (int k = 0; k < n_it; ++k) {
-        const int px = r + 2 + (int)(rg_u(key, n) * span), py = r + 2 + (int)(rg_u(key, n + 1) * span);
-        const bool coin = rg_u(key, n + 2) >= 0.5;
+        const int px = r + 2 + (int)(rg_t(tape, NAVSIM_DRAW_MAP + 3 * k, key, n) * span);
+        const int py = r + 2 + (int)(rg_t(tape, NAVSIM_DRAW_MAP + 3 * k + 1, key, n + 1) * span);
+        const bool coin = rg_t(tape, NAVSIM_DRAW_MAP + 3 * k + 2, key, n + 2) >= 0.5;
         n += 3;
         const int nt = k + 1;
         if (tid == 0) best_s = 0xFFFFFFFFu;
@@ -141,50 +161,60 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
         }
         return;
     }
+    // ---- outdoor map: `live` x `live` cells in the corner [0, live)^2 of the arena's size x size array (stored row
+    // y = live - 1 - r of generator row r: np.flipud over the live rows); everything outside is occupied -- behind the
+    // 5-cell border wall no ray and no distance sees it
+    const int live = outdoor_size(c);
+    const double* tape = rg_tape(st, e);
     const uint64_t key = nv::hash4(c.seed, (uint64_t)(c.env_index_base + e), (uint64_t)st.episode[e], 0x4D4150ULL);
-    double w = c.obstacle_width_lo + (c.obstacle_width_hi - c.obstacle_width_lo) * rg_u(key, 0);
+    double w = c.obstacle_width_lo + (c.obstacle_width_hi - c.obstacle_width_lo) * rg_t(tape, NAVSIM_DRAW_OBSTACLE_WIDTH, key, 0);
     const int hw = (int)(10.0 * w);
-    int span = size - 2 * hw - 3;
+    int span = live - 2 * hw - 3;
     span = span < 1 ? 1 : span;
     const int obs_hi = c.obstacle_number_hi > c.obstacle_number ? c.obstacle_number_hi : c.obstacle_number;
-    int n_obs = c.obstacle_number + (int)(rg_u(nv::hash4(c.seed, (uint64_t)(c.env_index_base + e), (uint64_t)st.episode[e], 0x50524DULL), 0) *
+    int n_obs = c.obstacle_number + (int)(rg_t(tape, NAVSIM_DRAW_OBSTACLE_NUMBER,
+                                               nv::hash4(c.seed, (uint64_t)(c.env_index_base + e), (uint64_t)st.episode[e], 0x50524DULL), 0) *
                                           (double)(obs_hi - c.obstacle_number + 1));
     n_obs = n_obs < 64 ? n_obs : 64;
     if (tid < n_obs) {
-        ocx[tid] = hw + 2 + (int)(rg_u(key, 1 + 2 * (uint64_t)tid) * span);
-        ocy[tid] = hw + 2 + (int)(rg_u(key, 2 + 2 * (uint64_t)tid) * span);
+        ocx[tid] = hw + 2 + (int)(rg_t(tape, NAVSIM_DRAW_MAP + 2 * tid, key, 1 + 2 * (uint64_t)tid) * span);
+        ocy[tid] = hw + 2 + (int)(rg_t(tape, NAVSIM_DRAW_MAP + 2 * tid + 1, key, 2 + 2 * (uint64_t)tid) * span);
     }
     __syncthreads();
-    // this workgroup owns rows [r0, r1): background first, then the parts of the obstacle squares inside them
+    // this workgroup owns the STORED rows [y0, y1): background first, then the parts of the obstacle squares inside them
     const int rows = (size + kRegenSlices - 1) / kRegenSlices;
-    const int r0 = blockIdx.y * rows, r1 = (r0 + rows < size) ? r0 + rows : size;
+    const int y0 = blockIdx.y * rows, y1 = (y0 + rows < size) ? y0 + rows : size;
+    auto wall = [&](int y, int x) -> uint32_t {                  // border frame of the live map, occupied outside it
+        const int r = live - 1 - y;
+        return (uint32_t)!(y < live && x < live && r >= 5 && r < live - 5 && x >= 5 && x < live - 5);
+    };
     if ((size & 3) == 0) {                                       // 4 cells per store
         const int wpr = size >> 2;
         uint32_t* occ32 = (uint32_t*)occ;
-        for (int idx = r0 * wpr + tid; idx < r1 * wpr; idx += 256) {
-            int r = idx / wpr, q4 = (idx - r * wpr) * 4;
+        for (int idx = y0 * wpr + tid; idx < y1 * wpr; idx += 256) {
+            const int y = idx / wpr, x4 = (idx - y * wpr) * 4;
             uint32_t wv = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int q = q4 + j;
-                wv |= (uint32_t)(!(r >= 5 && r < size - 5 && q >= 5 && q < size - 5)) << (8 * j);
-            }
-            occ32[(size_t)(size - 1 - r) * wpr + (q4 >> 2)] = wv;
+            for (int j = 0; j < 4; ++j) wv |= wall(y, x4 + j) << (8 * j);
+            occ32[idx] = wv;
         }
     } else {
-        for (int idx = r0 * size + tid; idx < r1 * size; idx += 256) {
-            int r = idx / size, q = idx - r * size;
-            occ[(size_t)(size - 1 - r) * size + q] = !(r >= 5 && r < size - 5 && q >= 5 && q < size - 5);
+        for (int idx = y0 * size + tid; idx < y1 * size; idx += 256) {
+            const int y = idx / size, x = idx - y * size;
+            occ[idx] = (uint8_t)wall(y, x);
         }
     }
     __syncthreads();
     const int side = 2 * hw + 1;
     for (int o = 0; o < n_obs; ++o) {
+        // generator rows cx - hw .. cx + hw (clipped to the live map) are stored rows live - 1 - r
         const int cx = ocx[o], cy = ocy[o];
-        const int ra = (cx - hw > r0) ? cx - hw : r0, rb = (cx + hw < r1 - 1) ? cx + hw : r1 - 1;
-        for (int idx = tid; idx < (rb - ra + 1) * side; idx += 256) {
-            int r = ra + idx / side, q = cy - hw + idx % side;
-            if (q >= 0 && q < size) occ[(size_t)(size - 1 - r) * size + q] = 1;
+        int ya = live - 1 - (cx + hw), yb = live - 1 - (cx - hw);
+        ya = ya < 0 ? 0 : ya; yb = yb > live - 1 ? live - 1 : yb;
+        ya = ya > y0 ? ya : y0; yb = yb < y1 - 1 ? yb : y1 - 1;
+        for (int idx = tid; idx < (yb - ya + 1) * side; idx += 256) {
+            const int y = ya + idx / side, x = cy - hw + idx % side;
+            if (x >= 0 && x < live) occ[(size_t)y * size + x] = 1;
         }
     }
     // the exact field of this band of rows, from the geometry
@@ -193,38 +223,39 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
     const int tpr = (size + 7) >> 3;
     // eight cells per thread at a time, boxes in the outer loop: a box is read from LDS once per eight cells
     constexpr int CH = 8;
-    for (int base = r0 * size; base < r1 * size; base += 256 * CH) {
+    for (int base = y0 * size; base < y1 * size; base += 256 * CH) {
         int rr[CH], qq[CH], d2[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int idx = base + j * 256 + tid;
-            const int r = idx / size, q = idx - r * size;
+            const int y = idx / size, q = idx - y * size;
+            const int r = live - 1 - y;
             rr[j] = r; qq[j] = q;
             int m = r - 4;
-            m = (size - 5 - r) < m ? (size - 5 - r) : m;
+            m = (live - 5 - r) < m ? (live - 5 - r) : m;
             m = (q - 4) < m ? (q - 4) : m;
-            m = (size - 5 - q) < m ? (size - 5 - q) : m;
-            d2[j] = (m > 0) ? m * m : 0;                                        // border frame: m <= 0
+            m = (live - 5 - q) < m ? (live - 5 - q) : m;
+            d2[j] = (m > 0) ? m * m : 0;                                        // border frame and beyond: m <= 0
         }
         for (int o = 0; o < n_obs; ++o) {
-            int x0 = ocx[o] - hw, x1 = ocx[o] + hw, y0 = ocy[o] - hw, y1 = ocy[o] + hw;
-            x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0;                        // boxes are drawn clipped to the map
-            x1 = x1 > size - 1 ? size - 1 : x1; y1 = y1 > size - 1 ? size - 1 : y1;
+            int x0 = ocx[o] - hw, x1 = ocx[o] + hw, yy0 = ocy[o] - hw, yy1 = ocy[o] + hw;
+            x0 = x0 < 0 ? 0 : x0; yy0 = yy0 < 0 ? 0 : yy0;                     // boxes are drawn clipped to the map
+            x1 = x1 > live - 1 ? live - 1 : x1; yy1 = yy1 > live - 1 ? live - 1 : yy1;
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 int dr = x0 - rr[j] > rr[j] - x1 ? x0 - rr[j] : rr[j] - x1;
                 dr = dr < 0 ? 0 : dr;
-                int dq = y0 - qq[j] > qq[j] - y1 ? y0 - qq[j] : qq[j] - y1;
+                int dq = yy0 - qq[j] > qq[j] - yy1 ? yy0 - qq[j] : qq[j] - yy1;
                 dq = dq < 0 ? 0 : dq;
                 const int v = dr * dr + dq * dq;
-                d2[j] = v < d2[j] ? v : d2[j];
+                d2[j] = (d2[j] > 0 && v < d2[j]) ? v : d2[j];
             }
         }
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int idx = base + j * 256 + tid;
-            if (idx >= r1 * size) continue;
-            const int y = size - 1 - rr[j], x = qq[j];                          // the stored orientation (flipud)
+            if (idx >= y1 * size) continue;
+            const int y = idx / size, x = qq[j];                                // the stored orientation (flipud)
             if (c.field_format == NAVSIM_FIELD_F32) {
                 ((float*)fs)[(size_t)y * size + x] = sqrtf((float)d2[j]);
             } else {
@@ -259,24 +290,38 @@ __global__ __launch_bounds__(256) void regen_field_kernel(char* __restrict__ dst
     }
 }
 
+// The acceptance rules of _sample_start_goal_path (env.py:366-383) -- oracle rg_start_ok / rg_goal_ok /
+// rg_robot_path_ok; navsim_debug_spawn_decisions evaluates these very functions on supplied candidates.
+__device__ __forceinline__ bool rg_start_ok(double x, double y, double rx, double ry, double min_robot) {
+    const double ddx = rx - x, ddy = ry - y;
+    return !(sqrt(ddx * ddx + ddy * ddy) < min_robot);                 // env.py:371-373: dropped when dist < 4
+}
+__device__ __forceinline__ bool rg_goal_ok(double sx, double sy, double gx, double gy, double dmin, double dmax) {
+    const double ddx = sx - gx, ddy = sy - gy;
+    const double dist = sqrt(ddx * ddx + ddy * ddy);
+    return dmin < dist && dist < dmax;                                 // env.py:379
+}
+__device__ __forceinline__ bool rg_robot_path_ok(double plen, double sx, double sy, double gx, double gy) {
+    const double ddx = gx - sx, ddy = gy - sy;
+    return !(plen > 2.0 * sqrt(ddx * ddx + ddy * ddy));                // env.py:761
+}
+
+// kind 0: any free cell; 1: a start, dropped when closer than dmin to (rx, ry); 2: a goal of the start (rx, ry).
+// Cells are drawn in the live map [0, size)^2.
 template <typename Field>
-__device__ __forceinline__ void rg_sample(const navsim_config& c, const Field& f, uint64_t key, uint64_t& n,
-                                          double clr, bool use_ref, double rx, double ry, double dmin, double dmax,
+__device__ __forceinline__ void rg_sample(const navsim_config& c, const Field& f, int size, uint64_t key, uint64_t& n,
+                                          double clr, int kind, double rx, double ry, double dmin, double dmax,
                                           double& x, double& y) {
-    const int W = c.map_w, H = c.map_h;
     int bi = 0, bj = 0;
     float bd = -1.0f;
     for (int t = 0; t < 64; ++t) {
-        int i = (int)(rg_u(key, n++) * W), j = (int)(rg_u(key, n++) * H);
+        int i = (int)(rg_u(key, n++) * size), j = (int)(rg_u(key, n++) * size);
         float d = f.at(i, j);
         double px = ((double)i + 0.5) * c.resolution + c.origin_x;
         double py = ((double)j + 0.5) * c.resolution + c.origin_y;
         bool ok = (double)d >= clr;
-        if (ok && use_ref) {
-            double ddx = px - rx, ddy = py - ry;
-            double dist = sqrt(ddx * ddx + ddy * ddy);
-            ok = dist > dmin && dist < dmax;
-        }
+        if (ok && kind == 1) ok = rg_start_ok(px, py, rx, ry, dmin);
+        if (ok && kind == 2) ok = rg_goal_ok(rx, ry, px, py, dmin, dmax);
         if (ok) { x = px; y = py; return; }
         if (d > bd) { bd = d; bi = i; bj = j; }
     }
@@ -284,15 +329,57 @@ __device__ __forceinline__ void rg_sample(const navsim_config& c, const Field& f
     y = ((double)bj + 0.5) * c.resolution + c.origin_y;
 }
 
+// env.py:776-781: reset() re-draws the robot when its first scan -- taken before any pedestrian exists -- has a beam
+// inside the discomfort zone.  All threads of the workgroup scan the static map from `pose` (the plain march of
+// calc_range through Field::at, full beam directions, march limited like the step's) and agree on the answer.
+// No scan noise here (oracle spawn_in_discomfort: build-defined like every random number).
+template <typename Field>
+__device__ __forceinline__ bool spawn_in_discomfort(const navsim_config& c, const navsim_state& st, const Field& f,
+                                                    const double* pose) {
+    const int B = c.n_beams, H = c.map_h, W = c.map_w;
+    const float lx = (float)pose[0], ly = (float)pose[1], lth = (float)pose[2];      // env.py:386
+    int i0, j0;
+    nv::xy_to_ij_f32(lx, ly, c, i0, j0);                                             // env.py:419
+    const float x0 = (float)i0, y0 = (float)j0;
+    const float max_range = march_limit(H, W, c.range_max, c.resolution);
+    const float res = (float)c.resolution, rmax = (float)c.range_max;
+    const double step = nv::linspace_step(c);
+    int bad = 0;
+    for (int k = (int)threadIdx.x; k < B; k += (int)blockDim.x) {
+        float dx, dy;
+        nv::beam_dir((float)(nv::linspace_k(c, k, step) + (double)lth), dx, dy);
+        float t = 0.0f, r = max_range;
+        while (t < max_range) {
+            const int px = (int)(x0 + dx * t), py = (int)(y0 + dy * t);
+            if (px >= W || px < 0 || py < 0 || py >= H) break;
+            const float d = f.at(px, py);
+            if (d <= 0.0f) {
+                const float xd = (float)px - x0, yd = (float)py - y0;
+                r = sqrtf(xd * xd + yd * yd);
+                break;
+            }
+            const float stp = (c.march_rule == NAVSIM_MARCH_F32) ? d * 0.999f : (float)((double)d * 0.999);
+            t += (stp > 1.0f) ? stp : 1.0f;
+        }
+        r = r * res;
+        r = r < 0.0f ? 0.0f : r;
+        r = r > rmax ? rmax : r;
+        bad |= (r < st.scan_discomfort[k]);
+    }
+    return __syncthreads_or(bad) != 0;
+}
+
 // install the new field, draw the start / goal table, the robot and the pedestrians
 template <typename Field>
 __global__ __launch_bounds__(256) void regen_commit_kernel(navsim_config c, navsim_state st,
                                                            const int* __restrict__ count, const int* __restrict__ list,
-                                                           const char* __restrict__ field_scratch, size_t field_bytes) {
+                                                           const char* __restrict__ field_scratch, size_t field_bytes,
+                                                           const int* __restrict__ kind) {
     __shared__ double robot_xy[2];
     const int b = blockIdx.x;
     if (b >= *count) return;
     const int e = list[b], tid = threadIdx.x;
+    const int size = live_size(c, kind, b);
     const int N = c.max_peds, K = c.n_spawn, P = NAVSIM_MAX_WAYPOINTS;
     const Field f(st.field, st.field_overflow, e, c.map_h, c.map_w);
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
@@ -302,16 +389,21 @@ __global__ __launch_bounds__(256) void regen_commit_kernel(navsim_config c, navs
     for (int k = tid; k < K; k += 256) {
         uint64_t key = nv::hash4(c.seed, genv, ep, 0x53504157ULL + (uint64_t)k), n = 0;
         double x, y, gx, gy;
-        rg_sample(c, f, key, n, clr, false, 0, 0, 0, 0, x, y);
+        rg_sample(c, f, size, key, n, clr, 0, 0, 0, 0, 0, x, y);
         double th = nv::kTwoPi * rg_u(key, n++);
-        rg_sample(c, f, key, n, clr, true, x, y, c.min_goal_dist, c.max_goal_dist, gx, gy);
+        rg_sample(c, f, size, key, n, clr, 2, x, y, c.min_goal_dist, c.max_goal_dist, gx, gy);
         sp[3 * k] = x; sp[3 * k + 1] = y; sp[3 * k + 2] = th;
         sg[2 * k] = gx; sg[2 * k + 1] = gy;
     }
     __threadfence_block();
     __syncthreads();
+    int idx = (int)(nv::hash4(c.seed, genv, ep, 0x5eedULL) % (uint64_t)K);
+    if (c.regen_check_discomfort)                // env.py:776-781: first table entry from idx on whose first scan is clear
+        for (int s_ = 0; s_ < K; ++s_) {         // (block-uniform loop)
+            const int j = (idx + s_) % K;
+            if (!spawn_in_discomfort(c, st, f, sp + 3 * j)) { idx = j; break; }
+        }
     if (tid == 0) {
-        int idx = (int)(nv::hash4(c.seed, genv, ep, 0x5eedULL) % (uint64_t)K);
         double* rp = st.robot_pose + 3 * (size_t)e;
         rp[0] = sp[3 * idx]; rp[1] = sp[3 * idx + 1]; rp[2] = sp[3 * idx + 2];
         st.robot_goal[2 * e] = sg[2 * idx]; st.robot_goal[2 * e + 1] = sg[2 * idx + 1];
@@ -325,9 +417,9 @@ __global__ __launch_bounds__(256) void regen_commit_kernel(navsim_config c, navs
         size_t q = (size_t)e * N + i;
         uint64_t key = nv::hash4(c.seed, genv, ep, 0x504544ULL + (uint64_t)i), m = 0;
         double x, y, gx, gy;
-        rg_sample(c, f, key, m, pclr, true, robot_xy[0], robot_xy[1], c.ped_min_robot_dist, 1.0e300, x, y);
+        rg_sample(c, f, size, key, m, pclr, 1, robot_xy[0], robot_xy[1], c.ped_min_robot_dist, 0, x, y);
         double th = nv::kTwoPi * rg_u(key, m++);
-        rg_sample(c, f, key, m, pclr, true, x, y, c.ped_min_goal_dist, 1.0e300, gx, gy);
+        rg_sample(c, f, size, key, m, pclr, 2, x, y, c.ped_min_goal_dist, 1.0e300, gx, gy);
         st.ped_pose[q * 3] = x; st.ped_pose[q * 3 + 1] = y; st.ped_pose[q * 3 + 2] = th;
         st.ped_vel[q * 2] = 0.0; st.ped_vel[q * 2 + 1] = 0.0;
         ((double*)st.ped_v_pref)[q] = c.v_pref_lo + (c.v_pref_hi - c.v_pref_lo) * rg_u(key, m++);
@@ -549,6 +641,7 @@ struct RegenPlanWs {
     double* qstart;       // [M, Q, 2]
     double* qgoal;        // [M, Q, 2]
     double* qwp;          // [M, Q, P, 2]   robot stage only (pedestrian paths go straight into the state)
+    const int* kind;      // [M] regen_indoor_kernel's map kind (live map size)
     int32_t* qnwp;        // [M, Q]
     double* qlen;         // [M, Q]
     uint8_t* active;      // [M, Q]
@@ -557,19 +650,16 @@ struct RegenPlanWs {
     int Q;
 };
 
-__device__ __forceinline__ void rgp_cell(const navsim_config& c, const uint8_t* __restrict__ cost, int Hc, int Wc,
-                                         double res_c, uint64_t key, uint64_t& n, bool use_ref, double rx, double ry,
-                                         double dmin, double dmax, double& x, double& y) {
+__device__ __forceinline__ void rgp_cell(const navsim_config& c, const uint8_t* __restrict__ cost, int Wc, int live_w,
+                                         int live_h, double res_c, uint64_t key, uint64_t& n, int kind, double rx,
+                                         double ry, double dmin, double dmax, double& x, double& y) {
     for (int t = 0; t < 16; ++t) {
-        int I = (int)(rg_u(key, n++) * Wc), J = (int)(rg_u(key, n++) * Hc);
+        int I = (int)(rg_u(key, n++) * live_w), J = (int)(rg_u(key, n++) * live_h);
         x = ((double)I + 0.5) * res_c + c.origin_x;
         y = ((double)J + 0.5) * res_c + c.origin_y;
         if (cost[(size_t)J * Wc + I]) continue;
-        if (use_ref) {
-            double ddx = x - rx, ddy = y - ry;
-            double dist = sqrt(ddx * ddx + ddy * ddy);
-            if (!(dist > dmin && dist < dmax)) continue;
-        }
+        if (kind == 1 && !rg_start_ok(x, y, rx, ry, dmin)) continue;
+        if (kind == 2 && !rg_goal_ok(rx, ry, x, y, dmin, dmax)) continue;
         return;
     }
 }
@@ -588,6 +678,7 @@ __global__ __launch_bounds__(256) void regen_install_kernel(navsim_config c, nav
 
 // robot stage, one round: accept what the previous round planned, then draw a new candidate for every
 // slot that is still open (round == 4: accept only, pick the robot, initialise the pedestrians)
+template <typename Field>
 __global__ __launch_bounds__(256) void regen_robot_round_kernel(navsim_config c, navsim_state st,
                                                                 const int* __restrict__ count,
                                                                 const int* __restrict__ list, RegenPlanWs ws, int round) {
@@ -596,6 +687,7 @@ __global__ __launch_bounds__(256) void regen_robot_round_kernel(navsim_config c,
     const int e = list[b], tid = threadIdx.x;
     const int N = c.max_peds, K = c.n_spawn, Q = ws.Q;
     const int Hc = c.map_h / 5, Wc = c.map_w / 5;
+    const int live_c = live_size(c, ws.kind, b) / 5;         // candidates are cells of the live map's costmap
     const double res_c = c.resolution * 5.0;
     const uint8_t* cost = ws.cost + (size_t)(ws.cost_by_arena ? e : b) * Hc * Wc;
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
@@ -606,15 +698,14 @@ __global__ __launch_bounds__(256) void regen_robot_round_kernel(navsim_config c,
         if (k >= K) { ws.active[q] = 0; continue; }
         uint8_t& res = ws.res_robot[(size_t)b * K + k];
         if (round > 0 && !res) {
-            double ddx = sg[2 * k] - sp[3 * k], ddy = sg[2 * k + 1] - sp[3 * k + 1];
-            res = ws.qnwp[q] > 0 && ws.qlen[q] <= 2.0 * sqrt(ddx * ddx + ddy * ddy);      // env.py:761
+            res = ws.qnwp[q] > 0 && rg_robot_path_ok(ws.qlen[q], sp[3 * k], sp[3 * k + 1], sg[2 * k], sg[2 * k + 1]);
         }
         ws.active[q] = 0;
         if (res || round >= 4) continue;
         uint64_t key = nv::hash4(c.seed, genv, ep, 0x52504C00ULL + (uint64_t)round * 256 + (uint64_t)k), n = 0;
         double x, y, gx, gy;
-        rgp_cell(c, cost, Hc, Wc, res_c, key, n, false, 0, 0, 0, 0, x, y);
-        rgp_cell(c, cost, Hc, Wc, res_c, key, n, true, x, y, c.min_goal_dist, c.max_goal_dist, gx, gy);
+        rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, n, 0, 0, 0, 0, 0, x, y);
+        rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, n, 2, x, y, c.min_goal_dist, c.max_goal_dist, gx, gy);
         sp[3 * k] = x; sp[3 * k + 1] = y; sp[3 * k + 2] = nv::kTwoPi * rg_u(key, n++);
         sg[2 * k] = gx; sg[2 * k + 1] = gy;
         ws.qstart[2 * q] = x; ws.qstart[2 * q + 1] = y;
@@ -624,11 +715,21 @@ __global__ __launch_bounds__(256) void regen_robot_round_kernel(navsim_config c,
     if (round < 4) return;
     __threadfence_block();
     __syncthreads();
-    if (tid == 0) {
-        int idx = (int)(nv::hash4(c.seed, genv, ep, 0x5eedULL) % (uint64_t)K);
+    int idx = (int)(nv::hash4(c.seed, genv, ep, 0x5eedULL) % (uint64_t)K);
+    {   // first resolved pair from idx on (cyclic) whose first scan is outside the discomfort zone (env.py:776-781);
+        // none: the first resolved one; none resolved: idx.  Block-uniform control flow.
+        const Field f(st.field, st.field_overflow, e, c.map_h, c.map_w);
         const uint8_t* res = ws.res_robot + (size_t)b * K;
-        if (!res[idx])
-            for (int s_ = 1; s_ < K; ++s_) { int j = (idx + s_) % K; if (res[j]) { idx = j; break; } }
+        int first_res = -1, pick = -1;
+        for (int s_ = 0; s_ < K && pick < 0; ++s_) {
+            const int j = (idx + s_) % K;
+            if (!res[j]) continue;
+            if (first_res < 0) first_res = j;
+            if (!c.regen_check_discomfort || !spawn_in_discomfort(c, st, f, sp + 3 * j)) pick = j;
+        }
+        idx = pick >= 0 ? pick : (first_res >= 0 ? first_res : idx);
+    }
+    if (tid == 0) {
         double* rp = st.robot_pose + 3 * (size_t)e;
         rp[0] = sp[3 * idx]; rp[1] = sp[3 * idx + 1]; rp[2] = sp[3 * idx + 2];
         st.robot_goal[2 * e] = sg[2 * idx]; st.robot_goal[2 * e + 1] = sg[2 * idx + 1];
@@ -654,6 +755,7 @@ __global__ __launch_bounds__(256) void regen_ped_round_kernel(navsim_config c, n
     const int e = list[b], tid = threadIdx.x;
     const int N = c.max_peds, Q = ws.Q, P = NAVSIM_MAX_WAYPOINTS;
     const int Hc = c.map_h / 5, Wc = c.map_w / 5;
+    const int live_c = live_size(c, ws.kind, b) / 5;
     const double res_c = c.resolution * 5.0;
     const uint8_t* cost = ws.cost + (size_t)(ws.cost_by_arena ? e : b) * Hc * Wc;
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
@@ -670,8 +772,8 @@ __global__ __launch_bounds__(256) void regen_ped_round_kernel(navsim_config c, n
         if (res || round >= 4) continue;
         uint64_t key = nv::hash4(c.seed, genv, ep, 0x50504C00ULL + (uint64_t)round * 256 + (uint64_t)i), nn = 0;
         double x, y, gx, gy;
-        rgp_cell(c, cost, Hc, Wc, res_c, key, nn, true, rx, ry, c.ped_min_robot_dist, 1.0e300, x, y);
-        rgp_cell(c, cost, Hc, Wc, res_c, key, nn, true, x, y, c.ped_min_goal_dist, 1.0e300, gx, gy);
+        rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, nn, 1, rx, ry, c.ped_min_robot_dist, 0, x, y);
+        rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, nn, 2, x, y, c.ped_min_goal_dist, 1.0e300, gx, gy);
         st.ped_pose[pq * 3] = x; st.ped_pose[pq * 3 + 1] = y;
         double* w = st.ped_waypoints + (pq * P) * 2;
         w[0] = gx; w[1] = gy;
@@ -758,7 +860,7 @@ __global__ __launch_bounds__(256) void replan_kernel(navsim_config c, navsim_sta
         if (tid == 0) {
             uint64_t key = nv::hash4(c.seed, genv, when, 0x52504E00ULL + (uint64_t)round * 256 + (uint64_t)i), m = 0;
             double gx, gy;
-            rgp_cell(c, cost, Hc, Wc, res_c, key, m, true, px, py, c.ped_min_goal_dist, 1.0e300, gx, gy);
+            rgp_cell(c, cost, Wc, Wc, Hc, res_c, key, m, 2, px, py, c.ped_min_goal_dist, 1.0e300, gx, gy);
             goal_s[0] = gx; goal_s[1] = gy;
         }
         __syncthreads();
@@ -771,4 +873,27 @@ __global__ __launch_bounds__(256) void replan_kernel(navsim_config c, navsim_sta
         }
         __syncthreads();                                 // nwp_s is rewritten by the next round
     }
+}
+
+// --------------------------------------------------------------------------------------------
+// navsim_debug_spawn_decisions (tests only; oracle navsim_spawn_decisions_cpu): the spawn loops' acceptance rules
+// on SUPPLIED candidates, one workgroup per candidate, through the very functions the samplers above call.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spawn_decisions_kernel(navsim_config c, const uint8_t* __restrict__ cost, int Hc, int Wc,
+                                                              const int32_t* __restrict__ kind, const double* __restrict__ start,
+                                                              const double* __restrict__ goal, const double* __restrict__ robot,
+                                                              double* __restrict__ wp_scratch, int32_t* __restrict__ code) {
+    __shared__ int32_t nwp_s;
+    __shared__ double plen_s;
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const double sx = start[2 * m], sy = start[2 * m + 1], gx = goal[2 * m], gy = goal[2 * m + 1];
+    const bool ped = kind[m] == 1;
+    int rc = 0;
+    if (ped && robot && !rg_start_ok(sx, sy, robot[2 * m], robot[2 * m + 1], c.ped_min_robot_dist)) rc = 1;
+    else if (!rg_goal_ok(sx, sy, gx, gy, ped ? c.ped_min_goal_dist : c.min_goal_dist, ped ? 1.0e300 : c.max_goal_dist)) rc = 2;
+    if (rc) { if (tid == 0) code[m] = rc; return; }                      // uniform per workgroup
+    plan_query(cost, Hc, Wc, c.resolution * 5.0, c.origin_x, c.origin_y, sx, sy, gx, gy, ped ? 2.0 : 5.0,
+               NAVSIM_MAX_WAYPOINTS, wp_scratch + (size_t)m * NAVSIM_MAX_WAYPOINTS * 2, &nwp_s, nullptr, &plen_s);
+    __syncthreads();
+    if (tid == 0) code[m] = nwp_s <= 0 ? 3 : ((!ped && !rg_robot_path_ok(plen_s, sx, sy, gx, gy)) ? 4 : 0);
 }

@@ -288,6 +288,7 @@ int navsim_default_config(navsim_config* c) {
     c->num_humans_lo = 0; c->num_humans_hi = 0;              // 0: navsim_regen keeps n_peds
     c->scan_noise_std_lo = 0.0; c->scan_noise_std_hi = -1.0; // < 0: navsim_regen keeps scan_noise_std
     c->march_rule = NAVSIM_MARCH_F64;
+    c->regen_check_discomfort = 1;          // env.py:776-781
     c->step_block = 0;
     c->ped_split = 0;
     c->seed = 1234;
@@ -665,6 +666,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         auto take = [&](size_t bytes) { off = (off + 255) & ~(size_t)255; char* p = w + off; off += bytes; return p; };
         RegenPlanWs ws;
         ws.Q = Q;
+        ws.kind = kind;
         ws.cost = (uint8_t*)take((size_t)M * cc);
         ws.cost_by_arena = st->costmap != nullptr;
         if (st->costmap) ws.cost = st->costmap;
@@ -681,7 +683,10 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
                                                                       st->costmap ? list : nullptr);
         regen_install_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes, ws);
         for (int round = 0; round <= 4; ++round) {
-            regen_robot_round_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, ws, round);
+            if (c->field_format == NAVSIM_FIELD_F32)
+                regen_robot_round_kernel<FieldF32><<<M, 256, 0, s>>>(*c, *st, count, list, ws, round);
+            else
+                regen_robot_round_kernel<FieldU16T><<<M, 256, 0, s>>>(*c, *st, count, list, ws, round);
             if (round < 4) regen_plan_kernel<<<M * Q, 256, lds, s>>>(*c, *st, count, list, ws, 0);
         }
         if (c->ped_model != NAVSIM_PED_NONE && c->max_peds > 0)
@@ -694,9 +699,9 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     }
     if (!c->regen_plan) {
         if (c->field_format == NAVSIM_FIELD_F32)
-            regen_commit_kernel<FieldF32><<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes);
+            regen_commit_kernel<FieldF32><<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes, kind);
         else
-            regen_commit_kernel<FieldU16T><<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes);
+            regen_commit_kernel<FieldU16T><<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes, kind);
     }
     if (launch_status() != NAVSIM_OK) return NAVSIM_E_LAUNCH;
     // first observation of the new episodes; the other arenas keep the row the step just wrote
@@ -881,6 +886,20 @@ int navsim_debug_xy_to_ij(const navsim_config* c, const double* xy, int32_t as_f
 
 // text of the HIP error behind the last NAVSIM_E_LAUNCH on this thread
 const char* navsim_last_hip_error(void) { return hipGetErrorString(g_last_hip_error); }
+
+// tests only: the spawn loops' acceptance rules on supplied candidates (include/navsim.h)
+int navsim_debug_spawn_decisions(const navsim_config* c, const uint8_t* cost, int32_t Hc, int32_t Wc, int32_t n,
+                                 const int32_t* kind, const double* start, const double* goal, const double* robot,
+                                 double* wp_scratch, int32_t* code, void* stream) {
+    (void)hipGetLastError();
+    if (!c || !cost || !kind || !start || !goal || !wp_scratch || !code || n < 0 || Hc < 1 || Wc < 1) return NAVSIM_E_ARG;
+    if (n == 0) return NAVSIM_OK;
+    if (!plan_fits(Hc, Wc) || allow_lds((const void*)spawn_decisions_kernel, plan_lds(Hc, Wc)) != NAVSIM_OK)
+        return NAVSIM_E_UNSUPPORTED;
+    spawn_decisions_kernel<<<n, 256, plan_lds(Hc, Wc), (hipStream_t)stream>>>(*c, cost, Hc, Wc, kind, start, goal, robot,
+                                                                            wp_scratch, code);
+    return launch_status();
+}
 
 // microbenchmark hook, see gather_probe_kernel
 int navsim_debug_gather(const float* x, uint64_t n_words, int32_t mode, int32_t iters, int32_t n_threads,

@@ -6,7 +6,7 @@ Field order and types must match include/navsim.h exactly; tests/test_abi.py com
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK = 0
 E_ARG = -1
@@ -101,13 +101,13 @@ class NavsimConfig(C.Structure):
         ("iterations_hi", C.c_int32),
         ("num_humans_lo", C.c_int32),
         ("num_humans_hi", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("outdoor_map_size", C.c_int32),
         ("scan_noise_std_lo", C.c_double),
         ("scan_noise_std_hi", C.c_double),
         ("march_rule", C.c_int32),
         ("step_block", C.c_int32),
         ("ped_split", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("regen_check_discomfort", C.c_int32),
     ]
 
     def copy(self):
@@ -125,7 +125,7 @@ class NavsimState(C.Structure):
         "robot_pose", "robot_goal", "prev_action", "prev_pose", "n_hist", "episode", "steps",
         "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist", "ped_v_pref", "ped_has_legs",
         "ped_waypoints", "ped_n_waypoints", "ped_cmd",
-        "spawn_pose", "spawn_goal", "costmap", "arena_cost", "launch_order",
+        "spawn_pose", "spawn_goal", "costmap", "arena_cost", "launch_order", "regen_draws",
     )]
 
 
@@ -205,6 +205,7 @@ STATE_LAYOUT = {
     "costmap": ("uint8", ("E", "Hc", "Wc")),
     "arena_cost": ("int32", ("E",)),
     "launch_order": ("int32", ("E",)),
+    "regen_draws": ("float64", ("E", 464)),         # tests only: draws supplied (NAVSIM_DRAW_* layout)
 }
 
 IO_LAYOUT = {
@@ -305,5 +306,5 @@ EXPORTS = (
     "navsim_crowd_check", "navsim_crowd_angular_map", "navsim_crowd_local_map", "navsim_crowd_orca", "navsim_crowd_agent_step",
     "navsim_step", "navsim_reset_obs", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math", "navsim_debug_xy_to_ij",
-    "navsim_debug_gather", "navsim_debug_set_stamps",
+    "navsim_debug_gather", "navsim_debug_set_stamps", "navsim_debug_spawn_decisions",
 )

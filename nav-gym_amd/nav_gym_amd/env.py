@@ -125,6 +125,12 @@ class NavGymEnv(object):
         self.max_goal_dist = max_goal_dist
         self.env_param_range = env_param_range
         self.num_envs = int(num_envs)
+        # map_size="reference": the reference's own two sizes (map_generator.py:108-142) -- every arena is allocated at
+        # 1000 x 1000 cells, a corridor episode fills it, an outdoor episode draws its 400 x 400 map in the corner
+        # [0, 400)^2 (the rest is occupied: nothing behind the border wall is ever seen).  An integer: one size for both.
+        self.outdoor_map_size = 0
+        if map_size == "reference":
+            map_size, self.outdoor_map_size = 1000, 400
         self.map_size = int(map_size)
         self.device = device
         self.seed_value = int(seed)
@@ -157,7 +163,8 @@ class NavGymEnv(object):
         # (env.py:295), and the per-episode draws of env_param_range (env.py:281-292)
         cfg.regen_plan = int(self.plan_paths)
         cfg.regen_indoor_ratio = float(indoor_ratio)
-        room = self.map_size * cfg.resolution
+        cfg.outdoor_map_size = int(self.outdoor_map_size)
+        room = (self.outdoor_map_size or self.map_size) * cfg.resolution
         cfg.min_goal_dist = float(min(min_goal_dist, 0.4 * room))
         cfg.max_goal_dist = float(min(max_goal_dist, 0.8 * room))
         cfg.v_pref_lo, cfg.v_pref_hi = float(human_v_pref_range[0]), float(human_v_pref_range[1])
@@ -254,8 +261,12 @@ class NavGymEnv(object):
             self.sim.t["policy_prev_actions"].zero_()           # env.py:739
         self._episode_batch += 1
         self.sim.regenerate_all(new_episode=not first)
-        self.map_info = {"data": (self.sim.occupancy(0).astype(np.int8) * 100), "origin": (cfg.origin_x, cfg.origin_y),
-                         "resolution": cfg.resolution, "width": self.map_size, "height": self.map_size}
+        occ0 = self.sim.occupancy(0)
+        live = self.map_size
+        if self.outdoor_map_size and occ0[self.outdoor_map_size:, :].all() and occ0[:, self.outdoor_map_size:].all():
+            live = self.outdoor_map_size                  # arena 0 drew an outdoor map: the reference's 400 x 400 array
+        self.map_info = {"data": (occ0[:live, :live].astype(np.int8) * 100), "origin": (cfg.origin_x, cfg.origin_y),
+                         "resolution": cfg.resolution, "width": live, "height": live}
         n0 = int(self.sim.t["n_peds"][0]) if "n_peds" in self.sim.t else 0
         self.humans = [_AgentView(self, "human", i) for i in range(n0)]
         return self._obs_dict()

@@ -282,6 +282,28 @@ def debug_xy_to_ij(cfg, xy, as_f32):
     return out
 
 
+def debug_spawn_decisions(cfg, cost, kind, start, goal, robot=None):
+    """navsim_debug_spawn_decisions: the spawn loops' acceptance rules on supplied candidates (tests only).
+    cost uint8 CUDA [Hc,Wc]; kind int32 [n]; start / goal / robot float64 [n,2] -> int32 codes [n]."""
+    torch = require_gpu()
+    dev = cost.device
+    cost = cost.to(torch.uint8).contiguous()
+    Hc, Wc = cost.shape
+    kind = torch.as_tensor(kind).to(device=dev, dtype=torch.int32).contiguous()
+    n = kind.shape[0]
+    f64 = lambda a: None if a is None else torch.as_tensor(a).to(device=dev, dtype=torch.float64).contiguous().reshape(n, 2)
+    start, goal, robot = f64(start), f64(goal), f64(robot)
+    ws = torch.zeros((n, abi.MAX_WAYPOINTS, 2), dtype=torch.float64, device=dev)
+    code = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    L = load()
+    L.navsim_debug_spawn_decisions.argtypes = [C.POINTER(abi.NavsimConfig), C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p]
+    check(L.navsim_debug_spawn_decisions(C.byref(cfg), _ptr(cost), Hc, Wc, n, _ptr(kind), _ptr(start), _ptr(goal),
+                                         _ptr(robot), _ptr(ws), _ptr(code), _stream()), "navsim_debug_spawn_decisions")
+    return code
+
+
 def debug_math(fn, x, x2=None):
     torch = require_gpu()
     out = torch.empty_like(x)

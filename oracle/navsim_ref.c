@@ -99,6 +99,7 @@ int navsim_default_config_cpu(navsim_config* c) {
     c->iterations_lo = 80; c->iterations_hi = 150;
     c->num_humans_lo = 0; c->num_humans_hi = 0;
     c->scan_noise_std_lo = 0.0; c->scan_noise_std_hi = -1.0;
+    c->regen_check_discomfort = 1;          /* env.py:776-781 */
     c->seed = 1234;
     return NAVSIM_OK;
 }
@@ -583,6 +584,18 @@ static void robot_scan(const navsim_config* c, const navsim_state* st, int e, in
     }
 }
 
+/* env.py:776-781: reset() re-draws the robot when its first scan -- taken before any pedestrian exists -- has a beam
+ * inside the discomfort zone.  (The reference's check scan carries the episode's scan noise; the oracle has no noise
+ * generator and the device adds none here: BUILD-DEFINED, like every random number.) */
+static int spawn_in_discomfort(const navsim_config* c, const navsim_state* st, int e, const double* pose) {
+    float* ranges = (float*)malloc(sizeof(float) * (size_t)c->n_beams);
+    robot_scan(c, st, e, 0, pose, ranges);
+    int bad = 0;
+    for (int k = 0; k < c->n_beams && !bad; ++k) bad = ranges[k] < st->scan_discomfort[k];
+    free(ranges);
+    return bad;
+}
+
 /* env.py:685-693: pedestrian scans (human lidar, robot + other pedestrians as polygons, no legs) */
 int navsim_ped_scans_cpu(const navsim_config* c, const navsim_state* st, float* out) {
     if (!c || !st || !out || c->ped_model == NAVSIM_PED_NONE) return NAVSIM_E_ARG;
@@ -1039,28 +1052,41 @@ static inline double rg_u(uint64_t key, uint64_t i) {
     return (double)(nvr_mix64(key + i * 0x9E3779B97F4A7C15ULL) >> 11) * (1.0 / 9007199254740992.0);
 }
 
-static void regen_map(const navsim_config* c, uint64_t genv, uint64_t ep, uint8_t* occ) {
-    const int size = c->map_w;
+/* a draw: the supplied one (tests only, navsim_state.regen_draws, NAVSIM_DRAW_* layout) or the hash-keyed one */
+static inline double rg_t(const double* tape, int slot, uint64_t key, uint64_t i) {
+    return tape ? tape[slot] : rg_u(key, i);
+}
+/* side of the map an outdoor episode draws (cfg.outdoor_map_size; the reference: 400 inside its 1000-cell arenas) */
+static inline int outdoor_size(const navsim_config* c) {
+    return (c->outdoor_map_size > 0 && c->outdoor_map_size < c->map_w) ? c->outdoor_map_size : c->map_w;
+}
+
+/* create_outdoor_map (map_generator.py:126-143) at size x size cells in the corner [0, size)^2 of the arena's
+ * map_w x map_w array (everything outside is occupied: behind the 5-cell border wall no ray and no distance sees it) */
+static void regen_map(const navsim_config* c, uint64_t genv, uint64_t ep, uint8_t* occ, const double* tape) {
+    const int size = outdoor_size(c), A = c->map_w;
     const uint64_t key = nvr_hash4(c->seed, genv, ep, 0x4D4150ULL);
     uint64_t n = 0;
-    double w = c->obstacle_width_lo + (c->obstacle_width_hi - c->obstacle_width_lo) * rg_u(key, n++);
-    int hw = (int)(10.0 * w);                                              /* map_generator.py:134 */
+    double w = c->obstacle_width_lo + (c->obstacle_width_hi - c->obstacle_width_lo) * rg_t(tape, NAVSIM_DRAW_OBSTACLE_WIDTH, key, n++);
+    int hw = (int)(10.0 * w);                                              /* map_generator.py:127 */
+    if (size < A) memset(occ, 1, (size_t)A * A);
     for (int r = 0; r < size; ++r)
         for (int q = 0; q < size; ++q)
-            occ[(size_t)(size - 1 - r) * size + q] = !(r >= 5 && r < size - 5 && q >= 5 && q < size - 5);
+            occ[(size_t)(size - 1 - r) * A + q] = !(r >= 5 && r < size - 5 && q >= 5 && q < size - 5);
     int span = size - 2 * hw - 3;                                          /* range(hw+2, size-hw-1) */
     if (span < 1) span = 1;
     /* env_param['obstacle_number'] (env.py:281-292): uniform over lo..hi inclusive, its own key */
     const int obs_hi = c->obstacle_number_hi > c->obstacle_number ? c->obstacle_number_hi : c->obstacle_number;
-    int n_obs = c->obstacle_number + (int)(rg_u(nvr_hash4(c->seed, genv, ep, 0x50524DULL), 0) *
+    int n_obs = c->obstacle_number + (int)(rg_t(tape, NAVSIM_DRAW_OBSTACLE_NUMBER, nvr_hash4(c->seed, genv, ep, 0x50524DULL), 0) *
                                            (double)(obs_hi - c->obstacle_number + 1));
     if (n_obs > 64) n_obs = 64;
     for (int o = 0; o < n_obs; ++o) {
-        int cx = hw + 2 + (int)(rg_u(key, n++) * span);
-        int cy = hw + 2 + (int)(rg_u(key, n++) * span);
+        int cx = hw + 2 + (int)(rg_t(tape, NAVSIM_DRAW_MAP + 2 * o, key, n) * span);
+        int cy = hw + 2 + (int)(rg_t(tape, NAVSIM_DRAW_MAP + 2 * o + 1, key, n + 1) * span);
+        n += 2;
         for (int r = cx - hw; r <= cx + hw; ++r)
             for (int q = cy - hw; q <= cy + hw; ++q)
-                if (r >= 0 && r < size && q >= 0 && q < size) occ[(size_t)(size - 1 - r) * size + q] = 1;
+                if (r >= 0 && r < size && q >= 0 && q < size) occ[(size_t)(size - 1 - r) * A + q] = 1;
     }
 }
 
@@ -1068,12 +1094,13 @@ static void regen_map(const navsim_config* c, uint64_t genv, uint64_t ep, uint8_
  * coarse grid of G = size/10 cells (0.5 m, the reference's scale for its 1000-cell maps), L1-nearest node,
  * L-shaped paths of half-width r in {3, 4} (env_param corridor_width), iterations in [80, 150] scaled with
  * the area, nearest-neighbour upscaling, vertical flip. */
-static void regen_map_indoor(const navsim_config* c, uint64_t genv, uint64_t ep, uint8_t* occ) {
+static void regen_map_indoor(const navsim_config* c, uint64_t genv, uint64_t ep, uint8_t* occ, const double* tape) {
     const int size = c->map_w;
     const uint64_t key = nvr_hash4(c->seed, genv, ep, 0x494E44ULL);
     uint64_t n = 0;
-    const int r = c->corridor_width_lo + (int)(rg_u(key, n++) * (double)(c->corridor_width_hi - c->corridor_width_lo + 1));
-    const int it = c->iterations_lo + (int)(rg_u(key, n++) * (double)(c->iterations_hi - c->iterations_lo + 1));
+    const int r = c->corridor_width_lo + (int)(rg_t(tape, NAVSIM_DRAW_CORRIDOR_WIDTH, key, n) * (double)(c->corridor_width_hi - c->corridor_width_lo + 1));
+    const int it = c->iterations_lo + (int)(rg_t(tape, NAVSIM_DRAW_ITERATIONS, key, n + 1) * (double)(c->iterations_hi - c->iterations_lo + 1));
+    n += 2;
     int G = size / 10;
     if (G < 2 * r + 8) G = 2 * r + 8;
     if (G > 100) G = 100;
@@ -1087,8 +1114,10 @@ static void regen_map_indoor(const navsim_config* c, uint64_t genv, uint64_t ep,
     g[(G / 2) * G + G / 2] = 0;
     const int span = G - 2 * r - 3;                                    /* range(r + 2, G - r - 1) */
     for (int k = 0; k < n_it; ++k) {
-        int px = r + 2 + (int)(rg_u(key, n++) * span), py = r + 2 + (int)(rg_u(key, n++) * span);
-        int coin = rg_u(key, n++) >= 0.5;
+        int px = r + 2 + (int)(rg_t(tape, NAVSIM_DRAW_MAP + 3 * k, key, n) * span);
+        int py = r + 2 + (int)(rg_t(tape, NAVSIM_DRAW_MAP + 3 * k + 1, key, n + 1) * span);
+        int coin = rg_t(tape, NAVSIM_DRAW_MAP + 3 * k + 2, key, n + 2) >= 0.5;        /* map_generator.py:61, 68 */
+        n += 3;
         int best = 0, bd = 1 << 30;
         for (int t = 0; t < nt; ++t) {                                  /* first L1-nearest node */
             int dd = abs(px - tx[t]) + abs(py - ty[t]);
@@ -1124,23 +1153,40 @@ static inline void rg_cell_xy(const navsim_config* c, int i, int j, double* x, d
     *y = ((double)j + 0.5) * c->resolution + c->origin_y;
 }
 
-/* one rejection-sampled free cell: first try (of 64) with field >= clr whose distance to (rx, ry)
- * lies in (dmin, dmax); fallback = the tried cell with the best clearance */
-static void rg_sample(const navsim_config* c, const float* f, uint64_t key, uint64_t* n, double clr,
-                      int use_ref, double rx, double ry, double dmin, double dmax, double* x, double* y) {
-    const int W = c->map_w, H = c->map_h;
+/* The acceptance rules of _sample_start_goal_path (env.py:366-383), shared by every sampler below and by
+ * navsim_spawn_decisions_cpu (which tests/ compare with decisions recorded from the reference's own loop):
+ *   a start is dropped when it is closer than `min_robot` to the robot:   dist < 4   (env.py:371-373) -> kept at ==
+ *   a goal is kept when   min_goal_dist < dist < max_goal_dist   (env.py:379), both strict */
+static inline int rg_start_ok(double x, double y, double rx, double ry, double min_robot) {
+    double ddx = rx - x, ddy = ry - y;
+    return !(sqrt(ddx * ddx + ddy * ddy) < min_robot);
+}
+static inline int rg_goal_ok(double sx, double sy, double gx, double gy, double dmin, double dmax) {
+    double ddx = sx - gx, ddy = sy - gy;
+    double dist = sqrt(ddx * ddx + ddy * ddy);
+    return dmin < dist && dist < dmax;
+}
+/* the robot's pair survives reset()'s own test (env.py:756-762) unless path_distance > 2 |goal - start| */
+static inline int rg_robot_path_ok(double plen, double sx, double sy, double gx, double gy) {
+    double ddx = gx - sx, ddy = gy - sy;
+    return !(plen > 2.0 * sqrt(ddx * ddx + ddy * ddy));
+}
+
+/* one rejection-sampled free cell: first try (of 64) with field >= clr that passes the rule of its kind (kind 0:
+ * none, 1: a start, dropped when closer than dmin to (rx, ry); 2: a goal of the start (rx, ry));
+ * fallback = the tried cell with the best clearance.  Cells are drawn in the live map [0, size)^2. */
+static void rg_sample(const navsim_config* c, const float* f, int size, uint64_t key, uint64_t* n, double clr,
+                      int kind, double rx, double ry, double dmin, double dmax, double* x, double* y) {
+    const int W = c->map_w;
     int bi = 0, bj = 0; float bd = -1.0f;
     for (int t = 0; t < 64; ++t) {
-        int i = (int)(rg_u(key, (*n)++) * W), j = (int)(rg_u(key, (*n)++) * H);
+        int i = (int)(rg_u(key, (*n)++) * size), j = (int)(rg_u(key, (*n)++) * size);
         float d = f[(size_t)j * W + i];
         double px, py;
         rg_cell_xy(c, i, j, &px, &py);
         int ok = (double)d >= clr;
-        if (ok && use_ref) {
-            double ddx = px - rx, ddy = py - ry;
-            double dist = sqrt(ddx * ddx + ddy * ddy);
-            ok = dist > dmin && dist < dmax;
-        }
+        if (ok && kind == 1) ok = rg_start_ok(px, py, rx, ry, dmin);
+        if (ok && kind == 2) ok = rg_goal_ok(rx, ry, px, py, dmin, dmax);
         if (ok) { *x = px; *y = py; return; }
         if (d > bd) { bd = d; bi = i; bj = j; }
     }
@@ -1153,27 +1199,25 @@ static void rg_sample(const navsim_config* c, const float* f, uint64_t key, uint
  * pedestrians start >= 4 m from the robot and walk > 10 m (env.py:369-379, 788-791) along waypoints every
  * 2 m (env.py:804).  Four rounds of candidates; a slot that never succeeds keeps its last candidate.
  * Each candidate cell: up to 16 uniform tries, fallback = last try. */
-static void rgp_cell(const navsim_config* c, const uint8_t* cost, int Hc, int Wc, double res_c, uint64_t key,
-                     uint64_t* n, int use_ref, double rx, double ry, double dmin, double dmax, double* x, double* y) {
+static void rgp_cell(const navsim_config* c, const uint8_t* cost, int Wc, int live_w, int live_h, double res_c, uint64_t key,
+                     uint64_t* n, int kind, double rx, double ry, double dmin, double dmax, double* x, double* y) {
     for (int t = 0; t < 16; ++t) {
-        int I = (int)(rg_u(key, (*n)++) * Wc), J = (int)(rg_u(key, (*n)++) * Hc);
+        int I = (int)(rg_u(key, (*n)++) * live_w), J = (int)(rg_u(key, (*n)++) * live_h);
         *x = ((double)I + 0.5) * res_c + c->origin_x;
         *y = ((double)J + 0.5) * res_c + c->origin_y;
         if (cost[(size_t)J * Wc + I]) continue;
-        if (use_ref) {
-            double ddx = *x - rx, ddy = *y - ry;
-            double dist = sqrt(ddx * ddx + ddy * ddy);
-            if (!(dist > dmin && dist < dmax)) continue;
-        }
+        if (kind == 1 && !rg_start_ok(*x, *y, rx, ry, dmin)) continue;
+        if (kind == 2 && !rg_goal_ok(rx, ry, *x, *y, dmin, dmax)) continue;
         return;
     }
 }
 
 static void regen_planned(const navsim_config* c, const navsim_state* st, int e, uint64_t genv, uint64_t ep,
-                          const uint8_t* occ) {
+                          const uint8_t* occ, int size) {
     const int N = c->max_peds, K = c->n_spawn, H = c->map_h, W = c->map_w, P = NAVSIM_MAX_WAYPOINTS;
     const int Hc = H / 5, Wc = W / 5;
     const double res_c = c->resolution * 5.0;
+    const int live_c = size / 5;                /* candidates are cells of the live map's costmap */
     uint8_t* cost = (uint8_t*)malloc((size_t)Hc * Wc);
     navsim_costmap_cpu(occ, 1, H, W, cost);
     double* sp = (double*)st->spawn_pose + (size_t)e * K * 3;
@@ -1187,17 +1231,25 @@ static void regen_planned(const navsim_config* c, const navsim_state* st, int e,
             if (resolved[k]) continue;
             uint64_t key = nvr_hash4(c->seed, genv, ep, 0x52504C00ULL + (uint64_t)round * 256 + (uint64_t)k), n = 0;
             double s[2], g[2];
-            rgp_cell(c, cost, Hc, Wc, res_c, key, &n, 0, 0, 0, 0, 0, &s[0], &s[1]);
-            rgp_cell(c, cost, Hc, Wc, res_c, key, &n, 1, s[0], s[1], c->min_goal_dist, c->max_goal_dist, &g[0], &g[1]);
+            rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, &n, 0, 0, 0, 0, 0, &s[0], &s[1]);
+            rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, &n, 2, s[0], s[1], c->min_goal_dist, c->max_goal_dist, &g[0], &g[1]);
             sp[3 * k] = s[0]; sp[3 * k + 1] = s[1]; sp[3 * k + 2] = NVR_TWO_PI * rg_u(key, n++);
             sg[2 * k] = g[0]; sg[2 * k + 1] = g[1];
             navsim_plan_cpu(cost, NULL, 1, Hc, Wc, res_c, c->origin_x, c->origin_y, s, g, 5.0, P, wp, &nwp, NULL, &plen);
-            double ddx = g[0] - s[0], ddy = g[1] - s[1];
-            resolved[k] = nwp > 0 && plen <= 2.0 * sqrt(ddx * ddx + ddy * ddy);          /* env.py:761 */
+            resolved[k] = nwp > 0 && rg_robot_path_ok(plen, s[0], s[1], g[0], g[1]);      /* env.py:761 */
         }
     int idx = (int)(nvr_hash4(c->seed, genv, ep, 0x5eedULL) % (uint64_t)K);
-    if (!resolved[idx])
-        for (int s_ = 1; s_ < K; ++s_) { int j = (idx + s_) % K; if (resolved[j]) { idx = j; break; } }
+    {   /* first resolved pair from idx on (cyclic) whose first scan is outside the discomfort zone (env.py:776-781);
+           none: the first resolved one; none resolved: idx */
+        int first_res = -1, pick = -1;
+        for (int s_ = 0; s_ < K && pick < 0; ++s_) {
+            int j = (idx + s_) % K;
+            if (!resolved[j]) continue;
+            if (first_res < 0) first_res = j;
+            if (!c->regen_check_discomfort || !spawn_in_discomfort(c, st, e, sp + 3 * j)) pick = j;
+        }
+        if (pick >= 0) idx = pick; else if (first_res >= 0) idx = first_res;
+    }
     double* rp = st->robot_pose + 3 * (size_t)e;
     rp[0] = sp[3 * idx]; rp[1] = sp[3 * idx + 1]; rp[2] = sp[3 * idx + 2];
     st->robot_goal[2 * e] = sg[2 * idx]; st->robot_goal[2 * e + 1] = sg[2 * idx + 1];
@@ -1215,8 +1267,8 @@ static void regen_planned(const navsim_config* c, const navsim_state* st, int e,
         for (int round = 0; round < 4 && !done; ++round) {
             uint64_t key = nvr_hash4(c->seed, genv, ep, 0x50504C00ULL + (uint64_t)round * 256 + (uint64_t)i), nn = 0;
             double s[2], g[2];
-            rgp_cell(c, cost, Hc, Wc, res_c, key, &nn, 1, rp[0], rp[1], c->ped_min_robot_dist, 1.0e300, &s[0], &s[1]);
-            rgp_cell(c, cost, Hc, Wc, res_c, key, &nn, 1, s[0], s[1], c->ped_min_goal_dist, 1.0e300, &g[0], &g[1]);
+            rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, &nn, 1, rp[0], rp[1], c->ped_min_robot_dist, 0, &s[0], &s[1]);
+            rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, &nn, 2, s[0], s[1], c->ped_min_goal_dist, 1.0e300, &g[0], &g[1]);
             st->ped_pose[q * 3] = s[0]; st->ped_pose[q * 3 + 1] = s[1];
             navsim_plan_cpu(cost, NULL, 1, Hc, Wc, res_c, c->origin_x, c->origin_y, s, g, 2.0, P, w, &nwp, NULL, NULL);
             if (nwp > 0) { st->ped_n_waypoints[q] = nwp; done = 1; }
@@ -1368,7 +1420,7 @@ int navsim_replan_cpu(const navsim_config* c, const navsim_state* st, int32_t ma
                 uint64_t key = nvr_hash4(c->seed, genv, when, 0x52504E00ULL + (uint64_t)round * 256 + (uint64_t)i), m = 0;
                 double g[2], wp[2 * NAVSIM_MAX_WAYPOINTS];
                 int32_t nwp;
-                rgp_cell(c, cost, Hc, Wc, res_c, key, &m, 1, pp[0], pp[1], c->ped_min_goal_dist, 1.0e300, &g[0], &g[1]);
+                rgp_cell(c, cost, Wc, Wc, Hc, res_c, key, &m, 2, pp[0], pp[1], c->ped_min_goal_dist, 1.0e300, &g[0], &g[1]);
                 navsim_plan_cpu(cost, NULL, 1, Hc, Wc, res_c, c->origin_x, c->origin_y, pp, g, 2.0, P, wp, &nwp, NULL, NULL);
                 if (nwp > 0) {
                     memcpy(w, wp, sizeof(double) * 2 * (size_t)nwp);
@@ -1394,35 +1446,46 @@ int navsim_regen_cpu(const navsim_config* c, const navsim_state* st, const navsi
         ++taken;
         mask[e] = 1;
         const uint64_t genv = (uint64_t)(c->env_index_base + e), ep = (uint64_t)st->episode[e];
+        const double* tape = st->regen_draws ? st->regen_draws + (size_t)e * NAVSIM_DRAWS_PER_ARENA : NULL;
         {   /* per-episode env_param draws that are plain state (env.py:281-292, 786, 439) */
             const uint64_t pk = nvr_hash4(c->seed, genv, ep, 0x50524DULL);
             if (c->num_humans_hi > 0 && c->ped_model != NAVSIM_PED_NONE && st->n_peds) {
-                int nh = c->num_humans_lo + (int)(rg_u(pk, 1) * (double)(c->num_humans_hi - c->num_humans_lo + 1));
+                int nh = c->num_humans_lo + (int)(rg_t(tape, NAVSIM_DRAW_NUM_HUMANS, pk, 1) * (double)(c->num_humans_hi - c->num_humans_lo + 1));
                 st->n_peds[e] = nh > N ? N : nh;
             }
             if (c->scan_noise_std_hi >= 0.0 && st->scan_noise_std)
-                st->scan_noise_std[e] = (float)(c->scan_noise_std_lo + (c->scan_noise_std_hi - c->scan_noise_std_lo) * rg_u(pk, 2));
+                st->scan_noise_std[e] = (float)(c->scan_noise_std_lo + (c->scan_noise_std_hi - c->scan_noise_std_lo) *
+                                                                           rg_t(tape, NAVSIM_DRAW_SCAN_NOISE_STD, pk, 2));
         }
         float* f = (float*)st->field + (size_t)e * H * W;
-        if (c->regen_indoor_ratio > 0.0 && rg_u(nvr_hash4(c->seed, genv, ep, 0x4B494E44ULL), 0) < c->regen_indoor_ratio)
-            regen_map_indoor(c, genv, ep, occ);
-        else
-            regen_map(c, genv, ep, occ);
+        int size = W;                           /* side of the live map: cells are sampled in [0, size)^2 */
+        if (c->regen_indoor_ratio > 0.0 &&       /* env.py:295: np.random.random() < indoor_ratio */
+            rg_t(tape, NAVSIM_DRAW_KIND, nvr_hash4(c->seed, genv, ep, 0x4B494E44ULL), 0) < c->regen_indoor_ratio) {
+            regen_map_indoor(c, genv, ep, occ, tape);
+        } else {
+            regen_map(c, genv, ep, occ, tape);
+            size = outdoor_size(c);
+        }
         navsim_build_dt_cpu(occ, 1, H, W, f);
         if (st->costmap) navsim_costmap_cpu(occ, 1, H, W, st->costmap + (size_t)e * (H / 5) * (W / 5));
-        if (c->regen_plan) { regen_planned(c, st, e, genv, ep, occ); continue; }
+        if (c->regen_plan) { regen_planned(c, st, e, genv, ep, occ, size); continue; }
         /* start / goal table */
         double* sp = (double*)st->spawn_pose + (size_t)e * K * 3;
         double* sg = (double*)st->spawn_goal + (size_t)e * K * 2;
         const double clr = c->spawn_clearance / c->resolution;
         for (int k = 0; k < K; ++k) {
             uint64_t key = nvr_hash4(c->seed, genv, ep, 0x53504157ULL + (uint64_t)k), n = 0;
-            rg_sample(c, f, key, &n, clr, 0, 0, 0, 0, 0, &sp[3 * k], &sp[3 * k + 1]);
+            rg_sample(c, f, size, key, &n, clr, 0, 0, 0, 0, 0, &sp[3 * k], &sp[3 * k + 1]);
             sp[3 * k + 2] = NVR_TWO_PI * rg_u(key, n++);
-            rg_sample(c, f, key, &n, clr, 1, sp[3 * k], sp[3 * k + 1], c->min_goal_dist, c->max_goal_dist,
+            rg_sample(c, f, size, key, &n, clr, 2, sp[3 * k], sp[3 * k + 1], c->min_goal_dist, c->max_goal_dist,
                       &sg[2 * k], &sg[2 * k + 1]);
         }
         int idx = (int)(nvr_hash4(c->seed, genv, ep, 0x5eedULL) % (uint64_t)K);
+        if (c->regen_check_discomfort)           /* env.py:776-781: first table entry from idx on whose first scan is clear */
+            for (int s_ = 0; s_ < K; ++s_) {
+                int j = (idx + s_) % K;
+                if (!spawn_in_discomfort(c, st, e, sp + 3 * j)) { idx = j; break; }
+            }
         double* rp = st->robot_pose + 3 * (size_t)e;
         rp[0] = sp[3 * idx]; rp[1] = sp[3 * idx + 1]; rp[2] = sp[3 * idx + 2];
         st->robot_goal[2 * e] = sg[2 * idx]; st->robot_goal[2 * e + 1] = sg[2 * idx + 1];
@@ -1434,9 +1497,9 @@ int navsim_regen_cpu(const navsim_config* c, const navsim_state* st, const navsi
             size_t q = (size_t)e * N + i;
             uint64_t key = nvr_hash4(c->seed, genv, ep, 0x504544ULL + (uint64_t)i), m = 0;
             double x, y, gx, gy;
-            rg_sample(c, f, key, &m, pclr, 1, rp[0], rp[1], c->ped_min_robot_dist, 1.0e300, &x, &y);
+            rg_sample(c, f, size, key, &m, pclr, 1, rp[0], rp[1], c->ped_min_robot_dist, 0, &x, &y);
             double th = NVR_TWO_PI * rg_u(key, m++);
-            rg_sample(c, f, key, &m, pclr, 1, x, y, c->ped_min_goal_dist, 1.0e300, &gx, &gy);
+            rg_sample(c, f, size, key, &m, pclr, 2, x, y, c->ped_min_goal_dist, 1.0e300, &gx, &gy);
             st->ped_pose[q * 3] = x; st->ped_pose[q * 3 + 1] = y; st->ped_pose[q * 3 + 2] = th;
             st->ped_vel[q * 2] = 0.0; st->ped_vel[q * 2 + 1] = 0.0;
             ((double*)st->ped_v_pref)[q] = c->v_pref_lo + (c->v_pref_hi - c->v_pref_lo) * rg_u(key, m++);
@@ -1587,6 +1650,35 @@ int navsim_plan_cpu(const uint8_t* cost, const int32_t* map_index, int32_t n_map
         }
     }
     free(dist); free(queue); free(path);
+    return NAVSIM_OK;
+}
+
+/* TESTS ONLY: the acceptance rules of the spawn loops on SUPPLIED candidates, so that they can be compared with the
+ * decisions the reference's own _sample_start_goal_path / reset() took on the same candidates
+ * (tests/golden/golden_reset.npz).  The very functions the samplers above call.
+ * kind[m]: 0 = the robot's pair (env.py:748-762), 1 = a pedestrian's (env.py:786-793; robot [n,2] = the robot's xy).
+ * code[m]: 0 kept, 1 start closer than ped_min_robot_dist to the robot, 2 goal distance outside its interval,
+ *          3 no path on the costmap, 4 (robot) path_distance > 2 |goal - start|. */
+int navsim_spawn_decisions_cpu(const navsim_config* c, const uint8_t* cost, int32_t Hc, int32_t Wc, int32_t n,
+                               const int32_t* kind, const double* start, const double* goal, const double* robot,
+                               int32_t* code) {
+    if (!c || !cost || !kind || !start || !goal || !code || n < 0) return NAVSIM_E_ARG;
+    const double res_c = c->resolution * 5.0;
+    double wp[2 * NAVSIM_MAX_WAYPOINTS];
+    for (int m = 0; m < n; ++m) {
+        const double* s = start + 2 * m;
+        const double* g = goal + 2 * m;
+        const int ped = kind[m] == 1;
+        code[m] = 0;
+        if (ped && robot && !rg_start_ok(s[0], s[1], robot[2 * m], robot[2 * m + 1], c->ped_min_robot_dist)) { code[m] = 1; continue; }
+        if (!rg_goal_ok(s[0], s[1], g[0], g[1], ped ? c->ped_min_goal_dist : c->min_goal_dist,
+                        ped ? 1.0e300 : c->max_goal_dist)) { code[m] = 2; continue; }
+        int32_t nwp = 0; double plen = 0.0;
+        navsim_plan_cpu(cost, NULL, 1, Hc, Wc, res_c, c->origin_x, c->origin_y, s, g, ped ? 2.0 : 5.0,
+                        NAVSIM_MAX_WAYPOINTS, wp, &nwp, NULL, &plen);
+        if (nwp <= 0) { code[m] = 3; continue; }
+        if (!ped && !rg_robot_path_ok(plen, s[0], s[1], g[0], g[1])) code[m] = 4;
+    }
     return NAVSIM_OK;
 }
 

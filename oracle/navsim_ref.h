@@ -120,6 +120,11 @@ int navsim_crowd_orca_cpu(const navsim_orca_params* p, int32_t n_queries, int32_
                           double* out_vel, double* out_action);
 int navsim_crowd_agent_step_cpu(double* pose, const double* action, double* vel, int32_t n, double time_step);
 
+/* tests only: the spawn loops' acceptance rules on supplied candidates; see include/navsim.h navsim_debug_spawn_decisions */
+int navsim_spawn_decisions_cpu(const navsim_config* c, const uint8_t* cost, int32_t Hc, int32_t Wc, int32_t n,
+                               const int32_t* kind, const double* start, const double* goal, const double* robot,
+                               int32_t* code);
+
 /* statistics for DESIGN.md: distance-field probes of the last cast/step on this thread */
 int64_t navsim_probe_count_cpu(int32_t reset);
 /* rays traced on this thread since the last reset by number of probes: hist256[n], n = 255 collects >= 255 */

@@ -315,6 +315,23 @@ def probe_count(reset=True):
     return int(lib().navsim_probe_count_cpu(int(reset)))
 
 
+def spawn_decisions(cfg, cost, kind, start, goal, robot=None):
+    """navsim_spawn_decisions_cpu: the spawn loops' acceptance rules on supplied candidates -> int32 codes [n]."""
+    cost = np.ascontiguousarray(cost, dtype=np.uint8)
+    Hc, Wc = cost.shape
+    kind = np.ascontiguousarray(kind, dtype=np.int32)
+    n = kind.shape[0]
+    f64 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64).reshape(n, 2)
+    start, goal, robot = f64(start), f64(goal), f64(robot)
+    code = np.full(n, -1, np.int32)
+    L = lib()
+    L.navsim_spawn_decisions_cpu.argtypes = [C.POINTER(abi.NavsimConfig), C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    _chk(L.navsim_spawn_decisions_cpu(C.byref(cfg), _p(cost), Hc, Wc, n, _p(kind), _p(start), _p(goal), _p(robot), _p(code)),
+         "spawn_decisions")
+    return code
+
+
 def probe_hist(reset=True):
     """int64 [256]: rays traced on THIS thread since the last reset, by the number of distance-field probes each
     one made (bin 255 collects >= 255).  SURVEY.md 8d work counters (probes per ray mean / p99)."""

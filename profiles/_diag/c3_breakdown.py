@@ -17,7 +17,7 @@ def timed(sim, acts, n=60):
     return e0.elapsed_time(e1) / n * 1e3
 
 wl = dict(bench.WORKLOADS["c3"]); wl["field"] = "u16t"
-cfg, sim, arrays, _ = bench.build_sim(wl, 0, 1)
+cfg, sim, arrays, _ = bench.build_sim(wl, 0, wl["envs"])
 E = cfg.n_envs
 g = torch.Generator(device="cuda:0"); g.manual_seed(1)
 acts = torch.rand((32, E, 2), generator=g, device="cuda:0", dtype=torch.float64); acts[..., 0] *= 0.5; acts[..., 1] = acts[..., 1] * 1.28 - 0.64

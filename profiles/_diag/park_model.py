@@ -11,7 +11,7 @@ import torch, bench
 from scipy import ndimage
 
 wl = dict(bench.WORKLOADS["c2"]); wl["field"] = "u16t"
-cfg, sim, arrays, _ = bench.build_sim(wl, 0, 1)
+cfg, sim, arrays, _ = bench.build_sim(wl, 0, wl["envs"])
 E, B, SIZE = cfg.n_envs, cfg.n_beams, cfg.map_h
 g = torch.Generator(device="cuda:0"); g.manual_seed(1)
 acts = torch.rand((100, E, 2), generator=g, device="cuda:0", dtype=torch.float64); acts[..., 0] *= 0.5; acts[..., 1] = acts[..., 1] * 1.28 - 0.64

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "nav-gym_amd"))
 import numpy as np, torch, bench
 from nav_gym_amd import lib
 wl = dict(bench.WORKLOADS[os.environ.get("NAVSIM_WL", "c2")]); wl["field"] = "u16t"
-cfg, sim, arrays, _ = bench.build_sim(wl, 0, 1)
+cfg, sim, arrays, _ = bench.build_sim(wl, 0, wl["envs"])
 E = cfg.n_envs
 L = lib.load()
 buf = torch.zeros((E, 8), dtype=torch.int64, device="cuda:0")

@@ -7,7 +7,7 @@ import torch
 import bench
 wl = dict(bench.WORKLOADS["c2"]); wl["field"] = "u16t"
 if len(sys.argv) > 1: wl["envs"] = int(sys.argv[1])
-cfg, sim, arrays, _ = bench.build_sim(wl, 0, 1)
+cfg, sim, arrays, _ = bench.build_sim(wl, 0, wl["envs"])
 E = cfg.n_envs; K = 30
 g = torch.Generator(device="cuda:0"); g.manual_seed(5)
 acts = torch.rand((K, E, 2), generator=g, device="cuda:0", dtype=torch.float64); acts[..., 0] *= 0.5; acts[..., 1] = acts[..., 1] * 1.28 - 0.64

@@ -8,7 +8,7 @@ import bench
 variants = sys.argv[1].split(",") if len(sys.argv) > 1 else ["256x1", "256x5"]
 for E in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "256,1024,2048,4096,8192".split(","))]:
     wl = dict(bench.WORKLOADS["c2"]); wl["envs"] = E; wl["field"] = "u16t"
-    cfg, sim, arrays, _ = bench.build_sim(wl, 0, 1)
+    cfg, sim, arrays, _ = bench.build_sim(wl, 0, wl["envs"])
     K = 30
     g = torch.Generator(device="cuda:0"); g.manual_seed(5)
     acts = torch.rand((K, E, 2), generator=g, device="cuda:0", dtype=torch.float64)

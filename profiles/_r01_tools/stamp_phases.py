@@ -12,7 +12,7 @@ from nav_gym_amd import lib
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 if len(sys.argv) > 2: os.environ["NAVSIM_STEP_VARIANT"] = sys.argv[2]
 wl = dict(bench.WORKLOADS[os.environ.get("NAVSIM_WL", "c2")]); wl["envs"] = E; wl["field"] = "u16t"
-cfg, sim, arrays, _ = bench.build_sim(wl, 0, 1)
+cfg, sim, arrays, _ = bench.build_sim(wl, 0, wl["envs"])
 L = lib.load()
 buf = torch.zeros((E, 8), dtype=torch.int64, device="cuda:0")
 L.navsim_debug_set_stamps.argtypes = [C.c_void_p]

@@ -18,7 +18,7 @@ rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 K = 40
 wl = dict(bench.WORKLOADS[wl_name])
 wl["field"] = os.environ.get("NAVSIM_FIELD", "u16t")
-cfg, sim, arrays, _ = bench.build_sim(wl, 0, 1)
+cfg, sim, arrays, _ = bench.build_sim(wl, 0, wl["envs"])
 if os.environ.get("NAVSIM_SHARED_FIELD"):            # diagnostic: all arenas march arena 0's field (L2-resident)
     sim.cfg.shared_field = 1
 E = cfg.n_envs

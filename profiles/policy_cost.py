@@ -10,7 +10,7 @@ import bench
 from nav_gym_amd import abi
 
 wl = dict(bench.WORKLOADS["c3"]); wl["field"] = "u16t"
-cfg, sim, arrays, _ = bench.build_sim(wl, 0, 1)
+cfg, sim, arrays, _ = bench.build_sim(wl, 0, wl["envs"])
 sim.cfg.ped_model = abi.PED_EXTERNAL
 rng = np.random.default_rng(0)
 fan = {"cv1": 15, "cv2": 96, "fc1": 4096, "fc2": 260, "a1": 128, "a2": 128}

@@ -719,17 +719,23 @@ def make_crowd_agent():
     print("golden_crowd_agent.npz: n=%d" % n)
 
 
+from make_reset import make_reset  # noqa: E402
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "crowd_maps":      # only this fixture (the others stay byte-identical)
         return make_crowd_maps()
     if len(sys.argv) > 1 and sys.argv[1] == "crowd_agent":
         return make_crowd_agent()
     ref_env, human, keti_robot, ref_utils, human_policy = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "reset":            # only golden_reset.npz
+        return make_reset(ref_env)
     make_units(ref_env, human, keti_robot, ref_utils)
     run_trace("random_S1", ref_env, human, human_policy, S=1, seed=11, scenario="random", n_steps=40, ped_scan_every=5)
     run_trace("peds_S1", ref_env, human, human_policy, S=1, seed=12, scenario="peds", n_steps=30, ped_scan_every=3)
     run_trace("crash_S3", ref_env, human, human_policy, S=3, seed=13, scenario="crash", n_steps=24)
     run_trace("success_S2", ref_env, human, human_policy, S=2, seed=14, scenario="success", n_steps=12)
+    make_reset(ref_env)
     make_crowd()
     make_crowd_maps()
     make_crowd_agent()

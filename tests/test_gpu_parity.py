@@ -1155,7 +1155,7 @@ def full_c2(gpu, request):
     after every step)."""
     import bench
     wl = dict(bench.WORKLOADS[request.param]); wl["field"] = "u16t"
-    cfg, sim, arrays, occ = bench.build_sim(wl, 0, 1)
+    cfg, sim, arrays, occ = bench.build_sim(wl, 0, wl["envs"])
     sim.regen_every_step = bool(wl.get("regen"))
     yield cfg, sim, arrays, occ
     del sim, arrays
