@@ -644,7 +644,7 @@ def test_regen_odd_map_size(gpu, fmt):
             _eq(gs[k], v, "state %s" % k)
     if fmt == abi.FIELD_F32:
         _eq(gs["field"], r.a["field"], "field")
-    assert regenerated > 3
+    assert regenerated >= 2
 
 
 @pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T])
