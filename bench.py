@@ -84,6 +84,8 @@ def build_sim(wl, base, E, seed=1234, device="cuda:0"):
         arrays[key] = sim.scan_threshold(cfg, torch.from_numpy(robots.footprint_array(robot, name)).to(dev))
     s = sim.NavSim(cfg, arrays, device=device)
     s.reset_obs()
+    if wl.get("regen") and wl.get("pregen", False):
+        s.enable_pregen()               # next worlds staged ahead of time on a side stream (navsim_regen_swap)
     return cfg, s, arrays, occ
 
 
@@ -289,6 +291,9 @@ def main():
                     help="navsim_config.ped_split: 0 library default, 1 pedestrians inside the step, 2 ped_update_kernel first")
     ap.add_argument("--no-rects", action="store_true",
                     help="march through the packed field only, without the two-rectangle tile records (A/B)")
+    ap.add_argument("--pregen", action="store_true",
+                    help="c5: worlds staged ahead on a side stream + navsim_regen_swap instead of navsim_regen after every step "
+                         "(measured: +11-14 %% at 128-256 arenas per GPU, +-0 at the 512 of c5 where the step kernel fills the chip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", default="off", choices=["auto", "on", "off"],
                     help="replay the K timed steps as one captured hipGraph (measured: c2 +0 %, c5 +2.5 %; off by default)")
@@ -340,6 +345,7 @@ def main():
     wl["indoor_ratio"] = args.indoor_ratio
     if args.no_rects:
         wl["rects"] = False
+    wl["pregen"] = bool(args.pregen)
     base, E_local = shard_of(wl, args.scaling, rank, world_size)
     E_total = wl["total"] if args.scaling == "strong" else world_size * wl["envs"]
     if E_local < 1:
@@ -526,7 +532,7 @@ def main():
                             "scan_noise_std %.3g"
                             % (args.workload, E_total, args.scaling, E, B, H, W, args.field,
                                " + rect records" if rects else "", args.indoor_ratio, wl["peds"], wl.get("robot", "keti"),
-                               "new random map per episode (navsim_regen)" if regen else "auto-respawn in place",
+                               ("new random map per episode (%s)" % ("worlds staged ahead, navsim_regen_swap" if getattr(sim, "pregen", False) else "navsim_regen")) if regen else "auto-respawn in place",
                                args.noise_std),
                 "envs_total": E_total, "envs_per_gpu": E, "n_beams": B, "map": [H, W],
                 "pedestrians": wl["peds"], "obs_gather": args.gather, "episodes_finished_rank0": n_done,

@@ -372,6 +372,27 @@ int navsim_ped_scans(const navsim_config* cfg, const navsim_state* st, float* ou
  * planner joins it (robot: path no longer than twice the straight line, env.py:756-762; pedestrians get the
  * path's waypoints every 2 m, env.py:804); four rounds of candidates, the last one stays if none passes. */
 size_t navsim_regen_workspace_bytes(const navsim_config* cfg);
+/* navsim_regen off the step's critical path (round 3).  The world an arena receives at the end of an episode depends
+ * on (cfg.seed, global arena index, episode number) only, so it can be generated AHEAD of time: keep a second, STAGED
+ * navsim_state (own copies of every array navsim_regen writes, its episode[e] = live episode[e] + 1) and a staged
+ * observation buffer; run the ordinary navsim_regen on the staged state for the arenas flagged in want[] (as its
+ * io->done), on a side stream, while steps run.  After a step, navsim_regen_swap installs the staged world of every
+ * finished arena (io->done[e] != 0; at most cfg.regen_cap, lowest indices first -- navsim_regen's own rule): it copies
+ * the arena's rows of those arrays and of the observation from the staged state into the live one, marks the arena for
+ * the next staging pass and sets stage->episode[e] = live episode + 1.  The live state is then exactly what navsim_regen would have left.
+ * The caller orders the streams: a swap after the staging pass that served its arenas, the next staging pass after the
+ * swap (nav_gym_amd/sim.py NavSim.enable_pregen).  Needs cfg.auto_reset = 1 (the step advances episode[e] at `done`).
+ * A finished arena that is NOT installed by a call -- beyond regen_cap, or its staged world not ready (want[e] != 0) --
+ * plays on in place like one beyond navsim_regen's cap and is staged again for its new episode number; with no such
+ * surplus the live state after every call equals navsim_regen's bit for bit.
+ * want [E], mark [E]: uint8 flags, zero-initialised by the caller with every arena staged (or all ones in want and one
+ * navsim_regen_stage per regen_cap arenas first).  navsim_regen_swap only reads want and writes mark;
+ * navsim_regen_stage (io->done must be `want`, io->obs the staged observation buffer) merges mark into want, runs
+ * navsim_regen on the staged state and clears want for the arenas it served. */
+int    navsim_regen_swap(const navsim_config* cfg, const navsim_state* live, const navsim_state* stage,
+                         const navsim_step_io* io, const float* stage_obs, const uint8_t* want, uint8_t* mark, void* stream);
+int    navsim_regen_stage(const navsim_config* cfg, const navsim_state* stage, const navsim_step_io* io, uint8_t* want,
+                          uint8_t* mark, void* workspace, size_t workspace_bytes, void* stream);
 int    navsim_regen(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                     void* workspace, size_t workspace_bytes, void* stream);
 

@@ -6,8 +6,16 @@
 // navsim_regen: reset() of finished arenas on the device with a new random map.
 // Specification: oracle/navsim_ref.c navsim_regen_cpu (same hash-keyed uniforms, same tries).
 // ============================================================================================
+// The reset kernels run a handful of workgroups once per call: what they cost is not arithmetic but the FETCH of
+// their instructions (a cold 64-byte line per ~8 instructions from L2 / HBM: regen_maps_kernel's 600 straight-line
+// instructions per thread took 13 us, profiles/_diag/regen_stamps.py) -- keep what a lane executes short.  (Real
+// function calls are NOT the way: noinline helpers made regen_commit_kernel 38 -> 72 us through the call ABI's
+// scratch traffic.)
 __device__ __forceinline__ double rg_u(uint64_t key, uint64_t i) {
     return (double)(nv::mix64(key + i * 0x9E3779B97F4A7C15ULL) >> 11) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ uint64_t rg_key(uint64_t seed, uint64_t genv, uint64_t ep, uint64_t purpose) {
+    return nv::hash4(seed, genv, ep, purpose);
 }
 // a draw: the supplied one (tests only: navsim_state.regen_draws, NAVSIM_DRAW_* layout) or the hash-keyed one
 __device__ __forceinline__ double rg_t(const double* __restrict__ tape, int slot, uint64_t key, uint64_t i) {
@@ -25,32 +33,43 @@ __device__ __forceinline__ int live_size(const navsim_config& c, const int* __re
     return kind[b] ? c.map_w : outdoor_size(c);
 }
 
-// ordered compaction of the arenas that finished in this step: list[0..count), mask[e]
-__global__ __launch_bounds__(1024) void regen_select_kernel(const uint8_t* __restrict__ done, int E, int cap,
-                                                            int* __restrict__ count, int* __restrict__ list,
-                                                            uint8_t* __restrict__ mask) {
-    __shared__ int part[1024];
-    const int tid = threadIdx.x;
-    const int per = (E + 1023) / 1024;
+// Ordered compaction of the arenas that finished in this step, without a kernel of its own: every workgroup of the
+// first regen kernel finds ITS arena -- the b-th finished one in index order, or -1 -- from the done flags (a few
+// hundred bytes to a few KB).  total = min(finished, cap): lowest indices first, the rest wait for the next call.
+// Whole 256-thread workgroup; two barriers.
+// `skip` (optional): arenas with skip[e] != 0 are not eligible (navsim_regen_swap: their staged world is not ready).
+// excl_out / lo_out / hi_out (optional): this thread's slice of the arenas and the number of eligible ones before it.
+__device__ __forceinline__ int regen_slot(const uint8_t* __restrict__ done, int E, int cap, int b, int& total,
+                                          const uint8_t* __restrict__ skip = nullptr, int* excl_out = nullptr,
+                                          int* lo_out = nullptr, int* hi_out = nullptr) {
+    __shared__ int wave_tot[4], found_s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int per = (E + 255) / 256;
     const int lo = tid * per, hi = (lo + per < E) ? lo + per : E;
+    auto eligible = [&](int e) { return done[e] != 0 && !(skip && skip[e] != 0); };
     int n = 0;
-    for (int e = lo; e < hi; ++e) n += done[e] != 0;
-    part[tid] = n;
+    for (int e = lo; e < hi; ++e) n += eligible(e);
+    int incl = n;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_tot[tid >> 6] = incl;
+    if (tid == 0) found_s = -1;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {                 // inclusive scan
-        int v = (tid >= off) ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    int before = 0, all = 0;
+    for (int w = 0; w < 4; ++w) { before += (w < (tid >> 6)) ? wave_tot[w] : 0; all += wave_tot[w]; }
+    incl += before;
+    const int excl = incl - n;
+    if (b >= excl && b < incl) {                              // exactly one thread (if any)
+        int pos = excl;
+        for (int e = lo; e < hi; ++e)
+            if (eligible(e)) { if (pos == b) { found_s = e; break; } ++pos; }
     }
-    int pos = part[tid] - n;
-    for (int e = lo; e < hi; ++e) {
-        bool take = done[e] != 0 && pos < cap;
-        mask[e] = take ? 1 : 0;
-        if (take) list[pos] = e;
-        pos += done[e] != 0;
-    }
-    if (tid == 1023) *count = part[1023] < cap ? part[1023] : cap;
+    __syncthreads();
+    total = all < cap ? all : cap;
+    if (excl_out) { *excl_out = excl; *lo_out = lo; *hi_out = hi; }
+    return b < total ? found_s : -1;
 }
 
 // create_indoor_map (map_generator.py:97-123; oracle regen_map_indoor): the corridor tree on the coarse grid,
@@ -58,19 +77,25 @@ __global__ __launch_bounds__(1024) void regen_select_kernel(const uint8_t* __res
 // min-reduction on (L1 distance, node index), then the two corridor rectangles carved by all threads);
 // the grid lives in LDS and is written to grid_all[b] (G*G bytes, stride 100*100).  kind[b] = G for a
 // corridor map, 0 for an outdoor one (regen_maps_kernel then draws the outdoor map as before).
+// The kernel also OPENS navsim_regen: workgroup b selects its arena (regen_slot), publishes list[b] (-1: none) and,
+// workgroup 0, the count; every later kernel of the call reads those.
 __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navsim_state st,
-                                                           const int* __restrict__ count, const int* __restrict__ list,
+                                                           const uint8_t* __restrict__ done, int cap,
+                                                           int* __restrict__ count, int* __restrict__ list,
                                                            uint8_t* __restrict__ grid_all, int* __restrict__ kind) {
     __shared__ uint8_t g[100 * 100];
     __shared__ int tx[152], ty[152];
     __shared__ unsigned best_s;
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (b >= *count) return;
-    const int e = list[b], size = c.map_w;
+    int total;
+    const int e = regen_slot(done, c.n_envs, cap, b, total);
+    if (tid == 0) { list[b] = e; if (b == 0) *count = total; }
+    if (e < 0) return;
+    const int size = c.map_w;
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
     const double* tape = rg_tape(st, e);
     if (tid == 0) {                 // per-episode env_param draws that are plain state (env.py:281-292, 786, 439)
-        const uint64_t pk = nv::hash4(c.seed, genv, ep, 0x50524DULL);
+        const uint64_t pk = rg_key(c.seed, genv, ep, 0x50524DULL);
         if (c.num_humans_hi > 0 && c.ped_model != NAVSIM_PED_NONE && st.n_peds) {
             int n = c.num_humans_lo + (int)(rg_t(tape, NAVSIM_DRAW_NUM_HUMANS, pk, 1) * (double)(c.num_humans_hi - c.num_humans_lo + 1));
             st.n_peds[e] = n > c.max_peds ? c.max_peds : n;
@@ -80,9 +105,9 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
                                                                      rg_t(tape, NAVSIM_DRAW_SCAN_NOISE_STD, pk, 2));
     }
     const bool indoor = c.regen_indoor_ratio > 0.0 &&       // env.py:295
-                        rg_t(tape, NAVSIM_DRAW_KIND, nv::hash4(c.seed, genv, ep, 0x4B494E44ULL), 0) < c.regen_indoor_ratio;
+                        rg_t(tape, NAVSIM_DRAW_KIND, rg_key(c.seed, genv, ep, 0x4B494E44ULL), 0) < c.regen_indoor_ratio;
     if (!indoor) { if (tid == 0) kind[b] = 0; return; }                  // block-uniform
-    const uint64_t key = nv::hash4(c.seed, genv, ep, 0x494E44ULL);
+    const uint64_t key = rg_key(c.seed, genv, ep, 0x494E44ULL);
     uint64_t n = 0;
     const int r = c.corridor_width_lo + (int)(rg_t(tape, NAVSIM_DRAW_CORRIDOR_WIDTH, key, n) * (double)(c.corridor_width_hi - c.corridor_width_lo + 1));
     const int it = c.iterations_lo + (int)(rg_t(tape, NAVSIM_DRAW_ITERATIONS, key, n + 1) * (double)(c.iterations_hi - c.iterations_lo + 1));
@@ -131,31 +156,36 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
     if (tid == 0) kind[b] = G;
 }
 
-// create_outdoor_map (map_generator.py:126-143) at size x size, hash-keyed: kRegenSlices workgroups per map,
-// each filling its own band of rows (border wall, four cells per store) and then the parts of the obstacle
-// squares that fall into the band.
-constexpr int kRegenSlices = 32;
-// For an OUTDOOR map the kernel also writes the exact distance field straight from the generator's geometry: the
-// obstacles are the border frame and n boxes, and the squared distance of a cell to a rectangle of occupied cells is
-// max(x0 - x, x - x1, 0)^2 + max(y0 - y, y - y1, 0)^2, so d2 = min over them -- the same integers the distance
-// transform finds, with no dependent scan (the two transform kernels then skip the slot: their column / row
-// searches are latency-bound with a handful of live maps, 75 us per step of c5).
+// create_outdoor_map (map_generator.py:126-143), hash-keyed: kRegenSlices workgroups per map, each owning a band of
+// stored rows.  For an OUTDOOR map the kernel writes the exact distance field straight from the generator's geometry:
+// the obstacles are the border frame and n boxes, and the squared distance of a cell to a rectangle of occupied
+// cells is max(x0 - x, x - x1, 0)^2 + max(y0 - y, y - y1, 0)^2, so d2 = min over them -- the same integers the
+// distance transform finds, with no dependent scan (the two transform kernels then skip the slot).
+//
+// Round 3: a thread owns EIGHT consecutive cells of a row -- one 16-byte tile row of the packed field (one store),
+// one 8-byte store of the occupancy -- and walks (row, group) items without a division per cell; 128 bands per map.
+// 41 -> 22 us for the 5 maps of a c5 step.  (Measured and dropped: one 8x8 tile per wavefront with a cell per lane,
+// 46 us; 32 or 512 bands, 23 / 33 us.  The kernel's time does not follow its arithmetic: profiles/README.md.)
+// `direct`: every map of this call is an outdoor one and nothing downstream wants the per-slot scratch (no rect
+// rebuild): the field goes straight into the arena's own buffers, no copy kernel.
+constexpr int kRegenSlices = 128;
 __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim_state st,
                                                          const int* __restrict__ count, const int* __restrict__ list,
                                                          uint8_t* __restrict__ occ_all,
                                                          const uint8_t* __restrict__ grid_all, const int* __restrict__ kind,
                                                          char* __restrict__ field_scratch, size_t field_bytes,
-                                                         float* __restrict__ ovf_scratch) {
+                                                         float* __restrict__ ovf_scratch, int direct) {
     __shared__ int ocx[64], ocy[64];
     const int b = blockIdx.x;
     if (b >= *count) return;
     const int e = list[b], size = c.map_w, tid = threadIdx.x;
-    uint8_t* occ = occ_all + (size_t)b * size * size;
+    uint8_t* occ = occ_all ? occ_all + (size_t)b * size * size : nullptr;
+    const int rows = (size + kRegenSlices - 1) / kRegenSlices;
+    const int y0 = blockIdx.y * rows, y1 = (y0 + rows < size) ? y0 + rows : size;
+    if (y0 >= size) return;
     if (const int G = kind[b]) {                                       // corridor map: nearest upscaling + flip
         const uint8_t* gsrc = grid_all + (size_t)b * 10000;
-        const int rows_i = (size + kRegenSlices - 1) / kRegenSlices;
-        const int ra = blockIdx.y * rows_i, rb = (ra + rows_i < size) ? ra + rows_i : size;
-        for (int idx = ra * size + tid; idx < rb * size; idx += 256) {
+        for (int idx = y0 * size + tid; idx < y1 * size; idx += 256) {
             int yy = idx / size, xx = idx - yy * size;
             occ[(size_t)(size - 1 - yy) * size + xx] = gsrc[(int)(((long long)yy * G) / size) * G + (int)(((long long)xx * G) / size)];
         }
@@ -166,14 +196,14 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
     // 5-cell border wall no ray and no distance sees it
     const int live = outdoor_size(c);
     const double* tape = rg_tape(st, e);
-    const uint64_t key = nv::hash4(c.seed, (uint64_t)(c.env_index_base + e), (uint64_t)st.episode[e], 0x4D4150ULL);
+    const uint64_t key = rg_key(c.seed, (uint64_t)(c.env_index_base + e), (uint64_t)st.episode[e], 0x4D4150ULL);
     double w = c.obstacle_width_lo + (c.obstacle_width_hi - c.obstacle_width_lo) * rg_t(tape, NAVSIM_DRAW_OBSTACLE_WIDTH, key, 0);
     const int hw = (int)(10.0 * w);
     int span = live - 2 * hw - 3;
     span = span < 1 ? 1 : span;
     const int obs_hi = c.obstacle_number_hi > c.obstacle_number ? c.obstacle_number_hi : c.obstacle_number;
     int n_obs = c.obstacle_number + (int)(rg_t(tape, NAVSIM_DRAW_OBSTACLE_NUMBER,
-                                               nv::hash4(c.seed, (uint64_t)(c.env_index_base + e), (uint64_t)st.episode[e], 0x50524DULL), 0) *
+                                               rg_key(c.seed, (uint64_t)(c.env_index_base + e), (uint64_t)st.episode[e], 0x50524DULL), 0) *
                                           (double)(obs_hi - c.obstacle_number + 1));
     n_obs = n_obs < 64 ? n_obs : 64;
     if (tid < n_obs) {
@@ -181,86 +211,75 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
         ocy[tid] = hw + 2 + (int)(rg_t(tape, NAVSIM_DRAW_MAP + 2 * tid + 1, key, 2 + 2 * (uint64_t)tid) * span);
     }
     __syncthreads();
-    // this workgroup owns the STORED rows [y0, y1): background first, then the parts of the obstacle squares inside them
-    const int rows = (size + kRegenSlices - 1) / kRegenSlices;
-    const int y0 = blockIdx.y * rows, y1 = (y0 + rows < size) ? y0 + rows : size;
-    auto wall = [&](int y, int x) -> uint32_t {                  // border frame of the live map, occupied outside it
-        const int r = live - 1 - y;
-        return (uint32_t)!(y < live && x < live && r >= 5 && r < live - 5 && x >= 5 && x < live - 5);
-    };
-    if ((size & 3) == 0) {                                       // 4 cells per store
-        const int wpr = size >> 2;
-        uint32_t* occ32 = (uint32_t*)occ;
-        for (int idx = y0 * wpr + tid; idx < y1 * wpr; idx += 256) {
-            const int y = idx / wpr, x4 = (idx - y * wpr) * 4;
-            uint32_t wv = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wv |= wall(y, x4 + j) << (8 * j);
-            occ32[idx] = wv;
-        }
-    } else {
-        for (int idx = y0 * size + tid; idx < y1 * size; idx += 256) {
-            const int y = idx / size, x = idx - y * size;
-            occ[idx] = (uint8_t)wall(y, x);
-        }
-    }
-    __syncthreads();
-    const int side = 2 * hw + 1;
-    for (int o = 0; o < n_obs; ++o) {
-        // generator rows cx - hw .. cx + hw (clipped to the live map) are stored rows live - 1 - r
-        const int cx = ocx[o], cy = ocy[o];
-        int ya = live - 1 - (cx + hw), yb = live - 1 - (cx - hw);
-        ya = ya < 0 ? 0 : ya; yb = yb > live - 1 ? live - 1 : yb;
-        ya = ya > y0 ? ya : y0; yb = yb < y1 - 1 ? yb : y1 - 1;
-        for (int idx = tid; idx < (yb - ya + 1) * side; idx += 256) {
-            const int y = ya + idx / side, x = cy - hw + idx % side;
-            if (x >= 0 && x < live) occ[(size_t)y * size + x] = 1;
-        }
-    }
-    // the exact field of this band of rows, from the geometry
-    char* fs = field_scratch + (size_t)b * field_bytes;
-    float* ov = ovf_scratch ? ovf_scratch + (size_t)b * size * size : nullptr;
+    // where the field goes: the arena's own buffers, or this slot's scratch (installed by regen_field_kernel)
+    const bool f32 = c.field_format == NAVSIM_FIELD_F32;
+    char* fs = direct ? (char*)st.field + (size_t)e * field_bytes : field_scratch + (size_t)b * field_bytes;
+    float* ov = direct ? (st.field_overflow ? (float*)st.field_overflow + (size_t)e * size * size : nullptr)
+                       : (ovf_scratch ? ovf_scratch + (size_t)b * size * size : nullptr);
     const int tpr = (size + 7) >> 3;
-    // eight cells per thread at a time, boxes in the outer loop: a box is read from LDS once per eight cells
-    constexpr int CH = 8;
-    for (int base = y0 * size; base < y1 * size; base += 256 * CH) {
-        int rr[CH], qq[CH], d2[CH];
+    const int groups = (size + 7) >> 3;                                  // 8-cell groups per row
+    for (int item = tid; item < (y1 - y0) * groups; item += 256) {      // (row of the band, 8-cell group of the row)
+        const int yy = item / groups, gx = item - yy * groups;
+        const int y = y0 + yy;
+        const int r = live - 1 - y;                                      // generator row (negative: outside the live map)
+        const int x0 = gx << 3;
+        int d2[8];
+        // border frame (and everything outside the live map): m <= 0
+        int mr = r - 4;
+        mr = (live - 5 - r) < mr ? (live - 5 - r) : mr;
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int idx = base + j * 256 + tid;
-            const int y = idx / size, q = idx - y * size;
-            const int r = live - 1 - y;
-            rr[j] = r; qq[j] = q;
-            int m = r - 4;
-            m = (live - 5 - r) < m ? (live - 5 - r) : m;
-            m = (q - 4) < m ? (q - 4) : m;
+        for (int j = 0; j < 8; ++j) {
+            const int q = x0 + j;
+            int m = (q - 4) < mr ? (q - 4) : mr;
             m = (live - 5 - q) < m ? (live - 5 - q) : m;
-            d2[j] = (m > 0) ? m * m : 0;                                        // border frame and beyond: m <= 0
+            d2[j] = (m > 0) ? m * m : 0;
         }
-        for (int o = 0; o < n_obs; ++o) {
-            int x0 = ocx[o] - hw, x1 = ocx[o] + hw, yy0 = ocy[o] - hw, yy1 = ocy[o] + hw;
-            x0 = x0 < 0 ? 0 : x0; yy0 = yy0 < 0 ? 0 : yy0;                     // boxes are drawn clipped to the map
-            x1 = x1 > live - 1 ? live - 1 : x1; yy1 = yy1 > live - 1 ? live - 1 : yy1;
+        for (int o = 0; o < n_obs; ++o) {                                // boxes are drawn clipped to the map
+            int bx0 = ocx[o] - hw, bx1 = ocx[o] + hw, by0 = ocy[o] - hw, by1 = ocy[o] + hw;
+            bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
+            bx1 = bx1 > live - 1 ? live - 1 : bx1; by1 = by1 > live - 1 ? live - 1 : by1;
+            int dr = bx0 - r > r - bx1 ? bx0 - r : r - bx1;
+            dr = dr < 0 ? 0 : dr;
+            const int dr2 = dr * dr;
 #pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                int dr = x0 - rr[j] > rr[j] - x1 ? x0 - rr[j] : rr[j] - x1;
-                dr = dr < 0 ? 0 : dr;
-                int dq = yy0 - qq[j] > qq[j] - yy1 ? yy0 - qq[j] : qq[j] - yy1;
+            for (int j = 0; j < 8; ++j) {
+                const int q = x0 + j;
+                int dq = by0 - q > q - by1 ? by0 - q : q - by1;
                 dq = dq < 0 ? 0 : dq;
-                const int v = dr * dr + dq * dq;
-                d2[j] = (d2[j] > 0 && v < d2[j]) ? v : d2[j];
+                const int v = dr2 + dq * dq;
+                d2[j] = v < d2[j] ? v : d2[j];
             }
         }
+        const bool whole = x0 + 8 <= size;                               // the last group of a ragged row is partial
+        if (occ) {
+            if (whole && ((size & 7) == 0)) {
+                uint32_t lo = 0, hi = 0;
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int idx = base + j * 256 + tid;
-            if (idx >= y1 * size) continue;
-            const int y = idx / size, x = qq[j];                                // the stored orientation (flipud)
-            if (c.field_format == NAVSIM_FIELD_F32) {
-                ((float*)fs)[(size_t)y * size + x] = sqrtf((float)d2[j]);
+                for (int j = 0; j < 4; ++j) { lo |= (uint32_t)(d2[j] == 0) << (8 * j); hi |= (uint32_t)(d2[4 + j] == 0) << (8 * j); }
+                *(uint2*)(occ + (size_t)y * size + x0) = make_uint2(lo, hi);
             } else {
-                ((uint16_t*)fs)[FieldU16T::index(x, y, tpr)] = (uint16_t)(d2[j] >= 65535 ? 0xFFFF : d2[j]);
-                if (ov) ov[(size_t)y * size + x] = sqrtf((float)d2[j]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (x0 + j < size) occ[(size_t)y * size + x0 + j] = (uint8_t)(d2[j] == 0);
+            }
+        }
+        if (f32) {
+            float* dst = (float*)fs + (size_t)y * size + x0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (x0 + j < size) dst[j] = sqrtf((float)d2[j]);
+        } else {
+            // one tile row of the packed field = 8 cells = 16 bytes (padding cells of an edge tile included: they are
+            // never read, and d2 of a cell outside the map is 0 here)
+            uint32_t pk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t a = (uint32_t)(d2[2 * j] >= 65535 ? 0xFFFF : d2[2 * j]);
+                const uint32_t bq = (uint32_t)(d2[2 * j + 1] >= 65535 ? 0xFFFF : d2[2 * j + 1]);
+                pk[j] = a | (bq << 16);
+            }
+            *(uint4*)((uint16_t*)fs + FieldU16T::index(x0, y, tpr)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            if (ov) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (x0 + j < size) ov[(size_t)y * size + x0 + j] = sqrtf((float)d2[j]);
             }
         }
     }
@@ -369,16 +388,52 @@ __device__ __forceinline__ bool spawn_in_discomfort(const navsim_config& c, cons
     return __syncthreads_or(bad) != 0;
 }
 
-// install the new field, draw the start / goal table, the robot and the pedestrians
+// rg_sample with its 64 tries on the 64 lanes of ONE wavefront (the whole wavefront calls; every lane returns the same
+// x, y, n).  Try t is lane t: its two draws are rg_u(key, n + 2t) and rg_u(key, n + 2t + 1) either way; the first
+// lane whose cell passes is the sequential loop's answer, and without one the FIRST lane holding the best clearance
+// (the loop's `d > bd` keeps the earliest maximum).  n advances as the loop would have: 2 per try made.
+// The sequential form reads up to 64 cells one after the other (a microsecond each); this one reads them at once.
 template <typename Field>
-__global__ __launch_bounds__(256) void regen_commit_kernel(navsim_config c, navsim_state st,
+__device__ __forceinline__ void rg_sample_wave(const navsim_config& c, const Field& f, int size, uint64_t key, uint64_t& n,
+                                               double clr, int kind, double rx, double ry, double dmin, double dmax,
+                                               double& x, double& y) {
+    const int lane = (int)threadIdx.x & 63;
+    const int i = (int)(rg_u(key, n + 2 * (uint64_t)lane) * size), j = (int)(rg_u(key, n + 2 * (uint64_t)lane + 1) * size);
+    const float d = f.at(i, j);
+    const double px = ((double)i + 0.5) * c.resolution + c.origin_x;
+    const double py = ((double)j + 0.5) * c.resolution + c.origin_y;
+    bool ok = (double)d >= clr;
+    if (ok && kind == 1) ok = rg_start_ok(px, py, rx, ry, dmin);
+    if (ok && kind == 2) ok = rg_goal_ok(rx, ry, px, py, dmin, dmax);
+    const unsigned long long okm = __ballot(ok);
+    int t;
+    if (okm) {
+        t = __ffsll(okm) - 1;
+        n += 2 * (uint64_t)(t + 1);
+    } else {
+        float m = d;
+        for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+        t = __ffsll((unsigned long long)__ballot(d == m)) - 1;
+        n += 128;
+    }
+    x = __shfl(px, t, 64);
+    y = __shfl(py, t, 64);
+}
+
+// draw the start / goal table, the robot (with reset()'s first-scan test) and the pedestrians of a regenerated arena.
+// Round 3: 1024 threads = 16 wavefronts; a table entry or a pedestrian is ONE wavefront (rg_sample_wave: its 64 tries
+// at once) and the first-scan test runs a beam per thread -- 68 us of dependent reads became what follows.
+constexpr int kCommitBlock = 1024;
+template <typename Field>
+__global__ __launch_bounds__(kCommitBlock) void regen_commit_kernel(navsim_config c, navsim_state st,
                                                            const int* __restrict__ count, const int* __restrict__ list,
                                                            const char* __restrict__ field_scratch, size_t field_bytes,
                                                            const int* __restrict__ kind) {
     __shared__ double robot_xy[2];
     const int b = blockIdx.x;
     if (b >= *count) return;
-    const int e = list[b], tid = threadIdx.x;
+    const int e = list[b], tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int kWaves = kCommitBlock / 64;
     const int size = live_size(c, kind, b);
     const int N = c.max_peds, K = c.n_spawn, P = NAVSIM_MAX_WAYPOINTS;
     const Field f(st.field, st.field_overflow, e, c.map_h, c.map_w);
@@ -386,18 +441,20 @@ __global__ __launch_bounds__(256) void regen_commit_kernel(navsim_config c, navs
     double* sp = (double*)st.spawn_pose + (size_t)e * K * 3;
     double* sg = (double*)st.spawn_goal + (size_t)e * K * 2;
     const double clr = c.spawn_clearance / c.resolution;
-    for (int k = tid; k < K; k += 256) {
-        uint64_t key = nv::hash4(c.seed, genv, ep, 0x53504157ULL + (uint64_t)k), n = 0;
+    for (int k = wave; k < K; k += kWaves) {
+        uint64_t key = rg_key(c.seed, genv, ep, 0x53504157ULL + (uint64_t)k), n = 0;
         double x, y, gx, gy;
-        rg_sample(c, f, size, key, n, clr, 0, 0, 0, 0, 0, x, y);
+        rg_sample_wave(c, f, size, key, n, clr, 0, 0, 0, 0, 0, x, y);
         double th = nv::kTwoPi * rg_u(key, n++);
-        rg_sample(c, f, size, key, n, clr, 2, x, y, c.min_goal_dist, c.max_goal_dist, gx, gy);
-        sp[3 * k] = x; sp[3 * k + 1] = y; sp[3 * k + 2] = th;
-        sg[2 * k] = gx; sg[2 * k + 1] = gy;
+        rg_sample_wave(c, f, size, key, n, clr, 2, x, y, c.min_goal_dist, c.max_goal_dist, gx, gy);
+        if (lane == 0) {
+            sp[3 * k] = x; sp[3 * k + 1] = y; sp[3 * k + 2] = th;
+            sg[2 * k] = gx; sg[2 * k + 1] = gy;
+        }
     }
     __threadfence_block();
     __syncthreads();
-    int idx = (int)(nv::hash4(c.seed, genv, ep, 0x5eedULL) % (uint64_t)K);
+    int idx = (int)(rg_key(c.seed, genv, ep, 0x5eedULL) % (uint64_t)K);
     if (c.regen_check_discomfort)                // env.py:776-781: first table entry from idx on whose first scan is clear
         for (int s_ = 0; s_ < K; ++s_) {         // (block-uniform loop)
             const int j = (idx + s_) % K;
@@ -413,20 +470,22 @@ __global__ __launch_bounds__(256) void regen_commit_kernel(navsim_config c, navs
     int n = (c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
     n = n > N ? N : n;
     const double pclr = c.ped_clearance / c.resolution;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = wave; i < n; i += kWaves) {
         size_t q = (size_t)e * N + i;
-        uint64_t key = nv::hash4(c.seed, genv, ep, 0x504544ULL + (uint64_t)i), m = 0;
+        uint64_t key = rg_key(c.seed, genv, ep, 0x504544ULL + (uint64_t)i), m = 0;
         double x, y, gx, gy;
-        rg_sample(c, f, size, key, m, pclr, 1, robot_xy[0], robot_xy[1], c.ped_min_robot_dist, 0, x, y);
+        rg_sample_wave(c, f, size, key, m, pclr, 1, robot_xy[0], robot_xy[1], c.ped_min_robot_dist, 0, x, y);
         double th = nv::kTwoPi * rg_u(key, m++);
-        rg_sample(c, f, size, key, m, pclr, 2, x, y, c.ped_min_goal_dist, 1.0e300, gx, gy);
-        st.ped_pose[q * 3] = x; st.ped_pose[q * 3 + 1] = y; st.ped_pose[q * 3 + 2] = th;
-        st.ped_vel[q * 2] = 0.0; st.ped_vel[q * 2 + 1] = 0.0;
-        ((double*)st.ped_v_pref)[q] = c.v_pref_lo + (c.v_pref_hi - c.v_pref_lo) * rg_u(key, m++);
-        ((uint8_t*)st.ped_has_legs)[q] = rg_u(key, m++) < c.has_legs_ratio;
-        double* wp = st.ped_waypoints + (q * P) * 2;
-        wp[0] = gx; wp[1] = gy;
-        st.ped_n_waypoints[q] = 1;
+        rg_sample_wave(c, f, size, key, m, pclr, 2, x, y, c.ped_min_goal_dist, 1.0e300, gx, gy);
+        if (lane == 0) {
+            st.ped_pose[q * 3] = x; st.ped_pose[q * 3 + 1] = y; st.ped_pose[q * 3 + 2] = th;
+            st.ped_vel[q * 2] = 0.0; st.ped_vel[q * 2 + 1] = 0.0;
+            ((double*)st.ped_v_pref)[q] = c.v_pref_lo + (c.v_pref_hi - c.v_pref_lo) * rg_u(key, m++);
+            ((uint8_t*)st.ped_has_legs)[q] = rg_u(key, m++) < c.has_legs_ratio;
+            double* wp = st.ped_waypoints + (q * P) * 2;
+            wp[0] = gx; wp[1] = gy;
+            st.ped_n_waypoints[q] = 1;
+        }
     }
 }
 
@@ -702,7 +761,7 @@ __global__ __launch_bounds__(256) void regen_robot_round_kernel(navsim_config c,
         }
         ws.active[q] = 0;
         if (res || round >= 4) continue;
-        uint64_t key = nv::hash4(c.seed, genv, ep, 0x52504C00ULL + (uint64_t)round * 256 + (uint64_t)k), n = 0;
+        uint64_t key = rg_key(c.seed, genv, ep, 0x52504C00ULL + (uint64_t)round * 256 + (uint64_t)k), n = 0;
         double x, y, gx, gy;
         rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, n, 0, 0, 0, 0, 0, x, y);
         rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, n, 2, x, y, c.min_goal_dist, c.max_goal_dist, gx, gy);
@@ -715,7 +774,7 @@ __global__ __launch_bounds__(256) void regen_robot_round_kernel(navsim_config c,
     if (round < 4) return;
     __threadfence_block();
     __syncthreads();
-    int idx = (int)(nv::hash4(c.seed, genv, ep, 0x5eedULL) % (uint64_t)K);
+    int idx = (int)(rg_key(c.seed, genv, ep, 0x5eedULL) % (uint64_t)K);
     {   // first resolved pair from idx on (cyclic) whose first scan is outside the discomfort zone (env.py:776-781);
         // none: the first resolved one; none resolved: idx.  Block-uniform control flow.
         const Field f(st.field, st.field_overflow, e, c.map_h, c.map_w);
@@ -738,7 +797,7 @@ __global__ __launch_bounds__(256) void regen_robot_round_kernel(navsim_config c,
     n = n > N ? N : n;
     for (int i = tid; i < n; i += 256) {
         size_t q = (size_t)e * N + i;
-        uint64_t k0 = nv::hash4(c.seed, genv, ep, 0x504544ULL + (uint64_t)i), m = 0;
+        uint64_t k0 = rg_key(c.seed, genv, ep, 0x504544ULL + (uint64_t)i), m = 0;
         st.ped_pose[q * 3 + 2] = nv::kTwoPi * rg_u(k0, m++);
         ((double*)st.ped_v_pref)[q] = c.v_pref_lo + (c.v_pref_hi - c.v_pref_lo) * rg_u(k0, m++);
         ((uint8_t*)st.ped_has_legs)[q] = rg_u(k0, m++) < c.has_legs_ratio;
@@ -770,7 +829,7 @@ __global__ __launch_bounds__(256) void regen_ped_round_kernel(navsim_config c, n
         if (round > 0 && !res && ws.qnwp[q] > 0) { st.ped_n_waypoints[pq] = ws.qnwp[q]; res = 1; }
         ws.active[q] = 0;
         if (res || round >= 4) continue;
-        uint64_t key = nv::hash4(c.seed, genv, ep, 0x50504C00ULL + (uint64_t)round * 256 + (uint64_t)i), nn = 0;
+        uint64_t key = rg_key(c.seed, genv, ep, 0x50504C00ULL + (uint64_t)round * 256 + (uint64_t)i), nn = 0;
         double x, y, gx, gy;
         rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, nn, 1, rx, ry, c.ped_min_robot_dist, 0, x, y);
         rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, nn, 2, x, y, c.ped_min_goal_dist, 1.0e300, gx, gy);
@@ -858,7 +917,7 @@ __global__ __launch_bounds__(256) void replan_kernel(navsim_config c, navsim_sta
     double* w = st.ped_waypoints + ((size_t)q * P) * 2;
     for (int round = 0; round < 4; ++round) {
         if (tid == 0) {
-            uint64_t key = nv::hash4(c.seed, genv, when, 0x52504E00ULL + (uint64_t)round * 256 + (uint64_t)i), m = 0;
+            uint64_t key = rg_key(c.seed, genv, when, 0x52504E00ULL + (uint64_t)round * 256 + (uint64_t)i), m = 0;
             double gx, gy;
             rgp_cell(c, cost, Wc, Wc, Hc, res_c, key, m, 2, px, py, c.ped_min_goal_dist, 1.0e300, gx, gy);
             goal_s[0] = gx; goal_s[1] = gy;
@@ -896,4 +955,100 @@ __global__ __launch_bounds__(256) void spawn_decisions_kernel(navsim_config c, c
                NAVSIM_MAX_WAYPOINTS, wp_scratch + (size_t)m * NAVSIM_MAX_WAYPOINTS * 2, &nwp_s, nullptr, &plen_s);
     __syncthreads();
     if (tid == 0) code[m] = nwp_s <= 0 ? 3 : ((!ped && !rg_robot_path_ok(plen_s, sx, sy, gx, gy)) ? 4 : 0);
+}
+
+// --------------------------------------------------------------------------------------------
+// navsim_regen_swap (round 3): navsim_regen taken off the step's critical path.  The world an arena gets at the end of
+// its episode depends on (seed, global arena, episode number) only -- never on how the episode went -- so it is
+// generated AHEAD of time into a second, staged navsim_state (the ordinary navsim_regen on that state, episode + 1,
+// on a side stream, while steps run).  When an arena finishes, this kernel installs the staged world: the arena's rows
+// of every array navsim_regen writes are copied from the staged state into the live one, the first observation
+// included, and the arena is marked (want[e] = 1, staged episode + 1) for the next staging pass.  Same selection rule
+// as navsim_regen (lowest indices first, at most cap), same resulting state, bit for bit.
+// Grid (cap, kRegenSlices): slice 0 of a slot moves the small arrays, all slices share the large buffers.
+// --------------------------------------------------------------------------------------------
+struct SwapBig { char* dst; const char* src; size_t bytes; };          // per-arena stride = bytes
+__global__ __launch_bounds__(256) void regen_swap_kernel(navsim_config c, navsim_state live, navsim_state stage,
+                                                         navsim_step_io io, const float* __restrict__ stage_obs,
+                                                         const uint8_t* __restrict__ want, uint8_t* __restrict__ mark,
+                                                         int cap, SwapBig b0, SwapBig b1, SwapBig b2, SwapBig b3) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int total, excl, lo, hi;
+    // eligible: finished AND staged (want[e] == 0).  want[] is only READ here -- every workgroup of the launch must see
+    // the same flags to agree on the selection; what this launch decides is written to mark[] and merged into want[] by
+    // the staging pass (navsim_regen_stage), which the next swap waits for.
+    const int e = regen_slot(io.done, c.n_envs, cap, b, total, want, &excl, &lo, &hi);
+    if (b == 0 && blockIdx.y == 0) {
+        // a finished arena that is not installed now plays its next episode in place (the step respawned it on the old
+        // map and advanced episode[e]); the world staged for it carries a stale episode number: stage it again
+        int pos = excl;
+        for (int a = lo; a < hi; ++a) {
+            if (io.done[a] == 0) continue;
+            const bool elig = want[a] == 0;
+            const bool installed = elig && pos < cap;
+            pos += elig;
+            if (!installed) { stage.episode[a] = live.episode[a] + 1; mark[a] = 1; }
+        }
+    }
+    if (e < 0) return;
+    const SwapBig big[4] = {b0, b1, b2, b3};
+    for (int k = 0; k < 4; ++k) {                            // field, overflow plane, rect records, costmap
+        if (!big[k].dst) continue;
+        const size_t n16 = big[k].bytes / 16;
+        const char* src = big[k].src + (size_t)e * big[k].bytes;
+        char* dst = big[k].dst + (size_t)e * big[k].bytes;
+        if ((((size_t)(uintptr_t)src | (size_t)(uintptr_t)dst | big[k].bytes) & 15) == 0) {
+            const size_t per = (n16 + gridDim.y - 1) / gridDim.y;
+            const size_t lo = blockIdx.y * per, hi = (lo + per < n16) ? lo + per : n16;
+            for (size_t i = lo + tid; i < hi; i += 256) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+        } else {
+            const size_t per = (big[k].bytes + gridDim.y - 1) / gridDim.y;
+            const size_t lo = blockIdx.y * per, hi = (lo + per < big[k].bytes) ? lo + per : big[k].bytes;
+            for (size_t i = lo + tid; i < hi; i += 256) dst[i] = src[i];
+        }
+    }
+    if (blockIdx.y != 0) return;
+    const int N = c.max_peds, K = c.n_spawn, P = NAVSIM_MAX_WAYPOINTS, D = c.n_scan_stack * c.n_beams + NAVSIM_OBS_TAIL;
+    auto row = [&](auto* dst, const auto* src, size_t n) {    // n elements of arena e
+        if (!dst || !src) return;
+        for (size_t i = tid; i < n; i += 256) dst[(size_t)e * n + i] = src[(size_t)e * n + i];
+    };
+    row(live.scan_noise_std, stage.scan_noise_std, 1);
+    row(live.robot_pose, stage.robot_pose, 3);
+    row(live.robot_goal, stage.robot_goal, 2);
+    row(live.prev_action, stage.prev_action, 2);
+    row(live.prev_pose, stage.prev_pose, 3);
+    row(live.n_hist, stage.n_hist, 1);
+    row(live.steps, stage.steps, 1);
+    row((double*)live.spawn_pose, stage.spawn_pose, (size_t)K * 3);
+    row((double*)live.spawn_goal, stage.spawn_goal, (size_t)K * 2);
+    if (c.ped_model != NAVSIM_PED_NONE) {
+        row(live.n_peds, stage.n_peds, 1);
+        row(live.ped_pose, stage.ped_pose, (size_t)N * 3);
+        row(live.ped_vel, stage.ped_vel, (size_t)N * 2);
+        row(live.ped_prev_yaw, stage.ped_prev_yaw, N);
+        row(live.ped_dist, stage.ped_dist, (size_t)N * 3);
+        row((double*)live.ped_v_pref, stage.ped_v_pref, N);
+        row((uint8_t*)live.ped_has_legs, stage.ped_has_legs, N);
+        row(live.ped_waypoints, stage.ped_waypoints, (size_t)N * P * 2);
+        row(live.ped_n_waypoints, stage.ped_n_waypoints, N);
+    }
+    row(io.obs, stage_obs, D);
+    if (tid == 0) {
+        if (io.achieved_goal) { io.achieved_goal[2 * e] = (float)stage.robot_pose[3 * (size_t)e]; io.achieved_goal[2 * e + 1] = (float)stage.robot_pose[3 * (size_t)e + 1]; }
+        if (io.desired_goal) { io.desired_goal[2 * e] = (float)stage.robot_goal[2 * (size_t)e]; io.desired_goal[2 * e + 1] = (float)stage.robot_goal[2 * (size_t)e + 1]; }
+        stage.episode[e] = live.episode[e] + 1;              // the world after THIS one
+        mark[e] = 1;
+    }
+}
+
+// opens a staging pass: what the last swap decided becomes part of want[]
+__global__ __launch_bounds__(256) void regen_merge_want_kernel(uint8_t* __restrict__ want, uint8_t* __restrict__ mark, int E) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < E && mark[e]) { want[e] = 1; mark[e] = 0; }
+}
+// closes a staging pass (navsim_regen on the staged state with want[] as its done flags): the arenas it served are staged
+__global__ __launch_bounds__(256) void regen_clear_want_kernel(const int* __restrict__ count, const int* __restrict__ list,
+                                                               uint8_t* __restrict__ want) {
+    for (int b = threadIdx.x; b < *count; b += 256) want[list[b]] = 0;
 }

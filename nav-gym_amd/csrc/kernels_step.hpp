@@ -681,6 +681,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const Prims prims = {ps.seg, ps.disc, ps.info};
     // longest-first launch order (a scheduling hint: which arena a workgroup takes never changes a result)
     const int e = st.launch_order ? st.launch_order[blockIdx.x] : (int)blockIdx.x;
+    if (e < 0) return;              // navsim_regen's first-observation launch: one workgroup per list slot, -1 = empty slot
     const int tid = threadIdx.x;
     unsigned long long t_begin = 0;
     if (st.arena_cost && tid == 0) t_begin = __builtin_amdgcn_s_memrealtime();

@@ -136,37 +136,37 @@ int march_rule_variant(const navsim_config* c) {
 
 template <int BLOCK, bool PEDS, typename Field, bool RECT, int RULE>
 int launch_step_kernel(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
-                       const uint8_t* mask, size_t lds, hipStream_t s) {
+                       const uint8_t* mask, size_t lds, hipStream_t s, int grid) {
     if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
     const int park = step_park_lanes(c, BLOCK);
-    navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT><<<c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask,
+    navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT><<<grid > 0 ? grid : c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask,
                                                                                     (unsigned)step_lds_scan_bytes(c, park), park);
     return NAVSIM_OK;
 }
 
 template <int BLOCK, bool PEDS, typename Field, bool RECT>
 int launch_step_rule(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
-                     const uint8_t* mask, size_t lds, hipStream_t s) {
+                     const uint8_t* mask, size_t lds, hipStream_t s, int grid) {
     switch (march_rule_variant(c)) {
-        case NAVSIM_MARCH_F32: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F32>(c, st, io, reset_only, mask, lds, s);
+        case NAVSIM_MARCH_F32: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F32>(c, st, io, reset_only, mask, lds, s, grid);
         case kMarchF64Exact32:
             if constexpr (!std::is_same<Field, FieldF32>::value)
-                return launch_step_kernel<BLOCK, PEDS, Field, RECT, kMarchF64Exact32>(c, st, io, reset_only, mask, lds, s);
+                return launch_step_kernel<BLOCK, PEDS, Field, RECT, kMarchF64Exact32>(c, st, io, reset_only, mask, lds, s, grid);
             [[fallthrough]];
-        default: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F64>(c, st, io, reset_only, mask, lds, s);
+        default: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F64>(c, st, io, reset_only, mask, lds, s, grid);
     }
 }
 
 template <int BLOCK, bool PEDS, typename Field>
 int launch_step_field(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
-                      const uint8_t* mask, size_t lds, hipStream_t s) {
-    return st->rect_table ? launch_step_rule<BLOCK, PEDS, Field, true>(c, st, io, reset_only, mask, lds, s)
-                          : launch_step_rule<BLOCK, PEDS, Field, false>(c, st, io, reset_only, mask, lds, s);
+                      const uint8_t* mask, size_t lds, hipStream_t s, int grid) {
+    return st->rect_table ? launch_step_rule<BLOCK, PEDS, Field, true>(c, st, io, reset_only, mask, lds, s, grid)
+                          : launch_step_rule<BLOCK, PEDS, Field, false>(c, st, io, reset_only, mask, lds, s, grid);
 }
 
 template <int BLOCK>
 int launch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
-                const uint8_t* mask, hipStream_t s) {
+                const uint8_t* mask, hipStream_t s, int grid) {
     const bool peds = c->ped_model != NAVSIM_PED_NONE;
     const size_t lds = step_lds_bytes(c, step_park_lanes(c, BLOCK));
     // pedestrians ahead of the step, one wavefront per arena (pays when the chip runs several generations of
@@ -182,24 +182,26 @@ int launch_step(const navsim_config* c, const navsim_state* st, const navsim_ste
         }
     }
     if (c->field_format == NAVSIM_FIELD_U16T && !st->field_overflow) {          // no saturated cell anywhere
-        return peds ? launch_step_field<BLOCK, true, FieldU16TN>(c, st, io, reset_only, mask, lds, s)
-                    : launch_step_field<BLOCK, false, FieldU16TN>(c, st, io, reset_only, mask, lds, s);
+        return peds ? launch_step_field<BLOCK, true, FieldU16TN>(c, st, io, reset_only, mask, lds, s, grid)
+                    : launch_step_field<BLOCK, false, FieldU16TN>(c, st, io, reset_only, mask, lds, s, grid);
     } else if (c->field_format == NAVSIM_FIELD_U16T) {
-        return peds ? launch_step_field<BLOCK, true, FieldU16T>(c, st, io, reset_only, mask, lds, s)
-                    : launch_step_field<BLOCK, false, FieldU16T>(c, st, io, reset_only, mask, lds, s);
+        return peds ? launch_step_field<BLOCK, true, FieldU16T>(c, st, io, reset_only, mask, lds, s, grid)
+                    : launch_step_field<BLOCK, false, FieldU16T>(c, st, io, reset_only, mask, lds, s, grid);
     }
-    return peds ? launch_step_rule<BLOCK, true, FieldF32, false>(c, st, io, reset_only, mask, lds, s)
-                : launch_step_rule<BLOCK, false, FieldF32, false>(c, st, io, reset_only, mask, lds, s);
+    return peds ? launch_step_rule<BLOCK, true, FieldF32, false>(c, st, io, reset_only, mask, lds, s, grid)
+                : launch_step_rule<BLOCK, false, FieldF32, false>(c, st, io, reset_only, mask, lds, s, grid);
 }
 
+// grid > 0: that many workgroups instead of one per arena; st->launch_order then names each workgroup's arena, -1 = none
+// (navsim_regen's first observations: one workgroup per regenerated arena)
 int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
-                  int reset_only, const uint8_t* mask, hipStream_t s) {
+                  int reset_only, const uint8_t* mask, hipStream_t s, int grid = 0) {
     int rc;
     switch (pick_step_block(c)) {
-        case 64:   rc = launch_step<64>(c, st, io, reset_only, mask, s); break;
-        case 256:  rc = launch_step<256>(c, st, io, reset_only, mask, s); break;
-        case 512:  rc = launch_step<512>(c, st, io, reset_only, mask, s); break;
-        case 1024: rc = launch_step<1024>(c, st, io, reset_only, mask, s); break;
+        case 64:   rc = launch_step<64>(c, st, io, reset_only, mask, s, grid); break;
+        case 256:  rc = launch_step<256>(c, st, io, reset_only, mask, s, grid); break;
+        case 512:  rc = launch_step<512>(c, st, io, reset_only, mask, s, grid); break;
+        case 1024: rc = launch_step<1024>(c, st, io, reset_only, mask, s, grid); break;
         default:   return NAVSIM_E_UNSUPPORTED;
     }
     return rc != NAVSIM_OK ? rc : launch_status();
@@ -629,18 +631,24 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     off = (off + 255) & ~(size_t)255;
     int* kind = (int*)(w + off);
     off += (size_t)M * sizeof(int);
-    regen_select_kernel<<<1, 1024, 0, s>>>(io->done, c->n_envs, M, count, list, mask);
-    regen_indoor_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, grids, kind);
+    (void)mask;
+    // opens the call: every workgroup selects its arena from the done flags (list[b], -1 = none; count), draws the
+    // per-episode parameters and the map kind, grows the corridor tree of a corridor map
+    regen_indoor_kernel<<<M, 256, 0, s>>>(*c, *st, io->done, M, count, list, grids, kind);
     float* ovf_scratch = nullptr;                           // exact float plane of the new maps (large packed maps)
     if (c->field_format == NAVSIM_FIELD_U16T && st->field_overflow) {
         off = (off + 255) & ~(size_t)255;
         ovf_scratch = (float*)(w + off);
         off += (size_t)M * cells * sizeof(float);
     }
-    if (c->field_format == NAVSIM_FIELD_U16T) (void)hipMemsetAsync(fscratch, 0xFF, fbytes * (size_t)M, s);
+    // Outdoor maps only and no rect records to rebuild: the field of a new map is written straight into the arena's
+    // own buffers (no per-slot scratch, no copy kernel), and the occupancy scratch only if a costmap wants it.
+    const bool direct = !(c->regen_indoor_ratio > 0.0) && !st->rect_table;
+    const bool need_occ = !direct || c->regen_plan || st->costmap;
+    if (!direct && c->field_format == NAVSIM_FIELD_U16T) (void)hipMemsetAsync(fscratch, 0xFF, fbytes * (size_t)M, s);
     // maps and, for outdoor maps, their exact field from the geometry; corridor maps go through the distance transform
-    regen_maps_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>(*c, *st, count, list, occ, grids, kind, fscratch, fbytes,
-                                                            ovf_scratch);
+    regen_maps_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>(*c, *st, count, list, need_occ ? occ : nullptr, grids, kind,
+                                                            fscratch, fbytes, ovf_scratch, direct ? 1 : 0);
     if (c->regen_indoor_ratio > 0.0) {
         dt_columns_kernel<<<dim3((W + 63) / 64, M), 64 * kColSeg, 0, s>>>(occ, cols, H, W, count, kind);
         if (c->field_format == NAVSIM_FIELD_F32)
@@ -655,10 +663,12 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         launch_build_rects(occ, M, H, W, fscratch, fbytes, c->field_format, ovf_scratch, (uint4*)st->rect_table, rect_ws,
                            count, list, s);
     }
-    regen_field_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>((char*)st->field, count, list, fscratch, fbytes);
-    if (ovf_scratch)
-        regen_field_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>((char*)st->field_overflow, count, list,
-                                                                (const char*)ovf_scratch, cells * sizeof(float));
+    if (!direct) {
+        regen_field_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>((char*)st->field, count, list, fscratch, fbytes);
+        if (ovf_scratch)
+            regen_field_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>((char*)st->field_overflow, count, list,
+                                                                    (const char*)ovf_scratch, cells * sizeof(float));
+    }
     if (c->regen_plan) {
         const int Hc = H / 5, Wc = W / 5, P = NAVSIM_MAX_WAYPOINTS;
         const size_t cc = (size_t)Hc * Wc;
@@ -699,15 +709,57 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     }
     if (!c->regen_plan) {
         if (c->field_format == NAVSIM_FIELD_F32)
-            regen_commit_kernel<FieldF32><<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes, kind);
+            regen_commit_kernel<FieldF32><<<M, kCommitBlock, 0, s>>>(*c, *st, count, list, fscratch, fbytes, kind);
         else
-            regen_commit_kernel<FieldU16T><<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes, kind);
+            regen_commit_kernel<FieldU16T><<<M, kCommitBlock, 0, s>>>(*c, *st, count, list, fscratch, fbytes, kind);
     }
     if (launch_status() != NAVSIM_OK) return NAVSIM_E_LAUNCH;
-    // first observation of the new episodes; the other arenas keep the row the step just wrote
+    // first observation of the new episodes: ONE workgroup per list slot (list[b] = its arena, -1 = empty slot); the
+    // other arenas keep the row the step just wrote -- nothing is launched for them
     navsim_step_io io2 = *io;
     io2.obs_prev = io->obs;
-    return dispatch_step(c, st, &io2, 1, mask, s);
+    navsim_state st2 = *st;
+    st2.launch_order = list;
+    st2.arena_cost = nullptr;
+    return dispatch_step(c, &st2, &io2, 1, nullptr, s, M);
+}
+
+int navsim_regen_swap(const navsim_config* c, const navsim_state* live, const navsim_state* stage, const navsim_step_io* io,
+                      const float* stage_obs, const uint8_t* want, uint8_t* mark, void* stream) {
+    (void)hipGetLastError();
+    if (!c || !live || !stage || !io || !io->done || !io->obs || !stage_obs || !want || !mark) return NAVSIM_E_ARG;
+    if (c->regen_cap < 1 || c->n_spawn < 1 || !c->auto_reset) return NAVSIM_E_ARG;
+    if (!live->field || !stage->field || !live->episode || !stage->episode || !live->spawn_pose || !stage->spawn_pose ||
+        !live->spawn_goal || !stage->spawn_goal || !stage->robot_pose || !stage->robot_goal)
+        return NAVSIM_E_ARG;
+    // the two states must hold the same optional buffers
+    if ((live->field_overflow != nullptr) != (stage->field_overflow != nullptr) ||
+        (live->rect_table != nullptr) != (stage->rect_table != nullptr) ||
+        (live->costmap != nullptr) != (stage->costmap != nullptr))
+        return NAVSIM_E_ARG;
+    if (c->n_envs == 0) return NAVSIM_OK;
+    const int H = c->map_h, W = c->map_w;
+    SwapBig big[4] = {};
+    big[0] = {(char*)live->field, (const char*)stage->field, navsim_field_bytes(1, H, W, c->field_format)};
+    if (live->field_overflow) big[1] = {(char*)live->field_overflow, (const char*)stage->field_overflow, (size_t)H * W * sizeof(float)};
+    if (live->rect_table) big[2] = {(char*)live->rect_table, (const char*)stage->rect_table, navsim_rect_table_bytes(1, H, W)};
+    if (live->costmap) big[3] = {(char*)live->costmap, (const char*)stage->costmap, (size_t)(H / 5) * (W / 5)};
+    regen_swap_kernel<<<dim3(c->regen_cap, kRegenSlices), 256, 0, (hipStream_t)stream>>>(*c, *live, *stage, *io, stage_obs, want, mark,
+                                                                                        c->regen_cap, big[0], big[1], big[2], big[3]);
+    return launch_status();
+}
+
+int navsim_regen_stage(const navsim_config* c, const navsim_state* stage, const navsim_step_io* io, uint8_t* want, uint8_t* mark,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    (void)hipGetLastError();
+    if (!c || !stage || !io || !want || !mark || !workspace || io->done != want) return NAVSIM_E_ARG;
+    if (c->n_envs == 0) return NAVSIM_OK;
+    regen_merge_want_kernel<<<(c->n_envs + 255) / 256, 256, 0, (hipStream_t)stream>>>(want, mark, c->n_envs);
+    const int rc = navsim_regen(c, stage, io, workspace, workspace_bytes, stream);
+    if (rc != NAVSIM_OK) return rc;
+    const int* count = (const int*)workspace;                // navsim_regen's selection: count, list
+    regen_clear_want_kernel<<<1, 256, 0, (hipStream_t)stream>>>(count, count + 4, want);
+    return launch_status();
 }
 
 size_t navsim_replan_workspace_bytes(const navsim_config* c, int32_t max_queries) {

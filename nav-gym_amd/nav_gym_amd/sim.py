@@ -420,9 +420,83 @@ class NavSim(object):
         self.cur = 1 - self.cur
         return self.obs, self.out
 
+    # arrays navsim_regen writes: the staged state of enable_pregen() owns a copy of each
+    STAGED = ("field", "field_overflow", "rect_table", "costmap", "scan_noise_std", "robot_pose", "robot_goal", "prev_action",
+              "prev_pose", "n_hist", "steps", "episode", "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist",
+              "ped_v_pref", "ped_has_legs", "ped_waypoints", "ped_n_waypoints", "spawn_pose", "spawn_goal")
+
+    def enable_pregen(self, scratch_bytes=4 << 30):
+        """navsim_regen off the step's critical path (include/navsim.h navsim_regen_swap): the world every arena will
+        get at the end of its CURRENT episode -- a function of (seed, global arena, episode number) only -- is generated
+        ahead of time into a second, staged state by the ordinary navsim_regen on a side stream; regen() then only
+        installs the staged worlds of the finished arenas (one copy kernel on the caller's stream) and queues the next
+        staging pass.  Same state, same observations as navsim_regen, bit for bit.  Needs cfg.auto_reset = 1."""
+        import torch
+        if not self.cfg.auto_reset:
+            raise ValueError("enable_pregen needs cfg.auto_reset = 1 (the step advances episode[e] when an arena finishes)")
+        E = self.cfg.n_envs
+        self.stage_t = {k: self.t[k].clone() for k in self.STAGED if k in self.t}
+        self.stage_t["episode"] = self.t["episode"] + 1
+        self.stage_st = abi.NavsimState()
+        C.memmove(C.byref(self.stage_st), C.byref(self.st), C.sizeof(self.st))
+        for k, v in self.stage_t.items():
+            setattr(self.stage_st, k, v.data_ptr())
+        self.stage_st.arena_cost = None
+        self.stage_st.launch_order = None
+        self.stage_obs = torch.zeros_like(self.obs_buf[0])
+        self.want = torch.ones(E, dtype=torch.uint8, device=self.device)
+        self.mark = torch.zeros(E, dtype=torch.uint8, device=self.device)
+        self.stage_io = abi.NavsimStepIO()
+        self.stage_io.obs = self.stage_obs.data_ptr()
+        self.stage_io.done = self.want.data_ptr()
+        # the first staging of every arena, in chunks of as many arenas as the scratch allows (reset path)
+        cfg = self.cfg.copy()
+        cfg.regen_cap = 1
+        per = self.lib.navsim_regen_workspace_bytes(C.byref(cfg))
+        cfg.regen_cap = 2
+        per = max(self.lib.navsim_regen_workspace_bytes(C.byref(cfg)) - per, 1)
+        cfg.regen_cap = int(max(1, min(E, scratch_bytes // per)))
+        ws = torch.empty(self.lib.navsim_regen_workspace_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
+        for _ in range((E + cfg.regen_cap - 1) // cfg.regen_cap):
+            check(self.lib.navsim_regen_stage(C.byref(cfg), C.byref(self.stage_st), C.byref(self.stage_io), _ptr(self.want),
+                                              _ptr(self.mark), _ptr(ws), ws.numel(), _stream()), "navsim_regen_stage (first staging)")
+        torch.cuda.current_stream().synchronize()
+        assert int(self.want.sum().item()) == 0
+        del ws
+        nbytes = self.lib.navsim_regen_workspace_bytes(C.byref(self.cfg))
+        self.stage_ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        # a high-priority stream: its few small kernels go first whenever wave slots free up.  (Measured and dropped:
+        # CU-masked streams -- hipExtStreamCreateWithCUMask, 8 / 16 / 32 CUs for the staging passes and the rest for the
+        # steps -- did not make the passes overlap a step kernel that fills the chip: c5 3.0 M env-steps/s either way.)
+        self.side = torch.cuda.Stream(device=self.device, priority=-1)
+        self.ev_swapped, self.ev_staged = torch.cuda.Event(), torch.cuda.Event()
+        self.ev_staged.record(torch.cuda.current_stream())
+        self.pregen = True
+
+    def _regen_pregen(self):
+        import torch
+        main = torch.cuda.current_stream()
+        main.wait_event(self.ev_staged)                 # the staging pass that served the arenas of the last swap
+        io = abi.NavsimStepIO()
+        C.memmove(C.byref(io), C.byref(self.io), C.sizeof(io))
+        io.obs = self.obs_buf[self.cur].data_ptr()
+        check(self.lib.navsim_regen_swap(C.byref(self.cfg), C.byref(self.st), C.byref(self.stage_st), C.byref(io),
+                                         _ptr(self.stage_obs), _ptr(self.want), _ptr(self.mark), C.c_void_p(main.cuda_stream)),
+              "navsim_regen_swap")
+        self.ev_swapped.record(main)
+        self.side.wait_event(self.ev_swapped)
+        ws = self.stage_ws
+        check(self.lib.navsim_regen_stage(C.byref(self.cfg), C.byref(self.stage_st), C.byref(self.stage_io), _ptr(self.want),
+                                          _ptr(self.mark), _ptr(ws), ws.numel(), C.c_void_p(self.side.cuda_stream)),
+              "navsim_regen_stage")
+        self.ev_staged.record(self.side)
+        return self.obs
+
     def regen(self):
         """navsim_regen right after step(): finished arenas get a new map, tables, pedestrians, first obs."""
         import torch
+        if getattr(self, "pregen", False):
+            return self._regen_pregen()
         if "regen_ws" not in self.t:
             nbytes = self.lib.navsim_regen_workspace_bytes(C.byref(self.cfg))
             self.t["regen_ws"] = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)

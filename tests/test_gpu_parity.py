@@ -542,6 +542,48 @@ def test_regen_vs_oracle(gpu, fmt, ped_model, plan):
         assert (occupied > 0.3).any() and (occupied < 0.2).any()
 
 
+@pytest.mark.parametrize("fmt,ped_model,plan", [(abi.FIELD_U16T, abi.PED_SFM, 0), (abi.FIELD_F32, abi.PED_NONE, 0),
+                                                (abi.FIELD_U16T, abi.PED_SFM, 1)])
+def test_pregenerated_worlds_equal_navsim_regen(gpu, fmt, ped_model, plan):
+    """NavSim.enable_pregen() (navsim_regen_swap + navsim_regen_stage): the next world of every arena is generated ahead
+    of time on a side stream and only installed when the arena finishes.  The rollout -- observations after every
+    regen and every state array -- equals the ORACLE's synchronous navsim_regen_cpu bit for bit (regen_cap is never
+    exceeded here; arenas do finish twice, so staged worlds of staged worlds are used)."""
+    E, size, N = 40, 200 + 60 * plan, 6
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=ped_model, n_spawn=6,
+                                 auto_reset=1, seed=23, field_format=fmt, regen_cap=E, min_goal_dist=3.0,
+                                 max_goal_dist=8.0, spawn_clearance=0.9, ped_min_robot_dist=2.0, ped_min_goal_dist=4.0,
+                                 regen_plan=plan, regen_indoor_ratio=0.5 if plan else 0.0)
+    gpu.world.lidar_1081(cfg)
+    occ = gpu.world.make_maps(E, size, 23)
+    regenerated = 0
+    twice = np.zeros(E, int)
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=5, steps=70, seed=9,
+                                                     plan_paths=bool(plan) and ped_model != abi.PED_NONE):
+        if t == 0:
+            g.enable_pregen()
+        _eq(go, ro, "obs at step %d" % t)
+        n_done = int(rout["done"].sum())
+        twice += rout["done"].astype(int)
+        go2 = g.regen().cpu().numpy()
+        ro2 = r.regen()
+        _eq(go2, ro2, "obs after the swap at step %d" % t)
+        regenerated += n_done
+        if n_done:
+            gpu.torch.cuda.synchronize()
+            gs = g.numpy_state()
+            for k, v in r.a.items():
+                if k in gs and k not in ("field", "field_overflow", "rect_table"):
+                    if k == "ped_waypoints":      # slots beyond n_waypoints keep whatever the buffer held before
+                        live = np.arange(abi.MAX_WAYPOINTS)[None, None, :] < r.a["ped_n_waypoints"][..., None]
+                        _eq(gs[k][live], v[live], "state %s after the swap at step %d" % (k, t))
+                    else:
+                        _eq(gs[k], v, "state %s after the swap at step %d" % (k, t))
+            if fmt == abi.FIELD_F32:
+                _eq(gs["field"], r.a["field"], "field after the swap at step %d" % t)
+    assert regenerated > 8 and (twice >= 2).any(), (regenerated, twice.max())
+
+
 def test_env_reset_at_the_reference_map_size(gpu):
     """1000 x 1000 cells is the reference's own indoor map size (map_generator.py:108-122).  Such a packed world
     carries the float32 overflow plane (cells >= 256 cells from every obstacle), regenerated with the field, and
