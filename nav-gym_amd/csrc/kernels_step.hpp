@@ -488,29 +488,137 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShar
     discomfort = dc;
 }
 
-// Phase 1 for the pedestrians of one arena (env.py:617-693 with the build-defined social force or external
-// commands): waypoint pop, forces / integration, new goal, leg odometry, state.  Called by every thread of the
-// workgroup (it synchronises); pedestrian i lives on thread i.  Shared by the fused step kernel and by
-// ped_update_kernel, which runs it on one wavefront per arena ahead of the step.
+// ---- pieces of phase 1 for ONE pedestrian (env.py:617-693 with the build-defined social force or external commands),
+// shared by the fused step kernel (pedestrian i on thread i of the arena's workgroup) and by ped_update_kernel (a pack
+// of arenas per workgroup).  Same functions, same operation order: same results.
+// waypoint pop (env.py:633-642); returns the remaining count
+__device__ __forceinline__ int ped_pop_waypoints(double* wp, int nw, const double (&pp)[3]) {
+    while (nw > 1) {
+        double ddx = pp[0] - wp[0], ddy = pp[1] - wp[1];
+        if (sqrt(ddx * ddx + ddy * ddy) < 1.0) {
+            for (int k = 0; k + 1 < nw; ++k) { wp[2 * k] = wp[2 * k + 2]; wp[2 * k + 1] = wp[2 * k + 3]; }
+            nw -= 1;
+        } else break;
+    }
+    return nw;
+}
+// the (i, j) of pair term t of an arena with n pedestrians: the strict upper triangle row by row (n (n - 1) / 2 terms
+// between pedestrians, each evaluated once), then the robot (index n) acting on pedestrian t - n_pp
+__device__ __forceinline__ void ped_pair_index(int t, int n, int& i, int& j) {
+    const int n_pp = n * (n - 1) / 2;
+    if (t < n_pp) {
+        i = 0;
+        int rem = t;
+        while (rem >= n - 1 - i) { rem -= n - 1 - i; ++i; }
+        j = i + 1 + rem;
+    } else {
+        i = t - n_pp; j = n;
+    }
+}
+// pair term t of an arena into its [n, n + 1] table: the term on pedestrian j from pedestrian i is EXACTLY minus the term
+// on i from j (every operand of sfm_pair changes sign or stays -- differences, their squares, quotients, the odd atan2
+// of two sign-symmetric products -- and round-to-nearest is symmetric under negation), so each unordered pedestrian
+// pair is evaluated once and stored twice; the robot (index n) only acts, it receives nothing
+__device__ __forceinline__ void ped_pair_term(const navsim_config& c, const PedShared& ps, double2* pair, int n, int t) {
+    int i, j;
+    ped_pair_index(t, n, i, j);
+    double fx, fy;
+    sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
+    pair[i * (n + 1) + j] = make_double2(fx, fy);
+    if (j < n) pair[j * (n + 1) + i] = make_double2(-fx, -fy);
+}
+// forces on pedestrian i and its semi-implicit Euler step: desired + social (its row of the pair
+// table in partner order, or evaluated here when there is no table) + obstacle (distance-field gradient)
+template <typename Field>
+__device__ __forceinline__ void ped_sfm_step(const navsim_config& c, const Field& field, const PedShared& ps,
+                                             const double2* pair, int n, int i, double vpref, const double* wp, double dt,
+                                             double (&pp)[3], double (&pvel)[2]) {
+    double ex = wp[0] - ps.ax[i], ey = wp[1] - ps.ay[i];
+    double L = sqrt(ex * ex + ey * ey);
+    if (L > 1e-9) { ex = ex / L; ey = ey / L; } else { ex = 0.0; ey = 0.0; }
+    double fdx = (vpref * ex - ps.avx[i]) / c.sfm_tau;
+    double fdy = (vpref * ey - ps.avy[i]) / c.sfm_tau;
+    double fsx = 0.0, fsy = 0.0;
+    for (int j = 0; j <= n; ++j) {
+        if (j == i) continue;
+        double fx, fy;
+        if (pair) { double2 f = pair[i * (n + 1) + j]; fx = f.x; fy = f.y; }
+        else sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
+        fsx += fx;
+        fsy += fy;
+    }
+    double fox = 0.0, foy = 0.0;
+    {
+        const int H = c.map_h, W = c.map_w;
+        int ci, cj;
+        nv::xy_to_ij(ps.ax[i], ps.ay[i], c, ci, cj);
+        ci = ci > W - 1 ? W - 1 : ci;
+        cj = cj > H - 1 ? H - 1 : cj;
+        int il_ = ci > 0 ? ci - 1 : 0, ir = ci < W - 1 ? ci + 1 : W - 1;
+        int jl = cj > 0 ? cj - 1 : 0, jr = cj < H - 1 ? cj + 1 : H - 1;
+        double d = (double)field.at(ci, cj) * c.resolution;
+        double gx = (double)field.at(ir, cj) - (double)field.at(il_, cj);
+        double gy = (double)field.at(ci, jr) - (double)field.at(ci, jl);
+        double gl = sqrt(gx * gx + gy * gy);
+        if (gl > 0.0) {
+            double mag = nv::exp_neg(-(d - c.sfm_agent_radius) / c.sfm_sigma_obstacle);
+            fox = mag * (gx / gl);
+            foy = mag * (gy / gl);
+        }
+    }
+    double accx = c.sfm_k_desired * fdx + c.sfm_k_social * fsx + c.sfm_k_obstacle * fox;
+    double accy = c.sfm_k_desired * fdy + c.sfm_k_social * fsy + c.sfm_k_obstacle * foy;
+    double vx = ps.avx[i] + accx * dt;
+    double vy = ps.avy[i] + accy * dt;
+    double sp = sqrt(vx * vx + vy * vy);
+    if (sp > vpref) {
+        double k = (sp > 0.0) ? vpref / sp : 0.0;
+        vx = vx * k; vy = vy * k;
+    }
+    pp[0] = pp[0] + vx * dt;
+    pp[1] = pp[1] + vy * dt;
+    double sp2 = sqrt(vx * vx + vy * vy);
+    if (sp2 > 1e-6) pp[2] = nv::mod_2pi(nv::atan2_(vy, vx));
+    pvel[0] = vx; pvel[1] = vy;
+}
+// new goal at the final waypoint (env.py:667-680: table draw, or wait for navsim_replan), leg odometry and the
+// pedestrian's obs yaw (env.py:683-693), state
+__device__ __forceinline__ void ped_finish(const navsim_config& c, const navsim_state& st, int e, int i, size_t pq, double* wp,
+                                           int nw, double dt, uint64_t genv, uint64_t steps_now, const double (&pp)[3],
+                                           const double (&pvel)[2]) {
+    double ddx = pp[0] - wp[2 * (nw - 1)], ddy = pp[1] - wp[2 * (nw - 1) + 1];
+    if (sqrt(ddx * ddx + ddy * ddy) < 0.5 && c.n_spawn > 0 && st.spawn_pose && !st.costmap) {
+        uint64_t h = nv::hash4(c.seed, genv, (uint64_t)i + 1000, steps_now);
+        for (int tries = 0; tries < c.n_spawn; ++tries) {
+            int idx = (int)((h + (uint64_t)tries) % (uint64_t)c.n_spawn);
+            const double* cand = st.spawn_pose + ((size_t)e * c.n_spawn + idx) * 3;
+            double gx = cand[0] - pp[0], gy = cand[1] - pp[1];
+            if (sqrt(gx * gx + gy * gy) > 10.0) {
+                wp[0] = cand[0]; wp[1] = cand[1]; nw = 1;
+                break;
+            }
+        }
+    }
+    st.ped_n_waypoints[pq] = nw;
+    double dist[3] = {st.ped_dist[pq * 3], st.ped_dist[pq * 3 + 1], st.ped_dist[pq * 3 + 2]};
+    nv::leg_odometry(pp, pvel, st.ped_prev_yaw[pq], dt, dist);
+    st.ped_dist[pq * 3] = dist[0]; st.ped_dist[pq * 3 + 1] = dist[1]; st.ped_dist[pq * 3 + 2] = dist[2];
+    st.ped_prev_yaw[pq] = nv::wrap_pi(pp[2]);
+    st.ped_pose[pq * 3] = pp[0]; st.ped_pose[pq * 3 + 1] = pp[1]; st.ped_pose[pq * 3 + 2] = pp[2];
+    st.ped_vel[pq * 2] = pvel[0]; st.ped_vel[pq * 2 + 1] = pvel[1];
+}
+
+// Phase 1 for the pedestrians of one arena inside the fused step kernel.  Called by every thread of the workgroup
+// (it synchronises); pedestrian i lives on thread i.
 template <int BLOCK, typename Field>
 __device__ __forceinline__ void ped_phase(const navsim_config& c, const navsim_state& st, const Field& field, int e,
                                           int n, int tid, bool is_ped, size_t pq, double dt, uint64_t genv,
                                           uint64_t steps_now, const double* old_rp, double prev_v, const PedShared& ps,
                                           char* pair_scratch, unsigned pair_bytes, double (&pp)[3], double (&pvel)[2]) {
-    const int N = c.max_peds, P = NAVSIM_MAX_WAYPOINTS;
-    (void)N;
+    const int P = NAVSIM_MAX_WAYPOINTS;
     double* wp = st.ped_waypoints ? st.ped_waypoints + (pq * P) * 2 : nullptr;
     int nw = 1;
-    if (is_ped) {
-        nw = st.ped_n_waypoints[pq];
-        while (nw > 1) {                                   // env.py:633-642
-            double ddx = pp[0] - wp[0], ddy = pp[1] - wp[1];
-            if (sqrt(ddx * ddx + ddy * ddy) < 1.0) {
-                for (int k = 0; k + 1 < nw; ++k) { wp[2 * k] = wp[2 * k + 2]; wp[2 * k + 1] = wp[2 * k + 3]; }
-                nw -= 1;
-            } else break;
-        }
-    }
+    if (is_ped) nw = ped_pop_waypoints(wp, st.ped_n_waypoints[pq], pp);
     if (c.ped_model == NAVSIM_PED_SFM) {
         // stage every agent's position / velocity at time t (pedestrians, then the robot)
         if (is_ped) { ps.ax[tid] = pp[0]; ps.ay[tid] = pp[1]; ps.avx[tid] = pvel[0]; ps.avy[tid] = pvel[1]; }
@@ -521,152 +629,116 @@ __device__ __forceinline__ void ped_phase(const navsim_config& c, const navsim_s
             ps.avx[n] = prev_v * cs; ps.avy[n] = prev_v * s;
         }
         __syncthreads();
-        // the n*(n+1) pair terms are independent: spread them over the whole workgroup (LDS scratch
-        // = the scan's dir/rng area, free until the march), then every pedestrian adds its row in
-        // partner order -- the same sums, in the same order, as a sequential loop
+        // the n (n - 1) / 2 + n pair terms are independent: spread them over the whole workgroup (LDS scratch = the
+        // scan's dir/rng area, free until the march), then every pedestrian adds its row in partner order -- the same
+        // sums, in the same order, as a sequential loop
         double2* pair = (double2*)pair_scratch;
         const bool pair_par = pair_bytes >= (unsigned)(n * (n + 1)) * sizeof(double2) && n > 1;
         if (pair_par) {
-            // The term on pedestrian j from pedestrian i is EXACTLY minus the term on i from j: every operand
-            // of sfm_pair changes sign or stays (differences, their squares, quotients, the odd atan2 of two
-            // sign-symmetric products), and round-to-nearest is symmetric under negation.  So each unordered
-            // pedestrian pair is evaluated once and stored twice; the robot (index n) only acts, it receives
-            // nothing.  n (n - 1) / 2 + n evaluations instead of n (n + 1).
-            const int n_pp = n * (n - 1) / 2;
-            for (int t = tid; t < n_pp + n; t += BLOCK) {
-                int i, j;
-                if (t < n_pp) {                                 // row-major walk of the strict upper triangle
-                    i = 0;
-                    int rem = t;
-                    while (rem >= n - 1 - i) { rem -= n - 1 - i; ++i; }
-                    j = i + 1 + rem;
-                } else {
-                    i = t - n_pp; j = n;
-                }
-                double fx, fy;
-                sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
-                pair[i * (n + 1) + j] = make_double2(fx, fy);
-                if (j < n) pair[j * (n + 1) + i] = make_double2(-fx, -fy);
-            }
+            const int n_terms = n * (n - 1) / 2 + n;
+            for (int t = tid; t < n_terms; t += BLOCK) ped_pair_term(c, ps, pair, n, t);
             __syncthreads();
         }
-        if (is_ped) {
-            const int i = tid;
-            double vpref = st.ped_v_pref[pq];
-            double ex = wp[0] - ps.ax[i], ey = wp[1] - ps.ay[i];
-            double L = sqrt(ex * ex + ey * ey);
-            if (L > 1e-9) { ex = ex / L; ey = ey / L; } else { ex = 0.0; ey = 0.0; }
-            double fdx = (vpref * ex - ps.avx[i]) / c.sfm_tau;
-            double fdy = (vpref * ey - ps.avy[i]) / c.sfm_tau;
-            double fsx = 0.0, fsy = 0.0;
-            for (int j = 0; j <= n; ++j) {
-                if (j == i) continue;
-                double fx, fy;
-                if (pair_par) { double2 f = pair[i * (n + 1) + j]; fx = f.x; fy = f.y; }
-                else sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
-                fsx += fx;
-                fsy += fy;
-            }
-            double fox = 0.0, foy = 0.0;
-            {
-                const int H = c.map_h, W = c.map_w;
-                int ci, cj;
-                nv::xy_to_ij(ps.ax[i], ps.ay[i], c, ci, cj);
-                ci = ci > W - 1 ? W - 1 : ci;
-                cj = cj > H - 1 ? H - 1 : cj;
-                int il_ = ci > 0 ? ci - 1 : 0, ir = ci < W - 1 ? ci + 1 : W - 1;
-                int jl = cj > 0 ? cj - 1 : 0, jr = cj < H - 1 ? cj + 1 : H - 1;
-                double d = (double)field.at(ci, cj) * c.resolution;
-                double gx = (double)field.at(ir, cj) - (double)field.at(il_, cj);
-                double gy = (double)field.at(ci, jr) - (double)field.at(ci, jl);
-                double gl = sqrt(gx * gx + gy * gy);
-                if (gl > 0.0) {
-                    double mag = nv::exp_neg(-(d - c.sfm_agent_radius) / c.sfm_sigma_obstacle);
-                    fox = mag * (gx / gl);
-                    foy = mag * (gy / gl);
-                }
-            }
-            double accx = c.sfm_k_desired * fdx + c.sfm_k_social * fsx + c.sfm_k_obstacle * fox;
-            double accy = c.sfm_k_desired * fdy + c.sfm_k_social * fsy + c.sfm_k_obstacle * foy;
-            double vx = ps.avx[i] + accx * dt;
-            double vy = ps.avy[i] + accy * dt;
-            double sp = sqrt(vx * vx + vy * vy);
-            if (sp > vpref) {
-                double k = (sp > 0.0) ? vpref / sp : 0.0;
-                vx = vx * k; vy = vy * k;
-            }
-            pp[0] = pp[0] + vx * dt;
-            pp[1] = pp[1] + vy * dt;
-            double sp2 = sqrt(vx * vx + vy * vy);
-            if (sp2 > 1e-6) pp[2] = nv::mod_2pi(nv::atan2_(vy, vx));
-            pvel[0] = vx; pvel[1] = vy;
-        }
+        if (is_ped) ped_sfm_step(c, field, ps, pair_par ? pair : nullptr, n, tid, st.ped_v_pref[pq], wp, dt, pp, pvel);
     } else if (c.ped_model == NAVSIM_PED_EXTERNAL && is_ped) {
         const double* cmd = st.ped_cmd + pq * 2;
         nv::set_vel(pp, cmd[0], cmd[1], dt, 0.0, pvel);     // env.py:662
     }
-    if (is_ped) {
-        // ---- new goal at the final waypoint (env.py:667-680): table draw, or wait for navsim_replan
-        double ddx = pp[0] - wp[2 * (nw - 1)], ddy = pp[1] - wp[2 * (nw - 1) + 1];
-        if (sqrt(ddx * ddx + ddy * ddy) < 0.5 && c.n_spawn > 0 && st.spawn_pose && !st.costmap) {
-            uint64_t h = nv::hash4(c.seed, genv, (uint64_t)tid + 1000, steps_now);
-            for (int tries = 0; tries < c.n_spawn; ++tries) {
-                int idx = (int)((h + (uint64_t)tries) % (uint64_t)c.n_spawn);
-                const double* cand = st.spawn_pose + ((size_t)e * c.n_spawn + idx) * 3;
-                double gx = cand[0] - pp[0], gy = cand[1] - pp[1];
-                if (sqrt(gx * gx + gy * gy) > 10.0) {
-                    wp[0] = cand[0]; wp[1] = cand[1]; nw = 1;
-                    break;
-                }
-            }
-        }
-        st.ped_n_waypoints[pq] = nw;
-        // ---- leg odometry, then the pedestrian's obs yaw (env.py:683-693)
-        double dist[3] = {st.ped_dist[pq * 3], st.ped_dist[pq * 3 + 1], st.ped_dist[pq * 3 + 2]};
-        nv::leg_odometry(pp, pvel, st.ped_prev_yaw[pq], dt, dist);
-        st.ped_dist[pq * 3] = dist[0]; st.ped_dist[pq * 3 + 1] = dist[1]; st.ped_dist[pq * 3 + 2] = dist[2];
-        st.ped_prev_yaw[pq] = nv::wrap_pi(pp[2]);
-        st.ped_pose[pq * 3] = pp[0]; st.ped_pose[pq * 3 + 1] = pp[1]; st.ped_pose[pq * 3 + 2] = pp[2];
-        st.ped_vel[pq * 2] = pvel[0]; st.ped_vel[pq * 2 + 1] = pvel[1];
-    }
+    if (is_ped) ped_finish(c, st, e, tid, pq, wp, nw, dt, genv, steps_now, pp, pvel);
 }
 
-// The pedestrians of every arena, one wavefront per arena, launched ahead of the fused step.  Inside the step
-// this phase is a third of a workgroup's lifetime during which three of its four wavefronts only hold their
-// slots; here an arena costs one wavefront.  Same device function, same results.
+// The pedestrians of every arena ahead of the fused step (navsim_config.ped_split).  Inside the step this phase is a
+// third of a workgroup's lifetime during which three of its four wavefronts only hold their slots; here it costs what it
+// computes.  Round 3: a workgroup takes a PACK of arenas: arena s of the pack owns threads [s N, (s + 1) N) for its
+// pedestrians, and the pair terms of the whole pack form ONE list walked by all threads (2 x 210 terms over 128
+// threads).  Same functions per pedestrian and per pair as the fused form: same results.
+// (measured on c3, same box, threads x arenas per workgroup: 64 x 1 19.56 M env-steps/s, 64 x 3 17.8, 128 x 1 19.55,
+// 128 x 2 19.94, 256 x 1 19.35: the kernel follows neither its lane utilisation nor its chain length -- it waits for the
+// scattered pedestrian state and field lines; profiles/README.md)
 #ifndef NAVSIM_PED_UPDATE_BLOCK
-#define NAVSIM_PED_UPDATE_BLOCK 64
+#define NAVSIM_PED_UPDATE_BLOCK 128
+#endif
+#ifndef NAVSIM_PED_PACK_MAX
+#define NAVSIM_PED_PACK_MAX 2
 #endif
 constexpr int kPedUpdateBlock = NAVSIM_PED_UPDATE_BLOCK;
+constexpr int kPedPack = 8;
+__host__ __device__ inline int ped_pack(int N) {
+    int g = N > 0 ? kPedUpdateBlock / N : 1;
+    g = g > NAVSIM_PED_PACK_MAX ? NAVSIM_PED_PACK_MAX : g;
+    return g < 1 ? 1 : (g > kPedPack ? kPedPack : g);
+}
+__host__ __device__ inline size_t ped_pair_bytes(int N) { return ((size_t)N * (N + 1) * sizeof(double2) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t ped_slot_bytes(int N) { return ped_pair_bytes(N) + ((ped_lds_bytes(N) + 15) & ~(size_t)15); }
 template <typename Field>
 __global__ __launch_bounds__(kPedUpdateBlock) void ped_update_kernel(navsim_config c, navsim_state st) {
     extern __shared__ __attribute__((aligned(16))) char ped_dyn[];
-    const int e = blockIdx.x, tid = threadIdx.x;
-    const int N = c.max_peds;
-    int n = st.n_peds[e];
-    n = n > N ? N : n;
-    if (n <= 0) return;
-    const unsigned pair_bytes = (unsigned)(((size_t)N * (N + 1) * sizeof(double2) + 15) & ~(size_t)15);
-    const PedShared ps = ped_lds_carve(ped_dyn + pair_bytes, N);
-    const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, c.map_h, c.map_w);
-    const double old_rp[3] = {st.robot_pose[3 * (size_t)e], st.robot_pose[3 * (size_t)e + 1], st.robot_pose[3 * (size_t)e + 2]};
-    const double prev_v = st.prev_action[2 * (size_t)e];
-    const size_t pq = (size_t)e * N + (tid < n ? tid : 0);
-    const bool is_ped = tid < n;
+    __shared__ int slot_n[kPedPack], slot_off[kPedPack + 1];
+    const int lane = threadIdx.x;                                      // thread of the workgroup
+    const int N = c.max_peds, G = ped_pack(N), P = NAVSIM_MAX_WAYPOINTS;
+    const int s = lane / N, i = lane - s * N;                          // arena of the pack, pedestrian of the arena
+    const int e = (int)blockIdx.x * G + s;
+    const bool slot_ok = s < G && e < c.n_envs;
+    int n = slot_ok ? st.n_peds[e] : 0;
+    n = n > N ? N : (n < 0 ? 0 : n);
+    const bool is_ped = slot_ok && i < n;
+    const size_t slot_bytes = ped_slot_bytes(N);
+    char* my = ped_dyn + (size_t)(slot_ok ? s : 0) * slot_bytes;
+    const PedShared ps = ped_lds_carve(my + ped_pair_bytes(N), N);
+    if (lane < kPedPack) slot_n[lane] = 0;
+    __syncthreads();
+    if (slot_ok && i == 0) slot_n[s] = n;
+    const size_t pq = (size_t)(slot_ok ? e : 0) * N + (is_ped ? i : 0);
+    const Field field(st.field, st.field_overflow, c.shared_field ? 0 : (slot_ok ? e : 0), c.map_h, c.map_w);
     double pp[3] = {0.0, 0.0, 0.0}, pvel[2] = {0.0, 0.0};
+    double* wp = st.ped_waypoints + (pq * P) * 2;
+    int nw = 1;
     if (is_ped) {
         pp[0] = st.ped_pose[pq * 3]; pp[1] = st.ped_pose[pq * 3 + 1]; pp[2] = st.ped_pose[pq * 3 + 2];
         pvel[0] = st.ped_vel[pq * 2]; pvel[1] = st.ped_vel[pq * 2 + 1];
+        nw = ped_pop_waypoints(wp, st.ped_n_waypoints[pq], pp);
+    }
+    const double dt = c.time_step;
+    if (c.ped_model == NAVSIM_PED_SFM) {
+        if (is_ped) { ps.ax[i] = pp[0]; ps.ay[i] = pp[1]; ps.avx[i] = pvel[0]; ps.avy[i] = pvel[1]; }
+        if (slot_ok && i == 0 && n > 0) {                              // the robot at time t: entry n of the arena's arrays
+            const double* rp = st.robot_pose + 3 * (size_t)e;
+            const double prev_v = st.prev_action[2 * (size_t)e];
+            double sn, cs;
+            nv::sincos(rp[2], sn, cs);
+            ps.ax[n] = rp[0]; ps.ay[n] = rp[1];
+            ps.avx[n] = prev_v * cs; ps.avy[n] = prev_v * sn;
+        }
+        __syncthreads();
+        if (lane == 0) {                                               // the pack's pair terms as one list
+            int off = 0;
+            for (int q = 0; q < G; ++q) { slot_off[q] = off; const int m = slot_n[q]; off += m > 1 ? m * (m - 1) / 2 + m : 0; }
+            slot_off[G] = off;
+        }
+        __syncthreads();
+        const int total = slot_off[G];
+        for (int t = lane; t < total; t += kPedUpdateBlock) {
+            int q = 0;
+            while (t >= slot_off[q + 1]) ++q;
+            char* base = ped_dyn + (size_t)q * slot_bytes;
+            ped_pair_term(c, ped_lds_carve(base + ped_pair_bytes(N), N), (double2*)base, slot_n[q], t - slot_off[q]);
+        }
+        __syncthreads();
+        if (is_ped) ped_sfm_step(c, field, ps, n > 1 ? (const double2*)my : nullptr, n, i, st.ped_v_pref[pq], wp, dt, pp, pvel);
+    } else if (c.ped_model == NAVSIM_PED_EXTERNAL && is_ped) {
+        const double* cmd = st.ped_cmd + pq * 2;
+        nv::set_vel(pp, cmd[0], cmd[1], dt, 0.0, pvel);               // env.py:662
     }
     // the step increments steps[e] before anything else (env.py:592); it has not run yet
-    ped_phase<kPedUpdateBlock, Field>(c, st, field, e, n, tid, is_ped, pq, c.time_step, (uint64_t)(c.env_index_base + e),
-                         (uint64_t)st.steps[e] + 1, old_rp, prev_v, ps, ped_dyn, pair_bytes, pp, pvel);
+    if (is_ped) ped_finish(c, st, e, i, pq, wp, nw, dt, (uint64_t)(c.env_index_base + e), (uint64_t)st.steps[e] + 1, pp, pvel);
 }
 
 // The fused step.  BLOCK threads = one arena; PEDS: the pedestrian variants (primitives + culled merge in LDS);
 // RULE: the march step rule (NAVSIM_MARCH_*), a compile-time copy of cfg.march_rule so that the probe loop
-// carries no select.
-template <int BLOCK, bool PEDS, typename Field, int RULE, bool RECT>
+// carries no select.  PINL (pedestrian variants): the pedestrian phase is compiled into the kernel; false = the
+// pedestrians were advanced by ped_update_kernel, and the kernel carries neither that phase nor the 108 bytes of
+// private scratch per lane its float64 chains spilled to under the 64-register cap (round 3: Scratch_Size 0).
+template <int BLOCK, bool PEDS, typename Field, int RULE, bool RECT, bool PINL>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void navsim_step_kernel(navsim_config c, navsim_state st,
                                                             navsim_step_io io, int reset_only,
                                                             const uint8_t* __restrict__ reset_mask,
@@ -743,9 +815,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             sh.rp[0] = p[0]; sh.rp[1] = p[1]; sh.rp[2] = p[2];
         }
     } else if (!reset_only) {
-        if (!peds_done)
-            ped_phase<BLOCK, Field>(c, st, field, e, n, tid, is_ped, pq, dt, genv, (uint64_t)st.steps[e], sh.old_rp, pa_g[0],
-                                    ps, dyn_lds, dyn_lds_bytes, pp, pvel);
+        if constexpr (PINL) {
+            if (!peds_done)
+                ped_phase<BLOCK, Field>(c, st, field, e, n, tid, is_ped, pq, dt, genv, (uint64_t)st.steps[e], sh.old_rp, pa_g[0],
+                                        ps, dyn_lds, dyn_lds_bytes, pp, pvel);
+        }
         // ---- robot (env.py:664)
         if (tid == 0) {
             double p[3] = {sh.old_rp[0], sh.old_rp[1], sh.old_rp[2]};

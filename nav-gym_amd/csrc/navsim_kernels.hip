@@ -107,8 +107,8 @@ size_t step_lds_bytes(const navsim_config* c, int park_lanes) {
     if (c->ped_model != NAVSIM_PED_NONE) lds = ((lds + 15) & ~(size_t)15) + ped_lds_bytes(c->max_peds);
     return lds;
 }
-size_t ped_update_lds_bytes(const navsim_config* c) {
-    return (((size_t)c->max_peds * (c->max_peds + 1) * sizeof(double2) + 15) & ~(size_t)15) + ped_lds_bytes(c->max_peds);
+size_t ped_update_lds_bytes(const navsim_config* c) {                    // ped_update_kernel: a pack of arenas per wavefront
+    return (size_t)ped_pack(c->max_peds) * ped_slot_bytes(c->max_peds);
 }
 
 // Threads per arena (cfg.step_block = 0).  With >= 12 arenas per CU the chip is kept full by 256-thread
@@ -134,14 +134,24 @@ int march_rule_variant(const navsim_config* c) {
     return (c->field_format == NAVSIM_FIELD_U16T && side <= 1448) ? kMarchF64Exact32 : NAVSIM_MARCH_F64;
 }
 
+template <int BLOCK, bool PEDS, typename Field, bool RECT, int RULE, bool PINL>
+int launch_step_pinl(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
+                     const uint8_t* mask, size_t lds, hipStream_t s, int grid) {
+    if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
+    const int park = step_park_lanes(c, BLOCK);
+    navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL><<<grid > 0 ? grid : c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask,
+                                                                                    (unsigned)step_lds_scan_bytes(c, park), park);
+    return NAVSIM_OK;
+}
+// pedestrian variants: the form without the pedestrian phase when ped_update_kernel has run (reset_only bit 1) or
+// nothing is integrated at all (a reset-only launch), else the form that carries it
 template <int BLOCK, bool PEDS, typename Field, bool RECT, int RULE>
 int launch_step_kernel(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
                        const uint8_t* mask, size_t lds, hipStream_t s, int grid) {
-    if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
-    const int park = step_park_lanes(c, BLOCK);
-    navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT><<<grid > 0 ? grid : c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask,
-                                                                                    (unsigned)step_lds_scan_bytes(c, park), park);
-    return NAVSIM_OK;
+    if constexpr (PEDS) {
+        if (reset_only == 0) return launch_step_pinl<BLOCK, PEDS, Field, RECT, RULE, true>(c, st, io, reset_only, mask, lds, s, grid);
+    }
+    return launch_step_pinl<BLOCK, PEDS, Field, RECT, RULE, false>(c, st, io, reset_only, mask, lds, s, grid);
 }
 
 template <int BLOCK, bool PEDS, typename Field, bool RECT>
@@ -176,8 +186,9 @@ int launch_step(const navsim_config* c, const navsim_state* st, const navsim_ste
         const bool split = c->ped_split == 2 || (c->ped_split == 0 && c->n_envs >= 3072);
         if (split) {
             const size_t pl = ped_update_lds_bytes(c);
-            if (c->field_format == NAVSIM_FIELD_U16T) ped_update_kernel<FieldU16T><<<c->n_envs, kPedUpdateBlock, pl, s>>>(*c, *st);
-            else                                      ped_update_kernel<FieldF32><<<c->n_envs, kPedUpdateBlock, pl, s>>>(*c, *st);
+            const int G = ped_pack(c->max_peds), grid = (c->n_envs + G - 1) / G;
+            if (c->field_format == NAVSIM_FIELD_U16T) ped_update_kernel<FieldU16T><<<grid, kPedUpdateBlock, pl, s>>>(*c, *st);
+            else                                      ped_update_kernel<FieldF32><<<grid, kPedUpdateBlock, pl, s>>>(*c, *st);
             reset_only |= 2;
         }
     }
