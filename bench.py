@@ -289,6 +289,8 @@ def main():
     ap.add_argument("--lpt-period", type=int, default=0, help="steps between launch-order sorts (0 = NavSim's default)")
     ap.add_argument("--ped-split", type=int, default=0, choices=[0, 1, 2],
                     help="navsim_config.ped_split: 0 library default, 1 pedestrians inside the step, 2 ped_update_kernel first")
+    ap.add_argument("--rect-lds", type=int, default=0, choices=[0, 1, 2],
+                    help="navsim_config.rect_lds: 0 library default (record table staged in LDS for small launches), 1 never, 2 always")
     ap.add_argument("--no-rects", action="store_true",
                     help="march through the packed field only, without the two-rectangle tile records (A/B)")
     ap.add_argument("--pregen", action="store_true",
@@ -355,6 +357,7 @@ def main():
         sim.cfg.step_block = args.step_block
     if args.ped_split:
         sim.cfg.ped_split = args.ped_split
+    sim.cfg.rect_lds = args.rect_lds
     if args.lpt_period:
         sim.lpt_period = args.lpt_period
     E, K, Wm = cfg.n_envs, args.steps, args.warmup

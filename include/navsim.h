@@ -162,6 +162,10 @@ typedef struct navsim_config {
     int32_t regen_check_discomfort;   /* navsim_regen: 1 (default) = a robot start whose FIRST scan (no pedestrians, no noise) has a
                                          beam inside the discomfort zone is dropped and the next start / goal pair of the
                                          spawn table takes its place, like reset() re-draws the robot (env.py:776-781) */
+    int32_t rect_lds;                 /* fused step with rect records: 0 = the library stages an arena's record table in
+                                         LDS when the launch is small enough for that to pay, 1 = never,
+                                         2 = whenever the table fits (16 B per 8x8 tile next to the step's other LDS) */
+    int32_t reserved0;
 } navsim_config;
 
 /* ------------------------------------------------------------------------------------------

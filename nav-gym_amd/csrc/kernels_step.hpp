@@ -293,7 +293,9 @@ __device__ __forceinline__ bool mask_lane(lanemask_t m) { return mask_sel(m, 1, 
 // One probe of calc_range (env.py:425) for every lane of `active`: sample position, distance there, hit test, step.
 // Lanes that are finished or outside the map run along with their updates masked off.  A lane that hits keeps the
 // t of its hit probe (the hit cell is recomputed from it after the march).
-template <typename Field, int RULE, bool RECT>
+// RECT: 0 = the field alone; 1 = the tile's two-rectangle record from global memory; 2 = from the arena's record table
+// staged in LDS (`rects` then points into LDS; round 3, launches of few arenas per CU).
+template <typename Field, int RULE, int RECT>
 __device__ __forceinline__ void probe_round(const Field& field, const char* __restrict__ rects, unsigned tpr,
                                             float x0, float y0, float dx, float dy, unsigned uW, unsigned uH,
                                             float max_range, float& t, lanemask_t& active, lanemask_t& hit) {
@@ -304,11 +306,11 @@ __device__ __forceinline__ void probe_round(const Field& field, const char* __re
     const lanemask_t live = active & mask_ult((unsigned)px, uW) & mask_ult((unsigned)py, uH);
     lanemask_t occ;
     float d;
-    if constexpr (!RECT) {
+    if constexpr (RECT == 0) {
         px = mask_sel(live, px, 0);
         py = mask_sel(live, py, 0);
     }
-    if constexpr (RECT) {
+    if constexpr (RECT != 0) {
         // the tile's two-rectangle record (kernels_rect.hpp): exact integer d2 without touching the field; the
         // rare probe in a tile without a valid record reads the field.  32-bit lane offset on a uniform base.
         // tile rows and tiles per row stay far below 2^24: the 24-bit multiply-add is a full-rate instruction
@@ -320,7 +322,13 @@ __device__ __forceinline__ void probe_round(const Field& field, const char* __re
         // of the four loaded dwords to other registers before using them (3 of 42 vector instructions per probe).
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         u32x4 rec;
-        asm volatile("global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(rec) : "v"(off), "s"(rects) : "memory");
+        if constexpr (RECT == 2) {
+            typedef __attribute__((address_space(3))) const char lds_char;
+            typedef __attribute__((address_space(3))) const u32x4 lds_rec;
+            rec = *(lds_rec*)((lds_char*)rects + off);               // ds_read_b128
+        } else {
+            asm volatile("global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(rec) : "v"(off), "s"(rects) : "memory");
+        }
         const int da = rect_dist2(rec.x, rec.y, cell), db = rect_dist2(rec.z, rec.w, cell);
         const int d2 = da < db ? da : db;
         const lanemask_t inval = live & mask_eq(rec.x & 0xFFFFu, (unsigned)kRectInvalid);
@@ -377,7 +385,7 @@ __device__ __forceinline__ int lanes_below(lanemask_t m) {          // set bits 
 // 1081 beams are 16.9 chunks, so a static `k += BLOCK` walk gives wavefront 0 of every 256-thread workgroup five
 // chunks and the others four, and the workgroup lives as long as its slowest wavefront.  Which wavefront
 // marches a beam changes no result.  The caller zeroes sh.next_chunk behind a barrier before every scan.
-template <int BLOCK, typename Field, bool TO_LDS, int RULE, bool RECT>
+template <int BLOCK, typename Field, bool TO_LDS, int RULE, int RECT>
 __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShared& sh,
                                                 const Field& field, const uint4* __restrict__ rects,
                                                 const double* __restrict__ tab,
@@ -738,11 +746,11 @@ __global__ __launch_bounds__(kPedUpdateBlock) void ped_update_kernel(navsim_conf
 // carries no select.  PINL (pedestrian variants): the pedestrian phase is compiled into the kernel; false = the
 // pedestrians were advanced by ped_update_kernel, and the kernel carries neither that phase nor the 108 bytes of
 // private scratch per lane its float64 chains spilled to under the 64-register cap (round 3: Scratch_Size 0).
-template <int BLOCK, bool PEDS, typename Field, int RULE, bool RECT, bool PINL>
+template <int BLOCK, bool PEDS, typename Field, int RULE, int RECT, bool PINL>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void navsim_step_kernel(navsim_config c, navsim_state st,
                                                             navsim_step_io io, int reset_only,
                                                             const uint8_t* __restrict__ reset_mask,
-                                                            unsigned dyn_lds_bytes, int park_lanes) {
+                                                            unsigned dyn_lds_bytes, int park_lanes, unsigned rect_lds_offset) {
     __shared__ StepShared sh;
     const int peds_done = (reset_only >> 1) & 1;     // the pedestrians were advanced by ped_update_kernel
     reset_only &= 1;
@@ -763,6 +771,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, c.map_h, c.map_w);
     const uint4* rects = RECT ? (const uint4*)st.rect_table + (size_t)(c.shared_field ? 0 : e) * rect_tiles_per_map(c.map_h, c.map_w)
                               : nullptr;
+    if constexpr (RECT == 2) {
+        // "Map tiles staged through LDS": the arena's whole record table (16 B per 8x8 tile: 63.5 KB for 500 x 500
+        // cells) is copied into LDS once, by all threads, and every probe of the scan reads its record with one
+        // ds_read_b128 (~0.1 us) instead of a global load (0.5-2 us from L2 / HBM).  It costs residency -- two
+        // 1024-thread workgroups per CU -- so the host takes this form only for launches of a few arenas per CU, where
+        // a launch is one or two generations and lasts as long as its rays' probe chains (dispatch_step).
+        uint4* tab_lds = (uint4*)(dyn_lds + rect_lds_offset);
+        const int n_tiles = (int)rect_tiles_per_map(c.map_h, c.map_w);
+        for (int i = threadIdx.x; i < n_tiles; i += BLOCK) tab_lds[i] = rects[i];
+        rects = tab_lds;                                        // made visible by the barrier that ends phase 0
+    }
     float* obs_row = io.obs + (size_t)e * D;
     const float* obs_prev = io.obs_prev ? io.obs_prev + (size_t)e * D : nullptr;
     double* rp_g = st.robot_pose + 3 * (size_t)e;

@@ -35,6 +35,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef NAVSIM_RECT_LDS_MAX_PER_CU
+#define NAVSIM_RECT_LDS_MAX_PER_CU 4       // arenas per CU up to which the fused step stages the rect records in LDS
+#endif
+
 // gfx950 only: bit-identity of the scans rests on properties of THIS ISA that are proven by exhaustive
 // device tests -- v_rsq_f32's rounding inside sqrt_small_int, the float32-only march step (navmath.hpp) -- and on
 // v_dot2_i32_i16 / v_pk_* forms that other targets lack.  Another offload arch must not compile silently.
@@ -134,73 +138,113 @@ int march_rule_variant(const navsim_config* c) {
     return (c->field_format == NAVSIM_FIELD_U16T && side <= 1448) ? kMarchF64Exact32 : NAVSIM_MARCH_F64;
 }
 
-template <int BLOCK, bool PEDS, typename Field, bool RECT, int RULE, bool PINL>
+// How a step is launched: threads per arena, where the probes find the rect records, the dynamic LDS.
+struct StepPlan {
+    int block;              // threads per arena
+    int rect;               // 0 no rect records, 1 records read from global memory, 2 the arena's table staged in LDS
+    int park;               // rays a wavefront parks per chunk
+    size_t lds;             // dynamic LDS per workgroup
+    unsigned rect_off;      // byte offset of the staged table inside it
+};
+// The record table in LDS ("map tiles staged through LDS"): a probe costs a ds_read_b128 instead of a global load, the
+// workgroup 63.5 KB of LDS (500 x 500 cells) -- two 1024-thread workgroups per CU instead of eight 256-thread ones.
+// Measured on the c2 world (profiles/r03_rect_lds/sweep_c2_world.txt, M env-steps/s, records in global memory -> in LDS):
+// 128 arenas 4.4 -> 4.8, 256: 7.9 -> 8.8, 512: 12.9 -> 14.4, 1024: 17.0 -> 19.1 (+10-13 %: the launch is one or two
+// generations and lasts as long as the probe chains of its slowest rays); 1536: 24.2 -> 21.6, 2048: 26.3 -> 23.0,
+// 4096: 36.0 -> 24.5 (residency beats latency once the chip runs several generations).  So: up to 4 arenas per CU.
+constexpr long kRectLdsMaxArenasPerCu = NAVSIM_RECT_LDS_MAX_PER_CU;
+StepPlan plan_step(const navsim_config* c, const navsim_state* st) {
+    StepPlan p;
+    p.block = pick_step_block(c);
+    p.rect = st->rect_table ? 1 : 0;
+    p.park = step_park_lanes(c, p.block);
+    p.lds = step_lds_bytes(c, p.park);
+    p.rect_off = 0;
+    if (p.rect && c->rect_lds != 1 && c->field_format == NAVSIM_FIELD_U16T && c->n_beams > 256 && !c->shared_field) {
+        const int b2 = (c->step_block == 512 || c->step_block == 1024) ? c->step_block : (c->step_block ? 0 : 1024);
+        if (b2) {
+            const size_t table = rect_tiles_per_map(c->map_h, c->map_w) * sizeof(uint4);
+            const size_t base = (step_lds_bytes(c, step_park_lanes(c, b2)) + 15) & ~(size_t)15;
+            const size_t total = base + table + 1024;               // + the kernel's static LDS, allocation granules
+            const bool two_per_cu = 2 * total <= kLdsPerCu, one_per_cu = total <= kLdsPerCu;
+            const bool small = (long)c->n_envs <= kRectLdsMaxArenasPerCu * device_cu_count();
+            if (c->rect_lds == 2 ? one_per_cu : (two_per_cu && small)) {
+                p.block = b2; p.rect = 2; p.park = step_park_lanes(c, b2);
+                p.lds = base + table; p.rect_off = (unsigned)base;
+            }
+        }
+    }
+    return p;
+}
+
+template <int BLOCK, bool PEDS, typename Field, int RECT, int RULE, bool PINL>
 int launch_step_pinl(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
-                     const uint8_t* mask, size_t lds, hipStream_t s, int grid) {
-    if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
-    const int park = step_park_lanes(c, BLOCK);
-    navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL><<<grid > 0 ? grid : c->n_envs, BLOCK, lds, s>>>(*c, *st, *io, reset_only, mask,
-                                                                                    (unsigned)step_lds_scan_bytes(c, park), park);
+                     const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
+    if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL>, p.lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
+    navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL><<<grid > 0 ? grid : c->n_envs, BLOCK, p.lds, s>>>(
+        *c, *st, *io, reset_only, mask, (unsigned)step_lds_scan_bytes(c, p.park), p.park, p.rect_off);
     return NAVSIM_OK;
 }
 // pedestrian variants: the form without the pedestrian phase when ped_update_kernel has run (reset_only bit 1) or
 // nothing is integrated at all (a reset-only launch), else the form that carries it
-template <int BLOCK, bool PEDS, typename Field, bool RECT, int RULE>
+template <int BLOCK, bool PEDS, typename Field, int RECT, int RULE>
 int launch_step_kernel(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
-                       const uint8_t* mask, size_t lds, hipStream_t s, int grid) {
+                       const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
     if constexpr (PEDS) {
-        if (reset_only == 0) return launch_step_pinl<BLOCK, PEDS, Field, RECT, RULE, true>(c, st, io, reset_only, mask, lds, s, grid);
+        if (reset_only == 0) return launch_step_pinl<BLOCK, PEDS, Field, RECT, RULE, true>(c, st, io, reset_only, mask, p, s, grid);
     }
-    return launch_step_pinl<BLOCK, PEDS, Field, RECT, RULE, false>(c, st, io, reset_only, mask, lds, s, grid);
+    return launch_step_pinl<BLOCK, PEDS, Field, RECT, RULE, false>(c, st, io, reset_only, mask, p, s, grid);
 }
 
-template <int BLOCK, bool PEDS, typename Field, bool RECT>
+template <int BLOCK, bool PEDS, typename Field, int RECT>
 int launch_step_rule(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
-                     const uint8_t* mask, size_t lds, hipStream_t s, int grid) {
+                     const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
     switch (march_rule_variant(c)) {
-        case NAVSIM_MARCH_F32: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F32>(c, st, io, reset_only, mask, lds, s, grid);
+        case NAVSIM_MARCH_F32: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F32>(c, st, io, reset_only, mask, p, s, grid);
         case kMarchF64Exact32:
             if constexpr (!std::is_same<Field, FieldF32>::value)
-                return launch_step_kernel<BLOCK, PEDS, Field, RECT, kMarchF64Exact32>(c, st, io, reset_only, mask, lds, s, grid);
+                return launch_step_kernel<BLOCK, PEDS, Field, RECT, kMarchF64Exact32>(c, st, io, reset_only, mask, p, s, grid);
             [[fallthrough]];
-        default: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F64>(c, st, io, reset_only, mask, lds, s, grid);
+        default: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F64>(c, st, io, reset_only, mask, p, s, grid);
     }
 }
 
 template <int BLOCK, bool PEDS, typename Field>
 int launch_step_field(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
-                      const uint8_t* mask, size_t lds, hipStream_t s, int grid) {
-    return st->rect_table ? launch_step_rule<BLOCK, PEDS, Field, true>(c, st, io, reset_only, mask, lds, s, grid)
-                          : launch_step_rule<BLOCK, PEDS, Field, false>(c, st, io, reset_only, mask, lds, s, grid);
+                      const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
+    if constexpr (BLOCK >= 512) {                            // the LDS form exists for the wide workgroups only
+        if (p.rect == 2) return launch_step_rule<BLOCK, PEDS, Field, 2>(c, st, io, reset_only, mask, p, s, grid);
+    }
+    return p.rect ? launch_step_rule<BLOCK, PEDS, Field, 1>(c, st, io, reset_only, mask, p, s, grid)
+                  : launch_step_rule<BLOCK, PEDS, Field, 0>(c, st, io, reset_only, mask, p, s, grid);
 }
 
 template <int BLOCK>
 int launch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
-                const uint8_t* mask, hipStream_t s, int grid) {
+                const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
     const bool peds = c->ped_model != NAVSIM_PED_NONE;
-    const size_t lds = step_lds_bytes(c, step_park_lanes(c, BLOCK));
-    // pedestrians ahead of the step, one wavefront per arena (pays when the chip runs several generations of
+    // pedestrians ahead of the step, a pack of arenas per workgroup (pays when the chip runs several generations of
     // arenas: c3 13.2 -> 14.0 M env-steps/s; a 512-arena launch is latency-bound and loses 2 % to the extra
     // kernel, so small batches keep the fused form)
     if (peds && !reset_only && ped_update_lds_bytes(c) <= 64 * 1024) {
         const bool split = c->ped_split == 2 || (c->ped_split == 0 && c->n_envs >= 3072);
         if (split) {
             const size_t pl = ped_update_lds_bytes(c);
-            const int G = ped_pack(c->max_peds), grid = (c->n_envs + G - 1) / G;
-            if (c->field_format == NAVSIM_FIELD_U16T) ped_update_kernel<FieldU16T><<<grid, kPedUpdateBlock, pl, s>>>(*c, *st);
-            else                                      ped_update_kernel<FieldF32><<<grid, kPedUpdateBlock, pl, s>>>(*c, *st);
+            const int G = ped_pack(c->max_peds), pgrid = (c->n_envs + G - 1) / G;
+            if (c->field_format == NAVSIM_FIELD_U16T) ped_update_kernel<FieldU16T><<<pgrid, kPedUpdateBlock, pl, s>>>(*c, *st);
+            else                                      ped_update_kernel<FieldF32><<<pgrid, kPedUpdateBlock, pl, s>>>(*c, *st);
             reset_only |= 2;
         }
     }
     if (c->field_format == NAVSIM_FIELD_U16T && !st->field_overflow) {          // no saturated cell anywhere
-        return peds ? launch_step_field<BLOCK, true, FieldU16TN>(c, st, io, reset_only, mask, lds, s, grid)
-                    : launch_step_field<BLOCK, false, FieldU16TN>(c, st, io, reset_only, mask, lds, s, grid);
+        return peds ? launch_step_field<BLOCK, true, FieldU16TN>(c, st, io, reset_only, mask, p, s, grid)
+                    : launch_step_field<BLOCK, false, FieldU16TN>(c, st, io, reset_only, mask, p, s, grid);
     } else if (c->field_format == NAVSIM_FIELD_U16T) {
-        return peds ? launch_step_field<BLOCK, true, FieldU16T>(c, st, io, reset_only, mask, lds, s, grid)
-                    : launch_step_field<BLOCK, false, FieldU16T>(c, st, io, reset_only, mask, lds, s, grid);
+        return peds ? launch_step_field<BLOCK, true, FieldU16T>(c, st, io, reset_only, mask, p, s, grid)
+                    : launch_step_field<BLOCK, false, FieldU16T>(c, st, io, reset_only, mask, p, s, grid);
     }
-    return peds ? launch_step_rule<BLOCK, true, FieldF32, false>(c, st, io, reset_only, mask, lds, s, grid)
-                : launch_step_rule<BLOCK, false, FieldF32, false>(c, st, io, reset_only, mask, lds, s, grid);
+    return peds ? launch_step_rule<BLOCK, true, FieldF32, 0>(c, st, io, reset_only, mask, p, s, grid)
+                : launch_step_rule<BLOCK, false, FieldF32, 0>(c, st, io, reset_only, mask, p, s, grid);
 }
 
 // grid > 0: that many workgroups instead of one per arena; st->launch_order then names each workgroup's arena, -1 = none
@@ -208,11 +252,12 @@ int launch_step(const navsim_config* c, const navsim_state* st, const navsim_ste
 int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
                   int reset_only, const uint8_t* mask, hipStream_t s, int grid = 0) {
     int rc;
-    switch (pick_step_block(c)) {
-        case 64:   rc = launch_step<64>(c, st, io, reset_only, mask, s, grid); break;
-        case 256:  rc = launch_step<256>(c, st, io, reset_only, mask, s, grid); break;
-        case 512:  rc = launch_step<512>(c, st, io, reset_only, mask, s, grid); break;
-        case 1024: rc = launch_step<1024>(c, st, io, reset_only, mask, s, grid); break;
+    const StepPlan p = plan_step(c, st);
+    switch (p.block) {
+        case 64:   rc = launch_step<64>(c, st, io, reset_only, mask, p, s, grid); break;
+        case 256:  rc = launch_step<256>(c, st, io, reset_only, mask, p, s, grid); break;
+        case 512:  rc = launch_step<512>(c, st, io, reset_only, mask, p, s, grid); break;
+        case 1024: rc = launch_step<1024>(c, st, io, reset_only, mask, p, s, grid); break;
         default:   return NAVSIM_E_UNSUPPORTED;
     }
     return rc != NAVSIM_OK ? rc : launch_status();
@@ -302,6 +347,7 @@ int navsim_default_config(navsim_config* c) {
     c->scan_noise_std_lo = 0.0; c->scan_noise_std_hi = -1.0; // < 0: navsim_regen keeps scan_noise_std
     c->march_rule = NAVSIM_MARCH_F64;
     c->regen_check_discomfort = 1;          // env.py:776-781
+    c->rect_lds = 0;
     c->step_block = 0;
     c->ped_split = 0;
     c->seed = 1234;
@@ -494,9 +540,9 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
     if (st->rect_table && (c->field_format != NAVSIM_FIELD_U16T || c->map_h > 1024 || c->map_w > 1024)) return NAVSIM_E_UNSUPPORTED;
     if (c->step_block != 0 && c->step_block != 64 && c->step_block != 256 && c->step_block != 512 &&
         c->step_block != 1024) return NAVSIM_E_ARG;
-    if (c->ped_split < 0 || c->ped_split > 2) return NAVSIM_E_ARG;
+    if (c->ped_split < 0 || c->ped_split > 2 || c->rect_lds < 0 || c->rect_lds > 2) return NAVSIM_E_ARG;
     if (c->ped_model != NAVSIM_PED_NONE && c->max_peds < 1) return NAVSIM_E_ARG;
-    if (step_lds_bytes(c, step_park_lanes(c, pick_step_block(c))) > kLdsPerCu) return NAVSIM_E_UNSUPPORTED;   // beams x pedestrians beyond one CU's LDS
+    if (plan_step(c, st).lds > kLdsPerCu) return NAVSIM_E_UNSUPPORTED;   // beams x pedestrians beyond one CU's LDS
     if (!st->field || !st->scan_threshold || !st->scan_discomfort || !st->robot_pose || !st->robot_goal ||
         !st->prev_action || !st->prev_pose || !st->n_hist || !st->episode || !st->steps || !io->obs)
         return NAVSIM_E_ARG;

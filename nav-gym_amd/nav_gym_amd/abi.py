@@ -108,6 +108,8 @@ class NavsimConfig(C.Structure):
         ("step_block", C.c_int32),
         ("ped_split", C.c_int32),
         ("regen_check_discomfort", C.c_int32),
+        ("rect_lds", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
     def copy(self):

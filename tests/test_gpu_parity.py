@@ -329,7 +329,7 @@ def _rollout_pair(gpu, cfg, occ, n_peds, steps, seed, noise=False, policy=None, 
         yield t, go.cpu().numpy(), {k: v.cpu().numpy() for k, v in gout.items()}, ro, rout, g, r
 
 
-@pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T, "u16t-no-rects"])
+@pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T, "u16t-no-rects", "u16t-rects-from-global-memory"])
 @pytest.mark.parametrize("ped_model,S,auto_reset", [(abi.PED_NONE, 1, 1), (abi.PED_SFM, 2, 1), (abi.PED_EXTERNAL, 3, 0)])
 def test_step_rollout_vs_oracle(gpu, ped_model, S, auto_reset, fmt):
     """48 arenas x 60 steps on 240x240 maps, 1081 beams: every output and every state array of the
@@ -337,11 +337,14 @@ def test_step_rollout_vs_oracle(gpu, ped_model, S, auto_reset, fmt):
     float32 field, for the packed uint16 tile field with the two-rectangle tile records the bench marches
     through (navsim_build_rects), and for the packed field alone."""
     world_kw = {}
+    rect_lds = 0                # a launch of 48 arenas stages the rect records in LDS (1024 threads per arena) ...
     if fmt == "u16t-no-rects":
         fmt, world_kw = abi.FIELD_U16T, {"rect_table": False}
+    if fmt == "u16t-rects-from-global-memory":
+        fmt, rect_lds = abi.FIELD_U16T, 1               # ... unless told to read them from global memory, like large launches do
     E, size, N = 48, 240, 8
     cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, n_scan_stack=S, ped_model=ped_model,
-                                 auto_reset=auto_reset, n_spawn=8, seed=4242, field_format=fmt)
+                                 auto_reset=auto_reset, n_spawn=8, seed=4242, field_format=fmt, rect_lds=rect_lds)
     gpu.world.lidar_1081(cfg)
     occ = gpu.world.make_maps(E, size, 4242)
     crashes = resets = 0
