@@ -31,6 +31,30 @@ HUMAN = dict(
 
 ROBOTS = {"keti": KETI, "husky": HUSKY}
 
+# Husky wheel geometry (third_party/husky_description/urdf/husky.urdf.xacro:61-67)
+HUSKY_TRACK = 0.5708
+HUSKY_WHEEL_RADIUS = 0.1651
+
+
+def husky_twist_from_wheels(omega_left, omega_right):
+    """Skid-steer form of the Husky command (BUILD-DEFINED like the model itself): wheel speeds of
+    the left / right side in rad/s -> the (v, omega) the step integrates,
+    v = r (w_l + w_r) / 2, omega = r (w_r - w_l) / track.  Arrays or torch tensors of any shape; returns the same kind,
+    last axis (v, omega)."""
+    v = HUSKY_WHEEL_RADIUS * (omega_left + omega_right) * 0.5
+    w = HUSKY_WHEEL_RADIUS * (omega_right - omega_left) / HUSKY_TRACK
+    if hasattr(v, "stack") or type(v).__module__.startswith("torch"):
+        import torch
+        return torch.stack([v, w], dim=-1)
+    return np.stack([np.asarray(v, dtype=np.float64), np.asarray(w, dtype=np.float64)], axis=-1)
+
+
+def husky_wheels_from_twist(v, omega):
+    """Inverse of husky_twist_from_wheels: (v, omega) -> (omega_left, omega_right) in rad/s."""
+    wl = (v - 0.5 * HUSKY_TRACK * omega) / HUSKY_WHEEL_RADIUS
+    wr = (v + 0.5 * HUSKY_TRACK * omega) / HUSKY_WHEEL_RADIUS
+    return wl, wr
+
 
 def footprint_array(robot, key):
     return np.asarray(ROBOTS[robot][key], dtype=np.float32)

@@ -303,6 +303,17 @@ def test_bench_without_gpu_fails_loudly():
     assert r.returncode != 0 and "no CPU fallback" in r.stderr
 
 
+def test_husky_skid_steer_command():
+    """Husky as a skid-steer base (husky.urdf.xacro:61-67: track 0.5708 m, wheel radius 0.1651 m): wheel speeds <->
+    the (v, omega) the step integrates; equal speeds drive straight, opposite speeds turn on the spot."""
+    from nav_gym_amd import robots
+    tw = robots.husky_twist_from_wheels(np.array([3.0, 2.0, -1.0]), np.array([3.0, 4.0, 1.0]))
+    assert np.allclose(tw[0], [3.0 * 0.1651, 0.0]) and tw[2, 0] == 0.0 and tw[2, 1] > 0
+    assert np.allclose(tw[1], [0.1651 * 3.0, 0.1651 * 2.0 / 0.5708])
+    wl, wr = robots.husky_wheels_from_twist(tw[:, 0], tw[:, 1])
+    assert np.allclose(wl, [3.0, 2.0, -1.0]) and np.allclose(wr, [3.0, 4.0, 1.0])
+
+
 def test_export_transform_matches_reference_utils():
     """export._transform restates utils.transform_xys (ros_env.py:100-135 uses it for the three footprint
     polygons); golden: the reference's own output for a translation (3.25, -1.5) and yaw 0.7."""
