@@ -168,20 +168,22 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
 // 46 us; 32 or 512 bands, 23 / 33 us.  The kernel's time does not follow its arithmetic: profiles/README.md.)
 // `direct`: every map of this call is an outdoor one and nothing downstream wants the per-slot scratch (no rect
 // rebuild): the field goes straight into the arena's own buffers, no copy kernel.
+// The GRID is bounded (kRegenGrid workgroups walk the (slot, band) items of the arenas that really finished): a launch
+// of regen_cap x 128 workgroups of which 27 in 32 slots find nothing to do cost 4 ns per such workgroup -- 9.9 / 14.2 /
+// 22.6 us for regen_cap 8 / 16 / 32 with the same 5 maps to draw (profiles/_diag/regen_twice.sh).
 constexpr int kRegenSlices = 128;
-__global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim_state st,
-                                                         const int* __restrict__ count, const int* __restrict__ list,
-                                                         uint8_t* __restrict__ occ_all,
-                                                         const uint8_t* __restrict__ grid_all, const int* __restrict__ kind,
-                                                         char* __restrict__ field_scratch, size_t field_bytes,
-                                                         float* __restrict__ ovf_scratch, int direct) {
-    __shared__ int ocx[64], ocy[64];
-    const int b = blockIdx.x;
-    if (b >= *count) return;
+constexpr int kRegenGrid = 1024;
+inline int regen_grid(int slots) { const long n = (long)slots * kRegenSlices; return (int)(n < kRegenGrid ? n : kRegenGrid); }
+__device__ __forceinline__ void regen_maps_item(const navsim_config& c, const navsim_state& st, int b, int slice,
+                                                const int* __restrict__ list,
+                                                uint8_t* __restrict__ occ_all,
+                                                const uint8_t* __restrict__ grid_all, const int* __restrict__ kind,
+                                                char* __restrict__ field_scratch, size_t field_bytes,
+                                                float* __restrict__ ovf_scratch, int direct, int* ocx, int* ocy) {
     const int e = list[b], size = c.map_w, tid = threadIdx.x;
     uint8_t* occ = occ_all ? occ_all + (size_t)b * size * size : nullptr;
     const int rows = (size + kRegenSlices - 1) / kRegenSlices;
-    const int y0 = blockIdx.y * rows, y1 = (y0 + rows < size) ? y0 + rows : size;
+    const int y0 = slice * rows, y1 = (y0 + rows < size) ? y0 + rows : size;
     if (y0 >= size) return;
     if (const int G = kind[b]) {                                       // corridor map: nearest upscaling + flip
         const uint8_t* gsrc = grid_all + (size_t)b * 10000;
@@ -285,28 +287,45 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
     }
 }
 
+__global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim_state st,
+                                                         const int* __restrict__ count, const int* __restrict__ list,
+                                                         uint8_t* __restrict__ occ_all,
+                                                         const uint8_t* __restrict__ grid_all, const int* __restrict__ kind,
+                                                         char* __restrict__ field_scratch, size_t field_bytes,
+                                                         float* __restrict__ ovf_scratch, int direct) {
+    __shared__ int ocx[64], ocy[64];
+    const int n_items = *count * kRegenSlices;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {     // block-uniform loop
+        regen_maps_item(c, st, item / kRegenSlices, item % kRegenSlices, list, occ_all, grid_all, kind, field_scratch,
+                        field_bytes, ovf_scratch, direct, ocx, ocy);
+        __syncthreads();                                                 // ocx / ocy are rewritten by the next item
+    }
+}
+
 // install the new distance field of every regenerated arena (kRegenSlices workgroups per map, 16-byte copies)
 __global__ __launch_bounds__(256) void regen_field_kernel(char* __restrict__ dst_base, const int* __restrict__ count,
                                                           const int* __restrict__ list,
                                                           const char* __restrict__ field_scratch, size_t field_bytes) {
-    const int b = blockIdx.x;
-    if (b >= *count) return;
+  const int n_items = *count * kRegenSlices;                 // bounded grid, like regen_maps_kernel
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int b = item / kRegenSlices, slice = item % kRegenSlices;
     const int e = list[b], tid = threadIdx.x;
     const char* src_b = field_scratch + (size_t)b * field_bytes;
     char* dst_b = dst_base + (size_t)e * field_bytes;
     if (((field_bytes | (size_t)(uintptr_t)src_b | (size_t)(uintptr_t)dst_b) & 15) == 0) {
         const size_t n16 = field_bytes / 16;
         const size_t per = (n16 + kRegenSlices - 1) / kRegenSlices;
-        const size_t lo = blockIdx.y * per, hi = (lo + per < n16) ? lo + per : n16;
+        const size_t lo = slice * per, hi = (lo + per < n16) ? lo + per : n16;
         const uint4* src = (const uint4*)src_b;
         uint4* dst = (uint4*)dst_b;
         for (size_t i = lo + tid; i < hi; i += 256) dst[i] = src[i];
     } else {                                              // odd map sizes: every field format is 2-byte granular
         const size_t n2 = field_bytes / 2;
         const size_t per = (n2 + kRegenSlices - 1) / kRegenSlices;
-        const size_t lo = blockIdx.y * per, hi = (lo + per < n2) ? lo + per : n2;
+        const size_t lo = slice * per, hi = (lo + per < n2) ? lo + per : n2;
         for (size_t i = lo + tid; i < hi; i += 256) ((uint16_t*)dst_b)[i] = ((const uint16_t*)src_b)[i];
     }
+  }
 }
 
 // The acceptance rules of _sample_start_goal_path (env.py:366-383) -- oracle rg_start_ok / rg_goal_ok /
@@ -365,10 +384,17 @@ __device__ __forceinline__ bool spawn_in_discomfort(const navsim_config& c, cons
     const double step = nv::linspace_step(c);
     int bad = 0;
     for (int k = (int)threadIdx.x; k < B; k += (int)blockDim.x) {
+        // Only "is this beam shorter than its discomfort threshold?" is asked, so the march stops early: a hit found at
+        // parameter t lies at least t - sqrt(2) cells from the origin, hence from t >= dthr / resolution + 4 on no hit
+        // can be inside the zone.  Same answer as the full scan (oracle: robot_scan, then the comparison), a few probes
+        // instead of the chain of the longest ray: 27 -> 4 us of regen_commit_kernel.
+        const float dthr = st.scan_discomfort[k];
+        float lim = dthr / res + 4.0f;
+        lim = lim < max_range ? lim : max_range;
         float dx, dy;
         nv::beam_dir((float)(nv::linspace_k(c, k, step) + (double)lth), dx, dy);
         float t = 0.0f, r = max_range;
-        while (t < max_range) {
+        while (t < lim) {
             const int px = (int)(x0 + dx * t), py = (int)(y0 + dy * t);
             if (px >= W || px < 0 || py < 0 || py >= H) break;
             const float d = f.at(px, py);
@@ -383,7 +409,7 @@ __device__ __forceinline__ bool spawn_in_discomfort(const navsim_config& c, cons
         r = r * res;
         r = r < 0.0f ? 0.0f : r;
         r = r > rmax ? rmax : r;
-        bad |= (r < st.scan_discomfort[k]);
+        bad |= (r < dthr);
     }
     return __syncthreads_or(bad) != 0;
 }
@@ -972,7 +998,7 @@ __global__ __launch_bounds__(256) void regen_swap_kernel(navsim_config c, navsim
                                                          navsim_step_io io, const float* __restrict__ stage_obs,
                                                          const uint8_t* __restrict__ want, uint8_t* __restrict__ mark,
                                                          int cap, SwapBig b0, SwapBig b1, SwapBig b2, SwapBig b3) {
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x;                      // (grid (cap, slices): opt-in path, not bounded yet)
     int total, excl, lo, hi;
     // eligible: finished AND staged (want[e] == 0).  want[] is only READ here -- every workgroup of the launch must see
     // the same flags to agree on the selection; what this launch decides is written to mark[] and merged into want[] by

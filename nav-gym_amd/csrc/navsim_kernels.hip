@@ -704,7 +704,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     const bool need_occ = !direct || c->regen_plan || st->costmap;
     if (!direct && c->field_format == NAVSIM_FIELD_U16T) (void)hipMemsetAsync(fscratch, 0xFF, fbytes * (size_t)M, s);
     // maps and, for outdoor maps, their exact field from the geometry; corridor maps go through the distance transform
-    regen_maps_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>(*c, *st, count, list, need_occ ? occ : nullptr, grids, kind,
+    regen_maps_kernel<<<regen_grid(M), 256, 0, s>>>(*c, *st, count, list, need_occ ? occ : nullptr, grids, kind,
                                                             fscratch, fbytes, ovf_scratch, direct ? 1 : 0);
     if (c->regen_indoor_ratio > 0.0) {
         dt_columns_kernel<<<dim3((W + 63) / 64, M), 64 * kColSeg, 0, s>>>(occ, cols, H, W, count, kind);
@@ -721,9 +721,9 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
                            count, list, s);
     }
     if (!direct) {
-        regen_field_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>((char*)st->field, count, list, fscratch, fbytes);
+        regen_field_kernel<<<regen_grid(M), 256, 0, s>>>((char*)st->field, count, list, fscratch, fbytes);
         if (ovf_scratch)
-            regen_field_kernel<<<dim3(M, kRegenSlices), 256, 0, s>>>((char*)st->field_overflow, count, list,
+            regen_field_kernel<<<regen_grid(M), 256, 0, s>>>((char*)st->field_overflow, count, list,
                                                                     (const char*)ovf_scratch, cells * sizeof(float));
     }
     if (c->regen_plan) {
