@@ -69,8 +69,9 @@ __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim
             probe_round<Field, RULE, RECT>(field, rects, tpr, x0, y0, dx, dy, (unsigned)W, (unsigned)H, max_range, t, active, hit);
         rng[k] = ray_result(hit, x0, y0, dx, dy, t, max_range) * res;
     }
-    __syncthreads();
     const Prims pr = {seg, nullptr, info_s};
+    prim_in_range<BLOCK>(nseg_s, nseg_s, lx_s, ly_s, rmax * 1.0001f + 0.01f, pr);     // which rectangles can matter at all
+    __syncthreads();
     merge_prims_culled_core<BLOCK>(PB, lx_s, ly_s, (float)step, (float)(c.ped_angle_min + lth), nseg_s, 0, pr, dir, rng,
                                    rmax * 1.0001f + 0.01f);
     __syncthreads();

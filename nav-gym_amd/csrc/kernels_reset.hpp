@@ -77,8 +77,23 @@ __device__ __forceinline__ int regen_slot(const uint8_t* __restrict__ done, int 
 // min-reduction on (L1 distance, node index), then the two corridor rectangles carved by all threads);
 // the grid lives in LDS and is written to grid_all[b] (G*G bytes, stride 100*100).  kind[b] = G for a
 // corridor map, 0 for an outdoor one (regen_maps_kernel then draws the outdoor map as before).
+// per-episode env_param draws that are plain state (env.py:281-292, 786, 439): one thread per regenerated arena
+__device__ __forceinline__ void regen_params(const navsim_config& c, const navsim_state& st, int e) {
+    const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
+    const double* tape = rg_tape(st, e);
+    const uint64_t pk = rg_key(c.seed, genv, ep, 0x50524DULL);
+    if (c.num_humans_hi > 0 && c.ped_model != NAVSIM_PED_NONE && st.n_peds) {
+        int n = c.num_humans_lo + (int)(rg_t(tape, NAVSIM_DRAW_NUM_HUMANS, pk, 1) * (double)(c.num_humans_hi - c.num_humans_lo + 1));
+        st.n_peds[e] = n > c.max_peds ? c.max_peds : n;
+    }
+    if (c.scan_noise_std_hi >= 0.0 && st.scan_noise_std)
+        st.scan_noise_std[e] = (float)(c.scan_noise_std_lo + (c.scan_noise_std_hi - c.scan_noise_std_lo) *
+                                                                 rg_t(tape, NAVSIM_DRAW_SCAN_NOISE_STD, pk, 2));
+}
+
 // The kernel also OPENS navsim_regen: workgroup b selects its arena (regen_slot), publishes list[b] (-1: none) and,
-// workgroup 0, the count; every later kernel of the call reads those.
+// workgroup 0, the count; every later kernel of the call reads those.  (Worlds of outdoor maps only skip this kernel:
+// regen_maps_kernel opens the call itself.)
 __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navsim_state st,
                                                            const uint8_t* __restrict__ done, int cap,
                                                            int* __restrict__ count, int* __restrict__ list,
@@ -94,16 +109,7 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
     const int size = c.map_w;
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
     const double* tape = rg_tape(st, e);
-    if (tid == 0) {                 // per-episode env_param draws that are plain state (env.py:281-292, 786, 439)
-        const uint64_t pk = rg_key(c.seed, genv, ep, 0x50524DULL);
-        if (c.num_humans_hi > 0 && c.ped_model != NAVSIM_PED_NONE && st.n_peds) {
-            int n = c.num_humans_lo + (int)(rg_t(tape, NAVSIM_DRAW_NUM_HUMANS, pk, 1) * (double)(c.num_humans_hi - c.num_humans_lo + 1));
-            st.n_peds[e] = n > c.max_peds ? c.max_peds : n;
-        }
-        if (c.scan_noise_std_hi >= 0.0 && st.scan_noise_std)
-            st.scan_noise_std[e] = (float)(c.scan_noise_std_lo + (c.scan_noise_std_hi - c.scan_noise_std_lo) *
-                                                                     rg_t(tape, NAVSIM_DRAW_SCAN_NOISE_STD, pk, 2));
-    }
+    if (tid == 0) regen_params(c, st, e);
     const bool indoor = c.regen_indoor_ratio > 0.0 &&       // env.py:295
                         rg_t(tape, NAVSIM_DRAW_KIND, rg_key(c.seed, genv, ep, 0x4B494E44ULL), 0) < c.regen_indoor_ratio;
     if (!indoor) { if (tid == 0) kind[b] = 0; return; }                  // block-uniform
@@ -174,18 +180,18 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
 constexpr int kRegenSlices = 128;
 constexpr int kRegenGrid = 1024;
 inline int regen_grid(int slots) { const long n = (long)slots * kRegenSlices; return (int)(n < kRegenGrid ? n : kRegenGrid); }
-__device__ __forceinline__ void regen_maps_item(const navsim_config& c, const navsim_state& st, int b, int slice,
-                                                const int* __restrict__ list,
+__device__ __forceinline__ void regen_maps_item(const navsim_config& c, const navsim_state& st, int b, int slice, int e,
                                                 uint8_t* __restrict__ occ_all,
                                                 const uint8_t* __restrict__ grid_all, const int* __restrict__ kind,
                                                 char* __restrict__ field_scratch, size_t field_bytes,
-                                                float* __restrict__ ovf_scratch, int direct, int* ocx, int* ocy) {
-    const int e = list[b], size = c.map_w, tid = threadIdx.x;
+                                                float* __restrict__ ovf_scratch, int direct, bool all_outdoor,
+                                                int* ocx, int* ocy) {
+    const int size = c.map_w, tid = threadIdx.x;
     uint8_t* occ = occ_all ? occ_all + (size_t)b * size * size : nullptr;
     const int rows = (size + kRegenSlices - 1) / kRegenSlices;
     const int y0 = slice * rows, y1 = (y0 + rows < size) ? y0 + rows : size;
     if (y0 >= size) return;
-    if (const int G = kind[b]) {                                       // corridor map: nearest upscaling + flip
+    if (const int G = all_outdoor ? 0 : kind[b]) {                     // corridor map: nearest upscaling + flip
         const uint8_t* gsrc = grid_all + (size_t)b * 10000;
         for (int idx = y0 * size + tid; idx < y1 * size; idx += 256) {
             int yy = idx / size, xx = idx - yy * size;
@@ -287,17 +293,42 @@ __device__ __forceinline__ void regen_maps_item(const navsim_config& c, const na
     }
 }
 
+// `done` != NULL: the kernel OPENS the call (worlds of outdoor maps only: no regen_indoor_kernel launch): every
+// workgroup finds the arena of its item from the done flags itself (regen_slot), the workgroup of a slot's first band
+// publishes list[b], kind[b] = 0 and draws the per-episode parameters, workgroup 0 publishes the count and marks the
+// empty slots.
 __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim_state st,
-                                                         const int* __restrict__ count, const int* __restrict__ list,
+                                                         int* __restrict__ count, int* __restrict__ list,
                                                          uint8_t* __restrict__ occ_all,
-                                                         const uint8_t* __restrict__ grid_all, const int* __restrict__ kind,
+                                                         const uint8_t* __restrict__ grid_all, int* __restrict__ kind,
                                                          char* __restrict__ field_scratch, size_t field_bytes,
-                                                         float* __restrict__ ovf_scratch, int direct) {
+                                                         float* __restrict__ ovf_scratch, int direct,
+                                                         const uint8_t* __restrict__ done, int cap) {
     __shared__ int ocx[64], ocy[64];
-    const int n_items = *count * kRegenSlices;
+    int n_items;
+    if (done) {
+        int total;
+        (void)regen_slot(done, c.n_envs, cap, 0, total);
+        n_items = total * kRegenSlices;
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0) *count = total;
+            for (int b = total + (int)threadIdx.x; b < cap; b += 256) list[b] = -1;
+        }
+    } else {
+        n_items = *count * kRegenSlices;
+    }
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {     // block-uniform loop
-        regen_maps_item(c, st, item / kRegenSlices, item % kRegenSlices, list, occ_all, grid_all, kind, field_scratch,
-                        field_bytes, ovf_scratch, direct, ocx, ocy);
+        const int b = item / kRegenSlices, slice = item % kRegenSlices;
+        int e;
+        if (done) {
+            int total;
+            e = regen_slot(done, c.n_envs, cap, b, total);
+            if (slice == 0 && threadIdx.x == 0) { list[b] = e; kind[b] = 0; regen_params(c, st, e); }
+        } else {
+            e = list[b];
+        }
+        regen_maps_item(c, st, b, slice, e, occ_all, grid_all, kind, field_scratch, field_bytes, ovf_scratch, direct,
+                        done != nullptr, ocx, ocy);       // (kind[b] of this call may not be written yet: not read then)
         __syncthreads();                                                 // ocx / ocy are rewritten by the next item
     }
 }

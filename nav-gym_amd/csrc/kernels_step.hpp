@@ -153,8 +153,7 @@ __device__ __forceinline__ void merge_prims_culled_core(int B, float lx, float l
     const float kTwoPiF = 6.2831853f;
     const float Kf = (stepf > 0.0f) ? kTwoPiF / stepf : 0.0f;
     const int nprim = nseg + ndisc;
-    prim_in_range<BLOCK>(nprim, nseg, lx, ly, rcull, pr);
-    __syncthreads();
+    (void)rcull;                                                // prim_in_range(rcull) ran before the scan (prims_prepare)
     // eight lanes per primitive, eight primitives per wavefront at a time (a pedestrian a few metres away
     // spans 10-50 beams; measured 4 / 8 / 16 / 32 / 64 lanes: c3 11.81 / 11.80 / 11.68 / 11.13 / 10.26 M env-steps/s)
 #ifndef NAVSIM_MERGE_G
@@ -203,12 +202,19 @@ __device__ __forceinline__ void merge_prims_culled_core(int B, float lx, float l
     }
 }
 
+// which primitives can matter at all (info[]): needs only the primitives and the lidar pose, so it runs BEFORE the scan
+// and is covered by the barrier that ends the scan
+__host__ __device__ inline float prim_cull_range(double range_max) { return (float)range_max * 1.0001f + 0.01f; }
+template <int BLOCK>
+__device__ __forceinline__ void prims_prepare(const navsim_config& c, const StepShared& sh, const Prims pr) {
+    prim_in_range<BLOCK>(sh.nseg + sh.ndisc, sh.nseg, sh.lx, sh.ly, prim_cull_range(c.range_max), pr);
+}
 template <int BLOCK>
 __device__ __forceinline__ void merge_prims_culled(const navsim_config& c, const StepShared& sh, const Prims pr,
                                                    const float2* __restrict__ dir, float* __restrict__ rng) {
     merge_prims_culled_core<BLOCK>(c.n_beams, sh.lx, sh.ly, (float)nv::linspace_step(c),
                                    (float)(c.angle_min + (double)sh.lth), sh.nseg, sh.ndisc, pr, dir, rng,
-                                   (float)c.range_max * 1.0001f + 0.01f);
+                                   prim_cull_range(c.range_max));
 }
 
 // raw ranges (cells) -> metres, pedestrians, clip, noise, crash / discomfort flags, observation row
@@ -230,18 +236,18 @@ __device__ __forceinline__ void finish_beams(const navsim_config& c, const StepS
     const float r_all = sh.r_all;
     int cr = 0, dc = 0;
     const uint64_t nkey = (noise_std > 0.0f) ? nv::noise_stream(c.seed, genv, noise_key) : 0;
+    // rng[] holds METRES (the scan stored range * resolution as each ray finished): round 3 dropped the conversion pass
+    // and its barrier; prim_in_range has run before the scan
     const bool culled = dir && rng_rw && (nseg | ndisc);           // LDS-resident: bearing-culled merge
+    (void)r_all; (void)res;
     if (culled) {
-        for (int k = (int)threadIdx.x; k < B; k += BLOCK)
-            rng_rw[k] = ((r_all >= 0.0f) ? r_all : rng[k]) * res;   // env.py:426
-        __syncthreads();
 #ifndef NAVSIM_DIAG_NO_MERGE          // diagnostic build only (pedestrians invisible): what does the merge cost?
         merge_prims_culled<BLOCK>(c, sh, pr, dir, rng_rw);
 #endif
         __syncthreads();
     }
     for (int k = (int)threadIdx.x; k < B; k += BLOCK) {
-        float rr = culled ? rng[k] : ((r_all >= 0.0f) ? r_all : rng[k]) * res;
+        float rr = rng[k];
         if (!culled && (nseg | ndisc)) {
             float dx, dy;
             if (dir) { float2 d = dir[k]; dx = d.x; dy = d.y; }
@@ -410,8 +416,8 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShar
     int cr = 0, dc = 0;
     // what happens to a finished ray (identical for every schedule)
     auto finish = [&](int k, float dx, float dy, float rr) {
-        if (TO_LDS) {                                           // pedestrians: culled merge on the LDS copy
-            rng_lds[k] = rr;
+        if (TO_LDS) {                                           // pedestrians: culled merge on the LDS copy, in metres
+            rng_lds[k] = rr * res;                              // env.py:426 (rr is r_all itself where the origin is occupied)
             dir_lds[k] = make_float2(dx, dy);
             return;
         }
@@ -431,6 +437,7 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShar
             if (S - 1 - j > n_hist) obs_row[(size_t)j * B + k] = rr;
     };
     const float miss = (r_all >= 0.0f) ? r_all : max_range;
+    if constexpr (TO_LDS) prims_prepare<BLOCK>(c, sh, pr);      // info[] of the culled merge: visible after the scan's barrier
     constexpr bool kPark = step_parks(BLOCK, TO_LDS);           // compiled in only where the host ever asks for it
     int own_chunk = 0;                                    // one wavefront per arena: no counter needed
     const int lane = (int)threadIdx.x & 63;

@@ -691,7 +691,9 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     (void)mask;
     // opens the call: every workgroup selects its arena from the done flags (list[b], -1 = none; count), draws the
     // per-episode parameters and the map kind, grows the corridor tree of a corridor map
-    regen_indoor_kernel<<<M, 256, 0, s>>>(*c, *st, io->done, M, count, list, grids, kind);
+    // (worlds of outdoor maps only: regen_maps_kernel opens the call itself, one launch less)
+    const bool direct = !(c->regen_indoor_ratio > 0.0) && !st->rect_table;
+    if (!direct) regen_indoor_kernel<<<M, 256, 0, s>>>(*c, *st, io->done, M, count, list, grids, kind);
     float* ovf_scratch = nullptr;                           // exact float plane of the new maps (large packed maps)
     if (c->field_format == NAVSIM_FIELD_U16T && st->field_overflow) {
         off = (off + 255) & ~(size_t)255;
@@ -700,12 +702,12 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     }
     // Outdoor maps only and no rect records to rebuild: the field of a new map is written straight into the arena's
     // own buffers (no per-slot scratch, no copy kernel), and the occupancy scratch only if a costmap wants it.
-    const bool direct = !(c->regen_indoor_ratio > 0.0) && !st->rect_table;
     const bool need_occ = !direct || c->regen_plan || st->costmap;
     if (!direct && c->field_format == NAVSIM_FIELD_U16T) (void)hipMemsetAsync(fscratch, 0xFF, fbytes * (size_t)M, s);
     // maps and, for outdoor maps, their exact field from the geometry; corridor maps go through the distance transform
     regen_maps_kernel<<<regen_grid(M), 256, 0, s>>>(*c, *st, count, list, need_occ ? occ : nullptr, grids, kind,
-                                                            fscratch, fbytes, ovf_scratch, direct ? 1 : 0);
+                                                            fscratch, fbytes, ovf_scratch, direct ? 1 : 0,
+                                                            direct ? io->done : nullptr, M);
     if (c->regen_indoor_ratio > 0.0) {
         dt_columns_kernel<<<dim3((W + 63) / 64, M), 64 * kColSeg, 0, s>>>(occ, cols, H, W, count, kind);
         if (c->field_format == NAVSIM_FIELD_F32)
