@@ -236,7 +236,7 @@ def launch_ranks(n_gpus, argv):
         raise SystemExit("bench.py: every rank exited 0 but rank 0 printed no JSON line")
 
 
-def profiled_counters(workload, E, field, rects):
+def profiled_counters(workload, E, field, rects, indoor_ratio=0.0):
     """Counter figures of the step kernel from the committed PMC profile of this workload (rocprofv3 --pmc passes,
     profiles/run_profiles.sh -> traffic.json): HBM bytes per launch and the vector-issue fraction.  Counters cannot be
     collected inside the timed process, so they are quoted -- and ONLY when the profile was taken from the same
@@ -253,7 +253,8 @@ def profiled_counters(workload, E, field, rects):
         src = "profiles/%s_%s/traffic.json@%s" % (rnd, workload, t.get("commit", "?"))
         if t.get("kernel_src_sha") != lib.source_hash():
             return None, "%s is of other kernel sources (%s, this build %s)" % (src, t.get("kernel_src_sha"), lib.source_hash())
-        if t.get("envs_per_gpu") != E or field != "u16t" or t.get("rect_table", True) != rects:
+        if (t.get("envs_per_gpu") != E or field != "u16t" or t.get("rect_table", True) != rects or
+                abs(float(t.get("indoor_ratio") or 0.0) - float(indoor_ratio)) > 1e-9):
             return None, "%s is of another launch shape" % src
         t["source"] = src
         return t, None
@@ -512,7 +513,7 @@ def main():
         A1 = algorithmic_bytes_per_env_step(H, W, B, S, wl["peds"], 1)
         achieved = A * E / (kernel_ms * 1e-3) / 1e9                # GB/s over the kernel's own duration
         frac = achieved / 8000.0
-        prof, why_not = profiled_counters(args.workload, E, args.field, rects)
+        prof, why_not = profiled_counters(args.workload, E, args.field, rects, args.indoor_ratio)
         tbytes = prof.get("hbm_bytes_per_launch") if prof else None
         all_values = [E_total * K / el for el, _ in [(elapsed, kernel_ms)] + more]
         value = E_total * K / elapsed

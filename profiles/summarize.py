@@ -124,6 +124,7 @@ if "TCC_EA0_RDREQ_128B_sum" in res:
     json.dump({"hbm_bytes_per_launch": rd + w, "read_bytes": rd, "write_bytes": w,
                "commit": head, "kernel_src_sha": src_sha,
                "envs_per_gpu": cfgb.get("envs_per_gpu"), "rect_table": cfgb.get("rect_table"),
+               "indoor_ratio": cfgb.get("indoor_ratio", 0.0),
                "workload": cfgb.get("workload"),
                "kernel_avg_us": (sum(s) / len(s) / 1e3) if step_ns else None,
                "step_launches": len(step_ns), "reset_only_launches_set_aside": len(reset_ns),
