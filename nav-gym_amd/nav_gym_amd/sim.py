@@ -354,8 +354,9 @@ class NavSim(object):
             self.t["beam_table"] = tab
             self.st.beam_table = tab.data_ptr()
         # longest-first launch order (navsim_launch_order): the step measures every arena's workgroup, every
-        # few steps the arenas are re-sorted so that the slow ones start first (lpt_period = 0 disables)
-        self.lpt_period = 4
+        # few steps the arenas are re-sorted so that the slow ones start first (lpt_period = 0 disables).  8 measured
+        # against 4 / 16 / 32 / 64 in profiles/r03_lpt/: the costs drift slowly, the sort is 13 us
+        self.lpt_period = 8
         self._steps_launched = 0
         # only when a launch runs several generations of workgroups: with one generation everything starts
         # at once and the order is irrelevant (threads per arena as dispatch_step picks them)
