@@ -32,6 +32,8 @@ struct PedShared {
     float* info;                             // [6 N] merge_prims_culled_core scratch: in-range flag per primitive
 };
 __host__ __device__ inline size_t ped_lds_bytes(int N) { return (size_t)136 * N + 32; }
+// the arena's table of social-force pair terms, [N][N + 1] double2 (ped_pair_term); in the fused step it sits behind PedShared
+__host__ __device__ inline size_t ped_pair_bytes(int N) { return ((size_t)N * (N + 1) * sizeof(double2) + 15) & ~(size_t)15; }
 __device__ __forceinline__ PedShared ped_lds_carve(char* base, int N) {
     PedShared ps;
     double* d = (double*)base;
@@ -400,7 +402,7 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShar
                                                 const float* __restrict__ thr, const float* __restrict__ dthr,
                                                 float* __restrict__ obs_row, int n_hist, float noise_std,
                                                 uint64_t noise_key, uint64_t genv,
-                                                int& crash, int& discomfort) {
+                                                int& crash, int& discomfort, bool prepare_prims = true) {
     const int B = c.n_beams, S = c.n_scan_stack, H = c.map_h, W = c.map_w;
     const float max_range = march_limit(H, W, c.range_max, c.resolution);
     const float res = (float)c.resolution;
@@ -437,7 +439,8 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShar
             if (S - 1 - j > n_hist) obs_row[(size_t)j * B + k] = rr;
     };
     const float miss = (r_all >= 0.0f) ? r_all : max_range;
-    if constexpr (TO_LDS) prims_prepare<BLOCK>(c, sh, pr);      // info[] of the culled merge: visible after the scan's barrier
+    // info[] of the culled merge: visible after the scan's barrier (the step's first scan: wavefront 0 has written it)
+    if constexpr (TO_LDS) { if (prepare_prims) prims_prepare<BLOCK>(c, sh, pr); }
     constexpr bool kPark = step_parks(BLOCK, TO_LDS);           // compiled in only where the host ever asks for it
     int own_chunk = 0;                                    // one wavefront per arena: no counter needed
     const int lane = (int)threadIdx.x & 63;
@@ -623,43 +626,51 @@ __device__ __forceinline__ void ped_finish(const navsim_config& c, const navsim_
     st.ped_vel[pq * 2] = pvel[0]; st.ped_vel[pq * 2 + 1] = pvel[1];
 }
 
-// Phase 1 for the pedestrians of one arena inside the fused step kernel.  Called by every thread of the workgroup
-// (it synchronises); pedestrian i lives on thread i.
-template <int BLOCK, typename Field>
-__device__ __forceinline__ void ped_phase(const navsim_config& c, const navsim_state& st, const Field& field, int e,
-                                          int n, int tid, bool is_ped, size_t pq, double dt, uint64_t genv,
-                                          uint64_t steps_now, const double* old_rp, double prev_v, const PedShared& ps,
-                                          char* pair_scratch, unsigned pair_bytes, double (&pp)[3], double (&pvel)[2]) {
+// LDS written by some lanes of a wavefront and read by others of the SAME wavefront: no workgroup barrier (the other
+// wavefronts are elsewhere), only the order of the wavefront's own LDS accesses, which the fences pin for the compiler
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Phase 1 for the pedestrians of one arena inside the fused step kernel: run by wavefront 0 ALONE (pedestrian i on its
+// lane i, N <= 64), while the arena's other wavefronts already march the static map -- nothing of the scan before its
+// merge reads a pedestrian, and nothing here reads the robot's new pose.  Round 3, c5: the phase used to hold the other
+// 15 wavefronts of a 1024-thread workgroup at a barrier for 15 of the workgroup's 41 us.  The pair terms (n (n - 1) / 2
+// + n, independent) are spread over the 64 lanes into the arena's pair table (LDS behind PedShared), then every
+// pedestrian adds its row in partner order -- the same sums, in the same order, as a sequential loop.
+template <typename Field>
+__device__ __forceinline__ void ped_phase_wave(const navsim_config& c, const navsim_state& st, const Field& field, int e,
+                                               int n, int lane, bool is_ped, size_t pq, double dt, uint64_t genv,
+                                               uint64_t steps_now, const double* old_rp, double prev_v, const PedShared& ps,
+                                               double2* pair, double (&pp)[3], double (&pvel)[2]) {
     const int P = NAVSIM_MAX_WAYPOINTS;
     double* wp = st.ped_waypoints ? st.ped_waypoints + (pq * P) * 2 : nullptr;
     int nw = 1;
     if (is_ped) nw = ped_pop_waypoints(wp, st.ped_n_waypoints[pq], pp);
     if (c.ped_model == NAVSIM_PED_SFM) {
         // stage every agent's position / velocity at time t (pedestrians, then the robot)
-        if (is_ped) { ps.ax[tid] = pp[0]; ps.ay[tid] = pp[1]; ps.avx[tid] = pvel[0]; ps.avy[tid] = pvel[1]; }
-        if (tid == 0) {
+        if (is_ped) { ps.ax[lane] = pp[0]; ps.ay[lane] = pp[1]; ps.avx[lane] = pvel[0]; ps.avy[lane] = pvel[1]; }
+        if (lane == 0) {
             double s, cs;
             nv::sincos(old_rp[2], s, cs);
             ps.ax[n] = old_rp[0]; ps.ay[n] = old_rp[1];
             ps.avx[n] = prev_v * cs; ps.avy[n] = prev_v * s;
         }
-        __syncthreads();
-        // the n (n - 1) / 2 + n pair terms are independent: spread them over the whole workgroup (LDS scratch = the
-        // scan's dir/rng area, free until the march), then every pedestrian adds its row in partner order -- the same
-        // sums, in the same order, as a sequential loop
-        double2* pair = (double2*)pair_scratch;
-        const bool pair_par = pair_bytes >= (unsigned)(n * (n + 1)) * sizeof(double2) && n > 1;
+        wave_lds_sync();
+        const bool pair_par = pair != nullptr && n > 1;
         if (pair_par) {
             const int n_terms = n * (n - 1) / 2 + n;
-            for (int t = tid; t < n_terms; t += BLOCK) ped_pair_term(c, ps, pair, n, t);
-            __syncthreads();
+            for (int t = lane; t < n_terms; t += 64) ped_pair_term(c, ps, pair, n, t);
+            wave_lds_sync();
         }
-        if (is_ped) ped_sfm_step(c, field, ps, pair_par ? pair : nullptr, n, tid, st.ped_v_pref[pq], wp, dt, pp, pvel);
+        if (is_ped) ped_sfm_step(c, field, ps, pair_par ? pair : nullptr, n, lane, st.ped_v_pref[pq], wp, dt, pp, pvel);
     } else if (c.ped_model == NAVSIM_PED_EXTERNAL && is_ped) {
         const double* cmd = st.ped_cmd + pq * 2;
         nv::set_vel(pp, cmd[0], cmd[1], dt, 0.0, pvel);     // env.py:662
     }
-    if (is_ped) ped_finish(c, st, e, tid, pq, wp, nw, dt, genv, steps_now, pp, pvel);
+    if (is_ped) ped_finish(c, st, e, lane, pq, wp, nw, dt, genv, steps_now, pp, pvel);
 }
 
 // The pedestrians of every arena ahead of the fused step (navsim_config.ped_split).  Inside the step this phase is a
@@ -683,7 +694,6 @@ __host__ __device__ inline int ped_pack(int N) {
     g = g > NAVSIM_PED_PACK_MAX ? NAVSIM_PED_PACK_MAX : g;
     return g < 1 ? 1 : (g > kPedPack ? kPedPack : g);
 }
-__host__ __device__ inline size_t ped_pair_bytes(int N) { return ((size_t)N * (N + 1) * sizeof(double2) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t ped_slot_bytes(int N) { return ped_pair_bytes(N) + ((ped_lds_bytes(N) + 15) & ~(size_t)15); }
 template <typename Field>
 __global__ __launch_bounds__(kPedUpdateBlock) void ped_update_kernel(navsim_config c, navsim_state st) {
@@ -807,7 +817,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const float noise_std = (c.add_scan_noise && st.scan_noise_std) ? st.scan_noise_std[e] : 0.0f;
 
     NAVSIM_STAMP(0);
-    // ---------------------------------------------------------------- phase 0: scalars
+    // ---------------------------------------------------------------- phase 0: scalars, robot, lidar pose
+    // The robot moves here, ahead of the pedestrians (env.py:664 comes after their commands, but nothing the pedestrian
+    // phase computes reads the robot's new pose -- the social force sees old_rp -- and nothing here reads a pedestrian):
+    // after ONE barrier the scan can start while wavefront 0 is still with the pedestrians.
     if (tid == 0) {
         sh.old_rp[0] = rp_g[0]; sh.old_rp[1] = rp_g[1]; sh.old_rp[2] = rp_g[2];
         sh.nseg = 0; sh.ndisc = 0; sh.rescan = 0; sh.respawn = 0;
@@ -820,79 +833,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 else           a0 = (a0 < -lim) ? a0 : -lim;
             }
             sh.act[0] = a0; sh.act[1] = a1;
-        }
-    }
-    __syncthreads();
-
-    NAVSIM_STAMP(1);
-    // ---------------------------------------------------------------- phase 1: pedestrians
-    double pp[3] = {0.0, 0.0, 0.0};
-    double pvel[2] = {0.0, 0.0};
-    const size_t pq = (size_t)e * N + (tid < n ? tid : 0);
-    const bool is_ped = PEDS && tid < n;
-    if (is_ped) {
-        pp[0] = st.ped_pose[pq * 3]; pp[1] = st.ped_pose[pq * 3 + 1]; pp[2] = st.ped_pose[pq * 3 + 2];
-        pvel[0] = st.ped_vel[pq * 2]; pvel[1] = st.ped_vel[pq * 2 + 1];
-    }
-    if (!reset_only && !PEDS) {
-        if (tid == 0) {                                         // env.py:664
-            double p[3] = {sh.old_rp[0], sh.old_rp[1], sh.old_rp[2]};
-            nv::set_vel(p, sh.act[0], sh.act[1], dt, c.axle_offset, nullptr);
+            double p[3] = {sh.old_rp[0], sh.old_rp[1], sh.old_rp[2]};        // env.py:664
+            nv::set_vel(p, a0, a1, dt, c.axle_offset, nullptr);
             sh.rp[0] = p[0]; sh.rp[1] = p[1]; sh.rp[2] = p[2];
-        }
-    } else if (!reset_only) {
-        if constexpr (PINL) {
-            if (!peds_done)
-                ped_phase<BLOCK, Field>(c, st, field, e, n, tid, is_ped, pq, dt, genv, (uint64_t)st.steps[e], sh.old_rp, pa_g[0],
-                                        ps, dyn_lds, dyn_lds_bytes, pp, pvel);
-        }
-        // ---- robot (env.py:664)
-        if (tid == 0) {
-            double p[3] = {sh.old_rp[0], sh.old_rp[1], sh.old_rp[2]};
-            nv::set_vel(p, sh.act[0], sh.act[1], dt, c.axle_offset, nullptr);
-            sh.rp[0] = p[0]; sh.rp[1] = p[1]; sh.rp[2] = p[2];
-        }
-    } else {
-        if (tid == 0) { sh.rp[0] = sh.old_rp[0]; sh.rp[1] = sh.old_rp[1]; sh.rp[2] = sh.old_rp[2]; }
-        if (is_ped) {                                           // env.py:809, 812-820
-            st.ped_dist[pq * 3] = 0.0; st.ped_dist[pq * 3 + 1] = 0.0; st.ped_dist[pq * 3 + 2] = 0.0;
-            st.ped_prev_yaw[pq] = nv::wrap_pi(pp[2]);
-        }
-    }
-
-    // ---------------------------------------------------------------- phase 2: what the lidar sees
-    if (is_ped) {                                               // env.py:392-414
-        float dist3[3];
-        if (reset_only) { dist3[0] = dist3[1] = dist3[2] = 0.0f; }
-        else { dist3[0] = (float)st.ped_dist[pq * 3]; dist3[1] = (float)st.ped_dist[pq * 3 + 1];
-               dist3[2] = (float)st.ped_dist[pq * 3 + 2]; }
-        if (st.ped_has_legs[pq] && c.lidar_legs) {
-            float cc[4];
-            nv::leg_centres((float)pp[0], (float)pp[1], (float)pp[2], dist3[0], dist3[1], dist3[2], cc);
-            int q = atomicAdd(&sh.ndisc, 2);
-            ps.disc[q][0] = cc[0]; ps.disc[q][1] = cc[1];
-            ps.disc[q + 1][0] = cc[2]; ps.disc[q + 1][1] = cc[3];
         } else {
-            const double fpx[4] = {0.22, -0.22, -0.22, 0.22};   // human.py:5-10
-            const double fpy[4] = {0.19, 0.19, -0.19, -0.19};
-            double s, cs;
-            nv::sincos(pp[2], s, cs);
-            float vx[4], vy[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                vx[v] = (float)((cs * fpx[v] - s * fpy[v]) + pp[0]);
-                vy[v] = (float)((s * fpx[v] + cs * fpy[v]) + pp[1]);
-            }
-            int q = atomicAdd(&sh.nseg, 4);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                int w = (v + 1) & 3;
-                ps.seg[q + v][0] = vx[v]; ps.seg[q + v][1] = vy[v];
-                ps.seg[q + v][2] = vx[w]; ps.seg[q + v][3] = vy[w];
-            }
+            sh.rp[0] = sh.old_rp[0]; sh.rp[1] = sh.old_rp[1]; sh.rp[2] = sh.old_rp[2];
         }
-    }
-    if (tid == 0) {
         sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];   // env.py:386
         nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);                              // env.py:419
         nv::sincos((double)sh.lth, sh.sT, sh.cT);
@@ -902,6 +848,70 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         sh.next_chunk = 0; sh.park_count = 0; sh.park_next = 0;
     }
     __syncthreads();
+
+    NAVSIM_STAMP(1);
+    // ---------------------------------------------------------------- phases 1 + 2: pedestrians, what the lidar sees of them
+    // wavefront 0 alone (pedestrian i on lane i); the others go straight to the scan, whose barrier before the merge
+    // publishes the primitives
+    if constexpr (PEDS) {
+        if (tid < 64) {
+            const int lane = tid;
+            double pp[3] = {0.0, 0.0, 0.0};
+            double pvel[2] = {0.0, 0.0};
+            const size_t pq = (size_t)e * N + (lane < n ? lane : 0);
+            const bool is_ped = lane < n;
+            if (is_ped) {
+                pp[0] = st.ped_pose[pq * 3]; pp[1] = st.ped_pose[pq * 3 + 1]; pp[2] = st.ped_pose[pq * 3 + 2];
+                pvel[0] = st.ped_vel[pq * 2]; pvel[1] = st.ped_vel[pq * 2 + 1];
+            }
+            if (!reset_only) {
+                if constexpr (PINL) {
+                    if (!peds_done) {
+                        // the pair table: dynamic LDS behind PedShared (the host allocates it for the launches that carry the phase)
+                        double2* pair = (double2*)(dyn_lds + ((dyn_lds_bytes + 15u) & ~15u) + ((ped_lds_bytes(N) + 15) & ~(size_t)15));
+                        ped_phase_wave<Field>(c, st, field, e, n, lane, is_ped, pq, dt, genv, (uint64_t)st.steps[e], sh.old_rp,
+                                              pa_g[0], ps, pair, pp, pvel);
+                    }
+                }
+            } else if (is_ped) {                                    // env.py:809, 812-820
+                st.ped_dist[pq * 3] = 0.0; st.ped_dist[pq * 3 + 1] = 0.0; st.ped_dist[pq * 3 + 2] = 0.0;
+                st.ped_prev_yaw[pq] = nv::wrap_pi(pp[2]);
+            }
+            if (is_ped) {                                           // env.py:392-414
+                float dist3[3];
+                if (reset_only) { dist3[0] = dist3[1] = dist3[2] = 0.0f; }
+                else { dist3[0] = (float)st.ped_dist[pq * 3]; dist3[1] = (float)st.ped_dist[pq * 3 + 1];
+                       dist3[2] = (float)st.ped_dist[pq * 3 + 2]; }
+                if (st.ped_has_legs[pq] && c.lidar_legs) {
+                    float cc[4];
+                    nv::leg_centres((float)pp[0], (float)pp[1], (float)pp[2], dist3[0], dist3[1], dist3[2], cc);
+                    int q = atomicAdd(&sh.ndisc, 2);
+                    ps.disc[q][0] = cc[0]; ps.disc[q][1] = cc[1];
+                    ps.disc[q + 1][0] = cc[2]; ps.disc[q + 1][1] = cc[3];
+                } else {
+                    const double fpx[4] = {0.22, -0.22, -0.22, 0.22};   // human.py:5-10
+                    const double fpy[4] = {0.19, 0.19, -0.19, -0.19};
+                    double s, cs;
+                    nv::sincos(pp[2], s, cs);
+                    float vx[4], vy[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        vx[v] = (float)((cs * fpx[v] - s * fpy[v]) + pp[0]);
+                        vy[v] = (float)((s * fpx[v] + cs * fpy[v]) + pp[1]);
+                    }
+                    int q = atomicAdd(&sh.nseg, 4);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        int w = (v + 1) & 3;
+                        ps.seg[q + v][0] = vx[v]; ps.seg[q + v][1] = vy[v];
+                        ps.seg[q + v][2] = vx[w]; ps.seg[q + v][3] = vy[w];
+                    }
+                }
+            }
+            wave_lds_sync();
+            prims_prepare<64>(c, sh, prims);                        // in-range flags of the culled merge (this wavefront's lanes)
+        }
+    }
 
     NAVSIM_STAMP(2);
     // ---------------------------------------------------------------- phase 3: scan A
@@ -914,7 +924,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     float2* dir_lds = (float2*)scan_lds;
     float* rng_lds = (float*)(scan_lds + sizeof(float2) * (size_t)B);
     scan_beams_pred<BLOCK, Field, PEDS, RULE, RECT>(c, sh, field, rects, st.beam_table, prims, dir_lds, rng_lds, park, park_lanes, st.scan_threshold,
-                                                         st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort);
+                                                         st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort, false);
 
     NAVSIM_STAMP(3);
     if (!reset_only) {

@@ -106,13 +106,24 @@ size_t step_lds_scan_bytes(const navsim_config* c, int park_lanes) {
     return park_lds_bytes(c->n_beams, park_lanes) +
            (c->ped_model != NAVSIM_PED_NONE ? (size_t)c->n_beams * (sizeof(float2) + sizeof(float)) : 0);
 }
-size_t step_lds_bytes(const navsim_config* c, int park_lanes) {
-    size_t lds = step_lds_scan_bytes(c, park_lanes);
-    if (c->ped_model != NAVSIM_PED_NONE) lds = ((lds + 15) & ~(size_t)15) + ped_lds_bytes(c->max_peds);
-    return lds;
-}
 size_t ped_update_lds_bytes(const navsim_config* c) {                    // ped_update_kernel: a pack of arenas per wavefront
     return (size_t)ped_pack(c->max_peds) * ped_slot_bytes(c->max_peds);
+}
+// pedestrians ahead of the step, a pack of arenas per workgroup (ped_update_kernel), instead of inside it: pays when the
+// chip runs several generations of arenas (c3 13.2 -> 14.0 M env-steps/s in round 2); small batches keep the fused form,
+// whose pedestrian phase runs on wavefront 0 beside the scan of the others
+bool ped_split_on(const navsim_config* c) {
+    if (c->ped_model == NAVSIM_PED_NONE || ped_update_lds_bytes(c) > 64 * 1024) return false;
+    return c->ped_split == 2 || (c->ped_split == 0 && c->n_envs >= 3072);
+}
+size_t step_lds_bytes(const navsim_config* c, int park_lanes) {
+    size_t lds = step_lds_scan_bytes(c, park_lanes);
+    if (c->ped_model != NAVSIM_PED_NONE) {
+        lds = ((lds + 15) & ~(size_t)15) + ped_lds_bytes(c->max_peds);
+        // the fused pedestrian phase keeps its pair table behind PedShared (kernels_step.hpp ped_phase_wave)
+        if (!ped_split_on(c)) lds = ((lds + 15) & ~(size_t)15) + ped_pair_bytes(c->max_peds);
+    }
+    return lds;
 }
 
 // Threads per arena (cfg.step_block = 0).  With >= 12 arenas per CU the chip is kept full by 256-thread
@@ -223,18 +234,12 @@ template <int BLOCK>
 int launch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
                 const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
     const bool peds = c->ped_model != NAVSIM_PED_NONE;
-    // pedestrians ahead of the step, a pack of arenas per workgroup (pays when the chip runs several generations of
-    // arenas: c3 13.2 -> 14.0 M env-steps/s; a 512-arena launch is latency-bound and loses 2 % to the extra
-    // kernel, so small batches keep the fused form)
-    if (peds && !reset_only && ped_update_lds_bytes(c) <= 64 * 1024) {
-        const bool split = c->ped_split == 2 || (c->ped_split == 0 && c->n_envs >= 3072);
-        if (split) {
-            const size_t pl = ped_update_lds_bytes(c);
-            const int G = ped_pack(c->max_peds), pgrid = (c->n_envs + G - 1) / G;
-            if (c->field_format == NAVSIM_FIELD_U16T) ped_update_kernel<FieldU16T><<<pgrid, kPedUpdateBlock, pl, s>>>(*c, *st);
-            else                                      ped_update_kernel<FieldF32><<<pgrid, kPedUpdateBlock, pl, s>>>(*c, *st);
-            reset_only |= 2;
-        }
+    if (peds && !reset_only && ped_split_on(c)) {            // pedestrians ahead of the step (ped_split_on)
+        const size_t pl = ped_update_lds_bytes(c);
+        const int G = ped_pack(c->max_peds), pgrid = (c->n_envs + G - 1) / G;
+        if (c->field_format == NAVSIM_FIELD_U16T) ped_update_kernel<FieldU16T><<<pgrid, kPedUpdateBlock, pl, s>>>(*c, *st);
+        else                                      ped_update_kernel<FieldF32><<<pgrid, kPedUpdateBlock, pl, s>>>(*c, *st);
+        reset_only |= 2;
     }
     if (c->field_format == NAVSIM_FIELD_U16T && !st->field_overflow) {          // no saturated cell anywhere
         return peds ? launch_step_field<BLOCK, true, FieldU16TN>(c, st, io, reset_only, mask, p, s, grid)
