@@ -157,8 +157,9 @@ typedef struct navsim_config {
     /* Launch geometry of the fused step.  Validated plain data: the library reads no environment variable. */
     int32_t step_block;               /* threads per arena: 0 = chosen from the batch size,
                                          else 64, 256, 512 or 1024 */
-    int32_t ped_split;                /* pedestrian update in its own one-wavefront-per-arena kernel ahead of the
-                                         step: 0 = for large batches (>= 3072 arenas), 1 = never, 2 = always */
+    int32_t ped_split;                /* pedestrian update in its own kernel (a pack of arenas per workgroup) ahead of the
+                                         step: 0 or 1 = no, inside the step on one wavefront beside the scan (faster at every
+                                         batch size since round 3), 2 = yes */
     int32_t regen_check_discomfort;   /* navsim_regen: 1 (default) = a robot start whose FIRST scan (no pedestrians, no noise) has a
                                          beam inside the discomfort zone is dropped and the next start / goal pair of the
                                          spawn table takes its place, like reset() re-draws the robot (env.py:776-781) */

@@ -32,8 +32,8 @@ struct PedShared {
     float* info;                             // [6 N] merge_prims_culled_core scratch: in-range flag per primitive
 };
 __host__ __device__ inline size_t ped_lds_bytes(int N) { return (size_t)136 * N + 32; }
-// the arena's table of social-force pair terms, [N][N + 1] double2 (ped_pair_term); in the fused step it sits behind PedShared
-__host__ __device__ inline size_t ped_pair_bytes(int N) { return ((size_t)N * (N + 1) * sizeof(double2) + 15) & ~(size_t)15; }
+// the arena's table of social-force pair terms, N (N - 1) / 2 + N double2 (ped_pair_term); in the fused step it sits behind PedShared
+__host__ __device__ inline size_t ped_pair_bytes(int N) { return ((size_t)(N * (N - 1) / 2 + N) * sizeof(double2) + 15) & ~(size_t)15; }
 __device__ __forceinline__ PedShared ped_lds_carve(char* base, int N) {
     PedShared ps;
     double* d = (double*)base;
@@ -533,20 +533,29 @@ __device__ __forceinline__ void ped_pair_index(int t, int n, int& i, int& j) {
         i = t - n_pp; j = n;
     }
 }
-// pair term t of an arena into its [n, n + 1] table: the term on pedestrian j from pedestrian i is EXACTLY minus the term
-// on i from j (every operand of sfm_pair changes sign or stays -- differences, their squares, quotients, the odd atan2
-// of two sign-symmetric products -- and round-to-nearest is symmetric under negation), so each unordered pedestrian
-// pair is evaluated once and stored twice; the robot (index n) only acts, it receives nothing
+// pair term t of an arena into its table of n (n - 1) / 2 + n terms (slot t = term t): the term on pedestrian j from
+// pedestrian i is EXACTLY minus the term on i from j (every operand of sfm_pair changes sign or stays -- differences, their
+// squares, quotients, the odd atan2 of two sign-symmetric products -- and round-to-nearest is symmetric under negation), so
+// each unordered pedestrian pair is evaluated and stored once and read twice (ped_pair_read negates for the second
+// reader); the robot (index n) only acts, it receives nothing.  (Round 3: the table was [n][n + 1] with both signs stored;
+// half of it keeps eight 256-thread arenas on a CU once the fused kernel carries the table.)
 __device__ __forceinline__ void ped_pair_term(const navsim_config& c, const PedShared& ps, double2* pair, int n, int t) {
     int i, j;
     ped_pair_index(t, n, i, j);
     double fx, fy;
     sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
-    pair[i * (n + 1) + j] = make_double2(fx, fy);
-    if (j < n) pair[j * (n + 1) + i] = make_double2(-fx, -fy);
+    pair[t] = make_double2(fx, fy);
+}
+// the term on pedestrian i from agent j (j != i; j == n: the robot)
+__device__ __forceinline__ double2 ped_pair_read(const double2* pair, int n, int i, int j) {
+    if (j == n) return pair[n * (n - 1) / 2 + i];
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const double2 f = pair[lo * (n - 1) - lo * (lo - 1) / 2 + (hi - lo - 1)];       // ped_pair_index's row-by-row upper triangle
+    return i < j ? f : make_double2(-f.x, -f.y);
 }
 // forces on pedestrian i and its semi-implicit Euler step: desired + social (its row of the pair
-// table in partner order, or evaluated here when there is no table) + obstacle (distance-field gradient)
+// table in partner order; a second, inlined sfm_pair in this loop cost the fused kernel 100 bytes of spills) + obstacle
+// (distance-field gradient)
 template <typename Field>
 __device__ __forceinline__ void ped_sfm_step(const navsim_config& c, const Field& field, const PedShared& ps,
                                              const double2* pair, int n, int i, double vpref, const double* wp, double dt,
@@ -557,13 +566,11 @@ __device__ __forceinline__ void ped_sfm_step(const navsim_config& c, const Field
     double fdx = (vpref * ex - ps.avx[i]) / c.sfm_tau;
     double fdy = (vpref * ey - ps.avy[i]) / c.sfm_tau;
     double fsx = 0.0, fsy = 0.0;
-    for (int j = 0; j <= n; ++j) {
+    for (int j = 0; j <= n; ++j) {                      // the row of the pair table, in partner order
         if (j == i) continue;
-        double fx, fy;
-        if (pair) { double2 f = pair[i * (n + 1) + j]; fx = f.x; fy = f.y; }
-        else sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
-        fsx += fx;
-        fsy += fy;
+        const double2 f = ped_pair_read(pair, n, i, j);
+        fsx += f.x;
+        fsy += f.y;
     }
     double fox = 0.0, foy = 0.0;
     {
@@ -640,32 +647,41 @@ __device__ __forceinline__ void wave_lds_sync() {
 // 15 wavefronts of a 1024-thread workgroup at a barrier for 15 of the workgroup's 41 us.  The pair terms (n (n - 1) / 2
 // + n, independent) are spread over the 64 lanes into the arena's pair table (LDS behind PedShared), then every
 // pedestrian adds its row in partner order -- the same sums, in the same order, as a sequential loop.
-template <typename Field>
-__device__ __forceinline__ void ped_phase_wave(const navsim_config& c, const navsim_state& st, const Field& field, int e,
-                                               int n, int lane, bool is_ped, size_t pq, double dt, uint64_t genv,
-                                               uint64_t steps_now, const double* old_rp, double prev_v, const PedShared& ps,
-                                               double2* pair, double (&pp)[3], double (&pvel)[2]) {
+// (a) before the workgroup's first barrier -- beside the robot's step on another wavefront: waypoint pop, every agent's
+// position / velocity at time t staged (pedestrians, then the robot from its global state, which nobody writes before
+// the end of the kernel); returns the remaining waypoint count
+__device__ __forceinline__ int ped_stage_wave(const navsim_config& c, const navsim_state& st, int n, int lane, bool is_ped,
+                                              size_t pq, const double* rp_t, double prev_v, const PedShared& ps,
+                                              const double (&pp)[3], const double (&pvel)[2]) {
     const int P = NAVSIM_MAX_WAYPOINTS;
     double* wp = st.ped_waypoints ? st.ped_waypoints + (pq * P) * 2 : nullptr;
     int nw = 1;
     if (is_ped) nw = ped_pop_waypoints(wp, st.ped_n_waypoints[pq], pp);
     if (c.ped_model == NAVSIM_PED_SFM) {
-        // stage every agent's position / velocity at time t (pedestrians, then the robot)
         if (is_ped) { ps.ax[lane] = pp[0]; ps.ay[lane] = pp[1]; ps.avx[lane] = pvel[0]; ps.avy[lane] = pvel[1]; }
         if (lane == 0) {
             double s, cs;
-            nv::sincos(old_rp[2], s, cs);
-            ps.ax[n] = old_rp[0]; ps.ay[n] = old_rp[1];
+            nv::sincos(rp_t[2], s, cs);
+            ps.ax[n] = rp_t[0]; ps.ay[n] = rp_t[1];
             ps.avx[n] = prev_v * cs; ps.avy[n] = prev_v * s;
         }
+    }
+    return nw;
+}
+// (b) behind it: pair terms, forces and the Euler step, new goals, leg odometry, state
+template <typename Field>
+__device__ __forceinline__ void ped_advance_wave(const navsim_config& c, const navsim_state& st, const Field& field, int e,
+                                                 int n, int lane, bool is_ped, size_t pq, double dt, uint64_t genv,
+                                                 uint64_t steps_now, const PedShared& ps, double2* pair, int nw,
+                                                 double (&pp)[3], double (&pvel)[2]) {
+    const int P = NAVSIM_MAX_WAYPOINTS;
+    double* wp = st.ped_waypoints ? st.ped_waypoints + (pq * P) * 2 : nullptr;
+    if (c.ped_model == NAVSIM_PED_SFM) {
+        wave_lds_sync();                                    // the staged agents (the workgroup barrier lies in between as well)
+        const int n_terms = n * (n - 1) / 2 + n;
+        for (int t = lane; t < n_terms; t += 64) ped_pair_term(c, ps, pair, n, t);
         wave_lds_sync();
-        const bool pair_par = pair != nullptr && n > 1;
-        if (pair_par) {
-            const int n_terms = n * (n - 1) / 2 + n;
-            for (int t = lane; t < n_terms; t += 64) ped_pair_term(c, ps, pair, n, t);
-            wave_lds_sync();
-        }
-        if (is_ped) ped_sfm_step(c, field, ps, pair_par ? pair : nullptr, n, lane, st.ped_v_pref[pq], wp, dt, pp, pvel);
+        if (is_ped) ped_sfm_step(c, field, ps, pair, n, lane, st.ped_v_pref[pq], wp, dt, pp, pvel);
     } else if (c.ped_model == NAVSIM_PED_EXTERNAL && is_ped) {
         const double* cmd = st.ped_cmd + pq * 2;
         nv::set_vel(pp, cmd[0], cmd[1], dt, 0.0, pvel);     // env.py:662
@@ -737,7 +753,7 @@ __global__ __launch_bounds__(kPedUpdateBlock) void ped_update_kernel(navsim_conf
         __syncthreads();
         if (lane == 0) {                                               // the pack's pair terms as one list
             int off = 0;
-            for (int q = 0; q < G; ++q) { slot_off[q] = off; const int m = slot_n[q]; off += m > 1 ? m * (m - 1) / 2 + m : 0; }
+            for (int q = 0; q < G; ++q) { slot_off[q] = off; const int m = slot_n[q]; off += m * (m - 1) / 2 + m; }
             slot_off[G] = off;
         }
         __syncthreads();
@@ -749,7 +765,7 @@ __global__ __launch_bounds__(kPedUpdateBlock) void ped_update_kernel(navsim_conf
             ped_pair_term(c, ped_lds_carve(base + ped_pair_bytes(N), N), (double2*)base, slot_n[q], t - slot_off[q]);
         }
         __syncthreads();
-        if (is_ped) ped_sfm_step(c, field, ps, n > 1 ? (const double2*)my : nullptr, n, i, st.ped_v_pref[pq], wp, dt, pp, pvel);
+        if (is_ped) ped_sfm_step(c, field, ps, (const double2*)my, n, i, st.ped_v_pref[pq], wp, dt, pp, pvel);
     } else if (c.ped_model == NAVSIM_PED_EXTERNAL && is_ped) {
         const double* cmd = st.ped_cmd + pq * 2;
         nv::set_vel(pp, cmd[0], cmd[1], dt, 0.0, pvel);               // env.py:662
@@ -817,11 +833,31 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const float noise_std = (c.add_scan_noise && st.scan_noise_std) ? st.scan_noise_std[e] : 0.0f;
 
     NAVSIM_STAMP(0);
+    // wavefront 0 of the pedestrian variants: pedestrian i on lane i.  Its loads, the waypoint pop and the staging of the
+    // agents run beside phase 0, which a lane of wavefront 1 computes.
+    double pp[3] = {0.0, 0.0, 0.0};
+    double pvel[2] = {0.0, 0.0};
+    const bool is_ped = PEDS && tid < n;                        // n <= 64
+    const size_t pq = (size_t)e * N + (is_ped ? tid : 0);
+    const bool ped_advance = PEDS && PINL && !reset_only && !peds_done;
+    int ped_nw = 1;
+    if constexpr (PEDS) {
+        if (tid < 64) {
+            if (is_ped) {
+                pp[0] = st.ped_pose[pq * 3]; pp[1] = st.ped_pose[pq * 3 + 1]; pp[2] = st.ped_pose[pq * 3 + 2];
+                pvel[0] = st.ped_vel[pq * 2]; pvel[1] = st.ped_vel[pq * 2 + 1];
+            }
+            if constexpr (PINL) {
+                if (ped_advance) ped_nw = ped_stage_wave(c, st, n, tid, is_ped, pq, rp_g, pa_g[0], ps, pp, pvel);
+            }
+        }
+    }
+    constexpr int kPhase0Thread = (PEDS && BLOCK > 64) ? 64 : 0;
     // ---------------------------------------------------------------- phase 0: scalars, robot, lidar pose
     // The robot moves here, ahead of the pedestrians (env.py:664 comes after their commands, but nothing the pedestrian
     // phase computes reads the robot's new pose -- the social force sees old_rp -- and nothing here reads a pedestrian):
     // after ONE barrier the scan can start while wavefront 0 is still with the pedestrians.
-    if (tid == 0) {
+    if (tid == kPhase0Thread) {
         sh.old_rp[0] = rp_g[0]; sh.old_rp[1] = rp_g[1]; sh.old_rp[2] = rp_g[2];
         sh.nseg = 0; sh.ndisc = 0; sh.rescan = 0; sh.respawn = 0;
         if (!reset_only) {
@@ -856,24 +892,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     if constexpr (PEDS) {
         if (tid < 64) {
             const int lane = tid;
-            double pp[3] = {0.0, 0.0, 0.0};
-            double pvel[2] = {0.0, 0.0};
-            const size_t pq = (size_t)e * N + (lane < n ? lane : 0);
-            const bool is_ped = lane < n;
-            if (is_ped) {
-                pp[0] = st.ped_pose[pq * 3]; pp[1] = st.ped_pose[pq * 3 + 1]; pp[2] = st.ped_pose[pq * 3 + 2];
-                pvel[0] = st.ped_vel[pq * 2]; pvel[1] = st.ped_vel[pq * 2 + 1];
-            }
-            if (!reset_only) {
-                if constexpr (PINL) {
-                    if (!peds_done) {
-                        // the pair table: dynamic LDS behind PedShared (the host allocates it for the launches that carry the phase)
-                        double2* pair = (double2*)(dyn_lds + ((dyn_lds_bytes + 15u) & ~15u) + ((ped_lds_bytes(N) + 15) & ~(size_t)15));
-                        ped_phase_wave<Field>(c, st, field, e, n, lane, is_ped, pq, dt, genv, (uint64_t)st.steps[e], sh.old_rp,
-                                              pa_g[0], ps, pair, pp, pvel);
-                    }
+            if constexpr (PINL) {
+                if (ped_advance) {
+                    // the pair table: dynamic LDS behind PedShared (the host allocates it for the launches that carry the phase)
+                    double2* pair = (double2*)(dyn_lds + ((dyn_lds_bytes + 15u) & ~15u) + ((ped_lds_bytes(N) + 15) & ~(size_t)15));
+                    ped_advance_wave<Field>(c, st, field, e, n, lane, is_ped, pq, dt, genv, (uint64_t)st.steps[e], ps, pair,
+                                            ped_nw, pp, pvel);
                 }
-            } else if (is_ped) {                                    // env.py:809, 812-820
+            }
+            if (reset_only && is_ped) {                             // env.py:809, 812-820
                 st.ped_dist[pq * 3] = 0.0; st.ped_dist[pq * 3 + 1] = 0.0; st.ped_dist[pq * 3 + 2] = 0.0;
                 st.ped_prev_yaw[pq] = nv::wrap_pi(pp[2]);
             }

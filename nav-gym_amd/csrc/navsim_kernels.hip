@@ -109,12 +109,13 @@ size_t step_lds_scan_bytes(const navsim_config* c, int park_lanes) {
 size_t ped_update_lds_bytes(const navsim_config* c) {                    // ped_update_kernel: a pack of arenas per wavefront
     return (size_t)ped_pack(c->max_peds) * ped_slot_bytes(c->max_peds);
 }
-// pedestrians ahead of the step, a pack of arenas per workgroup (ped_update_kernel), instead of inside it: pays when the
-// chip runs several generations of arenas (c3 13.2 -> 14.0 M env-steps/s in round 2); small batches keep the fused form,
-// whose pedestrian phase runs on wavefront 0 beside the scan of the others
+// pedestrians ahead of the step, a pack of arenas per workgroup (ped_update_kernel), instead of inside it: only on request
+// (cfg.ped_split = 2).  Round 2 split large batches automatically (the fused phase held three of four wavefronts at a
+// barrier: c3 13.2 -> 14.0 M env-steps/s); since the phase runs on wavefront 0 BESIDE the scan of the others the fused
+// form wins everywhere (c3, same box: split 21.0, fused 21.9 M; c5 fused 3.84 -> 4.28 M).
 bool ped_split_on(const navsim_config* c) {
     if (c->ped_model == NAVSIM_PED_NONE || ped_update_lds_bytes(c) > 64 * 1024) return false;
-    return c->ped_split == 2 || (c->ped_split == 0 && c->n_envs >= 3072);
+    return c->ped_split == 2;
 }
 size_t step_lds_bytes(const navsim_config* c, int park_lanes) {
     size_t lds = step_lds_scan_bytes(c, park_lanes);
