@@ -188,7 +188,10 @@ __device__ __forceinline__ void merge_prims_culled_core(int B, float lx, float l
         float rel = ac - beta0;
         rel -= kTwoPiF * floorf(rel / kTwoPiF + 0.5f);              // [-pi, pi)
         const float klo = (rel - w) / stepf - 2.0f, khi = (rel + w) / stepf + 2.0f;
-        for (int m = full ? 0 : -1; m <= (full ? 0 : 1); ++m) {
+        // aliases of the bearing: rel + w <= pi + 1.6 < 2 pi - 2 beams, so rel - 2 pi (m = -1) lies below beam 0 unless the
+        // beams are very few
+        const int m_first = (kTwoPiF - 2.0f * stepf > 4.8f) ? 0 : -1;
+        for (int m = full ? 0 : m_first; m <= (full ? 0 : 1); ++m) {
             int k0 = full ? 0 : (int)floorf(klo + (float)m * Kf);
             int k1 = full ? B - 1 : (int)ceilf(khi + (float)m * Kf);
             k0 = k0 < 0 ? 0 : k0;
@@ -536,7 +539,7 @@ __device__ __forceinline__ void ped_pair_index(int t, int n, int& i, int& j) {
 // pair term t of an arena into its table of n (n - 1) / 2 + n terms (slot t = term t): the term on pedestrian j from
 // pedestrian i is EXACTLY minus the term on i from j (every operand of sfm_pair changes sign or stays -- differences, their
 // squares, quotients, the odd atan2 of two sign-symmetric products -- and round-to-nearest is symmetric under negation), so
-// each unordered pedestrian pair is evaluated and stored once and read twice (ped_pair_read negates for the second
+// each unordered pedestrian pair is evaluated and stored once and read twice (ped_sfm_step subtracts for the second
 // reader); the robot (index n) only acts, it receives nothing.  (Round 3: the table was [n][n + 1] with both signs stored;
 // half of it keeps eight 256-thread arenas on a CU once the fused kernel carries the table.)
 __device__ __forceinline__ void ped_pair_term(const navsim_config& c, const PedShared& ps, double2* pair, int n, int t) {
@@ -545,13 +548,6 @@ __device__ __forceinline__ void ped_pair_term(const navsim_config& c, const PedS
     double fx, fy;
     sfm_pair(c, ps.ax[i], ps.ay[i], ps.avx[i], ps.avy[i], ps.ax[j], ps.ay[j], ps.avx[j], ps.avy[j], fx, fy);
     pair[t] = make_double2(fx, fy);
-}
-// the term on pedestrian i from agent j (j != i; j == n: the robot)
-__device__ __forceinline__ double2 ped_pair_read(const double2* pair, int n, int i, int j) {
-    if (j == n) return pair[n * (n - 1) / 2 + i];
-    const int lo = i < j ? i : j, hi = i < j ? j : i;
-    const double2 f = pair[lo * (n - 1) - lo * (lo - 1) / 2 + (hi - lo - 1)];       // ped_pair_index's row-by-row upper triangle
-    return i < j ? f : make_double2(-f.x, -f.y);
 }
 // forces on pedestrian i and its semi-implicit Euler step: desired + social (its row of the pair
 // table in partner order; a second, inlined sfm_pair in this loop cost the fused kernel 100 bytes of spills) + obstacle
@@ -566,9 +562,23 @@ __device__ __forceinline__ void ped_sfm_step(const navsim_config& c, const Field
     double fdx = (vpref * ex - ps.avx[i]) / c.sfm_tau;
     double fdy = (vpref * ey - ps.avy[i]) / c.sfm_tau;
     double fsx = 0.0, fsy = 0.0;
-    for (int j = 0; j <= n; ++j) {                      // the row of the pair table, in partner order
-        if (j == i) continue;
-        const double2 f = ped_pair_read(pair, n, i, j);
+    // the terms on pedestrian i in partner order j = 0 .. n (ped_pair_term's slots): partners below i hold the pair in
+    // THEIR row, with the opposite sign (x - y is x + (-y) exactly); then its own row; then the robot
+    {
+        int slot = i - 1;                                   // (0, i)
+        for (int j = 0; j < i; ++j) {
+            const double2 f = pair[slot];
+            fsx -= f.x;
+            fsy -= f.y;
+            slot += n - 2 - j;                              // (j + 1, i)
+        }
+        slot = i * (n - 1) - i * (i - 1) / 2;               // (i, i + 1)
+        for (int j = i + 1; j < n; ++j, ++slot) {
+            const double2 f = pair[slot];
+            fsx += f.x;
+            fsy += f.y;
+        }
+        const double2 f = pair[n * (n - 1) / 2 + i];
         fsx += f.x;
         fsy += f.y;
     }
