@@ -10,7 +10,7 @@
 template <typename Field, int BLOCK, int RULE, bool RECT>
 __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim_state st, float* __restrict__ out) {
     __shared__ float seg[4 * (NAVSIM_MAX_PEDS + 1)][4];
-    __shared__ float info_s[4 * (NAVSIM_MAX_PEDS + 1)];
+    __shared__ float info_s[8 * (NAVSIM_MAX_PEDS + 1)];          // beam-index interval per rectangle side (prim_in_range)
     __shared__ int nseg_s, i0_s, j0_s;
     __shared__ float lx_s, ly_s, lth_s;
     extern __shared__ __attribute__((aligned(16))) char dyn[];       // float2 dir[PB], float rng[PB]
@@ -70,10 +70,10 @@ __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim
         rng[k] = ray_result(hit, x0, y0, dx, dy, t, max_range) * res;
     }
     const Prims pr = {seg, nullptr, info_s};
-    prim_in_range<BLOCK>(nseg_s, nseg_s, lx_s, ly_s, rmax * 1.0001f + 0.01f, pr);     // which rectangles can matter at all
+    prim_in_range<BLOCK>(nseg_s, nseg_s, lx_s, ly_s, rmax * 1.0001f + 0.01f, pr, (float)step,
+                         (float)(c.ped_angle_min + lth));                             // which sides can matter, for which beams
     __syncthreads();
-    merge_prims_culled_core<BLOCK>(PB, lx_s, ly_s, (float)step, (float)(c.ped_angle_min + lth), nseg_s, 0, pr, dir, rng,
-                                   rmax * 1.0001f + 0.01f);
+    merge_prims_culled_core<BLOCK>(PB, lx_s, ly_s, (float)step, nseg_s, 0, pr, dir, rng);
     __syncthreads();
     float* row = out + ((size_t)e * N + i) * PB;
     for (int k = tid; k < PB; k += BLOCK) {

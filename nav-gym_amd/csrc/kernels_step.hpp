@@ -23,15 +23,15 @@ struct StepShared {
     double wave_ratio[kMaxWaves];
 };
 // Pedestrian scratch of the pedestrian variants of the kernel, carved out of dynamic LDS behind the scan's
-// dir / rng area and sized by cfg.max_peds (N), not by the compiled maximum: 136 N + 32 bytes, so that a
+// dir / rng area and sized by cfg.max_peds (N), not by the compiled maximum: 144 N + 32 bytes, so that a
 // 20-pedestrian world still fits 8 arenas per CU (the static 64-pedestrian layout allowed 7).
 struct PedShared {
     double *ax, *ay, *avx, *avy;             // [N + 1] agent positions / velocities at time t (robot last)
     float (*seg)[4];                         // [4 N] rectangle edges seen by the lidar ...
     float (*disc)[2];                        // [2 N] ... leg discs (stored right behind seg)
-    float* info;                             // [6 N] merge_prims_culled_core scratch: in-range flag per primitive
+    float* info;                             // [8 N] merge_prims_culled_core: beam-index interval of every primitive (prim_in_range)
 };
-__host__ __device__ inline size_t ped_lds_bytes(int N) { return (size_t)136 * N + 32; }
+__host__ __device__ inline size_t ped_lds_bytes(int N) { return (size_t)144 * N + 32; }
 // the arena's table of social-force pair terms, N (N - 1) / 2 + N double2 (ped_pair_term); in the fused step it sits behind PedShared
 __host__ __device__ inline size_t ped_pair_bytes(int N) { return ((size_t)(N * (N - 1) / 2 + N) * sizeof(double2) + 15) & ~(size_t)15; }
 __device__ __forceinline__ PedShared ped_lds_carve(char* base, int N) {
@@ -128,50 +128,25 @@ __device__ __forceinline__ void first_probe(const Field& field, int i0, int j0, 
 // three 2*pi aliases) and runs the SAME float32 seg_merge / circle_merge on those beams only;
 // results land with an LDS atomicMin on the (non-negative) float bits, so they do not depend on the
 // order of primitives.  rng[] holds metres, dir[] the beam directions.
-// One lane per primitive: can it change the clipped scan at all?  Every point of a segment is at least
-// |u| - |v - u| from the lidar (a disc: |u| - r); beyond the clip range a hit cannot matter, because
-// clip(min(r, t)) = clip(r) for t >= range_max.  info[p] < 0 marks such a primitive.
+// One lane per primitive, once per scan: can it change the clipped scan at all, and which beams can hit it?  Every
+// point of a segment is at least |u| - |v - u| from the lidar (a disc: |u| - r); beyond the clip range a hit cannot
+// matter, because clip(min(r, t)) = clip(r) for t >= range_max.  info[2 p], info[2 p + 1] = the beam-index interval
+// [klo, khi] of the primitive's bearing (before the 2 pi aliases), empty (klo > khi) for a primitive out of range, all
+// beams (klo = -inf) where a bearing is meaningless.  (Round 3: the eight lanes that share a primitive in the merge
+// used to derive the interval themselves, two atan2f per primitive and ROUND of the merge instead of per primitive:
+// 6 % of c3's vector instructions.)
+constexpr float kPrimAllBeams = 1.0e30f;
 template <int BLOCK>
-__device__ __forceinline__ void prim_in_range(int nprim, int nseg, float lx, float ly, float rcull, const Prims pr) {
+__device__ __forceinline__ void prim_in_range(int nprim, int nseg, float lx, float ly, float rcull, const Prims pr,
+                                              float stepf, float beta0) {
+    const float kTwoPiF = 6.2831853f;
     for (int p = (int)threadIdx.x; p < nprim; p += BLOCK) {
         bool skip;
+        float ac = 0.0f, w = 0.0f;
+        bool full = (stepf <= 0.0f);
         if (p < nseg) {
             float ux = pr.seg[p][0] - lx, uy = pr.seg[p][1] - ly, vx = pr.seg[p][2] - lx, vy = pr.seg[p][3] - ly;
             skip = sqrtf(ux * ux + uy * uy) - sqrtf((vx - ux) * (vx - ux) + (vy - uy) * (vy - uy)) > rcull;
-        } else {
-            float ux = pr.disc[p - nseg][0] - lx, uy = pr.disc[p - nseg][1] - ly;
-            skip = sqrtf(ux * ux + uy * uy) - nv::kLegRadius > rcull;
-        }
-        pr.info[p] = skip ? -1.0f : 1.0f;
-    }
-}
-
-template <int BLOCK>
-__device__ __forceinline__ void merge_prims_culled_core(int B, float lx, float ly, float stepf, float beta0,
-                                                        int nseg, int ndisc, const Prims pr,
-                                                        const float2* __restrict__ dir, float* __restrict__ rng,
-                                                        float rcull) {
-    const int lane = (int)threadIdx.x & 63;
-    const float kTwoPiF = 6.2831853f;
-    const float Kf = (stepf > 0.0f) ? kTwoPiF / stepf : 0.0f;
-    const int nprim = nseg + ndisc;
-    (void)rcull;                                                // prim_in_range(rcull) ran before the scan (prims_prepare)
-    // eight lanes per primitive, eight primitives per wavefront at a time (a pedestrian a few metres away
-    // spans 10-50 beams; measured 4 / 8 / 16 / 32 / 64 lanes: c3 11.81 / 11.80 / 11.68 / 11.13 / 10.26 M env-steps/s)
-#ifndef NAVSIM_MERGE_G
-#define NAVSIM_MERGE_G 8
-#endif
-    constexpr int G = NAVSIM_MERGE_G;
-    const int sub = lane & (G - 1);
-    for (int p = ((int)threadIdx.x) / G; p < nprim; p += BLOCK / G) {
-        if (pr.info[p] < 0.0f) continue;                            // beyond the clip range
-        const bool is_seg = p < nseg;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        float ac = 0.0f, w = 0.0f;
-        bool full = (stepf <= 0.0f);
-        if (is_seg) {
-            a0 = pr.seg[p][0]; a1 = pr.seg[p][1]; a2 = pr.seg[p][2]; a3 = pr.seg[p][3];
-            float ux = a0 - lx, uy = a1 - ly, vx = a2 - lx, vy = a3 - ly;
             float b1 = atan2f(uy, ux), b2 = atan2f(vy, vx);
             float d = b2 - b1;
             d -= kTwoPiF * floorf(d / kTwoPiF + 0.5f);              // (-pi, pi]
@@ -179,18 +154,48 @@ __device__ __forceinline__ void merge_prims_culled_core(int B, float lx, float l
             w = 0.5f * fabsf(d);
             if (fabsf(d) > 3.0f || ux * ux + uy * uy < 1e-6f || vx * vx + vy * vy < 1e-6f) full = true;
         } else {
-            a0 = pr.disc[p - nseg][0]; a1 = pr.disc[p - nseg][1];
-            float ux = a0 - lx, uy = a1 - ly;
+            float ux = pr.disc[p - nseg][0] - lx, uy = pr.disc[p - nseg][1] - ly;
             float dist = sqrtf(ux * ux + uy * uy);
+            skip = dist - nv::kLegRadius > rcull;
             if (dist <= nv::kLegRadius * 1.05f) full = true;
             else { ac = atan2f(uy, ux); w = asinf(fminf(1.0f, nv::kLegRadius / dist)); }
         }
         float rel = ac - beta0;
         rel -= kTwoPiF * floorf(rel / kTwoPiF + 0.5f);              // [-pi, pi)
-        const float klo = (rel - w) / stepf - 2.0f, khi = (rel + w) / stepf + 2.0f;
-        // aliases of the bearing: rel + w <= pi + 1.6 < 2 pi - 2 beams, so rel - 2 pi (m = -1) lies below beam 0 unless the
-        // beams are very few
-        const int m_first = (kTwoPiF - 2.0f * stepf > 4.8f) ? 0 : -1;
+        float klo = (rel - w) / stepf - 2.0f, khi = (rel + w) / stepf + 2.0f;   // two beams of margin
+        if (full) { klo = -kPrimAllBeams; khi = kPrimAllBeams; }
+        if (skip) { klo = kPrimAllBeams; khi = -kPrimAllBeams; }
+        pr.info[2 * p] = klo;
+        pr.info[2 * p + 1] = khi;
+    }
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void merge_prims_culled_core(int B, float lx, float ly, float stepf,
+                                                        int nseg, int ndisc, const Prims pr,
+                                                        const float2* __restrict__ dir, float* __restrict__ rng) {
+    const int lane = (int)threadIdx.x & 63;
+    const float kTwoPiF = 6.2831853f;
+    const float Kf = (stepf > 0.0f) ? kTwoPiF / stepf : 0.0f;
+    const int nprim = nseg + ndisc;
+    // eight lanes per primitive, eight primitives per wavefront at a time (a pedestrian a few metres away
+    // spans 10-50 beams; measured 4 / 8 / 16 / 32 / 64 lanes: c3 11.81 / 11.80 / 11.68 / 11.13 / 10.26 M env-steps/s)
+#ifndef NAVSIM_MERGE_G
+#define NAVSIM_MERGE_G 8
+#endif
+    constexpr int G = NAVSIM_MERGE_G;
+    const int sub = lane & (G - 1);
+    // aliases of the bearing: rel + w <= pi + 1.6 < 2 pi - 2 beams, so rel - 2 pi (m = -1) lies below beam 0 unless the
+    // beams are very few
+    const int m_first = (kTwoPiF - 2.0f * stepf > 4.8f) ? 0 : -1;
+    for (int p = ((int)threadIdx.x) / G; p < nprim; p += BLOCK / G) {
+        const float klo = pr.info[2 * p], khi = pr.info[2 * p + 1];  // prim_in_range ran before the scan (prims_prepare)
+        if (klo > khi) continue;                                    // beyond the clip range
+        const bool full = klo < -0.5f * kPrimAllBeams;
+        const bool is_seg = p < nseg;
+        float a0, a1, a2 = 0.f, a3 = 0.f;
+        if (is_seg) { a0 = pr.seg[p][0]; a1 = pr.seg[p][1]; a2 = pr.seg[p][2]; a3 = pr.seg[p][3]; }
+        else { a0 = pr.disc[p - nseg][0]; a1 = pr.disc[p - nseg][1]; }
         for (int m = full ? 0 : m_first; m <= (full ? 0 : 1); ++m) {
             int k0 = full ? 0 : (int)floorf(klo + (float)m * Kf);
             int k1 = full ? B - 1 : (int)ceilf(khi + (float)m * Kf);
@@ -207,19 +212,18 @@ __device__ __forceinline__ void merge_prims_culled_core(int B, float lx, float l
     }
 }
 
-// which primitives can matter at all (info[]): needs only the primitives and the lidar pose, so it runs BEFORE the scan
-// and is covered by the barrier that ends the scan
+// which primitives can matter, and for which beams (info[]): needs only the primitives and the lidar pose, so it runs
+// BEFORE the scan and is covered by the barrier that ends the scan
 __host__ __device__ inline float prim_cull_range(double range_max) { return (float)range_max * 1.0001f + 0.01f; }
 template <int BLOCK>
 __device__ __forceinline__ void prims_prepare(const navsim_config& c, const StepShared& sh, const Prims pr) {
-    prim_in_range<BLOCK>(sh.nseg + sh.ndisc, sh.nseg, sh.lx, sh.ly, prim_cull_range(c.range_max), pr);
+    prim_in_range<BLOCK>(sh.nseg + sh.ndisc, sh.nseg, sh.lx, sh.ly, prim_cull_range(c.range_max), pr,
+                         (float)nv::linspace_step(c), (float)(c.angle_min + (double)sh.lth));
 }
 template <int BLOCK>
 __device__ __forceinline__ void merge_prims_culled(const navsim_config& c, const StepShared& sh, const Prims pr,
                                                    const float2* __restrict__ dir, float* __restrict__ rng) {
-    merge_prims_culled_core<BLOCK>(c.n_beams, sh.lx, sh.ly, (float)nv::linspace_step(c),
-                                   (float)(c.angle_min + (double)sh.lth), sh.nseg, sh.ndisc, pr, dir, rng,
-                                   prim_cull_range(c.range_max));
+    merge_prims_culled_core<BLOCK>(c.n_beams, sh.lx, sh.ly, (float)nv::linspace_step(c), sh.nseg, sh.ndisc, pr, dir, rng);
 }
 
 // raw ranges (cells) -> metres, pedestrians, clip, noise, crash / discomfort flags, observation row
