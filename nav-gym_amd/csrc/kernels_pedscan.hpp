@@ -9,11 +9,12 @@
 // ============================================================================================
 template <typename Field, int BLOCK, int RULE, bool RECT>
 __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim_state st, float* __restrict__ out) {
-    __shared__ float seg[4 * (NAVSIM_MAX_PEDS + 1)][4];
-    __shared__ float info_s[8 * (NAVSIM_MAX_PEDS + 1)];          // beam-index interval per rectangle side (prim_in_range)
     __shared__ int nseg_s, i0_s, j0_s;
     __shared__ float lx_s, ly_s, lth_s;
-    extern __shared__ __attribute__((aligned(16))) char dyn[];       // float2 dir[PB], float rng[PB]
+    // dynamic LDS (ped_scan_lds_bytes): float2 dir[PB], float rng[PB], then the rectangle sides of the other agents and
+    // their beam-index intervals (prim_in_range), sized by cfg.max_peds -- the compiled maximum of 64 pedestrians cost
+    // 6 KB per workgroup and, with 512 beams, two of the CU's 16 workgroups
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
     const int e = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
     const int N = c.max_peds, PB = c.ped_n_beams, H = c.map_h, W = c.map_w;
     int n = st.n_peds[e];
@@ -21,6 +22,8 @@ __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim
     if (i >= n) return;
     float2* dir = (float2*)dyn;
     float* rng = (float*)(dyn + sizeof(float2) * (size_t)PB);
+    float (*seg)[4] = (float(*)[4])(dyn + ((12 * (size_t)PB + 15) & ~(size_t)15));
+    float* info_s = (float*)(seg + 4 * (N + 1));
     if (tid == 0) {
         nseg_s = 0;
         const double* pp = st.ped_pose + ((size_t)e * N + i) * 3;

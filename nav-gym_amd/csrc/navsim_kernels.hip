@@ -574,7 +574,8 @@ int navsim_ped_scans(const navsim_config* c, const navsim_state* st, float* out,
     if (c->max_peds > NAVSIM_MAX_PEDS || c->ped_n_beams > 4096) return NAVSIM_E_UNSUPPORTED;
     if (c->n_envs == 0) return NAVSIM_OK;
     dim3 grid(c->max_peds, c->n_envs);
-    size_t lds = (size_t)c->ped_n_beams * (sizeof(float2) + sizeof(float));
+    // dir + rng per beam, then 4 sides x 16 B + 4 intervals x 8 B per other agent (kernels_pedscan.hpp)
+    size_t lds = (((size_t)c->ped_n_beams * (sizeof(float2) + sizeof(float)) + 15) & ~(size_t)15) + (size_t)(c->max_peds + 1) * (64 + 32);
     hipStream_t s = (hipStream_t)stream;
     // 128 threads per pedestrian (measured 64 / 128 / 256 / 512: 1.11 / 0.78 / 0.93 / 1.50 ms on c3)
     const int rule = march_rule_variant(c);
