@@ -871,31 +871,50 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     // The robot moves here, ahead of the pedestrians (env.py:664 comes after their commands, but nothing the pedestrian
     // phase computes reads the robot's new pose -- the social force sees old_rp -- and nothing here reads a pedestrian):
     // after ONE barrier the scan can start while wavefront 0 is still with the pedestrians.
-    if (tid == kPhase0Thread) {
-        sh.old_rp[0] = rp_g[0]; sh.old_rp[1] = rp_g[1]; sh.old_rp[2] = rp_g[2];
-        sh.nseg = 0; sh.ndisc = 0; sh.rescan = 0; sh.respawn = 0;
+    // Its three sincos -- the robot's old heading, its new heading, the float32 lidar heading -- depend on the old heading and
+    // the action only: three lanes evaluate one each, at once (a lane's work costs the wavefront's issue slots whether one
+    // lane or three are live; two sincos fewer are 180 of an arena's 11 500 vector instructions on c2).
+    const int l0 = tid - kPhase0Thread;
+    if (l0 >= 0 && l0 < 3) {
+        const double th_old = rp_g[2];
+        double a0 = 0.0, a1 = 0.0;
         if (!reset_only) {
-            double a0 = io.action[2 * e], a1 = io.action[2 * e + 1];
-            st.steps[e] += 1;                                  // env.py:592
+            a0 = io.action[2 * e]; a1 = io.action[2 * e + 1];
             if (c.min_turning_radius > 0.0) {                  // env.py:595-600
                 double lim = fabs(a1) * c.min_turning_radius;
                 if (a0 >= 0.0) a0 = (a0 > lim) ? a0 : lim;
                 else           a0 = (a0 < -lim) ? a0 : -lim;
             }
-            sh.act[0] = a0; sh.act[1] = a1;
-            double p[3] = {sh.old_rp[0], sh.old_rp[1], sh.old_rp[2]};        // env.py:664
-            nv::set_vel(p, a0, a1, dt, c.axle_offset, nullptr);
-            sh.rp[0] = p[0]; sh.rp[1] = p[1]; sh.rp[2] = p[2];
-        } else {
-            sh.rp[0] = sh.old_rp[0]; sh.rp[1] = sh.old_rp[1]; sh.rp[2] = sh.old_rp[2];
         }
-        sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];   // env.py:386
-        nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);                              // env.py:419
-        nv::sincos((double)sh.lth, sh.sT, sh.cT);
-        first_probe<RULE>(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
-        sh.step_key = (unsigned long long)st.episode[e] * 0x100000000ULL +
-                      (unsigned long long)(reset_only ? 0 : st.steps[e]) * 2ULL;
-        sh.next_chunk = 0; sh.park_count = 0; sh.park_next = 0;
+        const double th = th_old + a1 * dt;                     // set_vel's intermediate heading
+        const double th_new = reset_only ? th_old : nv::mod_2pi(th);
+        const float lth = (float)th_new;                        // env.py:386
+        const double ang = (l0 == 0) ? th_old : ((l0 == 1) ? th : (double)lth);
+        double sn, cs;
+        nv::sincos(ang, sn, cs);
+        const int w0 = kPhase0Thread & 63;                      // lane of l0 = 0 inside its wavefront (0)
+        const double s0 = __shfl(sn, w0), c0 = __shfl(cs, w0), s1 = __shfl(sn, w0 + 1), c1 = __shfl(cs, w0 + 1);
+        const double sT = __shfl(sn, w0 + 2), cT = __shfl(cs, w0 + 2);
+        if (l0 == 0) {
+            sh.old_rp[0] = rp_g[0]; sh.old_rp[1] = rp_g[1]; sh.old_rp[2] = th_old;
+            sh.nseg = 0; sh.ndisc = 0; sh.rescan = 0; sh.respawn = 0;
+            if (!reset_only) {
+                st.steps[e] += 1;                              // env.py:592
+                sh.act[0] = a0; sh.act[1] = a1;
+                double p[3] = {sh.old_rp[0], sh.old_rp[1], sh.old_rp[2]};        // env.py:664
+                nv::set_vel_with(p, a0, a1, dt, c.axle_offset, s0, c0, s1, c1, nullptr);
+                sh.rp[0] = p[0]; sh.rp[1] = p[1]; sh.rp[2] = p[2];
+            } else {
+                sh.rp[0] = sh.old_rp[0]; sh.rp[1] = sh.old_rp[1]; sh.rp[2] = sh.old_rp[2];
+            }
+            sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];   // env.py:386
+            nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);                              // env.py:419
+            sh.sT = sT; sh.cT = cT;                            // sincos((double)sh.lth): sh.rp[2] is th_new
+            first_probe<RULE>(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
+            sh.step_key = (unsigned long long)st.episode[e] * 0x100000000ULL +
+                          (unsigned long long)(reset_only ? 0 : st.steps[e]) * 2ULL;
+            sh.next_chunk = 0; sh.park_count = 0; sh.park_next = 0;
+        }
     }
     __syncthreads();
 

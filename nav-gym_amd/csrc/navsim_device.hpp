@@ -133,21 +133,27 @@ __device__ __forceinline__ void leg_centres(float apx, float apy, float ath, flo
     out[3] = (float)((s * lx + c * ly) + py);
 }
 
-// Human.set_vel (human.py:32-41) / KetiRobot.set_vel (keti_robot.py:64-93), `off` = axle offset
-__device__ __forceinline__ void set_vel(double p[3], double v, double w, double dt, double off,
-                                        double* vel) {
-    double s0, c0, s1, c1;
-    sincos(p[2], s0, c0);
+// Human.set_vel (human.py:32-41) / KetiRobot.set_vel (keti_robot.py:64-93), `off` = axle offset.
+// set_vel_with: the same update with (s0, c0) = sincos(p[2]) and (s1, c1) = sincos(p[2] + w dt) supplied (the fused step
+// evaluates its three sincos of phase 0 on three lanes at once)
+__device__ __forceinline__ void set_vel_with(double p[3], double v, double w, double dt, double off, double s0, double c0,
+                                             double s1, double c1, double* vel) {
     if (vel) { vel[0] = v * c0; vel[1] = v * s0; }
     double rx = p[0] + off * c0;
     double ry = p[1] + off * s0;
-    double th = p[2] + w * dt;
-    sincos(th, s1, c1);
     rx = rx + c1 * v * dt;
     ry = ry + s1 * v * dt;
     p[0] = rx + (-off) * c1;
     p[1] = ry + (-off) * s1;
     p[2] = mod_2pi(p[2] + w * dt);
+}
+__device__ __forceinline__ void set_vel(double p[3], double v, double w, double dt, double off,
+                                        double* vel) {
+    double s0, c0, s1, c1;
+    sincos(p[2], s0, c0);
+    double th = p[2] + w * dt;
+    sincos(th, s1, c1);
+    set_vel_with(p, v, w, dt, off, s0, c0, s1, c1, vel);
 }
 
 // batch_xy_to_ij (env.py:1228-1253), float64 inputs
