@@ -393,8 +393,8 @@ def test_step_rollout_256_threads_parked_rays(gpu, fmt, S):
 
 @pytest.mark.parametrize("ped_model", [abi.PED_SFM, abi.PED_EXTERNAL])
 def test_step_rollout_with_split_pedestrian_kernel(gpu, ped_model):
-    """Large batches advance the pedestrians in ped_update_kernel ahead of the fused step (one wavefront per
-    arena); forced here on a small batch (cfg.ped_split = 2): every output and state array still equals the
+    """cfg.ped_split = 2 advances the pedestrians in ped_update_kernel ahead of the fused step (a pack of arenas per
+    workgroup; the default since round 3 is the fused form, wavefront 0 beside the scan): every output and state array equals the
     oracle's."""
     E, size, N = 24, 240, 8
     cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, n_scan_stack=2, ped_model=ped_model,
@@ -449,6 +449,32 @@ def test_step_fuzzed_configurations(gpu, seed):
     for k, v in r.a.items():
         if k in gs and k not in ("field", "field_overflow", "rect_table"):
             _eq(gs[k], v, "state %s" % k)
+
+
+@pytest.mark.parametrize("step_block", [64, 256, 1024])
+def test_step_rollout_with_the_maximum_pedestrian_count(gpu, step_block):
+    """64 pedestrians per arena (NAVSIM_MAX_PEDS: every lane of the wavefront that runs the pedestrian phase is a
+    pedestrian, 2080 pair terms, up to 256 lidar primitives) and a ragged count beside it: the fused step equals the oracle."""
+    E, size, N = 6, 400, 64
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, n_scan_stack=2, ped_model=abi.PED_SFM,
+                                 auto_reset=1, n_spawn=8, seed=77, field_format=abi.FIELD_U16T, step_block=step_block)
+    gpu.world.lidar_1081(cfg)
+    occ = gpu.world.make_maps(E, size, 77)
+    steps = 0
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=N, steps=6, seed=77,
+                                                     min_goal_dist=4.0, max_goal_dist=9.0, robot_clearance=0.6):
+        if t == 0:                                   # a ragged count in two arenas (n_peds is read every step)
+            for sim_arrays in (g.t["n_peds"],):
+                sim_arrays[1] = 37; sim_arrays[4] = 1
+            r.a["n_peds"][1] = 37; r.a["n_peds"][4] = 1
+        for k in rout:
+            _eq(gout[k], rout[k], "%s at step %d" % (k, t))
+        _eq(go, ro, "obs at step %d" % t)
+        steps += 1
+    assert steps == 6
+    gs = g.numpy_state()
+    for k in ("ped_pose", "ped_vel", "ped_dist", "ped_prev_yaw", "robot_pose"):
+        _eq(gs[k], r.a[k], "state %s" % k)
 
 
 def test_packed_field_decodes_to_float_field(gpu):
