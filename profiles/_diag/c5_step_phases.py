@@ -17,7 +17,8 @@ if os.environ.get("NAVSIM_BEAMS"):            # what does the 17th chunk of 64 b
 cfg, sim, arrays, _ = bench.build_sim(wl, 0, wl["envs"])
 E = cfg.n_envs
 L = lib.load()
-buf = torch.zeros((E, 8), dtype=torch.int64, device="cuda:0")
+SLOTS = int(os.environ.get("NAVSIM_STAMP_SLOTS", "8"))      # 16 with profiles/_diag/tried/ped_chain_stamps.patch.txt
+buf = torch.zeros((E, SLOTS), dtype=torch.int64, device="cuda:0")
 L.navsim_debug_set_stamps.argtypes = [C.c_void_p]
 assert L.navsim_debug_set_stamps(C.c_void_p(buf.data_ptr())) == 0
 g = torch.Generator(device="cuda:0"); g.manual_seed(5)
