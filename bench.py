@@ -242,22 +242,29 @@ def profiled_counters(workload, E, field, rects, indoor_ratio=0.0):
     collected inside the timed process, so they are quoted -- and ONLY when the profile was taken from the same
     library sources (lib.source_hash) and launch shape; otherwise (None, reason)."""
     from nav_gym_amd import lib
+    reason = None
+    # profiles/<round>_<workload>/ and its variants of other launch shapes (…_indoor: corridor maps only)
     for rnd in ("r03", "r02"):
-        tp = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, workload), "traffic.json")
-        if not os.path.exists(tp):
-            continue
-        try:
-            t = json.load(open(tp))
-        except Exception:
-            continue
-        src = "profiles/%s_%s/traffic.json@%s" % (rnd, workload, t.get("commit", "?"))
-        if t.get("kernel_src_sha") != lib.source_hash():
-            return None, "%s is of other kernel sources (%s, this build %s)" % (src, t.get("kernel_src_sha"), lib.source_hash())
-        if (t.get("envs_per_gpu") != E or field != "u16t" or t.get("rect_table", True) != rects or
-                abs(float(t.get("indoor_ratio") or 0.0) - float(indoor_ratio)) > 1e-9):
-            return None, "%s is of another launch shape" % src
-        t["source"] = src
-        return t, None
+        for variant in ("", "_indoor"):
+            tp = os.path.join(ROOT, "profiles", "%s_%s%s" % (rnd, workload, variant), "traffic.json")
+            if not os.path.exists(tp):
+                continue
+            try:
+                t = json.load(open(tp))
+            except Exception:
+                continue
+            src = "profiles/%s_%s%s/traffic.json@%s" % (rnd, workload, variant, t.get("commit", "?"))
+            if t.get("kernel_src_sha") != lib.source_hash():
+                reason = reason or "%s is of other kernel sources (%s, this build %s)" % (src, t.get("kernel_src_sha"), lib.source_hash())
+                continue
+            if (t.get("envs_per_gpu") != E or field != "u16t" or t.get("rect_table", True) != rects or
+                    abs(float(t.get("indoor_ratio") or 0.0) - float(indoor_ratio)) > 1e-9):
+                reason = reason or "%s is of another launch shape" % src
+                continue
+            t["source"] = src
+            return t, None
+        if reason:
+            return None, reason
     return None, "no committed PMC profile of this workload"
 
 
