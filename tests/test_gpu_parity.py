@@ -411,7 +411,8 @@ def test_step_rollout_with_split_pedestrian_kernel(gpu, ped_model):
             _eq(gs[k], v, "state %s" % k)
 
 
-@pytest.mark.parametrize("seed", list(range(101, 117)))
+# NAVSIM_FUZZ_SEEDS=n widens the sweep for a one-off run (profiles/r03_soak/fuzz_4000.txt: 4000 seeds at the final kernels)
+@pytest.mark.parametrize("seed", list(range(101, 101 + int(os.environ.get("NAVSIM_FUZZ_SEEDS", "16")))))
 def test_step_fuzzed_configurations(gpu, seed):
     """Random launch shapes: map size (incl. odd), beam count and field of view, stack depth, pedestrian
     count and model, field format, arena count (which also moves the threads-per-arena heuristic), robot
