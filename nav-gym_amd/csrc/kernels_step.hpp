@@ -703,14 +703,15 @@ __device__ __forceinline__ void ped_advance_wave(const navsim_config& c, const n
     if (is_ped) ped_finish(c, st, e, lane, pq, wp, nw, dt, genv, steps_now, pp, pvel);
 }
 
-// The pedestrians of every arena ahead of the fused step (navsim_config.ped_split).  Inside the step this phase is a
-// third of a workgroup's lifetime during which three of its four wavefronts only hold their slots; here it costs what it
-// computes.  Round 3: a workgroup takes a PACK of arenas: arena s of the pack owns threads [s N, (s + 1) N) for its
-// pedestrians, and the pair terms of the whole pack form ONE list walked by all threads (2 x 210 terms over 128
-// threads).  Same functions per pedestrian and per pair as the fused form: same results.
+// The pedestrians of every arena ahead of the fused step (navsim_config.ped_split = 2; rounds 1-2 took this form for large
+// batches because the fused phase then held three of a workgroup's four wavefronts at a barrier -- since it runs on
+// wavefront 0 beside the scan, ped_stage_wave / ped_advance_wave, the fused form is faster at every batch size and this
+// kernel is kept for callers that ask for it).  A workgroup takes a PACK of arenas: arena s of the pack owns threads
+// [s N, (s + 1) N) for its pedestrians, and the pair terms of the whole pack form ONE list walked by all threads (2 x 210
+// terms over 128 threads).  Same functions per pedestrian and per pair as the fused form: same results.
 // (measured on c3, same box, threads x arenas per workgroup: 64 x 1 19.56 M env-steps/s, 64 x 3 17.8, 128 x 1 19.55,
-// 128 x 2 19.94, 256 x 1 19.35: the kernel follows neither its lane utilisation nor its chain length -- it waits for the
-// scattered pedestrian state and field lines; profiles/README.md)
+// 128 x 2 19.94, 256 x 1 19.35; by counters 2 290 vector instructions per wavefront at 0.40 of the issue cycles,
+// profiles/_diag/ped_update_pmc.sh)
 #ifndef NAVSIM_PED_UPDATE_BLOCK
 #define NAVSIM_PED_UPDATE_BLOCK 128
 #endif
@@ -790,9 +791,9 @@ __global__ __launch_bounds__(kPedUpdateBlock) void ped_update_kernel(navsim_conf
 
 // The fused step.  BLOCK threads = one arena; PEDS: the pedestrian variants (primitives + culled merge in LDS);
 // RULE: the march step rule (NAVSIM_MARCH_*), a compile-time copy of cfg.march_rule so that the probe loop
-// carries no select.  PINL (pedestrian variants): the pedestrian phase is compiled into the kernel; false = the
-// pedestrians were advanced by ped_update_kernel, and the kernel carries neither that phase nor the 108 bytes of
-// private scratch per lane its float64 chains spilled to under the 64-register cap (round 3: Scratch_Size 0).
+// carries no select.  PINL (pedestrian variants): the pedestrian phase is compiled into the kernel (wavefront 0 runs it
+// beside the scan of the others; 36-44 bytes of private scratch per lane under the 64-register cap, none in a hot loop);
+// false = reset-only launches and launches behind ped_update_kernel: no pedestrian phase, Scratch_Size 0.
 template <int BLOCK, bool PEDS, typename Field, int RULE, int RECT, bool PINL>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void navsim_step_kernel(navsim_config c, navsim_state st,
                                                             navsim_step_io io, int reset_only,
@@ -801,7 +802,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     __shared__ StepShared sh;
     const int peds_done = (reset_only >> 1) & 1;     // the pedestrians were advanced by ped_update_kernel
     reset_only &= 1;
-    // dynamic LDS (pedestrian variants only): [float2 dir[B], float rng[B]][PedShared]
+    // dynamic LDS (pedestrian variants only): [float2 dir[B], float rng[B]][PedShared][pair table][rect records (RECT = 2)]
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     PedShared ps = {};
     if constexpr (PEDS) ps = ped_lds_carve(dyn_lds + ((dyn_lds_bytes + 15u) & ~15u), c.max_peds);
@@ -978,7 +979,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     int n_hist = reset_only ? 0 : st.n_hist[e];
     int crash = 0, discomfort = 0;
     const uint64_t step_key = sh.step_key;
-    // dynamic LDS: [parked rays][pedestrian variants: float2 dir[B], float rng[B]][PedShared]
+    // dynamic LDS: [parked rays][pedestrian variants: float2 dir[B], float rng[B]][PedShared][pair table (fused pedestrian phase)]
     float4* park = (float4*)dyn_lds;
     char* scan_lds = dyn_lds + park_lds_bytes(B, park_lanes);
     float2* dir_lds = (float2*)scan_lds;
