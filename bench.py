@@ -71,10 +71,12 @@ def build_sim(wl, base, E, seed=1234, device="cuda:0"):
     goal = (10.0, 20.0) if wl["size"] >= 400 else (2.0, 4.0)
     arrays = world.make_world(cfg, occ, n_peds=wl["peds"], device=device, min_goal_dist=goal[0], max_goal_dist=goal[1],
                               robot_clearance=1.2 if wl["size"] >= 400 else 0.9,
-                              # rect records: the march's shortcut around most field reads.  Not with navsim_regen every
-                              # step: rebuilding the records of a handful of new maps is latency-bound (~0.1 ms per
-                              # step) and costs more than it saves there (c5: 2.14 M env-steps/s without, 1.54 M with)
-                              rect_table=wl.get("rects", False if wl.get("regen") else None))
+                              # rect records: the march's shortcut around most field reads.  With navsim_regen every step
+                              # they stay on for worlds of OUTDOOR maps (the records of a new map come out of the pass that
+                              # writes its field, kernels_reset.hpp regen_maps_item: c5 4.30 -> 4.55 M env-steps/s); a world
+                              # that also draws corridor maps would run the verified builder for a handful of new maps
+                              # per step, which is latency-bound (~0.1 ms) and costs more than it saves
+                              rect_table=wl.get("rects", (float(wl.get("indoor_ratio", 0.0)) == 0.0) if wl.get("regen") else None))
     dev = torch.device(device)
     robot = wl.get("robot", "keti")
     cfg.axle_offset = robots.ROBOTS[robot]["axle_offset"]
@@ -301,6 +303,8 @@ def main():
                     help="navsim_config.rect_lds: 0 library default (record table staged in LDS for small launches), 1 never, 2 always")
     ap.add_argument("--no-rects", action="store_true",
                     help="march through the packed field only, without the two-rectangle tile records (A/B)")
+    ap.add_argument("--rects", action="store_true",
+                    help="keep the tile records also in a world that regenerates its maps (c5; A/B)")
     ap.add_argument("--pregen", action="store_true",
                     help="c5: worlds staged ahead on a side stream + navsim_regen_swap instead of navsim_regen after every step "
                          "(measured: +11-14 %% at 128-256 arenas per GPU, +-0 at the 512 of c5 where the step kernel fills the chip)")
@@ -355,6 +359,8 @@ def main():
     wl["indoor_ratio"] = args.indoor_ratio
     if args.no_rects:
         wl["rects"] = False
+    if args.rects:
+        wl["rects"] = True
     wl["pregen"] = bool(args.pregen)
     base, E_local = shard_of(wl, args.scaling, rank, world_size)
     E_total = wl["total"] if args.scaling == "strong" else world_size * wl["envs"]

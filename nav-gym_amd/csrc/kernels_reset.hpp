@@ -169,28 +169,59 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
 // distance transform finds, with no dependent scan (the two transform kernels then skip the slot).
 //
 // Round 3: a thread owns EIGHT consecutive cells of a row -- one 16-byte tile row of the packed field (one store),
-// one 8-byte store of the occupancy -- and walks (row, group) items without a division per cell; 128 bands per map.
-// 41 -> 22 us for the 5 maps of a c5 step.  (Measured and dropped: one 8x8 tile per wavefront with a cell per lane,
+// one 8-byte store of the occupancy -- without a division per cell; 128 slices per map walk its (tile row, 32 tiles)
+// units, the eight rows of a tile on adjacent lanes.  41 -> 22 us for the 5 maps of a c5 step.  (Measured and dropped: one 8x8 tile per wavefront with a cell per lane,
 // 46 us; 32 or 512 bands, 23 / 33 us.  The kernel's time does not follow its arithmetic: profiles/README.md.)
-// `direct`: every map of this call is an outdoor one and nothing downstream wants the per-slot scratch (no rect
-// rebuild): the field goes straight into the arena's own buffers, no copy kernel.
+// `direct`: every map of this call is an outdoor one and nothing downstream wants the per-slot scratch: the field goes
+// straight into the arena's own buffers, no copy kernel; a world that keeps rect records gets the records of the new map
+// from the same pass (rect_all; 12.6 -> 13.8 us, against 66-87 us of the verified builder for the same maps).
 // The GRID is bounded (kRegenGrid workgroups walk the (slot, band) items of the arenas that really finished): a launch
 // of regen_cap x 128 workgroups of which 27 in 32 slots find nothing to do cost 4 ns per such workgroup -- 9.9 / 14.2 /
 // 22.6 us for regen_cap 8 / 16 / 32 with the same 5 maps to draw (profiles/_diag/regen_twice.sh).
 constexpr int kRegenSlices = 128;
 constexpr int kRegenGrid = 1024;
 inline int regen_grid(int slots) { const long n = (long)slots * kRegenSlices; return (int)(n < kRegenGrid ? n : kRegenGrid); }
+// ---- rect records of an OUTDOOR map from the generator's geometry (round 3).  The map IS a union of rectangles of occupied
+// cells -- four border walls (stretched over everything outside the live map) and the clipped boxes -- and its exact d2 is
+// the minimum of the rectangle distances (regen_maps_item writes the field that way).  So the record of an 8x8 tile
+// (kernels_rect.hpp) needs no search and no verification pass: the tile's record is valid iff the nearest rectangle of
+// every in-map cell of the tile (ties: the lowest index) is one of at most two rectangles, and those two ARE the record
+// (regen_maps_item: the same pass that writes the field).
+struct RectSet2 { int a, b, bad; };
+__device__ __forceinline__ void rect_set_insert(RectSet2& s, int x) {
+    if (x < 0 || x == s.a || x == s.b) return;
+    if (s.a < 0) s.a = x;
+    else if (s.b < 0) s.b = x;
+    else s.bad = 1;
+}
+// rectangle `idx` of the map in field coordinates (x = column, y = stored row): 0..3 the walls, 4 + o box o
+__device__ __forceinline__ void regen_rect_of(int idx, int live, int size, int hw, const int* ocx, const int* ocy,
+                                              unsigned& lo, unsigned& hi) {
+    int x0, x1, y0, y1;
+    if (idx == 0)      { x0 = 0; x1 = 4; y0 = 0; y1 = size - 1; }                  // q <= 4
+    else if (idx == 1) { x0 = live - 5; x1 = size - 1; y0 = 0; y1 = size - 1; }    // q >= live - 5 (and the padding beside)
+    else if (idx == 2) { x0 = 0; x1 = size - 1; y0 = live - 5; y1 = size - 1; }    // generator rows r <= 4: stored rows y >= live - 5 (and the padding above)
+    else if (idx == 3) { x0 = 0; x1 = size - 1; y0 = 0; y1 = 4; }                  // r >= live - 5: y <= 4
+    else {
+        const int o = idx - 4;
+        int bx0 = ocx[o] - hw, bx1 = ocx[o] + hw, by0 = ocy[o] - hw, by1 = ocy[o] + hw;
+        bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
+        bx1 = bx1 > live - 1 ? live - 1 : bx1; by1 = by1 > live - 1 ? live - 1 : by1;
+        x0 = by0; x1 = by1; y0 = live - 1 - bx1; y1 = live - 1 - bx0;
+    }
+    lo = ((unsigned)y0 << 16) | (unsigned)x0;
+    hi = ((unsigned)y1 << 16) | (unsigned)x1;
+}
 __device__ __forceinline__ void regen_maps_item(const navsim_config& c, const navsim_state& st, int b, int slice, int e,
                                                 uint8_t* __restrict__ occ_all,
                                                 const uint8_t* __restrict__ grid_all, const int* __restrict__ kind,
                                                 char* __restrict__ field_scratch, size_t field_bytes,
                                                 float* __restrict__ ovf_scratch, int direct, bool all_outdoor,
-                                                int* ocx, int* ocy) {
+                                                uint4* __restrict__ rect_all, int* ocx, int* ocy) {
     const int size = c.map_w, tid = threadIdx.x;
     uint8_t* occ = occ_all ? occ_all + (size_t)b * size * size : nullptr;
     const int rows = (size + kRegenSlices - 1) / kRegenSlices;
     const int y0 = slice * rows, y1 = (y0 + rows < size) ? y0 + rows : size;
-    if (y0 >= size) return;
     if (const int G = all_outdoor ? 0 : kind[b]) {                     // corridor map: nearest upscaling + flip
         const uint8_t* gsrc = grid_all + (size_t)b * 10000;
         for (int idx = y0 * size + tid; idx < y1 * size; idx += 256) {
@@ -224,70 +255,110 @@ __device__ __forceinline__ void regen_maps_item(const navsim_config& c, const na
     char* fs = direct ? (char*)st.field + (size_t)e * field_bytes : field_scratch + (size_t)b * field_bytes;
     float* ov = direct ? (st.field_overflow ? (float*)st.field_overflow + (size_t)e * size * size : nullptr)
                        : (ovf_scratch ? ovf_scratch + (size_t)b * size * size : nullptr);
-    const int tpr = (size + 7) >> 3;
-    const int groups = (size + 7) >> 3;                                  // 8-cell groups per row
-    for (int item = tid; item < (y1 - y0) * groups; item += 256) {      // (row of the band, 8-cell group of the row)
-        const int yy = item / groups, gx = item - yy * groups;
-        const int y = y0 + yy;
-        const int r = live - 1 - y;                                      // generator row (negative: outside the live map)
-        const int x0 = gx << 3;
-        int d2[8];
-        // border frame (and everything outside the live map): m <= 0
-        int mr = r - 4;
-        mr = (live - 5 - r) < mr ? (live - 5 - r) : mr;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int q = x0 + j;
-            int m = (q - 4) < mr ? (q - 4) : mr;
-            m = (live - 5 - q) < m ? (live - 5 - q) : m;
-            d2[j] = (m > 0) ? m * m : 0;
-        }
-        for (int o = 0; o < n_obs; ++o) {                                // boxes are drawn clipped to the map
-            int bx0 = ocx[o] - hw, bx1 = ocx[o] + hw, by0 = ocy[o] - hw, by1 = ocy[o] + hw;
-            bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
-            bx1 = bx1 > live - 1 ? live - 1 : bx1; by1 = by1 > live - 1 ? live - 1 : by1;
-            int dr = bx0 - r > r - bx1 ? bx0 - r : r - bx1;
-            dr = dr < 0 ? 0 : dr;
-            const int dr2 = dr * dr;
+    // Work units: (tile row, block of 32 tiles) -- 256 threads = 32 tiles x 8 rows, thread = (tile of the block, row of the
+    // tile); unit u of the map belongs to slice u % kRegenSlices.  A thread owns EIGHT consecutive cells of a row = one
+    // 16-byte tile row of the packed field; the eight threads of a tile are adjacent lanes: their stores fill the tile's
+    // 128 bytes, and the tile's rect record (kernels_rect.hpp) falls out of the same pass.
+    const int tpr = (size + 7) >> 3, blocks = (tpr + 31) >> 5;
+    const int ry = tid & 7, tsub = tid >> 3;
+    for (int u = slice; u < tpr * blocks; u += kRegenSlices) {
+        const int ty = u / blocks, tx = (u - ty * blocks) * 32 + tsub;
+        const int y = ty * 8 + ry, x0 = tx << 3;
+        const bool in_map = tx < tpr && y < size;
+        RectSet2 set = {-1, -1, 0};
+        if (in_map) {
+            const int r = live - 1 - y;                                      // generator row (negative: outside the live map)
+            int d2[8], arg[8];
+            // border frame (and everything outside the live map): m <= 0.  arg: the rectangle the distance comes from
+            // (regen_rect_of: 0..3 the walls, 4 + o box o; the lowest index wins a tie)
+            int mr = r - 4, ar = 2;
+            if (live - 5 - r < mr) { mr = live - 5 - r; ar = 3; }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int q = x0 + j;
-                int dq = by0 - q > q - by1 ? by0 - q : q - by1;
-                dq = dq < 0 ? 0 : dq;
-                const int v = dr2 + dq * dq;
-                d2[j] = v < d2[j] ? v : d2[j];
+                int m = mr, am = ar;
+                if (q - 4 < m || (q - 4 == m && 0 < am)) { m = q - 4; am = 0; }
+                if (live - 5 - q < m || (live - 5 - q == m && 1 < am)) { m = live - 5 - q; am = 1; }
+                d2[j] = (m > 0) ? m * m : 0;
+                arg[j] = am;
             }
-        }
-        const bool whole = x0 + 8 <= size;                               // the last group of a ragged row is partial
-        if (occ) {
-            if (whole && ((size & 7) == 0)) {
-                uint32_t lo = 0, hi = 0;
+            for (int o = 0; o < n_obs; ++o) {                                // boxes are drawn clipped to the map
+                int bx0 = ocx[o] - hw, bx1 = ocx[o] + hw, by0 = ocy[o] - hw, by1 = ocy[o] + hw;
+                bx0 = bx0 < 0 ? 0 : bx0; by0 = by0 < 0 ? 0 : by0;
+                bx1 = bx1 > live - 1 ? live - 1 : bx1; by1 = by1 > live - 1 ? live - 1 : by1;
+                int dr = bx0 - r > r - bx1 ? bx0 - r : r - bx1;
+                dr = dr < 0 ? 0 : dr;
+                const int dr2 = dr * dr;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { lo |= (uint32_t)(d2[j] == 0) << (8 * j); hi |= (uint32_t)(d2[4 + j] == 0) << (8 * j); }
-                *(uint2*)(occ + (size_t)y * size + x0) = make_uint2(lo, hi);
+                for (int j = 0; j < 8; ++j) {
+                    const int q = x0 + j;
+                    int dq = by0 - q > q - by1 ? by0 - q : q - by1;
+                    dq = dq < 0 ? 0 : dq;
+                    const int v = dr2 + dq * dq;
+                    if (v < d2[j]) { d2[j] = v; arg[j] = 4 + o; }
+                }
+            }
+            const bool whole = x0 + 8 <= size;                               // the last group of a ragged row is partial
+            if (occ) {
+                if (whole && ((size & 7) == 0)) {
+                    uint32_t lo = 0, hi = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { lo |= (uint32_t)(d2[j] == 0) << (8 * j); hi |= (uint32_t)(d2[4 + j] == 0) << (8 * j); }
+                    *(uint2*)(occ + (size_t)y * size + x0) = make_uint2(lo, hi);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (x0 + j < size) occ[(size_t)y * size + x0 + j] = (uint8_t)(d2[j] == 0);
+                }
+            }
+            if (f32) {
+                float* dst = (float*)fs + (size_t)y * size + x0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (x0 + j < size) dst[j] = sqrtf((float)d2[j]);
             } else {
+                // one tile row of the packed field = 8 cells = 16 bytes (padding cells of an edge tile included: they are
+                // never read, and d2 of a cell outside the map is 0 here)
+                uint32_t pk[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) if (x0 + j < size) occ[(size_t)y * size + x0 + j] = (uint8_t)(d2[j] == 0);
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t a = (uint32_t)(d2[2 * j] >= 65535 ? 0xFFFF : d2[2 * j]);
+                    const uint32_t bq = (uint32_t)(d2[2 * j + 1] >= 65535 ? 0xFFFF : d2[2 * j + 1]);
+                    pk[j] = a | (bq << 16);
+                }
+                *(uint4*)((uint16_t*)fs + FieldU16T::index(x0, y, tpr)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                if (ov) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (x0 + j < size) ov[(size_t)y * size + x0 + j] = sqrtf((float)d2[j]);
+                }
+            }
+            if (rect_all) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (x0 + j < size) rect_set_insert(set, arg[j]);
             }
         }
-        if (f32) {
-            float* dst = (float*)fs + (size_t)y * size + x0;
+        // The record of the tile, when the world keeps a rect table and this call writes fields directly (outdoor maps only).
+        // The map IS a union of rectangles of occupied cells -- four border walls (stretched over everything outside the
+        // live map) and the clipped boxes -- and its exact d2 is the minimum of the rectangle distances, so the record needs
+        // no search and no verification pass: it is valid iff the nearest rectangle of every in-map cell of the tile is one
+        // of at most two rectangles, and those two ARE the record.  Sets of at most two indices, merged over the tile's
+        // eight rows by three shuffles.
+        if (rect_all) {                                                      // block-uniform
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if (x0 + j < size) dst[j] = sqrtf((float)d2[j]);
-        } else {
-            // one tile row of the packed field = 8 cells = 16 bytes (padding cells of an edge tile included: they are
-            // never read, and d2 of a cell outside the map is 0 here)
-            uint32_t pk[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t a = (uint32_t)(d2[2 * j] >= 65535 ? 0xFFFF : d2[2 * j]);
-                const uint32_t bq = (uint32_t)(d2[2 * j + 1] >= 65535 ? 0xFFFF : d2[2 * j + 1]);
-                pk[j] = a | (bq << 16);
+            for (int off = 1; off < 8; off <<= 1) {
+                const int oa = __shfl_xor(set.a, off), ob = __shfl_xor(set.b, off), obad = __shfl_xor(set.bad, off);
+                rect_set_insert(set, oa);
+                rect_set_insert(set, ob);
+                set.bad |= obad;
             }
-            *(uint4*)((uint16_t*)fs + FieldU16T::index(x0, y, tpr)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-            if (ov) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) if (x0 + j < size) ov[(size_t)y * size + x0 + j] = sqrtf((float)d2[j]);
+            if (ry == 0 && tx < tpr) {
+                uint4 rec;
+                if (set.bad || set.a < 0) {
+                    rec = make_uint4(kRectInvalid, 0u, 0u, 0u);
+                } else {
+                    regen_rect_of(set.a, live, size, hw, ocx, ocy, rec.x, rec.y);
+                    regen_rect_of(set.b < 0 ? set.a : set.b, live, size, hw, ocx, ocy, rec.z, rec.w);
+                }
+                (rect_all + (size_t)e * rect_tiles_per_map(size, size))[(size_t)ty * tpr + tx] = rec;
             }
         }
     }
@@ -303,7 +374,7 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
                                                          const uint8_t* __restrict__ grid_all, int* __restrict__ kind,
                                                          char* __restrict__ field_scratch, size_t field_bytes,
                                                          float* __restrict__ ovf_scratch, int direct,
-                                                         const uint8_t* __restrict__ done, int cap) {
+                                                         const uint8_t* __restrict__ done, int cap, uint4* __restrict__ rect_all) {
     __shared__ int ocx[64], ocy[64];
     int n_items;
     if (done) {
@@ -328,7 +399,7 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
             e = list[b];
         }
         regen_maps_item(c, st, b, slice, e, occ_all, grid_all, kind, field_scratch, field_bytes, ovf_scratch, direct,
-                        done != nullptr, ocx, ocy);       // (kind[b] of this call may not be written yet: not read then)
+                        done != nullptr, rect_all, ocx, ocy);       // (kind[b] of this call may not be written yet: not read then)
         __syncthreads();                                                 // ocx / ocy are rewritten by the next item
     }
 }

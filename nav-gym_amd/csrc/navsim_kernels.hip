@@ -165,7 +165,7 @@ struct StepPlan {
 // generations and lasts as long as the probe chains of its slowest rays); 1536: 24.2 -> 21.6, 2048: 26.3 -> 23.0,
 // 4096: 36.0 -> 24.5 (residency beats latency once the chip runs several generations).  So: up to 4 arenas per CU.
 constexpr long kRectLdsMaxArenasPerCu = NAVSIM_RECT_LDS_MAX_PER_CU;
-StepPlan plan_step(const navsim_config* c, const navsim_state* st) {
+StepPlan plan_step(const navsim_config* c, const navsim_state* st, int grid = 0) {
     StepPlan p;
     p.block = pick_step_block(c);
     p.rect = st->rect_table ? 1 : 0;
@@ -179,8 +179,11 @@ StepPlan plan_step(const navsim_config* c, const navsim_state* st) {
             const size_t base = (step_lds_bytes(c, step_park_lanes(c, b2)) + 15) & ~(size_t)15;
             const size_t total = base + table + 1024;               // + the kernel's static LDS, allocation granules
             const bool two_per_cu = 2 * total <= kLdsPerCu, one_per_cu = total <= kLdsPerCu;
-            const bool small = (long)c->n_envs <= kRectLdsMaxArenasPerCu * device_cu_count();
-            if (c->rect_lds == 2 ? one_per_cu : (two_per_cu && small)) {
+            const bool small = (long)(grid > 0 ? grid : c->n_envs) <= kRectLdsMaxArenasPerCu * device_cu_count();
+            // a launch of at most one workgroup per CU (navsim_regen's first observations: a handful of lone scans, each as
+            // long as its probe chains) may take a CU's whole LDS
+            const bool lone = grid > 0 && grid <= device_cu_count();
+            if (c->rect_lds == 2 ? one_per_cu : ((two_per_cu && small) || (one_per_cu && lone))) {
                 p.block = b2; p.rect = 2; p.park = step_park_lanes(c, b2);
                 p.lds = base + table; p.rect_off = (unsigned)base;
             }
@@ -258,7 +261,7 @@ int launch_step(const navsim_config* c, const navsim_state* st, const navsim_ste
 int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
                   int reset_only, const uint8_t* mask, hipStream_t s, int grid = 0) {
     int rc;
-    const StepPlan p = plan_step(c, st);
+    const StepPlan p = plan_step(c, st, grid);
     switch (p.block) {
         case 64:   rc = launch_step<64>(c, st, io, reset_only, mask, p, s, grid); break;
         case 256:  rc = launch_step<256>(c, st, io, reset_only, mask, p, s, grid); break;
@@ -699,7 +702,10 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     // opens the call: every workgroup selects its arena from the done flags (list[b], -1 = none; count), draws the
     // per-episode parameters and the map kind, grows the corridor tree of a corridor map
     // (worlds of outdoor maps only: regen_maps_kernel opens the call itself, one launch less)
-    const bool direct = !(c->regen_indoor_ratio > 0.0) && !st->rect_table;
+    // (a world of outdoor maps that keeps rect records: regen_maps_kernel writes the records of a new map from the
+    // generator's rectangles, regen_rect_records -- no search, no verification pass, no builder launches)
+    const bool direct = !(c->regen_indoor_ratio > 0.0);
+    uint4* direct_rects = (direct && st->rect_table) ? (uint4*)st->rect_table : nullptr;
     if (!direct) regen_indoor_kernel<<<M, 256, 0, s>>>(*c, *st, io->done, M, count, list, grids, kind);
     float* ovf_scratch = nullptr;                           // exact float plane of the new maps (large packed maps)
     if (c->field_format == NAVSIM_FIELD_U16T && st->field_overflow) {
@@ -714,7 +720,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     // maps and, for outdoor maps, their exact field from the geometry; corridor maps go through the distance transform
     regen_maps_kernel<<<regen_grid(M), 256, 0, s>>>(*c, *st, count, list, need_occ ? occ : nullptr, grids, kind,
                                                             fscratch, fbytes, ovf_scratch, direct ? 1 : 0,
-                                                            direct ? io->done : nullptr, M);
+                                                            direct ? io->done : nullptr, M, direct_rects);
     if (c->regen_indoor_ratio > 0.0) {
         dt_columns_kernel<<<dim3((W + 63) / 64, M), 64 * kColSeg, 0, s>>>(occ, cols, H, W, count, kind);
         if (c->field_format == NAVSIM_FIELD_F32)
@@ -722,7 +728,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         else
             dt_rows_kernel<1><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, ovf_scratch, nullptr, H, W, count, kind);
     }
-    if (st->rect_table) {                                   // keep the rect records of the regenerated arenas current
+    if (st->rect_table && !direct) {                        // keep the rect records of the regenerated arenas current
         off = (off + 255) & ~(size_t)255;
         char* rect_ws = w + off;
         off += navsim_build_rects_workspace_bytes(M, H, W) + 256;

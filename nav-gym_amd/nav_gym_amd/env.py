@@ -243,7 +243,11 @@ class NavGymEnv(object):
         first = self.sim is None
         if first:
             dev = torch.device(self.device)
-            with_rects = (cfg.field_format == abi.FIELD_U16T and not self.randomize_maps and self.map_size <= 1024)
+            # rect records (the march's shortcut around most field reads): always for fixed maps; with a new map per episode
+            # only in worlds of outdoor maps, whose records come out of the pass that writes the new field -- corridor maps
+            # would need the verified builder for a handful of maps per step, which costs more than the records save
+            with_rects = (cfg.field_format == abi.FIELD_U16T and self.map_size <= 1024 and
+                          (not self.randomize_maps or not cfg.regen_indoor_ratio > 0.0))
             arrays = world.empty_world(cfg, device=self.device,
                                        plan_paths=self.plan_paths and cfg.ped_model != abi.PED_NONE,
                                        rect_table=with_rects)

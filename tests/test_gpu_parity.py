@@ -1348,6 +1348,41 @@ def test_full_size_c2_determinism_and_shard_invariance(gpu, full_c2):
             assert torch.equal(full[t][1][k], torch.cat([a[t][1][k], b[t][1][k]])), k
 
 
+@pytest.mark.parametrize("size,live,step_block", [(200, 0, 0), (253, 0, 256), (300, 200, 1024)])
+def test_regen_writes_the_rect_records_of_outdoor_maps_from_the_generator(gpu, size, live, step_block):
+    """A world of outdoor maps that keeps rect records: navsim_regen writes the records of a new map from the generator's
+    rectangles (regen_rect_records: no search, no verification pass).  Every valid record reproduces the exact field on
+    every cell of its tile, almost every tile has one, and the rollout (whose first observations after a regen march
+    through the records staged in LDS) stays identical to the oracle's.  253: ragged edge tiles; 300 / 200: a live map
+    inside a larger arena (map_size="reference")."""
+    E, N = 24, 4
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_SFM, n_spawn=6,
+                                 auto_reset=1, seed=23, field_format=abi.FIELD_U16T, regen_cap=8, min_goal_dist=3.0,
+                                 max_goal_dist=8.0, spawn_clearance=0.9, ped_min_robot_dist=2.0, ped_min_goal_dist=4.0,
+                                 regen_indoor_ratio=0.0, step_block=step_block)
+    if live:
+        cfg.outdoor_map_size = live
+    gpu.world.lidar_1081(cfg)
+    occ = gpu.world.make_maps(E, size, 23)
+    regenerated = 0
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=3, steps=40, seed=9):
+        _eq(go, ro, "obs at step %d" % t)
+        assert "rect_table" in g.t
+        n_done = int(rout["done"].sum())
+        _eq(g.regen().cpu().numpy(), r.regen(), "obs after regen at step %d" % t)
+        regenerated += min(n_done, 8)
+        if n_done:
+            gs = g.numpy_state()
+            for k, v in r.a.items():
+                if k in gs and k not in ("field", "field_overflow", "rect_table"):
+                    _eq(gs[k], v, "state %s after regen at step %d" % (k, t))
+            d2, valid = _decode_rect_table(g.t["rect_table"].cpu().numpy(), size, size)
+            exact = np.rint(r.a["field"].astype(np.float64) ** 2).astype(np.int64)
+            assert np.array_equal(d2[valid], exact[valid]), "a record differs from the exact field at step %d" % t
+            assert valid.mean() > 0.93          # 200 x 200 cells with 10 boxes: 0.97; the bench's 500 x 500: 0.995
+    assert regenerated >= 6
+
+
 def _decode_rect_table(table, H, W):
     """Host evaluation of navsim_build_rects records: -> (d2 int64 [E,H,W], valid bool [E,H,W])."""
     E = table.shape[0]
