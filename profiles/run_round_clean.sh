@@ -18,3 +18,4 @@ python3 "$R/bench.py" --no-rects --no-cpu-baseline 2>/dev/null | grep '^{"metric
 for E in 512 1024; do
   python3 "$R/bench.py" --envs $E --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | tail -1 > "$O/bench_clean_envs$E.json"
 done
+python3 "$R/bench.py" --workload c5 --graph on --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | tail -1 > "$R/gpurun_out/prof_${TAG}_c5/bench_clean_graph.json"
