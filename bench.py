@@ -295,7 +295,8 @@ def main():
     ap.add_argument("--step-block", type=int, default=0, help="threads per arena (0 = library default)")
     ap.add_argument("--spinup-ms", type=float, default=500.0,
                     help="untimed GPU work before the warm-up steps (leaves the idle power state); 0 = none")
-    ap.add_argument("--no-cold-pass", action="store_true", help="skip the extra K steps timed before the spin-up")
+    ap.add_argument("--no-cold-pass", action="store_true", help="skip the extra K steps timed without spin-up (value_no_spinup)")
+    ap.add_argument("--cold-idle-s", type=float, default=3.0, help="idle seconds in front of the value_no_spinup pass")
     ap.add_argument("--lpt-period", type=int, default=0, help="steps between launch-order sorts (0 = NavSim's default)")
     ap.add_argument("--ped-split", type=int, default=0, choices=[0, 1, 2],
                     help="navsim_config.ped_split: 0 library default, 1 pedestrians inside the step, 2 ped_update_kernel first")
@@ -449,13 +450,6 @@ def main():
             elapsed = float(tt.item())
         return elapsed, sum(a.elapsed_time(b) for a, b in ev) / K
 
-    # the same K steps WITHOUT the spin-up below, straight after the host-side set-up (GPU still in its idle
-    # power state), reported beside `value` as value_no_spinup
-    cold = None
-    if args.spinup_ms > 0 and not args.no_cold_pass:
-        for t in range(Wm):
-            run(t)
-        cold = timed()
     # 25 steps of 0.12 ms are 3 ms of GPU work: after the host-side set-up the GPU is still in its idle power state and
     # the kernel runs 5 % slower than in a long run (measured: kernel 121 vs 116 us).  Half a second of untimed work
     # that touches no simulator state (the library's device sincos on a scratch tensor) precedes the warm-up steps.
@@ -506,6 +500,17 @@ def main():
         sim.cfg.add_scan_noise = 0
         noise_off = timed()
         sim.cfg.add_scan_noise = 1
+    # the same K steps WITHOUT the spin-up, GPU in its idle power state, reported beside `value` as
+    # value_no_spinup.  Taken LAST, after a few seconds of idle (round 3: taken first, it moved the simulation and its
+    # launch-order schedule 25 steps on and cost the first timed window -- the one `value` is -- 1-3 %,
+    # profiles/r03_lpt/driver_shape_first_repeat.txt), with W untimed steps in front like `value`.
+    cold = None
+    if args.spinup_ms > 0 and not args.no_cold_pass:
+        fence()
+        time.sleep(args.cold_idle_s)
+        for t in range(Wm):
+            run(t)
+        cold = timed()
 
     if rank == 0:
         import statistics
