@@ -382,12 +382,22 @@ __device__ __forceinline__ float ray_result(lanemask_t hit, float x0, float y0, 
 // 70 per scan -- are marched 64 at a time.  Which wavefront finishes a ray, and when, changes no result.  On the c2
 // bench state (profiles/_diag/park_model.py) 0.84 of the probe rounds remain at 8 lanes and 0.82 at 16; a group of
 // parked rays points everywhere, so its record loads do not coalesce and the kernel gains less than that: c2 +4.6 % at
-// 16 lanes (+1 % at 8, 24 = 16, 32 +1 %).  The pedestrian variants gain nothing at 8 and lose 3 % at 16, and a launch
-// that is a single generation of workgroups lasts as long as its slowest workgroup and loses to the second pass
-// (c4 -8 %, c5 -4 %): parking is compiled into the 256-thread kernels without pedestrians only.
+// 16 lanes (+1 % at 8, 24 = 16, 32 +1 %).  A launch that is a single generation of workgroups lasts as long as its slowest
+// workgroup and loses to the second pass (c4 -8 %, c5 -4 %): parking is compiled into the 256-thread kernels only.  The
+// pedestrian variants park since the end of round 3 (park_lds_bytes: the parked ray lives in its own rng / dir slots):
+// c3 23.2 -> 24.0 M at 16 lanes (8: 23.6; 24 and 32, which cost the eighth arena of a CU its LDS: 23.2, 23.0).
 constexpr int kParkLanesMax = 16;
-__host__ __device__ constexpr bool step_parks(int block, bool peds) { return block == 256 && !peds; }
-__host__ __device__ inline size_t park_lds_bytes(int B, int park_lanes) { return (size_t)((B + 63) / 64) * park_lanes * 16; }
+#ifndef NAVSIM_PARK_LANES_PEDS
+#define NAVSIM_PARK_LANES_PEDS 16
+#endif
+__host__ __device__ constexpr bool step_parks(int block, bool peds) { return block == 256 && (!peds || NAVSIM_PARK_LANES_PEDS > 0); }
+// A parked ray is (beam, t, direction).  Without pedestrians: 16 bytes in the park area.  In the pedestrian variants the
+// ray's own slots of the LDS copy -- rng[k], dir[k], which it fills only when it finishes -- hold t and the direction
+// meanwhile, and the park area keeps the beam index alone (2 bytes): 0.5 KB instead of 4.3, which is what keeps eight
+// arenas on a CU (round 2 measured parking in these variants with the 16-byte records: -3 %, for the lost residency).
+__host__ __device__ inline size_t park_lds_bytes(int B, int park_lanes, bool peds) {
+    return (((size_t)((B + 63) / 64) * park_lanes * (peds ? 2 : 16)) + 15) & ~(size_t)15;
+}
 __device__ __forceinline__ int lanes_below(lanemask_t m) {          // set bits of m below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
@@ -479,7 +489,15 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShar
                 int base = 0;
                 if (lane == 0) base = atomicAdd(&sh.park_count, (int)__builtin_popcountll(active));
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (marching) park[base + lanes_below(active)] = make_float4(__int_as_float(k), t, dx, dy);
+                if (marching) {
+                    if constexpr (TO_LDS) {
+                        ((unsigned short*)park)[base + lanes_below(active)] = (unsigned short)k;
+                        rng_lds[k] = t;
+                        dir_lds[k] = make_float2(dx, dy);
+                    } else {
+                        park[base + lanes_below(active)] = make_float4(__int_as_float(k), t, dx, dy);
+                    }
+                }
             }
             if (valid & !marching) finish(k, dx, dy, ray_result(hit, x0, y0, dx, dy, t, miss));
         }
@@ -494,10 +512,18 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShar
         g = __builtin_amdgcn_readfirstlane(g);
         if (g >= n_parked) break;
         const bool valid = g + lane < n_parked;
-        const float4 r = park[valid ? g + lane : g];
-        const int k = __float_as_int(r.x);
-        float t = r.y;
-        const float dx = r.z, dy = r.w;
+        int k;
+        float t, dx, dy;
+        if constexpr (TO_LDS) {
+            k = (int)((const unsigned short*)park)[valid ? g + lane : g];
+            t = rng_lds[k];
+            const float2 d = dir_lds[k];
+            dx = d.x; dy = d.y;
+        } else {
+            const float4 r = park[valid ? g + lane : g];
+            k = __float_as_int(r.x);
+            t = r.y; dx = r.z; dy = r.w;
+        }
         lanemask_t active = mask_of(valid);
         lanemask_t hit = 0;
         while (active != 0)
@@ -981,7 +1007,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const uint64_t step_key = sh.step_key;
     // dynamic LDS: [parked rays][pedestrian variants: float2 dir[B], float rng[B]][PedShared][pair table (fused pedestrian phase)]
     float4* park = (float4*)dyn_lds;
-    char* scan_lds = dyn_lds + park_lds_bytes(B, park_lanes);
+    char* scan_lds = dyn_lds + park_lds_bytes(B, park_lanes, PEDS);
     float2* dir_lds = (float2*)scan_lds;
     float* rng_lds = (float*)(scan_lds + sizeof(float2) * (size_t)B);
     scan_beams_pred<BLOCK, Field, PEDS, RULE, RECT>(c, sh, field, rects, st.beam_table, prims, dir_lds, rng_lds, park, park_lanes, st.scan_threshold,

@@ -100,11 +100,14 @@ int device_cu_count() {
 // rays a wavefront parks per chunk (kernels_step.hpp "Parking"): only where a launch runs several generations of
 // 256-thread workgroups, and not in the pedestrian variants
 int step_park_lanes(const navsim_config* c, int block) {
-    return step_parks(block, c->ped_model != NAVSIM_PED_NONE) ? kParkLanesMax : 0;
+    const bool peds = c->ped_model != NAVSIM_PED_NONE;
+    if (!step_parks(block, peds)) return 0;
+    if (peds) return c->n_beams <= 65535 ? NAVSIM_PARK_LANES_PEDS : 0;      // the park area keeps 16-bit beam indices there
+    return kParkLanesMax;
 }
 size_t step_lds_scan_bytes(const navsim_config* c, int park_lanes) {
-    return park_lds_bytes(c->n_beams, park_lanes) +
-           (c->ped_model != NAVSIM_PED_NONE ? (size_t)c->n_beams * (sizeof(float2) + sizeof(float)) : 0);
+    const bool peds = c->ped_model != NAVSIM_PED_NONE;
+    return park_lds_bytes(c->n_beams, park_lanes, peds) + (peds ? (size_t)c->n_beams * (sizeof(float2) + sizeof(float)) : 0);
 }
 size_t ped_update_lds_bytes(const navsim_config* c) {                    // ped_update_kernel: a pack of arenas per wavefront
     return (size_t)ped_pack(c->max_peds) * ped_slot_bytes(c->max_peds);
