@@ -52,13 +52,20 @@ __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim
             seg[q + v][0] = vx[v]; seg[q + v][1] = vy[v]; seg[q + v][2] = vx[w]; seg[q + v][3] = vy[w];
         }
     }
+    __syncthreads();                                                                 // seg[] and nseg_s: written by threads <= n, read by all
+    const Prims pr = {seg, nullptr, info_s};
+    const double step = (PB > 1) ? (c.ped_angle_last - c.ped_angle_min) / (double)(PB - 1) : 0.0;
+    const float rmax = (float)c.ped_range_max;
+    // which sides can matter, for which beams: needs only the sides and the lidar pose, so it runs before the march and
+    // the barrier behind the march publishes info_s
+    prim_in_range<BLOCK>(nseg_s, nseg_s, lx_s, ly_s, rmax * 1.0001f + 0.01f, pr, (float)step,
+                         (float)(c.ped_angle_min + (double)lth_s));
     const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, H, W);
     const char* rects = RECT ? (const char*)st.rect_table + (size_t)(c.shared_field ? 0 : e) * rect_tiles_per_map(H, W) * sizeof(uint4)
                              : nullptr;
     const unsigned tpr = (unsigned)((W + 7) >> kRectShift);
     const float max_range = march_limit(H, W, c.ped_range_max, c.resolution);
-    const float res = (float)c.resolution, rmax = (float)c.ped_range_max;
-    const double step = (PB > 1) ? (c.ped_angle_last - c.ped_angle_min) / (double)(PB - 1) : 0.0;
+    const float res = (float)c.resolution;
     const float x0 = (float)i0_s, y0 = (float)j0_s;
     const double lth = (double)lth_s;
     for (int k = tid; k < PB; k += BLOCK) {
@@ -72,9 +79,6 @@ __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim
             probe_round<Field, RULE, RECT>(field, rects, tpr, x0, y0, dx, dy, (unsigned)W, (unsigned)H, max_range, t, active, hit);
         rng[k] = ray_result(hit, x0, y0, dx, dy, t, max_range) * res;
     }
-    const Prims pr = {seg, nullptr, info_s};
-    prim_in_range<BLOCK>(nseg_s, nseg_s, lx_s, ly_s, rmax * 1.0001f + 0.01f, pr, (float)step,
-                         (float)(c.ped_angle_min + lth));                             // which sides can matter, for which beams
     __syncthreads();
     merge_prims_culled_core<BLOCK>(PB, lx_s, ly_s, (float)step, nseg_s, 0, pr, dir, rng);
     __syncthreads();

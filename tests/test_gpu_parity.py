@@ -528,6 +528,26 @@ def test_ped_scans_vs_oracle(gpu, fmt):
         assert (exp[:, :17] < 6.0).any()
 
 
+@pytest.mark.parametrize("beams", [16, 64, 100])
+def test_ped_scans_few_beams_many_pedestrians(gpu, beams):
+    """ped_scan_kernel with fewer beams than threads and more agents than one wavefront's share of primitives (round-3
+    advisor finding: with ped_n_beams <= 64 the second wavefront marches nothing and used to read the side table and
+    its count before the threads that write them had passed a barrier).  24 and 64 pedestrians (thread 64, second
+    wavefront, then writes the robot's sides), repeated calls must agree with the oracle every time."""
+    for N, n_peds, seed in ((24, 24, 41), (64, 64, 43)):
+        E, size = 6, 240
+        cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_SFM, n_spawn=8,
+                                     auto_reset=1, seed=seed, field_format=abi.FIELD_U16T, ped_n_beams=beams)
+        gpu.world.lidar_1081(cfg)
+        occ = gpu.world.make_maps(E, size, seed)
+        for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=n_peds, steps=3, seed=8):
+            exp = r.ped_scans()
+            for rep in range(3):
+                _eq(g.ped_scans().cpu().numpy()[:, :n_peds], exp[:, :n_peds],
+                    "pedestrian scans, %d beams, %d pedestrians, step %d" % (beams, n_peds, t))
+            assert (exp[:, :n_peds] < 6.0).any()
+
+
 @pytest.mark.parametrize("fmt,ped_model,plan", [(abi.FIELD_F32, abi.PED_NONE, 0), (abi.FIELD_U16T, abi.PED_SFM, 0),
                                                 (abi.FIELD_F32, abi.PED_SFM, 1), (abi.FIELD_U16T, abi.PED_NONE, 1)])
 def test_regen_vs_oracle(gpu, fmt, ped_model, plan):
