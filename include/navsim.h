@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NAVSIM_ABI_VERSION 3
+#define NAVSIM_ABI_VERSION 4
 
 /* error codes */
 #define NAVSIM_OK            0
@@ -50,16 +50,25 @@ extern "C" {
                                     bit-identical to the float32 field */
 #define NAVSIM_FIELD_TILE    8
 
-/* how the sphere-tracing step 0.999 * d of range_libc's RayMarching::calc_range (env.py:425) is rounded
- * (navsim_config.march_rule).  The package's source is not in the reference tree, so which of the two the
- * upstream binary computes is UNPINNED; both are implemented on both sides and the
- * switch is this one field.  DESIGN.md records how many rays change their hit cell between them. */
-#define NAVSIM_MARCH_F64     0   /* t += max(fl32(fl64(d) * 0.999), 1): a double coefficient (default) */
-#define NAVSIM_MARCH_F32     1   /* t += max(d * 0.999f, 1): a float member `step_coeff` */
+/* How range_libc's RayMarching::calc_range (env.py:425) rounds its sphere-tracing step `d * step_coeff` and its sample
+ * position `x0 + ray_direction_x * t` (navsim_config.march_rule).  The package's source is not in the reference tree,
+ * so which of these the upstream BINARY computes is UNPINNED; all are implemented on both sides
+ * and the switch is this one field.  DESIGN.md records how many rays change their hit cell between them.
+ *   The published header (RangeLib.h, class RayMarching) declares the coefficient as a float data member
+ *   (`float step_coeff = 0.999;`, beside `float distThreshold = 0.0;`), so `d * step_coeff` is a float32 product:
+ *   NAVSIM_MARCH_F32 is the reading of the SOURCE and the default since ABI 4 (rounds 1-3 defaulted to the double
+ *   reading, NAVSIM_MARCH_F64, kept as a switch).  What the source cannot settle is the compiler: upstream's
+ *   setup.py builds with -O3 -march=native -ffast-math, and GCC contracts a * b + c into one fused multiply-add
+ *   wherever the target has FMA (-ffp-contract=fast is GCC's default outside ISO mode), i.e. the sample position
+ *   becomes fmaf(dir, t, x0) on every x86 since Haswell: NAVSIM_MARCH_F32_FMA.  (The hit distance
+ *   sqrtf(xd * xd + yd * yd) is unaffected: xd, yd are integers below 2^12, both products are exact.) */
+#define NAVSIM_MARCH_F64     0   /* t += max(fl32(fl64(d) * 0.999), 1): a double coefficient */
+#define NAVSIM_MARCH_F32     1   /* t += max(d * 0.999f, 1): the float member `step_coeff` of the source (default) */
+#define NAVSIM_MARCH_F32_FMA 2   /* NAVSIM_MARCH_F32 with the sample position contracted: px = (int)fmaf(dx, t, x0) */
 
 /* compiled limits */
 #define NAVSIM_MAX_PEDS      64
-#define NAVSIM_MAX_WAYPOINTS 16
+#define NAVSIM_MAX_WAYPOINTS 256 /* upper limit of navsim_config.max_waypoints (the stride P of ped_waypoints) */
 #define NAVSIM_OBS_TAIL      7   /* prev_pose(2) pose(2) vel(2) yaw(1): env.py:455 */
 
 /* ------------------------------------------------------------------------------------------
@@ -166,8 +175,30 @@ typedef struct navsim_config {
     int32_t rect_lds;                 /* fused step with rect records: 0 = the library stages an arena's record table in
                                          LDS when the launch is small enough for that to pay, 1 = never,
                                          2 = whenever the table fits (16 B per 8x8 tile next to the step's other LDS) */
-    int32_t reserved0;
+    int32_t max_waypoints;            /* P: waypoints kept per pedestrian = stride of navsim_state.ped_waypoints, 1 ..
+                                         NAVSIM_MAX_WAYPOINTS.  The reference keeps EVERY waypoint of a route
+                                         (path_to_waypoints, env.py:1261-1277; env.py:788-804); navsim_default_config
+                                         sets 64 = 128 m of route at the 2 m interval (a 1000 x 1000 map is 50 m wide).
+                                         A longer route is stored cut after P waypoints, counted in
+                                         counters[NAVSIM_COUNTER_ROUTES_CUT], and -- when navsim_state.ped_goal is
+                                         present -- continued to the SAME goal by navsim_replan when the pedestrian
+                                         reaches the cut */
+
+    /* The action's form (round 4; BUILD-DEFINED like the Husky model itself: the reference drives KetiRobot with
+     * (v, omega) only).  NAVSIM_ACTION_WHEELS: io->action holds the angular speeds (left, right) of a skid-steer
+     * base's wheel pairs in rad/s, converted on the device as v = r (wl + wr) / 2, omega = r (wr - wl) / track
+     * (third_party/husky_description/urdf/husky.urdf.xacro:61-67: track 0.5708, wheel radius 0.1651).
+     * clamp_action = 1 clamps the twist to [linvel_lo, linvel_hi] x [rotvel_lo, rotvel_hi] before anything else
+     * (the reference only prints a warning and never clips, env.py:606-613: 0 is the default).  The twist after
+     * conversion and clamp is what the step integrates and what the observation's `vel` slots carry. */
+    int32_t action_kind;              /* NAVSIM_ACTION_* */
+    int32_t clamp_action;
+    double wheel_radius, wheel_track;
+    double linvel_lo, linvel_hi, rotvel_lo, rotvel_hi;   /* __init__.py:12-13 linvel_range, rotvel_range */
 } navsim_config;
+
+#define NAVSIM_ACTION_TWIST  0   /* io->action = (v, omega): the reference's action (env.py:591) */
+#define NAVSIM_ACTION_WHEELS 1   /* io->action = (omega_left, omega_right) in rad/s */
 
 /* ------------------------------------------------------------------------------------------
  * Per-shard simulator state: structure of device arrays, env-major.  E = n_envs, N = max_peds,
@@ -211,7 +242,7 @@ typedef struct navsim_state {
     double*  ped_dist;              /* [E,N,3] leg odometry (env.py:255) */
     const double*  ped_v_pref;      /* [E,N] */
     const uint8_t* ped_has_legs;    /* [E,N] */
-    double*  ped_waypoints;         /* [E,N,P,2] remaining waypoints, [0] is the current local goal */
+    double*  ped_waypoints;         /* [E,N,P,2] remaining waypoints, [0] is the current local goal; P = cfg.max_waypoints */
     int32_t* ped_n_waypoints;       /* [E,N] >= 1 */
     const double*  ped_cmd;         /* [E,N,2] (v, omega) for NAVSIM_PED_EXTERNAL, else NULL */
 
@@ -237,7 +268,29 @@ typedef struct navsim_state {
      * that the reference's own generators can be replayed on the same draws (tests/golden/make_golden.py reset).
      * NULL (always, outside those tests) = hash-keyed draws. */
     const double* regen_draws;
+
+    /* ---- ABI 4 ---- */
+    /* [E,N,2] or NULL: the goal of every pedestrian's current route, written by whoever plans it (navsim_regen,
+     * navsim_replan; the caller for routes it supplies).  A route was stored cut exactly when its last stored
+     * waypoint differs from this goal (path_to_waypoints closes every list with the goal cell's centre, env.py:1273);
+     * navsim_replan then plans from where the pedestrian stands to the SAME goal instead of drawing a new one.
+     * NULL: a pedestrian that reaches the end of a cut list draws a new goal there. */
+    double*  ped_goal;
+    /* [NAVSIM_N_COUNTERS] uint64 or NULL: running totals, incremented on the device, zeroed by the caller when it
+     * likes.  They make the library's caps observable: no call ever fails or blocks because of a cap. */
+    unsigned long long* counters;
 } navsim_state;
+
+#define NAVSIM_N_COUNTERS              8
+#define NAVSIM_COUNTER_REGEN_SERVED    0   /* arenas given a new world by navsim_regen / installed by navsim_regen_swap */
+#define NAVSIM_COUNTER_REGEN_UNSERVED  1   /* finished arenas a navsim_regen / navsim_regen_swap call left beyond
+                                              cfg.regen_cap (or not staged yet): they play their next episode in place */
+#define NAVSIM_COUNTER_REPLAN_SERVED   2   /* pedestrians navsim_replan planned for (whether or not a path was found) */
+#define NAVSIM_COUNTER_REPLAN_UNSERVED 3   /* pedestrians due for a re-plan beyond max_queries: counted in every call that
+                                              leaves them waiting */
+#define NAVSIM_COUNTER_ROUTES_CUT      4   /* routes longer than cfg.max_waypoints, stored cut (navsim_regen with
+                                              regen_plan, navsim_replan) */
+#define NAVSIM_COUNTER_ROUTES_RESUMED  5   /* cut routes navsim_replan continued to their own goal (ped_goal) */
 
 #define NAVSIM_DRAWS_PER_ARENA      464
 #define NAVSIM_DRAW_KIND            0   /* np.random.random() < indoor_ratio             (env.py:295) */
@@ -375,7 +428,9 @@ int navsim_ped_scans(const navsim_config* cfg, const navsim_state* st, float* ou
  * carry st->field_overflow, which is regenerated together with the field (NAVSIM_E_UNSUPPORTED otherwise).
  * cfg->regen_plan = 1: starts and goals are centres of free COSTMAP cells and a pair is kept only when the
  * planner joins it (robot: path no longer than twice the straight line, env.py:756-762; pedestrians get the
- * path's waypoints every 2 m, env.py:804); four rounds of candidates, the last one stays if none passes. */
+ * path's waypoints every 2 m, env.py:804); four rounds of candidates, the last one stays if none passes.
+ * Finished arenas beyond cfg.regen_cap keep their map and play their next episode in place (the step has already
+ * respawned them from the spawn table); counters[NAVSIM_COUNTER_REGEN_UNSERVED] counts them. */
 size_t navsim_regen_workspace_bytes(const navsim_config* cfg);
 /* navsim_regen off the step's critical path (round 3).  The world an arena receives at the end of an episode depends
  * on (cfg.seed, global arena index, episode number) only, so it can be generated AHEAD of time: keep a second, STAGED
@@ -419,7 +474,10 @@ int    navsim_plan(const uint8_t* cost, const int32_t* map_index, int32_t n_quer
  * more than cfg->ped_min_goal_dist away (up to 4 rounds of 16 draws) -- and the waypoints of the shortest
  * path to it every 2 m; it keeps its old waypoint when no round finds a path ("only if the human is not
  * adjacent to a wall").  At most max_queries pedestrians per call, in (arena, pedestrian) order; the rest
- * are served by a later call.  Needs st->costmap.  Call after navsim_step / navsim_regen on the same stream. */
+ * are served by a later call and counted in counters[NAVSIM_COUNTER_REPLAN_UNSERVED].  A pedestrian standing at
+ * the end of a CUT route (st->ped_goal present and different from its last stored waypoint) is first planned to
+ * that same goal; only if no path joins them does it draw a new goal like the others.
+ * Needs st->costmap.  Call after navsim_step / navsim_regen on the same stream. */
 size_t navsim_replan_workspace_bytes(const navsim_config* cfg, int32_t max_queries);
 int    navsim_replan(const navsim_config* cfg, const navsim_state* st, int32_t max_queries, void* workspace,
                      size_t workspace_bytes, void* stream);
@@ -563,7 +621,7 @@ int navsim_debug_xy_to_ij(const navsim_config* cfg, const double* xy, int32_t as
  * functions navsim_regen's samplers call -- so that tests can compare them with the decisions the reference's own
  * _sample_start_goal_path / reset() took on the same candidates (tests/golden/golden_reset.npz).
  * cost [Hc,Wc] uint8 costmap (nonzero = blocked); kind [n]: 0 = the robot's pair, 1 = a pedestrian's; start, goal
- * [n,2] metres; robot [n,2] the robot's xy for kind 1 (may be NULL); wp_scratch [n, NAVSIM_MAX_WAYPOINTS, 2].
+ * [n,2] metres; robot [n,2] the robot's xy for kind 1 (may be NULL); wp_scratch [n, cfg.max_waypoints, 2].
  * code [n]: 0 kept, 1 start closer than cfg.ped_min_robot_dist to the robot, 2 goal distance outside its interval
  * (robot: cfg.min_goal_dist < d < cfg.max_goal_dist; pedestrian: d > cfg.ped_min_goal_dist), 3 no path, 4 (robot)
  * path_distance > 2 |goal - start|. */

@@ -85,8 +85,9 @@ __global__ __launch_bounds__(64 * kColSeg) void dt_columns_kernel(const uint8_t*
 
 // The march step of a free sample at distance d (cells): t += max(0.999 * d, 1), RayMarching::calc_range of
 // range_libc (env.py:425).  How the product is rounded is NOT pinned by anything in /root/reference (the
-// package's source is absent; oracle/navsim_ref.c states the two candidates): NAVSIM_MARCH_F64 keeps the
-// coefficient a double, fl32(fl64(d) * 0.999); NAVSIM_MARCH_F32 keeps it a float member, d * 0.999f.
+// package's source is absent; include/navsim.h NAVSIM_MARCH_* states the candidates): NAVSIM_MARCH_F64 keeps the
+// coefficient a double, fl32(fl64(d) * 0.999); NAVSIM_MARCH_F32 keeps it a float member, d * 0.999f (the default);
+// NAVSIM_MARCH_F32_FMA is the float member with the sample position contracted into an FMA (march_pos).
 //
 // kMarchF64Exact32 is the SAME function as NAVSIM_MARCH_F64 evaluated without float64 instructions (v_cvt_f64_f32,
 // v_mul_f64, v_cvt_f32_f64 cost the probe loop 5 % of the c2 step): 0.999 = c_hi + c_lo in float32, the product's
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(64 * kColSeg) void dt_columns_kernel(const uint8_t*
 // distance the packed field or a rect record can produce on maps up to 1448 cells per side; the host selects it
 // only there (march_rule_variant).  Not identical for arbitrary floats, so the float32 field (caller-supplied
 // values) and larger maps keep the float64 instructions.
-constexpr int kMarchF64Exact32 = 2;
+constexpr int kMarchF64Exact32 = 3;
 template <int RULE>
 __device__ __forceinline__ float march_step(float d) {
     float stp;
@@ -104,9 +105,16 @@ __device__ __forceinline__ float march_step(float d) {
         const float hi = d * c_hi;
         stp = hi + __builtin_fmaf(d, c_lo, __builtin_fmaf(d, c_hi, -hi));
     } else {
-        stp = (RULE == NAVSIM_MARCH_F32) ? d * 0.999f : (float)((double)d * 0.999);
+        stp = (RULE == NAVSIM_MARCH_F32 || RULE == NAVSIM_MARCH_F32_FMA) ? d * 0.999f : (float)((double)d * 0.999);
     }
     return (stp > 1.0f) ? stp : 1.0f;
+}
+// the sample position x0 + dx * t of calc_range: two roundings (v_mul_f32 + v_add_f32; the translation unit is
+// -ffp-contract=off) or, under NAVSIM_MARCH_F32_FMA, the single rounding of the FMA GCC contracts it into
+template <int RULE>
+__device__ __forceinline__ float march_pos(float x0, float dx, float t) {
+    if (RULE == NAVSIM_MARCH_F32_FMA) return __builtin_fmaf(dx, t, x0);
+    return x0 + dx * t;
 }
 
 // distance-field accessors -------------------------------------------------------------------

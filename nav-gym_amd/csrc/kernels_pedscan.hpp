@@ -77,7 +77,7 @@ __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim
         lanemask_t active = mask_of(true), hit = 0;
         while (active != 0)
             probe_round<Field, RULE, RECT>(field, rects, tpr, x0, y0, dx, dy, (unsigned)W, (unsigned)H, max_range, t, active, hit);
-        rng[k] = ray_result(hit, x0, y0, dx, dy, t, max_range) * res;
+        rng[k] = ray_result<RULE>(hit, x0, y0, dx, dy, t, max_range) * res;
     }
     __syncthreads();
     merge_prims_culled_core<BLOCK>(PB, lx_s, ly_s, (float)step, nseg_s, 0, pr, dir, rng);

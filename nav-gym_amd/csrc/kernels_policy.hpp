@@ -175,7 +175,7 @@ __global__ __launch_bounds__(128) void policy_head_kernel(navsim_config c, navsi
     __shared__ float h2[kHeadPeds][kPolH2];
     __shared__ float head[kHeadPeds][2];
     __shared__ int live_s[kHeadPeds];
-    const int tid = threadIdx.x, N = c.max_peds, P = NAVSIM_MAX_WAYPOINTS;
+    const int tid = threadIdx.x, N = c.max_peds, P = c.max_waypoints;
     const int pb = blockIdx.x * kHeadPeds;
     for (int idx = tid; idx < kHeadPeds * kPolH1; idx += 128) {
         const int s = idx / kPolH1, k = idx - s * kPolH1;

@@ -41,7 +41,7 @@ __device__ __forceinline__ int live_size(const navsim_config& c, const int* __re
 // excl_out / lo_out / hi_out (optional): this thread's slice of the arenas and the number of eligible ones before it.
 __device__ __forceinline__ int regen_slot(const uint8_t* __restrict__ done, int E, int cap, int b, int& total,
                                           const uint8_t* __restrict__ skip = nullptr, int* excl_out = nullptr,
-                                          int* lo_out = nullptr, int* hi_out = nullptr) {
+                                          int* lo_out = nullptr, int* hi_out = nullptr, int* all_out = nullptr) {
     __shared__ int wave_tot[4], found_s;
     const int tid = threadIdx.x, lane = tid & 63;
     const int per = (E + 255) / 256;
@@ -69,6 +69,7 @@ __device__ __forceinline__ int regen_slot(const uint8_t* __restrict__ done, int 
     __syncthreads();
     total = all < cap ? all : cap;
     if (excl_out) { *excl_out = excl; *lo_out = lo; *hi_out = hi; }
+    if (all_out) *all_out = all;
     return b < total ? found_s : -1;
 }
 
@@ -91,6 +92,13 @@ __device__ __forceinline__ void regen_params(const navsim_config& c, const navsi
                                                                  rg_t(tape, NAVSIM_DRAW_SCAN_NOISE_STD, pk, 2));
 }
 
+// navsim_state.counters: what a call served and what its cap left waiting (one thread of the opening kernel)
+__device__ __forceinline__ void count_served(const navsim_state& st, int served_slot, int served, int unserved) {
+    if (!st.counters) return;
+    if (served > 0) atomicAdd(&st.counters[served_slot], (unsigned long long)served);
+    if (unserved > 0) atomicAdd(&st.counters[served_slot + 1], (unsigned long long)unserved);
+}
+
 // The kernel also OPENS navsim_regen: workgroup b selects its arena (regen_slot), publishes list[b] (-1: none) and,
 // workgroup 0, the count; every later kernel of the call reads those.  (Worlds of outdoor maps only skip this kernel:
 // regen_maps_kernel opens the call itself.)
@@ -102,9 +110,9 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
     __shared__ int tx[152], ty[152];
     __shared__ unsigned best_s;
     const int b = blockIdx.x, tid = threadIdx.x;
-    int total;
-    const int e = regen_slot(done, c.n_envs, cap, b, total);
-    if (tid == 0) { list[b] = e; if (b == 0) *count = total; }
+    int total, all;
+    const int e = regen_slot(done, c.n_envs, cap, b, total, nullptr, nullptr, nullptr, nullptr, &all);
+    if (tid == 0) { list[b] = e; if (b == 0) { *count = total; count_served(st, NAVSIM_COUNTER_REGEN_SERVED, total, all - total); } }
     if (e < 0) return;
     const int size = c.map_w;
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
@@ -378,11 +386,11 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
     __shared__ int ocx[64], ocy[64];
     int n_items;
     if (done) {
-        int total;
-        (void)regen_slot(done, c.n_envs, cap, 0, total);
+        int total, all;
+        (void)regen_slot(done, c.n_envs, cap, 0, total, nullptr, nullptr, nullptr, nullptr, &all);
         n_items = total * kRegenSlices;
         if (blockIdx.x == 0) {
-            if (threadIdx.x == 0) *count = total;
+            if (threadIdx.x == 0) { *count = total; count_served(st, NAVSIM_COUNTER_REGEN_SERVED, total, all - total); }
             for (int b = total + (int)threadIdx.x; b < cap; b += 256) list[b] = -1;
         }
     } else {
@@ -496,8 +504,10 @@ __device__ __forceinline__ bool spawn_in_discomfort(const navsim_config& c, cons
         float dx, dy;
         nv::beam_dir((float)(nv::linspace_k(c, k, step) + (double)lth), dx, dy);
         float t = 0.0f, r = max_range;
+        const bool fma_pos = c.march_rule == NAVSIM_MARCH_F32_FMA;
         while (t < lim) {
-            const int px = (int)(x0 + dx * t), py = (int)(y0 + dy * t);
+            const int px = (int)(fma_pos ? __builtin_fmaf(dx, t, x0) : x0 + dx * t);
+            const int py = (int)(fma_pos ? __builtin_fmaf(dy, t, y0) : y0 + dy * t);
             if (px >= W || px < 0 || py < 0 || py >= H) break;
             const float d = f.at(px, py);
             if (d <= 0.0f) {
@@ -505,7 +515,7 @@ __device__ __forceinline__ bool spawn_in_discomfort(const navsim_config& c, cons
                 r = sqrtf(xd * xd + yd * yd);
                 break;
             }
-            const float stp = (c.march_rule == NAVSIM_MARCH_F32) ? d * 0.999f : (float)((double)d * 0.999);
+            const float stp = (c.march_rule != NAVSIM_MARCH_F64) ? d * 0.999f : (float)((double)d * 0.999);
             t += (stp > 1.0f) ? stp : 1.0f;
         }
         r = r * res;
@@ -563,7 +573,7 @@ __global__ __launch_bounds__(kCommitBlock) void regen_commit_kernel(navsim_confi
     const int e = list[b], tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     constexpr int kWaves = kCommitBlock / 64;
     const int size = live_size(c, kind, b);
-    const int N = c.max_peds, K = c.n_spawn, P = NAVSIM_MAX_WAYPOINTS;
+    const int N = c.max_peds, K = c.n_spawn, P = c.max_waypoints;
     const Field f(st.field, st.field_overflow, e, c.map_h, c.map_w);
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
     double* sp = (double*)st.spawn_pose + (size_t)e * K * 3;
@@ -613,6 +623,7 @@ __global__ __launch_bounds__(kCommitBlock) void regen_commit_kernel(navsim_confi
             double* wp = st.ped_waypoints + (q * P) * 2;
             wp[0] = gx; wp[1] = gy;
             st.ped_n_waypoints[q] = 1;
+            if (st.ped_goal) { st.ped_goal[q * 2] = gx; st.ped_goal[q * 2 + 1] = gy; }
         }
     }
 }
@@ -665,7 +676,8 @@ inline bool plan_fits(int Hc, int Wc) { return (size_t)Hc * Wc <= 65535 && plan_
 __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc, int Wc, double res_c, double ox,
                                            double oy, double sx_, double sy_, double gx_, double gy_, double interval,
                                            int max_wp, double* __restrict__ w, int32_t* __restrict__ n_wp,
-                                           int32_t* __restrict__ path_cells, double* __restrict__ path_len) {
+                                           int32_t* __restrict__ path_cells, double* __restrict__ path_len,
+                                           unsigned long long* __restrict__ cut_counter = nullptr) {
     extern __shared__ int16_t dist[];
     __shared__ int cnt[3], reached;
     const int tid = threadIdx.x;
@@ -767,6 +779,16 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
     int n = 0, count = 0, ci = si, cj = sj;
     const double fx0 = ((double)si + 0.5) * res_c + ox, fy0 = ((double)sj + 0.5) * res_c + oy;
     double fx = fx0, fy = fy0;                           // env.py:1261-1277, cut while walking
+    // path_distance (env.py:757-759: |start - wp0| + sum |wp_k+1 - wp_k|) over EVERY waypoint of the path, accumulated
+    // as they are cut -- also over those beyond max_wp, which are counted but not stored
+    double L = 0.0, lx = sx_, ly = sy_;
+    auto emit = [&](double cx, double cy) {
+        if (count < max_wp) { w[2 * count] = cx; w[2 * count + 1] = cy; }
+        ++count;
+        const double ax = cx - lx, ay = cy - ly;
+        L += sqrt(ax * ax + ay * ay);
+        lx = cx; ly = cy;
+    };
     const double i2_hi = interval * interval * (1.0 + 1.0e-12), i2_lo = interval * interval * (1.0 - 1.0e-12);
     for (;;) {
         ++n;
@@ -778,32 +800,17 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
         // and correctly rounded, so the two tests agree outside that band)
         const double d2 = dx * dx + dy * dy;
         const bool far = (d2 > i2_hi) || (!(d2 < i2_lo) && sqrt(d2) > interval);
-        if (far) {
-            if (count < max_wp) { w[2 * count] = cx; w[2 * count + 1] = cy; }
-            ++count; fx = cx; fy = cy;
-        }
-        if (dcur == 0) {                                 // the goal cell closes the list
-            if (count < max_wp) { w[2 * count] = cx; w[2 * count + 1] = cy; }
-            ++count;
-            break;
-        }
+        if (far) { emit(cx, cy); fx = cx; fy = cy; }
+        if (dcur == 0) { emit(cx, cy); break; }          // the goal cell closes the list
         const int want = dcur - 1;                       // first neighbour one hop closer, (+i, -i, +j, -j)
         const bool e0 = ci + 1 < Wc && dist[k + 1] == want, e1 = ci > 0 && dist[k - 1] == want;
         const bool e2 = cj + 1 < Hc && dist[k + Wc] == want;
         if (e0) ++ci; else if (e1) --ci; else if (e2) ++cj; else --cj;
     }
-    int nw = count < max_wp ? count : max_wp;
-    *n_wp = nw;
+    *n_wp = count < max_wp ? count : max_wp;
     if (path_cells) *path_cells = n;
-    if (path_len) {
-        double sx = sx_ - w[0], sy = sy_ - w[1];
-        double L = sqrt(sx * sx + sy * sy);
-        for (int k = 0; k + 1 < nw; ++k) {
-            double ax = w[2 * k + 2] - w[2 * k], ay = w[2 * k + 3] - w[2 * k + 1];
-            L += sqrt(ax * ax + ay * ay);
-        }
-        *path_len = L;
-    }
+    if (path_len) *path_len = L;
+    if (count > max_wp && cut_counter) atomicAdd(cut_counter, 1ull);       // a route stored cut (include/navsim.h)
 }
 
 __global__ __launch_bounds__(256) void plan_kernel(const uint8_t* __restrict__ cost, const int32_t* __restrict__ map_index,
@@ -940,7 +947,7 @@ __global__ __launch_bounds__(256) void regen_ped_round_kernel(navsim_config c, n
     const int b = blockIdx.x;
     if (b >= *count) return;
     const int e = list[b], tid = threadIdx.x;
-    const int N = c.max_peds, Q = ws.Q, P = NAVSIM_MAX_WAYPOINTS;
+    const int N = c.max_peds, Q = ws.Q, P = c.max_waypoints;
     const int Hc = c.map_h / 5, Wc = c.map_w / 5;
     const int live_c = live_size(c, ws.kind, b) / 5;
     const double res_c = c.resolution * 5.0;
@@ -965,6 +972,7 @@ __global__ __launch_bounds__(256) void regen_ped_round_kernel(navsim_config c, n
         double* w = st.ped_waypoints + (pq * P) * 2;
         w[0] = gx; w[1] = gy;
         st.ped_n_waypoints[pq] = 1;
+        if (st.ped_goal) { st.ped_goal[pq * 2] = gx; st.ped_goal[pq * 2 + 1] = gy; }
         ws.qstart[2 * q] = x; ws.qstart[2 * q + 1] = y;
         ws.qgoal[2 * q] = gx; ws.qgoal[2 * q + 1] = gy;
         ws.active[q] = 1;
@@ -976,12 +984,13 @@ __global__ __launch_bounds__(256) void regen_plan_kernel(navsim_config c, navsim
                                                          const int* __restrict__ list, RegenPlanWs ws, int ped_stage) {
     const int q = blockIdx.x, b = q / ws.Q, k = q - b * ws.Q;
     if (b >= *count || !ws.active[q]) return;            // uniform per workgroup
-    const int Hc = c.map_h / 5, Wc = c.map_w / 5, P = NAVSIM_MAX_WAYPOINTS;
+    const int Hc = c.map_h / 5, Wc = c.map_w / 5, P = c.max_waypoints;
     double* w = ped_stage ? st.ped_waypoints + (((size_t)list[b] * c.max_peds + k) * P) * 2
                           : ws.qwp + (size_t)q * P * 2;
     plan_query(ws.cost + (size_t)(ws.cost_by_arena ? list[b] : b) * Hc * Wc, Hc, Wc, c.resolution * 5.0, c.origin_x, c.origin_y, ws.qstart[2 * q],
                ws.qstart[2 * q + 1], ws.qgoal[2 * q], ws.qgoal[2 * q + 1], ped_stage ? 2.0 : 5.0, P, w, ws.qnwp + q,
-               nullptr, ped_stage ? nullptr : ws.qlen + q);
+               nullptr, ped_stage ? nullptr : ws.qlen + q,
+               (ped_stage && st.counters) ? st.counters + NAVSIM_COUNTER_ROUTES_CUT : nullptr);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -990,7 +999,7 @@ __global__ __launch_bounds__(256) void regen_plan_kernel(navsim_config c, navsim
 // --------------------------------------------------------------------------------------------
 // one wavefront per arena: bit i of due[e] = pedestrian i stands within 0.5 m of its final waypoint
 __global__ __launch_bounds__(64) void replan_flag_kernel(navsim_config c, navsim_state st, uint64_t* __restrict__ due) {
-    const int e = blockIdx.x, i = threadIdx.x, N = c.max_peds, P = NAVSIM_MAX_WAYPOINTS;
+    const int e = blockIdx.x, i = threadIdx.x, N = c.max_peds, P = c.max_waypoints;
     bool flag = false;
     if (i < N && i < st.n_peds[e]) {
         const size_t q = (size_t)e * N + i;
@@ -1006,7 +1015,8 @@ __global__ __launch_bounds__(64) void replan_flag_kernel(navsim_config c, navsim
 
 // ordered compaction of the set bits, (arena, pedestrian) order, at most cap entries
 __global__ __launch_bounds__(1024) void replan_select_kernel(const uint64_t* __restrict__ due, int E, int N, int cap,
-                                                             int* __restrict__ count, int* __restrict__ list) {
+                                                             int* __restrict__ count, int* __restrict__ list,
+                                                             navsim_state st) {
     __shared__ int part[1024];
     const int tid = threadIdx.x;
     const int per = (E + 1023) / 1024;
@@ -1025,7 +1035,11 @@ __global__ __launch_bounds__(1024) void replan_select_kernel(const uint64_t* __r
     if (n)
         for (int e = lo; e < hi && pos < cap; ++e)
             for (uint64_t m = due[e]; m && pos < cap; m &= m - 1) list[pos++] = e * N + (__ffsll((unsigned long long)m) - 1);
-    if (tid == 1023) *count = part[1023] < cap ? part[1023] : cap;
+    if (tid == 1023) {
+        const int served = part[1023] < cap ? part[1023] : cap;
+        *count = served;
+        count_served(st, NAVSIM_COUNTER_REPLAN_SERVED, served, part[1023] - served);
+    }
 }
 
 __global__ __launch_bounds__(256) void replan_kernel(navsim_config c, navsim_state st, const int* __restrict__ count,
@@ -1034,7 +1048,7 @@ __global__ __launch_bounds__(256) void replan_kernel(navsim_config c, navsim_sta
     __shared__ int32_t nwp_s;
     const int b = blockIdx.x;
     if (b >= *count) return;
-    const int q = list[b], N = c.max_peds, P = NAVSIM_MAX_WAYPOINTS, tid = threadIdx.x;
+    const int q = list[b], N = c.max_peds, P = c.max_waypoints, tid = threadIdx.x;
     const int e = q / N, i = q - e * N;
     const int Hc = c.map_h / 5, Wc = c.map_w / 5;
     const double res_c = c.resolution * 5.0;
@@ -1043,19 +1057,37 @@ __global__ __launch_bounds__(256) void replan_kernel(navsim_config c, navsim_sta
     const uint64_t when = (uint64_t)st.steps[e] + ((uint64_t)st.episode[e] << 40);
     const double px = st.ped_pose[(size_t)q * 3], py = st.ped_pose[(size_t)q * 3 + 1];
     double* w = st.ped_waypoints + ((size_t)q * P) * 2;
-    for (int round = 0; round < 4; ++round) {
+    unsigned long long* cut_counter = st.counters ? st.counters + NAVSIM_COUNTER_ROUTES_CUT : nullptr;
+    // The end of a route that was stored CUT (its last stored waypoint is not its goal): the pedestrian walks on to the
+    // goal it had (round -1: no draw); only if no path joins them does it draw a new goal like the others.  Every thread
+    // reads the same two words before any of them is rewritten (block-uniform).
+    bool cut = false;
+    if (st.ped_goal) {
+        const int nw = st.ped_n_waypoints[q];
+        cut = w[2 * (nw - 1)] != st.ped_goal[(size_t)q * 2] || w[2 * (nw - 1) + 1] != st.ped_goal[(size_t)q * 2 + 1];
+    }
+    __syncthreads();
+    for (int round = cut ? -1 : 0; round < 4; ++round) {
         if (tid == 0) {
-            uint64_t key = rg_key(c.seed, genv, when, 0x52504E00ULL + (uint64_t)round * 256 + (uint64_t)i), m = 0;
             double gx, gy;
-            rgp_cell(c, cost, Wc, Wc, Hc, res_c, key, m, 2, px, py, c.ped_min_goal_dist, 1.0e300, gx, gy);
+            if (round < 0) {
+                gx = st.ped_goal[(size_t)q * 2]; gy = st.ped_goal[(size_t)q * 2 + 1];
+            } else {
+                uint64_t key = rg_key(c.seed, genv, when, 0x52504E00ULL + (uint64_t)round * 256 + (uint64_t)i), m = 0;
+                rgp_cell(c, cost, Wc, Wc, Hc, res_c, key, m, 2, px, py, c.ped_min_goal_dist, 1.0e300, gx, gy);
+            }
             goal_s[0] = gx; goal_s[1] = gy;
         }
         __syncthreads();
         plan_query(cost, Hc, Wc, res_c, c.origin_x, c.origin_y, px, py, goal_s[0], goal_s[1], 2.0, P, w, &nwp_s,
-                   nullptr, nullptr);
+                   nullptr, nullptr, cut_counter);
         __syncthreads();
         if (nwp_s > 0) {
-            if (tid == 0) st.ped_n_waypoints[q] = nwp_s;
+            if (tid == 0) {
+                st.ped_n_waypoints[q] = nwp_s;
+                if (st.ped_goal) { st.ped_goal[(size_t)q * 2] = goal_s[0]; st.ped_goal[(size_t)q * 2 + 1] = goal_s[1]; }
+                if (round < 0 && st.counters) atomicAdd(&st.counters[NAVSIM_COUNTER_ROUTES_RESUMED], 1ull);
+            }
             break;
         }
         __syncthreads();                                 // nwp_s is rewritten by the next round
@@ -1080,7 +1112,7 @@ __global__ __launch_bounds__(256) void spawn_decisions_kernel(navsim_config c, c
     else if (!rg_goal_ok(sx, sy, gx, gy, ped ? c.ped_min_goal_dist : c.min_goal_dist, ped ? 1.0e300 : c.max_goal_dist)) rc = 2;
     if (rc) { if (tid == 0) code[m] = rc; return; }                      // uniform per workgroup
     plan_query(cost, Hc, Wc, c.resolution * 5.0, c.origin_x, c.origin_y, sx, sy, gx, gy, ped ? 2.0 : 5.0,
-               NAVSIM_MAX_WAYPOINTS, wp_scratch + (size_t)m * NAVSIM_MAX_WAYPOINTS * 2, &nwp_s, nullptr, &plen_s);
+               c.max_waypoints, wp_scratch + (size_t)m * c.max_waypoints * 2, &nwp_s, nullptr, &plen_s);
     __syncthreads();
     if (tid == 0) code[m] = nwp_s <= 0 ? 3 : ((!ped && !rg_robot_path_ok(plen_s, sx, sy, gx, gy)) ? 4 : 0);
 }
@@ -1109,14 +1141,16 @@ __global__ __launch_bounds__(256) void regen_swap_kernel(navsim_config c, navsim
     if (b == 0 && blockIdx.y == 0) {
         // a finished arena that is not installed now plays its next episode in place (the step respawned it on the old
         // map and advanced episode[e]); the world staged for it carries a stale episode number: stage it again
-        int pos = excl;
+        int pos = excl, n_in = 0, n_out = 0;
         for (int a = lo; a < hi; ++a) {
             if (io.done[a] == 0) continue;
             const bool elig = want[a] == 0;
             const bool installed = elig && pos < cap;
             pos += elig;
             if (!installed) { stage.episode[a] = live.episode[a] + 1; mark[a] = 1; }
+            n_in += installed; n_out += !installed;
         }
+        count_served(live, NAVSIM_COUNTER_REGEN_SERVED, n_in, n_out);
     }
     if (e < 0) return;
     const SwapBig big[4] = {b0, b1, b2, b3};
@@ -1136,7 +1170,7 @@ __global__ __launch_bounds__(256) void regen_swap_kernel(navsim_config c, navsim
         }
     }
     if (blockIdx.y != 0) return;
-    const int N = c.max_peds, K = c.n_spawn, P = NAVSIM_MAX_WAYPOINTS, D = c.n_scan_stack * c.n_beams + NAVSIM_OBS_TAIL;
+    const int N = c.max_peds, K = c.n_spawn, P = c.max_waypoints, D = c.n_scan_stack * c.n_beams + NAVSIM_OBS_TAIL;
     auto row = [&](auto* dst, const auto* src, size_t n) {    // n elements of arena e
         if (!dst || !src) return;
         for (size_t i = tid; i < n; i += 256) dst[(size_t)e * n + i] = src[(size_t)e * n + i];
@@ -1160,6 +1194,7 @@ __global__ __launch_bounds__(256) void regen_swap_kernel(navsim_config c, navsim
         row((uint8_t*)live.ped_has_legs, stage.ped_has_legs, N);
         row(live.ped_waypoints, stage.ped_waypoints, (size_t)N * P * 2);
         row(live.ped_n_waypoints, stage.ped_n_waypoints, N);
+        row(live.ped_goal, stage.ped_goal, (size_t)N * 2);
     }
     row(io.obs, stage_obs, D);
     if (tid == 0) {

@@ -316,7 +316,9 @@ __device__ __forceinline__ void probe_round(const Field& field, const char* __re
                                             float max_range, float& t, lanemask_t& active, lanemask_t& hit) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));            // v_pk_mul_f32 + v_pk_add_f32 (never fused:
     const f32x2 org = {x0, y0}, dir = {dx, dy};                          // the translation unit is -ffp-contract=off)
-    const f32x2 pos = org + dir * t;
+    f32x2 pos;
+    if constexpr (RULE == NAVSIM_MARCH_F32_FMA) pos = __builtin_elementwise_fma(dir, (f32x2){t, t}, org);   // v_pk_fma_f32
+    else pos = org + dir * t;
     int px = (int)pos.x, py = (int)pos.y;
     const lanemask_t live = active & mask_ult((unsigned)px, uW) & mask_ult((unsigned)py, uH);
     lanemask_t occ;
@@ -370,9 +372,10 @@ __device__ __forceinline__ void probe_round(const Field& field, const char* __re
 }
 
 // raw range (cells) of a finished ray: the hit cell recomputed from the t of the hit probe
+template <int RULE>
 __device__ __forceinline__ float ray_result(lanemask_t hit, float x0, float y0, float dx, float dy, float t, float miss) {
-    const float xd = (float)(int)(x0 + dx * t) - x0;
-    const float yd = (float)(int)(y0 + dy * t) - y0;
+    const float xd = (float)(int)march_pos<RULE>(x0, dx, t) - x0;
+    const float yd = (float)(int)march_pos<RULE>(y0, dy, t) - y0;
     return mask_sel(hit, sqrtf(xd * xd + yd * yd), miss);
 }
 
@@ -480,7 +483,7 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShar
         if constexpr (!kPark) {
             while (active != 0)
                 probe_round<Field, RULE, RECT>(field, (const char*)rects, tpr, x0, y0, dx, dy, uW, uH, max_range, t, active, hit);
-            if (valid) finish(k, dx, dy, ray_result(hit, x0, y0, dx, dy, t, miss));
+            if (valid) finish(k, dx, dy, ray_result<RULE>(hit, x0, y0, dx, dy, t, miss));
         } else {
             while ((int)__builtin_popcountll(active) > park_lanes)
                 probe_round<Field, RULE, RECT>(field, (const char*)rects, tpr, x0, y0, dx, dy, uW, uH, max_range, t, active, hit);
@@ -499,7 +502,7 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShar
                     }
                 }
             }
-            if (valid & !marching) finish(k, dx, dy, ray_result(hit, x0, y0, dx, dy, t, miss));
+            if (valid & !marching) finish(k, dx, dy, ray_result<RULE>(hit, x0, y0, dx, dy, t, miss));
         }
     }
     // the parked rays, 64 at a time
@@ -528,7 +531,7 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShar
         lanemask_t hit = 0;
         while (active != 0)
             probe_round<Field, RULE, RECT>(field, (const char*)rects, tpr, x0, y0, dx, dy, uW, uH, max_range, t, active, hit);
-        if (valid) finish(k, dx, dy, ray_result(hit, x0, y0, dx, dy, t, miss));
+        if (valid) finish(k, dx, dy, ray_result<RULE>(hit, x0, y0, dx, dy, t, miss));
     }
     if (TO_LDS) {
         __syncthreads();
@@ -660,6 +663,7 @@ __device__ __forceinline__ void ped_finish(const navsim_config& c, const navsim_
             double gx = cand[0] - pp[0], gy = cand[1] - pp[1];
             if (sqrt(gx * gx + gy * gy) > 10.0) {
                 wp[0] = cand[0]; wp[1] = cand[1]; nw = 1;
+                if (st.ped_goal) { st.ped_goal[pq * 2] = cand[0]; st.ped_goal[pq * 2 + 1] = cand[1]; }
                 break;
             }
         }
@@ -693,7 +697,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 __device__ __forceinline__ int ped_stage_wave(const navsim_config& c, const navsim_state& st, int n, int lane, bool is_ped,
                                               size_t pq, const double* rp_t, double prev_v, const PedShared& ps,
                                               const double (&pp)[3], const double (&pvel)[2]) {
-    const int P = NAVSIM_MAX_WAYPOINTS;
+    const int P = c.max_waypoints;
     double* wp = st.ped_waypoints ? st.ped_waypoints + (pq * P) * 2 : nullptr;
     int nw = 1;
     if (is_ped) nw = ped_pop_waypoints(wp, st.ped_n_waypoints[pq], pp);
@@ -714,7 +718,7 @@ __device__ __forceinline__ void ped_advance_wave(const navsim_config& c, const n
                                                  int n, int lane, bool is_ped, size_t pq, double dt, uint64_t genv,
                                                  uint64_t steps_now, const PedShared& ps, double2* pair, int nw,
                                                  double (&pp)[3], double (&pvel)[2]) {
-    const int P = NAVSIM_MAX_WAYPOINTS;
+    const int P = c.max_waypoints;
     double* wp = st.ped_waypoints ? st.ped_waypoints + (pq * P) * 2 : nullptr;
     if (c.ped_model == NAVSIM_PED_SFM) {
         wave_lds_sync();                                    // the staged agents (the workgroup barrier lies in between as well)
@@ -757,7 +761,7 @@ __global__ __launch_bounds__(kPedUpdateBlock) void ped_update_kernel(navsim_conf
     extern __shared__ __attribute__((aligned(16))) char ped_dyn[];
     __shared__ int slot_n[kPedPack], slot_off[kPedPack + 1];
     const int lane = threadIdx.x;                                      // thread of the workgroup
-    const int N = c.max_peds, G = ped_pack(N), P = NAVSIM_MAX_WAYPOINTS;
+    const int N = c.max_peds, G = ped_pack(N), P = c.max_waypoints;
     const int s = lane / N, i = lane - s * N;                          // arena of the pack, pedestrian of the arena
     const int e = (int)blockIdx.x * G + s;
     const bool slot_ok = s < G && e < c.n_envs;
@@ -907,6 +911,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         double a0 = 0.0, a1 = 0.0;
         if (!reset_only) {
             a0 = io.action[2 * e]; a1 = io.action[2 * e + 1];
+            if (c.action_kind == NAVSIM_ACTION_WHEELS) {       // skid-steer wheel speeds (left, right) -> twist (include/navsim.h)
+                const double wl = a0, wr = a1;
+                a0 = c.wheel_radius * (wl + wr) * 0.5;
+                a1 = c.wheel_radius * (wr - wl) / c.wheel_track;
+            }
+            if (c.clamp_action) {                              // build option; the reference never clips (env.py:611-613)
+                a0 = a0 < c.linvel_lo ? c.linvel_lo : (a0 > c.linvel_hi ? c.linvel_hi : a0);
+                a1 = a1 < c.rotvel_lo ? c.rotvel_lo : (a1 > c.rotvel_hi ? c.rotvel_hi : a1);
+            }
             if (c.min_turning_radius > 0.0) {                  // env.py:595-600
                 double lim = fabs(a1) * c.min_turning_radius;
                 if (a0 >= 0.0) a0 = (a0 > lim) ? a0 : lim;

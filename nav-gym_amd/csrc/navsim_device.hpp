@@ -71,9 +71,10 @@ __device__ __forceinline__ bool beam_dir_from_table(double ct, double st, double
 __device__ __forceinline__ float trace_ray(const float* __restrict__ f, int H, int W, float x0, float y0,
                                            float dx, float dy, float max_range, int march_rule) {
     float t = 0.0f;
+    const bool fma_pos = march_rule == NAVSIM_MARCH_F32_FMA;            // include/navsim.h: the contracted sample position
     while (t < max_range) {
-        float fx = x0 + dx * t;
-        float fy = y0 + dy * t;
+        float fx = fma_pos ? __builtin_fmaf(dx, t, x0) : x0 + dx * t;
+        float fy = fma_pos ? __builtin_fmaf(dy, t, y0) : y0 + dy * t;
         int px = (int)fx;
         int py = (int)fy;
         if (px >= W || px < 0 || py < 0 || py >= H) return max_range;
@@ -83,7 +84,7 @@ __device__ __forceinline__ float trace_ray(const float* __restrict__ f, int H, i
             float yd = (float)py - y0;
             return sqrtf(xd * xd + yd * yd);
         }
-        float step = (march_rule == NAVSIM_MARCH_F32) ? d * 0.999f : (float)((double)d * 0.999);
+        float step = (march_rule != NAVSIM_MARCH_F64) ? d * 0.999f : (float)((double)d * 0.999);
         t += (step > 1.0f) ? step : 1.0f;
     }
     return max_range;

@@ -148,7 +148,7 @@ int pick_step_block(const navsim_config* c) {
 // which compiled form of the march step serves cfg.march_rule (kernels_field.hpp march_step): the float32-only
 // evaluation of NAVSIM_MARCH_F64 where every distance is sqrtf of an integer below 2^22
 int march_rule_variant(const navsim_config* c) {
-    if (c->march_rule == NAVSIM_MARCH_F32) return NAVSIM_MARCH_F32;
+    if (c->march_rule == NAVSIM_MARCH_F32 || c->march_rule == NAVSIM_MARCH_F32_FMA) return c->march_rule;
     const int side = c->map_h > c->map_w ? c->map_h : c->map_w;
     return (c->field_format == NAVSIM_FIELD_U16T && side <= 1448) ? kMarchF64Exact32 : NAVSIM_MARCH_F64;
 }
@@ -219,6 +219,7 @@ int launch_step_rule(const navsim_config* c, const navsim_state* st, const navsi
                      const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
     switch (march_rule_variant(c)) {
         case NAVSIM_MARCH_F32: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F32>(c, st, io, reset_only, mask, p, s, grid);
+        case NAVSIM_MARCH_F32_FMA: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F32_FMA>(c, st, io, reset_only, mask, p, s, grid);
         case kMarchF64Exact32:
             if constexpr (!std::is_same<Field, FieldF32>::value)
                 return launch_step_kernel<BLOCK, PEDS, Field, RECT, kMarchF64Exact32>(c, st, io, reset_only, mask, p, s, grid);
@@ -357,7 +358,14 @@ int navsim_default_config(navsim_config* c) {
     c->iterations_lo = 80; c->iterations_hi = 150;           // __init__.py:33
     c->num_humans_lo = 0; c->num_humans_hi = 0;              // 0: navsim_regen keeps n_peds
     c->scan_noise_std_lo = 0.0; c->scan_noise_std_hi = -1.0; // < 0: navsim_regen keeps scan_noise_std
-    c->march_rule = NAVSIM_MARCH_F64;
+    c->march_rule = NAVSIM_MARCH_F32;          // RangeLib.h: `float step_coeff = 0.999;` (include/navsim.h NAVSIM_MARCH_*)
+    c->max_waypoints = 64;                     // 128 m of route at the 2 m interval (include/navsim.h)
+    c->action_kind = NAVSIM_ACTION_TWIST;      // env.py:591
+    c->clamp_action = 0;                       // env.py:611-613: never clipped
+    c->wheel_radius = 0.1651;                  // third_party/husky_description/urdf/husky.urdf.xacro:67
+    c->wheel_track = 0.5708;                   // husky.urdf.xacro:62
+    c->linvel_lo = 0.0; c->linvel_hi = 0.5;    // __init__.py:12
+    c->rotvel_lo = -0.64; c->rotvel_hi = 0.64; // __init__.py:13
     c->regen_check_discomfort = 1;          // env.py:776-781
     c->rect_lds = 0;
     c->step_block = 0;
@@ -475,7 +483,7 @@ int navsim_cast_static(const float* field, int32_t E, int32_t H, int32_t W, cons
                        int32_t n_per_env, float max_range, int32_t march_rule, float* out, void* stream) {
     (void)hipGetLastError();   // drop stale errors of unrelated earlier runtime calls
     if (!field || E < 0 || n_per_env < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
-    if (march_rule != NAVSIM_MARCH_F64 && march_rule != NAVSIM_MARCH_F32) return NAVSIM_E_ARG;
+    if (march_rule < NAVSIM_MARCH_F64 || march_rule > NAVSIM_MARCH_F32_FMA) return NAVSIM_E_ARG;
     long long total = (long long)E * n_per_env;
     if (total == 0) return NAVSIM_OK;
     if (!q || !out) return NAVSIM_E_ARG;
@@ -548,7 +556,10 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
     if (c->n_envs < 0 || c->n_beams < 1 || c->n_scan_stack < 1 || c->map_h < 1 || c->map_w < 1) return NAVSIM_E_ARG;
     if (c->max_peds > NAVSIM_MAX_PEDS) return NAVSIM_E_UNSUPPORTED;
     if (c->field_format != NAVSIM_FIELD_F32 && c->field_format != NAVSIM_FIELD_U16T) return NAVSIM_E_UNSUPPORTED;
-    if (c->march_rule != NAVSIM_MARCH_F64 && c->march_rule != NAVSIM_MARCH_F32) return NAVSIM_E_ARG;
+    if (c->march_rule < NAVSIM_MARCH_F64 || c->march_rule > NAVSIM_MARCH_F32_FMA) return NAVSIM_E_ARG;
+    if (c->action_kind != NAVSIM_ACTION_TWIST && c->action_kind != NAVSIM_ACTION_WHEELS) return NAVSIM_E_ARG;
+    if (c->action_kind == NAVSIM_ACTION_WHEELS && !(c->wheel_track > 0.0)) return NAVSIM_E_ARG;
+    if (c->ped_model != NAVSIM_PED_NONE && (c->max_waypoints < 1 || c->max_waypoints > NAVSIM_MAX_WAYPOINTS)) return NAVSIM_E_ARG;
     if (st->rect_table && (c->field_format != NAVSIM_FIELD_U16T || c->map_h > 1024 || c->map_w > 1024)) return NAVSIM_E_UNSUPPORTED;
     if (c->step_block != 0 && c->step_block != 64 && c->step_block != 256 && c->step_block != 512 &&
         c->step_block != 1024) return NAVSIM_E_ARG;
@@ -587,6 +598,7 @@ int navsim_ped_scans(const navsim_config* c, const navsim_state* st, float* out,
     const int rule = march_rule_variant(c);
 #define NAVSIM_PSCAN(F, RECT) \
     do { if (rule == NAVSIM_MARCH_F32)      ped_scan_kernel<F, 128, NAVSIM_MARCH_F32, RECT><<<grid, 128, lds, s>>>(*c, *st, out); \
+         else if (rule == NAVSIM_MARCH_F32_FMA) ped_scan_kernel<F, 128, NAVSIM_MARCH_F32_FMA, RECT><<<grid, 128, lds, s>>>(*c, *st, out); \
          else if (rule == kMarchF64Exact32 && !std::is_same<F, FieldF32>::value) \
                                             ped_scan_kernel<F, 128, kMarchF64Exact32, RECT><<<grid, 128, lds, s>>>(*c, *st, out); \
          else                               ped_scan_kernel<F, 128, NAVSIM_MARCH_F64, RECT><<<grid, 128, lds, s>>>(*c, *st, out); } while (0)
@@ -639,7 +651,7 @@ size_t navsim_regen_workspace_bytes(const navsim_config* c) {
     }
     b += M * (10000 + sizeof(int)) + 512;                   // corridor grids, map kinds
     if (c->regen_plan) {
-        const size_t cc = (size_t)(c->map_h / 5) * (c->map_w / 5), P = NAVSIM_MAX_WAYPOINTS;
+        const size_t cc = (size_t)(c->map_h / 5) * (c->map_w / 5), P = (size_t)(c->max_waypoints > 0 ? c->max_waypoints : 1);
         const size_t Q = (size_t)(c->n_spawn > c->max_peds ? c->n_spawn : c->max_peds);
         b += M * cc + 256;                                            // costmaps
         b += M * Q * (2 + 2 + 2 * P + 1) * sizeof(double) + 256;      // start, goal, waypoints, length
@@ -671,6 +683,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     if (c->field_format == NAVSIM_FIELD_F32 && st->field_overflow) return NAVSIM_E_UNSUPPORTED;
     if (st->rect_table && (c->field_format != NAVSIM_FIELD_U16T || c->map_h > 1024)) return NAVSIM_E_UNSUPPORTED;
     if (workspace_bytes < navsim_regen_workspace_bytes(c) || !st->spawn_pose || !st->spawn_goal) return NAVSIM_E_ARG;
+    if (c->regen_plan && (c->max_waypoints < 1 || c->max_waypoints > NAVSIM_MAX_WAYPOINTS)) return NAVSIM_E_ARG;
     if (c->regen_plan && (c->n_spawn > 256 || c->map_h < 5 || !plan_fits(c->map_h / 5, c->map_w / 5) ||
                           allow_lds((const void*)regen_plan_kernel, plan_lds(c->map_h / 5, c->map_w / 5)) != NAVSIM_OK))
         return NAVSIM_E_UNSUPPORTED;
@@ -745,7 +758,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
                                                                     (const char*)ovf_scratch, cells * sizeof(float));
     }
     if (c->regen_plan) {
-        const int Hc = H / 5, Wc = W / 5, P = NAVSIM_MAX_WAYPOINTS;
+        const int Hc = H / 5, Wc = W / 5, P = c->max_waypoints;
         const size_t cc = (size_t)Hc * Wc;
         const int Q = c->n_spawn > c->max_peds ? c->n_spawn : c->max_peds;
         auto take = [&](size_t bytes) { off = (off + 255) & ~(size_t)255; char* p = w + off; off += bytes; return p; };
@@ -810,7 +823,7 @@ int navsim_regen_swap(const navsim_config* c, const navsim_state* live, const na
     // the two states must hold the same optional buffers
     if ((live->field_overflow != nullptr) != (stage->field_overflow != nullptr) ||
         (live->rect_table != nullptr) != (stage->rect_table != nullptr) ||
-        (live->costmap != nullptr) != (stage->costmap != nullptr))
+        (live->costmap != nullptr) != (stage->costmap != nullptr) || (live->ped_goal != nullptr) != (stage->ped_goal != nullptr))
         return NAVSIM_E_ARG;
     if (c->n_envs == 0) return NAVSIM_OK;
     const int H = c->map_h, W = c->map_w;
@@ -849,7 +862,8 @@ int navsim_replan(const navsim_config* c, const navsim_state* st, int32_t max_qu
         !st->ped_n_waypoints || !st->n_peds || !st->steps || !st->episode)
         return NAVSIM_E_ARG;
     if (workspace_bytes < navsim_replan_workspace_bytes(c, max_queries)) return NAVSIM_E_ARG;
-    if (c->ped_model == NAVSIM_PED_NONE || c->n_envs == 0 || max_queries == 0) return NAVSIM_OK;
+    if (c->ped_model == NAVSIM_PED_NONE || c->n_envs == 0) return NAVSIM_OK;
+    if (c->max_waypoints < 1 || c->max_waypoints > NAVSIM_MAX_WAYPOINTS) return NAVSIM_E_ARG;
     const int Hc = c->map_h / 5, Wc = c->map_w / 5;
     if (Hc < 1 || Wc < 1 || !plan_fits(Hc, Wc) || allow_lds((const void*)replan_kernel, plan_lds(Hc, Wc)) != NAVSIM_OK)
         return NAVSIM_E_UNSUPPORTED;
@@ -858,8 +872,8 @@ int navsim_replan(const navsim_config* c, const navsim_state* st, int32_t max_qu
     int* list = (int*)((char*)workspace + 256);
     uint64_t* due = (uint64_t*)((char*)workspace + 256 + (((size_t)max_queries * sizeof(int32_t) + 255) & ~(size_t)255));
     replan_flag_kernel<<<c->n_envs, 64, 0, s>>>(*c, *st, due);
-    replan_select_kernel<<<1, 1024, 0, s>>>(due, c->n_envs, c->max_peds, max_queries, count, list);
-    replan_kernel<<<max_queries, 256, plan_lds(Hc, Wc), s>>>(*c, *st, count, list);
+    replan_select_kernel<<<1, 1024, 0, s>>>(due, c->n_envs, c->max_peds, max_queries, count, list, *st);
+    if (max_queries > 0) replan_kernel<<<max_queries, 256, plan_lds(Hc, Wc), s>>>(*c, *st, count, list);
     return launch_status();
 }
 
@@ -883,6 +897,7 @@ int navsim_ped_policy(const navsim_config* c, const navsim_state* st, const navs
         !w->a1_w || !w->a1_b || !w->a2_w || !w->a2_b)
         return NAVSIM_E_ARG;
     if (c->ped_n_beams != 512 || c->max_peds < 1) return NAVSIM_E_UNSUPPORTED;
+    if (c->max_waypoints < 1 || c->max_waypoints > NAVSIM_MAX_WAYPOINTS) return NAVSIM_E_ARG;
     if (workspace_bytes < navsim_ped_policy_workspace_bytes(c)) return NAVSIM_E_ARG;
     const size_t P = (size_t)c->n_envs * (size_t)c->max_peds;
     if (P == 0) return NAVSIM_OK;
@@ -1019,7 +1034,8 @@ int navsim_debug_spawn_decisions(const navsim_config* c, const uint8_t* cost, in
                                  const int32_t* kind, const double* start, const double* goal, const double* robot,
                                  double* wp_scratch, int32_t* code, void* stream) {
     (void)hipGetLastError();
-    if (!c || !cost || !kind || !start || !goal || !wp_scratch || !code || n < 0 || Hc < 1 || Wc < 1) return NAVSIM_E_ARG;
+    if (!c || !cost || !kind || !start || !goal || !wp_scratch || !code || n < 0 || Hc < 1 || Wc < 1 ||
+        c->max_waypoints < 1 || c->max_waypoints > NAVSIM_MAX_WAYPOINTS) return NAVSIM_E_ARG;
     if (n == 0) return NAVSIM_OK;
     if (!plan_fits(Hc, Wc) || allow_lds((const void*)spawn_decisions_kernel, plan_lds(Hc, Wc)) != NAVSIM_OK)
         return NAVSIM_E_UNSUPPORTED;

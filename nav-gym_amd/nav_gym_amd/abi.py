@@ -6,7 +6,7 @@ Field order and types must match include/navsim.h exactly; tests/test_abi.py com
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK = 0
 E_ARG = -1
@@ -19,7 +19,7 @@ PED_EXTERNAL = 1
 PED_SFM = 2
 
 MAX_PEDS = 64
-MAX_WAYPOINTS = 16
+MAX_WAYPOINTS = 256     # upper limit of cfg.max_waypoints (the stride P of ped_waypoints; navsim_default_config: 64)
 OBS_TAIL = 7
 
 FIELD_F32 = 0
@@ -27,7 +27,15 @@ FIELD_U16T = 1
 FIELD_TILE = 8
 
 MARCH_F64 = 0          # t += max(fl32(fl64(d) * 0.999), 1)
-MARCH_F32 = 1          # t += max(d * 0.999f, 1)
+MARCH_F32 = 1          # t += max(d * 0.999f, 1): RangeLib.h's float member step_coeff (default since ABI 4)
+MARCH_F32_FMA = 2      # MARCH_F32 with the sample position contracted into an FMA (GCC -O3 -march=native on FMA hardware)
+MARCH_RULES = (MARCH_F64, MARCH_F32, MARCH_F32_FMA)
+
+ACTION_TWIST = 0       # io.action = (v, omega)
+ACTION_WHEELS = 1      # io.action = (omega_left, omega_right) of a skid-steer base, rad/s
+
+N_COUNTERS = 8
+COUNTERS = ("regen_served", "regen_unserved", "replan_served", "replan_unserved", "routes_cut", "routes_resumed")
 
 
 class NavsimConfig(C.Structure):
@@ -109,7 +117,15 @@ class NavsimConfig(C.Structure):
         ("ped_split", C.c_int32),
         ("regen_check_discomfort", C.c_int32),
         ("rect_lds", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("max_waypoints", C.c_int32),
+        ("action_kind", C.c_int32),
+        ("clamp_action", C.c_int32),
+        ("wheel_radius", C.c_double),
+        ("wheel_track", C.c_double),
+        ("linvel_lo", C.c_double),
+        ("linvel_hi", C.c_double),
+        ("rotvel_lo", C.c_double),
+        ("rotvel_hi", C.c_double),
     ]
 
     def copy(self):
@@ -128,6 +144,7 @@ class NavsimState(C.Structure):
         "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist", "ped_v_pref", "ped_has_legs",
         "ped_waypoints", "ped_n_waypoints", "ped_cmd",
         "spawn_pose", "spawn_goal", "costmap", "arena_cost", "launch_order", "regen_draws",
+        "ped_goal", "counters",
     )]
 
 
@@ -208,6 +225,8 @@ STATE_LAYOUT = {
     "arena_cost": ("int32", ("E",)),
     "launch_order": ("int32", ("E",)),
     "regen_draws": ("float64", ("E", 464)),         # tests only: draws supplied (NAVSIM_DRAW_* layout)
+    "ped_goal": ("float64", ("E", "N", 2)),         # goal of every pedestrian's current route
+    "counters": ("int64", (N_COUNTERS,)),           # uint64 on the device; the totals stay far below 2^63
 }
 
 IO_LAYOUT = {
@@ -228,7 +247,7 @@ def resolve_shape(shape, cfg):
     """Turns a symbolic shape of STATE_LAYOUT / IO_LAYOUT into integers for `cfg`."""
     sym = {
         "E": cfg.n_envs, "N": cfg.max_peds, "B": cfg.n_beams, "S": cfg.n_scan_stack,
-        "K": max(cfg.n_spawn, 1), "P": MAX_WAYPOINTS, "H": cfg.map_h, "W": cfg.map_w,
+        "K": max(cfg.n_spawn, 1), "P": cfg.max_waypoints, "H": cfg.map_h, "W": cfg.map_w,
         "D": cfg.n_scan_stack * cfg.n_beams + OBS_TAIL, "Hc": cfg.map_h // 5, "Wc": cfg.map_w // 5,
         "T": ((cfg.map_h + 7) // 8) * ((cfg.map_w + 7) // 8),
     }

@@ -19,7 +19,17 @@ and default to the reference's behaviour for num_envs == 1:
                     policy_weights = the state_dict of human_policy.pth, a path to it, or a dict of arrays),
                     'sfm' (build-defined social force), 'external' (caller supplies (v, w) per
                     pedestrian -- the slot the reference fills with HumanPolicy) or 'none'
+    action_kind     'twist' (default): action = (v, omega) like the reference (env.py:591); 'wheels': action = the
+                    angular speeds (left, right) of a skid-steer base's wheel pairs in rad/s, converted on the device
+                    with the robot's wheel radius / track (robots.py; Husky: husky.urdf.xacro:61-67)
+    clip_actions    True: the twist is clamped to linvel_range x rotvel_range on the device (the reference only prints
+                    a warning and never clips, env.py:606-613: default False)
+    max_waypoints   waypoints kept per pedestrian route (default 64 = 128 m at the 2 m interval; the reference keeps
+                    all of them, env.py:788-804); longer routes are stored cut, counted, and continued to the same goal
     device, seed, env_index_base (global index of arena 0: sharding), auto_reset, field_format
+
+`env.counters()` reports what the caps of the device-side reset path left unserved (arenas beyond regen_cap,
+pedestrians beyond replan_cap, routes cut at max_waypoints) since the last call.
 
 num_envs == 1 returns NumPy float64 arrays with the reference's shapes; num_envs > 1 returns torch
 tensors on `device` (float32 observations).  Everything on the step() path runs in the HIP library;
@@ -107,7 +117,8 @@ class NavGymEnv(object):
                  reward_discomfort_factor, env_param_range, *,
                  num_envs=1, n_beams=None, lidar=None, map_size=400, pedestrian_model="sfm", policy_weights=None,
                  num_humans=None, device="cuda:0", seed=0, env_index_base=0, auto_reset=None,
-                 field_format=abi.FIELD_U16T, n_spawn=16, randomize_maps=False, plan_paths=True):
+                 field_format=abi.FIELD_U16T, n_spawn=16, randomize_maps=False, plan_paths=True,
+                 action_kind="twist", clip_actions=False, max_waypoints=64, march_rule=None):
         from . import lib
         if robot_type not in robots.ROBOTS:
             raise NotImplementedError(robot_type)            # env.py:772-773
@@ -161,6 +172,18 @@ class NavGymEnv(object):
         # reset() -- of the whole batch and, with randomize_maps, of every finished arena -- runs on the device
         # (navsim_regen): planning on the costmap as env.py:342-383 when plan_paths, the map kind by indoor_ratio
         # (env.py:295), and the per-episode draws of env_param_range (env.py:281-292)
+        if action_kind not in ("twist", "wheels"):
+            raise ValueError("action_kind must be 'twist' or 'wheels'")
+        self.action_kind = action_kind
+        cfg.action_kind = abi.ACTION_WHEELS if action_kind == "wheels" else abi.ACTION_TWIST
+        cfg.clamp_action = int(bool(clip_actions))
+        cfg.linvel_lo, cfg.linvel_hi = float(linvel_range[0]), float(linvel_range[1])
+        cfg.rotvel_lo, cfg.rotvel_hi = float(rotvel_range[0]), float(rotvel_range[1])
+        cfg.wheel_radius = float(spec.get("wheel_radius", robots.HUSKY_WHEEL_RADIUS))
+        cfg.wheel_track = float(spec.get("wheel_track", robots.HUSKY_TRACK))
+        cfg.max_waypoints = int(max_waypoints)
+        if march_rule is not None:                    # include/navsim.h NAVSIM_MARCH_*: the unpinned rounding of range_libc
+            cfg.march_rule = int(march_rule)
         cfg.regen_plan = int(self.plan_paths)
         cfg.regen_indoor_ratio = float(indoor_ratio)
         cfg.outdoor_map_size = int(self.outdoor_map_size)
@@ -202,8 +225,14 @@ class NavGymEnv(object):
         self.map_info = None
         self.scan_threshold = None
         self.scan_discomfort_threshold = None
-        self.action_space = spaces.Box(low=np.array([linvel_range[0], rotvel_range[0]]),
-                                       high=np.array([linvel_range[1], rotvel_range[1]]), dtype=np.float32)
+        if action_kind == "wheels":                   # wheel speeds that reach every corner of the twist box
+            corners = [robots.wheels_from_twist(v, w, cfg.wheel_radius, cfg.wheel_track)
+                       for v in linvel_range for w in rotvel_range]
+            lo, hi = float(np.min(corners)), float(np.max(corners))
+            self.action_space = spaces.Box(low=np.array([lo, lo]), high=np.array([hi, hi]), dtype=np.float32)
+        else:
+            self.action_space = spaces.Box(low=np.array([linvel_range[0], rotvel_range[0]]),
+                                           high=np.array([linvel_range[1], rotvel_range[1]]), dtype=np.float32)
         D = num_scan_stack * cfg.n_beams + 7
         self.observation_space = spaces.Dict({
             'observation': spaces.Box(-np.inf, np.inf, shape=(D,), dtype=np.float32),
@@ -310,6 +339,15 @@ class NavGymEnv(object):
             return obs, float(out["reward"][0].item()), bool(out["done"][0].item()), info
         info = {"is_success": out["is_success"], "is_crash": out["is_crash"], "distance": out["distance"]}
         return obs, out["reward"], out["done"].bool(), info
+
+    def counters(self, reset=True):
+        """What the device-side reset path served and what its caps left waiting since the last call (abi.COUNTERS):
+        regen_served / regen_unserved (finished arenas beyond cfg.regen_cap play their next episode on the old map),
+        replan_served / replan_unserved (pedestrians beyond replan_cap wait for the next step), routes_cut (routes
+        longer than max_waypoints) and routes_resumed (cut routes continued to their own goal)."""
+        if self.sim is None:
+            return {k: 0 for k in abi.COUNTERS}
+        return self.sim.counters(reset=reset)
 
     def human_scans(self):
         """The pedestrians' own 512-beam half-plane scans (env.py:685-693), float32 [E, N, 512]: what

@@ -21,6 +21,7 @@ HUSKY = dict(
     axle_offset=0.0,
     angle_min=-3.141592, angle_max=3.141592, angle_increment=0.0122718463, range_max=25.0, n_angles=512,
     linvel_range=[0.0, 1.0], rotvel_range=[-2.0, 2.0],
+    wheel_radius=0.1651, wheel_track=0.5708,      # husky.urdf.xacro:67, 62
 )
 
 # Human (human.py:5-16)
@@ -54,6 +55,12 @@ def husky_wheels_from_twist(v, omega):
     wl = (v - 0.5 * HUSKY_TRACK * omega) / HUSKY_WHEEL_RADIUS
     wr = (v + 0.5 * HUSKY_TRACK * omega) / HUSKY_WHEEL_RADIUS
     return wl, wr
+
+
+def wheels_from_twist(v, omega, radius, track):
+    """(omega_left, omega_right) in rad/s of a skid-steer base for the twist (v, omega): the inverse of what the step
+    computes on the device under NAVSIM_ACTION_WHEELS (include/navsim.h)."""
+    return (v - 0.5 * track * omega) / radius, (v + 0.5 * track * omega) / radius
 
 
 def footprint_array(robot, key):

@@ -88,7 +88,7 @@ def build_rects(occ, field, fmt, overflow=None):
     return table
 
 
-def cast_static(field, queries, max_range, march_rule=abi.MARCH_F64):
+def cast_static(field, queries, max_range, march_rule=abi.MARCH_F32):
     torch = require_gpu()
     E, H, W = field.shape
     q = queries.contiguous()
@@ -293,7 +293,7 @@ def debug_spawn_decisions(cfg, cost, kind, start, goal, robot=None):
     n = kind.shape[0]
     f64 = lambda a: None if a is None else torch.as_tensor(a).to(device=dev, dtype=torch.float64).contiguous().reshape(n, 2)
     start, goal, robot = f64(start), f64(goal), f64(robot)
-    ws = torch.zeros((n, abi.MAX_WAYPOINTS, 2), dtype=torch.float64, device=dev)
+    ws = torch.zeros((n, cfg.max_waypoints, 2), dtype=torch.float64, device=dev)
     code = torch.full((n,), -1, dtype=torch.int32, device=dev)
     L = load()
     L.navsim_debug_spawn_decisions.argtypes = [C.POINTER(abi.NavsimConfig), C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
@@ -348,6 +348,9 @@ class NavSim(object):
                 raise ValueError("%s: shape %s, expected %s" % (name, tuple(t.shape), want))
             self.t[name] = t
             setattr(self.st, name, t.data_ptr())
+        if "counters" not in self.t:                            # what the library's caps left unserved (include/navsim.h)
+            self.t["counters"] = torch.zeros(abi.N_COUNTERS, dtype=torch.int64, device=self.device)
+            self.st.counters = self.t["counters"].data_ptr()
         if "beam_table" not in self.t:                          # accelerator table, built on device
             tab = torch.empty((self.cfg.n_beams, 2), dtype=torch.float64, device=self.device)
             check(self.lib.navsim_beam_table(C.byref(self.cfg), _ptr(tab), _stream()), "navsim_beam_table")
@@ -424,7 +427,7 @@ class NavSim(object):
     # arrays navsim_regen writes: the staged state of enable_pregen() owns a copy of each
     STAGED = ("field", "field_overflow", "rect_table", "costmap", "scan_noise_std", "robot_pose", "robot_goal", "prev_action",
               "prev_pose", "n_hist", "steps", "episode", "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist",
-              "ped_v_pref", "ped_has_legs", "ped_waypoints", "ped_n_waypoints", "spawn_pose", "spawn_goal")
+              "ped_v_pref", "ped_has_legs", "ped_waypoints", "ped_n_waypoints", "ped_goal", "spawn_pose", "spawn_goal")
 
     def enable_pregen(self, scratch_bytes=4 << 30):
         """navsim_regen off the step's critical path (include/navsim.h navsim_regen_swap): the world every arena will
@@ -444,6 +447,7 @@ class NavSim(object):
             setattr(self.stage_st, k, v.data_ptr())
         self.stage_st.arena_cost = None
         self.stage_st.launch_order = None
+        self.stage_st.counters = None          # staging ahead serves nobody yet: navsim_regen_swap counts the installs
         self.stage_obs = torch.zeros_like(self.obs_buf[0])
         self.want = torch.ones(E, dtype=torch.uint8, device=self.device)
         self.mark = torch.zeros(E, dtype=torch.uint8, device=self.device)
@@ -540,6 +544,14 @@ class NavSim(object):
                   "navsim_regen (reset of all arenas)")
         torch.cuda.current_stream().synchronize()          # `ws` and `done` are released on return
         return self.obs
+
+    def counters(self, reset=False):
+        """navsim_state.counters as a dict (abi.COUNTERS): arenas / pedestrians the calls served and what their caps
+        (cfg.regen_cap, replan's max_queries, cfg.max_waypoints) left waiting or cut.  One device -> host copy."""
+        v = self.t["counters"].cpu().numpy()
+        if reset:
+            self.t["counters"].zero_()
+        return {k: int(v[i]) for i, k in enumerate(abi.COUNTERS)}
 
     def occupancy(self, e=0):
         """uint8 [H, W] occupancy grid (1 = occupied) of arena e, read back from its distance field

@@ -185,7 +185,7 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
     if "costmap" in a:              # env.py:756-762: keep pairs joined by a path <= 2x the straight line
         mi = torch.arange(E, device=dev, dtype=torch.int32).repeat_interleave(K)
         s_, g_ = xy[:, :K].reshape(-1, 2), goal[:, :K].reshape(-1, 2)
-        _, pn, _, plen = sim.plan(a["costmap"], s_, g_, 5.0, max_wp=abi.MAX_WAYPOINTS, res_c=res * 5, origin=org,
+        _, pn, _, plen = sim.plan(a["costmap"], s_, g_, 5.0, max_wp=cfg.max_waypoints, res_c=res * 5, origin=org,
                                   map_index=mi)
         valid = ((pn > 0) & (plen <= 2.0 * (g_ - s_).norm(dim=1))).reshape(E, K)
         # an invalid slot borrows the next valid one in cyclic order (none valid: left as drawn)
@@ -233,18 +233,20 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
         a["ped_dist"] = torch.zeros((E, N, 3), dtype=torch.float64, device=dev)
         a["ped_v_pref"] = v_pref_range[0] + (v_pref_range[1] - v_pref_range[0]) * _uniform(seed, genv, 23, (N,), dev)
         a["ped_has_legs"] = (_uniform(seed, genv, 24, (N,), dev) < has_legs_ratio).to(torch.uint8)
-        wp = torch.zeros((E, N, abi.MAX_WAYPOINTS, 2), dtype=torch.float64, device=dev)
+        P = cfg.max_waypoints
+        wp = torch.zeros((E, N, P, 2), dtype=torch.float64, device=dev)
         wp[:, :, 0] = pgoal
         nwp = torch.ones((E, N), dtype=torch.int32, device=dev)
         if "costmap" in a:                                                  # env.py:788-804
             mi = torch.arange(E, device=dev, dtype=torch.int32).repeat_interleave(N)
             pw, pn, _, _ = sim.plan(a["costmap"], start.reshape(-1, 2), pgoal.reshape(-1, 2), 2.0,
-                                    max_wp=abi.MAX_WAYPOINTS, res_c=res * 5, origin=org, map_index=mi)
+                                    max_wp=P, res_c=res * 5, origin=org, map_index=mi)
             found = (pn > 0).reshape(E, N)
-            wp = torch.where(found[..., None, None], pw.reshape(E, N, abi.MAX_WAYPOINTS, 2), wp)
+            wp = torch.where(found[..., None, None], pw.reshape(E, N, P, 2), wp)
             nwp = torch.where(found, pn.reshape(E, N), nwp)
         a["ped_waypoints"] = wp.contiguous()
         a["ped_n_waypoints"] = nwp.contiguous()
+        a["ped_goal"] = pgoal.contiguous()          # a route stored cut is continued to this goal (navsim_replan)
         a["ped_cmd"] = torch.zeros((E, N, 2), dtype=torch.float64, device=dev)
     return a
 
@@ -288,8 +290,9 @@ def empty_world(cfg, device="cuda:0", plan_paths=False, rect_table=False):
         a["ped_dist"] = z((E, N, 3), torch.float64)
         a["ped_v_pref"] = z((E, N), torch.float64)
         a["ped_has_legs"] = z((E, N), torch.uint8)
-        a["ped_waypoints"] = z((E, N, abi.MAX_WAYPOINTS, 2), torch.float64)
+        a["ped_waypoints"] = z((E, N, cfg.max_waypoints, 2), torch.float64)
         a["ped_n_waypoints"] = torch.ones((E, N), dtype=torch.int32, device=dev)
+        a["ped_goal"] = z((E, N, 2), torch.float64)
         a["ped_cmd"] = z((E, N, 2), torch.float64)
     return a
 

@@ -20,6 +20,9 @@ int navsim_costmap_cpu(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W,
 int navsim_plan_cpu(const uint8_t* cost, const int32_t* map_index, int32_t n_maps, int32_t Hc, int32_t Wc,
                     double res_c, double ox, double oy, const double* start, const double* goal, double interval,
                     int32_t max_wp, double* wp, int32_t* n_wp, int32_t* path_cells, double* path_len);
+static int plan_cpu(const uint8_t* cost, const int32_t* map_index, int32_t n_maps, int32_t Hc, int32_t Wc,
+                    double res_c, double ox, double oy, const double* start, const double* goal, double interval,
+                    int32_t max_wp, double* wp, int32_t* n_wp, int32_t* path_cells, double* path_len, int32_t* n_total);
 
 int64_t navsim_probe_count_cpu(int32_t reset) {
     int64_t v = g_probe_count;
@@ -100,6 +103,14 @@ int navsim_default_config_cpu(navsim_config* c) {
     c->num_humans_lo = 0; c->num_humans_hi = 0;
     c->scan_noise_std_lo = 0.0; c->scan_noise_std_hi = -1.0;
     c->regen_check_discomfort = 1;          /* env.py:776-781 */
+    c->march_rule = NAVSIM_MARCH_F32;       /* RangeLib.h: `float step_coeff = 0.999;` (include/navsim.h NAVSIM_MARCH_*) */
+    c->max_waypoints = 64;                  /* include/navsim.h */
+    c->action_kind = NAVSIM_ACTION_TWIST;   /* env.py:591 */
+    c->clamp_action = 0;                    /* env.py:611-613: never clipped */
+    c->wheel_radius = 0.1651;               /* third_party/husky_description/urdf/husky.urdf.xacro:67 */
+    c->wheel_track = 0.5708;                /* husky.urdf.xacro:62 */
+    c->linvel_lo = 0.0; c->linvel_hi = 0.5;         /* __init__.py:12 */
+    c->rotvel_lo = -0.64; c->rotvel_hi = 0.64;      /* __init__.py:13 */
     c->seed = 1234;
     return NAVSIM_OK;
 }
@@ -180,11 +191,16 @@ int navsim_build_dt_cpu(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W
  *         if d <= 0: return sqrtf((px-x)^2 + (py-y)^2)
  *         t += max(d * step_coeff, 1.0)
  *     return max_range
- * The rounding of `d * step_coeff` is the one thing recall cannot settle: with a double literal 0.999 the
- * product is fl32(fl64(d) * 0.999) (NAVSIM_MARCH_F64, the default here); if upstream keeps `step_coeff` as a
- * float member it is the float32 product d * 0.999f (NAVSIM_MARCH_F32).  Both are implemented, selected by
- * navsim_config.march_rule (`march_rule` argument of the mirror primitive); tests/test_oracle_crosscheck.py
- * counts how many rays change their hit cell between them and DESIGN.md records the number.
+ * Two roundings recall cannot settle, hence a switch (navsim_config.march_rule, include/navsim.h NAVSIM_MARCH_*; the
+ * `march_rule` argument of the mirror primitive):
+ *   `d * step_coeff` -- the published class keeps `float step_coeff = 0.999;` as a data member, so the product is the
+ *   float32 d * 0.999f (NAVSIM_MARCH_F32, the default since round 4); were it a double literal the product would be
+ *   fl32(fl64(d) * 0.999) (NAVSIM_MARCH_F64, the default of rounds 1-3);
+ *   `x + dx*t` -- two float32 roundings as written, ONE when the compiler contracts it into an FMA, which GCC does for
+ *   upstream's build flags (-O3 -march=native -ffast-math) on every x86 with FMA: NAVSIM_MARCH_F32_FMA = the float
+ *   coefficient with px = (int)fmaf(dx, t, x).
+ * tests/test_oracle_crosscheck.py counts how many rays change their hit cell between the rules and DESIGN.md records
+ * the numbers.
  * Assumptions stated: no ROS world<->grid conversion (numpy-constructed map), grid[x][y] is
  * occupancy[y][x]; cosf/sinf are replaced by the specified nvr_cos/nvr_sin evaluated in double on
  * the float32 heading and rounded once to float32.
@@ -192,9 +208,10 @@ int navsim_build_dt_cpu(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W
 static float trace_ray_counted(const float* f, int H, int W, float x0, float y0, float dx, float dy,
                                float max_range, int march_rule, int* n_probes) {
     float t = 0.0f;
+    const int fma_pos = march_rule == NAVSIM_MARCH_F32_FMA;
     while (t < max_range) {
-        float fx = x0 + dx * t;
-        float fy = y0 + dy * t;
+        float fx = fma_pos ? fmaf(dx, t, x0) : x0 + dx * t;
+        float fy = fma_pos ? fmaf(dy, t, y0) : y0 + dy * t;
         int px = (int)fx;
         int py = (int)fy;
         if (px >= W || px < 0 || py < 0 || py >= H) return max_range;
@@ -206,7 +223,7 @@ static float trace_ray_counted(const float* f, int H, int W, float x0, float y0,
             float yd = (float)py - y0;
             return sqrtf(xd * xd + yd * yd);
         }
-        float step = (march_rule == NAVSIM_MARCH_F32) ? d * 0.999f : (float)((double)d * 0.999);
+        float step = (march_rule != NAVSIM_MARCH_F64) ? d * 0.999f : (float)((double)d * 0.999);
         t += (step > 1.0f) ? step : 1.0f;
     }
     return max_range;
@@ -229,7 +246,7 @@ static inline void beam_dir(float heading, float* dx, float* dy) {
 int navsim_cast_static_cpu(const float* field, int32_t E, int32_t H, int32_t W,
                            const float* q, int32_t n, float max_range, int32_t march_rule, float* out) {
     if (!field || !q || !out || E < 0 || n < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
-    if (march_rule != NAVSIM_MARCH_F64 && march_rule != NAVSIM_MARCH_F32) return NAVSIM_E_ARG;
+    if (march_rule < NAVSIM_MARCH_F64 || march_rule > NAVSIM_MARCH_F32_FMA) return NAVSIM_E_ARG;
     for (int e = 0; e < E; ++e) {
         const float* f = field + (size_t)e * H * W;
         for (int k = 0; k < n; ++k) {
@@ -748,7 +765,7 @@ int navsim_reward_done_cpu(const navsim_config* c, const void* obs, const void* 
  * ======================================================================================= */
 static void sfm_update(const navsim_config* c, const navsim_state* st, int e, int n,
                        const double* robot_pose, const double* robot_prev_action) {
-    const int N = c->max_peds, H = c->map_h, W = c->map_w, P = NAVSIM_MAX_WAYPOINTS;
+    const int N = c->max_peds, H = c->map_h, W = c->map_w, P = c->max_waypoints;
     const float* f = (const float*)st->field + (size_t)(c->shared_field ? 0 : e) * H * W;
     double ax[NAVSIM_MAX_PEDS + 1], ay[NAVSIM_MAX_PEDS + 1];      /* agent positions (peds + robot) */
     double avx[NAVSIM_MAX_PEDS + 1], avy[NAVSIM_MAX_PEDS + 1];
@@ -865,11 +882,20 @@ static void pack_obs(const navsim_config* c, const float* scan, const float* obs
 static void step_env(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int e,
                      float* scan) {
     const int B = c->n_beams, S = c->n_scan_stack, N = c->max_peds, D = S * B + 7;
-    const int P = NAVSIM_MAX_WAYPOINTS;
+    const int P = c->max_waypoints;
     const double dt = c->time_step;
     const uint64_t genv = (uint64_t)(c->env_index_base + e);
     double a0 = io->action[2 * e], a1 = io->action[2 * e + 1];
     st->steps[e] += 1;                                                         /* env.py:592 */
+    if (c->action_kind == NAVSIM_ACTION_WHEELS) {      /* BUILD-DEFINED: skid-steer wheel speeds (left, right) -> twist */
+        const double wl = a0, wr = a1;
+        a0 = c->wheel_radius * (wl + wr) * 0.5;
+        a1 = c->wheel_radius * (wr - wl) / c->wheel_track;
+    }
+    if (c->clamp_action) {                             /* build option; the reference never clips (env.py:611-613) */
+        a0 = a0 < c->linvel_lo ? c->linvel_lo : (a0 > c->linvel_hi ? c->linvel_hi : a0);
+        a1 = a1 < c->rotvel_lo ? c->rotvel_lo : (a1 > c->rotvel_hi ? c->rotvel_hi : a1);
+    }
     if (c->min_turning_radius > 0.0) {                                         /* env.py:595-600 */
         double lim = fabs(a1) * c->min_turning_radius;
         if (a0 >= 0.0) a0 = (a0 > lim) ? a0 : lim;
@@ -924,6 +950,7 @@ static void step_env(const navsim_config* c, const navsim_state* st, const navsi
                 double gx = cand[0] - pp[0], gy = cand[1] - pp[1];
                 if (sqrt(gx * gx + gy * gy) > 10.0) {
                     wp[0] = cand[0]; wp[1] = cand[1]; *nw = 1;
+                    if (st->ped_goal) { st->ped_goal[((size_t)e * N + i) * 2] = cand[0]; st->ped_goal[((size_t)e * N + i) * 2 + 1] = cand[1]; }
                     break;
                 }
             }
@@ -988,6 +1015,9 @@ int navsim_step_range_cpu(const navsim_config* c, const navsim_state* st, const 
         !io->is_crash || !io->distance) return NAVSIM_E_ARG;
     if (c->max_peds > NAVSIM_MAX_PEDS || c->n_scan_stack < 1) return NAVSIM_E_UNSUPPORTED;
     if (c->field_format != NAVSIM_FIELD_F32) return NAVSIM_E_UNSUPPORTED;   /* oracle reads float32 only */
+    if (c->ped_model != NAVSIM_PED_NONE && (c->max_waypoints < 1 || c->max_waypoints > NAVSIM_MAX_WAYPOINTS)) return NAVSIM_E_ARG;
+    if (c->march_rule < NAVSIM_MARCH_F64 || c->march_rule > NAVSIM_MARCH_F32_FMA) return NAVSIM_E_ARG;
+    if (c->action_kind != NAVSIM_ACTION_TWIST && c->action_kind != NAVSIM_ACTION_WHEELS) return NAVSIM_E_ARG;
     float* scan = (float*)malloc(sizeof(float) * (size_t)c->n_beams);
     for (int e = e0; e < e1; ++e) step_env(c, st, io, e, scan);
     free(scan);
@@ -1214,7 +1244,7 @@ static void rgp_cell(const navsim_config* c, const uint8_t* cost, int Wc, int li
 
 static void regen_planned(const navsim_config* c, const navsim_state* st, int e, uint64_t genv, uint64_t ep,
                           const uint8_t* occ, int size) {
-    const int N = c->max_peds, K = c->n_spawn, H = c->map_h, W = c->map_w, P = NAVSIM_MAX_WAYPOINTS;
+    const int N = c->max_peds, K = c->n_spawn, H = c->map_h, W = c->map_w, P = c->max_waypoints;
     const int Hc = H / 5, Wc = W / 5;
     const double res_c = c->resolution * 5.0;
     const int live_c = size / 5;                /* candidates are cells of the live map's costmap */
@@ -1270,7 +1300,10 @@ static void regen_planned(const navsim_config* c, const navsim_state* st, int e,
             rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, &nn, 1, rp[0], rp[1], c->ped_min_robot_dist, 0, &s[0], &s[1]);
             rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, &nn, 2, s[0], s[1], c->ped_min_goal_dist, 1.0e300, &g[0], &g[1]);
             st->ped_pose[q * 3] = s[0]; st->ped_pose[q * 3 + 1] = s[1];
-            navsim_plan_cpu(cost, NULL, 1, Hc, Wc, res_c, c->origin_x, c->origin_y, s, g, 2.0, P, w, &nwp, NULL, NULL);
+            int32_t total = 0;
+            if (st->ped_goal) { st->ped_goal[q * 2] = g[0]; st->ped_goal[q * 2 + 1] = g[1]; }
+            plan_cpu(cost, NULL, 1, Hc, Wc, res_c, c->origin_x, c->origin_y, s, g, 2.0, P, w, &nwp, NULL, NULL, &total);
+            if (total > P && st->counters) st->counters[NAVSIM_COUNTER_ROUTES_CUT] += 1;
             if (nwp > 0) { st->ped_n_waypoints[q] = nwp; done = 1; }
             else { w[0] = g[0]; w[1] = g[1]; st->ped_n_waypoints[q] = 1; }
         }
@@ -1354,7 +1387,7 @@ int navsim_ped_policy_cpu(const navsim_config* c, const navsim_state* st, const 
         !st->ped_n_waypoints || !st->ped_v_pref || !st->n_peds)
         return NAVSIM_E_ARG;
     if (c->ped_n_beams != 512) return NAVSIM_E_UNSUPPORTED;
-    const int N = c->max_peds, P = NAVSIM_MAX_WAYPOINTS;
+    const int N = c->max_peds, P = c->max_waypoints;
     for (int e = 0; e < c->n_envs; ++e) {
         int n = st->n_peds[e] > N ? N : st->n_peds[e];
         for (int i = 0; i < N; ++i) {
@@ -1400,7 +1433,8 @@ int navsim_replan_cpu(const navsim_config* c, const navsim_state* st, int32_t ma
         max_queries < 0)
         return NAVSIM_E_ARG;
     if (c->ped_model == NAVSIM_PED_NONE) return NAVSIM_OK;
-    const int N = c->max_peds, P = NAVSIM_MAX_WAYPOINTS, Hc = c->map_h / 5, Wc = c->map_w / 5;
+    if (c->max_waypoints < 1 || c->max_waypoints > NAVSIM_MAX_WAYPOINTS) return NAVSIM_E_ARG;
+    const int N = c->max_peds, P = c->max_waypoints, Hc = c->map_h / 5, Wc = c->map_w / 5;
     const double res_c = c->resolution * 5.0;
     int served = 0;
     for (int e = 0; e < c->n_envs; ++e) {
@@ -1415,16 +1449,31 @@ int navsim_replan_cpu(const navsim_config* c, const navsim_state* st, int32_t ma
             int nw = st->ped_n_waypoints[q];
             double ddx = pp[0] - w[2 * (nw - 1)], ddy = pp[1] - w[2 * (nw - 1) + 1];
             if (!(sqrt(ddx * ddx + ddy * ddy) < 0.5)) continue;
-            if (served++ >= max_queries) return NAVSIM_OK;
-            for (int round = 0; round < 4; ++round) {
-                uint64_t key = nvr_hash4(c->seed, genv, when, 0x52504E00ULL + (uint64_t)round * 256 + (uint64_t)i), m = 0;
+            if (served >= max_queries) {                /* beyond the cap: waits for a later call, and is counted */
+                if (st->counters) st->counters[NAVSIM_COUNTER_REPLAN_UNSERVED] += 1;
+                continue;
+            }
+            ++served;
+            if (st->counters) st->counters[NAVSIM_COUNTER_REPLAN_SERVED] += 1;
+            /* the end of a route that was stored CUT (its last stored waypoint is not its goal): walk on to the goal it
+             * had (round -1, no draw); only if no path joins them draw a new goal like the others */
+            double* pg = st->ped_goal ? st->ped_goal + q * 2 : NULL;
+            const int cut = pg && (w[2 * (nw - 1)] != pg[0] || w[2 * (nw - 1) + 1] != pg[1]);
+            for (int round = cut ? -1 : 0; round < 4; ++round) {
                 double g[2], wp[2 * NAVSIM_MAX_WAYPOINTS];
-                int32_t nwp;
-                rgp_cell(c, cost, Wc, Wc, Hc, res_c, key, &m, 2, pp[0], pp[1], c->ped_min_goal_dist, 1.0e300, &g[0], &g[1]);
-                navsim_plan_cpu(cost, NULL, 1, Hc, Wc, res_c, c->origin_x, c->origin_y, pp, g, 2.0, P, wp, &nwp, NULL, NULL);
+                int32_t nwp, total = 0;
+                if (round < 0) { g[0] = pg[0]; g[1] = pg[1]; }
+                else {
+                    uint64_t key = nvr_hash4(c->seed, genv, when, 0x52504E00ULL + (uint64_t)round * 256 + (uint64_t)i), m = 0;
+                    rgp_cell(c, cost, Wc, Wc, Hc, res_c, key, &m, 2, pp[0], pp[1], c->ped_min_goal_dist, 1.0e300, &g[0], &g[1]);
+                }
+                plan_cpu(cost, NULL, 1, Hc, Wc, res_c, c->origin_x, c->origin_y, pp, g, 2.0, P, wp, &nwp, NULL, NULL, &total);
+                if (total > P && st->counters) st->counters[NAVSIM_COUNTER_ROUTES_CUT] += 1;
                 if (nwp > 0) {
                     memcpy(w, wp, sizeof(double) * 2 * (size_t)nwp);
                     st->ped_n_waypoints[q] = nwp;
+                    if (pg) { pg[0] = g[0]; pg[1] = g[1]; }
+                    if (round < 0 && st->counters) st->counters[NAVSIM_COUNTER_ROUTES_RESUMED] += 1;
                     break;
                 }
             }
@@ -1437,10 +1486,18 @@ int navsim_regen_cpu(const navsim_config* c, const navsim_state* st, const navsi
     if (!c || !st || !io || !io->done || !io->obs) return NAVSIM_E_ARG;
     if (c->field_format != NAVSIM_FIELD_F32 || c->map_h != c->map_w || c->n_spawn < 1) return NAVSIM_E_UNSUPPORTED;
     const int E = c->n_envs, N = c->max_peds, K = c->n_spawn, H = c->map_h, W = c->map_w;
-    const int P = NAVSIM_MAX_WAYPOINTS;
+    const int P = c->max_waypoints;
+    if (c->ped_model != NAVSIM_PED_NONE && (P < 1 || P > NAVSIM_MAX_WAYPOINTS)) return NAVSIM_E_ARG;
     uint8_t* mask = (uint8_t*)calloc((size_t)E, 1);
     uint8_t* occ = (uint8_t*)malloc((size_t)H * W);
     int taken = 0;
+    if (st->counters) {                          /* what this call serves, and what its cap leaves waiting */
+        int all = 0;
+        for (int e = 0; e < E; ++e) all += io->done[e] != 0;
+        const int served = all < c->regen_cap ? all : c->regen_cap;
+        st->counters[NAVSIM_COUNTER_REGEN_SERVED] += (unsigned long long)served;
+        st->counters[NAVSIM_COUNTER_REGEN_UNSERVED] += (unsigned long long)(all - served);
+    }
     for (int e = 0; e < E && taken < c->regen_cap; ++e) {
         if (!io->done[e]) continue;
         ++taken;
@@ -1507,6 +1564,7 @@ int navsim_regen_cpu(const navsim_config* c, const navsim_state* st, const navsi
             double* wp = st->ped_waypoints + (q * P) * 2;
             wp[0] = gx; wp[1] = gy;
             st->ped_n_waypoints[q] = 1;
+            if (st->ped_goal) { st->ped_goal[q * 2] = gx; st->ped_goal[q * 2 + 1] = gy; }
         }
     }
     /* first observation of the new episodes (env.py:808-831); other arenas keep the row the step wrote */
@@ -1558,10 +1616,14 @@ int navsim_costmap_cpu(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W,
     return NAVSIM_OK;
 }
 
-/* env.py:1261-1277 on a path of n points (x, y); returns the number of waypoints written (<= max_wp;
- * the scan continues past max_wp so that the count is exact, later ones are dropped) */
-static int path_to_waypoints(const double* path, int n, double interval, double* wp, int max_wp) {
+/* env.py:1261-1277 on a path of n points (x, y); returns the number of waypoints of the path.  The first max_wp of them
+ * are written (the reference keeps all of them: max_wp is this build's cfg.max_waypoints); the scan continues past
+ * max_wp so that the count is exact.  `start` / `len` (optional): path_distance of env.py:757-759, |start - wp0| +
+ * sum |wp_k+1 - wp_k| over EVERY waypoint, stored or not. */
+static int path_to_waypoints(const double* path, int n, double interval, double* wp, int max_wp,
+                             const double* start, double* len) {
     int first = 0, count = 0;
+    double L = 0.0, lx = start ? start[0] : 0.0, ly = start ? start[1] : 0.0;
     for (;;) {
         int found = -1;
         for (int k = first; k < n; ++k) {
@@ -1571,15 +1633,21 @@ static int path_to_waypoints(const double* path, int n, double interval, double*
         int pick = (found >= 0) ? found : n - 1;
         if (count < max_wp) { wp[2 * count] = path[2 * pick]; wp[2 * count + 1] = path[2 * pick + 1]; }
         ++count;
+        {
+            const double ax = path[2 * pick] - lx, ay = path[2 * pick + 1] - ly;
+            L += sqrt(ax * ax + ay * ay);
+            lx = path[2 * pick]; ly = path[2 * pick + 1];
+        }
         if (found < 0) break;
         first = found;
     }
+    if (len) *len = L;
     return count;
 }
 
 int navsim_path_to_waypoints_cpu(const double* path, int32_t n, double interval, double* wp, int32_t max_wp) {
     if (!path || !wp || n < 1) return NAVSIM_E_ARG;
-    return path_to_waypoints(path, n, interval, wp, max_wp);
+    return path_to_waypoints(path, n, interval, wp, max_wp, NULL, NULL);
 }
 
 /* n queries: query m plans on costmap map_index[m] (or m when map_index is NULL); cost [*,Hc,Wc]
@@ -1588,6 +1656,13 @@ int navsim_path_to_waypoints_cpu(const double* path, int32_t n, double interval,
 int navsim_plan_cpu(const uint8_t* cost, const int32_t* map_index, int32_t n_maps, int32_t Hc, int32_t Wc,
                     double res_c, double ox, double oy, const double* start, const double* goal, double interval,
                     int32_t max_wp, double* wp, int32_t* n_wp, int32_t* path_cells, double* path_len) {
+    return plan_cpu(cost, map_index, n_maps, Hc, Wc, res_c, ox, oy, start, goal, interval, max_wp, wp, n_wp, path_cells,
+                    path_len, NULL);
+}
+/* n_total [n] (optional): waypoints of the whole path, of which min(n_total, max_wp) were stored */
+static int plan_cpu(const uint8_t* cost, const int32_t* map_index, int32_t n_maps, int32_t Hc, int32_t Wc,
+                    double res_c, double ox, double oy, const double* start, const double* goal, double interval,
+                    int32_t max_wp, double* wp, int32_t* n_wp, int32_t* path_cells, double* path_len, int32_t* n_total) {
     if (!cost || !start || !goal || !wp || !n_wp) return NAVSIM_E_ARG;
     navsim_config cc;
     memset(&cc, 0, sizeof(cc));
@@ -1602,6 +1677,7 @@ int navsim_plan_cpu(const uint8_t* cost, const int32_t* map_index, int32_t n_map
         xy_to_ij(start[2 * m], start[2 * m + 1], &cc, &si, &sj);           /* env.py:348-349 */
         xy_to_ij(goal[2 * m], goal[2 * m + 1], &cc, &gi, &gj);
         n_wp[m] = 0;
+        if (n_total) n_total[m] = 0;
         if (path_cells) path_cells[m] = 0;
         if (path_len) path_len[m] = 0.0;
         if (si >= Wc || sj >= Hc || gi >= Wc || gj >= Hc) continue;
@@ -1636,18 +1712,12 @@ int navsim_plan_cpu(const uint8_t* cost, const int32_t* map_index, int32_t n_map
             }
         }
         double* w = wp + (size_t)m * max_wp * 2;
-        int cnt = path_to_waypoints(path, n, interval, w, max_wp);
+        double L = 0.0;
+        int cnt = path_to_waypoints(path, n, interval, w, max_wp, start + 2 * m, &L);
         n_wp[m] = cnt < max_wp ? cnt : max_wp;
+        if (n_total) n_total[m] = cnt;
         if (path_cells) path_cells[m] = n;
-        if (path_len) {
-            double sx = start[2 * m] - w[0], sy = start[2 * m + 1] - w[1];
-            double L = sqrt(sx * sx + sy * sy);
-            for (int k = 0; k + 1 < n_wp[m]; ++k) {
-                double ax = w[2 * k + 2] - w[2 * k], ay = w[2 * k + 3] - w[2 * k + 1];
-                L += sqrt(ax * ax + ay * ay);
-            }
-            path_len[m] = L;
-        }
+        if (path_len) path_len[m] = L;
     }
     free(dist); free(queue); free(path);
     return NAVSIM_OK;
@@ -1675,7 +1745,7 @@ int navsim_spawn_decisions_cpu(const navsim_config* c, const uint8_t* cost, int3
                         ped ? 1.0e300 : c->max_goal_dist)) { code[m] = 2; continue; }
         int32_t nwp = 0; double plen = 0.0;
         navsim_plan_cpu(cost, NULL, 1, Hc, Wc, res_c, c->origin_x, c->origin_y, s, g, ped ? 2.0 : 5.0,
-                        NAVSIM_MAX_WAYPOINTS, wp, &nwp, NULL, &plen);
+                        c->max_waypoints, wp, &nwp, NULL, &plen);
         if (nwp <= 0) { code[m] = 3; continue; }
         if (!ped && !rg_robot_path_ok(plen, s[0], s[1], g[0], g[1])) code[m] = 4;
     }

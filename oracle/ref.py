@@ -82,7 +82,7 @@ def build_dt(occ):
     return out
 
 
-def cast_static(field, queries, max_range, march_rule=0):
+def cast_static(field, queries, max_range, march_rule=abi.MARCH_F32):
     field = np.ascontiguousarray(field, dtype=np.float32)
     q = np.ascontiguousarray(queries, dtype=np.float32)
     E, H, W = field.shape
@@ -360,6 +360,9 @@ class RefSim(object):
                 raise ValueError("%s: shape %s, expected %s" % (name, arr.shape, want))
             self.a[name] = arr
             setattr(self.st, name, arr.ctypes.data)
+        if "counters" not in self.a:                # like NavSim: what the caps left unserved (include/navsim.h)
+            self.a["counters"] = np.zeros(abi.N_COUNTERS, np.int64)
+            self.st.counters = self.a["counters"].ctypes.data
         E = self.cfg.n_envs
         D = self.cfg.n_scan_stack * self.cfg.n_beams + abi.OBS_TAIL
         self.obs = [np.zeros((E, D), np.float32), np.zeros((E, D), np.float32)]
@@ -406,6 +409,9 @@ class RefSim(object):
 
     def replan(self, max_queries=1024):
         _chk(lib().navsim_replan_cpu(C.byref(self.cfg), C.byref(self.st), max_queries), "replan")
+
+    def counters(self):
+        return {k: int(self.a["counters"][i]) for i, k in enumerate(abi.COUNTERS)}
 
     def ped_scans(self):
         out = np.zeros((self.cfg.n_envs, self.cfg.max_peds, self.cfg.ped_n_beams), np.float32)

@@ -349,10 +349,11 @@ def make_units(ref_env, human, keti_robot, ref_utils):
 # --------------------------------------------------------------------------------------------
 # step() traces
 # --------------------------------------------------------------------------------------------
-def make_env(ref_env, human_policy, S, seed):
+def make_env(ref_env, human_policy, S, seed, indoor=False):
     kw = dict(sys.modules["gym"].registry["NavGym-v0"]["kwargs"])
     kw["num_scan_stack"] = S
-    kw["indoor_ratio"] = 0.0                      # outdoor 400x400 maps keep the fixture small
+    kw["indoor_ratio"] = 1.0 if indoor else 0.0   # outdoor 400x400 maps keep the fixture small; indoor = the reference's
+                                                  # 1000 x 1000 corridor map (create_indoor_map), for the long routes
     epr = dict(kw["env_param_range"])
     epr["scan_noise_std"] = ([0., 0.], "float")   # parity is defined without noise
     epr["num_humans"] = ([5, 7], "int")
@@ -400,7 +401,13 @@ def snapshot(env):
 
 
 def run_trace(name, ref_env, human, human_policy, S, seed, scenario, n_steps, ped_scan_every=0):
-    env = make_env(ref_env, human_policy, S, seed)
+    env = make_env(ref_env, human_policy, S, seed, indoor=(scenario == "corridor"))
+    if scenario == "corridor":
+        # the reference's own reset() on its own 1000 x 1000 corridor map: keep the first seed whose episode holds a
+        # pedestrian route of more than 16 waypoints (> 32 m: what the 16-waypoint cut of rounds 1-3 could not hold)
+        while max(len(h.waypoints) for h in env.humans) <= 16:
+            seed += 1
+            env = make_env(ref_env, human_policy, S, seed, indoor=True)
     rng = np.random.default_rng(seed)
     B = env.robot.n_angles
     occ = (env.map_info["data"] >= 0.1)
@@ -463,7 +470,7 @@ def run_trace(name, ref_env, human, human_policy, S, seed, scenario, n_steps, pe
     ped_scan_steps, ped_scans = [], []
     try:
         for t in range(T):
-            if scenario == "random":
+            if scenario in ("random", "corridor"):
                 a = np.array([rng.uniform(0, 0.5), rng.uniform(-0.64, 0.64)])
             elif scenario == "crash":
                 a = np.array([0.5, 0.0]) if t < 8 else np.array([rng.uniform(0, 0.5), rng.uniform(-0.64, 0.64)])
@@ -493,7 +500,59 @@ def run_trace(name, ref_env, human, human_policy, S, seed, scenario, n_steps, pe
         rec["ped_scan_steps"] = np.array(ped_scan_steps)
         rec["ped_scan"] = np.stack(ped_scans)
     np.savez_compressed(os.path.join(HERE, "golden_trace_%s.npz" % name), **rec)
-    print("golden_trace_%s.npz: T=%d N=%d crashes=%d successes=%d" % (name, T, N, int(crash.sum()), int(succ.sum())))
+    print("golden_trace_%s.npz: T=%d N=%d crashes=%d successes=%d longest route %d waypoints (seed %d)"
+          % (name, T, N, int(crash.sum()), int(succ.sum()), int(rec["init_ped_n_waypoints"].max()), seed))
+    return env
+
+
+def make_long_routes(ref_env, env):
+    """golden_long_routes.npz (round 4: routes of FULL length, env.py:788-804, 1261-1277).
+    (1) the reference's own path_to_waypoints on 16 synthetic paths of 70-150 m at the costmap's 0.25 m spacing:
+        30-70 waypoints at the 2 m interval;
+    (2) the reference's own _sample_start_goal_path (env.py:342-383; pedestrian rule: goal more than 10 m away, no
+        upper bound) on the costmap of `env` -- the 1000 x 1000 corridor episode of the corridor trace -- 24 times:
+        start, goal, the path the planner stand-in returned and the reference's waypoints of it.  The path's LENGTH is
+        what any shortest-path planner must reproduce; which of the equally short paths is taken is the stand-in's."""
+    rng = np.random.default_rng(20261004)
+    out = {}
+    paths, wps, n_pts, n_wps = [], [], [], []
+    for t in range(16):
+        m = int(rng.integers(340, 720))
+        # a walk with momentum on the 4-connected 0.25 m grid: long straight runs, so that it really travels
+        dirs = np.array([[0.25, 0], [0, 0.25], [-0.25, 0], [0, -0.25]])
+        d = int(rng.integers(0, 4))
+        steps = []
+        for _ in range(m):
+            if rng.random() < 0.08:
+                d = (d + int(rng.choice([1, 3]))) % 4
+            steps.append(dirs[d])
+        path = np.cumsum(np.vstack([[rng.uniform(5, 45, 2)], np.array(steps)]), axis=0)
+        w = ref_env.path_to_waypoints(path, interval=2)
+        pad = np.full((768, 2), np.nan); pad[: len(path)] = path
+        wpad = np.full((128, 2), np.nan); wpad[: len(w)] = w
+        paths.append(pad); wps.append(wpad); n_pts.append(len(path)); n_wps.append(len(w))
+    out.update(wp_paths=np.stack(paths), wp_out=np.stack(wps), wp_n_points=np.array(n_pts), wp_n=np.array(n_wps))
+    cm = env.cost_map_info
+    cost = (np.asarray(cm["data"]) > 0).astype(np.uint8)
+    out["cost_packed"] = np.packbits(cost); out["cost_shape"] = np.array(cost.shape)
+    out["cost_resolution"] = np.array(cm["resolution"])
+    starts, goals, lens, cells, rwps, rn, rpaths = [], [], [], [], [], [], []
+    np.random.seed(77)
+    while len(starts) < 24:
+        start, goal, path = env._sample_start_goal_path(cm, 10, np.inf)
+        w = ref_env.path_to_waypoints(path, interval=2)
+        if len(starts) < 12 and len(w) <= 16:          # half of them longer than the old cut
+            continue
+        starts.append(start); goals.append(goal); cells.append(len(path))
+        wpad = np.full((128, 2), np.nan); wpad[: len(w)] = w
+        rwps.append(wpad); rn.append(len(w))
+        ppad = np.full((768, 2), np.nan); ppad[: len(path)] = path
+        rpaths.append(ppad)
+    out.update(route_start=np.array(starts), route_goal=np.array(goals), route_cells=np.array(cells),
+               route_wp=np.stack(rwps), route_n_wp=np.array(rn), route_path=np.stack(rpaths))
+    np.savez_compressed(os.path.join(HERE, "golden_long_routes.npz"), **out)
+    print("golden_long_routes.npz: synthetic paths %d-%d waypoints; reference routes %d-%d waypoints"
+          % (min(n_wps), max(n_wps), min(rn), max(rn)))
 
 
 
@@ -730,11 +789,16 @@ def main():
     ref_env, human, keti_robot, ref_utils, human_policy = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "reset":            # only golden_reset.npz
         return make_reset(ref_env)
+    if len(sys.argv) > 1 and sys.argv[1] == "routes":           # only the round-4 fixtures (the others stay byte-identical)
+        env = run_trace("corridor_S1", ref_env, human, human_policy, S=1, seed=21, scenario="corridor", n_steps=100, ped_scan_every=20)
+        return make_long_routes(ref_env, env)
     make_units(ref_env, human, keti_robot, ref_utils)
     run_trace("random_S1", ref_env, human, human_policy, S=1, seed=11, scenario="random", n_steps=40, ped_scan_every=5)
     run_trace("peds_S1", ref_env, human, human_policy, S=1, seed=12, scenario="peds", n_steps=30, ped_scan_every=3)
     run_trace("crash_S3", ref_env, human, human_policy, S=3, seed=13, scenario="crash", n_steps=24)
     run_trace("success_S2", ref_env, human, human_policy, S=2, seed=14, scenario="success", n_steps=12)
+    env = run_trace("corridor_S1", ref_env, human, human_policy, S=1, seed=21, scenario="corridor", n_steps=100, ped_scan_every=20)
+    make_long_routes(ref_env, env)
     make_reset(ref_env)
     make_crowd()
     make_crowd_maps()

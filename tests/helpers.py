@@ -39,7 +39,7 @@ def trace_setup(tr, default_config, build_dt):
         ped_prev_yaw=np.zeros((1, N)), ped_dist=tr["init_ped_dist"][None].copy(),
         ped_v_pref=tr["ped_v_pref"][None].copy(),
         ped_has_legs=tr["ped_has_legs"][None].astype(np.uint8),
-        ped_waypoints=np.zeros((1, N, abi.MAX_WAYPOINTS, 2)),
+        ped_waypoints=np.zeros((1, N, cfg.max_waypoints, 2)),
         ped_n_waypoints=np.ones((1, N), np.int32),
         ped_cmd=np.zeros((1, N, 2)),
     )
@@ -80,7 +80,7 @@ def finished_world(cfg, occ, field, n_peds, thresholds):
         ped_pose=np.full((E, N, 3), 1.0e6), ped_vel=np.zeros((E, N, 2)),
         ped_prev_yaw=np.zeros((E, N)), ped_dist=np.zeros((E, N, 3)),
         ped_v_pref=np.ones((E, N)), ped_has_legs=np.ones((E, N), np.uint8),
-        ped_waypoints=np.full((E, N, abi.MAX_WAYPOINTS, 2), 1.0e6),
+        ped_waypoints=np.full((E, N, cfg.max_waypoints, 2), 1.0e6),
         ped_n_waypoints=np.ones((E, N), np.int32), ped_cmd=np.zeros((E, N, 2)),
         spawn_pose=np.tile(pose[:, None, :], (1, K, 1)), spawn_goal=np.tile(pose[:, None, :2], (1, K, 1)),
     )

@@ -145,7 +145,7 @@ def test_device_xy_to_ij_reference_goldens(gpu, golden_dir, size):
     _eq(got, ref.xy_to_ij_f32(units["xyf32_%d" % size], (0.0, 0.0), 0.05, size, size).astype(np.int32), "oracle")
 
 
-@pytest.mark.parametrize("rule", [abi.MARCH_F64, abi.MARCH_F32])
+@pytest.mark.parametrize("rule", abi.MARCH_RULES)
 @pytest.mark.parametrize("size", [100, 500])
 def test_cast_static(gpu, size, rule):
     rng = np.random.default_rng(size)
@@ -159,13 +159,13 @@ def test_cast_static(gpu, size, rule):
 
 
 def test_march_rule_switch_full_step(gpu):
-    """cfg.march_rule is the ONE switch between the two candidate roundings of range_libc's step
-    (include/navsim.h NAVSIM_MARCH_*): under NAVSIM_MARCH_F32 the fused step, the pedestrian scans and the
-    mirror primitive still equal the oracle bit for bit, and the two rules do differ on some beams (so the
+    """cfg.march_rule is the ONE switch between the candidate roundings of range_libc's march
+    (include/navsim.h NAVSIM_MARCH_*): under each of them the fused step, the pedestrian scans and the
+    mirror primitive equal the oracle bit for bit, and the rules do differ on some beams (so the
     switch is live on the device)."""
     E, size = 32, 240
     obs = {}
-    for rule in (abi.MARCH_F64, abi.MARCH_F32):
+    for rule in abi.MARCH_RULES:
         cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=6, ped_model=abi.PED_SFM, n_spawn=8,
                                      auto_reset=1, seed=99, field_format=abi.FIELD_U16T, march_rule=rule)
         gpu.world.lidar_1081(cfg)
@@ -188,7 +188,9 @@ def test_march_rule_switch_full_step(gpu):
         q = _t(gpu, d["q_%d" % m][None])
         _eq(gpu.sim.cast_static(f, q, float(H * W), abi.MARCH_F64).cpu().numpy()[0], d["r64_%d" % m], "rule F64 map %d" % m)
         _eq(gpu.sim.cast_static(f, q, float(H * W), abi.MARCH_F32).cpu().numpy()[0], d["r32_%d" % m], "rule F32 map %d" % m)
+        _eq(gpu.sim.cast_static(f, q, float(H * W), abi.MARCH_F32_FMA).cpu().numpy()[0], d["r32fma_%d" % m], "rule F32_FMA map %d" % m)
         assert not np.array_equal(d["r64_%d" % m], d["r32_%d" % m])
+        assert not np.array_equal(d["r32_%d" % m], d["r32fma_%d" % m])
 
 
 def test_render_polys_and_legs(gpu):
@@ -266,9 +268,10 @@ def test_reward_done(gpu, golden_dir, S, B, f64):
         assert np.array_equal(got["is_success"].cpu().numpy(), u[tag + "is_success"])
 
 
-@pytest.mark.parametrize("name", ["random_S1", "peds_S1", "crash_S3", "success_S2"])
+@pytest.mark.parametrize("name", ["random_S1", "peds_S1", "crash_S3", "success_S2", "corridor_S1"])
 def test_step_golden_traces(gpu, name):
-    """The fused HIP step reproduces the reference's own reset()/step() traces."""
+    """The fused HIP step reproduces the reference's own reset()/step() traces (corridor_S1: on the reference's own
+    1000 x 1000 corridor map, recorded in round 4)."""
     tr = load_trace(name)
     cfg, arrays, occ = trace_setup(tr, gpu.lib.default_config, lambda o: gpu.sim.build_dt(_t(gpu, o)).cpu().numpy())
     _eq(arrays["field"], ref.build_dt(occ[None]), "field")
@@ -428,7 +431,7 @@ def test_step_fuzzed_configurations(gpu, seed):
                                  auto_reset=int(rng.integers(0, 2)), n_spawn=int(rng.choice([1, 5])), seed=seed,
                                  field_format=fmt, min_turning_radius=float(rng.choice([0.0, 0.3])),
                                  lidar_legs=int(rng.integers(0, 2)), step_block=int(rng.choice([0, 0, 64, 256, 512, 1024])),
-                                 ped_split=int(rng.integers(0, 3)), march_rule=int(rng.integers(0, 2)))
+                                 ped_split=int(rng.integers(0, 3)), march_rule=int(rng.integers(0, 3)))
     nb = int(rng.choice([33, 64, 180, 512, 1081, 1300]))
     if nb == 1081:
         gpu.world.lidar_1081(cfg)
@@ -625,7 +628,7 @@ def test_pregenerated_worlds_equal_navsim_regen(gpu, fmt, ped_model, plan):
             for k, v in r.a.items():
                 if k in gs and k not in ("field", "field_overflow", "rect_table"):
                     if k == "ped_waypoints":      # slots beyond n_waypoints keep whatever the buffer held before
-                        live = np.arange(abi.MAX_WAYPOINTS)[None, None, :] < r.a["ped_n_waypoints"][..., None]
+                        live = np.arange(cfg.max_waypoints)[None, None, :] < r.a["ped_n_waypoints"][..., None]
                         _eq(gs[k][live], v[live], "state %s after the swap at step %d" % (k, t))
                     else:
                         _eq(gs[k], v, "state %s after the swap at step %d" % (k, t))
@@ -706,7 +709,7 @@ def test_reset_path_fuzzed(gpu, seed):
     for k, v in r.a.items():
         if k in gs and k not in ("field", "field_overflow", "rect_table"):
             if k == "ped_waypoints":
-                live = np.arange(abi.MAX_WAYPOINTS)[None, None, :] < r.a["ped_n_waypoints"][..., None]
+                live = np.arange(cfg.max_waypoints)[None, None, :] < r.a["ped_n_waypoints"][..., None]
                 _eq(gs[k][live], v[live], "state %s" % k)
             else:
                 _eq(gs[k], v, "state %s" % k)
@@ -761,13 +764,182 @@ def test_replan_vs_oracle(gpu, fmt):
         gs = g.numpy_state("ped_waypoints", "ped_n_waypoints", "costmap")
         n_now = r.a["ped_n_waypoints"].copy()
         _eq(gs["ped_n_waypoints"], n_now, "waypoint counts at step %d" % t)
-        live = np.arange(abi.MAX_WAYPOINTS)[None, None, :] < n_now[..., None]
+        live = np.arange(cfg.max_waypoints)[None, None, :] < n_now[..., None]
         _eq(gs["ped_waypoints"][live], r.a["ped_waypoints"][live], "waypoints at step %d" % t)
         if prev_n is not None:
             replans += int((n_now > prev_n).sum())
         prev_n = n_now
     _eq(gs["costmap"], r.a["costmap"], "costmap")
     assert replans >= 5, replans
+
+
+def test_long_routes_on_the_device(gpu, golden_dir):
+    """Round 4, row a16: routes of full length.  On the costmap of the reference's own 1000 x 1000 corridor episode and
+    the starts / goals its _sample_start_goal_path drew (tests/golden/golden_long_routes.npz), navsim_plan equals the
+    oracle bit for bit at the default capacity (64 waypoints: nothing is cut, routes of up to 29 waypoints) and with a
+    capacity of 8 (cut lists are prefixes of the full ones, path_distance still runs over every waypoint); the number of
+    cells of every path is the one the reference's planner stand-in found."""
+    d = np.load(os.path.join(golden_dir, "golden_long_routes.npz"))
+    shape = tuple(int(x) for x in d["cost_shape"])
+    cost = np.unpackbits(d["cost_packed"])[: shape[0] * shape[1]].reshape((1,) + shape)
+    res_c = float(d["cost_resolution"])
+    n = d["route_start"].shape[0]
+    mi = np.zeros(n, np.int32)
+    full = None
+    for cap in (gpu.lib.default_config().max_waypoints, 8):
+        gw, gn, gc, gl = gpu.sim.plan(_t(gpu, cost), _t(gpu, d["route_start"]), _t(gpu, d["route_goal"]), 2.0, max_wp=cap,
+                                      res_c=res_c, map_index=_t(gpu, mi))
+        rw, rn, rcells, rl = ref.plan(cost, d["route_start"], d["route_goal"], 2.0, max_wp=cap, res_c=res_c, map_index=mi)
+        _eq(gn.cpu().numpy(), rn, "waypoint counts (capacity %d)" % cap)
+        _eq(gc.cpu().numpy(), rcells, "path cells"); _eq(gc.cpu().numpy(), d["route_cells"].astype(np.int32), "path cells vs the reference's")
+        _eq(gl.cpu().numpy(), rl, "path_distance")
+        live = np.arange(cap)[None, :] < rn[:, None]
+        _eq(gw.cpu().numpy()[live], rw[live], "waypoints (capacity %d)" % cap)
+        if full is None:
+            full = (rw, rn, rl)
+            assert rn.max() > 16 and rn.max() < cap
+        else:
+            assert (rn == np.minimum(full[1], cap)).all() and np.array_equal(rl, full[2])
+            assert np.array_equal(rw[live], full[0][:, :cap][live])
+
+
+def _state_equal(g, r, cfg, what, skip=()):
+    gs = g.numpy_state()
+    for k, v in r.a.items():
+        if k not in gs or k in ("field", "field_overflow", "rect_table") or k in skip:
+            continue
+        if k == "ped_waypoints":                  # slots beyond n_waypoints keep whatever the buffer held before
+            live = np.arange(cfg.max_waypoints)[None, None, :] < r.a["ped_n_waypoints"][..., None]
+            _eq(gs[k][live], v[live], "state %s %s" % (k, what))
+        else:
+            _eq(gs[k], v, "state %s %s" % (k, what))
+
+
+def test_cut_routes_resume_to_their_goal(gpu):
+    """cfg.max_waypoints = 2 with goals at least 5 m away: every planned route is stored CUT (the reference keeps every
+    waypoint, env.py:788-804; the build keeps max_waypoints and counts the rest).  A pedestrian that reaches the end
+    of its cut list is planned to the SAME goal by navsim_replan (navsim_state.ped_goal), not to a new one; device ==
+    oracle bit for bit on every state array -- ped_goal and the counters included -- over the rollout."""
+    E, size, N = 12, 300, 6
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_SFM, n_spawn=6,
+                                 auto_reset=1, seed=37, field_format=abi.FIELD_U16T, ped_min_goal_dist=5.0, obstacle_number=6,
+                                 max_waypoints=2)
+    gpu.world.lidar_full_circle(cfg, 180)
+    occ = gpu.world.make_maps(E, size, 37, n_obstacles=6)
+    goal0 = None
+    kept = 0
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=5, steps=110, seed=4, plan_paths=True,
+                                                     v_pref_range=(0.55, 0.6)):
+        _eq(go, ro, "obs at step %d" % t)
+        if goal0 is None:
+            goal0 = r.a["ped_goal"].copy()
+            last = r.a["ped_waypoints"][np.arange(E)[:, None], np.arange(N)[None, :], r.a["ped_n_waypoints"] - 1]
+            cut0 = (r.a["ped_n_waypoints"][:, :5] == 2) & (last[:, :5] != goal0[:, :5]).any(axis=2)
+            assert cut0.mean() > 0.8, "nearly every route of this world must start cut"
+        before = r.counters()["routes_resumed"]
+        g.replan(64); r.replan(64)
+        if r.counters()["routes_resumed"] > before:          # a resumed route keeps its goal
+            kept += 1
+        if t % 10 == 9:
+            _state_equal(g, r, cfg, "at step %d" % t)
+    _state_equal(g, r, cfg, "at the end")
+    c = r.counters()
+    assert g.counters() == c
+    # (the first routes of this world were cut by the host-side navsim_plan calls of make_world, which count nothing:
+    # routes_cut counts the routes navsim_replan stored cut, i.e. resumed routes still more than two waypoints long)
+    assert c["routes_resumed"] >= 3 and c["routes_cut"] >= 3 and kept >= 3, c
+    # the pedestrians whose route was resumed and not yet completed still head for the goal they were given at the start
+    same = (r.a["ped_goal"][:, :5] == goal0[:, :5]).all(axis=2)
+    assert same.sum() >= 3
+
+
+def test_caps_are_counted(gpu):
+    """Round-3 verdict: arenas beyond cfg.regen_cap "play on in place" and pedestrians beyond navsim_replan's
+    max_queries wait -- silently.  navsim_state.counters makes both observable: device == oracle, and the numbers are
+    the ones the done flags / the waiting pedestrians imply."""
+    from helpers import finished_world
+    from nav_gym_amd import robots
+    E, size, N = 24, 200, 4
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_SFM, n_spawn=4,
+                                 auto_reset=1, seed=5, field_format=abi.FIELD_F32, regen_cap=5, min_goal_dist=3.0,
+                                 max_goal_dist=8.0, spawn_clearance=0.8, ped_min_robot_dist=1.5, ped_min_goal_dist=3.0)
+    gpu.world.lidar_full_circle(cfg, 90)
+    occ = gpu.world.make_maps(E, size, 5)
+    thr = ref.scan_threshold(cfg, robots.footprint_array("keti", "threshold_footprint"))
+    dthr = ref.scan_threshold(cfg, robots.footprint_array("keti", "discomfort_threshold_footprint"))
+    host = finished_world(cfg, occ, ref.build_dt(occ), 3, (thr, dthr))       # every robot already stands on its goal
+    host["costmap"] = ref.costmap(occ)
+    host["ped_goal"] = np.zeros((E, N, 2))
+    r = ref.RefSim(cfg, host)
+    g = gpu.sim.NavSim(cfg, {k: v for k, v in host.items()})
+    _eq(g.reset_obs().cpu().numpy(), r.reset_obs(), "reset obs")
+    act = np.zeros((E, 2))
+    go, gout = g.step(_t(gpu, act)); ro, rout = r.step(act)
+    assert rout["done"].all()
+    _eq(g.regen().cpu().numpy(), r.regen(), "obs after regen")
+    c = r.counters()
+    assert g.counters() == c
+    assert c["regen_served"] == 5 and c["regen_unserved"] == E - 5, c
+    # every pedestrian of the regenerated arenas is far from its goal; park three of them ON their final waypoint
+    for sim_ in (g, r):
+        a = sim_.t if sim_ is g else sim_.a
+        for (e, i) in ((0, 0), (1, 2), (3, 1)):
+            wp = a["ped_waypoints"][e, i, int(a["ped_n_waypoints"][e, i]) - 1]
+            a["ped_pose"][e, i, 0] = wp[0]; a["ped_pose"][e, i, 1] = wp[1]
+    due = int((np.linalg.norm(r.a["ped_pose"][:, :, :2] - r.a["ped_waypoints"][
+        np.arange(E)[:, None], np.arange(N)[None, :], r.a["ped_n_waypoints"] - 1], axis=2) < 0.5)[
+            np.arange(N)[None, :] < r.a["n_peds"][:, None]].sum())
+    assert due >= 3
+    g.replan(0); r.replan(0)                              # a cap of zero serves nobody and counts everybody
+    g.replan(2); r.replan(2)
+    c2 = r.counters()
+    assert g.counters() == c2
+    assert c2["replan_served"] == 2 and c2["replan_unserved"] == due + (due - 2), c2
+    _state_equal(g, r, cfg, "after the capped calls")
+
+
+@pytest.mark.parametrize("clamp", [0, 1])
+def test_wheel_speed_actions(gpu, clamp):
+    """NAVSIM_ACTION_WHEELS (round 4; build-defined like the Husky model): io.action = the angular speeds of a
+    skid-steer base's left / right wheel pairs, converted on the device with the Husky's wheel radius and track
+    (husky.urdf.xacro:61-67), optionally clamped to linvel_range x rotvel_range.  Device == oracle bit for bit, and
+    the rollout equals the one driven by the converted (and clipped) twists."""
+    from nav_gym_amd import robots
+    E, size = 24, 200
+    kw = dict(n_envs=E, map_h=size, map_w=size, max_peds=4, ped_model=abi.PED_SFM, n_spawn=6, auto_reset=1, seed=19,
+              field_format=abi.FIELD_U16T, axle_offset=0.0, clamp_action=clamp, linvel_lo=0.0, linvel_hi=1.0,
+              rotvel_lo=-2.0, rotvel_hi=2.0)
+    cfg_w = gpu.lib.default_config(action_kind=abi.ACTION_WHEELS, **kw)
+    cfg_t = gpu.lib.default_config(action_kind=abi.ACTION_TWIST, **kw)
+    assert (cfg_w.wheel_radius, cfg_w.wheel_track) == (robots.HUSKY_WHEEL_RADIUS, robots.HUSKY_TRACK)
+    for cfg in (cfg_w, cfg_t):
+        gpu.world.lidar_full_circle(cfg, 128)
+    occ = gpu.world.make_maps(E, size, 19)
+    arrays = gpu.world.make_world(cfg_w, occ, n_peds=3, device=gpu.dev)
+    arrays["scan_threshold"] = gpu.sim.scan_threshold(cfg_w, _t(gpu, robots.footprint_array("husky", "threshold_footprint")))
+    arrays["scan_discomfort"] = gpu.sim.scan_threshold(cfg_w, _t(gpu, robots.footprint_array("husky", "discomfort_threshold_footprint")))
+    host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "rect_table")}
+    host["field"] = ref.build_dt(occ)
+    gw, gt, r = gpu.sim.NavSim(cfg_w, arrays), gpu.sim.NavSim(cfg_t, arrays), ref.RefSim(cfg_w, host)
+    _eq(gw.reset_obs().cpu().numpy(), r.reset_obs(), "reset obs"); gt.reset_obs()
+    rng = np.random.default_rng(2)
+    clipped = 0
+    for t in range(25):
+        wheels = rng.uniform(-3.0, 9.0, (E, 2))                       # rad/s: up to 1.5 m/s, well beyond the limits
+        twist = robots.husky_twist_from_wheels(wheels[:, 0], wheels[:, 1])
+        if clamp:
+            clipped += int((twist[:, 0] > 1.0).sum() + (twist[:, 0] < 0.0).sum() + (np.abs(twist[:, 1]) > 2.0).sum())
+            twist = np.stack([np.clip(twist[:, 0], 0.0, 1.0), np.clip(twist[:, 1], -2.0, 2.0)], axis=1)
+        go, gout = gw.step(_t(gpu, wheels)); ro, rout = r.step(wheels)
+        go = go.cpu().numpy().copy()
+        _eq(go, ro, "obs at step %d" % t)
+        for k in rout:
+            _eq(gout[k].cpu().numpy(), rout[k], "%s at step %d" % (k, t))
+        go2, gout2 = gt.step(_t(gpu, twist))
+        _eq(go2.cpu().numpy(), go, "twist-driven obs at step %d" % t)
+    _state_equal(gw, r, cfg_w, "wheel-driven")
+    _eq(gw.numpy_state("prev_action")["prev_action"], gt.numpy_state("prev_action")["prev_action"], "prev_action holds the twist")
+    assert not clamp or clipped > 20
 
 
 def _policy_weights_random(seed):
@@ -849,7 +1021,7 @@ def test_policy_vs_reference_trace(gpu, name):
     tr = load_trace(name)
     cfg, arrays, occ = trace_setup(tr, gpu.lib.default_config, lambda o: gpu.sim.build_dt(_t(gpu, o)).cpu().numpy())
     N = tr["init_ped_pose"].shape[0]
-    wp = np.zeros((1, N, abi.MAX_WAYPOINTS, 2)); wp[0, :, :tr["init_ped_waypoints"].shape[1]] = tr["init_ped_waypoints"]
+    wp = np.zeros((1, N, cfg.max_waypoints, 2)); wp[0, :, :tr["init_ped_waypoints"].shape[1]] = tr["init_ped_waypoints"]
     arrays["ped_waypoints"] = wp
     arrays["ped_n_waypoints"] = tr["init_ped_n_waypoints"][None].astype(np.int32)
     g = gpu.sim.NavSim(cfg, arrays)
@@ -1276,8 +1448,8 @@ def test_full_size_c2_properties_and_sampled_oracle(gpu, full_c2):
         c1 = sub_cfg.copy(); c1.env_index_base = int(e)
         host = {}
         for k, t in sim.t.items():
-            if k in ("field", "field_overflow", "rect_table", "beam_table", "arena_cost", "launch_order", "regen_ws"):
-                continue
+            if k in ("field", "field_overflow", "rect_table", "beam_table", "arena_cost", "launch_order", "regen_ws", "counters"):
+                continue                              # (counters: per simulator, not per arena)
             a = t.detach().cpu().numpy()
             host[k] = a if k in ("scan_threshold", "scan_discomfort") else a[e:e + 1]
         host["field"] = ref.build_dt(occ[e:e + 1])
@@ -1342,7 +1514,7 @@ def test_full_size_c2_determinism_and_shard_invariance(gpu, full_c2):
         c = cfg.copy(); c.n_envs = hi - lo; c.env_index_base = base
         arr = {}
         for k, v in state0.items():
-            if k in ("arena_cost", "launch_order"):      # scheduling hints: each NavSim owns its own
+            if k in ("arena_cost", "launch_order", "counters"):      # scheduling hints / totals: each NavSim owns its own
                 continue
             if k == "field":
                 per = v.numel() // E

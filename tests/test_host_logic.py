@@ -85,14 +85,15 @@ def test_argument_validation_of_round2_entry_points():
     assert L.navsim_crowd_agent_step(None, None, None, 3, 0.25, None) == abi.E_ARG
     # config fields that replaced the environment knobs are validated by navsim_step
     cfg = lib.default_config()
-    assert (cfg.march_rule, cfg.step_block, cfg.ped_split) == (abi.MARCH_F64, 0, 0)
+    assert (cfg.march_rule, cfg.step_block, cfg.ped_split) == (abi.MARCH_F32, 0, 0)
+    assert (cfg.max_waypoints, cfg.action_kind, cfg.clamp_action) == (64, abi.ACTION_TWIST, 0)
     st, io = abi.NavsimState(), abi.NavsimStepIO()
     for name in ("field", "scan_threshold", "scan_discomfort", "robot_pose", "robot_goal", "prev_action", "prev_pose",
                  "n_hist", "episode", "steps"):
         setattr(st, name, C.cast(one, C.c_void_p))
     for name in ("action", "obs", "reward", "done", "is_success", "is_crash", "distance"):
         setattr(io, name, C.cast(one, C.c_void_p))
-    for field, bad in (("step_block", 100), ("ped_split", 3), ("march_rule", 2)):
+    for field, bad in (("step_block", 100), ("ped_split", 3), ("march_rule", 3), ("action_kind", 2)):
         c2 = cfg.copy(); setattr(c2, field, bad)
         assert L.navsim_step(C.byref(c2), C.byref(st), C.byref(io), None) == abi.E_ARG, field
     c2 = cfg.copy(); c2.field_format = abi.FIELD_F32; st.rect_table = C.cast(one, C.c_void_p)
@@ -346,7 +347,7 @@ def _fake_env(n_peds=3):
          "n_peds": torch.tensor([0, n_peds], dtype=torch.int32),
          "ped_pose": torch.rand((2, 4, 3), dtype=torch.float64) * 2 + 0.3,
          "ped_vel": torch.rand((2, 4, 2), dtype=torch.float64),
-         "ped_waypoints": torch.rand((2, 4, abi.MAX_WAYPOINTS, 2), dtype=torch.float64) * 2 + 0.3}
+         "ped_waypoints": torch.rand((2, 4, cfg.max_waypoints, 2), dtype=torch.float64) * 2 + 0.3}
     obs = torch.full((2, 64 + 7), 25.0, dtype=torch.float32)
     obs[1, :32] = 0.8                                       # half of the beams return at 0.8 m
     obs[1, -1] = 0.7

@@ -114,9 +114,10 @@ def test_scan_thresholds_match_reference_built(units):
     assert abs(thr[0] - 0.7) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["random_S1", "peds_S1", "crash_S3", "success_S2"])
+@pytest.mark.parametrize("name", ["random_S1", "peds_S1", "crash_S3", "success_S2", "corridor_S1"])
 def test_step_trace(name):
-    """The oracle's step() reproduces the reference's own step() on the recorded traces."""
+    """The oracle's step() reproduces the reference's own step() on the recorded traces (corridor_S1: the reference's
+    own 1000 x 1000 corridor map, round 4)."""
     tr = load_trace(name)
     cfg, arrays, _ = trace_setup(tr, ref.default_config, ref.build_dt)
     sim = ref.RefSim(cfg, arrays)
@@ -164,7 +165,61 @@ def test_path_to_waypoints(units):
     assert ref.path_to_waypoints(straight, 2)[0, 0] == 2.25
 
 
-@pytest.mark.parametrize("name", ["random_S1", "peds_S1", "crash_S3", "success_S2"])
+def _long_routes(golden_dir):
+    d = np.load(os.path.join(golden_dir, "golden_long_routes.npz"))
+    shape = tuple(int(x) for x in d["cost_shape"])
+    cost = np.unpackbits(d["cost_packed"])[: shape[0] * shape[1]].reshape(shape)
+    return d, cost
+
+
+def test_long_routes_vs_reference(golden_dir):
+    """Routes of FULL length (round 4; env.py:788-804, 1261-1277: the reference keeps every waypoint of a route).
+    (1) path_to_waypoints on 16 paths of 33-64 waypoints equals the reference's own output, waypoint for waypoint;
+    (2) 24 routes the reference's own _sample_start_goal_path drew on the costmap of its 1000 x 1000 corridor episode
+        (half of them longer than the 16 waypoints rounds 1-3 kept): the reference's waypoints of the recorded path are
+        reproduced exactly; the oracle's own planner joins the same start and goal with a path of the SAME number of
+        cells (a shortest path: which one is the build-defined tie-break) and keeps all of its waypoints."""
+    d, cost = _long_routes(golden_dir)
+    assert d["wp_n"].min() >= 30 and d["wp_n"].max() >= 60
+    for k in range(d["wp_paths"].shape[0]):
+        p = d["wp_paths"][k][: int(d["wp_n_points"][k])]
+        exp = d["wp_out"][k][: int(d["wp_n"][k])]
+        got = ref.path_to_waypoints(p, 2.0, max_wp=128)
+        assert got.shape == exp.shape and np.array_equal(got, exp), k
+    cfg = ref.default_config()
+    assert cfg.max_waypoints == 64
+    res_c = float(d["cost_resolution"])
+    n_long = 0
+    for k in range(d["route_start"].shape[0]):
+        n_exp = int(d["route_n_wp"][k])
+        path = d["route_path"][k][: int(d["route_cells"][k])]
+        got = ref.path_to_waypoints(path, 2.0, max_wp=128)
+        assert np.array_equal(got, d["route_wp"][k][:n_exp]), k
+        wp, n_wp, cells, plen = ref.plan(cost[None], d["route_start"][k][None], d["route_goal"][k][None], 2.0,
+                                         max_wp=cfg.max_waypoints, res_c=res_c)
+        assert cells[0] == d["route_cells"][k], (k, cells[0], d["route_cells"][k])
+        assert abs(int(n_wp[0]) - n_exp) <= 2 and n_wp[0] < cfg.max_waypoints       # nothing cut at the default capacity
+        assert np.array_equal(wp[0, n_wp[0] - 1], d["route_goal"][k])               # the list ends on the goal itself
+        n_long += n_exp > 16
+    assert n_long >= 12
+
+
+def test_cut_route_length_counts_every_waypoint(golden_dir):
+    """A route longer than max_wp is stored cut, but its path_distance (env.py:757-759) still runs over every waypoint
+    of the path: the robot's `path_distance > 2 |goal - start|` rule must not depend on the capacity."""
+    d, cost = _long_routes(golden_dir)
+    res_c = float(d["cost_resolution"])
+    k = int(np.argmax(d["route_n_wp"]))
+    s, g = d["route_start"][k][None], d["route_goal"][k][None]
+    wp_full, n_full, _, len_full = ref.plan(cost[None], s, g, 2.0, max_wp=128, res_c=res_c)
+    wp_cut, n_cut, _, len_cut = ref.plan(cost[None], s, g, 2.0, max_wp=8, res_c=res_c)
+    assert n_full[0] > 16 and n_cut[0] == 8
+    assert np.array_equal(wp_cut[0], wp_full[0, :8]) and len_cut[0] == len_full[0]
+    seg = np.diff(np.vstack([s, wp_full[0, : n_full[0]]]), axis=0)
+    assert abs(np.linalg.norm(seg, axis=1).sum() - len_full[0]) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["random_S1", "peds_S1", "crash_S3", "success_S2", "corridor_S1"])
 def test_policy_control_block_vs_reference_trace(name):
     """Row a10 (env.py:617-662 + human_policy.py:19-52): with the weights the traces were recorded with,
     the oracle's control block -- pedestrian scan -> clip / scale -> actor network -> clip -> * v_pref,
@@ -176,8 +231,8 @@ def test_policy_control_block_vs_reference_trace(name):
     cfg, arrays, occ = trace_setup(tr, ref.default_config, ref.build_dt)
     N = tr["init_ped_pose"].shape[0]
     nw = tr["init_ped_n_waypoints"]
-    assert nw.max() <= abi.MAX_WAYPOINTS
-    wp = np.zeros((1, N, abi.MAX_WAYPOINTS, 2))
+    assert nw.max() <= cfg.max_waypoints
+    wp = np.zeros((1, N, cfg.max_waypoints, 2))
     wp[0, :, :tr["init_ped_waypoints"].shape[1]] = tr["init_ped_waypoints"]
     arrays["ped_waypoints"] = wp
     arrays["ped_n_waypoints"] = nw[None].astype(np.int32)
@@ -204,6 +259,8 @@ def test_policy_control_block_vs_reference_trace(name):
         replanned |= np.linalg.norm(r.a["ped_pose"][0, :, :2] - last, axis=1) < 0.5
     assert checked >= 30 and worst < 1e-5, (checked, worst)
     assert replanned.sum() <= 1
+    if name == "corridor_S1":           # the route of more than 32 m is walked from its full waypoint list
+        assert nw.max() > 16 and (r.a["ped_n_waypoints"][0] < nw).any()
 
 
 def _crowd_golden():
