@@ -1071,6 +1071,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 sh.rp[0] = pv_g[0]; sh.rp[1] = pv_g[1]; sh.rp[2] = pv_g[2];
                 sh.rescan = 1;
             }
+#ifdef NAVSIM_DIAG_NO_RESCAN      // diagnostic build only (WRONG observations after a crash): what do the second scans cost the launch?
+            sh.rescan = 0;               // (round 4, profiles/r04_jobs/ab_norescan.txt: c2 113.8 -> 105.3 us, c2 at 512 arenas 34.0 -> 31.1, c5 58 -> 47)
+#endif
             if (sh.rescan) {
                 sh.next_chunk = 0; sh.park_count = 0; sh.park_next = 0;
                 sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];

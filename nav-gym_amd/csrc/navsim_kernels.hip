@@ -217,6 +217,10 @@ int launch_step_kernel(const navsim_config* c, const navsim_state* st, const nav
 template <int BLOCK, bool PEDS, typename Field, int RECT>
 int launch_step_rule(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
                      const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
+#ifdef NAVSIM_ONLY_RULE     // experiment builds (profiles/_diag/build_variant.sh): one march rule compiled, a quarter of the build time
+    if (march_rule_variant(c) != NAVSIM_ONLY_RULE) return NAVSIM_E_UNSUPPORTED;
+    return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_ONLY_RULE>(c, st, io, reset_only, mask, p, s, grid);
+#else
     switch (march_rule_variant(c)) {
         case NAVSIM_MARCH_F32: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F32>(c, st, io, reset_only, mask, p, s, grid);
         case NAVSIM_MARCH_F32_FMA: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F32_FMA>(c, st, io, reset_only, mask, p, s, grid);
@@ -226,6 +230,7 @@ int launch_step_rule(const navsim_config* c, const navsim_state* st, const navsi
             [[fallthrough]];
         default: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F64>(c, st, io, reset_only, mask, p, s, grid);
     }
+#endif
 }
 
 template <int BLOCK, bool PEDS, typename Field>
@@ -596,12 +601,17 @@ int navsim_ped_scans(const navsim_config* c, const navsim_state* st, float* out,
     hipStream_t s = (hipStream_t)stream;
     // 128 threads per pedestrian (measured 64 / 128 / 256 / 512: 1.11 / 0.78 / 0.93 / 1.50 ms on c3)
     const int rule = march_rule_variant(c);
+#ifdef NAVSIM_ONLY_RULE
+    if (rule != NAVSIM_ONLY_RULE) return NAVSIM_E_UNSUPPORTED;
+#define NAVSIM_PSCAN(F, RECT) ped_scan_kernel<F, 128, NAVSIM_ONLY_RULE, RECT><<<grid, 128, lds, s>>>(*c, *st, out)
+#else
 #define NAVSIM_PSCAN(F, RECT) \
     do { if (rule == NAVSIM_MARCH_F32)      ped_scan_kernel<F, 128, NAVSIM_MARCH_F32, RECT><<<grid, 128, lds, s>>>(*c, *st, out); \
          else if (rule == NAVSIM_MARCH_F32_FMA) ped_scan_kernel<F, 128, NAVSIM_MARCH_F32_FMA, RECT><<<grid, 128, lds, s>>>(*c, *st, out); \
          else if (rule == kMarchF64Exact32 && !std::is_same<F, FieldF32>::value) \
                                             ped_scan_kernel<F, 128, kMarchF64Exact32, RECT><<<grid, 128, lds, s>>>(*c, *st, out); \
          else                               ped_scan_kernel<F, 128, NAVSIM_MARCH_F64, RECT><<<grid, 128, lds, s>>>(*c, *st, out); } while (0)
+#endif
     if (c->field_format == NAVSIM_FIELD_U16T) {
         if (st->rect_table) NAVSIM_PSCAN(FieldU16T, true); else NAVSIM_PSCAN(FieldU16T, false);
     } else if (c->field_format == NAVSIM_FIELD_F32) {

@@ -1448,8 +1448,8 @@ def test_full_size_c2_properties_and_sampled_oracle(gpu, full_c2):
         c1 = sub_cfg.copy(); c1.env_index_base = int(e)
         host = {}
         for k, t in sim.t.items():
-            if k in ("field", "field_overflow", "rect_table", "beam_table", "arena_cost", "launch_order", "regen_ws", "counters"):
-                continue                              # (counters: per simulator, not per arena)
+            if k in ("field", "field_overflow", "rect_table", "beam_table", "arena_cost", "launch_order", "regen_ws", "counters", "job_board"):
+                continue                              # (counters, job board: per simulator, not per arena)
             a = t.detach().cpu().numpy()
             host[k] = a if k in ("scan_threshold", "scan_discomfort") else a[e:e + 1]
         host["field"] = ref.build_dt(occ[e:e + 1])
@@ -1514,7 +1514,7 @@ def test_full_size_c2_determinism_and_shard_invariance(gpu, full_c2):
         c = cfg.copy(); c.n_envs = hi - lo; c.env_index_base = base
         arr = {}
         for k, v in state0.items():
-            if k in ("arena_cost", "launch_order", "counters"):      # scheduling hints / totals: each NavSim owns its own
+            if k in ("arena_cost", "launch_order", "counters", "job_board"):      # scheduling hints / totals: each NavSim owns its own
                 continue
             if k == "field":
                 per = v.numel() // E
