@@ -293,6 +293,8 @@ def main():
     ap.add_argument("--no-noise-off-pass", action="store_true",
                     help="skip the extra K steps timed with scan noise off (profiling runs: one kind of launch only)")
     ap.add_argument("--step-block", type=int, default=0, help="threads per arena (0 = library default)")
+    ap.add_argument("--march-rule", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="navsim_config.march_rule (include/navsim.h NAVSIM_MARCH_*): -1 the library default (1 = F32)")
     ap.add_argument("--spinup-ms", type=float, default=500.0,
                     help="untimed GPU work before the warm-up steps (leaves the idle power state); 0 = none")
     ap.add_argument("--no-cold-pass", action="store_true", help="skip the extra K steps timed without spin-up (value_no_spinup)")
@@ -373,6 +375,8 @@ def main():
     if args.ped_split:
         sim.cfg.ped_split = args.ped_split
     sim.cfg.rect_lds = args.rect_lds
+    if args.march_rule >= 0:
+        sim.cfg.march_rule = args.march_rule
     if args.lpt_period:
         sim.lpt_period = args.lpt_period
     E, K, Wm = cfg.n_envs, args.steps, args.warmup
