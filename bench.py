@@ -30,6 +30,8 @@ WORKLOADS = {
     # envs = arenas per GPU (weak scaling), total = arenas of the whole job (strong scaling)
     "c1": dict(envs=1, total=1, beams=64, size=100, peds=0),
     "c2": dict(envs=4096, total=4096, beams=1081, size=500, peds=0),
+    # diagnostic shape (not a BASELINE config): c2 on 200 x 200 maps, whose record table (10 KB) fits LDS eight times per CU
+    "c2s": dict(envs=4096, total=4096, beams=1081, size=200, peds=0),
     "c3": dict(envs=4096, total=4096, beams=1081, size=500, peds=20),
     "c4": dict(envs=2048, total=16384, beams=1081, size=1000, peds=0),      # 16384 arenas over 8 GPUs
     # 4096 arenas over 8 GPUs, Husky, 20 pedestrians, a NEW random map at every episode end (navsim_regen)

@@ -172,9 +172,10 @@ typedef struct navsim_config {
     int32_t regen_check_discomfort;   /* navsim_regen: 1 (default) = a robot start whose FIRST scan (no pedestrians, no noise) has a
                                          beam inside the discomfort zone is dropped and the next start / goal pair of the
                                          spawn table takes its place, like reset() re-draws the robot (env.py:776-781) */
-    int32_t rect_lds;                 /* fused step with rect records: 0 = the library stages an arena's record table in
-                                         LDS when the launch is small enough for that to pay, 1 = never,
-                                         2 = whenever the table fits (16 B per 8x8 tile next to the step's other LDS) */
+    int32_t rect_lds;                 /* fused step with rect records: 0 = the library stages the index form of an arena's record
+                                         table (navsim_state.rect_index) in LDS whenever it is present and fits beside the step's
+                                         other LDS at the launch's residency, 1 = never (records from global
+                                         memory), 2 = whenever it fits one workgroup per CU */
     int32_t max_waypoints;            /* P: waypoints kept per pedestrian = stride of navsim_state.ped_waypoints, 1 ..
                                          NAVSIM_MAX_WAYPOINTS.  The reference keeps EVERY waypoint of a route
                                          (path_to_waypoints, env.py:1261-1277; env.py:788-804); navsim_default_config
@@ -279,6 +280,12 @@ typedef struct navsim_state {
     /* [NAVSIM_N_COUNTERS] uint64 or NULL: running totals, incremented on the device, zeroed by the caller when it
      * likes.  They make the library's caps observable: no call ever fails or blocks because of a cap. */
     unsigned long long* counters;
+    /* [E, navsim_rect_index_bytes(1, H, W)] or NULL: the INDEX form of rect_table (navsim_build_rect_index) -- per arena the
+     * distinct rectangles of its records (at most 255, 8 bytes each) and two list indices per 8x8 tile, 10 KB for a
+     * 500 x 500 map.  The fused step copies the arena's row into LDS and its scans probe LDS instead of global memory
+     * ("map tiles staged through LDS"; cfg.rect_lds).  Needs rect_table (other kernels keep reading the records);
+     * navsim_regen keeps it current.  Results are unchanged. */
+    void* rect_index;
 } navsim_state;
 
 #define NAVSIM_N_COUNTERS              8
@@ -352,6 +359,12 @@ int    navsim_build_field(const uint8_t* occ, int32_t n_maps, int32_t map_h, int
  * just get fewer valid records.  `field` / `format` / `overflow` as produced by navsim_build_field for the same
  * occupancy grids (overflow may be NULL: tiles holding a saturated cell are then invalid).  H, W <= 1024. */
 size_t navsim_rect_table_bytes(int32_t n_maps, int32_t map_h, int32_t map_w);
+/* The index form of `table` (navsim_state.rect_index): per map the distinct rectangles of its valid records and two list
+ * indices per tile.  n_rects [n_maps] int32 or NULL receives the number of distinct rectangles found (tiles naming one
+ * beyond the 255th get no index and are read from the field). */
+size_t navsim_rect_index_bytes(int32_t n_maps, int32_t map_h, int32_t map_w);
+int    navsim_build_rect_index(const void* table, int32_t n_maps, int32_t map_h, int32_t map_w, void* index,
+                               int32_t* n_rects, void* stream);
 size_t navsim_build_rects_workspace_bytes(int32_t n_maps, int32_t map_h, int32_t map_w);
 int    navsim_build_rects(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t map_w, const void* field,
                           int32_t format, const float* overflow, void* table, void* workspace, size_t workspace_bytes,

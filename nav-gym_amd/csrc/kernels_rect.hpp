@@ -46,6 +46,109 @@ __device__ __forceinline__ int rect_record_d2(const uint4 rec, unsigned p) {
 __device__ __forceinline__ int rect_record_d2(const uint4 rec, int px, int py) { return rect_record_d2(rec, rect_cell(px, py)); }
 __device__ __forceinline__ bool rect_record_invalid(const uint4 rec) { return (rec.x & 0xFFFFu) == kRectInvalid; }
 
+// ============================================================================================
+// The INDEX form of an arena's record table (round 4): "map tiles staged through LDS" at eight arenas per CU.
+//
+// A map holds few distinct rectangles -- an outdoor map 4 walls + its boxes (14 on the bench's maps), a corridor map the
+// maximal rectangles of its walls (a few dozen to a couple of hundred) -- and the 16-byte records of its 8x8 tiles name
+// the same ones over and over.  So an arena's table is stored a second time as
+//     list[256]   the distinct rectangles (8 bytes each: lo = y0 << 16 | x0, hi = y1 << 16 | x1)          2 048 B
+//     pair[tile]  two list indices per tile (A | B << 8; 0xFFFF = no valid record: read the field)        2 B per tile
+// 10 KB for a 500 x 500 map against the records' 63.5 KB, 34 KB for 1000 x 1000: the fused step copies the arena's row into
+// LDS once (all threads, 16-byte loads, beside phase 0) and every probe of its scans is a ds_read_u16 and two ds_read_b64 --
+// ~0.1 us instead of a global load's 0.5-2 us -- at the SAME residency as before (eight 256-thread workgroups per CU).
+// Why it matters (profiles/r04_split/README.md): a probe round is a dependent chain (position -> tile -> record -> d2 ->
+// sqrt -> step -> next position) and with eight wavefronts per SIMD its latency, not its instruction count, sets the pace;
+// the record load was the chain's longest link.  HBM traffic of a c2 launch: 220 -> 60 MB.
+// Derived from the verified records (rect_index_kernel below) or written next to them by navsim_regen's direct
+// generator: lossless by construction -- a tile whose rectangles do not fit the list (more than 255 distinct ones in the
+// map) simply has no index and is read from the field, like a tile without a valid record.
+// ============================================================================================
+constexpr int kRectListLen = 256;                    // list entries in a row (index 255 is the "no record" marker, never a rectangle)
+constexpr unsigned kRectNoIndex = 0xFFFFu;
+__host__ __device__ inline size_t rect_index_row_bytes(int H, int W) {
+    return (size_t)kRectListLen * 8 + ((rect_tiles_per_map(H, W) * 2 + 15) & ~(size_t)15);
+}
+// one workgroup per map: hash the distinct rectangles of the valid records (1024 slots, linear probing, 64-bit LDS CAS),
+// rank the occupied slots, write the list and the tile pairs.  Which rectangle gets which index depends on the order of
+// insertion; no result depends on it.
+constexpr int kRectHash = 1024;
+__global__ __launch_bounds__(256) void rect_index_kernel(const uint4* __restrict__ table, int H, int W, char* __restrict__ rows,
+                                                         int32_t* __restrict__ n_rects, const int* __restrict__ n_live,
+                                                         const int* __restrict__ list) {
+    __shared__ unsigned long long keys[kRectHash];
+    __shared__ unsigned short rank_s[kRectHash];
+    __shared__ int wave_tot[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    if (n_live && m >= *n_live) return;
+    const size_t row = list ? (size_t)list[m] : (size_t)m;
+    const int n_tiles = (int)rect_tiles_per_map(H, W);
+    const uint4* tab = table + row * (size_t)n_tiles;
+    char* out = rows + row * rect_index_row_bytes(H, W);
+    constexpr unsigned long long kEmpty = ~0ull;
+    for (int k = tid; k < kRectHash; k += 256) keys[k] = kEmpty;
+    __syncthreads();
+    auto slot_of = [&](unsigned lo, unsigned hi, bool insert) -> int {
+        const unsigned long long key = ((unsigned long long)hi << 32) | lo;
+        unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ULL) >> 54);         // 10 bits
+        for (int tries = 0; tries < kRectHash; ++tries, h = (h + 1) & (kRectHash - 1)) {
+            unsigned long long cur = keys[h];
+            if (cur == key) return (int)h;
+            if (cur == kEmpty) {
+                if (!insert) return -1;
+                cur = atomicCAS(&keys[h], kEmpty, key);
+                if (cur == kEmpty || cur == key) return (int)h;
+            }
+        }
+        return -1;
+    };
+    for (int t = tid; t < n_tiles; t += 256) {
+        const uint4 rec = tab[t];
+        if (rect_record_invalid(rec)) continue;
+        slot_of(rec.x, rec.y, true);
+        slot_of(rec.z, rec.w, true);
+    }
+    __syncthreads();
+    // ranks of the occupied slots in slot order (4 slots per thread, wave scan, 4 wave totals)
+    int occ[4], mine = 0;
+    for (int j = 0; j < 4; ++j) { occ[j] = keys[tid * 4 + j] != kEmpty; mine += occ[j]; }
+    int incl = mine;
+    const int lane = tid & 63;
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+    if (lane == 63) wave_tot[tid >> 6] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < 4; ++w) { before += (w < (tid >> 6)) ? wave_tot[w] : 0; total += wave_tot[w]; }
+    int r = before + incl - mine;
+    uint2* lst = (uint2*)out;
+    for (int j = 0; j < 4; ++j) {
+        unsigned short rk = 0xFFFF;
+        if (occ[j]) {
+            if (r < kRectListLen - 1) {
+                rk = (unsigned short)r;
+                const unsigned long long key = keys[tid * 4 + j];
+                lst[r] = make_uint2((unsigned)key, (unsigned)(key >> 32));
+            }
+            ++r;
+        }
+        rank_s[tid * 4 + j] = rk;
+    }
+    for (int k = total + tid; k < kRectListLen; k += 256) lst[k] = make_uint2(0u, 0u);      // unused entries stay defined
+    if (tid == 0 && n_rects) n_rects[row] = total;
+    __syncthreads();
+    uint16_t* pair = (uint16_t*)(out + (size_t)kRectListLen * 8);
+    for (int t = tid; t < n_tiles; t += 256) {
+        const uint4 rec = tab[t];
+        unsigned p = kRectNoIndex;
+        if (!rect_record_invalid(rec)) {
+            const int sa = slot_of(rec.x, rec.y, false), sb = slot_of(rec.z, rec.w, false);
+            const unsigned ra = sa >= 0 ? rank_s[sa] : 0xFFFFu, rb = sb >= 0 ? rank_s[sb] : 0xFFFFu;
+            if (ra < kRectListLen - 1 && rb < kRectListLen - 1) p = ra | (rb << 8);
+        }
+        pair[t] = (uint16_t)p;
+    }
+}
+
 // ---- builder pass 1: transpose of the occupancy grid (32x32 tiles through LDS), so that the vertical runs can be
 // found by the same coalesced row kernel
 __global__ __launch_bounds__(256) void rect_transpose_kernel(const uint8_t* __restrict__ occ, uint8_t* __restrict__ occT,

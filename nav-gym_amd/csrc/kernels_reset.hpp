@@ -225,7 +225,7 @@ __device__ __forceinline__ void regen_maps_item(const navsim_config& c, const na
                                                 const uint8_t* __restrict__ grid_all, const int* __restrict__ kind,
                                                 char* __restrict__ field_scratch, size_t field_bytes,
                                                 float* __restrict__ ovf_scratch, int direct, bool all_outdoor,
-                                                uint4* __restrict__ rect_all, int* ocx, int* ocy) {
+                                                uint4* __restrict__ rect_all, char* __restrict__ index_all, int* ocx, int* ocy) {
     const int size = c.map_w, tid = threadIdx.x;
     uint8_t* occ = occ_all ? occ_all + (size_t)b * size * size : nullptr;
     const int rows = (size + kRegenSlices - 1) / kRegenSlices;
@@ -269,6 +269,14 @@ __device__ __forceinline__ void regen_maps_item(const navsim_config& c, const na
     // 128 bytes, and the tile's rect record (kernels_rect.hpp) falls out of the same pass.
     const int tpr = (size + 7) >> 3, blocks = (tpr + 31) >> 5;
     const int ry = tid & 7, tsub = tid >> 3;
+    if (index_all && rect_all && slice == 0) {               // the list of the index form: walls 0..3, box o at 4 + o, the rest defined
+        uint2* lst = (uint2*)(index_all + (size_t)e * rect_index_row_bytes(size, size));
+        if (tid < kRectListLen) {
+            uint2 v = make_uint2(0u, 0u);
+            if (tid < 4 + n_obs) regen_rect_of(tid, live, size, hw, ocx, ocy, v.x, v.y);
+            lst[tid] = v;
+        }
+    }
     for (int u = slice; u < tpr * blocks; u += kRegenSlices) {
         const int ty = u / blocks, tx = (u - ty * blocks) * 32 + tsub;
         const int y = ty * 8 + ry, x0 = tx << 3;
@@ -367,6 +375,12 @@ __device__ __forceinline__ void regen_maps_item(const navsim_config& c, const na
                     regen_rect_of(set.b < 0 ? set.a : set.b, live, size, hw, ocx, ocy, rec.z, rec.w);
                 }
                 (rect_all + (size_t)e * rect_tiles_per_map(size, size))[(size_t)ty * tpr + tx] = rec;
+                // the index form of the same record (kernels_rect.hpp): the generator's own rectangle numbers
+                if (index_all) {
+                    uint16_t* pair = (uint16_t*)(index_all + (size_t)e * rect_index_row_bytes(size, size) + (size_t)kRectListLen * 8);
+                    pair[(size_t)ty * tpr + tx] = (set.bad || set.a < 0) ? (uint16_t)kRectNoIndex
+                                                                         : (uint16_t)((unsigned)set.a | ((unsigned)(set.b < 0 ? set.a : set.b) << 8));
+                }
             }
         }
     }
@@ -382,7 +396,8 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
                                                          const uint8_t* __restrict__ grid_all, int* __restrict__ kind,
                                                          char* __restrict__ field_scratch, size_t field_bytes,
                                                          float* __restrict__ ovf_scratch, int direct,
-                                                         const uint8_t* __restrict__ done, int cap, uint4* __restrict__ rect_all) {
+                                                         const uint8_t* __restrict__ done, int cap, uint4* __restrict__ rect_all,
+                                                         char* __restrict__ index_all) {
     __shared__ int ocx[64], ocy[64];
     int n_items;
     if (done) {
@@ -407,7 +422,7 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
             e = list[b];
         }
         regen_maps_item(c, st, b, slice, e, occ_all, grid_all, kind, field_scratch, field_bytes, ovf_scratch, direct,
-                        done != nullptr, rect_all, ocx, ocy);       // (kind[b] of this call may not be written yet: not read then)
+                        done != nullptr, rect_all, index_all, ocx, ocy);       // (kind[b] of this call may not be written yet: not read then)
         __syncthreads();                                                 // ocx / ocy are rewritten by the next item
     }
 }
@@ -1131,7 +1146,7 @@ struct SwapBig { char* dst; const char* src; size_t bytes; };          // per-ar
 __global__ __launch_bounds__(256) void regen_swap_kernel(navsim_config c, navsim_state live, navsim_state stage,
                                                          navsim_step_io io, const float* __restrict__ stage_obs,
                                                          const uint8_t* __restrict__ want, uint8_t* __restrict__ mark,
-                                                         int cap, SwapBig b0, SwapBig b1, SwapBig b2, SwapBig b3) {
+                                                         int cap, SwapBig b0, SwapBig b1, SwapBig b2, SwapBig b3, SwapBig b4) {
     const int b = blockIdx.x, tid = threadIdx.x;                      // (grid (cap, slices): opt-in path, not bounded yet)
     int total, excl, lo, hi;
     // eligible: finished AND staged (want[e] == 0).  want[] is only READ here -- every workgroup of the launch must see
@@ -1153,8 +1168,8 @@ __global__ __launch_bounds__(256) void regen_swap_kernel(navsim_config c, navsim
         count_served(live, NAVSIM_COUNTER_REGEN_SERVED, n_in, n_out);
     }
     if (e < 0) return;
-    const SwapBig big[4] = {b0, b1, b2, b3};
-    for (int k = 0; k < 4; ++k) {                            // field, overflow plane, rect records, costmap
+    const SwapBig big[5] = {b0, b1, b2, b3, b4};
+    for (int k = 0; k < 5; ++k) {                            // field, overflow plane, rect records, costmap, rect index rows
         if (!big[k].dst) continue;
         const size_t n16 = big[k].bytes / 16;
         const char* src = big[k].src + (size_t)e * big[k].bytes;

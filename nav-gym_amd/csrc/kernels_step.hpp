@@ -308,8 +308,9 @@ __device__ __forceinline__ bool mask_lane(lanemask_t m) { return mask_sel(m, 1, 
 // One probe of calc_range (env.py:425) for every lane of `active`: sample position, distance there, hit test, step.
 // Lanes that are finished or outside the map run along with their updates masked off.  A lane that hits keeps the
 // t of its hit probe (the hit cell is recomputed from it after the march).
-// RECT: 0 = the field alone; 1 = the tile's two-rectangle record from global memory; 2 = from the arena's record table
-// staged in LDS (`rects` then points into LDS; round 3, launches of few arenas per CU).
+// RECT: 0 = the field alone; 1 = the tile's two-rectangle record from global memory; 2 = from the INDEX form of the arena's
+// table staged in LDS (kernels_rect.hpp: `rects` then points at the LDS copy of the arena's row -- list[256], then two
+// list indices per tile; round 4.  Round 3 staged the 16-byte records themselves, 63.5 KB per arena: two workgroups per CU).
 template <typename Field, int RULE, int RECT>
 __device__ __forceinline__ void probe_round(const Field& field, const char* __restrict__ rects, unsigned tpr,
                                             float x0, float y0, float dx, float dy, unsigned uW, unsigned uH,
@@ -332,23 +333,32 @@ __device__ __forceinline__ void probe_round(const Field& field, const char* __re
         // rare probe in a tile without a valid record reads the field.  32-bit lane offset on a uniform base.
         // tile rows and tiles per row stay far below 2^24: the 24-bit multiply-add is a full-rate instruction
         // a lane that is not live keeps its out-of-map px, py (every result of it is masked) and reads record 0
-        const unsigned off = (unsigned)mask_sel(live, (int)((__umul24((unsigned)py >> kRectShift, tpr) + ((unsigned)px >> kRectShift)) *
-                                                               (unsigned)sizeof(uint4)), 0);
+        const unsigned tile = (unsigned)mask_sel(live, (int)(__umul24((unsigned)py >> kRectShift, tpr) + ((unsigned)px >> kRectShift)), 0);
         const unsigned cell = rect_cell(px, py);
-        // The load is written out: after a compiler-generated global_load_dwordx4 the register allocator moved three
-        // of the four loaded dwords to other registers before using them (3 of 42 vector instructions per probe).
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         u32x4 rec;
+        lanemask_t inval;
         if constexpr (RECT == 2) {
+            // the arena's row in LDS: ds_read_u16 of the tile's index pair, then the two rectangles (ds_read_b64 each; most
+            // lanes of a wavefront name the same few list entries: broadcast reads)
             typedef __attribute__((address_space(3))) const char lds_char;
-            typedef __attribute__((address_space(3))) const u32x4 lds_rec;
-            rec = *(lds_rec*)((lds_char*)rects + off);               // ds_read_b128
+            typedef __attribute__((address_space(3))) const unsigned short lds_u16;
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            typedef __attribute__((address_space(3))) const u32x2 lds_u2;
+            const unsigned pair = *(lds_u16*)((lds_char*)rects + kRectListLen * 8 + tile * 2u);
+            const u32x2 ra = *(lds_u2*)((lds_char*)rects + (pair & 0xFFu) * 8u);
+            const u32x2 rb = *(lds_u2*)((lds_char*)rects + (pair >> 8) * 8u);
+            rec.x = ra.x; rec.y = ra.y; rec.z = rb.x; rec.w = rb.y;
+            inval = live & mask_eq(pair, kRectNoIndex);
         } else {
+            // The load is written out: after a compiler-generated global_load_dwordx4 the register allocator moved three
+            // of the four loaded dwords to other registers before using them (3 of 42 vector instructions per probe).
+            const unsigned off = tile * (unsigned)sizeof(uint4);
             asm volatile("global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(rec) : "v"(off), "s"(rects) : "memory");
+            inval = live & mask_eq(rec.x & 0xFFFFu, (unsigned)kRectInvalid);
         }
         const int da = rect_dist2(rec.x, rec.y, cell), db = rect_dist2(rec.z, rec.w, cell);
         const int d2 = da < db ? da : db;
-        const lanemask_t inval = live & mask_eq(rec.x & 0xFFFFu, (unsigned)kRectInvalid);
         occ = live & mask_eq((unsigned)d2, 0u);
         d = Field::sqrt_d2(d2);
         if (inval != 0) {                                               // wave-uniform branch
@@ -850,14 +860,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const uint4* rects = RECT ? (const uint4*)st.rect_table + (size_t)(c.shared_field ? 0 : e) * rect_tiles_per_map(c.map_h, c.map_w)
                               : nullptr;
     if constexpr (RECT == 2) {
-        // "Map tiles staged through LDS": the arena's whole record table (16 B per 8x8 tile: 63.5 KB for 500 x 500
-        // cells) is copied into LDS once, by all threads, and every probe of the scan reads its record with one
-        // ds_read_b128 (~0.1 us) instead of a global load (0.5-2 us from L2 / HBM).  It costs residency -- two
-        // 1024-thread workgroups per CU -- so the host takes this form only for launches of a few arenas per CU, where
-        // a launch is one or two generations and lasts as long as its rays' probe chains (dispatch_step).
+        // "Map tiles staged through LDS": the INDEX form of the arena's record table (kernels_rect.hpp: 2 KB of distinct
+        // rectangles + 2 bytes per 8x8 tile = 10 KB for 500 x 500 cells) is copied into LDS once, by all threads, beside
+        // phase 0; every probe of the scans then reads LDS (~0.1 us) instead of global memory (0.5-2 us from L2 / HBM).
         uint4* tab_lds = (uint4*)(dyn_lds + rect_lds_offset);
-        const int n_tiles = (int)rect_tiles_per_map(c.map_h, c.map_w);
-        for (int i = threadIdx.x; i < n_tiles; i += BLOCK) tab_lds[i] = rects[i];
+        const size_t row_bytes = rect_index_row_bytes(c.map_h, c.map_w);
+        const uint4* src = (const uint4*)((const char*)st.rect_index + (size_t)(c.shared_field ? 0 : e) * row_bytes);
+        for (int i = threadIdx.x; i < (int)(row_bytes / 16); i += BLOCK) tab_lds[i] = src[i];
         rects = tab_lds;                                        // made visible by the barrier that ends phase 0
     }
     float* obs_row = io.obs + (size_t)e * D;

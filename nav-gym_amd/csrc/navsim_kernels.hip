@@ -35,9 +35,6 @@
 
 #pragma clang fp contract(off)
 
-#ifndef NAVSIM_RECT_LDS_MAX_PER_CU
-#define NAVSIM_RECT_LDS_MAX_PER_CU 4       // arenas per CU up to which the fused step stages the rect records in LDS
-#endif
 
 // gfx950 only: bit-identity of the scans rests on properties of THIS ISA that are proven by exhaustive
 // device tests -- v_rsq_f32's rounding inside sqrt_small_int, the float32-only march step (navmath.hpp) -- and on
@@ -161,13 +158,11 @@ struct StepPlan {
     size_t lds;             // dynamic LDS per workgroup
     unsigned rect_off;      // byte offset of the staged table inside it
 };
-// The record table in LDS ("map tiles staged through LDS"): a probe costs a ds_read_b128 instead of a global load, the
-// workgroup 63.5 KB of LDS (500 x 500 cells) -- two 1024-thread workgroups per CU instead of eight 256-thread ones.
-// Measured on the c2 world (profiles/r03_rect_lds/sweep_c2_world.txt, M env-steps/s, records in global memory -> in LDS):
-// 128 arenas 4.4 -> 4.8, 256: 7.9 -> 8.8, 512: 12.9 -> 14.4, 1024: 17.0 -> 19.1 (+10-13 %: the launch is one or two
-// generations and lasts as long as the probe chains of its slowest rays); 1536: 24.2 -> 21.6, 2048: 26.3 -> 23.0,
-// 4096: 36.0 -> 24.5 (residency beats latency once the chip runs several generations).  So: up to 4 arenas per CU.
-constexpr long kRectLdsMaxArenasPerCu = NAVSIM_RECT_LDS_MAX_PER_CU;
+// The record table in LDS ("map tiles staged through LDS").  Round 3 staged the 16-byte records themselves: 63.5 KB per
+// 500 x 500 arena, two 1024-thread workgroups per CU, +10-13 % for launches of up to 4 arenas per CU and a loss beyond
+// (profiles/r03_rect_lds/).  Round 4 stages the INDEX form (kernels_rect.hpp: 10 KB) at the residency the block size implies
+// anyway; measured, records in global memory -> index rows in LDS (profiles/r04_idx/ab.txt, M env-steps/s): c2 36.4 -> 40.9,
+// 1024 arenas 17.8 -> 21.4, 512 arenas 13.3 -> 14.4, c4 28.2 -> 33.8, c5 4.36 -> 4.73.
 StepPlan plan_step(const navsim_config* c, const navsim_state* st, int grid = 0) {
     StepPlan p;
     p.block = pick_step_block(c);
@@ -175,22 +170,19 @@ StepPlan plan_step(const navsim_config* c, const navsim_state* st, int grid = 0)
     p.park = step_park_lanes(c, p.block);
     p.lds = step_lds_bytes(c, p.park);
     p.rect_off = 0;
-    if (p.rect && c->rect_lds != 1 && c->field_format == NAVSIM_FIELD_U16T && c->n_beams > 256 && !c->shared_field) {
-        const int b2 = (c->step_block == 512 || c->step_block == 1024) ? c->step_block : (c->step_block ? 0 : 1024);
-        if (b2) {
-            const size_t table = rect_tiles_per_map(c->map_h, c->map_w) * sizeof(uint4);
-            const size_t base = (step_lds_bytes(c, step_park_lanes(c, b2)) + 15) & ~(size_t)15;
-            const size_t total = base + table + 1024;               // + the kernel's static LDS, allocation granules
-            const bool two_per_cu = 2 * total <= kLdsPerCu, one_per_cu = total <= kLdsPerCu;
-            const bool small = (long)(grid > 0 ? grid : c->n_envs) <= kRectLdsMaxArenasPerCu * device_cu_count();
-            // a launch of at most one workgroup per CU (navsim_regen's first observations: a handful of lone scans, each as
-            // long as its probe chains) may take a CU's whole LDS
-            const bool lone = grid > 0 && grid <= device_cu_count();
-            if (c->rect_lds == 2 ? one_per_cu : ((two_per_cu && small) || (one_per_cu && lone))) {
-                p.block = b2; p.rect = 2; p.park = step_park_lanes(c, b2);
-                p.lds = base + table; p.rect_off = (unsigned)base;
-            }
-        }
+    // The index form of the arena's table staged in LDS (kernels_rect.hpp; round 4): 10 KB for a 500 x 500 map, so it fits at
+    // the residency the block size already implies -- eight 256-thread, four 512-thread or two 1024-thread workgroups per CU --
+    // and every probe reads LDS.  (Round 3 staged the 16-byte records, 63.5 KB: two workgroups per CU, small launches only.)
+    if (p.rect && st->rect_index && c->rect_lds != 1 && c->field_format == NAVSIM_FIELD_U16T) {
+        const size_t row = rect_index_row_bytes(c->map_h, c->map_w);
+        const size_t base = (p.lds + 15) & ~(size_t)15;
+        const size_t total = base + row + 1024;                     // + the kernel's static LDS, allocation granules
+        const int per_cu = p.block >= 1024 ? 2 : (p.block == 512 ? 4 : 8);
+        // a launch of at most one workgroup per CU (navsim_regen's first observations: a handful of lone scans) may take
+        // a CU's whole LDS
+        const bool lone = grid > 0 && grid <= device_cu_count();
+        const bool fits = c->rect_lds == 2 || lone ? total <= kLdsPerCu : (size_t)per_cu * total <= kLdsPerCu;
+        if (fits) { p.rect = 2; p.lds = base + row; p.rect_off = (unsigned)base; }
     }
     return p;
 }
@@ -236,9 +228,7 @@ int launch_step_rule(const navsim_config* c, const navsim_state* st, const navsi
 template <int BLOCK, bool PEDS, typename Field>
 int launch_step_field(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
                       const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
-    if constexpr (BLOCK >= 512) {                            // the LDS form exists for the wide workgroups only
-        if (p.rect == 2) return launch_step_rule<BLOCK, PEDS, Field, 2>(c, st, io, reset_only, mask, p, s, grid);
-    }
+    if (p.rect == 2) return launch_step_rule<BLOCK, PEDS, Field, 2>(c, st, io, reset_only, mask, p, s, grid);
     return p.rect ? launch_step_rule<BLOCK, PEDS, Field, 1>(c, st, io, reset_only, mask, p, s, grid)
                   : launch_step_rule<BLOCK, PEDS, Field, 0>(c, st, io, reset_only, mask, p, s, grid);
 }
@@ -377,6 +367,20 @@ int navsim_default_config(navsim_config* c) {
     c->ped_split = 0;
     c->seed = 1234;
     return NAVSIM_OK;
+}
+
+size_t navsim_rect_index_bytes(int32_t n_maps, int32_t H, int32_t W) {
+    if (n_maps <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)n_maps * rect_index_row_bytes(H, W);
+}
+
+int navsim_build_rect_index(const void* table, int32_t n_maps, int32_t H, int32_t W, void* index, int32_t* n_rects, void* stream) {
+    (void)hipGetLastError();
+    if (!table || !index || n_maps < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
+    if (H > 1024 || W > 1024) return NAVSIM_E_UNSUPPORTED;
+    if (n_maps == 0) return NAVSIM_OK;
+    rect_index_kernel<<<n_maps, 256, 0, (hipStream_t)stream>>>((const uint4*)table, H, W, (char*)index, n_rects, nullptr, nullptr);
+    return launch_status();
 }
 
 size_t navsim_sizeof_config(void) { return sizeof(navsim_config); }
@@ -566,6 +570,7 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
     if (c->action_kind == NAVSIM_ACTION_WHEELS && !(c->wheel_track > 0.0)) return NAVSIM_E_ARG;
     if (c->ped_model != NAVSIM_PED_NONE && (c->max_waypoints < 1 || c->max_waypoints > NAVSIM_MAX_WAYPOINTS)) return NAVSIM_E_ARG;
     if (st->rect_table && (c->field_format != NAVSIM_FIELD_U16T || c->map_h > 1024 || c->map_w > 1024)) return NAVSIM_E_UNSUPPORTED;
+    if (st->rect_index && !st->rect_table) return NAVSIM_E_ARG;
     if (c->step_block != 0 && c->step_block != 64 && c->step_block != 256 && c->step_block != 512 &&
         c->step_block != 1024) return NAVSIM_E_ARG;
     if (c->ped_split < 0 || c->ped_split > 2 || c->rect_lds < 0 || c->rect_lds > 2) return NAVSIM_E_ARG;
@@ -732,6 +737,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     // generator's rectangles, regen_rect_records -- no search, no verification pass, no builder launches)
     const bool direct = !(c->regen_indoor_ratio > 0.0);
     uint4* direct_rects = (direct && st->rect_table) ? (uint4*)st->rect_table : nullptr;
+    char* direct_index = (direct_rects && st->rect_index) ? (char*)st->rect_index : nullptr;
     if (!direct) regen_indoor_kernel<<<M, 256, 0, s>>>(*c, *st, io->done, M, count, list, grids, kind);
     float* ovf_scratch = nullptr;                           // exact float plane of the new maps (large packed maps)
     if (c->field_format == NAVSIM_FIELD_U16T && st->field_overflow) {
@@ -746,7 +752,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     // maps and, for outdoor maps, their exact field from the geometry; corridor maps go through the distance transform
     regen_maps_kernel<<<regen_grid(M), 256, 0, s>>>(*c, *st, count, list, need_occ ? occ : nullptr, grids, kind,
                                                             fscratch, fbytes, ovf_scratch, direct ? 1 : 0,
-                                                            direct ? io->done : nullptr, M, direct_rects);
+                                                            direct ? io->done : nullptr, M, direct_rects, direct_index);
     if (c->regen_indoor_ratio > 0.0) {
         dt_columns_kernel<<<dim3((W + 63) / 64, M), 64 * kColSeg, 0, s>>>(occ, cols, H, W, count, kind);
         if (c->field_format == NAVSIM_FIELD_F32)
@@ -760,6 +766,8 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         off += navsim_build_rects_workspace_bytes(M, H, W) + 256;
         launch_build_rects(occ, M, H, W, fscratch, fbytes, c->field_format, ovf_scratch, (uint4*)st->rect_table, rect_ws,
                            count, list, s);
+        if (st->rect_index)
+            rect_index_kernel<<<M, 256, 0, s>>>((const uint4*)st->rect_table, H, W, (char*)st->rect_index, nullptr, count, list);
     }
     if (!direct) {
         regen_field_kernel<<<regen_grid(M), 256, 0, s>>>((char*)st->field, count, list, fscratch, fbytes);
@@ -832,18 +840,19 @@ int navsim_regen_swap(const navsim_config* c, const navsim_state* live, const na
         return NAVSIM_E_ARG;
     // the two states must hold the same optional buffers
     if ((live->field_overflow != nullptr) != (stage->field_overflow != nullptr) ||
-        (live->rect_table != nullptr) != (stage->rect_table != nullptr) ||
+        (live->rect_table != nullptr) != (stage->rect_table != nullptr) || (live->rect_index != nullptr) != (stage->rect_index != nullptr) ||
         (live->costmap != nullptr) != (stage->costmap != nullptr) || (live->ped_goal != nullptr) != (stage->ped_goal != nullptr))
         return NAVSIM_E_ARG;
     if (c->n_envs == 0) return NAVSIM_OK;
     const int H = c->map_h, W = c->map_w;
-    SwapBig big[4] = {};
+    SwapBig big[5] = {};
     big[0] = {(char*)live->field, (const char*)stage->field, navsim_field_bytes(1, H, W, c->field_format)};
     if (live->field_overflow) big[1] = {(char*)live->field_overflow, (const char*)stage->field_overflow, (size_t)H * W * sizeof(float)};
     if (live->rect_table) big[2] = {(char*)live->rect_table, (const char*)stage->rect_table, navsim_rect_table_bytes(1, H, W)};
     if (live->costmap) big[3] = {(char*)live->costmap, (const char*)stage->costmap, (size_t)(H / 5) * (W / 5)};
+    if (live->rect_index) big[4] = {(char*)live->rect_index, (const char*)stage->rect_index, rect_index_row_bytes(H, W)};
     regen_swap_kernel<<<dim3(c->regen_cap, kRegenSlices), 256, 0, (hipStream_t)stream>>>(*c, *live, *stage, *io, stage_obs, want, mark,
-                                                                                        c->regen_cap, big[0], big[1], big[2], big[3]);
+                                                                                        c->regen_cap, big[0], big[1], big[2], big[3], big[4]);
     return launch_status();
 }
 

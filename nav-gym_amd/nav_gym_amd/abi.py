@@ -144,7 +144,7 @@ class NavsimState(C.Structure):
         "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist", "ped_v_pref", "ped_has_legs",
         "ped_waypoints", "ped_n_waypoints", "ped_cmd",
         "spawn_pose", "spawn_goal", "costmap", "arena_cost", "launch_order", "regen_draws",
-        "ped_goal", "counters",
+        "ped_goal", "counters", "rect_index",
     )]
 
 
@@ -227,6 +227,7 @@ STATE_LAYOUT = {
     "regen_draws": ("float64", ("E", 464)),         # tests only: draws supplied (NAVSIM_DRAW_* layout)
     "ped_goal": ("float64", ("E", "N", 2)),         # goal of every pedestrian's current route
     "counters": ("int64", (N_COUNTERS,)),           # uint64 on the device; the totals stay far below 2^63
+    "rect_index": ("uint8", ("E", "R")),            # index form of rect_table: 256 rectangles x 8 B + 2 B per tile, per arena
 }
 
 IO_LAYOUT = {
@@ -243,6 +244,11 @@ IO_LAYOUT = {
 }
 
 
+def rect_index_row_bytes(H, W):
+    """navsim_rect_index_bytes(1, H, W): 256 list entries of 8 bytes, then 2 bytes per 8x8 tile (padded to 16)."""
+    return 256 * 8 + ((((H + 7) // 8) * ((W + 7) // 8) * 2 + 15) // 16) * 16
+
+
 def resolve_shape(shape, cfg):
     """Turns a symbolic shape of STATE_LAYOUT / IO_LAYOUT into integers for `cfg`."""
     sym = {
@@ -250,6 +256,7 @@ def resolve_shape(shape, cfg):
         "K": max(cfg.n_spawn, 1), "P": cfg.max_waypoints, "H": cfg.map_h, "W": cfg.map_w,
         "D": cfg.n_scan_stack * cfg.n_beams + OBS_TAIL, "Hc": cfg.map_h // 5, "Wc": cfg.map_w // 5,
         "T": ((cfg.map_h + 7) // 8) * ((cfg.map_w + 7) // 8),
+        "R": rect_index_row_bytes(cfg.map_h, cfg.map_w),
     }
     return tuple(sym[s] if isinstance(s, str) else s for s in shape)
 
@@ -280,6 +287,8 @@ def declare(lib, suffix=""):
         sig("navsim_rect_table_bytes", [i32, i32, i32], C.c_size_t)
         sig("navsim_build_rects_workspace_bytes", [i32, i32, i32], C.c_size_t)
         sig("navsim_build_rects", [_P, i32, i32, i32, _P, i32, _P, _P, _P, C.c_size_t, _P])
+        sig("navsim_rect_index_bytes", [i32, i32, i32], C.c_size_t)
+        sig("navsim_build_rect_index", [_P, i32, i32, i32, _P, _P, _P])
     sig("navsim_cast_static", [_P, i32, i32, i32, _P, i32, f32, i32, _P] + stream)
     sig("navsim_render_polys", [_P, _P, i32, i32, _P, _P, i32, _P] + stream)
     sig("navsim_render_legs", [_P, _P, i32, i32, _P, _P, i32, _P] + stream)
@@ -322,6 +331,7 @@ EXPORTS = (
     "navsim_abi_version", "navsim_error_string", "navsim_last_hip_error", "navsim_default_config",
     "navsim_build_dt_workspace_bytes", "navsim_build_dt", "navsim_field_bytes", "navsim_build_field",
     "navsim_rect_table_bytes", "navsim_build_rects_workspace_bytes", "navsim_build_rects",
+    "navsim_rect_index_bytes", "navsim_build_rect_index",
     "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
     "navsim_scan_threshold", "navsim_beam_table", "navsim_ped_scans", "navsim_regen_workspace_bytes", "navsim_regen", "navsim_regen_swap", "navsim_regen_stage",

@@ -32,6 +32,18 @@ def _stream():
 
 
 # ---- thin functional wrappers over the mirror primitives (used by tests and by NavSim) ----------
+def build_rect_index(table, H, W):
+    """navsim_build_rect_index: the index form of a record table (int32 CUDA [E, T, 4] from build_rects) -> (uint8 [E, R] rows,
+    int32 [E] distinct rectangles per map).  What the fused step stages in LDS (navsim_state.rect_index)."""
+    torch = require_gpu()
+    L = load()
+    E = table.shape[0]
+    rows = torch.empty((E, L.navsim_rect_index_bytes(1, H, W)), dtype=torch.uint8, device=table.device)
+    n_rects = torch.zeros(E, dtype=torch.int32, device=table.device)
+    check(L.navsim_build_rect_index(_ptr(table), E, H, W, _ptr(rows), _ptr(n_rects), _stream()), "navsim_build_rect_index")
+    return rows, n_rects
+
+
 def build_dt(occ):
     """occ: uint8 CUDA tensor [E,H,W] (nonzero = occupied) -> float32 distance field [E,H,W]."""
     torch = require_gpu()
@@ -425,7 +437,7 @@ class NavSim(object):
         return self.obs, self.out
 
     # arrays navsim_regen writes: the staged state of enable_pregen() owns a copy of each
-    STAGED = ("field", "field_overflow", "rect_table", "costmap", "scan_noise_std", "robot_pose", "robot_goal", "prev_action",
+    STAGED = ("field", "field_overflow", "rect_table", "rect_index", "costmap", "scan_noise_std", "robot_pose", "robot_goal", "prev_action",
               "prev_pose", "n_hist", "steps", "episode", "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist",
               "ped_v_pref", "ped_has_legs", "ped_waypoints", "ped_n_waypoints", "ped_goal", "spawn_pose", "spawn_goal")
 

@@ -152,6 +152,7 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
                 rect_table = max(H0, W0) <= 1024
             if rect_table and cfg.field_format == abi.FIELD_U16T:
                 a["rect_table"] = sim.build_rects(occ_t, packed, cfg.field_format, f32)
+                a["rect_index"], _ = sim.build_rect_index(a["rect_table"], H0, W0)    # what the step stages in LDS
         if plan_paths:
             a["costmap"] = sim.costmap(occ_t)
         del occ_t
@@ -270,6 +271,7 @@ def empty_world(cfg, device="cuda:0", plan_paths=False, rect_table=False):
         if rect_table:
             a["rect_table"] = z((E, ((H + 7) // 8) * ((W + 7) // 8), 4), torch.int32)
             a["rect_table"][:, :, 0] = 0x7FFF                  # "no valid record" until the builder has run
+            a["rect_index"] = torch.full((E, abi.rect_index_row_bytes(H, W)), 255, dtype=torch.uint8, device=dev)   # no index either
     if plan_paths:
         a["costmap"] = z((E, H // 5, W // 5), torch.uint8)
     a["spawn_pose"] = z((E, K, 3), torch.float64)

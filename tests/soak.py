@@ -25,7 +25,7 @@ def run_soak(steps, E, peds=False, size=500, log=None):
         arrays = world.make_world(cfg, occ, n_peds=20 if peds else 0, device=dev)
         for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
             arrays[key] = sim.scan_threshold(cfg, torch.from_numpy(robots.footprint_array("keti", name)).to(dev))
-        host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "rect_table")}
+        host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "rect_table", "rect_index")}
         host["field"] = ref.build_dt(occ)
         g = sim.NavSim(cfg, arrays)
         r = ref.RefSim(cfg, host)

@@ -308,7 +308,7 @@ def _rollout_pair(gpu, cfg, occ, n_peds, steps, seed, noise=False, policy=None, 
     from nav_gym_amd import robots
     arrays["scan_threshold"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array(key, "threshold_footprint")))
     arrays["scan_discomfort"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array(key, "discomfort_threshold_footprint")))
-    host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "rect_table")}
+    host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "rect_table", "rect_index")}
     host["field"] = ref.build_dt(occ)                 # the oracle always reads its own float32 field
     g = gpu.sim.NavSim(cfg, arrays)
     r = ref.RefSim(cfg, host)
@@ -360,7 +360,7 @@ def test_step_rollout_vs_oracle(gpu, ped_model, S, auto_reset, fmt):
         if t % 10 == 9:
             gs = g.numpy_state()
             for k, v in r.a.items():
-                if k in gs and k not in ("field", "field_overflow", "rect_table"):
+                if k in gs and k not in ("field", "field_overflow", "rect_table", "rect_index"):
                     _eq(gs[k], v, "state %s at step %d" % (k, t))
     assert crashes > 0, "rollout never exercised the crash-revert branch"
     assert resets > 0
@@ -389,7 +389,7 @@ def test_step_rollout_256_threads_parked_rays(gpu, fmt, S):
         crashes += int(rout["is_crash"].sum()); resets += int(rout["done"].sum())
     gs = g.numpy_state()
     for k, v in r.a.items():
-        if k in gs and k not in ("field", "field_overflow", "rect_table"):
+        if k in gs and k not in ("field", "field_overflow", "rect_table", "rect_index"):
             _eq(gs[k], v, "state %s at the end" % k)
     assert crashes > 0 and resets > 0
 
@@ -410,7 +410,7 @@ def test_step_rollout_with_split_pedestrian_kernel(gpu, ped_model):
         _eq(go, ro, "obs at step %d" % t)
     gs = g.numpy_state()
     for k, v in r.a.items():
-        if k in gs and k not in ("field", "field_overflow", "rect_table"):
+        if k in gs and k not in ("field", "field_overflow", "rect_table", "rect_index"):
             _eq(gs[k], v, "state %s" % k)
 
 
@@ -451,7 +451,7 @@ def test_step_fuzzed_configurations(gpu, seed):
         _eq(go, ro, "obs at step %d" % t)
     gs = g.numpy_state()
     for k, v in r.a.items():
-        if k in gs and k not in ("field", "field_overflow", "rect_table"):
+        if k in gs and k not in ("field", "field_overflow", "rect_table", "rect_index"):
             _eq(gs[k], v, "state %s" % k)
 
 
@@ -576,7 +576,7 @@ def test_regen_vs_oracle(gpu, fmt, ped_model, plan):
         if n_done:
             gs = g.numpy_state()
             for k, v in r.a.items():
-                if k in gs and k not in ("field", "field_overflow", "rect_table"):
+                if k in gs and k not in ("field", "field_overflow", "rect_table", "rect_index"):
                     _eq(gs[k], v, "state %s after regen at step %d" % (k, t))
             if fmt == abi.FIELD_F32:
                 _eq(gs["field"], r.a["field"], "field after regen at step %d" % t)
@@ -626,7 +626,7 @@ def test_pregenerated_worlds_equal_navsim_regen(gpu, fmt, ped_model, plan):
             gpu.torch.cuda.synchronize()
             gs = g.numpy_state()
             for k, v in r.a.items():
-                if k in gs and k not in ("field", "field_overflow", "rect_table"):
+                if k in gs and k not in ("field", "field_overflow", "rect_table", "rect_index"):
                     if k == "ped_waypoints":      # slots beyond n_waypoints keep whatever the buffer held before
                         live = np.arange(cfg.max_waypoints)[None, None, :] < r.a["ped_n_waypoints"][..., None]
                         _eq(gs[k][live], v[live], "state %s after the swap at step %d" % (k, t))
@@ -656,7 +656,7 @@ def test_env_reset_at_the_reference_map_size(gpu):
     for e in (0, 5, 11):
         c1 = cfg.copy(); c1.n_envs = 1; c1.env_index_base = int(e); c1.regen_cap = 1
         host = {k: v.cpu().numpy() for k, v in gpu.world.empty_world(c1, device="cpu", plan_paths=True).items()
-                if k not in ("field", "field_overflow", "rect_table")}
+                if k not in ("field", "field_overflow", "rect_table", "rect_index")}
         host["field"] = np.zeros((1, size, size), np.float32)
         host["scan_threshold"] = env.scan_threshold.cpu().numpy(); host["scan_discomfort"] = env.scan_discomfort_threshold.cpu().numpy()
         r = ref.RefSim(c1, host)
@@ -707,7 +707,7 @@ def test_reset_path_fuzzed(gpu, seed):
             g.replan(4); r.replan(4)
     gs = g.numpy_state()
     for k, v in r.a.items():
-        if k in gs and k not in ("field", "field_overflow", "rect_table"):
+        if k in gs and k not in ("field", "field_overflow", "rect_table", "rect_index"):
             if k == "ped_waypoints":
                 live = np.arange(cfg.max_waypoints)[None, None, :] < r.a["ped_n_waypoints"][..., None]
                 _eq(gs[k][live], v[live], "state %s" % k)
@@ -735,7 +735,7 @@ def test_regen_odd_map_size(gpu, fmt):
         _eq(g.regen().cpu().numpy(), r.regen(), "obs after regen at step %d" % t)
     gs = g.numpy_state()
     for k, v in r.a.items():
-        if k in gs and k not in ("field", "field_overflow", "rect_table"):
+        if k in gs and k not in ("field", "field_overflow", "rect_table", "rect_index"):
             _eq(gs[k], v, "state %s" % k)
     if fmt == abi.FIELD_F32:
         _eq(gs["field"], r.a["field"], "field")
@@ -806,7 +806,7 @@ def test_long_routes_on_the_device(gpu, golden_dir):
 def _state_equal(g, r, cfg, what, skip=()):
     gs = g.numpy_state()
     for k, v in r.a.items():
-        if k not in gs or k in ("field", "field_overflow", "rect_table") or k in skip:
+        if k not in gs or k in ("field", "field_overflow", "rect_table", "rect_index") or k in skip:
             continue
         if k == "ped_waypoints":                  # slots beyond n_waypoints keep whatever the buffer held before
             live = np.arange(cfg.max_waypoints)[None, None, :] < r.a["ped_n_waypoints"][..., None]
@@ -918,7 +918,7 @@ def test_wheel_speed_actions(gpu, clamp):
     arrays = gpu.world.make_world(cfg_w, occ, n_peds=3, device=gpu.dev)
     arrays["scan_threshold"] = gpu.sim.scan_threshold(cfg_w, _t(gpu, robots.footprint_array("husky", "threshold_footprint")))
     arrays["scan_discomfort"] = gpu.sim.scan_threshold(cfg_w, _t(gpu, robots.footprint_array("husky", "discomfort_threshold_footprint")))
-    host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "rect_table")}
+    host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "rect_table", "rect_index")}
     host["field"] = ref.build_dt(occ)
     gw, gt, r = gpu.sim.NavSim(cfg_w, arrays), gpu.sim.NavSim(cfg_t, arrays), ref.RefSim(cfg_w, host)
     _eq(gw.reset_obs().cpu().numpy(), r.reset_obs(), "reset obs"); gt.reset_obs()
@@ -974,7 +974,7 @@ def test_policy_closed_loop_vs_oracle(gpu, fmt):
         if t % 4 == 3:
             gs = g.numpy_state()
             for k, v in r.a.items():
-                if k in gs and k not in ("field", "field_overflow", "rect_table"):
+                if k in gs and k not in ("field", "field_overflow", "rect_table", "rect_index"):
                     _eq(gs[k], v, "state %s at step %d" % (k, t))
     m = r.prev_actions[:, :17]
     assert (m[..., 0] > 0).all() and (m[..., 0] < 1).all() and np.abs(m[..., 1]).max() < 1 and m.std() > 1e-3
@@ -1448,7 +1448,7 @@ def test_full_size_c2_properties_and_sampled_oracle(gpu, full_c2):
         c1 = sub_cfg.copy(); c1.env_index_base = int(e)
         host = {}
         for k, t in sim.t.items():
-            if k in ("field", "field_overflow", "rect_table", "beam_table", "arena_cost", "launch_order", "regen_ws", "counters", "job_board"):
+            if k in ("field", "field_overflow", "rect_table", "beam_table", "arena_cost", "launch_order", "regen_ws", "counters"):
                 continue                              # (counters, job board: per simulator, not per arena)
             a = t.detach().cpu().numpy()
             host[k] = a if k in ("scan_threshold", "scan_discomfort") else a[e:e + 1]
@@ -1514,7 +1514,7 @@ def test_full_size_c2_determinism_and_shard_invariance(gpu, full_c2):
         c = cfg.copy(); c.n_envs = hi - lo; c.env_index_base = base
         arr = {}
         for k, v in state0.items():
-            if k in ("arena_cost", "launch_order", "counters", "job_board"):      # scheduling hints / totals: each NavSim owns its own
+            if k in ("arena_cost", "launch_order", "counters"):      # scheduling hints / totals: each NavSim owns its own
                 continue
             if k == "field":
                 per = v.numel() // E
@@ -1566,7 +1566,7 @@ def test_regen_writes_the_rect_records_of_outdoor_maps_from_the_generator(gpu, s
         if n_done:
             gs = g.numpy_state()
             for k, v in r.a.items():
-                if k in gs and k not in ("field", "field_overflow", "rect_table"):
+                if k in gs and k not in ("field", "field_overflow", "rect_table", "rect_index"):
                     _eq(gs[k], v, "state %s after regen at step %d" % (k, t))
             d2, valid = _decode_rect_table(g.t["rect_table"].cpu().numpy(), size, size)
             exact = np.rint(r.a["field"].astype(np.float64) ** 2).astype(np.int64)
@@ -1817,7 +1817,7 @@ def test_edge_shapes(gpu):
     from nav_gym_amd import robots
     arrays["scan_threshold"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array("keti", "threshold_footprint")))
     arrays["scan_discomfort"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array("keti", "discomfort_threshold_footprint")))
-    host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "rect_table")}
+    host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "rect_table", "rect_index")}
     host["field"] = ref.build_dt(occ)
     g = gpu.sim.NavSim(cfg, arrays); r = ref.RefSim(cfg, host)
     _eq(g.reset_obs().cpu().numpy(), r.reset_obs(), "reset obs")
