@@ -196,6 +196,13 @@ typedef struct navsim_config {
     int32_t clamp_action;
     double wheel_radius, wheel_track;
     double linvel_lo, linvel_hi, rotvel_lo, rotvel_hi;   /* __init__.py:12-13 linvel_range, rotvel_range */
+    int32_t closed_maps;              /* 1 = the caller asserts that EVERY map of the world has a ring of at least 3 occupied cells
+                                         around it (all of the reference's maps have 5, map_generator.py:11, 61-93; every map
+                                         navsim_regen draws is closed): set it from navsim_maps_closed's answers.
+                                         The LDS form of the march (navsim_state.rect_index) needs it -- a ray of a closed map
+                                         never leaves the map, so that form carries no bounds test -- and is not used without.
+                                         A wrong assertion reads outside the tables. */
+    int32_t reserved1;
 } navsim_config;
 
 #define NAVSIM_ACTION_TWIST  0   /* io->action = (v, omega): the reference's action (env.py:591) */
@@ -365,6 +372,9 @@ size_t navsim_rect_table_bytes(int32_t n_maps, int32_t map_h, int32_t map_w);
 size_t navsim_rect_index_bytes(int32_t n_maps, int32_t map_h, int32_t map_w);
 int    navsim_build_rect_index(const void* table, int32_t n_maps, int32_t map_h, int32_t map_w, void* index,
                                int32_t* n_rects, void* stream);
+/* closed [n_maps] int32: 1 where every cell of the map's outer ring of 3 cells is occupied (navsim_config.closed_maps may
+ * be set when all are 1). */
+int    navsim_maps_closed(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t map_w, int32_t* closed, void* stream);
 size_t navsim_build_rects_workspace_bytes(int32_t n_maps, int32_t map_h, int32_t map_w);
 int    navsim_build_rects(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t map_w, const void* field,
                           int32_t format, const float* overflow, void* table, void* workspace, size_t workspace_bytes,

@@ -74,8 +74,8 @@ __host__ __device__ inline size_t rect_index_row_bytes(int H, int W) {
 // insertion; no result depends on it.
 constexpr int kRectHash = 1024;
 __global__ __launch_bounds__(256) void rect_index_kernel(const uint4* __restrict__ table, int H, int W, char* __restrict__ rows,
-                                                         int32_t* __restrict__ n_rects, const int* __restrict__ n_live,
-                                                         const int* __restrict__ list) {
+                                                         int32_t* __restrict__ n_rects,
+                                                         const int* __restrict__ n_live, const int* __restrict__ list) {
     __shared__ unsigned long long keys[kRectHash];
     __shared__ unsigned short rank_s[kRectHash];
     __shared__ int wave_tot[4];
@@ -147,6 +147,28 @@ __global__ __launch_bounds__(256) void rect_index_kernel(const uint4* __restrict
         }
         pair[t] = (uint16_t)p;
     }
+}
+
+// navsim_maps_closed: is every cell of the map's outer ring of kRectClosedRing cells occupied?  One workgroup per map.
+// (What cfg.closed_maps may be set from: the LDS form of the march carries no bounds test, kernels_step.hpp probe_round.)
+constexpr int kRectClosedRing = 3;
+__global__ __launch_bounds__(256) void maps_closed_kernel(const uint8_t* __restrict__ occ, int H, int W, int32_t* __restrict__ closed) {
+    const int m = blockIdx.x, tid = threadIdx.x, ring = kRectClosedRing;
+    const uint8_t* o = occ + (size_t)m * H * W;
+    int open_cells = 0;
+    if (H <= 2 * ring || W <= 2 * ring) open_cells = 1;
+    else {
+        // the ring as 2 * ring full rows + 2 * ring columns of the rows in between
+        const int n_row_cells = 2 * ring * W, n_col_cells = 2 * ring * (H - 2 * ring);
+        for (int k = tid; k < n_row_cells + n_col_cells; k += 256) {
+            int x, y;
+            if (k < n_row_cells) { const int r = k / W; x = k - r * W; y = r < ring ? r : H - 2 * ring + r; }
+            else { const int q = k - n_row_cells, r = q / (2 * ring), cidx = q - r * 2 * ring; y = ring + r; x = cidx < ring ? cidx : W - 2 * ring + cidx; }
+            if (!o[(size_t)y * W + x]) open_cells = 1;
+        }
+    }
+    open_cells = __syncthreads_or(open_cells);
+    if (tid == 0) closed[m] = open_cells ? 0 : 1;
 }
 
 // ---- builder pass 1: transpose of the occupancy grid (32x32 tiles through LDS), so that the vertical runs can be

@@ -173,7 +173,7 @@ StepPlan plan_step(const navsim_config* c, const navsim_state* st, int grid = 0)
     // The index form of the arena's table staged in LDS (kernels_rect.hpp; round 4): 10 KB for a 500 x 500 map, so it fits at
     // the residency the block size already implies -- eight 256-thread, four 512-thread or two 1024-thread workgroups per CU --
     // and every probe reads LDS.  (Round 3 staged the 16-byte records, 63.5 KB: two workgroups per CU, small launches only.)
-    if (p.rect && st->rect_index && c->rect_lds != 1 && c->field_format == NAVSIM_FIELD_U16T) {
+    if (p.rect && st->rect_index && c->closed_maps && c->rect_lds != 1 && c->field_format == NAVSIM_FIELD_U16T) {
         const size_t row = rect_index_row_bytes(c->map_h, c->map_w);
         const size_t base = (p.lds + 15) & ~(size_t)15;
         const size_t total = base + row + 1024;                     // + the kernel's static LDS, allocation granules
@@ -361,6 +361,7 @@ int navsim_default_config(navsim_config* c) {
     c->wheel_track = 0.5708;                   // husky.urdf.xacro:62
     c->linvel_lo = 0.0; c->linvel_hi = 0.5;    // __init__.py:12
     c->rotvel_lo = -0.64; c->rotvel_hi = 0.64; // __init__.py:13
+    c->closed_maps = 0;
     c->regen_check_discomfort = 1;          // env.py:776-781
     c->rect_lds = 0;
     c->step_block = 0;
@@ -380,6 +381,14 @@ int navsim_build_rect_index(const void* table, int32_t n_maps, int32_t H, int32_
     if (H > 1024 || W > 1024) return NAVSIM_E_UNSUPPORTED;
     if (n_maps == 0) return NAVSIM_OK;
     rect_index_kernel<<<n_maps, 256, 0, (hipStream_t)stream>>>((const uint4*)table, H, W, (char*)index, n_rects, nullptr, nullptr);
+    return launch_status();
+}
+
+int navsim_maps_closed(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W, int32_t* closed, void* stream) {
+    (void)hipGetLastError();
+    if (!occ || !closed || n_maps < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
+    if (n_maps == 0) return NAVSIM_OK;
+    maps_closed_kernel<<<n_maps, 256, 0, (hipStream_t)stream>>>(occ, H, W, closed);
     return launch_status();
 }
 

@@ -282,6 +282,9 @@ class NavGymEnv(object):
                                        rect_table=with_rects)
             for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
                 arrays[key] = simmod.scan_threshold(cfg, torch.from_numpy(robots.footprint_array(self.robot_type, name)).to(dev))
+            # every map of this world comes from navsim_regen, whose generators close their maps with a border wall
+            # (map_generator.py:11, 61-93): the LDS form of the march may be used (include/navsim.h closed_maps)
+            cfg.closed_maps = int("rect_index" in arrays)
             self.sim = simmod.NavSim(cfg, arrays, device=self.device)
             self.scan_threshold = arrays["scan_threshold"]
             self.scan_discomfort_threshold = arrays["scan_discomfort"]

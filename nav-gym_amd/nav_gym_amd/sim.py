@@ -44,6 +44,17 @@ def build_rect_index(table, H, W):
     return rows, n_rects
 
 
+def maps_closed(occ):
+    """navsim_maps_closed: occ uint8 CUDA [E,H,W] -> int32 [E], 1 where the map's outer ring of 3 cells is fully occupied.
+    cfg.closed_maps may be set when every map of a world is closed (the LDS form of the march has no bounds test)."""
+    torch = require_gpu()
+    occ = occ.to(torch.uint8).contiguous()
+    E, H, W = occ.shape
+    closed = torch.zeros(E, dtype=torch.int32, device=occ.device)
+    check(load().navsim_maps_closed(_ptr(occ), E, H, W, _ptr(closed), _stream()), "navsim_maps_closed")
+    return closed
+
+
 def build_dt(occ):
     """occ: uint8 CUDA tensor [E,H,W] (nonzero = occupied) -> float32 distance field [E,H,W]."""
     torch = require_gpu()

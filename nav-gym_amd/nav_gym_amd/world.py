@@ -153,6 +153,9 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
             if rect_table and cfg.field_format == abi.FIELD_U16T:
                 a["rect_table"] = sim.build_rects(occ_t, packed, cfg.field_format, f32)
                 a["rect_index"], _ = sim.build_rect_index(a["rect_table"], H0, W0)    # what the step stages in LDS
+                # the LDS form of the march needs closed maps (include/navsim.h closed_maps): asserted only when the library
+                # has found every map of this world closed
+                cfg.closed_maps = int(bool((sim.maps_closed(occ_t) == 1).all().item()))
         if plan_paths:
             a["costmap"] = sim.costmap(occ_t)
         del occ_t

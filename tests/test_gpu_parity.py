@@ -1662,6 +1662,73 @@ def test_rect_table_on_arbitrary_maps(gpu):
             _eq(gout[k], rout[k], "%s at step %d" % (k, t))
 
 
+def _decode_rect_index(rows, H, W):
+    """Host evaluation of the index form (navsim_build_rect_index): rows uint8 [E, R] -> the 16-byte records it stands for
+    (uint32 [E, T, 4]) and which tiles carry an index."""
+    E = rows.shape[0]
+    T_ = ((H + 7) // 8) * ((W + 7) // 8)
+    lst = rows[:, :2048].copy().view(np.uint32).reshape(E, 256, 2)
+    pair = rows[:, 2048:2048 + 2 * T_].copy().view(np.uint16).reshape(E, T_)
+    has = pair != 0xFFFF
+    ia, ib = (pair & 0xFF).astype(np.int64), (pair >> 8).astype(np.int64)
+    rec = np.zeros((E, T_, 4), np.uint32)
+    ar = np.arange(E)[:, None]
+    rec[..., 0:2] = lst[ar, ia]; rec[..., 2:4] = lst[ar, ib]
+    return rec, has
+
+
+@pytest.mark.parametrize("size,indoor", [(500, 0.0), (500, 1.0), (253, 0.5), (1000, 1.0)])
+def test_rect_index_is_the_record_table(gpu, size, indoor):
+    """Round 4, "map tiles staged through LDS": the index form of an arena's record table -- the distinct rectangles of its
+    records and two list indices per tile, 10 KB for 500 x 500 -- names, for every tile that has an index, exactly the two
+    rectangles of the tile's 16-byte record; every valid record of the reference's kind of maps gets one (the lists hold
+    14 rectangles for an outdoor map, a few dozen to ~200 for a corridor map); closed maps are recognised."""
+    n = 3 if size <= 500 else 1
+    occ = gpu.world.make_maps(n, size, 9 + size, indoor_ratio=indoor)
+    field, f32, _ = gpu.sim.build_field(_t(gpu, occ), abi.FIELD_U16T)
+    table = gpu.sim.build_rects(_t(gpu, occ), field, abi.FIELD_U16T, f32)
+    rows, n_rects = gpu.sim.build_rect_index(table, size, size)
+    closed = gpu.sim.maps_closed(_t(gpu, occ))
+    assert rows.shape[1] == abi.rect_index_row_bytes(size, size) == gpu.lib.load().navsim_rect_index_bytes(1, size, size)
+    rec, has = _decode_rect_index(rows.cpu().numpy(), size, size)
+    tab = table.cpu().numpy().view(np.uint32).reshape(n, -1, 4)
+    valid = (tab[..., 0] & 0xFFFF) != 0x7FFF
+    assert not (has & ~valid).any()                                  # an index only where there is a valid record
+    _eq(rec[has], tab[has], "records named by the index rows")
+    nr = n_rects.cpu().numpy()
+    assert (nr >= 5).all()
+    if (nr <= 255).all():
+        assert np.array_equal(has, valid), "every valid record has an index"
+    assert (closed.cpu().numpy() == 1).all(), "the reference's maps are closed"
+    # a gap in the border wall: not closed
+    occ2 = occ.copy(); occ2[0, :8, 40:60] = 0
+    occ2[-1, 100, size - 3] = 0                                      # one cell of the ring's inner layer
+    c2 = gpu.sim.maps_closed(_t(gpu, occ2)).cpu().numpy()
+    assert c2[0] == 0 and c2[-1] == 0 and (c2[1:-1] == 1).all()
+
+
+def test_open_maps_keep_the_bounds_test(gpu):
+    """A world with a gap in a border wall is not closed (cfg.closed_maps = 0 after make_world): the LDS form of the march,
+    which carries no bounds test, is not used, rays leave the map through the gap (range_max), and the rollout equals
+    the oracle bit for bit.  The same world with the gap filled is closed and takes the LDS form: also bit for bit."""
+    E, size = 12, 200
+    for gap in (True, False):
+        occ = gpu.world.make_maps(E, size, 61)
+        if gap:
+            occ[:, 60:140, :8] = 0                                   # the west wall is open for four metres
+        cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, n_spawn=6, auto_reset=1, seed=61, field_format=abi.FIELD_U16T)
+        gpu.world.lidar_1081(cfg)
+        left_the_map = 0
+        for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=0, steps=30, seed=6, min_goal_dist=2.0,
+                                                         max_goal_dist=6.0, robot_clearance=0.6):
+            _eq(go, ro, "obs at step %d (gap %s)" % (t, gap))
+            for k in rout:
+                _eq(gout[k], rout[k], "%s at step %d" % (k, t))
+            left_the_map += int((go[:, :1081] == 25.0).sum())
+        assert "rect_index" in g.t and g.cfg.closed_maps == (0 if gap else 1)
+        assert (left_the_map > 0) == gap
+
+
 @pytest.mark.parametrize("size,indoor", [(400, 0.0), (500, 1.0), (1000, 1.0)])
 def test_costmap_and_planner_vs_oracle(gpu, size, indoor):
     """Reset path: costmap (env.py:312-332) and shortest-path waypoints (env.py:343-354, 1261-1277) on
