@@ -349,15 +349,20 @@ __device__ __forceinline__ void probe_round(const Field& field, const char* __re
         if constexpr (RECT == 2) {
             // the arena's row in LDS: ds_read_u16 of the tile's index pair, then the two rectangles (ds_read_b64 each; most
             // lanes of a wavefront name the same few list entries: broadcast reads)
-            typedef __attribute__((address_space(3))) const char lds_char;
-            typedef __attribute__((address_space(3))) const unsigned short lds_u16;
+            // The row starts the dynamic LDS, so every address below is a register plus an immediate.  The two indices are
+            // read as bytes (ds_read_u8 x2: an index then needs one shift to become its rectangle's address; unpacking a
+            // ds_read_u16 took five vector instructions -- the LDS port is idle, the vector unit is what a round waits for).
+            // (the compiler fuses the two byte loads into one ds_read_u16 and unpacks it with and / shift / two shift-adds: four
+            // instructions; written out as two ds_read_u8 it is three, measured +1 % on c2 and -0.6 % on c4: left to the compiler)
+            typedef __attribute__((address_space(3))) const unsigned char lds_u8;
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             typedef __attribute__((address_space(3))) const u32x2 lds_u2;
-            const unsigned pair = *(lds_u16*)((lds_char*)rects + kRectListLen * 8 + tile * 2u);
-            const u32x2 ra = *(lds_u2*)((lds_char*)rects + (pair & 0xFFu) * 8u);
-            const u32x2 rb = *(lds_u2*)((lds_char*)rects + (pair >> 8) * 8u);
+            lds_u8* row = (lds_u8*)rects;
+            const unsigned ia = row[kRectListLen * 8 + tile * 2u], ib = row[kRectListLen * 8 + 1 + tile * 2u];
+            const u32x2 ra = *(lds_u2*)(row + ia * 8u);
+            const u32x2 rb = *(lds_u2*)(row + ib * 8u);
             rec.x = ra.x; rec.y = ra.y; rec.z = rb.x; rec.w = rb.y;
-            inval = live & mask_eq(pair, kRectNoIndex);
+            inval = live & mask_eq(ia, 0xFFu);                       // no index: both bytes are 0xFF
         } else {
             // The load is written out: after a compiler-generated global_load_dwordx4 the register allocator moved three
             // of the four loaded dwords to other registers before using them (3 of 42 vector instructions per probe).
@@ -407,7 +412,10 @@ __device__ __forceinline__ float ray_result(lanemask_t hit, float x0, float y0, 
 // workgroup and loses to the second pass (c4 -8 %, c5 -4 %): parking is compiled into the 256-thread kernels only.  The
 // pedestrian variants park since the end of round 3 (park_lds_bytes: the parked ray lives in its own rng / dir slots):
 // c3 23.2 -> 24.0 M at 16 lanes (8: 23.6; 24 and 32, which cost the eighth arena of a CU its LDS: 23.2, 23.0).
-constexpr int kParkLanesMax = 16;
+#ifndef NAVSIM_PARK_LANES
+#define NAVSIM_PARK_LANES 16
+#endif
+constexpr int kParkLanesMax = NAVSIM_PARK_LANES;
 #ifndef NAVSIM_PARK_LANES_PEDS
 #define NAVSIM_PARK_LANES_PEDS 16
 #endif
@@ -850,8 +858,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     __shared__ StepShared sh;
     const int peds_done = (reset_only >> 1) & 1;     // the pedestrians were advanced by ped_update_kernel
     reset_only &= 1;
-    // dynamic LDS (pedestrian variants only): [float2 dir[B], float rng[B]][PedShared][pair table][rect records (RECT = 2)]
-    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+    // dynamic LDS: [the arena's index row (RECT = 2)][parked rays][pedestrian variants: float2 dir[B], float rng[B]][PedShared][pair table]
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds_all[];
+    char* dyn_lds = dyn_lds_all + (RECT == 2 ? rect_lds_offset : 0u);      // (rect_lds_offset = the row's size: the rest sits behind it)
     PedShared ps = {};
     if constexpr (PEDS) ps = ped_lds_carve(dyn_lds + ((dyn_lds_bytes + 15u) & ~15u), c.max_peds);
     const Prims prims = {ps.seg, ps.disc, ps.info};
@@ -871,7 +880,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         // "Map tiles staged through LDS": the INDEX form of the arena's record table (kernels_rect.hpp: 2 KB of distinct
         // rectangles + 2 bytes per 8x8 tile = 10 KB for 500 x 500 cells) is copied into LDS once, by all threads, beside
         // phase 0; every probe of the scans then reads LDS (~0.1 us) instead of global memory (0.5-2 us from L2 / HBM).
-        uint4* tab_lds = (uint4*)(dyn_lds + rect_lds_offset);
+        uint4* tab_lds = (uint4*)dyn_lds_all;
         const size_t row_bytes = rect_index_row_bytes(c.map_h, c.map_w);
         const uint4* src = (const uint4*)((const char*)st.rect_index + (size_t)(c.shared_field ? 0 : e) * row_bytes);
         for (int i = threadIdx.x; i < (int)(row_bytes / 16); i += BLOCK) tab_lds[i] = src[i];

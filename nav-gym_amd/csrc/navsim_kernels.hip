@@ -182,7 +182,7 @@ StepPlan plan_step(const navsim_config* c, const navsim_state* st, int grid = 0)
         // a CU's whole LDS
         const bool lone = grid > 0 && grid <= device_cu_count();
         const bool fits = c->rect_lds == 2 || lone ? total <= kLdsPerCu : (size_t)per_cu * total <= kLdsPerCu;
-        if (fits) { p.rect = 2; p.lds = base + row; p.rect_off = (unsigned)base; }
+        if (fits) { p.rect = 2; p.lds = base + row; p.rect_off = (unsigned)row; }     // the row comes first, everything else behind it
     }
     return p;
 }
