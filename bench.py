@@ -7,12 +7,16 @@ N = 1: BASELINE.json configs[1] -- 4096 arenas, 1081-beam lidar, 500x500 static 
 diff-drive (KetiRobot kinematics), no pedestrians, auto-respawn of finished arenas in place.
 N > 1: one rank per GPU -- either launched by torch.distributed.run (WORLD_SIZE set), or, when called plainly
 as `python bench.py --gpus N`, this script spawns the N ranks itself before touching the GPU.
-`--scaling weak` (default): every rank owns the workload's per-GPU arena count (c2: 4096 per GPU; c4 / c5: 1/8 of
-their 8-GPU totals, so `--workload c4 --gpus 8` is the configured 16384 and `--workload c5 --gpus 8` the configured
-4096).  `--scaling strong`: the workload's TOTAL (c2: 4096) is split over the ranks by sharding.shard_range
-(ragged totals allowed).  Arenas are keyed by their global index either way.  The step has no exchange, so `value`
-involves no data-path collective; with N > 1 the line also carries `value_with_obs_gather`: the same K steps with the
-optional RCCL all-gather of the observation rows after every step (`--gather none` skips that pass).
+`--scaling strong`: the workload's TOTAL (c2: 4096) is split over the ranks by sharding.shard_range (ragged totals
+allowed).  `--scaling weak`: every rank owns the workload's per-GPU arena count (c2: 4096 per GPU; c4 / c5: 1/8 of their
+8-GPU totals, so `--workload c4 --gpus 8` is the configured 16384 and `--workload c5 --gpus 8` the configured 4096).
+Default (`--scaling auto`): with N > 1 ONE invocation measures both -- `value` is the STRONG number (BASELINE.json's metric
+reads "4096 envs ..., 1/2/4/8 MI355X": a fixed total), `value_weak` the weak one, each with its own `envs_total`; with
+N = 1 the two coincide.  Arenas are keyed by their global index either way.  The step has no exchange, so `value` involves
+no data-path collective; with N > 1 the line also carries `value_with_obs_gather`: the same K steps with the optional RCCL
+all-gather of the observation rows after every step (`--gather none` skips that pass).
+With N = 1 the default run appends short windows of the other BASELINE workloads (`other_workloads`: c3, c4, c5) and the
+same steps through the gym API (`value_gym_api`: NavGymEnv.step with torch actions); `--no-extras` skips them.
 
 One "step" = one launch of navsim_step over all local arenas, inputs resident in HBM.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
@@ -280,8 +284,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=0, help="override arenas per GPU (weak scaling)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: the workload's per-GPU arena count on every rank; strong: its TOTAL split over the ranks")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="weak: the workload's per-GPU arena count on every rank; strong: its TOTAL split over the ranks; auto: "
+                         "with N > 1 both from one invocation (value = strong, value_weak = weak), with N = 1 they coincide")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N = 1: skip the short windows of the other workloads (other_workloads) and the gym-API pass (value_gym_api)")
     ap.add_argument("--total-envs", type=int, default=0, help="override the total arena count (strong scaling; may be ragged)")
     ap.add_argument("--gather", default="auto", choices=["auto", "none", "all"],
                     help="auto: with N > 1 time a second pass with the RCCL all-gather of the observation rows after every "
@@ -355,6 +362,119 @@ def main():
         assert dist.get_world_size() == args.gpus
     coll_dev = device if backend == "nccl" else "cpu"
 
+    ctx = dict(rank=rank, world_size=world_size, dist=dist, backend=backend, device=device, coll_dev=coll_dev)
+    if args.scaling == "auto" and world_size > 1:
+        # BOTH curves from one invocation: `value` is the strong number (the metric's fixed total), value_weak the weak one
+        out = measure(args, "strong", ctx)
+        weak = measure(args, "weak", ctx, light=True)
+        if rank == 0:
+            out["value_weak"] = weak["value"]
+            out["weak"] = {k: weak[k] for k in ("value", "ms_per_step", "scaling")}
+            out["weak"].update(envs_total=weak["config"]["envs_total"], envs_per_gpu=weak["config"]["envs_per_gpu"],
+                               kernel_ms=weak["roofline"]["kernel_ms"], value_with_obs_gather=weak.get("value_with_obs_gather"))
+            out["value_strong"] = out["value"]
+    else:
+        out = measure(args, "weak" if args.scaling == "auto" else args.scaling, ctx)
+        if rank == 0:
+            out["value_weak" if out["scaling"] == "weak" else "value_strong"] = out["value"]
+    if rank == 0 and world_size == 1 and not args.no_extras and args.workload == "c2" and not args.envs:
+        out.update(extras(args, device))
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def extras(args, device):
+    """N = 1, default run only: what the driver's line would otherwise not show (round-3 verdict).  Short windows (200 steps
+    after 30) of the other BASELINE workloads, each on a freshly built world, and the c2 steps through the gym API --
+    NavGymEnv.step(torch actions): the action copy, the step, .bool() of the done flags, the observation dict."""
+    import torch
+    res = {"other_workloads": {}}
+    for name in ("c3", "c4", "c5"):
+        wl = dict(WORKLOADS[name]); wl["field"] = "u16t"; wl["indoor_ratio"] = 0.0
+        try:
+            cfg, sim, arrays, _ = build_sim(wl, 0, wl["envs"], device=device)
+            E = cfg.n_envs
+            sim.t["scan_noise_std"].fill_(args.noise_std); sim.cfg.add_scan_noise = int(args.noise_std > 0)
+            g = torch.Generator(device=device); g.manual_seed(77)
+            K, Wm = 200, 30
+            acts = torch.rand((K + Wm, E, 2), generator=g, device=device, dtype=torch.float64)
+            lin_hi, rot_hi = (1.0, 2.0) if wl.get("robot") == "husky" else (0.5, 0.64)
+            acts[..., 0] *= lin_hi; acts[..., 1] = (acts[..., 1] * 2.0 - 1.0) * rot_hi
+            regen = bool(wl.get("regen"))
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+
+            def one(t, e=None):
+                sim.io.action = acts[t].data_ptr()
+                sim._reorder()
+                if e is not None:
+                    e[0].record()
+                sim.launch_step(reorder=False)
+                if e is not None:
+                    e[1].record()
+                if regen:
+                    sim.regen()
+            for t in range(Wm):
+                one(t)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in range(K):
+                one(Wm + t, ev[t])
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / K
+            rects = "rect_table" in sim.t
+            lds = rects and "rect_index" in sim.t and bool(cfg.closed_maps)
+            s_map = (sim.t["rect_index"].shape[1] / float(cfg.map_h * cfg.map_w)) if lds else (0.25 if rects else 2)
+            A = algorithmic_bytes_per_env_step(cfg.map_h, cfg.map_w, cfg.n_beams, cfg.n_scan_stack, wl["peds"], s_map)
+            res["other_workloads"][name] = {
+                "value": E * K / el, "ms_per_step": el / K * 1e3, "kernel_ms": kernel_ms, "envs_per_gpu": E, "steps": K,
+                "frac": A * E / (kernel_ms * 1e-3) / 8.0e12, "s_map": s_map,
+                "workload": "%d arenas x %d beams, %dx%d maps, %d pedestrians, %s%s" % (
+                    E, cfg.n_beams, cfg.map_h, cfg.map_w, wl["peds"], wl.get("robot", "keti"), ", new map per episode" if regen else ""),
+                "kernel_ms_from": "one HIP event pair per step launch (the step kernel alone; ms_per_step also holds navsim_regen where it runs)"}
+            del sim, arrays
+            torch.cuda.empty_cache()
+        except Exception as exc:                              # an extra must not cost the run its line
+            res["other_workloads"][name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "nav-gym_amd"))
+        import nav_gym_env
+        wl = WORKLOADS["c2"]
+        E = wl["envs"]
+        env = nav_gym_env.make("NavGym-v0", num_envs=E, n_beams=wl["beams"], map_size=wl["size"], pedestrian_model="none",
+                               num_humans=0, indoor_ratio=0.0, device=device, seed=1234)
+        env.reset()
+        g = torch.Generator(device=device); g.manual_seed(78)
+        K, Wm = 200, 30
+        acts = torch.rand((K + Wm, E, 2), generator=g, device=device, dtype=torch.float64)
+        acts[..., 0] *= 0.5; acts[..., 1] = acts[..., 1] * 1.28 - 0.64
+        for t in range(Wm):
+            env.step(acts[t])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(K):
+            obs, rew, done, info = env.step(acts[Wm + t])
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        res["value_gym_api"] = E * K / el
+        res["gym_api"] = {"ms_per_step": el / K * 1e3, "envs": E, "steps": K,
+                          "what": "K calls of NavGymEnv.step(torch float64 actions [E,2]) on a c2-shaped world made by gym.make('NavGym-v0', "
+                                  "num_envs=4096, n_beams=1081, map_size=500, pedestrian_model='none', indoor_ratio=0) + reset() on the device; "
+                                  "returns the obs dict, reward, done.bool(), info (env.py:591-728's signature)"}
+        env.close()
+    except Exception as exc:
+        res["gym_api"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+    return res
+
+
+def measure(args, scaling, ctx, light=False):
+    """One measurement of args.workload under `scaling`: W warm-up steps, EXACTLY K timed steps between barrier +
+    synchronize, max over ranks -> the line (rank 0) / None.  light: the timed steps only (no repeats, no extra passes)."""
+    import torch
+    rank, world_size, dist, backend, device, coll_dev = (ctx[k] for k in ("rank", "world_size", "dist", "backend", "device", "coll_dev"))
     wl = dict(WORKLOADS[args.workload])
     if args.envs:
         wl["envs"] = args.envs
@@ -367,8 +487,8 @@ def main():
     if args.rects:
         wl["rects"] = True
     wl["pregen"] = bool(args.pregen)
-    base, E_local = shard_of(wl, args.scaling, rank, world_size)
-    E_total = wl["total"] if args.scaling == "strong" else world_size * wl["envs"]
+    base, E_local = shard_of(wl, scaling, rank, world_size)
+    E_total = wl["total"] if scaling == "strong" else world_size * wl["envs"]
     if E_local < 1:
         raise SystemExit("bench.py: rank %d owns no arena (%d arenas over %d ranks)" % (rank, E_total, world_size))
     cfg, sim, arrays, _ = build_sim(wl, base, E_local, device=device)
@@ -396,7 +516,7 @@ def main():
     gatherer = None
     if args.gather != "none" and dist is not None and backend == "nccl":
         from nav_gym_amd.sharding import RowGather
-        if args.scaling == "strong":
+        if scaling == "strong":
             gatherer = RowGather(E_total, sim.obs.shape[1:], torch.float32, device, rank, world_size)
         else:                               # weak: equal shards by construction
             gatherer = RowGather(world_size * E, sim.obs.shape[1:], torch.float32, device, rank, world_size)
@@ -490,7 +610,7 @@ def main():
                 print("bench: hipGraph capture failed (%s); timing plain launches" % type(exc).__name__, file=sys.stderr)
 
     elapsed, kernel_ms = timed()                     # THE measurement (`value`)
-    more = [timed() for _ in range(max(args.repeats - 1, 0))]
+    more = [timed() for _ in range(max(args.repeats - 1, 0))] if not light else []
     with_gather, gather_error = None, None
     if gatherer is not None and not gather_on[0]:    # the same K steps, every step followed by the obs all-gather
         gather_on[0] = True
@@ -502,7 +622,7 @@ def main():
             gather_error = "%s: %s" % (type(exc).__name__, str(exc)[:200])
         gather_on[0] = False
     noise_off = None
-    if args.noise_std > 0 and not args.no_noise_off_pass:   # the same K steps without the per-beam Gaussian, beside it
+    if args.noise_std > 0 and not args.no_noise_off_pass and not light:   # the same K steps without the per-beam Gaussian, beside it
         sim.cfg.add_scan_noise = 0
         noise_off = timed()
         sim.cfg.add_scan_noise = 1
@@ -511,7 +631,7 @@ def main():
     # launch-order schedule 25 steps on and cost the first timed window -- the one `value` is -- 1-3 %,
     # profiles/r03_lpt/driver_shape_first_repeat.txt), with W untimed steps in front like `value`.
     cold = None
-    if args.spinup_ms > 0 and not args.no_cold_pass:
+    if args.spinup_ms > 0 and not args.no_cold_pass and not light:
         fence()
         time.sleep(args.cold_idle_s)
         for t in range(Wm):
@@ -526,7 +646,13 @@ def main():
         # A = H*W*s_map + 4B + 4(S*B + 11) + 96 (+ 96 N), s_map = "bytes per cell of the map representation
         # the kernel streams once per env-step".  What this kernel reads of a map: with rect records 16 B per 8x8-cell
         # tile = 0.25 B per cell (most probes never touch the field); the packed uint16 field alone 2; float32 4.
-        if rects:
+        lds_rows = rects and "rect_index" in sim.t and bool(sim.cfg.closed_maps) and sim.cfg.rect_lds != 1
+        if lds_rows:
+            row_bytes = int(sim.t["rect_index"].shape[1])
+            s_map = row_bytes / float(cfg.map_h * cfg.map_w)
+            s_map_of = ("index form of the two-rectangle tile records, copied to LDS once per arena-step: 256 rectangles x 8 B + 2 B per "
+                        "8x8 cells = %d B per arena (nav-gym_amd/csrc/kernels_rect.hpp)" % row_bytes)
+        elif rects:
             s_map, s_map_of = 0.25, "two-rectangle tile records: 16 B per 8x8 cells (nav-gym_amd/csrc/kernels_rect.hpp)"
         elif cfg.field_format == abi.FIELD_U16T:
             s_map, s_map_of = 2, "packed uint16 squared-distance field in 8x8 tiles"
@@ -553,7 +679,7 @@ def main():
             "warmup": Wm,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -561,7 +687,7 @@ def main():
                 "workload": "%s: %d arenas (%s scaling: %d on rank 0) x %d-beam lidar, %dx%d per-arena occupancy maps "
                             "(%s distance field%s), indoor ratio %.2g, %d pedestrians/arena, %s kinematics, %s, "
                             "scan_noise_std %.3g"
-                            % (args.workload, E_total, args.scaling, E, B, H, W, args.field,
+                            % (args.workload, E_total, scaling, E, B, H, W, args.field,
                                " + rect records" if rects else "", args.indoor_ratio, wl["peds"], wl.get("robot", "keti"),
                                ("new random map per episode (%s)" % ("worlds staged ahead, navsim_regen_swap" if getattr(sim, "pregen", False) else "navsim_regen")) if regen else "auto-respawn in place",
                                args.noise_std),
@@ -582,6 +708,13 @@ def main():
                 # the kernel's own duration, against the HBM peak.  It is reported as asked; what actually limits the
                 # kernel is vector issue on the dependent probe chain (issue_frac_profiled, profiles/README.md).
                 "bound": "valu-issue (profiled); hbm frac reported per contract",
+                # the same duration against the bytes of the representations the march could stream instead (each lossless, each
+                # measured in an earlier round): what compressing the map bought, and why `frac` FELL while `value` ROSE
+                "frac_by_representation": {
+                    "index_rows_in_lds (round 4)": algorithmic_bytes_per_env_step(H, W, B, S, wl["peds"], (2048 + 2 * ((H + 7) // 8) * ((W + 7) // 8)) / float(H * W)) * E / (kernel_ms * 1e-3) / 8.0e12,
+                    "rect_records_16B_per_tile (rounds 2-3)": algorithmic_bytes_per_env_step(H, W, B, S, wl["peds"], 0.25) * E / (kernel_ms * 1e-3) / 8.0e12,
+                    "packed_u16_field (round 1)": algorithmic_bytes_per_env_step(H, W, B, S, wl["peds"], 2) * E / (kernel_ms * 1e-3) / 8.0e12,
+                    "occupancy_int8 (SURVEY 8d, s_map = 1)": A1 * E / (kernel_ms * 1e-3) / 8.0e12},
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": frac,
                 "s_map": s_map, "s_map_of": s_map_of, "algorithmic_bytes_per_env_step": A,
                 "algorithmic_bytes_per_launch": A * E,
@@ -626,15 +759,16 @@ def main():
         if noise_off is not None:
             out["noise_off"] = {"value": E_total * K / noise_off[0], "ms_per_step": noise_off[0] / K * 1e3,
                                 "kernel_ms": noise_off[1]}
-        if not args.no_cpu_baseline and world_size == 1:
+        if not args.no_cpu_baseline and world_size == 1 and not light:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
             pr = out["cpu_baseline"].pop("probes_per_ray")
             out["work"].update(probes_per_ray_mean=pr["mean"], probes_per_ray_p50=pr["p50"], probes_per_ray_p99=pr["p99"],
                                probes_per_ray_from="oracle/navsim_ref.c trace_ray (calc_range, env.py:425): " + pr["sample"])
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        del sim
+        torch.cuda.empty_cache()
+        return out
+    del sim
+    return None
 
 
 def dry_run(args, rank, world_size, backend):
@@ -649,8 +783,10 @@ def dry_run(args, rank, world_size, backend):
         wl["envs"] = args.envs
     if args.total_envs:
         wl["total"] = args.total_envs
-    base, count = shard_of(wl, args.scaling, rank, world_size)
-    E_total = wl["total"] if args.scaling == "strong" else world_size * wl["envs"]
+    both = args.scaling == "auto" and world_size > 1            # value = strong, value_weak = weak, one invocation
+    scaling = "strong" if both else ("weak" if args.scaling == "auto" else args.scaling)
+    base, count = shard_of(wl, scaling, rank, world_size)
+    E_total = wl["total"] if scaling == "strong" else world_size * wl["envs"]
     gathered_ok = None
     if world_size > 1:
         import torch
@@ -672,11 +808,16 @@ def dry_run(args, rank, world_size, backend):
         raise SystemExit(3)
     if rank == 0:
         from nav_gym_amd.sharding import shard_range
-        shards = [list(shard_of(wl, args.scaling, r, world_size)) for r in range(world_size)]
-        print(json.dumps({"metric": "dry-run (no GPU work, control flow only)", "value": None, "n_gpus": world_size,
-                          "steps": args.steps, "warmup": args.warmup, "max_rank_time": elapsed, "dry_run": True,
-                          "scaling": args.scaling, "envs_total": E_total, "shards": shards,
-                          "gather_in_global_order": gathered_ok}))
+        shards = [list(shard_of(wl, scaling, r, world_size)) for r in range(world_size)]
+        line = {"metric": "dry-run (no GPU work, control flow only)", "value": None, "n_gpus": world_size,
+                "steps": args.steps, "warmup": args.warmup, "max_rank_time": elapsed, "dry_run": True,
+                "scaling": scaling, "envs_total": E_total, "shards": shards, "gather_in_global_order": gathered_ok}
+        line["value_strong" if scaling == "strong" else "value_weak"] = None
+        if both:                                                    # the second pass of the real run: the weak curve
+            line["value_weak"] = None
+            line["weak"] = {"scaling": "weak", "envs_total": world_size * wl["envs"], "envs_per_gpu": wl["envs"],
+                            "shards": [list(shard_of(wl, "weak", r, world_size)) for r in range(world_size)]}
+        print(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

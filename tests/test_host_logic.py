@@ -279,9 +279,27 @@ def test_bench_strong_scaling_splits_the_configured_totals():
         out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert out["scaling"] == "strong" and out["envs_total"] == total
         assert out["shards"] == [[0, total // 2], [total // 2, total // 2]] and out["gather_in_global_order"] is True
-    r = _bench(["--gpus", "2", "--dry-run", "--workload", "c4"], NAVSIM_BENCH_BACKEND="gloo")
+    r = _bench(["--gpus", "2", "--dry-run", "--workload", "c4", "--scaling", "weak"], NAVSIM_BENCH_BACKEND="gloo")
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["scaling"] == "weak" and out["shards"] == [[0, 2048], [2048, 2048]] and out["envs_total"] == 4096
+
+
+def test_bench_default_with_several_gpus_reports_both_curves():
+    """Round-3 verdict: BASELINE.json's metric reads "4096 envs ..., 1/2/4/8 MI355X" -- a FIXED total.  With N > 1 the default
+    invocation therefore measures both curves: `value` (and value_strong) on the strong split of the 4096 arenas, value_weak
+    on 4096 arenas PER GPU, each with its own envs_total.  (Dry run: the keys and the shards; values are null.)"""
+    import json
+    r = _bench(["--gpus", "2", "--dry-run"], NAVSIM_BENCH_BACKEND="gloo")
+    assert r.returncode == 0, r.stderr
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["scaling"] == "strong" and out["envs_total"] == 4096 and out["shards"] == [[0, 2048], [2048, 2048]]
+    assert "value_strong" in out and "value_weak" in out
+    assert out["weak"]["scaling"] == "weak" and out["weak"]["envs_total"] == 8192 and out["weak"]["envs_per_gpu"] == 4096
+    assert out["weak"]["shards"] == [[0, 4096], [4096, 4096]]
+    # one GPU: the two coincide, the line says "weak" like the contract's example
+    r = _bench(["--gpus", "1", "--dry-run"])
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["scaling"] == "weak" and out["envs_total"] == 4096 and "value_weak" in out and "weak" not in out
 
 
 def test_bench_strong_scaling_ragged_split():
