@@ -220,6 +220,7 @@ class NavGymEnv(object):
                                      reward_discomfort_factor)
         self.sim = None
         self.prev_obs = None
+        self._bool = None
         self.robot = _AgentView(self, "robot")
         self.humans = []
         self.map_info = None
@@ -267,6 +268,7 @@ class NavGymEnv(object):
         from . import lib
         lib.require_gpu()                                 # no CPU fallback: fail before any work
         import torch
+        self._bool = torch.bool
         from . import sim as simmod
         cfg = self.cfg
         first = self.sim is None
@@ -308,10 +310,10 @@ class NavGymEnv(object):
         return self._obs_dict()
 
     def _obs_dict(self):
+        # no kernel of its own: the observation rows and the two goal arrays are what the step (or navsim_regen's
+        # first-observation launch) wrote (env.py:455-461: achieved_goal = the pose slots, desired_goal = the robot's goal)
         o = self.sim.obs
-        pose = o[:, -5:-3]
-        goal = self.sim.t["robot_goal"].to(o.dtype)
-        d = {"observation": o, "achieved_goal": pose, "desired_goal": goal}
+        d = {"observation": o, "achieved_goal": self.sim.out["achieved_goal"], "desired_goal": self.sim.out["desired_goal"]}
         if self.num_envs == 1:
             d = {k: v[0].double().cpu().numpy() for k, v in d.items()}
         self.prev_obs = d
@@ -326,7 +328,7 @@ class NavGymEnv(object):
         elif self.pedestrian_model == "policy":
             self.sim.ped_policy()                           # scans -> HumanPolicy actor -> (v, omega)
         a = np.asarray(action, dtype=np.float64).reshape(self.num_envs, 2) if not hasattr(action, "is_cuda") else action
-        _, out = self.sim.step(a)
+        _, out = self.sim.step(a)                          # (a float64 tensor on the device is read in place: no copy)
         if self.pedestrian_model == "policy" and self.auto_reset:
             # a new episode starts with prev_human_actions = 0 (env.py:739)
             self.sim.t["policy_prev_actions"].mul_((out["done"] == 0).to(self.sim.t["policy_prev_actions"].dtype)[:, None, None])
@@ -341,7 +343,7 @@ class NavGymEnv(object):
                     "distance": float(out["distance"][0].item())}
             return obs, float(out["reward"][0].item()), bool(out["done"][0].item()), info
         info = {"is_success": out["is_success"], "is_crash": out["is_crash"], "distance": out["distance"]}
-        return obs, out["reward"], out["done"].bool(), info
+        return obs, out["reward"], out["done"].view(self._bool), info      # (a view of the flags the kernel wrote: no kernel)
 
     def counters(self, reset=True):
         """What the device-side reset path served and what its caps left waiting since the last call (abi.COUNTERS):

@@ -440,7 +440,14 @@ class NavSim(object):
     def step(self, action=None):
         """One fused launch: NavGymEnv.step for all E arenas.  `action` [E,2] (v, omega)."""
         if action is not None:
-            self.action.copy_(self._as(action, self.action))
+            import torch
+            if (isinstance(action, torch.Tensor) and action.is_cuda and action.dtype == torch.float64 and action.is_contiguous()
+                    and action.device == self.device and action.numel() == self.action.numel()):
+                self.io.action = action.data_ptr()         # resident actions are read where they are (stream-ordered: no copy)
+                self._action_ref = action
+            else:
+                self.action.copy_(self._as(action, self.action))
+                self.io.action = self.action.data_ptr()
         self._reorder()
         self._flip()
         check(self.lib.navsim_step(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), _stream()), "navsim_step")
