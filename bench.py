@@ -321,8 +321,9 @@ def main():
                     help="c5: worlds staged ahead on a side stream + navsim_regen_swap instead of navsim_regen after every step "
                          "(measured: +11-14 %% at 128-256 arenas per GPU, +-0 at the 512 of c5 where the step kernel fills the chip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", default="off", choices=["auto", "on", "off"],
-                    help="replay the K timed steps as one captured hipGraph (measured: c2 +0 %, c5 +2.5 %; off by default)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="replay the K timed steps as one captured hipGraph: auto = where a step is several launches (c5's "
+                         "navsim_regen: +6 %); a one-kernel step gains nothing from it (c2 +-0)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / reduction control flow only, no GPU work (tests/test_host_logic.py)")
@@ -600,7 +601,7 @@ def measure(args, scaling, ctx, light=False):
     fence()
     # The K timed steps are launch-bound between kernels (~5 us of host gap per 220 us kernel): optionally capture
     # them once as a hipGraph and replay it.  Every node keeps its own action slice and observation buffers.
-    if args.graph != "off" and gatherer is None:
+    if (args.graph == "on" or (args.graph == "auto" and regen)) and gatherer is None:
         try:
             cur0 = sim.cur
             graph = torch.cuda.CUDAGraph()

@@ -618,6 +618,12 @@ int navsim_crowd_orca(const navsim_orca_params* p, int32_t n_queries, int32_t ma
  * vel = v * (cos, sin)(theta'); theta = theta' mod 2 pi.  pose [n,3] in/out, action [n,2], vel [n,2] or NULL. */
 int navsim_crowd_agent_step(double* pose, const double* action, double* vel, int32_t n, double time_step, void* stream);
 
+/* Everything a later navsim_step / navsim_reset_obs / navsim_regen / navsim_replan with this configuration would set ONCE per
+ * kernel (dynamic LDS above 64 KB needs hipFuncSetAttribute) is set now; nothing is launched.  Call it before capturing those
+ * calls in a hipGraph (nav_gym_amd/sim.py NavSim.enable_graphs): attribute calls do not belong inside a capture.  io: the
+ * buffers a reset would use (checked like navsim_reset_obs checks them). */
+int navsim_prepare(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io);
+
 /* First observation after reset() (env.py:822-831): scan at the current robot pose, stack filled
  * with copies, prev_pose = pose, vel = 0; sets prev_pose/prev_action/n_hist.  `mask` [E] uint8 or
  * NULL selects which envs are (re)initialised; others keep obs_prev -> obs copied through. */

@@ -187,10 +187,15 @@ StepPlan plan_step(const navsim_config* c, const navsim_state* st, int grid = 0)
     return p;
 }
 
+// navsim_prepare: walk the dispatch chain of a launch down to its kernel, set what has to be set once per kernel
+// (hipFuncSetAttribute for dynamic LDS above 64 KB) and launch nothing -- so that nothing of the kind happens inside a
+// hipGraph capture (round-3 advisor: navsim_regen's lone first-observation launch instantiates its own variant)
+thread_local bool g_prepare_only = false;
 template <int BLOCK, bool PEDS, typename Field, int RECT, int RULE, bool PINL>
 int launch_step_pinl(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
                      const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
     if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL>, p.lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
+    if (g_prepare_only) return NAVSIM_OK;
     navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL><<<grid > 0 ? grid : c->n_envs, BLOCK, p.lds, s>>>(
         *c, *st, *io, reset_only, mask, (unsigned)step_lds_scan_bytes(c, p.park), p.park, p.rect_off);
     return NAVSIM_OK;
@@ -237,7 +242,7 @@ template <int BLOCK>
 int launch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
                 const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
     const bool peds = c->ped_model != NAVSIM_PED_NONE;
-    if (peds && !reset_only && ped_split_on(c)) {            // pedestrians ahead of the step (ped_split_on)
+    if (peds && !reset_only && ped_split_on(c) && !g_prepare_only) {            // pedestrians ahead of the step (ped_split_on)
         const size_t pl = ped_update_lds_bytes(c);
         const int G = ped_pack(c->max_peds), pgrid = (c->n_envs + G - 1) / G;
         if (c->field_format == NAVSIM_FIELD_U16T) ped_update_kernel<FieldU16T><<<pgrid, kPedUpdateBlock, pl, s>>>(*c, *st);
@@ -585,6 +590,8 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
     if (c->ped_split < 0 || c->ped_split > 2 || c->rect_lds < 0 || c->rect_lds > 2) return NAVSIM_E_ARG;
     if (c->ped_model != NAVSIM_PED_NONE && c->max_peds < 1) return NAVSIM_E_ARG;
     if (plan_step(c, st).lds > kLdsPerCu) return NAVSIM_E_UNSUPPORTED;   // beams x pedestrians beyond one CU's LDS
+    // navsim_regen's first observations are a launch of their own geometry (plan_step's `lone` rule): validate it here too
+    if (c->regen_cap > 0 && plan_step(c, st, c->regen_cap).lds > kLdsPerCu) return NAVSIM_E_UNSUPPORTED;
     if (!st->field || !st->scan_threshold || !st->scan_discomfort || !st->robot_pose || !st->robot_goal ||
         !st->prev_action || !st->prev_pose || !st->n_hist || !st->episode || !st->steps || !io->obs)
         return NAVSIM_E_ARG;
@@ -1022,6 +1029,26 @@ int navsim_step(const navsim_config* c, const navsim_state* st, const navsim_ste
     if (rc != NAVSIM_OK) return rc;
     if (c->n_envs == 0) return NAVSIM_OK;
     return dispatch_step(c, st, io, 0, nullptr, (hipStream_t)stream);
+}
+
+int navsim_prepare(const navsim_config* c, const navsim_state* st, const navsim_step_io* io) {
+    (void)hipGetLastError();
+    int rc = check_step_args(c, st, io, 1);
+    if (rc != NAVSIM_OK) return rc;
+    if (c->n_envs == 0) return NAVSIM_OK;
+    g_prepare_only = true;
+    rc = dispatch_step(c, st, io, 0, nullptr, nullptr);                       // the step
+    if (rc == NAVSIM_OK) rc = dispatch_step(c, st, io, 1, nullptr, nullptr);  // first observations of a reset
+    if (rc == NAVSIM_OK && c->regen_cap > 0) rc = dispatch_step(c, st, io, 1, nullptr, nullptr, c->regen_cap);   // navsim_regen's lone launch
+    g_prepare_only = false;
+    if (rc != NAVSIM_OK) return rc;
+    const int Hc = c->map_h / 5, Wc = c->map_w / 5;
+    if (Hc >= 1 && Wc >= 1 && plan_fits(Hc, Wc)) {                           // the planners' LDS-resident search
+        (void)allow_lds((const void*)plan_kernel, plan_lds(Hc, Wc));
+        (void)allow_lds((const void*)regen_plan_kernel, plan_lds(Hc, Wc));
+        (void)allow_lds((const void*)replan_kernel, plan_lds(Hc, Wc));
+    }
+    return NAVSIM_OK;
 }
 
 int navsim_reset_obs(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,

@@ -24,6 +24,8 @@ and default to the reference's behaviour for num_envs == 1:
                     with the robot's wheel radius / track (robots.py; Husky: husky.urdf.xacro:61-67)
     clip_actions    True: the twist is clamped to linvel_range x rotvel_range on the device (the reference only prints
                     a warning and never clips, env.py:606-613: default False)
+    use_graphs      replay a step's launches (navsim_step, navsim_regen, navsim_replan) as one captured hipGraph; None
+                    (default) = when randomize_maps makes a step several launches (c5: +6 %); results are identical
     max_waypoints   waypoints kept per pedestrian route (default 64 = 128 m at the 2 m interval; the reference keeps
                     all of them, env.py:788-804); longer routes are stored cut, counted, and continued to the same goal
     device, seed, env_index_base (global index of arena 0: sharding), auto_reset, field_format
@@ -118,7 +120,7 @@ class NavGymEnv(object):
                  num_envs=1, n_beams=None, lidar=None, map_size=400, pedestrian_model="sfm", policy_weights=None,
                  num_humans=None, device="cuda:0", seed=0, env_index_base=0, auto_reset=None,
                  field_format=abi.FIELD_U16T, n_spawn=16, randomize_maps=False, plan_paths=True,
-                 action_kind="twist", clip_actions=False, max_waypoints=64, march_rule=None):
+                 action_kind="twist", clip_actions=False, max_waypoints=64, march_rule=None, use_graphs=None):
         from . import lib
         if robot_type not in robots.ROBOTS:
             raise NotImplementedError(robot_type)            # env.py:772-773
@@ -151,6 +153,8 @@ class NavGymEnv(object):
         self._episode_batch = 0
         self.randomize_maps = bool(randomize_maps)
         self.replan_cap = 1024                              # pedestrians re-planned per step, at most
+        self.use_graphs = bool(randomize_maps) if use_graphs is None else bool(use_graphs)
+        self._graphed = False
         self.plan_paths = bool(plan_paths) and int(map_size) <= 1000
         if field_format == abi.FIELD_U16T and int(map_size) > 1024:
             field_format = abi.FIELD_F32     # beyond the rect records' and the packed regeneration's tested range
@@ -299,6 +303,10 @@ class NavGymEnv(object):
             self.sim.t["policy_prev_actions"].zero_()           # env.py:739
         self._episode_batch += 1
         self.sim.regenerate_all(new_episode=not first)
+        if first and self.use_graphs and self.pedestrian_model != "policy":
+            self.sim.enable_graphs(regen=self.randomize_maps and self.auto_reset,
+                                   replan_cap=self.replan_cap if "costmap" in self.sim.t else 0)
+            self._graphed = True
         occ0 = self.sim.occupancy(0)
         live = self.map_size
         if self.outdoor_map_size and occ0[self.outdoor_map_size:, :].all() and occ0[:, self.outdoor_map_size:].all():
@@ -328,14 +336,17 @@ class NavGymEnv(object):
         elif self.pedestrian_model == "policy":
             self.sim.ped_policy()                           # scans -> HumanPolicy actor -> (v, omega)
         a = np.asarray(action, dtype=np.float64).reshape(self.num_envs, 2) if not hasattr(action, "is_cuda") else action
-        _, out = self.sim.step(a)                          # (a float64 tensor on the device is read in place: no copy)
-        if self.pedestrian_model == "policy" and self.auto_reset:
-            # a new episode starts with prev_human_actions = 0 (env.py:739)
-            self.sim.t["policy_prev_actions"].mul_((out["done"] == 0).to(self.sim.t["policy_prev_actions"].dtype)[:, None, None])
-        if self.randomize_maps and self.auto_reset:
-            self.sim.regen()
-        if "costmap" in self.sim.t:
-            self.sim.replan(self.replan_cap)
+        if self._graphed:                                   # step + regen + replan: one graph launch (NavSim.enable_graphs)
+            _, out = self.sim.step_graphed(a)
+        else:
+            _, out = self.sim.step(a)                      # (a float64 tensor on the device is read in place: no copy)
+            if self.pedestrian_model == "policy" and self.auto_reset:
+                # a new episode starts with prev_human_actions = 0 (env.py:739)
+                self.sim.t["policy_prev_actions"].mul_((out["done"] == 0).to(self.sim.t["policy_prev_actions"].dtype)[:, None, None])
+            if self.randomize_maps and self.auto_reset:
+                self.sim.regen()
+            if "costmap" in self.sim.t:
+                self.sim.replan(self.replan_cap)
         obs = self._obs_dict()
         if self.num_envs == 1:
             info = {"is_success": np.float32(out["is_success"][0].item()),

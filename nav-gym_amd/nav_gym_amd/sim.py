@@ -643,6 +643,52 @@ class NavSim(object):
         check(self.lib.navsim_ped_scans(C.byref(self.cfg), C.byref(self.st), _ptr(out), _stream()), "navsim_ped_scans")
         return out
 
+    # ---- hipGraph replay of a whole step (round 4).  A step of a world that draws new maps is four or five launches
+    # (navsim_step, navsim_regen's three, navsim_replan's three) whose gaps are launch-bound: c5 4.77 -> 5.08 M env-steps/s.
+    def enable_graphs(self, regen=False, replan_cap=0):
+        """Capture [navsim_step, navsim_regen (regen=True), navsim_replan (replan_cap > 0)] once per observation-buffer
+        parity and replay it in step_graphed().  Actions go through the simulator's own action buffer (a graph's
+        arguments are frozen), the longest-first launch order is not re-sorted (graphs are for the launches of one
+        generation, where it does not matter).  Same kernels, same arguments, same order: same results."""
+        import torch
+        if getattr(self, "pregen", False):
+            raise ValueError("enable_graphs and enable_pregen are alternatives")
+        io = abi.NavsimStepIO()
+        C.memmove(C.byref(io), C.byref(self.io), C.sizeof(io))
+        io.obs = self.obs_buf[self.cur].data_ptr()
+        check(self.lib.navsim_prepare(C.byref(self.cfg), C.byref(self.st), C.byref(io)), "navsim_prepare")
+        if regen and "regen_ws" not in self.t:
+            nbytes = self.lib.navsim_regen_workspace_bytes(C.byref(self.cfg))
+            self.t["regen_ws"] = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        if replan_cap:
+            key = "replan_ws_%d" % replan_cap
+            if key not in self.t:
+                self.t[key] = torch.zeros(self.lib.navsim_replan_workspace_bytes(C.byref(self.cfg), replan_cap), dtype=torch.uint8,
+                                          device=self.device)
+        self.io.action = self.action.data_ptr()
+        torch.cuda.synchronize(self.device)
+        cur0, self._graphs = self.cur, {}
+        for p in (0, 1):
+            self.cur = p
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.launch_step(reorder=False)
+                if regen:
+                    self.regen()
+                if replan_cap:
+                    self.replan(replan_cap)
+            self._graphs[p] = g
+        self.cur = cur0
+        torch.cuda.synchronize(self.device)
+
+    def step_graphed(self, action=None):
+        """step() (+ regen + replan, as captured by enable_graphs) as ONE graph launch."""
+        if action is not None:
+            self.action.copy_(self._as(action, self.action))
+        self._graphs[self.cur].replay()
+        self.cur = 1 - self.cur
+        return self.obs, self.out
+
     def launch_step(self, reorder=True):
         """step() without the action copy: inputs already resident (bench inner loop).  reorder=False: the
         caller has already called _reorder() (bench.py keeps it outside its per-kernel events)."""

@@ -1355,6 +1355,38 @@ def test_env_wrapper_gym_api(gpu):
     assert float(moved.max()) > 0.05 and bool(gpu.torch.isfinite(penv.sim.t["ped_pose"]).all())
 
 
+def test_env_graph_replay_equals_eager_steps(gpu):
+    """NavGymEnv(use_graphs=True) -- the default when randomize_maps makes a step several launches -- replays navsim_step +
+    navsim_regen + navsim_replan as ONE captured hipGraph per observation-buffer parity (NavSim.enable_graphs, behind
+    navsim_prepare): observations, rewards, flags, info and the state equal the eager calls step for step, and the
+    counters of the reset path (env.counters()) agree."""
+    import nav_gym_env
+    torch = gpu.torch
+    envs = [nav_gym_env.make("NavGym-v0", num_envs=24, map_size=300, num_humans=4, seed=9, randomize_maps=True, indoor_ratio=0.0,
+                             min_goal_dist=3, max_goal_dist=8, use_graphs=ug) for ug in (True, False)]
+    assert envs[0]._graphed is False and envs[1]._graphed is False
+    o = [e.reset() for e in envs]
+    assert envs[0]._graphed and not envs[1]._graphed
+    _eq(o[0]["observation"].cpu().numpy(), o[1]["observation"].cpu().numpy(), "reset observation")
+    g = torch.Generator(device=gpu.dev); g.manual_seed(2)
+    finished = 0
+    for t in range(70):
+        act = torch.rand((24, 2), generator=g, device=gpu.dev, dtype=torch.float64)
+        act[:, 0] = 0.5 if t % 5 else act[:, 0] * 0.5
+        act[:, 1] = act[:, 1] * 1.28 - 0.64
+        res = [e.step(act) for e in envs]
+        for k in ("observation", "achieved_goal", "desired_goal"):
+            _eq(res[0][0][k].cpu().numpy(), res[1][0][k].cpu().numpy(), "%s at step %d" % (k, t))
+        _eq(res[0][1].cpu().numpy(), res[1][1].cpu().numpy(), "reward at step %d" % t)
+        _eq(res[0][2].cpu().numpy(), res[1][2].cpu().numpy(), "done at step %d" % t)
+        finished += int(res[1][2].sum())
+    for k in ("robot_pose", "ped_pose", "ped_waypoints", "episode", "n_peds"):
+        _eq(envs[0].sim.t[k].cpu().numpy(), envs[1].sim.t[k].cpu().numpy(), "state " + k)
+    c0, c1 = envs[0].counters(), envs[1].counters()
+    assert finished > 3 and c0 == c1 and c1["regen_served"] >= finished and c1["regen_unserved"] == 0, (finished, c0, c1)
+    assert envs[1].counters() == {k: 0 for k in abi.COUNTERS}            # counters() reads and clears
+
+
 def test_env_reset_runs_on_the_device_and_matches_the_oracle(gpu, monkeypatch):
     """NavGymEnv.reset() of 4096 arenas x 500x500 maps: no map is generated on the host (world.make_maps must not
     be called); maps, fields, start / goal pairs joined by planned paths, pedestrians with planned waypoints, the
