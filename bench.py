@@ -252,7 +252,7 @@ def profiled_counters(workload, E, field, rects, indoor_ratio=0.0):
     from nav_gym_amd import lib
     reason = None
     # profiles/<round>_<workload>/ and its variants of other launch shapes (…_indoor: corridor maps only)
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         for variant in ("", "_indoor"):
             tp = os.path.join(ROOT, "profiles", "%s_%s%s" % (rnd, workload, variant), "traffic.json")
             if not os.path.exists(tp):

@@ -168,7 +168,8 @@ typedef struct navsim_config {
                                          else 64, 256, 512 or 1024 */
     int32_t ped_split;                /* pedestrian update in its own kernel (a pack of arenas per workgroup) ahead of the
                                          step: 0 or 1 = no, inside the step on one wavefront beside the scan (faster at every
-                                         batch size since round 3), 2 = yes */
+                                         batch size since round 3), 2 = yes (the pack shrinks to what fits 64 KB of LDS: one
+                                         arena per workgroup at 64 pedestrians) */
     int32_t regen_check_discomfort;   /* navsim_regen: 1 (default) = a robot start whose FIRST scan (no pedestrians, no noise) has a
                                          beam inside the discomfort zone is dropped and the next start / goal pair of the
                                          spawn table takes its place, like reset() re-draws the robot (env.py:776-781) */
@@ -639,7 +640,8 @@ size_t navsim_sizeof_state(void);
 size_t navsim_sizeof_step_io(void);
 /* deterministic device math of DESIGN.md section 4: fn 0 sin, 1 cos, 2 atan2(x, x2), 3 exp(x<=0),
  * 4 angle_correction (utils.py:5-9), 5 python-float % 2pi, 6 the packed field's sqrtf on integers, 11 / 12 the
- * march step of sqrtf(x) under NAVSIM_MARCH_F64 in its float64 form / in its float32-only form (7-10: diagnostics).
+ * march step of sqrtf(x) under NAVSIM_MARCH_F64 in its float64 form / in its float32-only form (7-10: diagnostics), 13 the
+ * beam-table direction against the full evaluation, 14 the social-force pair term's antisymmetry (0 = f(i,j) == -f(j,i) bitwise).
  * x, x2, out are device float64 [n]. */
 int navsim_debug_math(int32_t fn, const double* x, const double* x2, double* out, int32_t n, void* stream);
 /* batch_xy_to_ij (env.py:1228-1253) exactly as the scan evaluates it: xy [n,2] float64 in, ij [n,2] int32 out;

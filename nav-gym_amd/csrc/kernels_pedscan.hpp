@@ -233,6 +233,29 @@ __global__ void math_kernel(int fn, const double* x, const double* x2, double* o
             out[i] = !fast ? 1.0 : ((__float_as_uint(dx) == __float_as_uint(rx) && __float_as_uint(dy) == __float_as_uint(ry)) ? 0.0 : 2.0);
             break;
         }
+        case 14: {
+            // sfm_pair's antisymmetry, on which the fused step's half pair table rests (ped_pair_term stores the term of an
+            // unordered pedestrian pair once and ped_sfm_step SUBTRACTS it for the second reader): the force on j from i must
+            // be minus the force on i from j BIT FOR BIT.  x[i] seeds two agents (positions within a few metres, velocities
+            // below 1.5 m/s, some coincident or at rest); out = 0 when both components are exact negatives, else 1.
+            // A future anisotropic or field-of-view term breaks this loudly here instead of silently for the partner j < i.
+            navsim_config c = {};
+            c.sfm_lambda = 2.0; c.sfm_gamma = 0.35; c.sfm_n = 2.0; c.sfm_n_prime = 3.0;
+            uint64_t h = nv::mix64((uint64_t)__double_as_longlong(x[i]) + 0x9E3779B97F4A7C15ULL * (uint64_t)(i + 1));
+            auto u = [&]() { h = nv::mix64(h + 0x632BE59BD9B4E019ULL); return (double)(h >> 11) * (1.0 / 9007199254740992.0); };
+            double xi = 10.0 + 6.0 * u(), yi = 10.0 + 6.0 * u(), xj = 10.0 + 6.0 * u(), yj = 10.0 + 6.0 * u();
+            double vxi = 3.0 * u() - 1.5, vyi = 3.0 * u() - 1.5, vxj = 3.0 * u() - 1.5, vyj = 3.0 * u() - 1.5;
+            const double pick = u();
+            if (pick < 0.02) { xj = xi; yj = yi; }                          // coincident agents
+            else if (pick < 0.06) { vxi = vyi = vxj = vyj = 0.0; }          // both at rest
+            else if (pick < 0.10) { vxj = vxi; vyj = vyi; }                 // equal velocities
+            double fx, fy, gx, gy;
+            sfm_pair(c, xi, yi, vxi, vyi, xj, yj, vxj, vyj, fx, fy);
+            sfm_pair(c, xj, yj, vxj, vyj, xi, yi, vxi, vyi, gx, gy);
+            const bool ok = __double_as_longlong(fx) == __double_as_longlong(-gx) && __double_as_longlong(fy) == __double_as_longlong(-gy);
+            out[i] = ok ? 0.0 : 1.0;
+            break;
+        }
         default: out[i] = 0.0;
     }
 }

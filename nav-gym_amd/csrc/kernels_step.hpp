@@ -776,12 +776,17 @@ __device__ __forceinline__ void ped_advance_wave(const navsim_config& c, const n
 #endif
 constexpr int kPedUpdateBlock = NAVSIM_PED_UPDATE_BLOCK;
 constexpr int kPedPack = 8;
+__host__ __device__ inline size_t ped_slot_bytes(int N) { return ped_pair_bytes(N) + ((ped_lds_bytes(N) + 15) & ~(size_t)15); }
+// arenas per workgroup of ped_update_kernel: as many as its threads cover, at most NAVSIM_PED_PACK_MAX, and no more than fit the
+// 64 KB of dynamic LDS a kernel gets without asking (64 pedestrians: 42 KB per arena -> one; round-3 advisor: two did not
+// fit and cfg.ped_split = 2 silently ran the fused form)
 __host__ __device__ inline int ped_pack(int N) {
     int g = N > 0 ? kPedUpdateBlock / N : 1;
     g = g > NAVSIM_PED_PACK_MAX ? NAVSIM_PED_PACK_MAX : g;
-    return g < 1 ? 1 : (g > kPedPack ? kPedPack : g);
+    g = g < 1 ? 1 : (g > kPedPack ? kPedPack : g);
+    while (g > 1 && (size_t)g * ped_slot_bytes(N) > 64 * 1024) --g;
+    return g;
 }
-__host__ __device__ inline size_t ped_slot_bytes(int N) { return ped_pair_bytes(N) + ((ped_lds_bytes(N) + 15) & ~(size_t)15); }
 template <typename Field>
 __global__ __launch_bounds__(kPedUpdateBlock) void ped_update_kernel(navsim_config c, navsim_state st) {
     extern __shared__ __attribute__((aligned(16))) char ped_dyn[];

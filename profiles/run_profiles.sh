@@ -7,7 +7,7 @@ R="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$R/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="$* --repeats 1 --no-noise-off-pass --no-cold-pass"      # one kind of launch in the profile: K noise-on steps
+ARGS="$* --repeats 1 --no-noise-off-pass --no-cold-pass --no-extras --graph off"      # one kind of launch in the profile: K noise-on steps, plain launches
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 "$R/bench.py" $ARGS --no-cpu-baseline > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o pmc -- python3 "$R/bench.py" $ARGS --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_write" -o pmc -- python3 "$R/bench.py" $ARGS --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1

@@ -54,6 +54,15 @@ def test_device_math_bit_exact(gpu):
     _eq(gpu.sim.debug_math(3, _t(gpu, e)).cpu().numpy(), ref.math_fn(3, e), "exp")
 
 
+def test_social_force_pair_term_is_antisymmetric(gpu):
+    """The fused step keeps HALF of an arena's social-force pair table: the term on pedestrian j from i is stored once and
+    subtracted for the second reader, which is exact only while sfm_pair(i, j) == -sfm_pair(j, i) bit for bit (round-3
+    advisor).  Debug function 14 evaluates both orders on 2e6 random agent pairs, degenerate ones included."""
+    x = gpu.torch.arange(2_000_000, dtype=gpu.torch.float64, device=gpu.dev)
+    bad = gpu.sim.debug_math(14, x)
+    assert int(bad.sum()) == 0
+
+
 def test_packed_field_sqrt_is_correctly_rounded(gpu):
     """nv::sqrt_small_int (v_rsq_f32 + one exact-residual step, 5 instructions) against IEEE sqrt for EVERY integer the
     packed field or a rect record can hold: all of [0, 2^22) -- the packed field's d2 < 65536, a record's d2 < 2^21 on
@@ -394,17 +403,18 @@ def test_step_rollout_256_threads_parked_rays(gpu, fmt, S):
     assert crashes > 0 and resets > 0
 
 
-@pytest.mark.parametrize("ped_model", [abi.PED_SFM, abi.PED_EXTERNAL])
-def test_step_rollout_with_split_pedestrian_kernel(gpu, ped_model):
+@pytest.mark.parametrize("ped_model,N,n_peds", [(abi.PED_SFM, 8, 7), (abi.PED_EXTERNAL, 8, 7), (abi.PED_SFM, 64, 40)])
+def test_step_rollout_with_split_pedestrian_kernel(gpu, ped_model, N, n_peds):
     """cfg.ped_split = 2 advances the pedestrians in ped_update_kernel ahead of the fused step (a pack of arenas per
     workgroup; the default since round 3 is the fused form, wavefront 0 beside the scan): every output and state array equals the
-    oracle's."""
-    E, size, N = 24, 240, 8
+    oracle's.  With max_peds = 64 an arena's scratch is 42 KB and the pack shrinks to ONE arena per workgroup (round-3
+    advisor: two did not fit 64 KB of LDS and the request silently ran the fused form)."""
+    E, size = 24, 240
     cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, n_scan_stack=2, ped_model=ped_model,
                                  auto_reset=1, n_spawn=8, seed=13, field_format=abi.FIELD_U16T, ped_split=2)
     gpu.world.lidar_1081(cfg)
     occ = gpu.world.make_maps(E, size, 13)
-    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=7, steps=40, seed=5):
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=n_peds, steps=40 if N == 8 else 12, seed=5):
         for k in rout:
             _eq(gout[k], rout[k], "%s at step %d" % (k, t))
         _eq(go, ro, "obs at step %d" % t)
