@@ -432,6 +432,28 @@ def extras(args, device):
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
             kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / K
+            graphed = None
+            if regen:                   # the regenerating loop is launch-bound (step + navsim_regen's kernels per step): the
+                try:                    # same K steps again as ONE hipGraph replay -- that is the workload's `value`
+                    cur0 = sim.cur
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        for t in range(K):
+                            one(Wm + t)
+                    torch.cuda.synchronize()
+                    graph.replay(); torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    graph.replay()
+                    torch.cuda.synchronize()
+                    graphed = time.perf_counter() - t0
+                    del graph
+                except Exception as exc:
+                    sim.cur = cur0
+                    torch.cuda.synchronize()
+                    graphed = None
+            plain = el
+            if graphed is not None:
+                el = graphed
             rects = "rect_table" in sim.t
             lds = rects and "rect_index" in sim.t and bool(cfg.closed_maps)
             s_map = (sim.t["rect_index"].shape[1] / float(cfg.map_h * cfg.map_w)) if lds else (0.25 if rects else 2)
@@ -439,6 +461,8 @@ def extras(args, device):
             res["other_workloads"][name] = {
                 "value": E * K / el, "ms_per_step": el / K * 1e3, "kernel_ms": kernel_ms, "envs_per_gpu": E, "steps": K,
                 "frac": A * E / (kernel_ms * 1e-3) / 8.0e12, "s_map": s_map,
+                "launch": "hipGraph replay of the K steps" if graphed is not None else "one launch per step",
+                "value_plain_launches": E * K / plain,
                 "workload": "%d arenas x %d beams, %dx%d maps, %d pedestrians, %s%s" % (
                     E, cfg.n_beams, cfg.map_h, cfg.map_w, wl["peds"], wl.get("robot", "keti"), ", new map per episode" if regen else ""),
                 "kernel_ms_from": ("one HIP event pair per step launch (the step kernel alone; ms_per_step also holds navsim_regen)" if regen else
