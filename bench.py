@@ -625,7 +625,9 @@ def measure(args, scaling, ctx, light=False):
     fence()
     # The K timed steps are launch-bound between kernels (~5 us of host gap per 220 us kernel): optionally capture
     # them once as a hipGraph and replay it.  Every node keeps its own action slice and observation buffers.
-    if (args.graph == "on" or (args.graph == "auto" and regen)) and gatherer is None:
+    if args.graph == "on" and getattr(sim, "pregen", False):
+        raise SystemExit("bench: --pregen stages worlds on a side stream with host-side bookkeeping; it does not capture into a hipGraph")
+    if (args.graph == "on" or (args.graph == "auto" and regen and not getattr(sim, "pregen", False))) and gatherer is None:
         try:
             cur0 = sim.cur
             graph = torch.cuda.CUDAGraph()
