@@ -537,6 +537,14 @@ size_t navsim_ped_policy_workspace_bytes(const navsim_config* cfg);
 int    navsim_ped_policy(const navsim_config* cfg, const navsim_state* st, const navsim_policy_weights* w,
                          const float* ped_scans, float* prev_actions, double* ped_cmd, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* navsim_ped_scans + navsim_ped_policy in one pass over the pedestrians (round 4): every pedestrian's scan is taken from the
+ * CURRENT state by the workgroup that convolves it (env.py:685-693 -> 629-630, 647 -> human_policy.py:38-42), stays in LDS and
+ * never travels through HBM; the march of one pedestrian runs beside the convolutions of others.  scans_out [E,N,512] float32
+ * or NULL: the clipped scans, exactly what navsim_ped_scans writes (rows of dead slots untouched).  prev_actions, ped_cmd,
+ * workspace (navsim_ped_policy_workspace_bytes) as for navsim_ped_policy; results bit-identical to the two calls. */
+int    navsim_ped_scan_policy(const navsim_config* cfg, const navsim_state* st, const navsim_policy_weights* w,
+                              float* scans_out, float* prev_actions, double* ped_cmd, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* order[0..n) = the arenas sorted by descending cost (ties in unspecified order): longest-first launch order
  * for navsim_step (navsim_state.launch_order).  cost is what the step wrote to navsim_state.arena_cost. */

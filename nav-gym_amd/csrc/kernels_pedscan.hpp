@@ -7,19 +7,20 @@
 // HumanPolicy).  One workgroup per (pedestrian, arena): rectangles of the other agents in LDS,
 // march from the pedestrian's integer cell, bearing-culled polygon merge, clip to 6 m.
 // ============================================================================================
+// The scan of pedestrian i of arena e (n live pedestrians) by its BLOCK-thread workgroup, into rng[0 .. PB) of the
+// dynamic LDS region `dyn` (ped_scan_lds_bytes: float2 dir[PB], float rng[PB], then the rectangle sides of the other agents and
+// their beam-index intervals (prim_in_range), sized by cfg.max_peds): merged, NOT yet clipped.  Ends with a barrier.
+// tab (optional): cos / sin of the robot-frame beam angles -- the beam direction by beam_dir_fast (one float64 angle
+// addition whose float32 rounding is proven per beam), else the full sincos; identical results.
+struct PedScanShared { double cT, sT; int nseg, i0, j0; float lx, ly, lth; };
 template <typename Field, int BLOCK, int RULE, bool RECT>
-__global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim_state st, float* __restrict__ out) {
-    __shared__ int nseg_s, i0_s, j0_s;
-    __shared__ float lx_s, ly_s, lth_s;
-    // dynamic LDS (ped_scan_lds_bytes): float2 dir[PB], float rng[PB], then the rectangle sides of the other agents and
-    // their beam-index intervals (prim_in_range), sized by cfg.max_peds -- the compiled maximum of 64 pedestrians cost
-    // 6 KB per workgroup and, with 512 beams, two of the CU's 16 workgroups
-    extern __shared__ __attribute__((aligned(16))) char dyn[];
-    const int e = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void ped_scan_core(const navsim_config& c, const navsim_state& st, int e, int i, int n,
+                                                const double* __restrict__ tab, char* dyn, PedScanShared& ss) {
+    int& nseg_s = ss.nseg; int& i0_s = ss.i0; int& j0_s = ss.j0;
+    float& lx_s = ss.lx; float& ly_s = ss.ly; float& lth_s = ss.lth;
+    double& cT_s = ss.cT; double& sT_s = ss.sT;
+    const int tid = threadIdx.x;
     const int N = c.max_peds, PB = c.ped_n_beams, H = c.map_h, W = c.map_w;
-    int n = st.n_peds[e];
-    n = n > N ? N : n;
-    if (i >= n) return;
     float2* dir = (float2*)dyn;
     float* rng = (float*)(dyn + sizeof(float2) * (size_t)PB);
     float (*seg)[4] = (float(*)[4])(dyn + ((12 * (size_t)PB + 15) & ~(size_t)15));
@@ -29,6 +30,7 @@ __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim
         const double* pp = st.ped_pose + ((size_t)e * N + i) * 3;
         lx_s = (float)pp[0]; ly_s = (float)pp[1]; lth_s = (float)pp[2];              // env.py:386
         nv::xy_to_ij_f32(lx_s, ly_s, c, i0_s, j0_s);                                 // env.py:419
+        if (tab) { double sn, cs; nv::sincos((double)lth_s, sn, cs); cT_s = cs; sT_s = sn; }
     }
     __syncthreads();
     if (tid <= n && tid != i) {                                                      // env.py:404-414
@@ -68,10 +70,19 @@ __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim
     const float res = (float)c.resolution;
     const float x0 = (float)i0_s, y0 = (float)j0_s;
     const double lth = (double)lth_s;
-    for (int k = tid; k < PB; k += BLOCK) {
-        double lin = (PB == 1) ? c.ped_angle_min : ((k == PB - 1) ? c.ped_angle_last : (double)k * step + c.ped_angle_min);
+    for (int k = tid; k < PB; k += block_threads<BLOCK>()) {
+        const double lin = ped_beam_angle(c, k);
+        float heading = (float)(lin + lth);
         float dx, dy;
-        nv::beam_dir((float)(lin + lth), dx, dy);
+        bool fast = false;
+        if (tab) {
+            const double2 cs = ((const double2*)tab)[k];
+            fast = beam_dir_fast(lin, lth, cs.x, cs.y, cT_s, sT_s, heading, dx, dy);
+        }
+        if (!fast) nv::beam_dir(heading, dx, dy);
+#ifdef NAVSIM_DIAG_PED_CHEAP_DIR   // diagnostic build only (wrong directions): what does the exact direction cost?
+        dx = __cosf(heading); dy = __sinf(heading);
+#endif
         dir[k] = make_float2(dx, dy);
         float t = 0.0f;
         lanemask_t active = mask_of(true), hit = 0;
@@ -82,6 +93,22 @@ __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim
     __syncthreads();
     merge_prims_culled_core<BLOCK>(PB, lx_s, ly_s, (float)step, nseg_s, 0, pr, dir, rng);
     __syncthreads();
+}
+
+template <typename Field, int BLOCK, int RULE, bool RECT>
+__global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim_state st, float* __restrict__ out) {
+    // the compiled maximum of 64 pedestrians cost 6 KB per workgroup and, with 512 beams, two of the CU's 16 workgroups:
+    // the region is sized by cfg.max_peds
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    const int e = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
+    const int N = c.max_peds, PB = c.ped_n_beams;
+    int n = st.n_peds[e];
+    n = n > N ? N : n;
+    if (i >= n) return;
+    __shared__ PedScanShared ss;
+    ped_scan_core<Field, BLOCK, RULE, RECT>(c, st, e, i, n, nullptr, dyn, ss);
+    const float* rng = (const float*)(dyn + sizeof(float2) * (size_t)PB);
+    const float rmax = (float)c.ped_range_max;
     float* row = out + ((size_t)e * N + i) * PB;
     for (int k = tid; k < PB; k += BLOCK) {
         float r = rng[k];
@@ -89,6 +116,45 @@ __global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim
         r = r > rmax ? rmax : r;
         row[k] = r;
     }
+}
+
+// env.py:685-693 + 629-630, 647 + human_policy.py:38-42 in ONE workgroup per pedestrian (round 4, verdict item 7): the scan
+// stays in LDS, is clipped and scaled in place and feeds conv1 / conv2; the latency-bound march of one workgroup runs beside
+// the FMA-bound convolutions of its CU's other workgroups.  The scan's LDS region is reused by conv1's output.  scans_out
+// (optional): the clipped scan rows [E, N, 512], what navsim_ped_scans writes.  A dead slot writes nothing (its features
+// stay whatever the scratch held: policy_head_kernel never reads a dead slot's result).  Same functions, same order as
+// ped_scan_kernel -> policy_features_kernel: bit-identical.
+template <typename Field, int RULE, bool RECT>
+__global__ __launch_bounds__(256) void ped_scan_features_kernel(navsim_config c, navsim_state st, int p0, int n_ped,
+                                                                const double* __restrict__ tab, float* __restrict__ scans_out,
+                                                                const float* __restrict__ w1, const float* __restrict__ b1,
+                                                                const float* __restrict__ w2t, const float* __restrict__ b2,
+                                                                float* __restrict__ feat) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];      // max(scan region, o1[kConvCh][258])
+    __shared__ float x[520];
+    const int tid = threadIdx.x, p = blockIdx.x;
+    if (p >= n_ped) return;
+    const int N = c.max_peds;
+    const size_t q = (size_t)p0 + p;
+    const int e = (int)(q / N), i = (int)(q - (size_t)e * N);
+    int n = st.n_peds[e];
+    n = n > N ? N : n;
+    if (i >= n) return;
+    __shared__ PedScanShared ss;
+    // BLOCK = 0 (threads read from the launch): the 256-thread instantiation of the scan crashes this compiler's inliner
+    ped_scan_core<Field, 0, RULE, RECT>(c, st, e, i, n, tab, dyn, ss);
+    const float* rng = (const float*)(dyn + sizeof(float2) * 512);
+    const float rmax = (float)c.ped_range_max;
+    float* row = scans_out ? scans_out + q * 512 : nullptr;
+    for (int k = tid; k < 512; k += 256) {
+        float r = rng[k];
+        r = r < 0.0f ? 0.0f : r;
+        r = r > rmax ? rmax : r;
+        if (row) row[k] = r;
+        x[1 + k] = policy_input(r);
+    }
+    __syncthreads();                                                // rng is dead: conv1 writes over it
+    policy_conv(x, (float(*)[258])dyn, w1, b1, w2t, b2, feat + (size_t)p * kPolFeat);
 }
 
 // ============================================================================================

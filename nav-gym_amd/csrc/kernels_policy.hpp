@@ -13,49 +13,52 @@
 // ============================================================================================
 constexpr int kPolFeat = 4096, kPolH1 = 256, kPolH2 = 128, kPolIn2 = 260;
 
-__global__ __launch_bounds__(256) void policy_features_kernel(const float* __restrict__ scans, int p0, int n_ped,
-                                                              const float* __restrict__ w1, const float* __restrict__ b1,
-                                                              const float* __restrict__ w2t, const float* __restrict__ b2,
-                                                              float* __restrict__ feat) {
-    __shared__ float x[520];                 // x[1 + i] = input i, x[0] = left padding
-    __shared__ float o1[32][258];            // o1[c][1 + t], zero padding at both ends
+// conv1 + ReLU, conv2 + ReLU of ONE pedestrian by its 256-thread workgroup.  x[1 + i] = network input i (x[0] = left
+// padding, written here); o1 = [kConvCh][258] floats of LDS scratch; f = the pedestrian's 4096 features.  The caller has
+// written x[1 .. 512]; no barrier is needed before the call.
+// Round 4: conv1's 32 output channels pass through LDS kConvCh at a time -- conv2 accumulates over its input channels in
+// ascending order anyway, so it takes them as they come (same chains, same order: bit-identical).  The whole conv1 output
+// (33 KB) held a CU at four workgroups; 16.5 KB allow eight: 309 -> 267 us per 32 768 pedestrians (8 channels at a time:
+// 1030 us -- profiles/r04_fuse/ab_conv.txt).
+#ifndef NAVSIM_CONV_CH
+#define NAVSIM_CONV_CH 16
+#endif
+constexpr int kConvCh = NAVSIM_CONV_CH;
+constexpr size_t kConvLdsBytes = (size_t)kConvCh * 258 * sizeof(float);
+__device__ __forceinline__ void policy_conv(float* x, float (*o1)[258],
+                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                            const float* __restrict__ w2t, const float* __restrict__ b2,
+                                            float* __restrict__ f) {
     const int tid = threadIdx.x;
-    const int p = blockIdx.x;
-    if (p >= n_ped) return;
-    const float* scan = scans + (size_t)(p0 + p) * 512;
-    for (int k = tid; k < 512; k += 256) {                      // env.py:629-630
-        double v = (double)scan[k];
-        v = v < 0.0 ? 0.0 : (v > 6.0 ? 6.0 : v);
-        x[1 + k] = (float)(v / 6.0 - 0.5);
-    }
     if (tid == 0) x[0] = 0.0f;
-    if (tid < 32) { o1[tid][0] = 0.0f; o1[tid][256] = 0.0f; o1[tid][257] = 0.0f; }
+    if (tid < kConvCh) { o1[tid][0] = 0.0f; o1[tid][256] = 0.0f; o1[tid][257] = 0.0f; }
     __syncthreads();
-    if (tid < 255) {                                            // conv1: thread = output position
-        float xv[5];
+    float xv[5];                                                // conv1: thread = output position
 #pragma unroll
-        for (int k = 0; k < 5; ++k) xv[k] = x[2 * tid + k];     // input index 2t + k - 1
-        for (int o = 0; o < 32; ++o) {
-            float acc = 0.0f;
+    for (int k = 0; k < 5; ++k) xv[k] = (tid < 255) ? x[2 * tid + k] : 0.0f;     // input index 2t + k - 1
+    const int t = tid & 127;                                    // conv2: thread = (position, half of the channels)
+    const int og = __builtin_amdgcn_readfirstlane((tid >> 7) * 16);   // wave-uniform: weights come by s_load
+    float acc[16];
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch)
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    for (int c0 = 0; c0 < 32; c0 += kConvCh) {
+        if (c0 > 0) __syncthreads();                            // conv2 has read the previous channels
+        if (tid < 255) {
+            for (int o = c0; o < c0 + kConvCh; ++o) {
+                float a = 0.0f;
 #pragma unroll
-                for (int k = 0; k < 5; ++k) acc = __builtin_fmaf(w1[(o * 3 + ch) * 5 + k], xv[k], acc);
-            acc = acc + b1[o];
-            o1[o][1 + tid] = acc > 0.0f ? acc : 0.0f;
+                for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) a = __builtin_fmaf(w1[(o * 3 + ch) * 5 + k], xv[k], a);
+                a = a + b1[o];
+                o1[o - c0][1 + tid] = a > 0.0f ? a : 0.0f;
+            }
         }
-    }
-    __syncthreads();
-    {                                                           // conv2: thread = (position, half of the channels)
-        const int t = tid & 127;
-        const int og = __builtin_amdgcn_readfirstlane((tid >> 7) * 16);   // wave-uniform: weights come by s_load
-        float acc[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
-        for (int c = 0; c < 32; ++c) {
+        __syncthreads();
+        for (int c = 0; c < kConvCh; ++c) {
             const float i0 = o1[c][2 * t], i1 = o1[c][2 * t + 1], i2 = o1[c][2 * t + 2];   // index 2t + k - 1
             // w2t[c][k][o]: the 16 channels of this half are contiguous -> one scalar s_load_dwordx16 per k
-            const float* ww = w2t + (c * 3) * 32 + og;                  // wave-uniform
+            const float* ww = w2t + ((c0 + c) * 3) * 32 + og;           // wave-uniform
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 acc[j] = __builtin_fmaf(ww[j], i0, acc[j]);
@@ -63,13 +66,32 @@ __global__ __launch_bounds__(256) void policy_features_kernel(const float* __res
                 acc[j] = __builtin_fmaf(ww[64 + j], i2, acc[j]);
             }
         }
-        float* f = feat + (size_t)p * kPolFeat;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            float v = acc[j] + b2[og + j];
-            f[(og + j) * 128 + t] = v > 0.0f ? v : 0.0f;
-        }
     }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float v = acc[j] + b2[og + j];
+        f[(og + j) * 128 + t] = v > 0.0f ? v : 0.0f;
+    }
+}
+// network input of a clipped range (env.py:629-630)
+__device__ __forceinline__ float policy_input(float r) {
+    double v = (double)r;
+    v = v < 0.0 ? 0.0 : (v > 6.0 ? 6.0 : v);
+    return (float)(v / 6.0 - 0.5);
+}
+
+__global__ __launch_bounds__(256) void policy_features_kernel(const float* __restrict__ scans, int p0, int n_ped,
+                                                              const float* __restrict__ w1, const float* __restrict__ b1,
+                                                              const float* __restrict__ w2t, const float* __restrict__ b2,
+                                                              float* __restrict__ feat) {
+    __shared__ float x[520];                 // x[1 + i] = input i, x[0] = left padding
+    __shared__ float o1[kConvCh][258];       // o1[c][1 + t], zero padding at both ends
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x;
+    if (p >= n_ped) return;
+    const float* scan = scans + (size_t)(p0 + p) * 512;
+    for (int k = tid; k < 512; k += 256) x[1 + k] = policy_input(scan[k]);
+    policy_conv(x, o1, w1, b1, w2t, b2, feat + (size_t)p * kPolFeat);
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -149,11 +171,25 @@ __global__ __launch_bounds__(256) void policy_fc1_kernel(const float* __restrict
         }
 }
 
+// robot-frame angle of a pedestrian's beam k (env.py:685-693: linspace over the half plane, the end point exact)
+__device__ __forceinline__ double ped_beam_angle(const navsim_config& c, int k) {
+    const int PB = c.ped_n_beams;
+    const double step = (PB > 1) ? (c.ped_angle_last - c.ped_angle_min) / (double)(PB - 1) : 0.0;
+    return (PB == 1) ? c.ped_angle_min : ((k == PB - 1) ? c.ped_angle_last : (double)k * step + c.ped_angle_min);
+}
+
 // W2t[k][j] = W2[j][k]: coalesced rows for the head kernel; cv2t[c][k][o] = cv2_w[o][c][k]: the conv2 weights
 // of 16 adjacent output channels contiguous, so that the features kernel fetches them with wide scalar loads
+// tab (optional): cos / sin of the pedestrians' robot-frame beam angles [ped_n_beams][2], the table of beam_dir_fast
 __global__ __launch_bounds__(256) void policy_transpose_kernel(const float* __restrict__ w2, float* __restrict__ w2t,
-                                                               const float* __restrict__ cv2, float* __restrict__ cv2t) {
+                                                               const float* __restrict__ cv2, float* __restrict__ cv2t,
+                                                               navsim_config c, double* __restrict__ tab) {
     int idx = blockIdx.x * 256 + threadIdx.x;
+    if (tab && idx < c.ped_n_beams) {
+        double sn, cs;
+        nv::sincos(ped_beam_angle(c, idx), sn, cs);
+        tab[2 * idx] = cs; tab[2 * idx + 1] = sn;
+    }
     if (idx < kPolH2 * kPolIn2) {
         int j = idx / kPolIn2, k = idx - j * kPolIn2;
         w2t[k * kPolH2 + j] = w2[idx];
@@ -166,7 +202,10 @@ __global__ __launch_bounds__(256) void policy_transpose_kernel(const float* __re
 
 // Eight pedestrians per workgroup: the 133 KB second layer is streamed once per eight of them (one pedestrian
 // per workgroup made this kernel L2-bandwidth bound at 22 TB/s), thread j owns hidden unit j of all eight.
-constexpr int kHeadPeds = 8;
+#ifndef NAVSIM_HEAD_PEDS
+#define NAVSIM_HEAD_PEDS 8          // measured 8 / 16 / 32 on c3: policy 2.349 / 2.351 / 2.52 ms (profiles/r04_fuse/ab_head.txt)
+#endif
+constexpr int kHeadPeds = NAVSIM_HEAD_PEDS;
 __global__ __launch_bounds__(128) void policy_head_kernel(navsim_config c, navsim_state st, int p0, int n_ped,
                                                           const float* __restrict__ h1, const float* __restrict__ w2t,
                                                           navsim_policy_weights w, float* __restrict__ prev_actions,

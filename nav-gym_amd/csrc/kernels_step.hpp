@@ -136,11 +136,13 @@ __device__ __forceinline__ void first_probe(const Field& field, int i0, int j0, 
 // used to derive the interval themselves, two atan2f per primitive and ROUND of the merge instead of per primitive:
 // 6 % of c3's vector instructions.)
 constexpr float kPrimAllBeams = 1.0e30f;
+// threads of the workgroup: the template argument, or (BLOCK = 0) read from the launch
+template <int BLOCK> __device__ __forceinline__ int block_threads() { return BLOCK ? BLOCK : (int)blockDim.x; }
 template <int BLOCK>
 __device__ __forceinline__ void prim_in_range(int nprim, int nseg, float lx, float ly, float rcull, const Prims pr,
                                               float stepf, float beta0) {
     const float kTwoPiF = 6.2831853f;
-    for (int p = (int)threadIdx.x; p < nprim; p += BLOCK) {
+    for (int p = (int)threadIdx.x; p < nprim; p += block_threads<BLOCK>()) {
         bool skip;
         float ac = 0.0f, w = 0.0f;
         bool full = (stepf <= 0.0f);
@@ -188,7 +190,7 @@ __device__ __forceinline__ void merge_prims_culled_core(int B, float lx, float l
     // aliases of the bearing: rel + w <= pi + 1.6 < 2 pi - 2 beams, so rel - 2 pi (m = -1) lies below beam 0 unless the
     // beams are very few
     const int m_first = (kTwoPiF - 2.0f * stepf > 4.8f) ? 0 : -1;
-    for (int p = ((int)threadIdx.x) / G; p < nprim; p += BLOCK / G) {
+    for (int p = ((int)threadIdx.x) / G; p < nprim; p += block_threads<BLOCK>() / G) {
         const float klo = pr.info[2 * p], khi = pr.info[2 * p + 1];  // prim_in_range ran before the scan (prims_prepare)
         if (klo > khi) continue;                                    // beyond the clip range
         const bool full = klo < -0.5f * kPrimAllBeams;

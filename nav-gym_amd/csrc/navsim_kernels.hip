@@ -918,14 +918,16 @@ size_t navsim_ped_policy_workspace_bytes(const navsim_config* c) {
     if (!c) return 0;
     size_t P = (size_t)c->n_envs * (size_t)c->max_peds;
     size_t chunk = P < (size_t)kPolicyChunk ? P : (size_t)kPolicyChunk;
-    return 2048 + (size_t)(kPolH2 * kPolIn2 + 32 * 32 * 3) * sizeof(float) + chunk * (size_t)(kPolFeat + kPolH1) * sizeof(float);
+    return 2048 + 8192 + (size_t)(kPolH2 * kPolIn2 + 32 * 32 * 3) * sizeof(float) + chunk * (size_t)(kPolFeat + kPolH1) * sizeof(float);
 }
 
-int navsim_ped_policy(const navsim_config* c, const navsim_state* st, const navsim_policy_weights* w,
-                      const float* ped_scans, float* prev_actions, double* ped_cmd, void* workspace,
-                      size_t workspace_bytes, void* stream) {
+// ped_scans != NULL: the network reads those scans (navsim_ped_policy); NULL: every chunk's scans are taken by the fused
+// scan + features kernel from the current state and, when scans_out != NULL, also written there (navsim_ped_scan_policy)
+static int ped_policy_run(const navsim_config* c, const navsim_state* st, const navsim_policy_weights* w,
+                          const float* ped_scans, float* scans_out, float* prev_actions, double* ped_cmd, void* workspace,
+                          size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
-    if (!c || !st || !w || !ped_scans || !prev_actions || !ped_cmd || !workspace || !st->ped_pose ||
+    if (!c || !st || !w || !prev_actions || !ped_cmd || !workspace || !st->ped_pose ||
         !st->ped_waypoints || !st->ped_n_waypoints || !st->ped_v_pref || !st->n_peds)
         return NAVSIM_E_ARG;
     if (!w->cv1_w || !w->cv1_b || !w->cv2_w || !w->cv2_b || !w->fc1_w || !w->fc1_b || !w->fc2_w || !w->fc2_b ||
@@ -934,24 +936,69 @@ int navsim_ped_policy(const navsim_config* c, const navsim_state* st, const navs
     if (c->ped_n_beams != 512 || c->max_peds < 1) return NAVSIM_E_UNSUPPORTED;
     if (c->max_waypoints < 1 || c->max_waypoints > NAVSIM_MAX_WAYPOINTS) return NAVSIM_E_ARG;
     if (workspace_bytes < navsim_ped_policy_workspace_bytes(c)) return NAVSIM_E_ARG;
+    const bool fused = ped_scans == nullptr;
+    if (fused) {                                  // what navsim_ped_scans checks
+        if (c->ped_model == NAVSIM_PED_NONE || !st->robot_pose || !st->field) return NAVSIM_E_ARG;
+        if (c->max_peds > NAVSIM_MAX_PEDS) return NAVSIM_E_UNSUPPORTED;
+        if (c->field_format != NAVSIM_FIELD_U16T && c->field_format != NAVSIM_FIELD_F32) return NAVSIM_E_UNSUPPORTED;
+    }
     const size_t P = (size_t)c->n_envs * (size_t)c->max_peds;
     if (P == 0) return NAVSIM_OK;
     hipStream_t s = (hipStream_t)stream;
     float* w2t = (float*)workspace;
     float* cv2t = (float*)((char*)workspace + ((kPolH2 * kPolIn2 * sizeof(float) + 255) & ~(size_t)255));
-    float* feat = (float*)((char*)cv2t + ((32 * 32 * 3 * sizeof(float) + 1023) & ~(size_t)1023));
+    double* tab = (double*)((char*)cv2t + ((32 * 32 * 3 * sizeof(float) + 1023) & ~(size_t)1023));
+    float* feat = (float*)((char*)tab + 8192);
     const size_t chunk = P < (size_t)kPolicyChunk ? P : (size_t)kPolicyChunk;
     float* h1 = feat + chunk * kPolFeat;
     constexpr size_t fc1_lds = (size_t)2 * (128 + 128) * 33 * sizeof(float);       // 67,584 B
     if (allow_lds((const void*)policy_fc1_kernel, fc1_lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
-    policy_transpose_kernel<<<(kPolH2 * kPolIn2 + 255) / 256, 256, 0, s>>>(w->fc2_w, w2t, w->cv2_w, cv2t);
+    policy_transpose_kernel<<<(kPolH2 * kPolIn2 + 255) / 256, 256, 0, s>>>(w->fc2_w, w2t, w->cv2_w, cv2t, *c, fused ? tab : nullptr);
+    // fused kernel's dynamic LDS: the scan region (navsim_ped_scans) and conv1's output [kConvCh][258] share it
+    size_t lds = (((size_t)c->ped_n_beams * (sizeof(float2) + sizeof(float)) + 15) & ~(size_t)15) + (size_t)(c->max_peds + 1) * (64 + 32);
+    lds = lds < kConvLdsBytes ? kConvLdsBytes : lds;
+    const int rule = march_rule_variant(c);
+#ifdef NAVSIM_ONLY_RULE
+    if (fused && rule != NAVSIM_ONLY_RULE) return NAVSIM_E_UNSUPPORTED;
+#define NAVSIM_PSF(F, RECT) ped_scan_features_kernel<F, NAVSIM_ONLY_RULE, RECT><<<n, 256, lds, s>>>(*c, *st, (int)p0, n, tab, scans_out, w->cv1_w, w->cv1_b, cv2t, w->cv2_b, feat)
+#else
+#define NAVSIM_PSF_(F, R, RECT) ped_scan_features_kernel<F, R, RECT><<<n, 256, lds, s>>>(*c, *st, (int)p0, n, tab, scans_out, w->cv1_w, w->cv1_b, cv2t, w->cv2_b, feat)
+#define NAVSIM_PSF(F, RECT) \
+    do { if (rule == NAVSIM_MARCH_F32)          NAVSIM_PSF_(F, NAVSIM_MARCH_F32, RECT); \
+         else if (rule == NAVSIM_MARCH_F32_FMA) NAVSIM_PSF_(F, NAVSIM_MARCH_F32_FMA, RECT); \
+         else if (rule == kMarchF64Exact32 && !std::is_same<F, FieldF32>::value) NAVSIM_PSF_(F, kMarchF64Exact32, RECT); \
+         else                                   NAVSIM_PSF_(F, NAVSIM_MARCH_F64, RECT); } while (0)
+#endif
     for (size_t p0 = 0; p0 < P; p0 += chunk) {
         const int n = (int)(P - p0 < chunk ? P - p0 : chunk);
-        policy_features_kernel<<<n, 256, 0, s>>>(ped_scans, (int)p0, n, w->cv1_w, w->cv1_b, cv2t, w->cv2_b, feat);
+        if (!fused) {
+            policy_features_kernel<<<n, 256, 0, s>>>(ped_scans, (int)p0, n, w->cv1_w, w->cv1_b, cv2t, w->cv2_b, feat);
+        } else if (c->field_format == NAVSIM_FIELD_U16T) {
+            if (st->rect_table) NAVSIM_PSF(FieldU16T, true); else NAVSIM_PSF(FieldU16T, false);
+        } else {
+            NAVSIM_PSF(FieldF32, false);
+        }
         policy_fc1_kernel<<<dim3((n + 127) / 128, 2), 256, fc1_lds, s>>>(feat, n, w->fc1_w, w->fc1_b, h1);
         policy_head_kernel<<<(n + kHeadPeds - 1) / kHeadPeds, 128, 0, s>>>(*c, *st, (int)p0, n, h1, w2t, *w, prev_actions, ped_cmd);
     }
+#undef NAVSIM_PSF
+#ifndef NAVSIM_ONLY_RULE
+#undef NAVSIM_PSF_
+#endif
     return launch_status();
+}
+
+int navsim_ped_policy(const navsim_config* c, const navsim_state* st, const navsim_policy_weights* w,
+                      const float* ped_scans, float* prev_actions, double* ped_cmd, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    if (!ped_scans) return NAVSIM_E_ARG;
+    return ped_policy_run(c, st, w, ped_scans, nullptr, prev_actions, ped_cmd, workspace, workspace_bytes, stream);
+}
+
+int navsim_ped_scan_policy(const navsim_config* c, const navsim_state* st, const navsim_policy_weights* w,
+                           float* scans_out, float* prev_actions, double* ped_cmd, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    return ped_policy_run(c, st, w, nullptr, scans_out, prev_actions, ped_cmd, workspace, workspace_bytes, stream);
 }
 
 int navsim_crowd_check(const navsim_crowd_params* p, int32_t n_envs, int32_t max_agents, int32_t grid,

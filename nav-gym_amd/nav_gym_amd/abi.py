@@ -309,6 +309,7 @@ def declare(lib, suffix=""):
     else:
         sig("navsim_ped_policy_workspace_bytes", [cfgp], C.c_size_t)
         sig("navsim_ped_policy", [cfgp, stp, C.POINTER(NavsimPolicyWeights), _P, _P, _P, _P, C.c_size_t, _P])
+        sig("navsim_ped_scan_policy", [cfgp, stp, C.POINTER(NavsimPolicyWeights), _P, _P, _P, _P, C.c_size_t, _P])
         sig("navsim_launch_order", [_P, _P, i32, _P])
         sig("navsim_replan_workspace_bytes", [cfgp, i32], C.c_size_t)
         sig("navsim_replan", [cfgp, stp, i32, _P, C.c_size_t, _P])
@@ -340,7 +341,7 @@ EXPORTS = (
     "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
     "navsim_scan_threshold", "navsim_beam_table", "navsim_ped_scans", "navsim_regen_workspace_bytes", "navsim_regen", "navsim_regen_swap", "navsim_regen_stage",
-    "navsim_costmap", "navsim_plan", "navsim_launch_order", "navsim_replan_workspace_bytes", "navsim_replan", "navsim_ped_policy_workspace_bytes", "navsim_ped_policy",
+    "navsim_costmap", "navsim_plan", "navsim_launch_order", "navsim_replan_workspace_bytes", "navsim_replan", "navsim_ped_policy_workspace_bytes", "navsim_ped_policy", "navsim_ped_scan_policy",
     "navsim_crowd_check", "navsim_crowd_angular_map", "navsim_crowd_local_map", "navsim_crowd_orca", "navsim_crowd_agent_step",
     "navsim_step", "navsim_prepare", "navsim_reset_obs", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math", "navsim_debug_xy_to_ij",

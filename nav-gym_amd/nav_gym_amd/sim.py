@@ -624,12 +624,21 @@ class NavSim(object):
             self.t["policy_prev_actions"] = torch.zeros((self.cfg.n_envs, self.cfg.max_peds, 2), dtype=torch.float32,
                                                         device=self.device)
 
-    def ped_policy(self, scans=None):
+    def ped_policy(self, scans=None, fused=False, scans_out=None):
         """navsim_ped_policy (env.py:617-662): pedestrian scans -> HumanPolicy actor -> ped_cmd for a
-        NAVSIM_PED_EXTERNAL step.  Returns (ped_cmd [E,N,2] float64, clip(mean) [E,N,2] float32)."""
+        NAVSIM_PED_EXTERNAL step.  Returns (ped_cmd [E,N,2] float64, clip(mean) [E,N,2] float32).
+        scans=None: the scans of the current state (navsim_ped_scans first).  fused=True: navsim_ped_scan_policy -- every
+        scan is taken inside the pass by the workgroup that convolves it and only written to HBM when scans_out (float32
+        [E,N,512]) is given; bit-identical, saves the [E,N,512] buffer, measured 1 % slower than the two calls."""
+        ws = self.t["policy_ws"]
+        if fused:
+            check(self.lib.navsim_ped_scan_policy(C.byref(self.cfg), C.byref(self.st), C.byref(self.policy_w),
+                                                  _ptr(scans_out) if scans_out is not None else None,
+                                                  _ptr(self.t["policy_prev_actions"]), _ptr(self.t["ped_cmd"]), _ptr(ws),
+                                                  ws.numel(), _stream()), "navsim_ped_scan_policy")
+            return self.t["ped_cmd"], self.t["policy_prev_actions"]
         if scans is None:
             scans = self.ped_scans()
-        ws = self.t["policy_ws"]
         check(self.lib.navsim_ped_policy(C.byref(self.cfg), C.byref(self.st), C.byref(self.policy_w), _ptr(scans),
                                          _ptr(self.t["policy_prev_actions"]), _ptr(self.t["ped_cmd"]), _ptr(ws),
                                          ws.numel(), _stream()), "navsim_ped_policy")

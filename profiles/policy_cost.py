@@ -34,9 +34,14 @@ rows = {
     "ped_policy_ms": timed(lambda: sim.ped_policy(scans)),
     "step_external_ms": timed(lambda: sim.step(act)),
 }
-def full():
+def two_calls():
     sim.ped_policy(sim.ped_scans()); sim.step(act)
-rows["full_step_ms"] = timed(full)
+rows["full_step_two_calls_ms"] = timed(two_calls)          # navsim_ped_scans -> navsim_ped_policy: the scans through HBM
+rows["full_step_ms"] = rows["full_step_two_calls_ms"]
+rows["ped_scan_policy_fused_ms"] = timed(lambda: sim.ped_policy(fused=True))   # round 4: navsim_ped_scan_policy (scan -> conv in one workgroup)
+def fused():
+    sim.ped_policy(fused=True); sim.step(act)
+rows["full_step_fused_ms"] = timed(fused)
 P = E * cfg.max_peds
 rows["pedestrians"] = P
 rows["env_steps_per_s"] = E / (rows["full_step_ms"] * 1e-3)

@@ -1023,6 +1023,42 @@ def test_policy_large_batch_is_chunk_invariant(gpu):
     assert np.abs(mean[0, :, :18]).max() > 0
 
 
+@pytest.mark.parametrize("fmt,rects", [(abi.FIELD_U16T, True), (abi.FIELD_U16T, False), (abi.FIELD_F32, False)])
+def test_fused_scan_policy_equals_the_two_calls(gpu, fmt, rects):
+    """navsim_ped_scan_policy (round 4: every pedestrian's scan taken, clipped, scaled and convolved by ONE workgroup, the
+    beam directions through the beam table) == navsim_ped_scans followed by navsim_ped_policy, bit for bit: the scans it
+    can write out, the network output, the commands, the popped waypoints.  Ragged pedestrian counts (dead slots keep their
+    rows), pedestrians close enough to see each other and the robot."""
+    torch = gpu.torch
+    E, size, N = 12, 200, 20
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_EXTERNAL, n_spawn=6,
+                                 auto_reset=1, seed=23, field_format=fmt)
+    gpu.world.lidar_1081(cfg)
+    occ = gpu.world.make_maps(E, size, 23)
+    arrays = gpu.world.make_world(cfg, occ, n_peds=17, device=gpu.dev, rect_table=rects)
+    from nav_gym_amd import robots
+    for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
+        arrays[key] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array("keti", name)))
+    arrays["n_peds"][::3] = 9
+    arrays["n_peds"][1] = 0
+    g = gpu.sim.NavSim(cfg, arrays)
+    g.set_policy(_policy_weights_random(5))
+    g.t["policy_prev_actions"].copy_(torch.rand((E, N, 2), device=gpu.dev) * 0.5)
+    keep = {k: g.t[k].clone() for k in ("policy_prev_actions", "ped_waypoints", "ped_n_waypoints")}
+    scans = g.ped_scans()
+    cmd_a, mean_a = [x.clone() for x in g.ped_policy(scans)]
+    wp_a, nwp_a = g.t["ped_waypoints"].clone(), g.t["ped_n_waypoints"].clone()
+    for k, v in keep.items():
+        g.t[k].copy_(v)
+    out = torch.full_like(scans, -7.0)
+    cmd_b, mean_b = g.ped_policy(fused=True, scans_out=out)
+    assert torch.equal(cmd_a, cmd_b) and torch.equal(mean_a, mean_b)
+    assert torch.equal(wp_a, g.t["ped_waypoints"]) and torch.equal(nwp_a, g.t["ped_n_waypoints"])
+    live = (torch.arange(N, device=gpu.dev)[None, :] < g.t["n_peds"][:, None].clamp(max=N))
+    assert torch.equal(out[live], scans[live]) and bool((out[~live] == -7.0).all())
+    assert float(mean_b[live].abs().max()) > 0 and float(scans[live].min()) < 5.9
+
+
 @pytest.mark.parametrize("name", ["random_S1", "peds_S1"])
 def test_policy_vs_reference_trace(gpu, name):
     """The same control block against the reference's own step(): with the weights the golden traces were
