@@ -741,6 +741,75 @@ def make_crowd_maps():
           % (n, 100 * (amap < 1.0).mean(), m, 100 * (lmap == 0).mean()))
 
 
+def make_crowd_reset():
+    """CrowdSim.reset (crowd_sim.py:626-722) -- the reference's own method, configured from its own config file
+    (crowd_nav/config/test_soadrl_static.config: 5 humans, ORCA pedestrians, 14 m map at 0.1 m, up to 10 circles and 10 walls,
+    randomize_attributes), for phases 'test' (square_crossing) and 'val' (circle_crossing), which seed NumPy's global stream
+    with counter_offset + case number (crowd_sim.py:651-657): robot, humans, obstacle outlines, the occupancy map and the static
+    obstacles as pedestrians of 12 + 12 cases.  gym / rvo2 / tensorflow are import-only stand-ins; the humans' policy object is
+    the reference's ORCA class, which reset() only resets."""
+    import configparser, importlib
+    if REF_SRC not in sys.path:
+        sys.path.insert(0, REF_SRC)
+    for name in ("gym", "gym.envs", "gym.envs.registration", "rvo2", "cv2", "tensorflow", "PIL", "matplotlib",
+                 "crowd_nav", "crowd_nav.policy", "crowd_nav.policy.policy_factory"):
+        try:
+            importlib.import_module(name)
+        except Exception:
+            sys.modules[name] = types.ModuleType(name)
+    if not hasattr(sys.modules["gym"], "Env"):
+        sys.modules["gym"].Env = object
+    if not hasattr(sys.modules["gym.envs.registration"], "register"):
+        sys.modules["gym.envs.registration"].register = lambda **k: None
+    import warnings
+    if not hasattr(sys.modules["crowd_nav.policy.policy_factory"], "policy_factory"):
+        sys.modules["crowd_nav.policy.policy_factory"].policy_factory = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from crowd_sim.envs.policy.orca import ORCA
+        sys.modules["crowd_nav.policy.policy_factory"].policy_factory["orca"] = ORCA
+        from crowd_sim.envs import crowd_sim as cs
+        cs.policy_factory = {"orca": ORCA}
+        from crowd_sim.envs.utils.robot import Robot
+    config = configparser.RawConfigParser()
+    config.read(os.path.join(REF_SRC, "crowd_nav", "config", "test_soadrl_static.config"))
+
+    class RobotPolicy(object):                      # any learning policy: reset() only reads its name
+        name = "SARL"
+        time_step = None
+
+    rows = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for phase in ("test", "val"):
+            for case in list(range(10)) + [123, 499 if phase == "test" else 49]:
+                env = cs.CrowdSim()
+                env.configure(config, silent=True)
+                robot = Robot(config, "robot")
+                robot.set_policy(RobotPolicy())
+                env.set_robot(robot)
+                ob, local_map = env.reset(phase=phase, test_case=case)
+                r = env.robot
+                rows.append(dict(
+                    phase=phase, case=case,
+                    robot=np.array([r.px, r.py, r.gx, r.gy, r.vx, r.vy, r.theta, r.radius, r.v_pref]),
+                    humans=np.array([[h.px, h.py, h.gx, h.gy, h.vx, h.vy, h.theta, h.radius, h.v_pref, float(h.robot_visible)]
+                                     for h in env.humans]).reshape(-1, 10),
+                    verts=np.array(env.obstacle_vertices, dtype=np.float64).reshape(-1, 4, 2),
+                    map=np.asarray(env.map, dtype=np.uint8),
+                    static=np.array([[s.px, s.py, s.vx, s.vy, s.radius] for s in env.static_obstacles_as_pedestrians]).reshape(-1, 5),
+                    local_map=np.asarray(local_map, dtype=np.float64).reshape(-1),
+                    circle_radius=np.float64(env.last_circle_radius)))
+    out = {"n": np.int64(len(rows)), "phase": np.array([r["phase"] for r in rows]), "case": np.array([r["case"] for r in rows])}
+    for k, r in enumerate(rows):
+        for key in ("robot", "humans", "verts", "static", "local_map", "circle_radius"):
+            out["%s_%d" % (key, k)] = r[key]
+        out["map_%d" % k] = np.packbits(r["map"]); out["map_shape_%d" % k] = np.array(r["map"].shape)
+    np.savez_compressed(os.path.join(HERE, "golden_crowd_reset.npz"), **out)
+    print("golden_crowd_reset.npz: %d resets; humans per case %s; obstacles per case %s" % (
+        len(rows), [len(r["humans"]) for r in rows], [len(r["verts"]) for r in rows]))
+
+
 def make_crowd_agent():
     """Agent.step with an ActionRot (crowd_sim/envs/utils/agent.py:108-141), the reference's own method on 500 random
     states: new pose, velocity."""
@@ -786,6 +855,8 @@ def main():
         return make_crowd_maps()
     if len(sys.argv) > 1 and sys.argv[1] == "crowd_agent":
         return make_crowd_agent()
+    if len(sys.argv) > 1 and sys.argv[1] == "crowd_reset":
+        return make_crowd_reset()
     ref_env, human, keti_robot, ref_utils, human_policy = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "reset":            # only golden_reset.npz
         return make_reset(ref_env)
@@ -803,6 +874,7 @@ def main():
     make_crowd()
     make_crowd_maps()
     make_crowd_agent()
+    make_crowd_reset()
 
 
 if __name__ == "__main__":

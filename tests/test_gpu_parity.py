@@ -1302,6 +1302,84 @@ def test_crowd_sim_step_pipeline_vs_oracle(gpu):
     assert deviated > 100
 
 
+def test_crowd_sim_env_reset_and_steps(gpu, golden_dir):
+    """'CrowdSim-v0' as an env (crowd_sim/__init__.py:3-6, crowd_sim.py:626-722): reset(phase='test', test_case=0) of ten
+    envs = the reference's own test cases 0..9 (tests/golden/golden_crowd_reset.npz) -- the pedestrians' observable states,
+    their ragged counts, the static obstacles as pedestrians, and the robot's angular local map equal to what the
+    reference's reset() RETURNED (1e-12).  Then 20 steps in closed loop against the oracle's functions composed per env with
+    ITS humans only (ragged lists, the robot appended for the humans that see it): reward, info, done, every agent state
+    and the local map bit for bit."""
+    import crowd_sim
+    from nav_gym_amd import crowd
+    d = np.load(os.path.join(golden_dir, "golden_crowd_reset.npz"))
+    E = 10
+    env = crowd_sim.make("CrowdSim-v0", num_envs=E, device=gpu.dev)
+    ob, local_map = env.reset(phase="test", test_case=0)
+    nh = ob["n_humans"].cpu().numpy()
+    lm = local_map.cpu().numpy()
+    for e in range(E):
+        assert str(d["phase"][e]) == "test" and int(d["case"][e]) == e
+        hg = d["humans_%d" % e]
+        assert nh[e] == len(hg)
+        _eq(ob["humans"][e, :nh[e]].cpu().numpy(), np.stack([hg[:, 0], hg[:, 1], hg[:, 4], hg[:, 5], hg[:, 7]], 1), "humans of case %d" % e)
+        ks = int(ob["n_static"][e])
+        _eq(ob["static"][e, :ks].cpu().numpy(), d["static_%d" % e], "static obstacles of case %d" % e)
+        np.testing.assert_allclose(lm[e], d["local_map_%d" % e], rtol=0, atol=1e-12)
+    assert len(set(nh.tolist())) >= 3 and env.case_counter["test"] == E
+    # ---- closed loop against the oracle, env by env
+    st = env.stepper
+    params, mp = env._params(), env._map_params()
+    orca_p = dict(time_step=params["time_step"], neighbor_dist=10, time_horizon=5, time_horizon_obst=5, max_neighbors=10)
+    dt = float(params["time_step"])
+    h = [st.h[e, :nh[e]].cpu().numpy().copy() for e in range(E)]
+    r = st.r.cpu().numpy().copy()
+    sees = [st.sees_robot[e, :nh[e]].cpu().numpy() for e in range(E)]
+    verts = [st.verts[e, : int(st.n_obst[e])].cpu().numpy() for e in range(E)]
+    free = st.free_map.cpu().numpy()
+    gt = np.zeros(E)
+    rng = np.random.default_rng(3)
+    moved = 0
+    for t in range(20):
+        act = np.stack([rng.uniform(0.2, 1.0, E), rng.uniform(-0.3, 0.3, E)], axis=1)
+        ob, local_map, reward, done, info = env.step(_t(gpu, act))
+        for e in range(E):
+            n = nh[e]
+            hact = np.zeros((n, 2))
+            for k in range(n):
+                order = [k] + [j for j in range(n) if j != k]
+                A = n + int(sees[e][k])
+                ag = np.zeros((1, A, 6))
+                ag[0, :n, :4] = h[e][order, :4]; ag[0, :n, 4] = h[e][order, 4] + 0.01; ag[0, :n, 5] = h[e][k, 5]
+                if sees[e][k]:
+                    ag[0, n, :4] = r[e, :4]; ag[0, n, 4] = r[e, 4] + 0.01; ag[0, n, 5] = h[e][k, 5]
+                vel = h[e][k, 6:8] - h[e][k, 0:2]; sp = np.sqrt(vel[0] * vel[0] + vel[1] * vel[1])
+                pv = (vel / sp if sp > 1 else vel)[None]
+                _, a1 = ref.crowd_orca(orca_p, ag, pv, verts[e][None] if len(verts[e]) else None, None,
+                                       np.array([len(verts[e])], np.int32) if len(verts[e]) else None,
+                                       np.zeros(1, np.int32) if len(verts[e]) else None, h[e][k:k + 1, 8])
+                hact[k] = a1[0]
+            npose, nvel = ref.crowd_agent_step(np.array([[r[e, 0], r[e, 1], r[e, 8]]]), act[e:e + 1], dt)
+            robot10 = np.array([[r[e, 0], r[e, 1], npose[0, 0], npose[0, 1], nvel[0, 0], nvel[0, 1], r[e, 6], r[e, 7], r[e, 4], act[e, 1]]])
+            rew, dn, inf, md = ref.crowd_check(params, free[e:e + 1], robot10, h[e][None, :, :5], gt[e:e + 1])
+            r[e, 0:2] = npose[0, 0:2]; r[e, 2:4] = nvel[0]; r[e, 8] = npose[0, 2]
+            hpn, hvn = ref.crowd_agent_step(np.stack([h[e][:, 0], h[e][:, 1], h[e][:, 8]], -1), hact, dt)
+            moved += int((np.abs(hvn).max(axis=1) > 0.05).sum())
+            h[e][:, 0:2] = hpn[:, :2]; h[e][:, 2:4] = hvn; h[e][:, 8] = hpn[:, 2]
+            gt[e] += dt
+            amap = ref.crowd_angular_map(mp, np.array([[r[e, 0], r[e, 1], r[e, 8], r[e, 4]]]),
+                                         verts[e][None] if len(verts[e]) else np.zeros((1, 0, 4, 2)),
+                                         np.array([len(verts[e])], np.int32))
+            assert float(reward[e]) == float(rew[0]) and int(info[e]) == int(inf[0]) and bool(done[e]) == bool(dn[0]), (t, e)
+            _eq(st.h[e, :n].cpu().numpy(), h[e], "pedestrians of env %d at step %d" % (e, t))
+            _eq(st.r[e].cpu().numpy(), r[e], "robot of env %d at step %d" % (e, t))
+            _eq(local_map[e].cpu().numpy(), amap[0], "angular map of env %d at step %d" % (e, t))
+            if n < st.h.shape[1]:                     # padding rows never move
+                assert float(st.h[e, n:, 0].min()) >= 1e6
+    assert moved > 200
+    ob2, _ = env.reset(phase="test")                  # the next ten cases
+    assert env.case_counter["test"] == 2 * E and not gpu.torch.equal(ob2["humans"], ob["humans"])
+
+
 def test_config1_single_env_64_beams(gpu):
     """BASELINE config 1: 1 env, 64-beam lidar, 100x100 static map, no pedestrians."""
     cfg = gpu.lib.default_config(n_envs=1, map_h=100, map_w=100, n_spawn=4, auto_reset=0, seed=7)
