@@ -400,11 +400,12 @@ class NavGymEnv(object):
         return {"is_success": np.float32(r["is_success"][0].item()), "is_crash": np.float32(r["is_crash"][0].item()),
                 "distance": float(r["distance"][0].item())}
 
-    def render(self, mode="human", arena=0):
+    def render(self, mode="human", arena=0, text=True):
         """The reference's picture of ONE arena (env.py:833-1050) as a float32 BGR array [800, 800, 3] in [0, 1]:
         map, goal, pedestrians with local goals, robot with its three rectangles, lidar returns.  Host-side NumPy
-        (render.py); the reference's OpenCV window and text overlay are not reproduced -- both modes return the
-        image.  `arena` selects which arena of the batch is drawn."""
+        (render.py); the debug text (env.py:1035-1046: observation tail and reward terms, `text=False` leaves it out) is drawn
+        with a built-in font; the reference's OpenCV window is not opened -- both modes return the image.  `arena`
+        selects which arena of the batch is drawn."""
         if self.sim is None:
             raise RuntimeError("call reset() before render()")
         from . import render as rd
@@ -428,8 +429,32 @@ class NavGymEnv(object):
         o = self.sim.obs[e].cpu().numpy()
         B = cfg.n_beams
         scan = o[(cfg.n_scan_stack - 1) * B: cfg.n_scan_stack * B]
-        return rd.render_arena(map_info, robot, humans, scan, float(o[-1]),
-                               dict(angle_min=cfg.angle_min, angle_last=cfg.angle_last, range_max=np.float32(cfg.range_max)))
+        img = rd.render_arena(map_info, robot, humans, scan, float(o[-1]),
+                              dict(angle_min=cfg.angle_min, angle_last=cfg.angle_last, range_max=np.float32(cfg.range_max)))
+        if text:
+            self._make_render_txt(e)
+            rd.overlay_text(img, self.render_obs_txt, self.render_reward_txt)
+        return img
+
+    def _make_render_txt(self, e=0):
+        """render_obs_txt / render_reward_txt of arena e (env.py:182-217): the observation's tail and the six terms of
+        compute_rewards for it, evaluated on the host from the device's latest observation (render.reward_terms)."""
+        from . import render as rd
+        cfg = self.cfg
+        o = self.sim.obs[e].cpu().numpy().astype(np.float64)
+        B, S = cfg.n_beams, cfg.n_scan_stack
+        tail = o[S * B:]                                   # prev_pose(2) pose(2) vel(2) yaw (env.py:455)
+        goal = self.sim.out["desired_goal"][e].cpu().numpy() if "desired_goal" in self.sim.out else self.sim.t["robot_goal"][e].cpu().numpy()
+        steps = int(self.sim.t["steps"][e]) if "steps" in self.sim.t else 0
+        self.render_obs_txt = rd.obs_text(steps, tail[0:2], tail[2:4], tail[4:6], tail[6], goal)
+        factors = {k: getattr(self, k) for k in ("reward_scale", "reward_success_factor", "reward_crash_factor",
+                                                 "reward_progress_factor", "reward_forward_factor", "reward_rotation_factor",
+                                                 "reward_discomfort_factor")}
+        terms = rd.reward_terms(self.sim.obs[e].cpu().numpy()[(S - 1) * B: S * B], tail[0:2], tail[2:4], tail[4:6], goal,
+                                self.scan_threshold.cpu().numpy(), self.scan_discomfort_threshold.cpu().numpy(), factors,
+                                self.distance_threshold)
+        self.render_reward_txt = rd.reward_text(terms)
+        return terms
 
     def close(self):
         self.sim = None

@@ -4,7 +4,8 @@ The reference draws with OpenCV (not installed here) and shows a window; this re
 occupancy map (free white, obstacles black), goal (blue square, 1 m), pedestrians' local goals (yellow, 0.2 m),
 pedestrian / robot heading arrows and footprints, the robot's threshold and discomfort rectangles, the lidar
 returns below range_max (green discs, 0.2 m), flipped to world orientation and resized to 800 x 800 -- as a
-float32 BGR array in [0, 1] like the reference's `img`.  The debug text overlay (cv2.putText) is not drawn.
+float32 BGR array in [0, 1] like the reference's `img`.  The debug text overlay (env.py:1035-1046) is drawn with a
+built-in 5 x 7 stroke font at the reference's positions, colour and thickness (OpenCV's Hershey glyphs are not available).
 Drawing is in cell space with the reference's xy_to_ij (truncation, clipped to the map).
 """
 import numpy as np
@@ -108,3 +109,96 @@ def render_arena(map_info, robot, humans, scan, scan_yaw, lidar):
     yy = np.minimum((np.arange(HEIGHT) * (H / float(HEIGHT))).astype(int), H - 1)
     xx = np.minimum((np.arange(WIDTH) * (W / float(WIDTH))).astype(int), W - 1)
     return np.ascontiguousarray(img[yy][:, xx])
+
+
+# ---- the debug text of render() (env.py:182-217, 1035-1046) ------------------------------------------------------------
+def obs_text(steps, prev_pose, pose, vel, yaw, goal):
+    """_make_render_obs_txt (env.py:182-201): the six lines about the latest observation."""
+    return ('t: {}\n'.format(steps)
+            + 'prev_pose: ({:.2f} {:.2f})\n'.format(prev_pose[0], prev_pose[1])
+            + 'pose: ({:.2f} {:.2f})\n'.format(pose[0], pose[1])
+            + 'vel: ({:.2f} {:.2f})\n'.format(vel[0], vel[1])
+            + 'yaw: {:.2f}\n'.format(yaw)
+            + 'goal: ({:.2f} {:.2f})'.format(goal[0], goal[1]))
+
+
+REWARD_TERMS = ("reward_success", "reward_crash", "reward_progress", "reward_forward", "reward_rotation", "reward_discomfort")
+
+
+def reward_text(terms):
+    """_make_render_reward_txt (env.py:203-217): one line per term of compute_rewards."""
+    return "\n".join('{}: {:.5f}'.format(k, terms[k]) for k in REWARD_TERMS)
+
+
+def reward_terms(scan, prev_pose, pose, vel, goal, scan_threshold, scan_discomfort_threshold, factors, distance_threshold):
+    """The six terms of compute_rewards (env.py:513-573) for ONE observation, NumPy like the reference: scan [B] (the
+    latest scan), poses / vel / goal float64; factors: dict reward_scale, reward_*_factor.  Their sum is the step's reward."""
+    scan = np.asarray(scan, dtype=np.float64)             # the reference's observation is float64; the thresholds float32
+    thr = np.asarray(scan_threshold, dtype=np.float32); dthr = np.asarray(scan_discomfort_threshold, dtype=np.float32)
+    goal = np.asarray(goal, dtype=np.float64)
+    distance = np.linalg.norm(goal - np.asarray(pose, dtype=np.float64)[:2])
+    prev_distance = np.linalg.norm(goal - np.asarray(prev_pose, dtype=np.float64)[:2])
+    success = bool(distance < distance_threshold)
+    crash = bool(np.any(scan - thr < 0))
+    discomfort = bool(np.any(scan - dthr < 0)) and not crash
+    sc = factors["reward_scale"]
+    t = dict.fromkeys(REWARD_TERMS, 0.0)
+    if success:
+        t["reward_success"] = 1.0 * factors["reward_success_factor"] * sc
+    if crash:
+        t["reward_crash"] = -1.0 * factors["reward_crash_factor"] * sc
+    t["reward_progress"] = float((prev_distance - distance) * factors["reward_progress_factor"] * sc)
+    t["reward_forward"] = float(vel[0] * factors["reward_forward_factor"] * sc)
+    t["reward_rotation"] = float(-1.0 * (vel[1] ** 2) * factors["reward_rotation_factor"] * sc)
+    if discomfort:
+        ratio = np.min(np.divide(scan - thr, dthr - thr + 1e-6))
+        t["reward_discomfort"] = float(-(1.0 - ratio) * factors["reward_discomfort_factor"] * sc)
+    return t
+
+
+# 5 x 7 glyphs, one string of 7 rows per character ('#' = stroke); unknown characters draw as a box
+_GLYPHS = {
+    "0": ".###.|#...#|#..##|#.#.#|##..#|#...#|.###.", "1": "..#..|.##..|..#..|..#..|..#..|..#..|.###.",
+    "2": ".###.|#...#|....#|...#.|..#..|.#...|#####", "3": ".###.|#...#|....#|..##.|....#|#...#|.###.",
+    "4": "...#.|..##.|.#.#.|#..#.|#####|...#.|...#.", "5": "#####|#....|####.|....#|....#|#...#|.###.",
+    "6": "..##.|.#...|#....|####.|#...#|#...#|.###.", "7": "#####|....#|...#.|..#..|.#...|.#...|.#...",
+    "8": ".###.|#...#|#...#|.###.|#...#|#...#|.###.", "9": ".###.|#...#|#...#|.####|....#|...#.|.##..",
+    "a": ".....|.....|.###.|....#|.####|#...#|.####", "b": "#....|#....|####.|#...#|#...#|#...#|####.",
+    "c": ".....|.....|.###.|#....|#....|#...#|.###.", "d": "....#|....#|.####|#...#|#...#|#...#|.####",
+    "e": ".....|.....|.###.|#...#|#####|#....|.###.", "f": "..##.|.#..#|.#...|###..|.#...|.#...|.#...",
+    "g": ".....|.####|#...#|#...#|.####|....#|.###.", "h": "#....|#....|#.##.|##..#|#...#|#...#|#...#",
+    "i": "..#..|.....|.##..|..#..|..#..|..#..|.###.", "l": ".##..|..#..|..#..|..#..|..#..|..#..|.###.",
+    "m": ".....|.....|##.#.|#.#.#|#.#.#|#...#|#...#", "n": ".....|.....|#.##.|##..#|#...#|#...#|#...#",
+    "o": ".....|.....|.###.|#...#|#...#|#...#|.###.", "p": ".....|####.|#...#|#...#|####.|#....|#....",
+    "r": ".....|.....|#.##.|##..#|#....|#....|#....", "s": ".....|.....|.####|#....|.###.|....#|####.",
+    "t": ".#...|.#...|###..|.#...|.#...|.#..#|..##.", "u": ".....|.....|#...#|#...#|#...#|#..##|.##.#",
+    "v": ".....|.....|#...#|#...#|#...#|.#.#.|..#..", "w": ".....|.....|#...#|#...#|#.#.#|#.#.#|.#.#.",
+    "y": ".....|#...#|#...#|#...#|.####|....#|.###.", "_": ".....|.....|.....|.....|.....|.....|#####",
+    ":": ".....|..#..|.....|.....|.....|..#..|.....", ".": ".....|.....|.....|.....|.....|.##..|.##..",
+    "-": ".....|.....|.....|#####|.....|.....|.....", "(": "...#.|..#..|.#...|.#...|.#...|..#..|...#.",
+    ")": ".#...|..#..|...#.|...#.|...#.|..#..|.#...", " ": ".....|.....|.....|.....|.....|.....|.....",
+}
+
+
+def put_text(img, txt, org, scale=2, color=(0, 0, 1)):
+    """Draws txt with its BASELINE's left end at org = (x, y), like cv2.putText's origin (env.py:1037-1046); a glyph cell is
+    6 x 7 stroke units of `scale` pixels (2 -> 14 px tall letters, the height of FONT_HERSHEY_SIMPLEX at fontScale 0.7)."""
+    H, W = img.shape[:2]
+    x0, ytop = int(org[0]), int(org[1]) - 7 * scale
+    for ch in txt:
+        rows = _GLYPHS.get(ch, _GLYPHS.get(ch.lower(), "#####|#...#|#...#|#...#|#...#|#...#|#####")).split("|")
+        for ry, row in enumerate(rows):
+            for rx, c in enumerate(row):
+                if c == "#":
+                    ya, xa = ytop + ry * scale, x0 + rx * scale
+                    if ya < H and xa < W and ya + scale > 0 and xa + scale > 0:
+                        img[max(ya, 0):ya + scale, max(xa, 0):xa + scale] = color
+        x0 += 6 * scale
+    return img
+
+
+def overlay_text(img, obs_txt, reward_txt):
+    """env.py:1035-1046: every line of the two texts at (50, 50 + 50 i), red (BGR (0, 0, 1))."""
+    for i, txt in enumerate(obs_txt.split("\n") + reward_txt.split("\n")):
+        put_text(img, txt, (50, 50 + i * 50))
+    return img

@@ -1431,6 +1431,15 @@ def test_env_wrapper_gym_api(gpu):
     assert abs(env.robot.px - o2["achieved_goal"][0]) < 1e-5
     img = env.render(mode="rgb_array")                      # env.py:833-1050 for the arena (render.py)
     assert img.shape == (800, 800, 3) and img.dtype == np.float32 and (img == 0).any() and (img == 1).any()
+    # the debug text (env.py:182-217, 1035-1046): twelve lines, the six reward terms sum to the step's reward
+    lines = env.render_obs_txt.split("\n") + env.render_reward_txt.split("\n")
+    assert len(lines) == 12 and lines[0] == "t: %d" % (0 if d else 1) and lines[6].startswith("reward_success: ")
+    assert lines[2] == "pose: ({:.2f} {:.2f})".format(o2["observation"][-5], o2["observation"][-4])
+    plain = env.render(mode="rgb_array", text=False)
+    red = (img == np.array([0, 0, 1], np.float32)).all(axis=2) & ~(plain == np.array([0, 0, 1], np.float32)).all(axis=2)
+    assert red[30:52, 50:120].any() and red[580:602, 50:300].any() and not red[:, 700:].any()
+    if not info["is_crash"] and not d:
+        assert abs(sum(env._make_render_txt(0).values()) - r) < 1e-4
     from nav_gym_amd import export                          # ros_env.py:65-185 field lists
     assert export.reset_map_fields(env)["data"].shape == (400, 400)
     assert len(export.strict_update_fields(env)["humans"]) == 5

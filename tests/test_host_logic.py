@@ -468,3 +468,43 @@ def test_crowd_sim_is_registered_like_the_reference():
         crowd_sim.make("CrowdSim-v0", no_such_entry=1)
     with pytest.raises(RuntimeError):
         env.step(None)
+
+
+def test_render_debug_text_follows_the_reference_formats():
+    """render()'s debug text (env.py:182-217): the two multi-line strings in the reference's formats, the six reward terms of
+    compute_rewards (env.py:513-573) for one observation -- their sum equals the oracle's reward for that observation --
+    and the overlay: red glyph pixels on the twelve baselines y = 50 + 50 i from x = 50 (env.py:1035-1046)."""
+    from nav_gym_amd import render as rd
+    txt = rd.obs_text(7, [1.0, 2.0], [1.234, -0.005], [0.3, -0.1], 1.5, [10.0, 11.0])
+    assert txt == "t: 7\nprev_pose: (1.00 2.00)\npose: (1.23 -0.01)\nvel: (0.30 -0.10)\nyaw: 1.50\ngoal: (10.00 11.00)"
+    B = 64
+    rng = np.random.default_rng(0)
+    thr = np.full(B, 0.6, np.float32); dthr = np.full(B, 0.9, np.float32)
+    factors = dict(reward_scale=15.0, reward_success_factor=1, reward_crash_factor=1, reward_progress_factor=0.001,
+                   reward_forward_factor=0.0, reward_rotation_factor=0.005, reward_discomfort_factor=0.01)
+    cfg = ref.default_config(n_beams=B, n_scan_stack=1)
+    seen = set()
+    for case in range(40):
+        scan = rng.uniform(1.0, 20.0, B).astype(np.float32)
+        if case % 3 == 1:
+            scan[5] = 0.7                                  # discomfort
+        if case % 5 == 2:
+            scan[9] = 0.3                                  # crash
+        prev = rng.uniform(-5, 5, 2); pose = prev + rng.uniform(-0.1, 0.1, 2)
+        vel = np.array([rng.uniform(0, 0.5), rng.uniform(-0.6, 0.6)])
+        goal = pose + (rng.uniform(-0.2, 0.2, 2) if case % 7 == 3 else rng.uniform(3, 6, 2))
+        t = rd.reward_terms(scan, prev, pose, vel, goal, thr, dthr, factors, 0.5)
+        obs = np.concatenate([scan.astype(np.float64), prev, pose, vel, [0.2]])
+        out = ref.reward_done(cfg, obs[None], goal[None], thr, dthr)
+        assert abs(sum(t.values()) - float(out["reward"][0])) < 1e-9, (case, t)
+        seen |= {k for k, v in t.items() if v != 0.0}
+    assert {"reward_success", "reward_crash", "reward_progress", "reward_rotation", "reward_discomfort"} <= seen
+    rt = rd.reward_text(t).split("\n")
+    assert len(rt) == 6 and rt[2] == "reward_progress: {:.5f}".format(t["reward_progress"])
+    img = np.ones((800, 800, 3), np.float32)
+    rd.overlay_text(img, txt, rd.reward_text(t))
+    red = (img == np.array([0, 0, 1], np.float32)).all(axis=2)
+    for i in range(12):
+        assert red[50 + 50 * i - 14: 50 + 50 * i, 50:400].any(), i
+        assert not red[50 + 50 * i + 1: 50 + 50 * i + 30, :].any(), i
+    assert not red[:, :50].any()
