@@ -421,7 +421,11 @@ constexpr int kParkLanesMax = NAVSIM_PARK_LANES;
 #ifndef NAVSIM_PARK_LANES_PEDS
 #define NAVSIM_PARK_LANES_PEDS 16
 #endif
+#ifdef NAVSIM_PARK_512           // experiment, not kept (profiles/r04_blocks/ab_park512.txt: c2 at 768-2048 arenas and c4 -3..-5 %): parked rays in the 512-thread kernels too
+__host__ __device__ constexpr bool step_parks(int block, bool peds) { return (block == 256 && (!peds || NAVSIM_PARK_LANES_PEDS > 0)) || (block == 512 && !peds); }
+#else
 __host__ __device__ constexpr bool step_parks(int block, bool peds) { return block == 256 && (!peds || NAVSIM_PARK_LANES_PEDS > 0); }
+#endif
 // A parked ray is (beam, t, direction).  Without pedestrians: 16 bytes in the park area.  In the pedestrian variants the
 // ray's own slots of the LDS copy -- rng[k], dir[k], which it fills only when it finishes -- hold t and the direction
 // meanwhile, and the park area keeps the beam index alone (2 bytes): 0.5 KB instead of 4.3, which is what keeps eight

@@ -127,18 +127,21 @@ size_t step_lds_bytes(const navsim_config* c, int park_lanes) {
     return lds;
 }
 
-// Threads per arena (cfg.step_block = 0).  With >= 12 arenas per CU the chip is kept full by 256-thread
-// workgroups (8 per CU, several generations).  With fewer arenas a launch is one generation whose length is a
-// workgroup's own march, i.e. beams per thread: wider workgroups shorten it (measured, c2 world: 2048 arenas
-// 14.4 / 16.4 / 13.7 M env-steps/s for 256 / 512 / 1024 threads; 1024 arenas 8.8 / 11.3 / 11.6; 512 arenas
-// 5.2 / 6.7 / 7.3; 4096 arenas 19.5 / 17.4 / -).
+// Threads per arena (cfg.step_block = 0).  With >= 12 arenas per CU the chip is kept full by 256-thread workgroups (8 per
+// CU, several generations).  With fewer, wider workgroups shorten a launch that is as long as its slowest workgroup's own
+// march: 1024 threads while ALL arenas are resident at two per CU (<= 2 arenas per CU), else 512.
+// Round 4 re-sweep with the index rows in LDS (profiles/r04_blocks/, M env-steps/s at 256 / 512 / 1024 threads), c2 world:
+// 512 arenas 11.9 / 14.9 / 15.3; 640: - / 17.0 / 15.7; 768: 16.8 / 20.6 / 20.0; 1024: 21.2 / 25.0 / 22.4; 1536: 28.3 / 31.4 / 25.0;
+// 2048: 33.0 / 34.5 / 26.2; 3072: 40.2 / 37.5 / 27.2; 4096: 44.2 / 39.3 / 27.8.  c3 world (20 pedestrians): 512 arenas
+// - / 10.4 / 10.3; 640: - / 12.0 / 9.3; 1024: - / 16.0 / 11.9; 1536: 16.1 / 18.3 / -; 2048: 19.4 / 20.2 / -; 3072: 22.3 / 22.2 / -.
+// (Rounds 2-3 took 1024 threads up to 6 arenas per CU: a second generation of 1024-thread workgroups costs more than it saves.)
 int pick_step_block(const navsim_config* c) {
     if (c->step_block) return c->step_block;
     const int B = c->n_beams;
-    const long per_cu_x2 = 2L * c->n_envs / device_cu_count();           // arenas per CU, doubled
+    const long cus = device_cu_count();
     if (B <= 64) return 64;
-    if (per_cu_x2 >= 24 || B <= 256) return 256;
-    if (per_cu_x2 >= 12 || B <= 512) return 512;
+    if ((long)c->n_envs >= 12 * cus || B <= 256) return 256;
+    if ((long)c->n_envs > 2 * cus || B <= 512) return 512;
     return 1024;
 }
 

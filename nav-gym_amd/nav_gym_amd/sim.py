@@ -387,10 +387,9 @@ class NavSim(object):
         # only when a launch runs several generations of workgroups: with one generation everything starts
         # at once and the order is irrelevant (threads per arena as dispatch_step picks them)
         n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count or 256
-        per_cu_x2 = 2 * self.cfg.n_envs // n_cu
-        block = self.cfg.step_block or (
-            64 if self.cfg.n_beams <= 64 else (256 if per_cu_x2 >= 24 or self.cfg.n_beams <= 256 else
-                                               (512 if per_cu_x2 >= 12 or self.cfg.n_beams <= 512 else 1024)))
+        block = self.cfg.step_block or (                    # navsim_kernels.hip pick_step_block
+            64 if self.cfg.n_beams <= 64 else (256 if self.cfg.n_envs >= 12 * n_cu or self.cfg.n_beams <= 256 else
+                                               (512 if self.cfg.n_envs > 2 * n_cu or self.cfg.n_beams <= 512 else 1024)))
         generations = self.cfg.n_envs * (block // 64) / float(32 * n_cu)
         if (launch_order is True or (launch_order is None and generations > 1.25)) and "arena_cost" not in self.t:
             self.t["arena_cost"] = torch.zeros(self.cfg.n_envs, dtype=torch.int32, device=self.device)
