@@ -90,6 +90,12 @@ def build_sim(wl, base, E, seed=1234, device="cuda:0"):
         cfg.robot_seen_footprint[i] = float(v)
     for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
         arrays[key] = sim.scan_threshold(cfg, torch.from_numpy(robots.footprint_array(robot, name)).to(dev))
+    # a world that regenerates after every step: the restarted arenas' first observations come from navsim_regen's masked
+    # launch instead of a second scan inside the step (include/navsim.h defer_reset_scan) -- where a launch is one
+    # generation of workgroups (c5: 512 arenas per GPU).  --defer-reset-scan 0/1 overrides.
+    if wl.get("regen") and not wl.get("pregen", False):
+        want = wl.get("defer_reset_scan", -1)
+        cfg.defer_reset_scan = int(want) if want in (0, 1) else int(E <= 1024)
     s = sim.NavSim(cfg, arrays, device=device)
     s.reset_obs()
     if wl.get("regen") and wl.get("pregen", False):
@@ -317,6 +323,8 @@ def main():
                     help="march through the packed field only, without the two-rectangle tile records (A/B)")
     ap.add_argument("--rects", action="store_true",
                     help="keep the tile records also in a world that regenerates its maps (c5; A/B)")
+    ap.add_argument("--defer-reset-scan", type=int, default=-1, choices=[-1, 0, 1],
+                    help="regenerating workloads: 1 = navsim_regen scans the restarted arenas, 0 = the step does (-1: by batch size)")
     ap.add_argument("--pregen", action="store_true",
                     help="c5: worlds staged ahead on a side stream + navsim_regen_swap instead of navsim_regen after every step "
                          "(measured: +11-14 %% at 128-256 arenas per GPU, +-0 at the 512 of c5 where the step kernel fills the chip)")
@@ -519,6 +527,7 @@ def measure(args, scaling, ctx, light=False):
     if args.rects:
         wl["rects"] = True
     wl["pregen"] = bool(args.pregen)
+    wl["defer_reset_scan"] = args.defer_reset_scan
     base, E_local = shard_of(wl, scaling, rank, world_size)
     E_total = wl["total"] if scaling == "strong" else world_size * wl["envs"]
     if E_local < 1:

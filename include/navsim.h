@@ -203,7 +203,16 @@ typedef struct navsim_config {
                                          The LDS form of the march (navsim_state.rect_index) needs it -- a ray of a closed map
                                          never leaves the map, so that form carries no bounds test -- and is not used without.
                                          A wrong assertion reads outside the tables. */
-    int32_t reserved1;
+    int32_t defer_reset_scan;         /* 1 = navsim_step leaves the FIRST OBSERVATION of an arena it restarted (auto_reset) to the
+                                         navsim_regen call that must follow it: the step does the restart's bookkeeping (pose, goal,
+                                         episode, counters, tail of the row) and skips the second scan, navsim_regen produces the
+                                         first observation of EVERY arena whose done flag is set -- those it gives a new world and
+                                         those beyond regen_cap that restart in place -- in one masked launch over all arenas.
+                                         Between the two calls the scan rows of a finished arena's observation are unspecified.
+                                         Worth it where a launch is one generation of workgroups and lasts as long as its slowest
+                                         arena (c5: the restarted arenas' second scans were 10 of the step's 49 us); the masked
+                                         launch costs ~4 ns per arena, so not for thousands of arenas per GPU.  0 = the step scans
+                                         itself (default).  Not with navsim_regen_swap. */
 } navsim_config;
 
 #define NAVSIM_ACTION_TWIST  0   /* io->action = (v, omega): the reference's action (env.py:591) */

@@ -368,8 +368,15 @@ __device__ __forceinline__ void probe_round(const Field& field, const char* __re
         } else {
             // The load is written out: after a compiler-generated global_load_dwordx4 the register allocator moved three
             // of the four loaded dwords to other registers before using them (3 of 42 vector instructions per probe).
+            // The base goes through an s_mov inside the statement: when the register allocator has spilled `rects` to
+            // VGPR lanes it reloads it with v_readlane RIGHT in front of this statement, and a VMEM instruction may not read
+            // an SGPR within 5 wait states of the VALU instruction that wrote it -- a hazard the compiler pads for in its
+            // own code and cannot see inside inline assembly (round 4: the 64-thread pedestrian variant loaded from a stale
+            // base and faulted after an unrelated edit moved its spills).  SALU reads of such an SGPR are interlocked.
             const unsigned off = tile * (unsigned)sizeof(uint4);
-            asm volatile("global_load_dwordx4 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(rec) : "v"(off), "s"(rects) : "memory");
+            unsigned long long base;
+            asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, %1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(rec), "=&s"(base) : "v"(off), "s"(rects) : "memory");
             inval = live & mask_eq(rec.x & 0xFFFFu, (unsigned)kRectInvalid);
         }
         const int da = rect_dist2(rec.x, rec.y, cell), db = rect_dist2(rec.z, rec.w, cell);
@@ -905,7 +912,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     double* pv_g = st.prev_pose + 3 * (size_t)e;
 
     if (reset_only && reset_mask && !reset_mask[e]) {          // untouched env: carry the row over
-        if (obs_prev)
+        if (obs_prev && obs_prev != obs_row)                    // (navsim_regen hands the step's own rows in: nothing to move)
             for (int k = tid; k < D; k += BLOCK) obs_row[k] = obs_prev[k];
         return;
     }
@@ -1103,7 +1110,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 goal_g[0] = sg[0]; goal_g[1] = sg[1];
                 st.episode[e] += 1;
                 st.steps[e] = 0;
-                sh.respawn = 1; sh.rescan = 1;
+                // cfg.defer_reset_scan: the first observation of the new episode comes from the navsim_regen call that follows
+                // (one masked launch for every finished arena): no second scan here, the rows stay as scan A left them
+                sh.respawn = 1; sh.rescan = c.defer_reset_scan ? 0 : 1;
             } else if (o.crash != 0.0f) {                       // env.py:707-717
                 sh.rp[0] = pv_g[0]; sh.rp[1] = pv_g[1]; sh.rp[2] = pv_g[2];
                 sh.rescan = 1;

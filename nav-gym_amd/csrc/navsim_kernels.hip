@@ -180,7 +180,11 @@ StepPlan plan_step(const navsim_config* c, const navsim_state* st, int grid = 0)
         const size_t row = rect_index_row_bytes(c->map_h, c->map_w);
         const size_t base = (p.lds + 15) & ~(size_t)15;
         const size_t total = base + row + 1024;                     // + the kernel's static LDS, allocation granules
-        const int per_cu = p.block >= 1024 ? 2 : (p.block == 512 ? 4 : 8);
+        // workgroups per CU the rows must leave room for: all that the wave slots allow at 512 / 1024 threads; at 256 threads
+        // five of the eight are enough -- c3 (20 pedestrians: 20 KB of scan copy, pedestrian scratch and pair table per
+        // arena) fits five with the rows and runs 24.3 M env-steps/s against 23.7 M at eight with the records in global
+        // memory (profiles/r04_idx/ab2.txt, r04_defer/ab_c3_hazardfix.txt)
+        const int per_cu = p.block >= 1024 ? 2 : (p.block == 512 ? 4 : 5);
         // a launch of at most one workgroup per CU (navsim_regen's first observations: a handful of lone scans) may take
         // a CU's whole LDS
         const bool lone = grid > 0 && grid <= device_cu_count();
@@ -370,6 +374,7 @@ int navsim_default_config(navsim_config* c) {
     c->linvel_lo = 0.0; c->linvel_hi = 0.5;    // __init__.py:12
     c->rotvel_lo = -0.64; c->rotvel_hi = 0.64; // __init__.py:13
     c->closed_maps = 0;
+    c->defer_reset_scan = 0;
     c->regen_check_discomfort = 1;          // env.py:776-781
     c->rect_lds = 0;
     c->step_block = 0;
@@ -585,6 +590,7 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
     if (c->march_rule < NAVSIM_MARCH_F64 || c->march_rule > NAVSIM_MARCH_F32_FMA) return NAVSIM_E_ARG;
     if (c->action_kind != NAVSIM_ACTION_TWIST && c->action_kind != NAVSIM_ACTION_WHEELS) return NAVSIM_E_ARG;
     if (c->action_kind == NAVSIM_ACTION_WHEELS && !(c->wheel_track > 0.0)) return NAVSIM_E_ARG;
+    if (c->defer_reset_scan != 0 && c->defer_reset_scan != 1) return NAVSIM_E_ARG;
     if (c->ped_model != NAVSIM_PED_NONE && (c->max_waypoints < 1 || c->max_waypoints > NAVSIM_MAX_WAYPOINTS)) return NAVSIM_E_ARG;
     if (st->rect_table && (c->field_format != NAVSIM_FIELD_U16T || c->map_h > 1024 || c->map_w > 1024)) return NAVSIM_E_UNSUPPORTED;
     if (st->rect_index && !st->rect_table) return NAVSIM_E_ARG;
@@ -844,8 +850,15 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     navsim_step_io io2 = *io;
     io2.obs_prev = io->obs;
     navsim_state st2 = *st;
-    st2.launch_order = list;
     st2.arena_cost = nullptr;
+    if (c->defer_reset_scan) {
+        // the step left every restart's first observation to this call: one launch over all arenas, masked by the done
+        // flags -- the regenerated arenas and those beyond the cap that restarted in place (a workgroup whose flag is
+        // clear returns at once)
+        st2.launch_order = nullptr;
+        return dispatch_step(c, &st2, &io2, 1, io->done, s);
+    }
+    st2.launch_order = list;
     return dispatch_step(c, &st2, &io2, 1, nullptr, s, M);
 }
 
@@ -854,6 +867,7 @@ int navsim_regen_swap(const navsim_config* c, const navsim_state* live, const na
     (void)hipGetLastError();
     if (!c || !live || !stage || !io || !io->done || !io->obs || !stage_obs || !want || !mark) return NAVSIM_E_ARG;
     if (c->regen_cap < 1 || c->n_spawn < 1 || !c->auto_reset) return NAVSIM_E_ARG;
+    if (c->defer_reset_scan) return NAVSIM_E_UNSUPPORTED;     // a staged world brings its own first observation; arenas beyond the cap would get none
     if (!live->field || !stage->field || !live->episode || !stage->episode || !live->spawn_pose || !stage->spawn_pose ||
         !live->spawn_goal || !stage->spawn_goal || !stage->robot_pose || !stage->robot_goal)
         return NAVSIM_E_ARG;

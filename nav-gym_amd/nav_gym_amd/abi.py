@@ -127,7 +127,7 @@ class NavsimConfig(C.Structure):
         ("rotvel_lo", C.c_double),
         ("rotvel_hi", C.c_double),
         ("closed_maps", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("defer_reset_scan", C.c_int32),
     ]
 
     def copy(self):

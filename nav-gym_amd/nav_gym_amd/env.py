@@ -188,6 +188,10 @@ class NavGymEnv(object):
         cfg.max_waypoints = int(max_waypoints)
         if march_rule is not None:                    # include/navsim.h NAVSIM_MARCH_*: the unpinned rounding of range_libc
             cfg.march_rule = int(march_rule)
+        # with randomize_maps every step() is navsim_step + navsim_regen: the restarted arenas' first observations come from
+        # regen's masked launch instead of a second scan inside the step (include/navsim.h defer_reset_scan), where a
+        # launch is one generation of workgroups -- a few arenas per CU
+        cfg.defer_reset_scan = int(self.randomize_maps and self.auto_reset and self.num_envs <= 1024)
         cfg.regen_plan = int(self.plan_paths)
         cfg.regen_indoor_ratio = float(indoor_ratio)
         cfg.outdoor_map_size = int(self.outdoor_map_size)

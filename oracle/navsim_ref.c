@@ -103,6 +103,7 @@ int navsim_default_config_cpu(navsim_config* c) {
     c->num_humans_lo = 0; c->num_humans_hi = 0;
     c->scan_noise_std_lo = 0.0; c->scan_noise_std_hi = -1.0;
     c->regen_check_discomfort = 1;          /* env.py:776-781 */
+    c->defer_reset_scan = 0;
     c->march_rule = NAVSIM_MARCH_F32;       /* RangeLib.h: `float step_coeff = 0.999;` (include/navsim.h NAVSIM_MARCH_*) */
     c->max_waypoints = 64;                  /* include/navsim.h */
     c->action_kind = NAVSIM_ACTION_TWIST;   /* env.py:591 */
@@ -992,7 +993,9 @@ static void step_env(const navsim_config* c, const navsim_state* st, const navsi
         st->episode[e] += 1;
         st->steps[e] = 0;
         double zero[2] = {0.0, 0.0};
-        robot_scan(c, st, e, n, rp, scan);
+        /* cfg.defer_reset_scan: the first observation comes from the navsim_regen call that follows (its masked
+         * navsim_reset_obs over every finished arena); until then the scan rows of this row are unspecified (here: scan A) */
+        if (!c->defer_reset_scan) robot_scan(c, st, e, n, rp, scan);
         pack_obs(c, scan, NULL, 0, rp, rp, zero, goal, obs, ag, dg);
         pa[0] = 0.0; pa[1] = 0.0;
         st->n_hist[e] = (S - 1 < 1) ? S - 1 : 1;
@@ -1567,9 +1570,12 @@ int navsim_regen_cpu(const navsim_config* c, const navsim_state* st, const navsi
             if (st->ped_goal) { st->ped_goal[q * 2] = gx; st->ped_goal[q * 2 + 1] = gy; }
         }
     }
-    /* first observation of the new episodes (env.py:808-831); other arenas keep the row the step wrote */
+    /* first observation of the new episodes (env.py:808-831); other arenas keep the row the step wrote.
+     * cfg.defer_reset_scan: also of the arenas beyond the cap, which navsim_step restarted in place without scanning */
     navsim_step_io io2 = *io;
     io2.obs_prev = io->obs;
+    if (c->defer_reset_scan)
+        for (int e = 0; e < E; ++e) mask[e] = io->done[e] != 0;
     int rc = navsim_reset_obs_cpu(c, st, &io2, mask);
     free(mask); free(occ);
     return rc;

@@ -561,28 +561,43 @@ def test_ped_scans_few_beams_many_pedestrians(gpu, beams):
             assert (exp[:, :n_peds] < 6.0).any()
 
 
-@pytest.mark.parametrize("fmt,ped_model,plan", [(abi.FIELD_F32, abi.PED_NONE, 0), (abi.FIELD_U16T, abi.PED_SFM, 0),
-                                                (abi.FIELD_F32, abi.PED_SFM, 1), (abi.FIELD_U16T, abi.PED_NONE, 1)])
-def test_regen_vs_oracle(gpu, fmt, ped_model, plan):
+@pytest.mark.parametrize("fmt,ped_model,plan,defer", [(abi.FIELD_F32, abi.PED_NONE, 0, 0), (abi.FIELD_U16T, abi.PED_SFM, 0, 0),
+                                                      (abi.FIELD_F32, abi.PED_SFM, 1, 0), (abi.FIELD_U16T, abi.PED_NONE, 1, 0),
+                                                      (abi.FIELD_U16T, abi.PED_SFM, 0, 1), (abi.FIELD_U16T, abi.PED_NONE, 1, 1),
+                                                      (abi.FIELD_F32, abi.PED_SFM, 0, 1)])
+def test_regen_vs_oracle(gpu, fmt, ped_model, plan, defer):
     """navsim_regen: finished arenas get a new map, field, start/goal table, robot,
     pedestrians and first observation on the device -- every array bit-identical to the oracle's.
-    plan=1: candidates on the costmap, kept only when the planner joins them (env.py:342-383)."""
+    plan=1: candidates on the costmap, kept only when the planner joins them (env.py:342-383).
+    defer=1: cfg.defer_reset_scan -- the step leaves every restart's first observation to navsim_regen, which scans the
+    regenerated arenas AND those beyond regen_cap that restarted in place (regen_cap = 2 there: steps with more finished
+    arenas occur); between the two calls only the rows of unfinished arenas are specified."""
     E, size, N = 40, 200 + 60 * plan, 6
+    cap = 2 if defer else 5
     cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=ped_model, n_spawn=6,
-                                 auto_reset=1, seed=17, field_format=fmt, regen_cap=5, min_goal_dist=3.0,
+                                 auto_reset=1, seed=17, field_format=fmt, regen_cap=cap, min_goal_dist=3.0,
                                  max_goal_dist=8.0, spawn_clearance=0.9, ped_min_robot_dist=2.0, ped_min_goal_dist=4.0,
-                                 regen_plan=plan, regen_indoor_ratio=0.5 if fmt == abi.FIELD_U16T else 0.0)
+                                 regen_plan=plan, regen_indoor_ratio=0.5 if fmt == abi.FIELD_U16T else 0.0,
+                                 defer_reset_scan=defer)
     gpu.world.lidar_1081(cfg)
     occ = gpu.world.make_maps(E, size, 17)
     regenerated = capped = 0
+    B = cfg.n_beams * cfg.n_scan_stack
     for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=5, steps=45, seed=6,
                                                      plan_paths=bool(plan) and ped_model != abi.PED_NONE):
-        _eq(go, ro, "obs at step %d" % t)
+        if defer:
+            live = rout["done"] == 0
+            _eq(go[live], ro[live], "obs of the unfinished arenas at step %d" % t)
+            _eq(go[:, B:], ro[:, B:], "tails at step %d" % t)
+            for k in rout:
+                _eq(gout[k], rout[k], "%s at step %d" % (k, t))
+        else:
+            _eq(go, ro, "obs at step %d" % t)
         n_done = int(rout["done"].sum())
         go2 = g.regen().cpu().numpy()
         ro2 = r.regen()
         _eq(go2, ro2, "obs after regen at step %d" % t)
-        regenerated += min(n_done, 5); capped += n_done > 5
+        regenerated += min(n_done, cap); capped += n_done > cap
         if n_done:
             gs = g.numpy_state()
             for k, v in r.a.items():
@@ -590,7 +605,7 @@ def test_regen_vs_oracle(gpu, fmt, ped_model, plan):
                     _eq(gs[k], v, "state %s after regen at step %d" % (k, t))
             if fmt == abi.FIELD_F32:
                 _eq(gs["field"], r.a["field"], "field after regen at step %d" % t)
-    assert regenerated > 5
+    assert regenerated > 5 and (capped > 0 or not defer)
     if fmt == abi.FIELD_U16T:           # navsim_regen keeps the two-rectangle tile records of the new maps current
         d2, valid = _decode_rect_table(g.t["rect_table"].cpu().numpy(), size, size)
         exact = np.rint(r.a["field"].astype(np.float64) ** 2).astype(np.int64)
