@@ -52,6 +52,13 @@ for t in range(T):
                      rescan_phase5_us=float(np.median((b[:, 5] - b[:, 4])[resc])) / 100.0 if resc.any() else 0.0))
 for r in rows:
     print(r)
+if os.environ.get("NAVSIM_SLOWEST"):          # the last step's slowest workgroups, phase by phase (start offset | phases | life)
+    order = np.argsort(-(b[:, 6] - b[:, 0]))
+    starts = (b[:, 0] - b[:, 0].min()) / 100.0
+    print("start offsets (us): median %.2f p90 %.2f max %.2f" % (np.median(starts), np.percentile(starts, 90), starts.max()))
+    for w in list(order[:6]) + list(order[len(order) // 2: len(order) // 2 + 2]):
+        print("wg %4d start %.2f phases %s life %.2f%s" % (w, starts[w], [round(float(x) / 100.0, 2) for x in np.diff(b[w, :7])],
+                                                          (b[w, 6] - b[w, 0]) / 100.0, "  (re-scan)" if resc[w] else ""))
 if "counters" in sim.t:
     cn = sim.t["counters"].cpu().numpy()
     print("helper attempts over the %d steps: exhausted at the first look %d, empty descriptor %d, no chunk left at the add %d, chunks marched by helpers %d"
