@@ -479,13 +479,13 @@ def extras(args, device):
             torch.cuda.empty_cache()
         except Exception as exc:                              # an extra must not cost the run its line
             res["other_workloads"][name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
-    try:
-        sys.path.insert(0, os.path.join(ROOT, "nav-gym_amd"))
+    def gym_window(**kw):
+        """K calls of NavGymEnv.step(torch float64 actions [E,2]) after reset() on the device -> (env-steps/s, ms per call)"""
         import nav_gym_env
         wl = WORKLOADS["c2"]
         E = wl["envs"]
-        env = nav_gym_env.make("NavGym-v0", num_envs=E, n_beams=wl["beams"], map_size=wl["size"], pedestrian_model="none",
-                               num_humans=0, indoor_ratio=0.0, device=device, seed=1234)
+        env = nav_gym_env.make("NavGym-v0", num_envs=E, n_beams=wl["beams"], map_size=wl["size"], indoor_ratio=0.0,
+                               device=device, seed=1234, **kw)
         env.reset()
         g = torch.Generator(device=device); g.manual_seed(78)
         K, Wm = 200, 30
@@ -499,14 +499,25 @@ def extras(args, device):
             obs, rew, done, info = env.step(acts[Wm + t])
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        res["value_gym_api"] = E * K / el
-        res["gym_api"] = {"ms_per_step": el / K * 1e3, "envs": E, "steps": K,
+        env.close()
+        del env
+        torch.cuda.empty_cache()
+        return E * K / el, el / K * 1e3, E, K
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "nav-gym_amd"))
+        v, ms, E, K = gym_window(pedestrian_model="none", num_humans=0)
+        res["value_gym_api"] = v
+        res["gym_api"] = {"ms_per_step": ms, "envs": E, "steps": K,
                           "what": "K calls of NavGymEnv.step(torch float64 actions [E,2]) on a c2-shaped world made by gym.make('NavGym-v0', "
                                   "num_envs=4096, n_beams=1081, map_size=500, pedestrian_model='none', indoor_ratio=0) + reset() on the device; "
                                   "returns the obs dict, reward, done.bool(), info (env.py:591-728's signature)"}
-        env.close()
+        # the same API on the c3-shaped world: 20 social-force pedestrians per arena, whose routes are planned on the costmap and
+        # re-planned at their goals by navsim_replan inside every step() (plan_paths=True, the env's default), and without
+        for key, plan in (("plan_paths", True), ("no_plan_paths", False)):
+            v, ms, E, K = gym_window(pedestrian_model="sfm", num_humans=20, plan_paths=plan)
+            res["gym_api"]["c3_world_" + key] = {"value": v, "ms_per_step": ms}
     except Exception as exc:
-        res["gym_api"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+        res.setdefault("gym_api", {})["error"] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
     return res
 
 

@@ -688,6 +688,10 @@ constexpr size_t kPlanLdsMax = 160 * 1024 - 256;       // LDS per CU minus the s
 inline size_t plan_lds(int Hc, int Wc) { return (size_t)((Hc * Wc + 1) & ~1) * 4; }
 inline bool plan_fits(int Hc, int Wc) { return (size_t)Hc * Wc <= 65535 && plan_lds(Hc, Wc) <= kPlanLdsMax; }
 
+// BLOCK: threads of the workgroup that runs the query.  A level costs ~1.2 us of dependent LDS round trips (queue -> four
+// neighbours -> four atomics -> queue slot -> queue), not its barrier: navsim_replan with 64 / 128 / 256 threads per query takes
+// 130 / 112 / 112 us per step on the c3 world (profiles/r04_replan/ab_block.txt).
+template <int BLOCK = 256>
 __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc, int Wc, double res_c, double ox,
                                            double oy, double sx_, double sy_, double gx_, double gy_, double interval,
                                            int max_wp, double* __restrict__ w, int32_t* __restrict__ n_wp,
@@ -715,16 +719,16 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
     if ((((uintptr_t)c) & 3) == 0) {                                       // four cells per load
         const uint32_t* c4 = (const uint32_t*)c;
         uint2* d4 = (uint2*)dist;
-        for (int k = tid; k < n_cells / 4; k += 256) {
+        for (int k = tid; k < n_cells / 4; k += BLOCK) {
             const uint32_t v = c4[k];
             uint2 o;
             o.x = ((v & 0xFFu) ? 0xFFFEu : 0xFFFFu) | (((v >> 8) & 0xFFu) ? 0xFFFE0000u : 0xFFFF0000u);
             o.y = (((v >> 16) & 0xFFu) ? 0xFFFEu : 0xFFFFu) | ((v >> 24) ? 0xFFFE0000u : 0xFFFF0000u);
             d4[k] = o;
         }
-        for (int k = (n_cells & ~3) + tid; k < n_cells; k += 256) dist[k] = c[k] ? (int16_t)-2 : (int16_t)-1;
+        for (int k = (n_cells & ~3) + tid; k < n_cells; k += BLOCK) dist[k] = c[k] ? (int16_t)-2 : (int16_t)-1;
     } else {
-        for (int k = tid; k < n_cells; k += 256) dist[k] = c[k] ? (int16_t)-2 : (int16_t)-1;
+        for (int k = tid; k < n_cells; k += BLOCK) dist[k] = c[k] ? (int16_t)-2 : (int16_t)-1;
     }
     if ((n_cells & 1) && tid == 0) dist[n_cells] = -2;                    // pad half of the last 32-bit word
     __syncthreads();
@@ -745,7 +749,7 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
         // `level` and leaves a half-word some other lane claimed in this level unchanged; the lane that
         // saw 0xFFFF come back owns the cell.  Reached and blocked cells are filtered by the plain read.
         // The four reads, then the four atomics, are issued together (independent LDS round trips).
-        for (int f = lo + tid; f < hi; f += 256) {
+        for (int f = lo + tid; f < hi; f += BLOCK) {
             const int k = queue[f], j = k / Wc, i = k - j * Wc;
             const int m[4] = {k + 1, k - 1, k + Wc, k - Wc};
             const bool in[4] = {i + 1 < Wc, i > 0, j + 1 < Hc, j > 0};
@@ -1057,7 +1061,11 @@ __global__ __launch_bounds__(1024) void replan_select_kernel(const uint64_t* __r
     }
 }
 
-__global__ __launch_bounds__(256) void replan_kernel(navsim_config c, navsim_state st, const int* __restrict__ count,
+#ifndef NAVSIM_REPLAN_BLOCK
+#define NAVSIM_REPLAN_BLOCK 256
+#endif
+constexpr int kReplanBlock = NAVSIM_REPLAN_BLOCK;
+__global__ __launch_bounds__(kReplanBlock) void replan_kernel(navsim_config c, navsim_state st, const int* __restrict__ count,
                                                      const int* __restrict__ list) {
     __shared__ double goal_s[2];
     __shared__ int32_t nwp_s;
@@ -1094,7 +1102,7 @@ __global__ __launch_bounds__(256) void replan_kernel(navsim_config c, navsim_sta
             goal_s[0] = gx; goal_s[1] = gy;
         }
         __syncthreads();
-        plan_query(cost, Hc, Wc, res_c, c.origin_x, c.origin_y, px, py, goal_s[0], goal_s[1], 2.0, P, w, &nwp_s,
+        plan_query<kReplanBlock>(cost, Hc, Wc, res_c, c.origin_x, c.origin_y, px, py, goal_s[0], goal_s[1], 2.0, P, w, &nwp_s,
                    nullptr, nullptr, cut_counter);
         __syncthreads();
         if (nwp_s > 0) {

@@ -925,7 +925,7 @@ int navsim_replan(const navsim_config* c, const navsim_state* st, int32_t max_qu
     uint64_t* due = (uint64_t*)((char*)workspace + 256 + (((size_t)max_queries * sizeof(int32_t) + 255) & ~(size_t)255));
     replan_flag_kernel<<<c->n_envs, 64, 0, s>>>(*c, *st, due);
     replan_select_kernel<<<1, 1024, 0, s>>>(due, c->n_envs, c->max_peds, max_queries, count, list, *st);
-    if (max_queries > 0) replan_kernel<<<max_queries, 256, plan_lds(Hc, Wc), s>>>(*c, *st, count, list);
+    if (max_queries > 0) replan_kernel<<<max_queries, kReplanBlock, plan_lds(Hc, Wc), s>>>(*c, *st, count, list);
     return launch_status();
 }
 
