@@ -685,7 +685,12 @@ __global__ __launch_bounds__(256) void costmap_kernel(const uint8_t* __restrict_
 // Queue order is arbitrary; only `dist` feeds the path, so results are deterministic.
 // Thread 0 then walks the path and cuts the waypoints on the fly (nothing is stored per path cell).
 constexpr size_t kPlanLdsMax = 160 * 1024 - 256;       // LDS per CU minus the static variables
-inline size_t plan_lds(int Hc, int Wc) { return (size_t)((Hc * Wc + 1) & ~1) * 4; }
+// the bitmap form of the search (below): dist[n_cells] int16 + four bitmaps of Hc rows x ceil(Wc / 64) words
+inline size_t plan_lds_bitmap(int Hc, int Wc) { return (((size_t)Hc * Wc * 2 + 15) & ~(size_t)15) + 16 + (size_t)4 * Hc * ((Wc + 63) / 64) * 8; }
+inline size_t plan_lds(int Hc, int Wc) {
+    const size_t q = (size_t)((Hc * Wc + 1) & ~1) * 4, b = plan_lds_bitmap(Hc, Wc);
+    return q > b ? q : b;
+}
 inline bool plan_fits(int Hc, int Wc) { return (size_t)Hc * Wc <= 65535 && plan_lds(Hc, Wc) <= kPlanLdsMax; }
 
 // BLOCK: threads of the workgroup that runs the query.  A level costs ~1.2 us of dependent LDS round trips (queue -> four
@@ -716,6 +721,69 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
     }
     if (!ok) return;                                     // uniform: depends on the query only
     const int s_cell = sj * Wc + si, g_cell = gj * Wc + gi;
+#ifndef NAVSIM_PLAN_QUEUE          // (-DNAVSIM_PLAN_QUEUE: the queue form of rounds 1-3 below, kept for A/B)
+    // The hop field by a level-synchronous search on BITMAPS (round 4): a row of the costmap is ceil(Wc / 64) 64-bit words (bit b of
+    // word w = cell i = 64 w + b); a level is, per word, (frontier << 1 | frontier >> 1 | the words above and below) & free &
+    // ~visited -- seven independent LDS reads, a few bit operations, the hop count written for the (typically one to four) new
+    // bits, one barrier.  No queue, no atomics.  The field it writes is the field the queue search wrote (hops from the goal, every
+    // level completed), so the walk below -- and with it every waypoint -- is unchanged: 45 planner / regen / env tests
+    // bit-identical; navsim_replan on the c3 world 112 -> 99 us per step, regen_plan_kernel 579 -> 533 us
+    // (profiles/r04_replan/ab_bitmap.txt).
+    {
+        const int Ww = (Wc + 63) >> 6, n_words = Hc * Ww;
+        unsigned long long* bm = (unsigned long long*)(((uintptr_t)((char*)dist + (size_t)n_cells * 2) + 15) & ~(uintptr_t)15);
+        unsigned long long* free_b = bm, *seen = bm + n_words, *fa = bm + 2 * n_words, *fb = bm + 3 * n_words;
+        __shared__ int any_s[3];
+        for (int k = tid; k < n_cells; k += BLOCK) dist[k] = (int16_t)-1;
+        for (int x = tid; x < n_words; x += BLOCK) {
+            const int j = x / Ww, w = x - j * Ww;
+            const int i0 = w << 6, i1 = (i0 + 64 < Wc) ? i0 + 64 : Wc;
+            unsigned long long f = 0;
+            const uint8_t* row = c + (size_t)j * Wc;
+            for (int i = i0; i < i1; ++i) f |= (unsigned long long)(row[i] == 0) << (i - i0);
+            free_b[x] = f; seen[x] = 0; fa[x] = 0; fb[x] = 0;
+        }
+        if (tid == 0) { any_s[0] = 0; any_s[1] = 1; any_s[2] = 0; reached = (s_cell == g_cell); }
+        __syncthreads();
+        if (tid == 0) {
+            dist[g_cell] = 0;
+            const int x = gj * Ww + (gi >> 6);
+            fa[x] = 1ull << (gi & 63); seen[x] = fa[x];
+        }
+        __syncthreads();
+        unsigned long long* cur = fa, *nxt = fb;
+        const int s_word = sj * Ww + (si >> 6);
+        const unsigned long long s_bit = 1ull << (si & 63);
+        for (int level = 1; level < 32767; ++level) {
+            if (reached || !any_s[level % 3]) break;                         // any_s[level % 3]: did level - 1 find a cell
+            if (tid == 0) any_s[(level + 2) % 3] = 0;                        // the flag of level + 1 (last read two barriers ago)
+            bool found = false;
+            for (int x = tid; x < n_words; x += BLOCK) {
+                const int j = x / Ww, w = x - j * Ww;
+                const unsigned long long f = cur[x];
+                const unsigned long long l = (w > 0) ? cur[x - 1] >> 63 : 0ull, r = (w + 1 < Ww) ? cur[x + 1] << 63 : 0ull;
+                const unsigned long long u = (j > 0) ? cur[x - Ww] : 0ull, d = (j + 1 < Hc) ? cur[x + Ww] : 0ull;
+                const unsigned long long sn = seen[x];
+                unsigned long long cand = ((f << 1) | l | (f >> 1) | r | u | d) & free_b[x] & ~sn;
+                nxt[x] = cand;
+                if (cand) {
+                    seen[x] = sn | cand;
+                    found = true;
+                    if (x == s_word && (cand & s_bit)) reached = 1;
+                    const int base = j * Wc + (w << 6);
+                    while (cand) {
+                        const int b = __builtin_ctzll(cand);
+                        dist[base + b] = (int16_t)level;
+                        cand &= cand - 1;
+                    }
+                }
+            }
+            if (found) any_s[(level + 1) % 3] = 1;
+            __syncthreads();
+            unsigned long long* t = cur; cur = nxt; nxt = t;
+        }
+    }
+#else
     if ((((uintptr_t)c) & 3) == 0) {                                       // four cells per load
         const uint32_t* c4 = (const uint32_t*)c;
         uint2* d4 = (uint2*)dist;
@@ -791,6 +859,7 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
         lo = hi;
         hi += cnt[slot];
     }
+#endif
 #ifdef NAVSIM_DIAG_NO_WALK
     return;
 #endif
@@ -809,12 +878,12 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
         lx = cx; ly = cy;
     };
     const double i2_hi = interval * interval * (1.0 + 1.0e-12), i2_lo = interval * interval * (1.0 - 1.0e-12);
+    int dcur = dist[s_cell];                             // hops left: one fewer with every step of the walk (no re-read)
     for (;;) {
         ++n;
         const double cx = ((double)ci + 0.5) * res_c + ox, cy = ((double)cj + 0.5) * res_c + oy;
         const double dx = fx - cx, dy = fy - cy;
         const int k = cj * Wc + ci;
-        const int dcur = dist[k];
         // sqrt(d2) > interval, decided on d2 unless it sits within 1e-12 of interval^2 (sqrt is monotone
         // and correctly rounded, so the two tests agree outside that band)
         const double d2 = dx * dx + dy * dy;
@@ -825,6 +894,7 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
         const bool e0 = ci + 1 < Wc && dist[k + 1] == want, e1 = ci > 0 && dist[k - 1] == want;
         const bool e2 = cj + 1 < Hc && dist[k + Wc] == want;
         if (e0) ++ci; else if (e1) --ci; else if (e2) ++cj; else --cj;
+        dcur = want;
     }
     *n_wp = count < max_wp ? count : max_wp;
     if (path_cells) *path_cells = n;
