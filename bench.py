@@ -479,6 +479,8 @@ def extras(args, device):
             torch.cuda.empty_cache()
         except Exception as exc:                              # an extra must not cost the run its line
             res["other_workloads"][name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+    reset_s = [0.0]                                # wall time of the last gym_window's env.reset() (the whole batch, on the device)
+
     def gym_window(**kw):
         """K calls of NavGymEnv.step(torch float64 actions [E,2]) after reset() on the device -> (env-steps/s, ms per call)"""
         import nav_gym_env
@@ -486,7 +488,11 @@ def extras(args, device):
         E = wl["envs"]
         env = nav_gym_env.make("NavGym-v0", num_envs=E, n_beams=wl["beams"], map_size=wl["size"], indoor_ratio=0.0,
                                device=device, seed=1234, **kw)
-        env.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        env.reset()                                # maps, fields, records, costmaps, planned starts / goals / routes, first observations
+        torch.cuda.synchronize()
+        reset_s[0] = time.perf_counter() - t0
         g = torch.Generator(device=device); g.manual_seed(78)
         K, Wm = 200, 30
         acts = torch.rand((K + Wm, E, 2), generator=g, device=device, dtype=torch.float64)
@@ -507,7 +513,7 @@ def extras(args, device):
         sys.path.insert(0, os.path.join(ROOT, "nav-gym_amd"))
         v, ms, E, K = gym_window(pedestrian_model="none", num_humans=0)
         res["value_gym_api"] = v
-        res["gym_api"] = {"ms_per_step": ms, "envs": E, "steps": K,
+        res["gym_api"] = {"ms_per_step": ms, "envs": E, "steps": K, "reset_all_ms": reset_s[0] * 1e3,
                           "what": "K calls of NavGymEnv.step(torch float64 actions [E,2]) on a c2-shaped world made by gym.make('NavGym-v0', "
                                   "num_envs=4096, n_beams=1081, map_size=500, pedestrian_model='none', indoor_ratio=0) + reset() on the device; "
                                   "returns the obs dict, reward, done.bool(), info (env.py:591-728's signature)"}
@@ -515,7 +521,7 @@ def extras(args, device):
         # re-planned at their goals by navsim_replan inside every step() (plan_paths=True, the env's default), and without
         for key, plan in (("plan_paths", True), ("no_plan_paths", False)):
             v, ms, E, K = gym_window(pedestrian_model="sfm", num_humans=20, plan_paths=plan)
-            res["gym_api"]["c3_world_" + key] = {"value": v, "ms_per_step": ms}
+            res["gym_api"]["c3_world_" + key] = {"value": v, "ms_per_step": ms, "reset_all_ms": reset_s[0] * 1e3}
     except Exception as exc:
         res.setdefault("gym_api", {})["error"] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
     return res
