@@ -754,6 +754,40 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
         unsigned long long* cur = fa, *nxt = fb;
         const int s_word = sj * Ww + (si >> 6);
         const unsigned long long s_bit = 1ull << (si & 63);
+        if (n_words <= BLOCK) {
+            // every word has its own thread (costmaps up to 128 x 128 with 256 threads: 500 x 500-cell maps): what does not change
+            // from level to level -- the word's place, its free cells, its visited set -- stays in registers, and a level is
+            // five frontier reads, a dozen bit operations and the writes.  A workgroup of four wavefronts has a SIMD each:
+            // a level costs what its instructions cost (the two-levels-per-barrier form, 2.6 x the arithmetic for half the
+            // barriers, LOST: profiles/r04_replan/levels_bitmap2.txt).
+            const bool own = tid < n_words;
+            const int x = own ? tid : 0, j = x / Ww, w = x - j * Ww;
+            const bool hl = own && w > 0, hr = own && w + 1 < Ww, hu = own && j > 0, hd = own && j + 1 < Hc;
+            const unsigned long long my_free = own ? free_b[x] : 0ull;
+            unsigned long long my_seen = own ? seen[x] : 0ull;
+            const int base = j * Wc + (w << 6);
+            const bool start_here = own && x == s_word;
+            for (int level = 1; level < 32767; ++level) {
+                if (reached || !any_s[level % 3]) break;
+                if (tid == 0) any_s[(level + 2) % 3] = 0;
+                const unsigned long long f = own ? cur[x] : 0ull;
+                const unsigned long long l = hl ? cur[x - 1] >> 63 : 0ull, r = hr ? cur[x + 1] << 63 : 0ull;
+                const unsigned long long u = hu ? cur[x - Ww] : 0ull, d = hd ? cur[x + Ww] : 0ull;
+                unsigned long long cand = ((f << 1) | l | (f >> 1) | r | u | d) & my_free & ~my_seen;
+                if (own) nxt[x] = cand;
+                if (cand) {
+                    my_seen |= cand;
+                    any_s[(level + 1) % 3] = 1;
+                    if (start_here && (cand & s_bit)) reached = 1;
+                    while (cand) {
+                        dist[base + __builtin_ctzll(cand)] = (int16_t)level;
+                        cand &= cand - 1;
+                    }
+                }
+                __syncthreads();
+                unsigned long long* t = cur; cur = nxt; nxt = t;
+            }
+        } else
         for (int level = 1; level < 32767; ++level) {
             if (reached || !any_s[level % 3]) break;                         // any_s[level % 3]: did level - 1 find a cell
             if (tid == 0) any_s[(level + 2) % 3] = 0;                        // the flag of level + 1 (last read two barriers ago)
