@@ -768,11 +768,14 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
             const int base = j * Wc + (w << 6);
             const bool start_here = own && x == s_word;
             for (int level = 1; level < 32767; ++level) {
-                if (reached || !any_s[level % 3]) break;
-                if (tid == 0) any_s[(level + 2) % 3] = 0;
+                // the two flags and the five frontier words in ONE LDS round trip (the reads are issued together, the exit
+                // test follows them)
+                const int stop = reached, more = any_s[level % 3];
                 const unsigned long long f = own ? cur[x] : 0ull;
                 const unsigned long long l = hl ? cur[x - 1] >> 63 : 0ull, r = hr ? cur[x + 1] << 63 : 0ull;
                 const unsigned long long u = hu ? cur[x - Ww] : 0ull, d = hd ? cur[x + Ww] : 0ull;
+                if (stop || !more) break;
+                if (tid == 0) any_s[(level + 2) % 3] = 0;
                 unsigned long long cand = ((f << 1) | l | (f >> 1) | r | u | d) & my_free & ~my_seen;
                 if (own) nxt[x] = cand;
                 if (cand) {
@@ -912,18 +915,30 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
         lx = cx; ly = cy;
     };
     const double i2_hi = interval * interval * (1.0 + 1.0e-12), i2_lo = interval * interval * (1.0 - 1.0e-12);
+    // The anchor (fx, fy) is always a cell centre, so the distance to it is res_c * sqrt(di^2 + dj^2) up to rounding: the
+    // integer sum decides `far` except within 1e-6 of the threshold, where the float64 expression of env.py:1261-1277 does
+    // (a walked cell then costs integer work only: 0.32 -> 0.2 us, profiles/r04_replan/)
+    const double q = interval / res_c, q2_hi = q * q * (1.0 + 1.0e-6), q2_lo = q * q * (1.0 - 1.0e-6);
+    int ai = si, aj = sj;                                // the anchor's cell
     int dcur = dist[s_cell];                             // hops left: one fewer with every step of the walk (no re-read)
     for (;;) {
         ++n;
-        const double cx = ((double)ci + 0.5) * res_c + ox, cy = ((double)cj + 0.5) * res_c + oy;
-        const double dx = fx - cx, dy = fy - cy;
         const int k = cj * Wc + ci;
-        // sqrt(d2) > interval, decided on d2 unless it sits within 1e-12 of interval^2 (sqrt is monotone
-        // and correctly rounded, so the two tests agree outside that band)
-        const double d2 = dx * dx + dy * dy;
-        const bool far = (d2 > i2_hi) || (!(d2 < i2_lo) && sqrt(d2) > interval);
-        if (far) { emit(cx, cy); fx = cx; fy = cy; }
-        if (dcur == 0) { emit(cx, cy); break; }          // the goal cell closes the list
+        const int di = ci - ai, dj = cj - aj;
+        const double n2 = (double)(di * di + dj * dj);
+        bool far = n2 > q2_hi;
+        if (far | (dcur == 0) | !(n2 < q2_lo)) {
+            const double cx = ((double)ci + 0.5) * res_c + ox, cy = ((double)cj + 0.5) * res_c + oy;
+            if (!far && !(n2 < q2_lo)) {
+                // sqrt(d2) > interval, decided on d2 unless it sits within 1e-12 of interval^2 (sqrt is monotone
+                // and correctly rounded, so the two tests agree outside that band)
+                const double dx = fx - cx, dy = fy - cy;
+                const double d2 = dx * dx + dy * dy;
+                far = (d2 > i2_hi) || (!(d2 < i2_lo) && sqrt(d2) > interval);
+            }
+            if (far) { emit(cx, cy); fx = cx; fy = cy; ai = ci; aj = cj; }
+            if (dcur == 0) { emit(cx, cy); break; }      // the goal cell closes the list
+        }
         const int want = dcur - 1;                       // first neighbour one hop closer, (+i, -i, +j, -j)
         const bool e0 = ci + 1 < Wc && dist[k + 1] == want, e1 = ci > 0 && dist[k - 1] == want;
         const bool e2 = cj + 1 < Hc && dist[k + Wc] == want;
