@@ -702,7 +702,8 @@ def test_env_reset_at_the_reference_map_size(gpu):
             _eq(og[e:e + 1], ro, "arena %d obs at step %d" % (e, t))
 
 
-@pytest.mark.parametrize("seed", list(range(201, 213)))
+# NAVSIM_FUZZ_RESET_SEEDS=n widens the sweep for a one-off run (profiles/r04_soak/)
+@pytest.mark.parametrize("seed", list(range(201, 201 + int(os.environ.get("NAVSIM_FUZZ_RESET_SEEDS", "12")))))
 def test_reset_path_fuzzed(gpu, seed):
     """navsim_regen (+ planning, corridor maps, resident costmap) and navsim_replan at random sizes, formats,
     caps and pedestrian counts: state and observations stay bit-identical to the oracle."""
@@ -721,11 +722,16 @@ def test_reset_path_fuzzed(gpu, seed):
     gpu.world.lidar_full_circle(cfg, int(rng.choice([60, 180])))
     occ = gpu.world.make_maps(E, size, seed)
     with_costmap = bool(plan) and ped_model != abi.PED_NONE
+    cfg.defer_reset_scan = int(seed % 3 == 0)          # (drawn from the seed, not from rng: the worlds of the old seeds stay)
     regenerated = 0
     for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=N - 1, steps=22, seed=seed,
                                                      min_goal_dist=2.0, max_goal_dist=5.0, robot_clearance=0.6,
                                                      plan_paths=with_costmap):
-        _eq(go, ro, "obs at step %d" % t)
+        if cfg.defer_reset_scan:                       # the scan rows of finished arenas are navsim_regen's to write
+            live = rout["done"] == 0
+            _eq(go[live], ro[live], "obs of the unfinished arenas at step %d" % t)
+        else:
+            _eq(go, ro, "obs at step %d" % t)
         regenerated += int(rout["done"].sum())
         _eq(g.regen().cpu().numpy(), r.regen(), "obs after regen at step %d" % t)
         if with_costmap:
@@ -740,7 +746,7 @@ def test_reset_path_fuzzed(gpu, seed):
                 _eq(gs[k], v, "state %s" % k)
     if fmt == abi.FIELD_F32:
         _eq(gs["field"], r.a["field"], "field")
-    assert regenerated > 0
+    assert regenerated > 0 or seed > 212           # (the suite's twelve worlds all finish episodes; a wider sweep may draw one that does not)
 
 
 @pytest.mark.parametrize("fmt", [abi.FIELD_F32, abi.FIELD_U16T])
