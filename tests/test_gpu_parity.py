@@ -1401,6 +1401,41 @@ def test_crowd_sim_env_reset_and_steps(gpu, golden_dir):
     assert env.case_counter["test"] == 2 * E and not gpu.torch.equal(ob2["humans"], ob["humans"])
 
 
+@pytest.mark.parametrize("shape", [(63, 64), (64, 65), (97, 131), (128, 129), (150, 90), (200, 200)])
+def test_plan_random_costmaps_of_many_shapes(gpu, shape):
+    """navsim_plan's breadth-first search on bitmaps (round 4) against the oracle on random costmaps whose widths sit around the
+    64-bit word boundaries and whose sizes lie on both sides of the word-per-thread limit (128 x 128), square and not: sparse,
+    dense and wall-with-a-gap obstacle patterns, unreachable goals, start == goal.  Waypoints, counts, path cells and path
+    length identical.  (profiles/_diag/plan_fuzz.py is the wide form: 34 560 queries, profiles/r04_soak/plan_fuzz.txt.)"""
+    torch = gpu.torch
+    Hc, Wc = shape
+    rng = np.random.default_rng(Hc * 1000 + Wc)
+    n_maps, Q, res = 3, 30, 0.25
+    cost = np.zeros((n_maps, Hc, Wc), np.uint8)
+    cost[0] = rng.random((Hc, Wc)) < 0.08
+    cost[1] = rng.random((Hc, Wc)) < 0.33
+    for _ in range(max(Hc, Wc) // 6):
+        if rng.random() < 0.5:
+            r0 = rng.integers(1, Hc - 1); cost[2, r0, :] = 1; cost[2, r0, rng.integers(0, Wc)] = 0
+        else:
+            c0 = rng.integers(1, Wc - 1); cost[2, :, c0] = 1; cost[2, rng.integers(0, Hc), c0] = 0
+    mi = np.repeat(np.arange(n_maps, dtype=np.int32), Q)
+    start = np.stack([rng.uniform(0, Wc * res, n_maps * Q), rng.uniform(0, Hc * res, n_maps * Q)], 1)
+    goal = np.stack([rng.uniform(0, Wc * res, n_maps * Q), rng.uniform(0, Hc * res, n_maps * Q)], 1)
+    goal[::13] = start[::13]
+    joined = 0
+    for interval, P in ((2.0, 64), (0.6, 16)):
+        exp = ref.plan(cost, start, goal, interval, max_wp=P, res_c=res, map_index=mi)
+        got = gpu.sim.plan(_t(gpu, cost), _t(gpu, start), _t(gpu, goal), interval, max_wp=P, res_c=res, map_index=_t(gpu, mi))
+        live = np.arange(P)[None, :] < exp[1][:, None]
+        _eq(got[1].cpu().numpy(), exp[1], "waypoint counts")
+        _eq(got[2].cpu().numpy(), exp[2], "path cells")
+        _eq(got[3].cpu().numpy(), exp[3], "path length")
+        _eq(got[0].cpu().numpy()[live], exp[0][live], "waypoints")
+        joined += int((exp[1] > 0).sum())
+    assert joined > 20
+
+
 def test_config1_single_env_64_beams(gpu):
     """BASELINE config 1: 1 env, 64-beam lidar, 100x100 static map, no pedestrians."""
     cfg = gpu.lib.default_config(n_envs=1, map_h=100, map_w=100, n_spawn=4, auto_reset=0, seed=7)
