@@ -1,0 +1,41 @@
+"""navsim_ped_scan_policy (scan -> features in one workgroup) against navsim_ped_scans + navsim_ped_policy on random worlds: arena
+count, map size (incl. odd), pedestrian slots 1..64 with ragged live counts, field format, rect records or not, all three march
+rules.  Scans written out, network output, commands and popped waypoints must be identical."""
+import os, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+for p in ("nav-gym_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import numpy as np, torch
+from nav_gym_amd import abi, lib, robots, sim, world
+bad = n = 0
+for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
+    rng = np.random.default_rng(1000 + seed)
+    E = int(rng.choice([1, 5, 24])); size = int(rng.choice([120, 200, 253])); N = int(rng.choice([1, 3, 20, 37, 64]))
+    fmt = int(rng.choice([abi.FIELD_F32, abi.FIELD_U16T])); rects = bool(rng.integers(0, 2)) and fmt == abi.FIELD_U16T
+    cfg = lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_EXTERNAL, n_spawn=4, auto_reset=1,
+                             seed=seed, field_format=fmt, march_rule=int(rng.integers(0, 3)))
+    world.lidar_1081(cfg)
+    occ = world.make_maps(E, size, seed)
+    arrays = world.make_world(cfg, occ, n_peds=N, device="cuda:0", rect_table=rects, min_goal_dist=2.0, max_goal_dist=4.0,
+                              robot_clearance=0.6)
+    for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
+        arrays[key] = sim.scan_threshold(cfg, torch.from_numpy(robots.footprint_array("keti", name)).cuda())
+    arrays["n_peds"] = torch.from_numpy(rng.integers(0, N + 1, E).astype(np.int32)).cuda()
+    g = sim.NavSim(cfg, arrays)
+    fan = {"cv1": 15, "cv2": 96, "fc1": 4096, "fc2": 260, "a1": 128, "a2": 128}
+    g.set_policy({k: rng.uniform(-1, 1, s).astype(np.float32) / np.sqrt(fan[k.split("_")[0]]) for k, s in abi.POLICY_SHAPES.items()})
+    g.t["policy_prev_actions"].copy_(torch.rand((E, N, 2), device="cuda:0") * 0.5)
+    keep = {k: g.t[k].clone() for k in ("policy_prev_actions", "ped_waypoints", "ped_n_waypoints")}
+    scans = g.ped_scans()
+    a = [x.clone() for x in g.ped_policy(scans)] + [g.t["ped_waypoints"].clone(), g.t["ped_n_waypoints"].clone()]
+    for k, v in keep.items():
+        g.t[k].copy_(v)
+    out = torch.full_like(scans, -7.0)
+    b = list(g.ped_policy(fused=True, scans_out=out)) + [g.t["ped_waypoints"], g.t["ped_n_waypoints"]]
+    live = torch.arange(N, device="cuda:0")[None, :] < g.t["n_peds"][:, None].clamp(max=N)
+    ok = all(torch.equal(x, y) for x, y in zip(a, b)) and torch.equal(out[live], scans[live]) and bool((out[~live] == -7.0).all())
+    n += 1; bad += 0 if ok else 1
+    if not ok:
+        print("MISMATCH seed", seed, E, size, N, fmt, rects, cfg.march_rule)
+print("%d random worlds: %d mismatches between navsim_ped_scan_policy and the two calls" % (n, bad))
+sys.exit(1 if bad else 0)
