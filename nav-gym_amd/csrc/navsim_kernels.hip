@@ -8,7 +8,9 @@
 // observation row written once.  No MFMA on that path (there is no dense contraction in it); the one dense
 // layer of the widened rows, HumanPolicy's 4096 -> 256, runs on v_mfma_f32_32x32x2_f32 (kernels_policy.hpp).
 //
-// One translation unit, in sections:
+// Nine translation units (csrc/Makefile builds them in parallel): this file -- every kernel but the fused step, the launch
+// geometry / dispatch and the C ABI -- and navsim_step_inst.hip compiled once per (threads per arena, pedestrians or not)
+// family of the step kernel.  The sections (included inside each unit's anonymous namespace; not standalone headers):
 //   kernels_field.hpp    distance transform, field formats, march step, mirror primitives
 //   kernels_rect.hpp     two-rectangle records of the field's 8x8 tiles: builder and decode
 //   kernels_step.hpp     probe round / scan / merge / pedestrian phase / the fused step kernel
@@ -16,51 +18,12 @@
 //   kernels_policy.hpp   pedestrian control block with the HumanPolicy actor
 //   kernels_pedscan.hpp  pedestrian scans, CrowdSim collision block, beam table, test hooks
 //   kernels_crowd_maps.hpp  CrowdSim local maps;  kernels_crowd_orca.hpp  CrowdSim pedestrians (ORCA, Agent.step)
-//   this file            launch geometry / dispatch and the C ABI
+//   step_plan.hpp        launch geometry of the fused step (shared by this file and navsim_step_inst.hip)
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see nav-gym_amd/csrc/build.sh).
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <math.h>
-#include <string.h>
-
-#include <atomic>
-#include <type_traits>
-
-#include "../../include/navsim.h"
-#include "navmath.hpp"
-#include "navsim_device.hpp"
-
-#pragma clang fp contract(off)
-
-
-// gfx950 only: bit-identity of the scans rests on properties of THIS ISA that are proven by exhaustive
-// device tests -- v_rsq_f32's rounding inside sqrt_small_int, the float32-only march step (navmath.hpp) -- and on
-// v_dot2_i32_i16 / v_pk_* forms that other targets lack.  Another offload arch must not compile silently.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
-#error "navsim_kernels.hip is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
-#endif
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off per unit (nav-gym_amd/csrc/Makefile, driven by build.sh).
+#include "preamble.hpp"
 
 namespace {
-
-constexpr int kMaxWaves = 16;
-constexpr int kRegenMaxPackedSide = 520;    // see navsim_regen
-
-// Diagnostic build only (-DNAVSIM_STAMPS, profiles/stamp_phases.py): s_memtime at the phase
-// boundaries of each arena's workgroup, written to a buffer nothing else reads.  The shipped library
-// is built without it (no stamp executes in the measured kernel).
-#ifdef NAVSIM_STAMPS
-__device__ unsigned long long* g_stamps = nullptr;
-#ifdef NAVSIM_STAMPS_REALTIME      // chip-wide 100 MHz clock (comparable across XCDs) instead of the per-XCD shader clock
-#define NAVSIM_STAMP(i) do { if (threadIdx.x == 0 && g_stamps) g_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define NAVSIM_STAMP(i) do { if (threadIdx.x == 0 && g_stamps) g_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#endif
-#else
-#define NAVSIM_STAMP(i) do { } while (0)
-#endif
 
 #include "kernels_field.hpp"
 #include "kernels_rect.hpp"
@@ -70,184 +33,33 @@ __device__ unsigned long long* g_stamps = nullptr;
 #include "kernels_pedscan.hpp"
 #include "kernels_crowd_maps.hpp"
 #include "kernels_crowd_orca.hpp"
+#include "step_plan.hpp"
 
-// kernels that want more than 64 KB of dynamic LDS must say so once; more than the CU has is refused
-constexpr size_t kLdsPerCu = 160 * 1024;
-int allow_lds(const void* kernel, size_t lds) {
-    if (lds <= 64 * 1024) return NAVSIM_OK;
-    if (lds > kLdsPerCu) return NAVSIM_E_UNSUPPORTED;
-    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess
-               ? NAVSIM_OK : NAVSIM_E_UNSUPPORTED;
-}
+}  // namespace
 
-// compute units of the CURRENT device (cached per device ordinal; idempotent, so a race only repeats the query)
-int device_cu_count() {
-    static std::atomic<int> cache[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    int v = cache[dev].load(std::memory_order_relaxed);
-    if (v > 0) return v;
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cache[dev].store(n, std::memory_order_relaxed);
-    return n;
-}
+// the step kernel's instantiations live in eight units of their own (navsim_step_inst.hip): one launcher per
+// (threads per arena, pedestrians or not)
+#define NAVSIM_STEP_FAMILY(B, P) \
+    extern "C" int navsim_step_launch_##B##_##P(const navsim_config*, const navsim_state*, const navsim_step_io*, int, \
+                                                const uint8_t*, void*, int, int); \
+    extern "C" int navsim_step_set_stamps_##B##_##P(unsigned long long*);
+NAVSIM_STEP_FAMILY(64, 0) NAVSIM_STEP_FAMILY(64, 1) NAVSIM_STEP_FAMILY(256, 0) NAVSIM_STEP_FAMILY(256, 1)
+NAVSIM_STEP_FAMILY(512, 0) NAVSIM_STEP_FAMILY(512, 1) NAVSIM_STEP_FAMILY(1024, 0) NAVSIM_STEP_FAMILY(1024, 1)
+#undef NAVSIM_STEP_FAMILY
 
-// dynamic LDS of the fused step: parked rays; beam directions + ranges (pedestrian variants merge from LDS); PedShared
-// rays a wavefront parks per chunk (kernels_step.hpp "Parking"): only where a launch runs several generations of
-// 256-thread workgroups, and not in the pedestrian variants
-int step_park_lanes(const navsim_config* c, int block) {
-    const bool peds = c->ped_model != NAVSIM_PED_NONE;
-    if (!step_parks(block, peds)) return 0;
-    if (peds) return c->n_beams <= 65535 ? NAVSIM_PARK_LANES_PEDS : 0;      // the park area keeps 16-bit beam indices there
-    return kParkLanesMax;
-}
-size_t step_lds_scan_bytes(const navsim_config* c, int park_lanes) {
-    const bool peds = c->ped_model != NAVSIM_PED_NONE;
-    return park_lds_bytes(c->n_beams, park_lanes, peds) + (peds ? (size_t)c->n_beams * (sizeof(float2) + sizeof(float)) : 0);
-}
-size_t ped_update_lds_bytes(const navsim_config* c) {                    // ped_update_kernel: a pack of arenas per wavefront
-    return (size_t)ped_pack(c->max_peds) * ped_slot_bytes(c->max_peds);
-}
-// pedestrians ahead of the step, a pack of arenas per workgroup (ped_update_kernel), instead of inside it: only on request
-// (cfg.ped_split = 2).  Round 2 split large batches automatically (the fused phase held three of four wavefronts at a
-// barrier: c3 13.2 -> 14.0 M env-steps/s); since the phase runs on wavefront 0 BESIDE the scan of the others the fused
-// form wins everywhere (c3, same box: split 21.0, fused 21.9 M; c5 fused 3.84 -> 4.28 M).
-bool ped_split_on(const navsim_config* c) {
-    if (c->ped_model == NAVSIM_PED_NONE || ped_update_lds_bytes(c) > 64 * 1024) return false;
-    return c->ped_split == 2;
-}
-size_t step_lds_bytes(const navsim_config* c, int park_lanes) {
-    size_t lds = step_lds_scan_bytes(c, park_lanes);
-    if (c->ped_model != NAVSIM_PED_NONE) {
-        lds = ((lds + 15) & ~(size_t)15) + ped_lds_bytes(c->max_peds);
-        // the fused pedestrian phase keeps its pair table behind PedShared (kernels_step.hpp ped_phase_wave)
-        if (!ped_split_on(c)) lds = ((lds + 15) & ~(size_t)15) + ped_pair_bytes(c->max_peds);
-    }
-    return lds;
-}
-
-// Threads per arena (cfg.step_block = 0).  With >= 12 arenas per CU the chip is kept full by 256-thread workgroups (8 per
-// CU, several generations).  With fewer, wider workgroups shorten a launch that is as long as its slowest workgroup's own
-// march: 1024 threads while ALL arenas are resident at two per CU (<= 2 arenas per CU), else 512.
-// Round 4 re-sweep with the index rows in LDS (profiles/r04_blocks/, M env-steps/s at 256 / 512 / 1024 threads), c2 world:
-// 512 arenas 11.9 / 14.9 / 15.3; 640: - / 17.0 / 15.7; 768: 16.8 / 20.6 / 20.0; 1024: 21.2 / 25.0 / 22.4; 1536: 28.3 / 31.4 / 25.0;
-// 2048: 33.0 / 34.5 / 26.2; 3072: 40.2 / 37.5 / 27.2; 4096: 44.2 / 39.3 / 27.8.  c3 world (20 pedestrians): 512 arenas
-// - / 10.4 / 10.3; 640: - / 12.0 / 9.3; 1024: - / 16.0 / 11.9; 1536: 16.1 / 18.3 / -; 2048: 19.4 / 20.2 / -; 3072: 22.3 / 22.2 / -.
-// (Rounds 2-3 took 1024 threads up to 6 arenas per CU: a second generation of 1024-thread workgroups costs more than it saves.)
-int pick_step_block(const navsim_config* c) {
-    if (c->step_block) return c->step_block;
-    const int B = c->n_beams;
-    const long cus = device_cu_count();
-    if (B <= 64) return 64;
-    if ((long)c->n_envs >= 12 * cus || B <= 256) return 256;
-    if ((long)c->n_envs > 2 * cus || B <= 512) return 512;
-    return 1024;
-}
-
-// which compiled form of the march step serves cfg.march_rule (kernels_field.hpp march_step): the float32-only
-// evaluation of NAVSIM_MARCH_F64 where every distance is sqrtf of an integer below 2^22
-int march_rule_variant(const navsim_config* c) {
-    if (c->march_rule == NAVSIM_MARCH_F32 || c->march_rule == NAVSIM_MARCH_F32_FMA) return c->march_rule;
-    const int side = c->map_h > c->map_w ? c->map_h : c->map_w;
-    return (c->field_format == NAVSIM_FIELD_U16T && side <= 1448) ? kMarchF64Exact32 : NAVSIM_MARCH_F64;
-}
-
-// How a step is launched: threads per arena, where the probes find the rect records, the dynamic LDS.
-struct StepPlan {
-    int block;              // threads per arena
-    int rect;               // 0 no rect records, 1 records read from global memory, 2 the arena's table staged in LDS
-    int park;               // rays a wavefront parks per chunk
-    size_t lds;             // dynamic LDS per workgroup
-    unsigned rect_off;      // byte offset of the staged table inside it
-};
-// The record table in LDS ("map tiles staged through LDS").  Round 3 staged the 16-byte records themselves: 63.5 KB per
-// 500 x 500 arena, two 1024-thread workgroups per CU, +10-13 % for launches of up to 4 arenas per CU and a loss beyond
-// (profiles/r03_rect_lds/).  Round 4 stages the INDEX form (kernels_rect.hpp: 10 KB) at the residency the block size implies
-// anyway; measured, records in global memory -> index rows in LDS (profiles/r04_idx/ab.txt, M env-steps/s): c2 36.4 -> 40.9,
-// 1024 arenas 17.8 -> 21.4, 512 arenas 13.3 -> 14.4, c4 28.2 -> 33.8, c5 4.36 -> 4.73.
-StepPlan plan_step(const navsim_config* c, const navsim_state* st, int grid = 0) {
-    StepPlan p;
-    p.block = pick_step_block(c);
-    p.rect = st->rect_table ? 1 : 0;
-    p.park = step_park_lanes(c, p.block);
-    p.lds = step_lds_bytes(c, p.park);
-    p.rect_off = 0;
-    // The index form of the arena's table staged in LDS (kernels_rect.hpp; round 4): 10 KB for a 500 x 500 map, so it fits at
-    // the residency the block size already implies -- eight 256-thread, four 512-thread or two 1024-thread workgroups per CU --
-    // and every probe reads LDS.  (Round 3 staged the 16-byte records, 63.5 KB: two workgroups per CU, small launches only.)
-    if (p.rect && st->rect_index && c->closed_maps && c->rect_lds != 1 && c->field_format == NAVSIM_FIELD_U16T) {
-        const size_t row = rect_index_row_bytes(c->map_h, c->map_w);
-        const size_t base = (p.lds + 15) & ~(size_t)15;
-        const size_t total = base + row + 1024;                     // + the kernel's static LDS, allocation granules
-        // workgroups per CU the rows must leave room for: all that the wave slots allow at 512 / 1024 threads; at 256 threads
-        // five of the eight are enough -- c3 (20 pedestrians: 20 KB of scan copy, pedestrian scratch and pair table per
-        // arena) fits five with the rows and runs 24.3 M env-steps/s against 23.7 M at eight with the records in global
-        // memory (profiles/r04_idx/ab2.txt, r04_defer/ab_c3_hazardfix.txt)
-        const int per_cu = p.block >= 1024 ? 2 : (p.block == 512 ? 4 : 5);
-        // a launch of at most one workgroup per CU (navsim_regen's first observations: a handful of lone scans) may take
-        // a CU's whole LDS
-        const bool lone = grid > 0 && grid <= device_cu_count();
-        const bool fits = c->rect_lds == 2 || lone ? total <= kLdsPerCu : (size_t)per_cu * total <= kLdsPerCu;
-        if (fits) { p.rect = 2; p.lds = base + row; p.rect_off = (unsigned)row; }     // the row comes first, everything else behind it
-    }
-    return p;
-}
+namespace {
 
 // navsim_prepare: walk the dispatch chain of a launch down to its kernel, set what has to be set once per kernel
 // (hipFuncSetAttribute for dynamic LDS above 64 KB) and launch nothing -- so that nothing of the kind happens inside a
 // hipGraph capture (round-3 advisor: navsim_regen's lone first-observation launch instantiates its own variant)
 thread_local bool g_prepare_only = false;
-template <int BLOCK, bool PEDS, typename Field, int RECT, int RULE, bool PINL>
-int launch_step_pinl(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
-                     const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
-    if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL>, p.lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
-    if (g_prepare_only) return NAVSIM_OK;
-    navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL><<<grid > 0 ? grid : c->n_envs, BLOCK, p.lds, s>>>(
-        *c, *st, *io, reset_only, mask, (unsigned)step_lds_scan_bytes(c, p.park), p.park, p.rect_off);
-    return NAVSIM_OK;
-}
-// pedestrian variants: the form without the pedestrian phase when ped_update_kernel has run (reset_only bit 1) or
-// nothing is integrated at all (a reset-only launch), else the form that carries it
-template <int BLOCK, bool PEDS, typename Field, int RECT, int RULE>
-int launch_step_kernel(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
-                       const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
-    if constexpr (PEDS) {
-        if (reset_only == 0) return launch_step_pinl<BLOCK, PEDS, Field, RECT, RULE, true>(c, st, io, reset_only, mask, p, s, grid);
-    }
-    return launch_step_pinl<BLOCK, PEDS, Field, RECT, RULE, false>(c, st, io, reset_only, mask, p, s, grid);
-}
 
-template <int BLOCK, bool PEDS, typename Field, int RECT>
-int launch_step_rule(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
-                     const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
-#ifdef NAVSIM_ONLY_RULE     // experiment builds (profiles/_diag/build_variant.sh): one march rule compiled, a quarter of the build time
-    if (march_rule_variant(c) != NAVSIM_ONLY_RULE) return NAVSIM_E_UNSUPPORTED;
-    return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_ONLY_RULE>(c, st, io, reset_only, mask, p, s, grid);
-#else
-    switch (march_rule_variant(c)) {
-        case NAVSIM_MARCH_F32: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F32>(c, st, io, reset_only, mask, p, s, grid);
-        case NAVSIM_MARCH_F32_FMA: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F32_FMA>(c, st, io, reset_only, mask, p, s, grid);
-        case kMarchF64Exact32:
-            if constexpr (!std::is_same<Field, FieldF32>::value)
-                return launch_step_kernel<BLOCK, PEDS, Field, RECT, kMarchF64Exact32>(c, st, io, reset_only, mask, p, s, grid);
-            [[fallthrough]];
-        default: return launch_step_kernel<BLOCK, PEDS, Field, RECT, NAVSIM_MARCH_F64>(c, st, io, reset_only, mask, p, s, grid);
-    }
-#endif
-}
-
-template <int BLOCK, bool PEDS, typename Field>
-int launch_step_field(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
-                      const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
-    if (p.rect == 2) return launch_step_rule<BLOCK, PEDS, Field, 2>(c, st, io, reset_only, mask, p, s, grid);
-    return p.rect ? launch_step_rule<BLOCK, PEDS, Field, 1>(c, st, io, reset_only, mask, p, s, grid)
-                  : launch_step_rule<BLOCK, PEDS, Field, 0>(c, st, io, reset_only, mask, p, s, grid);
-}
-
-template <int BLOCK>
-int launch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
-                const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
+// grid > 0: that many workgroups instead of one per arena; st->launch_order then names each workgroup's arena, -1 = none
+// (navsim_regen's first observations: one workgroup per regenerated arena)
+int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
+                  int reset_only, const uint8_t* mask, hipStream_t s, int grid = 0) {
+    int rc;
+    const StepPlan p = plan_step(c, st, grid);
     const bool peds = c->ped_model != NAVSIM_PED_NONE;
     if (peds && !reset_only && ped_split_on(c) && !g_prepare_only) {            // pedestrians ahead of the step (ped_split_on)
         const size_t pl = ped_update_lds_bytes(c);
@@ -256,34 +68,20 @@ int launch_step(const navsim_config* c, const navsim_state* st, const navsim_ste
         else                                      ped_update_kernel<FieldF32><<<pgrid, kPedUpdateBlock, pl, s>>>(*c, *st);
         reset_only |= 2;
     }
-    if (c->field_format == NAVSIM_FIELD_U16T && !st->field_overflow) {          // no saturated cell anywhere
-        return peds ? launch_step_field<BLOCK, true, FieldU16TN>(c, st, io, reset_only, mask, p, s, grid)
-                    : launch_step_field<BLOCK, false, FieldU16TN>(c, st, io, reset_only, mask, p, s, grid);
-    } else if (c->field_format == NAVSIM_FIELD_U16T) {
-        return peds ? launch_step_field<BLOCK, true, FieldU16T>(c, st, io, reset_only, mask, p, s, grid)
-                    : launch_step_field<BLOCK, false, FieldU16T>(c, st, io, reset_only, mask, p, s, grid);
-    }
-    return peds ? launch_step_rule<BLOCK, true, FieldF32, 0>(c, st, io, reset_only, mask, p, s, grid)
-                : launch_step_rule<BLOCK, false, FieldF32, 0>(c, st, io, reset_only, mask, p, s, grid);
-}
-
-// grid > 0: that many workgroups instead of one per arena; st->launch_order then names each workgroup's arena, -1 = none
-// (navsim_regen's first observations: one workgroup per regenerated arena)
-int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
-                  int reset_only, const uint8_t* mask, hipStream_t s, int grid = 0) {
-    int rc;
-    const StepPlan p = plan_step(c, st, grid);
+    const int po = g_prepare_only ? 1 : 0;
+#define NAVSIM_STEP_CASE(B) \
+    case B: rc = peds ? navsim_step_launch_##B##_1(c, st, io, reset_only, mask, (void*)s, grid, po) \
+                      : navsim_step_launch_##B##_0(c, st, io, reset_only, mask, (void*)s, grid, po); break;
     switch (p.block) {
-        case 64:   rc = launch_step<64>(c, st, io, reset_only, mask, p, s, grid); break;
-        case 256:  rc = launch_step<256>(c, st, io, reset_only, mask, p, s, grid); break;
-        case 512:  rc = launch_step<512>(c, st, io, reset_only, mask, p, s, grid); break;
-        case 1024: rc = launch_step<1024>(c, st, io, reset_only, mask, p, s, grid); break;
+        NAVSIM_STEP_CASE(64) NAVSIM_STEP_CASE(256) NAVSIM_STEP_CASE(512) NAVSIM_STEP_CASE(1024)
         default:   return NAVSIM_E_UNSUPPORTED;
     }
+#undef NAVSIM_STEP_CASE
     return rc != NAVSIM_OK ? rc : launch_status();
 }
 
 }  // namespace
+
 
 // ============================================================================================
 // C ABI
@@ -1175,7 +973,12 @@ int navsim_debug_gather(const float* x, uint64_t n_words, int32_t mode, int32_t 
 // diagnostic build only: where the per-arena stamps go (NULL disables)
 int navsim_debug_set_stamps(unsigned long long* buf) {
 #ifdef NAVSIM_STAMPS
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)) == hipSuccess ? NAVSIM_OK : NAVSIM_E_LAUNCH;
+    int rc = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)) == hipSuccess ? NAVSIM_OK : NAVSIM_E_LAUNCH;
+#define NAVSIM_SET(B, P) if (rc == NAVSIM_OK) rc = navsim_step_set_stamps_##B##_##P(buf);
+    NAVSIM_SET(64, 0) NAVSIM_SET(64, 1) NAVSIM_SET(256, 0) NAVSIM_SET(256, 1) NAVSIM_SET(512, 0) NAVSIM_SET(512, 1)
+    NAVSIM_SET(1024, 0) NAVSIM_SET(1024, 1)
+#undef NAVSIM_SET
+    return rc;
 #else
     (void)buf;
     return NAVSIM_E_UNSUPPORTED;
