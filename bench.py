@@ -109,11 +109,10 @@ def cpu_baseline(wl, seconds=15.0):
     workload, all host cores, arenas split statically over threads."""
     import numpy as np
     import torch
-    from concurrent.futures import ThreadPoolExecutor
     from nav_gym_amd import abi, lib, robots, world
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ref
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     E = min(wl["envs"], 8 * cores)
     cfg = lib.default_config(n_envs=E, map_h=wl["size"], map_w=wl["size"], max_peds=max(wl["peds"], 1),
                              ped_model=abi.PED_SFM if wl["peds"] else abi.PED_NONE, n_spawn=16, auto_reset=1, seed=1234)
@@ -132,30 +131,35 @@ def cpu_baseline(wl, seconds=15.0):
     r = ref.RefSim(cfg, host)
     r.reset_obs()
     rng = np.random.default_rng(0)
-    pool = ThreadPoolExecutor(cores)
     nthr = min(cores, E)
 
-    def one():
-        act = np.stack([rng.uniform(0, 0.5, E), rng.uniform(-0.64, 0.64, E)], axis=1)
-        r.step_threads(act, pool, nthr)
-    one()
+    def actions(n):
+        return np.stack([rng.uniform(0, 0.5, (n, E)), rng.uniform(-0.64, 0.64, (n, E))], axis=2)
+    # The loop is the oracle's own (navsim_step_threads_cpu, round 5): POSIX threads inside the library, every thread owns
+    # E / nthr arenas for the whole call and never waits for another (arenas are independent), no Python between steps.
+    # (Round 4 dispatched every step through a Python thread pool: 256 futures per ~3 ms of native work -- 13x on 256 threads.)
+    r.step_native_threads(actions(2), nthr)                      # warm-up: page the fields in, start the threads once
+    t0 = time.perf_counter()
+    per_call = 4
+    r.step_native_threads(actions(per_call), nthr)
+    one_call = max(time.perf_counter() - t0, 1e-4)
+    per_call = int(max(2, min(2000, 2 * round(0.5 * per_call * 1.0 / one_call))))      # ~1 s of work per call, even
     t0 = time.perf_counter()
     n = 0
-    while time.perf_counter() - t0 < seconds and n < 2000:
-        one()
-        n += 1
+    while time.perf_counter() - t0 < seconds:
+        r.step_native_threads(actions(per_call), nthr)
+        n += per_call
     dt = time.perf_counter() - t0
-    # SURVEY.md 8d extras, bounded to a few seconds each: the same oracle on ONE thread, and a
+    # SURVEY.md 8d extras, bounded to a few seconds each: the same loop on ONE thread, and a
     # "reference-shaped" step (1 arena, 512 beams over 2*pi, 1000x1000 map, 10 pedestrians, every
     # pedestrian's own 512-beam scan computed each step as env.py:685-693 does)
     t1 = time.perf_counter()
     m = 0
-    while time.perf_counter() - t1 < 3.0 and m < 2000:
-        act = np.stack([rng.uniform(0, 0.5, E), rng.uniform(-0.64, 0.64, E)], axis=1)
-        r.step_threads(act, pool, 1)
-        m += 1
+    one_call_1 = max(2, int(per_call * 1.0 / max(nthr, 1)) // 2 * 2)
+    while time.perf_counter() - t1 < 3.0:
+        r.step_native_threads(actions(one_call_1), 1)
+        m += one_call_1
     one_thread = E * m / (time.perf_counter() - t1)
-    pool.shutdown()
     # SURVEY.md 8d work counters: distance-field probes per ray of the oracle's march (calc_range, env.py:425) on
     # this workload's arenas -- a few steps on the calling thread (the histogram is per thread)
     ref.probe_hist(reset=True)
@@ -194,9 +198,9 @@ def cpu_baseline(wl, seconds=15.0):
     except Exception:
         pass
     return dict(value=E * n / dt, unit="env-steps/s", cores=nthr, kind="port",
-                sample="%d arenas x %d steps of the same workload (oracle/navsim_ref.c, %d threads, %.1f s)"
-                       % (E, n, nthr, dt),
-                value_1_thread=one_thread,
+                sample="%d arenas x %d steps of the same workload (oracle/navsim_ref.c navsim_step_threads_cpu: %d POSIX threads, "
+                       "arenas split statically, %.1f s)" % (E, n, nthr, dt),
+                value_1_thread=one_thread, parallel_efficiency=(E * n / dt) / max(one_thread * nthr, 1e-9),
                 probes_per_ray=probes,
                 reference_shaped_us_per_step=ref_shaped_us,
                 reference_shaped="1 arena, 512 beams, 1000x1000 map, 10 pedestrians + their 512-beam scans, 1 thread "
@@ -479,22 +483,23 @@ def extras(args, device):
             torch.cuda.empty_cache()
         except Exception as exc:                              # an extra must not cost the run its line
             res["other_workloads"][name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
-    reset_s = [0.0]                                # wall time of the last gym_window's env.reset() (the whole batch, on the device)
-
-    def gym_window(**kw):
-        """K calls of NavGymEnv.step(torch float64 actions [E,2]) after reset() on the device -> (env-steps/s, ms per call)"""
+    def gym_window(E, K=200, Wm=30, **kw):
+        """K calls of NavGymEnv.step(torch float64 actions [E,2]) after reset() on the device -> dict(value, ms_per_step, envs,
+        steps, reset_first_ms, reset_steady_ms).  reset_first_ms: the first reset() of a new environment (allocations, the
+        library's first launches, graph capture where the env uses graphs); reset_steady_ms: a second reset() of the same
+        environment -- what an RL loop pays per reset of the whole batch (round-4 verdict: 689 ms vs 19 ms were these two)."""
         import nav_gym_env
-        wl = WORKLOADS["c2"]
-        E = wl["envs"]
-        env = nav_gym_env.make("NavGym-v0", num_envs=E, n_beams=wl["beams"], map_size=wl["size"], indoor_ratio=0.0,
-                               device=device, seed=1234, **kw)
+        env = nav_gym_env.make("NavGym-v0", num_envs=E, device=device, seed=1234, **kw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         env.reset()                                # maps, fields, records, costmaps, planned starts / goals / routes, first observations
         torch.cuda.synchronize()
-        reset_s[0] = time.perf_counter() - t0
+        first = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        env.reset()
+        torch.cuda.synchronize()
+        steady = time.perf_counter() - t0
         g = torch.Generator(device=device); g.manual_seed(78)
-        K, Wm = 200, 30
         acts = torch.rand((K + Wm, E, 2), generator=g, device=device, dtype=torch.float64)
         acts[..., 0] *= 0.5; acts[..., 1] = acts[..., 1] * 1.28 - 0.64
         for t in range(Wm):
@@ -505,25 +510,49 @@ def extras(args, device):
             obs, rew, done, info = env.step(acts[Wm + t])
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        counters = env.counters()
+        episodes = int(env.sim.t["episode"].sum().item())
         env.close()
         del env
         torch.cuda.empty_cache()
-        return E * K / el, el / K * 1e3, E, K
+        return {"value": E * K / el, "ms_per_step": el / K * 1e3, "envs": E, "steps": K, "reset_first_ms": first * 1e3,
+                "reset_steady_ms": steady * 1e3, "episodes_started": episodes, "counters": counters}
     try:
         sys.path.insert(0, os.path.join(ROOT, "nav-gym_amd"))
-        v, ms, E, K = gym_window(pedestrian_model="none", num_humans=0)
-        res["value_gym_api"] = v
-        res["gym_api"] = {"ms_per_step": ms, "envs": E, "steps": K, "reset_all_ms": reset_s[0] * 1e3,
+        wl = WORKLOADS["c2"]
+        c2_kw = dict(n_beams=wl["beams"], map_size=wl["size"], indoor_ratio=0.0)
+        w = gym_window(wl["envs"], pedestrian_model="none", num_humans=0, **c2_kw)
+        res["value_gym_api"] = w["value"]
+        res["gym_api"] = {"ms_per_step": w["ms_per_step"], "envs": w["envs"], "steps": w["steps"],
+                          "reset_first_ms": w["reset_first_ms"], "reset_steady_ms": w["reset_steady_ms"],
                           "what": "K calls of NavGymEnv.step(torch float64 actions [E,2]) on a c2-shaped world made by gym.make('NavGym-v0', "
                                   "num_envs=4096, n_beams=1081, map_size=500, pedestrian_model='none', indoor_ratio=0) + reset() on the device; "
-                                  "returns the obs dict, reward, done.bool(), info (env.py:591-728's signature)"}
+                                  "returns the obs dict, reward, done.bool(), info (env.py:591-728's signature).  reset_first_ms: the first reset() "
+                                  "of a new environment (allocation, first launches); reset_steady_ms: a second reset() of all arenas"}
         # the same API on the c3-shaped world: 20 social-force pedestrians per arena, whose routes are planned on the costmap and
-        # re-planned at their goals by navsim_replan inside every step() (plan_paths=True, the env's default), and without
+        # re-planned at their goals by navsim_replan (plan_paths=True, the env's default: since round 5 beside the step,
+        # navsim_step_part), and without
         for key, plan in (("plan_paths", True), ("no_plan_paths", False)):
-            v, ms, E, K = gym_window(pedestrian_model="sfm", num_humans=20, plan_paths=plan)
-            res["gym_api"]["c3_world_" + key] = {"value": v, "ms_per_step": ms, "reset_all_ms": reset_s[0] * 1e3}
+            w = gym_window(wl["envs"], pedestrian_model="sfm", num_humans=20, plan_paths=plan, **c2_kw)
+            res["gym_api"]["c3_world_" + key] = {k: w[k] for k in ("value", "ms_per_step", "reset_first_ms", "reset_steady_ms", "counters")}
     except Exception as exc:
         res.setdefault("gym_api", {})["error"] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
+    # The reference's OWN configuration (round-4 verdict: "the only configuration an hrl-nav user runs unmodified"): every
+    # registered default of NavGym-v0 (__init__.py:4-40) -- 512 beams over 2 pi (keti_robot.py:44-48), 1000 x 1000 corridor maps
+    # and 400 x 400 outdoor maps at indoor_ratio 0.5 (map_generator.py:97-143), 5-15 pedestrians on planned routes, scan
+    # noise 0-0.05, a NEW map at every episode end -- batched: E arenas per GPU.
+    try:
+        ref_def = {}
+        for model, E in (("sfm", 1024), ("sfm", 4096)):
+            w = gym_window(E, K=100, Wm=20, map_size="reference", randomize_maps=True, pedestrian_model=model)
+            ref_def["%s_%d" % (model, E)] = w
+        res.setdefault("gym_api", {})["reference_defaults"] = dict(
+            ref_def, what="gym.make('NavGym-v0', num_envs=E, map_size='reference', randomize_maps=True) and nothing else changed: the "
+                          "registered kwargs of __init__.py:4-40 (indoor_ratio 0.5, 5-15 pedestrians, planned routes, scan noise), "
+                          "KetiRobot's 512-beam lidar, 1000 x 1000 arenas (corridor maps fill them, outdoor maps use 400 x 400); "
+                          "pedestrians: build-defined social force ('policy' needs human_policy.pth, missing upstream)")
+    except Exception as exc:
+        res.setdefault("gym_api", {})["reference_defaults"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
     return res
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NAVSIM_ABI_VERSION 4
+#define NAVSIM_ABI_VERSION 5
 
 /* error codes */
 #define NAVSIM_OK            0
@@ -220,7 +220,7 @@ typedef struct navsim_config {
 
 /* ------------------------------------------------------------------------------------------
  * Per-shard simulator state: structure of device arrays, env-major.  E = n_envs, N = max_peds,
- * B = n_beams, S = n_scan_stack, K = n_spawn, P = NAVSIM_MAX_WAYPOINTS.
+ * B = n_beams, S = n_scan_stack, K = n_spawn, P = cfg.max_waypoints.
  * Poses are float64 like the reference's Python floats; scans are float32 like env.py:387.
  * ---------------------------------------------------------------------------------------- */
 typedef struct navsim_state {
@@ -260,8 +260,12 @@ typedef struct navsim_state {
     double*  ped_dist;              /* [E,N,3] leg odometry (env.py:255) */
     const double*  ped_v_pref;      /* [E,N] */
     const uint8_t* ped_has_legs;    /* [E,N] */
-    double*  ped_waypoints;         /* [E,N,P,2] remaining waypoints, [0] is the current local goal; P = cfg.max_waypoints */
-    int32_t* ped_n_waypoints;       /* [E,N] >= 1 */
+    double*  ped_waypoints;         /* [E,N,P,2] the waypoints of every pedestrian's current route as its planner stored them
+                                       (path_to_waypoints, env.py:1261-1277); entry ped_wp_head is the current local goal.
+                                       Written only by whoever plans a route (the caller, navsim_regen, navsim_replan, the
+                                       step's table draw): the waypoint pop of env.py:633-642 advances ped_wp_head
+                                       instead of shifting the list (ABI 5).  P = cfg.max_waypoints */
+    int32_t* ped_n_waypoints;       /* [E,N] >= 1: waypoints STORED for the current route; entry n - 1 is the final one */
     const double*  ped_cmd;         /* [E,N,2] (v, omega) for NAVSIM_PED_EXTERNAL, else NULL */
 
     /* auto-reset tables */
@@ -303,6 +307,22 @@ typedef struct navsim_state {
      * ("map tiles staged through LDS"; cfg.rect_lds).  Needs rect_table (other kernels keep reading the records);
      * navsim_regen keeps it current.  Results are unchanged. */
     void* rect_index;
+
+    /* ---- ABI 5 ---- */
+    /* [E,N]: index of the pedestrian's current waypoint in its row of ped_waypoints, 0 <= head < ped_n_waypoints.  The
+     * reference pops a reached waypoint off the front of a Python list (env.py:633-642); here the pop is head += 1 and the
+     * list stays where its planner put it.  Every planner resets it to 0.  Required with pedestrians. */
+    int32_t* ped_wp_head;
+    /* [E] or NULL: written by navsim_step for every arena it steps -- bit i set = pedestrian i stands within 0.5 m of its
+     * final waypoint after this step's update, i.e. it is due for navsim_replan (env.py:667-680).  When present
+     * navsim_replan takes its candidates from here instead of scanning the state itself (every candidate is re-checked
+     * against the current state, so flags of pedestrians that were served or regenerated meanwhile are harmless), and
+     * navsim_regen clears the word of every arena it gives a new world. */
+    unsigned long long* ped_due;
+    /* [E] or NULL: the flags the PREVIOUS step wrote (the caller alternates two buffers between ped_due and ped_due_prev).
+     * Read by navsim_step_part only: it splits a step into the arenas with and without a pedestrian waiting for
+     * navsim_replan, so that the re-plan of step t runs beside step t + 1 of all the other arenas. */
+    const unsigned long long* ped_due_prev;
 } navsim_state;
 
 #define NAVSIM_N_COUNTERS              8
@@ -441,6 +461,21 @@ int navsim_beam_table(const navsim_config* cfg, double* table, void* stream);
 int navsim_step(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                 void* stream);
 
+/* navsim_step for a PART of the arenas (ABI 5), chosen by the flags the previous step left in st->ped_due_prev:
+ * NAVSIM_STEP_NOT_DUE steps the arenas none of whose pedestrians waits for navsim_replan, NAVSIM_STEP_DUE the others;
+ * the two calls together are exactly one navsim_step (arenas are independent; every arena is stepped by one of them),
+ * NAVSIM_STEP_ALL is navsim_step.  What it is for: navsim_replan is a chain of dependent breadth-first levels that serves
+ * ~2 % of the arenas per step and used to sit serially behind every step (env.py:667-680 plans inside step()); with
+ *     stream A:  navsim_step_part(NOT_DUE)                                    } step t + 1
+ *     stream B:  navsim_replan (of step t) -> navsim_step_part(DUE)            }
+ * the re-plan runs beside the step of the arenas that do not need it (nav_gym_amd/sim.py NavSim.step_overlapped).
+ * Both calls use the same io (rows of arenas a call does not step are not touched) and the same two flag buffers. */
+#define NAVSIM_STEP_ALL     0
+#define NAVSIM_STEP_NOT_DUE 1
+#define NAVSIM_STEP_DUE     2
+int navsim_step_part(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io, int32_t part,
+                     void* stream);
+
 /* ---- env.py:685-693: the scan of every pedestrian (input of the reference's HumanPolicy) --------- */
 /* out [E, N, ped_n_beams] float32 metres: static map from the pedestrian's integer cell, the robot as its
  * threshold footprint and the other pedestrians as footprint rectangles (lidar_legs=False), clipped to
@@ -507,7 +542,9 @@ int    navsim_plan(const uint8_t* cost, const int32_t* map_index, int32_t n_quer
  * more than cfg->ped_min_goal_dist away (up to 4 rounds of 16 draws) -- and the waypoints of the shortest
  * path to it every 2 m; it keeps its old waypoint when no round finds a path ("only if the human is not
  * adjacent to a wall").  At most max_queries pedestrians per call, in (arena, pedestrian) order; the rest
- * are served by a later call and counted in counters[NAVSIM_COUNTER_REPLAN_UNSERVED].  A pedestrian standing at
+ * are served by a later call and counted in counters[NAVSIM_COUNTER_REPLAN_UNSERVED].  With st->ped_due present the
+ * candidates are the pedestrians flagged there by the last navsim_step (the same set, found without a pass over the
+ * state).  A pedestrian standing at
  * the end of a CUT route (st->ped_goal present and different from its last stored waypoint) is first planned to
  * that same goal; only if no path joins them does it draw a new goal like the others.
  * Needs st->costmap.  Call after navsim_step / navsim_regen on the same stream. */

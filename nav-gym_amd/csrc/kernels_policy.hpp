@@ -233,19 +233,13 @@ __global__ __launch_bounds__(128) void policy_head_kernel(navsim_config c, navsi
             else {
                 live = 1;
                 const double* pp = st.ped_pose + q * 3;
-                double* wp = st.ped_waypoints + (q * P) * 2;
-                int nw = st.ped_n_waypoints[q];
-                while (nw > 1) {                               // env.py:633-640
-                    double ddx = pp[0] - wp[0], ddy = pp[1] - wp[1];
-                    if (sqrt(ddx * ddx + ddy * ddy) < 1.0) {
-                        for (int k = 0; k + 1 < nw; ++k) { wp[2 * k] = wp[2 * k + 2]; wp[2 * k + 1] = wp[2 * k + 3]; }
-                        nw -= 1;
-                    } else break;
-                }
-                st.ped_n_waypoints[q] = nw;
+                const double* wp = st.ped_waypoints + (q * P) * 2;
+                const double p3[3] = {pp[0], pp[1], pp[2]};
+                const int head = ped_pop_waypoints(wp, st.ped_wp_head[q], st.ped_n_waypoints[q], p3);   // env.py:633-640
+                st.ped_wp_head[q] = head;
                 double sn, cs;
                 nv::sincos(pp[2], sn, cs);                     // env.py:644-645
-                double gx = wp[0] - pp[0], gy = wp[1] - pp[1];
+                double gx = wp[2 * head] - pp[0], gy = wp[2 * head + 1] - pp[1];
                 z[s][256] = (float)(gx * cs + gy * sn);
                 z[s][257] = (float)(-gx * sn + gy * cs);
                 z[s][258] = prev_actions[2 * q];

@@ -638,9 +638,11 @@ __global__ __launch_bounds__(kCommitBlock) void regen_commit_kernel(navsim_confi
             double* wp = st.ped_waypoints + (q * P) * 2;
             wp[0] = gx; wp[1] = gy;
             st.ped_n_waypoints[q] = 1;
+            st.ped_wp_head[q] = 0;
             if (st.ped_goal) { st.ped_goal[q * 2] = gx; st.ped_goal[q * 2 + 1] = gy; }
         }
     }
+    if (tid == 0 && st.ped_due) st.ped_due[e] = 0ull;      // new pedestrians: nobody waits for navsim_replan
 }
 
 // ============================================================================================
@@ -734,14 +736,30 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
         unsigned long long* bm = (unsigned long long*)(((uintptr_t)((char*)dist + (size_t)n_cells * 2) + 15) & ~(uintptr_t)15);
         unsigned long long* free_b = bm, *seen = bm + n_words, *fa = bm + 2 * n_words, *fb = bm + 3 * n_words;
         __shared__ int any_s[3];
-        for (int k = tid; k < n_cells; k += BLOCK) dist[k] = (int16_t)-1;
-        for (int x = tid; x < n_words; x += BLOCK) {
-            const int j = x / Ww, w = x - j * Ww;
-            const int i0 = w << 6, i1 = (i0 + 64 < Wc) ? i0 + 64 : Wc;
-            unsigned long long f = 0;
-            const uint8_t* row = c + (size_t)j * Wc;
-            for (int i = i0; i < i1; ++i) f |= (unsigned long long)(row[i] == 0) << (i - i0);
-            free_b[x] = f; seen[x] = 0; fa[x] = 0; fb[x] = 0;
+        {   // dist = -1 everywhere, 16 bytes per store (the area is 16-byte aligned and padded to it)
+            const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            uint4* d16 = (uint4*)dist;
+            for (int k = tid; k < (n_cells * 2 + 15) / 16; k += BLOCK) d16[k] = ones;
+        }
+        {   // the free-cell bitmap: a wavefront reads 64 cells of a row with one coalesced byte load and ballots them into the
+            // word; sixteen words per wavefront in flight (round 5: one thread used to assemble a word from 64 dependent byte
+            // loads -- 20 us of every query, profiles/r04_replan/levels_*.txt's offset)
+            constexpr int U = 16, kWaves = BLOCK / 64;
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int x0 = wave * U; x0 < n_words; x0 += kWaves * U) {
+                bool fr[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int x = x0 + u, j = x / Ww, w = x - j * Ww, i = (w << 6) + lane;
+                    fr[u] = (x < n_words && i < Wc) ? (c[(size_t)j * Wc + i] == 0) : false;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const unsigned long long f = __ballot(fr[u]);
+                    const int x = x0 + u;
+                    if (lane == 0 && x < n_words) { free_b[x] = f; seen[x] = 0; fa[x] = 0; fb[x] = 0; }
+                }
+            }
         }
         if (tid == 0) { any_s[0] = 0; any_s[1] = 1; any_s[2] = 0; reached = (s_cell == g_cell); }
         __syncthreads();
@@ -1094,12 +1112,13 @@ __global__ __launch_bounds__(256) void regen_ped_round_kernel(navsim_config c, n
     const double rx = st.robot_pose[3 * (size_t)e], ry = st.robot_pose[3 * (size_t)e + 1];
     int n = (c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
     n = n > N ? N : n;
+    if (tid == 0 && round == 0 && st.ped_due) st.ped_due[e] = 0ull;      // new pedestrians: nobody waits for navsim_replan
     for (int i = tid; i < Q; i += 256) {
         const size_t q = (size_t)b * Q + i;
         if (i >= n) { ws.active[q] = 0; continue; }
         const size_t pq = (size_t)e * N + i;
         uint8_t& res = ws.res_ped[(size_t)b * N + i];
-        if (round > 0 && !res && ws.qnwp[q] > 0) { st.ped_n_waypoints[pq] = ws.qnwp[q]; res = 1; }
+        if (round > 0 && !res && ws.qnwp[q] > 0) { st.ped_n_waypoints[pq] = ws.qnwp[q]; st.ped_wp_head[pq] = 0; res = 1; }
         ws.active[q] = 0;
         if (res || round >= 4) continue;
         uint64_t key = rg_key(c.seed, genv, ep, 0x50504C00ULL + (uint64_t)round * 256 + (uint64_t)i), nn = 0;
@@ -1110,6 +1129,7 @@ __global__ __launch_bounds__(256) void regen_ped_round_kernel(navsim_config c, n
         double* w = st.ped_waypoints + (pq * P) * 2;
         w[0] = gx; w[1] = gy;
         st.ped_n_waypoints[pq] = 1;
+        st.ped_wp_head[pq] = 0;
         if (st.ped_goal) { st.ped_goal[pq * 2] = gx; st.ped_goal[pq * 2 + 1] = gy; }
         ws.qstart[2 * q] = x; ws.qstart[2 * q + 1] = y;
         ws.qgoal[2 * q] = gx; ws.qgoal[2 * q + 1] = gy;
@@ -1204,9 +1224,14 @@ __global__ __launch_bounds__(kReplanBlock) void replan_kernel(navsim_config c, n
     // goal it had (round -1: no draw); only if no path joins them does it draw a new goal like the others.  Every thread
     // reads the same two words before any of them is rewritten (block-uniform).
     bool cut = false;
-    if (st.ped_goal) {
+    {
         const int nw = st.ped_n_waypoints[q];
-        cut = w[2 * (nw - 1)] != st.ped_goal[(size_t)q * 2] || w[2 * (nw - 1) + 1] != st.ped_goal[(size_t)q * 2 + 1];
+        // a candidate taken from st.ped_due may have been served or given a new world since the step flagged it: the
+        // arrival test of env.py:667 (replan_flag_kernel's) on the CURRENT state decides (block-uniform)
+        const double ddx = px - w[2 * (nw - 1)], ddy = py - w[2 * (nw - 1) + 1];
+        if (!(sqrt(ddx * ddx + ddy * ddy) < 0.5)) return;
+        if (st.ped_goal)
+            cut = w[2 * (nw - 1)] != st.ped_goal[(size_t)q * 2] || w[2 * (nw - 1) + 1] != st.ped_goal[(size_t)q * 2 + 1];
     }
     __syncthreads();
     for (int round = cut ? -1 : 0; round < 4; ++round) {
@@ -1227,6 +1252,7 @@ __global__ __launch_bounds__(kReplanBlock) void replan_kernel(navsim_config c, n
         if (nwp_s > 0) {
             if (tid == 0) {
                 st.ped_n_waypoints[q] = nwp_s;
+                st.ped_wp_head[q] = 0;
                 if (st.ped_goal) { st.ped_goal[(size_t)q * 2] = goal_s[0]; st.ped_goal[(size_t)q * 2 + 1] = goal_s[1]; }
                 if (round < 0 && st.counters) atomicAdd(&st.counters[NAVSIM_COUNTER_ROUTES_RESUMED], 1ull);
             }
@@ -1336,12 +1362,14 @@ __global__ __launch_bounds__(256) void regen_swap_kernel(navsim_config c, navsim
         row((uint8_t*)live.ped_has_legs, stage.ped_has_legs, N);
         row(live.ped_waypoints, stage.ped_waypoints, (size_t)N * P * 2);
         row(live.ped_n_waypoints, stage.ped_n_waypoints, N);
+        row(live.ped_wp_head, stage.ped_wp_head, N);
         row(live.ped_goal, stage.ped_goal, (size_t)N * 2);
     }
     row(io.obs, stage_obs, D);
     if (tid == 0) {
         if (io.achieved_goal) { io.achieved_goal[2 * e] = (float)stage.robot_pose[3 * (size_t)e]; io.achieved_goal[2 * e + 1] = (float)stage.robot_pose[3 * (size_t)e + 1]; }
         if (io.desired_goal) { io.desired_goal[2 * e] = (float)stage.robot_goal[2 * (size_t)e]; io.desired_goal[2 * e + 1] = (float)stage.robot_goal[2 * (size_t)e + 1]; }
+        if (live.ped_due) live.ped_due[e] = 0ull;           // new pedestrians: nobody waits for navsim_replan
         stage.episode[e] = live.episode[e] + 1;              // the world after THIS one
         mark[e] = 1;
     }

@@ -584,16 +584,16 @@ __device__ __forceinline__ void scan_beams_pred(const navsim_config& c, StepShar
 // ---- pieces of phase 1 for ONE pedestrian (env.py:617-693 with the build-defined social force or external commands),
 // shared by the fused step kernel (pedestrian i on thread i of the arena's workgroup) and by ped_update_kernel (a pack
 // of arenas per workgroup).  Same functions, same operation order: same results.
-// waypoint pop (env.py:633-642); returns the remaining count
-__device__ __forceinline__ int ped_pop_waypoints(double* wp, int nw, const double (&pp)[3]) {
-    while (nw > 1) {
-        double ddx = pp[0] - wp[0], ddy = pp[1] - wp[1];
-        if (sqrt(ddx * ddx + ddy * ddy) < 1.0) {
-            for (int k = 0; k + 1 < nw; ++k) { wp[2 * k] = wp[2 * k + 2]; wp[2 * k + 1] = wp[2 * k + 3]; }
-            nw -= 1;
-        } else break;
+// waypoint pop (env.py:633-642): the current waypoint is wp[head], a pop advances the head (ABI 5: the list is read-only between
+// two plans; rounds 1-4 shifted the whole remaining list through global memory on this lane, up to 63 double2 moves per pop on
+// the wavefront the c3 / c5 launches wait for).  wp = the pedestrian's row, nw = waypoints stored; returns the new head
+__device__ __forceinline__ int ped_pop_waypoints(const double* wp, int head, int nw, const double (&pp)[3]) {
+    while (head + 1 < nw) {
+        double ddx = pp[0] - wp[2 * head], ddy = pp[1] - wp[2 * head + 1];
+        if (sqrt(ddx * ddx + ddy * ddy) < 1.0) ++head;
+        else break;
     }
-    return nw;
+    return head;
 }
 // the (i, j) of pair term t of an arena with n pedestrians: the strict upper triangle row by row (n (n - 1) / 2 terms
 // between pedestrians, each evaluated once), then the robot (index n) acting on pedestrian t - n_pp
@@ -689,31 +689,35 @@ __device__ __forceinline__ void ped_sfm_step(const navsim_config& c, const Field
     pvel[0] = vx; pvel[1] = vy;
 }
 // new goal at the final waypoint (env.py:667-680: table draw, or wait for navsim_replan), leg odometry and the
-// pedestrian's obs yaw (env.py:683-693), state
-__device__ __forceinline__ void ped_finish(const navsim_config& c, const navsim_state& st, int e, int i, size_t pq, double* wp,
-                                           int nw, double dt, uint64_t genv, uint64_t steps_now, const double (&pp)[3],
+// pedestrian's obs yaw (env.py:683-693), state.  wp = the pedestrian's row of waypoints, head = its current one, nw = stored.
+// Returns whether the pedestrian stands within 0.5 m of its final waypoint (what navsim_replan serves: st.ped_due).
+__device__ __forceinline__ bool ped_finish(const navsim_config& c, const navsim_state& st, int e, int i, size_t pq, double* wp,
+                                           int head, int nw, double dt, uint64_t genv, uint64_t steps_now, const double (&pp)[3],
                                            const double (&pvel)[2]) {
     double ddx = pp[0] - wp[2 * (nw - 1)], ddy = pp[1] - wp[2 * (nw - 1) + 1];
-    if (sqrt(ddx * ddx + ddy * ddy) < 0.5 && c.n_spawn > 0 && st.spawn_pose && !st.costmap) {
+    const bool at_final = sqrt(ddx * ddx + ddy * ddy) < 0.5;
+    if (at_final && c.n_spawn > 0 && st.spawn_pose && !st.costmap) {
         uint64_t h = nv::hash4(c.seed, genv, (uint64_t)i + 1000, steps_now);
         for (int tries = 0; tries < c.n_spawn; ++tries) {
             int idx = (int)((h + (uint64_t)tries) % (uint64_t)c.n_spawn);
             const double* cand = st.spawn_pose + ((size_t)e * c.n_spawn + idx) * 3;
             double gx = cand[0] - pp[0], gy = cand[1] - pp[1];
             if (sqrt(gx * gx + gy * gy) > 10.0) {
-                wp[0] = cand[0]; wp[1] = cand[1]; nw = 1;
+                wp[0] = cand[0]; wp[1] = cand[1]; head = 0;
+                st.ped_n_waypoints[pq] = 1;
                 if (st.ped_goal) { st.ped_goal[pq * 2] = cand[0]; st.ped_goal[pq * 2 + 1] = cand[1]; }
                 break;
             }
         }
     }
-    st.ped_n_waypoints[pq] = nw;
+    st.ped_wp_head[pq] = head;
     double dist[3] = {st.ped_dist[pq * 3], st.ped_dist[pq * 3 + 1], st.ped_dist[pq * 3 + 2]};
     nv::leg_odometry(pp, pvel, st.ped_prev_yaw[pq], dt, dist);
     st.ped_dist[pq * 3] = dist[0]; st.ped_dist[pq * 3 + 1] = dist[1]; st.ped_dist[pq * 3 + 2] = dist[2];
     st.ped_prev_yaw[pq] = nv::wrap_pi(pp[2]);
     st.ped_pose[pq * 3] = pp[0]; st.ped_pose[pq * 3 + 1] = pp[1]; st.ped_pose[pq * 3 + 2] = pp[2];
     st.ped_vel[pq * 2] = pvel[0]; st.ped_vel[pq * 2 + 1] = pvel[1];
+    return at_final;
 }
 
 // LDS written by some lanes of a wavefront and read by others of the SAME wavefront: no workgroup barrier (the other
@@ -732,14 +736,18 @@ __device__ __forceinline__ void wave_lds_sync() {
 // pedestrian adds its row in partner order -- the same sums, in the same order, as a sequential loop.
 // (a) before the workgroup's first barrier -- beside the robot's step on another wavefront: waypoint pop, every agent's
 // position / velocity at time t staged (pedestrians, then the robot from its global state, which nobody writes before
-// the end of the kernel); returns the remaining waypoint count
+// the end of the kernel); returns the index of the current waypoint after the pop, nw = the waypoints stored
 __device__ __forceinline__ int ped_stage_wave(const navsim_config& c, const navsim_state& st, int n, int lane, bool is_ped,
                                               size_t pq, const double* rp_t, double prev_v, const PedShared& ps,
-                                              const double (&pp)[3], const double (&pvel)[2]) {
+                                              const double (&pp)[3], const double (&pvel)[2], int& nw) {
     const int P = c.max_waypoints;
-    double* wp = st.ped_waypoints ? st.ped_waypoints + (pq * P) * 2 : nullptr;
-    int nw = 1;
-    if (is_ped) nw = ped_pop_waypoints(wp, st.ped_n_waypoints[pq], pp);
+    const double* wp = st.ped_waypoints + (pq * P) * 2;
+    int head = 0;
+    nw = 1;
+    if (is_ped) {
+        nw = st.ped_n_waypoints[pq];
+        head = ped_pop_waypoints(wp, st.ped_wp_head[pq], nw, pp);
+    }
     if (c.ped_model == NAVSIM_PED_SFM) {
         if (is_ped) { ps.ax[lane] = pp[0]; ps.ay[lane] = pp[1]; ps.avx[lane] = pvel[0]; ps.avy[lane] = pvel[1]; }
         if (lane == 0) {
@@ -749,27 +757,31 @@ __device__ __forceinline__ int ped_stage_wave(const navsim_config& c, const navs
             ps.avx[n] = prev_v * cs; ps.avy[n] = prev_v * s;
         }
     }
-    return nw;
+    return head;
 }
 // (b) behind it: pair terms, forces and the Euler step, new goals, leg odometry, state
 template <typename Field>
 __device__ __forceinline__ void ped_advance_wave(const navsim_config& c, const navsim_state& st, const Field& field, int e,
                                                  int n, int lane, bool is_ped, size_t pq, double dt, uint64_t genv,
-                                                 uint64_t steps_now, const PedShared& ps, double2* pair, int nw,
+                                                 uint64_t steps_now, const PedShared& ps, double2* pair, int head, int nw,
                                                  double (&pp)[3], double (&pvel)[2]) {
     const int P = c.max_waypoints;
-    double* wp = st.ped_waypoints ? st.ped_waypoints + (pq * P) * 2 : nullptr;
+    double* wp = st.ped_waypoints + (pq * P) * 2;
     if (c.ped_model == NAVSIM_PED_SFM) {
         wave_lds_sync();                                    // the staged agents (the workgroup barrier lies in between as well)
         const int n_terms = n * (n - 1) / 2 + n;
         for (int t = lane; t < n_terms; t += 64) ped_pair_term(c, ps, pair, n, t);
         wave_lds_sync();
-        if (is_ped) ped_sfm_step(c, field, ps, pair, n, lane, st.ped_v_pref[pq], wp, dt, pp, pvel);
+        if (is_ped) ped_sfm_step(c, field, ps, pair, n, lane, st.ped_v_pref[pq], wp + 2 * head, dt, pp, pvel);
     } else if (c.ped_model == NAVSIM_PED_EXTERNAL && is_ped) {
         const double* cmd = st.ped_cmd + pq * 2;
         nv::set_vel(pp, cmd[0], cmd[1], dt, 0.0, pvel);     // env.py:662
     }
-    if (is_ped) ped_finish(c, st, e, lane, pq, wp, nw, dt, genv, steps_now, pp, pvel);
+    bool due = false;
+    if (is_ped) due = ped_finish(c, st, e, lane, pq, wp, head, nw, dt, genv, steps_now, pp, pvel);
+    // who waits for navsim_replan (navsim_state.ped_due): one word per arena, pedestrian i = bit i (this wavefront's lanes)
+    const unsigned long long m = __ballot(due);
+    if (st.ped_due && lane == 0) st.ped_due[e] = m;
 }
 
 // The pedestrians of every arena ahead of the fused step (navsim_config.ped_split = 2; rounds 1-2 took this form for large
@@ -822,12 +834,14 @@ __global__ __launch_bounds__(kPedUpdateBlock) void ped_update_kernel(navsim_conf
     const Field field(st.field, st.field_overflow, c.shared_field ? 0 : (slot_ok ? e : 0), c.map_h, c.map_w);
     double pp[3] = {0.0, 0.0, 0.0}, pvel[2] = {0.0, 0.0};
     double* wp = st.ped_waypoints + (pq * P) * 2;
-    int nw = 1;
+    int nw = 1, head = 0;
     if (is_ped) {
         pp[0] = st.ped_pose[pq * 3]; pp[1] = st.ped_pose[pq * 3 + 1]; pp[2] = st.ped_pose[pq * 3 + 2];
         pvel[0] = st.ped_vel[pq * 2]; pvel[1] = st.ped_vel[pq * 2 + 1];
-        nw = ped_pop_waypoints(wp, st.ped_n_waypoints[pq], pp);
+        nw = st.ped_n_waypoints[pq];
+        head = ped_pop_waypoints(wp, st.ped_wp_head[pq], nw, pp);
     }
+    if (st.ped_due && slot_ok && i == 0) st.ped_due[e] = 0ull;          // (ordered before the atomics below by the barriers in between)
     const double dt = c.time_step;
     if (c.ped_model == NAVSIM_PED_SFM) {
         if (is_ped) { ps.ax[i] = pp[0]; ps.ay[i] = pp[1]; ps.avx[i] = pvel[0]; ps.avy[i] = pvel[1]; }
@@ -854,13 +868,17 @@ __global__ __launch_bounds__(kPedUpdateBlock) void ped_update_kernel(navsim_conf
             ped_pair_term(c, ped_lds_carve(base + ped_pair_bytes(N), N), (double2*)base, slot_n[q], t - slot_off[q]);
         }
         __syncthreads();
-        if (is_ped) ped_sfm_step(c, field, ps, (const double2*)my, n, i, st.ped_v_pref[pq], wp, dt, pp, pvel);
+        if (is_ped) ped_sfm_step(c, field, ps, (const double2*)my, n, i, st.ped_v_pref[pq], wp + 2 * head, dt, pp, pvel);
     } else if (c.ped_model == NAVSIM_PED_EXTERNAL && is_ped) {
         const double* cmd = st.ped_cmd + pq * 2;
         nv::set_vel(pp, cmd[0], cmd[1], dt, 0.0, pvel);               // env.py:662
     }
+    __syncthreads();                                                   // every arena's ped_due word is zero by now
     // the step increments steps[e] before anything else (env.py:592); it has not run yet
-    if (is_ped) ped_finish(c, st, e, i, pq, wp, nw, dt, (uint64_t)(c.env_index_base + e), (uint64_t)st.steps[e] + 1, pp, pvel);
+    if (is_ped) {
+        const bool due = ped_finish(c, st, e, i, pq, wp, head, nw, dt, (uint64_t)(c.env_index_base + e), (uint64_t)st.steps[e] + 1, pp, pvel);
+        if (due && st.ped_due) atomicOr(&st.ped_due[e], 1ull << i);
+    }
 }
 
 // The fused step.  BLOCK threads = one arena; PEDS: the pedestrian variants (primitives + culled merge in LDS);
@@ -875,6 +893,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                                             unsigned dyn_lds_bytes, int park_lanes, unsigned rect_lds_offset) {
     __shared__ StepShared sh;
     const int peds_done = (reset_only >> 1) & 1;     // the pedestrians were advanced by ped_update_kernel
+    const int part = (reset_only >> 2) & 3;          // navsim_step_part: NAVSIM_STEP_NOT_DUE / NAVSIM_STEP_DUE
     reset_only &= 1;
     // dynamic LDS: [the arena's index row (RECT = 2)][parked rays][pedestrian variants: float2 dir[B], float rng[B]][PedShared][pair table]
     extern __shared__ __attribute__((aligned(16))) char dyn_lds_all[];
@@ -885,6 +904,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     // longest-first launch order (a scheduling hint: which arena a workgroup takes never changes a result)
     const int e = st.launch_order ? st.launch_order[blockIdx.x] : (int)blockIdx.x;
     if (e < 0) return;              // navsim_regen's first-observation launch: one workgroup per list slot, -1 = empty slot
+    // navsim_step_part: this launch steps the arenas with (NAVSIM_STEP_DUE) or without a pedestrian that waited for navsim_replan
+    // when the previous step ended; the other launch of the pair steps the rest.  Nothing of a skipped arena is touched.
+    if (part != NAVSIM_STEP_ALL && (st.ped_due_prev[e] != 0ull) != (part == NAVSIM_STEP_DUE)) return;
     const int tid = threadIdx.x;
     unsigned long long t_begin = 0;
     if (st.arena_cost && tid == 0) t_begin = __builtin_amdgcn_s_memrealtime();
@@ -929,7 +951,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const bool is_ped = PEDS && tid < n;                        // n <= 64
     const size_t pq = (size_t)e * N + (is_ped ? tid : 0);
     const bool ped_advance = PEDS && PINL && !reset_only && !peds_done;
-    int ped_nw = 1;
+    int ped_head = 0, ped_nw = 1;
     if constexpr (PEDS) {
         if (tid < 64) {
             if (is_ped) {
@@ -937,7 +959,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 pvel[0] = st.ped_vel[pq * 2]; pvel[1] = st.ped_vel[pq * 2 + 1];
             }
             if constexpr (PINL) {
-                if (ped_advance) ped_nw = ped_stage_wave(c, st, n, tid, is_ped, pq, rp_g, pa_g[0], ps, pp, pvel);
+                if (ped_advance) ped_head = ped_stage_wave(c, st, n, tid, is_ped, pq, rp_g, pa_g[0], ps, pp, pvel, ped_nw);
             }
         }
     }
@@ -1014,7 +1036,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                     // the pair table: dynamic LDS behind PedShared (the host allocates it for the launches that carry the phase)
                     double2* pair = (double2*)(dyn_lds + ((dyn_lds_bytes + 15u) & ~15u) + ((ped_lds_bytes(N) + 15) & ~(size_t)15));
                     ped_advance_wave<Field>(c, st, field, e, n, lane, is_ped, pq, dt, genv, (uint64_t)st.steps[e], ps, pair,
-                                            ped_nw, pp, pvel);
+                                            ped_head, ped_nw, pp, pvel);
                 }
             }
             if (reset_only && is_ped) {                             // env.py:809, 812-820

@@ -61,7 +61,7 @@ int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_s
     int rc;
     const StepPlan p = plan_step(c, st, grid);
     const bool peds = c->ped_model != NAVSIM_PED_NONE;
-    if (peds && !reset_only && ped_split_on(c) && !g_prepare_only) {            // pedestrians ahead of the step (ped_split_on)
+    if (peds && !(reset_only & 1) && ped_split_on(c) && !g_prepare_only) {            // pedestrians ahead of the step (ped_split_on)
         const size_t pl = ped_update_lds_bytes(c);
         const int G = ped_pack(c->max_peds), pgrid = (c->n_envs + G - 1) / G;
         if (c->field_format == NAVSIM_FIELD_U16T) ped_update_kernel<FieldU16T><<<pgrid, kPedUpdateBlock, pl, s>>>(*c, *st);
@@ -408,7 +408,7 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
     if (!reset_only && c->n_scan_stack > 1 && !io->obs_prev) return NAVSIM_E_ARG;
     if (c->ped_model != NAVSIM_PED_NONE) {
         if (!st->n_peds || !st->ped_pose || !st->ped_vel || !st->ped_prev_yaw || !st->ped_dist ||
-            !st->ped_has_legs || !st->ped_waypoints || !st->ped_n_waypoints)
+            !st->ped_has_legs || !st->ped_waypoints || !st->ped_n_waypoints || !st->ped_wp_head)
             return NAVSIM_E_ARG;
         if (c->ped_model == NAVSIM_PED_EXTERNAL && !st->ped_cmd && !reset_only) return NAVSIM_E_ARG;
         if (c->ped_model == NAVSIM_PED_SFM && !st->ped_v_pref) return NAVSIM_E_ARG;
@@ -709,7 +709,7 @@ int navsim_replan(const navsim_config* c, const navsim_state* st, int32_t max_qu
                   size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
     if (!c || !st || !workspace || max_queries < 0 || !st->costmap || !st->ped_pose || !st->ped_waypoints ||
-        !st->ped_n_waypoints || !st->n_peds || !st->steps || !st->episode)
+        !st->ped_n_waypoints || !st->ped_wp_head || !st->n_peds || !st->steps || !st->episode)
         return NAVSIM_E_ARG;
     if (workspace_bytes < navsim_replan_workspace_bytes(c, max_queries)) return NAVSIM_E_ARG;
     if (c->ped_model == NAVSIM_PED_NONE || c->n_envs == 0) return NAVSIM_OK;
@@ -721,8 +721,10 @@ int navsim_replan(const navsim_config* c, const navsim_state* st, int32_t max_qu
     int* count = (int*)workspace;
     int* list = (int*)((char*)workspace + 256);
     uint64_t* due = (uint64_t*)((char*)workspace + 256 + (((size_t)max_queries * sizeof(int32_t) + 255) & ~(size_t)255));
-    replan_flag_kernel<<<c->n_envs, 64, 0, s>>>(*c, *st, due);
-    replan_select_kernel<<<1, 1024, 0, s>>>(due, c->n_envs, c->max_peds, max_queries, count, list, *st);
+    // who is due: the flags the last step left in st->ped_due (ABI 5), else a pass over the state
+    const uint64_t* flags = (const uint64_t*)st->ped_due;
+    if (!flags) { replan_flag_kernel<<<c->n_envs, 64, 0, s>>>(*c, *st, due); flags = due; }
+    replan_select_kernel<<<1, 1024, 0, s>>>(flags, c->n_envs, c->max_peds, max_queries, count, list, *st);
     if (max_queries > 0) replan_kernel<<<max_queries, kReplanBlock, plan_lds(Hc, Wc), s>>>(*c, *st, count, list);
     return launch_status();
 }
@@ -743,7 +745,7 @@ static int ped_policy_run(const navsim_config* c, const navsim_state* st, const 
                           size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
     if (!c || !st || !w || !prev_actions || !ped_cmd || !workspace || !st->ped_pose ||
-        !st->ped_waypoints || !st->ped_n_waypoints || !st->ped_v_pref || !st->n_peds)
+        !st->ped_waypoints || !st->ped_n_waypoints || !st->ped_wp_head || !st->ped_v_pref || !st->n_peds)
         return NAVSIM_E_ARG;
     if (!w->cv1_w || !w->cv1_b || !w->cv2_w || !w->cv2_b || !w->fc1_w || !w->fc1_b || !w->fc2_w || !w->fc2_b ||
         !w->a1_w || !w->a1_b || !w->a2_w || !w->a2_b)
@@ -891,6 +893,18 @@ int navsim_step(const navsim_config* c, const navsim_state* st, const navsim_ste
     if (rc != NAVSIM_OK) return rc;
     if (c->n_envs == 0) return NAVSIM_OK;
     return dispatch_step(c, st, io, 0, nullptr, (hipStream_t)stream);
+}
+
+int navsim_step_part(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int32_t part, void* stream) {
+    (void)hipGetLastError();
+    if (part == NAVSIM_STEP_ALL) return navsim_step(c, st, io, stream);
+    if (part != NAVSIM_STEP_NOT_DUE && part != NAVSIM_STEP_DUE) return NAVSIM_E_ARG;
+    int rc = check_step_args(c, st, io, 0);
+    if (rc != NAVSIM_OK) return rc;
+    if (!st->ped_due_prev || !st->ped_due || st->ped_due == st->ped_due_prev) return NAVSIM_E_ARG;
+    if (c->ped_model != NAVSIM_PED_NONE && ped_split_on(c)) return NAVSIM_E_UNSUPPORTED;   // ped_update_kernel advances every arena
+    if (c->n_envs == 0) return NAVSIM_OK;
+    return dispatch_step(c, st, io, part << 2, nullptr, (hipStream_t)stream);
 }
 
 int navsim_prepare(const navsim_config* c, const navsim_state* st, const navsim_step_io* io) {

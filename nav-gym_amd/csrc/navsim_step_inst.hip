@@ -36,7 +36,7 @@ template <int BLOCK, bool PEDS, typename Field, int RECT, int RULE>
 int launch_step_kernel(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
                        const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
     if constexpr (PEDS) {
-        if (reset_only == 0) return launch_step_pinl<BLOCK, PEDS, Field, RECT, RULE, true>(c, st, io, reset_only, mask, p, s, grid);
+        if ((reset_only & 3) == 0) return launch_step_pinl<BLOCK, PEDS, Field, RECT, RULE, true>(c, st, io, reset_only, mask, p, s, grid);
     }
     return launch_step_pinl<BLOCK, PEDS, Field, RECT, RULE, false>(c, st, io, reset_only, mask, p, s, grid);
 }
@@ -83,7 +83,8 @@ int launch_step_family(const navsim_config* c, const navsim_state* st, const nav
 #define NAVSIM_CAT_(a, b, c) a##b##_##c
 #define NAVSIM_CAT(a, b, c) NAVSIM_CAT_(a, b, c)
 
-// reset_only: bit 0 = a reset-only launch, bit 1 = ped_update_kernel has already advanced the pedestrians; grid > 0: that
+// reset_only: bit 0 = a reset-only launch, bit 1 = ped_update_kernel has already advanced the pedestrians, bits 2-3 = the
+// NAVSIM_STEP_* part of navsim_step_part; grid > 0: that
 // many workgroups (st->launch_order names their arenas); prepare_only: set the kernel's attributes, launch nothing
 extern "C" __attribute__((visibility("hidden")))
 int NAVSIM_CAT(navsim_step_launch_, NAVSIM_INST_BLOCK, NAVSIM_INST_PEDS)(const navsim_config* c, const navsim_state* st,

@@ -6,7 +6,7 @@ Field order and types must match include/navsim.h exactly; tests/test_abi.py com
 """
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 OK = 0
 E_ARG = -1
@@ -30,6 +30,8 @@ MARCH_F64 = 0          # t += max(fl32(fl64(d) * 0.999), 1)
 MARCH_F32 = 1          # t += max(d * 0.999f, 1): RangeLib.h's float member step_coeff (default since ABI 4)
 MARCH_F32_FMA = 2      # MARCH_F32 with the sample position contracted into an FMA (GCC -O3 -march=native on FMA hardware)
 MARCH_RULES = (MARCH_F64, MARCH_F32, MARCH_F32_FMA)
+
+STEP_ALL, STEP_NOT_DUE, STEP_DUE = 0, 1, 2      # navsim_step_part
 
 ACTION_TWIST = 0       # io.action = (v, omega)
 ACTION_WHEELS = 1      # io.action = (omega_left, omega_right) of a skid-steer base, rad/s
@@ -147,6 +149,7 @@ class NavsimState(C.Structure):
         "ped_waypoints", "ped_n_waypoints", "ped_cmd",
         "spawn_pose", "spawn_goal", "costmap", "arena_cost", "launch_order", "regen_draws",
         "ped_goal", "counters", "rect_index",
+        "ped_wp_head", "ped_due", "ped_due_prev",
     )]
 
 
@@ -230,6 +233,9 @@ STATE_LAYOUT = {
     "ped_goal": ("float64", ("E", "N", 2)),         # goal of every pedestrian's current route
     "counters": ("int64", (N_COUNTERS,)),           # uint64 on the device; the totals stay far below 2^63
     "rect_index": ("uint8", ("E", "R")),            # index form of rect_table: 256 rectangles x 8 B + 2 B per tile, per arena
+    "ped_wp_head": ("int32", ("E", "N")),           # ABI 5: index of every pedestrian's current waypoint (the pop advances it)
+    "ped_due": ("int64", ("E",)),                   # uint64 on the device: bit i = pedestrian i waits for navsim_replan (written by the step)
+    "ped_due_prev": ("int64", ("E",)),              # the flags of the previous step (navsim_step_part)
 }
 
 IO_LAYOUT = {
@@ -328,6 +334,8 @@ def declare(lib, suffix=""):
     if not suffix:
         sig("navsim_prepare", [cfgp, stp, iop])
     sig("navsim_step", [cfgp, stp, iop] + stream)
+    if not suffix:
+        sig("navsim_step_part", [cfgp, stp, iop, i32, _P])
     sig("navsim_reset_obs", [cfgp, stp, iop, _P] + stream)
     return lib
 
@@ -343,7 +351,7 @@ EXPORTS = (
     "navsim_scan_threshold", "navsim_beam_table", "navsim_ped_scans", "navsim_regen_workspace_bytes", "navsim_regen", "navsim_regen_swap", "navsim_regen_stage",
     "navsim_costmap", "navsim_plan", "navsim_launch_order", "navsim_replan_workspace_bytes", "navsim_replan", "navsim_ped_policy_workspace_bytes", "navsim_ped_policy", "navsim_ped_scan_policy",
     "navsim_crowd_check", "navsim_crowd_angular_map", "navsim_crowd_local_map", "navsim_crowd_orca", "navsim_crowd_agent_step",
-    "navsim_step", "navsim_prepare", "navsim_reset_obs", "navsim_step_kernel_name",
+    "navsim_step", "navsim_step_part", "navsim_prepare", "navsim_reset_obs", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math", "navsim_debug_xy_to_ij",
     "navsim_debug_gather", "navsim_debug_set_stamps", "navsim_debug_spawn_decisions",
 )

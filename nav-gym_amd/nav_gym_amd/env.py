@@ -36,11 +36,43 @@ pedestrians beyond replan_cap, routes cut at max_waypoints) since the last call.
 num_envs == 1 returns NumPy float64 arrays with the reference's shapes; num_envs > 1 returns torch
 tensors on `device` (float32 observations).  Everything on the step() path runs in the HIP library;
 there is no CPU fallback.
+
+Lifetime of what step() returns (num_envs > 1): the observation dict, reward, done and info are views of device buffers
+the simulator keeps in PAIRS -- they stay intact through the next step() and are overwritten by the one after
+(`obs = next_obs`, `dones.append(done)` across one step are safe; keep a `.clone()` of anything needed longer).
+
+Pickling (env.py:30, 56-78: the reference is an EzPickle): `pickle.dumps(env)` stores the constructor's keyword
+arguments; the copy is a fresh environment that has not been reset().  `state_dict()` / `load_state_dict()` move the
+simulation state itself.  When `gym` is importable the class is a gym.Env (`unwrapped`, `spec`, `reward_range`).
 """
+import warnings
+
 import numpy as np
 
 from . import abi, robots, world
-from .registry import spaces
+from .registry import HAVE_GYM, spaces
+
+if HAVE_GYM:                                # the reference's base class (env.py:30), when the package is there
+    import gym as _gym
+    _EnvBase = _gym.Env
+else:
+    class _EnvBase(object):                 # what wrappers read of a gym.Env
+        reward_range = (-float("inf"), float("inf"))
+        spec = None
+
+        @property
+        def unwrapped(self):
+            return self
+
+        def seed(self, seed=None):
+            return [seed]
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *args):
+            self.close()
+            return False
 
 DEFAULT_KWARGS = {                       # nav_gym_env/__init__.py:6-38
     'robot_type': 'keti',
@@ -109,8 +141,15 @@ class _AgentView(object):
         return float(self._env.sim.t["robot_goal"][0, 1])
 
 
-class NavGymEnv(object):
+class NavGymEnv(_EnvBase):
     metadata = {"render.modes": ["human", "rgb_array"]}
+    _warned = set()                         # fallbacks are announced once per process
+
+    @classmethod
+    def _warn_once(cls, key, text):
+        if key not in cls._warned:
+            cls._warned.add(key)
+            warnings.warn(text, RuntimeWarning, stacklevel=3)
 
     def __init__(self, robot_type, time_step, min_turning_radius, distance_threshold, num_scan_stack,
                  linvel_range, rotvel_range, human_v_pref_range, human_has_legs_ratio, indoor_ratio,
@@ -124,6 +163,20 @@ class NavGymEnv(object):
         from . import lib
         if robot_type not in robots.ROBOTS:
             raise NotImplementedError(robot_type)            # env.py:772-773
+        # EzPickle (env.py:56-78): what the environment was made with is what a pickle of it carries
+        self._ctor_kwargs = dict(
+            robot_type=robot_type, time_step=time_step, min_turning_radius=min_turning_radius,
+            distance_threshold=distance_threshold, num_scan_stack=num_scan_stack, linvel_range=linvel_range,
+            rotvel_range=rotvel_range, human_v_pref_range=human_v_pref_range, human_has_legs_ratio=human_has_legs_ratio,
+            indoor_ratio=indoor_ratio, min_goal_dist=min_goal_dist, max_goal_dist=max_goal_dist, reward_scale=reward_scale,
+            reward_success_factor=reward_success_factor, reward_crash_factor=reward_crash_factor,
+            reward_progress_factor=reward_progress_factor, reward_forward_factor=reward_forward_factor,
+            reward_rotation_factor=reward_rotation_factor, reward_discomfort_factor=reward_discomfort_factor,
+            env_param_range=env_param_range, num_envs=num_envs, n_beams=n_beams, lidar=lidar, map_size=map_size,
+            pedestrian_model=pedestrian_model, policy_weights=policy_weights, num_humans=num_humans, device=device, seed=seed,
+            env_index_base=env_index_base, auto_reset=auto_reset, field_format=field_format, n_spawn=n_spawn,
+            randomize_maps=randomize_maps, plan_paths=plan_paths, action_kind=action_kind, clip_actions=clip_actions,
+            max_waypoints=max_waypoints, march_rule=march_rule, use_graphs=use_graphs)
         self.robot_type = robot_type
         self.time_step = time_step
         self.min_turning_radius = min_turning_radius
@@ -155,9 +208,16 @@ class NavGymEnv(object):
         self.replan_cap = 1024                              # pedestrians re-planned per step, at most
         self.use_graphs = bool(randomize_maps) if use_graphs is None else bool(use_graphs)
         self._graphed = False
+        self._overlap_replan = False
         self.plan_paths = bool(plan_paths) and int(map_size) <= 1000
+        if plan_paths and not self.plan_paths:
+            self._warn_once("plan_paths", "NavGymEnv: map_size %d > 1000: the planner's search lives in LDS (costmaps up to "
+                            "200 x 200 cells), plan_paths falls back to False -- pedestrians head straight for their goals"
+                            % int(map_size))
         if field_format == abi.FIELD_U16T and int(map_size) > 1024:
             field_format = abi.FIELD_F32     # beyond the rect records' and the packed regeneration's tested range
+            self._warn_once("field_format", "NavGymEnv: map_size %d > 1024: the packed uint16 distance field and its rect "
+                            "records are not used beyond 1024 cells per side, field_format falls back to FIELD_F32" % int(map_size))
         spec = robots.ROBOTS[robot_type]
         nh_hi = int(env_param_range["num_humans"][0][1]) if num_humans is None else int(num_humans)
         ped = {"none": abi.PED_NONE, "external": abi.PED_EXTERNAL, "sfm": abi.PED_SFM,
@@ -231,7 +291,7 @@ class NavGymEnv(object):
         self._bool = None
         self.robot = _AgentView(self, "robot")
         self.humans = []
-        self.map_info = None
+        self._map_info = None
         self.scan_threshold = None
         self.scan_discomfort_threshold = None
         if action_kind == "wheels":                   # wheel speeds that reach every corner of the twist box
@@ -307,19 +367,46 @@ class NavGymEnv(object):
             self.sim.t["policy_prev_actions"].zero_()           # env.py:739
         self._episode_batch += 1
         self.sim.regenerate_all(new_episode=not first)
+        # pedestrians on planned routes: navsim_replan overlaps the step (not with 'policy', whose control block runs in
+        # front of every step and reads the routes)
+        self._overlap_replan = ("costmap" in self.sim.t and self.sim.due is not None and self.pedestrian_model != "policy")
         if first and self.use_graphs and self.pedestrian_model != "policy":
             self.sim.enable_graphs(regen=self.randomize_maps and self.auto_reset,
                                    replan_cap=self.replan_cap if "costmap" in self.sim.t else 0)
             self._graphed = True
-        occ0 = self.sim.occupancy(0)
-        live = self.map_size
-        if self.outdoor_map_size and occ0[self.outdoor_map_size:, :].all() and occ0[:, self.outdoor_map_size:].all():
-            live = self.outdoor_map_size                  # arena 0 drew an outdoor map: the reference's 400 x 400 array
-        self.map_info = {"data": (occ0[:live, :live].astype(np.int8) * 100), "origin": (cfg.origin_x, cfg.origin_y),
-                         "resolution": cfg.resolution, "width": live, "height": live}
-        n0 = int(self.sim.t["n_peds"][0]) if "n_peds" in self.sim.t else 0
-        self.humans = [_AgentView(self, "human", i) for i in range(n0)]
+        self._map_info = None                             # read back from the device when somebody asks (map_info)
+        self._humans_of_episode = None
         return self._obs_dict()
+
+    @property
+    def map_info(self):
+        """Arena 0's map as RosEnv reads it (ros_env.py:69-81; env.py:297-310): built on first use after a reset() -- the
+        occupancy grid is read back from the device's distance field, which step() and reset() themselves never need
+        (round 4 copied it to the host in every reset())."""
+        if self.sim is None:
+            return None
+        if self._map_info is None:
+            cfg = self.cfg
+            occ0 = self.sim.occupancy(0)
+            live = self.map_size
+            if self.outdoor_map_size and occ0[self.outdoor_map_size:, :].all() and occ0[:, self.outdoor_map_size:].all():
+                live = self.outdoor_map_size              # arena 0 drew an outdoor map: the reference's 400 x 400 array
+            self._map_info = {"data": (occ0[:live, :live].astype(np.int8) * 100), "origin": (cfg.origin_x, cfg.origin_y),
+                              "resolution": cfg.resolution, "width": live, "height": live}
+        return self._map_info
+
+    @property
+    def humans(self):
+        """Views of arena 0's pedestrians (ros_env.py:120-176), as many as its current episode has."""
+        if self.sim is None or "n_peds" not in self.sim.t:
+            return []
+        if self._humans_of_episode is None:
+            self._humans_of_episode = [_AgentView(self, "human", i) for i in range(int(self.sim.t["n_peds"][0]))]
+        return self._humans_of_episode
+
+    @humans.setter
+    def humans(self, value):
+        self._humans_of_episode = list(value)
 
     def _obs_dict(self):
         # no kernel of its own: the observation rows and the two goal arrays are what the step (or navsim_regen's
@@ -342,6 +429,11 @@ class NavGymEnv(object):
         a = np.asarray(action, dtype=np.float64).reshape(self.num_envs, 2) if not hasattr(action, "is_cuda") else action
         if self._graphed:                                   # step + regen + replan: one graph launch (NavSim.enable_graphs)
             _, out = self.sim.step_graphed(a)
+        elif self._overlap_replan:
+            # planned routes: the re-plan of the previous step runs beside this step's launch (NavSim.launch_step_overlapped)
+            _, out = self.sim.step_overlapped(a, self.replan_cap)
+            if self.randomize_maps and self.auto_reset:
+                self.sim.regen()
         else:
             _, out = self.sim.step(a)                      # (a float64 tensor on the device is read in place: no copy)
             if self.pedestrian_model == "policy" and self.auto_reset:
@@ -350,7 +442,7 @@ class NavGymEnv(object):
             if self.randomize_maps and self.auto_reset:
                 self.sim.regen()
             if "costmap" in self.sim.t:
-                self.sim.replan(self.replan_cap)
+                self.sim.replan(self.replan_cap)           # ('policy': the control block in front of the next step reads the routes)
         obs = self._obs_dict()
         if self.num_envs == 1:
             info = {"is_success": np.float32(out["is_success"][0].item()),
@@ -462,3 +554,59 @@ class NavGymEnv(object):
 
     def close(self):
         self.sim = None
+
+    # ---- EzPickle (env.py:30, 56-78): a pickle carries the constructor's arguments, the copy is built from them -----------
+    def __getstate__(self):
+        return {"_ezpickle_kwargs": dict(self._ctor_kwargs)}
+
+    def __setstate__(self, d):
+        self.__init__(**d["_ezpickle_kwargs"])
+
+    def __reduce__(self):
+        return (_rebuild_env, (type(self), dict(self._ctor_kwargs)))
+
+    def state_dict(self):
+        """The simulation itself (every device array of the state, the observation / output buffers, their parity) as
+        host tensors: `load_state_dict` on an environment made with the same arguments and reset() once continues the
+        rollout bit for bit.  (Not part of the reference's API: its pickles carry the constructor arguments only.)"""
+        if self.sim is None:
+            raise RuntimeError("call reset() before state_dict()")
+        import torch
+        torch.cuda.synchronize(self.sim.device)
+        sd = {"t." + k: v.detach().cpu().clone() for k, v in self.sim.t.items() if not k.startswith(("replan_ws", "regen_ws", "policy_ws"))}
+        for i in (0, 1):
+            sd["obs.%d" % i] = self.sim.obs_buf[i].cpu().clone()
+            for k, v in self.sim.out_buf[i].items():
+                sd["out.%d.%s" % (i, k)] = v.cpu().clone()
+            if self.sim.due is not None:
+                sd["due.%d" % i] = self.sim.due[i].cpu().clone()
+        sd["cur"] = int(self.sim.cur)
+        sd["steps_launched"] = int(self.sim._steps_launched)
+        sd["episode_batch"] = int(self._episode_batch)
+        return sd
+
+    def load_state_dict(self, sd):
+        if self.sim is None:
+            raise RuntimeError("call reset() once before load_state_dict() (it allocates the device arrays)")
+        import torch
+        torch.cuda.synchronize(self.sim.device)
+        for k, v in sd.items():
+            if k.startswith("t."):
+                self.sim.t[k[2:]].copy_(v)
+        for i in (0, 1):
+            self.sim.obs_buf[i].copy_(sd["obs.%d" % i])
+            for k, v in self.sim.out_buf[i].items():
+                v.copy_(sd["out.%d.%s" % (i, k)])
+            if self.sim.due is not None:
+                self.sim.due[i].copy_(sd["due.%d" % i])
+        self.sim.cur = int(sd["cur"])
+        self.sim._steps_launched = int(sd["steps_launched"])
+        self._episode_batch = int(sd["episode_batch"])
+        self._map_info = None
+        self._humans_of_episode = None
+        torch.cuda.synchronize(self.sim.device)
+        self._obs_dict()
+
+
+def _rebuild_env(cls, kwargs):
+    return cls(**kwargs)

@@ -371,6 +371,17 @@ class NavSim(object):
                 raise ValueError("%s: shape %s, expected %s" % (name, tuple(t.shape), want))
             self.t[name] = t
             setattr(self.st, name, t.data_ptr())
+        self.due = None
+        if "ped_waypoints" in self.t:
+            # ABI 5: the index of every pedestrian's current waypoint (a route starts at its first one), and the two buffers
+            # of "waits for navsim_replan" flags the step writes / navsim_step_part reads.  The flags of the LATEST step
+            # live in due[self.cur] -- they flip with the observation buffers (_flip)
+            if "ped_wp_head" not in self.t:
+                self.t["ped_wp_head"] = torch.zeros((self.cfg.n_envs, self.cfg.max_peds), dtype=torch.int32, device=self.device)
+                self.st.ped_wp_head = self.t["ped_wp_head"].data_ptr()
+            self.due = [torch.zeros(self.cfg.n_envs, dtype=torch.int64, device=self.device) for _ in range(2)]
+            self.st.ped_due = self.due[0].data_ptr()
+            self.st.ped_due_prev = self.due[1].data_ptr()
         if "counters" not in self.t:                            # what the library's caps left unserved (include/navsim.h)
             self.t["counters"] = torch.zeros(abi.N_COUNTERS, dtype=torch.int64, device=self.device)
             self.st.counters = self.t["counters"].data_ptr()
@@ -400,24 +411,47 @@ class NavSim(object):
         D = self.cfg.n_scan_stack * self.cfg.n_beams + abi.OBS_TAIL
         self.obs_buf = [torch.zeros((E, D), dtype=torch.float32, device=self.device) for _ in range(2)]
         self.cur = 0
-        self.out = {k: torch.zeros(abi.resolve_shape(s, self.cfg), dtype=_dtype(d), device=self.device)
-                    for k, (d, s) in abi.IO_LAYOUT.items() if k not in ("obs", "obs_prev", "action")}
+        # what step() returns beside the observation (reward, done, info, the two goal arrays): two sets, flipped with the
+        # observation buffers, so that the arrays a step returned stay intact through the NEXT step (round-4 advisor: the
+        # env handed out views of single buffers that the next step overwrote -- `obs = next_obs`, `dones.append(done)`)
+        self.out_buf = [{k: torch.zeros(abi.resolve_shape(s, self.cfg), dtype=_dtype(d), device=self.device)
+                         for k, (d, s) in abi.IO_LAYOUT.items() if k not in ("obs", "obs_prev", "action")} for _ in range(2)]
         self.action = torch.zeros((E, 2), dtype=torch.float64, device=self.device)
         self.io = abi.NavsimStepIO()
         self.io.action = self.action.data_ptr()
-        for k, v in self.out.items():
+        for k, v in self.out_buf[0].items():
             setattr(self.io, k, v.data_ptr())
 
     @property
     def obs(self):
         return self.obs_buf[self.cur]
 
+    @property
+    def out(self):
+        """reward / done / is_success / is_crash / distance / achieved_goal / desired_goal of the latest step."""
+        return self.out_buf[self.cur]
+
     def _flip(self):
         self.io.obs_prev = self.obs_buf[self.cur].data_ptr()
         self.io.obs = self.obs_buf[1 - self.cur].data_ptr()
+        for k, v in self.out_buf[1 - self.cur].items():
+            setattr(self.io, k, v.data_ptr())
+        if self.due is not None:                    # the launch reads the latest flags and writes the other buffer
+            self.st.ped_due_prev = self.due[self.cur].data_ptr()
+            self.st.ped_due = self.due[1 - self.cur].data_ptr()
+
+    def _latest_flags(self):
+        """st.ped_due -> the flags the latest step wrote (due[self.cur]): what navsim_replan / navsim_regen read and clear.
+        (True after every step by construction; enable_graphs captures both parities from one state.)"""
+        if self.due is not None:
+            self.st.ped_due = self.due[self.cur].data_ptr()
+            self.st.ped_due_prev = self.due[1 - self.cur].data_ptr()
 
     def reset_obs(self, mask=None):
         """First observation of an episode (reference reset(), env.py:808-831) for masked envs."""
+        # a reset-only launch writes the goal arrays of the arenas it resets and nothing else: the other set starts as a copy
+        for k, v in self.out_buf[1 - self.cur].items():
+            v.copy_(self.out_buf[self.cur][k])
         self._flip()
         m = None
         if mask is not None:
@@ -425,6 +459,8 @@ class NavSim(object):
             m = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
         check(self.lib.navsim_reset_obs(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), _ptr(m), _stream()),
               "navsim_reset_obs")
+        if self.due is not None:                    # a reset-only launch advances nobody: the latest flags stay the latest
+            self.due[1 - self.cur].copy_(self.due[self.cur])
         self.cur = 1 - self.cur
         return self.obs
 
@@ -456,7 +492,7 @@ class NavSim(object):
     # arrays navsim_regen writes: the staged state of enable_pregen() owns a copy of each
     STAGED = ("field", "field_overflow", "rect_table", "rect_index", "costmap", "scan_noise_std", "robot_pose", "robot_goal", "prev_action",
               "prev_pose", "n_hist", "steps", "episode", "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist",
-              "ped_v_pref", "ped_has_legs", "ped_waypoints", "ped_n_waypoints", "ped_goal", "spawn_pose", "spawn_goal")
+              "ped_v_pref", "ped_has_legs", "ped_waypoints", "ped_n_waypoints", "ped_wp_head", "ped_goal", "spawn_pose", "spawn_goal")
 
     def enable_pregen(self, scratch_bytes=4 << 30):
         """navsim_regen off the step's critical path (include/navsim.h navsim_regen_swap): the world every arena will
@@ -477,6 +513,8 @@ class NavSim(object):
         self.stage_st.arena_cost = None
         self.stage_st.launch_order = None
         self.stage_st.counters = None          # staging ahead serves nobody yet: navsim_regen_swap counts the installs
+        self.stage_st.ped_due = None           # the live arenas' flags: navsim_regen_swap clears them at the install
+        self.stage_st.ped_due_prev = None
         self.stage_obs = torch.zeros_like(self.obs_buf[0])
         self.want = torch.ones(E, dtype=torch.uint8, device=self.device)
         self.mark = torch.zeros(E, dtype=torch.uint8, device=self.device)
@@ -511,6 +549,7 @@ class NavSim(object):
         import torch
         main = torch.cuda.current_stream()
         main.wait_event(self.ev_staged)                 # the staging pass that served the arenas of the last swap
+        self._latest_flags()
         io = abi.NavsimStepIO()
         C.memmove(C.byref(io), C.byref(self.io), C.sizeof(io))
         io.obs = self.obs_buf[self.cur].data_ptr()
@@ -537,6 +576,7 @@ class NavSim(object):
         io = abi.NavsimStepIO()
         C.memmove(C.byref(io), C.byref(self.io), C.sizeof(io))
         io.obs = self.obs_buf[self.cur].data_ptr()
+        self._latest_flags()
         ws = self.t["regen_ws"]
         check(self.lib.navsim_regen(C.byref(self.cfg), C.byref(self.st), C.byref(io), _ptr(ws), ws.numel(), _stream()),
               "navsim_regen")
@@ -551,6 +591,7 @@ class NavSim(object):
         must not reproduce the maps of the first)."""
         import torch
         E = self.cfg.n_envs
+        self._latest_flags()
         if new_episode:
             self.t["episode"] += 1
         cfg = self.cfg.copy()
@@ -594,17 +635,82 @@ class NavSim(object):
         tiles = blob.reshape(tpc, tpr, 8, 8).transpose(0, 2, 1, 3).reshape(tpc * 8, tpr * 8)
         return (tiles[:H, :W] == 0).astype(np.uint8)
 
-    def replan(self, max_queries=1024):
+    def replan(self, max_queries=1024, flags=True):
         """navsim_replan (env.py:667-680): pedestrians standing on their final waypoint get a new goal and
-        the waypoints of a planned path.  Needs the resident costmap (world.make_world(plan_paths=True))."""
+        the waypoints of a planned path.  Needs the resident costmap (world.make_world(plan_paths=True)).
+        flags=True: the candidates are the pedestrians the last step flagged (navsim_state.ped_due); False: the call
+        finds them by its own pass over the state (after the caller moved pedestrians by hand)."""
         import torch
         key = "replan_ws_%d" % max_queries
         if key not in self.t:
             nbytes = self.lib.navsim_replan_workspace_bytes(C.byref(self.cfg), max_queries)
             self.t[key] = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         ws = self.t[key]
-        check(self.lib.navsim_replan(C.byref(self.cfg), C.byref(self.st), max_queries, _ptr(ws), ws.numel(), _stream()),
+        self._latest_flags()
+        st = self.st
+        if not flags:
+            st = abi.NavsimState()
+            C.memmove(C.byref(st), C.byref(self.st), C.sizeof(st))
+            st.ped_due = None
+        check(self.lib.navsim_replan(C.byref(self.cfg), C.byref(st), max_queries, _ptr(ws), ws.numel(), _stream()),
               "navsim_replan")
+
+    # ---- navsim_replan beside the step (round 5).  env.py:667-680 plans a new route inside step() for the pedestrian that
+    # reached its goal; here that is one breadth-first search per arrived pedestrian (~2 % of the arenas per step), a chain of
+    # dependent levels that used to sit serially behind every step (c3 world through the gym API: 166 us of step + 98 us of
+    # re-plan).  The arenas WITHOUT a waiting pedestrian do not need its result: navsim_step_part steps them on the caller's
+    # stream while a side stream runs the re-plan of the previous step and then steps the arenas that waited for it.
+    # Same kernels on the same per-arena inputs in the same per-arena order -- step(t), replan(t), step(t + 1) -- so every
+    # result is what the serial sequence gives.
+    def _overlap_streams(self):
+        import torch
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream(device=self.device, priority=-1)    # few, small workgroups: first in line for free slots
+        return torch.cuda.current_stream(self.device), self._side
+
+    def launch_step_overlapped(self, replan_cap=1024, reorder=True):
+        """[navsim_replan of the PREVIOUS step's flags -> navsim_step_part(DUE)] on a side stream beside
+        navsim_step_part(NOT_DUE) on the current stream, joined at the end.  Needs the costmap (planned routes)."""
+        import torch
+        main, side = self._overlap_streams()
+        key = "replan_ws_%d" % replan_cap
+        if key not in self.t:
+            self.t[key] = torch.zeros(self.lib.navsim_replan_workspace_bytes(C.byref(self.cfg), replan_cap), dtype=torch.uint8,
+                                      device=self.device)
+        ws = self.t[key]
+        if reorder:
+            self._reorder()
+        side.wait_stream(main)                      # the previous step (both parts were joined on `main`), regen, the actions
+        # the re-plan reads st.ped_due = the flags the previous step wrote: launched BEFORE the buffers flip
+        self._latest_flags()
+        rc = self.lib.navsim_replan(C.byref(self.cfg), C.byref(self.st), replan_cap, _ptr(ws), ws.numel(), C.c_void_p(side.cuda_stream))
+        if rc:
+            check(rc, "navsim_replan")
+        self._flip()
+        rc = self.lib.navsim_step_part(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), abi.STEP_NOT_DUE, C.c_void_p(main.cuda_stream))
+        if rc:
+            check(rc, "navsim_step_part (not due)")
+        rc = self.lib.navsim_step_part(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), abi.STEP_DUE, C.c_void_p(side.cuda_stream))
+        if rc:
+            check(rc, "navsim_step_part (due)")
+        main.wait_stream(side)
+        self.cur = 1 - self.cur
+
+    def step_overlapped(self, action=None, replan_cap=1024):
+        """step() of a world with planned pedestrian routes: replan (of the previous step) + step, overlapped
+        (launch_step_overlapped).  The sequence of calls  step_overlapped, step_overlapped, ...  equals
+        step, replan, step, replan, ...  shifted by one replan: finish a rollout with replan() to leave the same state."""
+        if action is not None:
+            import torch
+            if (isinstance(action, torch.Tensor) and action.is_cuda and action.dtype == torch.float64 and action.is_contiguous()
+                    and action.device == self.device and action.numel() == self.action.numel()):
+                self.io.action = action.data_ptr()
+                self._action_ref = action
+            else:
+                self.action.copy_(self._as(action, self.action))
+                self.io.action = self.action.data_ptr()
+        self.launch_step_overlapped(replan_cap)
+        return self.obs, self.out
 
     def set_policy(self, weights):
         """HumanPolicy actor weights: dict of arrays / tensors named like abi.POLICY_FIELDS, or a reference
@@ -653,11 +759,14 @@ class NavSim(object):
 
     # ---- hipGraph replay of a whole step (round 4).  A step of a world that draws new maps is four or five launches
     # (navsim_step, navsim_regen's three, navsim_replan's three) whose gaps are launch-bound: c5 4.77 -> 5.08 M env-steps/s.
-    def enable_graphs(self, regen=False, replan_cap=0):
-        """Capture [navsim_step, navsim_regen (regen=True), navsim_replan (replan_cap > 0)] once per observation-buffer
-        parity and replay it in step_graphed().  Actions go through the simulator's own action buffer (a graph's
+    def enable_graphs(self, regen=False, replan_cap=0, overlap=True):
+        """Capture a whole step once per observation-buffer parity and replay it in step_graphed():
+        [navsim_step, navsim_regen (regen=True)], and with replan_cap > 0 the re-plan -- overlap=True (default): the re-plan
+        of the PREVIOUS step beside this step's launch (launch_step_overlapped: a fork and a join inside the graph), False:
+        navsim_replan behind the step as in round 4.  Actions go through the simulator's own action buffer (a graph's
         arguments are frozen), the longest-first launch order is not re-sorted (graphs are for the launches of one
-        generation, where it does not matter).  Same kernels, same arguments, same order: same results."""
+        generation, where it does not matter).  Same kernels, same arguments, same per-arena order: same results.
+        The configuration is captured BY VALUE: step_graphed() re-captures when self.cfg has changed since."""
         import torch
         if getattr(self, "pregen", False):
             raise ValueError("enable_graphs and enable_pregen are alternatives")
@@ -674,23 +783,35 @@ class NavSim(object):
                 self.t[key] = torch.zeros(self.lib.navsim_replan_workspace_bytes(C.byref(self.cfg), replan_cap), dtype=torch.uint8,
                                           device=self.device)
         self.io.action = self.action.data_ptr()
+        self._graph_args = (bool(regen), int(replan_cap), bool(overlap))
+        overlap = bool(overlap) and replan_cap > 0
+        if overlap:
+            self._overlap_streams()
         torch.cuda.synchronize(self.device)
         cur0, self._graphs = self.cur, {}
         for p in (0, 1):
             self.cur = p
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self.launch_step(reorder=False)
+                if overlap:
+                    self.launch_step_overlapped(replan_cap, reorder=False)
+                else:
+                    self.launch_step(reorder=False)
                 if regen:
                     self.regen()
-                if replan_cap:
+                if replan_cap and not overlap:
                     self.replan(replan_cap)
             self._graphs[p] = g
         self.cur = cur0
+        # a captured launch holds navsim_config BY VALUE (round-4 advisor: _override_reward_factor after the capture changed
+        # compute_rewards() but not the step): remember what was captured, step_graphed() compares
+        self._graph_cfg = bytes(self.cfg)
         torch.cuda.synchronize(self.device)
 
     def step_graphed(self, action=None):
         """step() (+ regen + replan, as captured by enable_graphs) as ONE graph launch."""
+        if bytes(self.cfg) != self._graph_cfg:      # the configuration changed since the capture: capture again
+            self.enable_graphs(*self._graph_args)
         if action is not None:
             self.action.copy_(self._as(action, self.action))
         self._graphs[self.cur].replay()
@@ -718,4 +839,8 @@ class NavSim(object):
         return a.to(device=self.device, dtype=like.dtype).reshape(like.shape)
 
     def numpy_state(self, *names):
-        return {n: self.t[n].detach().cpu().numpy() for n in (names or self.t.keys())}
+        """State arrays on the host.  "ped_due": the latest step's "waits for navsim_replan" flags (they flip, so not in t)."""
+        out = {n: self.t[n].detach().cpu().numpy() for n in (names or self.t.keys()) if n != "ped_due"}
+        if self.due is not None and (not names or "ped_due" in names):
+            out["ped_due"] = self.due[self.cur].detach().cpu().numpy()
+        return out

@@ -250,6 +250,7 @@ def make_world(cfg, occ, seed=None, n_peds=0, min_goal_dist=10.0, max_goal_dist=
             nwp = torch.where(found, pn.reshape(E, N), nwp)
         a["ped_waypoints"] = wp.contiguous()
         a["ped_n_waypoints"] = nwp.contiguous()
+        a["ped_wp_head"] = torch.zeros((E, N), dtype=torch.int32, device=dev)     # every route starts at its first waypoint
         a["ped_goal"] = pgoal.contiguous()          # a route stored cut is continued to this goal (navsim_replan)
         a["ped_cmd"] = torch.zeros((E, N, 2), dtype=torch.float64, device=dev)
     return a
@@ -297,6 +298,7 @@ def empty_world(cfg, device="cuda:0", plan_paths=False, rect_table=False):
         a["ped_has_legs"] = z((E, N), torch.uint8)
         a["ped_waypoints"] = z((E, N, cfg.max_waypoints, 2), torch.float64)
         a["ped_n_waypoints"] = torch.ones((E, N), dtype=torch.int32, device=dev)
+        a["ped_wp_head"] = z((E, N), torch.int32)
         a["ped_goal"] = z((E, N, 2), torch.float64)
         a["ped_cmd"] = z((E, N, 2), torch.float64)
     return a

@@ -10,6 +10,7 @@
 #include "navmath_ref.h"
 
 #include <float.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -764,6 +765,17 @@ int navsim_reward_done_cpu(const navsim_config* c, const void* obs, const void* 
  * are missing).  Follows the public pedsim model named by BASELINE.json's north_star; force names
  * as in third_party/pedsim_msgs/msg/AgentForce.msg:3-6.
  * ======================================================================================= */
+/* waypoint pop (env.py:633-642): the reference pops reached waypoints off the front of a Python list; the list here stays
+ * as its planner stored it and the index of the current waypoint advances (navsim_state.ped_wp_head, ABI 5).
+ * wp = the pedestrian's row, nw = waypoints stored. */
+static void pop_waypoints(const double* wp, int32_t* head, int nw, const double* pp) {
+    while (*head + 1 < nw) {
+        double ddx = pp[0] - wp[2 * *head], ddy = pp[1] - wp[2 * *head + 1];
+        if (sqrt(ddx * ddx + ddy * ddy) < 1.0) *head += 1;
+        else break;
+    }
+}
+
 static void sfm_update(const navsim_config* c, const navsim_state* st, int e, int n,
                        const double* robot_pose, const double* robot_prev_action) {
     const int N = c->max_peds, H = c->map_h, W = c->map_w, P = c->max_waypoints;
@@ -783,7 +795,7 @@ static void sfm_update(const navsim_config* c, const navsim_state* st, int e, in
     }
     double nvx[NAVSIM_MAX_PEDS], nvy[NAVSIM_MAX_PEDS];
     for (int i = 0; i < n; ++i) {
-        const double* wp = st->ped_waypoints + (((size_t)e * N + i) * P) * 2;
+        const double* wp = st->ped_waypoints + (((size_t)e * N + i) * P + (size_t)st->ped_wp_head[(size_t)e * N + i]) * 2;   /* the current waypoint */
         double vpref = st->ped_v_pref[(size_t)e * N + i];
         /* desired force */
         double ex = wp[0] - ax[i], ey = wp[1] - ay[i];
@@ -912,15 +924,8 @@ static void step_env(const navsim_config* c, const navsim_state* st, const navsi
     /* ---- pedestrians: waypoint pop (env.py:633-642), control + integration (env.py:650-662) */
     for (int i = 0; i < n; ++i) {
         double* pp = st->ped_pose + ((size_t)e * N + i) * 3;
-        double* wp = st->ped_waypoints + (((size_t)e * N + i) * P) * 2;
-        int* nw = st->ped_n_waypoints + (size_t)e * N + i;
-        while (*nw > 1) {
-            double ddx = pp[0] - wp[0], ddy = pp[1] - wp[1];
-            if (sqrt(ddx * ddx + ddy * ddy) < 1.0) {
-                for (int k = 0; k + 1 < *nw; ++k) { wp[2 * k] = wp[2 * k + 2]; wp[2 * k + 1] = wp[2 * k + 3]; }
-                *nw -= 1;
-            } else break;
-        }
+        const double* wp = st->ped_waypoints + (((size_t)e * N + i) * P) * 2;
+        pop_waypoints(wp, st->ped_wp_head + (size_t)e * N + i, st->ped_n_waypoints[(size_t)e * N + i], pp);
     }
     if (n > 0 && c->ped_model == NAVSIM_PED_EXTERNAL) {
         for (int i = 0; i < n; ++i) {
@@ -938,12 +943,15 @@ static void step_env(const navsim_config* c, const navsim_state* st, const navsi
     /* ---- pedestrians at their final waypoint take a new goal (env.py:667-680).  With a resident
      * costmap the pedestrian waits for navsim_replan_cpu, which plans like the reference; without one
      * it draws a goal >= 10 m away from the env's spawn table and heads straight for it. */
+    unsigned long long due = 0;                   /* navsim_state.ped_due: who stands on its final waypoint after this update */
     for (int i = 0; i < n; ++i) {
         double* pp = st->ped_pose + ((size_t)e * N + i) * 3;
         double* wp = st->ped_waypoints + (((size_t)e * N + i) * P) * 2;
         int* nw = st->ped_n_waypoints + (size_t)e * N + i;
         double ddx = pp[0] - wp[2 * (*nw - 1)], ddy = pp[1] - wp[2 * (*nw - 1) + 1];
-        if (sqrt(ddx * ddx + ddy * ddy) < 0.5 && c->n_spawn > 0 && st->spawn_pose && !st->costmap) {
+        const int at_final = sqrt(ddx * ddx + ddy * ddy) < 0.5;
+        if (at_final) due |= 1ull << i;
+        if (at_final && c->n_spawn > 0 && st->spawn_pose && !st->costmap) {
             uint64_t h = nvr_hash4(c->seed, genv, (uint64_t)i + 1000, (uint64_t)st->steps[e]);
             for (int tries = 0; tries < c->n_spawn; ++tries) {
                 int idx = (int)((h + (uint64_t)tries) % (uint64_t)c->n_spawn);
@@ -951,12 +959,14 @@ static void step_env(const navsim_config* c, const navsim_state* st, const navsi
                 double gx = cand[0] - pp[0], gy = cand[1] - pp[1];
                 if (sqrt(gx * gx + gy * gy) > 10.0) {
                     wp[0] = cand[0]; wp[1] = cand[1]; *nw = 1;
+                    st->ped_wp_head[(size_t)e * N + i] = 0;
                     if (st->ped_goal) { st->ped_goal[((size_t)e * N + i) * 2] = cand[0]; st->ped_goal[((size_t)e * N + i) * 2 + 1] = cand[1]; }
                     break;
                 }
             }
         }
     }
+    if (st->ped_due && c->ped_model != NAVSIM_PED_NONE) st->ped_due[e] = due;
 
     /* ---- leg odometry (env.py:683), then the pedestrian's obs yaw is refreshed (env.py:685-693;
      * the per-pedestrian 512-beam scans only feed HumanPolicy and are not produced: DESIGN.md) */
@@ -1030,6 +1040,63 @@ int navsim_step_range_cpu(const navsim_config* c, const navsim_state* st, const 
 int navsim_step_cpu(const navsim_config* c, const navsim_state* st, const navsim_step_io* io) {
     if (!c) return NAVSIM_E_ARG;
     return navsim_step_range_cpu(c, st, io, 0, c->n_envs);
+}
+
+/* The CPU baseline's own loop ("all host cores with envs split statically across threads"; round-4 verdict:
+ * the Python thread pool around navsim_step_range_cpu spent its time dispatching -- 5 % parallel efficiency on 256 threads).
+ * n_steps steps of every arena on n_threads POSIX threads: thread t owns the arenas [E t / n, E (t + 1) / n) for the whole
+ * run and never waits for another thread -- arenas are independent (env.py:80-131: all state is one env's), so there is no
+ * barrier between steps.  actions [n_steps, E, 2]; obs_a holds the current observations and receives those of even-numbered
+ * runs (step s reads one buffer and writes the other: n_steps even -> the final rows are in obs_a again); io supplies the
+ * output arrays.  Same arithmetic as navsim_step_cpu, arena by arena. */
+typedef struct {
+    const navsim_config* c; const navsim_state* st; navsim_step_io io; const double* actions;
+    float* obs[2]; int32_t e0, e1, n_steps; int rc;
+} step_job;
+
+static void* step_worker(void* arg) {
+    step_job* j = (step_job*)arg;
+    const size_t E = (size_t)j->c->n_envs;
+    float* scan = (float*)malloc(sizeof(float) * (size_t)j->c->n_beams);
+    for (int32_t s = 0; s < j->n_steps; ++s) {
+        navsim_step_io io = j->io;
+        io.action = j->actions + (size_t)s * E * 2;
+        io.obs_prev = j->obs[s & 1];
+        io.obs = j->obs[1 - (s & 1)];
+        for (int e = j->e0; e < j->e1; ++e) step_env(j->c, j->st, &io, e, scan);
+    }
+    free(scan);
+    j->rc = NAVSIM_OK;
+    return NULL;
+}
+
+int navsim_step_threads_cpu(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, const double* actions,
+                            float* obs_a, float* obs_b, int32_t n_threads, int32_t n_steps) {
+    if (!c || !st || !io || !actions || !obs_a || !obs_b || n_threads < 1 || n_steps < 0) return NAVSIM_E_ARG;
+    navsim_step_io probe = *io;
+    probe.action = actions; probe.obs = obs_b; probe.obs_prev = obs_a;
+    int rc = navsim_step_range_cpu(c, st, &probe, 0, 0);               /* the argument checks, no arena stepped */
+    if (rc != NAVSIM_OK) return rc;
+    if (n_threads > c->n_envs) n_threads = c->n_envs > 0 ? c->n_envs : 1;
+    step_job* jobs = (step_job*)calloc((size_t)n_threads, sizeof(step_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
+    for (int t = 0; t < n_threads; ++t) {
+        jobs[t].c = c; jobs[t].st = st; jobs[t].io = *io; jobs[t].actions = actions;
+        jobs[t].obs[0] = obs_a; jobs[t].obs[1] = obs_b; jobs[t].n_steps = n_steps;
+        jobs[t].e0 = (int32_t)((long long)c->n_envs * t / n_threads);
+        jobs[t].e1 = (int32_t)((long long)c->n_envs * (t + 1) / n_threads);
+        jobs[t].rc = NAVSIM_E_ARG;
+    }
+    int started = 0;
+    for (int t = 1; t < n_threads; ++t, ++started)
+        if (pthread_create(&th[t], NULL, step_worker, &jobs[t]) != 0) break;
+    step_worker(&jobs[0]);                                              /* the calling thread takes the first share */
+    for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
+    for (int t = started + 1; t < n_threads; ++t) step_worker(&jobs[t]);  /* a thread that could not be created: run its share here */
+    rc = NAVSIM_OK;
+    for (int t = 0; t < n_threads; ++t) if (jobs[t].rc != NAVSIM_OK) rc = jobs[t].rc;
+    free(jobs); free(th);
+    return rc;
 }
 
 /* first observation after reset() (env.py:808-831) */
@@ -1309,8 +1376,10 @@ static void regen_planned(const navsim_config* c, const navsim_state* st, int e,
             if (total > P && st->counters) st->counters[NAVSIM_COUNTER_ROUTES_CUT] += 1;
             if (nwp > 0) { st->ped_n_waypoints[q] = nwp; done = 1; }
             else { w[0] = g[0]; w[1] = g[1]; st->ped_n_waypoints[q] = 1; }
+            st->ped_wp_head[q] = 0;
         }
     }
+    if (st->ped_due) st->ped_due[e] = 0;
     free(cost);
 }
 
@@ -1387,7 +1456,7 @@ static void policy_actor(const navsim_policy_weights* w, const float x[512], con
 int navsim_ped_policy_cpu(const navsim_config* c, const navsim_state* st, const navsim_policy_weights* w,
                           const float* ped_scans, float* prev_actions, double* ped_cmd) {
     if (!c || !st || !w || !ped_scans || !prev_actions || !ped_cmd || !st->ped_pose || !st->ped_waypoints ||
-        !st->ped_n_waypoints || !st->ped_v_pref || !st->n_peds)
+        !st->ped_n_waypoints || !st->ped_wp_head || !st->ped_v_pref || !st->n_peds)
         return NAVSIM_E_ARG;
     if (c->ped_n_beams != 512) return NAVSIM_E_UNSUPPORTED;
     const int N = c->max_peds, P = c->max_waypoints;
@@ -1397,16 +1466,9 @@ int navsim_ped_policy_cpu(const navsim_config* c, const navsim_state* st, const 
             size_t q = (size_t)e * N + i;
             if (i >= n) { ped_cmd[2 * q] = 0.0; ped_cmd[2 * q + 1] = 0.0; continue; }
             const double* pp = st->ped_pose + q * 3;
-            double* wp = st->ped_waypoints + (q * P) * 2;
-            int nw = st->ped_n_waypoints[q];
-            while (nw > 1) {                                                  /* env.py:633-640 */
-                double ddx = pp[0] - wp[0], ddy = pp[1] - wp[1];
-                if (sqrt(ddx * ddx + ddy * ddy) < 1.0) {
-                    for (int k = 0; k + 1 < nw; ++k) { wp[2 * k] = wp[2 * k + 2]; wp[2 * k + 1] = wp[2 * k + 3]; }
-                    nw -= 1;
-                } else break;
-            }
-            st->ped_n_waypoints[q] = nw;
+            const double* wp = st->ped_waypoints + (q * P) * 2;
+            pop_waypoints(wp, st->ped_wp_head + q, st->ped_n_waypoints[q], pp);    /* env.py:633-640 */
+            wp += 2 * (size_t)st->ped_wp_head[q];
             double s, cs;
             nvr_sincos(pp[2], &s, &cs);                                       /* env.py:644-645 */
             double gx = wp[0] - pp[0], gy = wp[1] - pp[1];
@@ -1432,8 +1494,8 @@ int navsim_ped_policy_cpu(const navsim_config* c, const navsim_state* st, const 
 
 /* env.py:667-680 (see include/navsim.h navsim_replan) */
 int navsim_replan_cpu(const navsim_config* c, const navsim_state* st, int32_t max_queries) {
-    if (!c || !st || !st->costmap || !st->ped_pose || !st->ped_waypoints || !st->ped_n_waypoints || !st->n_peds ||
-        max_queries < 0)
+    if (!c || !st || !st->costmap || !st->ped_pose || !st->ped_waypoints || !st->ped_n_waypoints || !st->ped_wp_head ||
+        !st->n_peds || max_queries < 0)
         return NAVSIM_E_ARG;
     if (c->ped_model == NAVSIM_PED_NONE) return NAVSIM_OK;
     if (c->max_waypoints < 1 || c->max_waypoints > NAVSIM_MAX_WAYPOINTS) return NAVSIM_E_ARG;
@@ -1475,6 +1537,7 @@ int navsim_replan_cpu(const navsim_config* c, const navsim_state* st, int32_t ma
                 if (nwp > 0) {
                     memcpy(w, wp, sizeof(double) * 2 * (size_t)nwp);
                     st->ped_n_waypoints[q] = nwp;
+                    st->ped_wp_head[q] = 0;
                     if (pg) { pg[0] = g[0]; pg[1] = g[1]; }
                     if (round < 0 && st->counters) st->counters[NAVSIM_COUNTER_ROUTES_RESUMED] += 1;
                     break;
@@ -1567,8 +1630,10 @@ int navsim_regen_cpu(const navsim_config* c, const navsim_state* st, const navsi
             double* wp = st->ped_waypoints + (q * P) * 2;
             wp[0] = gx; wp[1] = gy;
             st->ped_n_waypoints[q] = 1;
+            st->ped_wp_head[q] = 0;
             if (st->ped_goal) { st->ped_goal[q * 2] = gx; st->ped_goal[q * 2 + 1] = gy; }
         }
+        if (st->ped_due) st->ped_due[e] = 0;
     }
     /* first observation of the new episodes (env.py:808-831); other arenas keep the row the step wrote.
      * cfg.defer_reset_scan: also of the arenas beyond the cap, which navsim_step restarted in place without scanning */

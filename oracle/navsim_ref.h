@@ -88,6 +88,12 @@ int navsim_step_cpu(const navsim_config* cfg, const navsim_state* st, const navs
 int navsim_step_range_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                           int32_t e0, int32_t e1);
 
+/* CPU baseline: n_steps steps of every arena on n_threads POSIX threads, arenas split statically, no barrier between steps
+ * (arenas are independent).  actions [n_steps, E, 2]; obs_a = current observations, obs_b = the second buffer (step s reads
+ * one and writes the other); io = the output arrays.  See navsim_ref.c. */
+int navsim_step_threads_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io, const double* actions,
+                            float* obs_a, float* obs_b, int32_t n_threads, int32_t n_steps);
+
 int navsim_reset_obs_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                          const uint8_t* mask);
 

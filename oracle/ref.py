@@ -360,6 +360,14 @@ class RefSim(object):
                 raise ValueError("%s: shape %s, expected %s" % (name, arr.shape, want))
             self.a[name] = arr
             setattr(self.st, name, arr.ctypes.data)
+        if "ped_waypoints" in self.a:               # like NavSim: ABI 5's waypoint heads (routes start at their first
+            E_, N_ = self.cfg.n_envs, self.cfg.max_peds  # waypoint) and the step's "waits for navsim_replan" flags
+            if "ped_wp_head" not in self.a:
+                self.a["ped_wp_head"] = np.zeros((E_, N_), np.int32)
+                self.st.ped_wp_head = self.a["ped_wp_head"].ctypes.data
+            if "ped_due" not in self.a:
+                self.a["ped_due"] = np.zeros(E_, np.int64)
+                self.st.ped_due = self.a["ped_due"].ctypes.data
         if "counters" not in self.a:                # like NavSim: what the caps left unserved (include/navsim.h)
             self.a["counters"] = np.zeros(abi.N_COUNTERS, np.int64)
             self.st.counters = self.a["counters"].ctypes.data
@@ -432,6 +440,21 @@ class RefSim(object):
         else:
             _chk(lib().navsim_step_range_cpu(C.byref(self.cfg), C.byref(self.st), C.byref(io), e0, e1), "step_range")
         self.cur = 1 - self.cur
+        return self.obs[self.cur], self.out
+
+    def step_native_threads(self, actions, n_threads):
+        """navsim_step_threads_cpu: len(actions) steps of every arena on n_threads POSIX threads inside the library (static
+        split of the arenas, no barrier between steps, no Python in the loop).  actions [n_steps, E, 2].  The CPU baseline
+        of bench.py; same results as len(actions) calls of step()."""
+        a = np.ascontiguousarray(actions, dtype=np.float64).reshape(-1, self.cfg.n_envs, 2)
+        io = self._io(a[0])
+        L = lib()
+        L.navsim_step_threads_cpu.argtypes = [C.POINTER(abi.NavsimConfig), C.POINTER(abi.NavsimState), C.POINTER(abi.NavsimStepIO),
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        _chk(L.navsim_step_threads_cpu(C.byref(self.cfg), C.byref(self.st), C.byref(io), _p(a), _p(self.obs[self.cur]),
+                                       _p(self.obs[1 - self.cur]), int(n_threads), int(a.shape[0])), "step_threads")
+        if a.shape[0] & 1:
+            self.cur = 1 - self.cur
         return self.obs[self.cur], self.out
 
     def step_threads(self, action, pool, n_threads):

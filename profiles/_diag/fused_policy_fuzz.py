@@ -25,13 +25,13 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     fan = {"cv1": 15, "cv2": 96, "fc1": 4096, "fc2": 260, "a1": 128, "a2": 128}
     g.set_policy({k: rng.uniform(-1, 1, s).astype(np.float32) / np.sqrt(fan[k.split("_")[0]]) for k, s in abi.POLICY_SHAPES.items()})
     g.t["policy_prev_actions"].copy_(torch.rand((E, N, 2), device="cuda:0") * 0.5)
-    keep = {k: g.t[k].clone() for k in ("policy_prev_actions", "ped_waypoints", "ped_n_waypoints")}
+    keep = {k: g.t[k].clone() for k in ("policy_prev_actions", "ped_waypoints", "ped_n_waypoints", "ped_wp_head")}
     scans = g.ped_scans()
-    a = [x.clone() for x in g.ped_policy(scans)] + [g.t["ped_waypoints"].clone(), g.t["ped_n_waypoints"].clone()]
+    a = [x.clone() for x in g.ped_policy(scans)] + [g.t["ped_waypoints"].clone(), g.t["ped_n_waypoints"].clone(), g.t["ped_wp_head"].clone()]
     for k, v in keep.items():
         g.t[k].copy_(v)
     out = torch.full_like(scans, -7.0)
-    b = list(g.ped_policy(fused=True, scans_out=out)) + [g.t["ped_waypoints"], g.t["ped_n_waypoints"]]
+    b = list(g.ped_policy(fused=True, scans_out=out)) + [g.t["ped_waypoints"], g.t["ped_n_waypoints"], g.t["ped_wp_head"]]
     live = torch.arange(N, device="cuda:0")[None, :] < g.t["n_peds"][:, None].clamp(max=N)
     ok = all(torch.equal(x, y) for x, y in zip(a, b)) and torch.equal(out[live], scans[live]) and bool((out[~live] == -7.0).all())
     n += 1; bad += 0 if ok else 1

@@ -702,6 +702,66 @@ def test_env_reset_at_the_reference_map_size(gpu):
             _eq(og[e:e + 1], ro, "arena %d obs at step %d" % (e, t))
 
 
+def test_reference_default_configuration_sampled_oracle(gpu):
+    """Round-4 verdict: the configuration a user of the reference runs unmodified -- every registered default of NavGym-v0
+    (__init__.py:4-40: indoor_ratio 0.5, 5-15 pedestrians on planned routes, per-episode env_param draws), KetiRobot's 512
+    beams over 2 pi (keti_robot.py:44-48), 1000 x 1000 corridor maps and 400 x 400 outdoor maps (map_generator.py:97-143),
+    a new map at every episode end -- batched over 1024 arenas through gym.make.  reset() and ten step() calls (graph replay:
+    the re-plan of the previous step beside the step, then navsim_regen) against single-arena oracles of sampled arenas,
+    bit for bit (scan noise off: its per-beam Gaussians are covered by the step tests); size-independent properties on all."""
+    import nav_gym_env
+    torch = gpu.torch
+    E = 1024
+    env = nav_gym_env.make("NavGym-v0", num_envs=E, map_size="reference", randomize_maps=True, seed=41, device=gpu.dev)
+    assert env.cfg.n_beams == 512 and env.cfg.map_h == 1000 and env.cfg.outdoor_map_size == 400 and env.plan_paths
+    assert env.cfg.regen_indoor_ratio == 0.5 and (env.cfg.num_humans_lo, env.cfg.num_humans_hi) == (5, 15)
+    obs = env.reset()
+    env.sim.cfg.add_scan_noise = 0                       # (the captured graphs are re-captured: NavSim.step_graphed)
+    env.cfg.add_scan_noise = 0
+    o0 = env.sim.reset_obs().cpu().numpy()
+    n_peds = env.sim.t["n_peds"].cpu().numpy()
+    assert n_peds.min() >= 5 and n_peds.max() <= 15 and len(np.unique(n_peds)) > 5
+    occupied = (env.sim.t["field_overflow"][:64] == 0).float().mean(dim=(1, 2)).cpu().numpy()
+    assert (occupied > 0.8).any() and (occupied < 0.8).any(), "both map kinds among the first 64 arenas"     # outdoor: 400^2 of 1000^2 live
+    sample = [0, 1, 17, 100, 511, 1023]
+    on_goal = torch.as_tensor([1, 100], device=gpu.dev)      # these finish at step 0: new map, pedestrians, routes, first observation
+    env.sim.t["robot_goal"][on_goal] = env.sim.t["robot_pose"][on_goal, :2]
+    cfg = env.sim.cfg
+    refs = []
+    for e in sample:
+        c1 = cfg.copy(); c1.n_envs = 1; c1.env_index_base = int(e); c1.regen_cap = 1
+        host = {k: v.cpu().numpy() for k, v in gpu.world.empty_world(c1, device="cpu", plan_paths=True).items()
+                if k not in ("field", "field_overflow", "rect_table", "rect_index")}
+        host["field"] = np.zeros((1, 1000, 1000), np.float32)
+        host["scan_threshold"] = env.scan_threshold.cpu().numpy(); host["scan_discomfort"] = env.scan_discomfort_threshold.cpu().numpy()
+        r = ref.RefSim(c1, host)
+        r.out["done"][:] = 1
+        _eq(o0[e:e + 1], r.regen(), "first observation of arena %d" % e)
+        if e in (1, 100):
+            r.a["robot_goal"][0] = r.a["robot_pose"][0, :2]
+        refs.append(r)
+    rng = np.random.default_rng(3)
+    regenerated = 0
+    for t in range(10):
+        act = np.stack([rng.uniform(0, 0.5, E), rng.uniform(-0.64, 0.64, E)], axis=1)
+        obs, rew, done, info = env.step(torch.from_numpy(act).to(gpu.dev))
+        og = obs["observation"].cpu().numpy()
+        dn = done.cpu().numpy()
+        assert int(dn.sum()) <= cfg.regen_cap, "more arenas finished than regen_cap: the single-arena oracles are not comparable"
+        assert np.isfinite(og).all() and (og[:, :512] >= 0).all() and (og[:, :512] <= 25.0).all()
+        for e, r in zip(sample, refs):
+            if t > 0:
+                r.replan(1024)                              # the device plans the previous step's arrivals beside this step
+            ro, rout = r.step(act[e:e + 1])
+            _eq(dn[e:e + 1].astype(np.uint8), rout["done"], "arena %d done at step %d" % (e, t))
+            _eq(rew[e:e + 1].cpu().numpy(), rout["reward"], "arena %d reward at step %d" % (e, t))
+            regenerated += int(rout["done"][0])
+            _eq(og[e:e + 1], r.regen(), "arena %d obs at step %d" % (e, t))
+    assert regenerated >= 2, "no sampled arena went through navsim_regen"
+    c = env.counters()
+    assert c["regen_served"] >= regenerated and c["regen_unserved"] == 0
+
+
 # NAVSIM_FUZZ_RESET_SEEDS=n widens the sweep for a one-off run (profiles/r04_soak/)
 @pytest.mark.parametrize("seed", list(range(201, 201 + int(os.environ.get("NAVSIM_FUZZ_RESET_SEEDS", "12")))))
 def test_reset_path_fuzzed(gpu, seed):
@@ -791,17 +851,68 @@ def test_replan_vs_oracle(gpu, fmt):
         if prev_n is None:
             assert (r.a["ped_n_waypoints"] > 1).any(), "no pedestrian started with a planned path"
         cap = 2 if t % 2 else 64
-        g.replan(cap); r.replan(cap)
-        gs = g.numpy_state("ped_waypoints", "ped_n_waypoints", "costmap")
-        n_now = r.a["ped_n_waypoints"].copy()
+        _eq(g.numpy_state("ped_due")["ped_due"], r.a["ped_due"], "who waits for a re-plan after step %d" % t)
+        # the candidates: the step's own flags (ABI 5) / the call's pass over the state, alternating -- the same set
+        g.replan(cap, flags=(t % 4 < 2)); r.replan(cap)
+        gs = g.numpy_state("ped_waypoints", "ped_n_waypoints", "ped_wp_head", "costmap")
+        n_now, head_now = r.a["ped_n_waypoints"].copy(), r.a["ped_wp_head"].copy()
         _eq(gs["ped_n_waypoints"], n_now, "waypoint counts at step %d" % t)
+        _eq(gs["ped_wp_head"], head_now, "current waypoints at step %d" % t)
         live = np.arange(cfg.max_waypoints)[None, None, :] < n_now[..., None]
         _eq(gs["ped_waypoints"][live], r.a["ped_waypoints"][live], "waypoints at step %d" % t)
-        if prev_n is not None:
-            replans += int((n_now > prev_n).sum())
-        prev_n = n_now
+        if prev_n is not None:                  # a new route starts at its first waypoint
+            replans += int(((head_now < prev_n[1]) | (n_now != prev_n[0])).sum())
+        prev_n = (n_now, head_now)
     _eq(gs["costmap"], r.a["costmap"], "costmap")
     assert replans >= 5, replans
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_replan_beside_the_step_equals_the_serial_sequence(gpu, graphs):
+    """Round 5: navsim_step_part.  The re-plan of step t runs on a side stream beside step t + 1 of the arenas that have no
+    pedestrian waiting for it; the arenas that do are stepped behind it (NavSim.launch_step_overlapped; graphs=True: the
+    fork and join captured in a hipGraph).  Per arena the order is still step, replan, step: observations, outputs and
+    every state array equal the oracle's serial  step, replan, step, ...  bit for bit, and both parts together step every
+    arena exactly once (steps[] advances by one everywhere)."""
+    E, size, N = 24, 300, 6
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_SFM, n_spawn=6,
+                                 auto_reset=0, seed=29, field_format=abi.FIELD_U16T, ped_min_goal_dist=3.0, obstacle_number=6)
+    gpu.world.lidar_full_circle(cfg, 180)
+    occ = gpu.world.make_maps(E, size, 29, n_obstacles=6)
+    torch = gpu.torch
+    from nav_gym_amd import robots
+    arrays = gpu.world.make_world(cfg, occ, n_peds=5, device=gpu.dev, plan_paths=True, v_pref_range=(0.5, 0.6))
+    arrays["scan_threshold"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array("keti", "threshold_footprint")))
+    arrays["scan_discomfort"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array("keti", "discomfort_threshold_footprint")))
+    host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "rect_table", "rect_index")}
+    host["field"] = ref.build_dt(occ)
+    g = gpu.sim.NavSim(cfg, arrays)
+    r = ref.RefSim(cfg, host)
+    _eq(g.reset_obs().cpu().numpy(), r.reset_obs(), "reset obs")
+    if graphs:
+        g.enable_graphs(regen=False, replan_cap=64, overlap=True)
+    rng = np.random.default_rng(3)
+    waited = split = 0
+    for t in range(100):
+        act = np.stack([rng.uniform(0.0, 0.3, E), rng.uniform(-0.64, 0.64, E)], axis=1)
+        n_due = int((r.a["ped_due"] != 0).sum())           # arenas the side stream steps behind the re-plan
+        waited += n_due; split += 0 < n_due < E
+        if t > 0:
+            r.replan(64)                                     # the serial sequence: ... step, replan, step ...
+        ro, rout = r.step(act)
+        if graphs:
+            go, gout = g.step_graphed(torch.from_numpy(act).to(gpu.dev))
+        else:
+            go, gout = g.step_overlapped(torch.from_numpy(act).to(gpu.dev), 64)
+        _eq(go.cpu().numpy(), ro, "obs at step %d" % t)
+        for k in rout:
+            _eq(gout[k].cpu().numpy(), rout[k], "%s at step %d" % (k, t))
+        assert int(g.t["steps"].min()) == t + 1 == int(g.t["steps"].max()), "an arena was stepped twice or not at all"
+        if t % 10 == 9:
+            _state_equal(g, r, cfg, "at step %d" % t)
+    _state_equal(g, r, cfg, "at the end")
+    assert waited >= 5 and split >= 5, (waited, split)
+    assert g.counters() == r.counters() and r.counters()["replan_served"] >= 5
 
 
 def test_long_routes_on_the_device(gpu, golden_dir):
@@ -921,8 +1032,9 @@ def test_caps_are_counted(gpu):
         np.arange(E)[:, None], np.arange(N)[None, :], r.a["ped_n_waypoints"] - 1], axis=2) < 0.5)[
             np.arange(N)[None, :] < r.a["n_peds"][:, None]].sum())
     assert due >= 3
-    g.replan(0); r.replan(0)                              # a cap of zero serves nobody and counts everybody
-    g.replan(2); r.replan(2)
+    # (the pedestrians were moved by hand: the step's flags know nothing of them, the calls look at the state themselves)
+    g.replan(0, flags=False); r.replan(0)                 # a cap of zero serves nobody and counts everybody
+    g.replan(2, flags=False); r.replan(2)
     c2 = r.counters()
     assert g.counters() == c2
     assert c2["replan_served"] == 2 and c2["replan_unserved"] == due + (due - 2), c2
@@ -1065,16 +1177,17 @@ def test_fused_scan_policy_equals_the_two_calls(gpu, fmt, rects):
     g = gpu.sim.NavSim(cfg, arrays)
     g.set_policy(_policy_weights_random(5))
     g.t["policy_prev_actions"].copy_(torch.rand((E, N, 2), device=gpu.dev) * 0.5)
-    keep = {k: g.t[k].clone() for k in ("policy_prev_actions", "ped_waypoints", "ped_n_waypoints")}
+    keep = {k: g.t[k].clone() for k in ("policy_prev_actions", "ped_waypoints", "ped_n_waypoints", "ped_wp_head")}
     scans = g.ped_scans()
     cmd_a, mean_a = [x.clone() for x in g.ped_policy(scans)]
-    wp_a, nwp_a = g.t["ped_waypoints"].clone(), g.t["ped_n_waypoints"].clone()
+    wp_a, nwp_a, head_a = g.t["ped_waypoints"].clone(), g.t["ped_n_waypoints"].clone(), g.t["ped_wp_head"].clone()
     for k, v in keep.items():
         g.t[k].copy_(v)
     out = torch.full_like(scans, -7.0)
     cmd_b, mean_b = g.ped_policy(fused=True, scans_out=out)
     assert torch.equal(cmd_a, cmd_b) and torch.equal(mean_a, mean_b)
     assert torch.equal(wp_a, g.t["ped_waypoints"]) and torch.equal(nwp_a, g.t["ped_n_waypoints"])
+    assert torch.equal(head_a, g.t["ped_wp_head"])
     live = (torch.arange(N, device=gpu.dev)[None, :] < g.t["n_peds"][:, None].clamp(max=N))
     assert torch.equal(out[live], scans[live]) and bool((out[~live] == -7.0).all())
     assert float(mean_b[live].abs().max()) > 0 and float(scans[live].min()) < 5.9

@@ -133,6 +133,53 @@ def test_registry_and_env_surface(golden_dir):
             env.reset()
 
 
+def test_env_pickles_like_an_ezpickle_and_looks_like_a_gym_env():
+    """env.py:30, 56-78: the reference is `gym.Env, utils.EzPickle` -- a pickle of it carries the constructor's arguments
+    and unpickling builds a fresh environment from them (rlkit-style snapshots pickle the env).  Same here, including
+    the build's own keyword arguments; and what wrappers read of a gym.Env is there whether or not gym is installed."""
+    import copy
+    import pickle
+    import nav_gym_env
+    env = nav_gym_env.make("NavGym-v0", num_envs=5, n_beams=1081, map_size=300, num_humans=3, seed=11, reward_scale=7.0,
+                           num_scan_stack=2, plan_paths=False, action_kind="wheels", robot_type="husky")
+    for other in (pickle.loads(pickle.dumps(env)), copy.deepcopy(env)):
+        assert type(other) is type(env) and other is not env and other.sim is None
+        assert other._ctor_kwargs == env._ctor_kwargs
+        assert bytes(other.cfg) == bytes(env.cfg)                  # the whole navsim_config, derived from the same arguments
+        assert other.observation_space.spaces["observation"].shape == (2 * 1081 + 7,)
+        assert np.array_equal(other.action_space.low, env.action_space.low)
+    assert env.unwrapped is env and env.reward_range[0] == -float("inf") and env.reward_range[1] == float("inf")
+    assert hasattr(env, "spec") and hasattr(env, "metadata") and callable(env.seed) and callable(env.close)
+    from nav_gym_amd import registry
+    if registry.HAVE_GYM:
+        import gym
+        assert isinstance(env, gym.Env)
+
+
+def test_env_fallbacks_are_announced_once():
+    """Round-4 verdict: plan_paths silently fell back to False above 1000 cells per side and field_format to FIELD_F32
+    above 1024.  Both are RuntimeWarnings now, once per process."""
+    import warnings
+    import nav_gym_env
+    from nav_gym_amd import abi
+    from nav_gym_amd.env import NavGymEnv
+    NavGymEnv._warned.clear()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        env = nav_gym_env.make("NavGym-v0", num_envs=2, map_size=1100)
+        assert env.plan_paths is False and env.cfg.field_format == abi.FIELD_F32
+        texts = [str(x.message) for x in w if issubclass(x.category, RuntimeWarning)]
+        assert any("plan_paths" in t for t in texts) and any("field_format" in t for t in texts), texts
+        n = len(texts)
+        nav_gym_env.make("NavGym-v0", num_envs=2, map_size=1100)                 # the second time: silent
+        assert len([x for x in w if issubclass(x.category, RuntimeWarning)]) == n
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        nav_gym_env.make("NavGym-v0", num_envs=2, map_size=500)                  # nothing falls back: nothing is said
+        nav_gym_env.make("NavGym-v0", num_envs=2, map_size=1100, plan_paths=False, field_format=abi.FIELD_F32)
+        assert not [x for x in w if issubclass(x.category, RuntimeWarning)]
+
+
 def test_world_generation_is_shard_invariant():
     import torch
     from nav_gym_amd import lib, world

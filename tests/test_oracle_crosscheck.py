@@ -393,3 +393,35 @@ if __name__ == "__main__":          # the figure quoted in DESIGN.md section 2 +
         out["r64_%d" % m] = a
         out["r32_%d" % m] = b
     np.savez_compressed(os.path.join(_root, "tests", "golden", "march_rule_cases.npz"), **out)
+
+
+def test_native_thread_pool_equals_sequential_steps():
+    """bench.py's CPU baseline (navsim_step_threads_cpu: POSIX threads inside the oracle, arenas split statically, no
+    barrier between steps) computes exactly what step() after step() computes: observations, outputs and state."""
+    import copy
+    from nav_gym_amd import lib, world
+    E, size, N = 13, 120, 4
+    cfg = lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_SFM, n_spawn=4, auto_reset=1,
+                             n_scan_stack=2, seed=8)
+    world.lidar_full_circle(cfg, 90)
+    occ = world.make_maps(E, size, 8)
+    import torch
+    arrays = world.make_world(cfg, occ, n_peds=3, device="cpu", field=torch.from_numpy(ref.build_dt(occ)), min_goal_dist=2.0,
+                              max_goal_dist=4.0, robot_clearance=0.8)
+    host = {k: v.numpy() for k, v in arrays.items()}
+    from nav_gym_amd import robots
+    host["scan_threshold"] = ref.scan_threshold(cfg, robots.footprint_array("keti", "threshold_footprint"))
+    host["scan_discomfort"] = ref.scan_threshold(cfg, robots.footprint_array("keti", "discomfort_threshold_footprint"))
+    a, b = ref.RefSim(cfg, host), ref.RefSim(cfg, host)
+    assert np.array_equal(a.reset_obs(), b.reset_obs())
+    rng = np.random.default_rng(1)
+    for n_steps, n_threads in ((5, 3), (4, 13), (1, 40)):
+        acts = np.stack([rng.uniform(0, 0.5, (n_steps, E)), rng.uniform(-0.64, 0.64, (n_steps, E))], axis=2)
+        for s in range(n_steps):
+            oa, outa = a.step(acts[s])
+        ob, outb = b.step_native_threads(acts, n_threads)
+        assert np.array_equal(oa, ob)
+        for k in outa:
+            assert np.array_equal(outa[k], outb[k]), k
+        for k in a.a:
+            assert np.array_equal(a.a[k], b.a[k]), k

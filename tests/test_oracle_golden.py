@@ -260,7 +260,7 @@ def test_policy_control_block_vs_reference_trace(name):
     assert checked >= 30 and worst < 1e-5, (checked, worst)
     assert replanned.sum() <= 1
     if name == "corridor_S1":           # the route of more than 32 m is walked from its full waypoint list
-        assert nw.max() > 16 and (r.a["ped_n_waypoints"][0] < nw).any()
+        assert nw.max() > 16 and (r.a["ped_wp_head"][0] > 0).any()       # (ABI 5: a pop advances the head, the list stays)
 
 
 def _crowd_golden():
