@@ -2252,7 +2252,7 @@ def test_edge_shapes(gpu):
     st0 = abi.NavsimState(); io0 = abi.NavsimStepIO()
     for name in ("field", "scan_threshold", "scan_discomfort", "robot_pose", "robot_goal", "prev_action", "prev_pose",
                  "n_hist", "episode", "steps", "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist", "ped_has_legs",
-                 "ped_waypoints", "ped_n_waypoints", "ped_cmd", "spawn_pose", "spawn_goal"):
+                 "ped_waypoints", "ped_n_waypoints", "ped_wp_head", "ped_cmd", "spawn_pose", "spawn_goal"):
         setattr(st0, name, g.t.get(name, g.t["robot_pose"]).data_ptr())
     for name in ("action", "obs", "obs_prev", "reward", "done", "is_success", "is_crash", "distance"):
         setattr(io0, name, g.obs.data_ptr())
