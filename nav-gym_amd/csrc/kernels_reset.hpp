@@ -674,41 +674,105 @@ __global__ __launch_bounds__(256) void costmap_kernel(const uint8_t* __restrict_
     cost[(out_index ? (size_t)out_index[m] : m) * (size_t)Hc * Wc + idx] = any ? 1 : 0;
 }
 
-// one workgroup per query: level-synchronous breadth-first distances from the goal in LDS (int16),
-// stopped at the start's level; thread 0 then walks the path (+i, -i, +j, -j order) and cuts it
-// into waypoints exactly like path_to_waypoints.
-// One query, executed by the whole 256-thread workgroup.  c = this query's costmap, w = its waypoint
-// row (max_wp x 2); n_wp / path_cells / path_len point at its slots.
+// One query, executed by a whole workgroup: shortest 4-connected path from the start's to the goal's costmap cell and its
+// waypoints (pyastar2d.astar_path + path_to_waypoints, env.py:343-354, 1261-1277; tie-break: oracle/navsim_ref.c).
+// c = this query's costmap, w = its waypoint row (max_wp x 2); n_wp / path_cells / path_len point at its slots.
 //
-// LDS: dist[n_cells] int16 (-2 blocked, -1 free and unreached, else hops from the goal) followed by
-// queue[n_cells] uint16, the breadth-first queue (every cell enters once; a level is the slice [lo, hi)).
-// A level costs O(frontier) and ONE barrier: each frontier lane claims its free unreached neighbours with
-// a 32-bit LDS atomic AND on the word holding the int16 (see `claim`), and the winner appends the cell.
-// Queue order is arbitrary; only `dist` feeds the path, so results are deterministic.
+// The search is level-synchronous from the GOAL on bitmaps: a row of the costmap is ceil(Wc / 64) 64-bit words (bit b of word w
+// = cell i = 64 w + b), every thread owns WPT of the words (free cells, what is still unreached, and the two DIRECTION planes of
+// its cells in registers); a level is, per word, (frontier << 1 | frontier >> 1 | the words above and below) & unreached -- five
+// LDS reads, a dozen bit operations, one LDS write, one barrier.
+// Round 5: no hop field.  Rounds 1-4 wrote every reached cell's hop count (int16 dist[], a divergent loop over the new bits of
+// every word in every level) and the walk looked for "the first neighbour one hop closer, in the order +i, -i, +j, -j".  A
+// neighbour is one hop closer exactly when it belongs to the frontier of the level BEFORE the cell's own, and that is what
+// the level's update has in its hands: the cell reached through (frontier >> 1) has its +i neighbour in the frontier, through
+// (frontier << 1) its -i neighbour, through the word below / above its +j / -j neighbour.  So the update records, for every cell
+// it reaches, the first of those four in the walk's order -- two bits per cell, two bit operations per plane and word -- and
+// the walk reads its next step instead of probing three neighbours' hop counts.  Same path, cell for cell (the planner, route
+// and trace tests are bit-identical); LDS per query 4 words of 8 bytes per costmap word: 6.4 KB for a 100 x 100 costmap (was 40).
 // Thread 0 then walks the path and cuts the waypoints on the fly (nothing is stored per path cell).
 constexpr size_t kPlanLdsMax = 160 * 1024 - 256;       // LDS per CU minus the static variables
-// the bitmap form of the search (below): dist[n_cells] int16 + four bitmaps of Hc rows x ceil(Wc / 64) words
-inline size_t plan_lds_bitmap(int Hc, int Wc) { return (((size_t)Hc * Wc * 2 + 15) & ~(size_t)15) + 16 + (size_t)4 * Hc * ((Wc + 63) / 64) * 8; }
-inline size_t plan_lds(int Hc, int Wc) {
-    const size_t q = (size_t)((Hc * Wc + 1) & ~1) * 4, b = plan_lds_bitmap(Hc, Wc);
-    return q > b ? q : b;
+constexpr int kPlanMaxWpt = 8;                         // costmap words a thread owns at most
+inline size_t plan_words(int Hc, int Wc) { return (size_t)Hc * ((Wc + 63) / 64); }
+// two frontier buffers and the two direction planes (the free-cell bitmap is assembled in the planes' area first)
+inline size_t plan_lds(int Hc, int Wc) { return 4 * plan_words(Hc, Wc) * sizeof(unsigned long long); }
+inline bool plan_fits(int Hc, int Wc) {
+    return (size_t)Hc * Wc <= 65535 && plan_words(Hc, Wc) <= (size_t)kPlanMaxWpt * 256 && plan_lds(Hc, Wc) <= kPlanLdsMax;
 }
-inline bool plan_fits(int Hc, int Wc) { return (size_t)Hc * Wc <= 65535 && plan_lds(Hc, Wc) <= kPlanLdsMax; }
 
-// BLOCK: threads of the workgroup that runs the query.  A level costs ~1.2 us of dependent LDS round trips (queue -> four
-// neighbours -> four atomics -> queue slot -> queue), not its barrier: navsim_replan with 64 / 128 / 256 threads per query takes
-// 130 / 112 / 112 us per step on the c3 world (profiles/r04_replan/ab_block.txt).
+// the levels: thread t owns the words t, t + BLOCK, ... (WPT of them).  Returns nothing; `reached` says whether the start was.
+template <int BLOCK, int WPT>
+__device__ __forceinline__ void plan_levels(unsigned long long* __restrict__ fa, unsigned long long* __restrict__ fb,
+                                            unsigned long long* __restrict__ planes, int Hc, int Wc, int Ww, int n_words,
+                                            int s_word, unsigned long long s_bit, int* any_s, int* reached) {
+    typedef unsigned long long u64;
+    const int tid = threadIdx.x;
+    u64 avail[WPT], dA[WPT], dB[WPT];                    // unreached free cells, direction planes (bit 0, bit 1)
+    bool own[WPT], hl[WPT], hr[WPT], hu[WPT], hd[WPT];
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {
+        const int x = tid + k * BLOCK;
+        own[k] = x < n_words;
+        const int j = own[k] ? x / Ww : 0, w = own[k] ? x - j * Ww : 0;
+        hl[k] = own[k] && w > 0; hr[k] = own[k] && w + 1 < Ww; hu[k] = own[k] && j > 0; hd[k] = own[k] && j + 1 < Hc;
+        // free cells (assembled in the planes' area by the caller) minus the goal's bit, which is level 0
+        avail[k] = own[k] ? planes[x] & ~fa[x] : 0ull;
+        dA[k] = 0ull; dB[k] = 0ull;
+    }
+    __syncthreads();                                     // everybody has read its free words: the area is the planes' from here on
+    u64* cur = fa, *nxt = fb;
+    for (int level = 1; level < 65536; ++level) {
+        // the two flags and the frontier words in ONE LDS round trip (the reads are issued together, the exit test follows)
+        const int stop = *reached, more = any_s[level % 3];
+        u64 f[WPT], l[WPT], r[WPT], u[WPT], d[WPT];
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            const int x = tid + k * BLOCK;
+            f[k] = own[k] ? cur[x] : 0ull;
+            l[k] = hl[k] ? cur[x - 1] >> 63 : 0ull; r[k] = hr[k] ? cur[x + 1] << 63 : 0ull;
+            u[k] = hu[k] ? cur[x - Ww] : 0ull; d[k] = hd[k] ? cur[x + Ww] : 0ull;
+        }
+        if (stop || !more) break;
+        if (tid == 0) any_s[(level + 2) % 3] = 0;      // the flag of level + 1 (last read two barriers ago)
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            const int x = tid + k * BLOCK;
+            const u64 R = (f[k] >> 1) | r[k];            // cells whose +i neighbour is in the frontier
+            const u64 L = (f[k] << 1) | l[k];            // ... -i neighbour
+            const u64 cand = (R | L | u[k] | d[k]) & avail[k];
+            if (own[k]) nxt[x] = cand;
+            avail[k] &= ~cand;
+            // the walk's order +i, -i, +j, -j as two bits per cell: 0, 1, 2, 3
+            const u64 t = cand & ~R;
+            dA[k] |= t & (L | ~d[k]);
+            dB[k] |= t & ~L;
+            found |= cand != 0ull;
+            if (x == s_word && (cand & s_bit)) *reached = 1;
+        }
+        if (found) any_s[(level + 1) % 3] = 1;
+        __syncthreads();
+        u64* t = cur; cur = nxt; nxt = t;
+    }
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {
+        const int x = tid + k * BLOCK;
+        if (own[k]) { planes[2 * x] = dA[k]; planes[2 * x + 1] = dB[k]; }
+    }
+}
+
+// BLOCK: threads of the workgroup that runs the query (round 4: 64 / 128 / 256 threads per query 130 / 112 / 112 us of
+// navsim_replan per step on the c3 world, profiles/r04_replan/ab_block.txt)
 template <int BLOCK = 256>
 __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc, int Wc, double res_c, double ox,
                                            double oy, double sx_, double sy_, double gx_, double gy_, double interval,
                                            int max_wp, double* __restrict__ w, int32_t* __restrict__ n_wp,
                                            int32_t* __restrict__ path_cells, double* __restrict__ path_len,
                                            unsigned long long* __restrict__ cut_counter = nullptr) {
-    extern __shared__ int16_t dist[];
-    __shared__ int cnt[3], reached;
+    typedef unsigned long long u64;
+    extern __shared__ __attribute__((aligned(16))) u64 plan_dyn[];
+    __shared__ int any_s[3], reached;
     const int tid = threadIdx.x;
-    const int n_cells = Hc * Wc;
-    uint16_t* queue = (uint16_t*)(dist + ((n_cells + 1) & ~1));
     navsim_config cc = {};
     cc.origin_x = ox; cc.origin_y = oy; cc.resolution = res_c; cc.map_h = Hc; cc.map_w = Wc;
     int si, sj, gi, gj;
@@ -722,203 +786,44 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
         if (path_len) *path_len = 0.0;
     }
     if (!ok) return;                                     // uniform: depends on the query only
-    const int s_cell = sj * Wc + si, g_cell = gj * Wc + gi;
-#ifndef NAVSIM_PLAN_QUEUE          // (-DNAVSIM_PLAN_QUEUE: the queue form of rounds 1-3 below, kept for A/B)
-    // The hop field by a level-synchronous search on BITMAPS (round 4): a row of the costmap is ceil(Wc / 64) 64-bit words (bit b of
-    // word w = cell i = 64 w + b); a level is, per word, (frontier << 1 | frontier >> 1 | the words above and below) & free &
-    // ~visited -- seven independent LDS reads, a few bit operations, the hop count written for the (typically one to four) new
-    // bits, one barrier.  No queue, no atomics.  The field it writes is the field the queue search wrote (hops from the goal, every
-    // level completed), so the walk below -- and with it every waypoint -- is unchanged: 45 planner / regen / env tests
-    // bit-identical; navsim_replan on the c3 world 112 -> 99 us per step, regen_plan_kernel 579 -> 533 us
-    // (profiles/r04_replan/ab_bitmap.txt).
+    const int Ww = (Wc + 63) >> 6, n_words = Hc * Ww;
+    u64* fa = plan_dyn, *fb = plan_dyn + n_words, *planes = plan_dyn + 2 * n_words;
+    {   // the free-cell bitmap (into the planes' area) and the goal as level 0: a wavefront reads 64 cells of a row with one
+        // coalesced byte load and ballots them into the word, sixteen words per wavefront in flight (round 4: one thread
+        // assembled a word from 64 dependent byte loads -- 20 us of every query, profiles/r04_replan/levels_*.txt's offset)
+        constexpr int U = 16, kWaves = BLOCK / 64;
+        const int wave = tid >> 6, lane = tid & 63;
+        const int g_word = gj * Ww + (gi >> 6);
+        for (int x0 = wave * U; x0 < n_words; x0 += kWaves * U) {
+            bool fr[U];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const int x = x0 + q, j = x / Ww, ww = x - j * Ww, i = (ww << 6) + lane;
+                fr[q] = (x < n_words && i < Wc) ? (c[(size_t)j * Wc + i] == 0) : false;
+            }
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const u64 fw = __ballot(fr[q]);
+                const int x = x0 + q;
+                if (lane == 0 && x < n_words) { planes[x] = fw; fa[x] = (x == g_word) ? 1ull << (gi & 63) : 0ull; fb[x] = 0ull; }
+            }
+        }
+        if (tid == 0) { any_s[0] = 0; any_s[1] = 1; any_s[2] = 0; reached = (si == gi && sj == gj); }
+    }
+    __syncthreads();
     {
-        const int Ww = (Wc + 63) >> 6, n_words = Hc * Ww;
-        unsigned long long* bm = (unsigned long long*)(((uintptr_t)((char*)dist + (size_t)n_cells * 2) + 15) & ~(uintptr_t)15);
-        unsigned long long* free_b = bm, *seen = bm + n_words, *fa = bm + 2 * n_words, *fb = bm + 3 * n_words;
-        __shared__ int any_s[3];
-        {   // dist = -1 everywhere, 16 bytes per store (the area is 16-byte aligned and padded to it)
-            const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-            uint4* d16 = (uint4*)dist;
-            for (int k = tid; k < (n_cells * 2 + 15) / 16; k += BLOCK) d16[k] = ones;
-        }
-        {   // the free-cell bitmap: a wavefront reads 64 cells of a row with one coalesced byte load and ballots them into the
-            // word; sixteen words per wavefront in flight (round 5: one thread used to assemble a word from 64 dependent byte
-            // loads -- 20 us of every query, profiles/r04_replan/levels_*.txt's offset)
-            constexpr int U = 16, kWaves = BLOCK / 64;
-            const int wave = tid >> 6, lane = tid & 63;
-            for (int x0 = wave * U; x0 < n_words; x0 += kWaves * U) {
-                bool fr[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int x = x0 + u, j = x / Ww, w = x - j * Ww, i = (w << 6) + lane;
-                    fr[u] = (x < n_words && i < Wc) ? (c[(size_t)j * Wc + i] == 0) : false;
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const unsigned long long f = __ballot(fr[u]);
-                    const int x = x0 + u;
-                    if (lane == 0 && x < n_words) { free_b[x] = f; seen[x] = 0; fa[x] = 0; fb[x] = 0; }
-                }
-            }
-        }
-        if (tid == 0) { any_s[0] = 0; any_s[1] = 1; any_s[2] = 0; reached = (s_cell == g_cell); }
-        __syncthreads();
-        if (tid == 0) {
-            dist[g_cell] = 0;
-            const int x = gj * Ww + (gi >> 6);
-            fa[x] = 1ull << (gi & 63); seen[x] = fa[x];
-        }
-        __syncthreads();
-        unsigned long long* cur = fa, *nxt = fb;
         const int s_word = sj * Ww + (si >> 6);
-        const unsigned long long s_bit = 1ull << (si & 63);
-        if (n_words <= BLOCK) {
-            // every word has its own thread (costmaps up to 128 x 128 with 256 threads: 500 x 500-cell maps): what does not change
-            // from level to level -- the word's place, its free cells, its visited set -- stays in registers, and a level is
-            // five frontier reads, a dozen bit operations and the writes.  A workgroup of four wavefronts has a SIMD each:
-            // a level costs what its instructions cost (the two-levels-per-barrier form, 2.6 x the arithmetic for half the
-            // barriers, LOST: profiles/r04_replan/levels_bitmap2.txt).
-            const bool own = tid < n_words;
-            const int x = own ? tid : 0, j = x / Ww, w = x - j * Ww;
-            const bool hl = own && w > 0, hr = own && w + 1 < Ww, hu = own && j > 0, hd = own && j + 1 < Hc;
-            const unsigned long long my_free = own ? free_b[x] : 0ull;
-            unsigned long long my_seen = own ? seen[x] : 0ull;
-            const int base = j * Wc + (w << 6);
-            const bool start_here = own && x == s_word;
-            for (int level = 1; level < 32767; ++level) {
-                // the two flags and the five frontier words in ONE LDS round trip (the reads are issued together, the exit
-                // test follows them)
-                const int stop = reached, more = any_s[level % 3];
-                const unsigned long long f = own ? cur[x] : 0ull;
-                const unsigned long long l = hl ? cur[x - 1] >> 63 : 0ull, r = hr ? cur[x + 1] << 63 : 0ull;
-                const unsigned long long u = hu ? cur[x - Ww] : 0ull, d = hd ? cur[x + Ww] : 0ull;
-                if (stop || !more) break;
-                if (tid == 0) any_s[(level + 2) % 3] = 0;
-                unsigned long long cand = ((f << 1) | l | (f >> 1) | r | u | d) & my_free & ~my_seen;
-                if (own) nxt[x] = cand;
-                if (cand) {
-                    my_seen |= cand;
-                    any_s[(level + 1) % 3] = 1;
-                    if (start_here && (cand & s_bit)) reached = 1;
-                    while (cand) {
-                        dist[base + __builtin_ctzll(cand)] = (int16_t)level;
-                        cand &= cand - 1;
-                    }
-                }
-                __syncthreads();
-                unsigned long long* t = cur; cur = nxt; nxt = t;
-            }
-        } else
-        for (int level = 1; level < 32767; ++level) {
-            if (reached || !any_s[level % 3]) break;                         // any_s[level % 3]: did level - 1 find a cell
-            if (tid == 0) any_s[(level + 2) % 3] = 0;                        // the flag of level + 1 (last read two barriers ago)
-            bool found = false;
-            for (int x = tid; x < n_words; x += BLOCK) {
-                const int j = x / Ww, w = x - j * Ww;
-                const unsigned long long f = cur[x];
-                const unsigned long long l = (w > 0) ? cur[x - 1] >> 63 : 0ull, r = (w + 1 < Ww) ? cur[x + 1] << 63 : 0ull;
-                const unsigned long long u = (j > 0) ? cur[x - Ww] : 0ull, d = (j + 1 < Hc) ? cur[x + Ww] : 0ull;
-                const unsigned long long sn = seen[x];
-                unsigned long long cand = ((f << 1) | l | (f >> 1) | r | u | d) & free_b[x] & ~sn;
-                nxt[x] = cand;
-                if (cand) {
-                    seen[x] = sn | cand;
-                    found = true;
-                    if (x == s_word && (cand & s_bit)) reached = 1;
-                    const int base = j * Wc + (w << 6);
-                    while (cand) {
-                        const int b = __builtin_ctzll(cand);
-                        dist[base + b] = (int16_t)level;
-                        cand &= cand - 1;
-                    }
-                }
-            }
-            if (found) any_s[(level + 1) % 3] = 1;
-            __syncthreads();
-            unsigned long long* t = cur; cur = nxt; nxt = t;
-        }
+        const u64 s_bit = 1ull << (si & 63);
+        if (n_words <= BLOCK)          plan_levels<BLOCK, 1>(fa, fb, planes, Hc, Wc, Ww, n_words, s_word, s_bit, any_s, &reached);
+        else if (n_words <= 2 * BLOCK) plan_levels<BLOCK, 2>(fa, fb, planes, Hc, Wc, Ww, n_words, s_word, s_bit, any_s, &reached);
+        else if (n_words <= 4 * BLOCK) plan_levels<BLOCK, 4>(fa, fb, planes, Hc, Wc, Ww, n_words, s_word, s_bit, any_s, &reached);
+        else                           plan_levels<BLOCK, kPlanMaxWpt>(fa, fb, planes, Hc, Wc, Ww, n_words, s_word, s_bit, any_s, &reached);
     }
-#else
-    if ((((uintptr_t)c) & 3) == 0) {                                       // four cells per load
-        const uint32_t* c4 = (const uint32_t*)c;
-        uint2* d4 = (uint2*)dist;
-        for (int k = tid; k < n_cells / 4; k += BLOCK) {
-            const uint32_t v = c4[k];
-            uint2 o;
-            o.x = ((v & 0xFFu) ? 0xFFFEu : 0xFFFFu) | (((v >> 8) & 0xFFu) ? 0xFFFE0000u : 0xFFFF0000u);
-            o.y = (((v >> 16) & 0xFFu) ? 0xFFFEu : 0xFFFFu) | ((v >> 24) ? 0xFFFE0000u : 0xFFFF0000u);
-            d4[k] = o;
-        }
-        for (int k = (n_cells & ~3) + tid; k < n_cells; k += BLOCK) dist[k] = c[k] ? (int16_t)-2 : (int16_t)-1;
-    } else {
-        for (int k = tid; k < n_cells; k += BLOCK) dist[k] = c[k] ? (int16_t)-2 : (int16_t)-1;
-    }
-    if ((n_cells & 1) && tid == 0) dist[n_cells] = -2;                    // pad half of the last 32-bit word
-    __syncthreads();
-    if (tid == 0) {
-        dist[g_cell] = 0; queue[0] = (uint16_t)g_cell;
-        cnt[0] = 0; cnt[1] = 0; cnt[2] = 0;
-        reached = (s_cell == g_cell);
-    }
-    __syncthreads();
-    uint32_t* words = (uint32_t*)dist;
-    const uint16_t* half = (const uint16_t*)dist;
-    int lo = 0, hi = 1;
-    for (int level = 1; level < 32767; ++level) {
-        if (reached || lo == hi) break;
-        const int slot = level % 3;
-        if (tid == 0) cnt[(level + 1) % 3] = 0;          // last read two barriers ago
-        // claim a neighbour for this level: one atomic AND turns an unreached half-word (0xFFFF) into
-        // `level` and leaves a half-word some other lane claimed in this level unchanged; the lane that
-        // saw 0xFFFF come back owns the cell.  Reached and blocked cells are filtered by the plain read.
-        // The four reads, then the four atomics, are issued together (independent LDS round trips).
-        for (int f = lo + tid; f < hi; f += BLOCK) {
-            const int k = queue[f], j = k / Wc, i = k - j * Wc;
-            const int m[4] = {k + 1, k - 1, k + Wc, k - Wc};
-            const bool in[4] = {i + 1 < Wc, i > 0, j + 1 < Hc, j > 0};
-            bool want[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) want[d] = in[d] && half[in[d] ? m[d] : k] == 0xFFFFu;
-            uint32_t old[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {               // branch-free: a lane with nothing to claim ANDs all ones
-                const uint32_t sh = (uint32_t)(m[d] & 1) * 16u;
-                const uint32_t mask = want[d] ? (((uint32_t)level << sh) | (0xFFFFu << (16u - sh))) : 0xFFFFFFFFu;
-                old[d] = atomicAnd(&words[(want[d] ? m[d] : k) >> 1], mask);
-            }
-            // queue slots: one atomic per wavefront (ballot prefix), not one per lane or per cell
-            uint64_t won[4];
-            int total = 0;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                want[d] = want[d] && ((old[d] >> ((uint32_t)(m[d] & 1) * 16u)) & 0xFFFFu) == 0xFFFFu;
-                won[d] = __ballot(want[d]);
-                total += __popcll(won[d]);
-            }
-            if (total) {                                     // wave-uniform
-                const uint64_t below = (1ull << (tid & 63)) - 1ull;
-                int base = 0;
-                if ((__ballot(1) & below) == 0) base = atomicAdd(&cnt[slot], total);     // first active lane
-                base = hi + __builtin_amdgcn_readfirstlane(base);
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    if (want[d]) {
-                        queue[base + __popcll(won[d] & below)] = (uint16_t)m[d];
-                        if (m[d] == s_cell) reached = 1;
-                    }
-                    base += __popcll(won[d]);
-                }
-            }
-        }
-        __syncthreads();
-        lo = hi;
-        hi += cnt[slot];
-    }
-#endif
+    __syncthreads();                                     // the planes (and the last level's `reached`)
 #ifdef NAVSIM_DIAG_NO_WALK
     return;
 #endif
-    if (tid != 0 || dist[s_cell] < 0) return;
+    if (tid != 0 || !reached) return;
     int n = 0, count = 0, ci = si, cj = sj;
     const double fx0 = ((double)si + 0.5) * res_c + ox, fy0 = ((double)sj + 0.5) * res_c + oy;
     double fx = fx0, fy = fy0;                           // env.py:1261-1277, cut while walking
@@ -938,14 +843,16 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
     // (a walked cell then costs integer work only: 0.32 -> 0.2 us, profiles/r04_replan/)
     const double q = interval / res_c, q2_hi = q * q * (1.0 + 1.0e-6), q2_lo = q * q * (1.0 - 1.0e-6);
     int ai = si, aj = sj;                                // the anchor's cell
-    int dcur = dist[s_cell];                             // hops left: one fewer with every step of the walk (no re-read)
+    // the direction planes of the current cell's word stay in registers while the walk stays inside the word
+    int wx = -1;
+    u64 pa = 0ull, pb = 0ull;
     for (;;) {
         ++n;
-        const int k = cj * Wc + ci;
         const int di = ci - ai, dj = cj - aj;
         const double n2 = (double)(di * di + dj * dj);
+        const bool at_goal = ci == gi && cj == gj;
         bool far = n2 > q2_hi;
-        if (far | (dcur == 0) | !(n2 < q2_lo)) {
+        if (far | at_goal | !(n2 < q2_lo)) {
             const double cx = ((double)ci + 0.5) * res_c + ox, cy = ((double)cj + 0.5) * res_c + oy;
             if (!far && !(n2 < q2_lo)) {
                 // sqrt(d2) > interval, decided on d2 unless it sits within 1e-12 of interval^2 (sqrt is monotone
@@ -955,13 +862,13 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
                 far = (d2 > i2_hi) || (!(d2 < i2_lo) && sqrt(d2) > interval);
             }
             if (far) { emit(cx, cy); fx = cx; fy = cy; ai = ci; aj = cj; }
-            if (dcur == 0) { emit(cx, cy); break; }      // the goal cell closes the list
+            if (at_goal) { emit(cx, cy); break; }        // the goal cell closes the list
         }
-        const int want = dcur - 1;                       // first neighbour one hop closer, (+i, -i, +j, -j)
-        const bool e0 = ci + 1 < Wc && dist[k + 1] == want, e1 = ci > 0 && dist[k - 1] == want;
-        const bool e2 = cj + 1 < Hc && dist[k + Wc] == want;
-        if (e0) ++ci; else if (e1) --ci; else if (e2) ++cj; else --cj;
-        dcur = want;
+        const int x = cj * Ww + (ci >> 6);               // the cell's step: +i, -i, +j, -j as the levels recorded it
+        if (x != wx) { pa = planes[2 * x]; pb = planes[2 * x + 1]; wx = x; }
+        const int bit = ci & 63;
+        const int dir = (int)((pa >> bit) & 1ull) | ((int)((pb >> bit) & 1ull) << 1);
+        if (dir == 0) ++ci; else if (dir == 1) --ci; else if (dir == 2) ++cj; else --cj;
     }
     *n_wp = count < max_wp ? count : max_wp;
     if (path_cells) *path_cells = n;
@@ -1171,46 +1078,63 @@ __global__ __launch_bounds__(64) void replan_flag_kernel(navsim_config c, navsim
     if (i == 0) due[e] = m;
 }
 
-// ordered compaction of the set bits, (arena, pedestrian) order, at most cap entries
-__global__ __launch_bounds__(1024) void replan_select_kernel(const uint64_t* __restrict__ due, int E, int N, int cap,
-                                                             int* __restrict__ count, int* __restrict__ list,
-                                                             navsim_state st) {
-    __shared__ int part[1024];
-    const int tid = threadIdx.x;
-    const int per = (E + 1023) / 1024;
-    const int lo = tid * per, hi = (lo + per < E) ? lo + per : E;
-    int n = 0;
-    for (int e = lo; e < hi; ++e) n += __popcll(due[e]);
-    part[tid] = n;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v = (tid >= off) ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int pos = part[tid] - n;
-    if (n)
-        for (int e = lo; e < hi && pos < cap; ++e)
-            for (uint64_t m = due[e]; m && pos < cap; m &= m - 1) list[pos++] = e * N + (__ffsll((unsigned long long)m) - 1);
-    if (tid == 1023) {
-        const int served = part[1023] < cap ? part[1023] : cap;
-        *count = served;
-        count_served(st, NAVSIM_COUNTER_REPLAN_SERVED, served, part[1023] - served);
-    }
-}
-
 #ifndef NAVSIM_REPLAN_BLOCK
 #define NAVSIM_REPLAN_BLOCK 256
 #endif
 constexpr int kReplanBlock = NAVSIM_REPLAN_BLOCK;
-__global__ __launch_bounds__(kReplanBlock) void replan_kernel(navsim_config c, navsim_state st, const int* __restrict__ count,
-                                                     const int* __restrict__ list) {
+// The b-th flagged pedestrian in (arena, pedestrian) order, as q = e N + i, or -1 when fewer are flagged; total = how many
+// are.  Every workgroup of replan_kernel finds its own query this way (round 5): the ordered compaction used to be a
+// kernel of its own (replan_select_kernel, one workgroup) in front of the searches -- 5 us on an idle chip, 33 us beside a
+// step kernel that fills it, and serial either way.  32 KB of flags per 4096 arenas, read from L2 by every workgroup.
+__device__ __forceinline__ int replan_pick(const uint64_t* __restrict__ due, int E, int N, int b, int& total) {
+    __shared__ int wave_tot[kReplanBlock / 64], q_s, total_s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int per = (E + kReplanBlock - 1) / kReplanBlock;
+    const int lo = tid * per, hi = (lo + per < E) ? lo + per : E;
+    int n = 0;
+    for (int e = lo; e < hi; ++e) n += __popcll(due[e]);
+    int incl = n;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_tot[tid >> 6] = incl;
+    if (tid == 0) q_s = -1;
+    __syncthreads();
+    int before = 0, all = 0;
+    for (int w = 0; w < kReplanBlock / 64; ++w) { if (w < (tid >> 6)) before += wave_tot[w]; all += wave_tot[w]; }
+    int pos = before + incl - n;                          // flagged pedestrians in front of this thread's words
+    if (b >= pos && b < pos + n)
+        for (int e = lo; e < hi; ++e) {
+            uint64_t m = due[e];
+            const int k = __popcll(m);
+            if (b < pos + k) {
+                for (int skip = b - pos; skip > 0; --skip) m &= m - 1;
+                q_s = e * N + (__ffsll((unsigned long long)m) - 1);
+                break;
+            }
+            pos += k;
+        }
+    if (tid == 0) total_s = all;
+    __syncthreads();
+    total = total_s;
+    return q_s;
+}
+
+__global__ __launch_bounds__(kReplanBlock) void replan_kernel(navsim_config c, navsim_state st, const uint64_t* __restrict__ due,
+                                                              int cap) {
     __shared__ double goal_s[2];
     __shared__ int32_t nwp_s;
-    const int b = blockIdx.x;
-    if (b >= *count) return;
-    const int q = list[b], N = c.max_peds, P = c.max_waypoints, tid = threadIdx.x;
+    // a handful of small workgroups beside a step kernel that keeps every SIMD's issue slots busy: first in line
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.x, N = c.max_peds, P = c.max_waypoints, tid = threadIdx.x;
+    int total;
+    const int q = replan_pick(due, c.n_envs, N, b, total);
+    if (b == 0 && tid == 0) {
+        const int served = total < cap ? total : cap;
+        count_served(st, NAVSIM_COUNTER_REPLAN_SERVED, served, total - served);
+    }
+    if (q < 0 || b >= cap) return;                        // (cap = 0: the one workgroup of the launch only counts)
     const int e = q / N, i = q - e * N;
     const int Hc = c.map_h / 5, Wc = c.map_w / 5;
     const double res_c = c.resolution * 5.0;

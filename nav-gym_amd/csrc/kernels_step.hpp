@@ -886,27 +886,54 @@ __global__ __launch_bounds__(kPedUpdateBlock) void ped_update_kernel(navsim_conf
 // carries no select.  PINL (pedestrian variants): the pedestrian phase is compiled into the kernel (wavefront 0 runs it
 // beside the scan of the others; 36-44 bytes of private scratch per lane under the 64-register cap, none in a hot loop);
 // false = reset-only launches and launches behind ped_update_kernel: no pedestrian phase, Scratch_Size 0.
+// The arena with a waiting pedestrian that launch slot `slot` of a NAVSIM_STEP_DUE launch steps: the slot-th arena, in index
+// order, whose word of st.ped_due_prev is not zero; -1 when fewer arenas wait.  Every workgroup of that launch finds its own
+// arena (a prefix count over E words from L2, ~2 us): the launch is as small as the work -- a few dozen workgroups instead of
+// one per arena, nearly all of which would only claim their LDS to find out that they have nothing to do
+// (profiles/r05_replan/timeline_v2.txt: 55-85 us for ~80 arenas).
+template <int BLOCK>
+__device__ __forceinline__ int due_arena_pick(const unsigned long long* __restrict__ due, int E, int slot) {
+    __shared__ int wave_tot[kMaxWaves], e_s;
+    const int tid = threadIdx.x, lane = tid & 63, nthr = block_threads<BLOCK>();
+    const int per = (E + nthr - 1) / nthr;
+    const int lo = tid * per, hi = (lo + per < E) ? lo + per : E;
+    int n = 0;
+    for (int e = lo; e < hi; ++e) n += due[e] != 0ull;
+    int incl = n;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63 || tid == nthr - 1) wave_tot[tid >> 6] = incl;
+    if (tid == 0) e_s = -1;
+    __syncthreads();
+    int pos = incl - n;
+    for (int w = 0; w < (tid >> 6); ++w) pos += wave_tot[w];
+    if (slot >= pos && slot < pos + n)
+        for (int e = lo; e < hi; ++e)
+            if (due[e] != 0ull && pos++ == slot) { e_s = e; break; }
+    __syncthreads();
+    const int e = e_s;
+    __syncthreads();                                     // (e_s is rewritten by the next pick of this workgroup)
+    return e;
+}
+
+// The fused step of ONE arena by the calling workgroup.  BLOCK threads; PEDS: the pedestrian variants (primitives + culled merge
+// in LDS); RULE: the march step rule (NAVSIM_MARCH_*), a compile-time copy of cfg.march_rule so that the probe loop carries no
+// select.  PINL (pedestrian variants): the pedestrian phase is compiled in (wavefront 0 runs it beside the scan of the others;
+// 36-44 bytes of private scratch per lane under the 64-register cap, none in a hot loop); false = reset-only launches and
+// launches behind ped_update_kernel: no pedestrian phase, Scratch_Size 0.
 template <int BLOCK, bool PEDS, typename Field, int RULE, int RECT, bool PINL>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void navsim_step_kernel(navsim_config c, navsim_state st,
-                                                            navsim_step_io io, int reset_only,
-                                                            const uint8_t* __restrict__ reset_mask,
-                                                            unsigned dyn_lds_bytes, int park_lanes, unsigned rect_lds_offset) {
+__device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_state& st, const navsim_step_io& io, const int e,
+                                           int reset_only, const int peds_done, const uint8_t* __restrict__ reset_mask,
+                                           unsigned dyn_lds_bytes, int park_lanes, unsigned rect_lds_offset) {
     __shared__ StepShared sh;
-    const int peds_done = (reset_only >> 1) & 1;     // the pedestrians were advanced by ped_update_kernel
-    const int part = (reset_only >> 2) & 3;          // navsim_step_part: NAVSIM_STEP_NOT_DUE / NAVSIM_STEP_DUE
-    reset_only &= 1;
     // dynamic LDS: [the arena's index row (RECT = 2)][parked rays][pedestrian variants: float2 dir[B], float rng[B]][PedShared][pair table]
     extern __shared__ __attribute__((aligned(16))) char dyn_lds_all[];
     char* dyn_lds = dyn_lds_all + (RECT == 2 ? rect_lds_offset : 0u);      // (rect_lds_offset = the row's size: the rest sits behind it)
     PedShared ps = {};
     if constexpr (PEDS) ps = ped_lds_carve(dyn_lds + ((dyn_lds_bytes + 15u) & ~15u), c.max_peds);
     const Prims prims = {ps.seg, ps.disc, ps.info};
-    // longest-first launch order (a scheduling hint: which arena a workgroup takes never changes a result)
-    const int e = st.launch_order ? st.launch_order[blockIdx.x] : (int)blockIdx.x;
-    if (e < 0) return;              // navsim_regen's first-observation launch: one workgroup per list slot, -1 = empty slot
-    // navsim_step_part: this launch steps the arenas with (NAVSIM_STEP_DUE) or without a pedestrian that waited for navsim_replan
-    // when the previous step ended; the other launch of the pair steps the rest.  Nothing of a skipped arena is touched.
-    if (part != NAVSIM_STEP_ALL && (st.ped_due_prev[e] != 0ull) != (part == NAVSIM_STEP_DUE)) return;
     const int tid = threadIdx.x;
     unsigned long long t_begin = 0;
     if (st.arena_cost && tid == 0) t_begin = __builtin_amdgcn_s_memrealtime();
@@ -1190,6 +1217,42 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
             st.arena_cost[e] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_begin);
     }
     NAVSIM_STAMP(6);
+}
+
+// The fused step.  One workgroup = one arena (template arguments: step_arena).  reset_only: bit 0 = a reset-only launch, bit 1 =
+// ped_update_kernel has advanced the pedestrians, bits 2-3 = the NAVSIM_STEP_* part of navsim_step_part.
+template <int BLOCK, bool PEDS, typename Field, int RULE, int RECT, bool PINL>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void navsim_step_kernel(navsim_config c, navsim_state st,
+                                                            navsim_step_io io, int reset_only,
+                                                            const uint8_t* __restrict__ reset_mask,
+                                                            unsigned dyn_lds_bytes, int park_lanes, unsigned rect_lds_offset) {
+    const int peds_done = (reset_only >> 1) & 1;
+    const int part = (reset_only >> 2) & 3;
+    reset_only &= 1;
+    // longest-first launch order (a scheduling hint: which arena a workgroup takes never changes a result)
+    const int e = st.launch_order ? st.launch_order[blockIdx.x] : (int)blockIdx.x;
+    if (e < 0) return;              // navsim_regen's first-observation launch: one workgroup per list slot, -1 = empty slot
+    // navsim_step_part, NAVSIM_STEP_NOT_DUE: the other launch of the pair (navsim_step_due_kernel) steps the arenas with a
+    // pedestrian that waited for navsim_replan when the previous step ended
+    if (part == NAVSIM_STEP_NOT_DUE && st.ped_due_prev[e] != 0ull) return;
+    step_arena<BLOCK, PEDS, Field, RULE, RECT, PINL>(c, st, io, e, reset_only, peds_done, reset_mask, dyn_lds_bytes, park_lanes, rect_lds_offset);
+}
+
+// navsim_step_part, NAVSIM_STEP_DUE: the few arenas that waited for navsim_replan, as a COMPACT launch -- workgroup b steps the
+// b-th, (b + gridDim.x)-th, ... arena whose word of st.ped_due_prev is set (due_arena_pick).  They end the step, so their
+// wavefronts go first wherever they share a SIMD with the other part's.  A kernel of its own: the loop around the arena's body
+// costs the body registers (round 5: inside navsim_step_kernel it took c2 from 92 to 114 us per launch).
+template <int BLOCK, typename Field, int RULE, int RECT>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void navsim_step_due_kernel(navsim_config c, navsim_state st,
+                                                            navsim_step_io io, unsigned dyn_lds_bytes, int park_lanes,
+                                                            unsigned rect_lds_offset) {
+    __builtin_amdgcn_s_setprio(2);
+    for (int slot = (int)blockIdx.x;; slot += (int)gridDim.x) {
+        const int e = due_arena_pick<BLOCK>(st.ped_due_prev, c.n_envs, slot);
+        if (e < 0) return;
+        step_arena<BLOCK, true, Field, RULE, RECT, true>(c, st, io, e, 0, 0, nullptr, dyn_lds_bytes, park_lanes, rect_lds_offset);
+        __syncthreads();                                 // the arena's LDS is reused by the next one
+    }
 }
 
 // navsim_launch_order: arenas by descending cost.  One workgroup: maximum, 1024-bucket histogram on the cost

@@ -59,7 +59,7 @@ thread_local bool g_prepare_only = false;
 int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
                   int reset_only, const uint8_t* mask, hipStream_t s, int grid = 0) {
     int rc;
-    const StepPlan p = plan_step(c, st, grid);
+    const StepPlan p = plan_step(c, st, ((reset_only >> 2) & 3) == NAVSIM_STEP_DUE ? 0 : grid);
     const bool peds = c->ped_model != NAVSIM_PED_NONE;
     if (peds && !(reset_only & 1) && ped_split_on(c) && !g_prepare_only) {            // pedestrians ahead of the step (ped_split_on)
         const size_t pl = ped_update_lds_bytes(c);
@@ -718,14 +718,13 @@ int navsim_replan(const navsim_config* c, const navsim_state* st, int32_t max_qu
     if (Hc < 1 || Wc < 1 || !plan_fits(Hc, Wc) || allow_lds((const void*)replan_kernel, plan_lds(Hc, Wc)) != NAVSIM_OK)
         return NAVSIM_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    int* count = (int*)workspace;
-    int* list = (int*)((char*)workspace + 256);
     uint64_t* due = (uint64_t*)((char*)workspace + 256 + (((size_t)max_queries * sizeof(int32_t) + 255) & ~(size_t)255));
     // who is due: the flags the last step left in st->ped_due (ABI 5), else a pass over the state
     const uint64_t* flags = (const uint64_t*)st->ped_due;
     if (!flags) { replan_flag_kernel<<<c->n_envs, 64, 0, s>>>(*c, *st, due); flags = due; }
-    replan_select_kernel<<<1, 1024, 0, s>>>(flags, c->n_envs, c->max_peds, max_queries, count, list, *st);
-    if (max_queries > 0) replan_kernel<<<max_queries, kReplanBlock, plan_lds(Hc, Wc), s>>>(*c, *st, count, list);
+    // one workgroup per query slot; each finds its own pedestrian in the flags (replan_pick), slot 0 counts.  At least one
+    // workgroup even at max_queries = 0: the call still counts who waits.
+    replan_kernel<<<max_queries > 0 ? max_queries : 1, kReplanBlock, plan_lds(Hc, Wc), s>>>(*c, *st, flags, max_queries);
     return launch_status();
 }
 
@@ -902,9 +901,23 @@ int navsim_step_part(const navsim_config* c, const navsim_state* st, const navsi
     int rc = check_step_args(c, st, io, 0);
     if (rc != NAVSIM_OK) return rc;
     if (!st->ped_due_prev || !st->ped_due || st->ped_due == st->ped_due_prev) return NAVSIM_E_ARG;
-    if (c->ped_model != NAVSIM_PED_NONE && ped_split_on(c)) return NAVSIM_E_UNSUPPORTED;   // ped_update_kernel advances every arena
+    if (c->ped_model == NAVSIM_PED_NONE) return NAVSIM_E_ARG;                               // nobody ever waits: there are no parts
+    if (ped_split_on(c)) return NAVSIM_E_UNSUPPORTED;                                       // ped_update_kernel advances every arena
     if (c->n_envs == 0) return NAVSIM_OK;
-    return dispatch_step(c, st, io, part << 2, nullptr, (hipStream_t)stream);
+    // the arenas with a waiting pedestrian are few (~2 % per step on the c3 world): a compact launch of E / 16 workgroups,
+    // each of which takes the b-th, (b + grid)-th, ... such arena (kernels_step.hpp due_arena_pick)
+    int grid = 0;
+    navsim_config c2 = *c;
+    if (part == NAVSIM_STEP_DUE) {
+        grid = c->n_envs / 16;
+        grid = grid < 32 ? 32 : (grid > 1024 ? 1024 : grid);
+        grid = grid > c->n_envs ? c->n_envs : grid;
+        // twice the other part's threads per arena: the compact launch ends the step, and its arenas share their SIMDs with the
+        // other part's wavefronts (c3 world through the gym API, 256 / 512 / 1024 threads: 19.3 / 19.8 / 18.8 M env-steps/s --
+        // a 1024-thread workgroup has to wait for 16 free wave slots on one CU; profiles/r05_replan/README.md)
+        if (!c->step_block) { const int b = pick_step_block(c); c2.step_block = b >= 512 ? 1024 : (b >= 256 ? 512 : b); }
+    }
+    return dispatch_step(&c2, st, io, part << 2, nullptr, (hipStream_t)stream, grid);
 }
 
 int navsim_prepare(const navsim_config* c, const navsim_state* st, const navsim_step_io* io) {
@@ -916,6 +929,8 @@ int navsim_prepare(const navsim_config* c, const navsim_state* st, const navsim_
     rc = dispatch_step(c, st, io, 0, nullptr, nullptr);                       // the step
     if (rc == NAVSIM_OK) rc = dispatch_step(c, st, io, 1, nullptr, nullptr);  // first observations of a reset
     if (rc == NAVSIM_OK && c->regen_cap > 0) rc = dispatch_step(c, st, io, 1, nullptr, nullptr, c->regen_cap);   // navsim_regen's lone launch
+    if (rc == NAVSIM_OK && c->ped_model != NAVSIM_PED_NONE && !ped_split_on(c))                                  // navsim_step_part's pair
+        rc = dispatch_step(c, st, io, NAVSIM_STEP_DUE << 2, nullptr, nullptr, 32);
     g_prepare_only = false;
     if (rc != NAVSIM_OK) return rc;
     const int Hc = c->map_h / 5, Wc = c->map_w / 5;

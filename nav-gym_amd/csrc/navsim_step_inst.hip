@@ -24,6 +24,15 @@ thread_local bool g_prepare_only = false;      // set per call from the entry po
 template <int BLOCK, bool PEDS, typename Field, int RECT, int RULE, bool PINL>
 int launch_step_pinl(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
                      const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
+    if constexpr (PEDS && PINL) {
+        if (((reset_only >> 2) & 3) == NAVSIM_STEP_DUE) {          // navsim_step_part's compact launch (kernels_step.hpp)
+            if (allow_lds((const void*)navsim_step_due_kernel<BLOCK, Field, RULE, RECT>, p.lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
+            if (g_prepare_only) return NAVSIM_OK;
+            navsim_step_due_kernel<BLOCK, Field, RULE, RECT><<<grid > 0 ? grid : c->n_envs, BLOCK, p.lds, s>>>(
+                *c, *st, *io, (unsigned)step_lds_scan_bytes(c, p.park), p.park, p.rect_off);
+            return NAVSIM_OK;
+        }
+    }
     if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL>, p.lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
     if (g_prepare_only) return NAVSIM_OK;
     navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL><<<grid > 0 ? grid : c->n_envs, BLOCK, p.lds, s>>>(
@@ -91,7 +100,9 @@ int NAVSIM_CAT(navsim_step_launch_, NAVSIM_INST_BLOCK, NAVSIM_INST_PEDS)(const n
                                                                         const navsim_step_io* io, int reset_only,
                                                                         const uint8_t* mask, void* stream, int grid,
                                                                         int prepare_only) {
-    const StepPlan p = plan_step(c, st, grid);
+    // (a NAVSIM_STEP_DUE launch is the ordinary step kernel on fewer workgroups: its grid does not change the plan)
+    const bool due_part = ((reset_only >> 2) & 3) == NAVSIM_STEP_DUE;
+    const StepPlan p = plan_step(c, st, due_part ? 0 : grid);
     if (p.block != NAVSIM_INST_BLOCK) return NAVSIM_E_UNSUPPORTED;
     g_prepare_only = prepare_only != 0;
     const int rc = launch_step_family<NAVSIM_INST_BLOCK, (NAVSIM_INST_PEDS != 0)>(c, st, io, reset_only, mask, p, (hipStream_t)stream, grid);

@@ -662,17 +662,25 @@ class NavSim(object):
     # stream while a side stream runs the re-plan of the previous step and then steps the arenas that waited for it.
     # Same kernels on the same per-arena inputs in the same per-arena order -- step(t), replan(t), step(t + 1) -- so every
     # result is what the serial sequence gives.
+    overlap_big_first = True          # which stream takes the big launch (launch_step_overlapped); A/B: profiles/r05_replan/
+
     def _overlap_streams(self):
         import torch
         if not hasattr(self, "_side"):
-            self._side = torch.cuda.Stream(device=self.device, priority=-1)    # few, small workgroups: first in line for free slots
+            self._side = torch.cuda.Stream(device=self.device, priority=-1 if self.overlap_big_first else 0)
         return torch.cuda.current_stream(self.device), self._side
 
     def launch_step_overlapped(self, replan_cap=1024, reorder=True):
-        """[navsim_replan of the PREVIOUS step's flags -> navsim_step_part(DUE)] on a side stream beside
-        navsim_step_part(NOT_DUE) on the current stream, joined at the end.  Needs the costmap (planned routes)."""
+        """navsim_step_part(NOT_DUE) beside [navsim_replan of the PREVIOUS step's flags -> navsim_step_part(DUE)], on two
+        streams, joined at the end.  Needs the costmap (planned routes).
+        overlap_big_first: the big launch goes to the caller's stream, where nothing has to be waited for, and the re-plan
+        chain to a high-priority side stream behind an event (a few us later): the chain is the shorter of the two, so the
+        join finds it finished.  Its workgroups fit beside a full complement of arena workgroups (6.4 KB of LDS per query
+        since round 5's planner; with round 4's 40 KB they trickled in as arenas retired and ended when the step did).
+        False: the other way round -- the re-plan first on the caller's stream, the big launch on the side stream."""
         import torch
         main, side = self._overlap_streams()
+        big, chain = (main, side) if self.overlap_big_first else (side, main)
         key = "replan_ws_%d" % replan_cap
         if key not in self.t:
             self.t[key] = torch.zeros(self.lib.navsim_replan_workspace_bytes(C.byref(self.cfg), replan_cap), dtype=torch.uint8,
@@ -683,14 +691,14 @@ class NavSim(object):
         side.wait_stream(main)                      # the previous step (both parts were joined on `main`), regen, the actions
         # the re-plan reads st.ped_due = the flags the previous step wrote: launched BEFORE the buffers flip
         self._latest_flags()
-        rc = self.lib.navsim_replan(C.byref(self.cfg), C.byref(self.st), replan_cap, _ptr(ws), ws.numel(), C.c_void_p(side.cuda_stream))
+        rc = self.lib.navsim_replan(C.byref(self.cfg), C.byref(self.st), replan_cap, _ptr(ws), ws.numel(), C.c_void_p(chain.cuda_stream))
         if rc:
             check(rc, "navsim_replan")
         self._flip()
-        rc = self.lib.navsim_step_part(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), abi.STEP_NOT_DUE, C.c_void_p(main.cuda_stream))
+        rc = self.lib.navsim_step_part(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), abi.STEP_NOT_DUE, C.c_void_p(big.cuda_stream))
         if rc:
             check(rc, "navsim_step_part (not due)")
-        rc = self.lib.navsim_step_part(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), abi.STEP_DUE, C.c_void_p(side.cuda_stream))
+        rc = self.lib.navsim_step_part(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), abi.STEP_DUE, C.c_void_p(chain.cuda_stream))
         if rc:
             check(rc, "navsim_step_part (due)")
         main.wait_stream(side)
