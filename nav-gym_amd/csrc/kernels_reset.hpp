@@ -108,7 +108,6 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
                                                            uint8_t* __restrict__ grid_all, int* __restrict__ kind) {
     __shared__ uint8_t g[100 * 100];
     __shared__ int tx[152], ty[152];
-    __shared__ unsigned best_s;
     const int b = blockIdx.x, tid = threadIdx.x;
     int total, all;
     const int e = regen_slot(done, c.n_envs, cap, b, total, nullptr, nullptr, nullptr, nullptr, &all);
@@ -131,23 +130,39 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
     G = G > 100 ? 100 : G;
     int n_it = (it * G * G + 5000) / 10000;
     n_it = n_it < 4 ? 4 : (n_it > 150 ? 150 : n_it);
+    // create_indoor_map (map_generator.py:97-123) grows a tree: iteration k draws a point p_k, joins it to the NEAREST node so
+    // far (nodes 0 .. k: the centre and p_0 .. p_k-1; ties to the oldest) by an L-shaped corridor and adds it to the tree.  The
+    // points are draws, not results: every iteration's nearest node depends on the points alone, and carving only ever clears
+    // cells -- so the iterations are independent.  Round 5: all points, then all nearest nodes (a thread per iteration), then
+    // all corridors, three barriers in all.  (Rounds 3-4 ran the loop as written, three barriers and an LDS atomic per
+    // iteration: 313 us per call at 1000 x 1000 cells -- the second-largest kernel of a step of the reference's own
+    // configuration, profiles/r05_refdef/.  Same grid, cell for cell: the reset goldens replay the reference's generator.)
+    __shared__ unsigned char coin_s[152], near_s[152];
     for (int k = tid; k < G * G; k += 256) g[k] = 1;
-    if (tid == 0) { tx[0] = G / 2; ty[0] = G / 2; }
-    __syncthreads();
-    if (tid == 0) g[(G / 2) * G + G / 2] = 0;
     const int span = G - 2 * r - 3;
+    if (tid == 0) { tx[0] = G / 2; ty[0] = G / 2; }
+    for (int k = tid; k < n_it; k += 256) {
+        const uint64_t nk = n + 3 * (uint64_t)k;
+        tx[k + 1] = r + 2 + (int)(rg_t(tape, NAVSIM_DRAW_MAP + 3 * k, key, nk) * span);
+        ty[k + 1] = r + 2 + (int)(rg_t(tape, NAVSIM_DRAW_MAP + 3 * k + 1, key, nk + 1) * span);
+        coin_s[k] = rg_t(tape, NAVSIM_DRAW_MAP + 3 * k + 2, key, nk + 2) >= 0.5;
+    }
+    __syncthreads();
+    for (int k = tid; k < n_it; k += 256) {
+        const int px = tx[k + 1], py = ty[k + 1];
+        unsigned best = 0xFFFFFFFFu;
+        for (int j = 0; j <= k; ++j) {
+            const unsigned key_j = ((unsigned)(abs(px - tx[j]) + abs(py - ty[j])) << 8) | (unsigned)j;
+            best = key_j < best ? key_j : best;
+        }
+        near_s[k] = (unsigned char)(best & 0xFFu);
+    }
+    if (tid == 0) g[(G / 2) * G + G / 2] = 0;
+    __syncthreads();
     for (int k = 0; k < n_it; ++k) {
-        const int px = r + 2 + (int)(rg_t(tape, NAVSIM_DRAW_MAP + 3 * k, key, n) * span);
-        const int py = r + 2 + (int)(rg_t(tape, NAVSIM_DRAW_MAP + 3 * k + 1, key, n + 1) * span);
-        const bool coin = rg_t(tape, NAVSIM_DRAW_MAP + 3 * k + 2, key, n + 2) >= 0.5;
-        n += 3;
-        const int nt = k + 1;
-        if (tid == 0) best_s = 0xFFFFFFFFu;
-        __syncthreads();
-        if (tid < nt) atomicMin(&best_s, ((unsigned)(abs(px - tx[tid]) + abs(py - ty[tid])) << 8) | (unsigned)tid);
-        __syncthreads();
-        const int best = (int)(best_s & 0xFFu);
-        const int qx = tx[best], qy = ty[best];
+        const int px = tx[k + 1], py = ty[k + 1];
+        const bool coin = coin_s[k] != 0;
+        const int qx = tx[near_s[k]], qy = ty[near_s[k]];
         const int x1 = px < qx ? px : qx, x2 = px < qx ? qx : px;
         const int y1 = py < qy ? py : qy, y2 = py < qy ? qy : py;
         const bool constellation1 = (px > qx && py < qy) || (px < qx && py > qy);
@@ -162,9 +177,9 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
             int a = x1 - r + idx / side, bq = cy - r + idx % side;
             if (a >= 0 && a < G && bq >= 0 && bq < G) g[a * G + bq] = 0;
         }
-        if (tid == 0) { tx[nt] = px; ty[nt] = py; g[px * G + py] = 0; }
-        __syncthreads();
+        if (tid == 0) g[px * G + py] = 0;
     }
+    __syncthreads();
     uint8_t* out = grid_all + (size_t)b * 10000;
     for (int k = tid; k < G * G; k += 256) out[k] = g[k];
     if (tid == 0) kind[b] = G;
@@ -696,6 +711,9 @@ constexpr int kPlanMaxWpt = 8;                         // costmap words a thread
 inline size_t plan_words(int Hc, int Wc) { return (size_t)Hc * ((Wc + 63) / 64); }
 // two frontier buffers and the two direction planes (the free-cell bitmap is assembled in the planes' area first)
 inline size_t plan_lds(int Hc, int Wc) { return 4 * plan_words(Hc, Wc) * sizeof(unsigned long long); }
+// threads per query: one costmap word per thread up to 1024 words (a 200 x 200 costmap -- 1000 x 1000 cells, the reference's
+// corridor maps -- is 800 words: at 256 threads a thread owned four and a level cost four words' arithmetic; round 5)
+inline int plan_block(int Hc, int Wc) { return plan_words(Hc, Wc) > 256 ? 1024 : 256; }
 inline bool plan_fits(int Hc, int Wc) {
     return (size_t)Hc * Wc <= 65535 && plan_words(Hc, Wc) <= (size_t)kPlanMaxWpt * 256 && plan_lds(Hc, Wc) <= kPlanLdsMax;
 }
@@ -708,15 +726,24 @@ __device__ __forceinline__ void plan_levels(unsigned long long* __restrict__ fa,
     typedef unsigned long long u64;
     const int tid = threadIdx.x;
     u64 avail[WPT], dA[WPT], dB[WPT];                    // unreached free cells, direction planes (bit 0, bit 1)
-    bool own[WPT], hl[WPT], hr[WPT], hu[WPT], hd[WPT];
+    // The neighbour words of a word on the map's edge do not exist: their index is clamped to the word itself and the value
+    // masked, so that a level's reads are straight-line code -- five ds_read issued back to back, ONE wait.  (Written as
+    // `has_left ? cur[x - 1] : 0` every read sat in its own exec-masked branch with its own wait: four LDS round trips per level.)
+    int xo[WPT], xl[WPT], xr[WPT], xu[WPT], xd[WPT];
+    u64 mo[WPT], ml[WPT], mr[WPT], mu[WPT], md[WPT];
+    bool own[WPT];
 #pragma unroll
     for (int k = 0; k < WPT; ++k) {
         const int x = tid + k * BLOCK;
         own[k] = x < n_words;
-        const int j = own[k] ? x / Ww : 0, w = own[k] ? x - j * Ww : 0;
-        hl[k] = own[k] && w > 0; hr[k] = own[k] && w + 1 < Ww; hu[k] = own[k] && j > 0; hd[k] = own[k] && j + 1 < Hc;
+        xo[k] = own[k] ? x : 0;
+        const int j = xo[k] / Ww, w = xo[k] - j * Ww;
+        const bool hl = own[k] && w > 0, hr = own[k] && w + 1 < Ww, hu = own[k] && j > 0, hd = own[k] && j + 1 < Hc;
+        xl[k] = hl ? xo[k] - 1 : xo[k]; xr[k] = hr ? xo[k] + 1 : xo[k]; xu[k] = hu ? xo[k] - Ww : xo[k]; xd[k] = hd ? xo[k] + Ww : xo[k];
+        mo[k] = own[k] ? ~0ull : 0ull; ml[k] = hl ? 1ull : 0ull; mr[k] = hr ? 1ull << 63 : 0ull;
+        mu[k] = hu ? ~0ull : 0ull; md[k] = hd ? ~0ull : 0ull;
         // free cells (assembled in the planes' area by the caller) minus the goal's bit, which is level 0
-        avail[k] = own[k] ? planes[x] & ~fa[x] : 0ull;
+        avail[k] = planes[xo[k]] & ~fa[xo[k]] & mo[k];
         dA[k] = 0ull; dB[k] = 0ull;
     }
     __syncthreads();                                     // everybody has read its free words: the area is the planes' from here on
@@ -727,28 +754,25 @@ __device__ __forceinline__ void plan_levels(unsigned long long* __restrict__ fa,
         u64 f[WPT], l[WPT], r[WPT], u[WPT], d[WPT];
 #pragma unroll
         for (int k = 0; k < WPT; ++k) {
-            const int x = tid + k * BLOCK;
-            f[k] = own[k] ? cur[x] : 0ull;
-            l[k] = hl[k] ? cur[x - 1] >> 63 : 0ull; r[k] = hr[k] ? cur[x + 1] << 63 : 0ull;
-            u[k] = hu[k] ? cur[x - Ww] : 0ull; d[k] = hd[k] ? cur[x + Ww] : 0ull;
+            f[k] = cur[xo[k]]; l[k] = cur[xl[k]]; r[k] = cur[xr[k]]; u[k] = cur[xu[k]]; d[k] = cur[xd[k]];
         }
         if (stop || !more) break;
         if (tid == 0) any_s[(level + 2) % 3] = 0;      // the flag of level + 1 (last read two barriers ago)
         bool found = false;
 #pragma unroll
         for (int k = 0; k < WPT; ++k) {
-            const int x = tid + k * BLOCK;
-            const u64 R = (f[k] >> 1) | r[k];            // cells whose +i neighbour is in the frontier
-            const u64 L = (f[k] << 1) | l[k];            // ... -i neighbour
-            const u64 cand = (R | L | u[k] | d[k]) & avail[k];
-            if (own[k]) nxt[x] = cand;
+            const u64 fk = f[k] & mo[k], dk = d[k] & md[k];
+            const u64 R = (fk >> 1) | ((r[k] << 63) & mr[k]);   // cells whose +i neighbour is in the frontier
+            const u64 L = (fk << 1) | ((l[k] >> 63) & ml[k]);   // ... -i neighbour
+            const u64 cand = (R | L | (u[k] & mu[k]) | dk) & avail[k];
+            if (own[k]) nxt[xo[k]] = cand;
             avail[k] &= ~cand;
             // the walk's order +i, -i, +j, -j as two bits per cell: 0, 1, 2, 3
             const u64 t = cand & ~R;
-            dA[k] |= t & (L | ~d[k]);
+            dA[k] |= t & (L | ~dk);
             dB[k] |= t & ~L;
             found |= cand != 0ull;
-            if (x == s_word && (cand & s_bit)) *reached = 1;
+            if (xo[k] == s_word && (cand & s_bit)) *reached = 1;
         }
         if (found) any_s[(level + 1) % 3] = 1;
         __syncthreads();
@@ -892,18 +916,27 @@ __global__ __launch_bounds__(256) void plan_kernel(const uint8_t* __restrict__ c
 // navsim_regen with cfg.regen_plan = 1 (oracle/navsim_ref.c regen_planned): candidates on the costmap,
 // a path must join start and goal.  Rounds of {sample, plan, accept} kernels; no host round trip.
 // --------------------------------------------------------------------------------------------
+// Round 5: the later rounds are SPECULATED.  A slot's candidate of round r is a function of (seed, arena, episode, r, slot) and
+// the costmap alone -- not of what the earlier rounds found -- so all four candidates of every slot are drawn at once; the
+// first round is planned, then rounds 1-3 of the slots it left open in ONE launch, and the first round that passes is taken:
+// what the sequential loop of the reference (env.py:748-762, 786-804) and of the oracle ends with, after two search latencies
+// instead of four.  (Rounds 3-4 ran {accept + draw, plan} x 4 per stage, 18 launches: 8 x 111-154 us of search per step of
+// the reference's own configuration, profiles/r05_refdef/.)  Query index q = (b R + r) Q + k: slot b of the call, round r,
+// table entry / pedestrian k.
+constexpr int kRegenRounds = 4;
 struct RegenPlanWs {
     uint8_t* cost;        // [M, Hc, Wc] scratch, or the resident st.costmap (then indexed by arena)
     int cost_by_arena;
-    double* qstart;       // [M, Q, 2]
-    double* qgoal;        // [M, Q, 2]
-    double* qwp;          // [M, Q, P, 2]   robot stage only (pedestrian paths go straight into the state)
+    double* qstart;       // [M, R, Q, 2]
+    double* qgoal;        // [M, R, Q, 2]
+    double* qtheta;       // [M, R, Q]      robot stage: the heading drawn with the candidate
+    double* qwp;          // [M, R, Q, P, 2]
     const int* kind;      // [M] regen_indoor_kernel's map kind (live map size)
-    int32_t* qnwp;        // [M, Q]
-    double* qlen;         // [M, Q]
-    uint8_t* active;      // [M, Q]
+    int32_t* qnwp;        // [M, R, Q]
+    double* qlen;         // [M, R, Q]
+    unsigned long long* qcut;   // [M, R, Q]  1 = the query's route was longer than P waypoints (counted for the round that is taken)
+    uint8_t* active;      // [M, R, Q]
     uint8_t* res_robot;   // [M, K]
-    uint8_t* res_ped;     // [M, N]
     int Q;
 };
 
@@ -921,55 +954,63 @@ __device__ __forceinline__ void rgp_cell(const navsim_config& c, const uint8_t* 
     }
 }
 
-// install the new field (same copy as regen_commit_kernel) and clear the per-slot flags
-__global__ __launch_bounds__(256) void regen_install_kernel(navsim_config c, navsim_state st,
-                                                            const int* __restrict__ count, const int* __restrict__ list,
-                                                            const char* __restrict__ field_scratch, size_t field_bytes,
-                                                            RegenPlanWs ws) {
-    const int b = blockIdx.x;
-    if (b >= *count) return;
-    const int tid = threadIdx.x;
-    for (int k = tid; k < c.n_spawn; k += 256) ws.res_robot[(size_t)b * c.n_spawn + k] = 0;
-    for (int i = tid; i < c.max_peds; i += 256) ws.res_ped[(size_t)b * c.max_peds + i] = 0;
-}
-
-// robot stage, one round: accept what the previous round planned, then draw a new candidate for every
-// slot that is still open (round == 4: accept only, pick the robot, initialise the pedestrians)
-template <typename Field>
-__global__ __launch_bounds__(256) void regen_robot_round_kernel(navsim_config c, navsim_state st,
-                                                                const int* __restrict__ count,
-                                                                const int* __restrict__ list, RegenPlanWs ws, int round) {
+// robot stage: the four candidates (start, heading, goal) of every entry of the arena's start / goal table
+__global__ __launch_bounds__(256) void regen_robot_sample_kernel(navsim_config c, navsim_state st,
+                                                                 const int* __restrict__ count,
+                                                                 const int* __restrict__ list, RegenPlanWs ws) {
     const int b = blockIdx.x;
     if (b >= *count) return;
     const int e = list[b], tid = threadIdx.x;
-    const int N = c.max_peds, K = c.n_spawn, Q = ws.Q;
+    const int K = c.n_spawn, Q = ws.Q;
     const int Hc = c.map_h / 5, Wc = c.map_w / 5;
     const int live_c = live_size(c, ws.kind, b) / 5;         // candidates are cells of the live map's costmap
     const double res_c = c.resolution * 5.0;
     const uint8_t* cost = ws.cost + (size_t)(ws.cost_by_arena ? e : b) * Hc * Wc;
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
-    double* sp = (double*)st.spawn_pose + (size_t)e * K * 3;
-    double* sg = (double*)st.spawn_goal + (size_t)e * K * 2;
-    for (int k = tid; k < Q; k += 256) {
-        const size_t q = (size_t)b * Q + k;
+    for (int idx = tid; idx < kRegenRounds * Q; idx += 256) {
+        const int round = idx / Q, k = idx - round * Q;
+        const size_t q = ((size_t)b * kRegenRounds + round) * Q + k;
+        ws.qcut[q] = 0ull; ws.qnwp[q] = 0;                   // (a later round is only planned where the first one failed)
         if (k >= K) { ws.active[q] = 0; continue; }
-        uint8_t& res = ws.res_robot[(size_t)b * K + k];
-        if (round > 0 && !res) {
-            res = ws.qnwp[q] > 0 && rg_robot_path_ok(ws.qlen[q], sp[3 * k], sp[3 * k + 1], sg[2 * k], sg[2 * k + 1]);
-        }
-        ws.active[q] = 0;
-        if (res || round >= 4) continue;
         uint64_t key = rg_key(c.seed, genv, ep, 0x52504C00ULL + (uint64_t)round * 256 + (uint64_t)k), n = 0;
         double x, y, gx, gy;
         rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, n, 0, 0, 0, 0, 0, x, y);
         rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, n, 2, x, y, c.min_goal_dist, c.max_goal_dist, gx, gy);
-        sp[3 * k] = x; sp[3 * k + 1] = y; sp[3 * k + 2] = nv::kTwoPi * rg_u(key, n++);
-        sg[2 * k] = gx; sg[2 * k + 1] = gy;
+        ws.qtheta[q] = nv::kTwoPi * rg_u(key, n++);
         ws.qstart[2 * q] = x; ws.qstart[2 * q + 1] = y;
         ws.qgoal[2 * q] = gx; ws.qgoal[2 * q + 1] = gy;
         ws.active[q] = 1;
     }
-    if (round < 4) return;
+}
+
+// robot stage: every table entry takes the candidate of the first round whose path exists and is short enough
+// (env.py:756-762), else the last round's; then the robot is picked and the pedestrians' parameters are drawn
+template <typename Field>
+__global__ __launch_bounds__(256) void regen_robot_accept_kernel(navsim_config c, navsim_state st,
+                                                                 const int* __restrict__ count,
+                                                                 const int* __restrict__ list, RegenPlanWs ws) {
+    const int b = blockIdx.x;
+    if (b >= *count) return;
+    const int e = list[b], tid = threadIdx.x;
+    const int N = c.max_peds, K = c.n_spawn, Q = ws.Q;
+    const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
+    double* sp = (double*)st.spawn_pose + (size_t)e * K * 3;
+    double* sg = (double*)st.spawn_goal + (size_t)e * K * 2;
+    for (int k = tid; k < K; k += 256) {
+        int take = kRegenRounds - 1;
+        uint8_t res = 0;
+        for (int round = 0; round < kRegenRounds; ++round) {
+            const size_t q = ((size_t)b * kRegenRounds + round) * Q + k;
+            if (ws.qnwp[q] > 0 && rg_robot_path_ok(ws.qlen[q], ws.qstart[2 * q], ws.qstart[2 * q + 1], ws.qgoal[2 * q], ws.qgoal[2 * q + 1])) {
+                take = round; res = 1;
+                break;
+            }
+        }
+        const size_t q = ((size_t)b * kRegenRounds + take) * Q + k;
+        sp[3 * k] = ws.qstart[2 * q]; sp[3 * k + 1] = ws.qstart[2 * q + 1]; sp[3 * k + 2] = ws.qtheta[q];
+        sg[2 * k] = ws.qgoal[2 * q]; sg[2 * k + 1] = ws.qgoal[2 * q + 1];
+        ws.res_robot[(size_t)b * K + k] = res;
+    }
     __threadfence_block();
     __syncthreads();
     int idx = (int)(rg_key(c.seed, genv, ep, 0x5eedULL) % (uint64_t)K);
@@ -1003,14 +1044,14 @@ __global__ __launch_bounds__(256) void regen_robot_round_kernel(navsim_config c,
     }
 }
 
-// pedestrian stage, one round (round == 4: accept only)
-__global__ __launch_bounds__(256) void regen_ped_round_kernel(navsim_config c, navsim_state st,
-                                                              const int* __restrict__ count,
-                                                              const int* __restrict__ list, RegenPlanWs ws, int round) {
+// pedestrian stage: the four candidates (start at least ped_min_robot_dist from the robot, goal) of every pedestrian
+__global__ __launch_bounds__(256) void regen_ped_sample_kernel(navsim_config c, navsim_state st,
+                                                               const int* __restrict__ count,
+                                                               const int* __restrict__ list, RegenPlanWs ws) {
     const int b = blockIdx.x;
     if (b >= *count) return;
     const int e = list[b], tid = threadIdx.x;
-    const int N = c.max_peds, Q = ws.Q, P = c.max_waypoints;
+    const int N = c.max_peds, Q = ws.Q;
     const int Hc = c.map_h / 5, Wc = c.map_w / 5;
     const int live_c = live_size(c, ws.kind, b) / 5;
     const double res_c = c.resolution * 5.0;
@@ -1019,43 +1060,90 @@ __global__ __launch_bounds__(256) void regen_ped_round_kernel(navsim_config c, n
     const double rx = st.robot_pose[3 * (size_t)e], ry = st.robot_pose[3 * (size_t)e + 1];
     int n = (c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
     n = n > N ? N : n;
-    if (tid == 0 && round == 0 && st.ped_due) st.ped_due[e] = 0ull;      // new pedestrians: nobody waits for navsim_replan
-    for (int i = tid; i < Q; i += 256) {
-        const size_t q = (size_t)b * Q + i;
+    if (tid == 0 && st.ped_due) st.ped_due[e] = 0ull;      // new pedestrians: nobody waits for navsim_replan
+    for (int idx = tid; idx < kRegenRounds * Q; idx += 256) {
+        const int round = idx / Q, i = idx - round * Q;
+        const size_t q = ((size_t)b * kRegenRounds + round) * Q + i;
+        ws.qcut[q] = 0ull; ws.qnwp[q] = 0;
         if (i >= n) { ws.active[q] = 0; continue; }
-        const size_t pq = (size_t)e * N + i;
-        uint8_t& res = ws.res_ped[(size_t)b * N + i];
-        if (round > 0 && !res && ws.qnwp[q] > 0) { st.ped_n_waypoints[pq] = ws.qnwp[q]; st.ped_wp_head[pq] = 0; res = 1; }
-        ws.active[q] = 0;
-        if (res || round >= 4) continue;
         uint64_t key = rg_key(c.seed, genv, ep, 0x50504C00ULL + (uint64_t)round * 256 + (uint64_t)i), nn = 0;
         double x, y, gx, gy;
         rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, nn, 1, rx, ry, c.ped_min_robot_dist, 0, x, y);
         rgp_cell(c, cost, Wc, live_c, live_c, res_c, key, nn, 2, x, y, c.ped_min_goal_dist, 1.0e300, gx, gy);
-        st.ped_pose[pq * 3] = x; st.ped_pose[pq * 3 + 1] = y;
-        double* w = st.ped_waypoints + (pq * P) * 2;
-        w[0] = gx; w[1] = gy;
-        st.ped_n_waypoints[pq] = 1;
-        st.ped_wp_head[pq] = 0;
-        if (st.ped_goal) { st.ped_goal[pq * 2] = gx; st.ped_goal[pq * 2 + 1] = gy; }
         ws.qstart[2 * q] = x; ws.qstart[2 * q + 1] = y;
         ws.qgoal[2 * q] = gx; ws.qgoal[2 * q + 1] = gy;
         ws.active[q] = 1;
     }
 }
 
-// plan every active query of the round; ped_stage: waypoints go straight into st.ped_waypoints
-__global__ __launch_bounds__(256) void regen_plan_kernel(navsim_config c, navsim_state st, const int* __restrict__ count,
-                                                         const int* __restrict__ list, RegenPlanWs ws, int ped_stage) {
-    const int q = blockIdx.x, b = q / ws.Q, k = q - b * ws.Q;
-    if (b >= *count || !ws.active[q]) return;            // uniform per workgroup
+// pedestrian stage: every pedestrian takes the candidate of the first round whose path exists, with its waypoints every 2 m
+// (env.py:788-804); none: the last round's start and its goal as the only waypoint
+__global__ __launch_bounds__(256) void regen_ped_accept_kernel(navsim_config c, navsim_state st,
+                                                               const int* __restrict__ count,
+                                                               const int* __restrict__ list, RegenPlanWs ws) {
+    const int b = blockIdx.x;
+    if (b >= *count) return;
+    const int e = list[b], tid = threadIdx.x;
+    const int N = c.max_peds, Q = ws.Q, P = c.max_waypoints;
+    int n = (c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
+    n = n > N ? N : n;
+    __shared__ int take_s[NAVSIM_MAX_PEDS];
+    for (int i = tid; i < n; i += 256) {
+        int take = -1;
+        for (int round = 0; round < kRegenRounds && take < 0; ++round)
+            if (ws.qnwp[((size_t)b * kRegenRounds + round) * Q + i] > 0) take = round;
+        take_s[i] = take;
+        const size_t q = ((size_t)b * kRegenRounds + (take < 0 ? kRegenRounds - 1 : take)) * Q + i;
+        const size_t pq = (size_t)e * N + i;
+        st.ped_pose[pq * 3] = ws.qstart[2 * q]; st.ped_pose[pq * 3 + 1] = ws.qstart[2 * q + 1];
+        st.ped_n_waypoints[pq] = take < 0 ? 1 : ws.qnwp[q];
+        st.ped_wp_head[pq] = 0;
+        if (st.ped_goal) { st.ped_goal[pq * 2] = ws.qgoal[2 * q]; st.ped_goal[pq * 2 + 1] = ws.qgoal[2 * q + 1]; }
+        if (take < 0) {
+            double* w = st.ped_waypoints + (pq * P) * 2;
+            w[0] = ws.qgoal[2 * q]; w[1] = ws.qgoal[2 * q + 1];
+        } else if (ws.qcut[q] && st.counters) {
+            atomicAdd(&st.counters[NAVSIM_COUNTER_ROUTES_CUT], 1ull);      // a route stored cut (include/navsim.h)
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * P; idx += 256) {             // the taken rounds' waypoints into the state
+        const int i = idx / P, k = idx - i * P;
+        const int take = take_s[i];
+        if (take < 0) continue;
+        const size_t q = ((size_t)b * kRegenRounds + take) * Q + i;
+        if (k >= ws.qnwp[q]) continue;
+        const size_t pq = (size_t)e * N + i;
+        double* w = st.ped_waypoints + (pq * P) * 2;
+        w[2 * k] = ws.qwp[(q * P + k) * 2]; w[2 * k + 1] = ws.qwp[(q * P + k) * 2 + 1];
+    }
+}
+
+// plan the candidates of a stage; ped_stage: waypoints every 2 m, else every 5 m (env.py:349-354).  pass 0: the first round's
+// candidates; pass 1: the later rounds' candidates of the slots whose first round failed -- all three at once.  (Speculating
+// all four rounds of every slot in one launch was measured and dropped: a launch of a few hundred searches is bound by
+// their latency, one of four times as many by their arithmetic -- 2 x 507 us against 8 x 111, profiles/r05_refdef/.)
+// A workgroup per (slot, round, entry) item of this stage, Qs entries per arena (table entries / pedestrians); idle ones cost
+// ~10 ns each.  (Measured and dropped: a bounded launch whose workgroups loop over the items of the arenas that really
+// finished -- the loop around the search costs its registers: 162 -> 226 us per launch, profiles/r05_refdef/.)
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void regen_plan_kernel(navsim_config c, navsim_state st, const int* __restrict__ count,
+                                                         const int* __restrict__ list, RegenPlanWs ws, int ped_stage, int pass, int Qs) {
+    const int item = (int)blockIdx.x;
+    const int b = item / (kRegenRounds * Qs), rem = item - b * (kRegenRounds * Qs), round = rem / Qs, k = rem - round * Qs;
+    if (b >= *count) return;
+    const size_t q = ((size_t)b * kRegenRounds + round) * ws.Q + k;
+    if (!ws.active[q] || (pass == 0) != (round == 0)) return;      // uniform per workgroup
+    if (pass) {                                          // did the slot's first round pass?  (the accept kernels' own tests)
+        const size_t q0 = q - (size_t)round * ws.Q;
+        const bool ok0 = ws.qnwp[q0] > 0 && (ped_stage || rg_robot_path_ok(ws.qlen[q0], ws.qstart[2 * q0], ws.qstart[2 * q0 + 1],
+                                                                            ws.qgoal[2 * q0], ws.qgoal[2 * q0 + 1]));
+        if (ok0) return;
+    }
     const int Hc = c.map_h / 5, Wc = c.map_w / 5, P = c.max_waypoints;
-    double* w = ped_stage ? st.ped_waypoints + (((size_t)list[b] * c.max_peds + k) * P) * 2
-                          : ws.qwp + (size_t)q * P * 2;
-    plan_query(ws.cost + (size_t)(ws.cost_by_arena ? list[b] : b) * Hc * Wc, Hc, Wc, c.resolution * 5.0, c.origin_x, c.origin_y, ws.qstart[2 * q],
-               ws.qstart[2 * q + 1], ws.qgoal[2 * q], ws.qgoal[2 * q + 1], ped_stage ? 2.0 : 5.0, P, w, ws.qnwp + q,
-               nullptr, ped_stage ? nullptr : ws.qlen + q,
-               (ped_stage && st.counters) ? st.counters + NAVSIM_COUNTER_ROUTES_CUT : nullptr);
+    plan_query<BLOCK>(ws.cost + (size_t)(ws.cost_by_arena ? list[b] : b) * Hc * Wc, Hc, Wc, c.resolution * 5.0, c.origin_x, c.origin_y,
+                      ws.qstart[2 * q], ws.qstart[2 * q + 1], ws.qgoal[2 * q], ws.qgoal[2 * q + 1], ped_stage ? 2.0 : 5.0, P,
+                      ws.qwp + q * P * 2, ws.qnwp + q, nullptr, ped_stage ? nullptr : ws.qlen + q, ped_stage ? ws.qcut + q : nullptr);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1078,14 +1166,11 @@ __global__ __launch_bounds__(64) void replan_flag_kernel(navsim_config c, navsim
     if (i == 0) due[e] = m;
 }
 
-#ifndef NAVSIM_REPLAN_BLOCK
-#define NAVSIM_REPLAN_BLOCK 256
-#endif
-constexpr int kReplanBlock = NAVSIM_REPLAN_BLOCK;
 // The b-th flagged pedestrian in (arena, pedestrian) order, as q = e N + i, or -1 when fewer are flagged; total = how many
 // are.  Every workgroup of replan_kernel finds its own query this way (round 5): the ordered compaction used to be a
 // kernel of its own (replan_select_kernel, one workgroup) in front of the searches -- 5 us on an idle chip, 33 us beside a
 // step kernel that fills it, and serial either way.  32 KB of flags per 4096 arenas, read from L2 by every workgroup.
+template <int kReplanBlock>
 __device__ __forceinline__ int replan_pick(const uint64_t* __restrict__ due, int E, int N, int b, int& total) {
     __shared__ int wave_tot[kReplanBlock / 64], q_s, total_s;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1121,6 +1206,7 @@ __device__ __forceinline__ int replan_pick(const uint64_t* __restrict__ due, int
     return q_s;
 }
 
+template <int kReplanBlock>
 __global__ __launch_bounds__(kReplanBlock) void replan_kernel(navsim_config c, navsim_state st, const uint64_t* __restrict__ due,
                                                               int cap) {
     __shared__ double goal_s[2];
@@ -1129,7 +1215,7 @@ __global__ __launch_bounds__(kReplanBlock) void replan_kernel(navsim_config c, n
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.x, N = c.max_peds, P = c.max_waypoints, tid = threadIdx.x;
     int total;
-    const int q = replan_pick(due, c.n_envs, N, b, total);
+    const int q = replan_pick<kReplanBlock>(due, c.n_envs, N, b, total);
     if (b == 0 && tid == 0) {
         const int served = total < cap ? total : cap;
         count_served(st, NAVSIM_COUNTER_REPLAN_SERVED, served, total - served);

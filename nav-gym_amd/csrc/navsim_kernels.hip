@@ -490,12 +490,12 @@ size_t navsim_regen_workspace_bytes(const navsim_config* c) {
     b += M * (10000 + sizeof(int)) + 512;                   // corridor grids, map kinds
     if (c->regen_plan) {
         const size_t cc = (size_t)(c->map_h / 5) * (c->map_w / 5), P = (size_t)(c->max_waypoints > 0 ? c->max_waypoints : 1);
-        const size_t Q = (size_t)(c->n_spawn > c->max_peds ? c->n_spawn : c->max_peds);
+        const size_t Q = (size_t)(c->n_spawn > c->max_peds ? c->n_spawn : c->max_peds), R = kRegenRounds;
         b += M * cc + 256;                                            // costmaps
-        b += M * Q * (2 + 2 + 2 * P + 1) * sizeof(double) + 256;      // start, goal, waypoints, length
-        b += M * Q * sizeof(int32_t) + 256;                           // waypoint counts
-        b += M * (Q + (size_t)c->n_spawn + (size_t)c->max_peds) + 256;   // active, resolved flags
-        b += 8 * 256;                                                 // alignment of the ten sub-buffers
+        b += M * R * Q * (2 + 2 + 1 + 2 * P + 1 + 1) * sizeof(double) + 256;   // start, goal, heading, waypoints, length, cut flag
+        b += M * R * Q * sizeof(int32_t) + 256;                       // waypoint counts
+        b += M * (R * Q + (size_t)c->n_spawn) + 256;                  // active, resolved flags
+        b += 12 * 256;                                                // alignment of the sub-buffers
     }
     return b + 1024;
 }
@@ -523,7 +523,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     if (workspace_bytes < navsim_regen_workspace_bytes(c) || !st->spawn_pose || !st->spawn_goal) return NAVSIM_E_ARG;
     if (c->regen_plan && (c->max_waypoints < 1 || c->max_waypoints > NAVSIM_MAX_WAYPOINTS)) return NAVSIM_E_ARG;
     if (c->regen_plan && (c->n_spawn > 256 || c->map_h < 5 || !plan_fits(c->map_h / 5, c->map_w / 5) ||
-                          allow_lds((const void*)regen_plan_kernel, plan_lds(c->map_h / 5, c->map_w / 5)) != NAVSIM_OK))
+                          plan_lds(c->map_h / 5, c->map_w / 5) > 64 * 1024))
         return NAVSIM_E_UNSUPPORTED;
     int rc = check_step_args(c, st, io, 1);
     if (rc != NAVSIM_OK) return rc;
@@ -599,7 +599,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
                                                                     (const char*)ovf_scratch, cells * sizeof(float));
     }
     if (c->regen_plan) {
-        const int Hc = H / 5, Wc = W / 5, P = c->max_waypoints;
+        const int Hc = H / 5, Wc = W / 5, P = c->max_waypoints, R = kRegenRounds;
         const size_t cc = (size_t)Hc * Wc;
         const int Q = c->n_spawn > c->max_peds ? c->n_spawn : c->max_peds;
         auto take = [&](size_t bytes) { off = (off + 255) & ~(size_t)255; char* p = w + off; off += bytes; return p; };
@@ -609,30 +609,37 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         ws.cost = (uint8_t*)take((size_t)M * cc);
         ws.cost_by_arena = st->costmap != nullptr;
         if (st->costmap) ws.cost = st->costmap;
-        ws.qstart = (double*)take((size_t)M * Q * 2 * sizeof(double));
-        ws.qgoal = (double*)take((size_t)M * Q * 2 * sizeof(double));
-        ws.qwp = (double*)take((size_t)M * Q * P * 2 * sizeof(double));
-        ws.qlen = (double*)take((size_t)M * Q * sizeof(double));
-        ws.qnwp = (int32_t*)take((size_t)M * Q * sizeof(int32_t));
-        ws.active = (uint8_t*)take((size_t)M * Q);
+        ws.qstart = (double*)take((size_t)M * R * Q * 2 * sizeof(double));
+        ws.qgoal = (double*)take((size_t)M * R * Q * 2 * sizeof(double));
+        ws.qtheta = (double*)take((size_t)M * R * Q * sizeof(double));
+        ws.qwp = (double*)take((size_t)M * R * Q * P * 2 * sizeof(double));
+        ws.qlen = (double*)take((size_t)M * R * Q * sizeof(double));
+        ws.qcut = (unsigned long long*)take((size_t)M * R * Q * sizeof(unsigned long long));
+        ws.qnwp = (int32_t*)take((size_t)M * R * Q * sizeof(int32_t));
+        ws.active = (uint8_t*)take((size_t)M * R * Q);
         ws.res_robot = (uint8_t*)take((size_t)M * c->n_spawn);
-        ws.res_ped = (uint8_t*)take((size_t)M * (c->max_peds > 0 ? c->max_peds : 1));
         const size_t lds = plan_lds(Hc, Wc);
         costmap_kernel<<<dim3(((int)cc + 255) / 256, M), 256, 0, s>>>(occ, H, W, ws.cost, count,
                                                                       st->costmap ? list : nullptr);
-        regen_install_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, fscratch, fbytes, ws);
-        for (int round = 0; round <= 4; ++round) {
-            if (c->field_format == NAVSIM_FIELD_F32)
-                regen_robot_round_kernel<FieldF32><<<M, 256, 0, s>>>(*c, *st, count, list, ws, round);
-            else
-                regen_robot_round_kernel<FieldU16T><<<M, 256, 0, s>>>(*c, *st, count, list, ws, round);
-            if (round < 4) regen_plan_kernel<<<M * Q, 256, lds, s>>>(*c, *st, count, list, ws, 0);
+        // the rounds of the reference's rejection loops (kernels_reset.hpp): all candidates drawn at once, round 0 planned, then
+        // rounds 1-3 of the slots it left open in one launch, the first round that passes taken -- four launches per stage
+        auto plan_pass = [&](int ped_stage, int pass) {
+            const int Qs = ped_stage ? c->max_peds : c->n_spawn;
+            const int grid = M * R * Qs;
+            if (plan_block(Hc, Wc) == 1024) regen_plan_kernel<1024><<<grid, 1024, lds, s>>>(*c, *st, count, list, ws, ped_stage, pass, Qs);
+            else                            regen_plan_kernel<256><<<grid, 256, lds, s>>>(*c, *st, count, list, ws, ped_stage, pass, Qs);
+        };
+        regen_robot_sample_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, ws);
+        plan_pass(0, 0);
+        plan_pass(0, 1);
+        if (c->field_format == NAVSIM_FIELD_F32) regen_robot_accept_kernel<FieldF32><<<M, 256, 0, s>>>(*c, *st, count, list, ws);
+        else                                     regen_robot_accept_kernel<FieldU16T><<<M, 256, 0, s>>>(*c, *st, count, list, ws);
+        if (c->ped_model != NAVSIM_PED_NONE && c->max_peds > 0) {
+            regen_ped_sample_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, ws);
+            plan_pass(1, 0);
+            plan_pass(1, 1);
+            regen_ped_accept_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, ws);
         }
-        if (c->ped_model != NAVSIM_PED_NONE && c->max_peds > 0)
-            for (int round = 0; round <= 4; ++round) {
-                regen_ped_round_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, ws, round);
-                if (round < 4) regen_plan_kernel<<<M * Q, 256, lds, s>>>(*c, *st, count, list, ws, 1);
-            }
     } else if (st->costmap) {
         costmap_kernel<<<dim3(((H / 5) * (W / 5) + 255) / 256, M), 256, 0, s>>>(occ, H, W, st->costmap, count, list);
     }
@@ -715,8 +722,7 @@ int navsim_replan(const navsim_config* c, const navsim_state* st, int32_t max_qu
     if (c->ped_model == NAVSIM_PED_NONE || c->n_envs == 0) return NAVSIM_OK;
     if (c->max_waypoints < 1 || c->max_waypoints > NAVSIM_MAX_WAYPOINTS) return NAVSIM_E_ARG;
     const int Hc = c->map_h / 5, Wc = c->map_w / 5;
-    if (Hc < 1 || Wc < 1 || !plan_fits(Hc, Wc) || allow_lds((const void*)replan_kernel, plan_lds(Hc, Wc)) != NAVSIM_OK)
-        return NAVSIM_E_UNSUPPORTED;
+    if (Hc < 1 || Wc < 1 || !plan_fits(Hc, Wc) || plan_lds(Hc, Wc) > 64 * 1024) return NAVSIM_E_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     uint64_t* due = (uint64_t*)((char*)workspace + 256 + (((size_t)max_queries * sizeof(int32_t) + 255) & ~(size_t)255));
     // who is due: the flags the last step left in st->ped_due (ABI 5), else a pass over the state
@@ -724,7 +730,8 @@ int navsim_replan(const navsim_config* c, const navsim_state* st, int32_t max_qu
     if (!flags) { replan_flag_kernel<<<c->n_envs, 64, 0, s>>>(*c, *st, due); flags = due; }
     // one workgroup per query slot; each finds its own pedestrian in the flags (replan_pick), slot 0 counts.  At least one
     // workgroup even at max_queries = 0: the call still counts who waits.
-    replan_kernel<<<max_queries > 0 ? max_queries : 1, kReplanBlock, plan_lds(Hc, Wc), s>>>(*c, *st, flags, max_queries);
+    if (plan_block(Hc, Wc) == 1024) replan_kernel<1024><<<max_queries > 0 ? max_queries : 1, 1024, plan_lds(Hc, Wc), s>>>(*c, *st, flags, max_queries);
+    else                            replan_kernel<256><<<max_queries > 0 ? max_queries : 1, 256, plan_lds(Hc, Wc), s>>>(*c, *st, flags, max_queries);
     return launch_status();
 }
 
@@ -936,8 +943,6 @@ int navsim_prepare(const navsim_config* c, const navsim_state* st, const navsim_
     const int Hc = c->map_h / 5, Wc = c->map_w / 5;
     if (Hc >= 1 && Wc >= 1 && plan_fits(Hc, Wc)) {                           // the planners' LDS-resident search
         (void)allow_lds((const void*)plan_kernel, plan_lds(Hc, Wc));
-        (void)allow_lds((const void*)regen_plan_kernel, plan_lds(Hc, Wc));
-        (void)allow_lds((const void*)replan_kernel, plan_lds(Hc, Wc));
     }
     return NAVSIM_OK;
 }

@@ -158,7 +158,7 @@ class NavGymEnv(_EnvBase):
                  reward_discomfort_factor, env_param_range, *,
                  num_envs=1, n_beams=None, lidar=None, map_size=400, pedestrian_model="sfm", policy_weights=None,
                  num_humans=None, device="cuda:0", seed=0, env_index_base=0, auto_reset=None,
-                 field_format=abi.FIELD_U16T, n_spawn=16, randomize_maps=False, plan_paths=True,
+                 field_format=abi.FIELD_U16T, n_spawn=None, randomize_maps=False, plan_paths=True,
                  action_kind="twist", clip_actions=False, max_waypoints=64, march_rule=None, use_graphs=None):
         from . import lib
         if robot_type not in robots.ROBOTS:
@@ -205,6 +205,11 @@ class NavGymEnv(_EnvBase):
         self._num_humans_fixed = num_humans
         self._episode_batch = 0
         self.randomize_maps = bool(randomize_maps)
+        # start / goal pairs kept per arena: what an arena restarts from IN PLACE.  A world that draws a new map per episode
+        # only does that for arenas beyond cfg.regen_cap in one step -- 4 pairs there (each is planned at every reset:
+        # env.py:342-383), 16 where the map stays
+        if n_spawn is None:
+            n_spawn = 4 if self.randomize_maps else 16
         self.replan_cap = 1024                              # pedestrians re-planned per step, at most
         self.use_graphs = bool(randomize_maps) if use_graphs is None else bool(use_graphs)
         self._graphed = False

@@ -662,7 +662,7 @@ class NavSim(object):
     # stream while a side stream runs the re-plan of the previous step and then steps the arenas that waited for it.
     # Same kernels on the same per-arena inputs in the same per-arena order -- step(t), replan(t), step(t + 1) -- so every
     # result is what the serial sequence gives.
-    overlap_big_first = True          # which stream takes the big launch (launch_step_overlapped); A/B: profiles/r05_replan/
+    overlap_big_first = False         # which stream takes the big launch (launch_step_overlapped); A/B: profiles/r05_replan/
 
     def _overlap_streams(self):
         import torch
@@ -673,11 +673,10 @@ class NavSim(object):
     def launch_step_overlapped(self, replan_cap=1024, reorder=True):
         """navsim_step_part(NOT_DUE) beside [navsim_replan of the PREVIOUS step's flags -> navsim_step_part(DUE)], on two
         streams, joined at the end.  Needs the costmap (planned routes).
-        overlap_big_first: the big launch goes to the caller's stream, where nothing has to be waited for, and the re-plan
-        chain to a high-priority side stream behind an event (a few us later): the chain is the shorter of the two, so the
-        join finds it finished.  Its workgroups fit beside a full complement of arena workgroups (6.4 KB of LDS per query
-        since round 5's planner; with round 4's 40 KB they trickled in as arenas retired and ended when the step did).
-        False: the other way round -- the re-plan first on the caller's stream, the big launch on the side stream."""
+        Which stream takes what (overlap_big_first = False, measured: profiles/r05_replan/README.md): the re-plan chain runs on
+        the caller's stream, where nothing has to be waited for, and the big launch on a side stream behind an event -- a few us
+        later, so the searches' workgroups are resident before 4096 arena workgroups take every slot of the chip
+        (c3 world through the gym API: 19.2-19.4 M env-steps/s; the other way round 18.6 M; serial, round 4: 15.5 M)."""
         import torch
         main, side = self._overlap_streams()
         big, chain = (main, side) if self.overlap_big_first else (side, main)
@@ -688,7 +687,8 @@ class NavSim(object):
         ws = self.t[key]
         if reorder:
             self._reorder()
-        side.wait_stream(main)                      # the previous step (both parts were joined on `main`), regen, the actions
+        for s_ in {big, chain} - {main}:            # the previous step (both parts were joined on `main`), regen, the actions
+            s_.wait_stream(main)
         # the re-plan reads st.ped_due = the flags the previous step wrote: launched BEFORE the buffers flip
         self._latest_flags()
         rc = self.lib.navsim_replan(C.byref(self.cfg), C.byref(self.st), replan_cap, _ptr(ws), ws.numel(), C.c_void_p(chain.cuda_stream))
@@ -701,7 +701,8 @@ class NavSim(object):
         rc = self.lib.navsim_step_part(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), abi.STEP_DUE, C.c_void_p(chain.cuda_stream))
         if rc:
             check(rc, "navsim_step_part (due)")
-        main.wait_stream(side)
+        for s_ in {big, chain} - {main}:
+            main.wait_stream(s_)
         self.cur = 1 - self.cur
 
     def step_overlapped(self, action=None, replan_cap=1024):

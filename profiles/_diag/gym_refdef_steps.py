@@ -1,0 +1,29 @@
+"""The reference's own configuration through the gym API (bench.py gym_api.reference_defaults): every registered default of
+NavGym-v0, 512 beams, 1000 x 1000 arenas (corridor maps) / 400 x 400 outdoor maps, 5-15 pedestrians on planned routes, a new map
+per episode.  Under rocprofv3 --kernel-trace --stats: what a step of that world is made of (profiles/r05_refdef/)."""
+import os, sys, time
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "nav-gym_amd"))
+import torch, nav_gym_env
+E = int(os.environ.get("NAVSIM_ENVS", "1024"))
+kw = {}
+if os.environ.get("NAVSIM_GRAPHS"):
+    kw["use_graphs"] = os.environ["NAVSIM_GRAPHS"] == "1"
+env = nav_gym_env.make("NavGym-v0", num_envs=E, map_size="reference", randomize_maps=True, device="cuda:0", seed=1234, **kw)
+env.reset()
+g = torch.Generator(device="cuda:0"); g.manual_seed(78)
+K, Wm = int(os.environ.get("NAVSIM_STEPS", "100")), 20
+acts = torch.rand((K + Wm, E, 2), generator=g, device="cuda:0", dtype=torch.float64)
+acts[..., 0] *= 0.5; acts[..., 1] = acts[..., 1] * 1.28 - 0.64
+for t in range(Wm):
+    env.step(acts[t])
+torch.cuda.synchronize()
+e0 = int(env.sim.t["episode"].sum().item())
+t0 = time.perf_counter()
+for t in range(K):
+    env.step(acts[Wm + t])
+torch.cuda.synchronize()
+el = time.perf_counter() - t0
+e1 = int(env.sim.t["episode"].sum().item())
+print("gym API, reference defaults, %d arenas: %.3f M env-steps/s, %.4f ms per step, %.1f episodes ended per step; counters %s"
+      % (E, E * K / el / 1e6, el / K * 1e3, (e1 - e0) / K, env.counters()))
