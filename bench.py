@@ -30,6 +30,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "nav-gym_amd"))
 
+# vector instructions of one probe round of the march (position 4, tile index 4, two-rectangle record decode 13, exact sqrt of
+# the integer d2 6, march step 4, hit test and selects 5), counted in the ISA of the c2 kernel
+PROBE_ROUND_VALU = 36
+PROBE_ROUND_FROM = ("navsim_step_kernel<256, false, FieldU16TT<false>, NAVSIM_MARCH_F32, 2, false>, loop .LBB12_96 of "
+                    "hipcc -S --cuda-device-only nav-gym_amd/csrc/navsim_step_inst.hip (profiles/r05_c2/probe_round_isa.txt)")
+
 WORKLOADS = {
     # envs = arenas per GPU (weak scaling), total = arenas of the whole job (strong scaling)
     "c1": dict(envs=1, total=1, beams=64, size=100, peds=0),
@@ -262,7 +268,7 @@ def profiled_counters(workload, E, field, rects, indoor_ratio=0.0):
     from nav_gym_amd import lib
     reason = None
     # profiles/<round>_<workload>/ and its variants of other launch shapes (…_indoor: corridor maps only)
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         for variant in ("", "_indoor"):
             tp = os.path.join(ROOT, "profiles", "%s_%s%s" % (rnd, workload, variant), "traffic.json")
             if not os.path.exists(tp):
@@ -853,6 +859,30 @@ def measure(args, scaling, ctx, light=False):
             pr = out["cpu_baseline"].pop("probes_per_ray")
             out["work"].update(probes_per_ray_mean=pr["mean"], probes_per_ray_p50=pr["p50"], probes_per_ray_p99=pr["p99"],
                                probes_per_ray_from="oracle/navsim_ref.c trace_ray (calc_range, env.py:425): " + pr["sample"])
+        # The bound the kernel actually has (round-4 verdict): vector issue.  From the committed PMC profile of THESE sources:
+        # how busy the vector units are, how many vector instructions an arena-step issues, and how many of them an ideal
+        # march would need -- every ray's probes (oracle histogram) x the probe round's instructions, 64 rays per instruction.
+        valu = {"probe_round_valu_insts": PROBE_ROUND_VALU, "probe_round_from": PROBE_ROUND_FROM}
+        if prof:
+            cnt = prof.get("counters", {})
+            valu["issue_frac"] = prof.get("valu_issue_frac")
+            if cnt.get("SQ_INSTS_VALU"):
+                valu["valu_insts_per_env_step"] = cnt["SQ_INSTS_VALU"] / float(E)
+            if cnt.get("SQ_THREAD_CYCLES_VALU") and cnt.get("SQ_ACTIVE_INST_VALU"):
+                # lanes the exec mask leaves on, per vector instruction (the march's own predication is finer: next figure)
+                valu["exec_lane_frac"] = cnt["SQ_THREAD_CYCLES_VALU"] / (cnt["SQ_ACTIVE_INST_VALU"] * 64.0)
+            valu["source"] = prof["source"]
+        else:
+            valu["unavailable"] = why_not
+        mean_probes = out["work"].get("probes_per_ray_mean")
+        if mean_probes:
+            ideal = B * mean_probes * PROBE_ROUND_VALU / 64.0
+            valu["ideal_march_insts_per_env_step"] = ideal
+            if valu.get("valu_insts_per_env_step"):
+                valu["ideal_march_frac"] = ideal / valu["valu_insts_per_env_step"]
+                # the rest: lanes idle inside probe rounds (a 64-beam chunk marches until its slowest ray), beam directions,
+                # noise, second scans after a crash, observation packing
+        out["roofline"]["valu"] = valu
         del sim
         torch.cuda.empty_cache()
         return out

@@ -18,6 +18,7 @@ struct StepShared {
     float t1;                     // march parameter after the shared first probe (origin cell)
     float r_all;                  // >= 0: every beam has this raw range (origin occupied / no march)
     unsigned long long step_key;  // scan-noise counter of this step
+    unsigned long long rescan_key;  // ... of the second scan (crash revert: step_key + 1; restart: the new episode's reset key)
     int next_chunk;               // scan: next 64-beam chunk to hand to a wavefront (reset before every scan)
     int park_count, park_next;    // scan: parked rays (written / handed out), reset with next_chunk
     double wave_ratio[kMaxWaves];
@@ -1046,6 +1047,7 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
             first_probe<RULE>(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
             sh.step_key = (unsigned long long)st.episode[e] * 0x100000000ULL +
                           (unsigned long long)(reset_only ? 0 : st.steps[e]) * 2ULL;
+            sh.rescan_key = sh.step_key + 1;
             sh.next_chunk = 0; sh.park_count = 0; sh.park_next = 0;
         }
     }
@@ -1159,6 +1161,10 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
                 goal_g[0] = sg[0]; goal_g[1] = sg[1];
                 st.episode[e] += 1;
                 st.steps[e] = 0;
+                // the first observation of the new episode draws its noise from the key a reset-only launch would use -- the
+                // same whether this launch scans it or navsim_regen does (cfg.defer_reset_scan), i.e. whatever the shard size
+                // (round-4 advisor: the two paths used different keys)
+                sh.rescan_key = (unsigned long long)st.episode[e] * 0x100000000ULL;
                 // cfg.defer_reset_scan: the first observation of the new episode comes from the navsim_regen call that follows
                 // (one masked launch for every finished arena): no second scan here, the rows stay as scan A left them
                 sh.respawn = 1; sh.rescan = c.defer_reset_scan ? 0 : 1;
@@ -1183,7 +1189,7 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
             if (sh.respawn) n_hist = 0;
             int c2, d2;
             scan_beams_pred<BLOCK, Field, PEDS, RULE, RECT>(c, sh, field, rects, st.beam_table, prims, dir_lds, rng_lds, park, park_lanes, st.scan_threshold,
-                                                                 st.scan_discomfort, obs_row, n_hist, noise_std, step_key + 1, genv, c2, d2);
+                                                                 st.scan_discomfort, obs_row, n_hist, noise_std, sh.rescan_key, genv, c2, d2);
         }
     }
 

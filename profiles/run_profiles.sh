@@ -16,6 +16,8 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d "$OUT/pmc_ea" -o pmc -- python3 "$R/bench.py" $ARGS --no-cpu-baseline > "$OUT/pmc_ea.log" 2>&1
 # vector-issue fraction (traffic.json valu_issue_frac -> bench.py roofline.issue_frac_profiled)
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_issue" -o pmc -- python3 "$R/bench.py" $ARGS --no-cpu-baseline > "$OUT/pmc_issue.log" 2>&1
+# lanes on per vector instruction (bench.py roofline.valu.exec_lane_frac)
+rocprofv3 --pmc SQ_THREAD_CYCLES_VALU --output-format csv -d "$OUT/pmc_lanes" -o pmc -- python3 "$R/bench.py" $ARGS --no-cpu-baseline > "$OUT/pmc_lanes.log" 2>&1
 if [ "${NAVSIM_PROFILE_DEEP:-0}" = "1" ]; then
 rocprofv3 --pmc TCC_REQ_sum TCC_READ_sum TCC_EA0_RDREQ_DRAM_sum TCC_TAG_STALL_sum --output-format csv -d "$OUT/pmc_tcc" -o pmc -- python3 "$R/bench.py" $ARGS --no-cpu-baseline > "$OUT/pmc_tcc.log" 2>&1
 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum --output-format csv -d "$OUT/pmc_tcp" -o pmc -- python3 "$R/bench.py" $ARGS --no-cpu-baseline > "$OUT/pmc_tcp.log" 2>&1

@@ -995,6 +995,42 @@ def test_cut_routes_resume_to_their_goal(gpu):
     assert same.sum() >= 3
 
 
+def test_restart_noise_does_not_depend_on_who_scans(gpu):
+    """Round-4 advisor: an arena beyond cfg.regen_cap restarts in place; its first observation was scanned by the step
+    (noise key of the old episode's step) or, with cfg.defer_reset_scan, by navsim_regen's masked launch (the new
+    episode's reset key) -- the same arena saw different noise depending on the batch size that picks the mode.  Both
+    paths draw from the reset key now: with scan noise ON, the observations after step + regen are identical."""
+    from helpers import finished_world
+    from nav_gym_amd import robots
+    E, size, N = 24, 200, 4
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_SFM, n_spawn=4,
+                                 auto_reset=1, seed=5, field_format=abi.FIELD_F32, regen_cap=5, min_goal_dist=3.0,
+                                 max_goal_dist=8.0, spawn_clearance=0.8, ped_min_robot_dist=1.5, ped_min_goal_dist=3.0,
+                                 add_scan_noise=1)
+    gpu.world.lidar_full_circle(cfg, 90)
+    occ = gpu.world.make_maps(E, size, 5)
+    thr = ref.scan_threshold(cfg, robots.footprint_array("keti", "threshold_footprint"))
+    dthr = ref.scan_threshold(cfg, robots.footprint_array("keti", "discomfort_threshold_footprint"))
+    host = finished_world(cfg, occ, ref.build_dt(occ), 3, (thr, dthr))       # every robot already stands on its goal
+    host["scan_noise_std"][:] = 0.03
+    # spread the in-place restarts over free cells (finished_world's table holds the finish pose only)
+    for e in range(E):
+        free = np.argwhere(host["field"][e] > 30)
+        pick = free[np.random.default_rng(e).integers(0, len(free), 4)]
+        host["spawn_pose"][e, :, 0] = (pick[:, 1] + 0.5) * cfg.resolution; host["spawn_pose"][e, :, 1] = (pick[:, 0] + 0.5) * cfg.resolution
+    obs = []
+    for defer in (0, 1):
+        c = cfg.copy(); c.defer_reset_scan = defer
+        g = gpu.sim.NavSim(c, {k: v.copy() for k, v in host.items()})
+        g.reset_obs()
+        _, out = g.step(_t(gpu, np.zeros((E, 2))))
+        assert bool(out["done"].all())
+        obs.append(g.regen().cpu().numpy().copy())
+        assert g.counters()["regen_unserved"] == E - 5
+    _eq(obs[0], obs[1], "observations after step + regen, scan noise on, step-scanned vs regen-scanned restarts")
+    assert len(np.unique(obs[0][5:, :90])) > 100             # the rows of the in-place restarts carry noise
+
+
 def test_caps_are_counted(gpu):
     """Round-3 verdict: arenas beyond cfg.regen_cap "play on in place" and pedestrians beyond navsim_replan's
     max_queries wait -- silently.  navsim_state.counters makes both observable: device == oracle, and the numbers are
