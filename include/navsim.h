@@ -405,6 +405,11 @@ int    navsim_build_rect_index(const void* table, int32_t n_maps, int32_t map_h,
 /* closed [n_maps] int32: 1 where every cell of the map's outer ring of 3 cells is occupied (navsim_config.closed_maps may
  * be set when all are 1). */
 int    navsim_maps_closed(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t map_w, int32_t* closed, void* stream);
+/* The same test on a WORLD: *n_open (device int32, zeroed by the caller) receives the number of arenas of st->field whose
+ * outer ring of 3 cells has a free cell (a cell is occupied exactly when its distance is 0).  cfg->closed_maps is an
+ * assertion the march of the LDS form relies on without testing it: a caller who assembles a world checks it with this
+ * (nav_gym_amd/sim.py NavSim does, once, at construction); every map navsim_regen draws is closed by construction. */
+int    navsim_world_closed(const navsim_config* cfg, const navsim_state* st, int32_t* n_open, void* stream);
 size_t navsim_build_rects_workspace_bytes(int32_t n_maps, int32_t map_h, int32_t map_w);
 int    navsim_build_rects(const uint8_t* occ, int32_t n_maps, int32_t map_h, int32_t map_w, const void* field,
                           int32_t format, const float* overflow, void* table, void* workspace, size_t workspace_bytes,

@@ -171,6 +171,29 @@ __global__ __launch_bounds__(256) void maps_closed_kernel(const uint8_t* __restr
     if (tid == 0) closed[m] = open_cells ? 0 : 1;
 }
 
+// navsim_world_closed: the same test on a world's DISTANCE FIELD (a cell is occupied exactly when its distance is 0), one
+// workgroup per arena; *n_open counts the arenas whose ring has a free cell.  What checks a caller's cfg.closed_maps
+// (round-4 advisor: the assertion was never verified against the world it was made about).
+template <typename Field>
+__global__ __launch_bounds__(256) void world_closed_kernel(const void* __restrict__ field, const float* __restrict__ overflow,
+                                                           int H, int W, int32_t* __restrict__ n_open) {
+    const int e = blockIdx.x, tid = threadIdx.x, ring = kRectClosedRing;
+    const Field f(field, overflow, e, H, W);
+    int open_cells = 0;
+    if (H <= 2 * ring || W <= 2 * ring) open_cells = 1;
+    else {
+        const int n_row_cells = 2 * ring * W, n_col_cells = 2 * ring * (H - 2 * ring);
+        for (int k = tid; k < n_row_cells + n_col_cells; k += 256) {
+            int x, y;
+            if (k < n_row_cells) { const int r = k / W; x = k - r * W; y = r < ring ? r : H - 2 * ring + r; }
+            else { const int q = k - n_row_cells, r = q / (2 * ring), cidx = q - r * 2 * ring; y = ring + r; x = cidx < ring ? cidx : W - 2 * ring + cidx; }
+            if (!f.occupied(f.load(x, y))) open_cells = 1;
+        }
+    }
+    open_cells = __syncthreads_or(open_cells);
+    if (tid == 0 && open_cells) atomicAdd(n_open, 1);
+}
+
 // ---- builder pass 1: transpose of the occupancy grid (32x32 tiles through LDS), so that the vertical runs can be
 // found by the same coalesced row kernel
 __global__ __launch_bounds__(256) void rect_transpose_kernel(const uint8_t* __restrict__ occ, uint8_t* __restrict__ occT,

@@ -203,6 +203,19 @@ int navsim_maps_closed(const uint8_t* occ, int32_t n_maps, int32_t H, int32_t W,
     return launch_status();
 }
 
+int navsim_world_closed(const navsim_config* c, const navsim_state* st, int32_t* n_open, void* stream) {
+    (void)hipGetLastError();
+    if (!c || !st || !st->field || !n_open || c->n_envs < 0 || c->map_h <= 0 || c->map_w <= 0) return NAVSIM_E_ARG;
+    if (c->field_format != NAVSIM_FIELD_F32 && c->field_format != NAVSIM_FIELD_U16T) return NAVSIM_E_UNSUPPORTED;
+    const int n = c->shared_field ? (c->n_envs > 0 ? 1 : 0) : c->n_envs;
+    if (n == 0) return NAVSIM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (c->field_format == NAVSIM_FIELD_F32) world_closed_kernel<FieldF32><<<n, 256, 0, s>>>(st->field, nullptr, c->map_h, c->map_w, n_open);
+    else if (st->field_overflow)             world_closed_kernel<FieldU16T><<<n, 256, 0, s>>>(st->field, st->field_overflow, c->map_h, c->map_w, n_open);
+    else                                     world_closed_kernel<FieldU16TN><<<n, 256, 0, s>>>(st->field, nullptr, c->map_h, c->map_w, n_open);
+    return launch_status();
+}
+
 size_t navsim_sizeof_config(void) { return sizeof(navsim_config); }
 size_t navsim_sizeof_state(void) { return sizeof(navsim_state); }
 size_t navsim_sizeof_step_io(void) { return sizeof(navsim_step_io); }

@@ -298,6 +298,7 @@ def declare(lib, suffix=""):
         sig("navsim_rect_index_bytes", [i32, i32, i32], C.c_size_t)
         sig("navsim_build_rect_index", [_P, i32, i32, i32, _P, _P, _P])
         sig("navsim_maps_closed", [_P, i32, i32, i32, _P, _P])
+        sig("navsim_world_closed", [cfgp, stp, _P, _P])
     sig("navsim_cast_static", [_P, i32, i32, i32, _P, i32, f32, i32, _P] + stream)
     sig("navsim_render_polys", [_P, _P, i32, i32, _P, _P, i32, _P] + stream)
     sig("navsim_render_legs", [_P, _P, i32, i32, _P, _P, i32, _P] + stream)
@@ -345,7 +346,7 @@ EXPORTS = (
     "navsim_abi_version", "navsim_error_string", "navsim_last_hip_error", "navsim_default_config",
     "navsim_build_dt_workspace_bytes", "navsim_build_dt", "navsim_field_bytes", "navsim_build_field",
     "navsim_rect_table_bytes", "navsim_build_rects_workspace_bytes", "navsim_build_rects",
-    "navsim_rect_index_bytes", "navsim_build_rect_index", "navsim_maps_closed",
+    "navsim_rect_index_bytes", "navsim_build_rect_index", "navsim_maps_closed", "navsim_world_closed",
     "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
     "navsim_scan_threshold", "navsim_beam_table", "navsim_ped_scans", "navsim_regen_workspace_bytes", "navsim_regen", "navsim_regen_swap", "navsim_regen_stage",

@@ -371,6 +371,14 @@ class NavSim(object):
                 raise ValueError("%s: shape %s, expected %s" % (name, tuple(t.shape), want))
             self.t[name] = t
             setattr(self.st, name, t.data_ptr())
+        if self.cfg.closed_maps and "rect_index" in self.t:
+            # cfg.closed_maps is an assertion about THIS world that the LDS form of the march relies on without a bounds
+            # test (include/navsim.h): verify it once, against the distance fields as they stand (round-4 advisor)
+            n_open = torch.zeros(1, dtype=torch.int32, device=self.device)
+            check(self.lib.navsim_world_closed(C.byref(self.cfg), C.byref(self.st), _ptr(n_open), _stream()), "navsim_world_closed")
+            if int(n_open.item()):
+                raise ValueError("cfg.closed_maps = 1, but %d arenas have a map without a closed ring of 3 occupied cells "
+                                 "(navsim_maps_closed / navsim_world_closed): clear closed_maps or close the maps" % int(n_open.item()))
         self.due = None
         if "ped_waypoints" in self.t:
             # ABI 5: the index of every pedestrian's current waypoint (a route starts at its first one), and the two buffers

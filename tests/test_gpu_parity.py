@@ -2097,6 +2097,20 @@ def test_open_maps_keep_the_bounds_test(gpu):
             left_the_map += int((go[:, :1081] == 25.0).sum())
         assert "rect_index" in g.t and g.cfg.closed_maps == (0 if gap else 1)
         assert (left_the_map > 0) == gap
+    # a WRONG assertion is refused where the world is assembled (round-4 advisor: nothing ever checked cfg.closed_maps):
+    # NavSim verifies it once against the fields it was given (navsim_world_closed)
+    occ = gpu.world.make_maps(E, size, 61)
+    occ[3, 60:140, :8] = 0
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, n_spawn=6, auto_reset=1, seed=61, field_format=abi.FIELD_U16T)
+    gpu.world.lidar_1081(cfg)
+    arrays = gpu.world.make_world(cfg, occ, n_peds=0, device=gpu.dev, min_goal_dist=2.0, max_goal_dist=6.0, robot_clearance=0.6)
+    from nav_gym_amd import robots
+    for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
+        arrays[key] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array("keti", name)))
+    assert cfg.closed_maps == 0
+    cfg.closed_maps = 1                                              # "every map of this world is closed": not true of arena 3
+    with pytest.raises(ValueError, match="1 arenas have a map without a closed ring"):
+        gpu.sim.NavSim(cfg, arrays)
 
 
 @pytest.mark.parametrize("size,indoor", [(400, 0.0), (500, 1.0), (1000, 1.0)])
