@@ -487,6 +487,10 @@ int navsim_step_part(const navsim_config* cfg, const navsim_state* st, const nav
  * ped_range_max, no noise.  Uses the CURRENT state (call it after navsim_step / navsim_reset_obs).
  * Rows of pedestrians >= n_peds[e] are left untouched. */
 int navsim_ped_scans(const navsim_config* cfg, const navsim_state* st, float* out, void* stream);
+/* The same for the arenas [e0, e0 + n_e) only (rows of the other arenas are not touched).  With navsim_ped_policy_part it
+ * lets a caller pipeline the two: the scans of the next slice of arenas -- a latency-bound march -- run on one stream beside
+ * the network of the current slice -- FMA / MFMA-bound -- on another (nav_gym_amd/sim.py NavSim.ped_policy, round 5). */
+int navsim_ped_scans_part(const navsim_config* cfg, const navsim_state* st, float* out, int32_t e0, int32_t n_e, void* stream);
 
 /* ---- reset() of finished arenas on the device, with a new random map ------------ */
 /* For every arena with done[e] != 0 (at most cfg.regen_cap, lowest indices first): a fresh outdoor map
@@ -588,6 +592,11 @@ size_t navsim_ped_policy_workspace_bytes(const navsim_config* cfg);
 int    navsim_ped_policy(const navsim_config* cfg, const navsim_state* st, const navsim_policy_weights* w,
                          const float* ped_scans, float* prev_actions, double* ped_cmd, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* navsim_ped_policy for the pedestrians of the arenas [e0, e0 + n_e) only; same arrays, same workspace (calls on one workspace
+ * must be ordered on one stream). */
+int    navsim_ped_policy_part(const navsim_config* cfg, const navsim_state* st, const navsim_policy_weights* w,
+                              const float* ped_scans, float* prev_actions, double* ped_cmd, void* workspace,
+                              size_t workspace_bytes, int32_t e0, int32_t n_e, void* stream);
 /* navsim_ped_scans + navsim_ped_policy in one pass over the pedestrians (round 4): every pedestrian's scan is taken from the
  * CURRENT state by the workgroup that convolves it (env.py:685-693 -> 629-630, 647 -> human_policy.py:38-42), stays in LDS and
  * never travels through HBM; the march of one pedestrian runs beside the convolutions of others.  scans_out [E,N,512] float32

@@ -96,11 +96,11 @@ __device__ __forceinline__ void ped_scan_core(const navsim_config& c, const navs
 }
 
 template <typename Field, int BLOCK, int RULE, bool RECT>
-__global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim_state st, float* __restrict__ out) {
+__global__ __launch_bounds__(BLOCK) void ped_scan_kernel(navsim_config c, navsim_state st, float* __restrict__ out, int e0) {
     // the compiled maximum of 64 pedestrians cost 6 KB per workgroup and, with 512 beams, two of the CU's 16 workgroups:
     // the region is sized by cfg.max_peds
     extern __shared__ __attribute__((aligned(16))) char dyn[];
-    const int e = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
+    const int e = e0 + (int)blockIdx.y, i = blockIdx.x, tid = threadIdx.x;      // (e0: navsim_ped_scans_part)
     const int N = c.max_peds, PB = c.ped_n_beams;
     int n = st.n_peds[e];
     n = n > N ? N : n;

@@ -431,12 +431,18 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
 }
 
 int navsim_ped_scans(const navsim_config* c, const navsim_state* st, float* out, void* stream) {
+    if (!c) return NAVSIM_E_ARG;
+    return navsim_ped_scans_part(c, st, out, 0, c->n_envs, stream);
+}
+
+int navsim_ped_scans_part(const navsim_config* c, const navsim_state* st, float* out, int32_t e0, int32_t n_e, void* stream) {
     (void)hipGetLastError();
     if (!c || !st || !out || c->ped_model == NAVSIM_PED_NONE || !st->n_peds || !st->ped_pose || !st->robot_pose ||
         !st->field || c->ped_n_beams < 1 || c->max_peds < 1) return NAVSIM_E_ARG;
+    if (e0 < 0 || n_e < 0 || (long)e0 + n_e > c->n_envs) return NAVSIM_E_ARG;
     if (c->max_peds > NAVSIM_MAX_PEDS || c->ped_n_beams > 4096) return NAVSIM_E_UNSUPPORTED;
-    if (c->n_envs == 0) return NAVSIM_OK;
-    dim3 grid(c->max_peds, c->n_envs);
+    if (n_e == 0) return NAVSIM_OK;
+    dim3 grid(c->max_peds, n_e);
     // dir + rng per beam, then 4 sides x 16 B + 4 intervals x 8 B per other agent (kernels_pedscan.hpp)
     size_t lds = (((size_t)c->ped_n_beams * (sizeof(float2) + sizeof(float)) + 15) & ~(size_t)15) + (size_t)(c->max_peds + 1) * (64 + 32);
     hipStream_t s = (hipStream_t)stream;
@@ -444,14 +450,14 @@ int navsim_ped_scans(const navsim_config* c, const navsim_state* st, float* out,
     const int rule = march_rule_variant(c);
 #ifdef NAVSIM_ONLY_RULE
     if (rule != NAVSIM_ONLY_RULE) return NAVSIM_E_UNSUPPORTED;
-#define NAVSIM_PSCAN(F, RECT) ped_scan_kernel<F, 128, NAVSIM_ONLY_RULE, RECT><<<grid, 128, lds, s>>>(*c, *st, out)
+#define NAVSIM_PSCAN(F, RECT) ped_scan_kernel<F, 128, NAVSIM_ONLY_RULE, RECT><<<grid, 128, lds, s>>>(*c, *st, out, e0)
 #else
 #define NAVSIM_PSCAN(F, RECT) \
-    do { if (rule == NAVSIM_MARCH_F32)      ped_scan_kernel<F, 128, NAVSIM_MARCH_F32, RECT><<<grid, 128, lds, s>>>(*c, *st, out); \
-         else if (rule == NAVSIM_MARCH_F32_FMA) ped_scan_kernel<F, 128, NAVSIM_MARCH_F32_FMA, RECT><<<grid, 128, lds, s>>>(*c, *st, out); \
+    do { if (rule == NAVSIM_MARCH_F32)      ped_scan_kernel<F, 128, NAVSIM_MARCH_F32, RECT><<<grid, 128, lds, s>>>(*c, *st, out, e0); \
+         else if (rule == NAVSIM_MARCH_F32_FMA) ped_scan_kernel<F, 128, NAVSIM_MARCH_F32_FMA, RECT><<<grid, 128, lds, s>>>(*c, *st, out, e0); \
          else if (rule == kMarchF64Exact32 && !std::is_same<F, FieldF32>::value) \
-                                            ped_scan_kernel<F, 128, kMarchF64Exact32, RECT><<<grid, 128, lds, s>>>(*c, *st, out); \
-         else                               ped_scan_kernel<F, 128, NAVSIM_MARCH_F64, RECT><<<grid, 128, lds, s>>>(*c, *st, out); } while (0)
+                                            ped_scan_kernel<F, 128, kMarchF64Exact32, RECT><<<grid, 128, lds, s>>>(*c, *st, out, e0); \
+         else                               ped_scan_kernel<F, 128, NAVSIM_MARCH_F64, RECT><<<grid, 128, lds, s>>>(*c, *st, out, e0); } while (0)
 #endif
     if (c->field_format == NAVSIM_FIELD_U16T) {
         if (st->rect_table) NAVSIM_PSCAN(FieldU16T, true); else NAVSIM_PSCAN(FieldU16T, false);
@@ -761,7 +767,7 @@ size_t navsim_ped_policy_workspace_bytes(const navsim_config* c) {
 // scan + features kernel from the current state and, when scans_out != NULL, also written there (navsim_ped_scan_policy)
 static int ped_policy_run(const navsim_config* c, const navsim_state* st, const navsim_policy_weights* w,
                           const float* ped_scans, float* scans_out, float* prev_actions, double* ped_cmd, void* workspace,
-                          size_t workspace_bytes, void* stream) {
+                          size_t workspace_bytes, void* stream, long p_begin = 0, long p_count = -1) {
     (void)hipGetLastError();
     if (!c || !st || !w || !prev_actions || !ped_cmd || !workspace || !st->ped_pose ||
         !st->ped_waypoints || !st->ped_n_waypoints || !st->ped_wp_head || !st->ped_v_pref || !st->n_peds)
@@ -778,14 +784,17 @@ static int ped_policy_run(const navsim_config* c, const navsim_state* st, const 
         if (c->max_peds > NAVSIM_MAX_PEDS) return NAVSIM_E_UNSUPPORTED;
         if (c->field_format != NAVSIM_FIELD_U16T && c->field_format != NAVSIM_FIELD_F32) return NAVSIM_E_UNSUPPORTED;
     }
-    const size_t P = (size_t)c->n_envs * (size_t)c->max_peds;
-    if (P == 0) return NAVSIM_OK;
+    const size_t P_all = (size_t)c->n_envs * (size_t)c->max_peds;
+    if (p_count < 0) p_count = (long)P_all - p_begin;
+    if (p_begin < 0 || (size_t)(p_begin + p_count) > P_all) return NAVSIM_E_ARG;
+    const size_t P = (size_t)(p_begin + p_count);                     // the chunks below walk [p_begin, P)
+    if (p_count == 0) return NAVSIM_OK;
     hipStream_t s = (hipStream_t)stream;
     float* w2t = (float*)workspace;
     float* cv2t = (float*)((char*)workspace + ((kPolH2 * kPolIn2 * sizeof(float) + 255) & ~(size_t)255));
     double* tab = (double*)((char*)cv2t + ((32 * 32 * 3 * sizeof(float) + 1023) & ~(size_t)1023));
     float* feat = (float*)((char*)tab + 8192);
-    const size_t chunk = P < (size_t)kPolicyChunk ? P : (size_t)kPolicyChunk;
+    const size_t chunk = P_all < (size_t)kPolicyChunk ? P_all : (size_t)kPolicyChunk;      // (the workspace's capacity)
     float* h1 = feat + chunk * kPolFeat;
     constexpr size_t fc1_lds = (size_t)2 * (128 + 128) * 33 * sizeof(float);       // 67,584 B
     if (allow_lds((const void*)policy_fc1_kernel, fc1_lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
@@ -805,7 +814,7 @@ static int ped_policy_run(const navsim_config* c, const navsim_state* st, const 
          else if (rule == kMarchF64Exact32 && !std::is_same<F, FieldF32>::value) NAVSIM_PSF_(F, kMarchF64Exact32, RECT); \
          else                                   NAVSIM_PSF_(F, NAVSIM_MARCH_F64, RECT); } while (0)
 #endif
-    for (size_t p0 = 0; p0 < P; p0 += chunk) {
+    for (size_t p0 = (size_t)p_begin; p0 < P; p0 += chunk) {
         const int n = (int)(P - p0 < chunk ? P - p0 : chunk);
         if (!fused) {
             policy_features_kernel<<<n, 256, 0, s>>>(ped_scans, (int)p0, n, w->cv1_w, w->cv1_b, cv2t, w->cv2_b, feat);
@@ -829,6 +838,14 @@ int navsim_ped_policy(const navsim_config* c, const navsim_state* st, const navs
                       size_t workspace_bytes, void* stream) {
     if (!ped_scans) return NAVSIM_E_ARG;
     return ped_policy_run(c, st, w, ped_scans, nullptr, prev_actions, ped_cmd, workspace, workspace_bytes, stream);
+}
+
+int navsim_ped_policy_part(const navsim_config* c, const navsim_state* st, const navsim_policy_weights* w,
+                           const float* ped_scans, float* prev_actions, double* ped_cmd, void* workspace,
+                           size_t workspace_bytes, int32_t e0, int32_t n_e, void* stream) {
+    if (!ped_scans || !c || e0 < 0 || n_e < 0 || (long)e0 + n_e > c->n_envs) return NAVSIM_E_ARG;
+    return ped_policy_run(c, st, w, ped_scans, nullptr, prev_actions, ped_cmd, workspace, workspace_bytes, stream,
+                          (long)e0 * c->max_peds, (long)n_e * c->max_peds);
 }
 
 int navsim_ped_scan_policy(const navsim_config* c, const navsim_state* st, const navsim_policy_weights* w,

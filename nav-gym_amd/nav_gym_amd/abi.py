@@ -309,6 +309,9 @@ def declare(lib, suffix=""):
         sig("navsim_beam_table", [cfgp, _P, _P])
         sig("navsim_debug_xy_to_ij", [cfgp, _P, i32, _P, i32, _P])
     sig("navsim_ped_scans", [cfgp, stp, _P] + stream)
+    if not suffix:
+        sig("navsim_ped_scans_part", [cfgp, stp, _P, i32, i32, _P])
+        sig("navsim_ped_policy_part", [cfgp, stp, C.POINTER(NavsimPolicyWeights), _P, _P, _P, _P, C.c_size_t, i32, i32, _P])
     if suffix:
         sig("navsim_regen", [cfgp, stp, iop])
         sig("navsim_replan", [cfgp, stp, i32])
@@ -349,7 +352,7 @@ EXPORTS = (
     "navsim_rect_index_bytes", "navsim_build_rect_index", "navsim_maps_closed", "navsim_world_closed",
     "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
-    "navsim_scan_threshold", "navsim_beam_table", "navsim_ped_scans", "navsim_regen_workspace_bytes", "navsim_regen", "navsim_regen_swap", "navsim_regen_stage",
+    "navsim_scan_threshold", "navsim_beam_table", "navsim_ped_scans", "navsim_ped_scans_part", "navsim_ped_policy_part", "navsim_regen_workspace_bytes", "navsim_regen", "navsim_regen_swap", "navsim_regen_stage",
     "navsim_costmap", "navsim_plan", "navsim_launch_order", "navsim_replan_workspace_bytes", "navsim_replan", "navsim_ped_policy_workspace_bytes", "navsim_ped_policy", "navsim_ped_scan_policy",
     "navsim_crowd_check", "navsim_crowd_angular_map", "navsim_crowd_local_map", "navsim_crowd_orca", "navsim_crowd_agent_step",
     "navsim_step", "navsim_step_part", "navsim_prepare", "navsim_reset_obs", "navsim_step_kernel_name",

@@ -746,13 +746,48 @@ class NavSim(object):
             self.t["policy_prev_actions"] = torch.zeros((self.cfg.n_envs, self.cfg.max_peds, 2), dtype=torch.float32,
                                                         device=self.device)
 
-    def ped_policy(self, scans=None, fused=False, scans_out=None):
+    def _ped_policy_pipelined(self, n_slices):
+        """scans -> network in slices of arenas on two streams (round 5; MEASURED AND NOT THE DEFAULT): the scans of slice
+        k + 1 beside the network of slice k, same kernels on the same rows.  The round-4 verdict's idea -- a latency-bound
+        march beside a layer at 0.8 of the f32 MFMA peak -- loses: 3.26 / 3.54 / 5.5 ms for 3 / 6 / 12 slices against 3.0 ms for
+        the two calls at c3 size (profiles/r05_policy/): the march's waves and the layer's share the CUs' issue slots and LDS,
+        smaller slices run the layer below its peak, and every slice costs two cross-stream waits."""
+        import torch
+        main = torch.cuda.current_stream(self.device)
+        if not hasattr(self, "_scan_stream"):
+            self._scan_stream = torch.cuda.Stream(device=self.device)
+            self.t["ped_scan_rows"] = torch.zeros((self.cfg.n_envs, self.cfg.max_peds, self.cfg.ped_n_beams), dtype=torch.float32,
+                                                  device=self.device)
+        side, rows, ws, E = self._scan_stream, self.t["ped_scan_rows"], self.t["policy_ws"], self.cfg.n_envs
+        bounds = [E * k // n_slices for k in range(n_slices + 1)]
+        side.wait_stream(main)                      # the state the scans read
+        events = []
+        for k in range(n_slices):
+            e0, n_e = bounds[k], bounds[k + 1] - bounds[k]
+            check(self.lib.navsim_ped_scans_part(C.byref(self.cfg), C.byref(self.st), _ptr(rows), e0, n_e, C.c_void_p(side.cuda_stream)),
+                  "navsim_ped_scans_part")
+            ev = torch.cuda.Event()
+            ev.record(side)
+            events.append(ev)
+        for k in range(n_slices):
+            e0, n_e = bounds[k], bounds[k + 1] - bounds[k]
+            main.wait_event(events[k])
+            check(self.lib.navsim_ped_policy_part(C.byref(self.cfg), C.byref(self.st), C.byref(self.policy_w), _ptr(rows),
+                                                  _ptr(self.t["policy_prev_actions"]), _ptr(self.t["ped_cmd"]), _ptr(ws), ws.numel(),
+                                                  e0, n_e, C.c_void_p(main.cuda_stream)), "navsim_ped_policy_part")
+        return self.t["ped_cmd"], self.t["policy_prev_actions"]
+
+    def ped_policy(self, scans=None, fused=False, scans_out=None, pipeline=None):
         """navsim_ped_policy (env.py:617-662): pedestrian scans -> HumanPolicy actor -> ped_cmd for a
         NAVSIM_PED_EXTERNAL step.  Returns (ped_cmd [E,N,2] float64, clip(mean) [E,N,2] float32).
-        scans=None: the scans of the current state (navsim_ped_scans first).  fused=True: navsim_ped_scan_policy -- every
+        scans=None: the scans of the current state (navsim_ped_scans first; pipeline=n: taken and consumed in n slices of
+        arenas on two streams, _ped_policy_pipelined -- measured slower, kept as an option).
+        fused=True: navsim_ped_scan_policy -- every
         scan is taken inside the pass by the workgroup that convolves it and only written to HBM when scans_out (float32
         [E,N,512]) is given; bit-identical, saves the [E,N,512] buffer, measured 1 % slower than the two calls."""
         ws = self.t["policy_ws"]
+        if scans is None and not fused and pipeline:
+            return self._ped_policy_pipelined(int(pipeline) if int(pipeline) > 1 else 3)
         if fused:
             check(self.lib.navsim_ped_scan_policy(C.byref(self.cfg), C.byref(self.st), C.byref(self.policy_w),
                                                   _ptr(scans_out) if scans_out is not None else None,

@@ -35,8 +35,14 @@ rows = {
     "step_external_ms": timed(lambda: sim.step(act)),
 }
 def two_calls():
-    sim.ped_policy(sim.ped_scans()); sim.step(act)
+    sim.ped_policy(sim.ped_scans(), pipeline=False); sim.step(act)
 rows["full_step_two_calls_ms"] = timed(two_calls)          # navsim_ped_scans -> navsim_ped_policy: the scans through HBM
+# round 5: the scans of the next slice of arenas beside the network of the current one (NavSim._ped_policy_pipelined)
+for n_slices in (3, 4, 6, 8, 12):
+    rows["ped_scans_policy_pipelined_%d_ms" % n_slices] = timed(lambda: sim.ped_policy(pipeline=n_slices))
+def pipelined():
+    sim.ped_policy(pipeline=3); sim.step(act)
+rows["full_step_pipelined_3_ms"] = timed(pipelined)
 rows["full_step_ms"] = rows["full_step_two_calls_ms"]
 rows["ped_scan_policy_fused_ms"] = timed(lambda: sim.ped_policy(fused=True))   # round 4: navsim_ped_scan_policy (scan -> conv in one workgroup)
 def fused():

@@ -2311,3 +2311,37 @@ def test_edge_shapes(gpu):
     z = torch.zeros(4, device=gpu.dev, dtype=torch.float64)
     assert L.navsim_integrate(z.data_ptr(), z.data_ptr(), None, 0, 0.2, 0.0, None) == 0
     assert L.navsim_cast_static(g.t["field"].data_ptr(), 0, size, size, None, 7, 1.0, 0, None, None) == 0
+
+
+def test_pipelined_ped_policy_equals_the_two_calls(gpu):
+    """Round 5: NavSim.ped_policy(pipeline=n) takes the pedestrians' scans and runs the network in slices of arenas on two
+    streams (navsim_ped_scans_part beside navsim_ped_policy_part; an option, not the default: it measured slower).  Same kernels on the same rows: commands, clipped means, the
+    waypoint heads it advances and the scan rows equal those of navsim_ped_scans followed by navsim_ped_policy."""
+    torch = gpu.torch
+    E, size, N = 700, 200, 12                      # 8400 pedestrian slots: above the pipeline's threshold, ragged slices
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_EXTERNAL, n_spawn=4,
+                                 auto_reset=1, seed=31, field_format=abi.FIELD_U16T)
+    gpu.world.lidar_1081(cfg)
+    occ = gpu.world.make_maps(E, size, 31)
+    arrays = gpu.world.make_world(cfg, occ, n_peds=9, device=gpu.dev, min_goal_dist=2.0, max_goal_dist=6.0, robot_clearance=0.6)
+    from nav_gym_amd import robots
+    for key, name in (("scan_threshold", "threshold_footprint"), ("scan_discomfort", "discomfort_threshold_footprint")):
+        arrays[key] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array("keti", name)))
+    arrays["n_peds"][::5] = 12
+    arrays["n_peds"][3] = 0
+    g = gpu.sim.NavSim(cfg, arrays)
+    g.set_policy(_policy_weights_random(7))
+    g.t["policy_prev_actions"].copy_(torch.rand((E, N, 2), device=gpu.dev) * 0.5)
+    keep = {k: g.t[k].clone() for k in ("policy_prev_actions", "ped_wp_head")}
+    scans = g.ped_scans()
+    cmd_a, mean_a = [x.clone() for x in g.ped_policy(scans, pipeline=False)]
+    head_a = g.t["ped_wp_head"].clone()
+    for n_slices in (3, 5):
+        for k, v in keep.items():
+            g.t[k].copy_(v)
+        g.t["ped_cmd"].zero_()
+        cmd_b, mean_b = g.ped_policy(pipeline=n_slices)
+        torch.cuda.synchronize()
+        assert torch.equal(cmd_a, cmd_b) and torch.equal(mean_a, mean_b) and torch.equal(head_a, g.t["ped_wp_head"])
+        live = (torch.arange(N, device=gpu.dev)[None, :] < g.t["n_peds"][:, None].clamp(max=N))
+        assert torch.equal(g.t["ped_scan_rows"][live], scans[live])
