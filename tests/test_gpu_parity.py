@@ -2218,6 +2218,25 @@ def test_bench_two_ranks_on_one_gpu(gpu):
     assert out["scaling"] == "strong" and out["config"]["envs_total"] == 600 and out["value_strong"] == out["value"]
     assert out["value_weak"] > 0 and out["weak"]["envs_total"] == 512 and out["weak"]["envs_per_gpu"] == 256
     assert abs(out["value_weak"] - 512 * 6 / (out["weak"]["ms_per_step"] * 6e-3)) < 1e-6 * out["value_weak"]
+    # Round-4 verdict: no 8-GPU node has run this yet -- the first one must not produce a line with a hole in it.  Every
+    # key the N > 1 line is read by, with the defaults the driver uses (no --envs / --total-envs: c2's 4096 strong, 4096 per
+    # GPU weak); sizes kept small through --steps only.
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--repeats", "1",
+                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "value_strong", "value_weak", "weak", "value_with_obs_gather"):
+        assert key in out, key
+    assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["envs_total"] == 4096 and out["config"]["envs_per_gpu"] == 2048
+    assert out["weak"]["envs_total"] == 8192 and out["weak"]["envs_per_gpu"] == 4096 and out["weak"]["scaling"] == "weak"
+    assert out["value"] == out["value_strong"] > 0 and out["value_weak"] > 0
+    assert abs(out["value"] - 4096 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-6 * out["value"]
+    assert abs(out["value_weak"] - 8192 * 4 / (out["weak"]["ms_per_step"] * 4e-3)) < 1e-6 * out["value_weak"]
+    assert out["roofline"]["kernel_ms"] > 0 and 0 < out["roofline"]["frac"] <= 1 and "valu" in out["roofline"]
+    assert out["config"]["workload"].startswith("c2: 4096 arenas (strong scaling: 2048 on rank 0)")
+    assert "other_workloads" not in out and "cpu_baseline" not in out       # N = 1 extras only
 
 
 def test_bench_line_contract(gpu):
