@@ -687,6 +687,17 @@ int navsim_crowd_orca(const navsim_orca_params* p, int32_t n_queries, int32_t ma
  * vel = v * (cos, sin)(theta'); theta = theta' mod 2 pi.  pose [n,3] in/out, action [n,2], vel [n,2] or NULL. */
 int navsim_crowd_agent_step(double* pose, const double* action, double* vel, int32_t n, double time_step, void* stream);
 
+/* navsim_replan + navsim_step in ONE launch (ABI 5): the pedestrians the PREVIOUS step flagged in st->ped_due_prev are
+ * re-planned (exactly as navsim_replan(cfg, st, max_queries) would: same candidates, same order, same cap and counters)
+ * and then every arena is stepped (exactly as navsim_step would).  The arena with a waiting pedestrian is re-planned by its
+ * own workgroup right before that workgroup steps it, and those workgroups open the launch, so the searches -- a chain of
+ * dependent breadth-first levels for ~2 % of the arenas -- run beside the step of all the others instead of behind it
+ * (round 4) or on a second stream (navsim_step_part).  Needs st->costmap, st->ped_due / ped_due_prev (two buffers the
+ * caller alternates, as for navsim_step_part).  A rollout  step_replan, step_replan, ...  equals  step, replan, step,
+ * replan, ...  shifted by one re-plan: the first call finds no flags, a final navsim_replan leaves the same state. */
+int navsim_step_replan(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io, int32_t max_queries,
+                       void* stream);
+
 /* Everything a later navsim_step / navsim_reset_obs / navsim_regen / navsim_replan with this configuration would set ONCE per
  * kernel (dynamic LDS above 64 KB needs hipFuncSetAttribute) is set now; nothing is launched.  Call it before capturing those
  * calls in a hipGraph (nav_gym_amd/sim.py NavSim.enable_graphs): attribute calls do not belong inside a capture.  io: the

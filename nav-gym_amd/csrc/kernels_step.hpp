@@ -893,30 +893,58 @@ __global__ __launch_bounds__(kPedUpdateBlock) void ped_update_kernel(navsim_conf
 // one per arena, nearly all of which would only claim their LDS to find out that they have nothing to do
 // (profiles/r05_replan/timeline_v2.txt: 55-85 us for ~80 arenas).
 template <int BLOCK>
-__device__ __forceinline__ int due_arena_pick(const unsigned long long* __restrict__ due, int E, int slot) {
-    __shared__ int wave_tot[kMaxWaves], e_s;
+__device__ __forceinline__ int due_arena_pick(const unsigned long long* __restrict__ due, int E, int slot,
+                                              int* peds_before = nullptr, int* n_peds = nullptr) {
+    // peds_before: waiting pedestrians of the arenas in front of the returned one; n_peds: waiting pedestrians in all
+    __shared__ int wave_a[kMaxWaves], wave_p[kMaxWaves], e_s, before_s;
     const int tid = threadIdx.x, lane = tid & 63, nthr = block_threads<BLOCK>();
     const int per = (E + nthr - 1) / nthr;
     const int lo = tid * per, hi = (lo + per < E) ? lo + per : E;
-    int n = 0;
-    for (int e = lo; e < hi; ++e) n += due[e] != 0ull;
-    int incl = n;
+    int n = 0, m = 0;
+    for (int e = lo; e < hi; ++e) { const unsigned long long w = due[e]; n += w != 0ull; m += __popcll(w); }
+    int incl = n, incl_p = m;
     for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
+        const int v = __shfl_up(incl, off, 64), vp = __shfl_up(incl_p, off, 64);
+        if (lane >= off) { incl += v; incl_p += vp; }
     }
-    if (lane == 63 || tid == nthr - 1) wave_tot[tid >> 6] = incl;
-    if (tid == 0) e_s = -1;
+    if (lane == 63 || tid == nthr - 1) { wave_a[tid >> 6] = incl; wave_p[tid >> 6] = incl_p; }
+    if (tid == 0) { e_s = -1; before_s = 0; }
     __syncthreads();
-    int pos = incl - n;
-    for (int w = 0; w < (tid >> 6); ++w) pos += wave_tot[w];
+    int pos = incl - n, pos_p = incl_p - m, all_p = 0;
+    for (int w = 0; w < (nthr + 63) / 64; ++w) {
+        if (w < (tid >> 6)) { pos += wave_a[w]; pos_p += wave_p[w]; }
+        all_p += wave_p[w];
+    }
     if (slot >= pos && slot < pos + n)
-        for (int e = lo; e < hi; ++e)
-            if (due[e] != 0ull && pos++ == slot) { e_s = e; break; }
+        for (int e = lo; e < hi; ++e) {
+            const unsigned long long w = due[e];
+            if (w == 0ull) continue;
+            if (pos++ == slot) { e_s = e; before_s = pos_p; break; }
+            pos_p += __popcll(w);
+        }
     __syncthreads();
     const int e = e_s;
+    if (peds_before) *peds_before = before_s;
+    if (n_peds) *n_peds = all_p;
     __syncthreads();                                     // (e_s is rewritten by the next pick of this workgroup)
     return e;
+}
+
+// rank of arena e among the arenas with a waiting pedestrian (those in front of it), and the waiting pedestrians in front
+template <int BLOCK>
+__device__ __forceinline__ int due_arena_rank(const unsigned long long* __restrict__ due, int e, int* peds_before) {
+    __shared__ int wave_a[kMaxWaves], wave_p[kMaxWaves];
+    const int tid = threadIdx.x, lane = tid & 63, nthr = block_threads<BLOCK>();
+    int n = 0, m = 0;
+    for (int k = tid; k < e; k += nthr) { const unsigned long long w = due[k]; n += w != 0ull; m += __popcll(w); }
+    for (int off = 32; off > 0; off >>= 1) { n += __shfl_down(n, off, 64); m += __shfl_down(m, off, 64); }
+    if (lane == 0) { wave_a[tid >> 6] = n; wave_p[tid >> 6] = m; }
+    __syncthreads();
+    int rank = 0, before = 0;
+    for (int w = 0; w < (nthr + 63) / 64; ++w) { rank += wave_a[w]; before += wave_p[w]; }
+    *peds_before = before;
+    __syncthreads();
+    return rank;
 }
 
 // The fused step of ONE arena by the calling workgroup.  BLOCK threads; PEDS: the pedestrian variants (primitives + culled merge
@@ -1228,7 +1256,18 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
 // The fused step.  One workgroup = one arena (template arguments: step_arena).  reset_only: bit 0 = a reset-only launch, bit 1 =
 // ped_update_kernel has advanced the pedestrians, bits 2-3 = the NAVSIM_STEP_* part of navsim_step_part.
 template <int BLOCK, bool PEDS, typename Field, int RULE, int RECT, bool PINL>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void navsim_step_kernel(navsim_config c, navsim_state st,
+// Wavefronts per SIMD the kernel is compiled for = its register budget.  The 256-thread pedestrian variants with the index
+// rows in LDS are resident at FIVE workgroups per CU (plan_step: 30 KB of LDS each) -- five wavefronts per SIMD, 96 registers
+// each; compiled for eight (64 registers, like every other variant, whose residency the wave slots bound) they spilled
+// 36 bytes per lane.  c3: 24.65 -> 26.4 M env-steps/s (profiles/r05_c3/ab_waves.txt; 4 / 5 / 6: 26.3 / 26.4 / 25.9).
+#ifndef NAVSIM_PEDS_WAVES_MIN
+#define NAVSIM_PEDS_WAVES_MIN 5
+#endif
+#ifndef NAVSIM_NOPEDS_WAVES_MIN
+#define NAVSIM_NOPEDS_WAVES_MIN 8
+#endif
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((PEDS && PINL && RECT == 2 && BLOCK == 256) ? NAVSIM_PEDS_WAVES_MIN : (!PEDS ? NAVSIM_NOPEDS_WAVES_MIN : 8), 8)))
+void navsim_step_kernel(navsim_config c, navsim_state st,
                                                             navsim_step_io io, int reset_only,
                                                             const uint8_t* __restrict__ reset_mask,
                                                             unsigned dyn_lds_bytes, int park_lanes, unsigned rect_lds_offset) {
@@ -1259,6 +1298,51 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         step_arena<BLOCK, true, Field, RULE, RECT, true>(c, st, io, e, 0, 0, nullptr, dyn_lds_bytes, park_lanes, rect_lds_offset);
         __syncthreads();                                 // the arena's LDS is reused by the next one
     }
+}
+
+// navsim_step_replan: navsim_replan of the previous step's flags INSIDE the step's launch (round 5).  env.py:667-680 plans a
+// new route inside step() for the pedestrian that reached its goal; as kernels of its own that search sat serially behind the
+// step (round 4: 166 + 98 us per step on the c3 world) or beside it on a second stream (navsim_step_part: ~207 us -- two
+// cross-stream waits per step and three launches sharing the chip).  Here the arena's own workgroup does it before it steps
+// the arena, and those workgroups go FIRST: the launch opens with G front workgroups, front workgroup b takes the b-th arena
+// with a waiting pedestrian (due_arena_pick), re-plans its pedestrians one after the other with all its threads
+// (replan_one: the search's LDS is the step's own dynamic LDS, not yet in use) and steps the arena; the other workgroups step
+// the arenas nobody waits in.  An arena of the front takes a search longer (~60-90 us) than the others and starts first: it is
+// done before the launch's last generation is.  One launch, one stream, no flags to wait for; per arena the order is still
+// step, replan, step.  The cap of navsim_replan (max_queries, in (arena, pedestrian) order, the rest wait and are counted)
+// is kept through the pedestrians' ranks.  More waiting arenas than front workgroups: the arena's own back workgroup does it.
+template <int BLOCK, typename Field, int RULE, int RECT>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((RECT == 2 && BLOCK == 256) ? NAVSIM_PEDS_WAVES_MIN : 8, 8)))
+void navsim_step_replan_kernel(navsim_config c, navsim_state st, navsim_step_io io, unsigned dyn_lds_bytes, int park_lanes,
+                               unsigned rect_lds_offset, int G, int cap) {
+    int e, before = 0;
+    bool plan = false;
+    if ((int)blockIdx.x < G) {
+        int n_peds;
+        e = due_arena_pick<BLOCK>(st.ped_due_prev, c.n_envs, (int)blockIdx.x, &before, &n_peds);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && st.counters && n_peds > 0) {       // what navsim_replan counts
+            const int served = n_peds < cap ? n_peds : cap;
+            if (served > 0) atomicAdd(&st.counters[NAVSIM_COUNTER_REPLAN_SERVED], (unsigned long long)served);
+            if (n_peds > served) atomicAdd(&st.counters[NAVSIM_COUNTER_REPLAN_UNSERVED], (unsigned long long)(n_peds - served));
+        }
+        if (e < 0) return;
+        plan = true;
+    } else {
+        const int b = (int)blockIdx.x - G;
+        e = st.launch_order ? st.launch_order[b] : b;     // longest-first launch order (a scheduling hint)
+        if (e < 0) return;
+        if (st.ped_due_prev[e] != 0ull) {                 // a front workgroup's arena -- unless more arenas wait than the front holds
+            if (due_arena_rank<BLOCK>(st.ped_due_prev, e, &before) < G) return;
+            plan = true;
+        }
+    }
+    if (plan) {
+        for (unsigned long long m = st.ped_due_prev[e]; m != 0ull; m &= m - 1ull, ++before) {      // block-uniform
+            if (before < cap) replan_one<BLOCK, 1>(c, st, e, (int)__builtin_ctzll(m));     // (one costmap word per thread: the host checked)
+            __syncthreads();                             // the search's LDS is reused by the next one and by the step
+        }
+    }
+    step_arena<BLOCK, true, Field, RULE, RECT, true>(c, st, io, e, 0, 0, nullptr, dyn_lds_bytes, park_lanes, rect_lds_offset);
 }
 
 // navsim_launch_order: arenas by descending cost.  One workgroup: maximum, 1024-bucket histogram on the cost

@@ -14,7 +14,8 @@
 //   kernels_field.hpp    distance transform, field formats, march step, mirror primitives
 //   kernels_rect.hpp     two-rectangle records of the field's 8x8 tiles: builder and decode
 //   kernels_step.hpp     probe round / scan / merge / pedestrian phase / the fused step kernel
-//   kernels_reset.hpp    navsim_regen, costmap, planner, navsim_replan
+//   kernels_plan.hpp     shortest paths on the costmap, waypoints, the re-plan of one pedestrian
+//   kernels_reset.hpp    navsim_regen, costmap, navsim_plan, navsim_replan
 //   kernels_policy.hpp   pedestrian control block with the HumanPolicy actor
 //   kernels_pedscan.hpp  pedestrian scans, CrowdSim collision block, beam table, test hooks
 //   kernels_crowd_maps.hpp  CrowdSim local maps;  kernels_crowd_orca.hpp  CrowdSim pedestrians (ORCA, Agent.step)
@@ -27,6 +28,7 @@ namespace {
 
 #include "kernels_field.hpp"
 #include "kernels_rect.hpp"
+#include "kernels_plan.hpp"
 #include "kernels_step.hpp"
 #include "kernels_reset.hpp"
 #include "kernels_policy.hpp"
@@ -41,7 +43,7 @@ namespace {
 // (threads per arena, pedestrians or not)
 #define NAVSIM_STEP_FAMILY(B, P) \
     extern "C" int navsim_step_launch_##B##_##P(const navsim_config*, const navsim_state*, const navsim_step_io*, int, \
-                                                const uint8_t*, void*, int, int); \
+                                                const uint8_t*, void*, int, int, int); \
     extern "C" int navsim_step_set_stamps_##B##_##P(unsigned long long*);
 NAVSIM_STEP_FAMILY(64, 0) NAVSIM_STEP_FAMILY(64, 1) NAVSIM_STEP_FAMILY(256, 0) NAVSIM_STEP_FAMILY(256, 1)
 NAVSIM_STEP_FAMILY(512, 0) NAVSIM_STEP_FAMILY(512, 1) NAVSIM_STEP_FAMILY(1024, 0) NAVSIM_STEP_FAMILY(1024, 1)
@@ -57,9 +59,9 @@ thread_local bool g_prepare_only = false;
 // grid > 0: that many workgroups instead of one per arena; st->launch_order then names each workgroup's arena, -1 = none
 // (navsim_regen's first observations: one workgroup per regenerated arena)
 int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
-                  int reset_only, const uint8_t* mask, hipStream_t s, int grid = 0) {
+                  int reset_only, const uint8_t* mask, hipStream_t s, int grid = 0, int aux = 0) {
     int rc;
-    const StepPlan p = plan_step(c, st, ((reset_only >> 2) & 3) == NAVSIM_STEP_DUE ? 0 : grid);
+    const StepPlan p = plan_step(c, st, ((reset_only >> 2) & 3) >= NAVSIM_STEP_DUE ? 0 : grid);
     const bool peds = c->ped_model != NAVSIM_PED_NONE;
     if (peds && !(reset_only & 1) && ped_split_on(c) && !g_prepare_only) {            // pedestrians ahead of the step (ped_split_on)
         const size_t pl = ped_update_lds_bytes(c);
@@ -70,8 +72,8 @@ int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_s
     }
     const int po = g_prepare_only ? 1 : 0;
 #define NAVSIM_STEP_CASE(B) \
-    case B: rc = peds ? navsim_step_launch_##B##_1(c, st, io, reset_only, mask, (void*)s, grid, po) \
-                      : navsim_step_launch_##B##_0(c, st, io, reset_only, mask, (void*)s, grid, po); break;
+    case B: rc = peds ? navsim_step_launch_##B##_1(c, st, io, reset_only, mask, (void*)s, grid, po, aux) \
+                      : navsim_step_launch_##B##_0(c, st, io, reset_only, mask, (void*)s, grid, po, aux); break;
     switch (p.block) {
         NAVSIM_STEP_CASE(64) NAVSIM_STEP_CASE(256) NAVSIM_STEP_CASE(512) NAVSIM_STEP_CASE(1024)
         default:   return NAVSIM_E_UNSUPPORTED;
@@ -957,6 +959,28 @@ int navsim_step_part(const navsim_config* c, const navsim_state* st, const navsi
     return dispatch_step(&c2, st, io, part << 2, nullptr, (hipStream_t)stream, grid);
 }
 
+int navsim_step_replan(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int32_t max_queries, void* stream) {
+    (void)hipGetLastError();
+    int rc = check_step_args(c, st, io, 0);
+    if (rc != NAVSIM_OK) return rc;
+    if (max_queries < 0 || c->ped_model == NAVSIM_PED_NONE || !st->costmap || !st->ped_due_prev || !st->ped_due ||
+        st->ped_due == st->ped_due_prev)
+        return NAVSIM_E_ARG;
+    if (ped_split_on(c)) return NAVSIM_E_UNSUPPORTED;                  // ped_update_kernel advances the pedestrians ahead of the launch
+    const int Hc = c->map_h / 5, Wc = c->map_w / 5;
+    if (Hc < 1 || Wc < 1 || !plan_fits(Hc, Wc) || plan_lds(Hc, Wc) > 64 * 1024) return NAVSIM_E_UNSUPPORTED;
+    // the search inside the step's launch owns one costmap word per thread (its registers are the step kernel's): costmaps of
+    // more words than the arena's workgroup has threads go through navsim_replan + navsim_step_part
+    if ((int)plan_words(Hc, Wc) > plan_step(c, st).block) return NAVSIM_E_UNSUPPORTED;
+    if (c->n_envs == 0) return NAVSIM_OK;
+    // front workgroups: one per arena with a waiting pedestrian, as many as wait in an ordinary step several times over
+    // (~2 % of the arenas on the c3 world); more than that and the arena's own workgroup plans (kernels_step.hpp)
+    int front = c->n_envs / 16;
+    front = front < 32 ? 32 : (front > 1024 ? 1024 : front);
+    front = front > c->n_envs ? c->n_envs : front;
+    return dispatch_step(c, st, io, 3 << 2, nullptr, (hipStream_t)stream, front, max_queries);
+}
+
 int navsim_prepare(const navsim_config* c, const navsim_state* st, const navsim_step_io* io) {
     (void)hipGetLastError();
     int rc = check_step_args(c, st, io, 1);
@@ -968,6 +992,9 @@ int navsim_prepare(const navsim_config* c, const navsim_state* st, const navsim_
     if (rc == NAVSIM_OK && c->regen_cap > 0) rc = dispatch_step(c, st, io, 1, nullptr, nullptr, c->regen_cap);   // navsim_regen's lone launch
     if (rc == NAVSIM_OK && c->ped_model != NAVSIM_PED_NONE && !ped_split_on(c))                                  // navsim_step_part's pair
         rc = dispatch_step(c, st, io, NAVSIM_STEP_DUE << 2, nullptr, nullptr, 32);
+    if (rc == NAVSIM_OK && c->ped_model != NAVSIM_PED_NONE && !ped_split_on(c) && st->costmap &&                 // navsim_step_replan
+        plan_fits(c->map_h / 5, c->map_w / 5) && (int)plan_words(c->map_h / 5, c->map_w / 5) <= plan_step(c, st).block)
+        rc = dispatch_step(c, st, io, 3 << 2, nullptr, nullptr, 32, 0);
     g_prepare_only = false;
     if (rc != NAVSIM_OK) return rc;
     const int Hc = c->map_h / 5, Wc = c->map_w / 5;

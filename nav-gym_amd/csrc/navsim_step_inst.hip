@@ -14,6 +14,7 @@
 namespace {
 #include "kernels_field.hpp"
 #include "kernels_rect.hpp"
+#include "kernels_plan.hpp"
 #include "kernels_step.hpp"
 #include "step_plan.hpp"
 
@@ -21,10 +22,19 @@ namespace {
 // (hipFuncSetAttribute for dynamic LDS above 64 KB) and launch nothing -- so that nothing of the kind happens inside a
 // hipGraph capture (round-3 advisor: navsim_regen's lone first-observation launch instantiates its own variant)
 thread_local bool g_prepare_only = false;      // set per call from the entry point's argument
+thread_local int g_aux = 0;                    // navsim_step_replan: max_queries
 template <int BLOCK, bool PEDS, typename Field, int RECT, int RULE, bool PINL>
 int launch_step_pinl(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
                      const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
     if constexpr (PEDS && PINL) {
+        if (((reset_only >> 2) & 3) == 3) {                        // navsim_step_replan: the re-plan inside the step's launch
+            const size_t pl = plan_lds(c->map_h / 5, c->map_w / 5), lds = p.lds > pl ? p.lds : pl;
+            if (allow_lds((const void*)navsim_step_replan_kernel<BLOCK, Field, RULE, RECT>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
+            if (g_prepare_only) return NAVSIM_OK;
+            navsim_step_replan_kernel<BLOCK, Field, RULE, RECT><<<grid + c->n_envs, BLOCK, lds, s>>>(
+                *c, *st, *io, (unsigned)step_lds_scan_bytes(c, p.park), p.park, p.rect_off, grid, g_aux);
+            return NAVSIM_OK;
+        }
         if (((reset_only >> 2) & 3) == NAVSIM_STEP_DUE) {          // navsim_step_part's compact launch (kernels_step.hpp)
             if (allow_lds((const void*)navsim_step_due_kernel<BLOCK, Field, RULE, RECT>, p.lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
             if (g_prepare_only) return NAVSIM_OK;
@@ -93,15 +103,16 @@ int launch_step_family(const navsim_config* c, const navsim_state* st, const nav
 #define NAVSIM_CAT(a, b, c) NAVSIM_CAT_(a, b, c)
 
 // reset_only: bit 0 = a reset-only launch, bit 1 = ped_update_kernel has already advanced the pedestrians, bits 2-3 = the
-// NAVSIM_STEP_* part of navsim_step_part; grid > 0: that
+// NAVSIM_STEP_* part of navsim_step_part (3: navsim_step_replan, aux = its max_queries); grid > 0: that
 // many workgroups (st->launch_order names their arenas); prepare_only: set the kernel's attributes, launch nothing
 extern "C" __attribute__((visibility("hidden")))
 int NAVSIM_CAT(navsim_step_launch_, NAVSIM_INST_BLOCK, NAVSIM_INST_PEDS)(const navsim_config* c, const navsim_state* st,
                                                                         const navsim_step_io* io, int reset_only,
                                                                         const uint8_t* mask, void* stream, int grid,
-                                                                        int prepare_only) {
+                                                                        int prepare_only, int aux) {
     // (a NAVSIM_STEP_DUE launch is the ordinary step kernel on fewer workgroups: its grid does not change the plan)
-    const bool due_part = ((reset_only >> 2) & 3) == NAVSIM_STEP_DUE;
+    const bool due_part = ((reset_only >> 2) & 3) >= NAVSIM_STEP_DUE;       // (also navsim_step_replan: grid = its front workgroups)
+    g_aux = aux;
     const StepPlan p = plan_step(c, st, due_part ? 0 : grid);
     if (p.block != NAVSIM_INST_BLOCK) return NAVSIM_E_UNSUPPORTED;
     g_prepare_only = prepare_only != 0;

@@ -340,6 +340,7 @@ def declare(lib, suffix=""):
     sig("navsim_step", [cfgp, stp, iop] + stream)
     if not suffix:
         sig("navsim_step_part", [cfgp, stp, iop, i32, _P])
+        sig("navsim_step_replan", [cfgp, stp, iop, i32, _P])
     sig("navsim_reset_obs", [cfgp, stp, iop, _P] + stream)
     return lib
 
@@ -355,7 +356,7 @@ EXPORTS = (
     "navsim_scan_threshold", "navsim_beam_table", "navsim_ped_scans", "navsim_ped_scans_part", "navsim_ped_policy_part", "navsim_regen_workspace_bytes", "navsim_regen", "navsim_regen_swap", "navsim_regen_stage",
     "navsim_costmap", "navsim_plan", "navsim_launch_order", "navsim_replan_workspace_bytes", "navsim_replan", "navsim_ped_policy_workspace_bytes", "navsim_ped_policy", "navsim_ped_scan_policy",
     "navsim_crowd_check", "navsim_crowd_angular_map", "navsim_crowd_local_map", "navsim_crowd_orca", "navsim_crowd_agent_step",
-    "navsim_step", "navsim_step_part", "navsim_prepare", "navsim_reset_obs", "navsim_step_kernel_name",
+    "navsim_step", "navsim_step_part", "navsim_step_replan", "navsim_prepare", "navsim_reset_obs", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math", "navsim_debug_xy_to_ij",
     "navsim_debug_gather", "navsim_debug_set_stamps", "navsim_debug_spawn_decisions",
 )

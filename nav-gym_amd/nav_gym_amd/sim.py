@@ -670,6 +670,18 @@ class NavSim(object):
     # stream while a side stream runs the re-plan of the previous step and then steps the arenas that waited for it.
     # Same kernels on the same per-arena inputs in the same per-arena order -- step(t), replan(t), step(t + 1) -- so every
     # result is what the serial sequence gives.
+    replan_in_step = True             # planned routes: navsim_step_replan (one launch) instead of the two-stream overlap
+
+    def launch_step_replan(self, replan_cap=1024, reorder=True):
+        """navsim_step_replan: the re-plan of the PREVIOUS step's flags inside this step's launch (include/navsim.h)."""
+        if reorder:
+            self._reorder()
+        self._flip()
+        rc = self.lib.navsim_step_replan(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), int(replan_cap), _stream())
+        if rc:
+            check(rc, "navsim_step_replan")
+        self.cur = 1 - self.cur
+
     overlap_big_first = False         # which stream takes the big launch (launch_step_overlapped); A/B: profiles/r05_replan/
 
     def _overlap_streams(self):
@@ -685,6 +697,19 @@ class NavSim(object):
         the caller's stream, where nothing has to be waited for, and the big launch on a side stream behind an event -- a few us
         later, so the searches' workgroups are resident before 4096 arena workgroups take every slot of the chip
         (c3 world through the gym API: 19.2-19.4 M env-steps/s; the other way round 18.6 M; serial, round 4: 15.5 M)."""
+        if self.replan_in_step:
+            if reorder:
+                self._reorder()
+            self._flip()
+            rc = self.lib.navsim_step_replan(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), int(replan_cap), _stream())
+            if rc == 0:
+                self.cur = 1 - self.cur
+                return
+            if rc != abi.E_UNSUPPORTED:
+                check(rc, "navsim_step_replan")
+            self.replan_in_step = False             # a costmap of more words than the arena's workgroup has threads: two streams
+            self._flip()                            # (idempotent: the same parity)
+            reorder = False
         import torch
         main, side = self._overlap_streams()
         big, chain = (main, side) if self.overlap_big_first else (side, main)

@@ -867,14 +867,17 @@ def test_replan_vs_oracle(gpu, fmt):
     assert replans >= 5, replans
 
 
-@pytest.mark.parametrize("graphs", [False, True])
-def test_replan_beside_the_step_equals_the_serial_sequence(gpu, graphs):
-    """Round 5: navsim_step_part.  The re-plan of step t runs on a side stream beside step t + 1 of the arenas that have no
-    pedestrian waiting for it; the arenas that do are stepped behind it (NavSim.launch_step_overlapped; graphs=True: the
-    fork and join captured in a hipGraph).  Per arena the order is still step, replan, step: observations, outputs and
-    every state array equal the oracle's serial  step, replan, step, ...  bit for bit, and both parts together step every
-    arena exactly once (steps[] advances by one everywhere)."""
-    E, size, N = 24, 300, 6
+@pytest.mark.parametrize("mode,graphs,E", [("in_step", False, 24), ("in_step", True, 24), ("in_step", False, 600),
+                                            ("two_streams", False, 24), ("two_streams", True, 24)])
+def test_replan_beside_the_step_equals_the_serial_sequence(gpu, mode, graphs, E):
+    """Round 5: the re-plan of step t beside step t + 1.  "in_step": navsim_step_replan -- ONE launch, the arena with a
+    waiting pedestrian is re-planned by its own workgroup, and those workgroups go first (600 arenas: 37 front workgroups,
+    more than one generation, a cap that is hit).  "two_streams": navsim_step_part -- the re-plan and then the waiting
+    arenas on one stream, the other arenas on a second one (graphs=True: the fork and join captured in a hipGraph).  Per
+    arena the order is still step, replan, step: observations, outputs and every state array equal the oracle's serial
+    step, replan, step, ...  bit for bit, and every arena is stepped exactly once (steps[] advances by one everywhere)."""
+    size, N = 300, 6
+    cap = 64 if E < 100 else 7                      # (600 arenas: more pedestrians wait than a call serves)
     cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_SFM, n_spawn=6,
                                  auto_reset=0, seed=29, field_format=abi.FIELD_U16T, ped_min_goal_dist=3.0, obstacle_number=6)
     gpu.world.lidar_full_circle(cfg, 180)
@@ -887,23 +890,24 @@ def test_replan_beside_the_step_equals_the_serial_sequence(gpu, graphs):
     host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "rect_table", "rect_index")}
     host["field"] = ref.build_dt(occ)
     g = gpu.sim.NavSim(cfg, arrays)
+    g.replan_in_step = mode == "in_step"
     r = ref.RefSim(cfg, host)
     _eq(g.reset_obs().cpu().numpy(), r.reset_obs(), "reset obs")
     if graphs:
-        g.enable_graphs(regen=False, replan_cap=64, overlap=True)
+        g.enable_graphs(regen=False, replan_cap=cap, overlap=True)
     rng = np.random.default_rng(3)
     waited = split = 0
-    for t in range(100):
+    for t in range(100 if E < 100 else 40):
         act = np.stack([rng.uniform(0.0, 0.3, E), rng.uniform(-0.64, 0.64, E)], axis=1)
         n_due = int((r.a["ped_due"] != 0).sum())           # arenas the side stream steps behind the re-plan
         waited += n_due; split += 0 < n_due < E
         if t > 0:
-            r.replan(64)                                     # the serial sequence: ... step, replan, step ...
+            r.replan(cap)                                    # the serial sequence: ... step, replan, step ...
         ro, rout = r.step(act)
         if graphs:
             go, gout = g.step_graphed(torch.from_numpy(act).to(gpu.dev))
         else:
-            go, gout = g.step_overlapped(torch.from_numpy(act).to(gpu.dev), 64)
+            go, gout = g.step_overlapped(torch.from_numpy(act).to(gpu.dev), cap)
         _eq(go.cpu().numpy(), ro, "obs at step %d" % t)
         for k in rout:
             _eq(gout[k].cpu().numpy(), rout[k], "%s at step %d" % (k, t))
@@ -913,6 +917,8 @@ def test_replan_beside_the_step_equals_the_serial_sequence(gpu, graphs):
     _state_equal(g, r, cfg, "at the end")
     assert waited >= 5 and split >= 5, (waited, split)
     assert g.counters() == r.counters() and r.counters()["replan_served"] >= 5
+    if E >= 100:
+        assert r.counters()["replan_unserved"] > 0, "the cap was never hit"
 
 
 def test_long_routes_on_the_device(gpu, golden_dir):
