@@ -118,7 +118,11 @@ def cpu_baseline(wl, seconds=15.0):
     from nav_gym_amd import abi, lib, robots, world
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ref
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cpu_quota()
+    # threads = the CPU time the process may actually use: the cgroup's quota where there is one (the GPU boxes of this
+    # pool show 256 CPUs and grant 16: more threads than that only take turns -- profiles/r05_cpu/scaling.txt)
+    cores = max(1, min(visible, int(quota + 0.999))) if quota else visible
     E = min(wl["envs"], 8 * cores)
     cfg = lib.default_config(n_envs=E, map_h=wl["size"], map_w=wl["size"], max_peds=max(wl["peds"], 1),
                              ped_model=abi.PED_SFM if wl["peds"] else abi.PED_NONE, n_spawn=16, auto_reset=1, seed=1234)
@@ -134,10 +138,13 @@ def cpu_baseline(wl, seconds=15.0):
     host = {k: v.numpy() for k, v in arrays.items()}
     host["scan_threshold"] = ref.scan_threshold(cfg, robots.footprint_array("keti", "threshold_footprint"))
     host["scan_discomfort"] = ref.scan_threshold(cfg, robots.footprint_array("keti", "discomfort_threshold_footprint"))
-    r = ref.RefSim(cfg, host)
+    nthr = min(cores, E)
+    # the fields -- what the march reads at random -- in pages first touched by the thread that marches them (pinned, static
+    # split: navsim_field_local_copy_cpu): on the GPU box's two sockets every thread then reads its own node's memory
+    host["field"] = ref.field_local_copy(host["field"], nthr)
+    r = ref.RefSim(cfg, host, keep=("field",))
     r.reset_obs()
     rng = np.random.default_rng(0)
-    nthr = min(cores, E)
 
     def actions(n):
         return np.stack([rng.uniform(0, 0.5, (n, E)), rng.uniform(-0.64, 0.64, (n, E))], axis=2)
@@ -159,13 +166,20 @@ def cpu_baseline(wl, seconds=15.0):
     # SURVEY.md 8d extras, bounded to a few seconds each: the same loop on ONE thread, and a
     # "reference-shaped" step (1 arena, 512 beams over 2*pi, 1000x1000 map, 10 pedestrians, every
     # pedestrian's own 512-beam scan computed each step as env.py:685-693 does)
+    # ONE thread on one thread's share of the arenas (the same working set per core as in the all-core run)
+    E1 = max(1, E // nthr)
+    c1t = cfg.copy(); c1t.n_envs = E1
+    h1t = {k: (v if k in ("scan_threshold", "scan_discomfort", "beam_table") else v[:E1]) for k, v in host.items()}
+    r1t = ref.RefSim(c1t, h1t)
+    r1t.reset_obs()
+    acts1 = lambda n: np.stack([rng.uniform(0, 0.5, (n, E1)), rng.uniform(-0.64, 0.64, (n, E1))], axis=2)
+    r1t.step_native_threads(acts1(2), 1)
     t1 = time.perf_counter()
     m = 0
-    one_call_1 = max(2, int(per_call * 1.0 / max(nthr, 1)) // 2 * 2)
     while time.perf_counter() - t1 < 3.0:
-        r.step_native_threads(actions(one_call_1), 1)
-        m += one_call_1
-    one_thread = E * m / (time.perf_counter() - t1)
+        r1t.step_native_threads(acts1(per_call), 1)
+        m += per_call
+    one_thread = E1 * m / (time.perf_counter() - t1)
     # SURVEY.md 8d work counters: distance-field probes per ray of the oracle's march (calc_range, env.py:425) on
     # this workload's arenas -- a few steps on the calling thread (the histogram is per thread)
     ref.probe_hist(reset=True)
@@ -204,13 +218,30 @@ def cpu_baseline(wl, seconds=15.0):
     except Exception:
         pass
     return dict(value=E * n / dt, unit="env-steps/s", cores=nthr, kind="port",
-                sample="%d arenas x %d steps of the same workload (oracle/navsim_ref.c navsim_step_threads_cpu: %d POSIX threads, "
-                       "arenas split statically, %.1f s)" % (E, n, nthr, dt),
+                sample="%d arenas x %d steps of the same workload (oracle/navsim_ref.c navsim_step_threads_cpu: %d pinned POSIX "
+                       "threads, arenas split statically, fields node-local, %.1f s); value_1_thread: one thread on %d arenas"
+                       % (E, n, nthr, dt, E1),
                 value_1_thread=one_thread, parallel_efficiency=(E * n / dt) / max(one_thread * nthr, 1e-9),
+                cpus_visible=visible, cpu_quota=quota,
                 probes_per_ray=probes,
                 reference_shaped_us_per_step=ref_shaped_us,
                 reference_shaped="1 arena, 512 beams, 1000x1000 map, 10 pedestrians + their 512-beam scans, 1 thread "
                                  "(restatement, not the reference binary)")
+
+
+def cpu_quota():
+    """CPUs' worth of time the cgroup grants this process (cgroup v2 cpu.max, v1 cfs quota / period), None = unlimited."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
 
 
 def _free_port():

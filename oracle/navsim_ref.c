@@ -1,3 +1,4 @@
+#define _GNU_SOURCE            /* sched_getaffinity / pthread_setaffinity_np: the CPU baseline pins its threads */
 /* navsim_ref.c -- TEST INFRASTRUCTURE: CPU oracle for the NavGym step() hot path.
  * See navsim_ref.h for the parity status of every row.  Compile with -ffp-contract=off
  * (oracle/Makefile): the HIP kernels must reproduce these float32/float64 operation sequences
@@ -11,6 +12,8 @@
 
 #include <float.h>
 #include <pthread.h>
+#include <sched.h>
+#include <sys/mman.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1046,28 +1049,75 @@ int navsim_step_cpu(const navsim_config* c, const navsim_state* st, const navsim
  * the Python thread pool around navsim_step_range_cpu spent its time dispatching -- 5 % parallel efficiency on 256 threads).
  * n_steps steps of every arena on n_threads POSIX threads: thread t owns the arenas [E t / n, E (t + 1) / n) for the whole
  * run and never waits for another thread -- arenas are independent (env.py:80-131: all state is one env's), so there is no
- * barrier between steps.  actions [n_steps, E, 2]; obs_a holds the current observations and receives those of even-numbered
+ * barrier between steps, and a thread takes each of its arenas through all n_steps before the next (cache blocking).  actions [n_steps, E, 2]; obs_a holds the current observations and receives those of even-numbered
  * runs (step s reads one buffer and writes the other: n_steps even -> the final rows are in obs_a again); io supplies the
  * output arrays.  Same arithmetic as navsim_step_cpu, arena by arena. */
 typedef struct {
     const navsim_config* c; const navsim_state* st; navsim_step_io io; const double* actions;
-    float* obs[2]; int32_t e0, e1, n_steps; int rc;
+    float* obs[2]; int32_t e0, e1, n_steps; int rc; int cpu;
+    const float* copy_src; float* copy_dst; size_t copy_per_arena;      /* navsim_field_local_copy_cpu */
 } step_job;
+
+/* thread t of n runs on the t-th CPU the process may use (`allowed`, taken before any thread is pinned): a thread keeps its
+ * arenas' data in ITS core's caches and, after navsim_field_local_copy_cpu, on its own memory node */
+static int nth_allowed_cpu(const cpu_set_t* allowed, int t) {
+    const int n = CPU_COUNT(allowed);
+    if (n <= 0) return -1;
+    int want = t % n;
+    for (int cpu = 0; cpu < CPU_SETSIZE; ++cpu)
+        if (CPU_ISSET(cpu, allowed) && want-- == 0) return cpu;
+    return -1;
+}
+static void pin_self(int cpu) {
+    if (cpu < 0) return;
+    cpu_set_t one;
+    CPU_ZERO(&one); CPU_SET(cpu, &one);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+}
 
 static void* step_worker(void* arg) {
     step_job* j = (step_job*)arg;
+    pin_self(j->cpu);
+    if (j->copy_dst) {                                                /* first touch of the copy by the thread that will read it */
+        memcpy(j->copy_dst + (size_t)j->e0 * j->copy_per_arena, j->copy_src + (size_t)j->e0 * j->copy_per_arena,
+               sizeof(float) * j->copy_per_arena * (size_t)(j->e1 - j->e0));
+        j->rc = NAVSIM_OK;
+        return NULL;
+    }
     const size_t E = (size_t)j->c->n_envs;
     float* scan = (float*)malloc(sizeof(float) * (size_t)j->c->n_beams);
-    for (int32_t s = 0; s < j->n_steps; ++s) {
-        navsim_step_io io = j->io;
-        io.action = j->actions + (size_t)s * E * 2;
-        io.obs_prev = j->obs[s & 1];
-        io.obs = j->obs[1 - (s & 1)];
-        for (int e = j->e0; e < j->e1; ++e) step_env(j->c, j->st, &io, e, scan);
-    }
+    /* arena by arena, every arena through ALL its steps before the next one: arenas are independent and the actions of every
+     * step are there, so the order is free -- and one arena's field (1 MB at 500 x 500 cells) stays in the core's cache for
+     * the whole run instead of the thread's eight being cycled through it once per step */
+    for (int e = j->e0; e < j->e1; ++e)
+        for (int32_t s = 0; s < j->n_steps; ++s) {
+            navsim_step_io io = j->io;
+            io.action = j->actions + (size_t)s * E * 2;
+            io.obs_prev = j->obs[s & 1];
+            io.obs = j->obs[1 - (s & 1)];
+            step_env(j->c, j->st, &io, e, scan);
+        }
     free(scan);
     j->rc = NAVSIM_OK;
     return NULL;
+}
+
+/* jobs[t].cpu from the process's allowed CPUs, run every job (the calling thread takes the first), give the caller its
+ * affinity back */
+static int run_jobs(step_job* jobs, pthread_t* th, int n_threads) {
+    cpu_set_t allowed;
+    const int have = sched_getaffinity(0, sizeof(allowed), &allowed) == 0;
+    for (int t = 0; t < n_threads; ++t) jobs[t].cpu = (have && n_threads > 1) ? nth_allowed_cpu(&allowed, t) : -1;
+    int started = 0;
+    for (int t = 1; t < n_threads; ++t, ++started)
+        if (pthread_create(&th[t], NULL, step_worker, &jobs[t]) != 0) break;
+    step_worker(&jobs[0]);
+    for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
+    for (int t = started + 1; t < n_threads; ++t) step_worker(&jobs[t]);  /* a thread that could not be created: run its share here */
+    if (have && n_threads > 1) (void)pthread_setaffinity_np(pthread_self(), sizeof(allowed), &allowed);
+    int rc = NAVSIM_OK;
+    for (int t = 0; t < n_threads; ++t) if (jobs[t].rc != NAVSIM_OK) rc = jobs[t].rc;
+    return rc;
 }
 
 int navsim_step_threads_cpu(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, const double* actions,
@@ -1087,17 +1137,38 @@ int navsim_step_threads_cpu(const navsim_config* c, const navsim_state* st, cons
         jobs[t].e1 = (int32_t)((long long)c->n_envs * (t + 1) / n_threads);
         jobs[t].rc = NAVSIM_E_ARG;
     }
-    int started = 0;
-    for (int t = 1; t < n_threads; ++t, ++started)
-        if (pthread_create(&th[t], NULL, step_worker, &jobs[t]) != 0) break;
-    step_worker(&jobs[0]);                                              /* the calling thread takes the first share */
-    for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
-    for (int t = started + 1; t < n_threads; ++t) step_worker(&jobs[t]);  /* a thread that could not be created: run its share here */
-    rc = NAVSIM_OK;
-    for (int t = 0; t < n_threads; ++t) if (jobs[t].rc != NAVSIM_OK) rc = jobs[t].rc;
+    rc = run_jobs(jobs, th, n_threads);
     free(jobs); free(th);
     return rc;
 }
+
+/* A copy of the distance fields [E, H, W] whose pages are first touched by the thread that steps those arenas in
+ * navsim_step_threads_cpu (same static split, same CPUs): on a multi-socket host the march then reads its own node's memory
+ * instead of the node of whoever built the fields.  Free it with navsim_free_cpu. */
+float* navsim_field_local_copy_cpu(const float* field, int32_t n_envs, int32_t map_h, int32_t map_w, int32_t n_threads) {
+    if (!field || n_envs <= 0 || map_h <= 0 || map_w <= 0 || n_threads < 1) return NULL;
+    if (n_threads > n_envs) n_threads = n_envs;
+    const size_t per = (size_t)map_h * map_w;
+    /* untouched pages, 2 MB-aligned and advised as huge pages: the march reads the fields at random, and with 4 KB pages
+     * over gigabytes of fields nearly every probe of an all-core run pays a page walk on top of its cache miss */
+    float* dst = NULL;
+    const size_t bytes = sizeof(float) * per * (size_t)n_envs;
+    if (posix_memalign((void**)&dst, (size_t)2 << 20, bytes) != 0) dst = NULL;
+    if (dst) (void)madvise(dst, bytes, MADV_HUGEPAGE);
+    step_job* jobs = (step_job*)calloc((size_t)n_threads, sizeof(step_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
+    if (!dst || !jobs || !th) { free(dst); free(jobs); free(th); return NULL; }
+    for (int t = 0; t < n_threads; ++t) {
+        jobs[t].e0 = (int32_t)((long long)n_envs * t / n_threads);
+        jobs[t].e1 = (int32_t)((long long)n_envs * (t + 1) / n_threads);
+        jobs[t].copy_src = field; jobs[t].copy_dst = dst; jobs[t].copy_per_arena = per;
+        jobs[t].rc = NAVSIM_E_ARG;
+    }
+    (void)run_jobs(jobs, th, n_threads);
+    free(jobs); free(th);
+    return dst;
+}
+void navsim_free_cpu(void* p) { free(p); }
 
 /* first observation after reset() (env.py:808-831) */
 int navsim_reset_obs_cpu(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,

@@ -94,6 +94,11 @@ int navsim_step_range_cpu(const navsim_config* cfg, const navsim_state* st, cons
 int navsim_step_threads_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io, const double* actions,
                             float* obs_a, float* obs_b, int32_t n_threads, int32_t n_steps);
 
+/* a copy of the fields [E, H, W] first touched by the threads of navsim_step_threads_cpu(n_threads) (node-local on a
+ * multi-socket host); NULL on failure; release with navsim_free_cpu */
+float* navsim_field_local_copy_cpu(const float* field, int32_t n_envs, int32_t map_h, int32_t map_w, int32_t n_threads);
+void navsim_free_cpu(void* p);
+
 int navsim_reset_obs_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                          const uint8_t* mask);
 

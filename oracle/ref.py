@@ -340,11 +340,35 @@ def probe_hist(reset=True):
     return h
 
 
+def field_local_copy(field, n_threads):
+    """navsim_field_local_copy_cpu: the float32 fields [E, H, W] copied into pages first touched by the threads that will
+    march them (RefSim.step_native_threads with the same thread count).  Returns an array that keeps the buffer alive."""
+    f = np.ascontiguousarray(field, dtype=np.float32)
+    E, H, W = f.shape
+    L = lib()
+    L.navsim_field_local_copy_cpu.restype = C.c_void_p
+    L.navsim_field_local_copy_cpu.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.navsim_free_cpu.argtypes = [C.c_void_p]
+    ptr = L.navsim_field_local_copy_cpu(_p(f), E, H, W, int(n_threads))
+    if not ptr:
+        return f
+
+    class _Owner(object):
+        def __del__(self, L=L, ptr=ptr):
+            L.navsim_free_cpu(ptr)
+    buf = (C.c_float * (E * H * W)).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=np.float32).reshape(E, H, W)
+    arr = arr.view(type("_LocalField", (np.ndarray,), {}))
+    arr._owner = _Owner()
+    return arr
+
+
 class RefSim(object):
     """Holds the numpy state of E envs and steps them through navsim_step_cpu."""
 
-    def __init__(self, cfg, arrays):
-        """arrays: dict name -> numpy array for every non-NULL field of navsim_state."""
+    def __init__(self, cfg, arrays, keep=()):
+        """arrays: dict name -> numpy array for every non-NULL field of navsim_state.  keep: names of arrays to use in place
+        (not copied: bench.py's node-local field copy)."""
         self.cfg = cfg.copy() if hasattr(cfg, "copy") else cfg
         self.cfg.field_format = abi.FIELD_F32     # the oracle always reads the float32 field
         self.a = {}
@@ -354,7 +378,7 @@ class RefSim(object):
             if arr is None:
                 setattr(self.st, name, None)
                 continue
-            arr = np.ascontiguousarray(arr, dtype=dtype).copy()
+            arr = arr if name in keep else np.ascontiguousarray(arr, dtype=dtype).copy()
             want = abi.resolve_shape(shape, self.cfg)
             if arr.shape != want:
                 raise ValueError("%s: shape %s, expected %s" % (name, arr.shape, want))
