@@ -79,6 +79,10 @@ def build_sim(wl, base, E, seed=1234, device="cuda:0"):
     if wl.get("regen"):
         cfg.regen_cap = max(16, E // 16)          # arenas regenerated per step at most (c5: ~5 finish per step)
     cfg.regen_indoor_ratio = float(wl.get("indoor_ratio", 0.0))
+    if wl.get("pipeline", 0):                     # --pregen-pipeline P: episodes shorter than 4 P steps restart in place
+        cfg.regen_min_steps = 4 * int(wl["pipeline"])
+        if wl.get("install", True):               # ... and the finished arenas install their staged worlds inside the step
+            cfg.regen_cap = E
     occ = world.make_maps(E, wl["size"], seed, env_index_base=base, indoor_ratio=wl.get("indoor_ratio", 0.0))
     goal = (10.0, 20.0) if wl["size"] >= 400 else (2.0, 4.0)
     arrays = world.make_world(cfg, occ, n_peds=wl["peds"], device=device, min_goal_dist=goal[0], max_goal_dist=goal[1],
@@ -105,7 +109,7 @@ def build_sim(wl, base, E, seed=1234, device="cuda:0"):
     s = sim.NavSim(cfg, arrays, device=device)
     s.reset_obs()
     if wl.get("regen") and wl.get("pregen", False):
-        s.enable_pregen()               # next worlds staged ahead of time on a side stream (navsim_regen_swap)
+        s.enable_pregen(pipeline=int(wl.get("pipeline", 0)), install=bool(wl.get("pipeline", 0)) and wl.get("install", True))    # next worlds staged ahead of time on a side stream (navsim_regen_swap)
     return cfg, s, arrays, occ
 
 
@@ -369,6 +373,11 @@ def main():
     ap.add_argument("--pregen", action="store_true",
                     help="c5: worlds staged ahead on a side stream + navsim_regen_swap instead of navsim_regen after every step "
                          "(measured: +11-14 %% at 128-256 arenas per GPU, +-0 at the 512 of c5 where the step kernel fills the chip)")
+    ap.add_argument("--pregen-pipeline", type=int, default=0, metavar="P",
+                    help="with --pregen: a staging pass every P steps, waited for two periods later (NavSim.enable_pregen(pipeline=P)); "
+                         "sets cfg.regen_min_steps = 4 P -- episodes shorter than that restart on their old map")
+    ap.add_argument("--pregen-swap-kernel", action="store_true",
+                    help="with --pregen-pipeline: install the staged worlds with navsim_regen_swap after the step instead of inside it (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the K timed steps as one captured hipGraph: auto = where a step is several launches (c5's "
@@ -609,7 +618,9 @@ def measure(args, scaling, ctx, light=False):
         wl["rects"] = False
     if args.rects:
         wl["rects"] = True
-    wl["pregen"] = bool(args.pregen)
+    wl["pregen"] = bool(args.pregen or args.pregen_pipeline)
+    wl["pipeline"] = int(args.pregen_pipeline)
+    wl["install"] = not args.pregen_swap_kernel
     wl["defer_reset_scan"] = args.defer_reset_scan
     base, E_local = shard_of(wl, scaling, rank, world_size)
     E_total = wl["total"] if scaling == "strong" else world_size * wl["envs"]
@@ -717,15 +728,21 @@ def measure(args, scaling, ctx, light=False):
     fence()
     # The K timed steps are launch-bound between kernels (~5 us of host gap per 220 us kernel): optionally capture
     # them once as a hipGraph and replay it.  Every node keeps its own action slice and observation buffers.
-    if args.graph == "on" and getattr(sim, "pregen", False):
-        raise SystemExit("bench: --pregen stages worlds on a side stream with host-side bookkeeping; it does not capture into a hipGraph")
-    if (args.graph == "on" or (args.graph == "auto" and regen and not getattr(sim, "pregen", False))) and gatherer is None:
+    piped = bool(getattr(sim, "pg_period", 0))       # pipelined staging passes: fork / join inside the capture (NavSim.pregen_join)
+    if args.graph == "on" and getattr(sim, "pregen", False) and not piped:
+        raise SystemExit("bench: --pregen without --pregen-pipeline waits for a pass of the previous step on the host's side of the "
+                         "capture; it does not go into a hipGraph")
+    if (args.graph == "on" or (args.graph == "auto" and regen and (piped or not getattr(sim, "pregen", False)))) and gatherer is None:
         try:
             cur0 = sim.cur
+            if piped:
+                sim.pregen_sync()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 for t in range(K):
                     run(Wm + t)
+                if piped:
+                    sim.pregen_join()
         except Exception as exc:                      # capture unsupported here: plain launches
             if args.graph == "on":
                 raise
@@ -815,10 +832,12 @@ def measure(args, scaling, ctx, light=False):
                             "scan_noise_std %.3g"
                             % (args.workload, E_total, scaling, E, B, H, W, args.field,
                                " + rect records" if rects else "", args.indoor_ratio, wl["peds"], wl.get("robot", "keti"),
-                               ("new random map per episode (%s)" % ("worlds staged ahead, navsim_regen_swap" if getattr(sim, "pregen", False) else "navsim_regen")) if regen else "auto-respawn in place",
+                               ("new random map per episode (%s)" % (("worlds staged ahead, installed inside the step (navsim_step_install)" if getattr(sim, "pg_install", False) else "worlds staged ahead, navsim_regen_swap") if getattr(sim, "pregen", False) else "navsim_regen")) if regen else "auto-respawn in place",
                                args.noise_std),
                 "envs_total": E_total, "envs_per_gpu": E, "n_beams": B, "map": [H, W],
                 "pedestrians": wl["peds"], "obs_gather": args.gather, "episodes_finished_rank0": n_done,
+                "regen_counters_rank0": (sim.counters() if regen else None),
+                "regen_min_steps": int(cfg.regen_min_steps), "pregen_pipeline": int(getattr(sim, "pg_period", 0) or 0),
                 "launch": "hipGraph replay of the K steps" if graph is not None else "one launch per step",
                 "ranks": world_size, "collective_backend": (backend if world_size > 1 else None),
                 "scan_noise_std": args.noise_std, "rect_table": rects, "rect_valid_tile_frac": tile_frac,

@@ -213,6 +213,14 @@ typedef struct navsim_config {
                                          arena (c5: the restarted arenas' second scans were 10 of the step's 49 us); the masked
                                          launch costs ~4 ns per arena, so not for thousands of arenas per GPU.  0 = the step scans
                                          itself (default).  Not with navsim_regen_swap. */
+    int32_t regen_min_steps;          /* > 0: an arena whose episode ended after FEWER steps than this restarts in place (same map,
+                                         next entry of its start / goal table) instead of receiving a new world from navsim_regen /
+                                         navsim_regen_swap; counted in counters[NAVSIM_COUNTER_REGEN_SHORT].  A rule of the
+                                         simulation's own history (navsim_state.done_steps), whatever the timing: it is what lets
+                                         worlds be generated AHEAD of time several steps deep (nav_gym_amd/sim.py enable_pregen
+                                         with a pipeline) and still be installed deterministically -- a world staged when an
+                                         arena restarts is guaranteed complete regen_min_steps steps later.  0 (default): every
+                                         finished arena is eligible.  Needs st->done_steps. */
 } navsim_config;
 
 #define NAVSIM_ACTION_TWIST  0   /* io->action = (v, omega): the reference's action (env.py:591) */
@@ -323,6 +331,17 @@ typedef struct navsim_state {
      * Read by navsim_step_part only: it splits a step into the arenas with and without a pedestrian waiting for
      * navsim_replan, so that the re-plan of step t runs beside step t + 1 of all the other arenas. */
     const unsigned long long* ped_due_prev;
+    /* [E] or NULL: written by navsim_step when an arena finishes (cfg.auto_reset): the number of steps its episode lasted.
+     * Read by navsim_regen / navsim_regen_swap for cfg.regen_min_steps. */
+    int32_t* done_steps;
+    /* [E] or NULL: the slot of the five per-map arrays (field, field_overflow, rect_table, rect_index, costmap) that holds
+     * arena e's map; NULL = slot e.  Those arrays then have max(map_slot) + 1 entries.  For navsim_step_install without map
+     * copies: the live and the staged state point at the SAME five arrays of 2 E slots, each with its own table (live
+     * 0 .. E-1, staged E .. 2E-1 to begin with), and an install exchanges the two states' entries for the arena.  Every
+     * entry point that reads or writes a map goes through the table (the step through the instantiations navsim_step_install
+     * uses, whatever the call: packed fields only, and navsim_step_part / navsim_step_replan return NAVSIM_E_UNSUPPORTED);
+     * not with cfg.shared_field. */
+    int32_t* map_slot;
 } navsim_state;
 
 #define NAVSIM_N_COUNTERS              8
@@ -335,6 +354,10 @@ typedef struct navsim_state {
 #define NAVSIM_COUNTER_ROUTES_CUT      4   /* routes longer than cfg.max_waypoints, stored cut (navsim_regen with
                                               regen_plan, navsim_replan) */
 #define NAVSIM_COUNTER_ROUTES_RESUMED  5   /* cut routes navsim_replan continued to their own goal (ped_goal) */
+#define NAVSIM_COUNTER_REGEN_SHORT     6   /* finished arenas whose episode was shorter than cfg.regen_min_steps: restarted in place */
+#define NAVSIM_COUNTER_REGEN_LATE      7   /* navsim_regen_swap (pipelined): eligible arenas whose staged world was not complete --
+                                              the caller's pipeline is deeper than cfg.regen_min_steps covers; they restart in
+                                              place and this stays 0 when the caller keeps the documented order */
 
 #define NAVSIM_DRAWS_PER_ARENA      464
 #define NAVSIM_DRAW_KIND            0   /* np.random.random() < indoor_ratio             (env.py:295) */
@@ -527,9 +550,30 @@ size_t navsim_regen_workspace_bytes(const navsim_config* cfg);
  * navsim_regen_stage (io->done must be `want`, io->obs the staged observation buffer) merges mark into want, runs
  * navsim_regen on the staged state and clears want for the arenas it served. */
 int    navsim_regen_swap(const navsim_config* cfg, const navsim_state* live, const navsim_state* stage,
-                         const navsim_step_io* io, const float* stage_obs, const uint8_t* want, uint8_t* mark, void* stream);
+                         const navsim_step_io* io, const float* stage_obs, const uint8_t* want, uint8_t* mark,
+                         const long long* ready, void* stream);
 int    navsim_regen_stage(const navsim_config* cfg, const navsim_state* stage, const navsim_step_io* io, uint8_t* want,
-                          uint8_t* mark, void* workspace, size_t workspace_bytes, void* stream);
+                          uint8_t* mark, long long* ready, void* workspace, size_t workspace_bytes, void* stream);
+/* Round 5, the PIPELINED form (ready != NULL, cfg.regen_min_steps > 0): staging passes need not finish before the next swap.
+ * ready [2 E] int64 (the second half is the passes' scratch; initialise [0, E) with the staged episode numbers once every arena
+ * is staged): navsim_regen_stage records for every arena it served the episode number it staged; navsim_regen_swap installs a finished arena's staged world iff its episode lasted at least cfg.regen_min_steps
+ * steps (live->done_steps) AND ready[e] equals the episode the arena now starts -- the first is a rule of the simulation (the
+ * oracle's navsim_regen_cpu applies it too), the second a safety net that only fails when the caller queued its staging
+ * passes too late (counters[NAVSIM_COUNTER_REGEN_LATE]); want[] is then not consulted.  mark [E rounded up to 4] uint8,
+ * 4-byte aligned: set and consumed with 32-bit atomics, so swaps may run while a pass merges it.  The caller's order
+ * (NavSim.enable_pregen(pipeline=P)): a staging pass every P steps on a side stream behind an event of that step; before the
+ * swap of step k P, wait for the pass queued at step (k - 2) P; cfg.regen_min_steps >= 4 P. */
+/* navsim_step + the pipelined navsim_regen_swap in ONE launch: an arena that finishes in this step, whose episode lasted
+ * cfg.regen_min_steps steps and whose staged world is ready (ready[e] == the episode that starts), takes that world -- its own
+ * workgroup copies the staged rows in place of the restart's second scan -- and asks for the next one (mark, stage->episode);
+ * every other finished arena restarts in place exactly as navsim_step leaves it and asks for a world with its new episode
+ * number.  Result = navsim_step followed by navsim_regen with regen_cap >= n_envs (every finished arena decides alone: the
+ * call needs cfg.regen_cap >= cfg.n_envs; the staging passes' cap is the one of the config THEY are given).  Counters as
+ * navsim_regen_swap.  Packed fields, pedestrians inside the step (ped_split 0 / 1); NAVSIM_E_UNSUPPORTED otherwise.
+ * The caller queues the staging passes as for the pipelined swap (replace "swap of step" by "step"). */
+int    navsim_step_install(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
+                           const navsim_state* stage, const float* stage_obs, uint8_t* mark, const long long* ready,
+                           void* stream);
 int    navsim_regen(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                     void* workspace, size_t workspace_bytes, void* stream);
 

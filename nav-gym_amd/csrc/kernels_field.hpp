@@ -122,6 +122,13 @@ __device__ __forceinline__ float march_pos(float x0, float dx, float t) {
 // 8x8-cell tiles, one tile = one 128-B line = one HBM fill (profiles/gather_granularity.py): a
 // fan of adjacent beams touches ~2.2x fewer lines than with float32 rows, and sqrtf(d2) is the
 // very float the float32 field holds.
+// Which slot of the per-map arrays (field, overflow plane, rect records, rect index rows, costmap) holds arena e's map:
+// navsim_state.map_slot (NULL: the arena's own index).  navsim_step_install exchanges the live and the staged state's entries
+// instead of copying a map.
+__device__ __forceinline__ int map_slot_of(const navsim_config& c, const navsim_state& st, int e) {
+    return c.shared_field ? 0 : (st.map_slot ? st.map_slot[e] : e);
+}
+
 struct FieldF32 {
     const float* p; int W;
     __device__ __forceinline__ FieldF32(const void* base, const float*, int e, int H, int W_)

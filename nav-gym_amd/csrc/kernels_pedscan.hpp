@@ -62,8 +62,9 @@ __device__ __forceinline__ void ped_scan_core(const navsim_config& c, const navs
     // the barrier behind the march publishes info_s
     prim_in_range<BLOCK>(nseg_s, nseg_s, lx_s, ly_s, rmax * 1.0001f + 0.01f, pr, (float)step,
                          (float)(c.ped_angle_min + (double)lth_s));
-    const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, H, W);
-    const char* rects = RECT ? (const char*)st.rect_table + (size_t)(c.shared_field ? 0 : e) * rect_tiles_per_map(H, W) * sizeof(uint4)
+    const int ms = map_slot_of(c, st, e);
+    const Field field(st.field, st.field_overflow, ms, H, W);
+    const char* rects = RECT ? (const char*)st.rect_table + (size_t)ms * rect_tiles_per_map(H, W) * sizeof(uint4)
                              : nullptr;
     const unsigned tpr = (unsigned)((W + 7) >> kRectShift);
     const float max_range = march_limit(H, W, c.ped_range_max, c.resolution);

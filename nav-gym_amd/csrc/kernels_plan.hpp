@@ -275,7 +275,7 @@ __device__ __forceinline__ void replan_one(const navsim_config& c, const navsim_
     const int q = e * N + i;
     const int Hc = c.map_h / 5, Wc = c.map_w / 5;
     const double res_c = c.resolution * 5.0;
-    const uint8_t* cost = st.costmap + (size_t)(c.shared_field ? 0 : e) * Hc * Wc;
+    const uint8_t* cost = st.costmap + (size_t)map_slot_of(c, st, e) * Hc * Wc;
     const uint64_t genv = (uint64_t)(c.env_index_base + e);
     const uint64_t when = (uint64_t)st.steps[e] + ((uint64_t)st.episode[e] << 40);
     const double px = st.ped_pose[(size_t)q * 3], py = st.ped_pose[(size_t)q * 3 + 1];

@@ -176,9 +176,10 @@ __global__ __launch_bounds__(256) void maps_closed_kernel(const uint8_t* __restr
 // (round-4 advisor: the assertion was never verified against the world it was made about).
 template <typename Field>
 __global__ __launch_bounds__(256) void world_closed_kernel(const void* __restrict__ field, const float* __restrict__ overflow,
-                                                           int H, int W, int32_t* __restrict__ n_open) {
+                                                           int H, int W, int32_t* __restrict__ n_open,
+                                                           const int32_t* __restrict__ map_slot) {
     const int e = blockIdx.x, tid = threadIdx.x, ring = kRectClosedRing;
-    const Field f(field, overflow, e, H, W);
+    const Field f(field, overflow, map_slot ? map_slot[e] : e, H, W);
     int open_cells = 0;
     if (H <= 2 * ring || W <= 2 * ring) open_cells = 1;
     else {

@@ -33,14 +33,25 @@ __device__ __forceinline__ int live_size(const navsim_config& c, const int* __re
 // Whole 256-thread workgroup; two barriers.
 // `skip` (optional): arenas with skip[e] != 0 are not eligible (navsim_regen_swap: their staged world is not ready).
 // excl_out / lo_out / hi_out (optional): this thread's slice of the arenas and the number of eligible ones before it.
+// Eligibility beyond the done flag (round 5): cfg.regen_min_steps -- an arena whose episode lasted fewer steps restarts in
+// place (done_steps: what the step recorded) -- and, for the pipelined swap, the staged world's completeness (ready[e] = the
+// episode number the last finished staging pass generated for arena e, episode[e] = the one the arena now starts).
+struct RegenRule { const int32_t* done_steps; int min_steps; const long long* ready; const int64_t* episode; };
+__device__ __forceinline__ bool regen_long_enough(const RegenRule& r, int e) {
+    return r.min_steps <= 0 || !r.done_steps || r.done_steps[e] >= r.min_steps;
+}
 __device__ __forceinline__ int regen_slot(const uint8_t* __restrict__ done, int E, int cap, int b, int& total,
                                           const uint8_t* __restrict__ skip = nullptr, int* excl_out = nullptr,
-                                          int* lo_out = nullptr, int* hi_out = nullptr, int* all_out = nullptr) {
+                                          int* lo_out = nullptr, int* hi_out = nullptr, int* all_out = nullptr,
+                                          const RegenRule rule = RegenRule{nullptr, 0, nullptr, nullptr}) {
     __shared__ int wave_tot[4], found_s;
     const int tid = threadIdx.x, lane = tid & 63;
     const int per = (E + 255) / 256;
     const int lo = tid * per, hi = (lo + per < E) ? lo + per : E;
-    auto eligible = [&](int e) { return done[e] != 0 && !(skip && skip[e] != 0); };
+    auto eligible = [&](int e) {
+        return done[e] != 0 && !(skip && skip[e] != 0) && regen_long_enough(rule, e) &&
+               !(rule.ready && rule.ready[e] != (long long)rule.episode[e]);
+    };
     int n = 0;
     for (int e = lo; e < hi; ++e) n += eligible(e);
     int incl = n;
@@ -93,6 +104,15 @@ __device__ __forceinline__ void count_served(const navsim_state& st, int served_
     if (unserved > 0) atomicAdd(&st.counters[served_slot + 1], (unsigned long long)unserved);
 }
 
+// counters[NAVSIM_COUNTER_REGEN_SHORT]: finished arenas whose episode was shorter than cfg.regen_min_steps (one 256-thread workgroup)
+__device__ __forceinline__ void count_short(const navsim_config& c, const navsim_state& st, const uint8_t* __restrict__ done) {
+    if (!st.counters || c.regen_min_steps <= 0 || !st.done_steps) return;
+    int n = 0;
+    for (int e = (int)threadIdx.x; e < c.n_envs; e += 256) n += done[e] != 0 && st.done_steps[e] < c.regen_min_steps;
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
+    if ((threadIdx.x & 63) == 0 && n > 0) atomicAdd(&st.counters[NAVSIM_COUNTER_REGEN_SHORT], (unsigned long long)n);
+}
+
 // The kernel also OPENS navsim_regen: workgroup b selects its arena (regen_slot), publishes list[b] (-1: none) and,
 // workgroup 0, the count; every later kernel of the call reads those.  (Worlds of outdoor maps only skip this kernel:
 // regen_maps_kernel opens the call itself.)
@@ -104,8 +124,10 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
     __shared__ int tx[152], ty[152];
     const int b = blockIdx.x, tid = threadIdx.x;
     int total, all;
-    const int e = regen_slot(done, c.n_envs, cap, b, total, nullptr, nullptr, nullptr, nullptr, &all);
+    const RegenRule rule = {st.done_steps, c.regen_min_steps, nullptr, nullptr};
+    const int e = regen_slot(done, c.n_envs, cap, b, total, nullptr, nullptr, nullptr, nullptr, &all, rule);
     if (tid == 0) { list[b] = e; if (b == 0) { *count = total; count_served(st, NAVSIM_COUNTER_REGEN_SERVED, total, all - total); } }
+    if (b == 0) count_short(c, st, done);
     if (e < 0) return;
     const int size = c.map_w;
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
@@ -269,8 +291,9 @@ __device__ __forceinline__ void regen_maps_item(const navsim_config& c, const na
     __syncthreads();
     // where the field goes: the arena's own buffers, or this slot's scratch (installed by regen_field_kernel)
     const bool f32 = c.field_format == NAVSIM_FIELD_F32;
-    char* fs = direct ? (char*)st.field + (size_t)e * field_bytes : field_scratch + (size_t)b * field_bytes;
-    float* ov = direct ? (st.field_overflow ? (float*)st.field_overflow + (size_t)e * size * size : nullptr)
+    const int ms = map_slot_of(c, st, e);                    // where the arena's map lives (navsim_state.map_slot)
+    char* fs = direct ? (char*)st.field + (size_t)ms * field_bytes : field_scratch + (size_t)b * field_bytes;
+    float* ov = direct ? (st.field_overflow ? (float*)st.field_overflow + (size_t)ms * size * size : nullptr)
                        : (ovf_scratch ? ovf_scratch + (size_t)b * size * size : nullptr);
     // Work units: (tile row, block of 32 tiles) -- 256 threads = 32 tiles x 8 rows, thread = (tile of the block, row of the
     // tile); unit u of the map belongs to slice u % kRegenSlices.  A thread owns EIGHT consecutive cells of a row = one
@@ -279,7 +302,7 @@ __device__ __forceinline__ void regen_maps_item(const navsim_config& c, const na
     const int tpr = (size + 7) >> 3, blocks = (tpr + 31) >> 5;
     const int ry = tid & 7, tsub = tid >> 3;
     if (index_all && rect_all && slice == 0) {               // the list of the index form: walls 0..3, box o at 4 + o, the rest defined
-        uint2* lst = (uint2*)(index_all + (size_t)e * rect_index_row_bytes(size, size));
+        uint2* lst = (uint2*)(index_all + (size_t)map_slot_of(c, st, e) * rect_index_row_bytes(size, size));
         if (tid < kRectListLen) {
             uint2 v = make_uint2(0u, 0u);
             if (tid < 4 + n_obs) regen_rect_of(tid, live, size, hw, ocx, ocy, v.x, v.y);
@@ -383,10 +406,10 @@ __device__ __forceinline__ void regen_maps_item(const navsim_config& c, const na
                     regen_rect_of(set.a, live, size, hw, ocx, ocy, rec.x, rec.y);
                     regen_rect_of(set.b < 0 ? set.a : set.b, live, size, hw, ocx, ocy, rec.z, rec.w);
                 }
-                (rect_all + (size_t)e * rect_tiles_per_map(size, size))[(size_t)ty * tpr + tx] = rec;
+                (rect_all + (size_t)ms * rect_tiles_per_map(size, size))[(size_t)ty * tpr + tx] = rec;
                 // the index form of the same record (kernels_rect.hpp): the generator's own rectangle numbers
                 if (index_all) {
-                    uint16_t* pair = (uint16_t*)(index_all + (size_t)e * rect_index_row_bytes(size, size) + (size_t)kRectListLen * 8);
+                    uint16_t* pair = (uint16_t*)(index_all + (size_t)ms * rect_index_row_bytes(size, size) + (size_t)kRectListLen * 8);
                     pair[(size_t)ty * tpr + tx] = (set.bad || set.a < 0) ? (uint16_t)kRectNoIndex
                                                                          : (uint16_t)((unsigned)set.a | ((unsigned)(set.b < 0 ? set.a : set.b) << 8));
                 }
@@ -411,9 +434,11 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
     int n_items;
     if (done) {
         int total, all;
-        (void)regen_slot(done, c.n_envs, cap, 0, total, nullptr, nullptr, nullptr, nullptr, &all);
+        (void)regen_slot(done, c.n_envs, cap, 0, total, nullptr, nullptr, nullptr, nullptr, &all,
+                         RegenRule{st.done_steps, c.regen_min_steps, nullptr, nullptr});
         n_items = total * kRegenSlices;
         if (blockIdx.x == 0) {
+            count_short(c, st, done);
             if (threadIdx.x == 0) { *count = total; count_served(st, NAVSIM_COUNTER_REGEN_SERVED, total, all - total); }
             for (int b = total + (int)threadIdx.x; b < cap; b += 256) list[b] = -1;
         }
@@ -425,7 +450,8 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
         int e;
         if (done) {
             int total;
-            e = regen_slot(done, c.n_envs, cap, b, total);
+            e = regen_slot(done, c.n_envs, cap, b, total, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           RegenRule{st.done_steps, c.regen_min_steps, nullptr, nullptr});
             if (slice == 0 && threadIdx.x == 0) { list[b] = e; kind[b] = 0; regen_params(c, st, e); }
         } else {
             e = list[b];
@@ -434,6 +460,14 @@ __global__ __launch_bounds__(256) void regen_maps_kernel(navsim_config c, navsim
                         done != nullptr, rect_all, index_all, ocx, ocy);       // (kind[b] of this call may not be written yet: not read then)
         __syncthreads();                                                 // ocx / ocy are rewritten by the next item
     }
+}
+
+// navsim_state.map_slot: the kernels below that are handed an array's base pointer and the list find a map through mlist[b],
+// the slot that holds the map of arena list[b] (without a table the list itself serves)
+__global__ __launch_bounds__(256) void regen_map_list_kernel(const int* __restrict__ list, const int32_t* __restrict__ map_slot,
+                                                             int* __restrict__ mlist, int cap) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < cap) mlist[b] = list[b] >= 0 ? map_slot[list[b]] : -1;
 }
 
 // install the new distance field of every regenerated arena (kRegenSlices workgroups per map, 16-byte copies)
@@ -582,7 +616,7 @@ __global__ __launch_bounds__(kCommitBlock) void regen_commit_kernel(navsim_confi
     constexpr int kWaves = kCommitBlock / 64;
     const int size = live_size(c, kind, b);
     const int N = c.max_peds, K = c.n_spawn, P = c.max_waypoints;
-    const Field f(st.field, st.field_overflow, e, c.map_h, c.map_w);
+    const Field f(st.field, st.field_overflow, map_slot_of(c, st, e), c.map_h, c.map_w);
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
     double* sp = (double*)st.spawn_pose + (size_t)e * K * 3;
     double* sg = (double*)st.spawn_goal + (size_t)e * K * 2;
@@ -718,7 +752,7 @@ __global__ __launch_bounds__(256) void regen_robot_sample_kernel(navsim_config c
     const int Hc = c.map_h / 5, Wc = c.map_w / 5;
     const int live_c = live_size(c, ws.kind, b) / 5;         // candidates are cells of the live map's costmap
     const double res_c = c.resolution * 5.0;
-    const uint8_t* cost = ws.cost + (size_t)(ws.cost_by_arena ? e : b) * Hc * Wc;
+    const uint8_t* cost = ws.cost + (size_t)(ws.cost_by_arena ? map_slot_of(c, st, e) : b) * Hc * Wc;
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
     for (int idx = tid; idx < kRegenRounds * Q; idx += 256) {
         const int round = idx / Q, k = idx - round * Q;
@@ -769,7 +803,7 @@ __global__ __launch_bounds__(256) void regen_robot_accept_kernel(navsim_config c
     int idx = (int)(rg_key(c.seed, genv, ep, 0x5eedULL) % (uint64_t)K);
     {   // first resolved pair from idx on (cyclic) whose first scan is outside the discomfort zone (env.py:776-781);
         // none: the first resolved one; none resolved: idx.  Block-uniform control flow.
-        const Field f(st.field, st.field_overflow, e, c.map_h, c.map_w);
+        const Field f(st.field, st.field_overflow, map_slot_of(c, st, e), c.map_h, c.map_w);
         const uint8_t* res = ws.res_robot + (size_t)b * K;
         int first_res = -1, pick = -1;
         for (int s_ = 0; s_ < K && pick < 0; ++s_) {
@@ -808,7 +842,7 @@ __global__ __launch_bounds__(256) void regen_ped_sample_kernel(navsim_config c, 
     const int Hc = c.map_h / 5, Wc = c.map_w / 5;
     const int live_c = live_size(c, ws.kind, b) / 5;
     const double res_c = c.resolution * 5.0;
-    const uint8_t* cost = ws.cost + (size_t)(ws.cost_by_arena ? e : b) * Hc * Wc;
+    const uint8_t* cost = ws.cost + (size_t)(ws.cost_by_arena ? map_slot_of(c, st, e) : b) * Hc * Wc;
     const uint64_t genv = (uint64_t)(c.env_index_base + e), ep = (uint64_t)st.episode[e];
     const double rx = st.robot_pose[3 * (size_t)e], ry = st.robot_pose[3 * (size_t)e + 1];
     int n = (c.ped_model == NAVSIM_PED_NONE) ? 0 : st.n_peds[e];
@@ -894,7 +928,7 @@ __global__ __launch_bounds__(BLOCK) void regen_plan_kernel(navsim_config c, navs
         if (ok0) return;
     }
     const int Hc = c.map_h / 5, Wc = c.map_w / 5, P = c.max_waypoints;
-    plan_query<BLOCK>(ws.cost + (size_t)(ws.cost_by_arena ? list[b] : b) * Hc * Wc, Hc, Wc, c.resolution * 5.0, c.origin_x, c.origin_y,
+    plan_query<BLOCK>(ws.cost + (size_t)(ws.cost_by_arena ? map_slot_of(c, st, list[b]) : b) * Hc * Wc, Hc, Wc, c.resolution * 5.0, c.origin_x, c.origin_y,
                       ws.qstart[2 * q], ws.qstart[2 * q + 1], ws.qgoal[2 * q], ws.qgoal[2 * q + 1], ped_stage ? 2.0 : 5.0, P,
                       ws.qwp + q * P * 2, ws.qnwp + q, nullptr, ped_stage ? nullptr : ws.qlen + q, ped_stage ? ws.qcut + q : nullptr);
 }
@@ -964,7 +998,7 @@ __global__ __launch_bounds__(kReplanBlock) void replan_kernel(navsim_config c, n
                                                               int cap) {
     // a handful of small workgroups beside a step kernel that keeps every SIMD's issue slots busy: first in line
     __builtin_amdgcn_s_setprio(3);
-    const int b = blockIdx.x, N = c.max_peds, P = c.max_waypoints, tid = threadIdx.x;
+    const int b = blockIdx.x, N = c.max_peds, tid = threadIdx.x;
     int total;
     const int q = replan_pick<kReplanBlock>(due, c.n_envs, N, b, total);
     if (b == 0 && tid == 0) {
@@ -1009,31 +1043,47 @@ __global__ __launch_bounds__(256) void spawn_decisions_kernel(navsim_config c, c
 // Grid (cap, kRegenSlices): slice 0 of a slot moves the small arrays, all slices share the large buffers.
 // --------------------------------------------------------------------------------------------
 struct SwapBig { char* dst; const char* src; size_t bytes; };          // per-arena stride = bytes
+// mark[]: one byte per arena, set and consumed through the 32-bit word that holds it (atomics), so that a swap may set a flag
+// while a staging pass merges the array (the pipelined form): stage_request, kernels_step.hpp
 __global__ __launch_bounds__(256) void regen_swap_kernel(navsim_config c, navsim_state live, navsim_state stage,
                                                          navsim_step_io io, const float* __restrict__ stage_obs,
                                                          const uint8_t* __restrict__ want, uint8_t* __restrict__ mark,
+                                                         const long long* __restrict__ ready,
                                                          int cap, SwapBig b0, SwapBig b1, SwapBig b2, SwapBig b3, SwapBig b4) {
     const int b = blockIdx.x, tid = threadIdx.x;                      // (grid (cap, slices): opt-in path, not bounded yet)
     int total, excl, lo, hi;
+    // Pipelined form (ready != NULL): eligible = finished, its episode lasted cfg.regen_min_steps steps (the simulation's rule)
+    // and the staged world is the one for the episode that starts now (the safety net); want[] is not consulted -- a staging
+    // pass may be merging it right now.
+    const RegenRule rule = {live.done_steps, c.regen_min_steps, ready, live.episode};
     // eligible: finished AND staged (want[e] == 0).  want[] is only READ here -- every workgroup of the launch must see
     // the same flags to agree on the selection; what this launch decides is written to mark[] and merged into want[] by
     // the staging pass (navsim_regen_stage), which the next swap waits for.
-    const int e = regen_slot(io.done, c.n_envs, cap, b, total, want, &excl, &lo, &hi);
+    const int e = regen_slot(io.done, c.n_envs, cap, b, total, ready ? nullptr : want, &excl, &lo, &hi, nullptr, rule);
     if (b == 0 && blockIdx.y == 0) {
         // a finished arena that is not installed now plays its next episode in place (the step respawned it on the old
         // map and advanced episode[e]); the world staged for it carries a stale episode number: stage it again
-        int pos = excl, n_in = 0, n_out = 0;
+        int pos = excl, n_in = 0, n_out = 0, n_short = 0, n_late = 0;
         for (int a = lo; a < hi; ++a) {
             if (io.done[a] == 0) continue;
-            const bool elig = want[a] == 0;
+            const bool lng = regen_long_enough(rule, a);
+            const bool rdy = ready ? ready[a] == (long long)live.episode[a] : want[a] == 0;
+            const bool elig = lng && rdy;
+            n_short += !lng; n_late += lng && !rdy;
             const bool installed = elig && pos < cap;
             pos += elig;
-            if (!installed) { stage.episode[a] = live.episode[a] + 1; mark[a] = 1; }
-            n_in += installed; n_out += !installed;
+            if (!installed) stage_request(stage.episode, mark, a, live.episode[a] + 1);      // (kernels_step.hpp: number first, then the flag)
+            n_in += installed; n_out += !installed && elig;
         }
         count_served(live, NAVSIM_COUNTER_REGEN_SERVED, n_in, n_out);
+        if (live.counters && n_short) atomicAdd(&live.counters[NAVSIM_COUNTER_REGEN_SHORT], (unsigned long long)n_short);
+        if (live.counters && n_late) atomicAdd(&live.counters[NAVSIM_COUNTER_REGEN_LATE], (unsigned long long)n_late);
     }
     if (e < 0) return;
+    if (live.map_slot && stage.map_slot && blockIdx.y == 0 && tid == 0) {       // the maps change places where they lie (navsim_state.map_slot)
+        const int32_t a = live.map_slot[e], b2_ = stage.map_slot[e];
+        live.map_slot[e] = b2_; stage.map_slot[e] = a;
+    }
     const SwapBig big[5] = {b0, b1, b2, b3, b4};
     for (int k = 0; k < 5; ++k) {                            // field, overflow plane, rect records, costmap, rect index rows
         if (!big[k].dst) continue;
@@ -1050,10 +1100,13 @@ __global__ __launch_bounds__(256) void regen_swap_kernel(navsim_config c, navsim
             for (size_t i = lo + tid; i < hi; i += 256) dst[i] = src[i];
         }
     }
-    if (blockIdx.y != 0) return;
+    // the small arrays: one per slice (each is a load -> store round trip; a single workgroup walking through all twenty
+    // of them one after the other took 15 of the kernel's 22 us on c5)
     const int N = c.max_peds, K = c.n_spawn, P = c.max_waypoints, D = c.n_scan_stack * c.n_beams + NAVSIM_OBS_TAIL;
+    int turn = 0;
     auto row = [&](auto* dst, const auto* src, size_t n) {    // n elements of arena e
-        if (!dst || !src) return;
+        const bool mine = (int)blockIdx.y == (turn++ % (int)gridDim.y);
+        if (!mine || !dst || !src) return;
         for (size_t i = tid; i < n; i += 256) dst[(size_t)e * n + i] = src[(size_t)e * n + i];
     };
     row(live.scan_noise_std, stage.scan_noise_std, 1);
@@ -1079,22 +1132,38 @@ __global__ __launch_bounds__(256) void regen_swap_kernel(navsim_config c, navsim
         row(live.ped_goal, stage.ped_goal, (size_t)N * 2);
     }
     row(io.obs, stage_obs, D);
-    if (tid == 0) {
+    if (tid == 0 && blockIdx.y == gridDim.y - 1) {
         if (io.achieved_goal) { io.achieved_goal[2 * e] = (float)stage.robot_pose[3 * (size_t)e]; io.achieved_goal[2 * e + 1] = (float)stage.robot_pose[3 * (size_t)e + 1]; }
         if (io.desired_goal) { io.desired_goal[2 * e] = (float)stage.robot_goal[2 * (size_t)e]; io.desired_goal[2 * e + 1] = (float)stage.robot_goal[2 * (size_t)e + 1]; }
         if (live.ped_due) live.ped_due[e] = 0ull;           // new pedestrians: nobody waits for navsim_replan
-        stage.episode[e] = live.episode[e] + 1;              // the world after THIS one
-        mark[e] = 1;
+        stage_request(stage.episode, mark, e, live.episode[e] + 1);      // the world after THIS one
     }
 }
 
 // opens a staging pass: what the last swap decided becomes part of want[]
-__global__ __launch_bounds__(256) void regen_merge_want_kernel(uint8_t* __restrict__ want, uint8_t* __restrict__ mark, int E) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e < E && mark[e]) { want[e] = 1; mark[e] = 0; }
+__global__ __launch_bounds__(256) void regen_merge_want_kernel(uint8_t* __restrict__ want, uint8_t* __restrict__ mark, int E,
+                                                               long long* __restrict__ ready, const int64_t* __restrict__ stage_episode) {
+    const int w = blockIdx.x * 256 + threadIdx.x;            // one 32-bit word of mark[] = four arenas
+    if (4 * w >= E) return;
+    const unsigned m = atomicExch((unsigned*)mark + w, 0u);  // (a swap may be setting flags of this word right now)
+    __threadfence();
+    for (int k = 0; k < 4; ++k) {
+        const int e = 4 * w + k;
+        if (e >= E) break;
+        if ((m >> (8 * k)) & 0xFFu) want[e] = 1;
+        // the episode numbers this pass generates for, as they stand NOW (ready[E + e]): a swap that re-marks an arena while the
+        // pass runs changes stage_episode[e] under it -- the world it leaves is then for no episode at all, and must not be
+        // recorded as the new number's (the arena is marked again and staged by the next pass)
+        if (ready) ready[E + e] = (long long)__hip_atomic_load(&stage_episode[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
-// closes a staging pass (navsim_regen on the staged state with want[] as its done flags): the arenas it served are staged
+// closes a staging pass (navsim_regen on the staged state with want[] as its done flags): the arenas it served are staged,
+// for the episode numbers the pass started with
 __global__ __launch_bounds__(256) void regen_clear_want_kernel(const int* __restrict__ count, const int* __restrict__ list,
-                                                               uint8_t* __restrict__ want) {
-    for (int b = threadIdx.x; b < *count; b += 256) want[list[b]] = 0;
+                                                               uint8_t* __restrict__ want, long long* __restrict__ ready, int E) {
+    for (int b = threadIdx.x; b < *count; b += 256) {
+        const int e = list[b];
+        want[e] = 0;
+        if (ready) ready[e] = ready[E + e];
+    }
 }

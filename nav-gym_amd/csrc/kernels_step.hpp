@@ -10,6 +10,8 @@ struct StepShared {
     double old_rp[3];             // robot pose at the start of the step (social force input)
     double act[2];                // action after the turning-radius clamp
     float lx, ly, lth;            // float32 lidar pose (env.py:386)
+    int steps_now;                // steps[e] after this step's increment (done_steps: read in the reward block without a global
+                                  // load; sits in what was padding -- the struct's size decides how many arenas share a CU)
     double cT, sT;                // cos / sin of (double)lth for the beam-table fast path
     int i0, j0;                   // integer ray origin (env.py:419)
     int nseg, ndisc;
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(kPedUpdateBlock) void ped_update_kernel(navsim_conf
     __syncthreads();
     if (slot_ok && i == 0) slot_n[s] = n;
     const size_t pq = (size_t)(slot_ok ? e : 0) * N + (is_ped ? i : 0);
-    const Field field(st.field, st.field_overflow, c.shared_field ? 0 : (slot_ok ? e : 0), c.map_h, c.map_w);
+    const Field field(st.field, st.field_overflow, map_slot_of(c, st, slot_ok ? e : 0), c.map_h, c.map_w);
     double pp[3] = {0.0, 0.0, 0.0}, pvel[2] = {0.0, 0.0};
     double* wp = st.ped_waypoints + (pq * P) * 2;
     int nw = 1, head = 0;
@@ -947,15 +949,142 @@ __device__ __forceinline__ int due_arena_rank(const unsigned long long* __restri
     return rank;
 }
 
+// navsim_step_install: what the step needs to install a finished arena's STAGED world itself (navsim_regen_swap's work, done by
+// the arena's own workgroup in place of the respawn's second scan).  big[]: field, overflow plane, rect records, costmap, rect
+// index rows -- per-arena stride = bytes.
+#ifndef NAVSIM_INSTALL_UNROLL
+#define NAVSIM_INSTALL_UNROLL 8
+#endif
+struct StepInstallBig { char* dst; const char* src; size_t bytes; };
+struct StepInstall {
+    navsim_state stage;                  // the staged state (include/navsim.h navsim_regen_stage)
+    const float* stage_obs;              // [E][D] first observations of the staged worlds
+    uint8_t* mark;                       // [E rounded up to 4] "stage me again" flags (32-bit atomics)
+    const long long* ready;              // [E] episode number the last finished staging pass generated for
+    StepInstallBig big[5];
+};
+// "stage arena e again, for episode ep": the number first, then the flag (a staging pass that takes the flag -- possibly while
+// this launch still runs -- must see the number: both go through the device-coherent path)
+__device__ __forceinline__ void stage_request(int64_t* stage_episode, uint8_t* mark, int e, int64_t ep) {
+    __hip_atomic_store(&stage_episode[e], ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    atomicOr((unsigned*)(mark + (e & ~3)), 1u << (8 * (e & 3)));
+}
+// every array navsim_regen writes, arena e, staged -> live (the list of regen_swap_kernel); whole workgroup
+template <int BLOCK>
+__device__ __forceinline__ void install_arena(const navsim_config& c, const navsim_state& live, const navsim_step_io& io,
+                                              const StepInstall& in, const int e, float* __restrict__ obs_row) {
+    const int tid = threadIdx.x;
+    // the map: with slot tables in both states (they then share the five per-map arrays) the two entries change places --
+    // the staged map becomes the live one where it lies, the old live map is what the next staging pass overwrites;
+    // otherwise the map is copied, by this one workgroup (c5, 500 x 500 cells: 600 KB, 12 us at the end of the launch)
+    const bool by_slot = live.map_slot && in.stage.map_slot;
+    if (by_slot && tid == 0) {
+        const int32_t a = live.map_slot[e], b = in.stage.map_slot[e];
+        live.map_slot[e] = b; in.stage.map_slot[e] = a;
+    }
+    for (int k = 0; k < 5 && !by_slot; ++k) {
+        if (!in.big[k].dst) continue;
+        const size_t bytes = in.big[k].bytes;
+        const char* src = in.big[k].src + (size_t)e * bytes;
+        char* dst = in.big[k].dst + (size_t)e * bytes;
+        if ((((size_t)(uintptr_t)src | (size_t)(uintptr_t)dst | bytes) & 15) == 0) {
+            const size_t n16 = bytes / 16;
+            size_t i = tid;
+#ifndef NAVSIM_DIAG_INSTALL_NO_BIG      // diagnostic build only (WRONG worlds): what do the map copies cost the launch?
+            constexpr int U = NAVSIM_INSTALL_UNROLL;             // loads in flight per lane: ONE workgroup moves the map
+            for (; i + (U - 1) * BLOCK < n16; i += U * BLOCK) {
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load((const u32x4*)src + i + u * BLOCK);   // read once
+#pragma unroll
+                for (int u = 0; u < U; ++u) ((u32x4*)dst)[i + u * BLOCK] = v[u];
+            }
+            for (; i < n16; i += BLOCK) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+#endif
+        } else {
+            for (size_t i = tid; i < bytes; i += BLOCK) dst[i] = src[i];
+        }
+    }
+    const navsim_state& stage = in.stage;
+    const int N = c.max_peds, K = c.n_spawn, P = c.max_waypoints, D = c.n_scan_stack * c.n_beams + NAVSIM_OBS_TAIL;
+    const bool peds = c.ped_model != NAVSIM_PED_NONE;
+    // The small arrays.  Every row is a load -> store round trip, and rows may alias as far as the compiler knows: walking through
+    // the twenty of them one after the other is twenty memory latencies (~25 us of the arena's tail on c5).  So: every row's
+    // first BLOCK elements are LOADED first, all rows, then stored; what a row has beyond BLOCK elements follows in a loop.
+#define NAVSIM_ROW_LOAD(name, dstp, srcp, cnt) \
+    const size_t n_##name = ((dstp) && (srcp)) ? (size_t)(cnt) : 0; \
+    auto v_##name = (srcp)[tid < (int)n_##name ? (size_t)e * n_##name + tid : 0];
+#define NAVSIM_ROW_STORE(name, dstp, srcp) \
+    if (tid < (int)n_##name) (dstp)[(size_t)e * n_##name + tid] = v_##name; \
+    for (size_t i = (size_t)tid + BLOCK; i < n_##name; i += BLOCK) (dstp)[(size_t)e * n_##name + i] = (srcp)[(size_t)e * n_##name + i];
+    // (a row that is absent has n = 0: its load reads element 0 of a pointer that may be NULL -- guard the pointer itself)
+#define NAVSIM_ROW_SRC(p) ((p) ? (p) : (decltype(p))live.steps)
+    NAVSIM_ROW_LOAD(noise, live.scan_noise_std, NAVSIM_ROW_SRC(stage.scan_noise_std), 1)
+    NAVSIM_ROW_LOAD(pose, live.robot_pose, NAVSIM_ROW_SRC(stage.robot_pose), 3)
+    NAVSIM_ROW_LOAD(goal, live.robot_goal, NAVSIM_ROW_SRC(stage.robot_goal), 2)
+    NAVSIM_ROW_LOAD(pact, live.prev_action, NAVSIM_ROW_SRC(stage.prev_action), 2)
+    NAVSIM_ROW_LOAD(ppose, live.prev_pose, NAVSIM_ROW_SRC(stage.prev_pose), 3)
+    NAVSIM_ROW_LOAD(nhist, live.n_hist, NAVSIM_ROW_SRC(stage.n_hist), 1)
+    NAVSIM_ROW_LOAD(steps, live.steps, NAVSIM_ROW_SRC(stage.steps), 1)
+    NAVSIM_ROW_LOAD(spose, live.spawn_pose, NAVSIM_ROW_SRC(stage.spawn_pose), (size_t)K * 3)
+    NAVSIM_ROW_LOAD(sgoal, live.spawn_goal, NAVSIM_ROW_SRC(stage.spawn_goal), (size_t)K * 2)
+    NAVSIM_ROW_LOAD(npeds, peds ? live.n_peds : nullptr, NAVSIM_ROW_SRC(stage.n_peds), 1)
+    NAVSIM_ROW_LOAD(ppos, peds ? live.ped_pose : nullptr, NAVSIM_ROW_SRC(stage.ped_pose), (size_t)N * 3)
+    NAVSIM_ROW_LOAD(pvel, peds ? live.ped_vel : nullptr, NAVSIM_ROW_SRC(stage.ped_vel), (size_t)N * 2)
+    NAVSIM_ROW_LOAD(pyaw, peds ? live.ped_prev_yaw : nullptr, NAVSIM_ROW_SRC(stage.ped_prev_yaw), N)
+    NAVSIM_ROW_LOAD(pdist, peds ? live.ped_dist : nullptr, NAVSIM_ROW_SRC(stage.ped_dist), (size_t)N * 3)
+    NAVSIM_ROW_LOAD(pvpref, peds ? (double*)live.ped_v_pref : nullptr, NAVSIM_ROW_SRC(stage.ped_v_pref), N)
+    NAVSIM_ROW_LOAD(plegs, peds ? (uint8_t*)live.ped_has_legs : nullptr, NAVSIM_ROW_SRC(stage.ped_has_legs), N)
+    NAVSIM_ROW_LOAD(pwp, peds ? live.ped_waypoints : nullptr, NAVSIM_ROW_SRC(stage.ped_waypoints), (size_t)N * P * 2)
+    NAVSIM_ROW_LOAD(pnwp, peds ? live.ped_n_waypoints : nullptr, NAVSIM_ROW_SRC(stage.ped_n_waypoints), N)
+    NAVSIM_ROW_LOAD(phead, peds ? live.ped_wp_head : nullptr, NAVSIM_ROW_SRC(stage.ped_wp_head), N)
+    NAVSIM_ROW_LOAD(pgoal, peds ? live.ped_goal : nullptr, NAVSIM_ROW_SRC(stage.ped_goal), (size_t)N * 2)
+    NAVSIM_ROW_LOAD(obs, obs_row - (size_t)e * D, in.stage_obs, D)
+    NAVSIM_ROW_STORE(noise, live.scan_noise_std, stage.scan_noise_std)
+    NAVSIM_ROW_STORE(pose, live.robot_pose, stage.robot_pose)
+    NAVSIM_ROW_STORE(goal, live.robot_goal, stage.robot_goal)
+    NAVSIM_ROW_STORE(pact, live.prev_action, stage.prev_action)
+    NAVSIM_ROW_STORE(ppose, live.prev_pose, stage.prev_pose)
+    NAVSIM_ROW_STORE(nhist, live.n_hist, stage.n_hist)
+    NAVSIM_ROW_STORE(steps, live.steps, stage.steps)
+    NAVSIM_ROW_STORE(spose, (double*)live.spawn_pose, stage.spawn_pose)
+    NAVSIM_ROW_STORE(sgoal, (double*)live.spawn_goal, stage.spawn_goal)
+    NAVSIM_ROW_STORE(npeds, live.n_peds, stage.n_peds)
+    NAVSIM_ROW_STORE(ppos, live.ped_pose, stage.ped_pose)
+    NAVSIM_ROW_STORE(pvel, live.ped_vel, stage.ped_vel)
+    NAVSIM_ROW_STORE(pyaw, live.ped_prev_yaw, stage.ped_prev_yaw)
+    NAVSIM_ROW_STORE(pdist, live.ped_dist, stage.ped_dist)
+    NAVSIM_ROW_STORE(pvpref, (double*)live.ped_v_pref, stage.ped_v_pref)
+    NAVSIM_ROW_STORE(plegs, (uint8_t*)live.ped_has_legs, stage.ped_has_legs)
+    NAVSIM_ROW_STORE(pwp, live.ped_waypoints, stage.ped_waypoints)
+    NAVSIM_ROW_STORE(pnwp, live.ped_n_waypoints, stage.ped_n_waypoints)
+    NAVSIM_ROW_STORE(phead, live.ped_wp_head, stage.ped_wp_head)
+    NAVSIM_ROW_STORE(pgoal, live.ped_goal, stage.ped_goal)
+    NAVSIM_ROW_STORE(obs, obs_row - (size_t)e * D, in.stage_obs)
+#undef NAVSIM_ROW_LOAD
+#undef NAVSIM_ROW_STORE
+#undef NAVSIM_ROW_SRC
+    if (tid == 0) {
+        if (io.achieved_goal) { io.achieved_goal[2 * e] = (float)stage.robot_pose[3 * (size_t)e]; io.achieved_goal[2 * e + 1] = (float)stage.robot_pose[3 * (size_t)e + 1]; }
+        if (io.desired_goal) { io.desired_goal[2 * e] = (float)stage.robot_goal[2 * (size_t)e]; io.desired_goal[2 * e + 1] = (float)stage.robot_goal[2 * (size_t)e + 1]; }
+        if (live.ped_due) live.ped_due[e] = 0ull;           // new pedestrians: nobody waits for navsim_replan
+    }
+}
+
 // The fused step of ONE arena by the calling workgroup.  BLOCK threads; PEDS: the pedestrian variants (primitives + culled merge
 // in LDS); RULE: the march step rule (NAVSIM_MARCH_*), a compile-time copy of cfg.march_rule so that the probe loop carries no
 // select.  PINL (pedestrian variants): the pedestrian phase is compiled in (wavefront 0 runs it beside the scan of the others;
 // 36-44 bytes of private scratch per lane under the 64-register cap, none in a hot loop); false = reset-only launches and
 // launches behind ped_update_kernel: no pedestrian phase, Scratch_Size 0.
-template <int BLOCK, bool PEDS, typename Field, int RULE, int RECT, bool PINL>
+// INSTALL (navsim_step_install): an arena that finishes takes its staged world instead of restarting in place, when its episode
+// was long enough (cfg.regen_min_steps) and the staged world is the one for the episode that starts (in->ready).
+template <int BLOCK, bool PEDS, typename Field, int RULE, int RECT, bool PINL, bool INSTALL = false>
 __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_state& st, const navsim_step_io& io, const int e,
                                            int reset_only, const int peds_done, const uint8_t* __restrict__ reset_mask,
-                                           unsigned dyn_lds_bytes, int park_lanes, unsigned rect_lds_offset) {
+                                           unsigned dyn_lds_bytes, int park_lanes, unsigned rect_lds_offset,
+                                           const StepInstall* in = nullptr) {
     __shared__ StepShared sh;
     // dynamic LDS: [the arena's index row (RECT = 2)][parked rays][pedestrian variants: float2 dir[B], float rng[B]][PedShared][pair table]
     extern __shared__ __attribute__((aligned(16))) char dyn_lds_all[];
@@ -969,8 +1098,12 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
     const int B = c.n_beams, S = c.n_scan_stack, N = c.max_peds, D = S * B + 7;
     const double dt = c.time_step;
     const uint64_t genv = (uint64_t)(c.env_index_base + e);
-    const Field field(st.field, st.field_overflow, c.shared_field ? 0 : e, c.map_h, c.map_w);
-    const uint4* rects = RECT ? (const uint4*)st.rect_table + (size_t)(c.shared_field ? 0 : e) * rect_tiles_per_map(c.map_h, c.map_w)
+    // where the arena's map lives: navsim_state.map_slot is honoured by the INSTALL instantiations only -- every launch on a
+    // state with a slot table is routed to them (dispatch_step); the lookup in front of the first field access cost the plain
+    // step 2.8 % on c2 (a scalar load per workgroup ahead of phase 0: 43.4 -> 42.2 M env-steps/s, same box)
+    const int ms = INSTALL ? map_slot_of(c, st, e) : (c.shared_field ? 0 : e);
+    const Field field(st.field, st.field_overflow, ms, c.map_h, c.map_w);
+    const uint4* rects = RECT ? (const uint4*)st.rect_table + (size_t)ms * rect_tiles_per_map(c.map_h, c.map_w)
                               : nullptr;
     if constexpr (RECT == 2) {
         // "Map tiles staged through LDS": the INDEX form of the arena's record table (kernels_rect.hpp: 2 KB of distinct
@@ -978,7 +1111,7 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
         // phase 0; every probe of the scans then reads LDS (~0.1 us) instead of global memory (0.5-2 us from L2 / HBM).
         uint4* tab_lds = (uint4*)dyn_lds_all;
         const size_t row_bytes = rect_index_row_bytes(c.map_h, c.map_w);
-        const uint4* src = (const uint4*)((const char*)st.rect_index + (size_t)(c.shared_field ? 0 : e) * row_bytes);
+        const uint4* src = (const uint4*)((const char*)st.rect_index + (size_t)ms * row_bytes);
         for (int i = threadIdx.x; i < (int)(row_bytes / 16); i += BLOCK) tab_lds[i] = src[i];
         rects = tab_lds;                                        // made visible by the barrier that ends phase 0
     }
@@ -1061,7 +1194,9 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
             sh.old_rp[0] = rp_g[0]; sh.old_rp[1] = rp_g[1]; sh.old_rp[2] = th_old;
             sh.nseg = 0; sh.ndisc = 0; sh.rescan = 0; sh.respawn = 0;
             if (!reset_only) {
-                st.steps[e] += 1;                              // env.py:592
+                const int64_t steps_now = st.steps[e] + 1;     // env.py:592
+                st.steps[e] = steps_now;
+                sh.steps_now = (int)steps_now;
                 sh.act[0] = a0; sh.act[1] = a1;
                 double p[3] = {sh.old_rp[0], sh.old_rp[1], sh.old_rp[2]};        // env.py:664
                 nv::set_vel_with(p, a0, a1, dt, c.axle_offset, s0, c0, s1, c1, nullptr);
@@ -1187,6 +1322,9 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
                 const double* sg = st.spawn_goal + ((size_t)e * c.n_spawn + idx) * 2;
                 sh.rp[0] = sp[0]; sh.rp[1] = sp[1]; sh.rp[2] = sp[2];
                 goal_g[0] = sg[0]; goal_g[1] = sg[1];
+#ifndef NAVSIM_DIAG_NO_DONE_STEPS    // diagnostic build only: what does the store cost the plain step's code?
+                if (st.done_steps) st.done_steps[e] = sh.steps_now;               // how long the episode lasted (cfg.regen_min_steps)
+#endif
                 st.episode[e] += 1;
                 st.steps[e] = 0;
                 // the first observation of the new episode draws its noise from the key a reset-only launch would use -- the
@@ -1196,6 +1334,17 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
                 // cfg.defer_reset_scan: the first observation of the new episode comes from the navsim_regen call that follows
                 // (one masked launch for every finished arena): no second scan here, the rows stay as scan A left them
                 sh.respawn = 1; sh.rescan = c.defer_reset_scan ? 0 : 1;
+                if constexpr (INSTALL) if (in->ready) {                 // (ready == NULL: a plain step on a state with slot tables)
+                    // (done_steps[e] and episode[e] as this block just left them: the ended episode's length, the new number)
+                    const bool lng = c.regen_min_steps <= 0 || st.done_steps[e] >= c.regen_min_steps;
+                    const bool rdy = in->ready[e] == (long long)st.episode[e];
+                    if (lng && rdy) { sh.respawn = 3; sh.rescan = 0; }          // 3: the staged world is installed below
+                    if (st.counters)
+                        atomicAdd(&st.counters[lng ? (rdy ? NAVSIM_COUNTER_REGEN_SERVED : NAVSIM_COUNTER_REGEN_LATE) : NAVSIM_COUNTER_REGEN_SHORT], 1ull);
+                    // installed: the world after this one; not installed: the arena plays its next episode in place, what is
+                    // staged for it carries a stale number
+                    stage_request(in->stage.episode, in->mark, e, st.episode[e] + 1);
+                }
             } else if (o.crash != 0.0f) {                       // env.py:707-717
                 sh.rp[0] = pv_g[0]; sh.rp[1] = pv_g[1]; sh.rp[2] = pv_g[2];
                 sh.rescan = 1;
@@ -1251,6 +1400,10 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
             st.arena_cost[e] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_begin);
     }
     NAVSIM_STAMP(6);
+    if constexpr (INSTALL) {
+        __syncthreads();                                       // what phase 6 wrote for the restart in place is overwritten
+        if (sh.respawn == 3) install_arena<BLOCK>(c, st, io, *in, e, obs_row);
+    }
 }
 
 // The fused step.  One workgroup = one arena (template arguments: step_arena).  reset_only: bit 0 = a reset-only launch, bit 1 =
@@ -1281,6 +1434,19 @@ void navsim_step_kernel(navsim_config c, navsim_state st,
     // pedestrian that waited for navsim_replan when the previous step ended
     if (part == NAVSIM_STEP_NOT_DUE && st.ped_due_prev[e] != 0ull) return;
     step_arena<BLOCK, PEDS, Field, RULE, RECT, PINL>(c, st, io, e, reset_only, peds_done, reset_mask, dyn_lds_bytes, park_lanes, rect_lds_offset);
+}
+
+// navsim_step_install: the step whose finished arenas install their staged worlds themselves (step_arena INSTALL).  Also every
+// other launch of the step kernel on a state with slot tables (navsim_state.map_slot): plain steps (in.ready == NULL: nothing is
+// installed) and reset-only launches.
+template <int BLOCK, bool PEDS, typename Field, int RULE, int RECT>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((PEDS && RECT == 2 && BLOCK == 256) ? NAVSIM_PEDS_WAVES_MIN : (!PEDS ? NAVSIM_NOPEDS_WAVES_MIN : 8), 8)))
+void navsim_step_install_kernel(navsim_config c, navsim_state st, navsim_step_io io, StepInstall in, int reset_only,
+                                const uint8_t* __restrict__ reset_mask,
+                                unsigned dyn_lds_bytes, int park_lanes, unsigned rect_lds_offset) {
+    const int e = st.launch_order ? st.launch_order[blockIdx.x] : (int)blockIdx.x;
+    if (e < 0) return;
+    step_arena<BLOCK, PEDS, Field, RULE, RECT, PEDS, true>(c, st, io, e, reset_only & 1, 0, reset_mask, dyn_lds_bytes, park_lanes, rect_lds_offset, &in);
 }
 
 // navsim_step_part, NAVSIM_STEP_DUE: the few arenas that waited for navsim_replan, as a COMPACT launch -- workgroup b steps the

@@ -43,7 +43,7 @@ namespace {
 // (threads per arena, pedestrians or not)
 #define NAVSIM_STEP_FAMILY(B, P) \
     extern "C" int navsim_step_launch_##B##_##P(const navsim_config*, const navsim_state*, const navsim_step_io*, int, \
-                                                const uint8_t*, void*, int, int, int); \
+                                                const uint8_t*, void*, int, int, int, const void*); \
     extern "C" int navsim_step_set_stamps_##B##_##P(unsigned long long*);
 NAVSIM_STEP_FAMILY(64, 0) NAVSIM_STEP_FAMILY(64, 1) NAVSIM_STEP_FAMILY(256, 0) NAVSIM_STEP_FAMILY(256, 1)
 NAVSIM_STEP_FAMILY(512, 0) NAVSIM_STEP_FAMILY(512, 1) NAVSIM_STEP_FAMILY(1024, 0) NAVSIM_STEP_FAMILY(1024, 1)
@@ -59,10 +59,19 @@ thread_local bool g_prepare_only = false;
 // grid > 0: that many workgroups instead of one per arena; st->launch_order then names each workgroup's arena, -1 = none
 // (navsim_regen's first observations: one workgroup per regenerated arena)
 int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
-                  int reset_only, const uint8_t* mask, hipStream_t s, int grid = 0, int aux = 0) {
+                  int reset_only, const uint8_t* mask, hipStream_t s, int grid = 0, int aux = 0, const StepInstall* install = nullptr) {
     int rc;
     const StepPlan p = plan_step(c, st, ((reset_only >> 2) & 3) >= NAVSIM_STEP_DUE ? 0 : grid);
     const bool peds = c->ped_model != NAVSIM_PED_NONE;
+    // a state with slot tables (navsim_state.map_slot): only the INSTALL instantiations look a map up through the table -- every
+    // launch goes to them, with nothing to install unless navsim_step_install says so
+    const StepInstall no_install = {};
+    if (st->map_slot && !install) {
+        if (((reset_only >> 2) & 3) != 0 || c->field_format != NAVSIM_FIELD_U16T || (peds && ped_split_on(c) && !(reset_only & 1)))
+            return NAVSIM_E_UNSUPPORTED;                                    // navsim_step_part / navsim_step_replan, float32 fields
+        install = &no_install;
+        reset_only |= 16;
+    }
     if (peds && !(reset_only & 1) && ped_split_on(c) && !g_prepare_only) {            // pedestrians ahead of the step (ped_split_on)
         const size_t pl = ped_update_lds_bytes(c);
         const int G = ped_pack(c->max_peds), pgrid = (c->n_envs + G - 1) / G;
@@ -72,8 +81,8 @@ int dispatch_step(const navsim_config* c, const navsim_state* st, const navsim_s
     }
     const int po = g_prepare_only ? 1 : 0;
 #define NAVSIM_STEP_CASE(B) \
-    case B: rc = peds ? navsim_step_launch_##B##_1(c, st, io, reset_only, mask, (void*)s, grid, po, aux) \
-                      : navsim_step_launch_##B##_0(c, st, io, reset_only, mask, (void*)s, grid, po, aux); break;
+    case B: rc = peds ? navsim_step_launch_##B##_1(c, st, io, reset_only, mask, (void*)s, grid, po, aux, install) \
+                      : navsim_step_launch_##B##_0(c, st, io, reset_only, mask, (void*)s, grid, po, aux, install); break;
     switch (p.block) {
         NAVSIM_STEP_CASE(64) NAVSIM_STEP_CASE(256) NAVSIM_STEP_CASE(512) NAVSIM_STEP_CASE(1024)
         default:   return NAVSIM_E_UNSUPPORTED;
@@ -212,9 +221,9 @@ int navsim_world_closed(const navsim_config* c, const navsim_state* st, int32_t*
     const int n = c->shared_field ? (c->n_envs > 0 ? 1 : 0) : c->n_envs;
     if (n == 0) return NAVSIM_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (c->field_format == NAVSIM_FIELD_F32) world_closed_kernel<FieldF32><<<n, 256, 0, s>>>(st->field, nullptr, c->map_h, c->map_w, n_open);
-    else if (st->field_overflow)             world_closed_kernel<FieldU16T><<<n, 256, 0, s>>>(st->field, st->field_overflow, c->map_h, c->map_w, n_open);
-    else                                     world_closed_kernel<FieldU16TN><<<n, 256, 0, s>>>(st->field, nullptr, c->map_h, c->map_w, n_open);
+    if (c->field_format == NAVSIM_FIELD_F32) world_closed_kernel<FieldF32><<<n, 256, 0, s>>>(st->field, nullptr, c->map_h, c->map_w, n_open, st->map_slot);
+    else if (st->field_overflow)             world_closed_kernel<FieldU16T><<<n, 256, 0, s>>>(st->field, st->field_overflow, c->map_h, c->map_w, n_open, st->map_slot);
+    else                                     world_closed_kernel<FieldU16TN><<<n, 256, 0, s>>>(st->field, nullptr, c->map_h, c->map_w, n_open, st->map_slot);
     return launch_status();
 }
 
@@ -404,6 +413,8 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
     if (c->action_kind != NAVSIM_ACTION_TWIST && c->action_kind != NAVSIM_ACTION_WHEELS) return NAVSIM_E_ARG;
     if (c->action_kind == NAVSIM_ACTION_WHEELS && !(c->wheel_track > 0.0)) return NAVSIM_E_ARG;
     if (c->defer_reset_scan != 0 && c->defer_reset_scan != 1) return NAVSIM_E_ARG;
+    if (c->regen_min_steps < 0) return NAVSIM_E_ARG;
+    if (st->map_slot && c->shared_field) return NAVSIM_E_ARG;              // one map for all arenas has no slots to choose from
     if (c->ped_model != NAVSIM_PED_NONE && (c->max_waypoints < 1 || c->max_waypoints > NAVSIM_MAX_WAYPOINTS)) return NAVSIM_E_ARG;
     if (st->rect_table && (c->field_format != NAVSIM_FIELD_U16T || c->map_h > 1024 || c->map_w > 1024)) return NAVSIM_E_UNSUPPORTED;
     if (st->rect_index && !st->rect_table) return NAVSIM_E_ARG;
@@ -498,7 +509,7 @@ int navsim_plan(const uint8_t* cost, const int32_t* map_index, int32_t n, int32_
 size_t navsim_regen_workspace_bytes(const navsim_config* c) {
     if (!c || c->regen_cap < 1) return 0;
     const size_t M = (size_t)c->regen_cap, cells = (size_t)c->map_h * c->map_w;
-    size_t b = 16 + M * 4;                                  // count, list
+    size_t b = 16 + M * 8;                                  // count, list, map slots of the list (navsim_state.map_slot)
     b = (b + 255) & ~(size_t)255;
     b += ((size_t)c->n_envs + 255) & ~(size_t)255;          // mask
     b += M * cells;                                         // occupancy scratch
@@ -543,6 +554,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     if (st->rect_table && (c->field_format != NAVSIM_FIELD_U16T || c->map_h > 1024)) return NAVSIM_E_UNSUPPORTED;
     if (workspace_bytes < navsim_regen_workspace_bytes(c) || !st->spawn_pose || !st->spawn_goal) return NAVSIM_E_ARG;
     if (c->regen_plan && (c->max_waypoints < 1 || c->max_waypoints > NAVSIM_MAX_WAYPOINTS)) return NAVSIM_E_ARG;
+    if (c->regen_min_steps < 0 || (c->regen_min_steps > 0 && !st->done_steps)) return NAVSIM_E_ARG;
     if (c->regen_plan && (c->n_spawn > 256 || c->map_h < 5 || !plan_fits(c->map_h / 5, c->map_w / 5) ||
                           plan_lds(c->map_h / 5, c->map_w / 5) > 64 * 1024))
         return NAVSIM_E_UNSUPPORTED;
@@ -555,7 +567,8 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     char* w = (char*)workspace;
     int* count = (int*)w;
     int* list = count + 4;
-    size_t off = (16 + (size_t)M * 4 + 255) & ~(size_t)255;
+    int* mlist = st->map_slot ? list + M : list;            // where the maps of the listed arenas live (regen_map_list_kernel)
+    size_t off = (16 + (size_t)M * 8 + 255) & ~(size_t)255;
     uint8_t* mask = (uint8_t*)(w + off);
     off += ((size_t)c->n_envs + 255) & ~(size_t)255;
     uint8_t* occ = (uint8_t*)(w + off);
@@ -597,6 +610,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     regen_maps_kernel<<<regen_grid(M), 256, 0, s>>>(*c, *st, count, list, need_occ ? occ : nullptr, grids, kind,
                                                             fscratch, fbytes, ovf_scratch, direct ? 1 : 0,
                                                             direct ? io->done : nullptr, M, direct_rects, direct_index);
+    if (st->map_slot) regen_map_list_kernel<<<(M + 255) / 256, 256, 0, s>>>(list, st->map_slot, mlist, M);
     if (c->regen_indoor_ratio > 0.0) {
         dt_columns_kernel<<<dim3((W + 63) / 64, M), 64 * kColSeg, 0, s>>>(occ, cols, H, W, count, kind);
         if (c->field_format == NAVSIM_FIELD_F32)
@@ -609,14 +623,14 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         char* rect_ws = w + off;
         off += navsim_build_rects_workspace_bytes(M, H, W) + 256;
         launch_build_rects(occ, M, H, W, fscratch, fbytes, c->field_format, ovf_scratch, (uint4*)st->rect_table, rect_ws,
-                           count, list, s);
+                           count, mlist, s);
         if (st->rect_index)
-            rect_index_kernel<<<M, 256, 0, s>>>((const uint4*)st->rect_table, H, W, (char*)st->rect_index, nullptr, count, list);
+            rect_index_kernel<<<M, 256, 0, s>>>((const uint4*)st->rect_table, H, W, (char*)st->rect_index, nullptr, count, mlist);
     }
     if (!direct) {
-        regen_field_kernel<<<regen_grid(M), 256, 0, s>>>((char*)st->field, count, list, fscratch, fbytes);
+        regen_field_kernel<<<regen_grid(M), 256, 0, s>>>((char*)st->field, count, mlist, fscratch, fbytes);
         if (ovf_scratch)
-            regen_field_kernel<<<regen_grid(M), 256, 0, s>>>((char*)st->field_overflow, count, list,
+            regen_field_kernel<<<regen_grid(M), 256, 0, s>>>((char*)st->field_overflow, count, mlist,
                                                                     (const char*)ovf_scratch, cells * sizeof(float));
     }
     if (c->regen_plan) {
@@ -641,7 +655,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         ws.res_robot = (uint8_t*)take((size_t)M * c->n_spawn);
         const size_t lds = plan_lds(Hc, Wc);
         costmap_kernel<<<dim3(((int)cc + 255) / 256, M), 256, 0, s>>>(occ, H, W, ws.cost, count,
-                                                                      st->costmap ? list : nullptr);
+                                                                      st->costmap ? mlist : nullptr);
         // the rounds of the reference's rejection loops (kernels_reset.hpp): all candidates drawn at once, round 0 planned, then
         // rounds 1-3 of the slots it left open in one launch, the first round that passes taken -- four launches per stage
         auto plan_pass = [&](int ped_stage, int pass) {
@@ -662,7 +676,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
             regen_ped_accept_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, ws);
         }
     } else if (st->costmap) {
-        costmap_kernel<<<dim3(((H / 5) * (W / 5) + 255) / 256, M), 256, 0, s>>>(occ, H, W, st->costmap, count, list);
+        costmap_kernel<<<dim3(((H / 5) * (W / 5) + 255) / 256, M), 256, 0, s>>>(occ, H, W, st->costmap, count, mlist);
     }
     if (!c->regen_plan) {
         if (c->field_format == NAVSIM_FIELD_F32)
@@ -688,10 +702,10 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     return dispatch_step(c, &st2, &io2, 1, nullptr, s, M);
 }
 
-int navsim_regen_swap(const navsim_config* c, const navsim_state* live, const navsim_state* stage, const navsim_step_io* io,
-                      const float* stage_obs, const uint8_t* want, uint8_t* mark, void* stream) {
-    (void)hipGetLastError();
-    if (!c || !live || !stage || !io || !io->done || !io->obs || !stage_obs || !want || !mark) return NAVSIM_E_ARG;
+extern "C++" {
+namespace {
+// navsim_regen_swap / navsim_step_install: the live and the staged state as a pair
+int check_stage_pair(const navsim_config* c, const navsim_state* live, const navsim_state* stage) {
     if (c->regen_cap < 1 || c->n_spawn < 1 || !c->auto_reset) return NAVSIM_E_ARG;
     if (c->defer_reset_scan) return NAVSIM_E_UNSUPPORTED;     // a staged world brings its own first observation; arenas beyond the cap would get none
     if (!live->field || !stage->field || !live->episode || !stage->episode || !live->spawn_pose || !stage->spawn_pose ||
@@ -702,29 +716,80 @@ int navsim_regen_swap(const navsim_config* c, const navsim_state* live, const na
         (live->rect_table != nullptr) != (stage->rect_table != nullptr) || (live->rect_index != nullptr) != (stage->rect_index != nullptr) ||
         (live->costmap != nullptr) != (stage->costmap != nullptr) || (live->ped_goal != nullptr) != (stage->ped_goal != nullptr))
         return NAVSIM_E_ARG;
-    if (c->n_envs == 0) return NAVSIM_OK;
+    return NAVSIM_OK;
+}
+// navsim_state.map_slot: both states or neither, and then over the SAME five arrays
+int check_map_slots(const navsim_state* live, const navsim_state* stage) {
+    if ((live->map_slot != nullptr) != (stage->map_slot != nullptr)) return NAVSIM_E_ARG;
+    if (live->map_slot && (live->map_slot == stage->map_slot || live->field != stage->field || live->field_overflow != stage->field_overflow ||
+                           live->rect_table != stage->rect_table || live->rect_index != stage->rect_index || live->costmap != stage->costmap))
+        return NAVSIM_E_ARG;
+    return NAVSIM_OK;
+}
+template <typename Big>
+void stage_big_buffers(const navsim_config* c, const navsim_state* live, const navsim_state* stage, Big big[5]) {
     const int H = c->map_h, W = c->map_w;
-    SwapBig big[5] = {};
     big[0] = {(char*)live->field, (const char*)stage->field, navsim_field_bytes(1, H, W, c->field_format)};
     if (live->field_overflow) big[1] = {(char*)live->field_overflow, (const char*)stage->field_overflow, (size_t)H * W * sizeof(float)};
     if (live->rect_table) big[2] = {(char*)live->rect_table, (const char*)stage->rect_table, navsim_rect_table_bytes(1, H, W)};
     if (live->costmap) big[3] = {(char*)live->costmap, (const char*)stage->costmap, (size_t)(H / 5) * (W / 5)};
     if (live->rect_index) big[4] = {(char*)live->rect_index, (const char*)stage->rect_index, rect_index_row_bytes(H, W)};
-    regen_swap_kernel<<<dim3(c->regen_cap, kRegenSlices), 256, 0, (hipStream_t)stream>>>(*c, *live, *stage, *io, stage_obs, want, mark,
+}
+}  // namespace
+}  // extern "C++"
+
+int navsim_step_install(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, const navsim_state* stage,
+                        const float* stage_obs, uint8_t* mark, const long long* ready, void* stream) {
+    (void)hipGetLastError();
+    int rc = check_step_args(c, st, io, 0);
+    if (rc != NAVSIM_OK) return rc;
+    if (!stage || !stage_obs || !mark || !ready || ((uintptr_t)mark & 3) != 0 || !st->done_steps || c->regen_min_steps < 1) return NAVSIM_E_ARG;
+    rc = check_stage_pair(c, st, stage);
+    if (rc != NAVSIM_OK) return rc;
+    // every finished arena decides for itself: there is no cap to apply in index order (navsim_regen_swap has one)
+    if (c->regen_cap < c->n_envs) return NAVSIM_E_UNSUPPORTED;
+    if (c->field_format != NAVSIM_FIELD_U16T || (c->ped_model != NAVSIM_PED_NONE && ped_split_on(c))) return NAVSIM_E_UNSUPPORTED;
+    if (c->n_envs == 0) return NAVSIM_OK;
+    rc = check_map_slots(st, stage);
+    if (rc != NAVSIM_OK) return rc;
+    StepInstall in = {};
+    in.stage = *stage; in.stage_obs = stage_obs; in.mark = mark; in.ready = ready;
+    if (!st->map_slot) stage_big_buffers(c, st, stage, in.big);             // (with slot tables the maps stay where they are)
+    return dispatch_step(c, st, io, 16, nullptr, (hipStream_t)stream, 0, 0, &in);
+}
+
+int navsim_regen_swap(const navsim_config* c, const navsim_state* live, const navsim_state* stage, const navsim_step_io* io,
+                      const float* stage_obs, const uint8_t* want, uint8_t* mark, const long long* ready, void* stream) {
+    (void)hipGetLastError();
+    if (!c || !live || !stage || !io || !io->done || !io->obs || !stage_obs || !want || !mark) return NAVSIM_E_ARG;
+    if (((uintptr_t)mark & 3) != 0) return NAVSIM_E_ARG;                 // mark[] is accessed through 32-bit atomics
+    if (ready && (c->regen_min_steps < 1 || !live->done_steps)) return NAVSIM_E_ARG;    // the pipelined form rests on the rule
+    const int rcp = check_stage_pair(c, live, stage);
+    if (rcp != NAVSIM_OK) return rcp;
+    if (c->n_envs == 0) return NAVSIM_OK;
+    const int rcs = check_map_slots(live, stage);
+    if (rcs != NAVSIM_OK) return rcs;
+    SwapBig big[5] = {};
+    if (!live->map_slot) stage_big_buffers(c, live, stage, big);
+    regen_swap_kernel<<<dim3(c->regen_cap, kRegenSlices), 256, 0, (hipStream_t)stream>>>(*c, *live, *stage, *io, stage_obs, want, mark, ready,
                                                                                         c->regen_cap, big[0], big[1], big[2], big[3], big[4]);
     return launch_status();
 }
 
 int navsim_regen_stage(const navsim_config* c, const navsim_state* stage, const navsim_step_io* io, uint8_t* want, uint8_t* mark,
-                       void* workspace, size_t workspace_bytes, void* stream) {
+                       long long* ready, void* workspace, size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
-    if (!c || !stage || !io || !want || !mark || !workspace || io->done != want) return NAVSIM_E_ARG;
+    if (!c || !stage || !io || !want || !mark || !workspace || io->done != want || !stage->episode) return NAVSIM_E_ARG;
+    if (((uintptr_t)mark & 3) != 0) return NAVSIM_E_ARG;
     if (c->n_envs == 0) return NAVSIM_OK;
-    regen_merge_want_kernel<<<(c->n_envs + 255) / 256, 256, 0, (hipStream_t)stream>>>(want, mark, c->n_envs);
-    const int rc = navsim_regen(c, stage, io, workspace, workspace_bytes, stream);
+    regen_merge_want_kernel<<<((c->n_envs + 3) / 4 + 255) / 256, 256, 0, (hipStream_t)stream>>>(want, mark, c->n_envs, ready, stage->episode);
+    // the staged state takes EVERY arena in want[], whatever its last episode's length (cfg.regen_min_steps is the live state's rule)
+    navsim_config cs = *c;
+    cs.regen_min_steps = 0;
+    const int rc = navsim_regen(&cs, stage, io, workspace, workspace_bytes, stream);
     if (rc != NAVSIM_OK) return rc;
     const int* count = (const int*)workspace;                // navsim_regen's selection: count, list
-    regen_clear_want_kernel<<<1, 256, 0, (hipStream_t)stream>>>(count, count + 4, want);
+    regen_clear_want_kernel<<<1, 256, 0, (hipStream_t)stream>>>(count, count + 4, want, ready, c->n_envs);
     return launch_status();
 }
 
@@ -995,6 +1060,10 @@ int navsim_prepare(const navsim_config* c, const navsim_state* st, const navsim_
     if (rc == NAVSIM_OK && c->ped_model != NAVSIM_PED_NONE && !ped_split_on(c) && st->costmap &&                 // navsim_step_replan
         plan_fits(c->map_h / 5, c->map_w / 5) && (int)plan_words(c->map_h / 5, c->map_w / 5) <= plan_step(c, st).block)
         rc = dispatch_step(c, st, io, 3 << 2, nullptr, nullptr, 32, 0);
+    if (rc == NAVSIM_OK && c->field_format == NAVSIM_FIELD_U16T && !(c->ped_model != NAVSIM_PED_NONE && ped_split_on(c))) {
+        const StepInstall none = {};                                                                             // navsim_step_install
+        rc = dispatch_step(c, st, io, 16, nullptr, nullptr, 0, 0, &none);
+    }
     g_prepare_only = false;
     if (rc != NAVSIM_OK) return rc;
     const int Hc = c->map_h / 5, Wc = c->map_w / 5;

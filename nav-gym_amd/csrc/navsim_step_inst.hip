@@ -23,6 +23,7 @@ namespace {
 // hipGraph capture (round-3 advisor: navsim_regen's lone first-observation launch instantiates its own variant)
 thread_local bool g_prepare_only = false;      // set per call from the entry point's argument
 thread_local int g_aux = 0;                    // navsim_step_replan: max_queries
+thread_local const StepInstall* g_install = nullptr;   // navsim_step_install (reset_only bit 4)
 template <int BLOCK, bool PEDS, typename Field, int RECT, int RULE, bool PINL>
 int launch_step_pinl(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
                      const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
@@ -43,6 +44,16 @@ int launch_step_pinl(const navsim_config* c, const navsim_state* st, const navsi
             return NAVSIM_OK;
         }
     }
+    if constexpr (PINL == PEDS && !std::is_same<Field, FieldF32>::value) {
+        if (reset_only & 16) {                                     // navsim_step_install: packed fields, pedestrians inside the step
+            if (allow_lds((const void*)navsim_step_install_kernel<BLOCK, PEDS, Field, RULE, RECT>, p.lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
+            if (g_prepare_only) return NAVSIM_OK;
+            navsim_step_install_kernel<BLOCK, PEDS, Field, RULE, RECT><<<grid > 0 ? grid : c->n_envs, BLOCK, p.lds, s>>>(
+                *c, *st, *io, *g_install, reset_only & 1, mask, (unsigned)step_lds_scan_bytes(c, p.park), p.park, p.rect_off);
+            return NAVSIM_OK;
+        }
+    }
+    if (reset_only & 16) return NAVSIM_E_UNSUPPORTED;
     if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL>, p.lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
     if (g_prepare_only) return NAVSIM_OK;
     navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL><<<grid > 0 ? grid : c->n_envs, BLOCK, p.lds, s>>>(
@@ -55,7 +66,7 @@ template <int BLOCK, bool PEDS, typename Field, int RECT, int RULE>
 int launch_step_kernel(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
                        const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
     if constexpr (PEDS) {
-        if ((reset_only & 3) == 0) return launch_step_pinl<BLOCK, PEDS, Field, RECT, RULE, true>(c, st, io, reset_only, mask, p, s, grid);
+        if ((reset_only & 3) == 0 || (reset_only & 16)) return launch_step_pinl<BLOCK, PEDS, Field, RECT, RULE, true>(c, st, io, reset_only, mask, p, s, grid);
     }
     return launch_step_pinl<BLOCK, PEDS, Field, RECT, RULE, false>(c, st, io, reset_only, mask, p, s, grid);
 }
@@ -103,16 +114,18 @@ int launch_step_family(const navsim_config* c, const navsim_state* st, const nav
 #define NAVSIM_CAT(a, b, c) NAVSIM_CAT_(a, b, c)
 
 // reset_only: bit 0 = a reset-only launch, bit 1 = ped_update_kernel has already advanced the pedestrians, bits 2-3 = the
-// NAVSIM_STEP_* part of navsim_step_part (3: navsim_step_replan, aux = its max_queries); grid > 0: that
+// NAVSIM_STEP_* part of navsim_step_part (3: navsim_step_replan, aux = its max_queries), bit 4 = navsim_step_install
+// (install = its StepInstall); grid > 0: that
 // many workgroups (st->launch_order names their arenas); prepare_only: set the kernel's attributes, launch nothing
 extern "C" __attribute__((visibility("hidden")))
 int NAVSIM_CAT(navsim_step_launch_, NAVSIM_INST_BLOCK, NAVSIM_INST_PEDS)(const navsim_config* c, const navsim_state* st,
                                                                         const navsim_step_io* io, int reset_only,
                                                                         const uint8_t* mask, void* stream, int grid,
-                                                                        int prepare_only, int aux) {
+                                                                        int prepare_only, int aux, const void* install) {
     // (a NAVSIM_STEP_DUE launch is the ordinary step kernel on fewer workgroups: its grid does not change the plan)
     const bool due_part = ((reset_only >> 2) & 3) >= NAVSIM_STEP_DUE;       // (also navsim_step_replan: grid = its front workgroups)
     g_aux = aux;
+    g_install = (const StepInstall*)install;
     const StepPlan p = plan_step(c, st, due_part ? 0 : grid);
     if (p.block != NAVSIM_INST_BLOCK) return NAVSIM_E_UNSUPPORTED;
     g_prepare_only = prepare_only != 0;

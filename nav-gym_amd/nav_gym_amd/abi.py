@@ -37,7 +37,8 @@ ACTION_TWIST = 0       # io.action = (v, omega)
 ACTION_WHEELS = 1      # io.action = (omega_left, omega_right) of a skid-steer base, rad/s
 
 N_COUNTERS = 8
-COUNTERS = ("regen_served", "regen_unserved", "replan_served", "replan_unserved", "routes_cut", "routes_resumed")
+COUNTERS = ("regen_served", "regen_unserved", "replan_served", "replan_unserved", "routes_cut", "routes_resumed",
+            "regen_short", "regen_late")
 
 
 class NavsimConfig(C.Structure):
@@ -130,6 +131,7 @@ class NavsimConfig(C.Structure):
         ("rotvel_hi", C.c_double),
         ("closed_maps", C.c_int32),
         ("defer_reset_scan", C.c_int32),
+        ("regen_min_steps", C.c_int32),
     ]
 
     def copy(self):
@@ -149,7 +151,7 @@ class NavsimState(C.Structure):
         "ped_waypoints", "ped_n_waypoints", "ped_cmd",
         "spawn_pose", "spawn_goal", "costmap", "arena_cost", "launch_order", "regen_draws",
         "ped_goal", "counters", "rect_index",
-        "ped_wp_head", "ped_due", "ped_due_prev",
+        "ped_wp_head", "ped_due", "ped_due_prev", "done_steps", "map_slot",
     )]
 
 
@@ -236,6 +238,8 @@ STATE_LAYOUT = {
     "ped_wp_head": ("int32", ("E", "N")),           # ABI 5: index of every pedestrian's current waypoint (the pop advances it)
     "ped_due": ("int64", ("E",)),                   # uint64 on the device: bit i = pedestrian i waits for navsim_replan (written by the step)
     "ped_due_prev": ("int64", ("E",)),              # the flags of the previous step (navsim_step_part)
+    "done_steps": ("int32", ("E",)),                # length of the episode that ended last (cfg.regen_min_steps)
+    "map_slot": ("int32", ("E",)),                  # slot of the five per-map arrays that holds arena e's map (NULL: e)
 }
 
 IO_LAYOUT = {
@@ -327,8 +331,9 @@ def declare(lib, suffix=""):
         sig("navsim_plan", [_P, _P, i32, i32, i32, f64, f64, f64, _P, _P, f64, i32, _P, _P, _P, _P, _P])
         sig("navsim_regen_workspace_bytes", [cfgp], C.c_size_t)
         sig("navsim_regen", [cfgp, stp, iop, _P, C.c_size_t, _P])
-        sig("navsim_regen_swap", [cfgp, stp, stp, iop, _P, _P, _P, _P])
-        sig("navsim_regen_stage", [cfgp, stp, iop, _P, _P, _P, C.c_size_t, _P])
+        sig("navsim_regen_swap", [cfgp, stp, stp, iop, _P, _P, _P, _P, _P])
+        sig("navsim_regen_stage", [cfgp, stp, iop, _P, _P, _P, _P, C.c_size_t, _P])
+        sig("navsim_step_install", [cfgp, stp, iop, stp, _P, _P, _P, _P])
     sig("navsim_crowd_check", [C.POINTER(NavsimCrowdParams), i32, i32, i32, _P, _P, _P, _P, _P, _P, _P, _P, _P] + stream)
     mpp = C.POINTER(NavsimCrowdMapParams)
     sig("navsim_crowd_angular_map", [mpp, i32, i32, i32, _P, _P, _P, _P] + stream)
@@ -353,7 +358,7 @@ EXPORTS = (
     "navsim_rect_index_bytes", "navsim_build_rect_index", "navsim_maps_closed", "navsim_world_closed",
     "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
-    "navsim_scan_threshold", "navsim_beam_table", "navsim_ped_scans", "navsim_ped_scans_part", "navsim_ped_policy_part", "navsim_regen_workspace_bytes", "navsim_regen", "navsim_regen_swap", "navsim_regen_stage",
+    "navsim_scan_threshold", "navsim_beam_table", "navsim_ped_scans", "navsim_ped_scans_part", "navsim_ped_policy_part", "navsim_regen_workspace_bytes", "navsim_regen", "navsim_regen_swap", "navsim_regen_stage", "navsim_step_install",
     "navsim_costmap", "navsim_plan", "navsim_launch_order", "navsim_replan_workspace_bytes", "navsim_replan", "navsim_ped_policy_workspace_bytes", "navsim_ped_policy", "navsim_ped_scan_policy",
     "navsim_crowd_check", "navsim_crowd_angular_map", "navsim_crowd_local_map", "navsim_crowd_orca", "navsim_crowd_agent_step",
     "navsim_step", "navsim_step_part", "navsim_step_replan", "navsim_prepare", "navsim_reset_obs", "navsim_step_kernel_name",

@@ -390,6 +390,9 @@ class NavSim(object):
             self.due = [torch.zeros(self.cfg.n_envs, dtype=torch.int64, device=self.device) for _ in range(2)]
             self.st.ped_due = self.due[0].data_ptr()
             self.st.ped_due_prev = self.due[1].data_ptr()
+        if "done_steps" not in self.t and self.cfg.auto_reset:  # length of every arena's last episode (cfg.regen_min_steps)
+            self.t["done_steps"] = torch.zeros(self.cfg.n_envs, dtype=torch.int32, device=self.device)
+            self.st.done_steps = self.t["done_steps"].data_ptr()
         if "counters" not in self.t:                            # what the library's caps left unserved (include/navsim.h)
             self.t["counters"] = torch.zeros(abi.N_COUNTERS, dtype=torch.int64, device=self.device)
             self.st.counters = self.t["counters"].data_ptr()
@@ -493,31 +496,82 @@ class NavSim(object):
                 self.io.action = self.action.data_ptr()
         self._reorder()
         self._flip()
-        check(self.lib.navsim_step(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), _stream()), "navsim_step")
+        self._launch()
         self.cur = 1 - self.cur
         return self.obs, self.out
+
+    def _launch(self):
+        """The step's launch on the current stream: navsim_step, or navsim_step_install behind the staging pass it may rest on."""
+        if not getattr(self, "pg_install", False):
+            rc = self.lib.navsim_step(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), _stream())
+            if rc:
+                check(rc, "navsim_step")
+            return
+        import torch                                            # enable_pregen(pipeline=P, install=True)
+        main = torch.cuda.current_stream()
+        P, k = self.pg_period, self.pg_k
+        if k % P == 0 and k >= 2 * P:
+            main.wait_event(self.pg_staged[(k // P - 2) % 3])   # the pass queued two periods ago; the later two may still run
+        check(self.lib.navsim_step_install(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), C.byref(self.stage_st),
+                                           _ptr(self.stage_obs), _ptr(self.mark), _ptr(self.ready),
+                                           C.c_void_p(main.cuda_stream)), "navsim_step_install")
 
     # arrays navsim_regen writes: the staged state of enable_pregen() owns a copy of each
     STAGED = ("field", "field_overflow", "rect_table", "rect_index", "costmap", "scan_noise_std", "robot_pose", "robot_goal", "prev_action",
               "prev_pose", "n_hist", "steps", "episode", "n_peds", "ped_pose", "ped_vel", "ped_prev_yaw", "ped_dist",
               "ped_v_pref", "ped_has_legs", "ped_waypoints", "ped_n_waypoints", "ped_wp_head", "ped_goal", "spawn_pose", "spawn_goal")
 
-    def enable_pregen(self, scratch_bytes=4 << 30):
+    MAPS = ("field", "field_overflow", "rect_table", "rect_index", "costmap")      # the per-map arrays (navsim_state.map_slot)
+
+    def enable_pregen(self, scratch_bytes=4 << 30, pipeline=0, install=False, stage_cap=None, map_slots=True):
         """navsim_regen off the step's critical path (include/navsim.h navsim_regen_swap): the world every arena will
         get at the end of its CURRENT episode -- a function of (seed, global arena, episode number) only -- is generated
         ahead of time into a second, staged state by the ordinary navsim_regen on a side stream; regen() then only
         installs the staged worlds of the finished arenas (one copy kernel on the caller's stream) and queues the next
-        staging pass.  Same state, same observations as navsim_regen, bit for bit.  Needs cfg.auto_reset = 1."""
+        staging pass.  Same state, same observations as navsim_regen, bit for bit.  Needs cfg.auto_reset = 1.
+
+        pipeline = P > 0 (round 5): a staging pass every P steps, and the steps wait only for the pass queued two periods
+        earlier -- a pass has P .. 2 P steps of wall time to finish beside the step kernels instead of having to fit between
+        two steps.  That needs the simulation's own guarantee that an arena does not want its next world sooner:
+        cfg.regen_min_steps >= 4 P (shorter episodes restart in place, in navsim_regen and the oracle alike), which makes
+        the outcome independent of timing; counters()['regen_late'] stays 0.
+
+        install=True (with pipeline): no swap kernel either -- step() is navsim_step_install, in which a finished arena's own
+        workgroup copies its staged world in place of the restart's second scan; regen() only queues the passes.  Every
+        arena decides alone, so cfg.regen_cap must be >= n_envs (no cap in index order); `stage_cap` bounds what ONE pass
+        stages (default: what 2 P steps finish at one arena in sixteen per step) -- arenas beyond it wait for the next pass.
+        map_slots (with install): the live and the staged state share the per-map arrays (t['field'], ... then hold 2 E slots)
+        and each has a slot table (navsim_state.map_slot); an install exchanges two table entries instead of copying the
+        map -- numpy_state() resolves the table, code that indexes t['field'] by arena must go through t['map_slot']."""
         import torch
         if not self.cfg.auto_reset:
             raise ValueError("enable_pregen needs cfg.auto_reset = 1 (the step advances episode[e] when an arena finishes)")
         E = self.cfg.n_envs
+        P = int(pipeline)
+        if P < 0 or (P > 0 and self.cfg.regen_min_steps < 4 * P):
+            raise ValueError("enable_pregen(pipeline=%d) needs cfg.regen_min_steps >= %d (it is %d): an arena must not want its "
+                             "next world before the pass that stages it was waited for" % (P, 4 * P, self.cfg.regen_min_steps))
+        self.pg_period, self.pg_k = P, 0
+        if install and (not P or self.cfg.regen_cap < E):
+            raise ValueError("enable_pregen(install=True) needs pipeline >= 1 and cfg.regen_cap >= n_envs (every finished arena "
+                             "decides alone inside the step: there is no cap in index order)")
+        self.ready = torch.zeros(2 * E, dtype=torch.int64, device=self.device) if P else None
         self.stage_t = {k: self.t[k].clone() for k in self.STAGED if k in self.t}
         self.stage_t["episode"] = self.t["episode"] + 1
         self.stage_st = abi.NavsimState()
         C.memmove(C.byref(self.stage_st), C.byref(self.st), C.sizeof(self.st))
         for k, v in self.stage_t.items():
             setattr(self.stage_st, k, v.data_ptr())
+        if install and map_slots:
+            for k in self.MAPS:
+                if k in self.t:
+                    both = torch.cat([self.t[k], self.stage_t[k]])
+                    self.t[k] = self.stage_t[k] = both
+                    setattr(self.st, k, both.data_ptr()); setattr(self.stage_st, k, both.data_ptr())
+            self.t["map_slot"] = torch.arange(E, dtype=torch.int32, device=self.device)
+            self.stage_t["map_slot"] = torch.arange(E, 2 * E, dtype=torch.int32, device=self.device)
+            self.st.map_slot = self.t["map_slot"].data_ptr()
+            self.stage_st.map_slot = self.stage_t["map_slot"].data_ptr()
         self.stage_st.arena_cost = None
         self.stage_st.launch_order = None
         self.stage_st.counters = None          # staging ahead serves nobody yet: navsim_regen_swap counts the installs
@@ -525,7 +579,7 @@ class NavSim(object):
         self.stage_st.ped_due_prev = None
         self.stage_obs = torch.zeros_like(self.obs_buf[0])
         self.want = torch.ones(E, dtype=torch.uint8, device=self.device)
-        self.mark = torch.zeros(E, dtype=torch.uint8, device=self.device)
+        self.mark = torch.zeros((E + 3) // 4 * 4, dtype=torch.uint8, device=self.device)   # consumed in 32-bit words
         self.stage_io = abi.NavsimStepIO()
         self.stage_io.obs = self.stage_obs.data_ptr()
         self.stage_io.done = self.want.data_ptr()
@@ -539,11 +593,18 @@ class NavSim(object):
         ws = torch.empty(self.lib.navsim_regen_workspace_bytes(C.byref(cfg)), dtype=torch.uint8, device=self.device)
         for _ in range((E + cfg.regen_cap - 1) // cfg.regen_cap):
             check(self.lib.navsim_regen_stage(C.byref(cfg), C.byref(self.stage_st), C.byref(self.stage_io), _ptr(self.want),
-                                              _ptr(self.mark), _ptr(ws), ws.numel(), _stream()), "navsim_regen_stage (first staging)")
+                                              _ptr(self.mark), _ptr(self.ready), _ptr(ws), ws.numel(), _stream()),
+                  "navsim_regen_stage (first staging)")
         torch.cuda.current_stream().synchronize()
         assert int(self.want.sum().item()) == 0
         del ws
-        nbytes = self.lib.navsim_regen_workspace_bytes(C.byref(self.cfg))
+        # a pipelined pass serves what the swaps of P steps marked: P caps' worth of arenas (twice that: what a pass leaves
+        # waits for the next one and would be late)
+        self.stage_cfg = self.cfg.copy()
+        if P:
+            per_step = max(16, E // 16) if install else self.cfg.regen_cap
+            self.stage_cfg.regen_cap = int(min(E, stage_cap if stage_cap else 2 * P * per_step))
+        nbytes = self.lib.navsim_regen_workspace_bytes(C.byref(self.stage_cfg))
         self.stage_ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         # a high-priority stream: its few small kernels go first whenever wave slots free up.  (Measured and dropped:
         # CU-masked streams -- hipExtStreamCreateWithCUMask, 8 / 16 / 32 CUs for the staging passes and the rest for the
@@ -551,27 +612,71 @@ class NavSim(object):
         self.side = torch.cuda.Stream(device=self.device, priority=-1)
         self.ev_swapped, self.ev_staged = torch.cuda.Event(), torch.cuda.Event()
         self.ev_staged.record(torch.cuda.current_stream())
+        self.pg_swapped = [torch.cuda.Event() for _ in range(3)]      # pass j uses slot j % 3; step j P waits for pass j - 2
+        self.pg_staged = [torch.cuda.Event() for _ in range(3)]
         self.pregen = True
+        self.pg_install = bool(install)
 
     def _regen_pregen(self):
         import torch
         main = torch.cuda.current_stream()
-        main.wait_event(self.ev_staged)                 # the staging pass that served the arenas of the last swap
+        P, k = self.pg_period, self.pg_k
+        self.pg_k += 1
+        j = k // P if P else 0
+        if self.pg_install:                              # step() has installed; only the passes are left
+            if k % P == 0:
+                self._latest_flags()
+                self._queue_pass(main, self.pg_swapped[j % 3], self.pg_staged[j % 3])
+            return self.obs
+        if not P:
+            main.wait_event(self.ev_staged)             # the staging pass that served the arenas of the last swap
+        elif k % P == 0 and j >= 2:
+            main.wait_event(self.pg_staged[(j - 2) % 3])    # the pass queued two periods ago; the later two may still run
         self._latest_flags()
         io = abi.NavsimStepIO()
         C.memmove(C.byref(io), C.byref(self.io), C.sizeof(io))
         io.obs = self.obs_buf[self.cur].data_ptr()
         check(self.lib.navsim_regen_swap(C.byref(self.cfg), C.byref(self.st), C.byref(self.stage_st), C.byref(io),
-                                         _ptr(self.stage_obs), _ptr(self.want), _ptr(self.mark), C.c_void_p(main.cuda_stream)),
+                                         _ptr(self.stage_obs), _ptr(self.want), _ptr(self.mark), _ptr(self.ready),
+                                         C.c_void_p(main.cuda_stream)),
               "navsim_regen_swap")
-        self.ev_swapped.record(main)
-        self.side.wait_event(self.ev_swapped)
-        ws = self.stage_ws
-        check(self.lib.navsim_regen_stage(C.byref(self.cfg), C.byref(self.stage_st), C.byref(self.stage_io), _ptr(self.want),
-                                          _ptr(self.mark), _ptr(ws), ws.numel(), C.c_void_p(self.side.cuda_stream)),
-              "navsim_regen_stage")
-        self.ev_staged.record(self.side)
+        if P and k % P != 0:
+            return self.obs                             # the next pass takes these arenas' marks with it
+        swapped, staged = (self.pg_swapped[j % 3], self.pg_staged[j % 3]) if P else (self.ev_swapped, self.ev_staged)
+        self._queue_pass(main, swapped, staged)
         return self.obs
+
+    def pregen_sync(self):
+        """Pipelined pre-generation: wait (host) for every staging pass queued so far and start the period count anew -- the
+        next 2 P steps then rest on no earlier pass.  Call it before capturing steps into a hipGraph: a captured wait must
+        not refer to an event recorded outside the capture."""
+        import torch
+        self.side.synchronize()
+        torch.cuda.current_stream().synchronize()
+        self.pg_k = 0
+        self.pg_open = []
+
+    def pregen_join(self):
+        """Pipelined pre-generation: the current stream waits for the staging passes still open (the last two periods') --
+        the join a hipGraph capture needs before it ends; a replay then starts like pregen_sync() left things."""
+        import torch
+        main = torch.cuda.current_stream()
+        for ev in self.pg_open:
+            main.wait_event(ev)
+        self.pg_k = 0
+        self.pg_open = []
+
+    def _queue_pass(self, main, swapped, staged):
+        """A staging pass on the side stream, behind everything `main` holds now."""
+        if self.pg_period:
+            self.pg_open = (getattr(self, "pg_open", []) + [staged])[-2:]
+        swapped.record(main)
+        self.side.wait_event(swapped)
+        ws = self.stage_ws
+        check(self.lib.navsim_regen_stage(C.byref(self.stage_cfg), C.byref(self.stage_st), C.byref(self.stage_io), _ptr(self.want),
+                                          _ptr(self.mark), _ptr(self.ready), _ptr(ws), ws.numel(), C.c_void_p(self.side.cuda_stream)),
+              "navsim_regen_stage")
+        staged.record(self.side)
 
     def regen(self):
         """navsim_regen right after step(): finished arenas get a new map, tables, pedestrians, first obs."""
@@ -603,6 +708,7 @@ class NavSim(object):
         if new_episode:
             self.t["episode"] += 1
         cfg = self.cfg.copy()
+        cfg.regen_min_steps = 0                 # a reset of everything: whatever the last episodes' lengths
         cfg.regen_cap = 1
         per = self.lib.navsim_regen_workspace_bytes(C.byref(cfg))
         cfg.regen_cap = 2
@@ -901,9 +1007,7 @@ class NavSim(object):
         if reorder:
             self._reorder()
         self._flip()
-        rc = self.lib.navsim_step(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), _stream())
-        if rc:
-            check(rc, "navsim_step")
+        self._launch()
         self.cur = 1 - self.cur
 
     def set_ped_cmd(self, cmd):
@@ -917,7 +1021,9 @@ class NavSim(object):
 
     def numpy_state(self, *names):
         """State arrays on the host.  "ped_due": the latest step's "waits for navsim_replan" flags (they flip, so not in t)."""
-        out = {n: self.t[n].detach().cpu().numpy() for n in (names or self.t.keys()) if n != "ped_due"}
+        slots = self.t.get("map_slot")                      # the per-map arrays by arena, wherever the maps lie
+        out = {n: (self.t[n][slots.long()] if slots is not None and n in self.MAPS else self.t[n]).detach().cpu().numpy()
+               for n in (names or self.t.keys()) if n != "ped_due"}
         if self.due is not None and (not names or "ped_due" in names):
             out["ped_due"] = self.due[self.cur].detach().cpu().numpy()
         return out

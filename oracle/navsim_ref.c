@@ -1003,6 +1003,7 @@ static void step_env(const navsim_config* c, const navsim_state* st, const navsi
         const double* sg = st->spawn_goal + ((size_t)e * c->n_spawn + idx) * 2;
         rp[0] = sp[0]; rp[1] = sp[1]; rp[2] = sp[2];
         goal[0] = sg[0]; goal[1] = sg[1];
+        if (st->done_steps) st->done_steps[e] = (int32_t)st->steps[e];   /* how long the episode lasted (cfg.regen_min_steps) */
         st->episode[e] += 1;
         st->steps[e] = 0;
         double zero[2] = {0.0, 0.0};
@@ -1619,8 +1620,15 @@ int navsim_replan_cpu(const navsim_config* c, const navsim_state* st, int32_t ma
     return NAVSIM_OK;
 }
 
+/* cfg.regen_min_steps (include/navsim.h; build-defined, the reference regenerates at every reset): an arena whose episode
+ * ended after fewer steps keeps its map and restarts in place */
+static int regen_long_enough(const navsim_config* c, const navsim_state* st, int e) {
+    return c->regen_min_steps <= 0 || !st->done_steps || st->done_steps[e] >= c->regen_min_steps;
+}
+
 int navsim_regen_cpu(const navsim_config* c, const navsim_state* st, const navsim_step_io* io) {
     if (!c || !st || !io || !io->done || !io->obs) return NAVSIM_E_ARG;
+    if (c->regen_min_steps < 0 || (c->regen_min_steps > 0 && !st->done_steps)) return NAVSIM_E_ARG;
     if (c->field_format != NAVSIM_FIELD_F32 || c->map_h != c->map_w || c->n_spawn < 1) return NAVSIM_E_UNSUPPORTED;
     const int E = c->n_envs, N = c->max_peds, K = c->n_spawn, H = c->map_h, W = c->map_w;
     const int P = c->max_waypoints;
@@ -1629,14 +1637,19 @@ int navsim_regen_cpu(const navsim_config* c, const navsim_state* st, const navsi
     uint8_t* occ = (uint8_t*)malloc((size_t)H * W);
     int taken = 0;
     if (st->counters) {                          /* what this call serves, and what its cap leaves waiting */
-        int all = 0;
-        for (int e = 0; e < E; ++e) all += io->done[e] != 0;
+        int all = 0, n_short = 0;
+        for (int e = 0; e < E; ++e) {
+            const int lng = regen_long_enough(c, st, e);
+            all += io->done[e] != 0 && lng;
+            n_short += io->done[e] != 0 && !lng;
+        }
         const int served = all < c->regen_cap ? all : c->regen_cap;
         st->counters[NAVSIM_COUNTER_REGEN_SERVED] += (unsigned long long)served;
         st->counters[NAVSIM_COUNTER_REGEN_UNSERVED] += (unsigned long long)(all - served);
+        st->counters[NAVSIM_COUNTER_REGEN_SHORT] += (unsigned long long)n_short;
     }
     for (int e = 0; e < E && taken < c->regen_cap; ++e) {
-        if (!io->done[e]) continue;
+        if (!io->done[e] || !regen_long_enough(c, st, e)) continue;
         ++taken;
         mask[e] = 1;
         const uint64_t genv = (uint64_t)(c->env_index_base + e), ep = (uint64_t)st->episode[e];

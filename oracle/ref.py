@@ -392,6 +392,9 @@ class RefSim(object):
             if "ped_due" not in self.a:
                 self.a["ped_due"] = np.zeros(E_, np.int64)
                 self.st.ped_due = self.a["ped_due"].ctypes.data
+        if "done_steps" not in self.a and self.cfg.auto_reset:      # like NavSim: length of every arena's last episode
+            self.a["done_steps"] = np.zeros(self.cfg.n_envs, np.int32)
+            self.st.done_steps = self.a["done_steps"].ctypes.data
         if "counters" not in self.a:                # like NavSim: what the caps left unserved (include/navsim.h)
             self.a["counters"] = np.zeros(abi.N_COUNTERS, np.int64)
             self.st.counters = self.a["counters"].ctypes.data

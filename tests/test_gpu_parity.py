@@ -662,6 +662,60 @@ def test_pregenerated_worlds_equal_navsim_regen(gpu, fmt, ped_model, plan):
     assert regenerated > 8 and (twice >= 2).any(), (regenerated, twice.max())
 
 
+@pytest.mark.parametrize("period,min_steps,slow,install", [(1, 12, False, False), (3, 12, False, False), (2, 10, True, False),
+                                                          (1, 12, False, "copy"), (3, 12, False, "slots"), (2, 10, True, "slots"),
+                                                          (1, 12, False, "slots")])
+def test_pipelined_pregeneration_equals_navsim_regen(gpu, monkeypatch, period, min_steps, slow, install):
+    """enable_pregen(pipeline=P) with cfg.regen_min_steps >= 4 P: staging passes every P steps, waited for two periods later.
+    The rule -- an episode shorter than regen_min_steps restarts in place -- is the simulation's (the oracle's
+    navsim_regen_cpu applies it from done_steps), so the rollout equals the oracle's synchronous one bit for bit whatever
+    the passes' timing: `slow` delays every pass by a few ms on its stream (several steps' worth).  Both kinds of
+    episode ends occur, and no arena ever finds its world unstaged (counters: regen_late 0).
+    install: step() is navsim_step_install -- the finished arena's own workgroup copies the staged world, no swap kernel;
+    "slots": the two states share the per-map arrays and exchange slot-table entries (navsim_state.map_slot), no map is copied."""
+    E, size, N = 48, 200, 6
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_SFM, n_spawn=6,
+                                 auto_reset=1, seed=29, field_format=abi.FIELD_U16T, regen_cap=E, min_goal_dist=3.0,
+                                 max_goal_dist=8.0, spawn_clearance=0.9, ped_min_robot_dist=2.0, ped_min_goal_dist=4.0,
+                                 regen_plan=0, regen_indoor_ratio=0.0, regen_min_steps=min_steps)
+    gpu.world.lidar_1081(cfg)
+    occ = gpu.world.make_maps(E, size, 29)
+    n_long = n_short = 0
+    for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=5, steps=110, seed=13):
+        if t == 0:
+            with pytest.raises(ValueError, match="regen_min_steps"):
+                g.enable_pregen(pipeline=min_steps // 4 + 1)
+            g.enable_pregen(pipeline=period, install=bool(install), map_slots=(install == "slots"))
+            if slow:
+                stage = g.lib.navsim_regen_stage
+                def delayed(*a, _stage=stage, _g=g):
+                    with gpu.torch.cuda.stream(_g.side):
+                        gpu.torch.cuda._sleep(6_000_000)          # ~ 3 ms at 2 GHz: longer than a step of this world
+                    return _stage(*a)
+                monkeypatch.setattr(g.lib, "navsim_regen_stage", delayed)
+        done = rout["done"].astype(bool)
+        for k in ("reward", "done", "is_success", "is_crash"):
+            _eq(gout[k], rout[k], "%s at step %d" % (k, t))
+        keep = ~done if install else np.ones(E, bool)       # (navsim_step_install: the finished arenas' rows are already the new worlds')
+        _eq(go[keep], ro[keep], "obs at step %d" % t)
+        lng = r.a["done_steps"] >= cfg.regen_min_steps
+        n_long += int((done & lng).sum()); n_short += int((done & ~lng).sum())
+        _eq(g.t["done_steps"].cpu().numpy()[done], r.a["done_steps"][done], "episode lengths at step %d" % t)
+        go2 = g.regen().cpu().numpy()
+        ro2 = r.regen()
+        _eq(go2, ro2, "obs after the swap at step %d" % t)
+        if done.any():
+            gpu.torch.cuda.synchronize()
+            gs = g.numpy_state()
+            for k, v in r.a.items():
+                if k in gs and k not in ("field", "field_overflow", "rect_table", "rect_index", "ped_waypoints", "counters"):
+                    _eq(gs[k], v, "state %s after the swap at step %d" % (k, t))
+    assert n_long > 8 and n_short > 0, (n_long, n_short)
+    cg, cr = g.counters(), r.counters()
+    assert cg["regen_late"] == 0 and cg["regen_unserved"] == 0
+    assert cg["regen_short"] == cr["regen_short"] == n_short and cg["regen_served"] == cr["regen_served"] == n_long
+
+
 def test_env_reset_at_the_reference_map_size(gpu):
     """1000 x 1000 cells is the reference's own indoor map size (map_generator.py:108-122).  Such a packed world
     carries the float32 overflow plane (cells >= 256 cells from every obstacle), regenerated with the field, and

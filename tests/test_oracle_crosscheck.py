@@ -395,6 +395,45 @@ if __name__ == "__main__":          # the figure quoted in DESIGN.md section 2 +
     np.savez_compressed(os.path.join(_root, "tests", "golden", "march_rule_cases.npz"), **out)
 
 
+def test_short_episodes_restart_in_place():
+    """cfg.regen_min_steps (build-defined; the reference draws a map at every reset): an arena whose episode ended after
+    fewer steps keeps its map -- the step's restart from the spawn table stands -- and is counted; one that lasted long
+    enough is regenerated.  The step records the length of the episode that ended (done_steps)."""
+    from nav_gym_amd import robots
+    from helpers import finished_world
+    E, size = 6, 200
+    cfg = ref.default_config(n_envs=E, map_h=size, map_w=size, max_peds=1, ped_model=abi.PED_NONE, n_spawn=4, auto_reset=1,
+                             seed=3, regen_cap=E, min_goal_dist=3.0, max_goal_dist=8.0, regen_min_steps=3)
+    rng = np.random.default_rng(0)
+    occ = np.stack([outdoor_map(rng, size) for _ in range(E)])
+    thr = ref.scan_threshold(cfg, robots.footprint_array("keti", "threshold_footprint"))
+    dthr = ref.scan_threshold(cfg, robots.footprint_array("keti", "discomfort_threshold_footprint"))
+    r = ref.RefSim(cfg, finished_world(cfg, occ, ref.build_dt(occ), 0, (thr, dthr)))
+    r.reset_obs()
+    # every arena ends its episode in this step; pretend half of them had been running for a while
+    r.a["steps"][:] = [0, 7, 1, 2, 0, 40]
+    _, out = r.step(np.zeros((E, 2)))
+    assert out["done"].all()
+    assert r.a["done_steps"].tolist() == [1, 8, 2, 3, 1, 41] and (r.a["steps"] == 0).all()
+    field0, pose0, ep0 = r.a["field"].copy(), r.a["robot_pose"].copy(), r.a["episode"].copy()
+    r.regen()
+    lng = r.a["done_steps"] >= 3
+    assert lng.tolist() == [False, True, False, True, False, True]
+    for e in range(E):
+        same_map = np.array_equal(r.a["field"][e], field0[e])
+        assert same_map == (not lng[e]), e
+        if not lng[e]:
+            assert np.array_equal(r.a["robot_pose"][e], pose0[e])           # the restart in place stands
+    assert np.array_equal(r.a["episode"], ep0)                              # the step advanced them, regen does not
+    c = r.counters()
+    assert c["regen_short"] == 3 and c["regen_served"] == 3 and c["regen_unserved"] == 0
+    # without the buffer the rule cannot be applied: refused, not ignored
+    r.st.done_steps = None
+    r.out["done"][:] = 1
+    with pytest.raises(Exception):
+        r.regen()
+
+
 def test_native_thread_pool_equals_sequential_steps():
     """bench.py's CPU baseline (navsim_step_threads_cpu: POSIX threads inside the oracle, arenas split statically, no
     barrier between steps) computes exactly what step() after step() computes: observations, outputs and state."""
