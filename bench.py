@@ -451,8 +451,13 @@ def extras(args, device):
     NavGymEnv.step(torch actions): the action copy, the step, .bool() of the done flags, the observation dict."""
     import torch
     res = {"other_workloads": {}}
-    for name in ("c3", "c4", "c5"):
-        wl = dict(WORKLOADS[name]); wl["field"] = "u16t"; wl["indoor_ratio"] = 0.0
+    # "c5_pipelined": c5 with the round-5 reset path -- worlds staged ahead by passes on a side stream (one every 4 steps),
+    # installed inside the step's own launch (navsim_step_install), cfg.regen_min_steps = 16 (an episode shorter than that
+    # restarts on its old map: the one rule the reference does not have, counted in regen_short)
+    for name in ("c3", "c4", "c5", "c5_pipelined"):
+        wl = dict(WORKLOADS[name.split("_")[0]]); wl["field"] = "u16t"; wl["indoor_ratio"] = 0.0
+        if name == "c5_pipelined":
+            wl.update(pregen=True, pipeline=4, install=True)
         try:
             cfg, sim, arrays, _ = build_sim(wl, 0, wl["envs"], device=device)
             E = cfg.n_envs
@@ -491,7 +496,7 @@ def extras(args, device):
             el = time.perf_counter() - t0
             kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / K
             graphed = None
-            if regen:                   # the regenerating loop is launch-bound (step + navsim_regen's kernels per step): the
+            if regen and not wl.get("pipeline"):   # the regenerating loop is launch-bound (step + navsim_regen's kernels per step): the
                 try:                    # same K steps again as ONE hipGraph replay -- that is the workload's `value`
                     cur0 = sim.cur
                     graph = torch.cuda.CUDAGraph()
@@ -525,6 +530,12 @@ def extras(args, device):
                     E, cfg.n_beams, cfg.map_h, cfg.map_w, wl["peds"], wl.get("robot", "keti"), ", new map per episode" if regen else ""),
                 "kernel_ms_from": ("one HIP event pair per step launch (the step kernel alone; ms_per_step also holds navsim_regen)" if regen else
                                    "one HIP event pair around the %d launches / %d (includes the gaps between launches)" % (K, K))}
+            if regen:
+                res["other_workloads"][name]["regen_counters"] = sim.counters()
+                res["other_workloads"][name]["regen_min_steps"] = int(cfg.regen_min_steps)
+            if wl.get("pipeline"):
+                res["other_workloads"][name]["reset_path"] = ("staging passes every %d steps on a side stream, installed inside the step "
+                                                              "(navsim_step_install, slot tables); plain launches" % wl["pipeline"])
             del sim, arrays
             torch.cuda.empty_cache()
         except Exception as exc:                              # an extra must not cost the run its line
@@ -592,6 +603,11 @@ def extras(args, device):
         for model, E in (("sfm", 1024), ("sfm", 4096)):
             w = gym_window(E, K=100, Wm=20, map_size="reference", randomize_maps=True, pedestrian_model=model)
             ref_def["%s_%d" % (model, E)] = w
+        # ... and the same world with the round-5 reset path switched on (the two kwargs are the only change): the worlds staged
+        # ahead, installed inside the step; an episode shorter than 16 steps restarts on its old map (counters: regen_short)
+        w = gym_window(1024, K=100, Wm=20, map_size="reference", randomize_maps=True, pedestrian_model="sfm",
+                       regen_min_steps=16, pregen_pipeline=4)
+        ref_def["sfm_1024_pregen_pipeline_4"] = w
         res.setdefault("gym_api", {})["reference_defaults"] = dict(
             ref_def, what="gym.make('NavGym-v0', num_envs=E, map_size='reference', randomize_maps=True) and nothing else changed: the "
                           "registered kwargs of __init__.py:4-40 (indoor_ratio 0.5, 5-15 pedestrians, planned routes, scan noise), "

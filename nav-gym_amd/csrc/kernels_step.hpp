@@ -1403,6 +1403,7 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
     if constexpr (INSTALL) {
         __syncthreads();                                       // what phase 6 wrote for the restart in place is overwritten
         if (sh.respawn == 3) install_arena<BLOCK>(c, st, io, *in, e, obs_row);
+        NAVSIM_STAMP(7);
     }
 }
 

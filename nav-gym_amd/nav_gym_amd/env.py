@@ -24,6 +24,10 @@ and default to the reference's behaviour for num_envs == 1:
                     with the robot's wheel radius / track (robots.py; Husky: husky.urdf.xacro:61-67)
     clip_actions    True: the twist is clamped to linvel_range x rotvel_range on the device (the reference only prints
                     a warning and never clips, env.py:606-613: default False)
+    regen_min_steps, pregen_pipeline   (randomize_maps) pregen_pipeline = P > 0: the next world of every arena is staged ahead
+                    of time on a side stream (a pass every P steps) and installed inside the step's own launch; needs
+                    regen_min_steps >= 4 P -- an episode shorter than regen_min_steps restarts on its old map, which the
+                    reference never does (it draws a map at every reset): opt-in, counted in counters()['regen_short']
     use_graphs      replay a step's launches (navsim_step, navsim_regen, navsim_replan) as one captured hipGraph; None
                     (default) = when randomize_maps makes a step several launches (c5: +6 %); results are identical
     max_waypoints   waypoints kept per pedestrian route (default 64 = 128 m at the 2 m interval; the reference keeps
@@ -159,7 +163,8 @@ class NavGymEnv(_EnvBase):
                  num_envs=1, n_beams=None, lidar=None, map_size=400, pedestrian_model="sfm", policy_weights=None,
                  num_humans=None, device="cuda:0", seed=0, env_index_base=0, auto_reset=None,
                  field_format=abi.FIELD_U16T, n_spawn=None, randomize_maps=False, plan_paths=True,
-                 action_kind="twist", clip_actions=False, max_waypoints=64, march_rule=None, use_graphs=None):
+                 action_kind="twist", clip_actions=False, max_waypoints=64, march_rule=None, use_graphs=None,
+                 regen_min_steps=0, pregen_pipeline=0, pregen_stage_cap=None):
         from . import lib
         if robot_type not in robots.ROBOTS:
             raise NotImplementedError(robot_type)            # env.py:772-773
@@ -176,7 +181,8 @@ class NavGymEnv(_EnvBase):
             pedestrian_model=pedestrian_model, policy_weights=policy_weights, num_humans=num_humans, device=device, seed=seed,
             env_index_base=env_index_base, auto_reset=auto_reset, field_format=field_format, n_spawn=n_spawn,
             randomize_maps=randomize_maps, plan_paths=plan_paths, action_kind=action_kind, clip_actions=clip_actions,
-            max_waypoints=max_waypoints, march_rule=march_rule, use_graphs=use_graphs)
+            max_waypoints=max_waypoints, march_rule=march_rule, use_graphs=use_graphs,
+            regen_min_steps=regen_min_steps, pregen_pipeline=pregen_pipeline, pregen_stage_cap=pregen_stage_cap)
         self.robot_type = robot_type
         self.time_step = time_step
         self.min_turning_radius = min_turning_radius
@@ -212,6 +218,19 @@ class NavGymEnv(_EnvBase):
             n_spawn = 4 if self.randomize_maps else 16
         self.replan_cap = 1024                              # pedestrians re-planned per step, at most
         self.use_graphs = bool(randomize_maps) if use_graphs is None else bool(use_graphs)
+        # pregen_pipeline = P > 0 (with randomize_maps): the next world of every arena is generated ahead of time by staging
+        # passes on a side stream, one every P steps, and a finished arena takes it inside the step's own launch
+        # (navsim_step_install) -- navsim_regen leaves the step's critical path.  It rests on regen_min_steps >= 4 P: an
+        # episode that ended after fewer steps restarts on its OLD map (the reference draws a map at every reset: opt-in).
+        self.pregen_pipeline = int(pregen_pipeline) if (self.randomize_maps and self.auto_reset) else 0
+        self.regen_min_steps = int(regen_min_steps)
+        self.pregen_stage_cap = pregen_stage_cap        # arenas one staging pass serves at most (None: NavSim.enable_pregen's default)
+        if self.pregen_pipeline:
+            if self.regen_min_steps < 4 * self.pregen_pipeline:
+                raise ValueError("pregen_pipeline=%d needs regen_min_steps >= %d" % (self.pregen_pipeline, 4 * self.pregen_pipeline))
+            if pedestrian_model == "policy":
+                raise ValueError("pregen_pipeline is not available with pedestrian_model='policy'")
+            self.use_graphs = False
         self._graphed = False
         self._overlap_replan = False
         self.plan_paths = bool(plan_paths) and int(map_size) <= 1000
@@ -257,6 +276,10 @@ class NavGymEnv(_EnvBase):
         # regen's masked launch instead of a second scan inside the step (include/navsim.h defer_reset_scan), where a
         # launch is one generation of workgroups -- a few arenas per CU
         cfg.defer_reset_scan = int(self.randomize_maps and self.auto_reset and self.num_envs <= 1024)
+        cfg.regen_min_steps = self.regen_min_steps if (self.randomize_maps and self.auto_reset) else 0
+        if self.pregen_pipeline:
+            cfg.defer_reset_scan = 0              # a staged world brings its first observation; restarts in place scan in the step
+            cfg.regen_cap = self.num_envs         # every finished arena decides alone inside the step (navsim_step_install)
         cfg.regen_plan = int(self.plan_paths)
         cfg.regen_indoor_ratio = float(indoor_ratio)
         cfg.outdoor_map_size = int(self.outdoor_map_size)
@@ -374,7 +397,15 @@ class NavGymEnv(_EnvBase):
         self.sim.regenerate_all(new_episode=not first)
         # pedestrians on planned routes: navsim_replan overlaps the step (not with 'policy', whose control block runs in
         # front of every step and reads the routes)
-        self._overlap_replan = ("costmap" in self.sim.t and self.sim.due is not None and self.pedestrian_model != "policy")
+        self._overlap_replan = ("costmap" in self.sim.t and self.sim.due is not None and self.pedestrian_model != "policy"
+                                and not self.pregen_pipeline)
+        if self.pregen_pipeline:
+            if cfg.field_format != abi.FIELD_U16T:
+                raise ValueError("pregen_pipeline needs the packed distance field (map_size <= 1024)")
+            if first:
+                self.sim.enable_pregen(pipeline=self.pregen_pipeline, install=True, stage_cap=self.pregen_stage_cap)
+            else:
+                self.sim.restage_all()                    # the worlds behind the ones this reset() just drew
         if first and self.use_graphs and self.pedestrian_model != "policy":
             self.sim.enable_graphs(regen=self.randomize_maps and self.auto_reset,
                                    replan_cap=self.replan_cap if "costmap" in self.sim.t else 0)
@@ -434,6 +465,11 @@ class NavGymEnv(_EnvBase):
         a = np.asarray(action, dtype=np.float64).reshape(self.num_envs, 2) if not hasattr(action, "is_cuda") else action
         if self._graphed:                                   # step + regen + replan: one graph launch (NavSim.enable_graphs)
             _, out = self.sim.step_graphed(a)
+        elif self.pregen_pipeline:
+            _, out = self.sim.step(a)                      # navsim_step_install: finished arenas take their staged worlds
+            self.sim.regen()                               # ... and every P steps a staging pass goes to the side stream
+            if "costmap" in self.sim.t:
+                self.sim.replan(self.replan_cap)
         elif self._overlap_replan:
             # planned routes: the re-plan of the previous step runs beside this step's launch (NavSim.launch_step_overlapped)
             _, out = self.sim.step_overlapped(a, self.replan_cap)

@@ -4,6 +4,7 @@ torch is plumbing here: it owns the HBM buffers and the HIP stream; every comput
 path happens in libnavsim_hip.so.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -539,7 +540,7 @@ class NavSim(object):
         install=True (with pipeline): no swap kernel either -- step() is navsim_step_install, in which a finished arena's own
         workgroup copies its staged world in place of the restart's second scan; regen() only queues the passes.  Every
         arena decides alone, so cfg.regen_cap must be >= n_envs (no cap in index order); `stage_cap` bounds what ONE pass
-        stages (default: what 2 P steps finish at one arena in sixteen per step) -- arenas beyond it wait for the next pass.
+        stages (default: what 2 P steps finish at one arena in 64 per step) -- arenas beyond it wait for the next pass.
         map_slots (with install): the live and the staged state share the per-map arrays (t['field'], ... then hold 2 E slots)
         and each has a slot table (navsim_state.map_slot); an install exchanges two table entries instead of copying the
         map -- numpy_state() resolves the table, code that indexes t['field'] by arena must go through t['map_slot']."""
@@ -583,7 +584,48 @@ class NavSim(object):
         self.stage_io = abi.NavsimStepIO()
         self.stage_io.obs = self.stage_obs.data_ptr()
         self.stage_io.done = self.want.data_ptr()
-        # the first staging of every arena, in chunks of as many arenas as the scratch allows (reset path)
+        self._stage_all(scratch_bytes)
+        # a pipelined pass serves what the swaps of P steps marked: P caps' worth of arenas (twice that: what a pass leaves
+        # waits for the next one and would be late)
+        self.stage_cap = self.cfg.regen_cap
+        if P:
+            # (install: every launch of a pass is sized by the cap, not by what it serves -- 512 slots for the ~35 arenas a pass
+            #  of the reference's configuration stages made its planner launches dispatch 30 000 empty workgroups, 367 us each)
+            per_step = max(8, E // 64) if install else self.cfg.regen_cap
+            self.stage_cap = int(min(E, stage_cap if stage_cap else 2 * P * per_step))
+        self.stage_cfg = self.cfg.copy()
+        self.stage_cfg.regen_cap = self.stage_cap
+        nbytes = self.lib.navsim_regen_workspace_bytes(C.byref(self.stage_cfg))
+        self.stage_ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        # a high-priority stream: its few small kernels go first whenever wave slots free up.  (Measured and dropped:
+        # CU-masked streams -- hipExtStreamCreateWithCUMask, 8 / 16 / 32 CUs for the staging passes and the rest for the
+        # steps -- did not make the passes overlap a step kernel that fills the chip: c5 3.0 M env-steps/s either way.
+        # Pipelined passes: the stream's priority, either way round, changes nothing -- c5 62.8 us per step.)
+        self.side = torch.cuda.Stream(device=self.device, priority=-1)
+        self.ev_swapped, self.ev_staged = torch.cuda.Event(), torch.cuda.Event()
+        self.ev_staged.record(torch.cuda.current_stream())
+        self.pg_swapped = [torch.cuda.Event() for _ in range(3)]      # pass j uses slot j % 3; step j P waits for pass j - 2
+        self.pg_staged = [torch.cuda.Event() for _ in range(3)]
+        self.pregen = True
+        self.pg_install = bool(install)
+
+    def restage_all(self, scratch_bytes=4 << 30):
+        """After regenerate_all() on a world with enable_pregen(): every staged world is stale (reset() drew new worlds and,
+        the second time, new episode numbers) -- stage the world behind each arena's current one again."""
+        import torch
+        self.side.synchronize()
+        torch.cuda.current_stream().synchronize()
+        self.stage_t["episode"].copy_(self.t["episode"] + 1)
+        self.want.fill_(1)
+        self.mark.zero_()
+        self.pg_k, self.pg_open = 0, []
+        self._stage_all(scratch_bytes)
+        self.ev_staged.record(torch.cuda.current_stream())
+
+    def _stage_all(self, scratch_bytes):
+        """The (first) staging of every arena, in chunks of as many arenas as the scratch allows (reset path)."""
+        import torch
+        E = self.cfg.n_envs
         cfg = self.cfg.copy()
         cfg.regen_cap = 1
         per = self.lib.navsim_regen_workspace_bytes(C.byref(cfg))
@@ -597,25 +639,6 @@ class NavSim(object):
                   "navsim_regen_stage (first staging)")
         torch.cuda.current_stream().synchronize()
         assert int(self.want.sum().item()) == 0
-        del ws
-        # a pipelined pass serves what the swaps of P steps marked: P caps' worth of arenas (twice that: what a pass leaves
-        # waits for the next one and would be late)
-        self.stage_cfg = self.cfg.copy()
-        if P:
-            per_step = max(16, E // 16) if install else self.cfg.regen_cap
-            self.stage_cfg.regen_cap = int(min(E, stage_cap if stage_cap else 2 * P * per_step))
-        nbytes = self.lib.navsim_regen_workspace_bytes(C.byref(self.stage_cfg))
-        self.stage_ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
-        # a high-priority stream: its few small kernels go first whenever wave slots free up.  (Measured and dropped:
-        # CU-masked streams -- hipExtStreamCreateWithCUMask, 8 / 16 / 32 CUs for the staging passes and the rest for the
-        # steps -- did not make the passes overlap a step kernel that fills the chip: c5 3.0 M env-steps/s either way.)
-        self.side = torch.cuda.Stream(device=self.device, priority=-1)
-        self.ev_swapped, self.ev_staged = torch.cuda.Event(), torch.cuda.Event()
-        self.ev_staged.record(torch.cuda.current_stream())
-        self.pg_swapped = [torch.cuda.Event() for _ in range(3)]      # pass j uses slot j % 3; step j P waits for pass j - 2
-        self.pg_staged = [torch.cuda.Event() for _ in range(3)]
-        self.pregen = True
-        self.pg_install = bool(install)
 
     def _regen_pregen(self):
         import torch
@@ -672,6 +695,8 @@ class NavSim(object):
             self.pg_open = (getattr(self, "pg_open", []) + [staged])[-2:]
         swapped.record(main)
         self.side.wait_event(swapped)
+        C.memmove(C.byref(self.stage_cfg), C.byref(self.cfg), C.sizeof(self.cfg))     # the configuration as it stands NOW
+        self.stage_cfg.regen_cap = self.stage_cap
         ws = self.stage_ws
         check(self.lib.navsim_regen_stage(C.byref(self.stage_cfg), C.byref(self.stage_st), C.byref(self.stage_io), _ptr(self.want),
                                           _ptr(self.mark), _ptr(self.ready), _ptr(ws), ws.numel(), C.c_void_p(self.side.cuda_stream)),

@@ -22,6 +22,11 @@ def run(t):
     sim.launch_step(reorder=False)
     sim.regen()
 
+import contextlib
+hi = torch.cuda.Stream(priority=-1) if os.environ.get("NAVSIM_DIAG_MAIN_HIGH") else None     # the steps on a high-priority stream
+torch.cuda.synchronize()
+ctx = torch.cuda.stream(hi) if hi is not None else contextlib.nullcontext()
+ctx.__enter__()
 for t in range(Wm):
     run(t)
 torch.cuda.synchronize()

@@ -9,6 +9,12 @@ E = int(os.environ.get("NAVSIM_ENVS", "1024"))
 kw = {}
 if os.environ.get("NAVSIM_GRAPHS"):
     kw["use_graphs"] = os.environ["NAVSIM_GRAPHS"] == "1"
+if os.environ.get("NAVSIM_PIPELINE"):          # pipelined pre-generation: regen_min_steps = 4 P
+    kw["pregen_pipeline"] = int(os.environ["NAVSIM_PIPELINE"]); kw["regen_min_steps"] = 4 * kw["pregen_pipeline"]
+if os.environ.get("NAVSIM_STAGE_CAP"):
+    kw["pregen_stage_cap"] = int(os.environ["NAVSIM_STAGE_CAP"])
+if os.environ.get("NAVSIM_MIN_STEPS"):
+    kw["regen_min_steps"] = int(os.environ["NAVSIM_MIN_STEPS"])
 env = nav_gym_env.make("NavGym-v0", num_envs=E, map_size="reference", randomize_maps=True, device="cuda:0", seed=1234, **kw)
 env.reset()
 g = torch.Generator(device="cuda:0"); g.manual_seed(78)

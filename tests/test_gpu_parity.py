@@ -756,22 +756,28 @@ def test_env_reset_at_the_reference_map_size(gpu):
             _eq(og[e:e + 1], ro, "arena %d obs at step %d" % (e, t))
 
 
-def test_reference_default_configuration_sampled_oracle(gpu):
+@pytest.mark.parametrize("pipeline", [0, 2])
+def test_reference_default_configuration_sampled_oracle(gpu, pipeline):
     """Round-4 verdict: the configuration a user of the reference runs unmodified -- every registered default of NavGym-v0
     (__init__.py:4-40: indoor_ratio 0.5, 5-15 pedestrians on planned routes, per-episode env_param draws), KetiRobot's 512
     beams over 2 pi (keti_robot.py:44-48), 1000 x 1000 corridor maps and 400 x 400 outdoor maps (map_generator.py:97-143),
     a new map at every episode end -- batched over 1024 arenas through gym.make.  reset() and ten step() calls (graph replay:
     the re-plan of the previous step beside the step, then navsim_regen) against single-arena oracles of sampled arenas,
-    bit for bit (scan noise off: its per-beam Gaussians are covered by the step tests); size-independent properties on all."""
+    bit for bit (scan noise off: its per-beam Gaussians are covered by the step tests); size-independent properties on all.
+    pipeline = 2: the same world with regen_min_steps = 8 and pregen_pipeline = 2 -- the worlds are staged ahead on a side
+    stream and installed inside the step (navsim_step_install, slot tables); the oracles apply the same rule."""
     import nav_gym_env
     torch = gpu.torch
     E = 1024
-    env = nav_gym_env.make("NavGym-v0", num_envs=E, map_size="reference", randomize_maps=True, seed=41, device=gpu.dev)
+    kw = dict(regen_min_steps=8, pregen_pipeline=2) if pipeline else {}
+    env = nav_gym_env.make("NavGym-v0", num_envs=E, map_size="reference", randomize_maps=True, seed=41, device=gpu.dev, **kw)
     assert env.cfg.n_beams == 512 and env.cfg.map_h == 1000 and env.cfg.outdoor_map_size == 400 and env.plan_paths
     assert env.cfg.regen_indoor_ratio == 0.5 and (env.cfg.num_humans_lo, env.cfg.num_humans_hi) == (5, 15)
     obs = env.reset()
     env.sim.cfg.add_scan_noise = 0                       # (the captured graphs are re-captured: NavSim.step_graphed)
     env.cfg.add_scan_noise = 0
+    if pipeline:
+        env.sim.restage_all()                                # (the staged first observations were drawn with the noise on)
     o0 = env.sim.reset_obs().cpu().numpy()
     n_peds = env.sim.t["n_peds"].cpu().numpy()
     assert n_peds.min() >= 5 and n_peds.max() <= 15 and len(np.unique(n_peds)) > 5
@@ -780,6 +786,9 @@ def test_reference_default_configuration_sampled_oracle(gpu):
     sample = [0, 1, 17, 100, 511, 1023]
     on_goal = torch.as_tensor([1, 100], device=gpu.dev)      # these finish at step 0: new map, pedestrians, routes, first observation
     env.sim.t["robot_goal"][on_goal] = env.sim.t["robot_pose"][on_goal, :2]
+    env.sim.t["steps"][on_goal] = 30                         # (long enough for cfg.regen_min_steps)
+    if pipeline:                                             # ... and one that ends its episode at once: it restarts in place
+        env.sim.t["robot_goal"][17] = env.sim.t["robot_pose"][17, :2]
     cfg = env.sim.cfg
     refs = []
     for e in sample:
@@ -790,8 +799,12 @@ def test_reference_default_configuration_sampled_oracle(gpu):
         host["scan_threshold"] = env.scan_threshold.cpu().numpy(); host["scan_discomfort"] = env.scan_discomfort_threshold.cpu().numpy()
         r = ref.RefSim(c1, host)
         r.out["done"][:] = 1
+        r.a["done_steps"][:] = 1 << 20                       # reset(): whatever cfg.regen_min_steps says about short episodes
         _eq(o0[e:e + 1], r.regen(), "first observation of arena %d" % e)
         if e in (1, 100):
+            r.a["robot_goal"][0] = r.a["robot_pose"][0, :2]
+            r.a["steps"][0] = 30
+        if e == 17 and pipeline:
             r.a["robot_goal"][0] = r.a["robot_pose"][0, :2]
         refs.append(r)
     rng = np.random.default_rng(3)
@@ -813,7 +826,11 @@ def test_reference_default_configuration_sampled_oracle(gpu):
             _eq(og[e:e + 1], r.regen(), "arena %d obs at step %d" % (e, t))
     assert regenerated >= 2, "no sampled arena went through navsim_regen"
     c = env.counters()
-    assert c["regen_served"] >= regenerated and c["regen_unserved"] == 0
+    assert c["regen_served"] >= regenerated and c["regen_unserved"] == 0 and c["regen_late"] == 0
+    if pipeline:
+        assert env.sim.pg_install and "map_slot" in env.sim.t and c["regen_short"] > 0
+        moved = (env.sim.t["map_slot"].cpu().numpy() != np.arange(E)).sum()
+        assert moved >= regenerated                          # the installed maps came by exchange of slot-table entries
 
 
 # NAVSIM_FUZZ_RESET_SEEDS=n widens the sweep for a one-off run (profiles/r04_soak/)
