@@ -601,7 +601,11 @@ class NavSim(object):
         # CU-masked streams -- hipExtStreamCreateWithCUMask, 8 / 16 / 32 CUs for the staging passes and the rest for the
         # steps -- did not make the passes overlap a step kernel that fills the chip: c5 3.0 M env-steps/s either way.
         # Pipelined passes: the stream's priority, either way round, changes nothing -- c5 62.8 us per step.)
-        self.side = torch.cuda.Stream(device=self.device, priority=-1)
+        # (Its priority: high for the pass that must fit between two steps; ordinary for pipelined passes, which have 2 P steps
+        # of slack -- and a process that has used a high-priority stream replays hipGraphs ~10 us per kernel slower from then
+        # on: a reference-default environment built afterwards ran at 0.59 M env-steps/s instead of 0.87 M,
+        # profiles/_diag/after_pregen.py.)
+        self.side = torch.cuda.Stream(device=self.device, priority=0 if P else -1)
         self.ev_swapped, self.ev_staged = torch.cuda.Event(), torch.cuda.Event()
         self.ev_staged.record(torch.cuda.current_stream())
         self.pg_swapped = [torch.cuda.Event() for _ in range(3)]      # pass j uses slot j % 3; step j P waits for pass j - 2

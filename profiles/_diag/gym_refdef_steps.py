@@ -17,6 +17,8 @@ if os.environ.get("NAVSIM_MIN_STEPS"):
     kw["regen_min_steps"] = int(os.environ["NAVSIM_MIN_STEPS"])
 env = nav_gym_env.make("NavGym-v0", num_envs=E, map_size="reference", randomize_maps=True, device="cuda:0", seed=1234, **kw)
 env.reset()
+for _ in range(int(os.environ.get("NAVSIM_RESETS", "1")) - 1):
+    env.reset()
 g = torch.Generator(device="cuda:0"); g.manual_seed(78)
 K, Wm = int(os.environ.get("NAVSIM_STEPS", "100")), 20
 acts = torch.rand((K + Wm, E, 2), generator=g, device="cuda:0", dtype=torch.float64)
