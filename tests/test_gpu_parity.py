@@ -662,10 +662,10 @@ def test_pregenerated_worlds_equal_navsim_regen(gpu, fmt, ped_model, plan):
     assert regenerated > 8 and (twice >= 2).any(), (regenerated, twice.max())
 
 
-@pytest.mark.parametrize("period,min_steps,slow,install", [(1, 12, False, False), (3, 12, False, False), (2, 10, True, False),
-                                                          (1, 12, False, "copy"), (3, 12, False, "slots"), (2, 10, True, "slots"),
-                                                          (1, 12, False, "slots")])
-def test_pipelined_pregeneration_equals_navsim_regen(gpu, monkeypatch, period, min_steps, slow, install):
+@pytest.mark.parametrize("period,min_steps,slow,install,E", [(1, 12, False, False, 48), (3, 12, False, False, 48), (2, 10, True, False, 48),
+                                                            (1, 12, False, "copy", 48), (3, 12, False, "slots", 48), (2, 10, True, "slots", 48),
+                                                            (1, 12, False, "slots", 48), (2, 8, False, "slots", 5), (1, 6, False, False, 1)])
+def test_pipelined_pregeneration_equals_navsim_regen(gpu, monkeypatch, period, min_steps, slow, install, E):
     """enable_pregen(pipeline=P) with cfg.regen_min_steps >= 4 P: staging passes every P steps, waited for two periods later.
     The rule -- an episode shorter than regen_min_steps restarts in place -- is the simulation's (the oracle's
     navsim_regen_cpu applies it from done_steps), so the rollout equals the oracle's synchronous one bit for bit whatever
@@ -673,7 +673,7 @@ def test_pipelined_pregeneration_equals_navsim_regen(gpu, monkeypatch, period, m
     episode ends occur, and no arena ever finds its world unstaged (counters: regen_late 0).
     install: step() is navsim_step_install -- the finished arena's own workgroup copies the staged world, no swap kernel;
     "slots": the two states share the per-map arrays and exchange slot-table entries (navsim_state.map_slot), no map is copied."""
-    E, size, N = 48, 200, 6
+    size, N = 200, 6                                # (E = 5, 1: the flags are consumed in 32-bit words of four arenas)
     cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_SFM, n_spawn=6,
                                  auto_reset=1, seed=29, field_format=abi.FIELD_U16T, regen_cap=E, min_goal_dist=3.0,
                                  max_goal_dist=8.0, spawn_clearance=0.9, ped_min_robot_dist=2.0, ped_min_goal_dist=4.0,
@@ -710,7 +710,7 @@ def test_pipelined_pregeneration_equals_navsim_regen(gpu, monkeypatch, period, m
             for k, v in r.a.items():
                 if k in gs and k not in ("field", "field_overflow", "rect_table", "rect_index", "ped_waypoints", "counters"):
                     _eq(gs[k], v, "state %s after the swap at step %d" % (k, t))
-    assert n_long > 8 and n_short > 0, (n_long, n_short)
+    assert (n_long > 8 and n_short > 0) or (E < 48 and n_long + n_short > 0), (n_long, n_short)
     cg, cr = g.counters(), r.counters()
     assert cg["regen_late"] == 0 and cg["regen_unserved"] == 0
     assert cg["regen_short"] == cr["regen_short"] == n_short and cg["regen_served"] == cr["regen_served"] == n_long
