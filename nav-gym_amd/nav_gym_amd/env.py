@@ -641,6 +641,8 @@ class NavGymEnv(_EnvBase):
             if self.sim.due is not None:
                 self.sim.due[i].copy_(sd["due.%d" % i])
         self.sim.cur = int(sd["cur"])
+        if getattr(self.sim, "pregen", False):             # the staged worlds are not part of the snapshot: stage them again
+            self.sim.restage_all(slots_from_live=True)
         self.sim._steps_launched = int(sd["steps_launched"])
         self._episode_batch = int(sd["episode_batch"])
         self._map_info = None

@@ -613,12 +613,17 @@ class NavSim(object):
         self.pregen = True
         self.pg_install = bool(install)
 
-    def restage_all(self, scratch_bytes=4 << 30):
+    def restage_all(self, scratch_bytes=4 << 30, slots_from_live=False):
         """After regenerate_all() on a world with enable_pregen(): every staged world is stale (reset() drew new worlds and,
-        the second time, new episode numbers) -- stage the world behind each arena's current one again."""
+        the second time, new episode numbers) -- stage the world behind each arena's current one again.
+        slots_from_live: the live slot table was replaced (load_state_dict) -- the staged one is its complement."""
         import torch
         self.side.synchronize()
         torch.cuda.current_stream().synchronize()
+        if slots_from_live and "map_slot" in self.t:
+            free = torch.ones(2 * self.cfg.n_envs, dtype=torch.bool, device=self.device)
+            free[self.t["map_slot"].long()] = False
+            self.stage_t["map_slot"].copy_(torch.nonzero(free).flatten().to(torch.int32))
         self.stage_t["episode"].copy_(self.t["episode"] + 1)
         self.want.fill_(1)
         self.mark.zero_()

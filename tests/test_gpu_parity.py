@@ -716,6 +716,42 @@ def test_pipelined_pregeneration_equals_navsim_regen(gpu, monkeypatch, period, m
     assert cg["regen_short"] == cr["regen_short"] == n_short and cg["regen_served"] == cr["regen_served"] == n_long
 
 
+@pytest.mark.parametrize("pipeline", [0, 2])
+def test_env_state_dict_continues_the_rollout(gpu, pipeline):
+    """NavGymEnv.state_dict() / load_state_dict(): a second environment made with the same arguments continues the first
+    one's rollout bit for bit -- new maps per episode, planned pedestrians; with the pipelined reset path the staged worlds
+    are not part of the snapshot and are staged again (they are functions of seed, arena and episode number)."""
+    import nav_gym_amd
+    torch = gpu.torch
+    kw = dict(nav_gym_amd.DEFAULT_KWARGS)
+    E = 24
+    extra = dict(regen_min_steps=8, pregen_pipeline=2) if pipeline else {}
+    make = lambda: nav_gym_amd.NavGymEnv(num_envs=E, map_size=200, seed=11, num_humans=4, randomize_maps=True, **kw, **extra)
+    g = torch.Generator(device=gpu.dev); g.manual_seed(5)
+    acts = torch.rand((60, E, 2), generator=g, device=gpu.dev, dtype=torch.float64)
+    acts[..., 0] *= 0.5; acts[..., 1] = acts[..., 1] * 1.28 - 0.64
+    acts[::5, :, 1] = 0.0; acts[::5, :, 0] = 0.5                       # straight bursts: crashes, episode ends
+    a = make(); a.reset()
+    for t in range(35):
+        a.step(acts[t])
+    sd = a.state_dict()
+    want = []
+    for t in range(35, 60):
+        o, r, d, _ = a.step(acts[t])
+        want.append((o["observation"].clone(), r.clone(), d.clone()))
+    ended = int(a.sim.t["episode"].sum().item())
+    b = make(); b.reset()
+    b.load_state_dict(sd)
+    for t in range(35, 60):
+        o, r, d, _ = b.step(acts[t])
+        wo, wr, wd = want[t - 35]
+        assert torch.equal(o["observation"], wo) and torch.equal(r, wr) and torch.equal(d, wd), "step %d" % t
+    assert int(b.sim.t["episode"].sum().item()) == ended
+    assert ended - int(sd["t.episode"].sum().item()) > 3, "no episode ended after the snapshot"
+    if pipeline:
+        assert b.counters()["regen_late"] == 0
+
+
 def test_env_reset_at_the_reference_map_size(gpu):
     """1000 x 1000 cells is the reference's own indoor map size (map_generator.py:108-122).  Such a packed world
     carries the float32 overflow plane (cells >= 256 cells from every obstacle), regenerated with the field, and
