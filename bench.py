@@ -759,7 +759,9 @@ def measure(args, scaling, ctx, light=False):
     if args.graph == "on" and getattr(sim, "pregen", False) and not piped:
         raise SystemExit("bench: --pregen without --pregen-pipeline waits for a pass of the previous step on the host's side of the "
                          "capture; it does not go into a hipGraph")
-    if (args.graph == "on" or (args.graph == "auto" and regen and (piped or not getattr(sim, "pregen", False)))) and gatherer is None:
+    # (auto: not for the pipelined passes -- as fork / join nodes of one graph they run at 3.5-5.1 M env-steps/s against 8.1 M
+    #  with plain launches, profiles/r05_pipe/README.md; --graph on still captures them)
+    if (args.graph == "on" or (args.graph == "auto" and regen and not getattr(sim, "pregen", False))) and gatherer is None:
         try:
             cur0 = sim.cur
             if piped:
