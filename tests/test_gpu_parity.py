@@ -664,7 +664,8 @@ def test_pregenerated_worlds_equal_navsim_regen(gpu, fmt, ped_model, plan):
 
 @pytest.mark.parametrize("period,min_steps,slow,install,E", [(1, 12, False, False, 48), (3, 12, False, False, 48), (2, 10, True, False, 48),
                                                             (1, 12, False, "copy", 48), (3, 12, False, "slots", 48), (2, 10, True, "slots", 48),
-                                                            (1, 12, False, "slots", 48), (2, 8, False, "slots", 5), (1, 6, False, False, 1)])
+                                                            (1, 12, False, "slots", 48), (2, 8, False, "slots", 5), (1, 6, False, False, 1),
+                                                            (2, 10, False, "slots-256", 48), (2, 10, False, "slots-64", 48)])
 def test_pipelined_pregeneration_equals_navsim_regen(gpu, monkeypatch, period, min_steps, slow, install, E):
     """enable_pregen(pipeline=P) with cfg.regen_min_steps >= 4 P: staging passes every P steps, waited for two periods later.
     The rule -- an episode shorter than regen_min_steps restarts in place -- is the simulation's (the oracle's
@@ -679,6 +680,11 @@ def test_pipelined_pregeneration_equals_navsim_regen(gpu, monkeypatch, period, m
                                  max_goal_dist=8.0, spawn_clearance=0.9, ped_min_robot_dist=2.0, ped_min_goal_dist=4.0,
                                  regen_plan=0, regen_indoor_ratio=0.0, regen_min_steps=min_steps)
     gpu.world.lidar_1081(cfg)
+    if str(install).startswith("slots-"):               # the install instantiations of the other threads-per-arena families
+        cfg.step_block = int(install.split("-")[1])
+        if cfg.step_block == 64:
+            gpu.world.lidar_full_circle(cfg, 64)
+        install = "slots"
     occ = gpu.world.make_maps(E, size, 29)
     n_long = n_short = 0
     for t, go, gout, ro, rout, g, r in _rollout_pair(gpu, cfg, occ, n_peds=5, steps=110, seed=13):
