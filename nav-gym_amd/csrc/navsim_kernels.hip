@@ -532,6 +532,29 @@ size_t navsim_regen_workspace_bytes(const navsim_config* c) {
     return b + 1024;
 }
 
+extern "C++" {
+namespace {
+// navsim_regen's fork: the distance transform of the new corridor maps beside the planner's first stage (which needs the
+// occupancy grid and the costmap only).  One helper stream and two events per host thread and device, created on first use;
+// inside a hipGraph capture the helper joins the capture through the first wait and leaves it through the second.
+struct RegenFork { int device = -1; hipStream_t side = nullptr; hipEvent_t forked = nullptr, joined = nullptr; };
+RegenFork* regen_fork() {
+    thread_local RegenFork f;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (f.device != dev) {
+        RegenFork n;
+        if (hipStreamCreateWithFlags(&n.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&n.forked, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&n.joined, hipEventDisableTiming) != hipSuccess) return nullptr;
+        n.device = dev;
+        f = n;                                               // (what an earlier device of this thread held stays allocated)
+    }
+    return &f;
+}
+}  // namespace
+}  // extern "C++"
+
 int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, void* workspace,
                  size_t workspace_bytes, void* stream) {
     (void)hipGetLastError();
@@ -611,28 +634,44 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
                                                             fscratch, fbytes, ovf_scratch, direct ? 1 : 0,
                                                             direct ? io->done : nullptr, M, direct_rects, direct_index);
     if (st->map_slot) regen_map_list_kernel<<<(M + 255) / 256, 256, 0, s>>>(list, st->map_slot, mlist, M);
+    // Corridor maps with planned starts: the distance transform, the rect records and the field's install go to a helper
+    // stream, beside the costmap and the robot stage's searches -- those read the occupancy grid only; the stage's accept
+    // kernel (first-scan test on the new field) waits for the helper.  (reference defaults, 1024 arenas: dt 150 us of a
+    // 1.1 ms step beside 150-400 us of searches.)  NAVSIM_REGEN_FORK=0 keeps one stream.
+    static const bool fork_on = !(getenv("NAVSIM_REGEN_FORK") && atoi(getenv("NAVSIM_REGEN_FORK")) == 0);
+    RegenFork* fk = (fork_on && !direct && c->regen_plan) ? regen_fork() : nullptr;
+    hipStream_t sf = s;                                      // the stream of the field's kernels
+    if (fk) {
+        if (hipEventRecord(fk->forked, s) != hipSuccess || hipStreamWaitEvent(fk->side, fk->forked, 0) != hipSuccess) fk = nullptr;
+        else sf = fk->side;
+    }
     if (c->regen_indoor_ratio > 0.0) {
-        dt_columns_kernel<<<dim3((W + 63) / 64, M), 64 * kColSeg, 0, s>>>(occ, cols, H, W, count, kind);
+        dt_columns_kernel<<<dim3((W + 63) / 64, M), 64 * kColSeg, 0, sf>>>(occ, cols, H, W, count, kind);
         if (c->field_format == NAVSIM_FIELD_F32)
-            dt_rows_kernel<0><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, nullptr, nullptr, H, W, count, kind);
+            dt_rows_kernel<0><<<dim3(H, M), 256, (size_t)W * 4, sf>>>(cols, fscratch, nullptr, nullptr, H, W, count, kind);
         else
-            dt_rows_kernel<1><<<dim3(H, M), 256, (size_t)W * 4, s>>>(cols, fscratch, ovf_scratch, nullptr, H, W, count, kind);
+            dt_rows_kernel<1><<<dim3(H, M), 256, (size_t)W * 4, sf>>>(cols, fscratch, ovf_scratch, nullptr, H, W, count, kind);
     }
     if (st->rect_table && !direct) {                        // keep the rect records of the regenerated arenas current
         off = (off + 255) & ~(size_t)255;
         char* rect_ws = w + off;
         off += navsim_build_rects_workspace_bytes(M, H, W) + 256;
         launch_build_rects(occ, M, H, W, fscratch, fbytes, c->field_format, ovf_scratch, (uint4*)st->rect_table, rect_ws,
-                           count, mlist, s);
+                           count, mlist, sf);
         if (st->rect_index)
-            rect_index_kernel<<<M, 256, 0, s>>>((const uint4*)st->rect_table, H, W, (char*)st->rect_index, nullptr, count, mlist);
+            rect_index_kernel<<<M, 256, 0, sf>>>((const uint4*)st->rect_table, H, W, (char*)st->rect_index, nullptr, count, mlist);
     }
     if (!direct) {
-        regen_field_kernel<<<regen_grid(M), 256, 0, s>>>((char*)st->field, count, mlist, fscratch, fbytes);
+        regen_field_kernel<<<regen_grid(M), 256, 0, sf>>>((char*)st->field, count, mlist, fscratch, fbytes);
         if (ovf_scratch)
-            regen_field_kernel<<<regen_grid(M), 256, 0, s>>>((char*)st->field_overflow, count, mlist,
-                                                                    (const char*)ovf_scratch, cells * sizeof(float));
+            regen_field_kernel<<<regen_grid(M), 256, 0, sf>>>((char*)st->field_overflow, count, mlist,
+                                                                     (const char*)ovf_scratch, cells * sizeof(float));
     }
+    bool join_pending = fk != nullptr;
+    if (fk && hipEventRecord(fk->joined, fk->side) != hipSuccess) return NAVSIM_E_LAUNCH;
+    auto join = [&]() {                                      // the caller's stream waits for the field (once)
+        if (join_pending) { (void)hipStreamWaitEvent(s, fk->joined, 0); join_pending = false; }
+    };
     if (c->regen_plan) {
         const int Hc = H / 5, Wc = W / 5, P = c->max_waypoints, R = kRegenRounds;
         const size_t cc = (size_t)Hc * Wc;
@@ -667,6 +706,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         regen_robot_sample_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, ws);
         plan_pass(0, 0);
         plan_pass(0, 1);
+        join();
         if (c->field_format == NAVSIM_FIELD_F32) regen_robot_accept_kernel<FieldF32><<<M, 256, 0, s>>>(*c, *st, count, list, ws);
         else                                     regen_robot_accept_kernel<FieldU16T><<<M, 256, 0, s>>>(*c, *st, count, list, ws);
         if (c->ped_model != NAVSIM_PED_NONE && c->max_peds > 0) {
@@ -678,6 +718,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     } else if (st->costmap) {
         costmap_kernel<<<dim3(((H / 5) * (W / 5) + 255) / 256, M), 256, 0, s>>>(occ, H, W, st->costmap, count, mlist);
     }
+    join();
     if (!c->regen_plan) {
         if (c->field_format == NAVSIM_FIELD_F32)
             regen_commit_kernel<FieldF32><<<M, kCommitBlock, 0, s>>>(*c, *st, count, list, fscratch, fbytes, kind);
@@ -1066,6 +1107,7 @@ int navsim_prepare(const navsim_config* c, const navsim_state* st, const navsim_
     }
     g_prepare_only = false;
     if (rc != NAVSIM_OK) return rc;
+    if (c->regen_plan && c->regen_indoor_ratio > 0.0) (void)regen_fork();     // navsim_regen's helper stream: not created inside a capture
     const int Hc = c->map_h / 5, Wc = c->map_w / 5;
     if (Hc >= 1 && Wc >= 1 && plan_fits(Hc, Wc)) {                           // the planners' LDS-resident search
         (void)allow_lds((const void*)plan_kernel, plan_lds(Hc, Wc));

@@ -29,7 +29,8 @@ and default to the reference's behaviour for num_envs == 1:
                     regen_min_steps >= 4 P -- an episode shorter than regen_min_steps restarts on its old map, which the
                     reference never does (it draws a map at every reset): opt-in, counted in counters()['regen_short']
     use_graphs      replay a step's launches (navsim_step, navsim_regen, navsim_replan) as one captured hipGraph; None
-                    (default) = when randomize_maps makes a step several launches (c5: +6 %); results are identical
+                    (default) = when randomize_maps makes a step several launches (c5: +6 %) and navsim_regen does not fork
+                    (corridor maps with planned starts: plain launches are as fast or faster); results are identical
     max_waypoints   waypoints kept per pedestrian route (default 64 = 128 m at the 2 m interval; the reference keeps
                     all of them, env.py:788-804); longer routes are stored cut, counted, and continued to the same goal
     device, seed, env_index_base (global index of arena 0: sharding), auto_reset, field_format
@@ -217,6 +218,7 @@ class NavGymEnv(_EnvBase):
         if n_spawn is None:
             n_spawn = 4 if self.randomize_maps else 16
         self.replan_cap = 1024                              # pedestrians re-planned per step, at most
+        self._use_graphs_arg = use_graphs
         self.use_graphs = bool(randomize_maps) if use_graphs is None else bool(use_graphs)
         # pregen_pipeline = P > 0 (with randomize_maps): the next world of every arena is generated ahead of time by staging
         # passes on a side stream, one every P steps, and a finished arena takes it inside the step's own launch
@@ -234,6 +236,10 @@ class NavGymEnv(_EnvBase):
         self._graphed = False
         self._overlap_replan = False
         self.plan_paths = bool(plan_paths) and int(map_size) <= 1000
+        if self._use_graphs_arg is None and self.plan_paths and float(indoor_ratio) > 0.0:
+            # corridor maps with planned starts: navsim_regen forks its distance transform beside the searches; as fork / join
+            # nodes of a hipGraph that gains nothing (reference defaults, 1024 arenas: 0.92 M graphed, 0.96 M plain launches)
+            self.use_graphs = False
         if plan_paths and not self.plan_paths:
             self._warn_once("plan_paths", "NavGymEnv: map_size %d > 1000: the planner's search lives in LDS (costmaps up to "
                             "200 x 200 cells), plan_paths falls back to False -- pedestrians head straight for their goals"

@@ -798,7 +798,7 @@ def test_env_reset_at_the_reference_map_size(gpu):
             _eq(og[e:e + 1], ro, "arena %d obs at step %d" % (e, t))
 
 
-@pytest.mark.parametrize("pipeline", [0, 2])
+@pytest.mark.parametrize("pipeline", [0, 2, "graphs"])
 def test_reference_default_configuration_sampled_oracle(gpu, pipeline):
     """Round-4 verdict: the configuration a user of the reference runs unmodified -- every registered default of NavGym-v0
     (__init__.py:4-40: indoor_ratio 0.5, 5-15 pedestrians on planned routes, per-episode env_param draws), KetiRobot's 512
@@ -811,8 +811,11 @@ def test_reference_default_configuration_sampled_oracle(gpu, pipeline):
     import nav_gym_env
     torch = gpu.torch
     E = 1024
-    kw = dict(regen_min_steps=8, pregen_pipeline=2) if pipeline else {}
+    kw = dict(regen_min_steps=8, pregen_pipeline=2) if pipeline == 2 else {}
+    if pipeline == "graphs":                                 # (the default is plain launches since navsim_regen forks: the captured form too)
+        kw, pipeline = dict(use_graphs=True), 0
     env = nav_gym_env.make("NavGym-v0", num_envs=E, map_size="reference", randomize_maps=True, seed=41, device=gpu.dev, **kw)
+    assert env.use_graphs == bool(kw.get("use_graphs", False))
     assert env.cfg.n_beams == 512 and env.cfg.map_h == 1000 and env.cfg.outdoor_map_size == 400 and env.plan_paths
     assert env.cfg.regen_indoor_ratio == 0.5 and (env.cfg.num_humans_lo, env.cfg.num_humans_hi) == (5, 15)
     obs = env.reset()
