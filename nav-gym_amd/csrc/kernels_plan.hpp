@@ -183,9 +183,13 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
         if constexpr (MAXWPT == 1) {
             plan_levels<BLOCK, 1>(fa, fb, planes, Hc, Wc, Ww, n_words, s_word, s_bit, any_s, &reached);      // (the caller checked n_words <= BLOCK)
         } else {
+            // (plan_fits: at most kPlanMaxWpt * 256 words -- a 1024-thread workgroup never owns more than two per thread; with
+            //  the four- and eight-word forms compiled in, its 128-register budget spilled 36-96 registers per lane)
             if (n_words <= BLOCK)          plan_levels<BLOCK, 1>(fa, fb, planes, Hc, Wc, Ww, n_words, s_word, s_bit, any_s, &reached);
-            else if (n_words <= 2 * BLOCK) plan_levels<BLOCK, 2>(fa, fb, planes, Hc, Wc, Ww, n_words, s_word, s_bit, any_s, &reached);
-            else if (n_words <= 4 * BLOCK) plan_levels<BLOCK, 4>(fa, fb, planes, Hc, Wc, Ww, n_words, s_word, s_bit, any_s, &reached);
+            else if (n_words <= 2 * BLOCK || BLOCK * 2 >= kPlanMaxWpt * 256)
+                                           plan_levels<BLOCK, 2>(fa, fb, planes, Hc, Wc, Ww, n_words, s_word, s_bit, any_s, &reached);
+            else if (n_words <= 4 * BLOCK || BLOCK * 4 >= kPlanMaxWpt * 256)
+                                           plan_levels<BLOCK, 4>(fa, fb, planes, Hc, Wc, Ww, n_words, s_word, s_bit, any_s, &reached);
             else                           plan_levels<BLOCK, kPlanMaxWpt>(fa, fb, planes, Hc, Wc, Ww, n_words, s_word, s_bit, any_s, &reached);
         }
     }
