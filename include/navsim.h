@@ -574,11 +574,6 @@ int    navsim_regen_stage(const navsim_config* cfg, const navsim_state* stage, c
 int    navsim_step_install(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                            const navsim_state* stage, const float* stage_obs, uint8_t* mark, const long long* ready,
                            void* stream);
-/* Streams: everything navsim_regen does is ordered behind `stream` and complete for work queued on `stream` after the call.
- * Worlds of corridor maps with planned starts (cfg.regen_indoor_ratio > 0, cfg.regen_plan): part of the call -- the distance
- * transform of the new maps -- runs on a helper stream of the library's own (one per host thread and device, created by
- * navsim_prepare or the first such call) between two events on `stream`; inside a hipGraph capture of `stream` the helper
- * joins and leaves the capture through them.  Environment NAVSIM_REGEN_FORK=0 keeps the call on `stream` alone. */
 int    navsim_regen(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                     void* workspace, size_t workspace_bytes, void* stream);
 
