@@ -175,7 +175,10 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
     }
     if (tid == 0) g[(G / 2) * G + G / 2] = 0;
     __syncthreads();
-    for (int k = 0; k < n_it; ++k) {
+    // (carving only clears cells: the corridors are independent too -- one per WAVEFRONT at a time, 64 lanes on its two
+    //  rectangles; all 256 threads on one corridor after the other was 60 of the kernel's 85 us at 150 iterations)
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int k = wave; k < n_it; k += 4) {
         const int px = tx[k + 1], py = ty[k + 1];
         const bool coin = coin_s[k] != 0;
         const int qx = tx[near_s[k]], qy = ty[near_s[k]];
@@ -185,15 +188,15 @@ __global__ __launch_bounds__(256) void regen_indoor_kernel(navsim_config c, navs
         const int hx = coin ? x1 : x2;
         const int cy = coin ? (constellation1 ? y1 : y2) : (constellation1 ? y2 : y1);
         const int wh = y2 - y1 + 2 * r + 1, hv = x2 - x1 + 2 * r + 1, side = 2 * r + 1;
-        for (int idx = tid; idx < side * wh; idx += 256) {
+        for (int idx = lane; idx < side * wh; idx += 64) {
             int a = hx - r + idx / wh, bq = y1 - r + idx % wh;
             if (a >= 0 && a < G && bq >= 0 && bq < G) g[a * G + bq] = 0;
         }
-        for (int idx = tid; idx < hv * side; idx += 256) {
+        for (int idx = lane; idx < hv * side; idx += 64) {
             int a = x1 - r + idx / side, bq = cy - r + idx % side;
             if (a >= 0 && a < G && bq >= 0 && bq < G) g[a * G + bq] = 0;
         }
-        if (tid == 0) g[px * G + py] = 0;
+        if (lane == 0) g[px * G + py] = 0;
     }
     __syncthreads();
     uint8_t* out = grid_all + (size_t)b * 10000;
