@@ -1103,13 +1103,12 @@ __global__ __launch_bounds__(256) void regen_swap_kernel(navsim_config c, navsim
             for (size_t i = lo + tid; i < hi; i += 256) dst[i] = src[i];
         }
     }
-    // the small arrays: one per slice (each is a load -> store round trip; a single workgroup walking through all twenty
-    // of them one after the other took 15 of the kernel's 22 us on c5)
+    // the small arrays, by slice 0 (spreading them over the slices, one array each, was measured: the kernel went from 22 to
+    // 32 us on c5 -- what it costs is the 4096 workgroups that each select their arena, not these rows)
+    if (blockIdx.y != 0) return;
     const int N = c.max_peds, K = c.n_spawn, P = c.max_waypoints, D = c.n_scan_stack * c.n_beams + NAVSIM_OBS_TAIL;
-    int turn = 0;
     auto row = [&](auto* dst, const auto* src, size_t n) {    // n elements of arena e
-        const bool mine = (int)blockIdx.y == (turn++ % (int)gridDim.y);
-        if (!mine || !dst || !src) return;
+        if (!dst || !src) return;
         for (size_t i = tid; i < n; i += 256) dst[(size_t)e * n + i] = src[(size_t)e * n + i];
     };
     row(live.scan_noise_std, stage.scan_noise_std, 1);
@@ -1135,7 +1134,7 @@ __global__ __launch_bounds__(256) void regen_swap_kernel(navsim_config c, navsim
         row(live.ped_goal, stage.ped_goal, (size_t)N * 2);
     }
     row(io.obs, stage_obs, D);
-    if (tid == 0 && blockIdx.y == gridDim.y - 1) {
+    if (tid == 0) {
         if (io.achieved_goal) { io.achieved_goal[2 * e] = (float)stage.robot_pose[3 * (size_t)e]; io.achieved_goal[2 * e + 1] = (float)stage.robot_pose[3 * (size_t)e + 1]; }
         if (io.desired_goal) { io.desired_goal[2 * e] = (float)stage.robot_goal[2 * (size_t)e]; io.desired_goal[2 * e + 1] = (float)stage.robot_goal[2 * (size_t)e + 1]; }
         if (live.ped_due) live.ped_due[e] = 0ull;           // new pedestrians: nobody waits for navsim_replan
