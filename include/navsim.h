@@ -571,9 +571,16 @@ int    navsim_regen_stage(const navsim_config* cfg, const navsim_state* stage, c
  * call needs cfg.regen_cap >= cfg.n_envs; the staging passes' cap is the one of the config THEY are given).  Counters as
  * navsim_regen_swap.  Packed fields, pedestrians inside the step (ped_split 0 / 1); NAVSIM_E_UNSUPPORTED otherwise.
  * The caller queues the staging passes as for the pipelined swap (replace "swap of step" by "step"). */
+/* late [E] uint8 or NULL -- the FALLBACK that needs no rule: the launch writes late[e] = 1 for every arena that finished,
+ * is due a new world (by cfg.regen_min_steps, if set) and whose staged world was not ready, 0 for every other arena; the caller
+ * follows the launch with navsim_regen(cfg', st, io' with io'->done = late) on the same stream (cfg' = cfg with a regen_cap that
+ * sizes the workspace; with no arena late the call's launches find nothing to do).  The result is then navsim_step +
+ * navsim_regen whatever the staging passes' timing -- also with cfg.regen_min_steps = 0, i.e. the reference's "a new map at
+ * every reset()" unchanged; the passes only decide how many arenas take the fast path.  late = NULL needs
+ * cfg.regen_min_steps >= 1 and the caller's order of passes and waits (above). */
 int    navsim_step_install(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                            const navsim_state* stage, const float* stage_obs, uint8_t* mark, const long long* ready,
-                           void* stream);
+                           uint8_t* late, void* stream);
 int    navsim_regen(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                     void* workspace, size_t workspace_bytes, void* stream);
 

@@ -961,6 +961,8 @@ struct StepInstall {
     const float* stage_obs;              // [E][D] first observations of the staged worlds
     uint8_t* mark;                       // [E rounded up to 4] "stage me again" flags (32-bit atomics)
     const long long* ready;              // [E] episode number the last finished staging pass generated for
+    uint8_t* late;                       // [E] or NULL: out, 1 = the arena finished, is due a new world and its staged one was not
+                                         // ready -- the caller regenerates it now (navsim_regen with these flags as io->done)
     StepInstallBig big[5];
 };
 // "stage arena e again, for episode ep": the number first, then the flag (a staging pass that takes the flag -- possibly while
@@ -1312,6 +1314,7 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
             nv::RewardOut o = nv::reward_scalar(c, prev_xy, pose, vel, goal, crash != 0, discomfort != 0, rmin);
             io.reward[e] = o.reward;
             io.done[e] = (uint8_t)o.done;
+            if constexpr (INSTALL) if (in->late) in->late[e] = 0;
             io.is_success[e] = o.success;
             io.is_crash[e] = o.crash;
             io.distance[e] = o.distance;
@@ -1339,6 +1342,7 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
                     const bool lng = c.regen_min_steps <= 0 || st.done_steps[e] >= c.regen_min_steps;
                     const bool rdy = in->ready[e] == (long long)st.episode[e];
                     if (lng && rdy) { sh.respawn = 3; sh.rescan = 0; }          // 3: the staged world is installed below
+                    else if (lng && in->late) in->late[e] = 1;                  // ... or generated now, by the caller's navsim_regen
                     if (st.counters)
                         atomicAdd(&st.counters[lng ? (rdy ? NAVSIM_COUNTER_REGEN_SERVED : NAVSIM_COUNTER_REGEN_LATE) : NAVSIM_COUNTER_REGEN_SHORT], 1ull);
                     // installed: the world after this one; not installed: the arena plays its next episode in place, what is

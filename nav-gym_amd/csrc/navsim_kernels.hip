@@ -780,11 +780,14 @@ void stage_big_buffers(const navsim_config* c, const navsim_state* live, const n
 }  // extern "C++"
 
 int navsim_step_install(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, const navsim_state* stage,
-                        const float* stage_obs, uint8_t* mark, const long long* ready, void* stream) {
+                        const float* stage_obs, uint8_t* mark, const long long* ready, uint8_t* late, void* stream) {
     (void)hipGetLastError();
     int rc = check_step_args(c, st, io, 0);
     if (rc != NAVSIM_OK) return rc;
-    if (!stage || !stage_obs || !mark || !ready || ((uintptr_t)mark & 3) != 0 || !st->done_steps || c->regen_min_steps < 1) return NAVSIM_E_ARG;
+    if (!stage || !stage_obs || !mark || !ready || ((uintptr_t)mark & 3) != 0 || !st->done_steps) return NAVSIM_E_ARG;
+    // what makes the outcome independent of the staging passes' timing: the rule (cfg.regen_min_steps, with the caller's order of
+    // passes and waits) or the fallback (late: arenas whose world was not ready are generated by the caller's navsim_regen)
+    if (c->regen_min_steps < 1 && !late) return NAVSIM_E_ARG;
     rc = check_stage_pair(c, st, stage);
     if (rc != NAVSIM_OK) return rc;
     // every finished arena decides for itself: there is no cap to apply in index order (navsim_regen_swap has one)
@@ -794,7 +797,7 @@ int navsim_step_install(const navsim_config* c, const navsim_state* st, const na
     rc = check_map_slots(st, stage);
     if (rc != NAVSIM_OK) return rc;
     StepInstall in = {};
-    in.stage = *stage; in.stage_obs = stage_obs; in.mark = mark; in.ready = ready;
+    in.stage = *stage; in.stage_obs = stage_obs; in.mark = mark; in.ready = ready; in.late = late;
     if (!st->map_slot) stage_big_buffers(c, st, stage, in.big);             // (with slot tables the maps stay where they are)
     return dispatch_step(c, st, io, 16, nullptr, (hipStream_t)stream, 0, 0, &in);
 }

@@ -333,7 +333,7 @@ def declare(lib, suffix=""):
         sig("navsim_regen", [cfgp, stp, iop, _P, C.c_size_t, _P])
         sig("navsim_regen_swap", [cfgp, stp, stp, iop, _P, _P, _P, _P, _P])
         sig("navsim_regen_stage", [cfgp, stp, iop, _P, _P, _P, _P, C.c_size_t, _P])
-        sig("navsim_step_install", [cfgp, stp, iop, stp, _P, _P, _P, _P])
+        sig("navsim_step_install", [cfgp, stp, iop, stp, _P, _P, _P, _P, _P])
     sig("navsim_crowd_check", [C.POINTER(NavsimCrowdParams), i32, i32, i32, _P, _P, _P, _P, _P, _P, _P, _P, _P] + stream)
     mpp = C.POINTER(NavsimCrowdMapParams)
     sig("navsim_crowd_angular_map", [mpp, i32, i32, i32, _P, _P, _P, _P] + stream)

@@ -25,9 +25,11 @@ and default to the reference's behaviour for num_envs == 1:
     clip_actions    True: the twist is clamped to linvel_range x rotvel_range on the device (the reference only prints
                     a warning and never clips, env.py:606-613: default False)
     regen_min_steps, pregen_pipeline   (randomize_maps) pregen_pipeline = P > 0: the next world of every arena is staged ahead
-                    of time on a side stream (a pass every P steps) and installed inside the step's own launch; needs
-                    regen_min_steps >= 4 P -- an episode shorter than regen_min_steps restarts on its old map, which the
-                    reference never does (it draws a map at every reset): opt-in, counted in counters()['regen_short']
+                    of time on a side stream (a pass every P steps) and installed inside the step's own launch.  With
+                    regen_min_steps = 0 (default) the rollout is EXACTLY the one without the pipeline: an arena that finishes
+                    before its world is staged is generated on the spot (counters()['regen_late']).  regen_min_steps >= 4 P
+                    drops that fallback's launches (fastest): an episode shorter than regen_min_steps restarts on its old map,
+                    which the reference never does (it draws a map at every reset) -- counted in counters()['regen_short']
     use_graphs      replay a step's launches (navsim_step, navsim_regen, navsim_replan) as one captured hipGraph; None
                     (default) = when randomize_maps makes a step several launches (c5: +6 %) and navsim_regen does not fork
                     (corridor maps with planned starts: plain launches are as fast or faster); results are identical
@@ -228,8 +230,9 @@ class NavGymEnv(_EnvBase):
         self.regen_min_steps = int(regen_min_steps)
         self.pregen_stage_cap = pregen_stage_cap        # arenas one staging pass serves at most (None: NavSim.enable_pregen's default)
         if self.pregen_pipeline:
-            if self.regen_min_steps < 4 * self.pregen_pipeline:
-                raise ValueError("pregen_pipeline=%d needs regen_min_steps >= %d" % (self.pregen_pipeline, 4 * self.pregen_pipeline))
+            # regen_min_steps >= 4 P: the rule (fastest; short episodes keep their map).  Below that -- 0 is the reference's own
+            # "a new map at every reset()" -- an arena that finishes before its world is staged is generated on the spot by
+            # navsim_regen (NavSim.enable_pregen fallback): same rollout as without the pipeline, bit for bit
             if pedestrian_model == "policy":
                 raise ValueError("pregen_pipeline is not available with pedestrian_model='policy'")
             self.use_graphs = False

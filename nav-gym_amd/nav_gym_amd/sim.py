@@ -514,7 +514,7 @@ class NavSim(object):
         if k % P == 0 and k >= 2 * P:
             main.wait_event(self.pg_staged[(k // P - 2) % 3])   # the pass queued two periods ago; the later two may still run
         check(self.lib.navsim_step_install(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), C.byref(self.stage_st),
-                                           _ptr(self.stage_obs), _ptr(self.mark), _ptr(self.ready),
+                                           _ptr(self.stage_obs), _ptr(self.mark), _ptr(self.ready), _ptr(self.late),
                                            C.c_void_p(main.cuda_stream)), "navsim_step_install")
 
     # arrays navsim_regen writes: the staged state of enable_pregen() owns a copy of each
@@ -524,7 +524,8 @@ class NavSim(object):
 
     MAPS = ("field", "field_overflow", "rect_table", "rect_index", "costmap")      # the per-map arrays (navsim_state.map_slot)
 
-    def enable_pregen(self, scratch_bytes=4 << 30, pipeline=0, install=False, stage_cap=None, map_slots=True):
+    def enable_pregen(self, scratch_bytes=4 << 30, pipeline=0, install=False, stage_cap=None, map_slots=True, fallback=None,
+                      fallback_cap=None):
         """navsim_regen off the step's critical path (include/navsim.h navsim_regen_swap): the world every arena will
         get at the end of its CURRENT episode -- a function of (seed, global arena, episode number) only -- is generated
         ahead of time into a second, staged state by the ordinary navsim_regen on a side stream; regen() then only
@@ -541,6 +542,11 @@ class NavSim(object):
         workgroup copies its staged world in place of the restart's second scan; regen() only queues the passes.  Every
         arena decides alone, so cfg.regen_cap must be >= n_envs (no cap in index order); `stage_cap` bounds what ONE pass
         stages (default: what 2 P steps finish at one arena in 64 per step) -- arenas beyond it wait for the next pass.
+        fallback (with install; default: on when cfg.regen_min_steps < 4 P): no rule is needed -- an arena that finishes before
+        its world is staged is regenerated on the spot by the ordinary navsim_regen (regen() launches it after every step, with
+        the flags the step wrote: launches that find nothing to do when nobody was late, `fallback_cap` arenas at most).  The
+        rollout then equals step + navsim_regen whatever the passes' timing, also with cfg.regen_min_steps = 0: the reference's
+        "a new map at every reset()" unchanged.
         map_slots (with install): the live and the staged state share the per-map arrays (t['field'], ... then hold 2 E slots)
         and each has a slot table (navsim_state.map_slot); an install exchanges two table entries instead of copying the
         map -- numpy_state() resolves the table, code that indexes t['field'] by arena must go through t['map_slot']."""
@@ -549,9 +555,14 @@ class NavSim(object):
             raise ValueError("enable_pregen needs cfg.auto_reset = 1 (the step advances episode[e] when an arena finishes)")
         E = self.cfg.n_envs
         P = int(pipeline)
-        if P < 0 or (P > 0 and self.cfg.regen_min_steps < 4 * P):
+        if fallback is None:
+            fallback = bool(install) and P > 0 and self.cfg.regen_min_steps < 4 * P
+        if fallback and not install:
+            raise ValueError("enable_pregen(fallback=True) is a feature of install=True")
+        if P < 0 or (P > 0 and self.cfg.regen_min_steps < 4 * P and not fallback):
             raise ValueError("enable_pregen(pipeline=%d) needs cfg.regen_min_steps >= %d (it is %d): an arena must not want its "
-                             "next world before the pass that stages it was waited for" % (P, 4 * P, self.cfg.regen_min_steps))
+                             "next world before the pass that stages it was waited for -- or fallback=True (install=True)"
+                             % (P, 4 * P, self.cfg.regen_min_steps))
         self.pg_period, self.pg_k = P, 0
         if install and (not P or self.cfg.regen_cap < E):
             raise ValueError("enable_pregen(install=True) needs pipeline >= 1 and cfg.regen_cap >= n_envs (every finished arena "
@@ -612,6 +623,13 @@ class NavSim(object):
         self.pg_staged = [torch.cuda.Event() for _ in range(3)]
         self.pregen = True
         self.pg_install = bool(install)
+        # the fallback: flags the step writes, and a navsim_regen of its own size for the arenas they name
+        self.late = torch.zeros(E, dtype=torch.uint8, device=self.device) if fallback else None
+        if fallback:
+            self.late_cfg = self.cfg.copy()
+            self.late_cap = int(min(E, fallback_cap if fallback_cap else max(16, E // 64)))
+            self.late_cfg.regen_cap = self.late_cap
+            self.late_ws = torch.zeros(self.lib.navsim_regen_workspace_bytes(C.byref(self.late_cfg)), dtype=torch.uint8, device=self.device)
 
     def restage_all(self, scratch_bytes=4 << 30, slots_from_live=False):
         """After regenerate_all() on a world with enable_pregen(): every staged world is stale (reset() drew new worlds and,
@@ -656,6 +674,16 @@ class NavSim(object):
         self.pg_k += 1
         j = k // P if P else 0
         if self.pg_install:                              # step() has installed; only the passes are left
+            if self.late is not None:                   # ... and whoever finished before its world was staged (rare): now
+                C.memmove(C.byref(self.late_cfg), C.byref(self.cfg), C.sizeof(self.cfg))
+                self.late_cfg.regen_cap = self.late_cap
+                io = abi.NavsimStepIO()
+                C.memmove(C.byref(io), C.byref(self.io), C.sizeof(io))
+                io.obs = self.obs_buf[self.cur].data_ptr()
+                io.done = self.late.data_ptr()
+                self._latest_flags()
+                check(self.lib.navsim_regen(C.byref(self.late_cfg), C.byref(self.st), C.byref(io), _ptr(self.late_ws),
+                                            self.late_ws.numel(), C.c_void_p(main.cuda_stream)), "navsim_regen (arenas whose world was not staged)")
             if k % P == 0:
                 self._latest_flags()
                 self._queue_pass(main, self.pg_swapped[j % 3], self.pg_staged[j % 3])

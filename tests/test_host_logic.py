@@ -103,15 +103,15 @@ def test_argument_validation_of_round2_entry_points():
     # round 5: navsim_step_install and the pipelined swap / stage refuse what they cannot do, before any launch
     ptr = C.cast(one, C.c_void_p)
     c2 = cfg.copy(); c2.n_envs = 4; c2.regen_cap = 4; c2.auto_reset = 1; c2.n_spawn = 2; c2.regen_min_steps = 0
-    assert L.navsim_step_install(C.byref(c2), C.byref(st), C.byref(io), None, ptr, ptr, ptr, None) == abi.E_ARG      # no staged state
-    assert L.navsim_step_install(C.byref(c2), C.byref(st), C.byref(io), C.byref(st), ptr, ptr, ptr, None) == abi.E_ARG   # no rule, no done_steps
+    assert L.navsim_step_install(C.byref(c2), C.byref(st), C.byref(io), None, ptr, ptr, ptr, None, None) == abi.E_ARG      # no staged state
+    assert L.navsim_step_install(C.byref(c2), C.byref(st), C.byref(io), C.byref(st), ptr, ptr, ptr, None, None) == abi.E_ARG   # no rule, no fallback, no done_steps
     c2.regen_min_steps = -1
     assert L.navsim_step(C.byref(c2), C.byref(st), C.byref(io), None) == abi.E_ARG
     c2.regen_min_steps = 8; st.done_steps = ptr; st.spawn_pose = ptr; st.spawn_goal = ptr
     c2.regen_cap = 2                                                       # a cap below n_envs: every arena decides alone
-    assert L.navsim_step_install(C.byref(c2), C.byref(st), C.byref(io), C.byref(st), ptr, ptr, ptr, None) == abi.E_UNSUPPORTED
+    assert L.navsim_step_install(C.byref(c2), C.byref(st), C.byref(io), C.byref(st), ptr, ptr, ptr, None, None) == abi.E_UNSUPPORTED
     odd = C.c_void_p(ptr.value + 1)                                        # mark[] is consumed in 32-bit words
-    assert L.navsim_step_install(C.byref(c2), C.byref(st), C.byref(io), C.byref(st), ptr, odd, ptr, None) == abi.E_ARG
+    assert L.navsim_step_install(C.byref(c2), C.byref(st), C.byref(io), C.byref(st), ptr, odd, ptr, None, None) == abi.E_ARG
     assert L.navsim_regen_swap(C.byref(c2), C.byref(st), C.byref(st), C.byref(io), ptr, ptr, odd, None, None) == abi.E_ARG
     st.map_slot = ptr; c2.shared_field = 1
     assert L.navsim_step(C.byref(c2), C.byref(st), C.byref(io), None) == abi.E_ARG              # one shared map has no slots
