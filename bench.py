@@ -79,8 +79,8 @@ def build_sim(wl, base, E, seed=1234, device="cuda:0"):
     if wl.get("regen"):
         cfg.regen_cap = max(16, E // 16)          # arenas regenerated per step at most (c5: ~5 finish per step)
     cfg.regen_indoor_ratio = float(wl.get("indoor_ratio", 0.0))
-    if wl.get("pipeline", 0):                     # --pregen-pipeline P: episodes shorter than 4 P steps restart in place
-        cfg.regen_min_steps = 4 * int(wl["pipeline"])
+    if wl.get("pipeline", 0):                     # --pregen-pipeline P: episodes shorter than 4 P steps restart in place ...
+        cfg.regen_min_steps = 0 if wl.get("no_rule") else 4 * int(wl["pipeline"])      # ... or (--pregen-no-rule) nobody does
         if wl.get("install", True):               # ... and the finished arenas install their staged worlds inside the step
             cfg.regen_cap = E
     occ = world.make_maps(E, wl["size"], seed, env_index_base=base, indoor_ratio=wl.get("indoor_ratio", 0.0))
@@ -376,6 +376,9 @@ def main():
     ap.add_argument("--pregen-pipeline", type=int, default=0, metavar="P",
                     help="with --pregen: a staging pass every P steps, waited for two periods later (NavSim.enable_pregen(pipeline=P)); "
                          "sets cfg.regen_min_steps = 4 P -- episodes shorter than that restart on their old map")
+    ap.add_argument("--pregen-no-rule", action="store_true",
+                    help="with --pregen-pipeline: cfg.regen_min_steps = 0 -- every finished arena gets a new map, as without the pipeline; "
+                         "one that finishes before its world is staged is regenerated on the spot (navsim_regen after every step)")
     ap.add_argument("--pregen-swap-kernel", action="store_true",
                     help="with --pregen-pipeline: install the staged worlds with navsim_regen_swap after the step instead of inside it (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -460,8 +463,8 @@ def extras(args, device):
     #  of ordinary priority, the order stays)
     def workload_window(name):
         wl = dict(WORKLOADS[name.split("_")[0]]); wl["field"] = "u16t"; wl["indoor_ratio"] = 0.0
-        if name == "c5_pipelined":
-            wl.update(pregen=True, pipeline=4, install=True)
+        if name.startswith("c5_pipelined"):
+            wl.update(pregen=True, pipeline=4, install=True, no_rule=name.endswith("no_rule"))
         try:
             cfg, sim, arrays, _ = build_sim(wl, 0, wl["envs"], device=device)
             E = cfg.n_envs
@@ -538,8 +541,11 @@ def extras(args, device):
                 res["other_workloads"][name]["regen_counters"] = sim.counters()
                 res["other_workloads"][name]["regen_min_steps"] = int(cfg.regen_min_steps)
             if wl.get("pipeline"):
-                res["other_workloads"][name]["reset_path"] = ("staging passes every %d steps on a side stream, installed inside the step "
-                                                              "(navsim_step_install, slot tables); plain launches" % wl["pipeline"])
+                res["other_workloads"][name]["reset_path"] = (
+                    "staging passes every %d steps on a side stream, installed inside the step (navsim_step_install, slot tables); plain launches; %s"
+                    % (wl["pipeline"], "NO rule: whoever finishes before its world is staged is regenerated on the spot (the rollout of "
+                       "navsim_regen after every step, bit for bit)" if wl.get("no_rule") else
+                       "cfg.regen_min_steps = %d: shorter episodes restart on their old map" % int(cfg.regen_min_steps)))
             del sim, arrays
             torch.cuda.empty_cache()
         except Exception as exc:                              # an extra must not cost the run its line
@@ -616,16 +622,20 @@ def extras(args, device):
                           "pedestrians: build-defined social force ('policy' needs human_policy.pth, missing upstream)")
     except Exception as exc:
         res.setdefault("gym_api", {})["reference_defaults"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
-    # the round-5 reset path, last (see above): the reference-default world with the two kwargs that switch it on -- the worlds
-    # staged ahead, installed inside the step; an episode shorter than 16 steps restarts on its old map (counters: regen_short)
+    # the round-5 reset path, last (see above): the reference-default world with the ONE kwarg that switches it on -- the worlds
+    # staged ahead, installed inside the step, whoever finishes before its world is staged regenerated on the spot: the same
+    # rollout as sfm_1024, bit for bit -- and with the rule that drops that fallback (an episode shorter than 16 steps restarts on
+    # its old map: counters regen_short)
     try:
-        w = gym_window(1024, K=100, Wm=20, map_size="reference", randomize_maps=True, pedestrian_model="sfm",
-                       regen_min_steps=16, pregen_pipeline=4)
-        if isinstance(res.get("gym_api", {}).get("reference_defaults"), dict):
-            res["gym_api"]["reference_defaults"]["sfm_1024_pregen_pipeline_4"] = w
+        for key, kw in (("sfm_1024_pregen_pipeline_4", dict(pregen_pipeline=4)),
+                        ("sfm_1024_pregen_pipeline_4_min_steps_16", dict(pregen_pipeline=4, regen_min_steps=16))):
+            w = gym_window(1024, K=100, Wm=20, map_size="reference", randomize_maps=True, pedestrian_model="sfm", **kw)
+            if isinstance(res.get("gym_api", {}).get("reference_defaults"), dict):
+                res["gym_api"]["reference_defaults"][key] = w
     except Exception as exc:
         res.setdefault("gym_api", {})["pregen_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
     workload_window("c5_pipelined")
+    workload_window("c5_pipelined_no_rule")
     return res
 
 
@@ -648,6 +658,7 @@ def measure(args, scaling, ctx, light=False):
     wl["pregen"] = bool(args.pregen or args.pregen_pipeline)
     wl["pipeline"] = int(args.pregen_pipeline)
     wl["install"] = not args.pregen_swap_kernel
+    wl["no_rule"] = bool(args.pregen_no_rule)
     wl["defer_reset_scan"] = args.defer_reset_scan
     base, E_local = shard_of(wl, scaling, rank, world_size)
     E_total = wl["total"] if scaling == "strong" else world_size * wl["envs"]
