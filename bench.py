@@ -613,7 +613,9 @@ def extras(args, device):
     try:
         ref_def = {}
         for model, E in (("sfm", 1024), ("sfm", 4096)):
-            w = gym_window(E, K=100, Wm=20, map_size="reference", randomize_maps=True, pedestrian_model=model)
+            # (pregen_pipeline=0: navsim_regen after every step -- the form of rounds 3-5; the env's default for this world is
+            #  the pipelined reset path, same rollout, measured LAST below as sfm_*_pregen_pipeline_4)
+            w = gym_window(E, K=100, Wm=20, map_size="reference", randomize_maps=True, pedestrian_model=model, pregen_pipeline=0)
             ref_def["%s_%d" % (model, E)] = w
         res.setdefault("gym_api", {})["reference_defaults"] = dict(
             ref_def, what="gym.make('NavGym-v0', num_envs=E, map_size='reference', randomize_maps=True) and nothing else changed: the "
@@ -628,8 +630,9 @@ def extras(args, device):
     # its old map: counters regen_short)
     try:
         for key, kw in (("sfm_1024_pregen_pipeline_4", dict(pregen_pipeline=4)),
+                        ("sfm_4096_pregen_pipeline_4", dict(pregen_pipeline=4)),
                         ("sfm_1024_pregen_pipeline_4_min_steps_16", dict(pregen_pipeline=4, regen_min_steps=16))):
-            w = gym_window(1024, K=100, Wm=20, map_size="reference", randomize_maps=True, pedestrian_model="sfm", **kw)
+            w = gym_window(4096 if "4096" in key else 1024, K=100, Wm=20, map_size="reference", randomize_maps=True, pedestrian_model="sfm", **kw)
             if isinstance(res.get("gym_api", {}).get("reference_defaults"), dict):
                 res["gym_api"]["reference_defaults"][key] = w
     except Exception as exc:

@@ -24,7 +24,8 @@ and default to the reference's behaviour for num_envs == 1:
                     with the robot's wheel radius / track (robots.py; Husky: husky.urdf.xacro:61-67)
     clip_actions    True: the twist is clamped to linvel_range x rotvel_range on the device (the reference only prints
                     a warning and never clips, env.py:606-613: default False)
-    regen_min_steps, pregen_pipeline   (randomize_maps) pregen_pipeline = P > 0: the next world of every arena is staged ahead
+    regen_min_steps, pregen_pipeline   (randomize_maps) pregen_pipeline = P > 0 (default: 4 for worlds of corridor maps with
+                    planned starts, else 0): the next world of every arena is staged ahead
                     of time on a side stream (a pass every P steps) and installed inside the step's own launch.  With
                     regen_min_steps = 0 (default) the rollout is EXACTLY the one without the pipeline: an arena that finishes
                     before its world is staged is generated on the spot (counters()['regen_late']).  regen_min_steps >= 4 P
@@ -167,7 +168,7 @@ class NavGymEnv(_EnvBase):
                  num_humans=None, device="cuda:0", seed=0, env_index_base=0, auto_reset=None,
                  field_format=abi.FIELD_U16T, n_spawn=None, randomize_maps=False, plan_paths=True,
                  action_kind="twist", clip_actions=False, max_waypoints=64, march_rule=None, use_graphs=None,
-                 regen_min_steps=0, pregen_pipeline=0, pregen_stage_cap=None):
+                 regen_min_steps=0, pregen_pipeline=None, pregen_stage_cap=None):
         from . import lib
         if robot_type not in robots.ROBOTS:
             raise NotImplementedError(robot_type)            # env.py:772-773
@@ -226,6 +227,12 @@ class NavGymEnv(_EnvBase):
         # passes on a side stream, one every P steps, and a finished arena takes it inside the step's own launch
         # (navsim_step_install) -- navsim_regen leaves the step's critical path.  It rests on regen_min_steps >= 4 P: an
         # episode that ended after fewer steps restarts on its OLD map (the reference draws a map at every reset: opt-in).
+        # None (default): 4 for worlds whose reset is heavy -- corridor maps with planned starts, the reference's own kind -- when
+        # the pipeline is available (packed field, i.e. map_size <= 1024; not with pedestrian_model='policy'); else 0.  With
+        # regen_min_steps = 0 it changes no result: the rollout is the one of pregen_pipeline=0, bit for bit.
+        if pregen_pipeline is None:
+            pregen_pipeline = 4 if (bool(plan_paths) and float(indoor_ratio) > 0.0 and pedestrian_model != "policy" and
+                                    field_format == abi.FIELD_U16T and (map_size == "reference" or int(map_size) <= 1000)) else 0
         self.pregen_pipeline = int(pregen_pipeline) if (self.randomize_maps and self.auto_reset) else 0
         self.regen_min_steps = int(regen_min_steps)
         self.pregen_stage_cap = pregen_stage_cap        # arenas one staging pass serves at most (None: NavSim.enable_pregen's default)

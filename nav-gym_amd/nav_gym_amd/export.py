@@ -27,12 +27,14 @@ def reset_map_fields(env, arena=0):
     import torch
     cfg = env.cfg
     f = env.sim.t["field"]
+    if "map_slot" in env.sim.t:                               # the arena's map may lie in another slot (pipelined reset path)
+        arena = int(env.sim.t["map_slot"][arena].item())
     if f.dtype == torch.float32 and f.dim() == 3:
         occ = (f[arena] == 0)
     else:                                                     # packed field: zero squared distance = occupied
         from . import abi
         tpr = (cfg.map_w + 7) // 8
-        raw = f.view(torch.int16).reshape(cfg.n_envs, (cfg.map_h + 7) // 8, tpr, 8, 8)[arena]
+        raw = f.view(torch.int16).reshape(-1, (cfg.map_h + 7) // 8, tpr, 8, 8)[arena]
         occ = (raw.permute(0, 2, 1, 3).reshape(-1, tpr * 8)[: cfg.map_h, : cfg.map_w] == 0)
     data = (occ.to(torch.int8) * 100).cpu().numpy()
     return {"data": data, "resolution": cfg.resolution, "width": cfg.map_h, "height": cfg.map_w,

@@ -803,6 +803,8 @@ class NavSim(object):
         """uint8 [H, W] occupancy grid (1 = occupied) of arena e, read back from its distance field
         (a cell is occupied exactly when its distance is 0)."""
         H, W = self.cfg.map_h, self.cfg.map_w
+        if "map_slot" in self.t:                        # where the arena's map lies (enable_pregen(install=True, map_slots=True))
+            e = int(self.t["map_slot"][e].item())
         if self.cfg.field_format == abi.FIELD_F32:
             return (self.t["field"][e] == 0).to(_dtype("uint8")).cpu().numpy()
         tpr, tpc = (W + 7) // 8, (H + 7) // 8

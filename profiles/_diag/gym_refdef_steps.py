@@ -6,7 +6,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "nav-gym_amd"))
 import torch, nav_gym_env
 E = int(os.environ.get("NAVSIM_ENVS", "1024"))
-kw = {}
+kw = {"pregen_pipeline": 0}                    # (the env's default for this world is 4: NAVSIM_PIPELINE chooses)
 if os.environ.get("NAVSIM_GRAPHS"):
     kw["use_graphs"] = os.environ["NAVSIM_GRAPHS"] == "1"
 if os.environ.get("NAVSIM_PIPELINE"):          # pipelined pre-generation: regen_min_steps = 4 P

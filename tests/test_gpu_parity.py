@@ -829,14 +829,14 @@ def test_reference_default_configuration_sampled_oracle(gpu, pipeline):
     import nav_gym_env
     torch = gpu.torch
     E = 1024
-    kw = dict(regen_min_steps=8, pregen_pipeline=2) if pipeline == 2 else {}
-    norule = pipeline == "norule"       # the pipeline WITHOUT a rule: whoever finishes before its world is staged is generated on the spot
-    if norule:
-        kw, pipeline = dict(pregen_pipeline=2), 2
+    kw = dict(regen_min_steps=8, pregen_pipeline=2) if pipeline == 2 else dict(pregen_pipeline=0)
+    norule = pipeline == "norule"       # the env's DEFAULT for this world: the pipeline without a rule -- whoever finishes before
+    if norule:                          # its world is staged is generated on the spot
+        kw, pipeline = {}, 4
     if pipeline == "graphs":                                 # (the default is plain launches since navsim_regen forks: the captured form too)
-        kw, pipeline = dict(use_graphs=True), 0
+        kw, pipeline = dict(use_graphs=True, pregen_pipeline=0), 0
     env = nav_gym_env.make("NavGym-v0", num_envs=E, map_size="reference", randomize_maps=True, seed=41, device=gpu.dev, **kw)
-    assert env.use_graphs == bool(kw.get("use_graphs", False))
+    assert env.use_graphs == bool(kw.get("use_graphs", False)) and env.pregen_pipeline == pipeline
     assert env.cfg.n_beams == 512 and env.cfg.map_h == 1000 and env.cfg.outdoor_map_size == 400 and env.plan_paths
     assert env.cfg.regen_indoor_ratio == 0.5 and (env.cfg.num_humans_lo, env.cfg.num_humans_hi) == (5, 15)
     obs = env.reset()
