@@ -577,6 +577,7 @@ def extras(args, device):
         t0 = time.perf_counter()
         for t in range(K):
             obs, rew, done, info = env.step(acts[Wm + t])
+        host = time.perf_counter() - t0            # the loop returns before the GPU has finished: what the host needs per step
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         counters = env.counters()
@@ -584,7 +585,7 @@ def extras(args, device):
         env.close()
         del env
         torch.cuda.empty_cache()
-        return {"value": E * K / el, "ms_per_step": el / K * 1e3, "envs": E, "steps": K, "reset_first_ms": first * 1e3,
+        return {"value": E * K / el, "ms_per_step": el / K * 1e3, "host_ms_per_step": host / K * 1e3, "envs": E, "steps": K, "reset_first_ms": first * 1e3,
                 "reset_steady_ms": steady * 1e3, "episodes_started": episodes, "counters": counters}
     try:
         sys.path.insert(0, os.path.join(ROOT, "nav-gym_amd"))

@@ -335,6 +335,44 @@ def debug_math(fn, x, x2=None):
     return out
 
 
+def concurrent_stream(device, priority=0, tries=8):
+    """A stream whose kernels really run BESIDE those of the current stream.  HIP spreads a process's streams over a handful of
+    hardware queues (four by default) in creation order; two streams that land on the same queue take turns, whatever the
+    events between them say -- a process that has created a few streams before (torch hands its pool out round-robin) got a
+    staging stream on the main stream's queue one time in four, and the pipelined reset path then ran at 1.6 M env-steps/s
+    instead of 2.4 M (profiles/_diag/bench_bisect.py).  So: try a few candidates, time two ~50 us spin kernels queued on the two
+    streams at once, and keep the first candidate on which they overlap (else the best seen)."""
+    import torch
+    main = torch.cuda.current_stream(device)
+    best, best_ms = None, None
+    spin = 100_000
+    for _ in range(tries):
+        cand = torch.cuda.Stream(device=device, priority=priority)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ms = []
+        for rep in range(2):                                    # (the first round also warms the spin kernel up)
+            torch.cuda.synchronize(device)
+            e0.record(main)
+            cand.wait_event(e0)
+            with torch.cuda.stream(cand):
+                torch.cuda._sleep(spin)
+            torch.cuda._sleep(spin)
+            main.wait_stream(cand)
+            e1.record(main)
+            torch.cuda.synchronize(device)
+            ms.append(e0.elapsed_time(e1))
+        with torch.cuda.stream(cand):                           # one spin alone: what "beside" is measured against
+            torch.cuda.synchronize(device)
+            e0.record(cand); torch.cuda._sleep(spin); e1.record(cand)
+            torch.cuda.synchronize(device)
+        alone = e0.elapsed_time(e1)
+        if best_ms is None or ms[1] < best_ms:
+            best, best_ms = cand, ms[1]
+        if ms[1] < 1.5 * alone:
+            return cand
+    return best
+
+
 class NavSim(object):
     """E arenas resident on one GPU.  `arrays` maps navsim_state field names to numpy arrays or
     torch tensors (host or device); missing optional fields stay NULL."""
@@ -616,7 +654,7 @@ class NavSim(object):
         # of slack -- and a process that has used a high-priority stream replays hipGraphs ~10 us per kernel slower from then
         # on: a reference-default environment built afterwards ran at 0.59 M env-steps/s instead of 0.87 M,
         # profiles/_diag/after_pregen.py.)
-        self.side = torch.cuda.Stream(device=self.device, priority=0 if P else -1)
+        self.side = concurrent_stream(self.device, priority=0 if P else -1)
         self.ev_swapped, self.ev_staged = torch.cuda.Event(), torch.cuda.Event()
         self.ev_staged.record(torch.cuda.current_stream())
         self.pg_swapped = [torch.cuda.Event() for _ in range(3)]      # pass j uses slot j % 3; step j P waits for pass j - 2
@@ -857,7 +895,7 @@ class NavSim(object):
     def _overlap_streams(self):
         import torch
         if not hasattr(self, "_side"):
-            self._side = torch.cuda.Stream(device=self.device, priority=-1 if self.overlap_big_first else 0)
+            self._side = concurrent_stream(self.device, priority=-1 if self.overlap_big_first else 0)
         return torch.cuda.current_stream(self.device), self._side
 
     def launch_step_overlapped(self, replan_cap=1024, reorder=True):

@@ -30,8 +30,10 @@ e0 = int(env.sim.t["episode"].sum().item())
 t0 = time.perf_counter()
 for t in range(K):
     env.step(acts[Wm + t])
+host = time.perf_counter() - t0
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
+print("host enqueue %.1f us per step, wall %.1f" % (host / K * 1e6, el / K * 1e6))
 e1 = int(env.sim.t["episode"].sum().item())
 print("gym API, reference defaults, %d arenas: %.3f M env-steps/s, %.4f ms per step, %.1f episodes ended per step; counters %s"
       % (E, E * K / el / 1e6, el / K * 1e3, (e1 - e0) / K, env.counters()))
