@@ -581,6 +581,14 @@ int    navsim_regen_stage(const navsim_config* cfg, const navsim_state* stage, c
 int    navsim_step_install(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                            const navsim_state* stage, const float* stage_obs, uint8_t* mark, const long long* ready,
                            uint8_t* late, void* stream);
+/* navsim_regen's helper stream.  Worlds of corridor maps with planned starts (cfg.regen_indoor_ratio > 0, cfg.regen_plan): the
+ * distance transform of the new maps runs on a second stream between two events on `stream` (inside a hipGraph capture of
+ * `stream` it joins and leaves the capture through them); environment NAVSIM_REGEN_FORK=0 keeps the call on `stream` alone.
+ * navsim_regen_helper(s): the calling host thread's helper stream from now on (NULL / never called: one of the library's own,
+ * created by navsim_prepare or the first such call).  Why a caller would choose: HIP spreads a process's streams over a few
+ * hardware queues in creation order, and two streams on the same queue take turns -- NavSim times candidates against the
+ * streams the helper is to run beside (nav_gym_amd/sim.py concurrent_stream). */
+int    navsim_regen_helper(void* stream);
 int    navsim_regen(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                     void* workspace, size_t workspace_bytes, void* stream);
 

@@ -538,13 +538,16 @@ namespace {
 // occupancy grid and the costmap only).  One helper stream and two events per host thread and device, created on first use;
 // inside a hipGraph capture the helper joins the capture through the first wait and leaves it through the second.
 struct RegenFork { int device = -1; hipStream_t side = nullptr; hipEvent_t forked = nullptr, joined = nullptr; };
+thread_local hipStream_t g_regen_helper = nullptr;          // navsim_regen_helper: the caller's choice of helper stream
 RegenFork* regen_fork() {
     thread_local RegenFork f;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (f.device == dev && g_regen_helper && f.side != g_regen_helper) f.side = g_regen_helper;     // (the events stay)
     if (f.device != dev) {
         RegenFork n;
-        if (hipStreamCreateWithFlags(&n.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (g_regen_helper) n.side = g_regen_helper;
+        else if (hipStreamCreateWithFlags(&n.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&n.forked, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&n.joined, hipEventDisableTiming) != hipSuccess) return nullptr;
         n.device = dev;
@@ -554,6 +557,11 @@ RegenFork* regen_fork() {
 }
 }  // namespace
 }  // extern "C++"
+
+int navsim_regen_helper(void* stream) {
+    g_regen_helper = (hipStream_t)stream;
+    return NAVSIM_OK;
+}
 
 int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, void* workspace,
                  size_t workspace_bytes, void* stream) {

@@ -335,7 +335,7 @@ def debug_math(fn, x, x2=None):
     return out
 
 
-def concurrent_stream(device, priority=0, tries=8):
+def concurrent_stream(device, priority=0, tries=8, beside=None):
     """A stream whose kernels really run BESIDE those of the current stream.  HIP spreads a process's streams over a handful of
     hardware queues (four by default) in creation order; two streams that land on the same queue take turns, whatever the
     events between them say -- a process that has created a few streams before (torch hands its pool out round-robin) got a
@@ -343,32 +343,35 @@ def concurrent_stream(device, priority=0, tries=8):
     instead of 2.4 M (profiles/_diag/bench_bisect.py).  So: try a few candidates, time two ~50 us spin kernels queued on the two
     streams at once, and keep the first candidate on which they overlap (else the best seen)."""
     import torch
-    main = torch.cuda.current_stream(device)
-    best, best_ms = None, None
+    others = list(beside) if beside else [torch.cuda.current_stream(device)]     # beside: the streams it must not share a queue with
+    best, best_ratio = None, None
     spin = 100_000
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(tries):
         cand = torch.cuda.Stream(device=device, priority=priority)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ms = []
-        for rep in range(2):                                    # (the first round also warms the spin kernel up)
-            torch.cuda.synchronize(device)
-            e0.record(main)
-            cand.wait_event(e0)
-            with torch.cuda.stream(cand):
-                torch.cuda._sleep(spin)
-            torch.cuda._sleep(spin)
-            main.wait_stream(cand)
-            e1.record(main)
-            torch.cuda.synchronize(device)
-            ms.append(e0.elapsed_time(e1))
-        with torch.cuda.stream(cand):                           # one spin alone: what "beside" is measured against
-            torch.cuda.synchronize(device)
-            e0.record(cand); torch.cuda._sleep(spin); e1.record(cand)
-            torch.cuda.synchronize(device)
+        with torch.cuda.stream(cand):                           # one spin alone: what "beside" is measured against (twice: warm-up)
+            for rep in range(2):
+                torch.cuda.synchronize(device)
+                e0.record(cand); torch.cuda._sleep(spin); e1.record(cand)
+                torch.cuda.synchronize(device)
         alone = e0.elapsed_time(e1)
-        if best_ms is None or ms[1] < best_ms:
-            best, best_ms = cand, ms[1]
-        if ms[1] < 1.5 * alone:
+        worst = 0.0
+        for other in others:
+            for rep in range(2):
+                torch.cuda.synchronize(device)
+                e0.record(other)
+                cand.wait_event(e0)
+                with torch.cuda.stream(cand):
+                    torch.cuda._sleep(spin)
+                with torch.cuda.stream(other):
+                    torch.cuda._sleep(spin)
+                other.wait_stream(cand)
+                e1.record(other)
+                torch.cuda.synchronize(device)
+            worst = max(worst, e0.elapsed_time(e1) / max(alone, 1e-6))
+        if best_ratio is None or worst < best_ratio:
+            best, best_ratio = cand, worst
+        if worst < 1.5:
             return cand
     return best
 
@@ -655,6 +658,11 @@ class NavSim(object):
         # on: a reference-default environment built afterwards ran at 0.59 M env-steps/s instead of 0.87 M,
         # profiles/_diag/after_pregen.py.)
         self.side = concurrent_stream(self.device, priority=0 if P else -1)
+        # navsim_regen's helper stream (the distance transform of new corridor maps beside the searches): beside the steps AND
+        # beside the passes -- three streams, three hardware queues
+        if self.cfg.regen_plan and self.cfg.regen_indoor_ratio > 0.0:
+            self._regen_helper = concurrent_stream(self.device, beside=[torch.cuda.current_stream(self.device), self.side])
+            check(self.lib.navsim_regen_helper(C.c_void_p(self._regen_helper.cuda_stream)), "navsim_regen_helper")
         self.ev_swapped, self.ev_staged = torch.cuda.Event(), torch.cuda.Event()
         self.ev_staged.record(torch.cuda.current_stream())
         self.pg_swapped = [torch.cuda.Event() for _ in range(3)]      # pass j uses slot j % 3; step j P waits for pass j - 2
@@ -778,11 +786,19 @@ class NavSim(object):
               "navsim_regen_stage")
         staged.record(self.side)
 
+    def _choose_regen_helper(self):
+        """navsim_regen's helper stream for worlds whose reset forks (include/navsim.h navsim_regen_helper): one that really runs
+        beside the current stream, chosen once (before any hipGraph capture of the call)."""
+        if getattr(self, "_regen_helper", None) is None and self.cfg.regen_plan and self.cfg.regen_indoor_ratio > 0.0:
+            self._regen_helper = concurrent_stream(self.device)
+            check(self.lib.navsim_regen_helper(C.c_void_p(self._regen_helper.cuda_stream)), "navsim_regen_helper")
+
     def regen(self):
         """navsim_regen right after step(): finished arenas get a new map, tables, pedestrians, first obs."""
         import torch
         if getattr(self, "pregen", False):
             return self._regen_pregen()
+        self._choose_regen_helper()
         if "regen_ws" not in self.t:
             nbytes = self.lib.navsim_regen_workspace_bytes(C.byref(self.cfg))
             self.t["regen_ws"] = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
@@ -805,6 +821,7 @@ class NavSim(object):
         import torch
         E = self.cfg.n_envs
         self._latest_flags()
+        self._choose_regen_helper()
         if new_episode:
             self.t["episode"] += 1
         cfg = self.cfg.copy()
@@ -1055,6 +1072,8 @@ class NavSim(object):
         import torch
         if getattr(self, "pregen", False):
             raise ValueError("enable_graphs and enable_pregen are alternatives")
+        if regen:
+            self._choose_regen_helper()                   # (timed with host synchronisation: before the capture)
         io = abi.NavsimStepIO()
         C.memmove(C.byref(io), C.byref(self.io), C.sizeof(io))
         io.obs = self.obs_buf[self.cur].data_ptr()
