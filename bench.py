@@ -622,7 +622,10 @@ def extras(args, device):
             ref_def, what="gym.make('NavGym-v0', num_envs=E, map_size='reference', randomize_maps=True) and nothing else changed: the "
                           "registered kwargs of __init__.py:4-40 (indoor_ratio 0.5, 5-15 pedestrians, planned routes, scan noise), "
                           "KetiRobot's 512-beam lidar, 1000 x 1000 arenas (corridor maps fill them, outdoor maps use 400 x 400); "
-                          "pedestrians: build-defined social force ('policy' needs human_policy.pth, missing upstream)")
+                          "pedestrians: build-defined social force ('policy' needs human_policy.pth, missing upstream).  "
+                          "sfm_E: with pregen_pipeline=0 (navsim_regen after every step); sfm_E_pregen_pipeline_4: the env's own default "
+                          "for this world -- worlds staged ahead on a side stream, installed inside the step, no rule: the same rollout "
+                          "bit for bit; ..._min_steps_16: with the rule that drops the fallback (shorter episodes keep their map)")
     except Exception as exc:
         res.setdefault("gym_api", {})["reference_defaults"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
     # the round-5 reset path, last (see above): the reference-default world with the ONE kwarg that switches it on -- the worlds
