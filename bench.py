@@ -623,9 +623,10 @@ def extras(args, device):
                           "registered kwargs of __init__.py:4-40 (indoor_ratio 0.5, 5-15 pedestrians, planned routes, scan noise), "
                           "KetiRobot's 512-beam lidar, 1000 x 1000 arenas (corridor maps fill them, outdoor maps use 400 x 400); "
                           "pedestrians: build-defined social force ('policy' needs human_policy.pth, missing upstream).  "
-                          "sfm_E: with pregen_pipeline=0 (navsim_regen after every step); sfm_E_pregen_pipeline_4: the env's own default "
-                          "for this world -- worlds staged ahead on a side stream, installed inside the step, no rule: the same rollout "
-                          "bit for bit; ..._min_steps_16: with the rule that drops the fallback (shorter episodes keep their map)")
+                          "sfm_E: with pregen_pipeline=0 (navsim_regen after every step); sfm_1024_env_default: NO kwarg beyond map_size and "
+                          "randomize_maps -- the env's own default for this world is pregen_pipeline=8: worlds staged ahead on a side stream, "
+                          "installed inside the step, no rule: the same rollout bit for bit; sfm_E_pregen_pipeline_4: a pass every 4 steps; "
+                          "..._min_steps_16: with the rule that drops the fallback (shorter episodes keep their map)")
     except Exception as exc:
         res.setdefault("gym_api", {})["reference_defaults"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
     # the round-5 reset path, last (see above): the reference-default world with the ONE kwarg that switches it on -- the worlds
@@ -633,7 +634,8 @@ def extras(args, device):
     # rollout as sfm_1024, bit for bit -- and with the rule that drops that fallback (an episode shorter than 16 steps restarts on
     # its old map: counters regen_short)
     try:
-        for key, kw in (("sfm_1024_pregen_pipeline_4", dict(pregen_pipeline=4)),
+        for key, kw in (("sfm_1024_env_default", dict()),          # nothing but map_size and randomize_maps: the env picks pregen_pipeline = 8
+                        ("sfm_1024_pregen_pipeline_4", dict(pregen_pipeline=4)),
                         ("sfm_4096_pregen_pipeline_4", dict(pregen_pipeline=4)),
                         ("sfm_1024_pregen_pipeline_4_min_steps_16", dict(pregen_pipeline=4, regen_min_steps=16))):
             w = gym_window(4096 if "4096" in key else 1024, K=100, Wm=20, map_size="reference", randomize_maps=True, pedestrian_model="sfm", **kw)

@@ -46,7 +46,7 @@ print("%d arenas: %.2f M env-steps/s, %d episodes finished, observation %s on %s
 
 # ---- the reference's own world, batched: every registered default, a new map at every episode end ----------
 # (512 beams, 1000 x 1000 corridor / 400 x 400 outdoor maps, 5-15 pedestrians on planned routes).  For such worlds the
-# env stages every arena's next world ahead of time on a side stream (pregen_pipeline=4 by default: the same rollout
+# env stages every arena's next world ahead of time on a side stream (pregen_pipeline=8 by default: the same rollout
 # as pregen_pipeline=0, bit for bit, about 2.4 x the throughput); env.counters() says how many arenas were served.
 E = 1024
 renv = nav_gym_env.make("NavGym-v0", num_envs=E, map_size="reference", randomize_maps=True)
