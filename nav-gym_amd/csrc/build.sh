@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds the gfx950 shared library in-tree (nav-gym_amd/nav_gym_amd/libnavsim_hip.so): `make` over csrc/Makefile, one job
-# per core (nine objects; 2 min 17 s from scratch on 8 cores, the pedestrian families being the long ones -- as one translation
+# per core (nine objects; 2 min 53 s from scratch on 8 cores, the pedestrian families being the long ones -- as one translation
 # unit the library of round 4 took 4 min 12 s -- and a minute or less after an edit that leaves some objects alone).  hipcc cross-compiles without a GPU.
 # NAVSIM_OUT / NAVSIM_OBJ redirect the library / the objects (diagnostic A/B builds keep their own object directory),
 # NAVSIM_EXTRA_FLAGS adds compiler flags.
