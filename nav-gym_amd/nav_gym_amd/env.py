@@ -612,6 +612,8 @@ class NavGymEnv(_EnvBase):
         return terms
 
     def close(self):
+        if self.sim is not None:
+            self.sim.close()                        # (staging passes in flight on a side stream: wait before the arrays go)
         self.sim = None
 
     # ---- EzPickle (env.py:30, 56-78): a pickle carries the constructor's arguments, the copy is built from them -----------

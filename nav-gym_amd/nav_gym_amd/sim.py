@@ -786,6 +786,23 @@ class NavSim(object):
               "navsim_regen_stage")
         staged.record(self.side)
 
+    def close(self):
+        """Waits for what this simulator has in flight on streams of its own (staging passes, the overlapped re-plan): their
+        kernels write into arrays that are about to be released."""
+        for name in ("side", "_side", "_scan_stream", "_regen_helper"):
+            st = getattr(self, name, None)
+            if st is not None:
+                try:
+                    st.synchronize()
+                except Exception:
+                    pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def _choose_regen_helper(self):
         """navsim_regen's helper stream for worlds whose reset forks (include/navsim.h navsim_regen_helper): one that really runs
         beside the current stream, chosen once (before any hipGraph capture of the call)."""
