@@ -634,7 +634,13 @@ class NavGymEnv(_EnvBase):
             raise RuntimeError("call reset() before state_dict()")
         import torch
         torch.cuda.synchronize(self.sim.device)
-        sd = {"t." + k: v.detach().cpu().clone() for k, v in self.sim.t.items() if not k.startswith(("replan_ws", "regen_ws", "policy_ws"))}
+        # (a world with slot tables -- the pipelined reset path -- holds 2 E map slots, E of them staged worlds that are not part
+        #  of the snapshot: the arenas' maps are saved in arena order, the table itself is not)
+        sd = {}
+        for k in self.sim.t:
+            if k.startswith(("replan_ws", "regen_ws", "policy_ws")) or k == "map_slot":
+                continue
+            sd["t." + k] = self.sim.by_arena(k).detach().cpu().clone()
         for i in (0, 1):
             sd["obs.%d" % i] = self.sim.obs_buf[i].cpu().clone()
             for k, v in self.sim.out_buf[i].items():
@@ -651,9 +657,16 @@ class NavGymEnv(_EnvBase):
             raise RuntimeError("call reset() once before load_state_dict() (it allocates the device arrays)")
         import torch
         torch.cuda.synchronize(self.sim.device)
+        slots = self.sim.t.get("map_slot")
+        if slots is not None:                              # the snapshot's maps go to the slots 0 .. E - 1, in arena order
+            slots.copy_(torch.arange(self.num_envs, dtype=slots.dtype, device=slots.device))
         for k, v in sd.items():
             if k.startswith("t."):
-                self.sim.t[k[2:]].copy_(v)
+                dst = self.sim.t[k[2:]]
+                if slots is not None and k[2:] in self.sim.MAPS:     # (2 E slots; a packed field is one flat blob)
+                    dst.reshape(2 * self.num_envs, -1)[: self.num_envs].copy_(v.reshape(self.num_envs, -1))
+                else:
+                    dst.copy_(v)
         for i in (0, 1):
             self.sim.obs_buf[i].copy_(sd["obs.%d" % i])
             for k, v in self.sim.out_buf[i].items():

@@ -1157,11 +1157,20 @@ class NavSim(object):
             a = torch.as_tensor(np.asarray(a))
         return a.to(device=self.device, dtype=like.dtype).reshape(like.shape)
 
+    def by_arena(self, name):
+        """t[name] with one entry per arena: the per-map arrays of a world with slot tables (2 E slots, a packed field being one
+        flat blob) gathered through t['map_slot']; every other array as it is."""
+        v = self.t[name]
+        slots = self.t.get("map_slot")
+        if slots is None or name not in self.MAPS:
+            return v
+        n_slots = 2 * self.cfg.n_envs
+        rows = v.reshape(n_slots, -1)[slots.long()]
+        return rows.reshape(-1) if v.dim() == 1 else rows.reshape((self.cfg.n_envs,) + tuple(v.shape[1:]))
+
     def numpy_state(self, *names):
         """State arrays on the host.  "ped_due": the latest step's "waits for navsim_replan" flags (they flip, so not in t)."""
-        slots = self.t.get("map_slot")                      # the per-map arrays by arena, wherever the maps lie
-        out = {n: (self.t[n][slots.long()] if slots is not None and n in self.MAPS else self.t[n]).detach().cpu().numpy()
-               for n in (names or self.t.keys()) if n != "ped_due"}
+        out = {n: self.by_arena(n).detach().cpu().numpy() for n in (names or self.t.keys()) if n != "ped_due"}
         if self.due is not None and (not names or "ped_due" in names):
             out["ped_due"] = self.due[self.cur].detach().cpu().numpy()
         return out
