@@ -477,7 +477,9 @@ def extras(args, device):
             regen = bool(wl.get("regen"))
             # one HIP event pair per step launch only where other kernels run between the steps (c5's navsim_regen): a pair per
             # step costs a few per cent of a 60 us step; elsewhere ONE pair brackets the K launches
-            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K if regen else 1)]
+            # (the pipelined reset path: its step launch is the whole step -- one pair around the K steps, like the one-kernel workloads)
+            per_step = regen and not wl.get("pipeline")
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K if per_step else 1)]
 
             def one(t, e=None):
                 sim.io.action = acts[t].data_ptr()
@@ -493,11 +495,11 @@ def extras(args, device):
                 one(t)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            if not regen:
+            if not per_step:
                 ev[0][0].record()
             for t in range(K):
-                one(Wm + t, ev[t] if regen else None)
-            if not regen:
+                one(Wm + t, ev[t] if per_step else None)
+            if not per_step:
                 ev[0][1].record()
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
@@ -535,7 +537,7 @@ def extras(args, device):
                 "value_plain_launches": E * K / plain,
                 "workload": "%d arenas x %d beams, %dx%d maps, %d pedestrians, %s%s" % (
                     E, cfg.n_beams, cfg.map_h, cfg.map_w, wl["peds"], wl.get("robot", "keti"), ", new map per episode" if regen else ""),
-                "kernel_ms_from": ("one HIP event pair per step launch (the step kernel alone; ms_per_step also holds navsim_regen)" if regen else
+                "kernel_ms_from": ("one HIP event pair per step launch (the step kernel alone; ms_per_step also holds navsim_regen)" if per_step else
                                    "one HIP event pair around the %d launches / %d (includes the gaps between launches)" % (K, K))}
             if regen:
                 res["other_workloads"][name]["regen_counters"] = sim.counters()
