@@ -343,6 +343,8 @@ def concurrent_stream(device, priority=0, tries=8, beside=None):
     instead of 2.4 M (profiles/_diag/bench_bisect.py).  So: try a few candidates, time two ~50 us spin kernels queued on the two
     streams at once, and keep the first candidate on which they overlap (else the best seen)."""
     import torch
+    if not hasattr(torch.cuda, "_sleep"):                       # (no spin kernel to time with: any stream)
+        return torch.cuda.Stream(device=device, priority=priority)
     others = list(beside) if beside else [torch.cuda.current_stream(device)]     # beside: the streams it must not share a queue with
     best, best_ratio = None, None
     spin = 100_000
