@@ -25,7 +25,7 @@ and default to the reference's behaviour for num_envs == 1:
     clip_actions    True: the twist is clamped to linvel_range x rotvel_range on the device (the reference only prints
                     a warning and never clips, env.py:606-613: default False)
     regen_min_steps, pregen_pipeline   (randomize_maps) pregen_pipeline = P > 0 (default: 8 for worlds of corridor maps with
-                    planned starts, else 0): the next world of every arena is staged ahead
+                    planned starts, else 4; 0 where the pipeline is not available): the next world of every arena is staged ahead
                     of time on a side stream (a pass every P steps) and installed inside the step's own launch.  With
                     regen_min_steps = 0 (default) the rollout is EXACTLY the one without the pipeline: an arena that finishes
                     before its world is staged is generated on the spot (counters()['regen_late']).  regen_min_steps >= 4 P
@@ -227,14 +227,19 @@ class NavGymEnv(_EnvBase):
         # passes on a side stream, one every P steps, and a finished arena takes it inside the step's own launch
         # (navsim_step_install) -- navsim_regen leaves the step's critical path.  It rests on regen_min_steps >= 4 P: an
         # episode that ended after fewer steps restarts on its OLD map (the reference draws a map at every reset: opt-in).
-        # None (default): 8 for worlds whose reset is heavy -- corridor maps with planned starts, the reference's own kind -- when
-        # the pipeline is available (packed field, i.e. map_size <= 1024; not with pedestrian_model='policy'); else 0.  With
-        # regen_min_steps = 0 it changes no result: the rollout is the one of pregen_pipeline=0, bit for bit.
+        # None (default): the pipelined reset path wherever it is available (packed field, i.e. map_size <= 1024; not with
+        # pedestrian_model='policy') -- a pass every 8 steps for worlds whose reset is heavy (corridor maps with planned starts,
+        # the reference's own kind: 64 to 4096 arenas run as fast or faster than with 4, profiles/r05_refdef/pipeline_sweep.txt),
+        # every 4 steps otherwise (a c5-shaped world through this API: 5.4 -> 7.4 M env-steps/s, with planned routes 1.3 -> 3.0 M,
+        # profiles/_diag/gym_c5_steps.py).  With regen_min_steps = 0 it changes no result: the rollout is the one of
+        # pregen_pipeline=0, bit for bit.
         if pregen_pipeline is None:
-            # (a pass every 8 steps: 64 to 4096 arenas of the reference's configuration run as fast or faster than with 4,
-            #  profiles/r05_refdef/pipeline_sweep.txt)
-            pregen_pipeline = 8 if (bool(plan_paths) and float(indoor_ratio) > 0.0 and pedestrian_model != "policy" and
-                                    field_format == abi.FIELD_U16T and (map_size == "reference" or int(map_size) <= 1000)) else 0
+            available = (pedestrian_model != "policy" and field_format == abi.FIELD_U16T and
+                         (map_size == "reference" or int(map_size) <= 1024))
+            heavy = bool(plan_paths) and float(indoor_ratio) > 0.0 and (map_size == "reference" or int(map_size) <= 1000)
+            pregen_pipeline = (8 if heavy else 4) if available else 0
+            if use_graphs:                         # (asked for: the graph replay of step + navsim_regen is the other form)
+                pregen_pipeline = 0
         self.pregen_pipeline = int(pregen_pipeline) if (self.randomize_maps and self.auto_reset) else 0
         self.regen_min_steps = int(regen_min_steps)
         self.pregen_stage_cap = pregen_stage_cap        # arenas one staging pass serves at most (None: NavSim.enable_pregen's default)

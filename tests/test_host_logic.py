@@ -196,8 +196,8 @@ def test_env_fallbacks_are_announced_once():
 
 
 def test_env_picks_the_pipelined_reset_path_where_it_pays():
-    """NavGymEnv(pregen_pipeline=None): 8 for worlds whose reset is heavy -- corridor maps with planned starts and a new map per
-    episode, the reference's own kind -- when the pipeline is available; 0 otherwise; an explicit value wins.  With
+    """NavGymEnv(pregen_pipeline=None), worlds with a new map per episode: 8 where the reset is heavy -- corridor maps with planned
+    starts, the reference's own kind --, 4 otherwise, 0 where the pipeline is not available; an explicit value wins.  With
     regen_min_steps = 0 (default) the pipeline changes no result, so the choice is one of speed only."""
     import pickle
     import nav_gym_env
@@ -208,13 +208,15 @@ def test_env_picks_the_pipelined_reset_path_where_it_pays():
     assert e.cfg.regen_cap == 8 and e.cfg.defer_reset_scan == 0 and e.use_graphs is False       # every arena decides alone
     assert pickle.loads(pickle.dumps(e)).pregen_pipeline == 8
     assert mk(num_envs=8, map_size="reference", randomize_maps=True, pregen_pipeline=0).pregen_pipeline == 0
+    g = mk(num_envs=8, map_size=500, randomize_maps=True, indoor_ratio=0.0, use_graphs=True)       # graph replay asked for: the other form
+    assert g.pregen_pipeline == 0 and g.use_graphs is True
     assert mk(num_envs=8, map_size="reference", randomize_maps=True, pregen_pipeline=2, regen_min_steps=8).cfg.regen_min_steps == 8
     assert mk(num_envs=8, map_size="reference").pregen_pipeline == 0                              # maps stay: nothing to stage
     assert mk(num_envs=1, map_size="reference", randomize_maps=True).pregen_pipeline == 0         # one arena: reset() is the user's
-    assert mk(num_envs=8, map_size=500, randomize_maps=True, indoor_ratio=0.0).pregen_pipeline == 0   # outdoor maps: a light reset
-    assert mk(num_envs=8, map_size=500, randomize_maps=True, plan_paths=False).pregen_pipeline == 0
+    assert mk(num_envs=8, map_size=500, randomize_maps=True, indoor_ratio=0.0).pregen_pipeline == 4   # outdoor maps: a lighter reset
+    assert mk(num_envs=8, map_size=500, randomize_maps=True, plan_paths=False).pregen_pipeline == 4
     assert mk(num_envs=8, map_size=1100, randomize_maps=True).pregen_pipeline == 0                # float32 field: no pipeline
-    assert mk(num_envs=8, map_size=500, randomize_maps=True, indoor_ratio=0.0, pregen_pipeline=4).pregen_pipeline == 4
+    assert mk(num_envs=8, map_size=500, randomize_maps=True, indoor_ratio=0.0, pregen_pipeline=2).pregen_pipeline == 2
 
 
 def test_world_generation_is_shard_invariant():
