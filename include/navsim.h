@@ -581,6 +581,12 @@ int    navsim_regen_stage(const navsim_config* cfg, const navsim_state* stage, c
 int    navsim_step_install(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                            const navsim_state* stage, const float* stage_obs, uint8_t* mark, const long long* ready,
                            uint8_t* late, void* stream);
+/* ... with navsim_replan(cfg, st, max_queries) of the PREVIOUS step's flags inside the same launch (navsim_step_replan's form and
+ * conditions: costmaps of up to one word per thread of the arena's workgroup, else NAVSIM_E_UNSUPPORTED -- the caller then
+ * runs navsim_replan behind navsim_step_install).  max_queries < 0: navsim_step_install. */
+int    navsim_step_install_replan(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
+                                  const navsim_state* stage, const float* stage_obs, uint8_t* mark, const long long* ready,
+                                  uint8_t* late, int32_t max_queries, void* stream);
 /* navsim_regen's helper stream.  Worlds of corridor maps with planned starts (cfg.regen_indoor_ratio > 0, cfg.regen_plan): the
  * distance transform of the new maps runs on a second stream between two events on `stream` (inside a hipGraph capture of
  * `stream` it joins and leaves the capture through them); environment NAVSIM_REGEN_FORK=0 keeps the call on `stream` alone.

@@ -1482,12 +1482,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 // done before the launch's last generation is.  One launch, one stream, no flags to wait for; per arena the order is still
 // step, replan, step.  The cap of navsim_replan (max_queries, in (arena, pedestrian) order, the rest wait and are counted)
 // is kept through the pedestrians' ranks.  More waiting arenas than front workgroups: the arena's own back workgroup does it.
-template <int BLOCK, typename Field, int RULE, int RECT>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((RECT == 2 && BLOCK == 256) ? NAVSIM_PEDS_WAVES_MIN : 8, 8)))
-void navsim_step_replan_kernel(navsim_config c, navsim_state st, navsim_step_io io, unsigned dyn_lds_bytes, int park_lanes,
-                               unsigned rect_lds_offset, int G, int cap) {
-    int e, before = 0;
-    bool plan = false;
+// which arena this workgroup steps, and whether it plans for it first (navsim_step_replan_kernel); false: nothing to do
+template <int BLOCK>
+__device__ __forceinline__ bool step_replan_pick(const navsim_config& c, const navsim_state& st, int G, int cap, int& e, bool& plan, int& before) {
+    before = 0;
+    plan = false;
     if ((int)blockIdx.x < G) {
         int n_peds;
         e = due_arena_pick<BLOCK>(st.ped_due_prev, c.n_envs, (int)blockIdx.x, &before, &n_peds);
@@ -1496,17 +1495,26 @@ void navsim_step_replan_kernel(navsim_config c, navsim_state st, navsim_step_io 
             if (served > 0) atomicAdd(&st.counters[NAVSIM_COUNTER_REPLAN_SERVED], (unsigned long long)served);
             if (n_peds > served) atomicAdd(&st.counters[NAVSIM_COUNTER_REPLAN_UNSERVED], (unsigned long long)(n_peds - served));
         }
-        if (e < 0) return;
+        if (e < 0) return false;
         plan = true;
     } else {
         const int b = (int)blockIdx.x - G;
         e = st.launch_order ? st.launch_order[b] : b;     // longest-first launch order (a scheduling hint)
-        if (e < 0) return;
+        if (e < 0) return false;
         if (st.ped_due_prev[e] != 0ull) {                 // a front workgroup's arena -- unless more arenas wait than the front holds
-            if (due_arena_rank<BLOCK>(st.ped_due_prev, e, &before) < G) return;
+            if (due_arena_rank<BLOCK>(st.ped_due_prev, e, &before) < G) return false;
             plan = true;
         }
     }
+    return true;
+}
+template <int BLOCK, typename Field, int RULE, int RECT>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((RECT == 2 && BLOCK == 256) ? NAVSIM_PEDS_WAVES_MIN : 8, 8)))
+void navsim_step_replan_kernel(navsim_config c, navsim_state st, navsim_step_io io, unsigned dyn_lds_bytes, int park_lanes,
+                               unsigned rect_lds_offset, int G, int cap) {
+    int e, before;
+    bool plan;
+    if (!step_replan_pick<BLOCK>(c, st, G, cap, e, plan, before)) return;
     if (plan) {
         for (unsigned long long m = st.ped_due_prev[e]; m != 0ull; m &= m - 1ull, ++before) {      // block-uniform
             if (before < cap) replan_one<BLOCK, 1>(c, st, e, (int)__builtin_ctzll(m));     // (one costmap word per thread: the host checked)
@@ -1514,6 +1522,23 @@ void navsim_step_replan_kernel(navsim_config c, navsim_state st, navsim_step_io 
         }
     }
     step_arena<BLOCK, true, Field, RULE, RECT, true>(c, st, io, e, 0, 0, nullptr, dyn_lds_bytes, park_lanes, rect_lds_offset);
+}
+// ... and with the install of the staged worlds (navsim_step_install with max_queries >= 0): the kernel of the pipelined reset
+// path for worlds whose pedestrians follow planned routes
+template <int BLOCK, typename Field, int RULE, int RECT>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((RECT == 2 && BLOCK == 256) ? NAVSIM_PEDS_WAVES_MIN : 8, 8)))
+void navsim_step_replan_install_kernel(navsim_config c, navsim_state st, navsim_step_io io, StepInstall in, unsigned dyn_lds_bytes,
+                                       int park_lanes, unsigned rect_lds_offset, int G, int cap) {
+    int e, before;
+    bool plan;
+    if (!step_replan_pick<BLOCK>(c, st, G, cap, e, plan, before)) return;
+    if (plan) {
+        for (unsigned long long m = st.ped_due_prev[e]; m != 0ull; m &= m - 1ull, ++before) {
+            if (before < cap) replan_one<BLOCK, 1>(c, st, e, (int)__builtin_ctzll(m));
+            __syncthreads();
+        }
+    }
+    step_arena<BLOCK, true, Field, RULE, RECT, true, true>(c, st, io, e, 0, 0, nullptr, dyn_lds_bytes, park_lanes, rect_lds_offset, &in);
 }
 
 // navsim_launch_order: arenas by descending cost.  One workgroup: maximum, 1024-bucket histogram on the cost

@@ -789,6 +789,12 @@ void stage_big_buffers(const navsim_config* c, const navsim_state* live, const n
 
 int navsim_step_install(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, const navsim_state* stage,
                         const float* stage_obs, uint8_t* mark, const long long* ready, uint8_t* late, void* stream) {
+    return navsim_step_install_replan(c, st, io, stage, stage_obs, mark, ready, late, -1, stream);
+}
+
+int navsim_step_install_replan(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, const navsim_state* stage,
+                               const float* stage_obs, uint8_t* mark, const long long* ready, uint8_t* late, int32_t max_queries,
+                               void* stream) {
     (void)hipGetLastError();
     int rc = check_step_args(c, st, io, 0);
     if (rc != NAVSIM_OK) return rc;
@@ -807,7 +813,17 @@ int navsim_step_install(const navsim_config* c, const navsim_state* st, const na
     StepInstall in = {};
     in.stage = *stage; in.stage_obs = stage_obs; in.mark = mark; in.ready = ready; in.late = late;
     if (!st->map_slot) stage_big_buffers(c, st, stage, in.big);             // (with slot tables the maps stay where they are)
-    return dispatch_step(c, st, io, 16, nullptr, (hipStream_t)stream, 0, 0, &in);
+    if (max_queries < 0) return dispatch_step(c, st, io, 16, nullptr, (hipStream_t)stream, 0, 0, &in);
+    // ... with navsim_replan of the previous step's flags inside the launch (navsim_step_replan's conditions)
+    if (c->ped_model == NAVSIM_PED_NONE || !st->costmap || !st->ped_due_prev || !st->ped_due || st->ped_due == st->ped_due_prev)
+        return NAVSIM_E_ARG;
+    const int Hc = c->map_h / 5, Wc = c->map_w / 5;
+    if (Hc < 1 || Wc < 1 || !plan_fits(Hc, Wc) || plan_lds(Hc, Wc) > 64 * 1024) return NAVSIM_E_UNSUPPORTED;
+    if ((int)plan_words(Hc, Wc) > plan_step(c, st).block) return NAVSIM_E_UNSUPPORTED;
+    int front = c->n_envs / 16;
+    front = front < 32 ? 32 : (front > 1024 ? 1024 : front);
+    front = front > c->n_envs ? c->n_envs : front;
+    return dispatch_step(c, st, io, (3 << 2) | 16, nullptr, (hipStream_t)stream, front, max_queries, &in);
 }
 
 int navsim_regen_swap(const navsim_config* c, const navsim_state* live, const navsim_state* stage, const navsim_step_io* io,

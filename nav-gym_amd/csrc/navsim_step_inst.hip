@@ -28,6 +28,17 @@ template <int BLOCK, bool PEDS, typename Field, int RECT, int RULE, bool PINL>
 int launch_step_pinl(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int reset_only,
                      const uint8_t* mask, const StepPlan& p, hipStream_t s, int grid) {
     if constexpr (PEDS && PINL) {
+        if (((reset_only >> 2) & 3) == 3 && (reset_only & 16)) {   // ... with the install of the staged worlds (packed fields)
+            if constexpr (!std::is_same<Field, FieldF32>::value) {
+                const size_t pl = plan_lds(c->map_h / 5, c->map_w / 5), lds = p.lds > pl ? p.lds : pl;
+                if (allow_lds((const void*)navsim_step_replan_install_kernel<BLOCK, Field, RULE, RECT>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
+                if (g_prepare_only) return NAVSIM_OK;
+                navsim_step_replan_install_kernel<BLOCK, Field, RULE, RECT><<<grid + c->n_envs, BLOCK, lds, s>>>(
+                    *c, *st, *io, *g_install, (unsigned)step_lds_scan_bytes(c, p.park), p.park, p.rect_off, grid, g_aux);
+                return NAVSIM_OK;
+            }
+            return NAVSIM_E_UNSUPPORTED;
+        }
         if (((reset_only >> 2) & 3) == 3) {                        // navsim_step_replan: the re-plan inside the step's launch
             const size_t pl = plan_lds(c->map_h / 5, c->map_w / 5), lds = p.lds > pl ? p.lds : pl;
             if (allow_lds((const void*)navsim_step_replan_kernel<BLOCK, Field, RULE, RECT>, lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;

@@ -489,9 +489,14 @@ class NavGymEnv(_EnvBase):
         if self._graphed:                                   # step + regen + replan: one graph launch (NavSim.enable_graphs)
             _, out = self.sim.step_graphed(a)
         elif self.pregen_pipeline:
-            _, out = self.sim.step(a)                      # navsim_step_install: finished arenas take their staged worlds
+            # navsim_step_install: finished arenas take their staged worlds; with planned routes the re-plan of the PREVIOUS
+            # step's arrivals inside the same launch where the search fits the arena's workgroup (else behind the step)
+            in_step = "costmap" in self.sim.t and self.pedestrian_model != "policy"
+            if in_step and self.sim.pg_replan_cap == 0:
+                self.sim.pg_replan_cap = self.replan_cap
+            _, out = self.sim.step(a)
             self.sim.regen()                               # ... and every P steps a staging pass goes to the side stream
-            if "costmap" in self.sim.t:
+            if "costmap" in self.sim.t and not (in_step and self.sim.pg_replan_in_step):
                 self.sim.replan(self.replan_cap)
         elif self._overlap_replan:
             # planned routes: the re-plan of the previous step runs beside this step's launch (NavSim.launch_step_overlapped)

@@ -556,6 +556,17 @@ class NavSim(object):
         P, k = self.pg_period, self.pg_k
         if k % P == 0 and k >= 2 * P:
             main.wait_event(self.pg_staged[(k // P - 2) % 3])   # the pass queued two periods ago; the later two may still run
+        # pg_replan_cap > 0 (worlds with planned pedestrian routes): navsim_replan of the previous step's flags inside this launch
+        # where the search fits the arena's workgroup (navsim_step_install_replan); else the caller re-plans behind the step
+        if getattr(self, "pg_replan_cap", 0) > 0 and self.pg_replan_in_step:
+            rc = self.lib.navsim_step_install_replan(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), C.byref(self.stage_st),
+                                                     _ptr(self.stage_obs), _ptr(self.mark), _ptr(self.ready), _ptr(self.late),
+                                                     int(self.pg_replan_cap), C.c_void_p(main.cuda_stream))
+            if rc == 0:
+                return
+            if rc != abi.E_UNSUPPORTED:
+                check(rc, "navsim_step_install_replan")
+            self.pg_replan_in_step = False
         check(self.lib.navsim_step_install(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), C.byref(self.stage_st),
                                            _ptr(self.stage_obs), _ptr(self.mark), _ptr(self.ready), _ptr(self.late),
                                            C.c_void_p(main.cuda_stream)), "navsim_step_install")
@@ -671,6 +682,7 @@ class NavSim(object):
         self.pg_staged = [torch.cuda.Event() for _ in range(3)]
         self.pregen = True
         self.pg_install = bool(install)
+        self.pg_replan_cap, self.pg_replan_in_step = 0, True       # (set pg_replan_cap to re-plan inside the step's launch, _launch)
         # the fallback: flags the step writes, and a navsim_regen of its own size for the arenas they name
         self.late = torch.zeros(E, dtype=torch.uint8, device=self.device) if fallback else None
         if fallback:

@@ -1059,6 +1059,75 @@ def test_replan_beside_the_step_equals_the_serial_sequence(gpu, mode, graphs, E)
         assert r.counters()["replan_unserved"] > 0, "the cap was never hit"
 
 
+@pytest.mark.parametrize("E,slow", [(24, False), (24, True), (300, False)])
+def test_pipelined_reset_with_the_replan_inside_the_step(gpu, monkeypatch, E, slow):
+    """navsim_step_install_replan: ONE launch per step for a world with planned pedestrian routes and a new map per episode --
+    the re-plan of the previous step's arrivals by the waiting arena's own workgroup, the step, and the install of the
+    finished arenas' staged worlds (no rule: whoever finds nothing staged is regenerated by navsim_regen right behind the
+    launch; `slow` delays the staging passes so that this happens).  Equals the oracle's serial  replan, step, regen, ...
+    bit for bit: observations, outputs, every state array, the counters."""
+    size, N = 300, 6
+    cap = 64
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_SFM, n_spawn=4,
+                                 auto_reset=1, seed=31, field_format=abi.FIELD_U16T, ped_min_goal_dist=3.0, obstacle_number=6,
+                                 regen_cap=E, regen_plan=1, min_goal_dist=3.0, max_goal_dist=8.0, ped_min_robot_dist=2.0,
+                                 spawn_clearance=0.9)
+    gpu.world.lidar_full_circle(cfg, 180)
+    occ = gpu.world.make_maps(E, size, 31, n_obstacles=6)
+    torch = gpu.torch
+    from nav_gym_amd import robots
+    arrays = gpu.world.make_world(cfg, occ, n_peds=5, device=gpu.dev, plan_paths=True, v_pref_range=(0.5, 0.6))
+    arrays["scan_threshold"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array("keti", "threshold_footprint")))
+    arrays["scan_discomfort"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array("keti", "discomfort_threshold_footprint")))
+    host = {k: v.cpu().numpy() for k, v in arrays.items() if k not in ("field", "field_overflow", "rect_table", "rect_index")}
+    host["field"] = ref.build_dt(occ)
+    g = gpu.sim.NavSim(cfg, arrays)
+    r = ref.RefSim(cfg, host)
+    _eq(g.reset_obs().cpu().numpy(), r.reset_obs(), "reset obs")
+    g.enable_pregen(pipeline=2, install=True)
+    assert g.late is not None
+    g.pg_replan_cap = cap
+    if slow:
+        stage = g.lib.navsim_regen_stage
+        def delayed(*a, _stage=stage, _g=g):
+            with torch.cuda.stream(_g.side):
+                torch.cuda._sleep(200_000_000)
+            return _stage(*a)
+        monkeypatch.setattr(g.lib, "navsim_regen_stage", delayed)
+    rng = np.random.default_rng(5)
+    ended = waited = 0
+    for t in range(90 if E < 100 else 40):
+        act = np.stack([rng.uniform(0.0, 0.5, E), rng.uniform(-0.64, 0.64, E)], axis=1)
+        if t % 7 == 3:
+            act[:, 0] = 0.5; act[:, 1] = 0.0            # bursts of straight driving: crashes, episode ends
+        waited += int((r.a["ped_due"] != 0).sum())
+        if t > 0:
+            r.replan(cap)
+        ro, rout = r.step(act)
+        ro2 = r.regen()
+        go, gout = g.step(torch.from_numpy(act).to(gpu.dev))
+        go2 = g.regen().cpu().numpy()
+        _eq(go2, ro2, "obs after step + regen at step %d" % t)
+        for k in rout:                                   # (the goal arrays are the new worlds' on both sides by now)
+            _eq(gout[k].cpu().numpy(), rout[k], "%s at step %d" % (k, t))
+        ended += int(rout["done"].sum())
+        if slow and t in (30, 31, 50, 51):              # two episode ends one step apart: the second finds nothing staged
+            idx = torch.arange(2, 8, device=gpu.dev)
+            g.t["robot_goal"][idx] = g.t["robot_pose"][idx, :2]
+            r.a["robot_goal"][2:8] = r.a["robot_pose"][2:8, :2]
+        if t % 10 == 9:
+            gpu.torch.cuda.synchronize()
+            gs = g.numpy_state()
+            for k, v in r.a.items():
+                if k in gs and k not in ("field", "field_overflow", "rect_table", "rect_index", "ped_waypoints", "counters"):
+                    _eq(gs[k], v, "state %s at step %d" % (k, t))
+    assert g.pg_replan_in_step, "the search did not fit the arena's workgroup: the launch fell back"
+    assert ended > 8 and waited >= 5, (ended, waited)
+    cg, cr = g.counters(), r.counters()
+    assert cg["replan_served"] == cr["replan_served"] >= 5 and cg["regen_served"] == cr["regen_served"] == ended
+    assert cg["regen_late"] > 0 or not slow
+
+
 def test_long_routes_on_the_device(gpu, golden_dir):
     """Round 4, row a16: routes of full length.  On the costmap of the reference's own 1000 x 1000 corridor episode and
     the starts / goals its _sample_start_goal_path drew (tests/golden/golden_long_routes.npz), navsim_plan equals the
