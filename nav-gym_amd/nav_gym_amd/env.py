@@ -233,6 +233,7 @@ class NavGymEnv(_EnvBase):
         # every 4 steps otherwise (a c5-shaped world through this API: 5.4 -> 7.4 M env-steps/s, with planned routes 1.3 -> 3.0 M,
         # profiles/_diag/gym_c5_steps.py).  With regen_min_steps = 0 it changes no result: the rollout is the one of
         # pregen_pipeline=0, bit for bit.
+        self._pregen_auto = pregen_pipeline is None
         if pregen_pipeline is None:
             available = (pedestrian_model != "policy" and field_format == abi.FIELD_U16T and
                          (map_size == "reference" or int(map_size) <= 1024))
@@ -422,6 +423,22 @@ class NavGymEnv(_EnvBase):
         # front of every step and reads the routes)
         self._overlap_replan = ("costmap" in self.sim.t and self.sim.due is not None and self.pedestrian_model != "policy"
                                 and not self.pregen_pipeline)
+        if self.pregen_pipeline and first and self._pregen_auto:
+            # the pipeline keeps a second, staged copy of every array navsim_regen writes (the maps above all) and builds it
+            # through a few GB of scratch: where that does not fit, the env's own choice falls back to navsim_regen after every step
+            need = 2 * sum(v.numel() * v.element_size() for k, v in self.sim.t.items() if k in self.sim.STAGED) + (6 << 30)
+            free = torch.cuda.mem_get_info(torch.device(self.device))[0]
+            if need > free:
+                self._warn_once("pregen_memory", "NavGymEnv: %.0f GB free on the device, the pipelined reset path would need about "
+                                "%.0f GB more than the world itself: pregen_pipeline falls back to 0 (navsim_regen after every step)"
+                                % (free / 2 ** 30, need / 2 ** 30))
+                self.pregen_pipeline = 0
+                for c_ in (cfg, self.sim.cfg):             # (the simulator holds its own copy)
+                    c_.regen_cap = min(self.num_envs, 64)
+                    c_.defer_reset_scan = int(self.num_envs <= 1024)
+                if self._use_graphs_arg is None:
+                    self.use_graphs = not (self.plan_paths and float(self.indoor_ratio) > 0.0)
+                self._overlap_replan = ("costmap" in self.sim.t and self.sim.due is not None and self.pedestrian_model != "policy")
         if self.pregen_pipeline:
             if cfg.field_format != abi.FIELD_U16T:
                 raise ValueError("pregen_pipeline needs the packed distance field (map_size <= 1024)")
