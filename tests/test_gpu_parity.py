@@ -740,6 +740,36 @@ def test_pipelined_pregeneration_equals_navsim_regen(gpu, monkeypatch, period, m
     assert cg["regen_short"] == cr["regen_short"] == n_short and cg["regen_served"] == cr["regen_served"] == n_long
 
 
+def test_env_pipeline_falls_back_when_the_staged_copy_does_not_fit(gpu, monkeypatch):
+    """The env's own choice of the pipelined reset path (pregen_pipeline=None) needs room for a second copy of the world: where
+    the device has none it says so once and runs navsim_regen after every step -- the same rollout."""
+    import warnings
+    import nav_gym_amd
+    from nav_gym_amd.env import NavGymEnv
+    torch = gpu.torch
+    kw = dict(nav_gym_amd.DEFAULT_KWARGS)
+    E = 16
+    mk = lambda: nav_gym_amd.NavGymEnv(num_envs=E, map_size=200, seed=21, num_humans=3, randomize_maps=True, **kw)
+    a = mk(); a.reset()
+    assert a.pregen_pipeline == 8 and a.sim.pg_install
+    NavGymEnv._warned.discard("pregen_memory")
+    total = torch.cuda.mem_get_info(torch.device(gpu.dev))[1]
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *args, **kwargs: (1 << 20, total))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        b = mk(); b.reset()
+    assert b.pregen_pipeline == 0 and not getattr(b.sim, "pregen", False) and b.sim.cfg.regen_cap == E
+    assert any("pregen_pipeline falls back" in str(x.message) for x in w)
+    g = torch.Generator(device=gpu.dev); g.manual_seed(2)
+    acts = torch.rand((40, E, 2), generator=g, device=gpu.dev, dtype=torch.float64)
+    acts[..., 0] *= 0.5; acts[..., 1] = acts[..., 1] * 1.28 - 0.64
+    acts[::4, :, 0] = 0.5; acts[::4, :, 1] = 0.0
+    for t in range(40):
+        oa, ra, da, _ = a.step(acts[t]); ob, rb, db, _ = b.step(acts[t])
+        assert torch.equal(oa["observation"], ob["observation"]) and torch.equal(ra, rb) and torch.equal(da, db), "step %d" % t
+    assert a.counters()["regen_served"] > 2
+
+
 @pytest.mark.parametrize("pipeline", [0, 2])
 def test_env_state_dict_continues_the_rollout(gpu, pipeline):
     """NavGymEnv.state_dict() / load_state_dict(): a second environment made with the same arguments continues the first
