@@ -113,6 +113,10 @@ def test_argument_validation_of_round2_entry_points():
     odd = C.c_void_p(ptr.value + 1)                                        # mark[] is consumed in 32-bit words
     assert L.navsim_step_install(C.byref(c2), C.byref(st), C.byref(io), C.byref(st), ptr, odd, ptr, None, None) == abi.E_ARG
     assert L.navsim_regen_swap(C.byref(c2), C.byref(st), C.byref(st), C.byref(io), ptr, ptr, odd, None, None) == abi.E_ARG
+    c0 = c2.copy(); c0.n_envs = 0; c0.regen_cap = 1; c0.field_format = abi.FIELD_U16T    # an empty shard: nothing to launch
+    assert L.navsim_step_install(C.byref(c0), C.byref(st), C.byref(io), C.byref(st), ptr, ptr, ptr, ptr, None) == 0
+    assert L.navsim_step_install_replan(C.byref(c0), C.byref(st), C.byref(io), C.byref(st), ptr, ptr, ptr, ptr, 8, None) == 0
+    assert L.navsim_regen_helper(None) == 0
     st.map_slot = ptr; c2.shared_field = 1
     assert L.navsim_step(C.byref(c2), C.byref(st), C.byref(io), None) == abi.E_ARG              # one shared map has no slots
 
