@@ -687,7 +687,11 @@ class NavSim(object):
         self.late = torch.zeros(E, dtype=torch.uint8, device=self.device) if fallback else None
         if fallback:
             self.late_cfg = self.cfg.copy()
-            self.late_cap = int(min(E, fallback_cap if fallback_cap else max(16, E // 64)))
+            # (every launch of the fallback is sized by its cap whether anybody is late or not: with 16 slots the planner's
+            #  four launches alone dispatched 2 x 960 empty 1024-thread workgroups per step, 0.25 ms of a 0.38 ms step of the
+            #  reference's configuration, profiles/r05_refdef/timeline_pipeline8_no_rule_cap16.txt.  Late arenas are one in
+            #  ~100 steps of that loop; more of them than the cap in ONE step would restart in place, counted as regen_unserved.)
+            self.late_cap = int(min(E, fallback_cap if fallback_cap else max(8, E // 128)))
             self.late_cfg.regen_cap = self.late_cap
             self.late_ws = torch.zeros(self.lib.navsim_regen_workspace_bytes(C.byref(self.late_cfg)), dtype=torch.uint8, device=self.device)
 
