@@ -598,7 +598,8 @@ class NavSim(object):
         stages (default: what 2 P steps finish at one arena in 64 per step) -- arenas beyond it wait for the next pass.
         fallback (with install; default: on when cfg.regen_min_steps < 4 P): no rule is needed -- an arena that finishes before
         its world is staged is regenerated on the spot by the ordinary navsim_regen (regen() launches it after every step, with
-        the flags the step wrote: launches that find nothing to do when nobody was late, `fallback_cap` arenas at most).  The
+        the flags the step wrote: launches that find nothing to do when nobody was late, `fallback_cap` arenas at most -- more late arenas than that in
+        ONE step restart on their old map like navsim_regen's own cap, counters()['regen_unserved']).  The
         rollout then equals step + navsim_regen whatever the passes' timing, also with cfg.regen_min_steps = 0: the reference's
         "a new map at every reset()" unchanged.
         map_slots (with install): the live and the staged state share the per-map arrays (t['field'], ... then hold 2 E slots)

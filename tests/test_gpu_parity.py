@@ -740,6 +740,42 @@ def test_pipelined_pregeneration_equals_navsim_regen(gpu, monkeypatch, period, m
     assert cg["regen_short"] == cr["regen_short"] == n_short and cg["regen_served"] == cr["regen_served"] == n_long
 
 
+def test_more_late_arenas_than_the_fallback_cap_are_counted(gpu):
+    """The fallback of the pipelined reset path regenerates at most `fallback_cap` late arenas per step (its launches are
+    sized by the cap even when nobody is late, so the default is small: max(8, E / 128)).  More than that in ONE step is
+    navsim_regen's own cap rule: the rest restart on their old map, and counters()['regen_unserved'] says how many -- the
+    only case in which the pipelined rollout is not step + navsim_regen's."""
+    torch = gpu.torch
+    E, size = 48, 200
+    cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=6, ped_model=abi.PED_SFM, n_spawn=6,
+                                 auto_reset=1, seed=29, field_format=abi.FIELD_U16T, regen_cap=E, min_goal_dist=3.0,
+                                 max_goal_dist=8.0, spawn_clearance=0.9, ped_min_robot_dist=2.0, ped_min_goal_dist=4.0,
+                                 regen_plan=0, regen_indoor_ratio=0.0, regen_min_steps=0)
+    gpu.world.lidar_1081(cfg)
+    occ = gpu.world.make_maps(E, size, 29)
+    arrays = gpu.world.make_world(cfg, occ, n_peds=5, device=gpu.dev)
+    from nav_gym_amd import robots
+    arrays["scan_threshold"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array("keti", "threshold_footprint")))
+    arrays["scan_discomfort"] = gpu.sim.scan_threshold(cfg, _t(gpu, robots.footprint_array("keti", "discomfort_threshold_footprint")))
+    g = gpu.sim.NavSim(cfg, arrays)
+    g.reset_obs()
+    g.enable_pregen(pipeline=2, install=True, fallback_cap=4)
+    assert g.late_cap == 4
+    act = torch.zeros((E, 2), dtype=torch.float64, device=gpu.dev)
+    act[:, 0] = 0.2
+    idx = torch.arange(2, 8, device=gpu.dev)
+    for t in range(24):
+        obs, out = g.step(act)
+        g.regen()
+        if t in (10, 11):                           # six arenas end two episodes one step apart: six late at once, four slots
+            torch.cuda.synchronize()                # (the pass queued after step 10 has merged its requests: the worlds the
+            g.t["robot_goal"][idx] = g.t["robot_pose"][idx, :2]     # six ask for at step 11 are staged after step 12 at the earliest)
+    torch.cuda.synchronize()
+    c = g.counters()
+    assert c["regen_late"] >= 6 and c["regen_unserved"] >= 2, c
+    assert torch.isfinite(obs).all()
+
+
 def test_env_pipeline_falls_back_when_the_staged_copy_does_not_fit(gpu, monkeypatch):
     """The env's own choice of the pipelined reset path (pregen_pipeline=None) needs room for a second copy of the world: where
     the device has none it says so once and runs navsim_regen after every step -- the same rollout."""
