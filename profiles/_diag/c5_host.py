@@ -1,5 +1,5 @@
 """c5 with pipelined pre-generation + in-step install: is the loop host-bound?  Host enqueue time per step (the loop returns
-before the GPU has finished) against the wall time per step, plain launches.  Args: pipeline period (default 4)."""
+before the GPU has finished) against the wall time per step, plain launches.  Args: pipeline period (default 4).  NAVSIM_NO_RULE=1: regen_min_steps 0, the fallback's navsim_regen after every step."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "nav-gym_amd"))
@@ -7,7 +7,7 @@ import torch
 import bench
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-wl = dict(bench.WORKLOADS["c5"]); wl.update(field="u16t", indoor_ratio=0.0, pregen=bool(P), pipeline=P, install=True)
+wl = dict(bench.WORKLOADS["c5"]); wl.update(field="u16t", indoor_ratio=0.0, pregen=bool(P), pipeline=P, install=True, no_rule=bool(os.environ.get('NAVSIM_NO_RULE')))
 cfg, sim, arrays, _ = bench.build_sim(wl, 0, wl["envs"])
 E = cfg.n_envs
 g = torch.Generator(device="cuda:0"); g.manual_seed(77)
