@@ -410,13 +410,24 @@ def main():
     dist = None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
+    # Libraries write to the process's stdout behind Python's back -- RCCL prints a version banner through C stdio, which a
+    # redirected stdout holds until the process EXITS, i.e. after the result line (seen with NAVSIM_BENCH_FORCE_DIST=1 on the
+    # one-GPU box).  The contract is ONE json line on stdout: file descriptor 1 is stderr for the rest of the run, and the line
+    # goes to the real one.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if os.environ.get("NAVSIM_BENCH_ONE_GPU"):
         local_rank = 0
     device = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
-    if world_size > 1:
+    # NAVSIM_BENCH_FORCE_DIST=1: a process group also at N = 1 -- the nccl (RCCL) branches below (device-side barrier and
+    # MAX reduction, the obs gather) then run on a one-GPU box, where gloo dry runs never reach them
+    if world_size > 1 or os.environ.get("NAVSIM_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -442,7 +453,7 @@ def main():
     if rank == 0 and world_size == 1 and not args.no_extras and args.workload == "c2" and not args.envs:
         out.update(extras(args, device))
     if rank == 0:
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -2459,6 +2459,34 @@ def test_soak_reduced(gpu, peds):
     assert len(passes) == 2 and all(d > 0 for _, _, d in passes), passes      # episodes did end and restart
 
 
+def test_bench_collectives_through_rccl_on_one_gpu(gpu):
+    """The branches of bench.py that only exist under the nccl (= RCCL) backend -- the process group bound to the device, the
+    device-side barrier and MAX reduction of the timed region, sharding.RowGather's all_gather_into_tensor after every step
+    (value_with_obs_gather) -- executed on this box's one GPU: NAVSIM_BENCH_FORCE_DIST=1 makes a process group of ONE rank.
+    Nothing crosses a link, but it is RCCL's init, communicator and kernels that run (the gloo stand-ins of the other tests
+    never reach these lines).  stdout must hold the ONE json line and nothing else: RCCL prints a version banner through C
+    stdio, which bench.py keeps off the real stdout."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NAVSIM_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NAVSIM_BENCH_BACKEND", "NAVSIM_BENCH_ONE_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--envs", "512", "--steps", "6", "--warmup", "2", "--repeats", "1",
+                        "--no-cpu-baseline", "--no-extras"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), r.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["config"]["envs_per_gpu"] == 512
+    g = out["obs_gather"]
+    assert out["value_with_obs_gather"] > 0 and "RCCL" in g["collective"] and g["equal_shards"]
+    assert g["bytes_total"] == g["bytes_per_rank"] == 512 * 1088 * 4
+    assert out["value_with_obs_gather"] <= out["value"] * 1.05            # the same steps plus a collective each
+
+
 def test_bench_two_ranks_on_one_gpu(gpu):
     """bench.py --gpus 2 end to end through the HIP library: the script spawns both ranks itself; they share
     this box's only GPU (NAVSIM_BENCH_ONE_GPU) and rendezvous over gloo (the driver's 8-GPU runs use RCCL, one
