@@ -88,6 +88,9 @@ __device__ __forceinline__ void plan_levels(unsigned long long* __restrict__ fa,
     }
     __syncthreads();                                     // everybody has read its free words: the area is the planes' from here on
     u64* cur = fa, *nxt = fb;
+    bool stale[WPT];                                     // my word of `nxt` may hold a frontier of two levels ago (fb: anything)
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) stale[k] = true;
     for (int level = 1; level < 65536; ++level) {
         // the two flags and the frontier words in ONE LDS round trip (the reads are issued together, the exit test follows)
         const int stop = *reached, more = any_s[level % 3];
@@ -101,6 +104,11 @@ __device__ __forceinline__ void plan_levels(unsigned long long* __restrict__ fa,
         bool found = false;
 #pragma unroll
         for (int k = 0; k < WPT; ++k) {
+            // a wavefront none of whose 64 words has a frontier bit in itself or a neighbour word skips the update (cand = 0
+            // changes nothing); it must still overwrite an OLD frontier in its word of `nxt` (`cur` of two levels ago): stale
+            const bool work = (f[k] | l[k] | r[k] | u[k] | d[k]) != 0ull || stale[k];
+            stale[k] = f[k] != 0ull;                            // `cur` is the next level's `nxt`
+            if (__builtin_amdgcn_ballot_w64(work) == 0ull) continue;
             const u64 fk = f[k] & mo[k], dk = d[k] & md[k];
             const u64 R = (fk >> 1) | ((r[k] << 63) & mr[k]);   // cells whose +i neighbour is in the frontier
             const u64 L = (fk << 1) | ((l[k] >> 63) & ml[k]);   // ... -i neighbour
