@@ -2476,6 +2476,11 @@ def test_bench_collectives_through_rccl_on_one_gpu(gpu):
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--envs", "512", "--steps", "6", "--warmup", "2", "--repeats", "1",
                         "--no-cpu-baseline", "--no-extras"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                        timeout=900)
+    if r.returncode != 0 and any(k in r.stderr for k in ("ncclSystemError", "ncclUnhandledCudaError", "ncclInternalError",
+                                                          "hipIpcGetMemHandle")):
+        # (a system-level RCCL failure -- no usable IPC, no device for the communicator; wrong arguments of ours would be
+        #  ncclInvalidArgument / ncclInvalidUsage or a Python error, and fail the test)
+        pytest.skip("RCCL could not initialise on this box: " + r.stderr[-300:])
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1 and lines[0].startswith('{"metric"'), r.stdout[-1500:]
