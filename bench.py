@@ -70,7 +70,8 @@ def build_sim(wl, base, E, seed=1234, device="cuda:0"):
     from nav_gym_amd import abi, lib, robots, sim, world
     cfg = lib.default_config(n_envs=E, map_h=wl["size"], map_w=wl["size"], max_peds=max(wl["peds"], 1),
                              ped_model=abi.PED_SFM if wl["peds"] else abi.PED_NONE,
-                             n_spawn=16, auto_reset=1, seed=seed, env_index_base=base,
+                             n_spawn=16, auto_reset=(abi.AUTORESET_NEXT_STEP if wl.get("next_step") else abi.AUTORESET_SAME_STEP),
+                             seed=seed, env_index_base=base,
                              field_format={"f32": abi.FIELD_F32}.get(wl.get("field"), abi.FIELD_U16T))
     if wl["beams"] == 1081:
         world.lidar_1081(cfg)
@@ -221,7 +222,33 @@ def cpu_baseline(wl, seconds=15.0):
         ref_shaped_us = (time.perf_counter() - t2) / k * 1e6
     except Exception:
         pass
-    return dict(value=E * n / dt, unit="env-steps/s", cores=nthr, kind="port",
+    # BASELINE.json configs[0] -- "1 env NavGym-v0, 64-beam lidar, 100 x 100 static map, no pedestrians, CPU reference step()":
+    # the oracle on ONE thread on that world (us per step; the GPU side is other_workloads.c1)
+    c1_us = None
+    try:
+        w1 = WORKLOADS["c1"]
+        cc = lib.default_config(n_envs=1, map_h=w1["size"], map_w=w1["size"], max_peds=1, ped_model=abi.PED_NONE, n_spawn=16,
+                                auto_reset=1, seed=1234)
+        world.lidar_full_circle(cc, w1["beams"])
+        occ_c1 = world.make_maps(1, w1["size"], 1234)
+        a_c1 = world.make_world(cc, occ_c1, n_peds=0, device="cpu", field=torch.from_numpy(ref.build_dt(occ_c1)), min_goal_dist=2.0,
+                                max_goal_dist=4.0, robot_clearance=0.9)
+        h_c1 = {k: v.numpy() for k, v in a_c1.items()}
+        h_c1["scan_threshold"] = ref.scan_threshold(cc, robots.footprint_array("keti", "threshold_footprint"))
+        h_c1["scan_discomfort"] = ref.scan_threshold(cc, robots.footprint_array("keti", "discomfort_threshold_footprint"))
+        r_c1 = ref.RefSim(cc, h_c1)
+        r_c1.reset_obs()
+        a1 = lambda n: np.stack([rng.uniform(0, 0.5, (n, 1)), rng.uniform(-0.64, 0.64, (n, 1))], axis=2)
+        r_c1.step_native_threads(a1(200), 1)
+        t4 = time.perf_counter()
+        k1 = 0
+        while time.perf_counter() - t4 < 1.0:
+            r_c1.step_native_threads(a1(2000), 1)
+            k1 += 2000
+        c1_us = (time.perf_counter() - t4) / k1 * 1e6
+    except Exception:
+        pass
+    return dict(value=E * n / dt, unit="env-steps/s", cores=nthr, kind="port", c1_us_per_step_1_thread=c1_us,
                 sample="%d arenas x %d steps of the same workload (oracle/navsim_ref.c navsim_step_threads_cpu: %d pinned POSIX "
                        "threads, arenas split statically, fields node-local, %.1f s); value_1_thread: one thread on %d arenas"
                        % (E, n, nthr, dt, E1),
@@ -426,13 +453,20 @@ def main():
     if world_size > 1 or os.environ.get("NAVSIM_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))     # (only the forced one-rank group gets here without one)
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # the communicator itself, before any kernel of ours has run: a failure up to here is the box's (no usable IPC,
+            # no device for RCCL), one after the marker below is ours -- a faulting kernel of this library surfaces as an
+            # ncclUnhandledCudaError at the next collective (tests/test_gpu_parity.py tells the two apart by the marker)
+            probe = torch.zeros(1, device=device)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
         else:
             dist.init_process_group(backend)
         assert dist.get_world_size() == args.gpus
+        print("navsim-bench: process group ready (%s, %d ranks)" % (backend, dist.get_world_size()), file=sys.stderr, flush=True)
     coll_dev = device if backend == "nccl" else "cpu"
 
     ctx = dict(rank=rank, world_size=world_size, dist=dist, backend=backend, device=device, coll_dev=coll_dev)
@@ -452,6 +486,10 @@ def main():
             out["value_weak" if out["scaling"] == "weak" else "value_strong"] = out["value"]
     if rank == 0 and world_size == 1 and not args.no_extras and args.workload == "c2" and not args.envs:
         out.update(extras(args, device))
+        c1 = out.get("other_workloads", {}).get("c1")
+        if isinstance(c1, dict) and "error" not in c1:      # BASELINE.json configs[0]: both sides of "CPU reference step()"
+            c1["cpu_us_per_step_1_thread"] = (out.get("cpu_baseline") or {}).get("c1_us_per_step_1_thread")
+            c1["cpu_kind"] = "port (oracle/navsim_ref.c: a restatement, not the reference binary), one thread" 
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
@@ -476,6 +514,11 @@ def extras(args, device):
         wl = dict(WORKLOADS[name.split("_")[0]]); wl["field"] = "u16t"; wl["indoor_ratio"] = 0.0
         if name.startswith("c5_pipelined"):
             wl.update(pregen=True, pipeline=4, install=True, no_rule=name.endswith("no_rule"))
+        if name.startswith("c5_next_step"):
+            # gymnasium's next-step auto-reset (NAVSIM_AUTORESET_NEXT_STEP): a finished arena returns its terminal observation and
+            # is reset by the NEXT call -- its workgroup installs the staged world at the front of the launch instead of
+            # stepping; no rule (cfg.regen_min_steps = 0: a new map at every reset, like the reference)
+            wl.update(pregen=True, pipeline=4, install=True, no_rule=True, next_step=True)
         try:
             cfg, sim, arrays, _ = build_sim(wl, 0, wl["envs"], device=device)
             E = cfg.n_envs
@@ -559,12 +602,59 @@ def extras(args, device):
                     % (wl["pipeline"], "NO rule: whoever finishes before its world is staged is regenerated on the spot (the rollout of "
                        "navsim_regen after every step, bit for bit)" if wl.get("no_rule") else
                        "cfg.regen_min_steps = %d: shorter episodes restart on their old map" % int(cfg.regen_min_steps)))
+                if wl.get("next_step"):
+                    res["other_workloads"][name]["autoreset"] = ("next step (NAVSIM_AUTORESET_NEXT_STEP): the call that ends an episode returns the "
+                                                                 "terminal observation, the next call resets the arena (counted as a step of it)")
             del sim, arrays
             torch.cuda.empty_cache()
         except Exception as exc:                              # an extra must not cost the run its line
             res["other_workloads"][name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     for name in ("c3", "c4", "c5"):
         workload_window(name)
+    # BASELINE.json configs[0]: ONE arena, 64 beams, 100 x 100 map, no pedestrians -- a launch of one 64-thread workgroup;
+    # us per step as the caller sees it (plain launches back to back) and the kernel alone (one event pair around the launches)
+    try:
+        wl1 = dict(WORKLOADS["c1"]); wl1["field"] = "u16t"; wl1["indoor_ratio"] = 0.0
+        cfg1, sim1, arrays1, _ = build_sim(wl1, 0, 1, device=device)
+        sim1.t["scan_noise_std"].fill_(args.noise_std); sim1.cfg.add_scan_noise = int(args.noise_std > 0)
+        g1 = torch.Generator(device=device); g1.manual_seed(79)
+        K1, W1 = 2000, 200
+        acts1 = torch.rand((K1 + W1, 1, 2), generator=g1, device=device, dtype=torch.float64)
+        acts1[..., 0] *= 0.5; acts1[..., 1] = (acts1[..., 1] * 2.0 - 1.0) * 0.64
+        def one1(t):
+            sim1.io.action = acts1[t].data_ptr()
+            sim1.launch_step(reorder=False)
+        for t in range(W1):
+            one1(t)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for t in range(K1):
+            one1(W1 + t)
+        e1.record()
+        torch.cuda.synchronize()
+        el1 = time.perf_counter() - t0
+        graph1 = torch.cuda.CUDAGraph()                     # the kernel alone: the same launches replayed without host gaps
+        cur0 = sim1.cur
+        with torch.cuda.graph(graph1):
+            for t in range(200):
+                one1(W1 + t)
+        torch.cuda.synchronize()
+        graph1.replay(); torch.cuda.synchronize()
+        g0, g1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record(); graph1.replay(); g1e.record()
+        torch.cuda.synchronize()
+        res["other_workloads"]["c1"] = {
+            "us_per_step": el1 / K1 * 1e6, "us_per_step_device": e0.elapsed_time(e1) / K1 * 1e3,
+            "kernel_us": g0.elapsed_time(g1e) / 200 * 1e3, "value": K1 / el1, "steps": K1,
+            "workload": "1 arena x 64 beams, 100x100 map, no pedestrians (BASELINE.json configs[0])",
+            "from": "us_per_step: wall clock of %d plain launches; us_per_step_device: one HIP event pair around them; kernel_us: 200 "
+                    "of the launches replayed as one hipGraph (no host gaps) / 200" % K1}
+        del graph1, sim1, arrays1
+        torch.cuda.empty_cache()
+    except Exception as exc:
+        res["other_workloads"]["c1"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
     def gym_window(E, K=200, Wm=30, **kw):
         """K calls of NavGymEnv.step(torch float64 actions [E,2]) after reset() on the device -> dict(value, ms_per_step, envs,
         steps, reset_first_ms, reset_steady_ms).  reset_first_ms: the first reset() of a new environment (allocations, the
@@ -658,6 +748,7 @@ def extras(args, device):
         res.setdefault("gym_api", {})["pregen_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:300])
     workload_window("c5_pipelined")
     workload_window("c5_pipelined_no_rule")
+    workload_window("c5_next_step_reset")
     return res
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NAVSIM_ABI_VERSION 5
+#define NAVSIM_ABI_VERSION 6
 
 /* error codes */
 #define NAVSIM_OK            0
@@ -84,7 +84,7 @@ typedef struct navsim_config {
     int32_t n_scan_stack;    /* S: num_scan_stack (__init__.py:11) */
     int32_t ped_model;       /* NAVSIM_PED_* */
     int32_t lidar_legs;      /* robot scan renders legs of has_legs pedestrians (env.py:695-698) */
-    int32_t auto_reset;      /* 1: a done env is re-seeded from the spawn table inside step() */
+    int32_t auto_reset;      /* NAVSIM_AUTORESET_*: what happens to an arena whose episode ends (below) */
     int32_t n_spawn;         /* K: spawn table entries per env (auto_reset) */
     int32_t add_scan_noise;  /* 1: Gaussian noise on beams != range_max (env.py:437-440) */
     int32_t env_index_base;  /* global index of local env 0 (multi-GPU sharding; seeds RNG) */
@@ -222,6 +222,23 @@ typedef struct navsim_config {
                                          arena restarts is guaranteed complete regen_min_steps steps later.  0 (default): every
                                          finished arena is eligible.  Needs st->done_steps. */
 } navsim_config;
+
+/* navsim_config.auto_reset.  The reference's step() returns the LAST observation of an episode together with done = True
+ * (env.py:700-728: after a crash the re-scan at the reverted pose) and leaves reset() to its caller (env.py:730).
+ *   NONE       exactly that: nothing restarts; the caller resets (navsim_restart + navsim_reset_obs / navsim_regen).
+ *   SAME_STEP  (build-defined vector-env reset, the default of a batch) the step that ends an episode also restarts the arena
+ *              -- next start / goal pair of its spawn table, next episode number -- and io->obs holds the FIRST observation of
+ *              the new episode; the terminal observation the reference would have returned goes to io->final_obs /
+ *              io->final_goals when those are given (rows of the arenas whose done flag this call sets).
+ *   NEXT_STEP  (gymnasium's next-step mode) the step that ends an episode returns the terminal observation in io->obs like
+ *              the reference, and restarts the arena in the STATE only (pose, goal, episode number, step counter); the arena's
+ *              next call must be a reset: the caller passes io->reset_mask = the done flags of the previous call, the arena's
+ *              action is ignored, its workgroup produces the first observation (or installs the staged world,
+ *              navsim_step_install; or leaves the row to the navsim_regen that follows, cfg.defer_reset_scan) and the call
+ *              returns reward 0, done 0, info 0 for it.  A navsim_regen for such arenas takes io->done = that same mask. */
+#define NAVSIM_AUTORESET_NONE      0
+#define NAVSIM_AUTORESET_SAME_STEP 1
+#define NAVSIM_AUTORESET_NEXT_STEP 2
 
 #define NAVSIM_ACTION_TWIST  0   /* io->action = (v, omega): the reference's action (env.py:591) */
 #define NAVSIM_ACTION_WHEELS 1   /* io->action = (omega_left, omega_right) in rad/s */
@@ -383,6 +400,17 @@ typedef struct navsim_step_io {
     float*   is_success;            /* [E] info['is_success'] (env.py:475) */
     float*   is_crash;              /* [E] info['is_crash']   (env.py:476) */
     double*  distance;              /* [E] info['distance']   (env.py:474) */
+    /* ---- ABI 6 ---- */
+    /* [E, S*B+7] or NULL: the TERMINAL observation of every arena whose done flag this call sets under
+     * NAVSIM_AUTORESET_SAME_STEP -- what the reference's step() returns with done = True (env.py:700-728): scan stack, tail
+     * and, after a crash, the re-scan at the reverted pose -- written BEFORE the arena restarts; rows of other arenas are not
+     * touched.  (NONE / NEXT_STEP: io->obs itself is that row; nothing is written here.) */
+    float*   final_obs;
+    /* [E,4] or NULL: achieved_goal (2) and desired_goal (2) of that terminal observation (env.py:455-461) */
+    float*   final_goals;
+    /* [E] uint8 or NULL: arenas to RESET instead of stepping (NAVSIM_AUTORESET_NEXT_STEP: the done flags of the previous
+     * call; their state was restarted when they finished).  Must not alias io->done. */
+    const uint8_t* reset_mask;
 } navsim_step_io;
 
 /* ---- library ---------------------------------------------------------------------------- */
@@ -593,7 +621,8 @@ int    navsim_step_install_replan(const navsim_config* cfg, const navsim_state* 
  * navsim_regen_helper(s): the calling host thread's helper stream from now on (NULL / never called: one of the library's own,
  * created by navsim_prepare or the first such call).  Why a caller would choose: HIP spreads a process's streams over a few
  * hardware queues in creation order, and two streams on the same queue take turns -- NavSim times candidates against the
- * streams the helper is to run beside (nav_gym_amd/sim.py concurrent_stream). */
+ * streams the helper is to run beside (nav_gym_amd/sim.py concurrent_stream).  A helper equal to the stream of a navsim_regen
+ * call means "this call does not fork" (the per-step fallback of the pipelined reset path: its helper belongs to the passes). */
 int    navsim_regen_helper(void* stream);
 int    navsim_regen(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                     void* workspace, size_t workspace_bytes, void* stream);
@@ -774,6 +803,13 @@ int navsim_prepare(const navsim_config* cfg, const navsim_state* st, const navsi
  * NULL selects which envs are (re)initialised; others keep obs_prev -> obs copied through. */
 int navsim_reset_obs(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                      const uint8_t* mask, void* stream);
+
+/* reset() of SOME arenas, part one (env.py:730-746; ABI 6): every arena with mask[e] != 0 takes the next start / goal pair of
+ * its spawn table and the next episode number, its step counter returns to 0 (and done_steps[e], when present, records the
+ * steps of the episode that is abandoned) -- what the step does at `done` under auto-reset.  Follow it with
+ * navsim_reset_obs(mask) (same map: first observations) or navsim_regen with io->done = mask (a new world per arena).
+ * Needs the spawn tables. */
+int navsim_restart(const navsim_config* cfg, const navsim_state* st, const uint8_t* mask, void* stream);
 
 /* Name of the fused step kernel as rocprofv3 reports it (bench.py / profiles). */
 const char* navsim_step_kernel_name(void);

@@ -1138,7 +1138,15 @@ __global__ __launch_bounds__(256) void regen_swap_kernel(navsim_config c, navsim
         if (io.achieved_goal) { io.achieved_goal[2 * e] = (float)stage.robot_pose[3 * (size_t)e]; io.achieved_goal[2 * e + 1] = (float)stage.robot_pose[3 * (size_t)e + 1]; }
         if (io.desired_goal) { io.desired_goal[2 * e] = (float)stage.robot_goal[2 * (size_t)e]; io.desired_goal[2 * e + 1] = (float)stage.robot_goal[2 * (size_t)e + 1]; }
         if (live.ped_due) live.ped_due[e] = 0ull;           // new pedestrians: nobody waits for navsim_replan
-        stage_request(stage.episode, mark, e, live.episode[e] + 1);      // the world after THIS one
+    }
+    // the world after THIS one -- requested when nothing of the staged world is read any more: in the pipelined form a staging
+    // pass may take the flag while this launch still runs (round-5 advisor).  This workgroup's own copies are behind the barrier;
+    // the other slices' are not, which is why navsim_regen_swap launches the pipelined form without slot tables as ONE slice
+    // per arena (with slot tables the slices have nothing to copy; the plain form's passes are ordered behind the swap by events).
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        stage_request(stage.episode, mark, e, live.episode[e] + 1);
     }
 }
 
@@ -1168,4 +1176,21 @@ __global__ __launch_bounds__(256) void regen_clear_want_kernel(const int* __rest
         want[e] = 0;
         if (ready) ready[e] = ready[E + e];
     }
+}
+
+// navsim_restart: reset() of the arenas of `mask`, part one (env.py:730-746) -- the next start / goal pair of the arena's table
+// and the next episode number: what the step does at `done` under auto-reset, as a call of its own
+__global__ __launch_bounds__(256) void restart_kernel(navsim_config c, navsim_state st, const uint8_t* __restrict__ mask) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= c.n_envs || !mask[e]) return;
+    const uint64_t genv = (uint64_t)(c.env_index_base + e);
+    const uint64_t h = nv::hash4(c.seed, genv, (uint64_t)st.episode[e], 0x5eedULL);
+    const int idx = (int)(h % (uint64_t)c.n_spawn);
+    const double* sp = st.spawn_pose + ((size_t)e * c.n_spawn + idx) * 3;
+    const double* sg = st.spawn_goal + ((size_t)e * c.n_spawn + idx) * 2;
+    st.robot_pose[3 * (size_t)e] = sp[0]; st.robot_pose[3 * (size_t)e + 1] = sp[1]; st.robot_pose[3 * (size_t)e + 2] = sp[2];
+    st.robot_goal[2 * (size_t)e] = sg[0]; st.robot_goal[2 * (size_t)e + 1] = sg[1];
+    if (st.done_steps) st.done_steps[e] = (int32_t)st.steps[e];
+    st.episode[e] += 1;
+    st.steps[e] = 0;
 }

@@ -23,6 +23,8 @@ struct StepShared {
     unsigned long long rescan_key;  // ... of the second scan (crash revert: step_key + 1; restart: the new episode's reset key)
     int next_chunk;               // scan: next 64-beam chunk to hand to a wavefront (reset before every scan)
     int park_count, park_next;    // scan: parked rays (written / handed out), reset with next_chunk
+    int term;                     // io.final_obs of an arena that restarts in this step: 1 = its rows are scan A's, 2 = a scan of their own
+                                  // (crash: the re-scan at the reverted pose, env.py:707-723); sits in what was padding
     double wave_ratio[kMaxWaves];
 };
 // Pedestrian scratch of the pedestrian variants of the kernel, carved out of dynamic LDS behind the scan's
@@ -972,6 +974,22 @@ __device__ __forceinline__ void stage_request(int64_t* stage_episode, uint8_t* m
     __threadfence();
     atomicOr((unsigned*)(mark + (e & ~3)), 1u << (8 * (e & 3)));
 }
+// ready[e] as the last finished staging pass left it, with acquire semantics at device scope: the rows install_arena is about to
+// read were written by that pass, possibly while this launch was already running, and a line of them may sit stale in this CU's
+// vector cache from an earlier install of a neighbouring arena (round-5 advisor) -- the acquire invalidates it
+__device__ __forceinline__ long long stage_ready(const long long* ready, int e) {
+    return __hip_atomic_load(&ready[e], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+}
+// behind install_arena, whole workgroup: "stage the world after this one".  Only now -- a staging pass that takes the flag writes
+// into the slot install_arena has just handed over and over the staged rows it has just read (round-5 advisor: the request used
+// to leave in the reward block, ahead of the copies, and held only because a pass needs longer to start than an install to end)
+__device__ __forceinline__ void install_publish(const StepInstall& in, const navsim_state& live, int e) {
+    __syncthreads();                                         // every thread's loads of the staged rows and stores of the live ones
+    if (threadIdx.x == 0) {
+        __threadfence();
+        stage_request(in.stage.episode, in.mark, e, live.episode[e] + 1);
+    }
+}
 // every array navsim_regen writes, arena e, staged -> live (the list of regen_swap_kernel); whole workgroup
 template <int BLOCK>
 __device__ __forceinline__ void install_arena(const navsim_config& c, const navsim_state& live, const navsim_step_io& io,
@@ -1124,6 +1142,19 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
     double* pa_g = st.prev_action + 2 * (size_t)e;
     double* pv_g = st.prev_pose + 3 * (size_t)e;
 
+    // NAVSIM_AUTORESET_NEXT_STEP: an arena of io.reset_mask finished in the previous call and restarted in the STATE there; this
+    // call RESETS it instead of stepping it -- the reset-only path for this one workgroup (first observation from the reset key,
+    // pedestrians not advanced, action ignored), reward / done / info zero
+    const bool pending = !reset_only && io.reset_mask && io.reset_mask[e] != 0;
+    if (pending) {
+        reset_only = 1;
+        if (tid == 0) {
+            io.reward[e] = 0.0; io.done[e] = 0; io.is_success[e] = 0.0f; io.is_crash[e] = 0.0f; io.distance[e] = 0.0;
+            if (st.ped_due) st.ped_due[e] = 0ull;
+        }
+        // cfg.defer_reset_scan: the navsim_regen that follows (io->done = the same mask) writes the row
+        if (c.defer_reset_scan) return;
+    }
     if (reset_only && reset_mask && !reset_mask[e]) {          // untouched env: carry the row over
         if (obs_prev && obs_prev != obs_row)                    // (navsim_regen hands the step's own rows in: nothing to move)
             for (int k = tid; k < D; k += BLOCK) obs_row[k] = obs_prev[k];
@@ -1194,7 +1225,26 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
         const double sT = __shfl(sn, w0 + 2), cT = __shfl(cs, w0 + 2);
         if (l0 == 0) {
             sh.old_rp[0] = rp_g[0]; sh.old_rp[1] = rp_g[1]; sh.old_rp[2] = th_old;
-            sh.nseg = 0; sh.ndisc = 0; sh.rescan = 0; sh.respawn = 0;
+            sh.nseg = 0; sh.ndisc = 0; sh.rescan = 0; sh.respawn = 0; sh.term = 0;
+            if constexpr (INSTALL) {
+                if (pending) {
+                    // NEXT_STEP with staged worlds: the arena restarted (state: episode number, done_steps) when it finished; now
+                    // it takes its staged world if that is the one for the episode that starts (and the ended episode was long
+                    // enough, cfg.regen_min_steps), else it starts in place and -- no rule -- asks the caller's navsim_regen
+                    if (in->late) in->late[e] = 0;
+                    if (in->ready) {
+                        const bool lng = c.regen_min_steps <= 0 || st.done_steps[e] >= c.regen_min_steps;
+                        const bool rdy = stage_ready(in->ready, e) == (long long)st.episode[e];
+                        if (lng && rdy) sh.respawn = 3;                                // installed behind the barrier below
+                        else {
+                            if (lng && in->late) in->late[e] = 1;
+                            stage_request(in->stage.episode, in->mark, e, st.episode[e] + 1);   // what is staged carries a stale number
+                        }
+                        if (st.counters)
+                            atomicAdd(&st.counters[lng ? (rdy ? NAVSIM_COUNTER_REGEN_SERVED : NAVSIM_COUNTER_REGEN_LATE) : NAVSIM_COUNTER_REGEN_SHORT], 1ull);
+                    }
+                }
+            }
             if (!reset_only) {
                 const int64_t steps_now = st.steps[e] + 1;     // env.py:592
                 st.steps[e] = steps_now;
@@ -1217,6 +1267,13 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
         }
     }
     __syncthreads();
+    if constexpr (INSTALL) {
+        if (pending && sh.respawn == 3) {                       // NEXT_STEP: the reset of this arena IS the install of its staged world
+            install_arena<BLOCK>(c, st, io, *in, e, obs_row);
+            install_publish(*in, st, e);
+            return;
+        }
+    }
 
     NAVSIM_STAMP(1);
     // ---------------------------------------------------------------- phases 1 + 2: pedestrians, what the lidar sees of them
@@ -1287,6 +1344,7 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
                                                          st.scan_discomfort, obs_row, n_hist, noise_std, step_key, genv, crash, discomfort, false);
 
     NAVSIM_STAMP(3);
+    bool restart_next = false;                                  // (thread 0) NEXT_STEP: the state restarts behind phase 6
     if (!reset_only) {
         crash = __syncthreads_or(crash);
         discomfort = __syncthreads_or(discomfort);
@@ -1318,7 +1376,26 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
             io.is_success[e] = o.success;
             io.is_crash[e] = o.crash;
             io.distance[e] = o.distance;
-            if (o.done && c.auto_reset && c.n_spawn > 0) {      // build-defined respawn
+            const bool restart = o.done && c.auto_reset != NAVSIM_AUTORESET_NONE && c.n_spawn > 0;
+            if (restart && c.auto_reset == NAVSIM_AUTORESET_SAME_STEP) {      // build-defined respawn
+                if (io.final_obs) {
+                    // the observation the reference's step() returns with done = True (env.py:700-728), before the restart takes
+                    // the row: tail and goals here; the scan rows from scan A (term 1) or, after a crash, from the re-scan at
+                    // the reverted pose (term 2, env.py:707-723) below
+                    const bool crashed = o.crash != 0.0f;
+                    const double tx = crashed ? pv_g[0] : sh.rp[0], ty = crashed ? pv_g[1] : sh.rp[1];
+                    const double tyaw = nv::wrap_pi(crashed ? pv_g[2] : sh.rp[2]);
+                    float* ft = io.final_obs + (size_t)e * D + (size_t)S * B;
+                    ft[0] = (float)pv_g[0]; ft[1] = (float)pv_g[1];
+                    ft[2] = (float)tx; ft[3] = (float)ty;
+                    ft[4] = (float)pa_g[0]; ft[5] = (float)pa_g[1];
+                    ft[6] = (float)tyaw;
+                    if (io.final_goals) {
+                        float* fg = io.final_goals + 4 * (size_t)e;
+                        fg[0] = (float)tx; fg[1] = (float)ty; fg[2] = (float)goal_g[0]; fg[3] = (float)goal_g[1];
+                    }
+                    sh.term = crashed ? 2 : 1;
+                }
                 uint64_t h = nv::hash4(c.seed, genv, (uint64_t)st.episode[e], 0x5eedULL);
                 int idx = (int)(h % (uint64_t)c.n_spawn);
                 const double* sp = st.spawn_pose + ((size_t)e * c.n_spawn + idx) * 3;
@@ -1340,37 +1417,67 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
                 if constexpr (INSTALL) if (in->ready) {                 // (ready == NULL: a plain step on a state with slot tables)
                     // (done_steps[e] and episode[e] as this block just left them: the ended episode's length, the new number)
                     const bool lng = c.regen_min_steps <= 0 || st.done_steps[e] >= c.regen_min_steps;
-                    const bool rdy = in->ready[e] == (long long)st.episode[e];
+                    const bool rdy = stage_ready(in->ready, e) == (long long)st.episode[e];
                     if (lng && rdy) { sh.respawn = 3; sh.rescan = 0; }          // 3: the staged world is installed below
                     else if (lng && in->late) in->late[e] = 1;                  // ... or generated now, by the caller's navsim_regen
                     if (st.counters)
                         atomicAdd(&st.counters[lng ? (rdy ? NAVSIM_COUNTER_REGEN_SERVED : NAVSIM_COUNTER_REGEN_LATE) : NAVSIM_COUNTER_REGEN_SHORT], 1ull);
-                    // installed: the world after this one; not installed: the arena plays its next episode in place, what is
-                    // staged for it carries a stale number
-                    stage_request(in->stage.episode, in->mark, e, st.episode[e] + 1);
+                    // not installed: the arena plays its next episode in place, what is staged for it carries a stale number --
+                    // stage it again.  Installed: the request for the world after this one leaves BEHIND the install
+                    // (install_publish), when nothing of the staged world is read any more
+                    if (!(lng && rdy)) stage_request(in->stage.episode, in->mark, e, st.episode[e] + 1);
                 }
-            } else if (o.crash != 0.0f) {                       // env.py:707-717
-                sh.rp[0] = pv_g[0]; sh.rp[1] = pv_g[1]; sh.rp[2] = pv_g[2];
-                sh.rescan = 1;
+            } else {
+                // NONE / NEXT_STEP: the outputs are the reference's (env.py:700-728); NEXT_STEP restarts the STATE behind phase 6
+                restart_next = restart;
+                if (o.crash != 0.0f) {                          // env.py:707-717
+                    sh.rp[0] = pv_g[0]; sh.rp[1] = pv_g[1]; sh.rp[2] = pv_g[2];
+                    sh.rescan = 1;
+                }
             }
 #ifdef NAVSIM_DIAG_NO_RESCAN      // diagnostic build only (WRONG observations after a crash): what do the second scans cost the launch?
             sh.rescan = 0;               // (round 4, profiles/r04_jobs/ab_norescan.txt: c2 113.8 -> 105.3 us, c2 at 512 arenas 34.0 -> 31.1, c5 58 -> 47)
 #endif
-            if (sh.rescan) {
+        }
+        __syncthreads();
+        // ------------------------------------------------------------ the terminal row of an arena that restarts in this step
+        float* final_row = io.final_obs ? io.final_obs + (size_t)e * D : nullptr;
+        if (sh.term == 1) {
+            // no crash: the reference returns scan A (this launch wrote it to the row's last slot; visible behind the barrier),
+            // stacked on the previous rows (env.py:257-279)
+            for (int j = 0; j < S; ++j) {
+                const bool old = j < S - 1 && S - 1 - j <= n_hist;
+                for (int k = tid; k < B; k += BLOCK)
+                    final_row[(size_t)j * B + k] = old ? obs_prev[(size_t)(j + 1) * B + k] : obs_row[(size_t)(S - 1) * B + k];
+            }
+            __syncthreads();                                    // ... before scan B overwrites that slot
+        }
+        // ------------------------------------------------------------ phase 5: scan B (env.py:718-723)
+        // pass 0 (only sh.term == 2: a crash ends the episode of an arena that restarts here): the reference's re-scan at the
+        // reverted pose, into the terminal row; pass 1: the scan of the row itself -- crash revert, or the restart's first
+        // observation.  ONE call site of the scan for both.
+        for (int pass = (sh.term == 2) ? 0 : 1; pass < 2; ++pass) {
+            if (pass == 1 && !sh.rescan) break;
+            if (tid == 0) {
+                const double* at = (pass == 0) ? pv_g : sh.rp;  // (pv_g: prev_pose, untouched until phase 6)
                 sh.next_chunk = 0; sh.park_count = 0; sh.park_next = 0;
-                sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];
+                sh.lx = (float)at[0]; sh.ly = (float)at[1]; sh.lth = (float)at[2];
                 nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);
                 nv::sincos((double)sh.lth, sh.sT, sh.cT);
                 first_probe<RULE>(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
             }
-        }
-        __syncthreads();
-        // ------------------------------------------------------------ phase 5: scan B (env.py:718-723)
-        if (sh.rescan) {
-            if (sh.respawn) n_hist = 0;
+            __syncthreads();
+            if (pass == 1 && sh.respawn) n_hist = 0;
             int c2, d2;
             scan_beams_pred<BLOCK, Field, PEDS, RULE, RECT>(c, sh, field, rects, st.beam_table, prims, dir_lds, rng_lds, park, park_lanes, st.scan_threshold,
-                                                                 st.scan_discomfort, obs_row, n_hist, noise_std, sh.rescan_key, genv, c2, d2);
+                                                                 st.scan_discomfort, pass == 0 ? final_row : obs_row, n_hist, noise_std,
+                                                                 pass == 0 ? step_key + 1 : sh.rescan_key, genv, c2, d2);
+            if (pass == 0) {
+                for (int j = 0; j < S - 1; ++j)
+                    if (S - 1 - j <= n_hist)
+                        for (int k = tid; k < B; k += BLOCK) final_row[(size_t)j * B + k] = obs_prev[(size_t)(j + 1) * B + k];
+                __syncthreads();                                // every wavefront is out of the scan before its set-up is rewritten
+            }
         }
     }
 
@@ -1400,13 +1507,30 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
         else       { pa_g[0] = sh.act[0]; pa_g[1] = sh.act[1]; st.n_hist[e] = (n_hist + 1 < S - 1) ? n_hist + 1 : S - 1; }
         if (reset_only) st.steps[e] = 0;
         pv_g[0] = sh.rp[0]; pv_g[1] = sh.rp[1]; pv_g[2] = yaw;
+        if (restart_next) {
+            // NAVSIM_AUTORESET_NEXT_STEP: the row, reward, done and info above are the ended episode's; the STATE already belongs
+            // to the next one -- the start / goal pair the same-step restart would take, the next episode number -- so that the
+            // next call's reset of this arena (io.reset_mask; or the navsim_regen keyed on it) depends on nothing else
+            uint64_t h = nv::hash4(c.seed, genv, (uint64_t)st.episode[e], 0x5eedULL);
+            int idx = (int)(h % (uint64_t)c.n_spawn);
+            const double* sp = st.spawn_pose + ((size_t)e * c.n_spawn + idx) * 3;
+            const double* sg = st.spawn_goal + ((size_t)e * c.n_spawn + idx) * 2;
+            rp_g[0] = sp[0]; rp_g[1] = sp[1]; rp_g[2] = sp[2];
+            goal_g[0] = sg[0]; goal_g[1] = sg[1];
+            if (st.done_steps) st.done_steps[e] = sh.steps_now;
+            st.episode[e] += 1;
+            st.steps[e] = 0;
+        }
         if (st.arena_cost && !reset_only)
             st.arena_cost[e] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_begin);
     }
     NAVSIM_STAMP(6);
     if constexpr (INSTALL) {
         __syncthreads();                                       // what phase 6 wrote for the restart in place is overwritten
-        if (sh.respawn == 3) install_arena<BLOCK>(c, st, io, *in, e, obs_row);
+        if (sh.respawn == 3) {
+            install_arena<BLOCK>(c, st, io, *in, e, obs_row);
+            install_publish(*in, st, e);
+        }
         NAVSIM_STAMP(7);
     }
 }

@@ -413,6 +413,12 @@ static int check_step_args(const navsim_config* c, const navsim_state* st, const
     if (c->action_kind != NAVSIM_ACTION_TWIST && c->action_kind != NAVSIM_ACTION_WHEELS) return NAVSIM_E_ARG;
     if (c->action_kind == NAVSIM_ACTION_WHEELS && !(c->wheel_track > 0.0)) return NAVSIM_E_ARG;
     if (c->defer_reset_scan != 0 && c->defer_reset_scan != 1) return NAVSIM_E_ARG;
+    if (c->auto_reset < NAVSIM_AUTORESET_NONE || c->auto_reset > NAVSIM_AUTORESET_NEXT_STEP) return NAVSIM_E_ARG;
+    if (io->final_goals && !io->final_obs) return NAVSIM_E_ARG;
+    if (io->reset_mask && !reset_only) {
+        if (io->reset_mask == io->done) return NAVSIM_E_ARG;                       // the launch reads one and writes the other
+        if (c->ped_model != NAVSIM_PED_NONE && ped_split_on(c)) return NAVSIM_E_UNSUPPORTED;   // ped_update_kernel advances every arena
+    }
     if (c->regen_min_steps < 0) return NAVSIM_E_ARG;
     if (st->map_slot && c->shared_field) return NAVSIM_E_ARG;              // one map for all arenas has no slots to choose from
     if (c->ped_model != NAVSIM_PED_NONE && (c->max_waypoints < 1 || c->max_waypoints > NAVSIM_MAX_WAYPOINTS)) return NAVSIM_E_ARG;
@@ -648,6 +654,7 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     // 1.1 ms step beside 150-400 us of searches.)  NAVSIM_REGEN_FORK=0 keeps one stream.
     static const bool fork_on = !(getenv("NAVSIM_REGEN_FORK") && atoi(getenv("NAVSIM_REGEN_FORK")) == 0);
     RegenFork* fk = (fork_on && !direct && c->regen_plan) ? regen_fork() : nullptr;
+    if (fk && fk->side == s) fk = nullptr;                   // navsim_regen_helper(this call's own stream): no fork for this call
     hipStream_t sf = s;                                      // the stream of the field's kernels
     if (fk) {
         if (hipEventRecord(fk->forked, s) != hipSuccess || hipStreamWaitEvent(fk->side, fk->forked, 0) != hipSuccess) fk = nullptr;
@@ -738,6 +745,8 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     // other arenas keep the row the step just wrote -- nothing is launched for them
     navsim_step_io io2 = *io;
     io2.obs_prev = io->obs;
+    io2.reset_mask = nullptr;                                // (a reset-only launch: its mask is the kernel's own argument)
+    io2.final_obs = nullptr; io2.final_goals = nullptr;
     navsim_state st2 = *st;
     st2.arena_cost = nullptr;
     if (c->defer_reset_scan) {
@@ -834,12 +843,16 @@ int navsim_regen_swap(const navsim_config* c, const navsim_state* live, const na
     if (ready && (c->regen_min_steps < 1 || !live->done_steps)) return NAVSIM_E_ARG;    // the pipelined form rests on the rule
     const int rcp = check_stage_pair(c, live, stage);
     if (rcp != NAVSIM_OK) return rcp;
+    if (c->auto_reset != NAVSIM_AUTORESET_SAME_STEP) return NAVSIM_E_UNSUPPORTED;     // (NEXT_STEP installs inside navsim_step_install)
     if (c->n_envs == 0) return NAVSIM_OK;
     const int rcs = check_map_slots(live, stage);
     if (rcs != NAVSIM_OK) return rcs;
     SwapBig big[5] = {};
     if (!live->map_slot) stage_big_buffers(c, live, stage, big);
-    regen_swap_kernel<<<dim3(c->regen_cap, kRegenSlices), 256, 0, (hipStream_t)stream>>>(*c, *live, *stage, *io, stage_obs, want, mark, ready,
+    // (pipelined form that copies maps: one slice per arena, so that the arena's request for its next world leaves behind ALL of
+    //  its copies -- kernels_reset.hpp regen_swap_kernel)
+    const int slices = (ready && !live->map_slot) ? 1 : kRegenSlices;
+    regen_swap_kernel<<<dim3(c->regen_cap, slices), 256, 0, (hipStream_t)stream>>>(*c, *live, *stage, *io, stage_obs, want, mark, ready,
                                                                                         c->regen_cap, big[0], big[1], big[2], big[3], big[4]);
     return launch_status();
 }
@@ -1149,6 +1162,16 @@ int navsim_reset_obs(const navsim_config* c, const navsim_state* st, const navsi
     if (rc != NAVSIM_OK) return rc;
     if (c->n_envs == 0) return NAVSIM_OK;
     return dispatch_step(c, st, io, 1, mask, (hipStream_t)stream);
+}
+
+int navsim_restart(const navsim_config* c, const navsim_state* st, const uint8_t* mask, void* stream) {
+    (void)hipGetLastError();
+    if (!c || !st || !mask || c->n_envs < 0 || c->n_spawn < 1 || !st->spawn_pose || !st->spawn_goal || !st->robot_pose ||
+        !st->robot_goal || !st->episode || !st->steps)
+        return NAVSIM_E_ARG;
+    if (c->n_envs == 0) return NAVSIM_OK;
+    restart_kernel<<<(c->n_envs + 255) / 256, 256, 0, (hipStream_t)stream>>>(*c, *st, mask);
+    return launch_status();
 }
 
 const char* navsim_step_kernel_name(void) { return "navsim_step_kernel"; }

@@ -6,7 +6,7 @@ Field order and types must match include/navsim.h exactly; tests/test_abi.py com
 """
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK = 0
 E_ARG = -1
@@ -32,6 +32,8 @@ MARCH_F32_FMA = 2      # MARCH_F32 with the sample position contracted into an F
 MARCH_RULES = (MARCH_F64, MARCH_F32, MARCH_F32_FMA)
 
 STEP_ALL, STEP_NOT_DUE, STEP_DUE = 0, 1, 2      # navsim_step_part
+
+AUTORESET_NONE, AUTORESET_SAME_STEP, AUTORESET_NEXT_STEP = 0, 1, 2      # cfg.auto_reset (include/navsim.h NAVSIM_AUTORESET_*)
 
 ACTION_TWIST = 0       # io.action = (v, omega)
 ACTION_WHEELS = 1      # io.action = (omega_left, omega_right) of a skid-steer base, rad/s
@@ -197,6 +199,7 @@ class NavsimStepIO(C.Structure):
     _fields_ = [(name, _P) for name in (
         "action", "obs_prev", "obs", "achieved_goal", "desired_goal",
         "reward", "done", "is_success", "is_crash", "distance",
+        "final_obs", "final_goals", "reset_mask",          # ABI 6
     )]
 
 
@@ -253,6 +256,13 @@ IO_LAYOUT = {
     "is_success": ("float32", ("E",)),
     "is_crash": ("float32", ("E",)),
     "distance": ("float64", ("E",)),
+}
+
+
+# ABI 6: the terminal observation of arenas that restart inside the step that ends their episode (NAVSIM_AUTORESET_SAME_STEP)
+FINAL_LAYOUT = {
+    "final_obs": ("float32", ("E", "D")),
+    "final_goals": ("float32", ("E", 4)),           # achieved_goal (2), desired_goal (2) of that observation
 }
 
 
@@ -349,6 +359,7 @@ def declare(lib, suffix=""):
         sig("navsim_step_part", [cfgp, stp, iop, i32, _P])
         sig("navsim_step_replan", [cfgp, stp, iop, i32, _P])
     sig("navsim_reset_obs", [cfgp, stp, iop, _P] + stream)
+    sig("navsim_restart", [cfgp, stp, _P] + stream)
     return lib
 
 
@@ -363,7 +374,7 @@ EXPORTS = (
     "navsim_scan_threshold", "navsim_beam_table", "navsim_ped_scans", "navsim_ped_scans_part", "navsim_ped_policy_part", "navsim_regen_workspace_bytes", "navsim_regen", "navsim_regen_swap", "navsim_regen_stage", "navsim_step_install", "navsim_regen_helper", "navsim_step_install_replan",
     "navsim_costmap", "navsim_plan", "navsim_launch_order", "navsim_replan_workspace_bytes", "navsim_replan", "navsim_ped_policy_workspace_bytes", "navsim_ped_policy", "navsim_ped_scan_policy",
     "navsim_crowd_check", "navsim_crowd_angular_map", "navsim_crowd_local_map", "navsim_crowd_orca", "navsim_crowd_agent_step",
-    "navsim_step", "navsim_step_part", "navsim_step_replan", "navsim_prepare", "navsim_reset_obs", "navsim_step_kernel_name",
+    "navsim_step", "navsim_step_part", "navsim_step_replan", "navsim_prepare", "navsim_reset_obs", "navsim_restart", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math", "navsim_debug_xy_to_ij",
     "navsim_debug_gather", "navsim_debug_set_stamps", "navsim_debug_spawn_decisions",
 )

@@ -37,6 +37,16 @@ and default to the reference's behaviour for num_envs == 1:
     max_waypoints   waypoints kept per pedestrian route (default 64 = 128 m at the 2 m interval; the reference keeps
                     all of them, env.py:788-804); longer routes are stored cut, counted, and continued to the same goal
     device, seed, env_index_base (global index of arena 0: sharding), auto_reset, field_format
+    autoreset_mode  (auto_reset) 'same_step' (default): the step() that ends an arena's episode also restarts it -- the returned
+                    observation row is the FIRST of the new episode, and the observation the reference's step() returns with
+                    done = True (env.py:700-728: the last one of the episode, after a crash the re-scan at the reverted pose)
+                    is info['final_observation'] (same keys as the observation dict; rows where info['final_mask'] = done);
+                    'next_step' (gymnasium's next-step mode): step() returns that terminal observation itself, like the
+                    reference, and the arena is reset by the NEXT step() -- its action is ignored, reward 0, done False, the
+                    observation is the new episode's first one, info['reset_mask'] marks it.  final_observation=False drops
+                    the terminal rows of 'same_step' (and their second scan after a crash).
+    reset(mask)     reset() of SOME arenas (the reference's reset() is per environment, env.py:730-831): a bool / 0-1 array
+                    [num_envs]; the others keep their state and their rows.  Not with the pipelined reset path.
 
 `env.counters()` reports what the caps of the device-side reset path left unserved (arenas beyond regen_cap,
 pedestrians beyond replan_cap, routes cut at max_waypoints) since the last call.
@@ -168,7 +178,8 @@ class NavGymEnv(_EnvBase):
                  num_humans=None, device="cuda:0", seed=0, env_index_base=0, auto_reset=None,
                  field_format=abi.FIELD_U16T, n_spawn=None, randomize_maps=False, plan_paths=True,
                  action_kind="twist", clip_actions=False, max_waypoints=64, march_rule=None, use_graphs=None,
-                 regen_min_steps=0, pregen_pipeline=None, pregen_stage_cap=None):
+                 regen_min_steps=0, pregen_pipeline=None, pregen_stage_cap=None, autoreset_mode="same_step",
+                 final_observation=True):
         from . import lib
         if robot_type not in robots.ROBOTS:
             raise NotImplementedError(robot_type)            # env.py:772-773
@@ -186,7 +197,8 @@ class NavGymEnv(_EnvBase):
             env_index_base=env_index_base, auto_reset=auto_reset, field_format=field_format, n_spawn=n_spawn,
             randomize_maps=randomize_maps, plan_paths=plan_paths, action_kind=action_kind, clip_actions=clip_actions,
             max_waypoints=max_waypoints, march_rule=march_rule, use_graphs=use_graphs,
-            regen_min_steps=regen_min_steps, pregen_pipeline=pregen_pipeline, pregen_stage_cap=pregen_stage_cap)
+            regen_min_steps=regen_min_steps, pregen_pipeline=pregen_pipeline, pregen_stage_cap=pregen_stage_cap,
+            autoreset_mode=autoreset_mode, final_observation=final_observation)
         self.robot_type = robot_type
         self.time_step = time_step
         self.min_turning_radius = min_turning_radius
@@ -212,6 +224,10 @@ class NavGymEnv(_EnvBase):
         self.seed_value = int(seed)
         self.pedestrian_model = pedestrian_model
         self.auto_reset = (self.num_envs > 1) if auto_reset is None else bool(auto_reset)
+        if autoreset_mode not in ("same_step", "next_step"):
+            raise ValueError("autoreset_mode must be 'same_step' or 'next_step'")
+        self.autoreset_mode = autoreset_mode
+        self.final_observation = bool(final_observation) and self.auto_reset and autoreset_mode == "same_step"
         self._num_humans_fixed = num_humans
         self._episode_batch = 0
         self.randomize_maps = bool(randomize_maps)
@@ -277,7 +293,9 @@ class NavGymEnv(_EnvBase):
             ped = abi.PED_NONE
         cfg = lib.default_config(
             n_envs=self.num_envs, map_h=self.map_size, map_w=self.map_size, max_peds=max(nh_hi, 1),
-            n_scan_stack=num_scan_stack, ped_model=ped, lidar_legs=1, auto_reset=int(self.auto_reset),
+            n_scan_stack=num_scan_stack, ped_model=ped, lidar_legs=1,
+            auto_reset=(abi.AUTORESET_NONE if not self.auto_reset else
+                        (abi.AUTORESET_NEXT_STEP if autoreset_mode == "next_step" else abi.AUTORESET_SAME_STEP)),
             n_spawn=n_spawn, add_scan_noise=1, env_index_base=env_index_base, field_format=field_format,
             time_step=time_step, axle_offset=spec["axle_offset"], min_turning_radius=float(min_turning_radius),
             distance_threshold=distance_threshold, range_max=spec["range_max"], seed=self.seed_value)
@@ -380,14 +398,31 @@ class NavGymEnv(_EnvBase):
                 setattr(self.sim.cfg, "reward_" + k, float(getattr(self, "reward_" + k)))
 
     # ---- reset (env.py:730-831), all arenas ---------------------------------------------------------
-    def reset(self):
+    def reset(self, mask=None):
         """reset() of every arena (env.py:730-831).  Nothing is generated on the host: maps, distance fields,
         costmaps, start / goal pairs (joined by a planned path when plan_paths), pedestrians, the per-episode
         env_param draws and the first observations all come from navsim_regen with every arena marked
-        finished (NavSim.regenerate_all)."""
+        finished (NavSim.regenerate_all).
+        mask [num_envs] (bool / 0-1): reset only those arenas -- the reference's reset() is per environment -- the others
+        keep their state and their observation rows (NavSim.reset_arenas: next start / goal pair and episode number, first
+        observation; with randomize_maps a new world each)."""
         from . import lib
         lib.require_gpu()                                 # no CPU fallback: fail before any work
         import torch
+        if mask is not None:
+            if self.sim is None:
+                raise RuntimeError("reset(mask) needs one reset() of every arena first")
+            if self.pregen_pipeline:
+                raise ValueError("reset(mask) is not available with the pipelined reset path (pregen_pipeline=0 for it)")
+            m = torch.as_tensor(np.asarray(mask) if not hasattr(mask, "is_cuda") else mask).reshape(self.num_envs)
+            if self._graphed:
+                torch.cuda.synchronize(self.sim.device)
+            self.sim.reset_arenas(m, new_world=self.randomize_maps)
+            if "policy_prev_actions" in self.sim.t:       # env.py:739
+                self.sim.t["policy_prev_actions"].mul_((m.to(self.sim.device) == 0).to(self.sim.t["policy_prev_actions"].dtype)[:, None, None])
+            self._map_info = None
+            self._humans_of_episode = None
+            return self._obs_dict()
         self._bool = torch.bool
         from . import sim as simmod
         cfg = self.cfg
@@ -407,7 +442,7 @@ class NavGymEnv(_EnvBase):
             # every map of this world comes from navsim_regen, whose generators close their maps with a border wall
             # (map_generator.py:11, 61-93): the LDS form of the march may be used (include/navsim.h closed_maps)
             cfg.closed_maps = int("rect_index" in arrays)
-            self.sim = simmod.NavSim(cfg, arrays, device=self.device)
+            self.sim = simmod.NavSim(cfg, arrays, device=self.device, final_obs=self.final_observation)
             self.scan_threshold = arrays["scan_threshold"]
             self.scan_discomfort_threshold = arrays["scan_discomfort"]
             if self.pedestrian_model == "policy":
@@ -524,19 +559,38 @@ class NavGymEnv(_EnvBase):
             _, out = self.sim.step(a)                      # (a float64 tensor on the device is read in place: no copy)
             if self.pedestrian_model == "policy" and self.auto_reset:
                 # a new episode starts with prev_human_actions = 0 (env.py:739)
-                self.sim.t["policy_prev_actions"].mul_((out["done"] == 0).to(self.sim.t["policy_prev_actions"].dtype)[:, None, None])
+                started = self.sim.reset_flags if self.autoreset_mode == "next_step" else out["done"]
+                self.sim.t["policy_prev_actions"].mul_((started == 0).to(self.sim.t["policy_prev_actions"].dtype)[:, None, None])
             if self.randomize_maps and self.auto_reset:
                 self.sim.regen()
             if "costmap" in self.sim.t:
                 self.sim.replan(self.replan_cap)           # ('policy': the control block in front of the next step reads the routes)
         obs = self._obs_dict()
+        # the LAST observation of an episode that ended in this step (env.py:700-728 returns it with done = True): under
+        # same-step auto-reset the row above already is the next episode's first one and the terminal one rides in info;
+        # next-step auto-reset returns it as the observation and marks the arenas this step reset instead
+        fin = self.sim.final
         if self.num_envs == 1:
             info = {"is_success": np.float32(out["is_success"][0].item()),
                     "is_crash": np.float32(out["is_crash"][0].item()),
                     "distance": float(out["distance"][0].item())}
-            return obs, float(out["reward"][0].item()), bool(out["done"][0].item()), info
+            done = bool(out["done"][0].item())
+            if fin is not None and done:
+                g = fin["final_goals"][0].double().cpu().numpy()
+                info["final_observation"] = {"observation": fin["final_obs"][0].double().cpu().numpy(),
+                                             "achieved_goal": g[:2], "desired_goal": g[2:]}
+            if self.auto_reset and self.autoreset_mode == "next_step":
+                info["reset_mask"] = bool(self.sim.reset_flags[0].item())
+            return obs, float(out["reward"][0].item()), done, info
         info = {"is_success": out["is_success"], "is_crash": out["is_crash"], "distance": out["distance"]}
-        return obs, out["reward"], out["done"].view(self._bool), info      # (a view of the flags the kernel wrote: no kernel)
+        done = out["done"].view(self._bool)                                # (a view of the flags the kernel wrote: no kernel)
+        if fin is not None:
+            info["final_observation"] = {"observation": fin["final_obs"], "achieved_goal": fin["final_goals"][:, :2],
+                                         "desired_goal": fin["final_goals"][:, 2:]}
+            info["final_mask"] = done
+        if self.auto_reset and self.autoreset_mode == "next_step":
+            info["reset_mask"] = self.sim.reset_flags.view(self._bool)
+        return obs, out["reward"], done, info
 
     def counters(self, reset=True):
         """What the device-side reset path served and what its caps left waiting since the last call (abi.COUNTERS):
@@ -674,6 +728,9 @@ class NavGymEnv(_EnvBase):
                 sd["out.%d.%s" % (i, k)] = v.cpu().clone()
             if self.sim.due is not None:
                 sd["due.%d" % i] = self.sim.due[i].cpu().clone()
+            if self.sim.final_buf is not None:
+                for k, v in self.sim.final_buf[i].items():
+                    sd["final.%d.%s" % (i, k)] = v.cpu().clone()
         sd["cur"] = int(self.sim.cur)
         sd["steps_launched"] = int(self.sim._steps_launched)
         sd["episode_batch"] = int(self._episode_batch)
@@ -700,6 +757,10 @@ class NavGymEnv(_EnvBase):
                 v.copy_(sd["out.%d.%s" % (i, k)])
             if self.sim.due is not None:
                 self.sim.due[i].copy_(sd["due.%d" % i])
+            if self.sim.final_buf is not None:
+                for k, v in self.sim.final_buf[i].items():
+                    if "final.%d.%s" % (i, k) in sd:
+                        v.copy_(sd["final.%d.%s" % (i, k)])
         self.sim.cur = int(sd["cur"])
         if getattr(self.sim, "pregen", False):             # the staged worlds are not part of the snapshot: stage them again
             self.sim.restage_all(slots_from_live=True)

@@ -382,9 +382,13 @@ class NavSim(object):
     """E arenas resident on one GPU.  `arrays` maps navsim_state field names to numpy arrays or
     torch tensors (host or device); missing optional fields stay NULL."""
 
-    def __init__(self, cfg, arrays, device="cuda:0", launch_order=None):
+    def __init__(self, cfg, arrays, device="cuda:0", launch_order=None, final_obs=False):
         """launch_order: None = longest-first launch order when a launch runs several generations of
-        workgroups, True / False = force it on / off (a scheduling hint: results never depend on it)."""
+        workgroups, True / False = force it on / off (a scheduling hint: results never depend on it).
+        final_obs: keep the terminal observation of arenas that restart inside the step that ends their episode
+        (cfg.auto_reset = AUTORESET_SAME_STEP; include/navsim.h navsim_step_io.final_obs) -> self.final.
+        cfg.auto_reset = AUTORESET_NEXT_STEP: step() hands the done flags of the previous step to the launch as its reset mask
+        (the arenas that finished are reset by the next step; regen() then serves those arenas)."""
         torch = require_gpu()
         self.lib = load()
         self.cfg = cfg.copy()
@@ -476,6 +480,12 @@ class NavSim(object):
         self.io.action = self.action.data_ptr()
         for k, v in self.out_buf[0].items():
             setattr(self.io, k, v.data_ptr())
+        # ABI 6: terminal observations (same-step restarts), kept in pairs like everything a step returns
+        self.final_buf = None
+        if final_obs:
+            self.final_buf = [{k: torch.zeros(abi.resolve_shape(s, self.cfg), dtype=_dtype(d), device=self.device)
+                               for k, (d, s) in abi.FINAL_LAYOUT.items()} for _ in range(2)]
+        self.next_step = self.cfg.auto_reset == abi.AUTORESET_NEXT_STEP
 
     @property
     def obs(self):
@@ -486,9 +496,24 @@ class NavSim(object):
         """reward / done / is_success / is_crash / distance / achieved_goal / desired_goal of the latest step."""
         return self.out_buf[self.cur]
 
+    @property
+    def final(self):
+        """final_obs / final_goals of the latest step: rows of the arenas whose done flag that step set (others: stale)."""
+        return None if self.final_buf is None else self.final_buf[self.cur]
+
+    @property
+    def reset_flags(self):
+        """AUTORESET_NEXT_STEP: the arenas the latest step RESET (= the done flags of the step before it)."""
+        return self.out_buf[1 - self.cur]["done"]
+
     def _flip(self):
         self.io.obs_prev = self.obs_buf[self.cur].data_ptr()
         self.io.obs = self.obs_buf[1 - self.cur].data_ptr()
+        # NEXT_STEP: whoever finished in the latest step (its done flags, out_buf[cur]) is reset by the launch that follows
+        self.io.reset_mask = self.out_buf[self.cur]["done"].data_ptr() if self.next_step else None
+        if self.final_buf is not None:
+            for k, v in self.final_buf[1 - self.cur].items():
+                setattr(self.io, k, v.data_ptr())
         for k, v in self.out_buf[1 - self.cur].items():
             setattr(self.io, k, v.data_ptr())
         if self.due is not None:                    # the launch reads the latest flags and writes the other buffer
@@ -507,11 +532,16 @@ class NavSim(object):
         # a reset-only launch writes the goal arrays of the arenas it resets and nothing else: the other set starts as a copy
         for k, v in self.out_buf[1 - self.cur].items():
             v.copy_(self.out_buf[self.cur][k])
-        self._flip()
         m = None
         if mask is not None:
             import torch
             m = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
+        # an arena that is reset is not finished: its done flag (NEXT_STEP: the next launch's reset mask) is cleared
+        if m is None:
+            self.out_buf[1 - self.cur]["done"].zero_()
+        else:
+            self.out_buf[1 - self.cur]["done"].mul_(m == 0)
+        self._flip()
         check(self.lib.navsim_reset_obs(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), _ptr(m), _stream()),
               "navsim_reset_obs")
         if self.due is not None:                    # a reset-only launch advances nobody: the latest flags stay the latest
@@ -747,8 +777,16 @@ class NavSim(object):
                 io.obs = self.obs_buf[self.cur].data_ptr()
                 io.done = self.late.data_ptr()
                 self._latest_flags()
+                # this call does not fork: navsim_regen's helper stream belongs to the staging passes, whose distance transforms the
+                # fallback's (mostly empty) fork / join would queue behind -- the pass back on the step's critical path
+                # (round-5 advisor).  A helper equal to the call's own stream means "no fork" (include/navsim.h).
+                helper = getattr(self, "_regen_helper", None)
+                if helper is not None:
+                    self.lib.navsim_regen_helper(C.c_void_p(main.cuda_stream))
                 check(self.lib.navsim_regen(C.byref(self.late_cfg), C.byref(self.st), C.byref(io), _ptr(self.late_ws),
                                             self.late_ws.numel(), C.c_void_p(main.cuda_stream)), "navsim_regen (arenas whose world was not staged)")
+                if helper is not None:
+                    self.lib.navsim_regen_helper(C.c_void_p(helper.cuda_stream))
             if k % P == 0:
                 self._latest_flags()
                 self._queue_pass(main, self.pg_swapped[j % 3], self.pg_staged[j % 3])
@@ -841,10 +879,47 @@ class NavSim(object):
         io = abi.NavsimStepIO()
         C.memmove(C.byref(io), C.byref(self.io), C.sizeof(io))
         io.obs = self.obs_buf[self.cur].data_ptr()
+        if self.next_step:                              # the arenas the latest step RESET: those that finished the step before
+            io.done = self.reset_flags.data_ptr()
         self._latest_flags()
         ws = self.t["regen_ws"]
         check(self.lib.navsim_regen(C.byref(self.cfg), C.byref(self.st), C.byref(io), _ptr(ws), ws.numel(), _stream()),
               "navsim_regen")
+        return self.obs
+
+    def reset_arenas(self, mask, new_world=False, scratch_bytes=1 << 30):
+        """reset() of the arenas of `mask` (uint8 / bool [E]) alone (env.py:730-831 is per environment): navsim_restart -- the
+        next start / goal pair of the arena's table, the next episode number -- then their first observations
+        (navsim_reset_obs) on the same map, or with new_world=True a new world each (navsim_regen in chunks of cfg.regen_cap
+        arenas; worlds that draw a map per episode).  The other arenas keep their state and their rows."""
+        import torch
+        if getattr(self, "pregen", False):
+            raise ValueError("reset_arenas is not available with enable_pregen (the staged worlds follow the episodes' own order)")
+        m = torch.as_tensor(mask).to(device=self.device).ne(0).to(torch.uint8).contiguous()
+        check(self.lib.navsim_restart(C.byref(self.cfg), C.byref(self.st), _ptr(m), _stream()), "navsim_restart")
+        self.reset_obs(m)
+        if self.due is not None:                        # nobody of a reset arena waits for navsim_replan
+            self.due[self.cur].mul_(m == 0)
+        if new_world:
+            self._choose_regen_helper()
+            cfg = self.cfg.copy()
+            cfg.regen_min_steps = 0
+            if "regen_ws" not in self.t:
+                self.t["regen_ws"] = torch.zeros(self.lib.navsim_regen_workspace_bytes(C.byref(self.cfg)), dtype=torch.uint8, device=self.device)
+            ws = self.t["regen_ws"]
+            io = abi.NavsimStepIO()
+            C.memmove(C.byref(io), C.byref(self.io), C.sizeof(io))
+            io.obs = self.obs_buf[self.cur].data_ptr()
+            self._latest_flags()
+            idx = torch.nonzero(m).flatten()
+            chunk = torch.zeros_like(m)
+            io.done = chunk.data_ptr()
+            for a in range(0, int(idx.numel()), int(self.cfg.regen_cap)):
+                chunk.zero_()
+                chunk[idx[a:a + int(self.cfg.regen_cap)]] = 1
+                check(self.lib.navsim_regen(C.byref(cfg), C.byref(self.st), C.byref(io), _ptr(ws), ws.numel(), _stream()),
+                      "navsim_regen (reset of some arenas)")
+            torch.cuda.current_stream().synchronize()  # `chunk` is released on return
         return self.obs
 
     def regenerate_all(self, new_episode=False, scratch_bytes=4 << 30):
@@ -879,6 +954,8 @@ class NavSim(object):
             done[a:a + chunk] = 1
             check(self.lib.navsim_regen(C.byref(cfg), C.byref(self.st), C.byref(io), _ptr(ws), ws.numel(), _stream()),
                   "navsim_regen (reset of all arenas)")
+        for b in self.out_buf:                             # nobody is finished after a reset (NEXT_STEP: the next launch's reset mask)
+            b["done"].zero_()
         torch.cuda.current_stream().synchronize()          # `ws` and `done` are released on return
         return self.obs
 

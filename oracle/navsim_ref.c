@@ -895,12 +895,45 @@ static void pack_obs(const navsim_config* c, const float* scan, const float* obs
 /* =========================================================================================
  * a1  NavGymEnv.step (env.py:591-728) for one env
  * ======================================================================================= */
+static void reset_env(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int e, float* scan);
+
+/* the next start / goal pair of the arena's table and the next episode number: what ends an episode under auto-reset
+ * (BUILD-DEFINED vector-env reset; include/navsim.h NAVSIM_AUTORESET_*, navsim_restart) */
+static void restart_state(const navsim_config* c, const navsim_state* st, int e) {
+    const uint64_t genv = (uint64_t)(c->env_index_base + e);
+    uint64_t h = nvr_hash4(c->seed, genv, (uint64_t)st->episode[e], 0x5eedULL);
+    int idx = (int)(h % (uint64_t)c->n_spawn);
+    const double* sp = st->spawn_pose + ((size_t)e * c->n_spawn + idx) * 3;
+    const double* sg = st->spawn_goal + ((size_t)e * c->n_spawn + idx) * 2;
+    double* rp = st->robot_pose + 3 * (size_t)e;
+    rp[0] = sp[0]; rp[1] = sp[1]; rp[2] = sp[2];
+    st->robot_goal[2 * e] = sg[0]; st->robot_goal[2 * e + 1] = sg[1];
+    if (st->done_steps) st->done_steps[e] = (int32_t)st->steps[e];   /* how long the episode lasted (cfg.regen_min_steps) */
+    st->episode[e] += 1;
+    st->steps[e] = 0;
+}
+
+int navsim_restart_cpu(const navsim_config* c, const navsim_state* st, const uint8_t* mask) {
+    if (!c || !st || !mask || c->n_spawn < 1 || !st->spawn_pose || !st->spawn_goal) return NAVSIM_E_ARG;
+    for (int e = 0; e < c->n_envs; ++e) if (mask[e]) restart_state(c, st, e);
+    return NAVSIM_OK;
+}
+
 static void step_env(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int e,
                      float* scan) {
     const int B = c->n_beams, S = c->n_scan_stack, N = c->max_peds, D = S * B + 7;
     const int P = c->max_waypoints;
     const double dt = c->time_step;
     const uint64_t genv = (uint64_t)(c->env_index_base + e);
+    if (io->reset_mask && io->reset_mask[e]) {
+        /* NAVSIM_AUTORESET_NEXT_STEP: the arena finished in the previous call (its state restarted there); this call resets
+         * it -- first observation as reset() gives it (env.py:808-831), pedestrians not advanced, reward / done / info zero.
+         * cfg.defer_reset_scan: the row is left to the navsim_regen_cpu that follows (io->done = the same mask) */
+        io->reward[e] = 0.0; io->done[e] = 0; io->is_success[e] = 0.0f; io->is_crash[e] = 0.0f; io->distance[e] = 0.0;
+        if (st->ped_due && c->ped_model != NAVSIM_PED_NONE) st->ped_due[e] = 0;
+        if (!c->defer_reset_scan) reset_env(c, st, io, e, scan);
+        return;
+    }
     double a0 = io->action[2 * e], a1 = io->action[2 * e + 1];
     st->steps[e] += 1;                                                         /* env.py:592 */
     if (c->action_kind == NAVSIM_ACTION_WHEELS) {      /* BUILD-DEFINED: skid-steer wheel speeds (left, right) -> twist */
@@ -994,18 +1027,31 @@ static void step_env(const navsim_config* c, const navsim_state* st, const navsi
     float* dg = io->desired_goal ? io->desired_goal + 2 * (size_t)e : NULL;
     int n_hist = st->n_hist[e];
 
-    if (o.done && c->auto_reset && c->n_spawn > 0) {
+    const int restart = o.done && c->auto_reset != NAVSIM_AUTORESET_NONE && c->n_spawn > 0;
+    if (restart && c->auto_reset == NAVSIM_AUTORESET_SAME_STEP) {
+        if (io->final_obs) {
+            /* what the reference's step() returns with done = True (env.py:700-728), before the restart takes the row */
+            double tp[3] = {rp[0], rp[1], rp[2]};
+            double vel[2] = {pa[0], pa[1]};
+            float* tscan = scan;
+            float* tmp = NULL;
+            if (o.crash != 0.0f) {                                             /* env.py:707-723 */
+                tp[0] = pv[0]; tp[1] = pv[1]; tp[2] = pv[2];
+                tmp = (float*)malloc(sizeof(float) * (size_t)B);
+                robot_scan(c, st, e, n, tp, tmp);
+                tscan = tmp;
+            }
+            float fag[2], fdg[2];
+            pack_obs(c, tscan, obs_prev, n_hist, pv, tp, vel, goal, io->final_obs + (size_t)e * D, fag, fdg);
+            if (io->final_goals) {
+                float* fg = io->final_goals + 4 * (size_t)e;
+                fg[0] = fag[0]; fg[1] = fag[1]; fg[2] = fdg[0]; fg[3] = fdg[1];
+            }
+            free(tmp);
+        }
         /* BUILD-DEFINED vector-env reset: respawn from the table, first obs as in reset()
          * (env.py:736-738, 822-831): prev_action = 0, prev_pose = pose, stack filled */
-        uint64_t h = nvr_hash4(c->seed, genv, (uint64_t)st->episode[e], 0x5eedULL);
-        int idx = (int)(h % (uint64_t)c->n_spawn);
-        const double* sp = st->spawn_pose + ((size_t)e * c->n_spawn + idx) * 3;
-        const double* sg = st->spawn_goal + ((size_t)e * c->n_spawn + idx) * 2;
-        rp[0] = sp[0]; rp[1] = sp[1]; rp[2] = sp[2];
-        goal[0] = sg[0]; goal[1] = sg[1];
-        if (st->done_steps) st->done_steps[e] = (int32_t)st->steps[e];   /* how long the episode lasted (cfg.regen_min_steps) */
-        st->episode[e] += 1;
-        st->steps[e] = 0;
+        restart_state(c, st, e);
         double zero[2] = {0.0, 0.0};
         /* cfg.defer_reset_scan: the first observation comes from the navsim_regen call that follows (its masked
          * navsim_reset_obs over every finished arena); until then the scan rows of this row are unspecified (here: scan A) */
@@ -1022,8 +1068,38 @@ static void step_env(const navsim_config* c, const navsim_state* st, const navsi
         pack_obs(c, scan, obs_prev, n_hist, pv, rp, vel, goal, obs, ag, dg);
         pa[0] = a0; pa[1] = a1;                                                /* env.py:725 */
         st->n_hist[e] = (n_hist + 1 < S - 1) ? n_hist + 1 : S - 1;             /* env.py:727 */
+        pv[0] = rp[0]; pv[1] = rp[1]; pv[2] = nvr_wrap_pi(rp[2]);              /* env.py:726 */
+        /* NAVSIM_AUTORESET_NEXT_STEP: the outputs above are the ended episode's (what the reference returns); the state
+         * already belongs to the next one, whose first observation the next call's reset of this arena produces */
+        if (restart) restart_state(c, st, e);
+        return;
     }
     pv[0] = rp[0]; pv[1] = rp[1]; pv[2] = nvr_wrap_pi(rp[2]);                  /* env.py:726 */
+}
+
+/* first observation of ONE arena from its current state (env.py:808-831); navsim_reset_obs_cpu's body */
+static void reset_env(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, int e, float* scan) {
+    const int B = c->n_beams, S = c->n_scan_stack, N = c->max_peds, D = S * B + 7;
+    float* obs = io->obs + (size_t)e * D;
+    double* rp = st->robot_pose + 3 * (size_t)e;
+    double* goal = st->robot_goal + 2 * (size_t)e;
+    int n = (c->ped_model == NAVSIM_PED_NONE) ? 0 : st->n_peds[e];
+    if (n > N) n = N;
+    for (int i = 0; i < n; ++i) {
+        size_t q = (size_t)e * N + i;
+        st->ped_dist[q * 3] = 0.0; st->ped_dist[q * 3 + 1] = 0.0; st->ped_dist[q * 3 + 2] = 0.0; /* env.py:809 */
+        st->ped_prev_yaw[q] = nvr_wrap_pi(st->ped_pose[q * 3 + 2]);                              /* env.py:812-820 */
+    }
+    double zero[2] = {0.0, 0.0};
+    robot_scan(c, st, e, n, rp, scan);
+    pack_obs(c, scan, NULL, 0, rp, rp, zero, goal, obs,
+             io->achieved_goal ? io->achieved_goal + 2 * (size_t)e : NULL,
+             io->desired_goal ? io->desired_goal + 2 * (size_t)e : NULL);
+    st->prev_action[2 * e] = 0.0; st->prev_action[2 * e + 1] = 0.0;        /* env.py:736 */
+    st->prev_pose[3 * e] = rp[0]; st->prev_pose[3 * e + 1] = rp[1];
+    st->prev_pose[3 * e + 2] = nvr_wrap_pi(rp[2]);
+    st->n_hist[e] = (S - 1 < 1) ? S - 1 : 1;                               /* env.py:830 */
+    st->steps[e] = 0;                                                      /* env.py:735 */
 }
 
 int navsim_step_range_cpu(const navsim_config* c, const navsim_state* st, const navsim_step_io* io,
@@ -1176,7 +1252,7 @@ int navsim_reset_obs_cpu(const navsim_config* c, const navsim_state* st, const n
                          const uint8_t* mask) {
     if (!c || !st || !io || !io->obs) return NAVSIM_E_ARG;
     if (c->field_format != NAVSIM_FIELD_F32) return NAVSIM_E_UNSUPPORTED;
-    const int B = c->n_beams, S = c->n_scan_stack, N = c->max_peds, D = S * B + 7;
+    const int B = c->n_beams, S = c->n_scan_stack, D = S * B + 7;
     float* scan = (float*)malloc(sizeof(float) * (size_t)B);
     for (int e = 0; e < c->n_envs; ++e) {
         float* obs = io->obs + (size_t)e * D;
@@ -1185,25 +1261,7 @@ int navsim_reset_obs_cpu(const navsim_config* c, const navsim_state* st, const n
                 memcpy(obs, io->obs_prev + (size_t)e * D, sizeof(float) * D);
             continue;
         }
-        double* rp = st->robot_pose + 3 * (size_t)e;
-        double* goal = st->robot_goal + 2 * (size_t)e;
-        int n = (c->ped_model == NAVSIM_PED_NONE) ? 0 : st->n_peds[e];
-        if (n > N) n = N;
-        for (int i = 0; i < n; ++i) {
-            size_t q = (size_t)e * N + i;
-            st->ped_dist[q * 3] = 0.0; st->ped_dist[q * 3 + 1] = 0.0; st->ped_dist[q * 3 + 2] = 0.0; /* env.py:809 */
-            st->ped_prev_yaw[q] = nvr_wrap_pi(st->ped_pose[q * 3 + 2]);                              /* env.py:812-820 */
-        }
-        double zero[2] = {0.0, 0.0};
-        robot_scan(c, st, e, n, rp, scan);
-        pack_obs(c, scan, NULL, 0, rp, rp, zero, goal, obs,
-                 io->achieved_goal ? io->achieved_goal + 2 * (size_t)e : NULL,
-                 io->desired_goal ? io->desired_goal + 2 * (size_t)e : NULL);
-        st->prev_action[2 * e] = 0.0; st->prev_action[2 * e + 1] = 0.0;        /* env.py:736 */
-        st->prev_pose[3 * e] = rp[0]; st->prev_pose[3 * e + 1] = rp[1];
-        st->prev_pose[3 * e + 2] = nvr_wrap_pi(rp[2]);
-        st->n_hist[e] = (S - 1 < 1) ? S - 1 : 1;                               /* env.py:830 */
-        st->steps[e] = 0;                                                      /* env.py:735 */
+        reset_env(c, st, io, e, scan);
     }
     free(scan);
     return NAVSIM_OK;

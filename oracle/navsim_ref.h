@@ -99,6 +99,8 @@ int navsim_step_threads_cpu(const navsim_config* cfg, const navsim_state* st, co
 float* navsim_field_local_copy_cpu(const float* field, int32_t n_envs, int32_t map_h, int32_t map_w, int32_t n_threads);
 void navsim_free_cpu(void* p);
 
+/* reset() of some arenas, part one (include/navsim.h navsim_restart) */
+int navsim_restart_cpu(const navsim_config* cfg, const navsim_state* st, const uint8_t* mask);
 int navsim_reset_obs_cpu(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                          const uint8_t* mask);
 

@@ -404,6 +404,12 @@ class RefSim(object):
         self.cur = 0
         self.out = {k: np.zeros(abi.resolve_shape(s, self.cfg), dtype=d)
                     for k, (d, s) in abi.IO_LAYOUT.items() if k not in ("obs", "obs_prev", "action")}
+        # ABI 6: terminal observations of same-step restarts (rows of arenas whose done flag the step set; kept apart from
+        # `out`, whose arrays the tests compare whole), and NEXT_STEP's reset mask = the done flags of the previous step
+        self.final = {k: np.zeros(abi.resolve_shape(s, self.cfg), dtype=d) for k, (d, s) in abi.FINAL_LAYOUT.items()}
+        self.next_step = self.cfg.auto_reset == abi.AUTORESET_NEXT_STEP
+        self.prev_done = np.zeros(E, np.uint8)          # the done flags of the latest step
+        self.reset_flags = np.zeros(E, np.uint8)        # the arenas the latest step reset
 
     def _io(self, action):
         io = abi.NavsimStepIO()
@@ -413,7 +419,22 @@ class RefSim(object):
         io.obs = self.obs[1 - self.cur].ctypes.data
         for k, v in self.out.items():
             setattr(io, k, v.ctypes.data)
+        for k, v in self.final.items():
+            setattr(io, k, v.ctypes.data)
+        if self.next_step and action is not None:
+            self.reset_flags[:] = self.prev_done
+            io.reset_mask = self.reset_flags.ctypes.data
         return io
+
+    def restart(self, mask):
+        """navsim_restart_cpu + navsim_reset_obs_cpu: reset() of the arenas of `mask` alone (same maps)."""
+        m = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+        L = lib()
+        L.navsim_restart_cpu.argtypes = [C.POINTER(abi.NavsimConfig), C.POINTER(abi.NavsimState), C.c_void_p]
+        _chk(L.navsim_restart_cpu(C.byref(self.cfg), C.byref(self.st), _p(m)), "restart")
+        if "ped_due" in self.a:
+            self.a["ped_due"][m != 0] = 0
+        return self.reset_obs(m)
 
     def set_ped_cmd(self, cmd):
         self.a["ped_cmd"][...] = cmd
@@ -425,6 +446,8 @@ class RefSim(object):
         io.obs = self.obs[self.cur].ctypes.data
         for k, v in self.out.items():
             setattr(io, k, v.ctypes.data)
+        if self.next_step:                          # the arenas the latest step reset: those that finished the step before
+            io.done = self.reset_flags.ctypes.data
         _chk(lib().navsim_regen_cpu(C.byref(self.cfg), C.byref(self.st), C.byref(io)), "regen")
         return self.obs[self.cur]
 
@@ -458,6 +481,10 @@ class RefSim(object):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         _chk(lib().navsim_reset_obs_cpu(C.byref(self.cfg), C.byref(self.st), C.byref(io), _p(m)), "reset_obs")
         self.cur = 1 - self.cur
+        if m is None:                               # an arena that is reset is not finished
+            self.prev_done[:] = 0; self.out["done"][:] = 0
+        else:
+            self.prev_done[m != 0] = 0; self.out["done"][m != 0] = 0
         return self.obs[self.cur]
 
     def step(self, action, e0=None, e1=None):
@@ -467,6 +494,7 @@ class RefSim(object):
         else:
             _chk(lib().navsim_step_range_cpu(C.byref(self.cfg), C.byref(self.st), C.byref(io), e0, e1), "step_range")
         self.cur = 1 - self.cur
+        self.prev_done[:] = self.out["done"]
         return self.obs[self.cur], self.out
 
     def step_native_threads(self, actions, n_threads):
