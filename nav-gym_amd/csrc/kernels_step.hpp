@@ -1100,7 +1100,13 @@ __device__ __forceinline__ void install_arena(const navsim_config& c, const navs
 // launches behind ped_update_kernel: no pedestrian phase, Scratch_Size 0.
 // INSTALL (navsim_step_install): an arena that finishes takes its staged world instead of restarting in place, when its episode
 // was long enough (cfg.regen_min_steps) and the staged world is the one for the episode that starts (in->ready).
-template <int BLOCK, bool PEDS, typename Field, int RULE, int RECT, bool PINL, bool INSTALL = false>
+// FEAT (ABI 6): the terminal observation of an arena that restarts in the step that ends its episode (io.final_obs) and
+// NAVSIM_AUTORESET_NEXT_STEP (io.reset_mask) are compiled in.  The pedestrian variants always carry them; the variants without
+// pedestrians exist in both forms and the host takes the plain one for calls that use neither -- the code of round 5, whose
+// register allocation in the probe loop the few extra live values of these paths disturb: measured on c2, same box, the one
+// kernel with everything in it 42.3 M env-steps/s against 43.0 M, and 41.1-41.5 M for two semantically equal formulations of the
+// new paths (profiles/r06_abi6/: the probe loop has the same 60 instructions in all of them and other registers).
+template <int BLOCK, bool PEDS, typename Field, int RULE, int RECT, bool PINL, bool INSTALL = false, bool FEAT = true>
 __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_state& st, const navsim_step_io& io, const int e,
                                            int reset_only, const int peds_done, const uint8_t* __restrict__ reset_mask,
                                            unsigned dyn_lds_bytes, int park_lanes, unsigned rect_lds_offset,
@@ -1145,7 +1151,8 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
     // NAVSIM_AUTORESET_NEXT_STEP: an arena of io.reset_mask finished in the previous call and restarted in the STATE there; this
     // call RESETS it instead of stepping it -- the reset-only path for this one workgroup (first observation from the reset key,
     // pedestrians not advanced, action ignored), reward / done / info zero
-    const bool pending = !reset_only && io.reset_mask && io.reset_mask[e] != 0;
+    constexpr bool kFeat = PEDS || FEAT;
+    const bool pending = kFeat && !reset_only && io.reset_mask && io.reset_mask[e] != 0;
     if (pending) {
         reset_only = 1;
         if (tid == 0) {
@@ -1378,7 +1385,7 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
             io.distance[e] = o.distance;
             const bool restart = o.done && c.auto_reset != NAVSIM_AUTORESET_NONE && c.n_spawn > 0;
             if (restart && c.auto_reset == NAVSIM_AUTORESET_SAME_STEP) {      // build-defined respawn
-                if (io.final_obs) {
+                if (kFeat && io.final_obs) {
                     // the observation the reference's step() returns with done = True (env.py:700-728), before the restart takes
                     // the row: tail and goals here; the scan rows from scan A (term 1) or, after a crash, from the re-scan at
                     // the reverted pose (term 2, env.py:707-723) below
@@ -1429,7 +1436,7 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
                 }
             } else {
                 // NONE / NEXT_STEP: the outputs are the reference's (env.py:700-728); NEXT_STEP restarts the STATE behind phase 6
-                restart_next = restart;
+                restart_next = kFeat && restart;
                 if (o.crash != 0.0f) {                          // env.py:707-717
                     sh.rp[0] = pv_g[0]; sh.rp[1] = pv_g[1]; sh.rp[2] = pv_g[2];
                     sh.rescan = 1;
@@ -1438,45 +1445,65 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
 #ifdef NAVSIM_DIAG_NO_RESCAN      // diagnostic build only (WRONG observations after a crash): what do the second scans cost the launch?
             sh.rescan = 0;               // (round 4, profiles/r04_jobs/ab_norescan.txt: c2 113.8 -> 105.3 us, c2 at 512 arenas 34.0 -> 31.1, c5 58 -> 47)
 #endif
+            if constexpr (!kFeat) {
+                if (sh.rescan) {                                // the plain form: the second scan's set-up here, one barrier
+                    sh.next_chunk = 0; sh.park_count = 0; sh.park_next = 0;
+                    sh.lx = (float)sh.rp[0]; sh.ly = (float)sh.rp[1]; sh.lth = (float)sh.rp[2];
+                    nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);
+                    nv::sincos((double)sh.lth, sh.sT, sh.cT);
+                    first_probe<RULE>(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
+                }
+            }
         }
         __syncthreads();
-        // ------------------------------------------------------------ the terminal row of an arena that restarts in this step
-        float* final_row = io.final_obs ? io.final_obs + (size_t)e * D : nullptr;
-        if (sh.term == 1) {
-            // no crash: the reference returns scan A (this launch wrote it to the row's last slot; visible behind the barrier),
-            // stacked on the previous rows (env.py:257-279)
-            for (int j = 0; j < S; ++j) {
-                const bool old = j < S - 1 && S - 1 - j <= n_hist;
-                for (int k = tid; k < B; k += BLOCK)
-                    final_row[(size_t)j * B + k] = old ? obs_prev[(size_t)(j + 1) * B + k] : obs_row[(size_t)(S - 1) * B + k];
+        if constexpr (!kFeat) {
+            // ------------------------------------------------------------ phase 5: scan B (env.py:718-723) -- the plain form
+            if (sh.rescan) {
+                if (sh.respawn) n_hist = 0;
+                int c2, d2;
+                scan_beams_pred<BLOCK, Field, PEDS, RULE, RECT>(c, sh, field, rects, st.beam_table, prims, dir_lds, rng_lds, park, park_lanes, st.scan_threshold,
+                                                                     st.scan_discomfort, obs_row, n_hist, noise_std, sh.rescan_key, genv, c2, d2);
             }
-            __syncthreads();                                    // ... before scan B overwrites that slot
-        }
-        // ------------------------------------------------------------ phase 5: scan B (env.py:718-723)
-        // pass 0 (only sh.term == 2: a crash ends the episode of an arena that restarts here): the reference's re-scan at the
-        // reverted pose, into the terminal row; pass 1: the scan of the row itself -- crash revert, or the restart's first
-        // observation.  ONE call site of the scan for both.
-        for (int pass = (sh.term == 2) ? 0 : 1; pass < 2; ++pass) {
-            if (pass == 1 && !sh.rescan) break;
-            if (tid == 0) {
-                const double* at = (pass == 0) ? pv_g : sh.rp;  // (pv_g: prev_pose, untouched until phase 6)
-                sh.next_chunk = 0; sh.park_count = 0; sh.park_next = 0;
-                sh.lx = (float)at[0]; sh.ly = (float)at[1]; sh.lth = (float)at[2];
-                nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);
-                nv::sincos((double)sh.lth, sh.sT, sh.cT);
-                first_probe<RULE>(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
+        } else {
+            // ------------------------------------------------------------ the terminal row of an arena that restarts in this step
+            float* final_row = io.final_obs ? io.final_obs + (size_t)e * D : nullptr;
+            const int term = sh.term;
+            if (term == 1) {
+                // no crash: the reference returns scan A (this launch wrote it to the row's last slot; visible behind the barrier),
+                // stacked on the previous rows (env.py:257-279)
+                for (int j = 0; j < S; ++j) {
+                    const bool old = j < S - 1 && S - 1 - j <= n_hist;
+                    for (int k = tid; k < B; k += BLOCK)
+                        final_row[(size_t)j * B + k] = old ? obs_prev[(size_t)(j + 1) * B + k] : obs_row[(size_t)(S - 1) * B + k];
+                }
+                __syncthreads();                                    // ... before scan B overwrites that slot
             }
-            __syncthreads();
-            if (pass == 1 && sh.respawn) n_hist = 0;
-            int c2, d2;
-            scan_beams_pred<BLOCK, Field, PEDS, RULE, RECT>(c, sh, field, rects, st.beam_table, prims, dir_lds, rng_lds, park, park_lanes, st.scan_threshold,
-                                                                 st.scan_discomfort, pass == 0 ? final_row : obs_row, n_hist, noise_std,
-                                                                 pass == 0 ? step_key + 1 : sh.rescan_key, genv, c2, d2);
-            if (pass == 0) {
-                for (int j = 0; j < S - 1; ++j)
-                    if (S - 1 - j <= n_hist)
-                        for (int k = tid; k < B; k += BLOCK) final_row[(size_t)j * B + k] = obs_prev[(size_t)(j + 1) * B + k];
-                __syncthreads();                                // every wavefront is out of the scan before its set-up is rewritten
+            // ------------------------------------------------------------ phase 5: scan B (env.py:718-723)
+            // pass 0 (only sh.term == 2: a crash ends the episode of an arena that restarts here): the reference's re-scan at the
+            // reverted pose, into the terminal row; pass 1: the scan of the row itself -- crash revert, or the restart's first
+            // observation.  ONE call site of the scan for both.
+            for (int pass = (term == 2) ? 0 : 1; pass < 2; ++pass) {
+                if (pass == 1 && !sh.rescan) break;
+                if (tid == 0) {
+                    const double* at = (pass == 0) ? pv_g : sh.rp;  // (pv_g: prev_pose, untouched until phase 6)
+                    sh.next_chunk = 0; sh.park_count = 0; sh.park_next = 0;
+                    sh.lx = (float)at[0]; sh.ly = (float)at[1]; sh.lth = (float)at[2];
+                    nv::xy_to_ij_f32(sh.lx, sh.ly, c, sh.i0, sh.j0);
+                    nv::sincos((double)sh.lth, sh.sT, sh.cT);
+                    first_probe<RULE>(field, sh.i0, sh.j0, (float)((long long)c.map_h * c.map_w), sh.t1, sh.r_all);
+                }
+                __syncthreads();
+                if (pass == 1 && sh.respawn) n_hist = 0;
+                int c2, d2;
+                scan_beams_pred<BLOCK, Field, PEDS, RULE, RECT>(c, sh, field, rects, st.beam_table, prims, dir_lds, rng_lds, park, park_lanes, st.scan_threshold,
+                                                                     st.scan_discomfort, pass == 0 ? final_row : obs_row, n_hist, noise_std,
+                                                                     pass == 0 ? step_key + 1 : sh.rescan_key, genv, c2, d2);
+                if (pass == 0) {
+                    for (int j = 0; j < S - 1; ++j)
+                        if (S - 1 - j <= n_hist)
+                            for (int k = tid; k < B; k += BLOCK) final_row[(size_t)j * B + k] = obs_prev[(size_t)(j + 1) * B + k];
+                    __syncthreads();                                // every wavefront is out of the scan before its set-up is rewritten
+                }
             }
         }
     }
@@ -1537,7 +1564,7 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
 
 // The fused step.  One workgroup = one arena (template arguments: step_arena).  reset_only: bit 0 = a reset-only launch, bit 1 =
 // ped_update_kernel has advanced the pedestrians, bits 2-3 = the NAVSIM_STEP_* part of navsim_step_part.
-template <int BLOCK, bool PEDS, typename Field, int RULE, int RECT, bool PINL>
+template <int BLOCK, bool PEDS, typename Field, int RULE, int RECT, bool PINL, bool FEAT = true>
 // Wavefronts per SIMD the kernel is compiled for = its register budget.  The 256-thread pedestrian variants with the index
 // rows in LDS are resident at FIVE workgroups per CU (plan_step: 30 KB of LDS each) -- five wavefronts per SIMD, 96 registers
 // each; compiled for eight (64 registers, like every other variant, whose residency the wave slots bound) they spilled
@@ -1562,7 +1589,7 @@ void navsim_step_kernel(navsim_config c, navsim_state st,
     // navsim_step_part, NAVSIM_STEP_NOT_DUE: the other launch of the pair (navsim_step_due_kernel) steps the arenas with a
     // pedestrian that waited for navsim_replan when the previous step ended
     if (part == NAVSIM_STEP_NOT_DUE && st.ped_due_prev[e] != 0ull) return;
-    step_arena<BLOCK, PEDS, Field, RULE, RECT, PINL>(c, st, io, e, reset_only, peds_done, reset_mask, dyn_lds_bytes, park_lanes, rect_lds_offset);
+    step_arena<BLOCK, PEDS, Field, RULE, RECT, PINL, false, FEAT>(c, st, io, e, reset_only, peds_done, reset_mask, dyn_lds_bytes, park_lanes, rect_lds_offset);
 }
 
 // navsim_step_install: the step whose finished arenas install their staged worlds themselves (step_arena INSTALL).  Also every

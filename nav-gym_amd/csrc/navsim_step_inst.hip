@@ -65,6 +65,18 @@ int launch_step_pinl(const navsim_config* c, const navsim_state* st, const navsi
         }
     }
     if (reset_only & 16) return NAVSIM_E_UNSUPPORTED;
+    if constexpr (!PEDS) {
+        // the plain form (kernels_step.hpp step_arena FEAT = false: no terminal observation, no next-step reset compiled in) for
+        // the calls that use neither -- round 5's code, and what the c2 / c4 bench lines run
+        const bool feat = io->final_obs || io->reset_mask || c->auto_reset == NAVSIM_AUTORESET_NEXT_STEP;
+        if (!feat) {
+            if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL, false>, p.lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
+            if (g_prepare_only) return NAVSIM_OK;
+            navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL, false><<<grid > 0 ? grid : c->n_envs, BLOCK, p.lds, s>>>(
+                *c, *st, *io, reset_only, mask, (unsigned)step_lds_scan_bytes(c, p.park), p.park, p.rect_off);
+            return NAVSIM_OK;
+        }
+    }
     if (allow_lds((const void*)navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL>, p.lds) != NAVSIM_OK) return NAVSIM_E_UNSUPPORTED;
     if (g_prepare_only) return NAVSIM_OK;
     navsim_step_kernel<BLOCK, PEDS, Field, RULE, RECT, PINL><<<grid > 0 ? grid : c->n_envs, BLOCK, p.lds, s>>>(

@@ -247,9 +247,15 @@ def test_next_step_autoreset_with_the_pipelined_reset_path(gpu, monkeypatch, per
                 gpu.torch.cuda._sleep(200_000_000)
             return _stage(*a)
         monkeypatch.setattr(g.lib, "navsim_regen_stage", delayed)
+    # ... and no pass at all is queued in two windows of the rollout: whoever ends two episodes inside one finds nothing staged
+    # the second time, whatever the box's timing (the requests wait in mark[] for the first pass behind the window)
+    hold = {"on": False}
+    queue = g._queue_pass
+    monkeypatch.setattr(g, "_queue_pass", lambda *a: None if hold["on"] else queue(*a))
     rng = np.random.default_rng(14)
     n_reset = 0
     for t in range(110):
+        hold["on"] = slow and (28 <= t <= 36 or 58 <= t <= 66)
         act = _actions(rng, cfg, t)
         go, gout = g.step(gpu.torch.from_numpy(act).to(gpu.dev))
         ro, rout = r.step(act)
@@ -363,3 +369,91 @@ def test_env_autoreset_modes_and_reset_mask(gpu):
     assert torch.equal(c.sim.t["episode"].cpu(), ep.cpu() + torch.from_numpy(mask.astype(np.int64)))
     for e_ in (a, b, c):
         e_.close()
+
+
+@pytest.mark.parametrize("name", ["c5", "c4"])
+def test_eight_shards_equal_one_world_at_the_configured_totals(gpu, name):
+    """SURVEY.md 8e's parity clause at BASELINE's own totals, on one GPU: c4's 16 384 arenas resp. c5's 4 096 as the EIGHT
+    shards an 8-GPU job runs (2048 / 512 arenas each, env_index_base = 0, 2048, ... / 0, 512, ...), built and stepped one
+    after the other exactly as bench.py builds a rank's share, against ONE world holding all of them: every output of
+    every step and the final state, bit for bit, in global arena order -- the order in which sharding.RowGather delivers
+    the shards' rows (tests/test_host_logic.py runs that gather with eight gloo ranks at these shard sizes)."""
+    import bench
+    torch = gpu.torch
+    wl = dict(bench.WORKLOADS[name]); wl["field"] = "u16t"
+    G, per, total = 8, wl["envs"], wl["total"]
+    assert G * per == total
+    regen = bool(wl.get("regen"))
+    steps = 6
+    g = torch.Generator(device=gpu.dev); g.manual_seed(21)
+    acts = torch.rand((steps, total, 2), generator=g, device=gpu.dev, dtype=torch.float64)
+    lin_hi, rot_hi = (1.0, 2.0) if wl.get("robot") == "husky" else (0.5, 0.64)
+    acts[..., 0] *= lin_hi; acts[..., 1] = (acts[..., 1] * 2.0 - 1.0) * rot_hi
+    skip = ("arena_cost", "launch_order", "counters", "regen_ws", "beam_table", "scan_threshold", "scan_discomfort")
+    shared = ("scan_threshold", "scan_discomfort")
+    big, rows, finals = {}, [[] for _ in range(steps)], {}
+    cfg_big = None
+    for r in range(G):                                           # the shards, one after the other
+        cfg, sim, arrays, occ = bench.build_sim(wl, r * per, per)
+        assert cfg.env_index_base == r * per and cfg.n_envs == per
+        if r == 0:
+            cfg_big = cfg.copy(); cfg_big.n_envs = total; cfg_big.env_index_base = 0
+            if regen:
+                cfg_big.regen_cap = G * cfg.regen_cap            # (a rank serves up to its own cap: the one world must serve them all)
+        for k, v in sim.t.items():                               # its initial state -> its slice of the one world
+            if k in skip and k not in shared:
+                continue
+            if k in shared:
+                big.setdefault(k, v.clone())
+                continue
+            if k not in big:
+                lead = v.numel() // per if v.dim() == 1 and k == "field" else None
+                shape = (total * lead,) if lead else (total,) + tuple(v.shape[1:])
+                big[k] = torch.empty(shape, dtype=v.dtype, device=v.device)
+            if v.dim() == 1 and k == "field":
+                n = v.numel()
+                big[k][r * n:(r + 1) * n].copy_(v)
+            else:
+                big[k][r * per:(r + 1) * per].copy_(v)
+        big.setdefault("obs0", torch.empty((total, sim.obs.shape[1]), dtype=sim.obs.dtype, device=gpu.dev))[r * per:(r + 1) * per].copy_(sim.obs)
+        if regen and r == 0:
+            on_goal = torch.as_tensor([2, 3, 100, 300, 511], device=gpu.dev)
+        for t in range(steps):
+            if regen and t in (0, 3):                            # c5: a few arenas of EVERY shard finish and get new worlds
+                sim.t["robot_goal"][on_goal] = sim.t["robot_pose"][on_goal, :2]
+            o, out = sim.step(acts[t, r * per:(r + 1) * per])
+            if regen:
+                assert int(out["done"].sum()) <= cfg.regen_cap
+                o = sim.regen()
+            rows[t].append((o.clone(), {k: v.clone() for k, v in sim.out.items()}))
+        for k in ("robot_pose", "robot_goal", "prev_pose", "prev_action", "episode", "steps", "n_hist", "n_peds", "ped_pose", "ped_vel",
+                  "ped_dist", "spawn_pose", "spawn_goal"):
+            if k in sim.t:
+                finals.setdefault(k, []).append(sim.t[k].clone())
+        sim.close()
+        del sim, arrays, occ
+        torch.cuda.empty_cache()
+    obs0 = big.pop("obs0")
+    one = gpu.sim.NavSim(cfg_big, big)
+    del big
+    torch.cuda.empty_cache()
+    one.obs_buf[one.cur].copy_(obs0)
+    for t in range(steps):
+        if regen and t in (0, 3):
+            idx = torch.cat([on_goal + r * per for r in range(G)])
+            one.t["robot_goal"][idx] = one.t["robot_pose"][idx, :2]
+        o, out = one.step(acts[t])
+        if regen:
+            assert int(out["done"].sum()) <= cfg_big.regen_cap
+            o = one.regen()
+            out = one.out
+        assert torch.equal(o, torch.cat([x[0] for x in rows[t]])), "observations at step %d" % t
+        for k in out:
+            assert torch.equal(out[k], torch.cat([x[1][k] for x in rows[t]])), "%s at step %d" % (k, t)
+    for k, parts in finals.items():
+        assert torch.equal(one.t[k], torch.cat(parts)), "state %s after %d steps" % (k, steps)
+    if regen:
+        assert int(one.t["episode"].sum().item()) >= 2 * G       # worlds WERE regenerated, in every shard
+    one.close()
+    del one
+    torch.cuda.empty_cache()

@@ -309,6 +309,46 @@ def test_two_rank_sharding_over_gloo(tmp_path):
     assert "SHARD_OK" in outs[0]
 
 
+_GATHER8 = r"""
+import os, sys
+sys.path[:0] = [%(root)r + "/nav-gym_amd"]
+import torch, torch.distributed as dist
+from nav_gym_amd.sharding import shard_range, RowGather
+rank, ws = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=ws)
+ok = True
+for total, D in ((16384, 3), (4096, 5), (4099, 2)):        # c4's and c5's totals over 8 ranks (2048 / 512 rows each), and a ragged one
+    start, count = shard_range(total, rank, ws)
+    rows = (torch.arange(start, start + count, dtype=torch.float32)[:, None] * 8.0 + torch.arange(D, dtype=torch.float32)[None, :])
+    g = RowGather(total, (D,), torch.float32, "cpu", rank, ws)
+    assert g.equal == (total %% ws == 0) and g.count == count
+    for rep in range(2):                                   # the resident buffers serve every call
+        out = g.run(rows + rep)
+        want = torch.arange(total, dtype=torch.float32)[:, None] * 8.0 + torch.arange(D, dtype=torch.float32)[None, :] + rep
+        ok = ok and torch.equal(out, want)
+if rank == 0:
+    print("GATHER8_OK" if ok else "GATHER8_BAD")
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_row_gather_delivers_eight_shards_in_global_arena_order(tmp_path):
+    """sharding.RowGather with EIGHT gloo ranks at the shard sizes of BASELINE's 8-GPU configs (c4: 16 384 arenas = 8 x 2048,
+    c5: 4 096 = 8 x 512) and a ragged total: what every rank receives is the shards' rows concatenated in rank order =
+    global arena order -- the layout tests/test_gpu_autoreset.py::test_eight_shards_equal_one_world_at_the_configured_totals
+    compares against one world holding all arenas."""
+    script = tmp_path / "gather8.py"
+    script.write_text(_GATHER8 % {"root": ROOT})
+    port = 31500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(8):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GATHER8_OK" in outs[0], outs[0]
+
+
 def _bench(args, **env):
     e = dict(os.environ, OMP_NUM_THREADS="1", **env)
     e.pop("WORLD_SIZE", None); e.pop("RANK", None)
