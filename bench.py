@@ -408,6 +408,11 @@ def main():
                          "one that finishes before its world is staged is regenerated on the spot (navsim_regen after every step)")
     ap.add_argument("--pregen-swap-kernel", action="store_true",
                     help="with --pregen-pipeline: install the staged worlds with navsim_regen_swap after the step instead of inside it (A/B)")
+    ap.add_argument("--autoreset", default="same_step", choices=["same_step", "next_step"],
+                    help="what ends an episode (include/navsim.h NAVSIM_AUTORESET_*): same_step = the arena restarts inside the step "
+                         "that ends its episode (the bench's form since round 1); next_step = that step returns the terminal "
+                         "observation and the NEXT one resets the arena (gymnasium's next-step mode)")
+    ap.add_argument("--only-windows", default="", help="diagnostic: print only these windows of other_workloads (comma-separated) and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="replay the K timed steps as one captured hipGraph: auto = where a step is several launches (c5's "
@@ -437,6 +442,11 @@ def main():
     dist = None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the product path has no CPU fallback")
+    if args.only_windows:
+        res = extras(args, "cuda:0")
+        for k, v in res["other_workloads"].items():
+            print(k, json.dumps({kk: vv for kk, vv in v.items() if kk in ("value", "ms_per_step", "kernel_ms", "regen_counters", "error", "launch")}))
+        return
     # Libraries write to the process's stdout behind Python's back -- RCCL prints a version banner through C stdio, which a
     # redirected stdout holds until the process EXITS, i.e. after the result line (seen with NAVSIM_BENCH_FORCE_DIST=1 on the
     # one-GPU box).  The contract is ONE json line on stdout: file descriptor 1 is stderr for the rest of the run, and the line
@@ -515,9 +525,11 @@ def extras(args, device):
         if name.startswith("c5_pipelined"):
             wl.update(pregen=True, pipeline=4, install=True, no_rule=name.endswith("no_rule"))
         if name.startswith("c5_next_step"):
-            # gymnasium's next-step auto-reset (NAVSIM_AUTORESET_NEXT_STEP): a finished arena returns its terminal observation and
-            # is reset by the NEXT call -- its workgroup installs the staged world at the front of the launch instead of
-            # stepping; no rule (cfg.regen_min_steps = 0: a new map at every reset, like the reference)
+            # gymnasium's next-step auto-reset (NAVSIM_AUTORESET_NEXT_STEP): a finished arena returns its terminal observation (after
+            # a crash the reference's re-scan at the reverted pose: a second scan same-step restarts without final_obs never pay)
+            # and is reset by the NEXT call -- its workgroup installs the staged world at the front of the launch instead of
+            # stepping; an arena that found nothing staged when its episode ended is regenerated BESIDE that launch on a third
+            # stream (navsim_step_install_next); no rule (cfg.regen_min_steps = 0: a new map at every reset, like the reference)
             wl.update(pregen=True, pipeline=4, install=True, no_rule=True, next_step=True)
         try:
             cfg, sim, arrays, _ = build_sim(wl, 0, wl["envs"], device=device)
@@ -609,6 +621,10 @@ def extras(args, device):
             torch.cuda.empty_cache()
         except Exception as exc:                              # an extra must not cost the run its line
             res["other_workloads"][name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+    if getattr(args, "only_windows", None):                  # diagnostic: just these windows of other_workloads
+        for name in args.only_windows.split(","):
+            workload_window(name)
+        return res
     for name in ("c3", "c4", "c5"):
         workload_window(name)
     # BASELINE.json configs[0]: ONE arena, 64 beams, 100 x 100 map, no pedestrians -- a launch of one 64-thread workgroup;
@@ -772,6 +788,7 @@ def measure(args, scaling, ctx, light=False):
     wl["pipeline"] = int(args.pregen_pipeline)
     wl["install"] = not args.pregen_swap_kernel
     wl["no_rule"] = bool(args.pregen_no_rule)
+    wl["next_step"] = args.autoreset == "next_step"
     wl["defer_reset_scan"] = args.defer_reset_scan
     base, E_local = shard_of(wl, scaling, rank, world_size)
     E_total = wl["total"] if scaling == "strong" else world_size * wl["envs"]

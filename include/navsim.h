@@ -61,7 +61,12 @@ extern "C" {
  *   setup.py builds with -O3 -march=native -ffast-math, and GCC contracts a * b + c into one fused multiply-add
  *   wherever the target has FMA (-ffp-contract=fast is GCC's default outside ISO mode), i.e. the sample position
  *   becomes fmaf(dir, t, x0) on every x86 since Haswell: NAVSIM_MARCH_F32_FMA.  (The hit distance
- *   sqrtf(xd * xd + yd * yd) is unaffected: xd, yd are integers below 2^12, both products are exact.) */
+ *   sqrtf(xd * xd + yd * yd) is unaffected: xd, yd are integers below 2^12, both products are exact.)
+ *   A fourth family of last-bit differences has NO switch: upstream takes the ray direction from the C library's cosf / sinf
+ *   of the float heading, this build from the correctly rounded fl32(cos64(fl64(heading))).  Measured (round 6,
+ *   tests/test_oracle_crosscheck.py direction_rounding_sensitivity, 10^7 rays on twenty 500 x 500 maps, glibc 2.35): the two
+ *   differ in dx or dy for 2.6 % of the headings, and 2 rays in 10^7 then change their hit cell (one ulp on either component
+ *   changes about 100 in 10^7) -- an order of magnitude below the rules above (26 and 62 in 10^7). */
 #define NAVSIM_MARCH_F64     0   /* t += max(fl32(fl64(d) * 0.999), 1): a double coefficient */
 #define NAVSIM_MARCH_F32     1   /* t += max(d * 0.999f, 1): the float member `step_coeff` of the source (default) */
 #define NAVSIM_MARCH_F32_FMA 2   /* NAVSIM_MARCH_F32 with the sample position contracted: px = (int)fmaf(dx, t, x0) */
@@ -599,6 +604,12 @@ int    navsim_regen_stage(const navsim_config* cfg, const navsim_state* stage, c
  * call needs cfg.regen_cap >= cfg.n_envs; the staging passes' cap is the one of the config THEY are given).  Counters as
  * navsim_regen_swap.  Packed fields, pedestrians inside the step (ped_split 0 / 1); NAVSIM_E_UNSUPPORTED otherwise.
  * The caller queues the staging passes as for the pipelined swap (replace "swap of step" by "step"). */
+/* NAVSIM_AUTORESET_NEXT_STEP with late = NULL and cfg.regen_min_steps = 0 (ABI 6): NO fallback call is needed -- an arena that is
+ * reset by this call (io->reset_mask) and finds no world staged regenerates its own world inside the launch, its workgroup
+ * running navsim_regen's device functions for that one arena in place of the step it does not take (rare, and slow for that
+ * one workgroup; the result is navsim_regen's bit for bit).  Worlds of outdoor maps (cfg.regen_indoor_ratio = 0) without
+ * cfg.regen_plan and without a costmap, at least 256 threads per arena, cfg.march_rule = NAVSIM_MARCH_F32 (the default);
+ * NAVSIM_E_UNSUPPORTED otherwise (pass `late` then). */
 /* late [E] uint8 or NULL -- the FALLBACK that needs no rule: the launch writes late[e] = 1 for every arena that finished,
  * is due a new world (by cfg.regen_min_steps, if set) and whose staged world was not ready, 0 for every other arena; the caller
  * follows the launch with navsim_regen(cfg', st, io' with io'->done = late) on the same stream (cfg' = cfg with a regen_cap that
@@ -615,6 +626,19 @@ int    navsim_step_install(const navsim_config* cfg, const navsim_state* st, con
 int    navsim_step_install_replan(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
                                   const navsim_state* stage, const float* stage_obs, uint8_t* mark, const long long* ready,
                                   uint8_t* late, int32_t max_queries, void* stream);
+/* NAVSIM_AUTORESET_NEXT_STEP (ABI 6): navsim_step_install[_replan] where an arena that finds no world staged is regenerated
+ * BESIDE the next launch instead of behind this one.  An arena that finishes in this call learns at once whether the world of
+ * the episode it will start is staged (ready[e]); if not, late_next[e] = 1 (0 for every other arena).  The next call receives
+ * those flags as late_prev: it only zeroes the outputs of the arenas flagged there, while the caller's
+ *     navsim_regen(cfg' = cfg with defer_reset_scan = 1 and a regen_cap of its own, st, io' with io'->done = late_prev)
+ * runs on ANOTHER stream at the same time (both behind the call that wrote the flags; the caller joins the two streams
+ * before its next call).  The arenas not flagged install their staged worlds at the front of the launch.  Same rollout as
+ * navsim_step + navsim_regen keyed on io->reset_mask, whatever the staging passes' timing -- with no rule (cfg.regen_min_steps
+ * = 0) and with nothing of the reset path on the steps' critical path.  late_next, late_prev: [E] uint8, two buffers the
+ * caller alternates; max_queries < 0: no re-plan inside the launch. */
+int    navsim_step_install_next(const navsim_config* cfg, const navsim_state* st, const navsim_step_io* io,
+                                const navsim_state* stage, const float* stage_obs, uint8_t* mark, const long long* ready,
+                                uint8_t* late_next, const uint8_t* late_prev, int32_t max_queries, void* stream);
 /* navsim_regen's helper stream.  Worlds of corridor maps with planned starts (cfg.regen_indoor_ratio > 0, cfg.regen_plan): the
  * distance transform of the new maps runs on a second stream between two events on `stream` (inside a hipGraph capture of
  * `stream` it joins and leaves the capture through them); environment NAVSIM_REGEN_FORK=0 keeps the call on `stream` alone.

@@ -963,6 +963,15 @@ struct StepInstall {
     const float* stage_obs;              // [E][D] first observations of the staged worlds
     uint8_t* mark;                       // [E rounded up to 4] "stage me again" flags (32-bit atomics)
     const long long* ready;              // [E] episode number the last finished staging pass generated for
+    // NAVSIM_AUTORESET_NEXT_STEP only (navsim_step_install_next): lateness is decided when the episode ENDS -- late_next[e] = 1
+    // for an arena that finishes in this call and finds no world staged for the episode it will start (0 for everyone else) --
+    // and late_prev = the flags the previous call wrote: an arena flagged there is reset by the caller's navsim_regen, which runs
+    // BESIDE this launch on another stream (this launch only zeroes the arena's outputs)
+    uint8_t* late_next;
+    const uint8_t* late_prev;
+    int lone;                            // NEXT_STEP: an arena that is reset and finds no world staged regenerates its own
+                                         // (regen_lone, kernels_regen_dev.hpp) -- no fallback launch at all; the host sets it for
+                                         // worlds of outdoor maps without planning / costmap and >= 256 threads per arena
     uint8_t* late;                       // [E] or NULL: out, 1 = the arena finished, is due a new world and its staged one was not
                                          // ready -- the caller regenerates it now (navsim_regen with these flags as io->done)
     StepInstallBig big[5];
@@ -1161,6 +1170,43 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
         }
         // cfg.defer_reset_scan: the navsim_regen that follows (io->done = the same mask) writes the row
         if (c.defer_reset_scan) return;
+        // (compiled into the default march rule's instantiations only: the other rules' kernels stay as small as they were, their
+        //  callers get NAVSIM_E_UNSUPPORTED from the host and take the flags + navsim_regen form)
+        if constexpr (INSTALL && BLOCK >= 256 && RULE == NAVSIM_MARCH_F32) {
+            if (in->lone && in->ready) {
+                // staged worlds, no rule, no fallback launch (round 6): this arena restarted -- in the state -- when it finished;
+                // now its workgroup takes the staged world, or, should none be staged for the episode that starts, generates
+                // that world ITSELF, in place of the step it does not take (regen_lone).  Decided by one thread, through LDS.
+                if (tid == 0) {
+                    const bool lng = c.regen_min_steps <= 0 || st.done_steps[e] >= c.regen_min_steps;
+                    const bool rdy = stage_ready(in->ready, e) == (long long)st.episode[e];
+                    sh.respawn = lng ? (rdy ? 3 : 5) : 0;
+                    if (!(lng && rdy)) stage_request(in->stage.episode, in->mark, e, st.episode[e] + 1);   // what is staged carries a stale number
+                    if (st.counters) {
+                        atomicAdd(&st.counters[lng ? (rdy ? NAVSIM_COUNTER_REGEN_SERVED : NAVSIM_COUNTER_REGEN_LATE) : NAVSIM_COUNTER_REGEN_SHORT], 1ull);
+                        if (lng && !rdy) atomicAdd(&st.counters[NAVSIM_COUNTER_REGEN_SERVED], 1ull);       // (as navsim_regen counts the arena it serves)
+                    }
+                }
+                __syncthreads();
+                const int verdict = sh.respawn;
+                __syncthreads();                                // (phase 0 rewrites the field)
+                if (verdict == 3) {
+                    install_arena<BLOCK>(c, st, io, *in, e, obs_row);
+                    install_publish(*in, st, e);
+                    return;
+                }
+                if (verdict == 5) {
+                    regen_lone<Field, BLOCK>(c, st, e);
+                    if constexpr (RECT == 2) {                  // the new map's index row replaces the old one in LDS
+                        uint4* tab_lds = (uint4*)dyn_lds_all;
+                        const size_t row_bytes = rect_index_row_bytes(c.map_h, c.map_w);
+                        const uint4* src = (const uint4*)((const char*)st.rect_index + (size_t)ms * row_bytes);
+                        for (int i = threadIdx.x; i < (int)(row_bytes / 16); i += BLOCK) tab_lds[i] = src[i];
+                    }
+                }
+                // (verdict 0, 5: the ordinary reset path below -- first observation from the state as it stands now)
+            }
+        }
     }
     if (reset_only && reset_mask && !reset_mask[e]) {          // untouched env: carry the row over
         if (obs_prev && obs_prev != obs_row)                    // (navsim_regen hands the step's own rows in: nothing to move)
@@ -1234,12 +1280,19 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
             sh.old_rp[0] = rp_g[0]; sh.old_rp[1] = rp_g[1]; sh.old_rp[2] = th_old;
             sh.nseg = 0; sh.ndisc = 0; sh.rescan = 0; sh.respawn = 0; sh.term = 0;
             if constexpr (INSTALL) {
-                if (pending) {
+                if (pending && !in->lone) {
                     // NEXT_STEP with staged worlds: the arena restarted (state: episode number, done_steps) when it finished; now
                     // it takes its staged world if that is the one for the episode that starts (and the ended episode was long
                     // enough, cfg.regen_min_steps), else it starts in place and -- no rule -- asks the caller's navsim_regen
                     if (in->late) in->late[e] = 0;
-                    if (in->ready) {
+                    if (in->late_next) in->late_next[e] = 0;
+                    if (in->late_prev && in->late_prev[e]) {
+                        // flagged when its episode ended (below, `restart_next`): its new world is being generated right now, beside
+                        // this launch, by the caller's navsim_regen -- state, map and first observation are that call's
+                        sh.respawn = 4;
+                        stage_request(in->stage.episode, in->mark, e, st.episode[e] + 1);       // what is staged carries a stale number
+                        if (st.counters) atomicAdd(&st.counters[NAVSIM_COUNTER_REGEN_LATE], 1ull);
+                    } else if (in->ready) {
                         const bool lng = c.regen_min_steps <= 0 || st.done_steps[e] >= c.regen_min_steps;
                         const bool rdy = stage_ready(in->ready, e) == (long long)st.episode[e];
                         if (lng && rdy) sh.respawn = 3;                                // installed behind the barrier below
@@ -1280,6 +1333,7 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
             install_publish(*in, st, e);
             return;
         }
+        if (pending && sh.respawn == 4) return;                 // ... or the caller's navsim_regen beside this launch
     }
 
     NAVSIM_STAMP(1);
@@ -1379,7 +1433,7 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
             nv::RewardOut o = nv::reward_scalar(c, prev_xy, pose, vel, goal, crash != 0, discomfort != 0, rmin);
             io.reward[e] = o.reward;
             io.done[e] = (uint8_t)o.done;
-            if constexpr (INSTALL) if (in->late) in->late[e] = 0;
+            if constexpr (INSTALL) { if (in->late) in->late[e] = 0; if (in->late_next) in->late_next[e] = 0; }
             io.is_success[e] = o.success;
             io.is_crash[e] = o.crash;
             io.distance[e] = o.distance;
@@ -1547,6 +1601,16 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
             if (st.done_steps) st.done_steps[e] = sh.steps_now;
             st.episode[e] += 1;
             st.steps[e] = 0;
+            if constexpr (INSTALL) {
+                if (in->late_next && in->ready) {
+                    // is the world for the episode that will start staged?  Decided NOW, a call ahead of the reset: an arena that
+                    // finds nothing is regenerated by the caller BESIDE the next launch instead of behind it (and what this
+                    // decides stands whatever a staging pass finishes in between: the regenerated world is the same world)
+                    const bool lng = c.regen_min_steps <= 0 || sh.steps_now >= c.regen_min_steps;
+                    const bool rdy = stage_ready(in->ready, e) == (long long)st.episode[e];
+                    in->late_next[e] = (lng && !rdy) ? 1 : 0;
+                }
+            }
         }
         if (st.arena_cost && !reset_only)
             st.arena_cost[e] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_begin);

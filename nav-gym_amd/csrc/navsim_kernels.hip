@@ -29,6 +29,7 @@ namespace {
 #include "kernels_field.hpp"
 #include "kernels_rect.hpp"
 #include "kernels_plan.hpp"
+#include "kernels_regen_dev.hpp"
 #include "kernels_step.hpp"
 #include "kernels_reset.hpp"
 #include "kernels_policy.hpp"
@@ -647,7 +648,11 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
     regen_maps_kernel<<<regen_grid(M), 256, 0, s>>>(*c, *st, count, list, need_occ ? occ : nullptr, grids, kind,
                                                             fscratch, fbytes, ovf_scratch, direct ? 1 : 0,
                                                             direct ? io->done : nullptr, M, direct_rects, direct_index);
-    if (st->map_slot) regen_map_list_kernel<<<(M + 255) / 256, 256, 0, s>>>(list, st->map_slot, mlist, M);
+    // (the slots of the listed arenas' maps: read by the distance transform's install, the record builders and the costmap --
+    //  a world of outdoor maps without a costmap writes its fields through the arena's own table entry and needs no list:
+    //  one launch less in c5's per-step fallback, round 6)
+    const bool need_mlist = st->map_slot && (!direct || c->regen_plan || st->costmap);
+    if (need_mlist) regen_map_list_kernel<<<(M + 255) / 256, 256, 0, s>>>(list, st->map_slot, mlist, M);
     // Corridor maps with planned starts: the distance transform, the rect records and the field's install go to a helper
     // stream, beside the costmap and the robot stage's searches -- those read the occupancy grid only; the stage's accept
     // kernel (first-scan test on the new field) waits for the helper.  (reference defaults, 1024 arenas: dt 150 us of a
@@ -801,16 +806,47 @@ int navsim_step_install(const navsim_config* c, const navsim_state* st, const na
     return navsim_step_install_replan(c, st, io, stage, stage_obs, mark, ready, late, -1, stream);
 }
 
+extern "C++" {
+namespace {
+int step_install_impl(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, const navsim_state* stage,
+                      const float* stage_obs, uint8_t* mark, const long long* ready, uint8_t* late, uint8_t* late_next,
+                      const uint8_t* late_prev, int32_t max_queries, void* stream);
+}
+}
+
 int navsim_step_install_replan(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, const navsim_state* stage,
                                const float* stage_obs, uint8_t* mark, const long long* ready, uint8_t* late, int32_t max_queries,
                                void* stream) {
+    return step_install_impl(c, st, io, stage, stage_obs, mark, ready, late, nullptr, nullptr, max_queries, stream);
+}
+
+int navsim_step_install_next(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, const navsim_state* stage,
+                             const float* stage_obs, uint8_t* mark, const long long* ready, uint8_t* late_next, const uint8_t* late_prev,
+                             int32_t max_queries, void* stream) {
+    if (!c || c->auto_reset != NAVSIM_AUTORESET_NEXT_STEP || !late_next || !late_prev || late_next == late_prev || !io || !io->reset_mask)
+        return NAVSIM_E_ARG;
+    return step_install_impl(c, st, io, stage, stage_obs, mark, ready, nullptr, late_next, late_prev, max_queries, stream);
+}
+
+extern "C++" {
+namespace {
+int step_install_impl(const navsim_config* c, const navsim_state* st, const navsim_step_io* io, const navsim_state* stage,
+                      const float* stage_obs, uint8_t* mark, const long long* ready, uint8_t* late, uint8_t* late_next,
+                      const uint8_t* late_prev, int32_t max_queries, void* stream) {
     (void)hipGetLastError();
     int rc = check_step_args(c, st, io, 0);
     if (rc != NAVSIM_OK) return rc;
     if (!stage || !stage_obs || !mark || !ready || ((uintptr_t)mark & 3) != 0 || !st->done_steps) return NAVSIM_E_ARG;
     // what makes the outcome independent of the staging passes' timing: the rule (cfg.regen_min_steps, with the caller's order of
     // passes and waits) or the fallback (late: arenas whose world was not ready are generated by the caller's navsim_regen)
-    if (c->regen_min_steps < 1 && !late) return NAVSIM_E_ARG;
+    // NEXT_STEP, neither: an arena that finds nothing staged regenerates its own world inside the launch (regen_lone) -- worlds of
+    // outdoor maps without planning / costmap, at least 256 threads per arena
+    const bool lone = c->auto_reset == NAVSIM_AUTORESET_NEXT_STEP && !late && !late_next && c->regen_min_steps < 1;
+    if (lone && (c->regen_indoor_ratio > 0.0 || c->regen_plan || st->costmap || plan_step(c, st).block < 256 || c->map_h != c->map_w ||
+                 march_rule_variant(c) != NAVSIM_MARCH_F32 ||
+                 c->obstacle_number > 64 || c->obstacle_number_hi > 64))
+        return NAVSIM_E_UNSUPPORTED;
+    if (c->regen_min_steps < 1 && !late && !late_next && !lone) return NAVSIM_E_ARG;
     rc = check_stage_pair(c, st, stage);
     if (rc != NAVSIM_OK) return rc;
     // every finished arena decides for itself: there is no cap to apply in index order (navsim_regen_swap has one)
@@ -821,6 +857,7 @@ int navsim_step_install_replan(const navsim_config* c, const navsim_state* st, c
     if (rc != NAVSIM_OK) return rc;
     StepInstall in = {};
     in.stage = *stage; in.stage_obs = stage_obs; in.mark = mark; in.ready = ready; in.late = late;
+    in.late_next = late_next; in.late_prev = late_prev; in.lone = lone ? 1 : 0;
     if (!st->map_slot) stage_big_buffers(c, st, stage, in.big);             // (with slot tables the maps stay where they are)
     if (max_queries < 0) return dispatch_step(c, st, io, 16, nullptr, (hipStream_t)stream, 0, 0, &in);
     // ... with navsim_replan of the previous step's flags inside the launch (navsim_step_replan's conditions)
@@ -834,6 +871,8 @@ int navsim_step_install_replan(const navsim_config* c, const navsim_state* st, c
     front = front > c->n_envs ? c->n_envs : front;
     return dispatch_step(c, st, io, (3 << 2) | 16, nullptr, (hipStream_t)stream, front, max_queries, &in);
 }
+}  // namespace
+}  // extern "C++"
 
 int navsim_regen_swap(const navsim_config* c, const navsim_state* live, const navsim_state* stage, const navsim_step_io* io,
                       const float* stage_obs, const uint8_t* want, uint8_t* mark, const long long* ready, void* stream) {

@@ -15,6 +15,7 @@ namespace {
 #include "kernels_field.hpp"
 #include "kernels_rect.hpp"
 #include "kernels_plan.hpp"
+#include "kernels_regen_dev.hpp"
 #include "kernels_step.hpp"
 #include "step_plan.hpp"
 

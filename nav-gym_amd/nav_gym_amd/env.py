@@ -359,6 +359,7 @@ class NavGymEnv(_EnvBase):
         self.sim = None
         self.prev_obs = None
         self._bool = None
+        self._views = {}                                    # per buffer parity: what step() hands out beside the observation
         self.robot = _AgentView(self, "robot")
         self.humans = []
         self._map_info = None
@@ -443,6 +444,7 @@ class NavGymEnv(_EnvBase):
             # (map_generator.py:11, 61-93): the LDS form of the march may be used (include/navsim.h closed_maps)
             cfg.closed_maps = int("rect_index" in arrays)
             self.sim = simmod.NavSim(cfg, arrays, device=self.device, final_obs=self.final_observation)
+            self._views = {}
             self.scan_threshold = arrays["scan_threshold"]
             self.scan_discomfort_threshold = arrays["scan_discomfort"]
             if self.pedestrian_model == "policy":
@@ -582,14 +584,25 @@ class NavGymEnv(_EnvBase):
             if self.auto_reset and self.autoreset_mode == "next_step":
                 info["reset_mask"] = bool(self.sim.reset_flags[0].item())
             return obs, float(out["reward"][0].item()), done, info
+        # (views of the buffers the kernel wrote, made ONCE per buffer parity: a step of 4096 arenas is 95 us on the device, and
+        #  every tensor slice or .view() costs the host 3-5 us -- round 6 measured 42 -> 36 M env-steps/s through this method
+        #  when the terminal rows' three views were built per call)
+        v = self._views.get(self.sim.cur)
+        if v is None:
+            v = {"done": out["done"].view(self._bool)}
+            if fin is not None:
+                v["final"] = {"observation": fin["final_obs"], "achieved_goal": fin["final_goals"][:, :2],
+                              "desired_goal": fin["final_goals"][:, 2:]}
+            if self.auto_reset and self.autoreset_mode == "next_step":
+                v["reset"] = self.sim.reset_flags.view(self._bool)
+            self._views[self.sim.cur] = v
         info = {"is_success": out["is_success"], "is_crash": out["is_crash"], "distance": out["distance"]}
-        done = out["done"].view(self._bool)                                # (a view of the flags the kernel wrote: no kernel)
+        done = v["done"]
         if fin is not None:
-            info["final_observation"] = {"observation": fin["final_obs"], "achieved_goal": fin["final_goals"][:, :2],
-                                         "desired_goal": fin["final_goals"][:, 2:]}
+            info["final_observation"] = v["final"]
             info["final_mask"] = done
-        if self.auto_reset and self.autoreset_mode == "next_step":
-            info["reset_mask"] = self.sim.reset_flags.view(self._bool)
+        if "reset" in v:
+            info["reset_mask"] = v["reset"]
         return obs, out["reward"], done, info
 
     def counters(self, reset=True):
@@ -696,6 +709,7 @@ class NavGymEnv(_EnvBase):
         if self.sim is not None:
             self.sim.close()                        # (staging passes in flight on a side stream: wait before the arrays go)
         self.sim = None
+        self._views = {}
 
     # ---- EzPickle (env.py:30, 56-78): a pickle carries the constructor's arguments, the copy is built from them -----------
     def __getstate__(self):

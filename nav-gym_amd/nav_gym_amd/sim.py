@@ -586,20 +586,65 @@ class NavSim(object):
         P, k = self.pg_period, self.pg_k
         if k % P == 0 and k >= 2 * P:
             main.wait_event(self.pg_staged[(k // P - 2) % 3])   # the pass queued two periods ago; the later two may still run
+        if getattr(self, "late2", None) is not None:
+            return self._launch_next_step(main)
         # pg_replan_cap > 0 (worlds with planned pedestrian routes): navsim_replan of the previous step's flags inside this launch
         # where the search fits the arena's workgroup (navsim_step_install_replan); else the caller re-plans behind the step
+        late = None if getattr(self, "lone", False) else self.late
         if getattr(self, "pg_replan_cap", 0) > 0 and self.pg_replan_in_step:
             rc = self.lib.navsim_step_install_replan(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), C.byref(self.stage_st),
-                                                     _ptr(self.stage_obs), _ptr(self.mark), _ptr(self.ready), _ptr(self.late),
+                                                     _ptr(self.stage_obs), _ptr(self.mark), _ptr(self.ready), _ptr(late),
                                                      int(self.pg_replan_cap), C.c_void_p(main.cuda_stream))
             if rc == 0:
                 return
             if rc != abi.E_UNSUPPORTED:
                 check(rc, "navsim_step_install_replan")
             self.pg_replan_in_step = False
-        check(self.lib.navsim_step_install(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), C.byref(self.stage_st),
-                                           _ptr(self.stage_obs), _ptr(self.mark), _ptr(self.ready), _ptr(self.late),
-                                           C.c_void_p(main.cuda_stream)), "navsim_step_install")
+        rc = self.lib.navsim_step_install(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), C.byref(self.stage_st),
+                                          _ptr(self.stage_obs), _ptr(self.mark), _ptr(self.ready), _ptr(late),
+                                          C.c_void_p(main.cuda_stream))
+        if rc == abi.E_UNSUPPORTED and late is None and self.late is not None:
+            self.lone = False                                   # (fewer than 256 threads per arena: flags + navsim_regen behind the step)
+            rc = self.lib.navsim_step_install(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), C.byref(self.stage_st),
+                                              _ptr(self.stage_obs), _ptr(self.mark), _ptr(self.ready), _ptr(self.late),
+                                              C.c_void_p(main.cuda_stream))
+        check(rc, "navsim_step_install")
+
+    def _launch_next_step(self, main):
+        """NEXT_STEP with staged worlds: the step's launch (arenas that finished in the previous call install their staged worlds
+        at its front) and, on the `urgent` stream at the same time, navsim_regen for the arenas that call flagged as late."""
+        import torch
+        prev, nxt = self.late2[self.cur], self.late2[1 - self.cur]      # (self.cur: the buffers of the PREVIOUS call)
+        cap = int(getattr(self, "pg_replan_cap", 0)) if self.pg_replan_in_step else 0
+        rc = self.lib.navsim_step_install_next(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), C.byref(self.stage_st),
+                                               _ptr(self.stage_obs), _ptr(self.mark), _ptr(self.ready), _ptr(nxt), _ptr(prev),
+                                               cap if cap > 0 else -1, C.c_void_p(main.cuda_stream))
+        if rc == abi.E_UNSUPPORTED and cap > 0:                 # the search does not fit the arena's workgroup: re-plan behind the step
+            self.pg_replan_in_step = False
+            rc = self.lib.navsim_step_install_next(C.byref(self.cfg), C.byref(self.st), C.byref(self.io), C.byref(self.stage_st),
+                                                   _ptr(self.stage_obs), _ptr(self.mark), _ptr(self.ready), _ptr(nxt), _ptr(prev),
+                                                   -1, C.c_void_p(main.cuda_stream))
+        check(rc, "navsim_step_install_next")
+        # beside it: the new worlds of the arenas the previous call found unstaged (mostly nobody: launches that find nothing to do)
+        urgent = self.urgent
+        urgent.wait_event(self.ev_stepped)                      # the previous call (its flags, its state) -- NOT this launch
+        C.memmove(C.byref(self.late_cfg), C.byref(self.cfg), C.sizeof(self.cfg))
+        self.late_cfg.regen_cap = self.late_cap
+        self.late_cfg.defer_reset_scan = 1
+        io = abi.NavsimStepIO()
+        C.memmove(C.byref(io), C.byref(self.io), C.sizeof(io))  # (self.io: this call's buffers -- _flip() ran)
+        io.done = prev.data_ptr()
+        io.reset_mask = None
+        helper = getattr(self, "_regen_helper", None)
+        if helper is not None:                                  # no fork: the helper stream belongs to the staging passes
+            self.lib.navsim_regen_helper(C.c_void_p(urgent.cuda_stream))
+        check(self.lib.navsim_regen(C.byref(self.late_cfg), C.byref(self.st), C.byref(io), _ptr(self.late_ws), self.late_ws.numel(),
+                                    C.c_void_p(urgent.cuda_stream)), "navsim_regen (arenas whose world was not staged, beside the step)")
+        if helper is not None:
+            self.lib.navsim_regen_helper(C.c_void_p(helper.cuda_stream))
+        self.ev_urgent.record(urgent)
+        main.wait_event(self.ev_urgent)                         # whatever follows this step on the caller's stream sees both
+        self.ev_stepped.record(main)
 
     # arrays navsim_regen writes: the staged state of enable_pregen() owns a copy of each
     STAGED = ("field", "field_overflow", "rect_table", "rect_index", "costmap", "scan_noise_std", "robot_pose", "robot_goal", "prev_action",
@@ -609,7 +654,7 @@ class NavSim(object):
     MAPS = ("field", "field_overflow", "rect_table", "rect_index", "costmap")      # the per-map arrays (navsim_state.map_slot)
 
     def enable_pregen(self, scratch_bytes=4 << 30, pipeline=0, install=False, stage_cap=None, map_slots=True, fallback=None,
-                      fallback_cap=None):
+                      fallback_cap=None, late_beside=False):
         """navsim_regen off the step's critical path (include/navsim.h navsim_regen_swap): the world every arena will
         get at the end of its CURRENT episode -- a function of (seed, global arena, episode number) only -- is generated
         ahead of time into a second, staged state by the ordinary navsim_regen on a side stream; regen() then only
@@ -716,6 +761,25 @@ class NavSim(object):
         self.pg_replan_cap, self.pg_replan_in_step = 0, True       # (set pg_replan_cap to re-plan inside the step's launch, _launch)
         # the fallback: flags the step writes, and a navsim_regen of its own size for the arenas they name
         self.late = torch.zeros(E, dtype=torch.uint8, device=self.device) if fallback else None
+        # NEXT_STEP (round 6): an arena learns when its episode ENDS whether the next world is staged; if not, the caller's
+        # navsim_regen generates it BESIDE the next step's launch, on a stream of its own (include/navsim.h
+        # navsim_step_install_next) -- nothing of the reset path is left on the steps' critical path, and no rule is needed
+        # MEASURED AND NOT THE DEFAULT (late_beside=True asks for it): c5, 512 arenas, no rule: 5.4 M env-steps/s against 6.9 M
+        # with the fallback's (mostly empty) launches behind the step on the same stream -- the two cross-stream waits per step
+        # cost more than the three launches they take off the critical path (profiles/r06_c5/README.md; the same finding as
+        # round 5's two-stream re-plan)
+        # NEXT_STEP, worlds of outdoor maps without planning or costmap: NO fallback call at all -- an arena that finds nothing staged
+        # regenerates its own world inside the step's launch, in place of the step it does not take (include/navsim.h
+        # navsim_step_install with late = NULL; kernels_regen_dev.hpp regen_lone).  The library refuses (fewer than 256 threads per
+        # arena): _launch falls back to the flags + navsim_regen form.
+        self.lone = bool(fallback and self.next_step and not late_beside and not (self.cfg.regen_indoor_ratio > 0.0) and
+                         not self.cfg.regen_plan and "costmap" not in self.t)
+        self.late2 = None
+        if fallback and self.next_step and late_beside:
+            self.late2 = [torch.zeros(E, dtype=torch.uint8, device=self.device) for _ in range(2)]
+            self.urgent = concurrent_stream(self.device, beside=[torch.cuda.current_stream(self.device), self.side])
+            self.ev_stepped, self.ev_urgent = torch.cuda.Event(), torch.cuda.Event()
+            self.ev_stepped.record(torch.cuda.current_stream())
         if fallback:
             self.late_cfg = self.cfg.copy()
             # (every launch of the fallback is sized by its cap whether anybody is late or not: with 16 slots the planner's
@@ -724,6 +788,9 @@ class NavSim(object):
             #  ~100 steps of that loop; more of them than the cap in ONE step would restart in place, counted as regen_unserved.)
             self.late_cap = int(min(E, fallback_cap if fallback_cap else max(8, E // 128)))
             self.late_cfg.regen_cap = self.late_cap
+            if self.late2 is not None:
+                self.late_cfg.defer_reset_scan = 1          # (the launch skips a flagged arena altogether: its row is navsim_regen's,
+                                                            #  also when the arena lies beyond this call's cap and restarts in place)
             self.late_ws = torch.zeros(self.lib.navsim_regen_workspace_bytes(C.byref(self.late_cfg)), dtype=torch.uint8, device=self.device)
 
     def restage_all(self, scratch_bytes=4 << 30, slots_from_live=False):
@@ -740,6 +807,11 @@ class NavSim(object):
         self.stage_t["episode"].copy_(self.t["episode"] + 1)
         self.want.fill_(1)
         self.mark.zero_()
+        if getattr(self, "late2", None) is not None:
+            self.urgent.synchronize()
+            for b in self.late2:
+                b.zero_()
+            self.ev_stepped.record(torch.cuda.current_stream())
         self.pg_k, self.pg_open = 0, []
         self._stage_all(scratch_bytes)
         self.ev_staged.record(torch.cuda.current_stream())
@@ -769,7 +841,7 @@ class NavSim(object):
         self.pg_k += 1
         j = k // P if P else 0
         if self.pg_install:                              # step() has installed; only the passes are left
-            if self.late is not None:                   # ... and whoever finished before its world was staged (rare): now
+            if self.late is not None and getattr(self, "late2", None) is None and not getattr(self, "lone", False):   # ... and whoever finished before its world was staged (rare): now
                 C.memmove(C.byref(self.late_cfg), C.byref(self.cfg), C.sizeof(self.cfg))
                 self.late_cfg.regen_cap = self.late_cap
                 io = abi.NavsimStepIO()
@@ -846,7 +918,7 @@ class NavSim(object):
     def close(self):
         """Waits for what this simulator has in flight on streams of its own (staging passes, the overlapped re-plan): their
         kernels write into arrays that are about to be released."""
-        for name in ("side", "_side", "_scan_stream", "_regen_helper"):
+        for name in ("side", "_side", "_scan_stream", "_regen_helper", "urgent"):
             st = getattr(self, name, None)
             if st is not None:
                 try:

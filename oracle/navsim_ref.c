@@ -264,6 +264,30 @@ int navsim_cast_static_cpu(const float* field, int32_t E, int32_t H, int32_t W,
     return NAVSIM_OK;
 }
 
+/* cross-check only (tests/test_oracle_crosscheck.py, the "fourth rounding"): the march with the ray directions SUPPLIED --
+ * q [n,4] = x, y, dx, dy -- and the directions themselves, as the specification evaluates them (which = 0: the correctly
+ * rounded fl32(cos64(fl64(heading))) of beam_dir) or as the C library of THIS machine does (which = 1: cosf / sinf, what
+ * upstream's RayMarching::calc_range calls; glibc's are not correctly rounded for every argument) */
+int navsim_cast_dirs_cpu(const float* field, int32_t H, int32_t W, const float* q, int32_t n, float max_range,
+                         int32_t march_rule, float* out) {
+    if (!field || !q || !out || n < 0 || H <= 0 || W <= 0) return NAVSIM_E_ARG;
+    if (march_rule < NAVSIM_MARCH_F64 || march_rule > NAVSIM_MARCH_F32_FMA) return NAVSIM_E_ARG;
+    for (int k = 0; k < n; ++k) {
+        const float* qq = q + (size_t)k * 4;
+        int cnt = 0;
+        out[k] = trace_ray_counted(field, H, W, qq[0], qq[1], qq[2], qq[3], max_range, march_rule, &cnt);
+    }
+    return NAVSIM_OK;
+}
+int navsim_dirs_cpu(const float* heading, int32_t n, int32_t which, float* out2) {
+    if (!heading || !out2 || n < 0) return NAVSIM_E_ARG;
+    for (int k = 0; k < n; ++k) {
+        if (which == 0) beam_dir(heading[k], &out2[2 * k], &out2[2 * k + 1]);
+        else { out2[2 * k] = cosf(heading[k]); out2[2 * k + 1] = sinf(heading[k]); }
+    }
+    return NAVSIM_OK;
+}
+
 /* cross-check only: same sampling rule with unit steps everywhere (no distance field) */
 int navsim_cast_unit_steps_cpu(const uint8_t* occ, int32_t H, int32_t W, const float* q, int32_t n,
                                float max_range, float* out) {

@@ -92,6 +92,29 @@ def cast_static(field, queries, max_range, march_rule=abi.MARCH_F32):
     return out
 
 
+def cast_dirs(field, q4, max_range, march_rule=abi.MARCH_F32):
+    """navsim_cast_dirs_cpu: the march of ONE map with supplied ray directions; q4 [n,4] = x, y, dx, dy (float32)."""
+    field = np.ascontiguousarray(field, dtype=np.float32)
+    H, W = field.shape[-2:]
+    q = np.ascontiguousarray(q4, dtype=np.float32).reshape(-1, 4)
+    out = np.empty(q.shape[0], np.float32)
+    L = lib()
+    L.navsim_cast_dirs_cpu.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_void_p]
+    _chk(L.navsim_cast_dirs_cpu(_p(field), H, W, _p(q), q.shape[0], max_range, int(march_rule), _p(out)), "cast_dirs")
+    return out
+
+
+def beam_dirs(heading, libm=False):
+    """(dx, dy) of float32 headings [n] -> float32 [n,2]: the specified directions (correctly rounded float64 cos / sin) or,
+    libm=True, this machine's C library's cosf / sinf."""
+    h = np.ascontiguousarray(heading, dtype=np.float32).reshape(-1)
+    out = np.empty((h.shape[0], 2), np.float32)
+    L = lib()
+    L.navsim_dirs_cpu.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    _chk(L.navsim_dirs_cpu(_p(h), h.shape[0], int(bool(libm)), _p(out)), "dirs")
+    return out
+
+
 def cast_unit_steps(occ, queries, max_range):
     occ = np.ascontiguousarray(occ, dtype=np.uint8)
     q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 3)

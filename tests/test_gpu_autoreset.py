@@ -221,13 +221,16 @@ def test_next_step_autoreset_with_navsim_regen(gpu, fmt, ped_model, plan, defer)
     assert regenerated > 5 and (capped > 0 or not defer), (regenerated, capped)
 
 
-@pytest.mark.parametrize("period,min_steps,slow,E,block", [(1, 0, False, 48, 0), (2, 0, True, 48, 0), (2, 8, False, 48, 0), (3, 0, True, 48, 256),
-                                                           (2, 0, False, 5, 0), (4, 0, False, 48, 64)])
-def test_next_step_autoreset_with_the_pipelined_reset_path(gpu, monkeypatch, period, min_steps, slow, E, block):
+@pytest.mark.parametrize("period,min_steps,slow,E,block,beside", [(1, 0, False, 48, 0, False), (2, 0, True, 48, 0, False), (2, 8, False, 48, 0, False),
+                                                                  (3, 0, True, 48, 256, False), (2, 0, False, 5, 0, False), (4, 0, False, 48, 64, False),
+                                                                  (2, 0, True, 48, 0, True), (3, 0, True, 48, 256, True), (1, 0, False, 5, 0, True)])
+def test_next_step_autoreset_with_the_pipelined_reset_path(gpu, monkeypatch, period, min_steps, slow, E, block, beside):
     """Next-step auto-reset with worlds staged ahead (navsim_step_install): the workgroup of an arena that is reset installs
     its staged world -- at the FRONT of the launch, in place of a step -- or, when the world is not staged yet, starts in
     place and flags the arena for the caller's navsim_regen (no rule) / restarts in place (cfg.regen_min_steps).  The rollout
-    equals the oracle's step + synchronous navsim_regen_cpu keyed on the same flags, bit for bit, whatever the passes' timing."""
+    equals the oracle's step + synchronous navsim_regen_cpu keyed on the same flags, bit for bit, whatever the passes' timing.
+    beside: navsim_step_install_next -- lateness decided when the episode ends, the late arenas regenerated on a third stream
+    BESIDE the launch that resets them (NavSim.enable_pregen(late_beside=True); measured slower, kept as an entry point)."""
     size, N = 200, 6
     cfg = gpu.lib.default_config(n_envs=E, map_h=size, map_w=size, max_peds=N, ped_model=abi.PED_SFM, n_spawn=6,
                                  auto_reset=abi.AUTORESET_NEXT_STEP, seed=31, field_format=abi.FIELD_U16T, regen_cap=E, min_goal_dist=3.0,
@@ -239,7 +242,8 @@ def test_next_step_autoreset_with_the_pipelined_reset_path(gpu, monkeypatch, per
         gpu.world.lidar_1081(cfg)
     occ = gpu.world.make_maps(E, size, 31)
     g, r = _pair(gpu, cfg, occ, 5)
-    g.enable_pregen(pipeline=period, install=True)
+    g.enable_pregen(pipeline=period, install=True, late_beside=beside)
+    assert (g.late2 is not None) == beside
     if slow:
         stage = g.lib.navsim_regen_stage
         def delayed(*a, _stage=stage, _g=g):
@@ -281,6 +285,8 @@ def test_next_step_autoreset_with_the_pipelined_reset_path(gpu, monkeypatch, per
     cg, cr = g.counters(), r.counters()
     assert n_reset > 8 or E < 8
     assert cg["regen_unserved"] == 0
+    # which form served the late arenas: the arena's own workgroup (regen_lone: no fallback launch) wherever the library offers it
+    assert g.lone == (min_steps == 0 and not beside and block != 64), (g.lone, block)
     # (a late arena is counted twice on the device: regen_late by the launch that found nothing staged, regen_served by the
     #  navsim_regen that then generated its world on the spot)
     assert cg["regen_short"] == cr["regen_short"] and cg["regen_served"] == cr["regen_served"], (cg, cr)
