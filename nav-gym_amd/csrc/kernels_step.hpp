@@ -27,6 +27,27 @@ struct StepShared {
                                   // (crash: the re-scan at the reverted pose, env.py:707-723); sits in what was padding
     double wave_ratio[kMaxWaves];
 };
+#ifdef NAVSIM_RECT_STATIC
+// experiment: the index row at LDS address 0 in a fixed layout -- list[256] (2 KB), then the tiles' first indices and the tiles'
+// second indices as two byte planes of 4096 tiles each
+constexpr unsigned kRectPlaneA = kRectListLen * 8, kRectPlaneB = kRectListLen * 8 + 4096, kRectStaticBytes = kRectListLen * 8 + 2 * 4096;
+template <bool ROW> struct StepLds { StepShared sh; };
+template <> struct StepLds<true> { char row[kRectStaticBytes]; StepShared sh; };
+// copy of an arena's index row (kernels_rect.hpp: list, then A | B << 8 per tile) into that layout
+template <int BLOCK>
+__device__ __forceinline__ void rect_row_to_planes(char* row_lds, const uint4* __restrict__ src, size_t row_bytes) {
+    for (int i = threadIdx.x; i < (int)(row_bytes / 16); i += BLOCK) {
+        const uint4 v = src[i];
+        if (i < (int)(kRectListLen * 8 / 16)) { ((uint4*)row_lds)[i] = v; continue; }
+        const int j = i - (int)(kRectListLen * 8 / 16);
+        uint2 a, b;
+        a.x = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u); a.y = __builtin_amdgcn_perm(v.w, v.z, 0x06040200u);
+        b.x = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u); b.y = __builtin_amdgcn_perm(v.w, v.z, 0x07050301u);
+        *(uint2*)(row_lds + kRectPlaneA + j * 8) = a;
+        *(uint2*)(row_lds + kRectPlaneB + j * 8) = b;
+    }
+}
+#endif
 // Pedestrian scratch of the pedestrian variants of the kernel, carved out of dynamic LDS behind the scan's
 // dir / rng area and sized by cfg.max_peds (N), not by the compiled maximum: 144 N + 32 bytes, so that a
 // 20-pedestrian world still fits 8 arenas per CU (the static 64-pedestrian layout allowed 7).
@@ -365,7 +386,11 @@ __device__ __forceinline__ void probe_round(const Field& field, const char* __re
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             typedef __attribute__((address_space(3))) const u32x2 lds_u2;
             lds_u8* row = (lds_u8*)rects;
+#ifdef NAVSIM_RECT_STATIC
+            const unsigned ia = row[kRectPlaneA + tile], ib = row[kRectPlaneB + tile];
+#else
             const unsigned ia = row[kRectListLen * 8 + tile * 2u], ib = row[kRectListLen * 8 + 1 + tile * 2u];
+#endif
             const u32x2 ra = *(lds_u2*)(row + ia * 8u);
             const u32x2 rb = *(lds_u2*)(row + ib * 8u);
             rec.x = ra.x; rec.y = ra.y; rec.z = rb.x; rec.w = rb.y;
@@ -1120,10 +1145,17 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
                                            int reset_only, const int peds_done, const uint8_t* __restrict__ reset_mask,
                                            unsigned dyn_lds_bytes, int park_lanes, unsigned rect_lds_offset,
                                            const StepInstall* in = nullptr) {
+#ifdef NAVSIM_RECT_STATIC
+    __shared__ __attribute__((aligned(256))) StepLds<RECT == 2> lds_static;
+    StepShared& sh = lds_static.sh;
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds_all[];
+    char* dyn_lds = dyn_lds_all;
+#else
     __shared__ StepShared sh;
     // dynamic LDS: [the arena's index row (RECT = 2)][parked rays][pedestrian variants: float2 dir[B], float rng[B]][PedShared][pair table]
     extern __shared__ __attribute__((aligned(16))) char dyn_lds_all[];
     char* dyn_lds = dyn_lds_all + (RECT == 2 ? rect_lds_offset : 0u);      // (rect_lds_offset = the row's size: the rest sits behind it)
+#endif
     PedShared ps = {};
     if constexpr (PEDS) ps = ped_lds_carve(dyn_lds + ((dyn_lds_bytes + 15u) & ~15u), c.max_peds);
     const Prims prims = {ps.seg, ps.disc, ps.info};
@@ -1144,10 +1176,15 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
         // "Map tiles staged through LDS": the INDEX form of the arena's record table (kernels_rect.hpp: 2 KB of distinct
         // rectangles + 2 bytes per 8x8 tile = 10 KB for 500 x 500 cells) is copied into LDS once, by all threads, beside
         // phase 0; every probe of the scans then reads LDS (~0.1 us) instead of global memory (0.5-2 us from L2 / HBM).
-        uint4* tab_lds = (uint4*)dyn_lds_all;
         const size_t row_bytes = rect_index_row_bytes(c.map_h, c.map_w);
         const uint4* src = (const uint4*)((const char*)st.rect_index + (size_t)ms * row_bytes);
+#ifdef NAVSIM_RECT_STATIC
+        uint4* tab_lds = (uint4*)lds_static.row;
+        rect_row_to_planes<BLOCK>(lds_static.row, src, row_bytes);
+#else
+        uint4* tab_lds = (uint4*)dyn_lds_all;
         for (int i = threadIdx.x; i < (int)(row_bytes / 16); i += BLOCK) tab_lds[i] = src[i];
+#endif
         rects = tab_lds;                                        // made visible by the barrier that ends phase 0
     }
     float* obs_row = io.obs + (size_t)e * D;
@@ -1198,10 +1235,14 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
                 if (verdict == 5) {
                     regen_lone<Field, BLOCK>(c, st, e);
                     if constexpr (RECT == 2) {                  // the new map's index row replaces the old one in LDS
-                        uint4* tab_lds = (uint4*)dyn_lds_all;
                         const size_t row_bytes = rect_index_row_bytes(c.map_h, c.map_w);
                         const uint4* src = (const uint4*)((const char*)st.rect_index + (size_t)ms * row_bytes);
+#ifdef NAVSIM_RECT_STATIC
+                        rect_row_to_planes<BLOCK>(lds_static.row, src, row_bytes);
+#else
+                        uint4* tab_lds = (uint4*)dyn_lds_all;
                         for (int i = threadIdx.x; i < (int)(row_bytes / 16); i += BLOCK) tab_lds[i] = src[i];
+#endif
                     }
                 }
                 // (verdict 0, 5: the ordinary reset path below -- first observation from the state as it stands now)
@@ -1626,6 +1667,25 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
     }
 }
 
+// Kernel arguments, read WHERE THEY ARE USED (round 6).  A struct passed to a kernel by value is copied out of the kernarg
+// segment at the kernel's entry -- the compiler turns the copy into scalar loads of every field the kernel uses, all of them in
+// the entry block, ~150 scalar registers of them for step_arena, which it then spills to lanes of vector registers
+// (v_writelane) and fetches back one by one where the fields are used (v_readlane): 563 such instructions in the c2 kernel, a
+// tenth of the vector instructions an arena's wavefronts issue, in a kernel the vector unit bounds.  Bound as references into
+// the kernarg segment itself (constant address space: uniform s_load at the use, rematerializable), the same fields cost no
+// vector instruction: 167 lane moves are left; c2 43.2 -> 45.0 M env-steps/s, c4 34.7 -> 36.5, c5 5.40 -> 5.60, and with the
+// step kernels' STEP_FLAGS of the Makefile c2 45.7, c3 26.1 -> 26.8 (same box: profiles/r06_c2/ab_kernargs.txt).
+// The views repeat the kernels' leading parameters: the kernarg segment lays arguments out like a struct's members.
+#ifndef NAVSIM_KARG_VIEW
+#define NAVSIM_KARG_VIEW 1
+#endif
+struct StepKernargs { navsim_config c; navsim_state st; navsim_step_io io; };
+struct StepInstallKernargs { navsim_config c; navsim_state st; navsim_step_io io; StepInstall in; };
+#if NAVSIM_KARG_VIEW
+#define NAVSIM_KERNARGS(View, ...) const View& ka = *(const View*)__builtin_amdgcn_kernarg_segment_ptr()
+#else
+#define NAVSIM_KERNARGS(View, ...) const View ka = {__VA_ARGS__}
+#endif
 // The fused step.  One workgroup = one arena (template arguments: step_arena).  reset_only: bit 0 = a reset-only launch, bit 1 =
 // ped_update_kernel has advanced the pedestrians, bits 2-3 = the NAVSIM_STEP_* part of navsim_step_part.
 template <int BLOCK, bool PEDS, typename Field, int RULE, int RECT, bool PINL, bool FEAT = true>
@@ -1640,10 +1700,12 @@ template <int BLOCK, bool PEDS, typename Field, int RULE, int RECT, bool PINL, b
 #define NAVSIM_NOPEDS_WAVES_MIN 8
 #endif
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((PEDS && PINL && RECT == 2 && BLOCK == 256) ? NAVSIM_PEDS_WAVES_MIN : (!PEDS ? NAVSIM_NOPEDS_WAVES_MIN : 8), 8)))
-void navsim_step_kernel(navsim_config c, navsim_state st,
-                                                            navsim_step_io io, int reset_only,
+void navsim_step_kernel(navsim_config c_, navsim_state st_,
+                                                            navsim_step_io io_, int reset_only,
                                                             const uint8_t* __restrict__ reset_mask,
                                                             unsigned dyn_lds_bytes, int park_lanes, unsigned rect_lds_offset) {
+    NAVSIM_KERNARGS(StepKernargs, c_, st_, io_);
+    const navsim_config& c = ka.c; const navsim_state& st = ka.st; const navsim_step_io& io = ka.io;
     const int peds_done = (reset_only >> 1) & 1;
     const int part = (reset_only >> 2) & 3;
     reset_only &= 1;
@@ -1661,9 +1723,11 @@ void navsim_step_kernel(navsim_config c, navsim_state st,
 // installed) and reset-only launches.
 template <int BLOCK, bool PEDS, typename Field, int RULE, int RECT>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((PEDS && RECT == 2 && BLOCK == 256) ? NAVSIM_PEDS_WAVES_MIN : (!PEDS ? NAVSIM_NOPEDS_WAVES_MIN : 8), 8)))
-void navsim_step_install_kernel(navsim_config c, navsim_state st, navsim_step_io io, StepInstall in, int reset_only,
+void navsim_step_install_kernel(navsim_config c_, navsim_state st_, navsim_step_io io_, StepInstall in_, int reset_only,
                                 const uint8_t* __restrict__ reset_mask,
                                 unsigned dyn_lds_bytes, int park_lanes, unsigned rect_lds_offset) {
+    NAVSIM_KERNARGS(StepInstallKernargs, c_, st_, io_, in_);
+    const navsim_config& c = ka.c; const navsim_state& st = ka.st; const navsim_step_io& io = ka.io; const StepInstall& in = ka.in;
     const int e = st.launch_order ? st.launch_order[blockIdx.x] : (int)blockIdx.x;
     if (e < 0) return;
     step_arena<BLOCK, PEDS, Field, RULE, RECT, PEDS, true>(c, st, io, e, reset_only & 1, 0, reset_mask, dyn_lds_bytes, park_lanes, rect_lds_offset, &in);
@@ -1674,9 +1738,11 @@ void navsim_step_install_kernel(navsim_config c, navsim_state st, navsim_step_io
 // wavefronts go first wherever they share a SIMD with the other part's.  A kernel of its own: the loop around the arena's body
 // costs the body registers (round 5: inside navsim_step_kernel it took c2 from 92 to 114 us per launch).
 template <int BLOCK, typename Field, int RULE, int RECT>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void navsim_step_due_kernel(navsim_config c, navsim_state st,
-                                                            navsim_step_io io, unsigned dyn_lds_bytes, int park_lanes,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void navsim_step_due_kernel(navsim_config c_, navsim_state st_,
+                                                            navsim_step_io io_, unsigned dyn_lds_bytes, int park_lanes,
                                                             unsigned rect_lds_offset) {
+    NAVSIM_KERNARGS(StepKernargs, c_, st_, io_);
+    const navsim_config& c = ka.c; const navsim_state& st = ka.st; const navsim_step_io& io = ka.io;
     __builtin_amdgcn_s_setprio(2);
     for (int slot = (int)blockIdx.x;; slot += (int)gridDim.x) {
         const int e = due_arena_pick<BLOCK>(st.ped_due_prev, c.n_envs, slot);
@@ -1725,8 +1791,10 @@ __device__ __forceinline__ bool step_replan_pick(const navsim_config& c, const n
 }
 template <int BLOCK, typename Field, int RULE, int RECT>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((RECT == 2 && BLOCK == 256) ? NAVSIM_PEDS_WAVES_MIN : 8, 8)))
-void navsim_step_replan_kernel(navsim_config c, navsim_state st, navsim_step_io io, unsigned dyn_lds_bytes, int park_lanes,
+void navsim_step_replan_kernel(navsim_config c_, navsim_state st_, navsim_step_io io_, unsigned dyn_lds_bytes, int park_lanes,
                                unsigned rect_lds_offset, int G, int cap) {
+    NAVSIM_KERNARGS(StepKernargs, c_, st_, io_);
+    const navsim_config& c = ka.c; const navsim_state& st = ka.st; const navsim_step_io& io = ka.io;
     int e, before;
     bool plan;
     if (!step_replan_pick<BLOCK>(c, st, G, cap, e, plan, before)) return;
@@ -1742,8 +1810,10 @@ void navsim_step_replan_kernel(navsim_config c, navsim_state st, navsim_step_io 
 // path for worlds whose pedestrians follow planned routes
 template <int BLOCK, typename Field, int RULE, int RECT>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((RECT == 2 && BLOCK == 256) ? NAVSIM_PEDS_WAVES_MIN : 8, 8)))
-void navsim_step_replan_install_kernel(navsim_config c, navsim_state st, navsim_step_io io, StepInstall in, unsigned dyn_lds_bytes,
+void navsim_step_replan_install_kernel(navsim_config c_, navsim_state st_, navsim_step_io io_, StepInstall in_, unsigned dyn_lds_bytes,
                                        int park_lanes, unsigned rect_lds_offset, int G, int cap) {
+    NAVSIM_KERNARGS(StepInstallKernargs, c_, st_, io_, in_);
+    const navsim_config& c = ka.c; const navsim_state& st = ka.st; const navsim_step_io& io = ka.io; const StepInstall& in = ka.in;
     int e, before;
     bool plan;
     if (!step_replan_pick<BLOCK>(c, st, G, cap, e, plan, before)) return;
