@@ -27,27 +27,6 @@ struct StepShared {
                                   // (crash: the re-scan at the reverted pose, env.py:707-723); sits in what was padding
     double wave_ratio[kMaxWaves];
 };
-#ifdef NAVSIM_RECT_STATIC
-// experiment: the index row at LDS address 0 in a fixed layout -- list[256] (2 KB), then the tiles' first indices and the tiles'
-// second indices as two byte planes of 4096 tiles each
-constexpr unsigned kRectPlaneA = kRectListLen * 8, kRectPlaneB = kRectListLen * 8 + 4096, kRectStaticBytes = kRectListLen * 8 + 2 * 4096;
-template <bool ROW> struct StepLds { StepShared sh; };
-template <> struct StepLds<true> { char row[kRectStaticBytes]; StepShared sh; };
-// copy of an arena's index row (kernels_rect.hpp: list, then A | B << 8 per tile) into that layout
-template <int BLOCK>
-__device__ __forceinline__ void rect_row_to_planes(char* row_lds, const uint4* __restrict__ src, size_t row_bytes) {
-    for (int i = threadIdx.x; i < (int)(row_bytes / 16); i += BLOCK) {
-        const uint4 v = src[i];
-        if (i < (int)(kRectListLen * 8 / 16)) { ((uint4*)row_lds)[i] = v; continue; }
-        const int j = i - (int)(kRectListLen * 8 / 16);
-        uint2 a, b;
-        a.x = __builtin_amdgcn_perm(v.y, v.x, 0x06040200u); a.y = __builtin_amdgcn_perm(v.w, v.z, 0x06040200u);
-        b.x = __builtin_amdgcn_perm(v.y, v.x, 0x07050301u); b.y = __builtin_amdgcn_perm(v.w, v.z, 0x07050301u);
-        *(uint2*)(row_lds + kRectPlaneA + j * 8) = a;
-        *(uint2*)(row_lds + kRectPlaneB + j * 8) = b;
-    }
-}
-#endif
 // Pedestrian scratch of the pedestrian variants of the kernel, carved out of dynamic LDS behind the scan's
 // dir / rng area and sized by cfg.max_peds (N), not by the compiled maximum: 144 N + 32 bytes, so that a
 // 20-pedestrian world still fits 8 arenas per CU (the static 64-pedestrian layout allowed 7).
@@ -386,11 +365,7 @@ __device__ __forceinline__ void probe_round(const Field& field, const char* __re
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             typedef __attribute__((address_space(3))) const u32x2 lds_u2;
             lds_u8* row = (lds_u8*)rects;
-#ifdef NAVSIM_RECT_STATIC
-            const unsigned ia = row[kRectPlaneA + tile], ib = row[kRectPlaneB + tile];
-#else
             const unsigned ia = row[kRectListLen * 8 + tile * 2u], ib = row[kRectListLen * 8 + 1 + tile * 2u];
-#endif
             const u32x2 ra = *(lds_u2*)(row + ia * 8u);
             const u32x2 rb = *(lds_u2*)(row + ib * 8u);
             rec.x = ra.x; rec.y = ra.y; rec.z = rb.x; rec.w = rb.y;
@@ -1145,17 +1120,10 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
                                            int reset_only, const int peds_done, const uint8_t* __restrict__ reset_mask,
                                            unsigned dyn_lds_bytes, int park_lanes, unsigned rect_lds_offset,
                                            const StepInstall* in = nullptr) {
-#ifdef NAVSIM_RECT_STATIC
-    __shared__ __attribute__((aligned(256))) StepLds<RECT == 2> lds_static;
-    StepShared& sh = lds_static.sh;
-    extern __shared__ __attribute__((aligned(16))) char dyn_lds_all[];
-    char* dyn_lds = dyn_lds_all;
-#else
     __shared__ StepShared sh;
     // dynamic LDS: [the arena's index row (RECT = 2)][parked rays][pedestrian variants: float2 dir[B], float rng[B]][PedShared][pair table]
     extern __shared__ __attribute__((aligned(16))) char dyn_lds_all[];
     char* dyn_lds = dyn_lds_all + (RECT == 2 ? rect_lds_offset : 0u);      // (rect_lds_offset = the row's size: the rest sits behind it)
-#endif
     PedShared ps = {};
     if constexpr (PEDS) ps = ped_lds_carve(dyn_lds + ((dyn_lds_bytes + 15u) & ~15u), c.max_peds);
     const Prims prims = {ps.seg, ps.disc, ps.info};
@@ -1178,13 +1146,8 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
         // phase 0; every probe of the scans then reads LDS (~0.1 us) instead of global memory (0.5-2 us from L2 / HBM).
         const size_t row_bytes = rect_index_row_bytes(c.map_h, c.map_w);
         const uint4* src = (const uint4*)((const char*)st.rect_index + (size_t)ms * row_bytes);
-#ifdef NAVSIM_RECT_STATIC
-        uint4* tab_lds = (uint4*)lds_static.row;
-        rect_row_to_planes<BLOCK>(lds_static.row, src, row_bytes);
-#else
         uint4* tab_lds = (uint4*)dyn_lds_all;
         for (int i = threadIdx.x; i < (int)(row_bytes / 16); i += BLOCK) tab_lds[i] = src[i];
-#endif
         rects = tab_lds;                                        // made visible by the barrier that ends phase 0
     }
     float* obs_row = io.obs + (size_t)e * D;
@@ -1237,12 +1200,8 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
                     if constexpr (RECT == 2) {                  // the new map's index row replaces the old one in LDS
                         const size_t row_bytes = rect_index_row_bytes(c.map_h, c.map_w);
                         const uint4* src = (const uint4*)((const char*)st.rect_index + (size_t)ms * row_bytes);
-#ifdef NAVSIM_RECT_STATIC
-                        rect_row_to_planes<BLOCK>(lds_static.row, src, row_bytes);
-#else
                         uint4* tab_lds = (uint4*)dyn_lds_all;
                         for (int i = threadIdx.x; i < (int)(row_bytes / 16); i += BLOCK) tab_lds[i] = src[i];
-#endif
                     }
                 }
                 // (verdict 0, 5: the ordinary reset path below -- first observation from the state as it stands now)

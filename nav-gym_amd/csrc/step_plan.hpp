@@ -135,11 +135,7 @@ StepPlan plan_step(const navsim_config* c, const navsim_state* st, int grid = 0)
         // a CU's whole LDS
         const bool lone = grid > 0 && grid <= device_cu_count();
         const bool fits = c->rect_lds == 2 || lone ? total <= kLdsPerCu : (size_t)per_cu * total <= kLdsPerCu;
-#ifdef NAVSIM_RECT_STATIC
-        if (fits && rect_tiles_per_map(c->map_h, c->map_w) <= 4096) { p.rect = 2; p.lds = base; p.rect_off = 0; }
-#else
         if (fits) { p.rect = 2; p.lds = base + row; p.rect_off = (unsigned)row; }     // the row comes first, everything else behind it
-#endif
     }
     return p;
 }
