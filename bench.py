@@ -30,11 +30,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "nav-gym_amd"))
 
-# vector instructions of one probe round of the march (position 4, tile index 4, two-rectangle record decode 13, exact sqrt of
-# the integer d2 6, march step 4, hit test and selects 5), counted in the ISA of the c2 kernel
-PROBE_ROUND_VALU = 36
-PROBE_ROUND_FROM = ("navsim_step_kernel<256, false, FieldU16TT<false>, NAVSIM_MARCH_F32, 2, false>, loop .LBB12_96 of "
-                    "hipcc -S --cuda-device-only nav-gym_amd/csrc/navsim_step_inst.hip (profiles/r05_c2/probe_round_isa.txt)")
+# vector instructions of one probe round of the march (position 4, tile address 4, the two indices' rectangle addresses 2, packed
+# cell 1, "no record" test 1, two-rectangle distance 9, exact sqrt of the integer d2 6, hit test 1, march step 3, next-t test and
+# select 2), counted in the ISA of the c2 kernel
+C1_CPU_KIND = "port (oracle/navsim_ref.c: a restatement, not the reference binary), one thread"
+PROBE_ROUND_VALU = 33
+PROBE_ROUND_FROM = ("navsim_step_kernel<256, false, FieldU16TT<false>, NAVSIM_MARCH_F32, 2, false, false>, loop .LBB13_100 of "
+                    "hipcc -S --cuda-device-only nav-gym_amd/csrc/navsim_step_inst.hip (profiles/r06_c2/probe_round_isa.txt)")
 
 WORKLOADS = {
     # envs = arenas per GPU (weak scaling), total = arenas of the whole job (strong scaling)
@@ -222,32 +224,7 @@ def cpu_baseline(wl, seconds=15.0):
         ref_shaped_us = (time.perf_counter() - t2) / k * 1e6
     except Exception:
         pass
-    # BASELINE.json configs[0] -- "1 env NavGym-v0, 64-beam lidar, 100 x 100 static map, no pedestrians, CPU reference step()":
-    # the oracle on ONE thread on that world (us per step; the GPU side is other_workloads.c1)
-    c1_us = None
-    try:
-        w1 = WORKLOADS["c1"]
-        cc = lib.default_config(n_envs=1, map_h=w1["size"], map_w=w1["size"], max_peds=1, ped_model=abi.PED_NONE, n_spawn=16,
-                                auto_reset=1, seed=1234)
-        world.lidar_full_circle(cc, w1["beams"])
-        occ_c1 = world.make_maps(1, w1["size"], 1234)
-        a_c1 = world.make_world(cc, occ_c1, n_peds=0, device="cpu", field=torch.from_numpy(ref.build_dt(occ_c1)), min_goal_dist=2.0,
-                                max_goal_dist=4.0, robot_clearance=0.9)
-        h_c1 = {k: v.numpy() for k, v in a_c1.items()}
-        h_c1["scan_threshold"] = ref.scan_threshold(cc, robots.footprint_array("keti", "threshold_footprint"))
-        h_c1["scan_discomfort"] = ref.scan_threshold(cc, robots.footprint_array("keti", "discomfort_threshold_footprint"))
-        r_c1 = ref.RefSim(cc, h_c1)
-        r_c1.reset_obs()
-        a1 = lambda n: np.stack([rng.uniform(0, 0.5, (n, 1)), rng.uniform(-0.64, 0.64, (n, 1))], axis=2)
-        r_c1.step_native_threads(a1(200), 1)
-        t4 = time.perf_counter()
-        k1 = 0
-        while time.perf_counter() - t4 < 1.0:
-            r_c1.step_native_threads(a1(2000), 1)
-            k1 += 2000
-        c1_us = (time.perf_counter() - t4) / k1 * 1e6
-    except Exception:
-        pass
+    c1_us = cpu_c1_us_per_step()
     return dict(value=E * n / dt, unit="env-steps/s", cores=nthr, kind="port", c1_us_per_step_1_thread=c1_us,
                 sample="%d arenas x %d steps of the same workload (oracle/navsim_ref.c navsim_step_threads_cpu: %d pinned POSIX "
                        "threads, arenas split statically, fields node-local, %.1f s); value_1_thread: one thread on %d arenas"
@@ -322,6 +299,41 @@ def launch_ranks(n_gpus, argv):
         raise SystemExit("bench.py: every rank exited 0 but rank 0 printed no JSON line")
 
 
+def cpu_c1_us_per_step():
+    """BASELINE.json configs[0] -- "1 env NavGym-v0, 64-beam lidar, 100 x 100 static map, no pedestrians, CPU reference step()":
+    the oracle on ONE thread on that world, microseconds per step (the GPU side is other_workloads.c1).  Part of the CPU baseline:
+    the one place besides tests/ and smoke() where bench.py runs the oracle."""
+    import numpy as np
+    import torch
+    from nav_gym_amd import abi, lib, robots, world
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref
+    rng = np.random.default_rng(7)
+    try:
+        w1 = WORKLOADS["c1"]
+        cc = lib.default_config(n_envs=1, map_h=w1["size"], map_w=w1["size"], max_peds=1, ped_model=abi.PED_NONE, n_spawn=16,
+                                auto_reset=1, seed=1234)
+        world.lidar_full_circle(cc, w1["beams"])
+        occ_c1 = world.make_maps(1, w1["size"], 1234)
+        a_c1 = world.make_world(cc, occ_c1, n_peds=0, device="cpu", field=torch.from_numpy(ref.build_dt(occ_c1)), min_goal_dist=2.0,
+                                max_goal_dist=4.0, robot_clearance=0.9)
+        h_c1 = {k: v.numpy() for k, v in a_c1.items()}
+        h_c1["scan_threshold"] = ref.scan_threshold(cc, robots.footprint_array("keti", "threshold_footprint"))
+        h_c1["scan_discomfort"] = ref.scan_threshold(cc, robots.footprint_array("keti", "discomfort_threshold_footprint"))
+        r_c1 = ref.RefSim(cc, h_c1)
+        r_c1.reset_obs()
+        a1 = lambda n: np.stack([rng.uniform(0, 0.5, (n, 1)), rng.uniform(-0.64, 0.64, (n, 1))], axis=2)
+        r_c1.step_native_threads(a1(200), 1)
+        t4 = time.perf_counter()
+        k1 = 0
+        while time.perf_counter() - t4 < 1.0:
+            r_c1.step_native_threads(a1(2000), 1)
+            k1 += 2000
+        return (time.perf_counter() - t4) / k1 * 1e6
+    except Exception:
+        return None
+
+
 def profiled_counters(workload, E, field, rects, indoor_ratio=0.0):
     """Counter figures of the step kernel from the committed PMC profile of this workload (rocprofv3 --pmc passes,
     profiles/run_profiles.sh -> traffic.json): HBM bytes per launch and the vector-issue fraction.  Counters cannot be
@@ -330,7 +342,7 @@ def profiled_counters(workload, E, field, rects, indoor_ratio=0.0):
     from nav_gym_amd import lib
     reason = None
     # profiles/<round>_<workload>/ and its variants of other launch shapes (…_indoor: corridor maps only)
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         for variant in ("", "_indoor"):
             tp = os.path.join(ROOT, "profiles", "%s_%s%s" % (rnd, workload, variant), "traffic.json")
             if not os.path.exists(tp):
@@ -445,7 +457,9 @@ def main():
     if args.only_windows:
         res = extras(args, "cuda:0")
         for k, v in res["other_workloads"].items():
-            print(k, json.dumps({kk: vv for kk, vv in v.items() if kk in ("value", "ms_per_step", "kernel_ms", "regen_counters", "error", "launch")}))
+            keep = ("value", "ms_per_step", "kernel_ms", "regen_counters", "error", "launch", "us_per_step", "us_per_step_device", "kernel_us",
+                    "cpu_us_per_step_1_thread", "cpu_kind", "workload")
+            print(k, json.dumps({kk: vv for kk, vv in v.items() if kk in keep}))
         return
     # Libraries write to the process's stdout behind Python's back -- RCCL prints a version banner through C stdio, which a
     # redirected stdout holds until the process EXITS, i.e. after the result line (seen with NAVSIM_BENCH_FORCE_DIST=1 on the
@@ -499,7 +513,7 @@ def main():
         c1 = out.get("other_workloads", {}).get("c1")
         if isinstance(c1, dict) and "error" not in c1:      # BASELINE.json configs[0]: both sides of "CPU reference step()"
             c1["cpu_us_per_step_1_thread"] = (out.get("cpu_baseline") or {}).get("c1_us_per_step_1_thread")
-            c1["cpu_kind"] = "port (oracle/navsim_ref.c: a restatement, not the reference binary), one thread" 
+            c1["cpu_kind"] = C1_CPU_KIND
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
@@ -621,12 +635,12 @@ def extras(args, device):
             torch.cuda.empty_cache()
         except Exception as exc:                              # an extra must not cost the run its line
             res["other_workloads"][name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
-    if getattr(args, "only_windows", None):                  # diagnostic: just these windows of other_workloads
-        for name in args.only_windows.split(","):
+    only = [n for n in (getattr(args, "only_windows", None) or "").split(",") if n]   # diagnostic: just these windows of other_workloads
+    for name in (only or ("c3", "c4", "c5")):
+        if name != "c1":
             workload_window(name)
+    if only and "c1" not in only:
         return res
-    for name in ("c3", "c4", "c5"):
-        workload_window(name)
     # BASELINE.json configs[0]: ONE arena, 64 beams, 100 x 100 map, no pedestrians -- a launch of one 64-thread workgroup;
     # us per step as the caller sees it (plain launches back to back) and the kernel alone (one event pair around the launches)
     try:
@@ -671,6 +685,12 @@ def extras(args, device):
         torch.cuda.empty_cache()
     except Exception as exc:
         res["other_workloads"]["c1"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+    if only:
+        c1 = res["other_workloads"]["c1"]
+        if "error" not in c1:
+            c1["cpu_us_per_step_1_thread"] = cpu_c1_us_per_step()
+            c1["cpu_kind"] = C1_CPU_KIND
+        return res
     def gym_window(E, K=200, Wm=30, **kw):
         """K calls of NavGymEnv.step(torch float64 actions [E,2]) after reset() on the device -> dict(value, ms_per_step, envs,
         steps, reset_first_ms, reset_steady_ms).  reset_first_ms: the first reset() of a new environment (allocations, the

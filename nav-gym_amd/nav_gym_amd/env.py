@@ -30,7 +30,10 @@ and default to the reference's behaviour for num_envs == 1:
                     regen_min_steps = 0 (default) the rollout is EXACTLY the one without the pipeline: an arena that finishes
                     before its world is staged is generated on the spot (counters()['regen_late']).  regen_min_steps >= 4 P
                     drops that fallback's launches (fastest): an episode shorter than regen_min_steps restarts on its old map,
-                    which the reference never does (it draws a map at every reset) -- counted in counters()['regen_short']
+                    which the reference never does (it draws a map at every reset) -- counted in counters()['regen_short'].
+                    The on-the-spot fallback serves at most max(8, num_envs // 128) arenas per step: more late arenas than
+                    that in ONE step keep their old map for the next episode and are counted in counters()['regen_unserved']
+                    (not seen in the soaks of profiles/r05_pipe/: a pass every P steps leaves a handful of late arenas per step)
     use_graphs      replay a step's launches (navsim_step, navsim_regen, navsim_replan) as one captured hipGraph; None
                     (default) = when randomize_maps makes a step several launches (c5: +6 %) and navsim_regen does not fork
                     (corridor maps with planned starts: plain launches are as fast or faster); results are identical

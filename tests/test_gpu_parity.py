@@ -2597,6 +2597,27 @@ def test_bench_line_contract(gpu):
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
 
 
+def test_bench_c1_window(gpu):
+    """BASELINE.json configs[0] (1 arena, 64 beams, 100 x 100, no pedestrians) in the bench's default line: `other_workloads.c1`
+    with the GPU's microseconds per step (wall clock, device, kernel alone) and the oracle's on one CPU thread (round-5 review,
+    item 5).  The default line's extras run at the configured size only; `--only-windows c1` prints that one window."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--only-windows", "c1"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith("c1 ")]
+    assert len(rows) == 1, r.stdout[-2000:]
+    c1 = json.loads(rows[0][3:])
+    assert "64 beams" in c1["workload"] and "1 arena" in c1["workload"]
+    assert 0.0 < c1["kernel_us"] <= c1["us_per_step_device"] * 1.05 and c1["us_per_step_device"] <= c1["us_per_step"] * 1.05
+    assert c1["cpu_us_per_step_1_thread"] > 0.0 and "restatement" in c1["cpu_kind"]
+    assert abs(c1["value"] - 1e6 / c1["us_per_step"]) < 1e-6 * c1["value"]
+
+
 def test_edge_shapes(gpu):
     """Ragged / extreme shapes: odd map size (edge tiles), beam count not a multiple of 64, deep scan
     stack, the compiled maximum of 64 pedestrians with ragged n_peds (0, 1, 64), wide action range,
