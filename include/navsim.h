@@ -875,6 +875,11 @@ int navsim_debug_gather(const float* x, uint64_t n_words, int32_t mode, int32_t 
  * workgroup; NULL disables.  Only a library built with -DNAVSIM_STAMPS records anything; the shipped build
  * compiles no stamp into the kernel and returns NAVSIM_E_UNSUPPORTED. */
 int navsim_debug_set_stamps(unsigned long long* buf);
+/* Self-test of the way the step kernels read their arguments (round 6: kernels_step.hpp NAVSIM_KERNARGS -- references into the
+ * kernarg segment laid out as a struct of the kernel's leading parameters, instead of the by-value copies): one launch whose
+ * parameters carry byte patterns compares every byte of the views with the copies.  NAVSIM_OK when they agree;
+ * NAVSIM_E_UNSUPPORTED when a toolchain lays kernel arguments out differently (build with -DNAVSIM_KARG_VIEW=0 then). */
+int navsim_debug_kernarg_layout(void* stream);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,21 @@ NAVSIM_STEP_FAMILY(512, 0) NAVSIM_STEP_FAMILY(512, 1) NAVSIM_STEP_FAMILY(1024, 0
 
 namespace {
 
+// navsim_debug_kernarg_layout: the views against the copies (the four leading parameters of the install kernels + one scalar)
+__global__ void kernarg_layout_probe_kernel(navsim_config c_, navsim_state st_, navsim_step_io io_, StepInstall in_, int tail, int* out) {
+    const StepInstallKernargs& ka = *(const StepInstallKernargs*)__builtin_amdgcn_kernarg_segment_ptr();
+    if (threadIdx.x != 0) return;
+    auto same = [](const void* a, const void* b, size_t n) {
+        const unsigned char* x = (const unsigned char*)a;
+        const unsigned char* y = (const unsigned char*)b;
+        for (size_t i = 0; i < n; ++i) if (x[i] != y[i]) return false;
+        return true;
+    };
+    const int tail_view = *(const int*)((const char*)&ka + sizeof(StepInstallKernargs));     // the scalar behind the structs
+    *out = (same(&c_, &ka.c, sizeof(c_)) && same(&st_, &ka.st, sizeof(st_)) && same(&io_, &ka.io, sizeof(io_)) &&
+            same(&in_, &ka.in, sizeof(in_)) && tail_view == tail && tail == 0x1234567) ? 1 : 0;
+}
+
 // navsim_prepare: walk the dispatch chain of a launch down to its kernel, set what has to be set once per kernel
 // (hipFuncSetAttribute for dynamic LDS above 64 KB) and launch nothing -- so that nothing of the kind happens inside a
 // hipGraph capture (round-3 advisor: navsim_regen's lone first-observation launch instantiates its own variant)
@@ -1259,6 +1274,26 @@ int navsim_debug_gather(const float* x, uint64_t n_words, int32_t mode, int32_t 
     if (!x || !out || n_threads <= 0) return NAVSIM_E_ARG;
     gather_probe_kernel<<<(n_threads + 255) / 256, 256, 0, (hipStream_t)stream>>>(x, n_words, mode, iters, 12345, out);
     return launch_status();
+}
+
+// self-test of NAVSIM_KERNARGS (kernels_step.hpp): the views into the kernarg segment against the by-value copies, byte for byte
+int navsim_debug_kernarg_layout(void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    navsim_config c; navsim_state st; navsim_step_io io; StepInstall in;
+    memset(&c, 0x5A, sizeof(c)); memset(&st, 0xA7, sizeof(st)); memset(&io, 0x3C, sizeof(io)); memset(&in, 0xE1, sizeof(in));
+    for (size_t i = 0; i < sizeof(c); ++i) ((unsigned char*)&c)[i] ^= (unsigned char)(i * 7u);
+    for (size_t i = 0; i < sizeof(st); ++i) ((unsigned char*)&st)[i] ^= (unsigned char)(i * 13u);
+    for (size_t i = 0; i < sizeof(io); ++i) ((unsigned char*)&io)[i] ^= (unsigned char)(i * 29u);
+    for (size_t i = 0; i < sizeof(in); ++i) ((unsigned char*)&in)[i] ^= (unsigned char)(i * 31u);
+    int* out = nullptr;
+    if (hipMalloc((void**)&out, sizeof(int)) != hipSuccess) return NAVSIM_E_LAUNCH;
+    int res = -1;
+    (void)hipMemcpyAsync(out, &res, sizeof(int), hipMemcpyHostToDevice, s);
+    kernarg_layout_probe_kernel<<<1, 64, 0, s>>>(c, st, io, in, 0x1234567, out);
+    const bool ok = hipMemcpyAsync(&res, out, sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    (void)hipFree(out);
+    if (!ok) return NAVSIM_E_LAUNCH;
+    return res == 1 ? NAVSIM_OK : NAVSIM_E_UNSUPPORTED;
 }
 
 // diagnostic build only: where the per-arena stamps go (NULL disables)

@@ -322,6 +322,7 @@ def declare(lib, suffix=""):
     if not suffix:
         sig("navsim_beam_table", [cfgp, _P, _P])
         sig("navsim_debug_xy_to_ij", [cfgp, _P, i32, _P, i32, _P])
+        sig("navsim_debug_kernarg_layout", [_P])
     sig("navsim_ped_scans", [cfgp, stp, _P] + stream)
     if not suffix:
         sig("navsim_ped_scans_part", [cfgp, stp, _P, i32, i32, _P])
@@ -377,5 +378,5 @@ EXPORTS = (
     "navsim_crowd_check", "navsim_crowd_angular_map", "navsim_crowd_local_map", "navsim_crowd_orca", "navsim_crowd_agent_step",
     "navsim_step", "navsim_step_part", "navsim_step_replan", "navsim_prepare", "navsim_reset_obs", "navsim_restart", "navsim_step_kernel_name",
     "navsim_sizeof_config", "navsim_sizeof_state", "navsim_sizeof_step_io", "navsim_debug_math", "navsim_debug_xy_to_ij",
-    "navsim_debug_gather", "navsim_debug_set_stamps", "navsim_debug_spawn_decisions",
+    "navsim_debug_gather", "navsim_debug_kernarg_layout", "navsim_debug_set_stamps", "navsim_debug_spawn_decisions",
 )

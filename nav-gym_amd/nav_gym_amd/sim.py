@@ -296,6 +296,13 @@ def crowd_agent_step(pose, action, time_step):
     return pose, vel
 
 
+def debug_kernarg_layout():
+    """navsim_debug_kernarg_layout: the step kernels' views of their arguments (references into the kernarg segment) against the
+    by-value copies, in one probe launch.  Raises when they differ."""
+    require_gpu()
+    check(load().navsim_debug_kernarg_layout(_stream()), "navsim_debug_kernarg_layout")
+
+
 def debug_xy_to_ij(cfg, xy, as_f32):
     """Device batch_xy_to_ij (env.py:1228-1253): xy float64 CUDA [n,2] -> int32 [n,2] (i, j)."""
     torch = require_gpu()

@@ -2597,6 +2597,13 @@ def test_bench_line_contract(gpu):
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
 
 
+def test_kernel_arguments_read_in_place(gpu):
+    """The step kernels bind references into the kernarg segment instead of copying their struct arguments (round 6,
+    kernels_step.hpp NAVSIM_KERNARGS): the layout that rests on -- arguments laid out like a struct's members -- is checked by a
+    probe launch on this toolchain and device."""
+    gpu.sim.debug_kernarg_layout()
+
+
 def test_bench_c1_window(gpu):
     """BASELINE.json configs[0] (1 arena, 64 beams, 100 x 100, no pedestrians) in the bench's default line: `other_workloads.c1`
     with the GPU's microseconds per step (wall clock, device, kernel alone) and the oracle's on one CPU thread (round-5 review,
