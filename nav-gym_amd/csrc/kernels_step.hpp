@@ -1119,7 +1119,7 @@ template <int BLOCK, bool PEDS, typename Field, int RULE, int RECT, bool PINL, b
 __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_state& st, const navsim_step_io& io, const int e,
                                            int reset_only, const int peds_done, const uint8_t* __restrict__ reset_mask,
                                            unsigned dyn_lds_bytes, int park_lanes, unsigned rect_lds_offset,
-                                           const StepInstall* in = nullptr) {
+                                           const StepInstall* in = nullptr, const int base_prio = 0) {
     __shared__ StepShared sh;
     // dynamic LDS: [the arena's index row (RECT = 2)][parked rays][pedestrian variants: float2 dir[B], float rng[B]][PedShared][pair table]
     extern __shared__ __attribute__((aligned(16))) char dyn_lds_all[];
@@ -1128,6 +1128,16 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
     if constexpr (PEDS) ps = ped_lds_carve(dyn_lds + ((dyn_lds_bytes + 15u) & ~15u), c.max_peds);
     const Prims prims = {ps.seg, ps.disc, ps.info};
     const int tid = threadIdx.x;
+    // Wave priorities (round 6; s_setprio: the SIMD's arbiter issues from the highest priority first, then the oldest wavefront).
+    // A workgroup's START -- the copy of its index row, phase 0's scalars on one lane, the pedestrian phase of wavefront 0 -- is
+    // a chain of memory latencies with next to no vector work: at priority 3 it never waits behind the marching wavefronts of
+    // the other arenas of the CU, and the workgroup reaches its own march sooner (c2 +1.9 %, c3 +1.9 %, c4 +1.5 %, c5 +2.1 %).
+    // The 256-thread variants without pedestrians (several generations of workgroups per launch, parked rays) also march ABOVE
+    // the packing phase of the workgroups that are done (2 against 0): c2 +5.9 % in all, 46.4 -> 49.1 M env-steps/s; the other
+    // variants lose with that (c4 -1.4 %, c3 +-0) and keep their march at the caller's priority.  Measured forms that lost:
+    // the march alone raised (c3 -9 %), everything behind scan A lowered (c4 -6 %), the tail raised (+-0): profiles/r06_c2/.
+    constexpr int kMarchPrio = (BLOCK == 256 && !PEDS) ? 2 : 0;
+    __builtin_amdgcn_s_setprio(3);
     unsigned long long t_begin = 0;
     if (st.arena_cost && tid == 0) t_begin = __builtin_amdgcn_s_memrealtime();
     const int B = c.n_beams, S = c.n_scan_stack, N = c.max_peds, D = S * B + 7;
@@ -1392,6 +1402,9 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
     }
 
     NAVSIM_STAMP(2);
+    if (kMarchPrio == 2 || base_prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (base_prio == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
     // ---------------------------------------------------------------- phase 3: scan A
     int n_hist = reset_only ? 0 : st.n_hist[e];
     int crash = 0, discomfort = 0;
@@ -1563,6 +1576,10 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
     }
 
     NAVSIM_STAMP(5);
+    if (kMarchPrio != 0 && base_prio < kMarchPrio) {
+        if (base_prio == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
     // ---------------------------------------------------------------- phase 6: pack the observation
     const bool fresh = reset_only || sh.respawn;                // first obs of an episode
     if (!fresh && obs_prev) {                                   // env.py:267-274: shift the stack
@@ -1706,7 +1723,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     for (int slot = (int)blockIdx.x;; slot += (int)gridDim.x) {
         const int e = due_arena_pick<BLOCK>(st.ped_due_prev, c.n_envs, slot);
         if (e < 0) return;
-        step_arena<BLOCK, true, Field, RULE, RECT, true>(c, st, io, e, 0, 0, nullptr, dyn_lds_bytes, park_lanes, rect_lds_offset);
+        step_arena<BLOCK, true, Field, RULE, RECT, true>(c, st, io, e, 0, 0, nullptr, dyn_lds_bytes, park_lanes, rect_lds_offset, nullptr, 2);
         __syncthreads();                                 // the arena's LDS is reused by the next one
     }
 }
