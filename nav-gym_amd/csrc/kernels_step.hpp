@@ -23,6 +23,7 @@ struct StepShared {
     unsigned long long rescan_key;  // ... of the second scan (crash revert: step_key + 1; restart: the new episode's reset key)
     int next_chunk;               // scan: next 64-beam chunk to hand to a wavefront (reset before every scan)
     int park_count, park_next;    // scan: parked rays (written / handed out), reset with next_chunk
+    int pair_done;                // pedestrian phase: wavefronts that have written their share of the pair table (ped_pair_share)
     int term;                     // io.final_obs of an arena that restarts in this step: 1 = its rows are scan A's, 2 = a scan of their own
                                   // (crash: the re-scan at the reverted pose, env.py:707-723); sits in what was padding
     double wave_ratio[kMaxWaves];
@@ -429,6 +430,9 @@ __device__ __forceinline__ float ray_result(lanemask_t hit, float x0, float y0, 
 #ifndef NAVSIM_PARK_LANES
 #define NAVSIM_PARK_LANES 16
 #endif
+#ifndef NAVSIM_PAIR_SHARE_MIN_BLOCK       // threads per arena from which the social force's pair terms are shared by four wavefronts
+#define NAVSIM_PAIR_SHARE_MIN_BLOCK 512
+#endif
 constexpr int kParkLanesMax = NAVSIM_PARK_LANES;
 #ifndef NAVSIM_PARK_LANES_PEDS
 #define NAVSIM_PARK_LANES_PEDS 16
@@ -764,18 +768,37 @@ __device__ __forceinline__ int ped_stage_wave(const navsim_config& c, const navs
     }
     return head;
 }
+// The pair terms shared by the first `waves` wavefronts of the workgroup (1024-thread variants, round 6): twenty pedestrians are
+// 210 independent terms of ~700 dependent float64 instructions each -- four rounds on wavefront 0's 64 lanes, 12.6 of the 21 us
+// its chain takes while fifteen wavefronts that finish their scan in 8 us wait for it (profiles/r03_c5_chain/ped_chain.txt); on
+// four wavefronts it is one round.  Each writes its share of the table, signals through sh.pair_done and leaves for the scan.
+// (Round 3 measured this form at +-0: wavefront 0's remaining chain then ran slower beside the marching wavefronts -- since round
+// 6 it runs at priority 3.)
+__device__ __forceinline__ void ped_pair_share(const navsim_config& c, const PedShared& ps, double2* pair, int n, int tid, int waves,
+                                               int* pair_done) {
+    const int n_terms = n * (n - 1) / 2 + n;
+    for (int t = tid; t < n_terms; t += waves * 64) ped_pair_term(c, ps, pair, n, t);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((tid & 63) == 0) __hip_atomic_fetch_add(pair_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 // (b) behind it: pair terms, forces and the Euler step, new goals, leg odometry, state
 template <typename Field>
 __device__ __forceinline__ void ped_advance_wave(const navsim_config& c, const navsim_state& st, const Field& field, int e,
                                                  int n, int lane, bool is_ped, size_t pq, double dt, uint64_t genv,
                                                  uint64_t steps_now, const PedShared& ps, double2* pair, int head, int nw,
-                                                 double (&pp)[3], double (&pvel)[2]) {
+                                                 double (&pp)[3], double (&pvel)[2], int* pair_done = nullptr, int pair_waves = 1) {
     const int P = c.max_waypoints;
     double* wp = st.ped_waypoints + (pq * P) * 2;
     if (c.ped_model == NAVSIM_PED_SFM) {
-        wave_lds_sync();                                    // the staged agents (the workgroup barrier lies in between as well)
-        const int n_terms = n * (n - 1) / 2 + n;
-        for (int t = lane; t < n_terms; t += 64) ped_pair_term(c, ps, pair, n, t);
+        if (pair_waves > 1) {
+            // the pair terms were shared out (ped_pair_share): wait for the other wavefronts' parts -- every wavefront of a workgroup
+            // is resident and writes its share right behind the workgroup's first barrier: a wait of one pair term's length
+            while (__hip_atomic_load(pair_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < pair_waves) __builtin_amdgcn_s_sleep(1);
+        } else {
+            wave_lds_sync();                                // the staged agents (the workgroup barrier lies in between as well)
+            const int n_terms = n * (n - 1) / 2 + n;
+            for (int t = lane; t < n_terms; t += 64) ped_pair_term(c, ps, pair, n, t);
+        }
         wave_lds_sync();
         if (is_ped) ped_sfm_step(c, field, ps, pair, n, lane, st.ped_v_pref[pq], wp + 2 * head, dt, pp, pvel);
     } else if (c.ped_model == NAVSIM_PED_EXTERNAL && is_ped) {
@@ -1333,7 +1356,7 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
             sh.step_key = (unsigned long long)st.episode[e] * 0x100000000ULL +
                           (unsigned long long)(reset_only ? 0 : st.steps[e]) * 2ULL;
             sh.rescan_key = sh.step_key + 1;
-            sh.next_chunk = 0; sh.park_count = 0; sh.park_next = 0;
+            sh.next_chunk = 0; sh.park_count = 0; sh.park_next = 0; sh.pair_done = 0;
         }
     }
     __syncthreads();
@@ -1351,15 +1374,23 @@ __device__ __forceinline__ void step_arena(const navsim_config& c, const navsim_
     // wavefront 0 alone (pedestrian i on lane i); the others go straight to the scan, whose barrier before the merge
     // publishes the primitives
     if constexpr (PEDS) {
+        // the pair table: dynamic LDS behind PedShared (the host allocates it for the launches that carry the phase)
+        double2* pair = (double2*)(dyn_lds + ((dyn_lds_bytes + 15u) & ~15u) + ((ped_lds_bytes(N) + 15) & ~(size_t)15));
+#ifdef NAVSIM_PAIR_SHARE_ALL
+        constexpr int kPairWaves = (BLOCK >= NAVSIM_PAIR_SHARE_MIN_BLOCK) ? 4 : 1;       // wavefronts that share the pair terms
+#else
+        constexpr int kPairWaves = (INSTALL && BLOCK >= NAVSIM_PAIR_SHARE_MIN_BLOCK) ? 4 : 1;       // wavefronts that share the pair terms
+#endif
+        const bool pair_shared = PINL && kPairWaves > 1 && ped_advance && c.ped_model == NAVSIM_PED_SFM;
+        if constexpr (PINL && kPairWaves > 1) {
+            if (pair_shared && tid < kPairWaves * 64) ped_pair_share(c, ps, pair, n, tid, kPairWaves, &sh.pair_done);
+        }
         if (tid < 64) {
             const int lane = tid;
             if constexpr (PINL) {
-                if (ped_advance) {
-                    // the pair table: dynamic LDS behind PedShared (the host allocates it for the launches that carry the phase)
-                    double2* pair = (double2*)(dyn_lds + ((dyn_lds_bytes + 15u) & ~15u) + ((ped_lds_bytes(N) + 15) & ~(size_t)15));
+                if (ped_advance)
                     ped_advance_wave<Field>(c, st, field, e, n, lane, is_ped, pq, dt, genv, (uint64_t)st.steps[e], ps, pair,
-                                            ped_head, ped_nw, pp, pvel);
-                }
+                                            ped_head, ped_nw, pp, pvel, &sh.pair_done, pair_shared ? kPairWaves : 1);
             }
             if (reset_only && is_ped) {                             // env.py:809, 812-820
                 st.ped_dist[pq * 3] = 0.0; st.ped_dist[pq * 3 + 1] = 0.0; st.ped_dist[pq * 3 + 2] = 0.0;
