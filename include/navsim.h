@@ -587,6 +587,14 @@ int    navsim_regen_swap(const navsim_config* cfg, const navsim_state* live, con
                          const long long* ready, void* stream);
 int    navsim_regen_stage(const navsim_config* cfg, const navsim_state* stage, const navsim_step_io* io, uint8_t* want,
                           uint8_t* mark, long long* ready, void* workspace, size_t workspace_bytes, void* stream);
+/* navsim_regen_stage for a SHARE of the arenas (round 6): part p of n takes the marks of the 32-bit words w of mark[] with
+ * w % n == p -- arenas in groups of four -- into ITS OWN want[] (one array per part; io->done = that array) and stages them.  Parts
+ * own disjoint arenas: passes of different parts may run at the same time on different streams, each with its own workspace
+ * (the launches of a staging pass for corridor maps with planned starts are latency-bound chains that leave the chip idle:
+ * NavSim alternates two parts).  navsim_regen_stage(...) = part 0 of 1. */
+int    navsim_regen_stage_part(const navsim_config* cfg, const navsim_state* stage, const navsim_step_io* io, uint8_t* want,
+                               uint8_t* mark, long long* ready, void* workspace, size_t workspace_bytes, int32_t part,
+                               int32_t n_parts, void* stream);
 /* Round 5, the PIPELINED form (ready != NULL, cfg.regen_min_steps > 0): staging passes need not finish before the next swap.
  * ready [2 E] int64 (the second half is the passes' scratch; initialise [0, E) with the staged episode numbers once every arena
  * is staged): navsim_regen_stage records for every arena it served the episode number it staged; navsim_regen_swap installs a finished arena's staged world iff its episode lasted at least cfg.regen_min_steps

@@ -744,9 +744,11 @@ __global__ __launch_bounds__(256) void regen_swap_kernel(navsim_config c, navsim
 
 // opens a staging pass: what the last swap decided becomes part of want[]
 __global__ __launch_bounds__(256) void regen_merge_want_kernel(uint8_t* __restrict__ want, uint8_t* __restrict__ mark, int E,
-                                                               long long* __restrict__ ready, const int64_t* __restrict__ stage_episode) {
+                                                               long long* __restrict__ ready, const int64_t* __restrict__ stage_episode,
+                                                               int part = 0, int n_parts = 1) {
     const int w = blockIdx.x * 256 + threadIdx.x;            // one 32-bit word of mark[] = four arenas
     if (4 * w >= E) return;
+    if (n_parts > 1 && w % n_parts != part) return;          // navsim_regen_stage_part: this pass's share of the arenas (by mark word)
     const unsigned m = atomicExch((unsigned*)mark + w, 0u);  // (a swap may be setting flags of this word right now)
     __threadfence();
     for (int k = 0; k < 4; ++k) {

@@ -913,11 +913,17 @@ int navsim_regen_swap(const navsim_config* c, const navsim_state* live, const na
 
 int navsim_regen_stage(const navsim_config* c, const navsim_state* stage, const navsim_step_io* io, uint8_t* want, uint8_t* mark,
                        long long* ready, void* workspace, size_t workspace_bytes, void* stream) {
+    return navsim_regen_stage_part(c, stage, io, want, mark, ready, workspace, workspace_bytes, 0, 1, stream);
+}
+
+int navsim_regen_stage_part(const navsim_config* c, const navsim_state* stage, const navsim_step_io* io, uint8_t* want, uint8_t* mark,
+                            long long* ready, void* workspace, size_t workspace_bytes, int32_t part, int32_t n_parts, void* stream) {
     (void)hipGetLastError();
     if (!c || !stage || !io || !want || !mark || !workspace || io->done != want || !stage->episode) return NAVSIM_E_ARG;
-    if (((uintptr_t)mark & 3) != 0) return NAVSIM_E_ARG;
+    if (((uintptr_t)mark & 3) != 0 || n_parts < 1 || part < 0 || part >= n_parts) return NAVSIM_E_ARG;
     if (c->n_envs == 0) return NAVSIM_OK;
-    regen_merge_want_kernel<<<((c->n_envs + 3) / 4 + 255) / 256, 256, 0, (hipStream_t)stream>>>(want, mark, c->n_envs, ready, stage->episode);
+    regen_merge_want_kernel<<<((c->n_envs + 3) / 4 + 255) / 256, 256, 0, (hipStream_t)stream>>>(want, mark, c->n_envs, ready, stage->episode,
+                                                                                                part, n_parts);
     // the staged state takes EVERY arena in want[], whatever its last episode's length (cfg.regen_min_steps is the live state's rule)
     navsim_config cs = *c;
     cs.regen_min_steps = 0;

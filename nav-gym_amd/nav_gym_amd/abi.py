@@ -344,6 +344,7 @@ def declare(lib, suffix=""):
         sig("navsim_regen", [cfgp, stp, iop, _P, C.c_size_t, _P])
         sig("navsim_regen_swap", [cfgp, stp, stp, iop, _P, _P, _P, _P, _P])
         sig("navsim_regen_stage", [cfgp, stp, iop, _P, _P, _P, _P, C.c_size_t, _P])
+        sig("navsim_regen_stage_part", [cfgp, stp, iop, _P, _P, _P, _P, C.c_size_t, i32, i32, _P])
         sig("navsim_step_install", [cfgp, stp, iop, stp, _P, _P, _P, _P, _P])
         sig("navsim_regen_helper", [_P])
         sig("navsim_step_install_replan", [cfgp, stp, iop, stp, _P, _P, _P, _P, C.c_int32, _P])
@@ -373,7 +374,7 @@ EXPORTS = (
     "navsim_rect_index_bytes", "navsim_build_rect_index", "navsim_maps_closed", "navsim_world_closed",
     "navsim_cast_static",
     "navsim_render_polys", "navsim_render_legs", "navsim_integrate", "navsim_reward_done",
-    "navsim_scan_threshold", "navsim_beam_table", "navsim_ped_scans", "navsim_ped_scans_part", "navsim_ped_policy_part", "navsim_regen_workspace_bytes", "navsim_regen", "navsim_regen_swap", "navsim_regen_stage", "navsim_step_install", "navsim_regen_helper", "navsim_step_install_replan", "navsim_step_install_next",
+    "navsim_scan_threshold", "navsim_beam_table", "navsim_ped_scans", "navsim_ped_scans_part", "navsim_ped_policy_part", "navsim_regen_workspace_bytes", "navsim_regen", "navsim_regen_swap", "navsim_regen_stage", "navsim_regen_stage_part", "navsim_step_install", "navsim_regen_helper", "navsim_step_install_replan", "navsim_step_install_next",
     "navsim_costmap", "navsim_plan", "navsim_launch_order", "navsim_replan_workspace_bytes", "navsim_replan", "navsim_ped_policy_workspace_bytes", "navsim_ped_policy", "navsim_ped_scan_policy",
     "navsim_crowd_check", "navsim_crowd_angular_map", "navsim_crowd_local_map", "navsim_crowd_orca", "navsim_crowd_agent_step",
     "navsim_step", "navsim_step_part", "navsim_step_replan", "navsim_prepare", "navsim_reset_obs", "navsim_restart", "navsim_step_kernel_name",

@@ -24,8 +24,8 @@ and default to the reference's behaviour for num_envs == 1:
                     with the robot's wheel radius / track (robots.py; Husky: husky.urdf.xacro:61-67)
     clip_actions    True: the twist is clamped to linvel_range x rotvel_range on the device (the reference only prints
                     a warning and never clips, env.py:606-613: default False)
-    regen_min_steps, pregen_pipeline   (randomize_maps) pregen_pipeline = P > 0 (default: 8 for worlds of corridor maps with
-                    planned starts, else 4; 0 where the pipeline is not available): the next world of every arena is staged ahead
+    regen_min_steps, pregen_pipeline   (randomize_maps) pregen_pipeline = P > 0 (default: 4; for worlds of corridor maps with
+                    planned starts the passes alternate between two side streams; 0 where the pipeline is not available): the next world of every arena is staged ahead
                     of time on a side stream (a pass every P steps) and installed inside the step's own launch.  With
                     regen_min_steps = 0 (default) the rollout is EXACTLY the one without the pipeline: an arena that finishes
                     before its world is staged is generated on the spot (counters()['regen_late']).  regen_min_steps >= 4 P
@@ -34,6 +34,11 @@ and default to the reference's behaviour for num_envs == 1:
                     The on-the-spot fallback serves at most max(8, num_envs // 128) arenas per step: more late arenas than
                     that in ONE step keep their old map for the next episode and are counted in counters()['regen_unserved']
                     (not seen in the soaks of profiles/r05_pipe/: a pass every P steps leaves a handful of late arenas per step)
+    pregen_fallback_poll   (pregen_pipeline, regen_min_steps < 4 P) True: step() reads one byte back from the device -- "did this step
+                    leave an arena without its staged world?" -- and launches the on-the-spot generation only then, instead of
+                    enqueueing its launches blind behind every step.  A host wait per step; default (None): on for worlds of
+                    corridor maps or planned starts, whose fallback is ~18 launches (the reference's configuration: 2.74 -> 3.25 M env-steps/s at 1024 arenas, 3.74 -> 4.07 M at 4096),
+                    off otherwise.  Same rollout either way.
     use_graphs      replay a step's launches (navsim_step, navsim_regen, navsim_replan) as one captured hipGraph; None
                     (default) = when randomize_maps makes a step several launches (c5: +6 %) and navsim_regen does not fork
                     (corridor maps with planned starts: plain launches are as fast or faster); results are identical
@@ -182,7 +187,7 @@ class NavGymEnv(_EnvBase):
                  field_format=abi.FIELD_U16T, n_spawn=None, randomize_maps=False, plan_paths=True,
                  action_kind="twist", clip_actions=False, max_waypoints=64, march_rule=None, use_graphs=None,
                  regen_min_steps=0, pregen_pipeline=None, pregen_stage_cap=None, autoreset_mode="same_step",
-                 final_observation=True):
+                 final_observation=True, pregen_fallback_poll=None):
         from . import lib
         if robot_type not in robots.ROBOTS:
             raise NotImplementedError(robot_type)            # env.py:772-773
@@ -201,7 +206,7 @@ class NavGymEnv(_EnvBase):
             randomize_maps=randomize_maps, plan_paths=plan_paths, action_kind=action_kind, clip_actions=clip_actions,
             max_waypoints=max_waypoints, march_rule=march_rule, use_graphs=use_graphs,
             regen_min_steps=regen_min_steps, pregen_pipeline=pregen_pipeline, pregen_stage_cap=pregen_stage_cap,
-            autoreset_mode=autoreset_mode, final_observation=final_observation)
+            autoreset_mode=autoreset_mode, final_observation=final_observation, pregen_fallback_poll=pregen_fallback_poll)
         self.robot_type = robot_type
         self.time_step = time_step
         self.min_turning_radius = min_turning_radius
@@ -247,22 +252,25 @@ class NavGymEnv(_EnvBase):
         # (navsim_step_install) -- navsim_regen leaves the step's critical path.  It rests on regen_min_steps >= 4 P: an
         # episode that ended after fewer steps restarts on its OLD map (the reference draws a map at every reset: opt-in).
         # None (default): the pipelined reset path wherever it is available (packed field, i.e. map_size <= 1024; not with
-        # pedestrian_model='policy') -- a pass every 8 steps for worlds whose reset is heavy (corridor maps with planned starts,
-        # the reference's own kind: 64 to 4096 arenas run as fast or faster than with 4, profiles/r05_refdef/pipeline_sweep.txt),
-        # every 4 steps otherwise (a c5-shaped world through this API: 5.4 -> 7.4 M env-steps/s, with planned routes 1.3 -> 3.0 M,
-        # profiles/_diag/gym_c5_steps.py).  With regen_min_steps = 0 it changes no result: the rollout is the one of
+        # pedestrian_model='policy') -- a pass every 4 steps (a c5-shaped world through this API: 5.4 -> 7.4 M env-steps/s, with planned
+        # routes 1.3 -> 3.0 M, profiles/_diag/gym_c5_steps.py); for worlds whose reset is heavy (corridor maps with planned starts, the
+        # reference's own kind) the passes alternate between two side streams, each of which starts one every 8 steps
+        # (profiles/r05_refdef/pipeline_sweep.txt, profiles/r06_planner/ab_stage_lanes.txt).  With regen_min_steps = 0 it changes no result: the rollout is the one of
         # pregen_pipeline=0, bit for bit.
         self._pregen_auto = pregen_pipeline is None
         if pregen_pipeline is None:
             available = (pedestrian_model != "policy" and field_format == abi.FIELD_U16T and
                          (map_size == "reference" or int(map_size) <= 1024))
             heavy = bool(plan_paths) and float(indoor_ratio) > 0.0 and (map_size == "reference" or int(map_size) <= 1000)
-            pregen_pipeline = (8 if heavy else 4) if available else 0
+            # (worlds of corridor maps with planned starts: a pass every 4 steps too since round 6 -- their passes alternate between
+            #  two side streams, NavSim.enable_pregen stage_lanes, i.e. each stream still starts one every 8 steps)
+            pregen_pipeline = 4 if available else 0
             if use_graphs:                         # (asked for: the graph replay of step + navsim_regen is the other form)
                 pregen_pipeline = 0
         self.pregen_pipeline = int(pregen_pipeline) if (self.randomize_maps and self.auto_reset) else 0
         self.regen_min_steps = int(regen_min_steps)
         self.pregen_stage_cap = pregen_stage_cap        # arenas one staging pass serves at most (None: NavSim.enable_pregen's default)
+        self.pregen_fallback_poll = pregen_fallback_poll   # None: NavSim.enable_pregen's default (on for corridor maps / planned starts)
         if self.pregen_pipeline:
             # regen_min_steps >= 4 P: the rule (fastest; short episodes keep their map).  Below that -- 0 is the reference's own
             # "a new map at every reset()" -- an arena that finishes before its world is staged is generated on the spot by
@@ -483,7 +491,8 @@ class NavGymEnv(_EnvBase):
             if cfg.field_format != abi.FIELD_U16T:
                 raise ValueError("pregen_pipeline needs the packed distance field (map_size <= 1024)")
             if first:
-                self.sim.enable_pregen(pipeline=self.pregen_pipeline, install=True, stage_cap=self.pregen_stage_cap)
+                self.sim.enable_pregen(pipeline=self.pregen_pipeline, install=True, stage_cap=self.pregen_stage_cap,
+                                       fallback_poll=self.pregen_fallback_poll)
             else:
                 self.sim.restage_all()                    # the worlds behind the ones this reset() just drew
         if first and self.use_graphs and self.pedestrian_model != "policy":

@@ -661,7 +661,7 @@ class NavSim(object):
     MAPS = ("field", "field_overflow", "rect_table", "rect_index", "costmap")      # the per-map arrays (navsim_state.map_slot)
 
     def enable_pregen(self, scratch_bytes=4 << 30, pipeline=0, install=False, stage_cap=None, map_slots=True, fallback=None,
-                      fallback_cap=None, late_beside=False):
+                      fallback_cap=None, late_beside=False, fallback_poll=None, stage_lanes=None):
         """navsim_regen off the step's critical path (include/navsim.h navsim_regen_swap): the world every arena will
         get at the end of its CURRENT episode -- a function of (seed, global arena, episode number) only -- is generated
         ahead of time into a second, staged state by the ordinary navsim_regen on a side stream; regen() then only
@@ -684,6 +684,17 @@ class NavSim(object):
         ONE step restart on their old map like navsim_regen's own cap, counters()['regen_unserved']).  The
         rollout then equals step + navsim_regen whatever the passes' timing, also with cfg.regen_min_steps = 0: the reference's
         "a new map at every reset()" unchanged.
+        fallback_poll (with fallback; round 6): the fallback's navsim_regen is launched only when the step flagged somebody -- regen()
+        reads "any flag set?" back from the device (one byte, a host wait for the step's launch) instead of enqueueing the
+        call's launches blind.  Default: on where that call is the long chain of worlds with corridor maps or planned starts
+        (~18 launches, ~160 us of mostly empty launches behind every ~80 us step of the reference's configuration:
+        profiles/r05_refdef/timeline_pipeline8_no_rule_cap16.txt), off where it is three short launches (c5) and under graph
+        capture.  Same rollout either way.
+        stage_lanes (with install and pipeline; round 6): 2 = the staging passes alternate between two side streams, each with its own
+        share of the arenas (navsim_regen_stage_part: groups of four by mark word), workspace and helper stream, so that two
+        passes run at the same time -- a pass for corridor maps with planned starts is a chain of ~25 latency-bound launches
+        (the planner's four wait for their longest search each) that leaves the chip idle, and the passes' rate is what bounds the
+        reference's configuration once the fallback's blind launches are gone.  Default: 2 for those worlds, else 1.
         map_slots (with install): the live and the staged state share the per-map arrays (t['field'], ... then hold 2 E slots)
         and each has a slot table (navsim_state.map_slot); an install exchanges two table entries instead of copying the
         map -- numpy_state() resolves the table, code that indexes t['field'] by arena must go through t['map_slot']."""
@@ -759,6 +770,25 @@ class NavSim(object):
         if self.cfg.regen_plan and self.cfg.regen_indoor_ratio > 0.0:
             self._regen_helper = concurrent_stream(self.device, beside=[torch.cuda.current_stream(self.device), self.side])
             check(self.lib.navsim_regen_helper(C.c_void_p(self._regen_helper.cuda_stream)), "navsim_regen_helper")
+        heavy = bool(self.cfg.regen_plan) or self.cfg.regen_indoor_ratio > 0.0
+        lanes = int(stage_lanes) if stage_lanes else (2 if (install and P and heavy) else 1)
+        if lanes not in (1, 2) or (lanes == 2 and not (install and P)):
+            raise ValueError("enable_pregen(stage_lanes=%r): 1, or 2 with install=True and pipeline > 0" % (stage_lanes,))
+        # lane 0 = the objects above; lane 1: its own want[], io, workspace, stream and helper stream
+        self.stage_lane = [dict(want=self.want, io=self.stage_io, ws=self.stage_ws, side=self.side,
+                                helper=getattr(self, "_regen_helper", None))]
+        if lanes == 2:
+            want2 = torch.zeros(E, dtype=torch.uint8, device=self.device)
+            io2 = abi.NavsimStepIO()
+            C.memmove(C.byref(io2), C.byref(self.stage_io), C.sizeof(io2))
+            io2.done = want2.data_ptr()
+            side2 = concurrent_stream(self.device, beside=[torch.cuda.current_stream(self.device), self.side], priority=0)
+            helper2 = None
+            if getattr(self, "_regen_helper", None) is not None:
+                helper2 = concurrent_stream(self.device, beside=[torch.cuda.current_stream(self.device), self.side, side2])
+            self.stage_lane.append(dict(want=want2, io=io2, ws=torch.zeros(nbytes, dtype=torch.uint8, device=self.device), side=side2,
+                                        helper=helper2))
+        self.pg_passes = 0
         self.ev_swapped, self.ev_staged = torch.cuda.Event(), torch.cuda.Event()
         self.ev_staged.record(torch.cuda.current_stream())
         self.pg_swapped = [torch.cuda.Event() for _ in range(3)]      # pass j uses slot j % 3; step j P waits for pass j - 2
@@ -787,6 +817,9 @@ class NavSim(object):
             self.urgent = concurrent_stream(self.device, beside=[torch.cuda.current_stream(self.device), self.side])
             self.ev_stepped, self.ev_urgent = torch.cuda.Event(), torch.cuda.Event()
             self.ev_stepped.record(torch.cuda.current_stream())
+        if fallback_poll is None:
+            fallback_poll = bool(self.cfg.regen_plan) or self.cfg.regen_indoor_ratio > 0.0
+        self.late_poll = bool(fallback and fallback_poll and not self.next_step)
         if fallback:
             self.late_cfg = self.cfg.copy()
             # (every launch of the fallback is sized by its cap whether anybody is late or not: with 16 slots the planner's
@@ -805,8 +838,11 @@ class NavSim(object):
         the second time, new episode numbers) -- stage the world behind each arena's current one again.
         slots_from_live: the live slot table was replaced (load_state_dict) -- the staged one is its complement."""
         import torch
-        self.side.synchronize()
+        for ln in getattr(self, "stage_lane", [dict(side=self.side)]):
+            ln["side"].synchronize()
         torch.cuda.current_stream().synchronize()
+        for ln in getattr(self, "stage_lane", [])[1:]:
+            ln["want"].zero_()
         if slots_from_live and "map_slot" in self.t:
             free = torch.ones(2 * self.cfg.n_envs, dtype=torch.bool, device=self.device)
             free[self.t["map_slot"].long()] = False
@@ -848,7 +884,11 @@ class NavSim(object):
         self.pg_k += 1
         j = k // P if P else 0
         if self.pg_install:                              # step() has installed; only the passes are left
-            if self.late is not None and getattr(self, "late2", None) is None and not getattr(self, "lone", False):   # ... and whoever finished before its world was staged (rare): now
+            need = self.late is not None and getattr(self, "late2", None) is None and not getattr(self, "lone", False)
+            if need and getattr(self, "late_poll", False) and not torch.cuda.is_current_stream_capturing():
+                # (the host waits for the step's launch here; what it saves is the fallback's blind launches behind EVERY step)
+                need = bool(self.late.any().item())
+            if need:   # ... and whoever finished before its world was staged (rare): now
                 C.memmove(C.byref(self.late_cfg), C.byref(self.cfg), C.sizeof(self.cfg))
                 self.late_cfg.regen_cap = self.late_cap
                 io = abi.NavsimStepIO()
@@ -893,7 +933,8 @@ class NavSim(object):
         next 2 P steps then rest on no earlier pass.  Call it before capturing steps into a hipGraph: a captured wait must
         not refer to an event recorded outside the capture."""
         import torch
-        self.side.synchronize()
+        for ln in getattr(self, "stage_lane", [dict(side=self.side)]):
+            ln["side"].synchronize()
         torch.cuda.current_stream().synchronize()
         self.pg_k = 0
         self.pg_open = []
@@ -912,21 +953,32 @@ class NavSim(object):
         """A staging pass on the side stream, behind everything `main` holds now."""
         if self.pg_period:
             self.pg_open = (getattr(self, "pg_open", []) + [staged])[-2:]
+        lanes = getattr(self, "stage_lane", None) or [dict(want=self.want, io=self.stage_io, ws=self.stage_ws, side=self.side, helper=None)]
+        n = len(lanes)
+        ln = lanes[self.pg_passes % n] if n > 1 else lanes[0]
+        part = self.pg_passes % n
+        self.pg_passes = getattr(self, "pg_passes", 0) + 1
+        side = ln["side"]
         swapped.record(main)
-        self.side.wait_event(swapped)
+        side.wait_event(swapped)
         C.memmove(C.byref(self.stage_cfg), C.byref(self.cfg), C.sizeof(self.cfg))     # the configuration as it stands NOW
         self.stage_cfg.regen_cap = self.stage_cap
-        ws = self.stage_ws
-        check(self.lib.navsim_regen_stage(C.byref(self.stage_cfg), C.byref(self.stage_st), C.byref(self.stage_io), _ptr(self.want),
-                                          _ptr(self.mark), _ptr(self.ready), _ptr(ws), ws.numel(), C.c_void_p(self.side.cuda_stream)),
-              "navsim_regen_stage")
-        staged.record(self.side)
+        ws = ln["ws"]
+        if n > 1 and ln["helper"] is not None:                 # this lane's passes fork their distance transforms to their own helper
+            self.lib.navsim_regen_helper(C.c_void_p(ln["helper"].cuda_stream))
+        check(self.lib.navsim_regen_stage_part(C.byref(self.stage_cfg), C.byref(self.stage_st), C.byref(ln["io"]), _ptr(ln["want"]),
+                                               _ptr(self.mark), _ptr(self.ready), _ptr(ws), ws.numel(), part, n,
+                                               C.c_void_p(side.cuda_stream)),
+              "navsim_regen_stage_part")
+        if n > 1 and ln["helper"] is not None and getattr(self, "_regen_helper", None) is not None:
+            self.lib.navsim_regen_helper(C.c_void_p(self._regen_helper.cuda_stream))
+        staged.record(side)
 
     def close(self):
         """Waits for what this simulator has in flight on streams of its own (staging passes, the overlapped re-plan): their
         kernels write into arrays that are about to be released."""
-        for name in ("side", "_side", "_scan_stream", "_regen_helper", "urgent"):
-            st = getattr(self, name, None)
+        extra = [ln[k] for ln in getattr(self, "stage_lane", [])[1:] for k in ("side", "helper")]
+        for st in [getattr(self, name, None) for name in ("side", "_side", "_scan_stream", "_regen_helper", "urgent")] + extra:
             if st is not None:
                 try:
                     st.synchronize()

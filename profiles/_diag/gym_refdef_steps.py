@@ -13,6 +13,15 @@ if os.environ.get("NAVSIM_PIPELINE"):          # pipelined pre-generation: regen
     kw["pregen_pipeline"] = int(os.environ["NAVSIM_PIPELINE"]); kw["regen_min_steps"] = 4 * kw["pregen_pipeline"]
 if os.environ.get("NAVSIM_STAGE_CAP"):
     kw["pregen_stage_cap"] = int(os.environ["NAVSIM_STAGE_CAP"])
+if os.environ.get("NAVSIM_POLL"):               # the fallback's launches only when the step flagged somebody (round 6): 1 / 0 (default: the env's)
+    kw["pregen_fallback_poll"] = os.environ["NAVSIM_POLL"] == "1"
+if os.environ.get("NAVSIM_LANES"):              # staging passes alternating between two side streams (round 6): handed to NavSim.enable_pregen
+    import nav_gym_amd.sim as _sim
+    _orig = _sim.NavSim.enable_pregen
+    def _ep(self, *a, _n=int(os.environ["NAVSIM_LANES"]), **k):
+        k.setdefault("stage_lanes", _n)
+        return _orig(self, *a, **k)
+    _sim.NavSim.enable_pregen = _ep
 if os.environ.get("NAVSIM_MIN_STEPS"):
     kw["regen_min_steps"] = int(os.environ["NAVSIM_MIN_STEPS"])
 env = nav_gym_env.make("NavGym-v0", num_envs=E, map_size="reference", randomize_maps=True, device="cuda:0", seed=1234, **kw)

@@ -787,7 +787,7 @@ def test_env_pipeline_falls_back_when_the_staged_copy_does_not_fit(gpu, monkeypa
     E = 16
     mk = lambda: nav_gym_amd.NavGymEnv(num_envs=E, map_size=200, seed=21, num_humans=3, randomize_maps=True, **kw)
     a = mk(); a.reset()
-    assert a.pregen_pipeline == 8 and a.sim.pg_install
+    assert a.pregen_pipeline == 4 and a.sim.pg_install and len(a.sim.stage_lane) == 2
     NavGymEnv._warned.discard("pregen_memory")
     total = torch.cuda.mem_get_info(torch.device(gpu.dev))[1]
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *args, **kwargs: (1 << 20, total))
@@ -804,6 +804,34 @@ def test_env_pipeline_falls_back_when_the_staged_copy_does_not_fit(gpu, monkeypa
         oa, ra, da, _ = a.step(acts[t]); ob, rb, db, _ = b.step(acts[t])
         assert torch.equal(oa["observation"], ob["observation"]) and torch.equal(ra, rb) and torch.equal(da, db), "step %d" % t
     assert a.counters()["regen_served"] > 2
+
+
+def test_polled_fallback_equals_the_blind_one(gpu):
+    """pregen_fallback_poll (round 6): the on-the-spot generation of an arena that finished before its world was staged is
+    launched only when the step flagged somebody (one byte read back per step) -- the env's default for worlds of corridor maps /
+    planned starts -- or enqueued blind behind every step: the same rollout, and late arenas do occur in it."""
+    import nav_gym_amd
+    torch = gpu.torch
+    kw = dict(nav_gym_amd.DEFAULT_KWARGS)
+    E = 48
+    mk = lambda poll: nav_gym_amd.NavGymEnv(num_envs=E, map_size=200, seed=33, num_humans=3, randomize_maps=True, pregen_pipeline=4,
+                                            pregen_fallback_poll=poll, **kw)
+    a, b, d = mk(True), mk(False), mk(None)
+    a.reset(); b.reset(); d.reset()
+    assert a.sim.late_poll and not b.sim.late_poll and d.sim.late_poll        # (planned starts: the default is to poll)
+    g = torch.Generator(device=gpu.dev); g.manual_seed(4)
+    T = 120
+    acts = torch.rand((T, E, 2), generator=g, device=gpu.dev, dtype=torch.float64)
+    acts[..., 0] *= 0.5; acts[..., 1] = acts[..., 1] * 1.28 - 0.64
+    acts[::3, :, 0] = 0.5; acts[::3, :, 1] = 0.0                              # (straight ahead every third step: episodes end often)
+    for t in range(T):
+        oa, ra, da, ia = a.step(acts[t]); ob, rb, db, ib = b.step(acts[t])
+        assert torch.equal(oa["observation"], ob["observation"]) and torch.equal(ra, rb) and torch.equal(da, db), "step %d" % t
+        assert torch.equal(ia["final_observation"]["observation"], ib["final_observation"]["observation"])
+    ca, cb = a.counters(), b.counters()
+    late = (ca.pop("regen_late"), cb.pop("regen_late"))     # (how many arenas were late depends on the passes' timing; nothing else does)
+    assert ca == cb and ca["regen_served"] > 10 and ca["regen_unserved"] == 0 and late[0] > 0, (ca, cb, late)
+    a.close(); b.close(); d.close()
 
 
 @pytest.mark.parametrize("pipeline", [0, 2])

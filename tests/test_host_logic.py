@@ -208,9 +208,9 @@ def test_env_picks_the_pipelined_reset_path_where_it_pays():
     from nav_gym_amd import abi
     mk = lambda **kw: nav_gym_env.make("NavGym-v0", **kw)
     e = mk(num_envs=8, map_size="reference", randomize_maps=True)
-    assert e.pregen_pipeline == 8 and e.regen_min_steps == 0 and e.cfg.regen_min_steps == 0
+    assert e.pregen_pipeline == 4 and e.regen_min_steps == 0 and e.cfg.regen_min_steps == 0
     assert e.cfg.regen_cap == 8 and e.cfg.defer_reset_scan == 0 and e.use_graphs is False       # every arena decides alone
-    assert pickle.loads(pickle.dumps(e)).pregen_pipeline == 8
+    assert pickle.loads(pickle.dumps(e)).pregen_pipeline == 4
     assert mk(num_envs=8, map_size="reference", randomize_maps=True, pregen_pipeline=0).pregen_pipeline == 0
     g = mk(num_envs=8, map_size=500, randomize_maps=True, indoor_ratio=0.0, use_graphs=True)       # graph replay asked for: the other form
     assert g.pregen_pipeline == 0 and g.use_graphs is True
