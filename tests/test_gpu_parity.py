@@ -926,7 +926,7 @@ def test_reference_default_configuration_sampled_oracle(gpu, pipeline):
     kw = dict(regen_min_steps=8, pregen_pipeline=2) if pipeline == 2 else dict(pregen_pipeline=0)
     norule = pipeline == "norule"       # the env's DEFAULT for this world: the pipeline without a rule -- whoever finishes before
     if norule:                          # its world is staged is generated on the spot
-        kw, pipeline = {}, 8
+        kw, pipeline = {}, 4
     if pipeline == "graphs":                                 # (the default is plain launches since navsim_regen forks: the captured form too)
         kw, pipeline = dict(use_graphs=True, pregen_pipeline=0), 0
     env = nav_gym_env.make("NavGym-v0", num_envs=E, map_size="reference", randomize_maps=True, seed=41, device=gpu.dev, **kw)
