@@ -190,6 +190,9 @@ __device__ __forceinline__ void plan_query(const uint8_t* __restrict__ c, int Hc
         const u64 s_bit = 1ull << (si & 63);
         if constexpr (MAXWPT == 1) {
             plan_levels<BLOCK, 1>(fa, fb, planes, Hc, Wc, Ww, n_words, s_word, s_bit, any_s, &reached);      // (the caller checked n_words <= BLOCK)
+        } else if constexpr (MAXWPT == 2) {                  // (the caller checked n_words <= 2 BLOCK: the 512-thread searches of large launches)
+            if (n_words <= BLOCK) plan_levels<BLOCK, 1>(fa, fb, planes, Hc, Wc, Ww, n_words, s_word, s_bit, any_s, &reached);
+            else                  plan_levels<BLOCK, 2>(fa, fb, planes, Hc, Wc, Ww, n_words, s_word, s_bit, any_s, &reached);
         } else {
             // (plan_fits: at most kPlanMaxWpt * 256 words -- a 1024-thread workgroup never owns more than two per thread; with
             //  the four- and eight-word forms compiled in, its 128-register budget spilled 36-96 registers per lane)

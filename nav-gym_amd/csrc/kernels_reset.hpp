@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void regen_ped_accept_kernel(navsim_config c, 
 // ~10 ns each.  (Measured and dropped: a bounded launch whose workgroups loop over the items of the arenas that really
 // finished -- the loop around the search costs its registers: 162 -> 226 us per launch, profiles/r05_refdef/.)
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void regen_plan_kernel(navsim_config c, navsim_state st, const int* __restrict__ count,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BLOCK == 512 ? 8 : 1, 8))) void regen_plan_kernel(navsim_config c, navsim_state st, const int* __restrict__ count,
                                                          const int* __restrict__ list, RegenPlanWs ws, int ped_stage, int pass, int Qs) {
     const int item = (int)blockIdx.x;
     const int b = item / (kRegenRounds * Qs), rem = item - b * (kRegenRounds * Qs), round = rem / Qs, k = rem - round * Qs;
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(BLOCK) void regen_plan_kernel(navsim_config c, navs
         if (ok0) return;
     }
     const int Hc = c.map_h / 5, Wc = c.map_w / 5, P = c.max_waypoints;
-    plan_query<BLOCK>(ws.cost + (size_t)(ws.cost_by_arena ? map_slot_of(c, st, list[b]) : b) * Hc * Wc, Hc, Wc, c.resolution * 5.0, c.origin_x, c.origin_y,
+    plan_query<BLOCK, BLOCK == 512 ? 2 : kPlanMaxWpt>(ws.cost + (size_t)(ws.cost_by_arena ? map_slot_of(c, st, list[b]) : b) * Hc * Wc, Hc, Wc, c.resolution * 5.0, c.origin_x, c.origin_y,
                       ws.qstart[2 * q], ws.qstart[2 * q + 1], ws.qgoal[2 * q], ws.qgoal[2 * q + 1], ped_stage ? 2.0 : 5.0, P,
                       ws.qwp + q * P * 2, ws.qnwp + q, nullptr, ped_stage ? nullptr : ws.qlen + q, ped_stage ? ws.qcut + q : nullptr);
 }

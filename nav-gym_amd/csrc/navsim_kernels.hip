@@ -50,6 +50,10 @@ NAVSIM_STEP_FAMILY(64, 0) NAVSIM_STEP_FAMILY(64, 1) NAVSIM_STEP_FAMILY(256, 0) N
 NAVSIM_STEP_FAMILY(512, 0) NAVSIM_STEP_FAMILY(512, 1) NAVSIM_STEP_FAMILY(1024, 0) NAVSIM_STEP_FAMILY(1024, 1)
 #undef NAVSIM_STEP_FAMILY
 
+#ifndef NAVSIM_PLAN_MANY_SEARCHES
+#define NAVSIM_PLAN_MANY_SEARCHES 2048          // searches per planner launch of navsim_regen from which 512 threads per search are used
+#endif
+
 namespace {
 
 // navsim_debug_kernarg_layout: the views against the copies (the four leading parameters of the install kernels + one scalar)
@@ -735,8 +739,14 @@ int navsim_regen(const navsim_config* c, const navsim_state* st, const navsim_st
         auto plan_pass = [&](int ped_stage, int pass) {
             const int Qs = ped_stage ? c->max_peds : c->n_spawn;
             const int grid = M * R * Qs;
-            if (plan_block(Hc, Wc) == 1024) regen_plan_kernel<1024><<<grid, 1024, lds, s>>>(*c, *st, count, list, ws, ped_stage, pass, Qs);
-            else                            regen_plan_kernel<256><<<grid, 256, lds, s>>>(*c, *st, count, list, ws, ped_stage, pass, Qs);
+            // Threads per search.  1024 (a costmap word per thread) is the shortest search -- and two searches per CU; 512 (two words
+            // per thread) is longer and four per CU.  A call that serves a handful of arenas (the per-step reset: under one search per
+            // CU) waits for its longest search; a staging pass of dozens of arenas is thousands of searches -- generations of
+            // workgroups -- and gets through them faster twice as many at a time (round 6).
+            const bool many = (long long)grid > (long long)NAVSIM_PLAN_MANY_SEARCHES && plan_words(Hc, Wc) <= 2 * 512;
+            if (plan_block(Hc, Wc) == 1024 && many) regen_plan_kernel<512><<<grid, 512, lds, s>>>(*c, *st, count, list, ws, ped_stage, pass, Qs);
+            else if (plan_block(Hc, Wc) == 1024)    regen_plan_kernel<1024><<<grid, 1024, lds, s>>>(*c, *st, count, list, ws, ped_stage, pass, Qs);
+            else                                    regen_plan_kernel<256><<<grid, 256, lds, s>>>(*c, *st, count, list, ws, ped_stage, pass, Qs);
         };
         regen_robot_sample_kernel<<<M, 256, 0, s>>>(*c, *st, count, list, ws);
         plan_pass(0, 0);
