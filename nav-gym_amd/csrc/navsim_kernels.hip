@@ -51,7 +51,7 @@ NAVSIM_STEP_FAMILY(512, 0) NAVSIM_STEP_FAMILY(512, 1) NAVSIM_STEP_FAMILY(1024, 0
 #undef NAVSIM_STEP_FAMILY
 
 #ifndef NAVSIM_PLAN_MANY_SEARCHES
-#define NAVSIM_PLAN_MANY_SEARCHES 2048          // searches per planner launch of navsim_regen from which 512 threads per search are used
+#define NAVSIM_PLAN_MANY_SEARCHES 4096          // searches per planner launch of navsim_regen ABOVE which 512 threads per search are used (staging passes; the per-step calls stay below)
 #endif
 
 namespace {
