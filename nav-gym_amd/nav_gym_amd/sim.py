@@ -716,7 +716,10 @@ class NavSim(object):
             raise ValueError("enable_pregen(install=True) needs pipeline >= 1 and cfg.regen_cap >= n_envs (every finished arena "
                              "decides alone inside the step: there is no cap in index order)")
         self.ready = torch.zeros(2 * E, dtype=torch.int64, device=self.device) if P else None
-        self.stage_t = {k: self.t[k].clone() for k in self.STAGED if k in self.t}
+        # (the per-map arrays of a slot-table world are allocated ONCE at twice the size below instead of cloned and then concatenated:
+        #  fresh device memory is what the first reset() of a large world waits for -- 50 GB at 4096 arenas of 1000 x 1000 cells)
+        shared_maps = bool(install and map_slots)
+        self.stage_t = {k: self.t[k].clone() for k in self.STAGED if k in self.t and not (shared_maps and k in self.MAPS)}
         self.stage_t["episode"] = self.t["episode"] + 1
         self.stage_st = abi.NavsimState()
         C.memmove(C.byref(self.stage_st), C.byref(self.st), C.sizeof(self.st))
@@ -725,7 +728,11 @@ class NavSim(object):
         if install and map_slots:
             for k in self.MAPS:
                 if k in self.t:
-                    both = torch.cat([self.t[k], self.stage_t[k]])
+                    live = self.t[k]
+                    n = live.shape[0]
+                    both = torch.empty((2 * n,) + tuple(live.shape[1:]), dtype=live.dtype, device=live.device)
+                    both[:n].copy_(live); both[n:].copy_(live)          # (the staged half: any valid world; _stage_all() redraws it)
+                    del live
                     self.t[k] = self.stage_t[k] = both
                     setattr(self.st, k, both.data_ptr()); setattr(self.stage_st, k, both.data_ptr())
             self.t["map_slot"] = torch.arange(E, dtype=torch.int32, device=self.device)
